@@ -1,0 +1,82 @@
+"""ctypes binding of libevc_hip.so (the C ABI declared in include/evc.h).
+
+The library is built in-tree by ``csrc/build.sh`` (see ``__graft_entry__.build``).
+Loading fails loudly: there is no CPU or PyTorch fallback for any kernel.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libevc_hip.so")
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> argtypes (every function returns int except the two noted below)
+SIGNATURES = {
+    "evc_check_device": [i32],
+    "evc_l2norm_chunk_fwd": [vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp, i32, vp],
+    "evc_frame_counts": [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp],
+    "evc_gemm_nt": [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i32, i32, vp],
+    "evc_lstm_layer_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp],
+    "evc_lstm_layer_bwd": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp],
+    "evc_transpose_to_bf16": [vp, i32, i64, i32, i32, vp, i64, i32, vp],
+    "evc_cast_f32_to_bf16": [vp, i64, i32, i32, vp, i64, vp],
+    "evc_rowsum_bf16": [vp, i64, i32, i32, vp, vp],
+    "evc_moe_tail_fwd": [vp, vp, i32, i32, i32, vp, vp, vp],
+    "evc_moe_tail_bwd": [vp, vp, vp, i32, i32, i32, vp, i64, vp, i64, vp],
+    "evc_ce_loss": [vp, vp, i32, i32, f32, vp, vp, i32, vp],
+    "evc_kl_pred_loss": [vp, vp, vp, vp, i32, i32, f32, vp, vp, i32, vp],
+    "evc_rep_loss": [vp, vp, i32, i32, f32, vp, vp, i32, vp],
+    "evc_grad_sqnorm": [vp, vp, f32, i64, vp, vp],
+    "evc_clip_adam_step": [vp, vp, vp, vp, i64, f32, vp, f32, f32, f32, f32, f32, vp, vp],
+    "evc_meanpool_fwd": [vp, vp, i32, i32, i32, vp, vp, vp],
+    "evc_sigmoid_fwd": [vp, i64, vp],
+    "evc_sigmoid_bwd": [vp, vp, i64, vp, vp],
+    "evc_sample_frames_gather": [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp],
+    "evc_bn_stats": [vp, i32, i32, vp, vp, vp, vp],
+    "evc_bn_apply": [vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp],
+    "evc_bn_relu6_bwd": [vp, vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp],
+    "evc_framepool_max_fwd": [vp, i32, i32, i32, vp, vp, vp, vp],
+    "evc_framepool_max_bwd": [vp, vp, i32, i32, i32, vp, vp],
+    "evc_fill_f32": [vp, i64, f32, vp],
+}
+EXPORTS = tuple(SIGNATURES) + ("evc_version", "evc_last_error")
+
+_lib = None
+
+
+class EvcError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libevc_hip.so; raise (never fall back) if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EvcError(
+            "libevc_hip.so not found at %s - build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or csrc/build.sh. "
+            "There is no CPU fallback for the HIP kernels." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.evc_version.argtypes = []
+    lib.evc_version.restype = C.c_int
+    lib.evc_last_error.argtypes = []
+    lib.evc_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke an entry point; raise EvcError with evc_last_error() on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise EvcError("%s failed (%d): %s" % (name, rc, lib.evc_last_error().decode()))

@@ -1,0 +1,62 @@
+// Shared host/device helpers for the evc HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/evc.h"
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// thread-local last-error text (evc_last_error)
+void evc_set_error(const char* fmt, ...);
+
+#define EVC_CHECK_HIP(expr)                                                        \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess) {                                                        \
+      evc_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return EVC_ERR_HIP;                                                          \
+    }                                                                              \
+  } while (0)
+
+#define EVC_REQUIRE(cond, code, ...)   \
+  do {                                 \
+    if (!(cond)) {                     \
+      evc_set_error(__VA_ARGS__);      \
+      return (code);                   \
+    }                                  \
+  } while (0)
+
+#define EVC_LAUNCH_CHECK() EVC_CHECK_HIP(hipGetLastError())
+
+// ---- device helpers -------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even; NaN stays NaN (plain cast semantics, see guide "Correctness boundaries")
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// tanh via exp: exact to ~1e-7 relative on the range the LSTM uses
+__device__ __forceinline__ float tanhf_(float x) {
+  float ax = fabsf(x);
+  float e = __expf(-2.0f * ax);
+  float t = (1.0f - e) / (1.0f + e);
+  return copysignf(t, x);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

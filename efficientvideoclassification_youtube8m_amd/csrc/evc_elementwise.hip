@@ -1,0 +1,722 @@
+// HBM-bound kernels of the hot path: input preparation, layout changes, MoE
+// tail, losses, regulariser + clip + Adam, pooling, batch-norm pieces.
+// All are streaming kernels: 16-byte vector accesses where rows allow,
+// grid-stride with >= 2048 workgroups on big tensors (256 CUs x 8).
+#include <stdarg.h>
+#include "evc_common.h"
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void evc_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* evc_last_error(void) { return g_err; }
+extern "C" int evc_version(void) { return EVC_VERSION; }
+extern "C" int evc_check_device(int dev) {
+  hipDeviceProp_t prop;
+  EVC_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+  EVC_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, EVC_ERR_UNSUPPORTED_ARCH,
+              "device %d is %s; libevc_hip is built for gfx950 only", dev, prop.gcnArchName);
+  return EVC_OK;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += sh[i];
+  return t;
+}
+
+// ---------------------------------------------------------------------------
+// a1 + a2: l2-normalise, sub-sample, cast, re-layout.  One wave per frame.
+// ---------------------------------------------------------------------------
+template <bool U8>
+__global__ __launch_bounds__(256) void l2norm_chunk_kernel(const float* __restrict__ x, const uint8_t* __restrict__ xq,
+                                                           const int* __restrict__ nfr, int B, int T, int F, int C1,
+                                                           bf16_t* __restrict__ out1, int every_n, int C2,
+                                                           bf16_t* __restrict__ out2, int normalize) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // b*T + s
+  if (row >= (long)B * T) return;
+  const int b = (int)(row / T), s = (int)(row % T);
+  const int nv = F >> 2;
+  float4 v[5];  // F <= 1280
+  float ss = 0.f;
+  const bool pad = U8 && s >= nfr[b];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int j = lane + i * 64;
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < nv) {
+      if (U8) {
+        if (!pad) {
+          const uchar4 q = ((const uchar4*)(xq + row * F))[j];
+          const float sc = 4.0f / 255.0f, bs = 4.0f / 512.0f - 2.0f;   // cs/utils.py:22-25
+          v[i] = make_float4(q.x * sc + bs, q.y * sc + bs, q.z * sc + bs, q.w * sc + bs);
+        }
+      } else {
+        v[i] = ((const float4*)(x + row * F))[j];
+      }
+      ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+    }
+  }
+  ss = wave_sum(ss);
+  const float inv = normalize ? rsqrtf(fmaxf(ss, 1e-12f)) : 1.0f;   // tf.nn.l2_normalize epsilon
+  const int L1 = T / C1;
+  bf16_t* o1 = out1 + (((long)(s % L1) * C1 + s / L1) * B + b) * F;
+  bf16_t* o2 = nullptr;
+  if (out2 && (s % every_n) == 0) {
+    const int s2 = s / every_n, S2 = T / every_n;
+    if (s2 < S2) {
+      const int L2 = S2 / C2;
+      o2 = out2 + (((long)(s2 % L2) * C2 + s2 / L2) * B + b) * F;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int j = lane + i * 64;
+    if (j < nv) {
+      ushort4 o;
+      o.x = f32_to_bf16(v[i].x * inv); o.y = f32_to_bf16(v[i].y * inv);
+      o.z = f32_to_bf16(v[i].z * inv); o.w = f32_to_bf16(v[i].w * inv);
+      ((ushort4*)o1)[j] = o;
+      if (o2) ((ushort4*)o2)[j] = o;
+    }
+  }
+}
+
+extern "C" int evc_l2norm_chunk_fwd(const float* x_raw, const uint8_t* x_u8, const int32_t* num_frames,
+                                    int B, int T, int F, int C1, evc_bf16* out1,
+                                    int every_n, int C2, evc_bf16* out2, int normalize, void* stream) {
+  EVC_REQUIRE(B > 0 && T > 0 && F > 0 && F % 4 == 0 && F <= 1280, EVC_ERR_BAD_SHAPE,
+              "evc_l2norm_chunk_fwd: F=%d must be a multiple of 4 and <= 1280", F);
+  EVC_REQUIRE(C1 > 0 && T % C1 == 0, EVC_ERR_BAD_SHAPE, "evc_l2norm_chunk_fwd: T=%d not divisible by C1=%d", T, C1);
+  if (out2) {
+    EVC_REQUIRE(every_n > 0 && C2 > 0 && (T / every_n) % C2 == 0 && (T / every_n) > 0, EVC_ERR_BAD_SHAPE,
+                "evc_l2norm_chunk_fwd: student view T/every_n=%d not divisible by C2=%d", T / (every_n > 0 ? every_n : 1), C2);
+  }
+  EVC_REQUIRE(!x_u8 || num_frames, EVC_ERR_BAD_ARG, "evc_l2norm_chunk_fwd: uint8 input needs num_frames");
+  const long rows = (long)B * T;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  if (x_u8)
+    hipLaunchKernelGGL(l2norm_chunk_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x_raw, x_u8, num_frames, B, T, F,
+                       C1, out1, every_n > 0 ? every_n : 1, C2, out2, normalize);
+  else
+    hipLaunchKernelGGL(l2norm_chunk_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x_raw, x_u8, num_frames, B, T, F,
+                       C1, out1, every_n > 0 ? every_n : 1, C2, out2, normalize);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// a2 integer part: frame counts (bit-exact vs the float64/float32 TF formulas)
+// ---------------------------------------------------------------------------
+__global__ void frame_counts_kernel(const int* __restrict__ nfr, int B, int every_n, int maxf, int C, int Lc,
+                                    long long* __restrict__ n_out, int* __restrict__ len1, int* __restrict__ len2) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  long long n = nfr[b];
+  if (every_n > 1) {
+    // tf.cast(tf.multiply(tf.divide(n, 300), S), tf.int64): float64 true division, truncation
+    const int S = maxf / every_n;
+    const double q = (double)nfr[b] / (double)maxf;
+    n = (long long)trunc(q * (double)S);
+  }
+  if (n_out) n_out[b] = n;
+  for (int i = 0; i < C; ++i) {
+    long long v = n - (long long)Lc * i;
+    v = v < 0 ? 0 : v;
+    v = v > Lc ? Lc : v;
+    len1[(long)i * B + b] = (int)v;
+  }
+  // tf.cast(tf.ceil(tf.cast(n, tf.float32) / Lc), tf.int32)
+  len2[b] = (int)ceilf((float)n / (float)Lc);
+}
+
+extern "C" int evc_frame_counts(const int32_t* num_frames, int B, int every_n, int max_frames_before_sampling,
+                                int num_chunks, int chunk_len, int64_t* n_out, int32_t* len_l1, int32_t* len_l2,
+                                void* stream) {
+  EVC_REQUIRE(B > 0 && every_n > 0 && num_chunks > 0 && chunk_len > 0, EVC_ERR_BAD_SHAPE, "evc_frame_counts: bad args");
+  hipLaunchKernelGGL(frame_counts_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, num_frames, B, every_n,
+                     max_frames_before_sampling, num_chunks, chunk_len, (long long*)n_out, len_l1, len_l2);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// transpose (+cast) to bf16: out[c][r] = in[r][c]; columns [R,Rpad) zeroed
+// ---------------------------------------------------------------------------
+template <bool F32>
+__global__ __launch_bounds__(256) void transpose_kernel(const void* __restrict__ in, long ld_in, int R, int C,
+                                                        bf16_t* __restrict__ out, long ld_out, int Rpad) {
+  __shared__ bf16_t tile[64][66];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + ty + 4 * i, c = c0 + tx;
+    bf16_t v = 0;
+    if (r < R && c < C) {
+      if (F32) v = f32_to_bf16(((const float*)in)[(long)r * ld_in + c]);
+      else v = ((const bf16_t*)in)[(long)r * ld_in + c];
+    }
+    tile[ty + 4 * i][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty + 4 * i, r = r0 + tx;
+    if (c < C && r < Rpad) out[(long)c * ld_out + r] = tile[tx][ty + 4 * i];
+  }
+}
+
+extern "C" int evc_transpose_to_bf16(const void* in, int in_f32, int64_t ld_in, int R, int C,
+                                     evc_bf16* out, int64_t ld_out, int Rpad, void* stream) {
+  EVC_REQUIRE(R > 0 && C > 0 && Rpad >= R && ld_out >= Rpad, EVC_ERR_BAD_SHAPE, "evc_transpose_to_bf16: bad shape");
+  dim3 grid((Rpad + 63) / 64, (C + 63) / 64);
+  if (in_f32)
+    hipLaunchKernelGGL(transpose_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, R, C, out, ld_out, Rpad);
+  else
+    hipLaunchKernelGGL(transpose_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, R, C, out, ld_out, Rpad);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+__global__ void cast_kernel(const float* __restrict__ in, long ld_in, int R, int C, bf16_t* __restrict__ out, long ld_out) {
+  const long n = (long)R * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C, c = i % C;
+    out[r * ld_out + c] = f32_to_bf16(in[r * ld_in + c]);
+  }
+}
+extern "C" int evc_cast_f32_to_bf16(const float* in, int64_t ld_in, int R, int C, evc_bf16* out, int64_t ld_out, void* stream) {
+  EVC_REQUIRE(R > 0 && C > 0, EVC_ERR_BAD_SHAPE, "evc_cast_f32_to_bf16: bad shape");
+  const long n = (long)R * C;
+  const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(cast_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, ld_in, R, C, out, ld_out);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+__global__ __launch_bounds__(256) void rowsum_bf16_kernel(const bf16_t* __restrict__ in, long ld, int C, float* __restrict__ out) {
+  __shared__ float sh[4];
+  const bf16_t* row = in + (long)blockIdx.x * ld;
+  float s = 0.f;
+  const int nv = C >> 3;
+  for (int j = threadIdx.x; j < nv; j += 256) {
+    const uint4 q = ((const uint4*)row)[j];
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s += __uint_as_float(w[k] << 16) + __uint_as_float(w[k] & 0xffff0000u);
+  }
+  for (int j = (nv << 3) + threadIdx.x; j < C; j += 256) s += bf16_to_f32(row[j]);
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+extern "C" int evc_rowsum_bf16(const evc_bf16* in, int64_t ld_in, int R, int C, float* out, void* stream) {
+  EVC_REQUIRE(R > 0 && C > 0 && ld_in % 8 == 0, EVC_ERR_BAD_SHAPE, "evc_rowsum_bf16: bad shape");
+  hipLaunchKernelGGL(rowsum_bf16_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, in, ld_in, C, out);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// a5: MoE tail
+// ---------------------------------------------------------------------------
+template <int M>
+__device__ __forceinline__ float moe_elem(const float* ga, const float* ea, float* g, float* e) {
+  float mx = ga[0];
+#pragma unroll
+  for (int m = 1; m <= M; ++m) mx = fmaxf(mx, ga[m]);
+  float den = 0.f;
+#pragma unroll
+  for (int m = 0; m <= M; ++m) { g[m] = __expf(ga[m] - mx); den += g[m]; }
+  const float inv = 1.f / den;
+  float p = 0.f;
+#pragma unroll
+  for (int m = 0; m <= M; ++m) g[m] *= inv;
+#pragma unroll
+  for (int m = 0; m < M; ++m) { e[m] = sigmoidf_(ea[m]); p += g[m] * e[m]; }
+  return p;
+}
+
+template <int M>
+__global__ __launch_bounds__(256) void moe_tail_fwd_kernel(const float* __restrict__ gl, const float* __restrict__ el, int V,
+                                                           float* __restrict__ pred, float* __restrict__ rowsum) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x;
+  const float* gr = gl + (long)b * V * (M + 1);
+  const float* er = el + (long)b * V * M;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < V; c += 256) {
+    float ga[M + 1], ea[M], g[M + 1], e[M];
+#pragma unroll
+    for (int m = 0; m <= M; ++m) ga[m] = gr[c * (M + 1) + m];
+#pragma unroll
+    for (int m = 0; m < M; ++m) ea[m] = er[c * M + m];
+    const float p = moe_elem<M>(ga, ea, g, e);
+    pred[(long)b * V + c] = p;
+    s += p;
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0 && rowsum) rowsum[b] = s;
+}
+
+template <int M>
+__global__ __launch_bounds__(256) void moe_tail_bwd_kernel(const float* __restrict__ gl, const float* __restrict__ el,
+                                                           const float* __restrict__ dpred, int V,
+                                                           bf16_t* __restrict__ dg, long ld_dg, bf16_t* __restrict__ de, long ld_de) {
+  const int b = blockIdx.x;
+  const float* gr = gl + (long)b * V * (M + 1);
+  const float* er = el + (long)b * V * M;
+  for (int c = threadIdx.x; c < V; c += 256) {
+    float ga[M + 1], ea[M], g[M + 1], e[M];
+#pragma unroll
+    for (int m = 0; m <= M; ++m) ga[m] = gr[c * (M + 1) + m];
+#pragma unroll
+    for (int m = 0; m < M; ++m) ea[m] = er[c * M + m];
+    moe_elem<M>(ga, ea, g, e);
+    const float dp = dpred[(long)b * V + c];
+    float sdot = 0.f;
+#pragma unroll
+    for (int m = 0; m < M; ++m) sdot += dp * e[m] * g[m];
+#pragma unroll
+    for (int m = 0; m <= M; ++m) {
+      const float dgm = (m < M) ? dp * e[m < M ? m : 0] : 0.f;
+      dg[(long)b * ld_dg + c * (M + 1) + m] = f32_to_bf16(g[m] * (dgm - sdot));
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) de[(long)b * ld_de + c * M + m] = f32_to_bf16(dp * g[m] * e[m] * (1.f - e[m]));
+  }
+}
+
+#define MOE_DISPATCH(KERNEL, ...)                                                                              \
+  switch (M) {                                                                                                 \
+    case 1: hipLaunchKernelGGL(KERNEL<1>, dim3(B), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;     \
+    case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(B), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;     \
+    case 3: hipLaunchKernelGGL(KERNEL<3>, dim3(B), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;     \
+    case 4: hipLaunchKernelGGL(KERNEL<4>, dim3(B), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;     \
+    default: evc_set_error("moe: num_mixtures=%d unsupported (1..4)", M); return EVC_ERR_BAD_SHAPE;            \
+  }
+
+extern "C" int evc_moe_tail_fwd(const float* gate_logits, const float* expert_logits, int B, int V, int M,
+                                float* pred, float* rowsum, void* stream) {
+  EVC_REQUIRE(B > 0 && V > 0, EVC_ERR_BAD_SHAPE, "evc_moe_tail_fwd: bad shape");
+  MOE_DISPATCH(moe_tail_fwd_kernel, gate_logits, expert_logits, V, pred, rowsum);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+extern "C" int evc_moe_tail_bwd(const float* gate_logits, const float* expert_logits, const float* dpred,
+                                int B, int V, int M, evc_bf16* dgate, int64_t ld_dgate,
+                                evc_bf16* dexpert, int64_t ld_dexpert, void* stream) {
+  EVC_REQUIRE(B > 0 && V > 0, EVC_ERR_BAD_SHAPE, "evc_moe_tail_bwd: bad shape");
+  MOE_DISPATCH(moe_tail_bwd_kernel, gate_logits, expert_logits, dpred, V, dgate, (long)ld_dgate, dexpert, (long)ld_dexpert);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// a6 + a7: losses.  grid-stride, block partials, one atomic per block.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ p, const uint8_t* __restrict__ y, long n,
+                                                      float inv_b, float gs, float* __restrict__ loss,
+                                                      float* __restrict__ dp, int acc) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  const float eps = 10e-6f;   // cs/losses.py:92
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float pv = p[i];
+    const bool pos = y[i] != 0;
+    const float a = pv + eps, bq = 1.f - pv + eps;
+    s -= pos ? __logf(a) : __logf(bq);
+    if (dp) {
+      const float g = (pos ? -1.f / a : 1.f / bq) * gs;
+      dp[i] = acc ? dp[i] + g : g;
+    }
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) atomicAdd(loss, s * inv_b);
+}
+extern "C" int evc_ce_loss(const float* pred, const uint8_t* labels, int B, int V, float grad_scale,
+                           float* loss, float* dpred, int accumulate_grad, void* stream) {
+  EVC_REQUIRE(B > 0 && V > 0, EVC_ERR_BAD_SHAPE, "evc_ce_loss: bad shape");
+  const long n = (long)B * V;
+  const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(ce_loss_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pred, labels, n, 1.0f / B, grad_scale, loss,
+                     dpred, accumulate_grad);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+__global__ __launch_bounds__(256) void kl_loss_kernel(const float* __restrict__ pt, const float* __restrict__ st,
+                                                      const float* __restrict__ ps, const float* __restrict__ ss, int V,
+                                                      float gs, float* __restrict__ loss, float* __restrict__ dps, int acc) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x;
+  const float it = 1.f / st[b], is = 1.f / ss[b];
+  float s = 0.f;
+  for (int c = threadIdx.x; c < V; c += 256) {
+    const long i = (long)b * V + c;
+    const float P = pt[i] * it, q = ps[i];
+    s += P * (__logf(P) - __logf(q * is));
+    if (dps) {
+      const float g = (-P / q + is) * gs;
+      dps[i] = acc ? dps[i] + g : g;
+    }
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) atomicAdd(loss, s);
+}
+extern "C" int evc_kl_pred_loss(const float* pred_t, const float* rowsum_t, const float* pred_s, const float* rowsum_s,
+                                int B, int V, float grad_scale, float* loss, float* dpred_s, int accumulate_grad,
+                                void* stream) {
+  EVC_REQUIRE(B > 0 && V > 0, EVC_ERR_BAD_SHAPE, "evc_kl_pred_loss: bad shape");
+  hipLaunchKernelGGL(kl_loss_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pred_t, rowsum_t, pred_s, rowsum_s, V,
+                     grad_scale, loss, dpred_s, accumulate_grad);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+__global__ __launch_bounds__(256) void rep_loss_kernel(const float* __restrict__ a, const float* __restrict__ b, long n,
+                                                       float inv_b, float gs, float* __restrict__ loss,
+                                                       float* __restrict__ db, int acc) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float d = a[i] - b[i];
+    s += d * d;
+    if (db) {
+      const float g = -2.f * d * inv_b * gs;
+      db[i] = acc ? db[i] + g : g;
+    }
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) atomicAdd(loss, s * inv_b);
+}
+extern "C" int evc_rep_loss(const float* state_t, const float* state_s, int B, int D, float grad_scale,
+                            float* loss, float* dstate_s, int accumulate_grad, void* stream) {
+  EVC_REQUIRE(B > 0 && D > 0, EVC_ERR_BAD_SHAPE, "evc_rep_loss: bad shape");
+  const long n = (long)B * D;
+  const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(rep_loss_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, state_t, state_s, n, 1.0f / B, grad_scale,
+                     loss, dstate_s, accumulate_grad);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// a8 + a9: regulariser, per-tensor clip, TF-Adam
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restrict__ g, const float* __restrict__ p, float l2,
+                                                          long n, float* __restrict__ sums) {
+  __shared__ float sh[4];
+  float sg = 0.f, sp = 0.f;
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 gv = ((const float4*)g)[i], pv = ((const float4*)p)[i];
+    const float a = gv.x + l2 * pv.x, b = gv.y + l2 * pv.y, c = gv.z + l2 * pv.z, d = gv.w + l2 * pv.w;
+    sg += a * a + b * b + c * c + d * d;
+    sp += pv.x * pv.x + pv.y * pv.y + pv.z * pv.z + pv.w * pv.w;
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float a = g[i] + l2 * p[i];
+    sg += a * a;
+    sp += p[i] * p[i];
+  }
+  sg = block_sum(sg, sh);
+  sp = block_sum(sp, sh);
+  if (threadIdx.x == 0) { atomicAdd(&sums[0], sg); atomicAdd(&sums[1], sp); }
+}
+extern "C" int evc_grad_sqnorm(const float* g, const float* p, float l2_coeff, int64_t n, float* sums, void* stream) {
+  EVC_REQUIRE(n > 0, EVC_ERR_BAD_SHAPE, "evc_grad_sqnorm: n must be positive");
+  EVC_REQUIRE(((uintptr_t)g % 16) == 0 && ((uintptr_t)p % 16) == 0, EVC_ERR_BAD_ALIGN, "evc_grad_sqnorm: 16-byte alignment");
+  const long nb = (n / 4 + 255) / 256;
+  const int grid = (int)(nb < 1 ? 1 : (nb < 2048 ? nb : 2048));
+  hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, p, l2_coeff, (long)n, sums);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+__global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, long n, float l2, const float* __restrict__ sums,
+                                                        float clip, float lr_t, float b1, float b2, float eps,
+                                                        bf16_t* __restrict__ pb) {
+  float scale = 1.f;
+  if (clip > 0.f) {
+    const float nrm = sqrtf(sums[0]);
+    scale = clip / fmaxf(nrm, clip);   // tf.clip_by_norm
+  }
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float pv = p[i];
+    const float gc = (g[i] + l2 * pv) * scale;
+    const float mn = b1 * m[i] + (1.f - b1) * gc;
+    const float vn = b2 * v[i] + (1.f - b2) * gc * gc;
+    const float pn = pv - lr_t * mn / (sqrtf(vn) + eps);
+    m[i] = mn; v[i] = vn; p[i] = pn;
+    if (pb) pb[i] = f32_to_bf16(pn);
+  }
+}
+extern "C" int evc_clip_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float l2_coeff,
+                                  const float* sums, float clip_norm, float lr_t, float beta1, float beta2, float eps,
+                                  evc_bf16* p_bf16, void* stream) {
+  EVC_REQUIRE(n > 0, EVC_ERR_BAD_SHAPE, "evc_clip_adam_step: n must be positive");
+  const long nb = (n + 255) / 256;
+  const int grid = (int)(nb < 4096 ? nb : 4096);
+  hipLaunchKernelGGL(clip_adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, l2_coeff, sums,
+                     clip_norm, lr_t, beta1, beta2, eps, p_bf16);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// a11: mean-pool over all padded frames / true n; sigmoid
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void meanpool_kernel(const float* __restrict__ x, const int* __restrict__ nfr, int T, int F,
+                                                       float* __restrict__ avg, bf16_t* __restrict__ avgb) {
+  const int b = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= F) return;
+  const float* xp = x + (long)b * T * F + f;
+  float s = 0.f;
+  for (int t = 0; t < T; ++t) s += xp[(long)t * F];
+  s /= (float)nfr[b];
+  if (avg) avg[(long)b * F + f] = s;
+  if (avgb) avgb[(long)b * F + f] = f32_to_bf16(s);
+}
+extern "C" int evc_meanpool_fwd(const float* x, const int32_t* num_frames, int B, int T, int F,
+                                float* avg_f32, evc_bf16* avg_bf16, void* stream) {
+  EVC_REQUIRE(B > 0 && T > 0 && F > 0, EVC_ERR_BAD_SHAPE, "evc_meanpool_fwd: bad shape");
+  hipLaunchKernelGGL(meanpool_kernel, dim3((F + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, num_frames, T, F, avg_f32,
+                     avg_bf16);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+__global__ void sigmoid_fwd_kernel(float* z, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) z[i] = sigmoidf_(z[i]);
+}
+__global__ void sigmoid_bwd_kernel(const float* p, const float* dp, long n, bf16_t* dz) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dz[i] = f32_to_bf16(dp[i] * p[i] * (1.f - p[i]));
+}
+static inline int grid_for(long n) { long nb = (n + 255) / 256; return (int)(nb < 1 ? 1 : (nb < 4096 ? nb : 4096)); }
+extern "C" int evc_sigmoid_fwd(float* z, int64_t n, void* stream) {
+  EVC_REQUIRE(n > 0, EVC_ERR_BAD_SHAPE, "evc_sigmoid_fwd: n");
+  hipLaunchKernelGGL(sigmoid_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, z, (long)n);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+extern "C" int evc_sigmoid_bwd(const float* p, const float* dp, int64_t n, evc_bf16* dz, void* stream) {
+  EVC_REQUIRE(n > 0, EVC_ERR_BAD_SHAPE, "evc_sigmoid_bwd: n");
+  hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, dp, (long)n, dz);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// a10: DBoF pieces
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sample_gather_kernel(const float* __restrict__ x, const float* __restrict__ u,
+                                                            const int* __restrict__ nfr, int B, int T, int F, int S,
+                                                            float* __restrict__ out, int* __restrict__ idx_out) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long)B * S) return;
+  const int b = (int)(row / S);
+  // tf.cast(tf.multiply(random_uniform, tf.cast(num_frames, tf.float32)), tf.int32)
+  int idx = (int)(u[row] * (float)nfr[b]);
+  if (lane == 0 && idx_out) idx_out[row] = idx;
+  idx = idx < 0 ? 0 : (idx >= T ? T - 1 : idx);
+  const float4* src = (const float4*)(x + ((long)b * T + idx) * F);
+  float4* dst = (float4*)(out + row * F);
+  for (int j = lane; j < (F >> 2); j += 64) dst[j] = src[j];
+}
+extern "C" int evc_sample_frames_gather(const float* x, const float* u, const int32_t* num_frames, int B, int T, int F,
+                                        int S, float* out, int32_t* idx_out, void* stream) {
+  EVC_REQUIRE(B > 0 && T > 0 && F > 0 && S > 0 && F % 4 == 0, EVC_ERR_BAD_SHAPE, "evc_sample_frames_gather: bad shape");
+  const long rows = (long)B * S;
+  hipLaunchKernelGGL(sample_gather_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, u, num_frames,
+                     B, T, F, S, out, idx_out);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// column statistics: grid (C/64, RS); block 64 columns x 4 row phases; f64 partials via atomics into ws[2C]
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, int R, int C, double* __restrict__ ws) {
+  __shared__ double sh[2][4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  double s = 0.0, q = 0.0;
+  if (c < C)
+    for (int r = blockIdx.y * 4 + ty; r < R; r += gridDim.y * 4) {
+      const double v = x[(long)r * C + c];
+      s += v; q += v * v;
+    }
+  sh[0][ty][tx] = s; sh[1][ty][tx] = q;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    s = sh[0][0][tx] + sh[0][1][tx] + sh[0][2][tx] + sh[0][3][tx];
+    q = sh[1][0][tx] + sh[1][1][tx] + sh[1][2][tx] + sh[1][3][tx];
+    atomicAdd(&ws[c], s);
+    atomicAdd(&ws[C + c], q);
+  }
+}
+__global__ void bn_stats_final_kernel(const double* __restrict__ ws, int R, int C, float* __restrict__ mean, float* __restrict__ var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mu = ws[c] / R;
+  double vv = ws[C + c] / R - mu * mu;
+  mean[c] = (float)mu;
+  var[c] = (float)(vv > 0 ? vv : 0);
+}
+extern "C" int evc_bn_stats(const float* x, int R, int C, double* ws, float* mean, float* var, void* stream) {
+  EVC_REQUIRE(R > 0 && C > 0 && ws, EVC_ERR_BAD_SHAPE, "evc_bn_stats: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  EVC_CHECK_HIP(hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st));
+  int rs = R / 256; rs = rs < 1 ? 1 : (rs > 64 ? 64 : rs);
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3((C + 63) / 64, rs), dim3(256), 0, st, x, R, C, ws);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, ws, R, C, mean, var);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+__global__ void bn_apply_kernel(const float* __restrict__ x, long n, int C, const float* __restrict__ mean,
+                                const float* __restrict__ var, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                int relu6, float* __restrict__ yf, bf16_t* __restrict__ yb) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    float y = (x[i] - mean[c]) * rsqrtf(var[c] + 1e-3f) * gamma[c] + beta[c];
+    if (relu6) y = fminf(fmaxf(y, 0.f), 6.f);
+    if (yf) yf[i] = y;
+    if (yb) yb[i] = f32_to_bf16(y);
+  }
+}
+extern "C" int evc_bn_apply(const float* x, int R, int C, const float* mean, const float* var, const float* gamma,
+                            const float* beta, int relu6, float* y_f32, evc_bf16* y_bf16, void* stream) {
+  EVC_REQUIRE(R > 0 && C > 0, EVC_ERR_BAD_SHAPE, "evc_bn_apply: bad shape");
+  const long n = (long)R * C;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, C, mean, var, gamma, beta,
+                     relu6, y_f32, y_bf16);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// backward of y = relu6?(gamma*xh+beta): pass 1 column sums of dyh=dy*mask and dyh*xh; pass 2 dx
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy, int R, int C,
+                                                             const float* __restrict__ mean, const float* __restrict__ var,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             int relu6, double* __restrict__ ws) {
+  __shared__ double sh[2][4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  double s = 0.0, q = 0.0;
+  if (c < C) {
+    const float mu = mean[c], inv = rsqrtf(var[c] + 1e-3f), ga = gamma[c], be = beta[c];
+    for (int r = blockIdx.y * 4 + ty; r < R; r += gridDim.y * 4) {
+      const long i = (long)r * C + c;
+      const float xh = (x[i] - mu) * inv;
+      float d = dy[i];
+      if (relu6) { const float y = xh * ga + be; if (!(y > 0.f && y < 6.f)) d = 0.f; }
+      s += d; q += (double)d * xh;
+    }
+  }
+  sh[0][ty][tx] = s; sh[1][ty][tx] = q;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    atomicAdd(&ws[c], sh[0][0][tx] + sh[0][1][tx] + sh[0][2][tx] + sh[0][3][tx]);
+    atomicAdd(&ws[C + c], sh[1][0][tx] + sh[1][1][tx] + sh[1][2][tx] + sh[1][3][tx]);
+  }
+}
+__global__ void bn_bwd_final_kernel(const float* __restrict__ x, const float* __restrict__ dy, long n, int R, int C,
+                                    const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, int relu6, const double* __restrict__ ws,
+                                    float* __restrict__ dxf, bf16_t* __restrict__ dxb, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const float inv = rsqrtf(var[c] + 1e-3f), ga = gamma[c];
+    const float xh = (x[i] - mean[c]) * inv;
+    float d = dy[i];
+    if (relu6) { const float y = xh * ga + beta[c]; if (!(y > 0.f && y < 6.f)) d = 0.f; }
+    const float sd = (float)ws[c], sdx = (float)ws[C + c];
+    // dx = gamma*inv/R * (R*d - sum(d) - xh*sum(d*xh))
+    const float dx = ga * inv * (d - sd / R - xh * sdx / R);
+    if (dxf) dxf[i] = dx;
+    if (dxb) dxb[i] = f32_to_bf16(dx);
+    if (i < C) { if (dgamma) dgamma[i] = (float)ws[C + i]; if (dbeta) dbeta[i] = (float)ws[i]; }
+  }
+}
+extern "C" int evc_bn_relu6_bwd(const float* x, const float* dy, int R, int C, const float* mean, const float* var,
+                                const float* gamma, const float* beta, int relu6, double* ws,
+                                float* dx_f32, evc_bf16* dx_bf16, float* dgamma, float* dbeta, void* stream) {
+  EVC_REQUIRE(R > 0 && C > 0 && ws, EVC_ERR_BAD_SHAPE, "evc_bn_relu6_bwd: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  EVC_CHECK_HIP(hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st));
+  int rs = R / 256; rs = rs < 1 ? 1 : (rs > 64 ? 64 : rs);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3((C + 63) / 64, rs), dim3(256), 0, st, x, dy, R, C, mean, var, gamma, beta, relu6, ws);
+  const long n = (long)R * C;
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, dy, n, R, C, mean, var, gamma, beta, relu6, ws,
+                     dx_f32, dx_bf16, dgamma, dbeta);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+__global__ __launch_bounds__(256) void framepool_max_fwd_kernel(const float* __restrict__ y, int S, int C, float* __restrict__ pf,
+                                                                bf16_t* __restrict__ pb, int* __restrict__ am) {
+  const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float* yp = y + (long)b * S * C + c;
+  float best = yp[0];
+  int bi = 0;
+  for (int s = 1; s < S; ++s) {
+    const float v = yp[(long)s * C];
+    if (v > best) { best = v; bi = s; }   // first maximum wins (numpy argmax / TF max-grad tie -> see DESIGN.md)
+  }
+  const long o = (long)b * C + c;
+  if (pf) pf[o] = best;
+  if (pb) pb[o] = f32_to_bf16(best);
+  if (am) am[o] = bi;
+}
+extern "C" int evc_framepool_max_fwd(const float* y, int B, int S, int C, float* pooled_f32, evc_bf16* pooled_bf16,
+                                     int32_t* argmax, void* stream) {
+  EVC_REQUIRE(B > 0 && S > 0 && C > 0, EVC_ERR_BAD_SHAPE, "evc_framepool_max_fwd: bad shape");
+  hipLaunchKernelGGL(framepool_max_fwd_kernel, dim3((C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, y, S, C, pooled_f32,
+                     pooled_bf16, argmax);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+__global__ void framepool_max_bwd_kernel(const float* __restrict__ dp, const int* __restrict__ am, int S, int C, long n,
+                                         float* __restrict__ dy) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long bs = i / C;
+    const int s = (int)(bs % S);
+    const long b = bs / S;
+    dy[i] = (am[b * C + c] == s) ? dp[b * C + c] : 0.f;
+  }
+}
+extern "C" int evc_framepool_max_bwd(const float* dpooled, const int32_t* argmax, int B, int S, int C, float* dy, void* stream) {
+  EVC_REQUIRE(B > 0 && S > 0 && C > 0, EVC_ERR_BAD_SHAPE, "evc_framepool_max_bwd: bad shape");
+  const long n = (long)B * S * C;
+  hipLaunchKernelGGL(framepool_max_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dpooled, argmax, S, C, n, dy);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+__global__ void fill_kernel(float* p, long n, float v) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+extern "C" int evc_fill_f32(float* p, int64_t n, float value, void* stream) {
+  EVC_REQUIRE(n > 0, EVC_ERR_BAD_SHAPE, "evc_fill_f32: n");
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, (long)n, value);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}

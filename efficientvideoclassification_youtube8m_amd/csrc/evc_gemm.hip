@@ -1,0 +1,297 @@
+// GEMM-shaped kernels of the hot path: generic NT GEMM, fused LSTM step
+// (forward, with the gate tail in the epilogue) and fused BPTT step.
+#include "gemm_core.h"
+
+// ===========================================================================
+// generic GEMM: C[M,N] (+)= A.B^T (+bias)
+// ===========================================================================
+struct StoreParams {
+  void* C; long ldc; int M, N; const float* bias; int out_bf16; int accumulate;
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT) void gemm_nt_kernel(GemmOperands p, StoreParams s, int tiles_m, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
+  const int nwg = tiles_m * tiles_n;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int tm = id % tiles_m, tn = id / tiles_m;
+  const int m0 = tm * Cfg::BM, u0 = tn * Cfg::BU;
+  f32x4 acc[Cfg::MI][Cfg::G][Cfg::NI];
+  gemm_mainloop<Cfg>(p, m0, u0, lds, acc);
+  TileCoords<Cfg> tc;
+#pragma unroll
+  for (int mi = 0; mi < Cfg::MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < Cfg::NI; ++ni) {
+      const int n = u0 + tc.unit0 + ni * 16;
+      if (n >= s.N) continue;
+      const float b = s.bias ? s.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + tc.row0 + mi * 16 + r;
+        if (m >= s.M) continue;
+        float v = acc[mi][0][ni][r] + b;
+        const long o = (long)m * s.ldc + n;
+        if (s.out_bf16) {
+          ((bf16_t*)s.C)[o] = f32_to_bf16(v);
+        } else {
+          float* cp = (float*)s.C + o;
+          if (s.accumulate) v += *cp;
+          *cp = v;
+        }
+      }
+    }
+}
+
+typedef TileCfg<128, 1, 128, 2, 2> CfgPlainBig;   // 128x128, 4 waves, 4x4 MFMA tiles per wave
+typedef TileCfg<64, 1, 64, 2, 2> CfgPlainSmall;   // 64x64 for skinny problems
+
+extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, void* C, int64_t ldc,
+                           int M, int N, int K, const float* bias, int out_bf16, int accumulate, void* stream) {
+  EVC_REQUIRE(M > 0 && N > 0 && K >= 0, EVC_ERR_BAD_SHAPE, "evc_gemm_nt: bad shape M=%d N=%d K=%d", M, N, K);
+  EVC_REQUIRE(K % 64 == 0, EVC_ERR_BAD_SHAPE, "evc_gemm_nt: K=%d must be a multiple of 64", K);
+  EVC_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0,
+              EVC_ERR_BAD_ALIGN, "evc_gemm_nt: operands must be 16-byte aligned (lda=%ld ldb=%ld)", (long)lda, (long)ldb);
+  EVC_REQUIRE(!(out_bf16 && accumulate), EVC_ERR_BAD_ARG, "evc_gemm_nt: accumulate needs f32 output");
+  GemmOperands p;
+  p.A1 = A; p.lda1 = lda; p.nk1 = K / 64; p.A2 = A; p.lda2 = lda; p.nk2 = 0;
+  p.B = B; p.ldb = ldb; p.group_stride = 0; p.M = M; p.Nu = N;
+  StoreParams s{C, ldc, M, N, bias, out_bf16, accumulate};
+  hipStream_t st = (hipStream_t)stream;
+  const long big_tiles = (long)ceil_div(M, 128) * ceil_div(N, 128);
+  if (big_tiles >= 192) {
+    const int tm = ceil_div(M, 128), tn = ceil_div(N, 128);
+    hipLaunchKernelGGL(gemm_nt_kernel<CfgPlainBig>, dim3(tm * tn), dim3(CfgPlainBig::NT), 0, st, p, s, tm, tn);
+  } else {
+    const int tm = ceil_div(M, 64), tn = ceil_div(N, 64);
+    hipLaunchKernelGGL(gemm_nt_kernel<CfgPlainSmall>, dim3(tm * tn), dim3(CfgPlainSmall::NT), 0, st, p, s, tm, tn);
+  }
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// ===========================================================================
+// LSTM forward step: z = [x_t, h_{t-1}] . W^T (+ zx) + bias ; gate tail fused
+// ===========================================================================
+struct LstmFwdParams {
+  const float* zx; long ldzx;        // hoisted x-projection rows for this step (or NULL)
+  const float* bias;                 // [4H]
+  const int* len; int t;
+  float* c_state; float* h_state; long ld_state;
+  bf16_t* hout;                      // [M][H] slab t+1
+  bf16_t* gates;                     // [M][4H] slab t or NULL
+  float* c_cache;                    // [M][H] slab t or NULL
+  int M, H;
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, LstmFwdParams e, int tiles_m, int tiles_n) {
+  static_assert(Cfg::G == 4, "LSTM step needs the four gate groups");
+  __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
+  const int nwg = tiles_m * tiles_n;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int tm = id % tiles_m, tn = id / tiles_m;
+  const int m0 = tm * Cfg::BM, u0 = tn * Cfg::BU;
+  f32x4 acc[Cfg::MI][4][Cfg::NI];
+  gemm_mainloop<Cfg>(p, m0, u0, lds, acc);
+  TileCoords<Cfg> tc;
+  const int H = e.H;
+#pragma unroll
+  for (int ni = 0; ni < Cfg::NI; ++ni) {
+    const int u = u0 + tc.unit0 + ni * 16;
+    if (u >= H) continue;
+    const float bi = e.bias[u], bj = e.bias[H + u], bf = e.bias[2 * H + u] + 1.0f /* forget_bias */, bo = e.bias[3 * H + u];
+#pragma unroll
+    for (int mi = 0; mi < Cfg::MI; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + tc.row0 + mi * 16 + r;
+        if (m >= e.M) continue;
+        const bool active = e.t < e.len[m];
+        const long hu = (long)m * H + u;
+        if (!active) {            // dynamic_rnn: state copied through, zero output
+          e.hout[hu] = 0;
+          continue;
+        }
+        float zi = acc[mi][0][ni][r] + bi, zj = acc[mi][1][ni][r] + bj;
+        float zf = acc[mi][2][ni][r] + bf, zo = acc[mi][3][ni][r] + bo;
+        if (e.zx) {
+          const float* zr = e.zx + (long)m * e.ldzx + u;
+          zi += zr[0]; zj += zr[H]; zf += zr[2 * H]; zo += zr[3 * H];
+        }
+        const float gi = sigmoidf_(zi), gj = tanhf_(zj), gf = sigmoidf_(zf), go = sigmoidf_(zo);
+        const long su = (long)m * e.ld_state + u;
+        const float c_old = e.c_state[su];
+        const float c_new = c_old * gf + gi * gj;
+        const float h_new = tanhf_(c_new) * go;
+        e.c_state[su] = c_new;
+        e.h_state[su] = h_new;
+        e.hout[hu] = f32_to_bf16(h_new);
+        if (e.gates) {
+          bf16_t* gp = e.gates + (long)m * 4 * H + u;
+          gp[0] = f32_to_bf16(gi); gp[H] = f32_to_bf16(gj); gp[2 * H] = f32_to_bf16(gf); gp[3 * H] = f32_to_bf16(go);
+          e.c_cache[hu] = c_new;
+        }
+      }
+    }
+  }
+}
+
+typedef TileCfg<128, 4, 32, 2, 2> CfgLstmBig;    // 128 rows x 32 units x 4 gates
+typedef TileCfg<64, 4, 16, 4, 1> CfgLstmSmall;   // 64 rows x 16 units x 4 gates (M ~ 256 steps)
+
+extern "C" int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const float* bias, const int32_t* len,
+                                  int T, int M, int Kin, int H, int hoist, float* zx_ws,
+                                  evc_bf16* hbuf, float* c_state, float* h_state, int64_t ld_state,
+                                  evc_bf16* gates, float* c_cache, void* stream) {
+  EVC_REQUIRE(T > 0 && M > 0 && H > 0 && Kin > 0, EVC_ERR_BAD_SHAPE, "evc_lstm_layer_fwd: bad shape");
+  EVC_REQUIRE(Kin % 64 == 0 && H % 64 == 0, EVC_ERR_BAD_SHAPE,
+              "evc_lstm_layer_fwd: Kin=%d and H=%d must be multiples of 64", Kin, H);
+  EVC_REQUIRE(!hoist || zx_ws, EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd: hoist needs zx_ws");
+  EVC_REQUIRE((gates == nullptr) == (c_cache == nullptr), EVC_ERR_BAD_ARG, "gates and c_cache go together");
+  hipStream_t st = (hipStream_t)stream;
+  const long ldw = Kin + H;
+  // zero state (rows with len==0 keep an all-zero state) and h_{-1}
+  EVC_CHECK_HIP(hipMemset2DAsync(c_state, ld_state * sizeof(float), 0, (size_t)H * sizeof(float), M, st));
+  EVC_CHECK_HIP(hipMemset2DAsync(h_state, ld_state * sizeof(float), 0, (size_t)H * sizeof(float), M, st));
+  EVC_CHECK_HIP(hipMemsetAsync(hbuf, 0, (size_t)M * H * sizeof(bf16_t), st));
+  if (hoist) {
+    int rc = evc_gemm_nt(x, Kin, wT, ldw, zx_ws, 4L * H, T * M, 4 * H, Kin, nullptr, 0, 0, stream);
+    if (rc) return rc;
+  }
+  const bool big = (long)ceil_div(M, 128) * ceil_div(H, 32) >= 192;
+  for (int t = 0; t < T; ++t) {
+    GemmOperands p;
+    p.M = M; p.Nu = H; p.group_stride = H; p.ldb = ldw;
+    const bf16_t* hprev = hbuf + (long)t * M * H;
+    if (hoist) {
+      p.A1 = hprev; p.lda1 = H; p.nk1 = (t == 0) ? 0 : H / 64; p.A2 = hprev; p.lda2 = H; p.nk2 = 0;
+      p.B = wT + Kin;
+    } else {
+      p.A1 = x + (long)t * M * Kin; p.lda1 = Kin; p.nk1 = Kin / 64;
+      p.A2 = hprev; p.lda2 = H; p.nk2 = (t == 0) ? 0 : H / 64;
+      p.B = wT;
+    }
+    LstmFwdParams e;
+    e.zx = hoist ? zx_ws + (long)t * M * 4 * H : nullptr; e.ldzx = 4L * H;
+    e.bias = bias; e.len = len; e.t = t;
+    e.c_state = c_state; e.h_state = h_state; e.ld_state = ld_state;
+    e.hout = hbuf + (long)(t + 1) * M * H;
+    e.gates = gates ? gates + (long)t * M * 4 * H : nullptr;
+    e.c_cache = c_cache ? c_cache + (long)t * M * H : nullptr;
+    e.M = M; e.H = H;
+    if (big) {
+      const int tm = ceil_div(M, CfgLstmBig::BM), tn = ceil_div(H, CfgLstmBig::BU);
+      hipLaunchKernelGGL(lstm_fwd_step_kernel<CfgLstmBig>, dim3(tm * tn), dim3(CfgLstmBig::NT), 0, st, p, e, tm, tn);
+    } else {
+      const int tm = ceil_div(M, CfgLstmSmall::BM), tn = ceil_div(H, CfgLstmSmall::BU);
+      hipLaunchKernelGGL(lstm_fwd_step_kernel<CfgLstmSmall>, dim3(tm * tn), dim3(CfgLstmSmall::NT), 0, st, p, e, tm, tn);
+    }
+  }
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// ===========================================================================
+// LSTM backward step t: dh = dz_{t+1} . Wh^T (+ final-state / upper-layer grads),
+// then the gate derivative -> dz_t, dc carried in dc_ws.
+// ===========================================================================
+struct LstmBwdParams {
+  const int* len; int t;
+  const bf16_t* gates;      // slab t   [M][4H]
+  const float* c_t;         // slab t   [M][H]
+  const float* c_prev;      // slab t-1 [M][H] or NULL (t == 0)
+  const float* dS_c; const float* dS_h; long ld_dS;
+  const float* dh_above;    // slab t [M][H] or NULL
+  float* dc_ws;             // [M][H]
+  bf16_t* dz;               // slab t [M][4H]
+  int M, H;
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT) void lstm_bwd_step_kernel(GemmOperands p, LstmBwdParams e, int tiles_m, int tiles_n) {
+  static_assert(Cfg::G == 1, "bwd step is a plain GEMM over the H units");
+  __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
+  const int nwg = tiles_m * tiles_n;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int tm = id % tiles_m, tn = id / tiles_m;
+  const int m0 = tm * Cfg::BM, u0 = tn * Cfg::BU;
+  f32x4 acc[Cfg::MI][1][Cfg::NI];
+  gemm_mainloop<Cfg>(p, m0, u0, lds, acc);
+  TileCoords<Cfg> tc;
+  const int H = e.H;
+#pragma unroll
+  for (int ni = 0; ni < Cfg::NI; ++ni) {
+    const int u = u0 + tc.unit0 + ni * 16;
+    if (u >= H) continue;
+#pragma unroll
+    for (int mi = 0; mi < Cfg::MI; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + tc.row0 + mi * 16 + r;
+        if (m >= e.M) continue;
+        const int ln = e.len[m];
+        bf16_t* dzp = e.dz + (long)m * 4 * H + u;
+        if (e.t >= ln) {  // inactive: state passes through, no gate gradient
+          dzp[0] = 0; dzp[H] = 0; dzp[2 * H] = 0; dzp[3 * H] = 0;
+          continue;
+        }
+        const bool last = (e.t == ln - 1);
+        const long hu = (long)m * H + u;
+        float dh = acc[mi][0][ni][r];
+        float dc_in;
+        if (last) {
+          const long su = (long)m * e.ld_dS + u;
+          dh = e.dS_h[su];        // nothing flows back from later (inactive) steps
+          dc_in = e.dS_c[su];
+        } else {
+          dc_in = e.dc_ws[hu];
+        }
+        if (e.dh_above) dh += e.dh_above[hu];
+        const bf16_t* gp = e.gates + (long)m * 4 * H + u;
+        const float gi = bf16_to_f32(gp[0]), gj = bf16_to_f32(gp[H]), gf = bf16_to_f32(gp[2 * H]), go = bf16_to_f32(gp[3 * H]);
+        const float tcv = tanhf_(e.c_t[hu]);
+        const float cp = e.c_prev ? e.c_prev[hu] : 0.f;
+        const float dc = dc_in + dh * go * (1.f - tcv * tcv);
+        e.dc_ws[hu] = dc * gf;
+        dzp[0] = f32_to_bf16(dc * gj * gi * (1.f - gi));
+        dzp[H] = f32_to_bf16(dc * gi * (1.f - gj * gj));
+        dzp[2 * H] = f32_to_bf16(dc * cp * gf * (1.f - gf));
+        dzp[3 * H] = f32_to_bf16(dh * tcv * go * (1.f - go));
+      }
+    }
+  }
+}
+
+extern "C" int evc_lstm_layer_bwd(const evc_bf16* w, const int32_t* len, int T, int M, int Kin, int H,
+                                  const evc_bf16* gates, const float* c_cache,
+                                  const float* dS_c, const float* dS_h, int64_t ld_dS,
+                                  const float* dh_above, float* dc_ws, evc_bf16* dz, void* stream) {
+  EVC_REQUIRE(T > 0 && M > 0 && H > 0 && Kin > 0 && H % 64 == 0, EVC_ERR_BAD_SHAPE, "evc_lstm_layer_bwd: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  const bool big = (long)ceil_div(M, 128) * ceil_div(H, 128) >= 96;
+  for (int t = T - 1; t >= 0; --t) {
+    GemmOperands p;
+    p.M = M; p.Nu = H; p.group_stride = 0;
+    p.A1 = dz + (long)(t + 1 < T ? t + 1 : t) * M * 4 * H; p.lda1 = 4L * H; p.nk1 = (t == T - 1) ? 0 : 4 * H / 64;
+    p.A2 = p.A1; p.lda2 = p.lda1; p.nk2 = 0;
+    p.B = w + (long)Kin * 4 * H; p.ldb = 4L * H;   // rows Kin..Kin+H of the TF kernel = Wh [H][4H]
+    LstmBwdParams e;
+    e.len = len; e.t = t;
+    e.gates = gates + (long)t * M * 4 * H;
+    e.c_t = c_cache + (long)t * M * H;
+    e.c_prev = t > 0 ? c_cache + (long)(t - 1) * M * H : nullptr;
+    e.dS_c = dS_c; e.dS_h = dS_h; e.ld_dS = ld_dS;
+    e.dh_above = dh_above ? dh_above + (long)t * M * H : nullptr;
+    e.dc_ws = dc_ws; e.dz = dz + (long)t * M * 4 * H; e.M = M; e.H = H;
+    if (big) {
+      const int tm = ceil_div(M, CfgPlainBig::BM), tn = ceil_div(H, CfgPlainBig::BU);
+      hipLaunchKernelGGL(lstm_bwd_step_kernel<CfgPlainBig>, dim3(tm * tn), dim3(CfgPlainBig::NT), 0, st, p, e, tm, tn);
+    } else {
+      const int tm = ceil_div(M, CfgPlainSmall::BM), tn = ceil_div(H, CfgPlainSmall::BU);
+      hipLaunchKernelGGL(lstm_bwd_step_kernel<CfgPlainSmall>, dim3(tm * tn), dim3(CfgPlainSmall::NT), 0, st, p, e, tm, tn);
+    }
+  }
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}

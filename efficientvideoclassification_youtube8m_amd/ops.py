@@ -1,0 +1,183 @@
+"""Thin torch-tensor wrappers over the C ABI (one call per kernel family).
+
+Tensors are only containers for device memory here: every wrapper extracts raw
+device pointers and enqueues on torch's current HIP stream.  No wrapper has a
+CPU or eager-PyTorch fallback; CPU tensors are rejected.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.EvcError("evc ops need device tensors (got a CPU tensor); there is no CPU path")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def check_device(dev=0):
+    _lib.call("evc_check_device", dev)
+
+
+# ---------------------------------------------------------------------------
+def gemm_nt(A, B, M, N, K, out, bias=None, accumulate=False, lda=None, ldb=None, ldc=None):
+    """out[M,N] (+)= A[M,K] @ B[N,K]^T (+ bias).  A, B bf16 K-contiguous."""
+    assert A.dtype == BF16 and B.dtype == BF16
+    lda = A.stride(0) if lda is None else lda
+    ldb = B.stride(0) if ldb is None else ldb
+    ldc = out.stride(0) if ldc is None else ldc
+    _lib.call("evc_gemm_nt", _p(A), lda, _p(B), ldb, _p(out), ldc, M, N, K, _p(bias),
+              1 if out.dtype == BF16 else 0, 1 if accumulate else 0, _stream())
+    return out
+
+
+def transpose_to_bf16(x, R, C, out, Rpad, ld_in=None):
+    """out[c][r] = x[r][c]; out is [C, >=Rpad] bf16 with columns [R,Rpad) zeroed."""
+    ld_in = x.stride(0) if ld_in is None else ld_in
+    _lib.call("evc_transpose_to_bf16", _p(x), 1 if x.dtype == F32 else 0, ld_in, R, C, _p(out), out.stride(0), Rpad, _stream())
+    return out
+
+
+def cast_bf16(x, out=None):
+    x2 = x.reshape(-1, x.shape[-1]) if x.dim() > 1 else x.reshape(1, -1)
+    if out is None:
+        out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    o2 = out.reshape(x2.shape)
+    _lib.call("evc_cast_f32_to_bf16", _p(x2), x2.stride(0), x2.shape[0], x2.shape[1], _p(o2), o2.stride(0), _stream())
+    return out
+
+
+def rowsum_bf16(x, R, C, out):
+    _lib.call("evc_rowsum_bf16", _p(x), x.stride(0), R, C, _p(out), _stream())
+    return out
+
+
+# ---------------------------------------------------------------------------
+def l2norm_chunk(x_raw, num_chunks, every_n=None, num_chunks_student=None, num_frames=None, normalize=True):
+    """a1+a2.  x_raw [B,T,F] f32 (or uint8 with num_frames).  Returns the
+    teacher view [Lc][C*B][F] bf16 and (if every_n) the student view."""
+    B, T, F = x_raw.shape
+    dev = x_raw.device
+    out1 = torch.empty((T // num_chunks, num_chunks * B, F), dtype=BF16, device=dev)
+    out2 = None
+    if every_n:
+        S = T // every_n
+        out2 = torch.empty((S // num_chunks_student, num_chunks_student * B, F), dtype=BF16, device=dev)
+    is_u8 = x_raw.dtype == torch.uint8
+    _lib.call("evc_l2norm_chunk_fwd", None if is_u8 else _p(x_raw), _p(x_raw) if is_u8 else None, _p(num_frames),
+              B, T, F, num_chunks, _p(out1), every_n or 1, num_chunks_student or 1, _p(out2), 1 if normalize else 0, _stream())
+    return out1, out2
+
+
+def frame_counts(num_frames, every_n, num_chunks, chunk_len, max_frames=300):
+    """a2 integer part.  Returns (n_used int64 [B], len_l1 int32 [C*B], len_l2 int32 [B])."""
+    B = num_frames.shape[0]
+    dev = num_frames.device
+    n_out = torch.empty(B, dtype=torch.int64, device=dev)
+    l1 = torch.empty(num_chunks * B, dtype=torch.int32, device=dev)
+    l2 = torch.empty(B, dtype=torch.int32, device=dev)
+    _lib.call("evc_frame_counts", _p(num_frames), B, every_n, max_frames, num_chunks, chunk_len, _p(n_out), _p(l1), _p(l2), _stream())
+    return n_out, l1, l2
+
+
+# ---------------------------------------------------------------------------
+def lstm_layer_fwd(x, wT, bias, lens, T, M, Kin, H, hbuf, c_state, h_state, ld_state,
+                   gates=None, c_cache=None, hoist=False, zx_ws=None):
+    _lib.call("evc_lstm_layer_fwd", _p(x), _p(wT), _p(bias), _p(lens), T, M, Kin, H, 1 if hoist else 0, _p(zx_ws),
+              _p(hbuf), _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_cache), _stream())
+
+
+def lstm_layer_bwd(w, lens, T, M, Kin, H, gates, c_cache, dS_c, dS_h, ld_dS, dh_above, dc_ws, dz):
+    _lib.call("evc_lstm_layer_bwd", _p(w), _p(lens), T, M, Kin, H, _p(gates), _p(c_cache), _p(dS_c), _p(dS_h), ld_dS,
+              _p(dh_above), _p(dc_ws), _p(dz), _stream())
+
+
+# ---------------------------------------------------------------------------
+def moe_tail_fwd(gate_logits, expert_logits, B, V, M, pred, rowsum):
+    _lib.call("evc_moe_tail_fwd", _p(gate_logits), _p(expert_logits), B, V, M, _p(pred), _p(rowsum), _stream())
+
+
+def moe_tail_bwd(gate_logits, expert_logits, dpred, B, V, M, dgate, dexpert):
+    _lib.call("evc_moe_tail_bwd", _p(gate_logits), _p(expert_logits), _p(dpred), B, V, M, _p(dgate), dgate.stride(0),
+              _p(dexpert), dexpert.stride(0), _stream())
+
+
+def ce_loss(pred, labels_u8, loss, dpred=None, grad_scale=1.0, accumulate_grad=False):
+    B, V = pred.shape
+    _lib.call("evc_ce_loss", _p(pred), _p(labels_u8), B, V, grad_scale, _p(loss), _p(dpred), 1 if accumulate_grad else 0, _stream())
+
+
+def kl_pred_loss(pred_t, rowsum_t, pred_s, rowsum_s, loss, dpred_s=None, grad_scale=1.0, accumulate_grad=False):
+    B, V = pred_t.shape
+    _lib.call("evc_kl_pred_loss", _p(pred_t), _p(rowsum_t), _p(pred_s), _p(rowsum_s), B, V, grad_scale, _p(loss), _p(dpred_s),
+              1 if accumulate_grad else 0, _stream())
+
+
+def rep_loss(state_t, state_s, loss, dstate_s=None, grad_scale=1.0, accumulate_grad=False):
+    B, D = state_t.shape
+    _lib.call("evc_rep_loss", _p(state_t), _p(state_s), B, D, grad_scale, _p(loss), _p(dstate_s), 1 if accumulate_grad else 0, _stream())
+
+
+def grad_sqnorm(g, p, l2_coeff, sums):
+    _lib.call("evc_grad_sqnorm", _p(g), _p(p), l2_coeff, g.numel(), _p(sums), _stream())
+
+
+def clip_adam_step(p, g, m, v, l2_coeff, sums, clip_norm, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, p_bf16=None):
+    _lib.call("evc_clip_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), l2_coeff, _p(sums), clip_norm, lr_t, beta1, beta2, eps,
+              _p(p_bf16), _stream())
+
+
+def meanpool(x, num_frames, avg_f32, avg_bf16):
+    B, T, F = x.shape
+    _lib.call("evc_meanpool_fwd", _p(x), _p(num_frames), B, T, F, _p(avg_f32), _p(avg_bf16), _stream())
+
+
+def sigmoid_(z):
+    _lib.call("evc_sigmoid_fwd", _p(z), z.numel(), _stream())
+    return z
+
+
+def sigmoid_bwd(p, dp, dz):
+    _lib.call("evc_sigmoid_bwd", _p(p), _p(dp), p.numel(), _p(dz), _stream())
+
+
+def sample_frames_gather(x, u, num_frames, out, idx_out=None):
+    B, T, F = x.shape
+    S = u.shape[1]
+    _lib.call("evc_sample_frames_gather", _p(x), _p(u), _p(num_frames), B, T, F, S, _p(out), _p(idx_out), _stream())
+
+
+def bn_stats(x, R, Cc, ws, mean, var):
+    _lib.call("evc_bn_stats", _p(x), R, Cc, _p(ws), _p(mean), _p(var), _stream())
+
+
+def bn_apply(x, R, Cc, mean, var, gamma, beta, relu6, y_f32=None, y_bf16=None):
+    _lib.call("evc_bn_apply", _p(x), R, Cc, _p(mean), _p(var), _p(gamma), _p(beta), 1 if relu6 else 0, _p(y_f32), _p(y_bf16), _stream())
+
+
+def bn_relu6_bwd(x, dy, R, Cc, mean, var, gamma, beta, relu6, ws, dx_f32=None, dx_bf16=None, dgamma=None, dbeta=None):
+    _lib.call("evc_bn_relu6_bwd", _p(x), _p(dy), R, Cc, _p(mean), _p(var), _p(gamma), _p(beta), 1 if relu6 else 0, _p(ws),
+              _p(dx_f32), _p(dx_bf16), _p(dgamma), _p(dbeta), _stream())
+
+
+def framepool_max_fwd(y, B, S, Cc, pooled_f32, pooled_bf16, argmax):
+    _lib.call("evc_framepool_max_fwd", _p(y), B, S, Cc, _p(pooled_f32), _p(pooled_bf16), _p(argmax), _stream())
+
+
+def framepool_max_bwd(dpooled, argmax, B, S, Cc, dy):
+    _lib.call("evc_framepool_max_bwd", _p(dpooled), _p(argmax), B, S, Cc, _p(dy), _stream())

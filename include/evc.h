@@ -1,0 +1,208 @@
+/*
+ * evc.h - C ABI of libevc_hip.so: the MI355X (gfx950) kernels behind the
+ * teacher/student frame-level aggregation + distillation hot path.
+ *
+ * The reference (shwetabhardwaj44/EfficientVideoClassification_Youtube8M) has
+ * no native code and no FFI: its hot path is Python graph wiring over
+ * TensorFlow-1.x primitive ops.  Each entry point below therefore replaces the
+ * TensorFlow op(s) invoked at the cited reference call site (paths relative to
+ * code_student_uniform/, "cs/").  The Python host
+ * (efficientvideoclassification_youtube8m_amd/) binds these with ctypes; the
+ * binding a reference maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller; the library never
+ *    allocates, frees or synchronises.  Scratch is caller-provided.
+ *  - calls only ENQUEUE work on `stream` (a hipStream_t passed as void*).
+ *  - return value: 0 = EVC_OK, negative = error; text via evc_last_error().
+ *  - bf16 tensors are raw uint16 bit patterns; "ld" = leading dimension in
+ *    ELEMENTS.  All bf16 GEMM operands are K-contiguous ("NT" form) with
+ *    16-byte aligned rows (ld % 8 == 0, pointer % 16 == 0) and K % 64 == 0.
+ *  - time-major activations: [T][M][width]; "M" = rows (videos x chunks).
+ */
+#ifndef EVC_H_
+#define EVC_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVC_OK 0
+#define EVC_ERR_BAD_SHAPE (-1)
+#define EVC_ERR_BAD_ALIGN (-2)
+#define EVC_ERR_UNSUPPORTED_ARCH (-3)
+#define EVC_ERR_HIP (-4)
+#define EVC_ERR_BAD_ARG (-5)
+
+#define EVC_VERSION 100
+
+typedef uint16_t evc_bf16;
+
+int evc_version(void);
+const char* evc_last_error(void);
+/* 0 if device `dev` is gfx950, EVC_ERR_UNSUPPORTED_ARCH otherwise. */
+int evc_check_device(int dev);
+
+/* ---- a1 + a2: input preparation -------------------------------------------
+ * tf.nn.l2_normalize(model_input_raw, 2)            cs/train.py:253-256
+ * + every_n frame sub-sampling (transpose/gather)   cs/train.py:262-272
+ * + bf16 cast + re-layout to the time-major chunked layout the LSTM consumes.
+ *
+ * x_raw [B, T, F] f32.  Teacher output out1: frame s -> chunk = s / (T/C1),
+ * t = s % (T/C1), row m = chunk*B + b; out1[t][m][F] bf16.  If out2 != NULL the
+ * frames s*every_n (s < S2 = T/every_n, integer division) are also written to
+ * out2 with C2 chunks of S2/C2 frames (the student's view).  F % 4 == 0.
+ * If x_u8 != NULL the input is the on-disk uint8 quantisation and is
+ * dequantised first as cs/utils.py:22-25 (q*4/255 + 4/512 - 2) with rows
+ * t >= num_frames[b] forced to zero (cs/readers.py:170-173); x_raw is ignored.
+ * normalize = 0 skips the l2-normalisation (input already normalised by the
+ * caller, as create_model() receives it at cs/train.py:282-284): cast + re-layout only.
+ */
+int evc_l2norm_chunk_fwd(const float* x_raw, const uint8_t* x_u8, const int32_t* num_frames,
+                         int B, int T, int F,
+                         int C1, evc_bf16* out1,
+                         int every_n, int C2, evc_bf16* out2, int normalize, void* stream);
+
+/* a2 (integer part, bit-exact): num_frames_student = int64(float64(n)/300*S)
+ * cs/train.py:263-264; and the per-chunk L1 lengths / L2 length of
+ * cs/frame_level_models.py:238-240,256 (teacher) and :308-310,327 (student).
+ * len_l1 [C*B] int32 with row m = chunk*B + b; len_l2 [B] int32.
+ * n_out [B] int64 receives the (possibly sub-sampled) frame count used. */
+int evc_frame_counts(const int32_t* num_frames, int B, int every_n, int max_frames_before_sampling,
+                     int num_chunks, int chunk_len, int64_t* n_out, int32_t* len_l1, int32_t* len_l2,
+                     void* stream);
+
+/* ---- generic bf16 MFMA GEMM (NT): C[M,N] (+)= A[M,K] . B[N,K]^T (+ bias[N]) --
+ * Replaces tf.matmul / slim.fully_connected's MatMul+BiasAdd
+ * (cs/video_level_models.py:423-435, cs/frame_level_models.py:148,172,80-82).
+ * out_bf16: 0 -> C is f32, 1 -> C is bf16.  accumulate: C += (f32 only).
+ * K % 64 == 0.  bias may be NULL. */
+int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, void* C, int64_t ldc,
+                int M, int N, int K, const float* bias, int out_bf16, int accumulate, void* stream);
+
+/* ---- a3/a4: one BasicLSTMCell layer over T steps with sequence lengths -----
+ * tf.nn.dynamic_rnn(MultiRNNCell[BasicLSTMCell(H, forget_bias=1.0)], x,
+ * sequence_length=len)  cs/frame_level_models.py:221-235,247-257,291-305,318-328
+ *
+ * x   [T][M][Kin] bf16 time-major layer input (for layer l>0: hbuf+M*H of layer l-1)
+ * wT  [4H][Kin+H] bf16 = kernel^T, gate row blocks in TF order i,j,f,o
+ * bias[4H] f32 (forget_bias 1.0 is added inside, as TF does at run time)
+ * len [M] int32: state copied through for t >= len[m]
+ * hoist: 0 = each step contracts [x_t, h_{t-1}] in one GEMM (K = Kin+H);
+ *        1 = x.Wx for all T hoisted into one GEMM into zx_ws [T*M][4H] f32.
+ * hbuf [(T+1)][M][H] bf16: slab 0 is zero-filled here, slab t+1 = h_t (0 where t >= len)
+ * c_state/h_state: f32 final state columns, row stride ld_state (so they can
+ *        point into the [M, 2*L*H] state tensor concat([c0,h0,c1,h1]));
+ *        zero for len == 0.
+ * gates [T][M][4H] bf16 (post-activation i,j,f,o) and c_cache [T][M][H] f32 are
+ *        saved for the backward pass when non-NULL.
+ */
+int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const float* bias, const int32_t* len,
+                       int T, int M, int Kin, int H, int hoist, float* zx_ws,
+                       evc_bf16* hbuf, float* c_state, float* h_state, int64_t ld_state,
+                       evc_bf16* gates, float* c_cache, void* stream);
+
+/* BPTT of the above (what tf.gradients builds inside
+ * slim.learning.create_train_op, cs/train.py:329-334,413-418).
+ * w   [Kin+H][4H] bf16 = kernel in TF layout (K-contiguous for dz . W^T)
+ * dS_c/dS_h: f32 gradient wrt the final c/h state, row stride ld_dS
+ * dh_above [T][M][H] f32 or NULL: gradient arriving at h_t from the layer above
+ * dc_ws [M][H] f32 scratch.   dz [T][M][4H] bf16 out (0 where t >= len).
+ */
+int evc_lstm_layer_bwd(const evc_bf16* w, const int32_t* len, int T, int M, int Kin, int H,
+                       const evc_bf16* gates, const float* c_cache,
+                       const float* dS_c, const float* dS_h, int64_t ld_dS,
+                       const float* dh_above, float* dc_ws, evc_bf16* dz, void* stream);
+
+/* ---- layout helpers --------------------------------------------------------
+ * out[c][r] = in[r][c], r < R, c < C; out has ld_out >= Rpad columns and
+ * columns [R, Rpad) are zero-filled (Rpad % 64 == 0 keeps GEMM K aligned).
+ * in_f32: 1 -> `in` is f32 (cast to bf16 on the way), 0 -> bf16. */
+int evc_transpose_to_bf16(const void* in, int in_f32, int64_t ld_in, int R, int C,
+                          evc_bf16* out, int64_t ld_out, int Rpad, void* stream);
+/* out_bf16[i] = bf16(in_f32[i]) for a [R, C] matrix (ld_in, ld_out). */
+int evc_cast_f32_to_bf16(const float* in, int64_t ld_in, int R, int C, evc_bf16* out, int64_t ld_out, void* stream);
+/* out[r] = sum_c in[r][c] (bf16 in, f32 out): bias gradients from dz^T. */
+int evc_rowsum_bf16(const evc_bf16* in, int64_t ld_in, int R, int C, float* out, void* stream);
+
+/* ---- a5: MoeModel tail -----------------------------------------------------
+ * cs/video_level_models.py:437-448: softmax over M+1 gate logits, sigmoid over
+ * M expert logits, p = sum_{m<M} g_m e_m.   gate_logits [B][V*(M+1)],
+ * expert_logits [B][V*M] (bias already added), class-major columns.
+ * pred [B][V] f32; rowsum[B] = sum_c pred (used by L_PRED).  M <= 4. */
+int evc_moe_tail_fwd(const float* gate_logits, const float* expert_logits, int B, int V, int M,
+                     float* pred, float* rowsum, void* stream);
+/* dL/dlogits from dL/dpred; writes bf16 (GEMM operand) transposed-ready row-major. */
+int evc_moe_tail_bwd(const float* gate_logits, const float* expert_logits, const float* dpred,
+                     int B, int V, int M, evc_bf16* dgate, int64_t ld_dgate,
+                     evc_bf16* dexpert, int64_t ld_dexpert, void* stream);
+
+/* ---- a6 + a7: losses ---------------------------------------------------------
+ * CrossEntropyLoss (cs/losses.py:90-97), L_PRED = sum_b KL(pT/sum pT || pS/sum pS)
+ * (cs/train.py:398-402), L_REP = mean_b sum_d (sT-sS)^2 (cs/train.py:359-362).
+ * Each call ACCUMULATES its scalar into *loss (f32, device; zero it first) and
+ * writes/accumulates the gradient.
+ */
+/* loss += scale_loss * mean_b CE ; dpred (=|+=) grad_scale * dCE/dpred. labels uint8 [B][V]. */
+int evc_ce_loss(const float* pred, const uint8_t* labels, int B, int V, float grad_scale,
+                float* loss, float* dpred, int accumulate_grad, void* stream);
+/* loss += KL sum ; dpred_student (=|+=) grad_scale * dKL/dpS. */
+int evc_kl_pred_loss(const float* pred_t, const float* rowsum_t, const float* pred_s, const float* rowsum_s,
+                     int B, int V, float grad_scale, float* loss, float* dpred_s, int accumulate_grad,
+                     void* stream);
+/* loss += mean_b sum_d (sT-sS)^2 ; dstate_s (=|+=) grad_scale * d/dsS. */
+int evc_rep_loss(const float* state_t, const float* state_s, int B, int D, float grad_scale,
+                 float* loss, float* dstate_s, int accumulate_grad, void* stream);
+
+/* ---- a8 + a9: regulariser, per-tensor clip, TF-Adam ---------------------------
+ * slim.l2_regularizer (cs/video_level_models.py:428,434) folded into the
+ * gradient: g_eff = g + l2_coeff * p  (l2_coeff = regularization_penalty*1e-8).
+ * Pass 1: sums[0] += sum(g_eff^2), sums[1] += sum(p^2)   (f32 device, zero first).
+ * Pass 2: clip_by_norm per tensor (slim create_train_op, cs/train.py:329-334)
+ *   scale = clip / max(sqrt(sums[0]), clip) (clip <= 0: no clipping), then
+ *   tf.train.AdamOptimizer update with lr_t = lr*sqrt(1-b2^t)/(1-b1^t),
+ *   p -= lr_t * m / (sqrt(v) + eps); optionally refreshes a bf16 copy of p.
+ */
+int evc_grad_sqnorm(const float* g, const float* p, float l2_coeff, int64_t n, float* sums, void* stream);
+int evc_clip_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float l2_coeff,
+                       const float* sums, float clip_norm, float lr_t, float beta1, float beta2, float eps,
+                       evc_bf16* p_bf16, void* stream);
+
+/* ---- a11: FrameLevelLogisticModel pooling ------------------------------------
+ * cs/frame_level_models.py:72-78: sum over ALL T (padded) frames / true n.
+ * x [B][T][F] f32 -> avg [B][F] bf16 (GEMM operand) and f32. */
+int evc_meanpool_fwd(const float* x, const int32_t* num_frames, int B, int T, int F,
+                     float* avg_f32, evc_bf16* avg_bf16, void* stream);
+/* elementwise sigmoid fwd (in place on f32 [n]) and dz = dp * p * (1-p) -> bf16 */
+int evc_sigmoid_fwd(float* z, int64_t n, void* stream);
+int evc_sigmoid_bwd(const float* p, const float* dp, int64_t n, evc_bf16* dz, void* stream);
+
+/* ---- a10: DbofModel pieces ----------------------------------------------------
+ * SampleRandomFrames (cs/model_utils.py:39-58): idx = int32(u * float32(n));
+ * gathers x[b, idx[b,s], :] -> out [B*S][F] f32.  u [B][S] f32 supplied by caller. */
+int evc_sample_frames_gather(const float* x, const float* u, const int32_t* num_frames, int B, int T, int F,
+                             int S, float* out, int32_t* idx_out, void* stream);
+/* slim.batch_norm training statistics over rows: mean[C], var[C] (biased, f64 accumulation). x [R][C] f32. */
+int evc_bn_stats(const float* x, int R, int C, double* ws /* 2*C, zeroed inside */, float* mean, float* var,
+                 void* stream);
+/* y = relu6?(gamma*(x-mean)*rsqrt(var+1e-3)+beta); writes f32 y and/or bf16 y. */
+int evc_bn_apply(const float* x, int R, int C, const float* mean, const float* var, const float* gamma,
+                 const float* beta, int relu6, float* y_f32, evc_bf16* y_bf16, void* stream);
+/* backward of relu6(bn(x)) given dy: needs x, stats; two passes inside. dx f32/bf16, dgamma, dbeta. */
+int evc_bn_relu6_bwd(const float* x, const float* dy, int R, int C, const float* mean, const float* var,
+                     const float* gamma, const float* beta, int relu6, double* ws /* 2*C, zeroed inside */,
+                     float* dx_f32, evc_bf16* dx_bf16, float* dgamma, float* dbeta, void* stream);
+/* FramePooling 'max' (cs/model_utils.py:77-78): y [B][S][C] f32 -> pooled [B][C] + argmax. */
+int evc_framepool_max_fwd(const float* y, int B, int S, int C, float* pooled_f32, evc_bf16* pooled_bf16,
+                          int32_t* argmax, void* stream);
+int evc_framepool_max_bwd(const float* dpooled, const int32_t* argmax, int B, int S, int C, float* dy, void* stream);
+
+/* utility: out[i] = value for n floats (avoids torch for tiny fills inside C loops) */
+int evc_fill_f32(float* p, int64_t n, float value, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVC_H_ */

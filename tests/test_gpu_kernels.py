@@ -1,0 +1,197 @@
+"""Kernel-level parity: each HIP entry point (through the C ABI) against the
+numpy oracle on seeded inputs.  Run on the MI355X box: pytest -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model_math as mm
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from efficientvideoclassification_youtube8m_amd import ops as _ops
+    _ops.check_device(0)
+    return _ops
+
+
+def bf16_round(a):
+    return torch.from_numpy(np.asarray(a, np.float32)).bfloat16().double().numpy()
+
+
+def to_bf16(a):
+    return torch.from_numpy(np.asarray(a, np.float32)).bfloat16().to(DEV)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 300, 128), (512, 4096, 1024), (64, 64, 2176),
+                                   (1, 5, 64), (1000, 130, 192), (4716, 64, 256)])
+def test_gemm_nt(ops, M, N, K):
+    rng = np.random.default_rng(M * 7 + N)
+    A = bf16_round(rng.standard_normal((M, K)))
+    B = bf16_round(rng.standard_normal((N, K)) * 0.1)
+    bias = rng.standard_normal(N).astype(np.float32)
+    ref = A @ B.T + bias
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    ops.gemm_nt(to_bf16(A), to_bf16(B), M, N, K, out, bias=torch.from_numpy(bias).to(DEV))
+    got = out.cpu().double().numpy()
+    scale = np.abs(A) @ np.abs(B.T) + 1.0
+    assert np.max(np.abs(got - ref) / scale) < 2e-6          # f32 accumulation of exact bf16 products
+    # accumulate + bf16 output paths
+    ops.gemm_nt(to_bf16(A), to_bf16(B), M, N, K, out, accumulate=True)
+    assert np.max(np.abs(out.cpu().double().numpy() - (2 * ref - bias)) / scale) < 4e-6
+    outb = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt(to_bf16(A), to_bf16(B), M, N, K, outb)
+    assert np.max(np.abs(outb.float().cpu().double().numpy() - (ref - bias)) / scale) < 8e-3
+
+
+def _lstm_ref(x, lens, kernel, bias):
+    s, cache = mm.multi_rnn_seq_fwd(x, lens, [(kernel, bias)])
+    return s, cache
+
+
+@pytest.mark.parametrize("M,T,Kin,H,hoist", [(256, 5, 64, 64, False), (256, 5, 64, 64, True), (200, 4, 128, 128, False),
+                                             (1536, 3, 192, 256, False), (1536, 3, 192, 256, True), (70, 6, 64, 128, True)])
+def test_lstm_layer_fwd_and_bwd(ops, M, T, Kin, H, hoist):
+    """One BasicLSTMCell layer over T steps with ragged lengths (incl. 0 and T):
+    final state, per-step h, and the BPTT dz / dx / dW against the oracle run on
+    the same bf16-rounded operands."""
+    rng = np.random.default_rng(M + T + Kin + H)
+    x = bf16_round(rng.standard_normal((M, T, Kin)) * 0.5)
+    kernel = bf16_round(mm.glorot_uniform(rng, (Kin + H, 4 * H)) * 2.0)
+    bias = (rng.standard_normal(4 * H) * 0.1).astype(np.float32).astype(np.float64)
+    lens = rng.integers(0, T + 1, size=M).astype(np.int32)
+    lens[:3] = [0, T, 1]
+    s_ref, cache = mm.multi_rnn_seq_fwd(x, lens, [(kernel, bias)])
+
+    xt = to_bf16(np.ascontiguousarray(x.transpose(1, 0, 2)))         # [T][M][Kin]
+    wT = to_bf16(np.ascontiguousarray(kernel.T))                       # [4H][Kin+H]
+    w = to_bf16(kernel)                                                # [Kin+H][4H]
+    b = torch.from_numpy(bias.astype(np.float32)).to(DEV)
+    ln = torch.from_numpy(lens).to(DEV)
+    hbuf = torch.full((T + 1, M, H), float("nan"), dtype=torch.bfloat16, device=DEV)
+    S = torch.full((M, 2 * H), float("nan"), dtype=torch.float32, device=DEV)
+    gates = torch.empty((T, M, 4 * H), dtype=torch.bfloat16, device=DEV)
+    cc = torch.empty((T, M, H), dtype=torch.float32, device=DEV)
+    zx = torch.empty((T * M, 4 * H), dtype=torch.float32, device=DEV) if hoist else None
+    ops.lstm_layer_fwd(xt, wT, b, ln, T, M, Kin, H, hbuf, S[:, :H], S[:, H:], 2 * H, gates, cc, hoist=hoist, zx_ws=zx)
+    got = S.cpu().double().numpy()
+    assert np.isfinite(got).all()
+    # h is re-quantised to bf16 between steps (the kernel's operand precision): 2^-9 relative per step
+    assert np.max(np.abs(got - s_ref)) < 6e-3, np.max(np.abs(got - s_ref))
+    assert np.all(got[0] == 0)                                          # len 0 -> zero state
+    hb = hbuf.float().cpu().numpy()
+    assert np.all(hb[0] == 0)
+    for t in range(T):
+        assert np.all(hb[t + 1][lens <= t] == 0)                        # zero output past the length
+
+    # ---- backward ----
+    dS = rng.standard_normal((M, 2 * H))
+    dh_above = rng.standard_normal((T, M, H)) * 0.3
+    # oracle: gradient wrt final state plus an extra loss sum(h_t * dh_above_t) on active steps
+    dx_ref, grads_ref = _bwd_ref(x, lens, kernel, bias, dS, dh_above)
+    dSt = torch.from_numpy(dS.astype(np.float32)).to(DEV)
+    dha = torch.from_numpy(dh_above.astype(np.float32)).to(DEV)
+    dz = torch.full((T, M, 4 * H), float("nan"), dtype=torch.bfloat16, device=DEV)
+    dcw = torch.empty((M, H), dtype=torch.float32, device=DEV)
+    ops.lstm_layer_bwd(w, ln, T, M, Kin, H, gates, cc, dSt[:, :H], dSt[:, H:], 2 * H, dha, dcw, dz)
+    dzf = dz.float().cpu().double().numpy()
+    assert np.isfinite(dzf).all()
+    for t in range(T):
+        assert np.all(dzf[t][lens <= t] == 0)
+    # dx = dz . Wx^T through the generic GEMM (hoisted in the product path)
+    dxo = torch.empty((T * M, Kin), dtype=torch.float32, device=DEV)
+    ops.gemm_nt(dz.reshape(T * M, 4 * H), w, T * M, Kin, 4 * H, dxo)
+    dx_got = dxo.cpu().double().numpy().reshape(T, M, Kin).transpose(1, 0, 2)
+    sc = np.abs(dx_ref).max() + 1e-6
+    assert np.max(np.abs(dx_got - dx_ref)) / sc < 2e-2
+    # dW^T = dz^T . [x | h_prev] via transposes + GEMM
+    KP = ops.round_up(T * M, 64)
+    dzT = torch.empty((4 * H, KP), dtype=torch.bfloat16, device=DEV)
+    ops.transpose_to_bf16(dz.reshape(T * M, 4 * H), T * M, 4 * H, dzT, KP)
+    xT = torch.empty((Kin, KP), dtype=torch.bfloat16, device=DEV)
+    ops.transpose_to_bf16(xt.reshape(T * M, Kin), T * M, Kin, xT, KP)
+    hT = torch.empty((H, KP), dtype=torch.bfloat16, device=DEV)
+    ops.transpose_to_bf16(hbuf[:T].reshape(T * M, H), T * M, H, hT, KP)
+    dWT = torch.empty((4 * H, Kin + H), dtype=torch.float32, device=DEV)
+    ops.gemm_nt(dzT, xT, 4 * H, Kin, KP, dWT)
+    ops.gemm_nt(dzT, hT, 4 * H, H, KP, dWT[:, Kin:], ldc=Kin + H)
+    dW_got = dWT.cpu().double().numpy().T
+    dW_ref = grads_ref[0][0]
+    sc = np.abs(dW_ref).max() + 1e-6
+    assert np.max(np.abs(dW_got - dW_ref)) / sc < 2e-2
+    db = torch.empty(4 * H, dtype=torch.float32, device=DEV)
+    ops.rowsum_bf16(dzT, 4 * H, KP, db)
+    sc = np.abs(grads_ref[0][1]).max() + 1e-6
+    assert np.max(np.abs(db.cpu().double().numpy() - grads_ref[0][1])) / sc < 2e-2
+
+
+def _bwd_ref(x, lens, kernel, bias, dS, dh_above):
+    """Oracle BPTT with an upper-layer gradient on the per-step outputs: emulate
+    the upper layer by a 2-layer stack is overkill, so extend the oracle's
+    single-layer BPTT by injecting dh_above where the step is active."""
+    layers = [(kernel, bias)]
+    _, cache = mm.multi_rnn_seq_fwd(x, lens, layers)
+    steps, lengths, xshape, H = cache
+    M, T, F = xshape
+    dc = dS[:, :H].copy()
+    dh = dS[:, H:].copy()
+    dK = np.zeros_like(kernel)
+    db = np.zeros_like(bias)
+    dx = np.zeros((M, T, F))
+    for t in range(T - 1, -1, -1):
+        act = (t < lengths)[:, None].astype(np.float64)
+        inp, h_prev, c_prev, (i, j, f, o, tc) = steps[t][0]
+        dh_new = act * (dh + dh_above[t])
+        dc_new = act * dc + dh_new * o * (1 - tc * tc)
+        dz = np.concatenate([dc_new * j * i * (1 - i), dc_new * i * (1 - j * j), dc_new * c_prev * f * (1 - f),
+                             dh_new * tc * o * (1 - o)], axis=1)
+        xin = np.concatenate([inp, h_prev], axis=1)
+        dK += xin.T @ dz
+        db += dz.sum(0)
+        dxin = dz @ kernel.T
+        dx[:, t] = dxin[:, :F]
+        dh = (1 - act) * dh + dxin[:, F:]
+        dc = (1 - act) * dc + dc_new * f
+    return dx, [(dK, db)]
+
+
+def test_l2norm_chunk_and_counts(ops):
+    rng = np.random.default_rng(5)
+    B, T, F = 6, 300, 1152
+    q, x, n, _ = mm.synthetic_batch(B, seed=3, dtype=np.float32)
+    xr = torch.from_numpy(x).to(DEV)
+    o1, o2 = ops.l2norm_chunk(xr, 20, every_n=10, num_chunks_student=5)
+    ref = mm.l2_normalize(x.astype(np.float64), 2)
+    # teacher view [15][20*B][F], row m = chunk*B + b
+    r1 = ref.reshape(B, 20, 15, F).transpose(2, 1, 0, 3).reshape(15, 20 * B, F)
+    assert np.max(np.abs(o1.float().cpu().numpy() - r1)) < 2 ** -8 * np.abs(r1).max()
+    rs = mm.subsample_frames(ref, 10)
+    r2 = rs.reshape(B, 5, 6, F).transpose(2, 1, 0, 3).reshape(6, 5 * B, F)
+    assert np.max(np.abs(o2.float().cpu().numpy() - r2)) < 2 ** -8 * np.abs(r2).max()
+    # the student rows are bit-identical copies of the teacher's rows for frames 0,10,20,...
+    t1 = o1.reshape(15, 20, B, F)
+    for s in range(30):
+        fr = s * 10
+        assert torch.equal(o2.reshape(6, 5, B, F)[s % 6, s // 6], t1[fr % 15, fr // 15])
+    # uint8 input path: dequantise + zero padding + normalise
+    qd = torch.from_numpy(q).to(DEV)
+    nd = torch.from_numpy(n).to(DEV)
+    u1, _ = ops.l2norm_chunk(qd, 20, num_frames=nd)
+    # (dequantisation may contract to an FMA on the device: allow one bf16 ulp)
+    assert (u1.float() - o1.float()).abs().max().item() <= 2 ** -8 * o1.float().abs().max().item()
+    assert (u1 != o1).float().mean().item() < 0.01
+    # integer part: bit-exact
+    for every_n in (1, 2, 3, 4, 6, 10, 30):
+        nn = torch.arange(0, 301, dtype=torch.int32, device=DEV)
+        S = 300 // every_n
+        C = 20 if every_n == 1 else 5
+        Lc = S // C if S % C == 0 else 1
+        n_used, l1, l2 = ops.frame_counts(nn, every_n, C, Lc)
+        ref_n = mm.student_num_frames(np.arange(301), every_n) if every_n > 1 else np.arange(301)
+        assert np.array_equal(n_used.cpu().numpy(), ref_n)
+        rl1, rl2 = mm.hlstm_chunk_lengths(ref_n, C, Lc)
+        assert np.array_equal(l1.cpu().numpy().reshape(C, 301), rl1.T)
+        assert np.array_equal(l2.cpu().numpy(), rl2)
