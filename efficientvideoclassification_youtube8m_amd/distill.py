@@ -1,0 +1,185 @@
+"""The training-iteration graph of the reference's train.py / train_finetune.py
+as an explicit schedule over the HIP kernels.
+
+Reference: ``build_graph`` cs/train.py:185-427 (teacher + student in one
+``sess.run``, cs/train.py:516-517) and cs/train_finetune.py:185-331
+(student only).  Quirks kept on purpose: L_REP counted
+twice in the student objective (cs/train.py:406), global_step += 2 per
+iteration (one increment per train op, :332,:416), per-tensor gradient
+clipping, teacher tensors constant in the student loss, both updates computed
+from the pre-update weights of the same step.
+
+Data parallel (new; the reference is single-device): one process per GPU,
+replicated parameters, per-rank batch, gradients summed with RCCL all-reduce
+(``torch.distributed`` backend "nccl") on the flat gradient buffer - the MoE
+segment is reduced as soon as it is final so it overlaps the LSTM BPTT, the
+teacher's reduce overlaps the student's forward/backward.  Batch-mean losses
+(CE, L_REP) are scaled by 1/world so the summed gradient equals the
+single-device gradient at the global batch; L_PRED is a batch *sum*
+(cs/train.py:402) and is not scaled.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import ops
+from .engine import HLstmTower
+
+F32 = torch.float32
+
+
+def exponential_decay(lr0, global_step, batch_size, decay_examples, rate):
+    """tf.train.exponential_decay(lr0, global_step*batch, decay_examples, rate,
+    staircase=True) - cs/train.py:223-236."""
+    return lr0 * rate ** math.floor(global_step * batch_size / decay_examples)
+
+
+def every_n_indices(every_n, max_frames=300):
+    """cs/train.py:265-269 (host-side restatement of the static index list)."""
+    idx, k = [], 0
+    while every_n * k <= max_frames - 1:
+        idx.append(every_n * k)
+        k += 1
+    return idx
+
+
+def validate_every_n(every_n, num_inputs_l1=5, max_frames=300):
+    """The reference's graph only builds when len(index list) == int(300/every_n)
+    and that count splits into 5 chunks (cs/train.py:262-272,
+    cs/frame_level_models.py:286,307).  Same failure, as a ValueError."""
+    if every_n <= 0:
+        raise ValueError("every_n must be a positive integer")
+    s = max_frames // every_n
+    if len(every_n_indices(every_n, max_frames)) != s or s == 0 or s % num_inputs_l1 != 0:
+        raise ValueError("every_n=%d: %d gathered frames cannot be split into %d equal chunks of the %d-frame "
+                         "student input" % (every_n, len(every_n_indices(every_n, max_frames)), num_inputs_l1, s))
+
+
+class DistillGraph:
+    """mode: 'teacher_student' (train.py), 'teacher' (teacher only, BASELINE cfg 2),
+    'student' (train_finetune.py)."""
+
+    LOSS_SLOTS = ("label_loss", "student_loss_state", "pred_loss", "student_label_loss")
+
+    def __init__(self, batch_size, every_n=10, mode="teacher_student", feature_size=1152, vocab_size=4716,
+                 max_frames=300, num_inputs_to_lstm=20, num_inputs_l1_student=5, lstm_cells=1024, lstm_layers=2,
+                 num_mixtures=2, base_learning_rate=0.001, learning_rate_decay=1.0,
+                 learning_rate_decay_examples=4000000, regularization_penalty=2.0, clip_gradient_norm=1.0,
+                 count_rep_twice=True, device="cuda:0", seed=7, process_group=None):
+        assert mode in ("teacher_student", "teacher", "student")
+        self.mode, self.B, self.every_n = mode, batch_size, every_n
+        self.max_frames, self.C1, self.C2 = max_frames, num_inputs_to_lstm, num_inputs_l1_student
+        self.lr0, self.lr_decay, self.lr_decay_examples = base_learning_rate, learning_rate_decay, learning_rate_decay_examples
+        self.reg_pen, self.clip = regularization_penalty, clip_gradient_norm
+        self.rep_w = 2.0 if count_rep_twice else 1.0
+        self.device = torch.device(device)
+        self.pg = process_group
+        self.world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.world = torch.distributed.get_world_size(process_group)
+        self.global_step = 0
+        self.teacher = self.student = None
+        if mode != "student":
+            self.teacher = HLstmTower(batch_size, max_frames, num_inputs_to_lstm, feature_size, vocab_size, lstm_cells,
+                                      lstm_layers, num_mixtures, device, True, "model", seed)
+        if mode != "teacher":
+            validate_every_n(every_n, num_inputs_l1_student, max_frames)
+            self.S = max_frames // every_n
+            self.student = HLstmTower(batch_size, self.S, num_inputs_l1_student, feature_size, vocab_size, lstm_cells,
+                                      lstm_layers, num_mixtures, device, True, "model_student", seed + 1)
+        self.losses = torch.zeros(8, dtype=F32, device=self.device)
+        self._dp_t = self._dp_s = self._ds_s = None
+        self._pending = []
+
+    # ---- data-parallel gradient reduction -------------------------------------
+    def _allreduce(self, flat, lo, hi):
+        if self.world == 1:
+            return
+        w = torch.distributed.all_reduce(flat[lo:hi], op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=True)
+        self._pending.append(w)
+
+    def _reduce_tower(self, tower, moe_first):
+        st = tower.store
+        moe_lo = st.offsets[tower.GATES]
+        if moe_first:
+            self._allreduce(st.grad, moe_lo, st.total)
+        else:
+            self._allreduce(st.grad, 0, moe_lo)
+
+    def _wait_reductions(self):
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+
+    # ---- one training iteration -----------------------------------------------
+    def step(self, x_raw, labels_u8, num_frames, apply=True):
+        """x_raw [B,300,F] f32 (or uint8), labels_u8 [B,V] uint8, num_frames [B] int32.
+        Returns a dict mirroring the graph collections the reference's loop
+        fetches (cs/train.py:336-344,420-425,516-517); tensors stay on device."""
+        B = x_raw.shape[0]
+        V = labels_u8.shape[1]
+        dev = self.device
+        if self._dp_t is None or self._dp_t.shape[0] != B:
+            self._dp_t = torch.empty((B, V), dtype=F32, device=dev)
+            self._dp_s = torch.empty((B, V), dtype=F32, device=dev)
+        need_student = self.student is not None
+        xt, xs = ops.l2norm_chunk(x_raw, self.C1, self.every_n if need_student else None, self.C2,
+                                  num_frames=num_frames if x_raw.dtype == torch.uint8 else None)
+        self.losses.zero_()
+        out = {}
+        inv_w = 1.0 / self.world
+        if self.teacher is not None:
+            _, l1, l2 = ops.frame_counts(num_frames, 1, self.C1, self.max_frames // self.C1, self.max_frames)
+            t_state, t_pred = self.teacher.forward(xt, l1, l2)
+            ops.ce_loss(t_pred, labels_u8, self.losses[0:1], self._dp_t, grad_scale=inv_w / B)
+            self.teacher.backward(None, self._dp_t,
+                                  on_moe_grads_ready=lambda: self._reduce_tower(self.teacher, True))
+            self._reduce_tower(self.teacher, False)
+            out.update(predictions=t_pred, teacher_state=t_state, loss=self.losses[0])
+        if need_student:
+            n_s, l1s, l2s = ops.frame_counts(num_frames, self.every_n, self.C2, self.S // self.C2, self.max_frames)
+            s_state, s_pred = self.student.forward(xs, l1s, l2s)
+            ops.ce_loss(s_pred, labels_u8, self.losses[3:4], self._dp_s, grad_scale=inv_w / B)
+            ds = None
+            if self.teacher is not None:
+                if self._ds_s is None or self._ds_s.shape != s_state.shape:
+                    self._ds_s = torch.empty_like(s_state)
+                ops.kl_pred_loss(t_pred, self.teacher.rowsum, s_pred, self.student.rowsum, self.losses[2:3], self._dp_s,
+                                 grad_scale=1.0, accumulate_grad=True)
+                ops.rep_loss(t_state, s_state, self.losses[1:2], self._ds_s, grad_scale=self.rep_w * inv_w)
+                ds = self._ds_s
+            self.student.backward(ds, self._dp_s,
+                                  on_moe_grads_ready=lambda: self._reduce_tower(self.student, True))
+            self._reduce_tower(self.student, False)
+            out.update(student_predictions=s_pred, student_state=s_state, num_frames_student=n_s,
+                       student_loss_state=self.losses[1], pred_loss=self.losses[2], student_label_loss=self.losses[3])
+        self._wait_reductions()
+        if apply:
+            self.apply_gradients(B)
+        out["global_step"] = self.global_step
+        return out
+
+    def apply_gradients(self, batch_size):
+        l2c = self.reg_pen * 1e-8
+        # both train ops read the same global_step value within one sess.run; each increments it
+        lr = exponential_decay(self.lr0, self.global_step, batch_size * self.world, self.lr_decay_examples, self.lr_decay)
+        if self.teacher is not None:
+            self.teacher.apply_gradients(lr, self.clip, l2c)
+            self.global_step += 1
+        if self.student is not None:
+            self.student.apply_gradients(lr, self.clip, l2c)
+            self.global_step += 1
+
+    def loss_report(self):
+        """Host floats in the order the reference logs them (cs/train.py:528-533)."""
+        v = self.losses.tolist()
+        rep = {k: v[i] for i, k in enumerate(self.LOSS_SLOTS)}
+        if self.world > 1:   # per-rank values -> global-batch values (means / sum)
+            t = torch.tensor([rep[k] for k in self.LOSS_SLOTS], dtype=torch.float64, device=self.device)
+            torch.distributed.all_reduce(t, group=self.pg)
+            t = t.tolist()
+            rep = {"label_loss": t[0] / self.world, "student_loss_state": t[1] / self.world, "pred_loss": t[2],
+                   "student_label_loss": t[3] / self.world}
+        return rep

@@ -1,0 +1,329 @@
+"""Execution engine of one model tower (teacher or student): parameters in
+kernel layout, preallocated activation/gradient workspaces and the explicit
+forward / backward / apply-gradients schedule over the C-ABI kernels.
+
+What it replaces in the reference: the TensorFlow graph built by
+``HierarchicalLstmModel.create_model`` / ``create_model_inference``
+(cs/frame_level_models.py:200-338) + ``MoeModel.create_model``
+(cs/video_level_models.py:397-448), its reverse-mode graph and the
+``slim.learning.create_train_op`` update (cs/train.py:329-334, 413-418).
+
+Memory layout (HBM, per tower; all preallocated once per batch size):
+  * master parameters, gradients and Adam slots: three flat f32 buffers with
+    one 64-byte aligned segment per variable (a single contiguous gradient
+    buffer = one RCCL all-reduce payload);
+  * LSTM kernels are stored TRANSPOSED, ``wT [4H][in+H]`` (K-contiguous B
+    operand of the forward GEMM), with a bf16 shadow of the same layout and a
+    bf16 shadow in TF layout ``w [in+H][4H]`` (K-contiguous for dz . W^T);
+  * MoE weights likewise ``[V*(M+1)][K]`` / ``[V*M][K]`` + shadows
+    ``[K][pad64(V*(M+1))]`` for the backward;
+  * activations are time-major ``[T][M][width]``; L1 rows are
+    ``m = chunk*B + b`` so L1's final state ``[C*B][2LH]`` *is* L2's
+    time-major input ``[C][B][2LH]`` with no re-layout.
+``state_dict()`` / ``load_state_dict()`` convert to/from the TF variable names
+and layouts of SURVEY.md Appendix C.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import ops
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _align(n, a=16):
+    return (n + a - 1) // a * a
+
+
+class ParamStore:
+    """Flat f32 master / grad / adam-m / adam-v buffers with named views."""
+
+    def __init__(self, shapes: "OrderedDict[str, tuple]", device):
+        self.shapes = shapes
+        self.offsets = OrderedDict()
+        off = 0
+        for k, shp in shapes.items():
+            self.offsets[k] = off
+            off += _align(int(math.prod(shp)))
+        self.total = off
+        self.master = torch.zeros(off, dtype=F32, device=device)
+        self.grad = torch.zeros(off, dtype=F32, device=device)
+        self.m = torch.zeros(off, dtype=F32, device=device)
+        self.v = torch.zeros(off, dtype=F32, device=device)
+
+    def view(self, buf, k):
+        shp = self.shapes[k]
+        n = int(math.prod(shp))
+        o = self.offsets[k]
+        return buf[o:o + n].view(*shp)
+
+    def p(self, k):
+        return self.view(self.master, k)
+
+    def g(self, k):
+        return self.view(self.grad, k)
+
+
+class LstmStack:
+    """L layers of BasicLSTMCell over T steps at M rows (one dynamic_rnn call
+    of the reference, with the weight-shared chunk loops folded into M)."""
+
+    def __init__(self, tower, scope, T, M, Kin, training):
+        self.tw, self.scope, self.T, self.M, self.Kin = tower, scope, T, M, Kin
+        H, L, dev = tower.H, tower.L, tower.device
+        self.H, self.L = H, L
+        self.S = torch.zeros((M, 2 * L * H), dtype=F32, device=dev)          # final state [c0|h0|c1|h1]
+        self.hbuf = [torch.empty((T + 1, M, H), dtype=BF16, device=dev) for _ in range(L)]
+        self.kin = [Kin] + [H] * (L - 1)
+        # hoist the x-projection when the per-step GEMM is small (M ~ batch): fewer, larger GEMMs
+        self.hoist = [M < 1024 for _ in range(L)]
+        self.zx = None
+        if any(self.hoist):
+            self.zx = torch.empty((T * M, 4 * H), dtype=F32, device=dev)
+        self.training = training
+        if training:
+            self.gates = [torch.empty((T, M, 4 * H), dtype=BF16, device=dev) for _ in range(L)]
+            self.cc = [torch.empty((T, M, H), dtype=F32, device=dev) for _ in range(L)]
+            self.KP = ops.round_up(T * M, 64)
+            self.dz = torch.empty((T, M, 4 * H), dtype=BF16, device=dev)
+            self.dzT = torch.empty((4 * H, self.KP), dtype=BF16, device=dev)
+            self.inT = torch.empty((max(self.kin), self.KP), dtype=BF16, device=dev)
+            self.hT = torch.empty((H, self.KP), dtype=BF16, device=dev)
+            self.dc_ws = torch.empty((M, H), dtype=F32, device=dev)
+            self.dx = [torch.empty((T * M, self.kin[l]), dtype=F32, device=dev) if (l > 0) else None for l in range(L)]
+
+    def names(self, l):
+        base = "%s/rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/" % (self.scope, l)
+        return base + "kernel", base + "bias"
+
+    def forward(self, x, lens):
+        """x [T][M][Kin] bf16 time-major; lens [M] int32.  Returns S [M, 2LH] f32."""
+        tw, H, L, T, M = self.tw, self.H, self.L, self.T, self.M
+        self.x_in, self.lens = x, lens
+        inp = x
+        for l in range(L):
+            kn, bn = self.names(l)
+            ops.lstm_layer_fwd(inp, tw.shadow_fwd[kn], tw.store.p(bn), lens, T, M, self.kin[l], H,
+                               self.hbuf[l], self.S[:, (2 * l) * H:], self.S[:, (2 * l + 1) * H:], 2 * L * H,
+                               self.gates[l] if self.training else None, self.cc[l] if self.training else None,
+                               hoist=self.hoist[l], zx_ws=self.zx)
+            inp = self.hbuf[l][1:]
+        return self.S
+
+    def backward(self, dS, need_dx):
+        """dS [M, 2LH] f32.  Accumulates nothing: writes grads of this stack's
+        kernels/biases into the tower's grad buffer; returns dX [T*M, Kin] f32
+        (gradient wrt the stack input) if need_dx."""
+        tw, H, L, T, M = self.tw, self.H, self.L, self.T, self.M
+        dh_above = None
+        dx_out = None
+        for l in range(L - 1, -1, -1):
+            kn, bn = self.names(l)
+            w = tw.shadow_bwd[kn]                                   # [kin+H][4H] bf16
+            kin = self.kin[l]
+            ops.lstm_layer_bwd(w, self.lens, T, M, kin, H, self.gates[l], self.cc[l],
+                               dS[:, (2 * l) * H:], dS[:, (2 * l + 1) * H:], 2 * L * H,
+                               dh_above, self.dc_ws, self.dz)
+            dz2 = self.dz.view(T * M, 4 * H)
+            # gradient wrt the layer input, all T at once (hoisted): dX = dz . Wx^T
+            if l > 0:
+                ops.gemm_nt(dz2, w, T * M, kin, 4 * H, self.dx[l])
+                dh_above = self.dx[l]
+            elif need_dx:
+                if self.dx[0] is None:
+                    self.dx[0] = torch.empty((T * M, kin), dtype=F32, device=tw.device)
+                ops.gemm_nt(dz2, w, T * M, kin, 4 * H, self.dx[0])
+                dx_out = self.dx[0]
+            # dW^T [4H][kin+H] = dz^T . [x_in | h_prev]; db = rowsum(dz^T)
+            KP = self.KP
+            ops.transpose_to_bf16(dz2, T * M, 4 * H, self.dzT, KP)
+            layer_in = self.x_in if l == 0 else self.hbuf[l - 1][1:]
+            inT = self.inT[:kin]
+            ops.transpose_to_bf16(layer_in.reshape(T * M, kin), T * M, kin, inT, KP)
+            ops.transpose_to_bf16(self.hbuf[l][:T].reshape(T * M, H), T * M, H, self.hT, KP)
+            gW = tw.store.g(kn)                                     # [4H][kin+H] f32
+            ops.gemm_nt(self.dzT, inT, 4 * H, kin, KP, gW, ldc=kin + H)
+            ops.gemm_nt(self.dzT, self.hT, 4 * H, H, KP, gW[:, kin:], ldc=kin + H)
+            ops.rowsum_bf16(self.dzT, 4 * H, KP, tw.store.g(bn))
+        return dx_out
+
+
+class HLstmTower:
+    """HierarchicalLstmModel + MoeModel for one variable scope ('model' or
+    'model_student')."""
+
+    GATES, EXPERTS, EBIAS = "classifier/gates/weights", "classifier/experts/weights", "classifier/experts/biases"
+
+    def __init__(self, batch_size, num_frames, num_chunks, feature_size=1152, vocab_size=4716,
+                 lstm_cells=1024, lstm_layers=2, num_mixtures=2, device="cuda:0", training=True,
+                 scope="model", seed=0):
+        assert num_frames % num_chunks == 0, "frames must split evenly into chunks (tf.split)"
+        self.B, self.T, self.C, self.F, self.V = batch_size, num_frames, num_chunks, feature_size, vocab_size
+        self.H, self.L, self.Mx = lstm_cells, lstm_layers, num_mixtures
+        self.device, self.training, self.scope = torch.device(device), training, scope
+        if feature_size % 64 or lstm_cells % 64:
+            raise ValueError("feature_size (%d) and lstm_cells (%d) must be multiples of 64 for the MFMA GEMM tiles"
+                             % (feature_size, lstm_cells))
+        H, L, F, V, Mx = self.H, self.L, self.F, self.V, self.Mx
+        K = 2 * L * H
+        self.K = K
+        shapes = OrderedDict()
+        for sc, in0 in (("RNN_L1", F), ("RNN_L2", K)):
+            for l in range(L):
+                nin = in0 if l == 0 else H
+                base = "%s/rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/" % (sc, l)
+                shapes[base + "kernel"] = (4 * H, nin + H)          # stored transposed
+                shapes[base + "bias"] = (4 * H,)
+        shapes[self.GATES] = (V * (Mx + 1), K)                      # stored transposed
+        shapes[self.EXPERTS] = (V * Mx, K)
+        shapes[self.EBIAS] = (V * Mx,)
+        self.store = ParamStore(shapes, self.device)
+        self.names = list(shapes.keys())
+        self.l2_names = (self.GATES, self.EXPERTS)                  # slim.l2_regularizer(1e-8) targets
+        self.shadow_fwd, self.shadow_bwd = {}, {}
+        for k, shp in shapes.items():
+            if len(shp) == 2:
+                self.shadow_fwd[k] = torch.zeros(shp, dtype=BF16, device=self.device)
+                self.shadow_bwd[k] = torch.zeros((shp[1], ops.round_up(shp[0], 64)), dtype=BF16, device=self.device)
+        self.adam_t = 0
+        self.sums = torch.zeros((len(self.names), 2), dtype=F32, device=self.device)
+        self._init_params(seed)
+        self._alloc(batch_size)
+
+    # ---- parameters -------------------------------------------------------
+    def _init_params(self, seed):
+        """TF defaults at the reference call sites: glorot-uniform kernels /
+        fully_connected weights, zero biases."""
+        gen = torch.Generator(device="cpu")
+        gen.manual_seed(seed)
+        for k, shp in self.store.shapes.items():
+            if len(shp) == 2:
+                fan_out, fan_in = shp                               # stored transposed: [out][in]
+                lim = math.sqrt(6.0 / (fan_in + fan_out))
+                w = (torch.rand(shp, generator=gen, dtype=F32) * 2 - 1) * lim
+                self.store.p(k).copy_(w)
+        self.refresh_shadows()
+
+    def refresh_shadows(self, fwd=True):
+        for k in self.shadow_fwd:
+            p = self.store.p(k)
+            if fwd:
+                ops.cast_bf16(p, self.shadow_fwd[k])
+            sb = self.shadow_bwd[k]
+            ops.transpose_to_bf16(p, p.shape[0], p.shape[1], sb, sb.shape[1])
+
+    def state_dict(self):
+        """TF-named, TF-layout copies (kernel [in+H,4H]; weights [K, V*(M+1)])."""
+        out = OrderedDict()
+        for k in self.names:
+            p = self.store.p(k)
+            out["%s/%s" % (self.scope, k)] = (p.t().contiguous() if p.dim() == 2 else p.clone())
+        return out
+
+    def load_state_dict(self, sd, prefix=None):
+        prefix = self.scope if prefix is None else prefix
+        for k in self.names:
+            src = sd["%s/%s" % (prefix, k)].to(self.device, F32)
+            p = self.store.p(k)
+            p.copy_(src.t() if p.dim() == 2 else src)
+        self.refresh_shadows()
+
+    # ---- workspaces ---------------------------------------------------------
+    def _alloc(self, B):
+        dev, H, L, K, V, Mx = self.device, self.H, self.L, self.K, self.V, self.Mx
+        self.B = B
+        Lc = self.T // self.C
+        self.l1 = LstmStack(self, "RNN_L1", Lc, self.C * B, self.F, self.training)
+        self.l2 = LstmStack(self, "RNN_L2", self.C, B, K, self.training)
+        self.S1_bf = torch.empty((self.C * B, K), dtype=BF16, device=dev)
+        self.x_bf = torch.empty((B, K), dtype=BF16, device=dev)
+        self.gate_logits = torch.empty((B, V * (Mx + 1)), dtype=F32, device=dev)
+        self.expert_logits = torch.empty((B, V * Mx), dtype=F32, device=dev)
+        self.pred = torch.empty((B, V), dtype=F32, device=dev)
+        self.rowsum = torch.empty((B,), dtype=F32, device=dev)
+        if self.training:
+            self.Bp = ops.round_up(B, 64)
+            self.dgl = torch.zeros((B, ops.round_up(V * (Mx + 1), 64)), dtype=BF16, device=dev)   # pad cols stay 0
+            self.del_ = torch.zeros((B, ops.round_up(V * Mx, 64)), dtype=BF16, device=dev)
+            self.dglT = torch.empty((V * (Mx + 1), self.Bp), dtype=BF16, device=dev)
+            self.delT = torch.empty((V * Mx, self.Bp), dtype=BF16, device=dev)
+            self.xT = torch.empty((K, self.Bp), dtype=BF16, device=dev)
+            self.dS2 = torch.empty((B, K), dtype=F32, device=dev)
+
+    # ---- forward ------------------------------------------------------------
+    def forward(self, x_view, len_l1, len_l2):
+        """x_view [Lc][C*B][F] bf16 (ops.l2norm_chunk); lengths from ops.frame_counts.
+        Returns (state [B, 2LH] f32, predictions [B, V] f32)."""
+        B = x_view.shape[1] // self.C
+        if B != self.B:
+            self._alloc(B)
+        S1 = self.l1.forward(x_view, len_l1)
+        ops.cast_bf16(S1, self.S1_bf)                                  # = L2 input [C][B][2LH]
+        S2 = self.l2.forward(self.S1_bf.view(self.C, B, self.K), len_l2)
+        self.moe_forward(S2)
+        return S2, self.pred
+
+    def moe_forward(self, state):
+        B, V, Mx, K = self.B, self.V, self.Mx, self.K
+        ops.cast_bf16(state, self.x_bf)
+        ops.gemm_nt(self.x_bf, self.shadow_fwd[self.GATES], B, V * (Mx + 1), K, self.gate_logits)
+        ops.gemm_nt(self.x_bf, self.shadow_fwd[self.EXPERTS], B, V * Mx, K, self.expert_logits,
+                    bias=self.store.p(self.EBIAS))
+        ops.moe_tail_fwd(self.gate_logits, self.expert_logits, B, V, Mx, self.pred, self.rowsum)
+        return self.pred
+
+    # ---- backward -----------------------------------------------------------
+    def backward(self, dstate, dpred, on_moe_grads_ready=None):
+        """dstate [B,2LH] f32 or None (gradient on the returned state), dpred [B,V] f32.
+        Fills self.store.grad (every segment is overwritten)."""
+        assert self.training
+        B, V, Mx, K, H, L = self.B, self.V, self.Mx, self.K, self.H, self.L
+        ops.moe_tail_bwd(self.gate_logits, self.expert_logits, dpred, B, V, Mx, self.dgl, self.del_)
+        V3p, V2p = self.dgl.shape[1], self.del_.shape[1]
+        if dstate is None:
+            ops.gemm_nt(self.dgl, self.shadow_bwd[self.GATES], B, K, V3p, self.dS2)
+        else:
+            self.dS2.copy_(dstate)
+            ops.gemm_nt(self.dgl, self.shadow_bwd[self.GATES], B, K, V3p, self.dS2, accumulate=True)
+        ops.gemm_nt(self.del_, self.shadow_bwd[self.EXPERTS], B, K, V2p, self.dS2, accumulate=True)
+        # weight grads: dW^T [V*(M+1)][K] = dlogits^T . x
+        Bp = self.Bp
+        ops.transpose_to_bf16(self.dgl, B, V * (Mx + 1), self.dglT, Bp)
+        ops.transpose_to_bf16(self.del_, B, V * Mx, self.delT, Bp)
+        ops.transpose_to_bf16(self.x_bf, B, K, self.xT, Bp)
+        ops.gemm_nt(self.dglT, self.xT, V * (Mx + 1), K, Bp, self.store.g(self.GATES))
+        ops.gemm_nt(self.delT, self.xT, V * Mx, K, Bp, self.store.g(self.EXPERTS))
+        ops.rowsum_bf16(self.delT, V * Mx, Bp, self.store.g(self.EBIAS))
+        if on_moe_grads_ready is not None:
+            on_moe_grads_ready()
+        dS1 = self.l2.backward(self.dS2, need_dx=True)                 # [C*B][2LH] = d(L1 final state)
+        self.l1.backward(dS1, need_dx=False)
+
+    # ---- optimizer ------------------------------------------------------------
+    def apply_gradients(self, lr, clip_norm=1.0, l2_coeff=0.0, beta1=0.9, beta2=0.999, eps=1e-8):
+        """slim create_train_op semantics: per-tensor clip_by_norm, TF-Adam
+        (cs/train.py:329-334); the MoE l2 regulariser gradient
+        (regularization_penalty * 1e-8 * W) is folded into the gradient before the
+        norm.  Returns nothing; reg loss is available from reg_loss()."""
+        self.adam_t += 1
+        t = self.adam_t
+        lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+        self.sums.zero_()
+        for i, k in enumerate(self.names):
+            l2 = l2_coeff if k in self.l2_names else 0.0
+            ops.grad_sqnorm(self.store.g(k), self.store.p(k), l2, self.sums[i])
+        for i, k in enumerate(self.names):
+            l2 = l2_coeff if k in self.l2_names else 0.0
+            ops.clip_adam_step(self.store.p(k), self.store.g(k), self.store.view(self.store.m, k),
+                               self.store.view(self.store.v, k), l2, self.sums[i], clip_norm, lr_t, beta1, beta2, eps,
+                               p_bf16=self.shadow_fwd.get(k))
+        self.refresh_shadows(fwd=False)
+
+    def reg_loss(self):
+        """sum of slim.l2_regularizer(1e-8) terms, from the norms of the last apply_gradients()."""
+        idx = [self.names.index(k) for k in self.l2_names]
+        return 1e-8 * 0.5 * self.sums[idx, 1].sum()

@@ -181,8 +181,10 @@ def test_l2norm_chunk_and_counts(ops):
     nd = torch.from_numpy(n).to(DEV)
     u1, _ = ops.l2norm_chunk(qd, 20, num_frames=nd)
     # (dequantisation may contract to an FMA on the device: allow one bf16 ulp)
-    assert (u1.float() - o1.float()).abs().max().item() <= 2 ** -8 * o1.float().abs().max().item()
-    assert (u1 != o1).float().mean().item() < 0.01
+    d_max = (u1.float() - o1.float()).abs().max().item()
+    o_max = o1.float().abs().max().item()
+    frac = (u1 != o1).float().mean().item()
+    assert d_max <= 2 ** -7 * o_max and frac < 0.01, (d_max, o_max, frac)
     # integer part: bit-exact
     for every_n in (1, 2, 3, 4, 6, 10, 30):
         nn = torch.arange(0, 301, dtype=torch.int32, device=DEV)
