@@ -367,7 +367,9 @@ __global__ __launch_bounds__(256) void kl_loss_kernel(const float* __restrict__ 
   for (int c = threadIdx.x; c < V; c += 256) {
     const long i = (long)b * V + c;
     const float P = pt[i] * it, q = ps[i];
-    s += P * (__logf(P) - __logf(q * is));
+    // 0*log(0) := 0 (its limit).  TF evaluates 0*(-inf) = NaN here and slim's
+    // check_numerics then aborts the reference run; see DESIGN.md "deviations".
+    if (P > 0.f) s += P * (__logf(P) - __logf(q * is));
     if (dps) {
       const float g = (-P / q + is) * gs;
       dps[i] = acc ? dps[i] + g : g;

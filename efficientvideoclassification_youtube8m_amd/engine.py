@@ -114,6 +114,32 @@ class LstmStack:
             inp = self.hbuf[l][1:]
         return self.S
 
+    def profile_fwd_layers(self, reps=3):
+        """Bench helper: time each layer's forward launch sequence with events on
+        the current stream.  Returns [(ms_per_call, step_launches, gemm_flops)] per
+        layer; flops are the algorithmic 2*M*4H*K of the per-step GEMMs (t=0 has
+        no recurrent half)."""
+        tw, H, T, M = self.tw, self.H, self.T, self.M
+        res = []
+        inp = self.x_in
+        for l in range(self.L):
+            kn, bn = self.names(l)
+            args = (inp, tw.shadow_fwd[kn], tw.store.p(bn), self.lens, T, M, self.kin[l], H, self.hbuf[l],
+                    self.S[:, (2 * l) * H:], self.S[:, (2 * l + 1) * H:], 2 * self.L * H,
+                    self.gates[l] if self.training else None, self.cc[l] if self.training else None)
+            ops.lstm_layer_fwd(*args, hoist=self.hoist[l], zx_ws=self.zx)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                ops.lstm_layer_fwd(*args, hoist=self.hoist[l], zx_ws=self.zx)
+            e1.record()
+            e1.synchronize()
+            kx = 0 if self.hoist[l] else self.kin[l]
+            flops = 2.0 * M * 4 * H * (kx * T + H * (T - 1))
+            res.append((e0.elapsed_time(e1) / reps, T, flops))
+            inp = self.hbuf[l][1:]
+        return res
+
     def backward(self, dS, need_dx):
         """dS [M, 2LH] f32.  Accumulates nothing: writes grads of this stack's
         kernels/biases into the tower's grad buffer; returns dX [T*M, Kin] f32

@@ -413,12 +413,21 @@ def exponential_decay(lr0, global_step, batch_size, decay_examples, rate):
 
 def adam_step(p, g, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-8):
     """tf.train.AdamOptimizer update (epsilon outside the bias correction).
-    t is the 1-based step count of this optimizer."""
-    m = beta1 * m + (1 - beta1) * g
-    v = beta2 * v + (1 - beta2) * g * g
+    t is the 1-based step count of this optimizer.  m and v are updated in
+    place (they are this optimizer's slots); returns (new p, m, v)."""
+    one = p.dtype.type(1.0)
+    m *= p.dtype.type(beta1)
+    m += (one - p.dtype.type(beta1)) * g
+    v *= p.dtype.type(beta2)
+    gg = g * g
+    gg *= one - p.dtype.type(beta2)
+    v += gg
     lr_t = lr * math.sqrt(1 - beta2 ** t) / (1 - beta1 ** t)
-    p = p - lr_t * m / (np.sqrt(v) + eps)
-    return p, m, v
+    den = np.sqrt(v, out=gg)
+    den += p.dtype.type(eps)
+    np.divide(m, den, out=den)
+    den *= p.dtype.type(lr_t)
+    return p - den, m, v
 
 
 # --------------------------------------------------------------------------
