@@ -31,13 +31,19 @@ SIGNATURES = {
     "evc_rep_loss": [vp, vp, i32, i32, f32, vp, vp, i32, vp],
     "evc_grad_sqnorm": [vp, vp, f32, i64, vp, vp],
     "evc_clip_adam_step": [vp, vp, vp, vp, i64, f32, vp, f32, f32, f32, f32, f32, vp, vp],
-    "evc_meanpool_fwd": [vp, vp, i32, i32, i32, vp, vp, vp],
+    "evc_meanpool_fwd": [vp, vp, i32, i32, i32, i32, vp, vp, vp],
     "evc_sigmoid_fwd": [vp, i64, vp],
     "evc_sigmoid_bwd": [vp, vp, i64, vp, vp],
-    "evc_sample_frames_gather": [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp],
+    "evc_sample_frames_gather": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp],
     "evc_bn_stats": [vp, i32, i32, vp, vp, vp, vp],
     "evc_bn_apply": [vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp],
-    "evc_bn_relu6_bwd": [vp, vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp],
+    "evc_bn_relu6_bwd": [vp, vp, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp],
+    "evc_bn_stats_partial": [vp, i32, i32, vp, vp],
+    "evc_bn_stats_finalize": [vp, i32, i32, vp, vp, vp],
+    "evc_ema_update": [vp, vp, f32, i32, vp],
+    "evc_bn_bwd_partial": [vp, vp, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp],
+    "evc_bn_bwd_finalize": [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp],
+    "evc_bn_relu6_framepool_fwd": [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
     "evc_framepool_max_fwd": [vp, i32, i32, i32, vp, vp, vp, vp],
     "evc_framepool_max_bwd": [vp, vp, i32, i32, i32, vp, vp],
     "evc_fill_f32": [vp, i64, f32, vp],

@@ -482,23 +482,52 @@ extern "C" int evc_clip_adam_step(float* p, const float* g, float* m, float* v, 
 // ---------------------------------------------------------------------------
 // a11: mean-pool over all padded frames / true n; sigmoid
 // ---------------------------------------------------------------------------
+// one wave per frame, TS frame-slices per video; per-lane register accumulators, LDS
+// reduce across the 4 waves, one atomicAdd per (block, feature).
 __global__ __launch_bounds__(256) void meanpool_kernel(const float* __restrict__ x, const int* __restrict__ nfr, int T, int F,
-                                                       float* __restrict__ avg, bf16_t* __restrict__ avgb) {
-  const int b = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
-  if (f >= F) return;
-  const float* xp = x + (long)b * T * F + f;
-  float s = 0.f;
-  for (int t = 0; t < T; ++t) s += xp[(long)t * F];
-  s /= (float)nfr[b];
-  if (avg) avg[(long)b * F + f] = s;
-  if (avgb) avgb[(long)b * F + f] = f32_to_bf16(s);
+                                                       int normalize, float* __restrict__ avg) {
+  __shared__ float red[4][1280];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.y, nv = F >> 2;
+  float4 acc[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = blockIdx.x * 4 + w; t < T; t += gridDim.x * 4) {
+    const float4* row = (const float4*)(x + ((long)b * T + t) * F);
+    float4 v[5];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int j = lane + i * 64;
+      v[i] = (j < nv) ? row[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+    }
+    float inv = 1.f;
+    if (normalize) inv = rsqrtf(fmaxf(wave_sum(ss), 1e-12f));
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      acc[i].x += v[i].x * inv; acc[i].y += v[i].y * inv; acc[i].z += v[i].z * inv; acc[i].w += v[i].w * inv;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int j = lane + i * 64;
+    if (j < nv) ((float4*)red[w])[j] = acc[i];
+  }
+  __syncthreads();
+  const float invn = 1.f / (float)nfr[b];
+  for (int f = threadIdx.x; f < F; f += 256)
+    atomicAdd(&avg[(long)b * F + f], (red[0][f] + red[1][f] + red[2][f] + red[3][f]) * invn);
 }
-extern "C" int evc_meanpool_fwd(const float* x, const int32_t* num_frames, int B, int T, int F,
+extern "C" int evc_meanpool_fwd(const float* x, const int32_t* num_frames, int B, int T, int F, int normalize,
                                 float* avg_f32, evc_bf16* avg_bf16, void* stream) {
-  EVC_REQUIRE(B > 0 && T > 0 && F > 0, EVC_ERR_BAD_SHAPE, "evc_meanpool_fwd: bad shape");
-  hipLaunchKernelGGL(meanpool_kernel, dim3((F + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, num_frames, T, F, avg_f32,
-                     avg_bf16);
+  EVC_REQUIRE(B > 0 && T > 0 && F > 0 && F % 4 == 0 && F <= 1280 && avg_f32, EVC_ERR_BAD_SHAPE, "evc_meanpool_fwd: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  EVC_CHECK_HIP(hipMemsetAsync(avg_f32, 0, sizeof(float) * B * F, st));
+  int ts = (T + 31) / 32;
+  hipLaunchKernelGGL(meanpool_kernel, dim3(ts, B), dim3(256), 0, st, x, num_frames, T, F, normalize, avg_f32);
   EVC_LAUNCH_CHECK();
+  if (avg_bf16) return evc_cast_f32_to_bf16(avg_f32, F, B, F, avg_bf16, F, stream);
   return EVC_OK;
 }
 
@@ -528,7 +557,7 @@ extern "C" int evc_sigmoid_bwd(const float* p, const float* dp, int64_t n, evc_b
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sample_gather_kernel(const float* __restrict__ x, const float* __restrict__ u,
                                                             const int* __restrict__ nfr, int B, int T, int F, int S,
-                                                            float* __restrict__ out, int* __restrict__ idx_out) {
+                                                            int normalize, float* __restrict__ out, int* __restrict__ idx_out) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= (long)B * S) return;
@@ -539,14 +568,20 @@ __global__ __launch_bounds__(256) void sample_gather_kernel(const float* __restr
   idx = idx < 0 ? 0 : (idx >= T ? T - 1 : idx);
   const float4* src = (const float4*)(x + ((long)b * T + idx) * F);
   float4* dst = (float4*)(out + row * F);
-  for (int j = lane; j < (F >> 2); j += 64) dst[j] = src[j];
+  float inv = 1.f;
+  if (normalize) {   // tf.nn.l2_normalize of the gathered frame (cs/train.py:256 applied before create_model)
+    float ss = 0.f;
+    for (int j = lane; j < (F >> 2); j += 64) { const float4 v = src[j]; ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+    inv = rsqrtf(fmaxf(wave_sum(ss), 1e-12f));
+  }
+  for (int j = lane; j < (F >> 2); j += 64) { float4 v = src[j]; v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv; dst[j] = v; }
 }
 extern "C" int evc_sample_frames_gather(const float* x, const float* u, const int32_t* num_frames, int B, int T, int F,
-                                        int S, float* out, int32_t* idx_out, void* stream) {
+                                        int S, int normalize, float* out, int32_t* idx_out, void* stream) {
   EVC_REQUIRE(B > 0 && T > 0 && F > 0 && S > 0 && F % 4 == 0, EVC_ERR_BAD_SHAPE, "evc_sample_frames_gather: bad shape");
   const long rows = (long)B * S;
   hipLaunchKernelGGL(sample_gather_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, u, num_frames,
-                     B, T, F, S, out, idx_out);
+                     B, T, F, S, normalize, out, idx_out);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }
@@ -579,13 +614,33 @@ __global__ void bn_stats_final_kernel(const double* __restrict__ ws, int R, int 
   mean[c] = (float)mu;
   var[c] = (float)(vv > 0 ? vv : 0);
 }
-extern "C" int evc_bn_stats(const float* x, int R, int C, double* ws, float* mean, float* var, void* stream) {
-  EVC_REQUIRE(R > 0 && C > 0 && ws, EVC_ERR_BAD_SHAPE, "evc_bn_stats: bad args");
+extern "C" int evc_bn_stats_partial(const float* x, int R, int C, double* ws, void* stream) {
+  EVC_REQUIRE(R > 0 && C > 0 && ws, EVC_ERR_BAD_SHAPE, "evc_bn_stats_partial: bad args");
   hipStream_t st = (hipStream_t)stream;
   EVC_CHECK_HIP(hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st));
   int rs = R / 256; rs = rs < 1 ? 1 : (rs > 64 ? 64 : rs);
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3((C + 63) / 64, rs), dim3(256), 0, st, x, R, C, ws);
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, ws, R, C, mean, var);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+extern "C" int evc_bn_stats_finalize(const double* ws, int R_total, int C, float* mean, float* var, void* stream) {
+  EVC_REQUIRE(R_total > 0 && C > 0 && ws, EVC_ERR_BAD_SHAPE, "evc_bn_stats_finalize: bad args");
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, R_total, C, mean, var);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+extern "C" int evc_bn_stats(const float* x, int R, int C, double* ws, float* mean, float* var, void* stream) {
+  int rc = evc_bn_stats_partial(x, R, C, ws, stream);
+  if (rc) return rc;
+  return evc_bn_stats_finalize(ws, R, C, mean, var, stream);
+}
+__global__ void ema_kernel(float* __restrict__ moving, const float* __restrict__ batch, float decay, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) moving[i] -= (1.f - decay) * (moving[i] - batch[i]);   // slim.batch_norm UPDATE_OPS (assign_moving_average)
+}
+extern "C" int evc_ema_update(float* moving, const float* batch_value, float decay, int n, void* stream) {
+  EVC_REQUIRE(n > 0, EVC_ERR_BAD_SHAPE, "evc_ema_update: n");
+  hipLaunchKernelGGL(ema_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, moving, batch_value, decay, n);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }
@@ -612,10 +667,16 @@ extern "C" int evc_bn_apply(const float* x, int R, int C, const float* mean, con
 }
 
 // backward of y = relu6?(gamma*xh+beta): pass 1 column sums of dyh=dy*mask and dyh*xh; pass 2 dx
+// dy of row r, column c: either dy[r][c], or (max-pool routing) dpooled[r/S][c] where argmax[r/S][c] == r%S.
+__device__ __forceinline__ float routed_dy(const float* __restrict__ dy, const int* __restrict__ am, int S, long r, int c, int C) {
+  if (!am) return dy[r * C + c];
+  const long b = r / S;
+  return (am[b * C + c] == (int)(r % S)) ? dy[b * C + c] : 0.f;
+}
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy, int R, int C,
                                                              const float* __restrict__ mean, const float* __restrict__ var,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             int relu6, double* __restrict__ ws) {
+                                                             int relu6, const int* __restrict__ am, int S, double* __restrict__ ws) {
   __shared__ double sh[2][4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
@@ -625,7 +686,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     for (int r = blockIdx.y * 4 + ty; r < R; r += gridDim.y * 4) {
       const long i = (long)r * C + c;
       const float xh = (x[i] - mu) * inv;
-      float d = dy[i];
+      float d = routed_dy(dy, am, S, r, c, C);
       if (relu6) { const float y = xh * ga + be; if (!(y > 0.f && y < 6.f)) d = 0.f; }
       s += d; q += (double)d * xh;
     }
@@ -639,14 +700,15 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 }
 __global__ void bn_bwd_final_kernel(const float* __restrict__ x, const float* __restrict__ dy, long n, int R, int C,
                                     const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ gamma,
-                                    const float* __restrict__ beta, int relu6, const double* __restrict__ ws,
+                                    const float* __restrict__ beta, int relu6, const int* __restrict__ am, int S,
+                                    const double* __restrict__ ws,
                                     float* __restrict__ dxf, bf16_t* __restrict__ dxb, float* __restrict__ dgamma,
                                     float* __restrict__ dbeta) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
     const float inv = rsqrtf(var[c] + 1e-3f), ga = gamma[c];
     const float xh = (x[i] - mean[c]) * inv;
-    float d = dy[i];
+    float d = routed_dy(dy, am, S, i / C, c, C);
     if (relu6) { const float y = xh * ga + beta[c]; if (!(y > 0.f && y < 6.f)) d = 0.f; }
     const float sd = (float)ws[c], sdx = (float)ws[C + c];
     // dx = gamma*inv/R * (R*d - sum(d) - xh*sum(d*xh))
@@ -656,17 +718,63 @@ __global__ void bn_bwd_final_kernel(const float* __restrict__ x, const float* __
     if (i < C) { if (dgamma) dgamma[i] = (float)ws[C + i]; if (dbeta) dbeta[i] = (float)ws[i]; }
   }
 }
-extern "C" int evc_bn_relu6_bwd(const float* x, const float* dy, int R, int C, const float* mean, const float* var,
-                                const float* gamma, const float* beta, int relu6, double* ws,
-                                float* dx_f32, evc_bf16* dx_bf16, float* dgamma, float* dbeta, void* stream) {
-  EVC_REQUIRE(R > 0 && C > 0 && ws, EVC_ERR_BAD_SHAPE, "evc_bn_relu6_bwd: bad args");
+extern "C" int evc_bn_bwd_partial(const float* x, const float* dy, int R, int C, const float* mean, const float* var,
+                                  const float* gamma, const float* beta, int relu6, const int32_t* argmax, int S,
+                                  double* ws, void* stream) {
+  EVC_REQUIRE(R > 0 && C > 0 && ws && (!argmax || (S > 0 && R % S == 0)), EVC_ERR_BAD_SHAPE, "evc_bn_bwd_partial: bad args");
   hipStream_t st = (hipStream_t)stream;
   EVC_CHECK_HIP(hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st));
   int rs = R / 256; rs = rs < 1 ? 1 : (rs > 64 ? 64 : rs);
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3((C + 63) / 64, rs), dim3(256), 0, st, x, dy, R, C, mean, var, gamma, beta, relu6, ws);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3((C + 63) / 64, rs), dim3(256), 0, st, x, dy, R, C, mean, var, gamma, beta, relu6,
+                     argmax, S, ws);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+extern "C" int evc_bn_bwd_finalize(const float* x, const float* dy, int R, int R_total, int C, const float* mean,
+                                   const float* var, const float* gamma, const float* beta, int relu6,
+                                   const int32_t* argmax, int S, const double* ws, float* dx_f32, evc_bf16* dx_bf16,
+                                   float* dgamma, float* dbeta, void* stream) {
+  EVC_REQUIRE(R > 0 && C > 0 && ws && R_total >= R, EVC_ERR_BAD_SHAPE, "evc_bn_bwd_finalize: bad args");
   const long n = (long)R * C;
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, dy, n, R, C, mean, var, gamma, beta, relu6, ws,
-                     dx_f32, dx_bf16, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, dy, n, R_total, C, mean, var,
+                     gamma, beta, relu6, argmax, S, ws, dx_f32, dx_bf16, dgamma, dbeta);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+extern "C" int evc_bn_relu6_bwd(const float* x, const float* dy, int R, int C, const float* mean, const float* var,
+                                const float* gamma, const float* beta, int relu6, const int32_t* argmax, int S, double* ws,
+                                float* dx_f32, evc_bf16* dx_bf16, float* dgamma, float* dbeta, void* stream) {
+  int rc = evc_bn_bwd_partial(x, dy, R, C, mean, var, gamma, beta, relu6, argmax, S, ws, stream);
+  if (rc) return rc;
+  return evc_bn_bwd_finalize(x, dy, R, R, C, mean, var, gamma, beta, relu6, argmax, S, ws, dx_f32, dx_bf16, dgamma, dbeta, stream);
+}
+
+// fused cluster_bn + relu6 + FramePooling('max'): act [B][S][C] f32 -> pooled [B][C]
+__global__ __launch_bounds__(256) void bn_relu6_pool_kernel(const float* __restrict__ act, int S, int C,
+                                                            const float* __restrict__ mean, const float* __restrict__ var,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ pf, bf16_t* __restrict__ pb, int* __restrict__ am) {
+  const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float mu = mean[c], sc = rsqrtf(var[c] + 1e-3f) * gamma[c], be = beta[c];
+  const float* ap = act + (long)b * S * C + c;
+  float best = -1.f;
+  int bi = 0;
+  for (int s = 0; s < S; ++s) {
+    const float y = fminf(fmaxf((ap[(long)s * C] - mu) * sc + be, 0.f), 6.f);
+    if (y > best) { best = y; bi = s; }
+  }
+  const long o = (long)b * C + c;
+  pf[o] = best;
+  if (pb) pb[o] = f32_to_bf16(best);
+  am[o] = bi;
+}
+extern "C" int evc_bn_relu6_framepool_fwd(const float* act, int B, int S, int C, const float* mean, const float* var,
+                                          const float* gamma, const float* beta, float* pooled_f32, evc_bf16* pooled_bf16,
+                                          int32_t* argmax, void* stream) {
+  EVC_REQUIRE(B > 0 && S > 0 && C > 0 && pooled_f32 && argmax, EVC_ERR_BAD_SHAPE, "evc_bn_relu6_framepool_fwd: bad args");
+  hipLaunchKernelGGL(bn_relu6_pool_kernel, dim3((C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, act, S, C, mean, var, gamma,
+                     beta, pooled_f32, pooled_bf16, argmax);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }

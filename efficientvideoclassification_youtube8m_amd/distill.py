@@ -183,3 +183,46 @@ class DistillGraph:
             rep = {"label_loss": t[0] / self.world, "student_loss_state": t[1] / self.world, "pred_loss": t[2],
                    "student_label_loss": t[3] / self.world}
         return rep
+
+
+class SingleTowerGraph:
+    """Teacher-only training step for dict-returning models (DbofModel,
+    FrameLevelLogisticModel).  The reference's train.py cannot run these
+    (it unpacks the H-LSTM tuple, cs/train.py:282 - SURVEY.md Appendix D-8);
+    this follows the upstream starter-code semantics it was forked from:
+    final_loss = regularization_penalty*reg + CE, one train op, global_step += 1."""
+
+    def __init__(self, tower, base_learning_rate=0.001, learning_rate_decay=1.0, learning_rate_decay_examples=4000000,
+                 regularization_penalty=2.0, clip_gradient_norm=1.0, process_group=None):
+        self.tower, self.device = tower, tower.device
+        self.lr0, self.lr_decay, self.lr_decay_examples = base_learning_rate, learning_rate_decay, learning_rate_decay_examples
+        self.reg_pen, self.clip, self.pg = regularization_penalty, clip_gradient_norm, process_group
+        self.world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.world = torch.distributed.get_world_size(process_group)
+        self.global_step = 0
+        self.losses = torch.zeros(4, dtype=F32, device=self.device)
+        self._dp = None
+
+    def step(self, x_raw, labels_u8, num_frames, uniform=None, apply=True):
+        from .towers import DbofTower
+        B, V = labels_u8.shape
+        if self._dp is None or self._dp.shape[0] != B:
+            self._dp = torch.empty((B, V), dtype=F32, device=self.device)
+        tw = self.tower
+        if isinstance(tw, DbofTower):
+            if uniform is None:
+                uniform = torch.rand((B, tw.S), dtype=F32, device=self.device)
+            pred = tw.forward(x_raw, num_frames, uniform)
+        else:
+            pred = tw.forward(x_raw, num_frames)
+        self.losses.zero_()
+        ops.ce_loss(pred, labels_u8, self.losses[0:1], self._dp, grad_scale=1.0 / (B * self.world))
+        tw.backward(self._dp)
+        if self.world > 1:
+            torch.distributed.all_reduce(tw.store.grad, group=self.pg)
+        if apply:
+            lr = exponential_decay(self.lr0, self.global_step, B * self.world, self.lr_decay_examples, self.lr_decay)
+            tw.apply_gradients(lr, self.clip, self.reg_pen * 1e-8)
+            self.global_step += 1
+        return {"predictions": pred, "loss": self.losses[0], "global_step": self.global_step}

@@ -178,11 +178,147 @@ class LstmStack:
         return dx_out
 
 
-class HLstmTower:
+class MoeHead:
+    """MoeModel (cs/video_level_models.py:394-448) on a [B, K] f32 input: two
+    bf16 MFMA GEMMs (gates without bias, experts with bias) + the fused
+    softmax/sigmoid/mix tail; backward gives d(input) and the weight grads."""
+
+    GATES, EXPERTS, EBIAS = "classifier/gates/weights", "classifier/experts/weights", "classifier/experts/biases"
+
+    def __init__(self, tower, K, V, Mx):
+        self.tw, self.K, self.V, self.Mx = tower, K, V, Mx
+
+    @staticmethod
+    def shapes(K, V, Mx):
+        sh = OrderedDict()
+        sh[MoeHead.GATES] = (V * (Mx + 1), K)           # stored transposed
+        sh[MoeHead.EXPERTS] = (V * Mx, K)
+        sh[MoeHead.EBIAS] = (V * Mx,)
+        return sh
+
+    def alloc(self, B, training):
+        dev, K, V, Mx = self.tw.device, self.K, self.V, self.Mx
+        self.B = B
+        self.x_bf = torch.empty((B, K), dtype=BF16, device=dev)
+        self.gate_logits = torch.empty((B, V * (Mx + 1)), dtype=F32, device=dev)
+        self.expert_logits = torch.empty((B, V * Mx), dtype=F32, device=dev)
+        self.pred = torch.empty((B, V), dtype=F32, device=dev)
+        self.rowsum = torch.empty((B,), dtype=F32, device=dev)
+        if training:
+            self.Bp = ops.round_up(B, 64)
+            self.dgl = torch.zeros((B, ops.round_up(V * (Mx + 1), 64)), dtype=BF16, device=dev)   # pad cols stay 0
+            self.del_ = torch.zeros((B, ops.round_up(V * Mx, 64)), dtype=BF16, device=dev)
+            self.dglT = torch.empty((V * (Mx + 1), self.Bp), dtype=BF16, device=dev)
+            self.delT = torch.empty((V * Mx, self.Bp), dtype=BF16, device=dev)
+            self.xT = torch.empty((K, self.Bp), dtype=BF16, device=dev)
+            self.dx = torch.empty((B, K), dtype=F32, device=dev)
+
+    def forward(self, x):
+        tw, B, V, Mx, K = self.tw, self.B, self.V, self.Mx, self.K
+        ops.cast_bf16(x, self.x_bf)
+        ops.gemm_nt(self.x_bf, tw.shadow_fwd[self.GATES], B, V * (Mx + 1), K, self.gate_logits)
+        ops.gemm_nt(self.x_bf, tw.shadow_fwd[self.EXPERTS], B, V * Mx, K, self.expert_logits,
+                    bias=tw.store.p(self.EBIAS))
+        ops.moe_tail_fwd(self.gate_logits, self.expert_logits, B, V, Mx, self.pred, self.rowsum)
+        return self.pred
+
+    def backward(self, dpred, dx_init=None):
+        """Returns dx [B,K] f32 (= dx_init + MoE contribution) and writes the three weight grads."""
+        tw, B, V, Mx, K = self.tw, self.B, self.V, self.Mx, self.K
+        ops.moe_tail_bwd(self.gate_logits, self.expert_logits, dpred, B, V, Mx, self.dgl, self.del_)
+        V3p, V2p = self.dgl.shape[1], self.del_.shape[1]
+        if dx_init is None:
+            ops.gemm_nt(self.dgl, tw.shadow_bwd[self.GATES], B, K, V3p, self.dx)
+        else:
+            self.dx.copy_(dx_init)
+            ops.gemm_nt(self.dgl, tw.shadow_bwd[self.GATES], B, K, V3p, self.dx, accumulate=True)
+        ops.gemm_nt(self.del_, tw.shadow_bwd[self.EXPERTS], B, K, V2p, self.dx, accumulate=True)
+        Bp = self.Bp
+        ops.transpose_to_bf16(self.dgl, B, V * (Mx + 1), self.dglT, Bp)
+        ops.transpose_to_bf16(self.del_, B, V * Mx, self.delT, Bp)
+        ops.transpose_to_bf16(self.x_bf, B, K, self.xT, Bp)
+        ops.gemm_nt(self.dglT, self.xT, V * (Mx + 1), K, Bp, tw.store.g(self.GATES))
+        ops.gemm_nt(self.delT, self.xT, V * Mx, K, Bp, tw.store.g(self.EXPERTS))
+        ops.rowsum_bf16(self.delT, V * Mx, Bp, tw.store.g(self.EBIAS))
+        return self.dx
+
+
+class TowerBase:
+    """Parameter store + bf16 shadows + per-tensor clip / TF-Adam shared by all model towers."""
+
+    l2_names = ()
+
+    def _setup_store(self, shapes, transposed_2d=True):
+        self.store = ParamStore(shapes, self.device)
+        self.names = list(shapes.keys())
+        self.shadow_fwd, self.shadow_bwd = {}, {}
+        for k, shp in shapes.items():
+            if len(shp) == 2:
+                self.shadow_fwd[k] = torch.zeros(shp, dtype=BF16, device=self.device)
+                self.shadow_bwd[k] = torch.zeros((shp[1], ops.round_up(shp[0], 64)), dtype=BF16, device=self.device)
+        self.adam_t = 0
+        self.sums = torch.zeros((len(self.names), 2), dtype=F32, device=self.device)
+
+    def refresh_shadows(self, fwd=True):
+        for k in self.shadow_fwd:
+            p = self.store.p(k)
+            if fwd:
+                ops.cast_bf16(p, self.shadow_fwd[k])
+            sb = self.shadow_bwd[k]
+            ops.transpose_to_bf16(p, p.shape[0], p.shape[1], sb, sb.shape[1])
+
+    def state_dict(self):
+        """TF-named, TF-layout copies (2-D weights are stored transposed internally)."""
+        out = OrderedDict()
+        for k in self.names:
+            p = self.store.p(k)
+            out["%s/%s" % (self.scope, k)] = (p.t().contiguous() if p.dim() == 2 else p.clone())
+        for k, v in getattr(self, "buffers", {}).items():
+            out["%s/%s" % (self.scope, k)] = v.clone()
+        return out
+
+    def load_state_dict(self, sd, prefix=None):
+        prefix = self.scope if prefix is None else prefix
+        for k in self.names:
+            src = sd["%s/%s" % (prefix, k)].to(self.device, F32)
+            p = self.store.p(k)
+            p.copy_(src.t() if p.dim() == 2 else src)
+        for k, v in getattr(self, "buffers", {}).items():
+            key = "%s/%s" % (prefix, k)
+            if key in sd:
+                v.copy_(sd[key].to(self.device, F32))
+        self.refresh_shadows()
+
+    def apply_gradients(self, lr, clip_norm=1.0, l2_coeff=0.0, beta1=0.9, beta2=0.999, eps=1e-8):
+        """slim create_train_op semantics: per-tensor clip_by_norm, TF-Adam
+        (cs/train.py:329-334); the l2 regulariser gradient
+        (regularization_penalty * 1e-8 * W) is folded into the gradient before the norm."""
+        self.adam_t += 1
+        t = self.adam_t
+        lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+        self.sums.zero_()
+        for i, k in enumerate(self.names):
+            l2 = l2_coeff if k in self.l2_names else 0.0
+            ops.grad_sqnorm(self.store.g(k), self.store.p(k), l2, self.sums[i])
+        for i, k in enumerate(self.names):
+            l2 = l2_coeff if k in self.l2_names else 0.0
+            ops.clip_adam_step(self.store.p(k), self.store.g(k), self.store.view(self.store.m, k),
+                               self.store.view(self.store.v, k), l2, self.sums[i], clip_norm, lr_t, beta1, beta2, eps,
+                               p_bf16=self.shadow_fwd.get(k))
+        self.refresh_shadows(fwd=False)
+
+    def reg_loss(self):
+        """sum of slim.l2_regularizer(1e-8) terms, from the norms of the last apply_gradients()."""
+        idx = [self.names.index(k) for k in self.l2_names]
+        return 1e-8 * 0.5 * self.sums[idx, 1].sum()
+
+
+class HLstmTower(TowerBase):
     """HierarchicalLstmModel + MoeModel for one variable scope ('model' or
     'model_student')."""
 
-    GATES, EXPERTS, EBIAS = "classifier/gates/weights", "classifier/experts/weights", "classifier/experts/biases"
+    GATES, EXPERTS, EBIAS = MoeHead.GATES, MoeHead.EXPERTS, MoeHead.EBIAS
+    l2_names = (MoeHead.GATES, MoeHead.EXPERTS)                     # slim.l2_regularizer(1e-8) targets
 
     def __init__(self, batch_size, num_frames, num_chunks, feature_size=1152, vocab_size=4716,
                  lstm_cells=1024, lstm_layers=2, num_mixtures=2, device="cuda:0", training=True,
@@ -204,19 +340,9 @@ class HLstmTower:
                 base = "%s/rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/" % (sc, l)
                 shapes[base + "kernel"] = (4 * H, nin + H)          # stored transposed
                 shapes[base + "bias"] = (4 * H,)
-        shapes[self.GATES] = (V * (Mx + 1), K)                      # stored transposed
-        shapes[self.EXPERTS] = (V * Mx, K)
-        shapes[self.EBIAS] = (V * Mx,)
-        self.store = ParamStore(shapes, self.device)
-        self.names = list(shapes.keys())
-        self.l2_names = (self.GATES, self.EXPERTS)                  # slim.l2_regularizer(1e-8) targets
-        self.shadow_fwd, self.shadow_bwd = {}, {}
-        for k, shp in shapes.items():
-            if len(shp) == 2:
-                self.shadow_fwd[k] = torch.zeros(shp, dtype=BF16, device=self.device)
-                self.shadow_bwd[k] = torch.zeros((shp[1], ops.round_up(shp[0], 64)), dtype=BF16, device=self.device)
-        self.adam_t = 0
-        self.sums = torch.zeros((len(self.names), 2), dtype=F32, device=self.device)
+        shapes.update(MoeHead.shapes(K, V, Mx))
+        self._setup_store(shapes)
+        self.moe = MoeHead(self, K, V, Mx)
         self._init_params(seed)
         self._alloc(batch_size)
 
@@ -234,51 +360,28 @@ class HLstmTower:
                 self.store.p(k).copy_(w)
         self.refresh_shadows()
 
-    def refresh_shadows(self, fwd=True):
-        for k in self.shadow_fwd:
-            p = self.store.p(k)
-            if fwd:
-                ops.cast_bf16(p, self.shadow_fwd[k])
-            sb = self.shadow_bwd[k]
-            ops.transpose_to_bf16(p, p.shape[0], p.shape[1], sb, sb.shape[1])
-
-    def state_dict(self):
-        """TF-named, TF-layout copies (kernel [in+H,4H]; weights [K, V*(M+1)])."""
-        out = OrderedDict()
-        for k in self.names:
-            p = self.store.p(k)
-            out["%s/%s" % (self.scope, k)] = (p.t().contiguous() if p.dim() == 2 else p.clone())
-        return out
-
-    def load_state_dict(self, sd, prefix=None):
-        prefix = self.scope if prefix is None else prefix
-        for k in self.names:
-            src = sd["%s/%s" % (prefix, k)].to(self.device, F32)
-            p = self.store.p(k)
-            p.copy_(src.t() if p.dim() == 2 else src)
-        self.refresh_shadows()
-
     # ---- workspaces ---------------------------------------------------------
     def _alloc(self, B):
-        dev, H, L, K, V, Mx = self.device, self.H, self.L, self.K, self.V, self.Mx
+        dev, K = self.device, self.K
         self.B = B
         Lc = self.T // self.C
         self.l1 = LstmStack(self, "RNN_L1", Lc, self.C * B, self.F, self.training)
         self.l2 = LstmStack(self, "RNN_L2", self.C, B, K, self.training)
         self.S1_bf = torch.empty((self.C * B, K), dtype=BF16, device=dev)
-        self.x_bf = torch.empty((B, K), dtype=BF16, device=dev)
-        self.gate_logits = torch.empty((B, V * (Mx + 1)), dtype=F32, device=dev)
-        self.expert_logits = torch.empty((B, V * Mx), dtype=F32, device=dev)
-        self.pred = torch.empty((B, V), dtype=F32, device=dev)
-        self.rowsum = torch.empty((B,), dtype=F32, device=dev)
-        if self.training:
-            self.Bp = ops.round_up(B, 64)
-            self.dgl = torch.zeros((B, ops.round_up(V * (Mx + 1), 64)), dtype=BF16, device=dev)   # pad cols stay 0
-            self.del_ = torch.zeros((B, ops.round_up(V * Mx, 64)), dtype=BF16, device=dev)
-            self.dglT = torch.empty((V * (Mx + 1), self.Bp), dtype=BF16, device=dev)
-            self.delT = torch.empty((V * Mx, self.Bp), dtype=BF16, device=dev)
-            self.xT = torch.empty((K, self.Bp), dtype=BF16, device=dev)
-            self.dS2 = torch.empty((B, K), dtype=F32, device=dev)
+        self.moe.alloc(B, self.training)
+
+    # convenience views used by the distillation graph / tests
+    @property
+    def pred(self):
+        return self.moe.pred
+
+    @property
+    def rowsum(self):
+        return self.moe.rowsum
+
+    @property
+    def gate_logits(self):
+        return self.moe.gate_logits
 
     # ---- forward ------------------------------------------------------------
     def forward(self, x_view, len_l1, len_l2):
@@ -290,66 +393,15 @@ class HLstmTower:
         S1 = self.l1.forward(x_view, len_l1)
         ops.cast_bf16(S1, self.S1_bf)                                  # = L2 input [C][B][2LH]
         S2 = self.l2.forward(self.S1_bf.view(self.C, B, self.K), len_l2)
-        self.moe_forward(S2)
-        return S2, self.pred
-
-    def moe_forward(self, state):
-        B, V, Mx, K = self.B, self.V, self.Mx, self.K
-        ops.cast_bf16(state, self.x_bf)
-        ops.gemm_nt(self.x_bf, self.shadow_fwd[self.GATES], B, V * (Mx + 1), K, self.gate_logits)
-        ops.gemm_nt(self.x_bf, self.shadow_fwd[self.EXPERTS], B, V * Mx, K, self.expert_logits,
-                    bias=self.store.p(self.EBIAS))
-        ops.moe_tail_fwd(self.gate_logits, self.expert_logits, B, V, Mx, self.pred, self.rowsum)
-        return self.pred
+        return S2, self.moe.forward(S2)
 
     # ---- backward -----------------------------------------------------------
     def backward(self, dstate, dpred, on_moe_grads_ready=None):
         """dstate [B,2LH] f32 or None (gradient on the returned state), dpred [B,V] f32.
         Fills self.store.grad (every segment is overwritten)."""
         assert self.training
-        B, V, Mx, K, H, L = self.B, self.V, self.Mx, self.K, self.H, self.L
-        ops.moe_tail_bwd(self.gate_logits, self.expert_logits, dpred, B, V, Mx, self.dgl, self.del_)
-        V3p, V2p = self.dgl.shape[1], self.del_.shape[1]
-        if dstate is None:
-            ops.gemm_nt(self.dgl, self.shadow_bwd[self.GATES], B, K, V3p, self.dS2)
-        else:
-            self.dS2.copy_(dstate)
-            ops.gemm_nt(self.dgl, self.shadow_bwd[self.GATES], B, K, V3p, self.dS2, accumulate=True)
-        ops.gemm_nt(self.del_, self.shadow_bwd[self.EXPERTS], B, K, V2p, self.dS2, accumulate=True)
-        # weight grads: dW^T [V*(M+1)][K] = dlogits^T . x
-        Bp = self.Bp
-        ops.transpose_to_bf16(self.dgl, B, V * (Mx + 1), self.dglT, Bp)
-        ops.transpose_to_bf16(self.del_, B, V * Mx, self.delT, Bp)
-        ops.transpose_to_bf16(self.x_bf, B, K, self.xT, Bp)
-        ops.gemm_nt(self.dglT, self.xT, V * (Mx + 1), K, Bp, self.store.g(self.GATES))
-        ops.gemm_nt(self.delT, self.xT, V * Mx, K, Bp, self.store.g(self.EXPERTS))
-        ops.rowsum_bf16(self.delT, V * Mx, Bp, self.store.g(self.EBIAS))
+        dS2 = self.moe.backward(dpred, dstate)
         if on_moe_grads_ready is not None:
             on_moe_grads_ready()
-        dS1 = self.l2.backward(self.dS2, need_dx=True)                 # [C*B][2LH] = d(L1 final state)
+        dS1 = self.l2.backward(dS2, need_dx=True)                      # [C*B][2LH] = d(L1 final state)
         self.l1.backward(dS1, need_dx=False)
-
-    # ---- optimizer ------------------------------------------------------------
-    def apply_gradients(self, lr, clip_norm=1.0, l2_coeff=0.0, beta1=0.9, beta2=0.999, eps=1e-8):
-        """slim create_train_op semantics: per-tensor clip_by_norm, TF-Adam
-        (cs/train.py:329-334); the MoE l2 regulariser gradient
-        (regularization_penalty * 1e-8 * W) is folded into the gradient before the
-        norm.  Returns nothing; reg loss is available from reg_loss()."""
-        self.adam_t += 1
-        t = self.adam_t
-        lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
-        self.sums.zero_()
-        for i, k in enumerate(self.names):
-            l2 = l2_coeff if k in self.l2_names else 0.0
-            ops.grad_sqnorm(self.store.g(k), self.store.p(k), l2, self.sums[i])
-        for i, k in enumerate(self.names):
-            l2 = l2_coeff if k in self.l2_names else 0.0
-            ops.clip_adam_step(self.store.p(k), self.store.g(k), self.store.view(self.store.m, k),
-                               self.store.view(self.store.v, k), l2, self.sums[i], clip_norm, lr_t, beta1, beta2, eps,
-                               p_bf16=self.shadow_fwd.get(k))
-        self.refresh_shadows(fwd=False)
-
-    def reg_loss(self):
-        """sum of slim.l2_regularizer(1e-8) terms, from the norms of the last apply_gradients()."""
-        idx = [self.names.index(k) for k in self.l2_names]
-        return 1e-8 * 0.5 * self.sums[idx, 1].sum()

@@ -142,9 +142,9 @@ def clip_adam_step(p, g, m, v, l2_coeff, sums, clip_norm, lr_t, beta1=0.9, beta2
               _p(p_bf16), _stream())
 
 
-def meanpool(x, num_frames, avg_f32, avg_bf16):
+def meanpool(x, num_frames, avg_f32, avg_bf16=None, normalize=False):
     B, T, F = x.shape
-    _lib.call("evc_meanpool_fwd", _p(x), _p(num_frames), B, T, F, _p(avg_f32), _p(avg_bf16), _stream())
+    _lib.call("evc_meanpool_fwd", _p(x), _p(num_frames), B, T, F, 1 if normalize else 0, _p(avg_f32), _p(avg_bf16), _stream())
 
 
 def sigmoid_(z):
@@ -156,23 +156,46 @@ def sigmoid_bwd(p, dp, dz):
     _lib.call("evc_sigmoid_bwd", _p(p), _p(dp), p.numel(), _p(dz), _stream())
 
 
-def sample_frames_gather(x, u, num_frames, out, idx_out=None):
+def sample_frames_gather(x, u, num_frames, out, idx_out=None, normalize=False):
     B, T, F = x.shape
     S = u.shape[1]
-    _lib.call("evc_sample_frames_gather", _p(x), _p(u), _p(num_frames), B, T, F, S, _p(out), _p(idx_out), _stream())
+    _lib.call("evc_sample_frames_gather", _p(x), _p(u), _p(num_frames), B, T, F, S, 1 if normalize else 0, _p(out), _p(idx_out), _stream())
 
 
 def bn_stats(x, R, Cc, ws, mean, var):
     _lib.call("evc_bn_stats", _p(x), R, Cc, _p(ws), _p(mean), _p(var), _stream())
 
 
+def bn_stats_partial(x, R, Cc, ws):
+    _lib.call("evc_bn_stats_partial", _p(x), R, Cc, _p(ws), _stream())
+
+
+def bn_stats_finalize(ws, R_total, Cc, mean, var):
+    _lib.call("evc_bn_stats_finalize", _p(ws), R_total, Cc, _p(mean), _p(var), _stream())
+
+
+def ema_update(moving, batch_value, decay=0.999):
+    _lib.call("evc_ema_update", _p(moving), _p(batch_value), decay, moving.numel(), _stream())
+
+
 def bn_apply(x, R, Cc, mean, var, gamma, beta, relu6, y_f32=None, y_bf16=None):
     _lib.call("evc_bn_apply", _p(x), R, Cc, _p(mean), _p(var), _p(gamma), _p(beta), 1 if relu6 else 0, _p(y_f32), _p(y_bf16), _stream())
 
 
-def bn_relu6_bwd(x, dy, R, Cc, mean, var, gamma, beta, relu6, ws, dx_f32=None, dx_bf16=None, dgamma=None, dbeta=None):
-    _lib.call("evc_bn_relu6_bwd", _p(x), _p(dy), R, Cc, _p(mean), _p(var), _p(gamma), _p(beta), 1 if relu6 else 0, _p(ws),
-              _p(dx_f32), _p(dx_bf16), _p(dgamma), _p(dbeta), _stream())
+def bn_bwd_partial(x, dy, R, Cc, mean, var, gamma, beta, relu6, ws, argmax=None, S=1):
+    _lib.call("evc_bn_bwd_partial", _p(x), _p(dy), R, Cc, _p(mean), _p(var), _p(gamma), _p(beta), 1 if relu6 else 0,
+              _p(argmax), S, _p(ws), _stream())
+
+
+def bn_bwd_finalize(x, dy, R, R_total, Cc, mean, var, gamma, beta, relu6, ws, argmax=None, S=1,
+                    dx_f32=None, dx_bf16=None, dgamma=None, dbeta=None):
+    _lib.call("evc_bn_bwd_finalize", _p(x), _p(dy), R, R_total, Cc, _p(mean), _p(var), _p(gamma), _p(beta),
+              1 if relu6 else 0, _p(argmax), S, _p(ws), _p(dx_f32), _p(dx_bf16), _p(dgamma), _p(dbeta), _stream())
+
+
+def bn_relu6_framepool_fwd(act, B, S, Cc, mean, var, gamma, beta, pooled_f32, pooled_bf16, argmax):
+    _lib.call("evc_bn_relu6_framepool_fwd", _p(act), B, S, Cc, _p(mean), _p(var), _p(gamma), _p(beta), _p(pooled_f32),
+              _p(pooled_bf16), _p(argmax), _stream())
 
 
 def framepool_max_fwd(y, B, S, Cc, pooled_f32, pooled_bf16, argmax):

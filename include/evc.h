@@ -172,8 +172,9 @@ int evc_clip_adam_step(float* p, const float* g, float* m, float* v, int64_t n, 
 
 /* ---- a11: FrameLevelLogisticModel pooling ------------------------------------
  * cs/frame_level_models.py:72-78: sum over ALL T (padded) frames / true n.
- * x [B][T][F] f32 -> avg [B][F] bf16 (GEMM operand) and f32. */
-int evc_meanpool_fwd(const float* x, const int32_t* num_frames, int B, int T, int F,
+ * x [B][T][F] f32 -> avg [B][F] f32 (required) and bf16 (GEMM operand, optional).
+ * normalize=1 fuses tf.nn.l2_normalize of every frame (cs/train.py:256) into the pooling pass. */
+int evc_meanpool_fwd(const float* x, const int32_t* num_frames, int B, int T, int F, int normalize,
                      float* avg_f32, evc_bf16* avg_bf16, void* stream);
 /* elementwise sigmoid fwd (in place on f32 [n]) and dz = dp * p * (1-p) -> bf16 */
 int evc_sigmoid_fwd(float* z, int64_t n, void* stream);
@@ -181,19 +182,41 @@ int evc_sigmoid_bwd(const float* p, const float* dp, int64_t n, evc_bf16* dz, vo
 
 /* ---- a10: DbofModel pieces ----------------------------------------------------
  * SampleRandomFrames (cs/model_utils.py:39-58): idx = int32(u * float32(n));
- * gathers x[b, idx[b,s], :] -> out [B*S][F] f32.  u [B][S] f32 supplied by caller. */
+ * gathers x[b, idx[b,s], :] -> out [B*S][F] f32.  u [B][S] f32 supplied by caller.
+ * normalize=1 l2-normalises each gathered frame (cs/train.py:256: same values as
+ * normalising all 300 frames first, 10x less work). */
 int evc_sample_frames_gather(const float* x, const float* u, const int32_t* num_frames, int B, int T, int F,
-                             int S, float* out, int32_t* idx_out, void* stream);
+                             int S, int normalize, float* out, int32_t* idx_out, void* stream);
 /* slim.batch_norm training statistics over rows: mean[C], var[C] (biased, f64 accumulation). x [R][C] f32. */
 int evc_bn_stats(const float* x, int R, int C, double* ws /* 2*C, zeroed inside */, float* mean, float* var,
                  void* stream);
 /* y = relu6?(gamma*(x-mean)*rsqrt(var+1e-3)+beta); writes f32 y and/or bf16 y. */
 int evc_bn_apply(const float* x, int R, int C, const float* mean, const float* var, const float* gamma,
                  const float* beta, int relu6, float* y_f32, evc_bf16* y_bf16, void* stream);
-/* backward of relu6(bn(x)) given dy: needs x, stats; two passes inside. dx f32/bf16, dgamma, dbeta. */
+/* The two halves of evc_bn_stats, exposed so data-parallel ranks can all-reduce
+ * the f64 partial sums ws[2*C] in between (SyncBN == single-device batch statistics). */
+int evc_bn_stats_partial(const float* x, int R, int C, double* ws, void* stream);
+int evc_bn_stats_finalize(const double* ws, int R_total, int C, float* mean, float* var, void* stream);
+/* slim.batch_norm UPDATE_OPS: moving -= (1-decay)*(moving - batch_value), decay 0.999. */
+int evc_ema_update(float* moving, const float* batch_value, float decay, int n, void* stream);
+/* backward of relu6?(bn(x)) given dy [R][C]: dx f32/bf16, dgamma, dbeta.  If argmax != NULL,
+ * dy is the POOLED gradient [R/S][C] and row r=(b,s) receives it only where argmax[b][c]==s
+ * (gradient of FramePooling 'max' fused in).  partial/finalize are split for SyncBN. */
+int evc_bn_bwd_partial(const float* x, const float* dy, int R, int C, const float* mean, const float* var,
+                       const float* gamma, const float* beta, int relu6, const int32_t* argmax, int S,
+                       double* ws /* 2*C, zeroed inside */, void* stream);
+int evc_bn_bwd_finalize(const float* x, const float* dy, int R, int R_total, int C, const float* mean,
+                        const float* var, const float* gamma, const float* beta, int relu6,
+                        const int32_t* argmax, int S, const double* ws, float* dx_f32, evc_bf16* dx_bf16,
+                        float* dgamma, float* dbeta, void* stream);
 int evc_bn_relu6_bwd(const float* x, const float* dy, int R, int C, const float* mean, const float* var,
-                     const float* gamma, const float* beta, int relu6, double* ws /* 2*C, zeroed inside */,
+                     const float* gamma, const float* beta, int relu6, const int32_t* argmax, int S,
+                     double* ws /* 2*C, zeroed inside */,
                      float* dx_f32, evc_bf16* dx_bf16, float* dgamma, float* dbeta, void* stream);
+/* cluster_bn + relu6 + FramePooling('max') in one pass over act [B][S][C] (cs/frame_level_models.py:149-167). */
+int evc_bn_relu6_framepool_fwd(const float* act, int B, int S, int C, const float* mean, const float* var,
+                               const float* gamma, const float* beta, float* pooled_f32, evc_bf16* pooled_bf16,
+                               int32_t* argmax, void* stream);
 /* FramePooling 'max' (cs/model_utils.py:77-78): y [B][S][C] f32 -> pooled [B][C] + argmax. */
 int evc_framepool_max_fwd(const float* y, int B, int S, int C, float* pooled_f32, evc_bf16* pooled_bf16,
                           int32_t* argmax, void* stream);

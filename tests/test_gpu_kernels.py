@@ -197,3 +197,64 @@ def test_l2norm_chunk_and_counts(ops):
         rl1, rl2 = mm.hlstm_chunk_lengths(ref_n, C, Lc)
         assert np.array_equal(l1.cpu().numpy().reshape(C, 301), rl1.T)
         assert np.array_equal(l2.cpu().numpy(), rl2)
+
+
+@pytest.mark.parametrize("R,C,S", [(48, 70, 8), (1920, 256, 30)])
+def test_batchnorm_relu6_pool_kernels(ops, R, C, S):
+    """slim.batch_norm training statistics / apply / backward, relu6 and the fused max-pool
+    routing, each against the oracle in f32-level tolerance (no bf16 in these kernels)."""
+    rng = np.random.default_rng(R + C)
+    B = R // S
+    x = (rng.standard_normal((R, C)) * 2 + 0.5).astype(np.float32)
+    gamma = (1 + 0.3 * rng.standard_normal(C)).astype(np.float32)
+    beta = (0.5 * rng.standard_normal(C) + 1.0).astype(np.float32)
+    xd, gd, bd = (torch.from_numpy(a).to(DEV) for a in (x, gamma, beta))
+    ws = torch.empty(2 * C, dtype=torch.float64, device=DEV)
+    mean = torch.empty(C, dtype=torch.float32, device=DEV)
+    var = torch.empty(C, dtype=torch.float32, device=DEV)
+    ops.bn_stats(xd, R, C, ws, mean, var)
+    x64 = x.astype(np.float64)
+    assert np.allclose(mean.cpu().numpy(), x64.mean(0), rtol=1e-5, atol=1e-6)
+    assert np.allclose(var.cpu().numpy(), x64.var(0), rtol=1e-5, atol=1e-6)
+    y_ref, cache = mm.batch_norm_train_fwd(x64, gamma.astype(np.float64), beta.astype(np.float64))
+    y = torch.empty((R, C), dtype=torch.float32, device=DEV)
+    ops.bn_apply(xd, R, C, mean, var, gd, bd, False, y_f32=y)
+    assert np.abs(y.cpu().numpy() - y_ref).max() < 1e-4
+    # plain BN backward
+    dy = rng.standard_normal((R, C)).astype(np.float32)
+    dyd = torch.from_numpy(dy).to(DEV)
+    dx_ref, dg_ref, db_ref = mm.batch_norm_train_bwd(dy.astype(np.float64), cache)
+    dx = torch.empty((R, C), dtype=torch.float32, device=DEV)
+    dg = torch.empty(C, dtype=torch.float32, device=DEV)
+    db = torch.empty(C, dtype=torch.float32, device=DEV)
+    ops.bn_bwd_partial(xd, dyd, R, C, mean, var, gd, bd, False, ws)
+    ops.bn_bwd_finalize(xd, dyd, R, R, C, mean, var, gd, bd, False, ws, dx_f32=dx, dgamma=dg, dbeta=db)
+    assert np.abs(dx.cpu().numpy() - dx_ref).max() < 1e-4 * max(1.0, np.abs(dx_ref).max())
+    assert np.allclose(dg.cpu().numpy(), dg_ref, rtol=1e-4, atol=1e-4)
+    assert np.allclose(db.cpu().numpy(), db_ref, rtol=1e-4, atol=1e-4)
+    # relu6 + max-pool forward, then routed backward; masks taken from the oracle's own y
+    a6 = mm.relu6(y_ref).reshape(B, S, C)
+    pooled = torch.empty((B, C), dtype=torch.float32, device=DEV)
+    am = torch.empty((B, C), dtype=torch.int32, device=DEV)
+    ops.bn_relu6_framepool_fwd(xd, B, S, C, mean, var, gd, bd, pooled, None, am)
+    assert np.abs(pooled.cpu().numpy() - a6.max(1)).max() < 1e-4
+    amr = a6.argmax(1)
+    safe = np.sort(a6, axis=1)[:, -1] - np.sort(a6, axis=1)[:, -2] > 1e-3        # unambiguous maxima
+    assert np.array_equal(am.cpu().numpy()[safe], amr[safe])
+    dpool = rng.standard_normal((B, C)).astype(np.float32)
+    da = np.zeros((B, S, C))
+    amg = am.cpu().numpy()
+    bi, ci = np.meshgrid(np.arange(B), np.arange(C), indexing="ij")
+    da[bi, amg, ci] = dpool
+    inside = (y_ref > 1e-3) & (y_ref < 6 - 1e-3)
+    edge = ~inside & ~((y_ref < -1e-3) | (y_ref > 6 + 1e-3))
+    dyb = da.reshape(R, C) * inside
+    dx_ref, dg_ref, db_ref = mm.batch_norm_train_bwd(dyb, cache)
+    ops.bn_bwd_partial(xd, torch.from_numpy(dpool).to(DEV), R, C, mean, var, gd, bd, True, ws, argmax=am, S=S)
+    ops.bn_bwd_finalize(xd, torch.from_numpy(dpool).to(DEV), R, R, C, mean, var, gd, bd, True, ws, argmax=am, S=S,
+                        dx_f32=dx, dgamma=dg, dbeta=db)
+    cols_ok = ~(edge & (da.reshape(R, C) != 0)).any(0)                               # columns with no boundary-valued routed entry
+    assert cols_ok.mean() > 0.9
+    assert np.abs(dx.cpu().numpy() - dx_ref)[:, cols_ok].max() < 1e-4 * max(1.0, np.abs(dx_ref).max())
+    assert np.allclose(dg.cpu().numpy()[cols_ok], dg_ref[cols_ok], rtol=1e-4, atol=1e-4)
+    assert np.allclose(db.cpu().numpy()[cols_ok], db_ref[cols_ok], rtol=1e-4, atol=1e-4)
