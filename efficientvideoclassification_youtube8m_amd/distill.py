@@ -57,6 +57,38 @@ def validate_every_n(every_n, num_inputs_l1=5, max_frames=300):
                          "student input" % (every_n, len(every_n_indices(every_n, max_frames)), num_inputs_l1, s))
 
 
+def dp_loss_scales(world):
+    """Per-rank gradient scale factors such that an all-reduce SUM over `world`
+    ranks (each holding B_local videos, losses normalised by B_local) equals the
+    single-device gradient at the global batch: CE (cs/losses.py:97) and L_REP
+    (cs/train.py:362) are batch means -> 1/world; L_PRED is a batch sum
+    (cs/train.py:402) -> 1.  The l2 regulariser is added once, after the reduce."""
+    return {"ce": 1.0 / world, "rep": 1.0 / world, "kl": 1.0}
+
+
+class GradReducer:
+    """Bucketed asynchronous gradient all-reduce (SUM) on slices of a flat buffer.
+    backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests."""
+
+    def __init__(self, process_group=None):
+        self.pg = process_group
+        self.world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.world = torch.distributed.get_world_size(process_group)
+        self._pending = []
+
+    def reduce(self, flat, lo, hi):
+        if self.world == 1 or hi <= lo:
+            return
+        self._pending.append(torch.distributed.all_reduce(flat[lo:hi], op=torch.distributed.ReduceOp.SUM,
+                                                          group=self.pg, async_op=True))
+
+    def wait(self):
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+
+
 class DistillGraph:
     """mode: 'teacher_student' (train.py), 'teacher' (teacher only, BASELINE cfg 2),
     'student' (train_finetune.py)."""
@@ -76,9 +108,8 @@ class DistillGraph:
         self.rep_w = 2.0 if count_rep_twice else 1.0
         self.device = torch.device(device)
         self.pg = process_group
-        self.world = 1
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            self.world = torch.distributed.get_world_size(process_group)
+        self.reducer = GradReducer(process_group)
+        self.world = self.reducer.world
         self.global_step = 0
         self.teacher = self.student = None
         if mode != "student":
@@ -91,27 +122,15 @@ class DistillGraph:
                                       lstm_layers, num_mixtures, device, True, "model_student", seed + 1)
         self.losses = torch.zeros(8, dtype=F32, device=self.device)
         self._dp_t = self._dp_s = self._ds_s = None
-        self._pending = []
 
     # ---- data-parallel gradient reduction -------------------------------------
-    def _allreduce(self, flat, lo, hi):
-        if self.world == 1:
-            return
-        w = torch.distributed.all_reduce(flat[lo:hi], op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=True)
-        self._pending.append(w)
-
     def _reduce_tower(self, tower, moe_first):
         st = tower.store
         moe_lo = st.offsets[tower.GATES]
         if moe_first:
-            self._allreduce(st.grad, moe_lo, st.total)
+            self.reducer.reduce(st.grad, moe_lo, st.total)
         else:
-            self._allreduce(st.grad, 0, moe_lo)
-
-    def _wait_reductions(self):
-        for w in self._pending:
-            w.wait()
-        self._pending = []
+            self.reducer.reduce(st.grad, 0, moe_lo)
 
     # ---- one training iteration -----------------------------------------------
     def step(self, x_raw, labels_u8, num_frames, apply=True):
@@ -129,11 +148,11 @@ class DistillGraph:
                                   num_frames=num_frames if x_raw.dtype == torch.uint8 else None)
         self.losses.zero_()
         out = {}
-        inv_w = 1.0 / self.world
+        sc = dp_loss_scales(self.world)
         if self.teacher is not None:
             _, l1, l2 = ops.frame_counts(num_frames, 1, self.C1, self.max_frames // self.C1, self.max_frames)
             t_state, t_pred = self.teacher.forward(xt, l1, l2)
-            ops.ce_loss(t_pred, labels_u8, self.losses[0:1], self._dp_t, grad_scale=inv_w / B)
+            ops.ce_loss(t_pred, labels_u8, self.losses[0:1], self._dp_t, grad_scale=sc["ce"] / B)
             self.teacher.backward(None, self._dp_t,
                                   on_moe_grads_ready=lambda: self._reduce_tower(self.teacher, True))
             self._reduce_tower(self.teacher, False)
@@ -141,21 +160,21 @@ class DistillGraph:
         if need_student:
             n_s, l1s, l2s = ops.frame_counts(num_frames, self.every_n, self.C2, self.S // self.C2, self.max_frames)
             s_state, s_pred = self.student.forward(xs, l1s, l2s)
-            ops.ce_loss(s_pred, labels_u8, self.losses[3:4], self._dp_s, grad_scale=inv_w / B)
+            ops.ce_loss(s_pred, labels_u8, self.losses[3:4], self._dp_s, grad_scale=sc["ce"] / B)
             ds = None
             if self.teacher is not None:
                 if self._ds_s is None or self._ds_s.shape != s_state.shape:
                     self._ds_s = torch.empty_like(s_state)
                 ops.kl_pred_loss(t_pred, self.teacher.rowsum, s_pred, self.student.rowsum, self.losses[2:3], self._dp_s,
-                                 grad_scale=1.0, accumulate_grad=True)
-                ops.rep_loss(t_state, s_state, self.losses[1:2], self._ds_s, grad_scale=self.rep_w * inv_w)
+                                 grad_scale=sc["kl"], accumulate_grad=True)
+                ops.rep_loss(t_state, s_state, self.losses[1:2], self._ds_s, grad_scale=self.rep_w * sc["rep"])
                 ds = self._ds_s
             self.student.backward(ds, self._dp_s,
                                   on_moe_grads_ready=lambda: self._reduce_tower(self.student, True))
             self._reduce_tower(self.student, False)
             out.update(student_predictions=s_pred, student_state=s_state, num_frames_student=n_s,
                        student_loss_state=self.losses[1], pred_loss=self.losses[2], student_label_loss=self.losses[3])
-        self._wait_reductions()
+        self.reducer.wait()
         if apply:
             self.apply_gradients(B)
         out["global_step"] = self.global_step

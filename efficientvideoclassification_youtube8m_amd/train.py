@@ -1,0 +1,206 @@
+"""Training binary with the reference's flag surface (cs/train.py, and
+cs/train_finetune.py via ``--finetune``):
+
+    python -m efficientvideoclassification_youtube8m_amd.train \
+        --train_data_pattern synthetic --train_dir ./model_HLSTM_TeaStud_every10_train/ \
+        --frame_features True --feature_names "rgb, audio" --feature_sizes "1024, 128" \
+        --model "HierarchicalLstmModel" --gpu 0 --batch_size 256 --num_inputs_to_lstm 20 \
+        --lstm_layers 2 --start_new_model True --num_epochs 1 --every_n 10      # = run_train.sh:6
+
+What is kept: flag names/defaults/syntax (flags.py), class lookup by name
+(``find_class_by_name``, cs/train.py:179-182), the teacher+student graph
+(``build_graph`` -> distill.DistillGraph), the per-step log line
+(cs/train.py:528-533), global_step += 2, resume-unless-``--start_new_model``.
+What is replaced: TF Supervisor/queue runners -> a plain loop; TF checkpoints ->
+``torch.save`` of a TF-named state dict (model.ckpt-<step>.pt, max_to_keep=1);
+TFRecord input -> synthetic batches until the reader lands.
+Multi-GPU: launch with ``python -m torch.distributed.run --nproc-per-node N``;
+``--gpu`` is then ignored in favour of LOCAL_RANK.
+"""
+from __future__ import annotations
+
+import glob
+import logging
+import os
+import sys
+import time
+
+import torch
+
+from . import eval_util, frame_level_models, losses, ops, video_level_models
+from .distill import DistillGraph, SingleTowerGraph
+from .flags import FLAGS, GetListOfFeatureNamesAndSizes
+from .towers import DbofTower, LogisticTower
+
+NUM_CLASSES = 4716       # readers.YT8MFrameFeatureReader default num_classes (cs/readers.py:121)
+
+
+def find_class_by_name(name, modules):
+    """Searches the provided modules for the named class and returns it (cs/train.py:179-182)."""
+    found = [getattr(module, name, None) for module in modules]
+    return next(a for a in found if a)
+
+
+def build_graph(model, label_loss_fn, feature_size, batch_size, every_n, device, finetune=False, process_group=None):
+    """Equivalent of cs/train.py:185-427 (and cs/train_finetune.py:185-331 when
+    finetune): returns the graph object whose ``step`` runs one iteration."""
+    if not isinstance(label_loss_fn, losses.CrossEntropyLoss):
+        raise NotImplementedError("only CrossEntropyLoss is fused into the training graph (SURVEY.md 8a row a6)")
+    common = dict(base_learning_rate=FLAGS.base_learning_rate, learning_rate_decay=FLAGS.learning_rate_decay,
+                  learning_rate_decay_examples=FLAGS.learning_rate_decay_examples,
+                  regularization_penalty=FLAGS.regularization_penalty, clip_gradient_norm=FLAGS.clip_gradient_norm,
+                  process_group=process_group)
+    if isinstance(model, frame_level_models.HierarchicalLstmModel):
+        mode = "student" if finetune else ("teacher_student" if every_n > 1 else "teacher")
+        return DistillGraph(batch_size, every_n=every_n, mode=mode, feature_size=feature_size, vocab_size=NUM_CLASSES,
+                            max_frames=FLAGS.max_num_frames, num_inputs_to_lstm=FLAGS.num_inputs_to_lstm,
+                            lstm_cells=FLAGS.lstm_cells, lstm_layers=FLAGS.lstm_layers,
+                            num_mixtures=FLAGS.moe_num_mixtures, device=device, **common)
+    if isinstance(model, frame_level_models.DbofModel):
+        tw = DbofTower(batch_size, FLAGS.max_num_frames, feature_size, NUM_CLASSES, FLAGS.iterations,
+                       FLAGS.dbof_cluster_size, FLAGS.dbof_hidden_size, FLAGS.moe_num_mixtures, device=device,
+                       process_group=process_group)
+        return SingleTowerGraph(tw, **common)
+    if isinstance(model, frame_level_models.FrameLevelLogisticModel):
+        return SingleTowerGraph(LogisticTower(batch_size, FLAGS.max_num_frames, feature_size, NUM_CLASSES, device=device),
+                                **common)
+    raise NotImplementedError("model %s has no training graph (NetVLAD/NeXtVLAD are empty stubs in the reference too)"
+                              % type(model).__name__)
+
+
+def synthetic_batches(batch_size, feature_size, device, videos_per_epoch, num_epochs, seed):
+    """Synthetic stand-in for get_input_data_tensors (cs/train.py:129-176): uint8
+    features dequantised by the input kernel, n ~ U{120..300}, ~3 labels/video."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    T = FLAGS.max_num_frames
+    for _ in range(num_epochs):
+        left = videos_per_epoch
+        while left > 0:
+            b = min(batch_size, left)                  # allow_smaller_final_batch=True (cs/train.py:175)
+            left -= b
+            q = torch.randint(0, 256, (b, T, feature_size), generator=g, device=device, dtype=torch.uint8)
+            n = torch.randint(min(120, T), T + 1, (b,), generator=g, device=device, dtype=torch.int32)
+            labels = torch.zeros((b, NUM_CLASSES), dtype=torch.uint8, device=device)
+            labels.scatter_(1, torch.randint(0, NUM_CLASSES, (b, 3), generator=g, device=device), 1)
+            yield q, labels, n
+
+
+def get_input_data(data_pattern, batch_size, feature_size, device, num_epochs, seed):
+    if data_pattern in ("", "synthetic"):
+        return synthetic_batches(batch_size, feature_size, device, FLAGS.synthetic_videos, num_epochs, seed)
+    files = glob.glob(data_pattern)
+    if not files:
+        raise IOError("Unable to find training files. data_pattern='" + data_pattern + "'.")   # cs/train.py:155-157
+    raise NotImplementedError("TFRecord input is the next scope row (SURVEY.md 8f #1); use --train_data_pattern synthetic")
+
+
+def latest_checkpoint(train_dir):
+    cks = glob.glob(os.path.join(train_dir, "model.ckpt-*.pt"))
+    return max(cks, key=lambda p: int(p.rsplit("-", 1)[1][:-3])) if cks else None
+
+
+def save_checkpoint(graph, train_dir, rank):
+    if rank != 0:
+        return
+    os.makedirs(train_dir, exist_ok=True)
+    sd = {"global_step": graph.global_step}
+    for tw in (getattr(graph, "teacher", None), getattr(graph, "student", None), getattr(graph, "tower", None)):
+        if tw is not None:
+            sd.update({k: v.cpu() for k, v in tw.state_dict().items()})
+            sd["%s/adam" % tw.scope] = {"t": tw.adam_t, "m": tw.store.m.cpu(), "v": tw.store.v.cpu()}
+    path = os.path.join(train_dir, "model.ckpt-%d.pt" % graph.global_step)
+    torch.save(sd, path)
+    for old in glob.glob(os.path.join(train_dir, "model.ckpt-*.pt")):      # max_to_keep=1 (cs/train.py:651)
+        if old != path:
+            os.remove(old)
+    return path
+
+
+def restore_checkpoint(graph, path):
+    sd = torch.load(path, map_location="cpu")
+    graph.global_step = int(sd["global_step"])
+    for tw in (getattr(graph, "teacher", None), getattr(graph, "student", None), getattr(graph, "tower", None)):
+        if tw is not None and any(k.startswith(tw.scope + "/") for k in sd):
+            tw.load_state_dict(sd)
+            ad = sd.get("%s/adam" % tw.scope)
+            if ad:
+                tw.adam_t = ad["t"]
+                tw.store.m.copy_(ad["m"])
+                tw.store.v.copy_(ad["v"])
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    finetune = "--finetune" in argv
+    argv = [a for a in argv if a != "--finetune"]
+    FLAGS.parse(argv)
+    for k, v in FLAGS.flag_values_dict().items():
+        print("Key: %s Value: %s" % (k, v))
+    logging.basicConfig(level=logging.INFO, format="INFO:evc:%(message)s")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(FLAGS.gpu)))
+    torch.cuda.set_device(local)
+    device = "cuda:%d" % local
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=torch.device(device))
+    ops.check_device(local)
+    task = "/job:master/task:%d" % rank
+    _, feature_sizes = GetListOfFeatureNamesAndSizes(FLAGS.feature_names, FLAGS.feature_sizes)
+    feature_size = sum(feature_sizes)
+    model = find_class_by_name(FLAGS.model, [frame_level_models, video_level_models])()
+    label_loss_fn = find_class_by_name(FLAGS.label_loss, [losses])()
+    if FLAGS.optimizer != "AdamOptimizer":
+        raise NotImplementedError("only AdamOptimizer (the reference default, cs/train.py:91) is built")
+    graph = build_graph(model, label_loss_fn, feature_size, FLAGS.batch_size, FLAGS.every_n, device, finetune)
+    logging.info("%s: Built graph.", task)
+    ck = None if FLAGS.start_new_model else latest_checkpoint(FLAGS.train_dir)
+    if FLAGS.start_new_model:
+        logging.info("%s: Flag 'start_new_model' is set. Building a new model.", task)
+    elif ck is None:
+        logging.info("%s: No checkpoint file found. Building a new model.", task)
+    else:
+        logging.info("%s: Restoring from %s", task, ck)
+        restore_checkpoint(graph, ck)
+    logging.info("Using batch size of %d for training.", FLAGS.batch_size)
+    data = get_input_data(FLAGS.train_data_pattern, FLAGS.batch_size, feature_size, device, FLAGS.num_epochs, 1234 + rank)
+    logging.info("%s: Entering training loop.", task)
+    start, last_save, it = time.time(), time.time(), 0
+    is_distill = isinstance(graph, DistillGraph)
+    for q, labels, n in data:
+        t0 = time.time()
+        out = graph.step(q, labels, n) if is_distill else graph.step(q.float() * (4.0 / 255.0) + (4.0 / 512.0 - 2.0), labels, n)
+        it += 1
+        if rank == 0 and it % max(1, FLAGS.log_every) == 0:
+            pred = out.get("predictions", out.get("student_predictions"))
+            p, y = pred.cpu().numpy(), labels.float().cpu().numpy()           # D2H sync, as the reference's fetch does
+            dt = time.time() - t0
+            hit, perr, gap = (eval_util.calculate_hit_at_one(p, y), eval_util.calculate_precision_at_equal_recall_rate(p, y),
+                              eval_util.calculate_gap(p, y))
+            if is_distill:
+                r = graph.loss_report()
+                logging.info("%s: training step %d| Hit@1: %.2f| PERR: %.2f| GAP: %.2f| Teacher_Loss: %s| L_REP: %s| L_PRED: %s"
+                             "| L_CE: %s", task, out["global_step"], hit, perr, gap, round(r["label_loss"], 2),
+                             round(r["student_loss_state"], 2), round(r["pred_loss"], 2), round(r["student_label_loss"], 2))
+            else:
+                logging.info("%s: training step %d| Hit@1: %.2f| PERR: %.2f| GAP: %.2f| Loss: %s", task, out["global_step"],
+                             hit, perr, gap, round(float(out["loss"]), 2))
+            logging.info("global_step/sec: %g  Examples/Second: %g", (2 if is_distill and graph.teacher and graph.student else 1) / dt,
+                         labels.shape[0] * world / dt)
+        if time.time() - last_save > 30 * 60:                                  # save_model_secs (cs/train.py:500)
+            save_checkpoint(graph, FLAGS.train_dir, rank)
+            last_save = time.time()
+        if FLAGS.max_steps and it >= FLAGS.max_steps:
+            break
+    logging.info("%s: Done training -- epoch limit reached.", task)
+    save_checkpoint(graph, FLAGS.train_dir, rank)
+    logging.info("%s: Exited training loop.", task)
+    print("Total time taken is " + str(time.time() - start))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

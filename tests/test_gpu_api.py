@@ -1,0 +1,122 @@
+"""The reference's plug-in interface (create_model / calculate_loss / flags /
+train.py main) driven end-to-end on the GPU.  pytest -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model_math as mm
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _params(tower):
+    pre = tower.scope + "/"
+    return {k[len(pre):]: v.detach().cpu().double().numpy() for k, v in tower.state_dict().items()}
+
+
+def test_create_model_interface_like_train_py():
+    """Mirrors cs/train.py:253-288,349-357: normalise, sub-sample, then
+    model.create_model(...) under 'model' and create_model_inference(...) under 'model_student'."""
+    from efficientvideoclassification_youtube8m_amd import frame_level_models, losses
+    from efficientvideoclassification_youtube8m_amd.flags import FLAGS
+    FLAGS.reset()
+    FLAGS.parse(["--lstm_cells", "64", "--lstm_layers", "2", "--num_inputs_to_lstm", "20", "--every_n", "10"])
+    B, F, V = 4, 64, 30
+    q, x, n, labels = mm.synthetic_batch(B, seed=9, feature_size=F, vocab_size=V, dtype=np.float32)
+    xn = mm.l2_normalize(x.astype(np.float64), 2)
+    model_input = torch.from_numpy(xn.astype(np.float32)).to(DEV)                 # tf.nn.l2_normalize output
+    num_frames = torch.from_numpy(n).to(DEV)
+    model = frame_level_models.HierarchicalLstmModel()
+    state, result = model.create_model(model_input, num_frames=num_frames, vocab_size=V, batch_size=B,
+                                       labels=labels, dropout=0.5, scope="model")
+    predictions = result["predictions"]
+    assert predictions.shape == (B, V) and state.shape == (B, 4 * 64)
+    P = _params(model.towers["model"])
+    s_ref, p_ref, _ = mm.hlstm_fwd(xn, n, P, 20)
+    assert np.abs(predictions.cpu().numpy() - p_ref).max() < 1e-3
+    assert np.abs(state.cpu().numpy() - s_ref).max() < 2e-2
+    loss = losses.CrossEntropyLoss().calculate_loss(predictions, torch.from_numpy(labels).to(DEV))
+    assert abs(loss.item() - mm.cross_entropy_loss(p_ref, labels)) < 1e-3 * mm.cross_entropy_loss(p_ref, labels)
+    # student: every_n sub-sampled frames + student frame count
+    idx = mm.every_n_indices(10)
+    n_s = mm.student_num_frames(n, 10)
+    s_state, s_res = model.create_model_inference(model_input[:, idx].contiguous(), num_frames=torch.from_numpy(n_s).to(DEV),
+                                                  vocab_size=V, every_n=10, num_inputs_L1=5, scope="model_student")
+    Ps = _params(model.towers["model_student"])
+    ss_ref, sp_ref, _ = mm.hlstm_fwd(xn[:, idx], n_s, Ps, 5)
+    assert np.abs(s_res["predictions"].cpu().numpy() - sp_ref).max() < 1e-3
+    # state-dict name contract (README.md:98,105)
+    keys = list(model.towers["model_student"].state_dict().keys())
+    assert keys == ["model_student/" + k for k in mm.HLSTM_PARAM_ORDER]
+    sd = model.towers["model"].state_dict()
+    assert sd["model/RNN_L1/rnn/multi_rnn_cell/cell_0/basic_lstm_cell/kernel"].shape == (F + 64, 4 * 64)
+    assert sd["model/classifier/gates/weights"].shape == (4 * 64, V * 3)
+    FLAGS.reset()
+
+
+def test_bad_shapes_raise_like_the_reference_graph_build():
+    from efficientvideoclassification_youtube8m_amd import frame_level_models
+    from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
+    from efficientvideoclassification_youtube8m_amd.flags import FLAGS
+    FLAGS.reset()
+    FLAGS.parse(["--lstm_cells", "64", "--lstm_layers", "2"])
+    with pytest.raises(ValueError):
+        DistillGraph(4, every_n=7, feature_size=64, vocab_size=10, lstm_cells=64, device=DEV)   # 43 frames vs S=42
+    x = torch.zeros((2, 290, 64), device=DEV)
+    with pytest.raises(ValueError):
+        frame_level_models.HierarchicalLstmModel().create_model(x, vocab_size=10, num_frames=torch.tensor([5, 5], device=DEV))
+    FLAGS.reset()
+
+
+def test_moe_and_dbof_and_logistic_create_model():
+    from efficientvideoclassification_youtube8m_amd import frame_level_models, video_level_models, model_utils
+    from efficientvideoclassification_youtube8m_amd.flags import FLAGS
+    FLAGS.reset()
+    FLAGS.parse(["--dbof_cluster_size", "128", "--dbof_hidden_size", "64", "--iterations", "6"])
+    rng = np.random.default_rng(0)
+    B, F, V = 5, 64, 21
+    q, x, n, labels = mm.synthetic_batch(B, seed=4, feature_size=F, vocab_size=V, dtype=np.float32)
+    xd, nd = torch.from_numpy(x).to(DEV), torch.from_numpy(n).to(DEV)
+    h = torch.from_numpy(rng.standard_normal((B, 128)).astype(np.float32)).to(DEV)
+    moe = video_level_models.MoeModel()
+    p = moe.create_model(model_input=h, vocab_size=V)["predictions"]
+    P = _params(moe.tower)
+    p_ref, _ = mm.moe_fwd(h.cpu().double().numpy(), P["classifier/gates/weights"], P["classifier/experts/weights"],
+                          P["classifier/experts/biases"], 2)
+    # O(1)-magnitude inputs: the bf16 operand rounding (2^-9) shows at ~2e-3 in the probabilities (precision)
+    assert np.abs(p.cpu().numpy() - p_ref).max() < 5e-3
+    out = frame_level_models.DbofModel().create_model(xd, vocab_size=V, num_frames=nd, normalize_input=True)
+    assert out["predictions"].shape == (B, V) and torch.isfinite(out["predictions"]).all()
+    out = frame_level_models.FrameLevelLogisticModel().create_model(xd, vocab_size=V, num_frames=nd)
+    assert out["predictions"].shape == (B, V)
+    fr = model_utils.SampleRandomFrames(xd, nd, 7)
+    assert fr.shape == (B, 7, F)
+    pooled = model_utils.FramePooling(fr, "max")
+    assert torch.allclose(pooled, fr.max(1).values)
+    with pytest.raises(ValueError):
+        model_utils.FramePooling(fr, "attention")
+    FLAGS.reset()
+
+
+def test_train_main_runs_and_resumes(tmp_path, capsys):
+    from efficientvideoclassification_youtube8m_amd import train
+    from efficientvideoclassification_youtube8m_amd.flags import FLAGS
+    FLAGS.reset()
+    args = ["--train_data_pattern", "synthetic", "--train_dir", str(tmp_path) + "/", "--frame_features", "True",
+            "--feature_names", "rgb, audio", "--feature_sizes", "64, 64", "--model", "HierarchicalLstmModel", "--gpu", "0",
+            "--batch_size", "8", "--num_inputs_to_lstm", "20", "--lstm_layers", "2", "--lstm_cells", "64",
+            "--num_epochs", "1", "--every_n", "10", "--synthetic_videos", "20", "--some_unknown_flag", "1"]
+    train.main(args + ["--start_new_model", "True"])
+    ck = train.latest_checkpoint(str(tmp_path))
+    assert ck.endswith("model.ckpt-6.pt")              # 3 iterations (8+8+4 videos) x 2 global steps
+    sd = torch.load(ck)
+    assert sd["global_step"] == 6 and "model_student/classifier/experts/biases" in sd
+    FLAGS.reset()
+    train.main(args + ["--start_new_model", "False"])  # resumes from step 6
+    assert train.latest_checkpoint(str(tmp_path)).endswith("model.ckpt-12.pt")
+    with pytest.raises(IOError):
+        FLAGS.reset()
+        train.main(["--train_data_pattern", "/nonexistent/train*.tfrecord", "--lstm_cells", "64", "--feature_sizes", "64",
+                    "--batch_size", "4", "--every_n", "10", "--start_new_model", "True", "--train_dir", str(tmp_path) + "/x/"])
+    FLAGS.reset()
