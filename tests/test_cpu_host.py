@@ -159,7 +159,7 @@ for grads, ref, params in ((tg, full["teacher_grads"], teacher), (sg, full["stud
             want = want - 2.0 * 1e-8 * params[k]          # the l2 term is added after the reduce, once
         assert np.allclose(g, want, rtol=1e-9, atol=1e-12), (rank, k)
 dist.destroy_process_group()
-print("rank", rank, "ok")
+sys.stdout.write("rank%d-ok\n" % rank); sys.stdout.flush()
 '''
 
 
@@ -174,4 +174,4 @@ def test_data_parallel_gradient_equals_global_batch_gloo(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+    assert r.stdout.count("-ok") == 2, r.stdout
