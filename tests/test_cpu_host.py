@@ -159,7 +159,7 @@ for grads, ref, params in ((tg, full["teacher_grads"], teacher), (sg, full["stud
             want = want - 2.0 * 1e-8 * params[k]          # the l2 term is added after the reduce, once
         assert np.allclose(g, want, rtol=1e-9, atol=1e-12), (rank, k)
 dist.destroy_process_group()
-sys.stdout.write("rank%d-ok\n" % rank); sys.stdout.flush()
+sys.stdout.write("rank" + str(rank) + "-ok\n"); sys.stdout.flush()
 '''
 
 
