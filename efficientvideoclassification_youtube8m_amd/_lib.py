@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libevc_hip.so")
+LIB_PATH = os.environ.get("EVC_LIB", os.path.join(_HERE, "libevc_hip.so"))   # EVC_LIB: debug builds only
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 

@@ -1,6 +1,54 @@
 // GEMM-shaped kernels of the hot path: generic NT GEMM, fused LSTM step
 // (forward, with the gate tail in the epilogue) and fused BPTT step.
-#include "gemm_core.h"
+#include "gemm_core_v2.h"
+#include <mutex>
+#include <stdlib.h>
+
+// A kernel is instantiated either on a v1 tile (TileCfg: static 2-stage LDS, K steps of 64)
+// or a v2 tile (TileCfg2: dynamic 4-stage LDS ring, K steps of 32).
+template <class Cfg> struct is_v2 { static constexpr bool value = false; };
+template <int a, int b, int c, int d, int e, int f, bool g> struct is_v2<TileCfg2<a, b, c, d, e, f, g>> { static constexpr bool value = true; };
+
+extern __shared__ __attribute__((aligned(16))) char lds_dyn[];
+
+template <class Cfg, int NG>
+__device__ __forceinline__ void run_mainloop(const GemmOperands& p, int m0, int u0, f32x4 (&acc)[Cfg::MI][NG][Cfg::NI]) {
+  if constexpr (is_v2<Cfg>::value) {
+    gemm_mainloop_v2<Cfg>(p, m0, u0, lds_dyn, acc);
+  } else {
+    __shared__ __attribute__((aligned(16))) char lds_static[Cfg::LDS_BYTES];   // static: keeps 2 workgroups per CU
+    gemm_mainloop<Cfg>(p, m0, u0, lds_static, acc);
+  }
+}
+
+// K-step granularity of a config (v1 walks 64-wide tiles, v2 32-wide)
+template <class Cfg> static inline int kdiv() { return is_v2<Cfg>::value ? 32 : 64; }
+
+template <class Cfg, class Kern, class... Args>
+static inline void launch_cfg(Kern kern, int grid, hipStream_t st, Args... args) {
+  if (is_v2<Cfg>::value) {
+    static std::once_flag once;
+    std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES); });
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, args...);
+  } else {
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::NT), 0, st, args...);
+  }
+}
+
+// debug/benchmark override of the tile choice: EVC_FORCE_TILE = 1 (v2) | 2 (v1 128x128) | 3 (v1 64x64)
+static inline int forced_tile() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("EVC_FORCE_TILE"); v = e ? atoi(e) : 0; }
+  return v;
+}
+
+// Tile choice: a CU works through ceil(tiles/256) tiles (co-resident workgroups share its matrix
+// pipe, so residency does not shorten that), each costing area x a per-flop factor measured on
+// MI355X with scripts/gemm_bench.py (v2 ~1000 TF/s -> 1.0, v1 128x128 ~800 -> 1.3, v1 64x64 ~400 -> 2.6).
+static inline double tile_cost(long tiles, int bm, int bn, int /*occ*/, double c) {
+  const long per_cu = (tiles + 255) / 256;
+  return (double)per_cu * bm * bn * c;
+}
 
 // ===========================================================================
 // generic GEMM: C[M,N] (+)= A.B^T (+bias)
@@ -11,13 +59,13 @@ struct StoreParams {
 
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::NT) void gemm_nt_kernel(GemmOperands p, StoreParams s, int tiles_m, int tiles_n) {
-  __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
   const int nwg = tiles_m * tiles_n;
   const int id = xcd_remap(blockIdx.x, nwg);
-  const int tm = id % tiles_m, tn = id / tiles_m;
+  int tm, tn;
+  tile_of(id, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * Cfg::BM, u0 = tn * Cfg::BU;
   f32x4 acc[Cfg::MI][Cfg::G][Cfg::NI];
-  gemm_mainloop<Cfg>(p, m0, u0, lds, acc);
+  run_mainloop<Cfg, Cfg::G>(p, m0, u0, acc);
   TileCoords<Cfg> tc;
 #pragma unroll
   for (int mi = 0; mi < Cfg::MI; ++mi)
@@ -45,6 +93,14 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_nt_kernel(GemmOperands p, StoreP
 
 typedef TileCfg<128, 1, 128, 2, 2> CfgPlainBig;   // 128x128, 4 waves, 4x4 MFMA tiles per wave
 typedef TileCfg<64, 1, 64, 2, 2> CfgPlainSmall;   // 64x64 for skinny problems
+typedef TileCfg2<256, 1, 256, 2, 4, 5, true> CfgPlainV2;   // 256x256, 8 waves (2x4), 128x64 per wave, 5-deep ring (160 KiB)
+
+template <class Cfg>
+static inline void launch_gemm(GemmOperands p, const StoreParams& s, int K, hipStream_t st) {
+  p.nk1 = K / kdiv<Cfg>();
+  const int tm = ceil_div(s.M, Cfg::BM), tn = ceil_div(s.N, Cfg::BU);
+  launch_cfg<Cfg>(gemm_nt_kernel<Cfg>, tm * tn, st, p, s, tm, tn);
+}
 
 extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, void* C, int64_t ldc,
                            int M, int N, int K, const float* bias, int out_bf16, int accumulate, void* stream) {
@@ -54,18 +110,19 @@ extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
               EVC_ERR_BAD_ALIGN, "evc_gemm_nt: operands must be 16-byte aligned (lda=%ld ldb=%ld)", (long)lda, (long)ldb);
   EVC_REQUIRE(!(out_bf16 && accumulate), EVC_ERR_BAD_ARG, "evc_gemm_nt: accumulate needs f32 output");
   GemmOperands p;
-  p.A1 = A; p.lda1 = lda; p.nk1 = K / 64; p.A2 = A; p.lda2 = lda; p.nk2 = 0;
+  p.A1 = A; p.lda1 = lda; p.nk1 = 0; p.A2 = A; p.lda2 = lda; p.nk2 = 0;
   p.B = B; p.ldb = ldb; p.group_stride = 0; p.M = M; p.Nu = N;
   StoreParams s{C, ldc, M, N, bias, out_bf16, accumulate};
   hipStream_t st = (hipStream_t)stream;
-  const long big_tiles = (long)ceil_div(M, 128) * ceil_div(N, 128);
-  if (big_tiles >= 192) {
-    const int tm = ceil_div(M, 128), tn = ceil_div(N, 128);
-    hipLaunchKernelGGL(gemm_nt_kernel<CfgPlainBig>, dim3(tm * tn), dim3(CfgPlainBig::NT), 0, st, p, s, tm, tn);
-  } else {
-    const int tm = ceil_div(M, 64), tn = ceil_div(N, 64);
-    hipLaunchKernelGGL(gemm_nt_kernel<CfgPlainSmall>, dim3(tm * tn), dim3(CfgPlainSmall::NT), 0, st, p, s, tm, tn);
-  }
+  // per-flop cost factors measured on MI355X (scripts/gemm_bench.py): v2 ~1000 TF/s, v1 128^2 ~800, v1 64^2 ~400
+  const double c_v2 = tile_cost((long)ceil_div(M, 256) * ceil_div(N, 256), 256, 256, 1, 1.0);
+  const double c_big = tile_cost((long)ceil_div(M, 128) * ceil_div(N, 128), 128, 128, 2, 1.3);
+  const double c_small = tile_cost((long)ceil_div(M, 64) * ceil_div(N, 64), 64, 64, 4, 2.6);
+  int pick = (c_v2 <= c_big && c_v2 <= c_small) ? 1 : (c_big <= c_small ? 2 : 3);
+  if (forced_tile()) pick = forced_tile();
+  if (pick == 1) launch_gemm<CfgPlainV2>(p, s, K, st);
+  else if (pick == 2) launch_gemm<CfgPlainBig>(p, s, K, st);
+  else launch_gemm<CfgPlainSmall>(p, s, K, st);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }
@@ -87,13 +144,13 @@ struct LstmFwdParams {
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, LstmFwdParams e, int tiles_m, int tiles_n) {
   static_assert(Cfg::G == 4, "LSTM step needs the four gate groups");
-  __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
   const int nwg = tiles_m * tiles_n;
   const int id = xcd_remap(blockIdx.x, nwg);
-  const int tm = id % tiles_m, tn = id / tiles_m;
+  int tm, tn;
+  tile_of(id, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * Cfg::BM, u0 = tn * Cfg::BU;
   f32x4 acc[Cfg::MI][4][Cfg::NI];
-  gemm_mainloop<Cfg>(p, m0, u0, lds, acc);
+  run_mainloop<Cfg, 4>(p, m0, u0, acc);
   TileCoords<Cfg> tc;
   const int H = e.H;
 #pragma unroll
@@ -139,6 +196,15 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, 
 
 typedef TileCfg<128, 4, 32, 2, 2> CfgLstmBig;    // 128 rows x 32 units x 4 gates
 typedef TileCfg<64, 4, 16, 4, 1> CfgLstmSmall;   // 64 rows x 16 units x 4 gates (M ~ 256 steps)
+typedef TileCfg2<320, 4, 64, 2, 4, 4, false> CfgLstmV2a;   // 320 rows x 64 units x 4 gates: M=5120,H=1024 -> exactly 256 workgroups
+typedef TileCfg2<256, 4, 64, 2, 4, 5, true> CfgLstmV2b;   // 256 rows x 64 units x 4 gates
+
+template <class Cfg>
+static inline void launch_lstm_fwd(GemmOperands p, const LstmFwdParams& e, int k1, int k2, hipStream_t st) {
+  p.nk1 = k1 / kdiv<Cfg>(); p.nk2 = k2 / kdiv<Cfg>();
+  const int tm = ceil_div(e.M, Cfg::BM), tn = ceil_div(e.H, Cfg::BU);
+  launch_cfg<Cfg>(lstm_fwd_step_kernel<Cfg>, tm * tn, st, p, e, tm, tn);
+}
 
 extern "C" int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const float* bias, const int32_t* len,
                                   int T, int M, int Kin, int H, int hoist, float* zx_ws,
@@ -159,17 +225,24 @@ extern "C" int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const f
     int rc = evc_gemm_nt(x, Kin, wT, ldw, zx_ws, 4L * H, T * M, 4 * H, Kin, nullptr, 0, 0, stream);
     if (rc) return rc;
   }
-  const bool big = (long)ceil_div(M, 128) * ceil_div(H, 32) >= 192;
+  const double cst[4] = {tile_cost((long)ceil_div(M, 320) * ceil_div(H, 64), 320, 256, 1, 1.0),
+                         tile_cost((long)ceil_div(M, 256) * ceil_div(H, 64), 256, 256, 1, 1.0),
+                         tile_cost((long)ceil_div(M, 128) * ceil_div(H, 32), 128, 128, 2, 1.3),
+                         tile_cost((long)ceil_div(M, 64) * ceil_div(H, 16), 64, 64, 4, 2.6)};
+  int pick = 0;
+  for (int i = 1; i < 4; ++i) if (cst[i] < cst[pick]) pick = i;
+  if (forced_tile() == 4) pick = 0; else if (forced_tile()) pick = forced_tile();    // 4 -> v2a (320), 1 -> v2b, 2 -> v1 big, 3 -> v1 small
   for (int t = 0; t < T; ++t) {
     GemmOperands p;
-    p.M = M; p.Nu = H; p.group_stride = H; p.ldb = ldw;
+    p.M = M; p.Nu = H; p.group_stride = H; p.ldb = ldw; p.nk1 = p.nk2 = 0;
     const bf16_t* hprev = hbuf + (long)t * M * H;
+    int k1, k2;
     if (hoist) {
-      p.A1 = hprev; p.lda1 = H; p.nk1 = (t == 0) ? 0 : H / 64; p.A2 = hprev; p.lda2 = H; p.nk2 = 0;
+      p.A1 = hprev; p.lda1 = H; k1 = (t == 0) ? 0 : H; p.A2 = hprev; p.lda2 = H; k2 = 0;
       p.B = wT + Kin;
     } else {
-      p.A1 = x + (long)t * M * Kin; p.lda1 = Kin; p.nk1 = Kin / 64;
-      p.A2 = hprev; p.lda2 = H; p.nk2 = (t == 0) ? 0 : H / 64;
+      p.A1 = x + (long)t * M * Kin; p.lda1 = Kin; k1 = Kin;
+      p.A2 = hprev; p.lda2 = H; k2 = (t == 0) ? 0 : H;
       p.B = wT;
     }
     LstmFwdParams e;
@@ -180,12 +253,11 @@ extern "C" int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const f
     e.gates = gates ? gates + (long)t * M * 4 * H : nullptr;
     e.c_cache = c_cache ? c_cache + (long)t * M * H : nullptr;
     e.M = M; e.H = H;
-    if (big) {
-      const int tm = ceil_div(M, CfgLstmBig::BM), tn = ceil_div(H, CfgLstmBig::BU);
-      hipLaunchKernelGGL(lstm_fwd_step_kernel<CfgLstmBig>, dim3(tm * tn), dim3(CfgLstmBig::NT), 0, st, p, e, tm, tn);
-    } else {
-      const int tm = ceil_div(M, CfgLstmSmall::BM), tn = ceil_div(H, CfgLstmSmall::BU);
-      hipLaunchKernelGGL(lstm_fwd_step_kernel<CfgLstmSmall>, dim3(tm * tn), dim3(CfgLstmSmall::NT), 0, st, p, e, tm, tn);
+    switch (pick) {
+      case 0: launch_lstm_fwd<CfgLstmV2a>(p, e, k1, k2, st); break;
+      case 1: launch_lstm_fwd<CfgLstmV2b>(p, e, k1, k2, st); break;
+      case 2: launch_lstm_fwd<CfgLstmBig>(p, e, k1, k2, st); break;
+      default: launch_lstm_fwd<CfgLstmSmall>(p, e, k1, k2, st); break;
     }
   }
   EVC_LAUNCH_CHECK();
@@ -211,13 +283,13 @@ struct LstmBwdParams {
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::NT) void lstm_bwd_step_kernel(GemmOperands p, LstmBwdParams e, int tiles_m, int tiles_n) {
   static_assert(Cfg::G == 1, "bwd step is a plain GEMM over the H units");
-  __shared__ __attribute__((aligned(16))) char lds[Cfg::LDS_BYTES];
   const int nwg = tiles_m * tiles_n;
   const int id = xcd_remap(blockIdx.x, nwg);
-  const int tm = id % tiles_m, tn = id / tiles_m;
+  int tm, tn;
+  tile_of(id, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * Cfg::BM, u0 = tn * Cfg::BU;
   f32x4 acc[Cfg::MI][1][Cfg::NI];
-  gemm_mainloop<Cfg>(p, m0, u0, lds, acc);
+  run_mainloop<Cfg, 1>(p, m0, u0, acc);
   TileCoords<Cfg> tc;
   const int H = e.H;
 #pragma unroll
@@ -263,19 +335,31 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_bwd_step_kernel(GemmOperands p, 
   }
 }
 
+template <class Cfg>
+static inline void launch_lstm_bwd(GemmOperands p, const LstmBwdParams& e, int k1, hipStream_t st) {
+  p.nk1 = k1 / kdiv<Cfg>();
+  const int tm = ceil_div(e.M, Cfg::BM), tn = ceil_div(e.H, Cfg::BU);
+  launch_cfg<Cfg>(lstm_bwd_step_kernel<Cfg>, tm * tn, st, p, e, tm, tn);
+}
+
 extern "C" int evc_lstm_layer_bwd(const evc_bf16* w, const int32_t* len, int T, int M, int Kin, int H,
                                   const evc_bf16* gates, const float* c_cache,
                                   const float* dS_c, const float* dS_h, int64_t ld_dS,
                                   const float* dh_above, float* dc_ws, evc_bf16* dz, void* stream) {
   EVC_REQUIRE(T > 0 && M > 0 && H > 0 && Kin > 0 && H % 64 == 0, EVC_ERR_BAD_SHAPE, "evc_lstm_layer_bwd: bad shape");
   hipStream_t st = (hipStream_t)stream;
-  const bool big = (long)ceil_div(M, 128) * ceil_div(H, 128) >= 96;
+  const double c_v2 = tile_cost((long)ceil_div(M, 256) * ceil_div(H, 256), 256, 256, 1, 1.0);
+  const double c_big = tile_cost((long)ceil_div(M, 128) * ceil_div(H, 128), 128, 128, 2, 1.3);
+  const double c_small = tile_cost((long)ceil_div(M, 64) * ceil_div(H, 64), 64, 64, 4, 2.6);
+  int pick = (c_v2 <= c_big && c_v2 <= c_small) ? 0 : (c_big <= c_small ? 1 : 2);
+  if (forced_tile()) pick = forced_tile() - 1;
   for (int t = T - 1; t >= 0; --t) {
     GemmOperands p;
-    p.M = M; p.Nu = H; p.group_stride = 0;
-    p.A1 = dz + (long)(t + 1 < T ? t + 1 : t) * M * 4 * H; p.lda1 = 4L * H; p.nk1 = (t == T - 1) ? 0 : 4 * H / 64;
-    p.A2 = p.A1; p.lda2 = p.lda1; p.nk2 = 0;
+    p.M = M; p.Nu = H; p.group_stride = 0; p.nk1 = p.nk2 = 0;
+    p.A1 = dz + (long)(t + 1 < T ? t + 1 : t) * M * 4 * H; p.lda1 = 4L * H;
+    p.A2 = p.A1; p.lda2 = p.lda1;
     p.B = w + (long)Kin * 4 * H; p.ldb = 4L * H;   // rows Kin..Kin+H of the TF kernel = Wh [H][4H]
+    const int k1 = (t == T - 1) ? 0 : 4 * H;
     LstmBwdParams e;
     e.len = len; e.t = t;
     e.gates = gates + (long)t * M * 4 * H;
@@ -284,12 +368,10 @@ extern "C" int evc_lstm_layer_bwd(const evc_bf16* w, const int32_t* len, int T, 
     e.dS_c = dS_c; e.dS_h = dS_h; e.ld_dS = ld_dS;
     e.dh_above = dh_above ? dh_above + (long)t * M * H : nullptr;
     e.dc_ws = dc_ws; e.dz = dz + (long)t * M * 4 * H; e.M = M; e.H = H;
-    if (big) {
-      const int tm = ceil_div(M, CfgPlainBig::BM), tn = ceil_div(H, CfgPlainBig::BU);
-      hipLaunchKernelGGL(lstm_bwd_step_kernel<CfgPlainBig>, dim3(tm * tn), dim3(CfgPlainBig::NT), 0, st, p, e, tm, tn);
-    } else {
-      const int tm = ceil_div(M, CfgPlainSmall::BM), tn = ceil_div(H, CfgPlainSmall::BU);
-      hipLaunchKernelGGL(lstm_bwd_step_kernel<CfgPlainSmall>, dim3(tm * tn), dim3(CfgPlainSmall::NT), 0, st, p, e, tm, tn);
+    switch (pick) {
+      case 0: launch_lstm_bwd<CfgPlainV2>(p, e, k1, st); break;
+      case 1: launch_lstm_bwd<CfgPlainBig>(p, e, k1, st); break;
+      default: launch_lstm_bwd<CfgPlainSmall>(p, e, k1, st); break;
     }
   }
   EVC_LAUNCH_CHECK();

@@ -91,8 +91,7 @@ class LstmStack:
             self.KP = ops.round_up(T * M, 64)
             self.dz = torch.empty((T, M, 4 * H), dtype=BF16, device=dev)
             self.dzT = torch.empty((4 * H, self.KP), dtype=BF16, device=dev)
-            self.inT = torch.empty((max(self.kin), self.KP), dtype=BF16, device=dev)
-            self.hT = torch.empty((H, self.KP), dtype=BF16, device=dev)
+            self.inhT = torch.empty((max(self.kin) + H, self.KP), dtype=BF16, device=dev)   # [x_in ; h_prev]^T
             self.dc_ws = torch.empty((M, H), dtype=F32, device=dev)
             self.dx = [torch.empty((T * M, self.kin[l]), dtype=F32, device=dev) if (l > 0) else None for l in range(L)]
 
@@ -168,12 +167,9 @@ class LstmStack:
             KP = self.KP
             ops.transpose_to_bf16(dz2, T * M, 4 * H, self.dzT, KP)
             layer_in = self.x_in if l == 0 else self.hbuf[l - 1][1:]
-            inT = self.inT[:kin]
-            ops.transpose_to_bf16(layer_in.reshape(T * M, kin), T * M, kin, inT, KP)
-            ops.transpose_to_bf16(self.hbuf[l][:T].reshape(T * M, H), T * M, H, self.hT, KP)
-            gW = tw.store.g(kn)                                     # [4H][kin+H] f32
-            ops.gemm_nt(self.dzT, inT, 4 * H, kin, KP, gW, ldc=kin + H)
-            ops.gemm_nt(self.dzT, self.hT, 4 * H, H, KP, gW[:, kin:], ldc=kin + H)
+            ops.transpose_to_bf16(layer_in.reshape(T * M, kin), T * M, kin, self.inhT[:kin], KP)
+            ops.transpose_to_bf16(self.hbuf[l][:T].reshape(T * M, H), T * M, H, self.inhT[kin:kin + H], KP)
+            ops.gemm_nt(self.dzT, self.inhT, 4 * H, kin + H, KP, tw.store.g(kn))   # one GEMM, N = kin+H
             ops.rowsum_bf16(self.dzT, 4 * H, KP, tw.store.g(bn))
         return dx_out
 
