@@ -157,7 +157,7 @@ extern "C" int evc_frame_counts(const int32_t* num_frames, int B, int every_n, i
 // ---------------------------------------------------------------------------
 template <bool F32>
 __global__ __launch_bounds__(256) void transpose_kernel(const void* __restrict__ in, long ld_in, int R, int C,
-                                                        bf16_t* __restrict__ out, long ld_out, int Rpad) {
+                                                        bf16_t* __restrict__ out, long ld_out, int Rpad, int il_H) {
   __shared__ bf16_t tile[64][66];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
@@ -175,18 +175,24 @@ __global__ __launch_bounds__(256) void transpose_kernel(const void* __restrict__
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int c = c0 + ty + 4 * i, r = r0 + tx;
-    if (c < C && r < Rpad) out[(long)c * ld_out + r] = tile[tx][ty + 4 * i];
+    // il_H > 0: input row r = g*H + u lands in output column u*4 + g (gate-interleaved K order)
+    // il_H < 0: input COLUMN c = u*4 + g (gate-interleaved) lands in output row g*H + u (TF order), H = -il_H
+    const int ro = (il_H > 0 && r < 4 * il_H) ? (r % il_H) * 4 + r / il_H : r;
+    const int co = (il_H < 0) ? (c & 3) * (-il_H) + (c >> 2) : c;
+    if (c < C && r < Rpad) out[(long)co * ld_out + ro] = tile[tx][ty + 4 * i];
   }
 }
 
 extern "C" int evc_transpose_to_bf16(const void* in, int in_f32, int64_t ld_in, int R, int C,
-                                     evc_bf16* out, int64_t ld_out, int Rpad, void* stream) {
+                                     evc_bf16* out, int64_t ld_out, int Rpad, int interleave_H, void* stream) {
   EVC_REQUIRE(R > 0 && C > 0 && Rpad >= R && ld_out >= Rpad, EVC_ERR_BAD_SHAPE, "evc_transpose_to_bf16: bad shape");
+  EVC_REQUIRE(interleave_H <= 0 || R == 4 * interleave_H, EVC_ERR_BAD_SHAPE, "evc_transpose_to_bf16: interleave_H needs R == 4*H");
+  EVC_REQUIRE(interleave_H >= 0 || C == -4 * interleave_H, EVC_ERR_BAD_SHAPE, "evc_transpose_to_bf16: interleave_H < 0 needs C == 4*H");
   dim3 grid((Rpad + 63) / 64, (C + 63) / 64);
   if (in_f32)
-    hipLaunchKernelGGL(transpose_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, R, C, out, ld_out, Rpad);
+    hipLaunchKernelGGL(transpose_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, R, C, out, ld_out, Rpad, interleave_H);
   else
-    hipLaunchKernelGGL(transpose_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, R, C, out, ld_out, Rpad);
+    hipLaunchKernelGGL(transpose_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, in, ld_in, R, C, out, ld_out, Rpad, interleave_H);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }

@@ -55,12 +55,23 @@ static inline double tile_cost(long tiles, int bm, int bn, int /*occ*/, double c
 // ===========================================================================
 struct StoreParams {
   void* C; long ldc; int M, N; const float* bias; int out_bf16; int accumulate;
+  int splits, ksteps_per_split;   // split-K: blockIdx = split * tiles + tile; partial sums joined by f32 atomics
 };
 
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::NT) void gemm_nt_kernel(GemmOperands p, StoreParams s, int tiles_m, int tiles_n) {
   const int nwg = tiles_m * tiles_n;
-  const int id = xcd_remap(blockIdx.x, nwg);
+  int bid = blockIdx.x, split = 0;
+  if (s.splits > 1) {               // this workgroup's K range (wave-uniform)
+    split = bid / nwg;
+    bid -= split * nwg;
+    const int k0 = split * s.ksteps_per_split;
+    const int kstep = is_v2<Cfg>::value ? 32 : 64;
+    p.A1 += (long)k0 * kstep;
+    p.B += (long)k0 * kstep;
+    p.nk1 = min(s.ksteps_per_split, p.nk1 - k0);
+  }
+  const int id = xcd_remap(bid, nwg);
   int tm, tn;
   tile_of(id, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * Cfg::BM, u0 = tn * Cfg::BU;
@@ -73,14 +84,16 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_nt_kernel(GemmOperands p, StoreP
     for (int ni = 0; ni < Cfg::NI; ++ni) {
       const int n = u0 + tc.unit0 + ni * 16;
       if (n >= s.N) continue;
-      const float b = s.bias ? s.bias[n] : 0.f;
+      const float b = (s.bias && split == 0) ? s.bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + tc.row0 + mi * 16 + r;
         if (m >= s.M) continue;
         float v = acc[mi][0][ni][r] + b;
         const long o = (long)m * s.ldc + n;
-        if (s.out_bf16) {
+        if (s.splits > 1) {
+          atomicAdd((float*)s.C + o, v);          // one global_atomic_add_f32 per element, executed at the memory side
+        } else if (s.out_bf16) {
           ((bf16_t*)s.C)[o] = f32_to_bf16(v);
         } else {
           float* cp = (float*)s.C + o;
@@ -96,10 +109,12 @@ typedef TileCfg<64, 1, 64, 2, 2> CfgPlainSmall;   // 64x64 for skinny problems
 typedef TileCfg2<256, 1, 256, 2, 4, 5, true> CfgPlainV2;   // 256x256, 8 waves (2x4), 128x64 per wave, 5-deep ring (160 KiB)
 
 template <class Cfg>
-static inline void launch_gemm(GemmOperands p, const StoreParams& s, int K, hipStream_t st) {
+static inline void launch_gemm(GemmOperands p, StoreParams s, int K, int splits, hipStream_t st) {
   p.nk1 = K / kdiv<Cfg>();
   const int tm = ceil_div(s.M, Cfg::BM), tn = ceil_div(s.N, Cfg::BU);
-  launch_cfg<Cfg>(gemm_nt_kernel<Cfg>, tm * tn, st, p, s, tm, tn);
+  s.splits = splits;
+  s.ksteps_per_split = ceil_div(p.nk1, splits);
+  launch_cfg<Cfg>(gemm_nt_kernel<Cfg>, tm * tn * splits, st, p, s, tm, tn);
 }
 
 extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, void* C, int64_t ldc,
@@ -112,17 +127,34 @@ extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
   GemmOperands p;
   p.A1 = A; p.lda1 = lda; p.nk1 = 0; p.A2 = A; p.lda2 = lda; p.nk2 = 0;
   p.B = B; p.ldb = ldb; p.group_stride = 0; p.M = M; p.Nu = N;
-  StoreParams s{C, ldc, M, N, bias, out_bf16, accumulate};
+  StoreParams s{C, ldc, M, N, bias, out_bf16, accumulate, 1, 0};
   hipStream_t st = (hipStream_t)stream;
+  // Split-K: a long-K product with too few 256x256 tiles to fill the 256 CUs (the weight-gradient
+  // GEMMs: M=4H, N~1-2K, K = T*M rows) is cut along K; partial tiles are summed with f32 atomics
+  // into a zeroed C (63 MB of atomic traffic at ~1.3 TB/s << the ~0.7 ms it saves per GEMM).
+  {
+    const long t2 = (long)ceil_div(M, 256) * ceil_div(N, 256);
+    if (!out_bf16 && t2 <= 128 && K >= 8192 && forced_tile() == 0) {
+      int splits = (int)(256 / t2);
+      const int max_by_k = K / 2048;                  // keep >= 64 K steps per split
+      if (splits > max_by_k) splits = max_by_k;
+      if (splits > 1) {
+        if (!accumulate) EVC_CHECK_HIP(hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st));
+        launch_gemm<CfgPlainV2>(p, s, K, splits, st);
+        EVC_LAUNCH_CHECK();
+        return EVC_OK;
+      }
+    }
+  }
   // per-flop cost factors measured on MI355X (scripts/gemm_bench.py): v2 ~1000 TF/s, v1 128^2 ~800, v1 64^2 ~400
   const double c_v2 = tile_cost((long)ceil_div(M, 256) * ceil_div(N, 256), 256, 256, 1, 1.0);
   const double c_big = tile_cost((long)ceil_div(M, 128) * ceil_div(N, 128), 128, 128, 2, 1.3);
   const double c_small = tile_cost((long)ceil_div(M, 64) * ceil_div(N, 64), 64, 64, 4, 2.6);
   int pick = (c_v2 <= c_big && c_v2 <= c_small) ? 1 : (c_big <= c_small ? 2 : 3);
   if (forced_tile()) pick = forced_tile();
-  if (pick == 1) launch_gemm<CfgPlainV2>(p, s, K, st);
-  else if (pick == 2) launch_gemm<CfgPlainBig>(p, s, K, st);
-  else launch_gemm<CfgPlainSmall>(p, s, K, st);
+  if (pick == 1) launch_gemm<CfgPlainV2>(p, s, K, 1, st);
+  else if (pick == 2) launch_gemm<CfgPlainBig>(p, s, K, 1, st);
+  else launch_gemm<CfgPlainSmall>(p, s, K, 1, st);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }
@@ -135,11 +167,15 @@ struct LstmFwdParams {
   const float* bias;                 // [4H]
   const int* len; int t;
   float* c_state; float* h_state; long ld_state;
-  bf16_t* hout;                      // [M][H] slab t+1
-  bf16_t* gates;                     // [M][4H] slab t or NULL
-  float* c_cache;                    // [M][H] slab t or NULL
+  bf16_t* hout;                      // [M][H] slab t+1 (row-major: next step's A operand)
+  bf16_t* hT; long ld_hT;            // h_t transposed, column base of slab t+1: hT[u*ld + m] (or NULL)
+  uint4* tape;                       // [M][H] 16-byte records of slab t (or NULL): {i,j | f,o | c_new | c_old}
   int M, H;
 };
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
 
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, LstmFwdParams e, int tiles_m, int tiles_n) {
@@ -160,13 +196,17 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, 
     const float bi = e.bias[u], bj = e.bias[H + u], bf = e.bias[2 * H + u] + 1.0f /* forget_bias */, bo = e.bias[3 * H + u];
 #pragma unroll
     for (int mi = 0; mi < Cfg::MI; ++mi) {
+      const int mb = m0 + tc.row0 + mi * 16;      // this lane's 4 consecutive rows mb..mb+3
+      if (mb >= e.M) continue;
+      float hv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m0 + tc.row0 + mi * 16 + r;
+        const int m = mb + r;
+        hv[r] = 0.f;
         if (m >= e.M) continue;
-        const bool active = e.t < e.len[m];
+        const int ln = e.len[m];
         const long hu = (long)m * H + u;
-        if (!active) {            // dynamic_rnn: state copied through, zero output
+        if (e.t >= ln) {            // dynamic_rnn: state copied through, zero output
           e.hout[hu] = 0;
           continue;
         }
@@ -182,12 +222,17 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, 
         const float c_new = c_old * gf + gi * gj;
         const float h_new = tanhf_(c_new) * go;
         e.c_state[su] = c_new;
-        e.h_state[su] = h_new;
+        if (e.t == ln - 1) e.h_state[su] = h_new;      // the returned state is the one after step len-1
         e.hout[hu] = f32_to_bf16(h_new);
-        if (e.gates) {
-          bf16_t* gp = e.gates + (long)m * 4 * H + u;
-          gp[0] = f32_to_bf16(gi); gp[H] = f32_to_bf16(gj); gp[2 * H] = f32_to_bf16(gf); gp[3 * H] = f32_to_bf16(go);
-          e.c_cache[hu] = c_new;
+        hv[r] = h_new;
+        if (e.tape) e.tape[hu] = make_uint4(pack_bf16x2(gi, gj), pack_bf16x2(gf, go), __float_as_uint(c_new), __float_as_uint(c_old));
+      }
+      if (e.hT) {                   // 4 consecutive rows of one unit = 8 contiguous bytes of h^T
+        bf16_t* tp = e.hT + (long)u * e.ld_hT + mb;
+        if (mb + 3 < e.M) {
+          *(uint2*)tp = make_uint2(pack_bf16x2(hv[0], hv[1]), pack_bf16x2(hv[2], hv[3]));
+        } else {
+          for (int r = 0; r < 4 && mb + r < e.M; ++r) tp[r] = f32_to_bf16(hv[r]);
         }
       }
     }
@@ -209,18 +254,21 @@ static inline void launch_lstm_fwd(GemmOperands p, const LstmFwdParams& e, int k
 extern "C" int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const float* bias, const int32_t* len,
                                   int T, int M, int Kin, int H, int hoist, float* zx_ws,
                                   evc_bf16* hbuf, float* c_state, float* h_state, int64_t ld_state,
-                                  evc_bf16* gates, float* c_cache, void* stream) {
+                                  void* tape, evc_bf16* hT, int64_t ld_hT, void* stream) {
   EVC_REQUIRE(T > 0 && M > 0 && H > 0 && Kin > 0, EVC_ERR_BAD_SHAPE, "evc_lstm_layer_fwd: bad shape");
   EVC_REQUIRE(Kin % 64 == 0 && H % 64 == 0, EVC_ERR_BAD_SHAPE,
               "evc_lstm_layer_fwd: Kin=%d and H=%d must be multiples of 64", Kin, H);
   EVC_REQUIRE(!hoist || zx_ws, EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd: hoist needs zx_ws");
-  EVC_REQUIRE((gates == nullptr) == (c_cache == nullptr), EVC_ERR_BAD_ARG, "gates and c_cache go together");
+  EVC_REQUIRE(!hT || (M % 4 == 0 && ld_hT % 4 == 0 && ld_hT >= (long)(T + 1) * M && ((uintptr_t)hT % 8) == 0), EVC_ERR_BAD_ALIGN,
+              "evc_lstm_layer_fwd: hT needs M %% 4 == 0, ld_hT %% 4 == 0 and ld_hT >= (T+1)*M (M=%d ld=%ld)", M, (long)ld_hT);
+  EVC_REQUIRE(!tape || ((uintptr_t)tape % 16) == 0, EVC_ERR_BAD_ALIGN, "evc_lstm_layer_fwd: tape must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const long ldw = Kin + H;
   // zero state (rows with len==0 keep an all-zero state) and h_{-1}
   EVC_CHECK_HIP(hipMemset2DAsync(c_state, ld_state * sizeof(float), 0, (size_t)H * sizeof(float), M, st));
   EVC_CHECK_HIP(hipMemset2DAsync(h_state, ld_state * sizeof(float), 0, (size_t)H * sizeof(float), M, st));
   EVC_CHECK_HIP(hipMemsetAsync(hbuf, 0, (size_t)M * H * sizeof(bf16_t), st));
+  if (hT) EVC_CHECK_HIP(hipMemset2DAsync(hT, ld_hT * sizeof(bf16_t), 0, (size_t)M * sizeof(bf16_t), H, st));   // h_{-1}^T = 0
   if (hoist) {
     int rc = evc_gemm_nt(x, Kin, wT, ldw, zx_ws, 4L * H, T * M, 4 * H, Kin, nullptr, 0, 0, stream);
     if (rc) return rc;
@@ -250,8 +298,8 @@ extern "C" int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const f
     e.bias = bias; e.len = len; e.t = t;
     e.c_state = c_state; e.h_state = h_state; e.ld_state = ld_state;
     e.hout = hbuf + (long)(t + 1) * M * H;
-    e.gates = gates ? gates + (long)t * M * 4 * H : nullptr;
-    e.c_cache = c_cache ? c_cache + (long)t * M * H : nullptr;
+    e.hT = hT ? hT + (long)(t + 1) * M : nullptr; e.ld_hT = ld_hT;
+    e.tape = tape ? (uint4*)tape + (long)t * M * H : nullptr;
     e.M = M; e.H = H;
     switch (pick) {
       case 0: launch_lstm_fwd<CfgLstmV2a>(p, e, k1, k2, st); break;
@@ -270,13 +318,11 @@ extern "C" int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const f
 // ===========================================================================
 struct LstmBwdParams {
   const int* len; int t;
-  const bf16_t* gates;      // slab t   [M][4H]
-  const float* c_t;         // slab t   [M][H]
-  const float* c_prev;      // slab t-1 [M][H] or NULL (t == 0)
+  const uint4* tape;        // slab t   [M][H] records {i,j | f,o | c_new | c_old}
   const float* dS_c; const float* dS_h; long ld_dS;
   const float* dh_above;    // slab t [M][H] or NULL
   float* dc_ws;             // [M][H]
-  bf16_t* dz;               // slab t [M][4H]
+  uint2* dz4;               // slab t [M][H] gate-interleaved: 4 bf16 (dz_i, dz_j, dz_f, dz_o) per (row, unit)
   int M, H;
 };
 
@@ -303,13 +349,12 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_bwd_step_kernel(GemmOperands p, 
         const int m = m0 + tc.row0 + mi * 16 + r;
         if (m >= e.M) continue;
         const int ln = e.len[m];
-        bf16_t* dzp = e.dz + (long)m * 4 * H + u;
+        const long hu = (long)m * H + u;
         if (e.t >= ln) {  // inactive: state passes through, no gate gradient
-          dzp[0] = 0; dzp[H] = 0; dzp[2 * H] = 0; dzp[3 * H] = 0;
+          e.dz4[hu] = make_uint2(0u, 0u);
           continue;
         }
         const bool last = (e.t == ln - 1);
-        const long hu = (long)m * H + u;
         float dh = acc[mi][0][ni][r];
         float dc_in;
         if (last) {
@@ -320,16 +365,15 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_bwd_step_kernel(GemmOperands p, 
           dc_in = e.dc_ws[hu];
         }
         if (e.dh_above) dh += e.dh_above[hu];
-        const bf16_t* gp = e.gates + (long)m * 4 * H + u;
-        const float gi = bf16_to_f32(gp[0]), gj = bf16_to_f32(gp[H]), gf = bf16_to_f32(gp[2 * H]), go = bf16_to_f32(gp[3 * H]);
-        const float tcv = tanhf_(e.c_t[hu]);
-        const float cp = e.c_prev ? e.c_prev[hu] : 0.f;
+        const uint4 rec = e.tape[hu];
+        const float gi = __uint_as_float(rec.x << 16), gj = __uint_as_float(rec.x & 0xffff0000u);
+        const float gf = __uint_as_float(rec.y << 16), go = __uint_as_float(rec.y & 0xffff0000u);
+        const float tcv = tanhf_(__uint_as_float(rec.z));
+        const float cp = __uint_as_float(rec.w);
         const float dc = dc_in + dh * go * (1.f - tcv * tcv);
         e.dc_ws[hu] = dc * gf;
-        dzp[0] = f32_to_bf16(dc * gj * gi * (1.f - gi));
-        dzp[H] = f32_to_bf16(dc * gi * (1.f - gj * gj));
-        dzp[2 * H] = f32_to_bf16(dc * cp * gf * (1.f - gf));
-        dzp[3 * H] = f32_to_bf16(dh * tcv * go * (1.f - go));
+        e.dz4[hu] = make_uint2(pack_bf16x2(dc * gj * gi * (1.f - gi), dc * gi * (1.f - gj * gj)),
+                               pack_bf16x2(dc * cp * gf * (1.f - gf), dh * tcv * go * (1.f - go)));
       }
     }
   }
@@ -342,32 +386,31 @@ static inline void launch_lstm_bwd(GemmOperands p, const LstmBwdParams& e, int k
   launch_cfg<Cfg>(lstm_bwd_step_kernel<Cfg>, tm * tn, st, p, e, tm, tn);
 }
 
-extern "C" int evc_lstm_layer_bwd(const evc_bf16* w, const int32_t* len, int T, int M, int Kin, int H,
-                                  const evc_bf16* gates, const float* c_cache,
-                                  const float* dS_c, const float* dS_h, int64_t ld_dS,
-                                  const float* dh_above, float* dc_ws, evc_bf16* dz, void* stream) {
+extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int T, int M, int Kin, int H,
+                                  const void* tape, const float* dS_c, const float* dS_h, int64_t ld_dS,
+                                  const float* dh_above, float* dc_ws, evc_bf16* dz4, void* stream) {
   EVC_REQUIRE(T > 0 && M > 0 && H > 0 && Kin > 0 && H % 64 == 0, EVC_ERR_BAD_SHAPE, "evc_lstm_layer_bwd: bad shape");
+  EVC_REQUIRE(tape && ((uintptr_t)tape % 16) == 0 && ((uintptr_t)dz4 % 16) == 0, EVC_ERR_BAD_ALIGN, "evc_lstm_layer_bwd: tape/dz4 alignment");
   hipStream_t st = (hipStream_t)stream;
-  const double c_v2 = tile_cost((long)ceil_div(M, 256) * ceil_div(H, 256), 256, 256, 1, 1.0);
-  const double c_big = tile_cost((long)ceil_div(M, 128) * ceil_div(H, 128), 128, 128, 2, 1.3);
-  const double c_small = tile_cost((long)ceil_div(M, 64) * ceil_div(H, 64), 64, 64, 4, 2.6);
-  int pick = (c_v2 <= c_big && c_v2 <= c_small) ? 0 : (c_big <= c_small ? 1 : 2);
+  // The BPTT step is dominated by its epilogue (tape / dc / dz traffic per element), not by the
+  // [M,4H]x[4H,H] GEMM: 64x64 tiles at 4 workgroups per CU overlap one workgroup's epilogue with the
+  // others' main loops and measured fastest at every M (120 vs 141 us at M=5120; 44 vs 93 at M=1280).
+  int pick = 2;
   if (forced_tile()) pick = forced_tile() - 1;
   for (int t = T - 1; t >= 0; --t) {
     GemmOperands p;
     p.M = M; p.Nu = H; p.group_stride = 0; p.nk1 = p.nk2 = 0;
-    p.A1 = dz + (long)(t + 1 < T ? t + 1 : t) * M * 4 * H; p.lda1 = 4L * H;
+    p.A1 = dz4 + (long)(t + 1 < T ? t + 1 : t) * M * 4 * H; p.lda1 = 4L * H;   // gate-interleaved K index u*4+g
     p.A2 = p.A1; p.lda2 = p.lda1;
-    p.B = w + (long)Kin * 4 * H; p.ldb = 4L * H;   // rows Kin..Kin+H of the TF kernel = Wh [H][4H]
+    p.B = w_il + (long)Kin * 4 * H; p.ldb = 4L * H;   // rows Kin..Kin+H of the kernel = Wh [H][4H], same K order
     const int k1 = (t == T - 1) ? 0 : 4 * H;
     LstmBwdParams e;
     e.len = len; e.t = t;
-    e.gates = gates + (long)t * M * 4 * H;
-    e.c_t = c_cache + (long)t * M * H;
-    e.c_prev = t > 0 ? c_cache + (long)(t - 1) * M * H : nullptr;
+    e.tape = (const uint4*)tape + (long)t * M * H;
     e.dS_c = dS_c; e.dS_h = dS_h; e.ld_dS = ld_dS;
     e.dh_above = dh_above ? dh_above + (long)t * M * H : nullptr;
-    e.dc_ws = dc_ws; e.dz = dz + (long)t * M * 4 * H; e.M = M; e.H = H;
+    e.dc_ws = dc_ws; e.dz4 = (uint2*)dz4 + (long)t * M * H;
+    e.M = M; e.H = H;
     switch (pick) {
       case 0: launch_lstm_bwd<CfgPlainV2>(p, e, k1, st); break;
       case 1: launch_lstm_bwd<CfgPlainBig>(p, e, k1, st); break;

@@ -46,10 +46,12 @@ def gemm_nt(A, B, M, N, K, out, bias=None, accumulate=False, lda=None, ldb=None,
     return out
 
 
-def transpose_to_bf16(x, R, C, out, Rpad, ld_in=None):
-    """out[c][r] = x[r][c]; out is [C, >=Rpad] bf16 with columns [R,Rpad) zeroed."""
+def transpose_to_bf16(x, R, C, out, Rpad, ld_in=None, interleave_H=0):
+    """out[c][r] = x[r][c]; out is [C, >=Rpad] bf16 with columns [R,Rpad) zeroed.
+    interleave_H: write input row g*H+u to output column u*4+g (gate-interleaved K order)."""
     ld_in = x.stride(0) if ld_in is None else ld_in
-    _lib.call("evc_transpose_to_bf16", _p(x), 1 if x.dtype == F32 else 0, ld_in, R, C, _p(out), out.stride(0), Rpad, _stream())
+    _lib.call("evc_transpose_to_bf16", _p(x), 1 if x.dtype == F32 else 0, ld_in, R, C, _p(out), out.stride(0), Rpad,
+              interleave_H, _stream())
     return out
 
 
@@ -97,14 +99,14 @@ def frame_counts(num_frames, every_n, num_chunks, chunk_len, max_frames=300):
 
 # ---------------------------------------------------------------------------
 def lstm_layer_fwd(x, wT, bias, lens, T, M, Kin, H, hbuf, c_state, h_state, ld_state,
-                   gates=None, c_cache=None, hoist=False, zx_ws=None):
+                   tape=None, hT=None, hoist=False, zx_ws=None):
     _lib.call("evc_lstm_layer_fwd", _p(x), _p(wT), _p(bias), _p(lens), T, M, Kin, H, 1 if hoist else 0, _p(zx_ws),
-              _p(hbuf), _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_cache), _stream())
+              _p(hbuf), _p(c_state), _p(h_state), ld_state, _p(tape), _p(hT), hT.stride(0) if hT is not None else 0, _stream())
 
 
-def lstm_layer_bwd(w, lens, T, M, Kin, H, gates, c_cache, dS_c, dS_h, ld_dS, dh_above, dc_ws, dz):
-    _lib.call("evc_lstm_layer_bwd", _p(w), _p(lens), T, M, Kin, H, _p(gates), _p(c_cache), _p(dS_c), _p(dS_h), ld_dS,
-              _p(dh_above), _p(dc_ws), _p(dz), _stream())
+def lstm_layer_bwd(w_il, lens, T, M, Kin, H, tape, dS_c, dS_h, ld_dS, dh_above, dc_ws, dz4):
+    _lib.call("evc_lstm_layer_bwd", _p(w_il), _p(lens), T, M, Kin, H, _p(tape), _p(dS_c), _p(dS_h), ld_dS,
+              _p(dh_above), _p(dc_ws), _p(dz4), _stream())
 
 
 # ---------------------------------------------------------------------------

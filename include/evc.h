@@ -96,32 +96,45 @@ int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, 
  * c_state/h_state: f32 final state columns, row stride ld_state (so they can
  *        point into the [M, 2*L*H] state tensor concat([c0,h0,c1,h1]));
  *        zero for len == 0.
- * gates [T][M][4H] bf16 (post-activation i,j,f,o) and c_cache [T][M][H] f32 are
- *        saved for the backward pass when non-NULL.
+ * tape  [T][M][H] 16-byte records {bf16 i, j | bf16 f, o | f32 c_new | f32 c_old}
+ *        (post-activation gates and cell values) saved for the backward pass, or NULL.
+ * hT    [H][ld_hT] bf16 or NULL: h transposed, written by the step epilogue as
+ *        8-byte (4-row) stores: hT[u][(t+1)*M + m] = h_t[m][u], columns [0,M) = 0.
+ *        It is the K-contiguous operand of the weight-gradient GEMM (h_prev^T =
+ *        columns [0,T*M), and the next layer's input^T = columns [M,(T+1)*M)).
+ *        Needs M % 4 == 0, ld_hT % 4 == 0, ld_hT >= (T+1)*M.
  */
 int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const float* bias, const int32_t* len,
                        int T, int M, int Kin, int H, int hoist, float* zx_ws,
                        evc_bf16* hbuf, float* c_state, float* h_state, int64_t ld_state,
-                       evc_bf16* gates, float* c_cache, void* stream);
+                       void* tape, evc_bf16* hT, int64_t ld_hT, void* stream);
 
 /* BPTT of the above (what tf.gradients builds inside
  * slim.learning.create_train_op, cs/train.py:329-334,413-418).
- * w   [Kin+H][4H] bf16 = kernel in TF layout (K-contiguous for dz . W^T)
+ * w_il [Kin+H][4H] bf16 = kernel in TF layout with the 4H axis GATE-INTERLEAVED
+ *        (column u*4+g holds TF column g*H+u; evc_transpose_to_bf16(..., interleave_H=H))
  * dS_c/dS_h: f32 gradient wrt the final c/h state, row stride ld_dS
  * dh_above [T][M][H] f32 or NULL: gradient arriving at h_t from the layer above
- * dc_ws [M][H] f32 scratch.   dz [T][M][4H] bf16 out (0 where t >= len).
+ * dc_ws [M][H] f32 scratch.
+ * dz4  [T][M][H][4] bf16 out: gate pre-activation gradients, gate-interleaved (0 where
+ *        t >= len); viewed as [T*M][4H] it is the A operand of dz . W^T with w_il.
+ *        (evc_transpose_to_bf16(dz4, ..., interleave_H=-H) gives dz^T in TF gate order for the
+ *        weight-gradient GEMM; writing it from this kernel's epilogue was measured 2.4x slower.)
  */
-int evc_lstm_layer_bwd(const evc_bf16* w, const int32_t* len, int T, int M, int Kin, int H,
-                       const evc_bf16* gates, const float* c_cache,
-                       const float* dS_c, const float* dS_h, int64_t ld_dS,
-                       const float* dh_above, float* dc_ws, evc_bf16* dz, void* stream);
+int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int T, int M, int Kin, int H,
+                       const void* tape, const float* dS_c, const float* dS_h, int64_t ld_dS,
+                       const float* dh_above, float* dc_ws, evc_bf16* dz4, void* stream);
 
 /* ---- layout helpers --------------------------------------------------------
  * out[c][r] = in[r][c], r < R, c < C; out has ld_out >= Rpad columns and
  * columns [R, Rpad) are zero-filled (Rpad % 64 == 0 keeps GEMM K aligned).
- * in_f32: 1 -> `in` is f32 (cast to bf16 on the way), 0 -> bf16. */
+ * in_f32: 1 -> `in` is f32 (cast to bf16 on the way), 0 -> bf16.
+ * interleave_H > 0 (needs R == 4*H): input row g*H+u is written to output column
+ * u*4+g instead of g*H+u - the gate-interleaved K order of evc_lstm_layer_bwd.
+ * interleave_H = -H (needs C == 4*H): the INPUT columns are gate-interleaved (dz4 of
+ * evc_lstm_layer_bwd); input column u*4+g is written to output row g*H+u (TF order). */
 int evc_transpose_to_bf16(const void* in, int in_f32, int64_t ld_in, int R, int C,
-                          evc_bf16* out, int64_t ld_out, int Rpad, void* stream);
+                          evc_bf16* out, int64_t ld_out, int Rpad, int interleave_H, void* stream);
 /* out_bf16[i] = bf16(in_f32[i]) for a [R, C] matrix (ld_in, ld_out). */
 int evc_cast_f32_to_bf16(const float* in, int64_t ld_in, int R, int C, evc_bf16* out, int64_t ld_out, void* stream);
 /* out[r] = sum_c in[r][c] (bf16 in, f32 out): bias gradients from dz^T. */
