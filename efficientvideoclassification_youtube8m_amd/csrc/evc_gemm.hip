@@ -106,6 +106,7 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_nt_kernel(GemmOperands p, StoreP
 
 typedef TileCfg<128, 1, 128, 2, 2> CfgPlainBig;   // 128x128, 4 waves, 4x4 MFMA tiles per wave
 typedef TileCfg<64, 1, 64, 2, 2> CfgPlainSmall;   // 64x64 for skinny problems
+typedef TileCfg<32, 1, 32, 2, 2> CfgPlainTiny;    // 32x32: M ~ batch recurrent steps (256 workgroups at M=256, H=1024)
 typedef TileCfg2<256, 1, 256, 2, 4, 5, true> CfgPlainV2;   // 256x256, 8 waves (2x4), 128x64 per wave, 5-deep ring (160 KiB)
 
 template <class Cfg>
@@ -396,6 +397,7 @@ extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int 
   // [M,4H]x[4H,H] GEMM: 64x64 tiles at 4 workgroups per CU overlap one workgroup's epilogue with the
   // others' main loops and measured fastest at every M (120 vs 141 us at M=5120; 44 vs 93 at M=1280).
   int pick = 2;
+  if ((long)ceil_div(M, 64) * ceil_div(H, 64) < 192) pick = 3;      // M ~ batch: 32x32 tiles to reach all 256 CUs
   if (forced_tile()) pick = forced_tile() - 1;
   for (int t = T - 1; t >= 0; --t) {
     GemmOperands p;
@@ -414,6 +416,7 @@ extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int 
     switch (pick) {
       case 0: launch_lstm_bwd<CfgPlainV2>(p, e, k1, st); break;
       case 1: launch_lstm_bwd<CfgPlainBig>(p, e, k1, st); break;
+      case 3: launch_lstm_bwd<CfgPlainTiny>(p, e, k1, st); break;
       default: launch_lstm_bwd<CfgPlainSmall>(p, e, k1, st); break;
     }
   }

@@ -99,7 +99,7 @@ class DistillGraph:
                  max_frames=300, num_inputs_to_lstm=20, num_inputs_l1_student=5, lstm_cells=1024, lstm_layers=2,
                  num_mixtures=2, base_learning_rate=0.001, learning_rate_decay=1.0,
                  learning_rate_decay_examples=4000000, regularization_penalty=2.0, clip_gradient_norm=1.0,
-                 count_rep_twice=True, device="cuda:0", seed=7, process_group=None):
+                 count_rep_twice=True, device="cuda:0", seed=7, process_group=None, overlap_towers=True):
         assert mode in ("teacher_student", "teacher", "student")
         self.mode, self.B, self.every_n = mode, batch_size, every_n
         self.max_frames, self.C1, self.C2 = max_frames, num_inputs_to_lstm, num_inputs_l1_student
@@ -122,6 +122,10 @@ class DistillGraph:
                                       lstm_layers, num_mixtures, device, True, "model_student", seed + 1)
         self.losses = torch.zeros(8, dtype=F32, device=self.device)
         self._dp_t = self._dp_s = self._ds_s = None
+        self.overlap_towers = overlap_towers
+        if self.device.type == "cuda":
+            self._side = torch.cuda.Stream(self.device)
+            self._ev_fwd, self._ev_student = torch.cuda.Event(), torch.cuda.Event()
 
     # ---- data-parallel gradient reduction -------------------------------------
     def _reduce_tower(self, tower, moe_first):
@@ -136,7 +140,12 @@ class DistillGraph:
     def step(self, x_raw, labels_u8, num_frames, apply=True):
         """x_raw [B,300,F] f32 (or uint8), labels_u8 [B,V] uint8, num_frames [B] int32.
         Returns a dict mirroring the graph collections the reference's loop
-        fetches (cs/train.py:336-344,420-425,516-517); tensors stay on device."""
+        fetches (cs/train.py:336-344,420-425,516-517); tensors stay on device.
+
+        Schedule: the teacher's backward and the whole student tower are independent once the
+        teacher's forward is done (teacher tensors are constants in the student loss), so the
+        student runs on a second HIP stream: its many small launches (M = batch L2 steps, 30-frame
+        L1) fill the CUs that the teacher's under-filled launches leave idle."""
         B = x_raw.shape[0]
         V = labels_u8.shape[1]
         dev = self.device
@@ -144,36 +153,52 @@ class DistillGraph:
             self._dp_t = torch.empty((B, V), dtype=F32, device=dev)
             self._dp_s = torch.empty((B, V), dtype=F32, device=dev)
         need_student = self.student is not None
+        main = torch.cuda.current_stream(dev)
         xt, xs = ops.l2norm_chunk(x_raw, self.C1, self.every_n if need_student else None, self.C2,
                                   num_frames=num_frames if x_raw.dtype == torch.uint8 else None)
         self.losses.zero_()
         out = {}
         sc = dp_loss_scales(self.world)
+        two_streams = self.teacher is not None and need_student and self.overlap_towers
         if self.teacher is not None:
             _, l1, l2 = ops.frame_counts(num_frames, 1, self.C1, self.max_frames // self.C1, self.max_frames)
             t_state, t_pred = self.teacher.forward(xt, l1, l2)
             ops.ce_loss(t_pred, labels_u8, self.losses[0:1], self._dp_t, grad_scale=sc["ce"] / B)
+            if two_streams:
+                self._ev_fwd.record(main)
+        if need_student:
+            side = self._side if two_streams else main
+            if two_streams:
+                side.wait_event(self._ev_fwd)
+            with torch.cuda.stream(side):
+                n_s, l1s, l2s = ops.frame_counts(num_frames, self.every_n, self.C2, self.S // self.C2, self.max_frames)
+                s_state, s_pred = self.student.forward(xs, l1s, l2s)
+                ops.ce_loss(s_pred, labels_u8, self.losses[3:4], self._dp_s, grad_scale=sc["ce"] / B)
+                ds = None
+                if self.teacher is not None:
+                    if self._ds_s is None or self._ds_s.shape != s_state.shape:
+                        self._ds_s = torch.empty_like(s_state)
+                    ops.kl_pred_loss(t_pred, self.teacher.rowsum, s_pred, self.student.rowsum, self.losses[2:3], self._dp_s,
+                                     grad_scale=sc["kl"], accumulate_grad=True)
+                    ops.rep_loss(t_state, s_state, self.losses[1:2], self._ds_s, grad_scale=self.rep_w * sc["rep"])
+                    ds = self._ds_s
+                self.student.backward(ds, self._dp_s,
+                                      on_moe_grads_ready=lambda: self._reduce_tower(self.student, True))
+                self._reduce_tower(self.student, False)
+                if two_streams:
+                    self._ev_student.record(side)
+                    for t in (xs, n_s, l1s, l2s):          # allocated on `main`, consumed on `side`
+                        if t is not None:
+                            t.record_stream(side)
+            out.update(student_predictions=s_pred, student_state=s_state, num_frames_student=n_s,
+                       student_loss_state=self.losses[1], pred_loss=self.losses[2], student_label_loss=self.losses[3])
+        if self.teacher is not None:
             self.teacher.backward(None, self._dp_t,
                                   on_moe_grads_ready=lambda: self._reduce_tower(self.teacher, True))
             self._reduce_tower(self.teacher, False)
             out.update(predictions=t_pred, teacher_state=t_state, loss=self.losses[0])
-        if need_student:
-            n_s, l1s, l2s = ops.frame_counts(num_frames, self.every_n, self.C2, self.S // self.C2, self.max_frames)
-            s_state, s_pred = self.student.forward(xs, l1s, l2s)
-            ops.ce_loss(s_pred, labels_u8, self.losses[3:4], self._dp_s, grad_scale=sc["ce"] / B)
-            ds = None
-            if self.teacher is not None:
-                if self._ds_s is None or self._ds_s.shape != s_state.shape:
-                    self._ds_s = torch.empty_like(s_state)
-                ops.kl_pred_loss(t_pred, self.teacher.rowsum, s_pred, self.student.rowsum, self.losses[2:3], self._dp_s,
-                                 grad_scale=sc["kl"], accumulate_grad=True)
-                ops.rep_loss(t_state, s_state, self.losses[1:2], self._ds_s, grad_scale=self.rep_w * sc["rep"])
-                ds = self._ds_s
-            self.student.backward(ds, self._dp_s,
-                                  on_moe_grads_ready=lambda: self._reduce_tower(self.student, True))
-            self._reduce_tower(self.student, False)
-            out.update(student_predictions=s_pred, student_state=s_state, num_frames_student=n_s,
-                       student_loss_state=self.losses[1], pred_loss=self.losses[2], student_label_loss=self.losses[3])
+        if two_streams:
+            main.wait_event(self._ev_student)
         self.reducer.wait()
         if apply:
             self.apply_gradients(B)
