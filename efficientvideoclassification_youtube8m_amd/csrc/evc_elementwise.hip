@@ -155,31 +155,57 @@ extern "C" int evc_frame_counts(const int32_t* num_frames, int B, int every_n, i
 // ---------------------------------------------------------------------------
 // transpose (+cast) to bf16: out[c][r] = in[r][c]; columns [R,Rpad) zeroed
 // ---------------------------------------------------------------------------
+// 64x64 tile through LDS; every thread moves 4 elements per access on both sides (8-byte bf16 /
+// 16-byte f32 loads along the input rows, 8-byte stores along the output rows), so each 16-lane
+// group reads / writes one full 128-byte line.
 template <bool F32>
 __global__ __launch_bounds__(256) void transpose_kernel(const void* __restrict__ in, long ld_in, int R, int C,
                                                         bf16_t* __restrict__ out, long ld_out, int Rpad, int il_H) {
-  __shared__ bf16_t tile[64][66];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  __shared__ bf16_t tile[64][68];   // [input row][input col], 136-byte pitch
+  const int q = threadIdx.x & 15, p = threadIdx.x >> 4;   // q: group of 4 elements, p: 0..15
   const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const bool vec_in = (ld_in % 4 == 0) && (((uintptr_t)in) % (F32 ? 16 : 8) == 0);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int r = r0 + ty + 4 * i, c = c0 + tx;
-    bf16_t v = 0;
-    if (r < R && c < C) {
-      if (F32) v = f32_to_bf16(((const float*)in)[(long)r * ld_in + c]);
-      else v = ((const bf16_t*)in)[(long)r * ld_in + c];
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + p + 16 * i, c = c0 + q * 4;
+    bf16_t v[4] = {0, 0, 0, 0};
+    if (r < R) {
+      if (vec_in && c + 3 < C) {
+        if (F32) {
+          const float4 f = *(const float4*)((const float*)in + (long)r * ld_in + c);
+          v[0] = f32_to_bf16(f.x); v[1] = f32_to_bf16(f.y); v[2] = f32_to_bf16(f.z); v[3] = f32_to_bf16(f.w);
+        } else {
+          const ushort4 u = *(const ushort4*)((const bf16_t*)in + (long)r * ld_in + c);
+          v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c + j < C) v[j] = F32 ? f32_to_bf16(((const float*)in)[(long)r * ld_in + c + j]) : ((const bf16_t*)in)[(long)r * ld_in + c + j];
+      }
     }
-    tile[ty + 4 * i][tx] = v;
+    *(ushort4*)&tile[p + 16 * i][q * 4] = make_ushort4(v[0], v[1], v[2], v[3]);
   }
   __syncthreads();
+  const bool vec_out = (ld_out % 4 == 0) && (((uintptr_t)out) % 8 == 0) && il_H <= 0;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int c = c0 + ty + 4 * i, r = r0 + tx;
-    // il_H > 0: input row r = g*H + u lands in output column u*4 + g (gate-interleaved K order)
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + p + 16 * i, r = r0 + q * 4;   // output row c (input column), 4 consecutive output columns r..r+3
+    if (c >= C) continue;
     // il_H < 0: input COLUMN c = u*4 + g (gate-interleaved) lands in output row g*H + u (TF order), H = -il_H
-    const int ro = (il_H > 0 && r < 4 * il_H) ? (r % il_H) * 4 + r / il_H : r;
     const int co = (il_H < 0) ? (c & 3) * (-il_H) + (c >> 2) : c;
-    if (c < C && r < Rpad) out[(long)co * ld_out + ro] = tile[tx][ty + 4 * i];
+    const int cl = p + 16 * i;
+    if (vec_out && r + 3 < Rpad) {
+      *(ushort4*)(out + (long)co * ld_out + r) = make_ushort4(tile[q * 4][cl], tile[q * 4 + 1][cl], tile[q * 4 + 2][cl], tile[q * 4 + 3][cl]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int rr = r + j;
+        // il_H > 0: input row rr = g*H + u lands in output column u*4 + g (gate-interleaved K order)
+        const int ro = (il_H > 0 && rr < 4 * il_H) ? (rr % il_H) * 4 + rr / il_H : rr;
+        if (rr < Rpad) out[(long)co * ld_out + ro] = tile[q * 4 + j][cl];
+      }
+    }
   }
 }
 

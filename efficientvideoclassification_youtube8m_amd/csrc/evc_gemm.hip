@@ -209,6 +209,11 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, 
         const long hu = (long)m * H + u;
         if (e.t >= ln) {            // dynamic_rnn: state copied through, zero output
           e.hout[hu] = 0;
+          if (e.t == 0) {           // zero-length row: its final state is the zero initial state
+            const long su0 = (long)m * e.ld_state + u;
+            e.c_state[su0] = 0.f;
+            e.h_state[su0] = 0.f;
+          }
           continue;
         }
         float zi = acc[mi][0][ni][r] + bi, zj = acc[mi][1][ni][r] + bj;
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, 
         }
         const float gi = sigmoidf_(zi), gj = tanhf_(zj), gf = sigmoidf_(zf), go = sigmoidf_(zo);
         const long su = (long)m * e.ld_state + u;
-        const float c_old = e.c_state[su];
+        const float c_old = (e.t == 0) ? 0.f : e.c_state[su];     // zero initial state (no memset of the state buffers)
         const float c_new = c_old * gf + gi * gj;
         const float h_new = tanhf_(c_new) * go;
         e.c_state[su] = c_new;
@@ -265,9 +270,8 @@ extern "C" int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const f
   EVC_REQUIRE(!tape || ((uintptr_t)tape % 16) == 0, EVC_ERR_BAD_ALIGN, "evc_lstm_layer_fwd: tape must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const long ldw = Kin + H;
-  // zero state (rows with len==0 keep an all-zero state) and h_{-1}
-  EVC_CHECK_HIP(hipMemset2DAsync(c_state, ld_state * sizeof(float), 0, (size_t)H * sizeof(float), M, st));
-  EVC_CHECK_HIP(hipMemset2DAsync(h_state, ld_state * sizeof(float), 0, (size_t)H * sizeof(float), M, st));
+  // h_{-1} = 0 (the state buffers need no clearing: step 0 treats c_old as 0 and writes the zero
+  // state of zero-length rows itself)
   EVC_CHECK_HIP(hipMemsetAsync(hbuf, 0, (size_t)M * H * sizeof(bf16_t), st));
   if (hT) EVC_CHECK_HIP(hipMemset2DAsync(hT, ld_hT * sizeof(bf16_t), 0, (size_t)M * sizeof(bf16_t), H, st));   // h_{-1}^T = 0
   if (hoist) {

@@ -159,6 +159,10 @@ class DistillGraph:
         self.losses.zero_()
         out = {}
         sc = dp_loss_scales(self.world)
+        # both train ops read the same global_step / learning rate within one iteration (cs/train.py:223-236)
+        lr = exponential_decay(self.lr0, self.global_step, B * self.world, self.lr_decay_examples, self.lr_decay)
+        l2c = self.reg_pen * 1e-8
+        self._teacher_applied = self._student_applied = False
         two_streams = self.teacher is not None and need_student and self.overlap_towers
         if self.teacher is not None:
             _, l1, l2 = ops.frame_counts(num_frames, 1, self.C1, self.max_frames // self.C1, self.max_frames)
@@ -185,6 +189,10 @@ class DistillGraph:
                 self.student.backward(ds, self._dp_s,
                                       on_moe_grads_ready=lambda: self._reduce_tower(self.student, True))
                 self._reduce_tower(self.student, False)
+                if apply and two_streams and self.world == 1:
+                    # the student's HBM-bound clip+Adam runs on the side stream under the teacher's BPTT
+                    self.student.apply_gradients(lr, self.clip, l2c)
+                    self._student_applied = True
                 if two_streams:
                     self._ev_student.record(side)
                     for t in (xs, n_s, l1s, l2s):          # allocated on `main`, consumed on `side`
@@ -197,24 +205,34 @@ class DistillGraph:
                                   on_moe_grads_ready=lambda: self._reduce_tower(self.teacher, True))
             self._reduce_tower(self.teacher, False)
             out.update(predictions=t_pred, teacher_state=t_state, loss=self.losses[0])
+            if apply and two_streams and self.world == 1:
+                # the teacher's HBM-bound clip+Adam overlaps the student's remaining kernels on the side stream
+                # (its outputs t_state / t_pred are separate buffers, untouched by the update)
+                self.teacher.apply_gradients(lr, self.clip, l2c)
+                self._teacher_applied = True
         if two_streams:
             main.wait_event(self._ev_student)
         self.reducer.wait()
         if apply:
-            self.apply_gradients(B)
+            self.apply_gradients(B, lr)
         out["global_step"] = self.global_step
         return out
 
-    def apply_gradients(self, batch_size):
+    def apply_gradients(self, batch_size, lr=None):
+        """Runs whichever train op has not been applied inside step(); each one increments
+        global_step (cs/train.py:332,416 -> += 2 per iteration, README.md:116,121)."""
         l2c = self.reg_pen * 1e-8
-        # both train ops read the same global_step value within one sess.run; each increments it
-        lr = exponential_decay(self.lr0, self.global_step, batch_size * self.world, self.lr_decay_examples, self.lr_decay)
+        if lr is None:
+            lr = exponential_decay(self.lr0, self.global_step, batch_size * self.world, self.lr_decay_examples, self.lr_decay)
         if self.teacher is not None:
-            self.teacher.apply_gradients(lr, self.clip, l2c)
+            if not getattr(self, "_teacher_applied", False):
+                self.teacher.apply_gradients(lr, self.clip, l2c)
             self.global_step += 1
         if self.student is not None:
-            self.student.apply_gradients(lr, self.clip, l2c)
+            if not getattr(self, "_student_applied", False):
+                self.student.apply_gradients(lr, self.clip, l2c)
             self.global_step += 1
+        self._teacher_applied = self._student_applied = False
 
     def loss_report(self):
         """Host floats in the order the reference logs them (cs/train.py:528-533)."""
