@@ -135,20 +135,26 @@ def main():
         dt = float(t.item())
     losses = graph.loss_report()
 
-    # ---- roofline of the dominant kernel: the fused LSTM forward step -----------
-    # lstm_fwd_step_kernel<TileCfg<128,4,32,2,2>> (L1 of both towers).  Live timing with
-    # events on the launch stream; algorithmic FLOPs = 2*M*4H*K of each step GEMM.
+    # ---- roofline of the dominant kernel: the fused LSTM forward step of the teacher's L1 ---------
+    # lstm_fwd_step_kernel<TileCfg2<320,4,64,2,4,4,false>> (30 launches per iteration, the largest
+    # FLOP share).  Live timing with events on the launch stream around each layer's 15-step launch
+    # sequence; algorithmic FLOPs = 2*M*4H*K of each step GEMM.
+    tower = graph.teacher if graph.teacher is not None else graph.student
     ms = launches = flops = 0.0
-    for tower in (graph.teacher, graph.student):
-        if tower is None:
-            continue
-        for (m, nl, fl) in tower.l1.profile_fwd_layers(reps=3):
-            ms, launches, flops = ms + m, launches + nl, flops + fl
+    for (m, nl, fl) in tower.l1.profile_fwd_layers(reps=3):
+        ms, launches, flops = ms + m, launches + nl, flops + fl
     avg_ms = ms / launches
     achieved = flops / (ms * 1e-3) / 1e12
-    roofline = {"bound": "mfma", "kernel": "lstm_fwd_step_kernel<TileCfg<128,4,32,2,2>>", "achieved": round(achieved, 2),
+    traffic = None
+    try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            traffic = json.load(f)["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    roofline = {"bound": "mfma", "kernel": "lstm_fwd_step_kernel<TileCfg2<320,4,64,2,4,4,false>>" if graph.teacher is not None
+                else "lstm_fwd_step_kernel (student L1)", "achieved": round(achieved, 2),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": int(launches),
+                "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": int(launches),
                 "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 2)}
 
     if rank == 0:

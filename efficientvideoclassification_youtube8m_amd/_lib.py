@@ -67,6 +67,9 @@ def load():
             "libevc_hip.so not found at %s - build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` or csrc/build.sh. "
             "There is no CPU fallback for the HIP kernels." % LIB_PATH)
+    # PyTorch-ROCm bundles its own HIP runtime; it must be the first one loaded into the process
+    # (loading this library first pulls in /opt/rocm's copy and torch then sees "No HIP GPUs").
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
