@@ -11,13 +11,13 @@ template <int a, int b, int c, int d, int e, int f, bool g> struct is_v2<TileCfg
 
 extern __shared__ __attribute__((aligned(16))) char lds_dyn[];
 
-template <class Cfg, int NG>
+template <class Cfg, int NG, bool SWAP = false>
 __device__ __forceinline__ void run_mainloop(const GemmOperands& p, int m0, int u0, f32x4 (&acc)[Cfg::MI][NG][Cfg::NI]) {
   if constexpr (is_v2<Cfg>::value) {
-    gemm_mainloop_v2<Cfg>(p, m0, u0, lds_dyn, acc);
+    gemm_mainloop_v2<Cfg, SWAP>(p, m0, u0, lds_dyn, acc);
   } else {
     __shared__ __attribute__((aligned(16))) char lds_static[Cfg::LDS_BYTES];   // static: keeps 2 workgroups per CU
-    gemm_mainloop<Cfg>(p, m0, u0, lds_static, acc);
+    gemm_mainloop<Cfg, SWAP>(p, m0, u0, lds_static, acc);
   }
 }
 
@@ -169,8 +169,9 @@ struct LstmFwdParams {
   const int* len; int t;
   float* c_state; float* h_state; long ld_state;
   bf16_t* hout;                      // [M][H] slab t+1 (row-major: next step's A operand)
-  bf16_t* hT; long ld_hT;            // h_t transposed, column base of slab t+1: hT[u*ld + m] (or NULL)
-  uint4* tape;                       // [M][H] 16-byte records of slab t (or NULL): {i,j | f,o | c_new | c_old}
+  uint2* gates;                      // [M][H] 8-byte records of slab t (or NULL): bf16 {i, j, f, o}
+  const float* c_in; float* c_out;   // cell state before / after this step: slabs t and t+1 of c_all, or the
+                                     // in-place c_state buffer when no history is kept (c_in == NULL at t == 0)
   int M, H;
 };
 
@@ -187,59 +188,77 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, 
   tile_of(id, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * Cfg::BM, u0 = tn * Cfg::BU;
   f32x4 acc[Cfg::MI][4][Cfg::NI];
-  run_mainloop<Cfg, 4>(p, m0, u0, acc);
-  TileCoords<Cfg> tc;
-  const int H = e.H;
+  run_mainloop<Cfg, 4, true>(p, m0, u0, acc);     // transposed accumulators: lane = one row, 4 consecutive units
+#ifdef EVC_ABLATE_EPI    // debug build: main loop only (keep the accumulators alive, store nothing)
+#pragma unroll
+  for (int mi = 0; mi < Cfg::MI; ++mi)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) asm volatile("" :: "v"(acc[mi][g][0]));
+  return;
+#endif
+  TileCoordsT<Cfg> tc;
+  const int H = e.H;     // H % 4 == 0 (checked on the host): a lane's 4 units never straddle H
 #pragma unroll
   for (int ni = 0; ni < Cfg::NI; ++ni) {
     const int u = u0 + tc.unit0 + ni * 16;
     if (u >= H) continue;
-    const float bi = e.bias[u], bj = e.bias[H + u], bf = e.bias[2 * H + u] + 1.0f /* forget_bias */, bo = e.bias[3 * H + u];
+    const float4 bi = *(const float4*)(e.bias + u), bj = *(const float4*)(e.bias + H + u);
+    const float4 bf = *(const float4*)(e.bias + 2 * H + u), bo = *(const float4*)(e.bias + 3 * H + u);
 #pragma unroll
     for (int mi = 0; mi < Cfg::MI; ++mi) {
-      const int mb = m0 + tc.row0 + mi * 16;      // this lane's 4 consecutive rows mb..mb+3
-      if (mb >= e.M) continue;
-      float hv[4];
+      const int m = m0 + tc.row0 + mi * 16;
+      if (m >= e.M) continue;
+      const int ln = e.len[m];
+      const long hu = (long)m * H + u;
+      const long su = (long)m * e.ld_state + u;
+      if (e.t >= ln) {              // dynamic_rnn: state copied through, zero output
+        *(uint2*)(e.hout + hu) = make_uint2(0u, 0u);
+        if (e.t == 0) {             // zero-length row: its final state is the zero initial state
+          *(float4*)(e.c_state + su) = make_float4(0.f, 0.f, 0.f, 0.f);
+          *(float4*)(e.h_state + su) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        continue;
+      }
+      const long cu = e.gates ? hu : su;      // c history slabs are dense [M][H]; the in-place buffer has stride ld_state
+      float zi[4], zj[4], zf[4], zo[4];
+      const float bia[4] = {bi.x, bi.y, bi.z, bi.w}, bja[4] = {bj.x, bj.y, bj.z, bj.w};
+      const float bfa[4] = {bf.x, bf.y, bf.z, bf.w}, boa[4] = {bo.x, bo.y, bo.z, bo.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = mb + r;
-        hv[r] = 0.f;
-        if (m >= e.M) continue;
-        const int ln = e.len[m];
-        const long hu = (long)m * H + u;
-        if (e.t >= ln) {            // dynamic_rnn: state copied through, zero output
-          e.hout[hu] = 0;
-          if (e.t == 0) {           // zero-length row: its final state is the zero initial state
-            const long su0 = (long)m * e.ld_state + u;
-            e.c_state[su0] = 0.f;
-            e.h_state[su0] = 0.f;
-          }
-          continue;
-        }
-        float zi = acc[mi][0][ni][r] + bi, zj = acc[mi][1][ni][r] + bj;
-        float zf = acc[mi][2][ni][r] + bf, zo = acc[mi][3][ni][r] + bo;
-        if (e.zx) {
-          const float* zr = e.zx + (long)m * e.ldzx + u;
-          zi += zr[0]; zj += zr[H]; zf += zr[2 * H]; zo += zr[3 * H];
-        }
-        const float gi = sigmoidf_(zi), gj = tanhf_(zj), gf = sigmoidf_(zf), go = sigmoidf_(zo);
-        const long su = (long)m * e.ld_state + u;
-        const float c_old = (e.t == 0) ? 0.f : e.c_state[su];     // zero initial state (no memset of the state buffers)
-        const float c_new = c_old * gf + gi * gj;
-        const float h_new = tanhf_(c_new) * go;
-        e.c_state[su] = c_new;
-        if (e.t == ln - 1) e.h_state[su] = h_new;      // the returned state is the one after step len-1
-        e.hout[hu] = f32_to_bf16(h_new);
-        hv[r] = h_new;
-        if (e.tape) e.tape[hu] = make_uint4(pack_bf16x2(gi, gj), pack_bf16x2(gf, go), __float_as_uint(c_new), __float_as_uint(c_old));
+        zi[r] = acc[mi][0][ni][r] + bia[r]; zj[r] = acc[mi][1][ni][r] + bja[r];
+        zf[r] = acc[mi][2][ni][r] + bfa[r] + 1.0f /* forget_bias */; zo[r] = acc[mi][3][ni][r] + boa[r];
       }
-      if (e.hT) {                   // 4 consecutive rows of one unit = 8 contiguous bytes of h^T
-        bf16_t* tp = e.hT + (long)u * e.ld_hT + mb;
-        if (mb + 3 < e.M) {
-          *(uint2*)tp = make_uint2(pack_bf16x2(hv[0], hv[1]), pack_bf16x2(hv[2], hv[3]));
-        } else {
-          for (int r = 0; r < 4 && mb + r < e.M; ++r) tp[r] = f32_to_bf16(hv[r]);
-        }
+      if (e.zx) {
+        const float* zr = e.zx + (long)m * e.ldzx + u;
+        const float4 a = *(const float4*)zr, b = *(const float4*)(zr + H), c = *(const float4*)(zr + 2 * H), d = *(const float4*)(zr + 3 * H);
+        zi[0] += a.x; zi[1] += a.y; zi[2] += a.z; zi[3] += a.w;
+        zj[0] += b.x; zj[1] += b.y; zj[2] += b.z; zj[3] += b.w;
+        zf[0] += c.x; zf[1] += c.y; zf[2] += c.z; zf[3] += c.w;
+        zo[0] += d.x; zo[1] += d.y; zo[2] += d.z; zo[3] += d.w;
+      }
+      float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);     // zero initial state (no memset of the state buffers)
+      if (e.t > 0) cv = *(const float4*)(e.c_in + cu);
+      const float co[4] = {cv.x, cv.y, cv.z, cv.w};
+      float cn[4], hn[4];
+      uint2 rec[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float gi = sigmoidf_(zi[r]), gj = tanhf_(zj[r]), gf = sigmoidf_(zf[r]), go = sigmoidf_(zo[r]);
+        cn[r] = co[r] * gf + gi * gj;
+        hn[r] = tanhf_(cn[r]) * go;
+        rec[r] = make_uint2(pack_bf16x2(gi, gj), pack_bf16x2(gf, go));
+      }
+      const float4 cnv = make_float4(cn[0], cn[1], cn[2], cn[3]);
+      *(float4*)(e.c_out + cu) = cnv;
+      if (e.t == ln - 1) {                             // the returned state is the one after step len-1
+        *(float4*)(e.h_state + su) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+        if (e.gates) *(float4*)(e.c_state + su) = cnv;
+      }
+      *(uint2*)(e.hout + hu) = make_uint2(pack_bf16x2(hn[0], hn[1]), pack_bf16x2(hn[2], hn[3]));
+      if (e.gates) {
+        uint4* gp = (uint4*)(e.gates + hu);            // 4 units x 8 bytes
+        gp[0] = make_uint4(rec[0].x, rec[0].y, rec[1].x, rec[1].y);
+        gp[1] = make_uint4(rec[2].x, rec[2].y, rec[3].x, rec[3].y);
       }
     }
   }
@@ -260,20 +279,21 @@ static inline void launch_lstm_fwd(GemmOperands p, const LstmFwdParams& e, int k
 extern "C" int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const float* bias, const int32_t* len,
                                   int T, int M, int Kin, int H, int hoist, float* zx_ws,
                                   evc_bf16* hbuf, float* c_state, float* h_state, int64_t ld_state,
-                                  void* tape, evc_bf16* hT, int64_t ld_hT, void* stream) {
+                                  void* gates, float* c_all, void* stream) {
   EVC_REQUIRE(T > 0 && M > 0 && H > 0 && Kin > 0, EVC_ERR_BAD_SHAPE, "evc_lstm_layer_fwd: bad shape");
   EVC_REQUIRE(Kin % 64 == 0 && H % 64 == 0, EVC_ERR_BAD_SHAPE,
               "evc_lstm_layer_fwd: Kin=%d and H=%d must be multiples of 64", Kin, H);
   EVC_REQUIRE(!hoist || zx_ws, EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd: hoist needs zx_ws");
-  EVC_REQUIRE(!hT || (M % 4 == 0 && ld_hT % 4 == 0 && ld_hT >= (long)(T + 1) * M && ((uintptr_t)hT % 8) == 0), EVC_ERR_BAD_ALIGN,
-              "evc_lstm_layer_fwd: hT needs M %% 4 == 0, ld_hT %% 4 == 0 and ld_hT >= (T+1)*M (M=%d ld=%ld)", M, (long)ld_hT);
-  EVC_REQUIRE(!tape || ((uintptr_t)tape % 16) == 0, EVC_ERR_BAD_ALIGN, "evc_lstm_layer_fwd: tape must be 16-byte aligned");
+  EVC_REQUIRE(ld_state % 4 == 0 && ((uintptr_t)c_state % 16) == 0 && ((uintptr_t)h_state % 16) == 0 && ((uintptr_t)bias % 16) == 0 &&
+              ((uintptr_t)hbuf % 8) == 0, EVC_ERR_BAD_ALIGN, "evc_lstm_layer_fwd: state/bias/hbuf must allow 16-byte vector access");
+  EVC_REQUIRE((gates == nullptr) == (c_all == nullptr), EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd: gates and c_all go together");
+  EVC_REQUIRE(!gates || (((uintptr_t)gates % 16) == 0 && ((uintptr_t)c_all % 16) == 0), EVC_ERR_BAD_ALIGN,
+              "evc_lstm_layer_fwd: gates / c_all must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const long ldw = Kin + H;
   // h_{-1} = 0 (the state buffers need no clearing: step 0 treats c_old as 0 and writes the zero
   // state of zero-length rows itself)
   EVC_CHECK_HIP(hipMemsetAsync(hbuf, 0, (size_t)M * H * sizeof(bf16_t), st));
-  if (hT) EVC_CHECK_HIP(hipMemset2DAsync(hT, ld_hT * sizeof(bf16_t), 0, (size_t)M * sizeof(bf16_t), H, st));   // h_{-1}^T = 0
   if (hoist) {
     int rc = evc_gemm_nt(x, Kin, wT, ldw, zx_ws, 4L * H, T * M, 4 * H, Kin, nullptr, 0, 0, stream);
     if (rc) return rc;
@@ -303,8 +323,9 @@ extern "C" int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const f
     e.bias = bias; e.len = len; e.t = t;
     e.c_state = c_state; e.h_state = h_state; e.ld_state = ld_state;
     e.hout = hbuf + (long)(t + 1) * M * H;
-    e.hT = hT ? hT + (long)(t + 1) * M : nullptr; e.ld_hT = ld_hT;
-    e.tape = tape ? (uint4*)tape + (long)t * M * H : nullptr;
+    e.gates = gates ? (uint2*)gates + (long)t * M * H : nullptr;
+    if (c_all) { e.c_in = c_all + (long)t * M * H; e.c_out = c_all + (long)(t + 1) * M * H; }   // slab t+1 = c after step t
+    else { e.c_in = c_state; e.c_out = c_state; }
     e.M = M; e.H = H;
     switch (pick) {
       case 0: launch_lstm_fwd<CfgLstmV2a>(p, e, k1, k2, st); break;
@@ -323,7 +344,8 @@ extern "C" int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const f
 // ===========================================================================
 struct LstmBwdParams {
   const int* len; int t;
-  const uint4* tape;        // slab t   [M][H] records {i,j | f,o | c_new | c_old}
+  const uint2* gates;       // slab t   [M][H] bf16 {i, j, f, o}
+  const float* c_new; const float* c_old;   // slabs t+1 / t of c_all (c_old == NULL at t == 0)
   const float* dS_c; const float* dS_h; long ld_dS;
   const float* dh_above;    // slab t [M][H] or NULL
   float* dc_ws;             // [M][H]
@@ -340,8 +362,8 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_bwd_step_kernel(GemmOperands p, 
   tile_of(id, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * Cfg::BM, u0 = tn * Cfg::BU;
   f32x4 acc[Cfg::MI][1][Cfg::NI];
-  run_mainloop<Cfg, 1>(p, m0, u0, acc);
-  TileCoords<Cfg> tc;
+  run_mainloop<Cfg, 1, true>(p, m0, u0, acc);     // transposed accumulators: lane = one row, 4 consecutive units
+  TileCoordsT<Cfg> tc;
   const int H = e.H;
 #pragma unroll
   for (int ni = 0; ni < Cfg::NI; ++ni) {
@@ -349,37 +371,56 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_bwd_step_kernel(GemmOperands p, 
     if (u >= H) continue;
 #pragma unroll
     for (int mi = 0; mi < Cfg::MI; ++mi) {
+      const int m = m0 + tc.row0 + mi * 16;
+      if (m >= e.M) continue;
+      const int ln = e.len[m];
+      const long hu = (long)m * H + u;
+      uint4* dzp = (uint4*)(e.dz4 + hu);            // 4 units x 8 bytes = 2 x 16 bytes
+      if (e.t >= ln) {  // inactive: state passes through, no gate gradient
+        dzp[0] = make_uint4(0u, 0u, 0u, 0u);
+        dzp[1] = make_uint4(0u, 0u, 0u, 0u);
+        continue;
+      }
+      const bool last = (e.t == ln - 1);
+      float dh[4] = {acc[mi][0][ni][0], acc[mi][0][ni][1], acc[mi][0][ni][2], acc[mi][0][ni][3]};
+      float4 dcv;
+      if (last) {
+        const long su = (long)m * e.ld_dS + u;
+        const float4 hv = *(const float4*)(e.dS_h + su);   // nothing flows back from later (inactive) steps
+        dh[0] = hv.x; dh[1] = hv.y; dh[2] = hv.z; dh[3] = hv.w;
+        dcv = *(const float4*)(e.dS_c + su);
+      } else {
+        dcv = *(const float4*)(e.dc_ws + hu);
+      }
+      if (e.dh_above) {
+        const float4 a = *(const float4*)(e.dh_above + hu);
+        dh[0] += a.x; dh[1] += a.y; dh[2] += a.z; dh[3] += a.w;
+      }
+      const float dci[4] = {dcv.x, dcv.y, dcv.z, dcv.w};
+      const uint4* gp = (const uint4*)(e.gates + hu);
+      const uint4 g01 = gp[0], g23 = gp[1];
+      const uint2 recs[4] = {make_uint2(g01.x, g01.y), make_uint2(g01.z, g01.w), make_uint2(g23.x, g23.y), make_uint2(g23.z, g23.w)};
+      const float4 cnv = *(const float4*)(e.c_new + hu);
+      float4 cov = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e.c_old) cov = *(const float4*)(e.c_old + hu);
+      const float cna[4] = {cnv.x, cnv.y, cnv.z, cnv.w}, coa[4] = {cov.x, cov.y, cov.z, cov.w};
+      float dcn[4];
+      uint2 dzr[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m0 + tc.row0 + mi * 16 + r;
-        if (m >= e.M) continue;
-        const int ln = e.len[m];
-        const long hu = (long)m * H + u;
-        if (e.t >= ln) {  // inactive: state passes through, no gate gradient
-          e.dz4[hu] = make_uint2(0u, 0u);
-          continue;
-        }
-        const bool last = (e.t == ln - 1);
-        float dh = acc[mi][0][ni][r];
-        float dc_in;
-        if (last) {
-          const long su = (long)m * e.ld_dS + u;
-          dh = e.dS_h[su];        // nothing flows back from later (inactive) steps
-          dc_in = e.dS_c[su];
-        } else {
-          dc_in = e.dc_ws[hu];
-        }
-        if (e.dh_above) dh += e.dh_above[hu];
-        const uint4 rec = e.tape[hu];
+        const uint2 rec = recs[r];
         const float gi = __uint_as_float(rec.x << 16), gj = __uint_as_float(rec.x & 0xffff0000u);
         const float gf = __uint_as_float(rec.y << 16), go = __uint_as_float(rec.y & 0xffff0000u);
-        const float tcv = tanhf_(__uint_as_float(rec.z));
-        const float cp = __uint_as_float(rec.w);
-        const float dc = dc_in + dh * go * (1.f - tcv * tcv);
-        e.dc_ws[hu] = dc * gf;
-        e.dz4[hu] = make_uint2(pack_bf16x2(dc * gj * gi * (1.f - gi), dc * gi * (1.f - gj * gj)),
-                               pack_bf16x2(dc * cp * gf * (1.f - gf), dh * tcv * go * (1.f - go)));
+        const float tcv = tanhf_(cna[r]);
+        const float cp = coa[r];
+        const float dc = dci[r] + dh[r] * go * (1.f - tcv * tcv);
+        dcn[r] = dc * gf;
+        dzr[r] = make_uint2(pack_bf16x2(dc * gj * gi * (1.f - gi), dc * gi * (1.f - gj * gj)),
+                            pack_bf16x2(dc * cp * gf * (1.f - gf), dh[r] * tcv * go * (1.f - go)));
       }
+      *(float4*)(e.dc_ws + hu) = make_float4(dcn[0], dcn[1], dcn[2], dcn[3]);
+      dzp[0] = make_uint4(dzr[0].x, dzr[0].y, dzr[1].x, dzr[1].y);
+      dzp[1] = make_uint4(dzr[2].x, dzr[2].y, dzr[3].x, dzr[3].y);
     }
   }
 }
@@ -392,10 +433,13 @@ static inline void launch_lstm_bwd(GemmOperands p, const LstmBwdParams& e, int k
 }
 
 extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int T, int M, int Kin, int H,
-                                  const void* tape, const float* dS_c, const float* dS_h, int64_t ld_dS,
+                                  const void* gates, const float* c_all, const float* dS_c, const float* dS_h, int64_t ld_dS,
                                   const float* dh_above, float* dc_ws, evc_bf16* dz4, void* stream) {
   EVC_REQUIRE(T > 0 && M > 0 && H > 0 && Kin > 0 && H % 64 == 0, EVC_ERR_BAD_SHAPE, "evc_lstm_layer_bwd: bad shape");
-  EVC_REQUIRE(tape && ((uintptr_t)tape % 16) == 0 && ((uintptr_t)dz4 % 16) == 0, EVC_ERR_BAD_ALIGN, "evc_lstm_layer_bwd: tape/dz4 alignment");
+  EVC_REQUIRE(gates && c_all && ((uintptr_t)gates % 16) == 0 && ((uintptr_t)c_all % 16) == 0 && ((uintptr_t)dz4 % 16) == 0,
+              EVC_ERR_BAD_ALIGN, "evc_lstm_layer_bwd: gates/c_all/dz4 alignment");
+  EVC_REQUIRE(ld_dS % 4 == 0 && ((uintptr_t)dS_c % 16) == 0 && ((uintptr_t)dS_h % 16) == 0 && ((uintptr_t)dc_ws % 16) == 0 &&
+              (!dh_above || ((uintptr_t)dh_above % 16) == 0), EVC_ERR_BAD_ALIGN, "evc_lstm_layer_bwd: f32 operands must allow 16-byte vector access");
   hipStream_t st = (hipStream_t)stream;
   // The BPTT step is dominated by its epilogue (tape / dc / dz traffic per element), not by the
   // [M,4H]x[4H,H] GEMM: 64x64 tiles at 4 workgroups per CU overlap one workgroup's epilogue with the
@@ -412,7 +456,9 @@ extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int 
     const int k1 = (t == T - 1) ? 0 : 4 * H;
     LstmBwdParams e;
     e.len = len; e.t = t;
-    e.tape = (const uint4*)tape + (long)t * M * H;
+    e.gates = (const uint2*)gates + (long)t * M * H;
+    e.c_new = c_all + (long)(t + 1) * M * H;
+    e.c_old = t > 0 ? c_all + (long)t * M * H : nullptr;
     e.dS_c = dS_c; e.dS_h = dS_h; e.ld_dS = ld_dS;
     e.dh_above = dh_above ? dh_above + (long)t * M * H : nullptr;
     e.dc_ws = dc_ws; e.dz4 = (uint2*)dz4 + (long)t * M * H;

@@ -66,7 +66,10 @@ __device__ __forceinline__ void tile_of(int id, int tiles_m, int tiles_n, int& t
   tn = r / rows;
 }
 
-template <class Cfg>
+// SWAP = true issues the MFMA with the B fragment as its first operand: the accumulator tile is then
+// TRANSPOSED - lane l holds column (row of A) l&15 and 4 consecutive rows (units of B)
+// (l>>4)*4+reg - so an epilogue that walks units fastest gets 16-byte vector accesses.
+template <class Cfg, bool SWAP = false>
 __device__ __forceinline__ void gemm_mainloop(const GemmOperands& p, const int m0, const int u0, char* lds,
                                               f32x4 (&acc)[Cfg::MI][Cfg::G][Cfg::NI]) {
   const int tid = threadIdx.x;
@@ -176,7 +179,8 @@ __device__ __forceinline__ void gemm_mainloop(const GemmOperands& p, const int m
         for (int g = 0; g < Cfg::G; ++g)
 #pragma unroll
           for (int ni = 0; ni < Cfg::NI; ++ni)
-            acc[mi][g][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[g][ni], acc[mi][g][ni], 0, 0, 0);
+            acc[mi][g][ni] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[g][ni], af[mi], acc[mi][g][ni], 0, 0, 0)
+                                  : __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[g][ni], acc[mi][g][ni], 0, 0, 0);
     }
     __syncthreads();
     cur ^= 1;
@@ -194,5 +198,17 @@ struct TileCoords {
     const int wr = wave / Cfg::WC, wc = wave % Cfg::WC;
     row0 = wr * Cfg::WM + (lane >> 4) * 4;
     unit0 = wc * Cfg::WU + (lane & 15);
+  }
+};
+// Same for a SWAP (transposed) accumulator: element (mi, ni, reg) is
+//   row  = wr*WM + mi*16 + (lane&15),   unit = wc*WU + ni*16 + (lane>>4)*4 + reg
+template <class Cfg>
+struct TileCoordsT {
+  int row0, unit0;  // add mi*16 / ni*16 + reg
+  __device__ __forceinline__ TileCoordsT() {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / Cfg::WC, wc = wave % Cfg::WC;
+    row0 = wr * Cfg::WM + (lane & 15);
+    unit0 = wc * Cfg::WU + (lane >> 4) * 4;
   }
 };

@@ -46,7 +46,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <class Cfg>
+template <class Cfg, bool SWAP = false>
 __device__ __forceinline__ void gemm_mainloop_v2(const GemmOperands& p, const int m0, const int u0, char* lds,
                                                  f32x4 (&acc)[Cfg::MI][Cfg::G][Cfg::NI]) {
   const int tid = threadIdx.x;
@@ -148,7 +148,8 @@ __device__ __forceinline__ void gemm_mainloop_v2(const GemmOperands& p, const in
       for (int g = 0; g < Cfg::G; ++g)
 #pragma unroll
         for (int ni = 0; ni < Cfg::NI; ++ni)
-          acc[mi][g][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[g][ni], acc[mi][g][ni], 0, 0, 0);
+          acc[mi][g][ni] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[g][ni], af[mi], acc[mi][g][ni], 0, 0, 0)
+                                : __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[g][ni], acc[mi][g][ni], 0, 0, 0);
   };
   auto end_of_step = [&]() {
     // The next step's fragment reads were issued BEFORE these MFMAs and have landed long before

@@ -86,22 +86,14 @@ class LstmStack:
             self.zx = torch.empty((T * M, 4 * H), dtype=F32, device=dev)
         self.training = training
         if training:
-            # tape: 16-byte records {i,j,f,o bf16 | c_new f32 | c_old f32} per (t, row, unit)
-            self.tape = [torch.empty((T, M, H, 4), dtype=torch.int32, device=dev) for _ in range(L)]
+            # history for BPTT: 8-byte gate records {i,j,f,o bf16} and the cell state after every step
+            self.gates = [torch.empty((T, M, H, 2), dtype=torch.int32, device=dev) for _ in range(L)]
+            self.c_all = [torch.empty((T + 1, M, H), dtype=F32, device=dev) for _ in range(L)]
             self.KP = ops.round_up(T * M, 64)
             self.dz = torch.empty((T, M, 4 * H), dtype=BF16, device=dev)          # gate-interleaved [T][M][H][4]
             self.dzT = torch.zeros((4 * H, self.KP), dtype=BF16, device=dev)      # TF gate order; pad columns stay 0
-            # direct transposed epilogue writes need 8-byte aligned 4-row groups
-            self.direct_T = (M % 8 == 0)
-            self.ldT = ops.round_up((T + 1) * M, 64) + 64
-            if self.direct_T:
-                self.hT = [torch.zeros((H, self.ldT), dtype=BF16, device=dev) for _ in range(L)]   # h^T, column (t+1)*M+m
-            else:
-                self.hT = [None] * L
-                self.hT_ws = torch.empty((H, self.KP), dtype=BF16, device=dev)
-            self.xT = torch.zeros((Kin, self.KP), dtype=BF16, device=dev)        # stack input transposed
-            if not self.direct_T and L > 1:
-                self.inT_ws = torch.empty((H, self.KP), dtype=BF16, device=dev)
+            self.xT = torch.empty((max(self.kin), self.KP), dtype=BF16, device=dev)   # layer input transposed
+            self.hT_ws = torch.empty((H, self.KP), dtype=BF16, device=dev)            # h_prev transposed
             self.dc_ws = torch.empty((M, H), dtype=F32, device=dev)
             self.dx = [torch.empty((T * M, self.kin[l]), dtype=F32, device=dev) if (l > 0) else None for l in range(L)]
 
@@ -118,7 +110,7 @@ class LstmStack:
             kn, bn = self.names(l)
             ops.lstm_layer_fwd(inp, tw.shadow_fwd[kn], tw.store.p(bn), lens, T, M, self.kin[l], H,
                                self.hbuf[l], self.S[:, (2 * l) * H:], self.S[:, (2 * l + 1) * H:], 2 * L * H,
-                               self.tape[l] if self.training else None, self.hT[l] if self.training else None,
+                               self.gates[l] if self.training else None, self.c_all[l] if self.training else None,
                                hoist=self.hoist[l], zx_ws=self.zx)
             inp = self.hbuf[l][1:]
         return self.S
@@ -135,7 +127,7 @@ class LstmStack:
             kn, bn = self.names(l)
             args = (inp, tw.shadow_fwd[kn], tw.store.p(bn), self.lens, T, M, self.kin[l], H, self.hbuf[l],
                     self.S[:, (2 * l) * H:], self.S[:, (2 * l + 1) * H:], 2 * self.L * H,
-                    self.tape[l] if self.training else None, self.hT[l] if self.training else None)
+                    self.gates[l] if self.training else None, self.c_all[l] if self.training else None)
             ops.lstm_layer_fwd(*args, hoist=self.hoist[l], zx_ws=self.zx)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -161,7 +153,7 @@ class LstmStack:
             w = tw.shadow_bwd[kn]                                   # [kin+H][4H] bf16, 4H axis gate-interleaved
             kin = self.kin[l]
             KP = self.KP
-            ops.lstm_layer_bwd(w, self.lens, T, M, kin, H, self.tape[l],
+            ops.lstm_layer_bwd(w, self.lens, T, M, kin, H, self.gates[l], self.c_all[l],
                                dS[:, (2 * l) * H:], dS[:, (2 * l + 1) * H:], 2 * L * H,
                                dh_above, self.dc_ws, self.dz)
             # dz^T in TF gate order for the weight-gradient GEMM (direct 4-row stores from the step
@@ -179,21 +171,12 @@ class LstmStack:
                 dx_out = self.dx[0]
             # dW^T [4H][kin+H] = dz^T . [x_in | h_prev]; db = rowsum(dz^T)
             gW = tw.store.g(kn)                                     # [4H][kin+H] f32
-            if self.direct_T:
-                if l == 0:
-                    ops.transpose_to_bf16(self.x_in.reshape(T * M, kin), T * M, kin, self.xT, KP)
-                    inT, ld_in = self.xT, self.xT.stride(0)
-                else:
-                    inT, ld_in = self.hT[l - 1][:, M:], self.ldT       # lower layer's h_t^T = columns [M, (T+1)M)
-                ops.gemm_nt(self.dzT, inT, 4 * H, kin, KP, gW, ldb=ld_in, ldc=kin + H)
-                ops.gemm_nt(self.dzT, self.hT[l], 4 * H, H, KP, gW[:, kin:], ldb=self.ldT, ldc=kin + H)
-            else:   # ragged M (not a multiple of 8): h / input transposes by the stand-alone kernel too
-                layer_in = self.x_in if l == 0 else self.hbuf[l - 1][1:]
-                inT = self.xT if l == 0 else self.inT_ws
-                ops.transpose_to_bf16(layer_in.reshape(T * M, kin), T * M, kin, inT, KP)
-                ops.transpose_to_bf16(self.hbuf[l][:T].reshape(T * M, H), T * M, H, self.hT_ws, KP)
-                ops.gemm_nt(self.dzT, inT, 4 * H, kin, KP, gW, ldc=kin + H)
-                ops.gemm_nt(self.dzT, self.hT_ws, 4 * H, H, KP, gW[:, kin:], ldc=kin + H)
+            layer_in = self.x_in if l == 0 else self.hbuf[l - 1][1:]
+            inT = self.xT[:kin]
+            ops.transpose_to_bf16(layer_in.reshape(T * M, kin), T * M, kin, inT, KP)
+            ops.transpose_to_bf16(self.hbuf[l][:T].reshape(T * M, H), T * M, H, self.hT_ws, KP)
+            ops.gemm_nt(self.dzT, inT, 4 * H, kin, KP, gW, ldc=kin + H)
+            ops.gemm_nt(self.dzT, self.hT_ws, 4 * H, H, KP, gW[:, kin:], ldc=kin + H)
             ops.rowsum_bf16(self.dzT, 4 * H, KP, tw.store.g(bn))
         return dx_out
 

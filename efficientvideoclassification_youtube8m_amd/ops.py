@@ -99,13 +99,13 @@ def frame_counts(num_frames, every_n, num_chunks, chunk_len, max_frames=300):
 
 # ---------------------------------------------------------------------------
 def lstm_layer_fwd(x, wT, bias, lens, T, M, Kin, H, hbuf, c_state, h_state, ld_state,
-                   tape=None, hT=None, hoist=False, zx_ws=None):
+                   gates=None, c_all=None, hoist=False, zx_ws=None):
     _lib.call("evc_lstm_layer_fwd", _p(x), _p(wT), _p(bias), _p(lens), T, M, Kin, H, 1 if hoist else 0, _p(zx_ws),
-              _p(hbuf), _p(c_state), _p(h_state), ld_state, _p(tape), _p(hT), hT.stride(0) if hT is not None else 0, _stream())
+              _p(hbuf), _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_all), _stream())
 
 
-def lstm_layer_bwd(w_il, lens, T, M, Kin, H, tape, dS_c, dS_h, ld_dS, dh_above, dc_ws, dz4):
-    _lib.call("evc_lstm_layer_bwd", _p(w_il), _p(lens), T, M, Kin, H, _p(tape), _p(dS_c), _p(dS_h), ld_dS,
+def lstm_layer_bwd(w_il, lens, T, M, Kin, H, gates, c_all, dS_c, dS_h, ld_dS, dh_above, dc_ws, dz4):
+    _lib.call("evc_lstm_layer_bwd", _p(w_il), _p(lens), T, M, Kin, H, _p(gates), _p(c_all), _p(dS_c), _p(dS_h), ld_dS,
               _p(dh_above), _p(dc_ws), _p(dz4), _stream())
 
 

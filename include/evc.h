@@ -96,18 +96,18 @@ int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, 
  * c_state/h_state: f32 final state columns, row stride ld_state (so they can
  *        point into the [M, 2*L*H] state tensor concat([c0,h0,c1,h1]));
  *        zero for len == 0.
- * tape  [T][M][H] 16-byte records {bf16 i, j | bf16 f, o | f32 c_new | f32 c_old}
- *        (post-activation gates and cell values) saved for the backward pass, or NULL.
- * hT    [H][ld_hT] bf16 or NULL: h transposed, written by the step epilogue as
- *        8-byte (4-row) stores: hT[u][(t+1)*M + m] = h_t[m][u], columns [0,M) = 0.
- *        It is the K-contiguous operand of the weight-gradient GEMM (h_prev^T =
- *        columns [0,T*M), and the next layer's input^T = columns [M,(T+1)*M)).
- *        Needs M % 4 == 0, ld_hT % 4 == 0, ld_hT >= (T+1)*M.
+ * gates [T][M][H] 8-byte records (bf16 post-activation i, j, f, o) and
+ * c_all [(T+1)][M][H] f32 (slab t+1 = cell state after step t; slab 0 is never read) are the
+ *        history kept for the backward pass; both NULL = inference (c_state is then updated in
+ *        place each step; with history it is written once, at t = len-1).
+ * Epilogue layout: the MFMA is issued with the weight fragment first, so a lane holds 4
+ * consecutive units of one row and every state / tape / h access is an 8-16 byte vector access
+ * (c_state, h_state, bias 16-byte aligned; ld_state % 4 == 0).
  */
 int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const float* bias, const int32_t* len,
                        int T, int M, int Kin, int H, int hoist, float* zx_ws,
                        evc_bf16* hbuf, float* c_state, float* h_state, int64_t ld_state,
-                       void* tape, evc_bf16* hT, int64_t ld_hT, void* stream);
+                       void* gates, float* c_all, void* stream);
 
 /* BPTT of the above (what tf.gradients builds inside
  * slim.learning.create_train_op, cs/train.py:329-334,413-418).
@@ -122,7 +122,7 @@ int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const float* bias,
  *        weight-gradient GEMM; writing it from this kernel's epilogue was measured 2.4x slower.)
  */
 int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int T, int M, int Kin, int H,
-                       const void* tape, const float* dS_c, const float* dS_h, int64_t ld_dS,
+                       const void* gates, const float* c_all, const float* dS_c, const float* dS_h, int64_t ld_dS,
                        const float* dh_above, float* dc_ws, evc_bf16* dz4, void* stream);
 
 /* ---- layout helpers --------------------------------------------------------

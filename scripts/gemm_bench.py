@@ -36,17 +36,17 @@ def lstm(M, T, Kin, H, hoist, name):
     ln = torch.full((M,), T, dtype=torch.int32, device=dev)
     hbuf = torch.empty(T + 1, M, H, dtype=torch.bfloat16, device=dev)
     S = torch.empty(M, 2 * H, device=dev)
-    tape = torch.empty(T, M, H, 4, dtype=torch.int32, device=dev)
-    hT = torch.zeros(H, ops.round_up((T + 1) * M, 64) + 64, dtype=torch.bfloat16, device=dev) if M % 8 == 0 else None
+    gates = torch.empty(T, M, H, 2, dtype=torch.int32, device=dev)
+    call = torch.empty(T + 1, M, H, device=dev)
     zx = torch.empty(T * M, 4 * H, device=dev) if hoist else None
-    f = lambda: ops.lstm_layer_fwd(x, wT, b, ln, T, M, Kin, H, hbuf, S[:, :H], S[:, H:], 2 * H, tape, hT, hoist=hoist, zx_ws=zx)
+    f = lambda: ops.lstm_layer_fwd(x, wT, b, ln, T, M, Kin, H, hbuf, S[:, :H], S[:, H:], 2 * H, gates, call, hoist=hoist, zx_ws=zx)
     ms = bench(f, 5)
     fl = 2.0 * M * 4 * H * (Kin * T + H * (T - 1))
     print("%-28s M=%6d T=%3d Kin=%5d H=%5d  %8.3f ms/layer %7.1f us/step %7.1f TFLOP/s" % (name, M, T, Kin, H, ms, ms / T * 1e3, fl / ms / 1e9))
     dS = torch.randn(M, 2 * H, device=dev)
     dz = torch.empty(T, M, 4 * H, dtype=torch.bfloat16, device=dev)
     dcw = torch.empty(M, H, device=dev)
-    g = lambda: ops.lstm_layer_bwd(w, ln, T, M, Kin, H, tape, dS[:, :H], dS[:, H:], 2 * H, None, dcw, dz)
+    g = lambda: ops.lstm_layer_bwd(w, ln, T, M, Kin, H, gates, call, dS[:, :H], dS[:, H:], 2 * H, None, dcw, dz)
     ms = bench(g, 5)
     fl = 2.0 * M * 4 * H * H * (T - 1)
     print("%-28s bwd                           %8.3f ms/layer %7.1f us/step %7.1f TFLOP/s" % ("", ms, ms / T * 1e3, fl / ms / 1e9))
