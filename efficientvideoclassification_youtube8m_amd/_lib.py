@@ -19,6 +19,8 @@ SIGNATURES = {
     "evc_l2norm_chunk_fwd": [vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp, i32, vp],
     "evc_frame_counts": [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp],
     "evc_gemm_nt": [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i32, i32, vp],
+    "evc_gemm_tn": [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp],
+    "evc_colsum_bf16": [vp, i64, i32, i32, i32, vp, vp],
     "evc_lstm_layer_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp],
     "evc_lstm_layer_bwd": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp],
     "evc_transpose_to_bf16": [vp, i32, i64, i32, i32, vp, i64, i32, i32, vp],

@@ -261,6 +261,38 @@ extern "C" int evc_rowsum_bf16(const evc_bf16* in, int64_t ld_in, int R, int C, 
   return EVC_OK;
 }
 
+// column sums of a bf16 [R][C] matrix (bias gradient straight from dz, no transposed copy):
+// out[perm(c)] += sum_r in[r][c]; a wave reads 1 KiB contiguous per row (16 B per lane).
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ in, long ld, int R, int C, int il_H,
+                                                          float* __restrict__ out) {
+  const int c8 = (blockIdx.x * 256 + threadIdx.x) * 8;
+  if (c8 >= C) return;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int r = blockIdx.y; r < R; r += gridDim.y) {
+    const uint4 q = *(const uint4*)(in + (long)r * ld + c8);
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s[2 * k] += __uint_as_float(w[k] << 16); s[2 * k + 1] += __uint_as_float(w[k] & 0xffff0000u); }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = c8 + k;
+    const int co = il_H > 0 ? (c & 3) * il_H + (c >> 2) : c;     // gate-interleaved column u*4+g -> TF position g*H+u
+    atomicAdd(&out[co], s[k]);
+  }
+}
+extern "C" int evc_colsum_bf16(const evc_bf16* in, int64_t ld_in, int R, int C, int deinterleave_H, float* out, void* stream) {
+  EVC_REQUIRE(R > 0 && C > 0 && C % 8 == 0 && ld_in % 8 == 0 && ((uintptr_t)in % 16) == 0, EVC_ERR_BAD_SHAPE, "evc_colsum_bf16: bad shape");
+  EVC_REQUIRE(deinterleave_H == 0 || C == 4 * deinterleave_H, EVC_ERR_BAD_SHAPE, "evc_colsum_bf16: deinterleave_H needs C == 4*H");
+  hipStream_t st = (hipStream_t)stream;
+  EVC_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float) * C, st));
+  const int gx = ceil_div(C / 8, 256);
+  int gy = R / 64; gy = gy < 1 ? 1 : (gy > 512 ? 512 : gy);
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(gx, gy), dim3(256), 0, st, in, ld_in, R, C, deinterleave_H, out);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
 // ---------------------------------------------------------------------------
 // a5: MoE tail
 // ---------------------------------------------------------------------------

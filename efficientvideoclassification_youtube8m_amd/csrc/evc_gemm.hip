@@ -1,6 +1,6 @@
 // GEMM-shaped kernels of the hot path: generic NT GEMM, fused LSTM step
 // (forward, with the gate tail in the epilogue) and fused BPTT step.
-#include "gemm_core_v2.h"
+#include "gemm_core_tn.h"
 #include <mutex>
 #include <stdlib.h>
 
@@ -156,6 +156,73 @@ extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
   if (pick == 1) launch_gemm<CfgPlainV2>(p, s, K, 1, st);
   else if (pick == 2) launch_gemm<CfgPlainBig>(p, s, K, 1, st);
   else launch_gemm<CfgPlainSmall>(p, s, K, 1, st);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// ===========================================================================
+// TN GEMM: C[M,N] (+)= A^T . B with A [K][lda], B [K][ldb] (weight gradients without transposes)
+// ===========================================================================
+struct StoreParamsT {
+  float* C; long ldc; int M, N;
+  int row_il_H;                   // > 0: row m = u*4+g of the product is stored at row g*H+u (gate de-interleave)
+  int accumulate, splits, ksteps_per_split;
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT) void gemm_tn_kernel(GemmOperandsT p, StoreParamsT s, int tiles_m, int tiles_n) {
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x, split = 0;
+  if (s.splits > 1) {
+    split = bid / nwg;
+    bid -= split * nwg;
+    const int k0 = split * s.ksteps_per_split;
+    p.A += (long)k0 * 32 * p.lda;
+    p.B += (long)k0 * 32 * p.ldb;
+    p.nk = min(s.ksteps_per_split, p.nk - k0);
+  }
+  const int id = xcd_remap(bid, nwg);
+  int tm, tn;
+  tile_of(id, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BU;
+  f32x4 acc[Cfg::MI][1][Cfg::NI];
+  gemm_mainloop_tn<Cfg>(p, m0, n0, lds_dyn, acc);
+  TileCoords<Cfg> tc;
+#pragma unroll
+  for (int mi = 0; mi < Cfg::MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < Cfg::NI; ++ni) {
+      const int n = n0 + tc.unit0 + ni * 16;
+      if (n >= s.N) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + tc.row0 + mi * 16 + r;
+        if (m >= s.M) continue;
+        const int mo = s.row_il_H > 0 ? (m & 3) * s.row_il_H + (m >> 2) : m;
+        float* cp = s.C + (long)mo * s.ldc + n;
+        const float v = acc[mi][0][ni][r];
+        if (s.splits > 1) atomicAdd(cp, v);
+        else *cp = s.accumulate ? *cp + v : v;
+      }
+    }
+}
+
+extern "C" int evc_gemm_tn(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, float* C, int64_t ldc,
+                           int M, int N, int K, int row_interleave_H, int accumulate, void* stream) {
+  EVC_REQUIRE(M >= 8 && N >= 8 && K > 0 && M % 8 == 0 && N % 8 == 0 && K % 32 == 0, EVC_ERR_BAD_SHAPE,
+              "evc_gemm_tn: needs M %% 8 == 0, N %% 8 == 0, K %% 32 == 0 (M=%d N=%d K=%d)", M, N, K);
+  EVC_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, EVC_ERR_BAD_ALIGN,
+              "evc_gemm_tn: operands must be 16-byte aligned (lda=%ld ldb=%ld)", (long)lda, (long)ldb);
+  EVC_REQUIRE(row_interleave_H == 0 || M == 4 * row_interleave_H, EVC_ERR_BAD_SHAPE, "evc_gemm_tn: row_interleave_H needs M == 4*H");
+  hipStream_t st = (hipStream_t)stream;
+  GemmOperandsT p{A, lda, B, ldb, M, N, K / 32};
+  const int tm = ceil_div(M, CfgPlainV2::BM), tn = ceil_div(N, CfgPlainV2::BU);
+  int splits = 256 / (tm * tn);
+  if (splits > K / 2048) splits = K / 2048;     // keep >= 64 K steps per split
+  if (splits < 1) splits = 1;
+  StoreParamsT s{C, ldc, M, N, row_interleave_H, accumulate, splits, ceil_div(p.nk, splits)};
+  if (splits > 1 && !accumulate) EVC_CHECK_HIP(hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st));
+  launch_cfg<CfgPlainV2>(gemm_tn_kernel<CfgPlainV2>, tm * tn * splits, st, p, s, tm, tn);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }

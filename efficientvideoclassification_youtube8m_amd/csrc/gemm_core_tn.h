@@ -1,0 +1,186 @@
+// "TN" main loop: acc[m][n] = sum_k A[k][m] * B[k][n], both operands stored with the
+// CONTRACTION index as the row (A [K][lda], B [K][ldb]; m / n contiguous) - the shape of the
+// weight-gradient products dW^T = dz^T . [x | h] where dz, x and h are all [rows = T*M][width].
+// It removes the transposed copies an NT kernel would need.
+//
+// Same skeleton as gemm_core_v2.h (256x256 tile, 8 waves, K steps of 32, 5-deep LDS-DMA ring with
+// counted vmcnt + raw barriers, register-double-buffered fragments).  Differences:
+//  * LDS image per stage: [32 k rows][BM m] bf16 (512-byte rows) - one LDS-DMA wave-instruction
+//    fills two full rows, so the global reads are 512-byte runs.
+//  * MFMA fragments come from ds_read_b64_tr_b16 (hardware transpose read; semantics verified by
+//    scripts/probes/tr_probe.hip): for the 16x16x32 A operand, lane l = 16g + 4q + p supplies the
+//    address of (row k = 8g + 4j + q, columns mc + 4p ..) and receives column mc + (l & 15) of rows
+//    8g + 4j .. +3; j = 0, 1 gives the 8 k values of the fragment.
+//  * Bank conflicts: a 32-lane half reads 8 rows x 32 bytes; 512-byte rows put them all on the same
+//    banks, so 16-byte chunk PAIRS are XOR-swizzled by h(row) = ((row>>3)&1)*4 + (row&3) (applied to
+//    the DMA source address and to the read address): the 8 rows land in 8 distinct 32-byte slots
+//    of the 256-byte bank row.
+//  * M % 8 == 0, N % 8 == 0 (16-byte chunks along m / n), K % 32 == 0; chunks beyond M / N are
+//    clamped in-bounds (results discarded by the epilogue).
+#pragma once
+#include "gemm_core_v2.h"
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+struct GemmOperandsT {
+  const bf16_t* A; long lda;   // [K][lda], m contiguous
+  const bf16_t* B; long ldb;   // [K][ldb], n contiguous
+  int M, N;                    // valid columns of A / B
+  int nk;                      // 32-wide K steps
+};
+
+__device__ __forceinline__ int tn_h(int row) { return (((row >> 3) & 1) << 2) | (row & 3); }
+
+template <class Cfg>
+__device__ __forceinline__ void gemm_mainloop_tn(GemmOperandsT p, const int m0, const int n0, char* lds,
+                                                 f32x4 (&acc)[Cfg::MI][1][Cfg::NI]) {
+  static_assert(Cfg::G == 1 && Cfg::PIPE && !Cfg::RAGGED, "TN loop: plain tiles, pipelined, even staging");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / Cfg::WC, wc = wave % Cfg::WC;
+  constexpr int ACPR = Cfg::BM / 8, BCPR = Cfg::BN / 8;          // 16-byte chunks per k row
+  constexpr int AROWB = Cfg::BM * 2, BROWB = Cfg::BN * 2;
+
+#pragma unroll
+  for (int mi = 0; mi < Cfg::MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < Cfg::NI; ++ni) acc[mi][0][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nk = p.nk;
+  if (nk == 0) return;
+
+  // ---- staging: chunk c = tid + i*NT -> k row c / CPR, physical chunk c % CPR ----
+  long a_off[Cfg::ACH], b_off[Cfg::BCH];
+#pragma unroll
+  for (int i = 0; i < Cfg::ACH; ++i) {
+    const int c = tid + i * Cfg::NT;
+    const int row = c / ACPR, pc = c % ACPR;
+    int col = m0 + ((pc ^ (tn_h(row) << 1)) << 3);
+    col = col + 8 <= p.M ? col : p.M - 8;
+    a_off[i] = (long)row * p.lda + col;
+  }
+#pragma unroll
+  for (int i = 0; i < Cfg::BCH; ++i) {
+    const int c = tid + i * Cfg::NT;
+    const int row = c / BCPR, pc = c % BCPR;
+    int col = n0 + ((pc ^ (tn_h(row) << 1)) << 3);
+    col = col + 8 <= p.N ? col : p.N - 8;
+    b_off[i] = (long)row * p.ldb + col;
+  }
+  const bf16_t* a_base = p.A;
+  const bf16_t* b_base = p.B;
+  const long a_step = 32 * p.lda, b_step = 32 * p.ldb;
+  int slot_issue = 0, slot_read = 0;
+
+  auto stage = [&]() {
+    char* sbase = lds + slot_issue * Cfg::STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < Cfg::ACH; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + a_off[i]),
+                                       (__attribute__((address_space(3))) void*)(sbase + (wave * 64 + i * Cfg::NT) * 16), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < Cfg::BCH; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_base + b_off[i]),
+                                       (__attribute__((address_space(3))) void*)(sbase + Cfg::A_BYTES + (wave * 64 + i * Cfg::NT) * 16), 16, 0, 0);
+    a_base += a_step;
+    b_base += b_step;
+    slot_issue = (slot_issue + 1 == Cfg::STAGES) ? 0 : slot_issue + 1;
+  };
+
+  // ---- fragment (transpose) read addresses within a stage ----
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  int a_rd[Cfg::MI][2], b_rd[Cfg::NI][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = 8 * g + 4 * j + q, hs = tn_h(r) << 1;
+#pragma unroll
+    for (int mi = 0; mi < Cfg::MI; ++mi) {
+      const int mc = wr * Cfg::WM + mi * 16;
+      a_rd[mi][j] = r * AROWB + ((((mc >> 3) + (pp >> 1)) ^ hs) << 4) + ((pp & 1) << 3);
+    }
+#pragma unroll
+    for (int ni = 0; ni < Cfg::NI; ++ni) {
+      const int nc = wc * Cfg::WU + ni * 16;
+      b_rd[ni][j] = Cfg::A_BYTES + r * BROWB + ((((nc >> 3) + (pp >> 1)) ^ hs) << 4) + ((pp & 1) << 3);
+    }
+  }
+  auto tr = [&](const char* ptr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)ptr);
+  };
+  auto read_frags = [&](bf16x8 (&af)[Cfg::MI], bf16x8 (&bfr)[Cfg::NI]) {
+    const char* sb = lds + slot_read * Cfg::STAGE_BYTES;
+    slot_read = (slot_read + 1 == Cfg::STAGES) ? 0 : slot_read + 1;
+#pragma unroll
+    for (int ni = 0; ni < Cfg::NI; ++ni) {
+      const s16x4 lo = tr(sb + b_rd[ni][0]), hi = tr(sb + b_rd[ni][1]);
+      bfr[ni] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int mi = 0; mi < Cfg::MI; ++mi) {
+      const s16x4 lo = tr(sb + a_rd[mi][0]), hi = tr(sb + a_rd[mi][1]);
+      af[mi] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+  };
+  auto mfma_all = [&](const bf16x8 (&af)[Cfg::MI], const bf16x8 (&bfr)[Cfg::NI]) {
+#pragma unroll
+    for (int mi = 0; mi < Cfg::MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < Cfg::NI; ++ni)
+        acc[mi][0][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[ni], acc[mi][0][ni], 0, 0, 0);
+  };
+  auto end_of_step = [&]() {   // see gemm_core_v2.h: retire the LDS reads explicitly, nothing loop-carried for hipcc
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+  };
+  constexpr int AHEAD = Cfg::STAGES - 2;
+  auto wait_landed = [&](int outstanding_stages) {
+    if (outstanding_stages >= AHEAD) wait_vmcnt<AHEAD * Cfg::PER>();
+    else if (outstanding_stages == 2) wait_vmcnt<2 * Cfg::PER>();
+    else if (outstanding_stages == 1) wait_vmcnt<Cfg::PER>();
+    else wait_vmcnt<0>();
+  };
+  static_assert(AHEAD == 3, "TN loop is written for the 5-deep ring");
+
+#pragma unroll
+  for (int i = 0; i < Cfg::STAGES - 1; ++i)
+    if (i < nk) stage();
+
+  auto full_step = [&](const bf16x8 (&afc)[Cfg::MI], const bf16x8 (&bfc)[Cfg::NI], bf16x8 (&afn)[Cfg::MI], bf16x8 (&bfn)[Cfg::NI]) {
+    wait_vmcnt<(AHEAD - 1) * Cfg::PER>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_setprio(1);
+    stage();
+    read_frags(afn, bfn);
+    mfma_all(afc, bfc);
+    __builtin_amdgcn_s_setprio(0);
+    end_of_step();
+  };
+  auto tail_step = [&](int kt, const bf16x8 (&afc)[Cfg::MI], const bf16x8 (&bfc)[Cfg::NI], bf16x8 (&afn)[Cfg::MI], bf16x8 (&bfn)[Cfg::NI]) {
+    if (kt + 1 < nk) {
+      wait_landed(min(nk, kt + Cfg::STAGES - 1) - (kt + 2));
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + Cfg::STAGES - 1 < nk) stage();
+      read_frags(afn, bfn);
+    }
+    mfma_all(afc, bfc);
+    end_of_step();
+  };
+  wait_landed(min(nk, Cfg::STAGES - 1) - 1);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  bf16x8 afA[Cfg::MI], bfA[Cfg::NI], afB[Cfg::MI], bfB[Cfg::NI];
+  read_frags(afA, bfA);
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  int kt = 0;
+  for (; kt + Cfg::STAGES < nk; kt += 2) {
+    full_step(afA, bfA, afB, bfB);
+    full_step(afB, bfB, afA, bfA);
+  }
+  for (; kt + 1 < nk; kt += 2) {
+    tail_step(kt, afA, bfA, afB, bfB);
+    tail_step(kt + 1, afB, bfB, afA, bfA);
+  }
+  if (kt < nk) tail_step(kt, afA, bfA, afB, bfB);
+}

@@ -91,9 +91,11 @@ class LstmStack:
             self.c_all = [torch.empty((T + 1, M, H), dtype=F32, device=dev) for _ in range(L)]
             self.KP = ops.round_up(T * M, 64)
             self.dz = torch.empty((T, M, 4 * H), dtype=BF16, device=dev)          # gate-interleaved [T][M][H][4]
-            self.dzT = torch.zeros((4 * H, self.KP), dtype=BF16, device=dev)      # TF gate order; pad columns stay 0
-            self.xT = torch.empty((max(self.kin), self.KP), dtype=BF16, device=dev)   # layer input transposed
-            self.hT_ws = torch.empty((H, self.KP), dtype=BF16, device=dev)            # h_prev transposed
+            self.use_tn = (T * M) % 32 == 0 and all(k % 8 == 0 for k in self.kin)
+            if not self.use_tn:   # ragged row counts: transposed copies for the NT kernel
+                self.dzT = torch.zeros((4 * H, self.KP), dtype=BF16, device=dev)
+                self.xT = torch.empty((max(self.kin), self.KP), dtype=BF16, device=dev)
+                self.hT_ws = torch.empty((H, self.KP), dtype=BF16, device=dev)
             self.dc_ws = torch.empty((M, H), dtype=F32, device=dev)
             self.dx = [torch.empty((T * M, self.kin[l]), dtype=F32, device=dev) if (l > 0) else None for l in range(L)]
 
@@ -156,9 +158,6 @@ class LstmStack:
             ops.lstm_layer_bwd(w, self.lens, T, M, kin, H, self.gates[l], self.c_all[l],
                                dS[:, (2 * l) * H:], dS[:, (2 * l + 1) * H:], 2 * L * H,
                                dh_above, self.dc_ws, self.dz)
-            # dz^T in TF gate order for the weight-gradient GEMM (direct 4-row stores from the step
-            # epilogue touch 16 rows/pages per store instruction and measured 2.4x slower overall)
-            ops.transpose_to_bf16(self.dz.view(T * M, 4 * H), T * M, 4 * H, self.dzT, KP, interleave_H=-H)
             dz2 = self.dz.view(T * M, 4 * H)
             # gradient wrt the layer input, all T at once (hoisted): dX = dz . Wx^T
             if l > 0:
@@ -169,15 +168,24 @@ class LstmStack:
                     self.dx[0] = torch.empty((T * M, kin), dtype=F32, device=tw.device)
                 ops.gemm_nt(dz2, w, T * M, kin, 4 * H, self.dx[0])
                 dx_out = self.dx[0]
-            # dW^T [4H][kin+H] = dz^T . [x_in | h_prev]; db = rowsum(dz^T)
+            # dW^T [4H][kin+H] = dz^T . [x_in | h_prev]; db = column sums of dz
             gW = tw.store.g(kn)                                     # [4H][kin+H] f32
-            layer_in = self.x_in if l == 0 else self.hbuf[l - 1][1:]
-            inT = self.xT[:kin]
-            ops.transpose_to_bf16(layer_in.reshape(T * M, kin), T * M, kin, inT, KP)
-            ops.transpose_to_bf16(self.hbuf[l][:T].reshape(T * M, H), T * M, H, self.hT_ws, KP)
-            ops.gemm_nt(self.dzT, inT, 4 * H, kin, KP, gW, ldc=kin + H)
-            ops.gemm_nt(self.dzT, self.hT_ws, 4 * H, H, KP, gW[:, kin:], ldc=kin + H)
-            ops.rowsum_bf16(self.dzT, 4 * H, KP, tw.store.g(bn))
+            layer_in = (self.x_in if l == 0 else self.hbuf[l - 1][1:]).reshape(T * M, kin)
+            h_prev = self.hbuf[l][:T].reshape(T * M, H)
+            if self.use_tn:
+                # "TN" products straight from the row-major activations (transpose reads in the kernel);
+                # the gate-interleaved rows of the product are stored in TF gate order
+                ops.gemm_tn(dz2, layer_in, 4 * H, kin, T * M, gW, row_interleave_H=H, ldc=kin + H)
+                ops.gemm_tn(dz2, h_prev, 4 * H, H, T * M, gW[:, kin:], row_interleave_H=H, ldc=kin + H)
+                ops.colsum_bf16(dz2, T * M, 4 * H, tw.store.g(bn), deinterleave_H=H)
+            else:   # T*M not a multiple of 32: transposed copies + NT products
+                ops.transpose_to_bf16(dz2, T * M, 4 * H, self.dzT, KP, interleave_H=-H)
+                inT = self.xT[:kin]
+                ops.transpose_to_bf16(layer_in, T * M, kin, inT, KP)
+                ops.transpose_to_bf16(h_prev, T * M, H, self.hT_ws, KP)
+                ops.gemm_nt(self.dzT, inT, 4 * H, kin, KP, gW, ldc=kin + H)
+                ops.gemm_nt(self.dzT, self.hT_ws, 4 * H, H, KP, gW[:, kin:], ldc=kin + H)
+                ops.rowsum_bf16(self.dzT, 4 * H, KP, tw.store.g(bn))
         return dx_out
 
 

@@ -46,6 +46,19 @@ def gemm_nt(A, B, M, N, K, out, bias=None, accumulate=False, lda=None, ldb=None,
     return out
 
 
+def gemm_tn(A, B, M, N, K, out, row_interleave_H=0, accumulate=False, lda=None, ldb=None, ldc=None):
+    """out[M,N] (+)= A[K,M]^T @ B[K,N] (both row-major over K), f32 out."""
+    assert A.dtype == BF16 and B.dtype == BF16 and out.dtype == F32
+    _lib.call("evc_gemm_tn", _p(A), A.stride(0) if lda is None else lda, _p(B), B.stride(0) if ldb is None else ldb,
+              _p(out), out.stride(0) if ldc is None else ldc, M, N, K, row_interleave_H, 1 if accumulate else 0, _stream())
+    return out
+
+
+def colsum_bf16(x, R, C, out, deinterleave_H=0):
+    _lib.call("evc_colsum_bf16", _p(x), x.stride(0), R, C, deinterleave_H, _p(out), _stream())
+    return out
+
+
 def transpose_to_bf16(x, R, C, out, Rpad, ld_in=None, interleave_H=0):
     """out[c][r] = x[r][c]; out is [C, >=Rpad] bf16 with columns [R,Rpad) zeroed.
     interleave_H: write input row g*H+u to output column u*4+g (gate-interleaved K order)."""

@@ -82,6 +82,15 @@ int evc_frame_counts(const int32_t* num_frames, int B, int every_n, int max_fram
 int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, void* C, int64_t ldc,
                 int M, int N, int K, const float* bias, int out_bf16, int accumulate, void* stream);
 
+/* "TN" product for the weight gradients: C[M,N] (+)= A^T . B with A [K][lda] and B [K][ldb] bf16
+ * (the contraction index is the ROW of both operands - dz, x and h are all [T*M rows][width]),
+ * f32 C.  Uses ds_read_b64_tr_b16 transpose reads, so no transposed copies are needed; long-K
+ * products are split along K and joined with f32 atomics.  M % 8 == 0, N % 8 == 0, K % 32 == 0.
+ * row_interleave_H > 0 (M == 4*H): A's columns are gate-interleaved (dz4); product row u*4+g is
+ * stored at row g*H+u (TF gate order). */
+int evc_gemm_tn(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, float* C, int64_t ldc,
+                int M, int N, int K, int row_interleave_H, int accumulate, void* stream);
+
 /* ---- a3/a4: one BasicLSTMCell layer over T steps with sequence lengths -----
  * tf.nn.dynamic_rnn(MultiRNNCell[BasicLSTMCell(H, forget_bias=1.0)], x,
  * sequence_length=len)  cs/frame_level_models.py:221-235,247-257,291-305,318-328
@@ -139,6 +148,9 @@ int evc_transpose_to_bf16(const void* in, int in_f32, int64_t ld_in, int R, int 
 int evc_cast_f32_to_bf16(const float* in, int64_t ld_in, int R, int C, evc_bf16* out, int64_t ld_out, void* stream);
 /* out[r] = sum_c in[r][c] (bf16 in, f32 out): bias gradients from dz^T. */
 int evc_rowsum_bf16(const evc_bf16* in, int64_t ld_in, int R, int C, float* out, void* stream);
+/* out[c'] = sum_r in[r][c] (bf16 in, f32 out; out is zeroed inside): bias gradients straight from
+ * dz4; deinterleave_H > 0 (C == 4*H) maps gate-interleaved column u*4+g to c' = g*H+u. */
+int evc_colsum_bf16(const evc_bf16* in, int64_t ld_in, int R, int C, int deinterleave_H, float* out, void* stream);
 
 /* ---- a5: MoeModel tail -----------------------------------------------------
  * cs/video_level_models.py:437-448: softmax over M+1 gate logits, sigmoid over

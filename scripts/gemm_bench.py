@@ -28,6 +28,16 @@ def gemm(M, N, K, name):
     print("%-28s M=%6d N=%6d K=%6d  %8.3f ms  %7.1f TFLOP/s  relerr %.1e" % (name, M, N, K, ms, 2.0 * M * N * K / ms / 1e9, err))
 
 
+def gemm_tn(M, N, K, name):
+    A = (torch.randn(K, M, device=dev) * 0.5).bfloat16()
+    B = (torch.randn(K, N, device=dev) * 0.5).bfloat16()
+    C = torch.empty(M, N, device=dev)
+    ms = bench(lambda: ops.gemm_tn(A, B, M, N, K, C))
+    ref = (A[:, :64].float().t() @ B.float())
+    err = (C[:64] - ref).abs().max().item() / ref.abs().max().item()
+    print("%-28s M=%6d N=%6d K=%6d  %8.3f ms  %7.1f TFLOP/s  relerr %.1e" % (name, M, N, K, ms, 2.0 * M * N * K / ms / 1e9, err))
+
+
 def lstm(M, T, Kin, H, hoist, name):
     x = (torch.randn(T, M, Kin, device=dev) * 0.3).bfloat16()
     wT = (torch.randn(4 * H, Kin + H, device=dev) * 0.03).bfloat16()
@@ -58,6 +68,9 @@ if __name__ == "__main__":
     gemm(76800, 4096, 1152, "x-projection (hoisted)")
     gemm(4096, 2176, 76800, "dW L1 layer0")
     gemm(76800, 1024, 4096, "dX L1 layer1")
+    gemm_tn(4096, 4096, 4096, "TN square 4096")
+    gemm_tn(4096, 1152, 76800, "TN dW L1 (x part)")
+    gemm_tn(4096, 1024, 76800, "TN dW L1 (h part)")
     gemm(256, 14148, 4096, "MoE gates fwd")
     gemm(14148, 4096, 256, "MoE dW gates")
     gemm(256, 4096, 14208, "MoE dx")

@@ -261,3 +261,31 @@ def test_batchnorm_relu6_pool_kernels(ops, R, C, S):
     assert np.abs(dx.cpu().numpy() - dx_ref)[:, cols_ok].max() < 1e-4 * max(1.0, np.abs(dx_ref).max())
     assert np.allclose(dg.cpu().numpy()[cols_ok], dg_ref[cols_ok], rtol=1e-4, atol=1e-4)
     assert np.allclose(db.cpu().numpy()[cols_ok], db_ref[cols_ok], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K,il", [(256, 256, 64, 0), (512, 264, 160, 0), (1024, 1152, 4096, 0), (4096, 1152, 10240, 1024),
+                                      (264, 8, 32, 0), (512, 1024, 8192, 128)])
+def test_gemm_tn_and_colsum(ops, M, N, K, il):
+    """C = A^T B with both operands row-major over K (ds_read_b64_tr_b16 transpose reads), incl.
+    split-K atomics (long K), ragged M/N tiles and the gate de-interleaving row map."""
+    rng = np.random.default_rng(M + N + K)
+    A = bf16_round(rng.standard_normal((K, M)) * 0.5)
+    B = bf16_round(rng.standard_normal((K, N)) * 0.5)
+    ref = A.T @ B
+    if il:
+        H = M // 4
+        ref = ref.reshape(H, 4, N).transpose(1, 0, 2).reshape(M, N)       # row u*4+g -> g*H+u
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    ops.gemm_tn(to_bf16(A), to_bf16(B), M, N, K, out, row_interleave_H=(M // 4 if il else 0))
+    got = out.cpu().double().numpy()
+    scale = (np.abs(A.T) @ np.abs(B)).max() + 1.0
+    assert np.isfinite(got).all()
+    assert np.max(np.abs(got - ref)) / scale < 3e-6
+    ops.gemm_tn(to_bf16(A), to_bf16(B), M, N, K, out, row_interleave_H=(M // 4 if il else 0), accumulate=True)
+    assert np.max(np.abs(out.cpu().double().numpy() - 2 * ref)) / scale < 6e-6
+    cs = torch.empty(M, dtype=torch.float32, device=DEV)
+    ops.colsum_bf16(to_bf16(A), K, M, cs, deinterleave_H=(M // 4 if il else 0))
+    cref = A.sum(0)
+    if il:
+        cref = cref.reshape(M // 4, 4).T.reshape(M)
+    assert np.max(np.abs(cs.cpu().double().numpy() - cref)) < 1e-3 * (np.abs(A).sum(0).max() + 1)
