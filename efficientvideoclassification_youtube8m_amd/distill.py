@@ -125,6 +125,7 @@ class DistillGraph:
         self.overlap_towers = overlap_towers
         if self.device.type == "cuda":
             self._side = torch.cuda.Stream(self.device)
+            self._aux_t, self._aux_s = torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)
             self._ev_fwd, self._ev_student = torch.cuda.Event(), torch.cuda.Event()
 
     # ---- data-parallel gradient reduction -------------------------------------
@@ -186,13 +187,12 @@ class DistillGraph:
                                      grad_scale=sc["kl"], accumulate_grad=True)
                     ops.rep_loss(t_state, s_state, self.losses[1:2], self._ds_s, grad_scale=self.rep_w * sc["rep"])
                     ds = self._ds_s
+                early = (lr, self.clip, l2c) if (apply and self.overlap_towers and self.world == 1) else None
                 self.student.backward(ds, self._dp_s,
-                                      on_moe_grads_ready=lambda: self._reduce_tower(self.student, True))
+                                      on_moe_grads_ready=lambda: self._reduce_tower(self.student, True),
+                                      aux=self._aux_s if self.overlap_towers else None, early_apply=early)
                 self._reduce_tower(self.student, False)
-                if apply and two_streams and self.world == 1:
-                    # the student's HBM-bound clip+Adam runs on the side stream under the teacher's BPTT
-                    self.student.apply_gradients(lr, self.clip, l2c)
-                    self._student_applied = True
+                self._student_applied = early is not None
                 if two_streams:
                     self._ev_student.record(side)
                     for t in (xs, n_s, l1s, l2s):          # allocated on `main`, consumed on `side`
@@ -201,15 +201,15 @@ class DistillGraph:
             out.update(student_predictions=s_pred, student_state=s_state, num_frames_student=n_s,
                        student_loss_state=self.losses[1], pred_loss=self.losses[2], student_label_loss=self.losses[3])
         if self.teacher is not None:
+            # weight-gradient GEMMs and the per-group clip+Adam go to an aux stream, under the BPTT chain
+            # (the tower's outputs t_state / t_pred are separate buffers, untouched by the update)
+            early = (lr, self.clip, l2c) if (apply and self.overlap_towers and self.world == 1) else None
             self.teacher.backward(None, self._dp_t,
-                                  on_moe_grads_ready=lambda: self._reduce_tower(self.teacher, True))
+                                  on_moe_grads_ready=lambda: self._reduce_tower(self.teacher, True),
+                                  aux=self._aux_t if self.overlap_towers else None, early_apply=early)
             self._reduce_tower(self.teacher, False)
             out.update(predictions=t_pred, teacher_state=t_state, loss=self.losses[0])
-            if apply and two_streams and self.world == 1:
-                # the teacher's HBM-bound clip+Adam overlaps the student's remaining kernels on the side stream
-                # (its outputs t_state / t_pred are separate buffers, untouched by the update)
-                self.teacher.apply_gradients(lr, self.clip, l2c)
-                self._teacher_applied = True
+            self._teacher_applied = early is not None
         if two_streams:
             main.wait_event(self._ev_student)
         self.reducer.wait()

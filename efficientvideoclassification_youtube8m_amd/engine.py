@@ -90,7 +90,8 @@ class LstmStack:
             self.gates = [torch.empty((T, M, H, 2), dtype=torch.int32, device=dev) for _ in range(L)]
             self.c_all = [torch.empty((T + 1, M, H), dtype=F32, device=dev) for _ in range(L)]
             self.KP = ops.round_up(T * M, 64)
-            self.dz = torch.empty((T, M, 4 * H), dtype=BF16, device=dev)          # gate-interleaved [T][M][H][4]
+            self.dz = [torch.empty((T, M, 4 * H), dtype=BF16, device=dev) for _ in range(L)]   # gate-interleaved [T][M][H][4];
+            # one per layer so a layer's weight-gradient GEMMs (aux stream) can run under the next layer's BPTT
             self.use_tn = (T * M) % 32 == 0 and all(k % 8 == 0 for k in self.kin)
             if not self.use_tn:   # ragged row counts: transposed copies for the NT kernel
                 self.dzT = torch.zeros((4 * H, self.KP), dtype=BF16, device=dev)
@@ -143,22 +144,25 @@ class LstmStack:
             inp = self.hbuf[l][1:]
         return res
 
-    def backward(self, dS, need_dx):
-        """dS [M, 2LH] f32.  Accumulates nothing: writes grads of this stack's
-        kernels/biases into the tower's grad buffer; returns dX [T*M, Kin] f32
-        (gradient wrt the stack input) if need_dx."""
+    def backward(self, dS, need_dx, aux=None):
+        """dS [M, 2LH] f32.  Writes the grads of this stack's kernels/biases into the tower's grad
+        buffer; returns dX [T*M, Kin] f32 (gradient wrt the stack input) if need_dx.
+        aux: optional side stream for the weight-gradient products, which nothing on the BPTT
+        critical path waits for; the caller joins it before using the gradients."""
         tw, H, L, T, M = self.tw, self.H, self.L, self.T, self.M
         dh_above = None
         dx_out = None
+        main = torch.cuda.current_stream(tw.device)
         for l in range(L - 1, -1, -1):
             kn, bn = self.names(l)
             w = tw.shadow_bwd[kn]                                   # [kin+H][4H] bf16, 4H axis gate-interleaved
             kin = self.kin[l]
             KP = self.KP
+            dz = self.dz[l]
             ops.lstm_layer_bwd(w, self.lens, T, M, kin, H, self.gates[l], self.c_all[l],
                                dS[:, (2 * l) * H:], dS[:, (2 * l + 1) * H:], 2 * L * H,
-                               dh_above, self.dc_ws, self.dz)
-            dz2 = self.dz.view(T * M, 4 * H)
+                               dh_above, self.dc_ws, dz)
+            dz2 = dz.view(T * M, 4 * H)
             # gradient wrt the layer input, all T at once (hoisted): dX = dz . Wx^T
             if l > 0:
                 ops.gemm_nt(dz2, w, T * M, kin, 4 * H, self.dx[l])
@@ -169,23 +173,30 @@ class LstmStack:
                 ops.gemm_nt(dz2, w, T * M, kin, 4 * H, self.dx[0])
                 dx_out = self.dx[0]
             # dW^T [4H][kin+H] = dz^T . [x_in | h_prev]; db = column sums of dz
-            gW = tw.store.g(kn)                                     # [4H][kin+H] f32
-            layer_in = (self.x_in if l == 0 else self.hbuf[l - 1][1:]).reshape(T * M, kin)
-            h_prev = self.hbuf[l][:T].reshape(T * M, H)
-            if self.use_tn:
-                # "TN" products straight from the row-major activations (transpose reads in the kernel);
-                # the gate-interleaved rows of the product are stored in TF gate order
-                ops.gemm_tn(dz2, layer_in, 4 * H, kin, T * M, gW, row_interleave_H=H, ldc=kin + H)
-                ops.gemm_tn(dz2, h_prev, 4 * H, H, T * M, gW[:, kin:], row_interleave_H=H, ldc=kin + H)
-                ops.colsum_bf16(dz2, T * M, 4 * H, tw.store.g(bn), deinterleave_H=H)
-            else:   # T*M not a multiple of 32: transposed copies + NT products
-                ops.transpose_to_bf16(dz2, T * M, 4 * H, self.dzT, KP, interleave_H=-H)
-                inT = self.xT[:kin]
-                ops.transpose_to_bf16(layer_in, T * M, kin, inT, KP)
-                ops.transpose_to_bf16(h_prev, T * M, H, self.hT_ws, KP)
-                ops.gemm_nt(self.dzT, inT, 4 * H, kin, KP, gW, ldc=kin + H)
-                ops.gemm_nt(self.dzT, self.hT_ws, 4 * H, H, KP, gW[:, kin:], ldc=kin + H)
-                ops.rowsum_bf16(self.dzT, 4 * H, KP, tw.store.g(bn))
+            side = main
+            if aux is not None:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                aux.wait_event(ev)
+                side = aux
+            with torch.cuda.stream(side):
+                gW = tw.store.g(kn)                                     # [4H][kin+H] f32
+                layer_in = (self.x_in if l == 0 else self.hbuf[l - 1][1:]).reshape(T * M, kin)
+                h_prev = self.hbuf[l][:T].reshape(T * M, H)
+                if self.use_tn:
+                    # "TN" products straight from the row-major activations (transpose reads in the kernel);
+                    # the gate-interleaved rows of the product are stored in TF gate order
+                    ops.gemm_tn(dz2, layer_in, 4 * H, kin, T * M, gW, row_interleave_H=H, ldc=kin + H)
+                    ops.gemm_tn(dz2, h_prev, 4 * H, H, T * M, gW[:, kin:], row_interleave_H=H, ldc=kin + H)
+                    ops.colsum_bf16(dz2, T * M, 4 * H, tw.store.g(bn), deinterleave_H=H)
+                else:   # T*M not a multiple of 32: transposed copies + NT products
+                    ops.transpose_to_bf16(dz2, T * M, 4 * H, self.dzT, KP, interleave_H=-H)
+                    inT = self.xT[:kin]
+                    ops.transpose_to_bf16(layer_in, T * M, kin, inT, KP)
+                    ops.transpose_to_bf16(h_prev, T * M, H, self.hT_ws, KP)
+                    ops.gemm_nt(self.dzT, inT, 4 * H, kin, KP, gW, ldc=kin + H)
+                    ops.gemm_nt(self.dzT, self.hT_ws, 4 * H, H, KP, gW[:, kin:], ldc=kin + H)
+                    ops.rowsum_bf16(self.dzT, 4 * H, KP, tw.store.g(bn))
         return dx_out
 
 
@@ -301,23 +312,36 @@ class TowerBase:
                 v.copy_(sd[key].to(self.device, F32))
         self.refresh_shadows()
 
-    def apply_gradients(self, lr, clip_norm=1.0, l2_coeff=0.0, beta1=0.9, beta2=0.999, eps=1e-8):
-        """slim create_train_op semantics: per-tensor clip_by_norm, TF-Adam
-        (cs/train.py:329-334); the l2 regulariser gradient
-        (regularization_penalty * 1e-8 * W) is folded into the gradient before the norm."""
+    def begin_update(self):
+        """Start one optimizer step (one tf.train op): bumps the Adam step count, clears the norm sums."""
         self.adam_t += 1
+        self.sums.zero_()
+
+    def apply_group(self, names, lr, clip_norm=1.0, l2_coeff=0.0, beta1=0.9, beta2=0.999, eps=1e-8, refresh=True):
+        """Per-tensor clip_by_norm + TF-Adam for a subset of the variables (their gradients must be
+        final).  slim create_train_op semantics (cs/train.py:329-334); the l2 regulariser gradient
+        (regularization_penalty * 1e-8 * W) is folded into the gradient before the norm."""
         t = self.adam_t
         lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
-        self.sums.zero_()
-        for i, k in enumerate(self.names):
+        idx = {k: i for i, k in enumerate(self.names)}
+        for k in names:
             l2 = l2_coeff if k in self.l2_names else 0.0
-            ops.grad_sqnorm(self.store.g(k), self.store.p(k), l2, self.sums[i])
-        for i, k in enumerate(self.names):
+            ops.grad_sqnorm(self.store.g(k), self.store.p(k), l2, self.sums[idx[k]])
+        for k in names:
             l2 = l2_coeff if k in self.l2_names else 0.0
             ops.clip_adam_step(self.store.p(k), self.store.g(k), self.store.view(self.store.m, k),
-                               self.store.view(self.store.v, k), l2, self.sums[i], clip_norm, lr_t, beta1, beta2, eps,
+                               self.store.view(self.store.v, k), l2, self.sums[idx[k]], clip_norm, lr_t, beta1, beta2, eps,
                                p_bf16=self.shadow_fwd.get(k))
-        self.refresh_shadows(fwd=False)
+        if refresh:
+            for k in names:
+                if k in self.shadow_bwd:
+                    p, sb = self.store.p(k), self.shadow_bwd[k]
+                    il = p.shape[0] // 4 if k.endswith("basic_lstm_cell/kernel") else 0
+                    ops.transpose_to_bf16(p, p.shape[0], p.shape[1], sb, sb.shape[1], interleave_H=il)
+
+    def apply_gradients(self, lr, clip_norm=1.0, l2_coeff=0.0, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.begin_update()
+        self.apply_group(self.names, lr, clip_norm, l2_coeff, beta1, beta2, eps)
 
     def reg_loss(self):
         """sum of slim.l2_regularizer(1e-8) terms, from the norms of the last apply_gradients()."""
@@ -408,12 +432,41 @@ class HLstmTower(TowerBase):
         return S2, self.moe.forward(S2)
 
     # ---- backward -----------------------------------------------------------
-    def backward(self, dstate, dpred, on_moe_grads_ready=None):
+    def param_groups(self):
+        """Variables in the order their gradients become final during backward()."""
+        moe = [self.GATES, self.EXPERTS, self.EBIAS]
+        l2 = [k for k in self.names if k.startswith("RNN_L2/")]
+        l1 = [k for k in self.names if k.startswith("RNN_L1/")]
+        return moe, l2, l1
+
+    def backward(self, dstate, dpred, on_moe_grads_ready=None, aux=None, early_apply=None):
         """dstate [B,2LH] f32 or None (gradient on the returned state), dpred [B,V] f32.
-        Fills self.store.grad (every segment is overwritten)."""
+        Fills self.store.grad (every segment is overwritten).
+        aux: side stream that takes the weight-gradient GEMMs (and, with early_apply =
+        (lr, clip, l2_coeff), the clip+Adam of each variable group as soon as its gradients are final)
+        off the BPTT critical path; it is joined into the current stream before returning."""
         assert self.training
+        main = torch.cuda.current_stream(self.device)
+        g_moe, g_l2, g_l1 = self.param_groups()
         dS2 = self.moe.backward(dpred, dstate)
         if on_moe_grads_ready is not None:
             on_moe_grads_ready()
-        dS1 = self.l2.backward(dS2, need_dx=True)                      # [C*B][2LH] = d(L1 final state)
-        self.l1.backward(dS1, need_dx=False)
+        if aux is not None and early_apply is not None:
+            self.begin_update()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            aux.wait_event(ev)
+            with torch.cuda.stream(aux):
+                self.apply_group(g_moe, *early_apply)                  # 2/3 of the parameters, under the LSTM BPTT
+        dS1 = self.l2.backward(dS2, need_dx=True, aux=aux)              # [C*B][2LH] = d(L1 final state)
+        if aux is not None and early_apply is not None:
+            with torch.cuda.stream(aux):                               # after L2's weight-gradient GEMMs (same stream)
+                self.apply_group(g_l2, *early_apply)
+        self.l1.backward(dS1, need_dx=False, aux=aux)
+        if aux is not None:
+            if early_apply is not None:
+                with torch.cuda.stream(aux):
+                    self.apply_group(g_l1, *early_apply)
+            ev = torch.cuda.Event()
+            ev.record(aux)
+            main.wait_event(ev)
