@@ -43,7 +43,8 @@ template <bool U8>
 __global__ __launch_bounds__(256) void l2norm_chunk_kernel(const float* __restrict__ x, const uint8_t* __restrict__ xq,
                                                            const int* __restrict__ nfr, int B, int T, int F, int C1,
                                                            bf16_t* __restrict__ out1, int every_n, int C2,
-                                                           bf16_t* __restrict__ out2, int normalize) {
+                                                           bf16_t* __restrict__ out2, int normalize,
+                                                           bf16_t* __restrict__ out1_lo, bf16_t* __restrict__ out2_lo) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // b*T + s
   if (row >= (long)B * T) return;
@@ -74,11 +75,14 @@ __global__ __launch_bounds__(256) void l2norm_chunk_kernel(const float* __restri
   const int L1 = T / C1;
   bf16_t* o1 = out1 + (((long)(s % L1) * C1 + s / L1) * B + b) * F;
   bf16_t* o2 = nullptr;
+  const long off1 = (((long)(s % L1) * C1 + s / L1) * B + b) * F;
+  long off2 = 0;
   if (out2 && (s % every_n) == 0) {
     const int s2 = s / every_n, S2 = T / every_n;
     if (s2 < S2) {
       const int L2 = S2 / C2;
-      o2 = out2 + (((long)(s2 % L2) * C2 + s2 / L2) * B + b) * F;
+      off2 = (((long)(s2 % L2) * C2 + s2 / L2) * B + b) * F;
+      o2 = out2 + off2;
     }
   }
 #pragma unroll
@@ -90,13 +94,21 @@ __global__ __launch_bounds__(256) void l2norm_chunk_kernel(const float* __restri
       o.z = f32_to_bf16(v[i].z * inv); o.w = f32_to_bf16(v[i].w * inv);
       ((ushort4*)o1)[j] = o;
       if (o2) ((ushort4*)o2)[j] = o;
+      if (out1_lo) {     // split-bf16 parity mode: low-order halves
+        ushort4 l;
+        l.x = f32_to_bf16(v[i].x * inv - bf16_to_f32(o.x)); l.y = f32_to_bf16(v[i].y * inv - bf16_to_f32(o.y));
+        l.z = f32_to_bf16(v[i].z * inv - bf16_to_f32(o.z)); l.w = f32_to_bf16(v[i].w * inv - bf16_to_f32(o.w));
+        ((ushort4*)(out1_lo + off1))[j] = l;
+        if (o2 && out2_lo) ((ushort4*)(out2_lo + off2))[j] = l;
+      }
     }
   }
 }
 
 extern "C" int evc_l2norm_chunk_fwd(const float* x_raw, const uint8_t* x_u8, const int32_t* num_frames,
                                     int B, int T, int F, int C1, evc_bf16* out1,
-                                    int every_n, int C2, evc_bf16* out2, int normalize, void* stream) {
+                                    int every_n, int C2, evc_bf16* out2, int normalize,
+                                    evc_bf16* out1_lo, evc_bf16* out2_lo, void* stream) {
   EVC_REQUIRE(B > 0 && T > 0 && F > 0 && F % 4 == 0 && F <= 1280, EVC_ERR_BAD_SHAPE,
               "evc_l2norm_chunk_fwd: F=%d must be a multiple of 4 and <= 1280", F);
   EVC_REQUIRE(C1 > 0 && T % C1 == 0, EVC_ERR_BAD_SHAPE, "evc_l2norm_chunk_fwd: T=%d not divisible by C1=%d", T, C1);
@@ -109,10 +121,10 @@ extern "C" int evc_l2norm_chunk_fwd(const float* x_raw, const uint8_t* x_u8, con
   dim3 grid((unsigned)((rows + 3) / 4));
   if (x_u8)
     hipLaunchKernelGGL(l2norm_chunk_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x_raw, x_u8, num_frames, B, T, F,
-                       C1, out1, every_n > 0 ? every_n : 1, C2, out2, normalize);
+                       C1, out1, every_n > 0 ? every_n : 1, C2, out2, normalize, out1_lo, out2_lo);
   else
     hipLaunchKernelGGL(l2norm_chunk_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x_raw, x_u8, num_frames, B, T, F,
-                       C1, out1, every_n > 0 ? every_n : 1, C2, out2, normalize);
+                       C1, out1, every_n > 0 ? every_n : 1, C2, out2, normalize, out1_lo, out2_lo);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }
@@ -235,6 +247,28 @@ extern "C" int evc_cast_f32_to_bf16(const float* in, int64_t ld_in, int R, int C
   const long n = (long)R * C;
   const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   hipLaunchKernelGGL(cast_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, ld_in, R, C, out, ld_out);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// split-bf16: hi = bf16(x), lo = bf16(x - hi): hi + lo carries ~16 mantissa bits of x
+__global__ void cast_split_kernel(const float* __restrict__ in, long ld_in, int R, int C, bf16_t* __restrict__ hi,
+                                  bf16_t* __restrict__ lo, long ld_out) {
+  const long n = (long)R * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C, c = i % C;
+    const float x = in[r * ld_in + c];
+    const bf16_t h = f32_to_bf16(x);
+    hi[r * ld_out + c] = h;
+    lo[r * ld_out + c] = f32_to_bf16(x - bf16_to_f32(h));
+  }
+}
+extern "C" int evc_cast_f32_to_bf16_split(const float* in, int64_t ld_in, int R, int C, evc_bf16* hi, evc_bf16* lo,
+                                          int64_t ld_out, void* stream) {
+  EVC_REQUIRE(R > 0 && C > 0, EVC_ERR_BAD_SHAPE, "evc_cast_f32_to_bf16_split: bad shape");
+  const long n = (long)R * C;
+  const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(cast_split_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, ld_in, R, C, hi, lo, ld_out);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }

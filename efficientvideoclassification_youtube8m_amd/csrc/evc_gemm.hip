@@ -11,13 +11,14 @@ template <int a, int b, int c, int d, int e, int f, bool g> struct is_v2<TileCfg
 
 extern __shared__ __attribute__((aligned(16))) char lds_dyn[];
 
-template <class Cfg, int NG, bool SWAP = false>
+template <class Cfg, int NG, bool SWAP = false, bool SPLIT = false>
 __device__ __forceinline__ void run_mainloop(const GemmOperands& p, int m0, int u0, f32x4 (&acc)[Cfg::MI][NG][Cfg::NI]) {
   if constexpr (is_v2<Cfg>::value) {
+    static_assert(!SPLIT, "the split-bf16 parity mode runs on the v1 tiles");
     gemm_mainloop_v2<Cfg, SWAP>(p, m0, u0, lds_dyn, acc);
   } else {
-    __shared__ __attribute__((aligned(16))) char lds_static[Cfg::LDS_BYTES];   // static: keeps 2 workgroups per CU
-    gemm_mainloop<Cfg, SWAP>(p, m0, u0, lds_static, acc);
+    __shared__ __attribute__((aligned(16))) char lds_static[(SPLIT ? 2 : 1) * Cfg::LDS_BYTES];   // static: keeps 2 workgroups per CU
+    gemm_mainloop<Cfg, SWAP, SPLIT>(p, m0, u0, lds_static, acc);
   }
 }
 
@@ -128,6 +129,7 @@ extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
   GemmOperands p;
   p.A1 = A; p.lda1 = lda; p.nk1 = 0; p.A2 = A; p.lda2 = lda; p.nk2 = 0;
   p.B = B; p.ldb = ldb; p.group_stride = 0; p.M = M; p.Nu = N;
+  p.A1lo = p.A2lo = p.Blo = nullptr;
   StoreParams s{C, ldc, M, N, bias, out_bf16, accumulate, 1, 0};
   hipStream_t st = (hipStream_t)stream;
   // Split-K: a long-K product with too few 256x256 tiles to fill the 256 CUs (the weight-gradient
@@ -236,6 +238,7 @@ struct LstmFwdParams {
   const int* len; int t;
   float* c_state; float* h_state; long ld_state;
   bf16_t* hout;                      // [M][H] slab t+1 (row-major: next step's A operand)
+  bf16_t* hout_lo;                   // low-order half of h_t (split-bf16 parity mode) or NULL
   uint2* gates;                      // [M][H] 8-byte records of slab t (or NULL): bf16 {i, j, f, o}
   const float* c_in; float* c_out;   // cell state before / after this step: slabs t and t+1 of c_all, or the
                                      // in-place c_state buffer when no history is kept (c_in == NULL at t == 0)
@@ -246,7 +249,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
 
-template <class Cfg>
+template <class Cfg, bool SPLIT = false>
 __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, LstmFwdParams e, int tiles_m, int tiles_n) {
   static_assert(Cfg::G == 4, "LSTM step needs the four gate groups");
   const int nwg = tiles_m * tiles_n;
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, 
   tile_of(id, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * Cfg::BM, u0 = tn * Cfg::BU;
   f32x4 acc[Cfg::MI][4][Cfg::NI];
-  run_mainloop<Cfg, 4, true>(p, m0, u0, acc);     // transposed accumulators: lane = one row, 4 consecutive units
+  run_mainloop<Cfg, 4, true, SPLIT>(p, m0, u0, acc);     // transposed accumulators: lane = one row, 4 consecutive units
 #ifdef EVC_ABLATE_EPI    // debug build: main loop only (keep the accumulators alive, store nothing)
 #pragma unroll
   for (int mi = 0; mi < Cfg::MI; ++mi)
@@ -280,6 +283,7 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, 
       const long su = (long)m * e.ld_state + u;
       if (e.t >= ln) {              // dynamic_rnn: state copied through, zero output
         *(uint2*)(e.hout + hu) = make_uint2(0u, 0u);
+        if (SPLIT) *(uint2*)(e.hout_lo + hu) = make_uint2(0u, 0u);
         if (e.t == 0) {             // zero-length row: its final state is the zero initial state
           *(float4*)(e.c_state + su) = make_float4(0.f, 0.f, 0.f, 0.f);
           *(float4*)(e.h_state + su) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -322,6 +326,12 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, 
         if (e.gates) *(float4*)(e.c_state + su) = cnv;
       }
       *(uint2*)(e.hout + hu) = make_uint2(pack_bf16x2(hn[0], hn[1]), pack_bf16x2(hn[2], hn[3]));
+      if (SPLIT) {
+        float lo[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lo[r] = hn[r] - bf16_to_f32(f32_to_bf16(hn[r]));
+        *(uint2*)(e.hout_lo + hu) = make_uint2(pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]));
+      }
       if (e.gates) {
         uint4* gp = (uint4*)(e.gates + hu);            // 4 units x 8 bytes
         gp[0] = make_uint4(rec[0].x, rec[0].y, rec[1].x, rec[1].y);
@@ -336,17 +346,42 @@ typedef TileCfg<64, 4, 16, 4, 1> CfgLstmSmall;   // 64 rows x 16 units x 4 gates
 typedef TileCfg2<320, 4, 64, 2, 4, 4, false> CfgLstmV2a;   // 320 rows x 64 units x 4 gates: M=5120,H=1024 -> exactly 256 workgroups
 typedef TileCfg2<256, 4, 64, 2, 4, 5, true> CfgLstmV2b;   // 256 rows x 64 units x 4 gates
 
-template <class Cfg>
+template <class Cfg, bool SPLIT = false>
 static inline void launch_lstm_fwd(GemmOperands p, const LstmFwdParams& e, int k1, int k2, hipStream_t st) {
   p.nk1 = k1 / kdiv<Cfg>(); p.nk2 = k2 / kdiv<Cfg>();
   const int tm = ceil_div(e.M, Cfg::BM), tn = ceil_div(e.H, Cfg::BU);
-  launch_cfg<Cfg>(lstm_fwd_step_kernel<Cfg>, tm * tn, st, p, e, tm, tn);
+  launch_cfg<Cfg>(lstm_fwd_step_kernel<Cfg, SPLIT>, tm * tn, st, p, e, tm, tn);
 }
+
+static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const float* bias, const int32_t* len,
+                               int T, int M, int Kin, int H, int hoist, float* zx_ws,
+                               evc_bf16* hbuf, float* c_state, float* h_state, int64_t ld_state,
+                               void* gates, float* c_all,
+                               const evc_bf16* x_lo, const evc_bf16* wT_lo, evc_bf16* hbuf_lo, void* stream);
 
 extern "C" int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const float* bias, const int32_t* len,
                                   int T, int M, int Kin, int H, int hoist, float* zx_ws,
                                   evc_bf16* hbuf, float* c_state, float* h_state, int64_t ld_state,
                                   void* gates, float* c_all, void* stream) {
+  return lstm_layer_fwd_impl(x, wT, bias, len, T, M, Kin, H, hoist, zx_ws, hbuf, c_state, h_state, ld_state, gates, c_all,
+                             nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int evc_lstm_layer_fwd_hp(const evc_bf16* x, const evc_bf16* x_lo, const evc_bf16* wT, const evc_bf16* wT_lo,
+                                     const float* bias, const int32_t* len, int T, int M, int Kin, int H,
+                                     evc_bf16* hbuf, evc_bf16* hbuf_lo, float* c_state, float* h_state, int64_t ld_state,
+                                     void* gates, float* c_all, void* stream) {
+  EVC_REQUIRE(x_lo && wT_lo && hbuf_lo, EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd_hp: the low-order halves are required");
+  return lstm_layer_fwd_impl(x, wT, bias, len, T, M, Kin, H, 0, nullptr, hbuf, c_state, h_state, ld_state, gates, c_all,
+                             x_lo, wT_lo, hbuf_lo, stream);
+}
+
+static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const float* bias, const int32_t* len,
+                               int T, int M, int Kin, int H, int hoist, float* zx_ws,
+                               evc_bf16* hbuf, float* c_state, float* h_state, int64_t ld_state,
+                               void* gates, float* c_all,
+                               const evc_bf16* x_lo, const evc_bf16* wT_lo, evc_bf16* hbuf_lo, void* stream) {
+  const bool split = x_lo != nullptr;
   EVC_REQUIRE(T > 0 && M > 0 && H > 0 && Kin > 0, EVC_ERR_BAD_SHAPE, "evc_lstm_layer_fwd: bad shape");
   EVC_REQUIRE(Kin % 64 == 0 && H % 64 == 0, EVC_ERR_BAD_SHAPE,
               "evc_lstm_layer_fwd: Kin=%d and H=%d must be multiples of 64", Kin, H);
@@ -361,6 +396,7 @@ extern "C" int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const f
   // h_{-1} = 0 (the state buffers need no clearing: step 0 treats c_old as 0 and writes the zero
   // state of zero-length rows itself)
   EVC_CHECK_HIP(hipMemsetAsync(hbuf, 0, (size_t)M * H * sizeof(bf16_t), st));
+  if (split) EVC_CHECK_HIP(hipMemsetAsync(hbuf_lo, 0, (size_t)M * H * sizeof(bf16_t), st));
   if (hoist) {
     int rc = evc_gemm_nt(x, Kin, wT, ldw, zx_ws, 4L * H, T * M, 4 * H, Kin, nullptr, 0, 0, stream);
     if (rc) return rc;
@@ -375,6 +411,7 @@ extern "C" int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const f
   for (int t = 0; t < T; ++t) {
     GemmOperands p;
     p.M = M; p.Nu = H; p.group_stride = H; p.ldb = ldw; p.nk1 = p.nk2 = 0;
+    p.A1lo = p.A2lo = p.Blo = nullptr;
     const bf16_t* hprev = hbuf + (long)t * M * H;
     int k1, k2;
     if (hoist) {
@@ -384,16 +421,19 @@ extern "C" int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const f
       p.A1 = x + (long)t * M * Kin; p.lda1 = Kin; k1 = Kin;
       p.A2 = hprev; p.lda2 = H; k2 = (t == 0) ? 0 : H;
       p.B = wT;
+      if (split) { p.A1lo = x_lo + (long)t * M * Kin; p.A2lo = hbuf_lo + (long)t * M * H; p.Blo = wT_lo; }
     }
     LstmFwdParams e;
     e.zx = hoist ? zx_ws + (long)t * M * 4 * H : nullptr; e.ldzx = 4L * H;
     e.bias = bias; e.len = len; e.t = t;
     e.c_state = c_state; e.h_state = h_state; e.ld_state = ld_state;
     e.hout = hbuf + (long)(t + 1) * M * H;
+    e.hout_lo = split ? hbuf_lo + (long)(t + 1) * M * H : nullptr;
     e.gates = gates ? (uint2*)gates + (long)t * M * H : nullptr;
     if (c_all) { e.c_in = c_all + (long)t * M * H; e.c_out = c_all + (long)(t + 1) * M * H; }   // slab t+1 = c after step t
     else { e.c_in = c_state; e.c_out = c_state; }
     e.M = M; e.H = H;
+    if (split) { launch_lstm_fwd<CfgLstmSmall, true>(p, e, k1, k2, st); continue; }   // parity mode: v1 64-row tiles, 3 MFMA products
     switch (pick) {
       case 0: launch_lstm_fwd<CfgLstmV2a>(p, e, k1, k2, st); break;
       case 1: launch_lstm_fwd<CfgLstmV2b>(p, e, k1, k2, st); break;
@@ -517,6 +557,7 @@ extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int 
   for (int t = T - 1; t >= 0; --t) {
     GemmOperands p;
     p.M = M; p.Nu = H; p.group_stride = 0; p.nk1 = p.nk2 = 0;
+    p.A1lo = p.A2lo = p.Blo = nullptr;
     p.A1 = dz4 + (long)(t + 1 < T ? t + 1 : t) * M * 4 * H; p.lda1 = 4L * H;   // gate-interleaved K index u*4+g
     p.A2 = p.A1; p.lda2 = p.lda1;
     p.B = w_il + (long)Kin * 4 * H; p.ldb = 4L * H;   // rows Kin..Kin+H of the kernel = Wh [H][4H], same K order

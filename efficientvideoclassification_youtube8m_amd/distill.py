@@ -99,7 +99,8 @@ class DistillGraph:
                  max_frames=300, num_inputs_to_lstm=20, num_inputs_l1_student=5, lstm_cells=1024, lstm_layers=2,
                  num_mixtures=2, base_learning_rate=0.001, learning_rate_decay=1.0,
                  learning_rate_decay_examples=4000000, regularization_penalty=2.0, clip_gradient_norm=1.0,
-                 count_rep_twice=True, device="cuda:0", seed=7, process_group=None, overlap_towers=True):
+                 count_rep_twice=True, device="cuda:0", seed=7, process_group=None, overlap_towers=True,
+                 precision="bf16"):
         assert mode in ("teacher_student", "teacher", "student")
         self.mode, self.B, self.every_n = mode, batch_size, every_n
         self.max_frames, self.C1, self.C2 = max_frames, num_inputs_to_lstm, num_inputs_l1_student
@@ -120,6 +121,11 @@ class DistillGraph:
             self.S = max_frames // every_n
             self.student = HLstmTower(batch_size, self.S, num_inputs_l1_student, feature_size, vocab_size, lstm_cells,
                                       lstm_layers, num_mixtures, device, True, "model_student", seed + 1)
+        self.precision = precision       # "high": split-bf16 operands in every forward GEMM (parity mode, ~3x fwd MFMA work)
+        if precision == "high":
+            for tw in (self.teacher, self.student):
+                if tw is not None:
+                    tw.set_precision("high")
         self.losses = torch.zeros(8, dtype=F32, device=self.device)
         self._dp_t = self._dp_s = self._ds_s = None
         self.overlap_towers = overlap_towers
@@ -156,7 +162,8 @@ class DistillGraph:
         need_student = self.student is not None
         main = torch.cuda.current_stream(dev)
         xt, xs = ops.l2norm_chunk(x_raw, self.C1, self.every_n if need_student else None, self.C2,
-                                  num_frames=num_frames if x_raw.dtype == torch.uint8 else None)
+                                  num_frames=num_frames if x_raw.dtype == torch.uint8 else None,
+                                  split=self.precision == "high")
         self.losses.zero_()
         out = {}
         sc = dp_loss_scales(self.world)
@@ -195,7 +202,7 @@ class DistillGraph:
                 self._student_applied = early is not None
                 if two_streams:
                     self._ev_student.record(side)
-                    for t in (xs, n_s, l1s, l2s):          # allocated on `main`, consumed on `side`
+                    for t in ((xs if isinstance(xs, tuple) else (xs,)) + (n_s, l1s, l2s)):   # allocated on `main`, consumed on `side`
                         if t is not None:
                             t.record_stream(side)
             out.update(student_predictions=s_pred, student_state=s_state, num_frames_student=n_s,

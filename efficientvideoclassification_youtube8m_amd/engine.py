@@ -105,8 +105,23 @@ class LstmStack:
         return base + "kernel", base + "bias"
 
     def forward(self, x, lens):
-        """x [T][M][Kin] bf16 time-major; lens [M] int32.  Returns S [M, 2LH] f32."""
+        """x [T][M][Kin] bf16 time-major (or a (hi, lo) pair in "high" precision); lens [M] int32.
+        Returns S [M, 2LH] f32."""
         tw, H, L, T, M = self.tw, self.H, self.L, self.T, self.M
+        if isinstance(x, tuple):        # split-bf16 parity mode: hi.hi + hi.lo + lo.hi in every step
+            x_hi, x_lo = x
+            self.x_in, self.lens = x_hi, lens
+            if not hasattr(self, "hbuf_lo"):
+                self.hbuf_lo = [torch.empty_like(h) for h in self.hbuf]
+            inp, inp_lo = x_hi, x_lo
+            for l in range(L):
+                kn, bn = self.names(l)
+                ops.lstm_layer_fwd_hp(inp, inp_lo, tw.shadow_fwd[kn], tw.shadow_lo[kn], tw.store.p(bn), lens, T, M,
+                                      self.kin[l], H, self.hbuf[l], self.hbuf_lo[l],
+                                      self.S[:, (2 * l) * H:], self.S[:, (2 * l + 1) * H:], 2 * L * H,
+                                      self.gates[l] if self.training else None, self.c_all[l] if self.training else None)
+                inp, inp_lo = self.hbuf[l][1:], self.hbuf_lo[l][1:]
+            return self.S
         self.x_in, self.lens = x, lens
         inp = x
         for l in range(L):
@@ -237,6 +252,16 @@ class MoeHead:
 
     def forward(self, x):
         tw, B, V, Mx, K = self.tw, self.B, self.V, self.Mx, self.K
+        if getattr(tw, "precision", "bf16") == "high":
+            if not hasattr(self, "x_lo") or self.x_lo.shape != self.x_bf.shape:
+                self.x_lo = torch.empty_like(self.x_bf)
+            ops.cast_bf16_split(x, self.x_bf, self.x_lo)
+            ops.gemm_nt_split(self.x_bf, self.x_lo, tw.shadow_fwd[self.GATES], tw.shadow_lo[self.GATES], B, V * (Mx + 1), K,
+                              self.gate_logits)
+            ops.gemm_nt_split(self.x_bf, self.x_lo, tw.shadow_fwd[self.EXPERTS], tw.shadow_lo[self.EXPERTS], B, V * Mx, K,
+                              self.expert_logits, bias=tw.store.p(self.EBIAS))
+            ops.moe_tail_fwd(self.gate_logits, self.expert_logits, B, V, Mx, self.pred, self.rowsum)
+            return self.pred
         ops.cast_bf16(x, self.x_bf)
         ops.gemm_nt(self.x_bf, tw.shadow_fwd[self.GATES], B, V * (Mx + 1), K, self.gate_logits)
         ops.gemm_nt(self.x_bf, tw.shadow_fwd[self.EXPERTS], B, V * Mx, K, self.expert_logits,
@@ -281,10 +306,21 @@ class TowerBase:
         self.adam_t = 0
         self.sums = torch.zeros((len(self.names), 2), dtype=F32, device=self.device)
 
+    precision = "bf16"     # "high": split-bf16 (hi+lo operands, 3 MFMA products) in the forward GEMMs
+
+    def set_precision(self, precision):
+        assert precision in ("bf16", "high")
+        self.precision = precision
+        if precision == "high" and not hasattr(self, "shadow_lo"):
+            self.shadow_lo = {k: torch.zeros_like(v) for k, v in self.shadow_fwd.items()}
+        self.refresh_shadows()
+
     def refresh_shadows(self, fwd=True):
         for k in self.shadow_fwd:
             p = self.store.p(k)
-            if fwd:
+            if self.precision == "high":
+                ops.cast_bf16_split(p, self.shadow_fwd[k], self.shadow_lo[k])
+            elif fwd:
                 ops.cast_bf16(p, self.shadow_fwd[k])
             sb = self.shadow_bwd[k]
             il = p.shape[0] // 4 if k.endswith("basic_lstm_cell/kernel") else 0     # LSTM: gate-interleaved 4H axis
@@ -332,6 +368,10 @@ class TowerBase:
             ops.clip_adam_step(self.store.p(k), self.store.g(k), self.store.view(self.store.m, k),
                                self.store.view(self.store.v, k), l2, self.sums[idx[k]], clip_norm, lr_t, beta1, beta2, eps,
                                p_bf16=self.shadow_fwd.get(k))
+        if self.precision == "high":
+            for k in names:
+                if k in self.shadow_fwd:
+                    ops.cast_bf16_split(self.store.p(k), self.shadow_fwd[k], self.shadow_lo[k])
         if refresh:
             for k in names:
                 if k in self.shadow_bwd:
@@ -423,12 +463,21 @@ class HLstmTower(TowerBase):
     def forward(self, x_view, len_l1, len_l2):
         """x_view [Lc][C*B][F] bf16 (ops.l2norm_chunk); lengths from ops.frame_counts.
         Returns (state [B, 2LH] f32, predictions [B, V] f32)."""
-        B = x_view.shape[1] // self.C
+        high = isinstance(x_view, tuple)
+        if high and self.precision != "high":
+            raise ValueError("(hi, lo) input needs tower.set_precision('high')")
+        B = (x_view[0] if high else x_view).shape[1] // self.C
         if B != self.B:
             self._alloc(B)
         S1 = self.l1.forward(x_view, len_l1)
-        ops.cast_bf16(S1, self.S1_bf)                                  # = L2 input [C][B][2LH]
-        S2 = self.l2.forward(self.S1_bf.view(self.C, B, self.K), len_l2)
+        if high:
+            if not hasattr(self, "S1_lo") or self.S1_lo.shape != self.S1_bf.shape:
+                self.S1_lo = torch.empty_like(self.S1_bf)
+            ops.cast_bf16_split(S1, self.S1_bf, self.S1_lo)
+            S2 = self.l2.forward((self.S1_bf.view(self.C, B, self.K), self.S1_lo.view(self.C, B, self.K)), len_l2)
+        else:
+            ops.cast_bf16(S1, self.S1_bf)                              # = L2 input [C][B][2LH]
+            S2 = self.l2.forward(self.S1_bf.view(self.C, B, self.K), len_l2)
         return S2, self.moe.forward(S2)
 
     # ---- backward -----------------------------------------------------------

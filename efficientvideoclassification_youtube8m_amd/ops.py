@@ -77,13 +77,28 @@ def cast_bf16(x, out=None):
     return out
 
 
+def cast_bf16_split(x, hi, lo):
+    """hi = bf16(x), lo = bf16(x - hi) for a 2-D f32 tensor (split-bf16 operands)."""
+    R, Cc = x.shape
+    _lib.call("evc_cast_f32_to_bf16_split", _p(x), x.stride(0), R, Cc, _p(hi), _p(lo), hi.stride(0), _stream())
+    return hi, lo
+
+
+def gemm_nt_split(A_hi, A_lo, B_hi, B_lo, M, N, K, out, bias=None):
+    """out = (A_hi + A_lo) @ (B_hi + B_lo)^T to ~2^-16: hi.hi + hi.lo + lo.hi (the lo.lo term is below f32 noise)."""
+    gemm_nt(A_hi, B_hi, M, N, K, out, bias=bias)
+    gemm_nt(A_hi, B_lo, M, N, K, out, accumulate=True)
+    gemm_nt(A_lo, B_hi, M, N, K, out, accumulate=True)
+    return out
+
+
 def rowsum_bf16(x, R, C, out):
     _lib.call("evc_rowsum_bf16", _p(x), x.stride(0), R, C, _p(out), _stream())
     return out
 
 
 # ---------------------------------------------------------------------------
-def l2norm_chunk(x_raw, num_chunks, every_n=None, num_chunks_student=None, num_frames=None, normalize=True):
+def l2norm_chunk(x_raw, num_chunks, every_n=None, num_chunks_student=None, num_frames=None, normalize=True, split=False):
     """a1+a2.  x_raw [B,T,F] f32 (or uint8 with num_frames).  Returns the
     teacher view [Lc][C*B][F] bf16 and (if every_n) the student view."""
     B, T, F = x_raw.shape
@@ -94,8 +109,13 @@ def l2norm_chunk(x_raw, num_chunks, every_n=None, num_chunks_student=None, num_f
         S = T // every_n
         out2 = torch.empty((S // num_chunks_student, num_chunks_student * B, F), dtype=BF16, device=dev)
     is_u8 = x_raw.dtype == torch.uint8
+    lo1 = torch.empty_like(out1) if split else None
+    lo2 = torch.empty_like(out2) if (split and out2 is not None) else None
     _lib.call("evc_l2norm_chunk_fwd", None if is_u8 else _p(x_raw), _p(x_raw) if is_u8 else None, _p(num_frames),
-              B, T, F, num_chunks, _p(out1), every_n or 1, num_chunks_student or 1, _p(out2), 1 if normalize else 0, _stream())
+              B, T, F, num_chunks, _p(out1), every_n or 1, num_chunks_student or 1, _p(out2), 1 if normalize else 0,
+              _p(lo1), _p(lo2), _stream())
+    if split:      # (hi, lo) pairs for the "high" precision forward
+        return (out1, lo1), ((out2, lo2) if out2 is not None else None)
     return out1, out2
 
 
@@ -115,6 +135,12 @@ def lstm_layer_fwd(x, wT, bias, lens, T, M, Kin, H, hbuf, c_state, h_state, ld_s
                    gates=None, c_all=None, hoist=False, zx_ws=None):
     _lib.call("evc_lstm_layer_fwd", _p(x), _p(wT), _p(bias), _p(lens), T, M, Kin, H, 1 if hoist else 0, _p(zx_ws),
               _p(hbuf), _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_all), _stream())
+
+
+def lstm_layer_fwd_hp(x, x_lo, wT, wT_lo, bias, lens, T, M, Kin, H, hbuf, hbuf_lo, c_state, h_state, ld_state,
+                      gates=None, c_all=None):
+    _lib.call("evc_lstm_layer_fwd_hp", _p(x), _p(x_lo), _p(wT), _p(wT_lo), _p(bias), _p(lens), T, M, Kin, H,
+              _p(hbuf), _p(hbuf_lo), _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_all), _stream())
 
 
 def lstm_layer_bwd(w_il, lens, T, M, Kin, H, gates, c_all, dS_c, dS_h, ld_dS, dh_above, dc_ws, dz4):

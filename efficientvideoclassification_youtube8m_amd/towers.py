@@ -156,13 +156,28 @@ class DbofTower(TowerBase):
         st = self.store
         ops.sample_frames_gather(x, uniform, num_frames, self.r, self.idx, normalize=normalize)
         self.bn_in.stats(self.r, R, is_training)
-        ops.bn_apply(self.r, R, F, self.bn_in.mean, self.bn_in.var, self.bn_in.gamma(), self.bn_in.beta(), False,
-                     y_bf16=self.r_bn)
-        ops.gemm_nt(self.r_bn, self.shadow_fwd[self.CW], R, Cc, F, self.act)
+        high = self.precision == "high"
+        if high:
+            if not hasattr(self, "r_bn_f32") or self.r_bn_f32.shape[0] != R:
+                self.r_bn_f32 = torch.empty((R, F), dtype=F32, device=self.device)
+                self.r_bn_lo = torch.empty((R, F), dtype=BF16, device=self.device)
+                self.pooled_lo = torch.empty((B, Cc), dtype=BF16, device=self.device)
+            ops.bn_apply(self.r, R, F, self.bn_in.mean, self.bn_in.var, self.bn_in.gamma(), self.bn_in.beta(), False,
+                         y_f32=self.r_bn_f32)
+            ops.cast_bf16_split(self.r_bn_f32, self.r_bn, self.r_bn_lo)
+            ops.gemm_nt_split(self.r_bn, self.r_bn_lo, self.shadow_fwd[self.CW], self.shadow_lo[self.CW], R, Cc, F, self.act)
+        else:
+            ops.bn_apply(self.r, R, F, self.bn_in.mean, self.bn_in.var, self.bn_in.gamma(), self.bn_in.beta(), False,
+                         y_bf16=self.r_bn)
+            ops.gemm_nt(self.r_bn, self.shadow_fwd[self.CW], R, Cc, F, self.act)
         self.bn_cl.stats(self.act, R, is_training)
         ops.bn_relu6_framepool_fwd(self.act, B, S, Cc, self.bn_cl.mean, self.bn_cl.var, self.bn_cl.gamma(),
                                    self.bn_cl.beta(), self.pooled, self.pooled_bf, self.argmax)
-        ops.gemm_nt(self.pooled_bf, self.shadow_fwd[self.HW], B, Hd, Cc, self.hid)
+        if high:
+            ops.cast_bf16_split(self.pooled, self.pooled_bf, self.pooled_lo)
+            ops.gemm_nt_split(self.pooled_bf, self.pooled_lo, self.shadow_fwd[self.HW], self.shadow_lo[self.HW], B, Hd, Cc, self.hid)
+        else:
+            ops.gemm_nt(self.pooled_bf, self.shadow_fwd[self.HW], B, Hd, Cc, self.hid)
         self.bn_h.stats(self.hid, B, is_training)
         ops.bn_apply(self.hid, B, Hd, self.bn_h.mean, self.bn_h.var, self.bn_h.gamma(), self.bn_h.beta(), True,
                      y_f32=self.h6)
@@ -234,7 +249,14 @@ class LogisticTower(TowerBase):
         if B != self.B:
             self._alloc(B)
         ops.meanpool(x, num_frames, self.avg, self.avg_bf, normalize=normalize)
-        ops.gemm_nt(self.avg_bf, self.shadow_fwd[self.W], B, self.V, self.F, self.pred, bias=self.store.p(self.Bn))
+        if self.precision == "high":
+            if not hasattr(self, "avg_lo") or self.avg_lo.shape != self.avg_bf.shape:
+                self.avg_lo = torch.empty_like(self.avg_bf)
+            ops.cast_bf16_split(self.avg, self.avg_bf, self.avg_lo)
+            ops.gemm_nt_split(self.avg_bf, self.avg_lo, self.shadow_fwd[self.W], self.shadow_lo[self.W], B, self.V, self.F,
+                              self.pred, bias=self.store.p(self.Bn))
+        else:
+            ops.gemm_nt(self.avg_bf, self.shadow_fwd[self.W], B, self.V, self.F, self.pred, bias=self.store.p(self.Bn))
         ops.sigmoid_(self.pred)
         return self.pred
 

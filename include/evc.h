@@ -63,7 +63,8 @@ int evc_check_device(int dev);
 int evc_l2norm_chunk_fwd(const float* x_raw, const uint8_t* x_u8, const int32_t* num_frames,
                          int B, int T, int F,
                          int C1, evc_bf16* out1,
-                         int every_n, int C2, evc_bf16* out2, int normalize, void* stream);
+                         int every_n, int C2, evc_bf16* out2, int normalize,
+                         evc_bf16* out1_lo, evc_bf16* out2_lo /* split-bf16 low halves or NULL */, void* stream);
 
 /* a2 (integer part, bit-exact): num_frames_student = int64(float64(n)/300*S)
  * cs/train.py:263-264; and the per-chunk L1 lengths / L2 length of
@@ -118,6 +119,16 @@ int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const float* bias,
                        evc_bf16* hbuf, float* c_state, float* h_state, int64_t ld_state,
                        void* gates, float* c_all, void* stream);
 
+/* "High" precision variant of evc_lstm_layer_fwd: every bf16 operand comes as hi + lo halves
+ * (evc_cast_f32_to_bf16_split / evc_l2norm_chunk_fwd's lo outputs) and the step issues
+ * hi.hi + hi.lo + lo.hi MFMAs (f32-operand accuracy, ~3x the matrix work); hbuf_lo receives the
+ * low half of every h_t.  Always the fused [x_t | h] form.  Used to hold the 1e-3 parity
+ * tolerance when states / activations are O(1) or larger (after training). */
+int evc_lstm_layer_fwd_hp(const evc_bf16* x, const evc_bf16* x_lo, const evc_bf16* wT, const evc_bf16* wT_lo,
+                          const float* bias, const int32_t* len, int T, int M, int Kin, int H,
+                          evc_bf16* hbuf, evc_bf16* hbuf_lo, float* c_state, float* h_state, int64_t ld_state,
+                          void* gates, float* c_all, void* stream);
+
 /* BPTT of the above (what tf.gradients builds inside
  * slim.learning.create_train_op, cs/train.py:329-334,413-418).
  * w_il [Kin+H][4H] bf16 = kernel in TF layout with the 4H axis GATE-INTERLEAVED
@@ -146,6 +157,11 @@ int evc_transpose_to_bf16(const void* in, int in_f32, int64_t ld_in, int R, int 
                           evc_bf16* out, int64_t ld_out, int Rpad, int interleave_H, void* stream);
 /* out_bf16[i] = bf16(in_f32[i]) for a [R, C] matrix (ld_in, ld_out). */
 int evc_cast_f32_to_bf16(const float* in, int64_t ld_in, int R, int C, evc_bf16* out, int64_t ld_out, void* stream);
+/* split-bf16 cast: hi = bf16(x), lo = bf16(x - hi).  Three NT products (hi.hi + hi.lo + lo.hi, via
+ * evc_gemm_nt with accumulate) then reproduce an f32-operand GEMM to ~2^-16 relative: the
+ * "high" precision forward mode for models whose activations are O(1) (DBoF after batch-norm). */
+int evc_cast_f32_to_bf16_split(const float* in, int64_t ld_in, int R, int C, evc_bf16* hi, evc_bf16* lo,
+                               int64_t ld_out, void* stream);
 /* out[r] = sum_c in[r][c] (bf16 in, f32 out): bias gradients from dz^T. */
 int evc_rowsum_bf16(const evc_bf16* in, int64_t ld_in, int R, int C, float* out, void* stream);
 /* out[c'] = sum_r in[r][c] (bf16 in, f32 out; out is zeroed inside): bias gradients straight from

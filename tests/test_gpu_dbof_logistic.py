@@ -65,6 +65,13 @@ def test_dbof_forward_backward(B, F, C, Hd, V, S, tol):
     assert np.allclose(_np(tw.buffers["input_bn/moving_mean"]), 0.001 * mu, rtol=1e-3, atol=1e-7)
     var = cache[5][4]
     assert np.allclose(_np(tw.buffers["cluster_bn/moving_variance"]), 1 - 0.001 * (1 - var), rtol=1e-3, atol=1e-6)
+    # "high" precision forward (split-bf16 operands): the north-star 1e-3 holds with O(1) activations
+    tw.set_precision("high")
+    pred_h = tw.forward(torch.from_numpy(x).to(DEV), torch.from_numpy(n).to(DEV), torch.from_numpy(u).to(DEV))
+    err_h = np.abs(_np(pred_h) - ref_pred).max()
+    print('dbof pred err (high precision) %.2e' % err_h)
+    assert err_h < (1e-3 if B >= 64 else 3e-3)
+    tw.set_precision("bf16")
     # eval mode uses the moving statistics
     p_eval = tw.forward(torch.from_numpy(x).to(DEV), torch.from_numpy(n).to(DEV), torch.from_numpy(u).to(DEV),
                         is_training=False)

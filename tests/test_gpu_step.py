@@ -109,3 +109,29 @@ def test_three_iterations_track_the_oracle():
         teacher = mm.apply_train_op(teacher, ref["teacher_grads"], slots_t, it + 1, 1e-3, 1.0)
         student = mm.apply_train_op(student, ref["student_grads"], slots_s, it + 1, 1e-3, 1.0)
     assert g.global_step == 6                      # += 2 per iteration (README.md:116,121)
+
+
+def test_high_precision_mode_after_training_steps():
+    """After a few optimizer steps the LSTM states are O(1)-O(10) and plain bf16 operands no longer
+    hold 1e-3 on the probabilities; the split-bf16 "high" precision forward does (same weights, same
+    inputs, float64 oracle)."""
+    from efficientvideoclassification_youtube8m_amd import smoke
+    from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
+    B, F, H, V, every_n = 8, 128, 128, 64, 10
+    q, x, n, labels = mm.synthetic_batch(B, seed=31, feature_size=F, vocab_size=V, dtype=np.float32)
+    xd, yd, nd = (torch.from_numpy(x).to(DEV), torch.from_numpy(labels.astype(np.uint8)).to(DEV), torch.from_numpy(n).to(DEV))
+    errs = {}
+    for prec in ("bf16", "high"):
+        g = DistillGraph(B, every_n=every_n, feature_size=F, vocab_size=V, lstm_cells=H, device=DEV, seed=9, precision=prec,
+                         base_learning_rate=0.01)
+        for _ in range(6):                      # grow the states / weights
+            g.step(xd, yd, nd)
+        out = g.step(xd, yd, nd, apply=False)
+        teacher, student = smoke.tower_params_numpy(g.teacher), smoke.tower_params_numpy(g.student)
+        ref = mm.teacher_student_step(x.astype(np.float64), n, labels, teacher, student, every_n, with_grads=False)
+        errs[prec] = (float(np.abs(out["predictions"].cpu().numpy() - ref["teacher_predictions"]).max()),
+                      float(np.abs(out["teacher_state"].cpu().numpy() - ref["teacher_state"]).max()),
+                      float(np.abs(ref["teacher_state"]).max()))
+    print("trained-state parity (pred err, state err, |state| max):", errs)
+    assert errs["high"][0] < 1e-3 and errs["high"][1] < 1e-3 * max(1.0, errs["high"][2])
+    assert errs["high"][0] < errs["bf16"][0]
