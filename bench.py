@@ -145,16 +145,18 @@ def main():
         ms, launches, flops = ms + m, launches + nl, flops + fl
     avg_ms = ms / launches
     achieved = flops / (ms * 1e-3) / 1e12
-    traffic = None
-    try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
+    traffic = mfma_busy = None
+    try:   # HBM bytes per launch / MFMA busy fraction from the committed rocprofv3 --pmc passes (profiles/)
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            traffic = json.load(f)["hbm_bytes_per_launch"]
+            pmc = json.load(f)
+        traffic = pmc["hbm_bytes_per_launch"]
+        mfma_busy = round(pmc["mfma"]["mfma_busy_fraction"], 4)
     except Exception:
         pass
     roofline = {"bound": "mfma", "kernel": "lstm_fwd_step_kernel<TileCfg2<320,4,64,2,4,4,false>>" if graph.teacher is not None
                 else "lstm_fwd_step_kernel (student L1)", "achieved": round(achieved, 2),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": int(launches),
+                "traffic": traffic, "mfma_busy_pmc": mfma_busy, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": int(launches),
                 "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 2)}
 
     if rank == 0:
