@@ -254,6 +254,76 @@ class DistillGraph:
         return rep
 
 
+class EvalGraph:
+    """Forward-only graph of cs/validate.py:109-189 (teacher built too, so that the
+    student_state_loss ||teacher_state - student_state||^2 can be logged) and of
+    cs/eval_finetune.py:108-175 (``student_only``).  Towers are built with
+    training=False (no backward tape); ``restore`` takes a TF-named state dict."""
+
+    def __init__(self, batch_size, every_n=10, student_only=False, feature_size=1152, vocab_size=4716, max_frames=300,
+                 num_inputs_to_lstm=20, num_inputs_l1_student=5, lstm_cells=1024, lstm_layers=2, num_mixtures=2,
+                 device="cuda:0", precision="bf16"):
+        validate_every_n(every_n, num_inputs_l1_student, max_frames)
+        self.every_n, self.max_frames, self.C1, self.C2 = every_n, max_frames, num_inputs_to_lstm, num_inputs_l1_student
+        self.S = max_frames // every_n
+        self.device = torch.device(device)
+        self.teacher = None
+        if not student_only:
+            self.teacher = HLstmTower(batch_size, max_frames, num_inputs_to_lstm, feature_size, vocab_size, lstm_cells,
+                                      lstm_layers, num_mixtures, device, False, "model", 7)
+        self.student = HLstmTower(batch_size, self.S, num_inputs_l1_student, feature_size, vocab_size, lstm_cells,
+                                  lstm_layers, num_mixtures, device, False, "model_student", 8)
+        self.precision = precision
+        if precision == "high":
+            for tw in (self.teacher, self.student):
+                if tw is not None:
+                    tw.set_precision("high")
+        self.losses = torch.zeros(4, dtype=F32, device=self.device)
+        self._side = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+        self._ev_in, self._ev_out = (torch.cuda.Event(), torch.cuda.Event()) if self._side else (None, None)
+
+    def restore(self, state_dict):
+        """saver_teacher / saver_student .restore (cs/validate.py:350-384): the 11 variables of each tower by name."""
+        for tw in (self.teacher, self.student):
+            if tw is not None:
+                tw.load_state_dict(state_dict)
+
+    def step(self, x_raw, labels_u8, num_frames):
+        """Returns predictions (student), student_label_loss, student_state_loss (teacher_student only) - the
+        tensors cs/validate.py:240 fetches.  The two towers are independent: they run on two streams."""
+        main = torch.cuda.current_stream(self.device)
+        split = self.precision == "high"
+        u8 = x_raw.dtype == torch.uint8
+        if self.teacher is not None:
+            xt, xs = ops.l2norm_chunk(x_raw, self.C1, self.every_n, self.C2, num_frames=num_frames if u8 else None, split=split)
+        else:
+            # student only: the teacher view is not needed; chunk the sub-sampled frames directly
+            _, xs = ops.l2norm_chunk(x_raw, self.C1, self.every_n, self.C2, num_frames=num_frames if u8 else None, split=split)
+            xt = None
+        self.losses.zero_()
+        out = {}
+        self._ev_in.record(main)
+        self._side.wait_event(self._ev_in)
+        with torch.cuda.stream(self._side):
+            n_s, l1s, l2s = ops.frame_counts(num_frames, self.every_n, self.C2, self.S // self.C2, self.max_frames)
+            s_state, s_pred = self.student.forward(xs, l1s, l2s)
+            ops.ce_loss(s_pred, labels_u8, self.losses[0:1])
+            self._ev_out.record(self._side)
+            for t in ((xs if isinstance(xs, tuple) else (xs,)) + (n_s, l1s, l2s)):
+                t.record_stream(self._side)
+        if self.teacher is not None:
+            _, l1, l2 = ops.frame_counts(num_frames, 1, self.C1, self.max_frames // self.C1, self.max_frames)
+            t_state, t_pred = self.teacher.forward(xt, l1, l2)
+            out.update(teacher_state=t_state, teacher_predictions=t_pred)
+        main.wait_event(self._ev_out)
+        if self.teacher is not None:
+            ops.rep_loss(t_state, s_state, self.losses[1:2])
+            out["student_state_loss"] = self.losses[1]
+        out.update(predictions=s_pred, student_state=s_state, num_frames=n_s, student_label_loss=self.losses[0],
+                   loss=self.losses[0])
+        return out
+
+
 class SingleTowerGraph:
     """Teacher-only training step for dict-returning models (DbofModel,
     FrameLevelLogisticModel).  The reference's train.py cannot run these

@@ -13,7 +13,8 @@ What is kept: flag names/defaults/syntax (flags.py), class lookup by name
 (cs/train.py:528-533), global_step += 2, resume-unless-``--start_new_model``.
 What is replaced: TF Supervisor/queue runners -> a plain loop; TF checkpoints ->
 ``torch.save`` of a TF-named state dict (model.ckpt-<step>.pt, max_to_keep=1);
-TFRecord input -> synthetic batches until the reader lands.
+TFRecord input -> readers.py (native parser, uint8 feed, pinned staging); the pattern
+"synthetic" generates random uint8 videos on the device instead.
 Multi-GPU: launch with ``python -m torch.distributed.run --nproc-per-node N``;
 ``--gpu`` is then ignored in favour of LOCAL_RANK.
 """
@@ -27,7 +28,7 @@ import time
 
 import torch
 
-from . import eval_util, frame_level_models, losses, ops, video_level_models
+from . import eval_util, frame_level_models, losses, ops, readers, video_level_models
 from .distill import DistillGraph, SingleTowerGraph
 from .flags import FLAGS, GetListOfFeatureNamesAndSizes
 from .towers import DbofTower, LogisticTower
@@ -86,18 +87,44 @@ def synthetic_batches(batch_size, feature_size, device, videos_per_epoch, num_ep
             yield q, labels, n
 
 
-def get_input_data(data_pattern, batch_size, feature_size, device, num_epochs, seed):
+def get_reader():
+    """cs/train.py:618-630: the reader the flags select."""
+    feature_names, feature_sizes = GetListOfFeatureNamesAndSizes(FLAGS.feature_names, FLAGS.feature_sizes)
+    if FLAGS.frame_features:
+        return readers.YT8MFrameFeatureReader(num_classes=NUM_CLASSES, feature_names=feature_names, feature_sizes=feature_sizes,
+                                              max_frames=FLAGS.max_num_frames)
+    return readers.YT8MAggregatedFeatureReader(num_classes=NUM_CLASSES, feature_names=feature_names, feature_sizes=feature_sizes)
+
+
+def get_input_data(data_pattern, batch_size, feature_size, device, num_epochs, seed, rank=0, world=1):
+    """get_input_data_tensors (cs/train.py:129-176) -> iterator of (features uint8, labels uint8, num_frames int32)
+    device tensors; ``batch_size`` is per GPU (cs/train.py:205 batch_size * num_towers)."""
     if data_pattern in ("", "synthetic"):
-        return synthetic_batches(batch_size, feature_size, device, FLAGS.synthetic_videos, num_epochs, seed)
-    files = glob.glob(data_pattern)
-    if not files:
-        raise IOError("Unable to find training files. data_pattern='" + data_pattern + "'.")   # cs/train.py:155-157
-    raise NotImplementedError("TFRecord input is the next scope row (SURVEY.md 8f #1); use --train_data_pattern synthetic")
+        return synthetic_batches(batch_size, feature_size, device, FLAGS.synthetic_videos, num_epochs, seed), None
+    logging.info("Using batch size of %d for training.", batch_size)
+    pipe = readers.get_input_data_tensors(get_reader(), data_pattern, batch_size=batch_size, num_epochs=num_epochs,
+                                          num_readers=FLAGS.num_readers, seed=seed, device=device, rank=rank, world_size=world)
+    logging.info("Number of training files / records on this rank: %d / %d.", len(pipe.index), pipe.num_records)
+    return (b[1:] for b in pipe), pipe.num_batches
+
+
+def dequantize_masked(q, n):
+    """Dequantize (cs/utils.py:22-25) + zero rows >= num_frames (cs/readers.py:170-173) for the graphs whose
+    input kernel takes float32 (the LSTM graph takes the uint8 tensor directly)."""
+    keep = (torch.arange(q.shape[1], device=q.device)[None, :] < n[:, None]).unsqueeze(-1)
+    return (q.float() * (4.0 / 255.0) + (4.0 / 512.0 - 2.0)) * keep
+
+
+def _ckpt_step(path):
+    name = os.path.basename(path)
+    return int(name[len("model.ckpt-"):-3]) if name.startswith("model.ckpt-") else 0
 
 
 def latest_checkpoint(train_dir):
-    cks = glob.glob(os.path.join(train_dir, "model.ckpt-*.pt"))
-    return max(cks, key=lambda p: int(p.rsplit("-", 1)[1][:-3])) if cks else None
+    """tf.train.latest_checkpoint: the highest-numbered model.ckpt-<step>.pt; the un-numbered model.ckpt.pt that
+    train_convert_model writes counts as step 0."""
+    cks = glob.glob(os.path.join(train_dir, "model.ckpt-*.pt")) + glob.glob(os.path.join(train_dir, "model.ckpt.pt"))
+    return max(cks, key=_ckpt_step) if cks else None
 
 
 def save_checkpoint(graph, train_dir, rank):
@@ -111,7 +138,7 @@ def save_checkpoint(graph, train_dir, rank):
             sd["%s/adam" % tw.scope] = {"t": tw.adam_t, "m": tw.store.m.cpu(), "v": tw.store.v.cpu()}
     path = os.path.join(train_dir, "model.ckpt-%d.pt" % graph.global_step)
     torch.save(sd, path)
-    for old in glob.glob(os.path.join(train_dir, "model.ckpt-*.pt")):      # max_to_keep=1 (cs/train.py:651)
+    for old in glob.glob(os.path.join(train_dir, "model.ckpt*.pt")):       # max_to_keep=1 (cs/train.py:651)
         if old != path:
             os.remove(old)
     return path
@@ -164,14 +191,21 @@ def main(argv=None):
     else:
         logging.info("%s: Restoring from %s", task, ck)
         restore_checkpoint(graph, ck)
-    logging.info("Using batch size of %d for training.", FLAGS.batch_size)
-    data = get_input_data(FLAGS.train_data_pattern, FLAGS.batch_size, feature_size, device, FLAGS.num_epochs, 1234 + rank)
+    data, num_batches = get_input_data(FLAGS.train_data_pattern, FLAGS.batch_size, feature_size, device, FLAGS.num_epochs,
+                                       1234 + rank, rank, world)
+    step_limit = FLAGS.max_steps or None
+    if world > 1 and num_batches is not None:
+        # ranks own different files: agree on the common number of iterations so that no rank waits in a
+        # gradient all-reduce for a peer whose input has run dry
+        nb = torch.tensor([num_batches], device=device)
+        torch.distributed.all_reduce(nb, op=torch.distributed.ReduceOp.MIN)
+        step_limit = min(step_limit or int(nb), int(nb))
     logging.info("%s: Entering training loop.", task)
     start, last_save, it = time.time(), time.time(), 0
     is_distill = isinstance(graph, DistillGraph)
     for q, labels, n in data:
         t0 = time.time()
-        out = graph.step(q, labels, n) if is_distill else graph.step(q.float() * (4.0 / 255.0) + (4.0 / 512.0 - 2.0), labels, n)
+        out = graph.step(q, labels, n) if is_distill else graph.step(dequantize_masked(q, n), labels, n)
         it += 1
         if rank == 0 and it % max(1, FLAGS.log_every) == 0:
             pred = out.get("predictions", out.get("student_predictions"))
@@ -192,7 +226,7 @@ def main(argv=None):
         if time.time() - last_save > 30 * 60:                                  # save_model_secs (cs/train.py:500)
             save_checkpoint(graph, FLAGS.train_dir, rank)
             last_save = time.time()
-        if FLAGS.max_steps and it >= FLAGS.max_steps:
+        if step_limit and it >= step_limit:
             break
     logging.info("%s: Done training -- epoch limit reached.", task)
     save_checkpoint(graph, FLAGS.train_dir, rank)

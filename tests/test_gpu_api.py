@@ -120,3 +120,42 @@ def test_train_main_runs_and_resumes(tmp_path, capsys):
         train.main(["--train_data_pattern", "/nonexistent/train*.tfrecord", "--lstm_cells", "64", "--feature_sizes", "64",
                     "--batch_size", "4", "--every_n", "10", "--start_new_model", "True", "--train_dir", str(tmp_path) + "/x/"])
     FLAGS.reset()
+
+
+def test_train_main_from_tfrecords(tmp_path):
+    """TFRecord files -> native reader -> uint8 batches -> fused dequant/l2norm kernel -> training."""
+    from efficientvideoclassification_youtube8m_amd import readers, train
+    from efficientvideoclassification_youtube8m_amd.flags import FLAGS
+    data = tmp_path / "data"
+    readers.write_synthetic_frame_dataset(str(data), 2, 9, feature_names=("rgb", "audio"), feature_sizes=(64, 64),
+                                          min_frames=100, max_frames=320, seed=3)
+    FLAGS.reset()
+    train.main(["--train_data_pattern", str(data / "train*.tfrecord"), "--train_dir", str(tmp_path / "m") + "/",
+                "--frame_features", "True", "--feature_names", "rgb, audio", "--feature_sizes", "64, 64",
+                "--model", "HierarchicalLstmModel", "--batch_size", "8", "--num_inputs_to_lstm", "20", "--lstm_layers", "2",
+                "--lstm_cells", "64", "--num_epochs", "2", "--every_n", "10", "--num_readers", "2", "--start_new_model", "True"])
+    ck = train.latest_checkpoint(str(tmp_path / "m"))
+    assert ck.endswith("model.ckpt-10.pt")              # 36 videos / 8 -> 5 iterations (4 full + one of 4) x 2 steps
+    sd = torch.load(ck)
+    assert all(torch.isfinite(v).all() for k, v in sd.items() if torch.is_tensor(v))
+    FLAGS.reset()
+
+
+def test_reader_batch_matches_oracle_input_path(tmp_path):
+    """A batch read from TFRecords, pushed through evc_l2norm_chunk_fwd (uint8 path), equals the oracle's
+    Dequantize + zero padding + l2_normalize + every_n subsampling of the same records."""
+    from efficientvideoclassification_youtube8m_amd import ops, readers
+    from oracle import model_math as mm
+    readers.write_synthetic_frame_dataset(str(tmp_path), 1, 6, min_frames=40, max_frames=330, seed=11)
+    rd = readers.YT8MFrameFeatureReader(feature_names=["rgb", "audio"], feature_sizes=[1024, 128], max_frames=300)
+    (ids, q, y, n), = list(readers.get_input_evaluation_tensors(rd, str(tmp_path / "train*.tfrecord"), batch_size=6, device="cuda:0"))
+    assert q.is_cuda and q.dtype == torch.uint8 and int(n.max()) == 300
+    xt, xs = ops.l2norm_chunk(q, 20, 10, 2, num_frames=n)
+    qn, nn = q.cpu().numpy(), n.cpu().numpy()
+    x = mm.dequantize(qn.astype(np.float64)) * (np.arange(300)[None, :, None] < nn[:, None, None])
+    xn = mm.l2_normalize(x, axis=2)
+    want_t = xn.reshape(6, 20, 15, 1152).transpose(2, 1, 0, 3).reshape(15, 120, 1152)
+    np.testing.assert_allclose(xt.float().cpu().numpy(), want_t, atol=2.0 ** -7 * np.abs(want_t).max())
+    idx = mm.every_n_indices(10)
+    want_s = xn[:, idx].reshape(6, 2, 15, 1152).transpose(2, 1, 0, 3).reshape(15, 12, 1152)
+    np.testing.assert_allclose(xs.float().cpu().numpy(), want_s, atol=2.0 ** -7 * np.abs(want_s).max())

@@ -1,0 +1,113 @@
+"""The reference's whole recipe (README.md / run_*.sh) on TFRecord files, small dims, on the GPU:
+train (teacher+student) -> validate -> train_convert_model -> train_finetune -> eval_finetune,
+with the evaluation numbers checked against the CPU oracle run on the same records + checkpoint."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import metrics as om
+from oracle import model_math as mm
+
+pytestmark = pytest.mark.gpu
+
+COMMON = ["--frame_features", "True", "--feature_names", "rgb, audio", "--feature_sizes", "64, 64", "--model",
+          "HierarchicalLstmModel", "--gpu", "0", "--num_inputs_to_lstm", "20", "--lstm_layers", "2", "--lstm_cells", "64",
+          "--every_n", "10", "--num_readers", "2"]
+
+
+def _oracle_eval(files, sd, student_only):
+    """Dequantize/pad/l2norm/sub-sample + H-LSTM forward in float64 for every record, then the oracle metrics."""
+    from efficientvideoclassification_youtube8m_amd import readers
+    rd = readers.YT8MFrameFeatureReader(feature_names=["rgb", "audio"], feature_sizes=[64, 64], max_frames=300)
+    q, y, n = [], [], []
+    for ids, mat, lab, nf in rd.prepare_reader(files):
+        q.append(mat[0]); y.append(lab[0]); n.append(nf[0])
+    q, y, n = np.stack(q), np.stack(y).astype(np.float64), np.asarray(n)
+    x = mm.dequantize(q.astype(np.float64)) * (np.arange(300)[None, :, None] < n[:, None, None])
+    xn = mm.l2_normalize(x, 2)
+
+    def params(scope):
+        return {k[len(scope) + 1:]: v.double().numpy() for k, v in sd.items() if k.startswith(scope + "/") and torch.is_tensor(v)}
+    idx = mm.every_n_indices(10)
+    s_state, s_pred, _ = mm.hlstm_fwd(xn[:, idx], mm.student_num_frames(n, 10), params("model_student"), 5)
+    rep = None
+    if not student_only:
+        t_state, _, _ = mm.hlstm_fwd(xn, n, params("model"), 20)
+        rep = t_state, s_state
+    return s_pred, y, rep
+
+
+def test_train_validate_convert_finetune_eval(tmp_path):
+    from efficientvideoclassification_youtube8m_amd import eval_finetune, readers, train, train_convert_model, train_finetune, validate
+    from efficientvideoclassification_youtube8m_amd.flags import FLAGS
+    data = tmp_path / "yt8m"
+    readers.write_synthetic_frame_dataset(str(data), 2, 12, feature_sizes=(64, 64), min_frames=60, max_frames=310, seed=1, prefix="train")
+    val_files = readers.write_synthetic_frame_dataset(str(data), 2, 7, feature_sizes=(64, 64), min_frames=60, max_frames=310, seed=2,
+                                                      prefix="validate")
+    tdir = str(tmp_path / "model_train") + "/"
+    FLAGS.reset()
+    train.main(COMMON + ["--train_data_pattern", str(data / "train*.tfrecord"), "--train_dir", tdir, "--batch_size", "8",
+                         "--num_epochs", "2", "--start_new_model", "True"])
+    assert train.latest_checkpoint(tdir).endswith("model.ckpt-12.pt")            # 48 videos / 8 = 6 iterations x 2
+
+    # ---- validate.py: teacher + student restored, student metrics + L_REP ----
+    FLAGS.reset()
+    info = validate.main(COMMON + ["--eval_data_pattern", str(data / "validate*.tfrecord"), "--train_dir", tdir, "--batch_size", "5",
+                                   "--top_k", "20", "--run_once", "True"])
+    assert info["epoch_id"] == 12
+    sd = torch.load(train.latest_checkpoint(tdir))
+    pred, y, (t_state, s_state) = _oracle_eval(val_files, sd, False)
+    ev = om.EvaluationMetrics(4716, 20)
+    for s in range(0, 14, 5):                                                     # batches of 5, 5, 4 in file order
+        ev.accumulate(pred[s:s + 5], y[s:s + 5], mm.cross_entropy_loss(pred[s:s + 5], y[s:s + 5]))
+    want = ev.get()
+    assert abs(info["avg_loss"] - want["avg_loss"]) < 1e-3 * want["avg_loss"]
+    assert abs(info["gap"] - want["gap"]) < 2e-2 and abs(info["avg_hit_at_one"] - want["avg_hit_at_one"]) < 0.15
+    events = open(tdir + "events.jsonl").read()
+    assert "Epoch/Eval_GAP" in events and "GlobalStep/Eval_Loss" in events
+
+    # ---- train_convert_model.py -> train_finetune.py -> eval_finetune.py ----
+    FLAGS.reset()
+    ck = train_convert_model.main(["--train_dir", tdir])
+    fdir = train_convert_model.finetune_dir(tdir)        # every 'train' in the path is removed, as in the reference
+    assert ck == fdir + "model.ckpt.pt"
+    FLAGS.reset()
+    train_finetune.main(COMMON + ["--train_data_pattern", str(data / "train*.tfrecord"), "--train_dir", fdir, "--batch_size", "8",
+                                  "--num_epochs", "1", "--start_new_model", "False"])
+    assert train.latest_checkpoint(fdir).endswith("model.ckpt-3.pt")             # student only: +1 per iteration, from 0
+    sdf = torch.load(train.latest_checkpoint(fdir))
+    assert not any(k.startswith("model/") for k in sdf)
+    moved = max((sdf[k] - sd[k]).abs().max().item() for k in sdf if k.startswith("model_student/") and torch.is_tensor(sdf[k]))
+    assert 0 < moved < 0.1                                                        # continued from the converted weights
+    FLAGS.reset()
+    info = eval_finetune.main(COMMON + ["--eval_data_pattern", str(data / "validate*.tfrecord"), "--train_dir", fdir,
+                                        "--batch_size", "14", "--run_once", "True"])
+    pred, y, _ = _oracle_eval(val_files, sdf, True)
+    want_loss = mm.cross_entropy_loss(pred, y)
+    assert info["epoch_id"] == 3 and abs(info["avg_loss"] - want_loss) < 1e-3 * want_loss
+    with pytest.raises(IOError, match="Unable to find the evaluation files"):
+        FLAGS.reset()
+        validate.main(COMMON + ["--eval_data_pattern", str(data / "nothing*.tfrecord"), "--train_dir", tdir, "--run_once", "True"])
+    with pytest.raises(IOError, match="not specified"):
+        FLAGS.reset()
+        validate.main(COMMON + ["--train_dir", tdir, "--run_once", "True"])
+    FLAGS.reset()
+
+
+def test_eval_graph_matches_training_graph_forward():
+    """EvalGraph (training=False towers, two streams) returns what DistillGraph computes for the same weights."""
+    from efficientvideoclassification_youtube8m_amd.distill import DistillGraph, EvalGraph
+    kw = dict(every_n=10, feature_size=128, vocab_size=50, lstm_cells=64, device="cuda:0")
+    g = DistillGraph(6, **kw)
+    e = EvalGraph(6, **kw)
+    sd = {}
+    sd.update(g.teacher.state_dict()); sd.update(g.student.state_dict())
+    e.restore(sd)
+    q, x, n, labels = mm.synthetic_batch(6, seed=3, feature_size=128, vocab_size=50, dtype=np.float32)
+    qd, nd, yd = torch.from_numpy(q).cuda(), torch.from_numpy(n).cuda(), torch.from_numpy(labels.astype(np.uint8)).cuda()
+    out_e = e.step(qd, yd, nd)
+    pe, se, le, re_ = out_e["predictions"].clone(), out_e["student_state"].clone(), float(out_e["loss"]), float(out_e["student_state_loss"])
+    out_g = g.step(qd, yd, nd, apply=False)
+    assert torch.equal(pe, out_g["student_predictions"]) and torch.equal(se, out_g["student_state"])
+    assert abs(le - float(out_g["student_label_loss"])) < 1e-4 * abs(le)
+    assert abs(re_ - float(out_g["student_loss_state"])) < 1e-4 * abs(re_) + 1e-7
