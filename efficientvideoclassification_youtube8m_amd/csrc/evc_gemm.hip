@@ -242,6 +242,7 @@ struct LstmFwdParams {
   uint2* gates;                      // [M][H] 8-byte records of slab t (or NULL): bf16 {i, j, f, o}
   const float* c_in; float* c_out;   // cell state before / after this step: slabs t and t+1 of c_all, or the
                                      // in-place c_state buffer when no history is kept (c_in == NULL at t == 0)
+  const int* row_map;                // slot -> row of c_state / h_state (row plan, evc_sort_rows_by_len) or NULL
   int M, H;
 };
 
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, 
       if (m >= e.M) continue;
       const int ln = e.len[m];
       const long hu = (long)m * H + u;
-      const long su = (long)m * e.ld_state + u;
+      const long su = (long)(e.row_map ? e.row_map[m] : m) * e.ld_state + u;
       if (e.t >= ln) {              // dynamic_rnn: state copied through, zero output
         *(uint2*)(e.hout + hu) = make_uint2(0u, 0u);
         if (SPLIT) *(uint2*)(e.hout_lo + hu) = make_uint2(0u, 0u);
@@ -343,8 +344,15 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, 
 
 typedef TileCfg<128, 4, 32, 2, 2> CfgLstmBig;    // 128 rows x 32 units x 4 gates
 typedef TileCfg<64, 4, 16, 4, 1> CfgLstmSmall;   // 64 rows x 16 units x 4 gates (M ~ 256 steps)
-typedef TileCfg2<320, 4, 64, 2, 4, 4, false> CfgLstmV2a;   // 320 rows x 64 units x 4 gates: M=5120,H=1024 -> exactly 256 workgroups
-typedef TileCfg2<256, 4, 64, 2, 4, 5, true> CfgLstmV2b;   // 256 rows x 64 units x 4 gates
+// v2 tiles: BM rows x 64 units x 4 gates (256 accumulator columns).  The row count of a step varies with the
+// batch (row plans drop the padding rows), so the tile height is chosen per launch to cut the active rows
+// into a multiple of 256 workgroups: 5120 rows -> 320, ~3600 -> 224, ...
+typedef TileCfg2<320, 4, 64, 2, 4, 4, false> CfgLstmV2a;
+typedef TileCfg2<288, 4, 64, 2, 4, 4, false> CfgLstmV2_288;
+typedef TileCfg2<256, 4, 64, 2, 4, 5, true> CfgLstmV2b;
+typedef TileCfg2<224, 4, 64, 2, 4, 5, true> CfgLstmV2_224;
+typedef TileCfg2<192, 4, 64, 2, 4, 5, true> CfgLstmV2_192;
+typedef TileCfg2<160, 4, 64, 2, 4, 5, true> CfgLstmV2_160;
 
 template <class Cfg, bool SPLIT = false>
 static inline void launch_lstm_fwd(GemmOperands p, const LstmFwdParams& e, int k1, int k2, hipStream_t st) {
@@ -353,34 +361,55 @@ static inline void launch_lstm_fwd(GemmOperands p, const LstmFwdParams& e, int k
   launch_cfg<Cfg>(lstm_fwd_step_kernel<Cfg, SPLIT>, tm * tn, st, p, e, tm, tn);
 }
 
+// forward tile for a step over `rows` rows: index into {320, 288, 256, 224, 192, 160 (v2), 128 (v1), 64 (v1)}
+static inline int pick_fwd_tile(int rows, int H) {
+  static const int bm[8] = {320, 288, 256, 224, 192, 160, 128, 64};
+  static const int bn[8] = {256, 256, 256, 256, 256, 256, 128, 64};
+  static const int bu[8] = {64, 64, 64, 64, 64, 64, 32, 16};
+  static const double cf[8] = {1.0, 1.0, 1.0, 1.02, 1.04, 1.08, 1.3, 2.6};   // smaller tiles: a little less efficient per flop
+  int best = 0;
+  double bc = 1e300;
+  for (int i = 0; i < 8; ++i) {
+    const double c = tile_cost((long)ceil_div(rows, bm[i]) * ceil_div(H, bu[i]), bm[i], bn[i], 1, cf[i]);
+    if (c < bc) { bc = c; best = i; }
+  }
+  const int f = forced_tile();        // debug: 1 -> 256, 2 -> v1 128, 3 -> v1 64, 4 -> 320, 5 -> 288, 6 -> 224, 7 -> 192, 8 -> 160
+  if (f) { static const int map[9] = {0, 2, 6, 7, 0, 1, 3, 4, 5}; best = map[f < 9 ? f : 0]; }
+  return best;
+}
+
 static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const float* bias, const int32_t* len,
                                int T, int M, int Kin, int H, int hoist, float* zx_ws,
                                evc_bf16* hbuf, float* c_state, float* h_state, int64_t ld_state,
                                void* gates, float* c_all,
-                               const evc_bf16* x_lo, const evc_bf16* wT_lo, evc_bf16* hbuf_lo, void* stream);
+                               const evc_bf16* x_lo, const evc_bf16* wT_lo, evc_bf16* hbuf_lo,
+                               const int32_t* row_map, const int32_t* rows_per_step, void* stream);
 
 extern "C" int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const float* bias, const int32_t* len,
                                   int T, int M, int Kin, int H, int hoist, float* zx_ws,
                                   evc_bf16* hbuf, float* c_state, float* h_state, int64_t ld_state,
-                                  void* gates, float* c_all, void* stream) {
+                                  void* gates, float* c_all, const int32_t* row_map, const int32_t* rows_per_step,
+                                  void* stream) {
   return lstm_layer_fwd_impl(x, wT, bias, len, T, M, Kin, H, hoist, zx_ws, hbuf, c_state, h_state, ld_state, gates, c_all,
-                             nullptr, nullptr, nullptr, stream);
+                             nullptr, nullptr, nullptr, row_map, rows_per_step, stream);
 }
 
 extern "C" int evc_lstm_layer_fwd_hp(const evc_bf16* x, const evc_bf16* x_lo, const evc_bf16* wT, const evc_bf16* wT_lo,
                                      const float* bias, const int32_t* len, int T, int M, int Kin, int H,
                                      evc_bf16* hbuf, evc_bf16* hbuf_lo, float* c_state, float* h_state, int64_t ld_state,
-                                     void* gates, float* c_all, void* stream) {
+                                     void* gates, float* c_all, const int32_t* row_map, const int32_t* rows_per_step,
+                                     void* stream) {
   EVC_REQUIRE(x_lo && wT_lo && hbuf_lo, EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd_hp: the low-order halves are required");
   return lstm_layer_fwd_impl(x, wT, bias, len, T, M, Kin, H, 0, nullptr, hbuf, c_state, h_state, ld_state, gates, c_all,
-                             x_lo, wT_lo, hbuf_lo, stream);
+                             x_lo, wT_lo, hbuf_lo, row_map, rows_per_step, stream);
 }
 
 static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const float* bias, const int32_t* len,
                                int T, int M, int Kin, int H, int hoist, float* zx_ws,
                                evc_bf16* hbuf, float* c_state, float* h_state, int64_t ld_state,
                                void* gates, float* c_all,
-                               const evc_bf16* x_lo, const evc_bf16* wT_lo, evc_bf16* hbuf_lo, void* stream) {
+                               const evc_bf16* x_lo, const evc_bf16* wT_lo, evc_bf16* hbuf_lo,
+                               const int32_t* row_map, const int32_t* rows_per_step, void* stream) {
   const bool split = x_lo != nullptr;
   EVC_REQUIRE(T > 0 && M > 0 && H > 0 && Kin > 0, EVC_ERR_BAD_SHAPE, "evc_lstm_layer_fwd: bad shape");
   EVC_REQUIRE(Kin % 64 == 0 && H % 64 == 0, EVC_ERR_BAD_SHAPE,
@@ -391,26 +420,25 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
   EVC_REQUIRE((gates == nullptr) == (c_all == nullptr), EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd: gates and c_all go together");
   EVC_REQUIRE(!gates || (((uintptr_t)gates % 16) == 0 && ((uintptr_t)c_all % 16) == 0), EVC_ERR_BAD_ALIGN,
               "evc_lstm_layer_fwd: gates / c_all must be 16-byte aligned");
+  if (rows_per_step)
+    for (int t = 0; t < T; ++t)
+      EVC_REQUIRE(rows_per_step[t] >= 0 && rows_per_step[t] <= M && (t == 0 || rows_per_step[t] <= rows_per_step[t - 1]), EVC_ERR_BAD_ARG,
+                  "evc_lstm_layer_fwd: rows_per_step[%d]=%d must be non-increasing and within [0, M=%d]", t, rows_per_step[t], M);
   hipStream_t st = (hipStream_t)stream;
   const long ldw = Kin + H;
   // h_{-1} = 0 (the state buffers need no clearing: step 0 treats c_old as 0 and writes the zero
-  // state of zero-length rows itself)
+  // state of the zero-length rows it covers itself; rows beyond rows_per_step[0] are the caller's)
   EVC_CHECK_HIP(hipMemsetAsync(hbuf, 0, (size_t)M * H * sizeof(bf16_t), st));
   if (split) EVC_CHECK_HIP(hipMemsetAsync(hbuf_lo, 0, (size_t)M * H * sizeof(bf16_t), st));
   if (hoist) {
     int rc = evc_gemm_nt(x, Kin, wT, ldw, zx_ws, 4L * H, T * M, 4 * H, Kin, nullptr, 0, 0, stream);
     if (rc) return rc;
   }
-  const double cst[4] = {tile_cost((long)ceil_div(M, 320) * ceil_div(H, 64), 320, 256, 1, 1.0),
-                         tile_cost((long)ceil_div(M, 256) * ceil_div(H, 64), 256, 256, 1, 1.0),
-                         tile_cost((long)ceil_div(M, 128) * ceil_div(H, 32), 128, 128, 2, 1.3),
-                         tile_cost((long)ceil_div(M, 64) * ceil_div(H, 16), 64, 64, 4, 2.6)};
-  int pick = 0;
-  for (int i = 1; i < 4; ++i) if (cst[i] < cst[pick]) pick = i;
-  if (forced_tile() == 4) pick = 0; else if (forced_tile()) pick = forced_tile();    // 4 -> v2a (320), 1 -> v2b, 2 -> v1 big, 3 -> v1 small
   for (int t = 0; t < T; ++t) {
+    const int Mt = rows_per_step ? rows_per_step[t] : M;     // active rows are the prefix [0, Mt) (row plan)
+    if (Mt == 0) break;
     GemmOperands p;
-    p.M = M; p.Nu = H; p.group_stride = H; p.ldb = ldw; p.nk1 = p.nk2 = 0;
+    p.M = Mt; p.Nu = H; p.group_stride = H; p.ldb = ldw; p.nk1 = p.nk2 = 0;
     p.A1lo = p.A2lo = p.Blo = nullptr;
     const bf16_t* hprev = hbuf + (long)t * M * H;
     int k1, k2;
@@ -432,12 +460,17 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
     e.gates = gates ? (uint2*)gates + (long)t * M * H : nullptr;
     if (c_all) { e.c_in = c_all + (long)t * M * H; e.c_out = c_all + (long)(t + 1) * M * H; }   // slab t+1 = c after step t
     else { e.c_in = c_state; e.c_out = c_state; }
-    e.M = M; e.H = H;
+    e.row_map = row_map;
+    e.M = Mt; e.H = H;
     if (split) { launch_lstm_fwd<CfgLstmSmall, true>(p, e, k1, k2, st); continue; }   // parity mode: v1 64-row tiles, 3 MFMA products
-    switch (pick) {
+    switch (pick_fwd_tile(Mt, H)) {
       case 0: launch_lstm_fwd<CfgLstmV2a>(p, e, k1, k2, st); break;
-      case 1: launch_lstm_fwd<CfgLstmV2b>(p, e, k1, k2, st); break;
-      case 2: launch_lstm_fwd<CfgLstmBig>(p, e, k1, k2, st); break;
+      case 1: launch_lstm_fwd<CfgLstmV2_288>(p, e, k1, k2, st); break;
+      case 2: launch_lstm_fwd<CfgLstmV2b>(p, e, k1, k2, st); break;
+      case 3: launch_lstm_fwd<CfgLstmV2_224>(p, e, k1, k2, st); break;
+      case 4: launch_lstm_fwd<CfgLstmV2_192>(p, e, k1, k2, st); break;
+      case 5: launch_lstm_fwd<CfgLstmV2_160>(p, e, k1, k2, st); break;
+      case 6: launch_lstm_fwd<CfgLstmBig>(p, e, k1, k2, st); break;
       default: launch_lstm_fwd<CfgLstmSmall>(p, e, k1, k2, st); break;
     }
   }
@@ -457,6 +490,8 @@ struct LstmBwdParams {
   const float* dh_above;    // slab t [M][H] or NULL
   float* dc_ws;             // [M][H]
   uint2* dz4;               // slab t [M][H] gate-interleaved: 4 bf16 (dz_i, dz_j, dz_f, dz_o) per (row, unit)
+  const int* row_map;       // slot -> row of dS_c / dS_h (row plan) or NULL
+  int m_active;             // rows [m_active, M) are inactive at this step: tiles entirely beyond it only zero dz
   int M, H;
 };
 
@@ -468,10 +503,18 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_bwd_step_kernel(GemmOperands p, 
   int tm, tn;
   tile_of(id, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * Cfg::BM, u0 = tn * Cfg::BU;
+  const int H = e.H;
+  if (m0 >= e.m_active) {     // no active row in this tile (row plan: active rows are a prefix): dz = 0, no GEMM
+    const int cols = min(Cfg::BU, H - u0) / 2;                  // 16-byte pieces (2 units) per row
+    for (int i = threadIdx.x; i < Cfg::BM * cols; i += Cfg::NT) {
+      const int m = m0 + i / cols, u = u0 + (i % cols) * 2;
+      if (m < e.M) *(uint4*)(e.dz4 + (long)m * H + u) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    return;
+  }
   f32x4 acc[Cfg::MI][1][Cfg::NI];
   run_mainloop<Cfg, 1, true>(p, m0, u0, acc);     // transposed accumulators: lane = one row, 4 consecutive units
   TileCoordsT<Cfg> tc;
-  const int H = e.H;
 #pragma unroll
   for (int ni = 0; ni < Cfg::NI; ++ni) {
     const int u = u0 + tc.unit0 + ni * 16;
@@ -492,7 +535,7 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_bwd_step_kernel(GemmOperands p, 
       float dh[4] = {acc[mi][0][ni][0], acc[mi][0][ni][1], acc[mi][0][ni][2], acc[mi][0][ni][3]};
       float4 dcv;
       if (last) {
-        const long su = (long)m * e.ld_dS + u;
+        const long su = (long)(e.row_map ? e.row_map[m] : m) * e.ld_dS + u;
         const float4 hv = *(const float4*)(e.dS_h + su);   // nothing flows back from later (inactive) steps
         dh[0] = hv.x; dh[1] = hv.y; dh[2] = hv.z; dh[3] = hv.w;
         dcv = *(const float4*)(e.dS_c + su);
@@ -539,22 +582,39 @@ static inline void launch_lstm_bwd(GemmOperands p, const LstmBwdParams& e, int k
   launch_cfg<Cfg>(lstm_bwd_step_kernel<Cfg>, tm * tn, st, p, e, tm, tn);
 }
 
+typedef TileCfg2<128, 1, 128, 2, 4, 5, true> CfgBwdV2_128;   // BPTT step tiles: BM rows x 128 units, 8 waves (2x4)
+typedef TileCfg2<160, 1, 128, 2, 4, 5, true> CfgBwdV2_160;
+typedef TileCfg2<192, 1, 128, 2, 4, 5, true> CfgBwdV2_192;
+
 extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int T, int M, int Kin, int H,
                                   const void* gates, const float* c_all, const float* dS_c, const float* dS_h, int64_t ld_dS,
-                                  const float* dh_above, float* dc_ws, evc_bf16* dz4, void* stream) {
+                                  const float* dh_above, float* dc_ws, evc_bf16* dz4,
+                                  const int32_t* row_map, const int32_t* rows_per_step, void* stream) {
   EVC_REQUIRE(T > 0 && M > 0 && H > 0 && Kin > 0 && H % 64 == 0, EVC_ERR_BAD_SHAPE, "evc_lstm_layer_bwd: bad shape");
   EVC_REQUIRE(gates && c_all && ((uintptr_t)gates % 16) == 0 && ((uintptr_t)c_all % 16) == 0 && ((uintptr_t)dz4 % 16) == 0,
               EVC_ERR_BAD_ALIGN, "evc_lstm_layer_bwd: gates/c_all/dz4 alignment");
   EVC_REQUIRE(ld_dS % 4 == 0 && ((uintptr_t)dS_c % 16) == 0 && ((uintptr_t)dS_h % 16) == 0 && ((uintptr_t)dc_ws % 16) == 0 &&
               (!dh_above || ((uintptr_t)dh_above % 16) == 0), EVC_ERR_BAD_ALIGN, "evc_lstm_layer_bwd: f32 operands must allow 16-byte vector access");
+  if (rows_per_step)
+    for (int t = 0; t < T; ++t)
+      EVC_REQUIRE(rows_per_step[t] >= 0 && rows_per_step[t] <= M && (t == 0 || rows_per_step[t] <= rows_per_step[t - 1]), EVC_ERR_BAD_ARG,
+                  "evc_lstm_layer_bwd: rows_per_step[%d]=%d must be non-increasing and within [0, M=%d]", t, rows_per_step[t], M);
   hipStream_t st = (hipStream_t)stream;
-  // The BPTT step is dominated by its epilogue (tape / dc / dz traffic per element), not by the
-  // [M,4H]x[4H,H] GEMM: 64x64 tiles at 4 workgroups per CU overlap one workgroup's epilogue with the
-  // others' main loops and measured fastest at every M (120 vs 141 us at M=5120; 44 vs 93 at M=1280).
-  int pick = 2;
-  if ((long)ceil_div(M, 64) * ceil_div(H, 64) < 192) pick = 3;      // M ~ batch: 32x32 tiles to reach all 256 CUs
-  if (forced_tile()) pick = forced_tile() - 1;
   for (int t = T - 1; t >= 0; --t) {
+    const int Mt = rows_per_step ? rows_per_step[t] : M;    // active rows = prefix [0, Mt); the grid still covers all M
+    // rows: tiles beyond Mt only zero their dz rows (the weight-gradient products contract over every row)
+    // Tile choice: 256 CUs work through ceil(tiles/256) tiles each.  v2 tiles (BM x 128, LDS-DMA ring) for the
+    // large steps; v1 64x64 / 32x32 (several workgroups per CU, epilogues overlap main loops) for the small ones.
+    static const int bm[5] = {192, 160, 128, 64, 32}, bn[5] = {128, 128, 128, 64, 32};
+    static const double cf[5] = {1.0, 1.0, 1.02, 2.0, 3.0};
+    int pick = 3;
+    double bc = 1e300;
+    const int ma = Mt > 0 ? Mt : 1;
+    for (int i = 0; i < 5; ++i) {
+      const double c = tile_cost((long)ceil_div(ma, bm[i]) * ceil_div(H, bn[i]), bm[i], bn[i], 1, cf[i]);
+      if (c < bc) { bc = c; pick = i; }
+    }
+    if (forced_tile()) pick = forced_tile() - 1;          // debug: 1 -> 192, 2 -> 160, 3 -> 128, 4 -> v1 64, 5 -> v1 32
     GemmOperands p;
     p.M = M; p.Nu = H; p.group_stride = 0; p.nk1 = p.nk2 = 0;
     p.A1lo = p.A2lo = p.Blo = nullptr;
@@ -570,11 +630,13 @@ extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int 
     e.dS_c = dS_c; e.dS_h = dS_h; e.ld_dS = ld_dS;
     e.dh_above = dh_above ? dh_above + (long)t * M * H : nullptr;
     e.dc_ws = dc_ws; e.dz4 = (uint2*)dz4 + (long)t * M * H;
+    e.row_map = row_map; e.m_active = Mt;
     e.M = M; e.H = H;
     switch (pick) {
-      case 0: launch_lstm_bwd<CfgPlainV2>(p, e, k1, st); break;
-      case 1: launch_lstm_bwd<CfgPlainBig>(p, e, k1, st); break;
-      case 3: launch_lstm_bwd<CfgPlainTiny>(p, e, k1, st); break;
+      case 0: launch_lstm_bwd<CfgBwdV2_192>(p, e, k1, st); break;
+      case 1: launch_lstm_bwd<CfgBwdV2_160>(p, e, k1, st); break;
+      case 2: launch_lstm_bwd<CfgBwdV2_128>(p, e, k1, st); break;
+      case 4: launch_lstm_bwd<CfgPlainTiny>(p, e, k1, st); break;
       default: launch_lstm_bwd<CfgPlainSmall>(p, e, k1, st); break;
     }
   }

@@ -22,9 +22,11 @@ from __future__ import annotations
 
 import math
 
+import numpy as np
 import torch
 
 from . import ops
+from .streams import concurrent_streams
 from .engine import HLstmTower
 
 F32 = torch.float32
@@ -129,9 +131,10 @@ class DistillGraph:
         self.losses = torch.zeros(8, dtype=F32, device=self.device)
         self._dp_t = self._dp_s = self._ds_s = None
         self.overlap_towers = overlap_towers
+        self.row_plans = True        # sort the L1 chunk rows by length and skip the padding rows (ops.RowPlan)
         if self.device.type == "cuda":
-            self._side = torch.cuda.Stream(self.device)
-            self._aux_t, self._aux_s = torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)
+            # four streams that measurably overlap (streams.py); the step never runs on the default stream
+            self._main, self._side, self._aux_t, self._aux_s = concurrent_streams(self.device, 4)
             self._ev_fwd, self._ev_student = torch.cuda.Event(), torch.cuda.Event()
 
     # ---- data-parallel gradient reduction -------------------------------------
@@ -144,7 +147,56 @@ class DistillGraph:
             self.reducer.reduce(st.grad, 0, moe_lo)
 
     # ---- one training iteration -----------------------------------------------
-    def step(self, x_raw, labels_u8, num_frames, apply=True):
+    def step(self, x_raw, labels_u8, num_frames, apply=True, num_frames_host=None):
+        """Runs ``_step`` on the graph's own main stream, ordered after the caller's current stream on entry
+        and before it on exit (so callers see ordinary single-stream semantics).
+
+        num_frames_host: the same frame counts on the host (numpy / CPU tensor / list), as the input pipeline
+        has them before the H2D copy.  The launch geometry of the row-planned L1 stacks depends on them; without
+        it they are read back from the device, which stalls the host on everything queued before."""
+        if num_frames_host is None:
+            num_frames_host = num_frames.cpu()
+        nh = np.asarray(num_frames_host, dtype=np.int64).reshape(-1)
+        caller = torch.cuda.current_stream(self.device)
+        if caller == self._main:
+            return self._step(x_raw, labels_u8, num_frames, apply, nh)
+        self._main.wait_stream(caller)
+        with torch.cuda.stream(self._main):
+            out = self._step(x_raw, labels_u8, num_frames, apply, nh)
+        for t in (x_raw, labels_u8, num_frames):
+            t.record_stream(self._main)
+        caller.wait_stream(self._main)
+        return out
+
+    debug_marks = None      # set to a list to collect (name, timing event) pairs of one step (scripts/step_marks.py)
+
+    def _mark(self, name, stream):
+        if self.debug_marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream)
+            self.debug_marks.append((name, ev))
+
+    def _plans(self, num_frames, nh, need_teacher, need_student):
+        """Frame counts (device) and the L1 row plans of both towers: rows sorted by length so the padding
+        rows drop out of every L1 kernel (ops.RowPlan).  Host twins of the counts give the launch geometry."""
+        t = s = None
+        if need_teacher:
+            _, l1, l2 = ops.frame_counts(num_frames, 1, self.C1, self.max_frames // self.C1, self.max_frames)
+            plan = None
+            if self.row_plans:
+                _, l1h, _ = ops.host_frame_counts(nh, 1, self.C1, self.max_frames // self.C1, self.max_frames)
+                plan = ops.RowPlan(l1, l1h, self.max_frames // self.C1)
+            t = (l1, l2, plan)
+        if need_student:
+            n_s, l1s, l2s = ops.frame_counts(num_frames, self.every_n, self.C2, self.S // self.C2, self.max_frames)
+            plan = None
+            if self.row_plans:
+                _, l1h, _ = ops.host_frame_counts(nh, self.every_n, self.C2, self.S // self.C2, self.max_frames)
+                plan = ops.RowPlan(l1s, l1h, self.S // self.C2)
+            s = (n_s, l1s, l2s, plan)
+        return t, s
+
+    def _step(self, x_raw, labels_u8, num_frames, apply=True, nh=None):
         """x_raw [B,300,F] f32 (or uint8), labels_u8 [B,V] uint8, num_frames [B] int32.
         Returns a dict mirroring the graph collections the reference's loop
         fetches (cs/train.py:336-344,420-425,516-517); tensors stay on device.
@@ -161,11 +213,14 @@ class DistillGraph:
             self._dp_s = torch.empty((B, V), dtype=F32, device=dev)
         need_student = self.student is not None
         main = torch.cuda.current_stream(dev)
+        tp, sp = self._plans(num_frames, nh, self.teacher is not None, need_student)
         xt, xs = ops.l2norm_chunk(x_raw, self.C1, self.every_n if need_student else None, self.C2,
                                   num_frames=num_frames if x_raw.dtype == torch.uint8 else None,
-                                  split=self.precision == "high")
+                                  split=self.precision == "high", plan1=tp[2] if tp else None, plan2=sp[3] if sp else None)
         self.losses.zero_()
         out = {}
+        mark = self._mark
+        mark("start", main)
         sc = dp_loss_scales(self.world)
         # both train ops read the same global_step / learning rate within one iteration (cs/train.py:223-236)
         lr = exponential_decay(self.lr0, self.global_step, B * self.world, self.lr_decay_examples, self.lr_decay)
@@ -173,19 +228,22 @@ class DistillGraph:
         self._teacher_applied = self._student_applied = False
         two_streams = self.teacher is not None and need_student and self.overlap_towers
         if self.teacher is not None:
-            _, l1, l2 = ops.frame_counts(num_frames, 1, self.C1, self.max_frames // self.C1, self.max_frames)
-            t_state, t_pred = self.teacher.forward(xt, l1, l2)
+            l1, l2, plan_t = tp
+            t_state, t_pred = self.teacher.forward(xt, l1, l2, plan_t)
             ops.ce_loss(t_pred, labels_u8, self.losses[0:1], self._dp_t, grad_scale=sc["ce"] / B)
             if two_streams:
                 self._ev_fwd.record(main)
+            mark("teacher_fwd_done", main)
         if need_student:
             side = self._side if two_streams else main
             if two_streams:
                 side.wait_event(self._ev_fwd)
             with torch.cuda.stream(side):
-                n_s, l1s, l2s = ops.frame_counts(num_frames, self.every_n, self.C2, self.S // self.C2, self.max_frames)
-                s_state, s_pred = self.student.forward(xs, l1s, l2s)
+                mark("student_start", side)
+                n_s, l1s, l2s, plan_s = sp
+                s_state, s_pred = self.student.forward(xs, l1s, l2s, plan_s)
                 ops.ce_loss(s_pred, labels_u8, self.losses[3:4], self._dp_s, grad_scale=sc["ce"] / B)
+                mark("student_fwd_done", side)
                 ds = None
                 if self.teacher is not None:
                     if self._ds_s is None or self._ds_s.shape != s_state.shape:
@@ -194,15 +252,19 @@ class DistillGraph:
                                      grad_scale=sc["kl"], accumulate_grad=True)
                     ops.rep_loss(t_state, s_state, self.losses[1:2], self._ds_s, grad_scale=self.rep_w * sc["rep"])
                     ds = self._ds_s
-                early = (lr, self.clip, l2c) if (apply and self.overlap_towers and self.world == 1) else None
+                early = (lr, self.clip, l2c) if (apply and self.overlap_towers and self.world == 1 and self._aux_s is not None) else None
                 self.student.backward(ds, self._dp_s,
                                       on_moe_grads_ready=lambda: self._reduce_tower(self.student, True),
                                       aux=self._aux_s if self.overlap_towers else None, early_apply=early)
                 self._reduce_tower(self.student, False)
                 self._student_applied = early is not None
+                mark("student_done", side)
                 if two_streams:
                     self._ev_student.record(side)
-                    for t in ((xs if isinstance(xs, tuple) else (xs,)) + (n_s, l1s, l2s)):   # allocated on `main`, consumed on `side`
+                    used = (xs if isinstance(xs, tuple) else (xs,)) + (n_s, l1s, l2s)
+                    if plan_s is not None:
+                        used += (plan_s.pos, plan_s.inv, plan_s.lens)
+                    for t in used:                                          # allocated on `main`, consumed on `side`
                         if t is not None:
                             t.record_stream(side)
             out.update(student_predictions=s_pred, student_state=s_state, num_frames_student=n_s,
@@ -210,11 +272,12 @@ class DistillGraph:
         if self.teacher is not None:
             # weight-gradient GEMMs and the per-group clip+Adam go to an aux stream, under the BPTT chain
             # (the tower's outputs t_state / t_pred are separate buffers, untouched by the update)
-            early = (lr, self.clip, l2c) if (apply and self.overlap_towers and self.world == 1) else None
+            early = (lr, self.clip, l2c) if (apply and self.overlap_towers and self.world == 1 and self._aux_t is not None) else None
             self.teacher.backward(None, self._dp_t,
                                   on_moe_grads_ready=lambda: self._reduce_tower(self.teacher, True),
                                   aux=self._aux_t if self.overlap_towers else None, early_apply=early)
             self._reduce_tower(self.teacher, False)
+            mark("teacher_bwd_done", main)
             out.update(predictions=t_pred, teacher_state=t_state, loss=self.losses[0])
             self._teacher_applied = early is not None
         if two_streams:
@@ -279,8 +342,9 @@ class EvalGraph:
                 if tw is not None:
                     tw.set_precision("high")
         self.losses = torch.zeros(4, dtype=F32, device=self.device)
-        self._side = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
-        self._ev_in, self._ev_out = (torch.cuda.Event(), torch.cuda.Event()) if self._side else (None, None)
+        self._main, self._side = concurrent_streams(self.device, 4)[:2]
+        self._ev_in, self._ev_out = torch.cuda.Event(), torch.cuda.Event()
+        self.row_plans = True
 
     def restore(self, state_dict):
         """saver_teacher / saver_student .restore (cs/validate.py:350-384): the 11 variables of each tower by name."""
@@ -288,32 +352,45 @@ class EvalGraph:
             if tw is not None:
                 tw.load_state_dict(state_dict)
 
-    def step(self, x_raw, labels_u8, num_frames):
+    def step(self, x_raw, labels_u8, num_frames, num_frames_host=None):
+        if num_frames_host is None:
+            num_frames_host = num_frames.cpu()
+        nh = np.asarray(num_frames_host, dtype=np.int64).reshape(-1)
+        caller = torch.cuda.current_stream(self.device)
+        self._main.wait_stream(caller)
+        with torch.cuda.stream(self._main):
+            out = self._step(x_raw, labels_u8, num_frames, nh)
+        for t in (x_raw, labels_u8, num_frames):
+            t.record_stream(self._main)
+        caller.wait_stream(self._main)
+        return out
+
+    def _step(self, x_raw, labels_u8, num_frames, nh):
         """Returns predictions (student), student_label_loss, student_state_loss (teacher_student only) - the
         tensors cs/validate.py:240 fetches.  The two towers are independent: they run on two streams."""
         main = torch.cuda.current_stream(self.device)
         split = self.precision == "high"
         u8 = x_raw.dtype == torch.uint8
-        if self.teacher is not None:
-            xt, xs = ops.l2norm_chunk(x_raw, self.C1, self.every_n, self.C2, num_frames=num_frames if u8 else None, split=split)
-        else:
-            # student only: the teacher view is not needed; chunk the sub-sampled frames directly
-            _, xs = ops.l2norm_chunk(x_raw, self.C1, self.every_n, self.C2, num_frames=num_frames if u8 else None, split=split)
-            xt = None
+        tp, sp = DistillGraph._plans(self, num_frames, nh, self.teacher is not None, True)
+        xt, xs = ops.l2norm_chunk(x_raw, self.C1, self.every_n, self.C2, num_frames=num_frames if u8 else None, split=split,
+                                  plan1=tp[2] if tp else None, plan2=sp[3])
         self.losses.zero_()
         out = {}
         self._ev_in.record(main)
         self._side.wait_event(self._ev_in)
+        n_s, l1s, l2s, plan_s = sp
         with torch.cuda.stream(self._side):
-            n_s, l1s, l2s = ops.frame_counts(num_frames, self.every_n, self.C2, self.S // self.C2, self.max_frames)
-            s_state, s_pred = self.student.forward(xs, l1s, l2s)
+            s_state, s_pred = self.student.forward(xs, l1s, l2s, plan_s)
             ops.ce_loss(s_pred, labels_u8, self.losses[0:1])
             self._ev_out.record(self._side)
-            for t in ((xs if isinstance(xs, tuple) else (xs,)) + (n_s, l1s, l2s)):
+            used = (xs if isinstance(xs, tuple) else (xs,)) + (n_s, l1s, l2s)
+            if plan_s is not None:
+                used += (plan_s.pos, plan_s.inv, plan_s.lens)
+            for t in used:
                 t.record_stream(self._side)
         if self.teacher is not None:
-            _, l1, l2 = ops.frame_counts(num_frames, 1, self.C1, self.max_frames // self.C1, self.max_frames)
-            t_state, t_pred = self.teacher.forward(xt, l1, l2)
+            l1, l2, plan_t = tp
+            t_state, t_pred = self.teacher.forward(xt, l1, l2, plan_t)
             out.update(teacher_state=t_state, teacher_predictions=t_pred)
         main.wait_event(self._ev_out)
         if self.teacher is not None:

@@ -77,7 +77,7 @@ class LstmStack:
         H, L, dev = tower.H, tower.L, tower.device
         self.H, self.L = H, L
         self.S = torch.zeros((M, 2 * L * H), dtype=F32, device=dev)          # final state [c0|h0|c1|h1]
-        self.hbuf = [torch.empty((T + 1, M, H), dtype=BF16, device=dev) for _ in range(L)]
+        self.hbuf = [torch.zeros((T + 1, M, H), dtype=BF16, device=dev) for _ in range(L)]   # zeros: stale rows stay finite
         self.kin = [Kin] + [H] * (L - 1)
         # hoist the x-projection when the per-step GEMM is small (M ~ batch): fewer, larger GEMMs
         self.hoist = [M < 1024 for _ in range(L)]
@@ -90,7 +90,7 @@ class LstmStack:
             self.gates = [torch.empty((T, M, H, 2), dtype=torch.int32, device=dev) for _ in range(L)]
             self.c_all = [torch.empty((T + 1, M, H), dtype=F32, device=dev) for _ in range(L)]
             self.KP = ops.round_up(T * M, 64)
-            self.dz = [torch.empty((T, M, 4 * H), dtype=BF16, device=dev) for _ in range(L)]   # gate-interleaved [T][M][H][4];
+            self.dz = [torch.zeros((T, M, 4 * H), dtype=BF16, device=dev) for _ in range(L)]   # gate-interleaved [T][M][H][4];
             # one per layer so a layer's weight-gradient GEMMs (aux stream) can run under the next layer's BPTT
             self.use_tn = (T * M) % 32 == 0 and all(k % 8 == 0 for k in self.kin)
             if not self.use_tn:   # ragged row counts: transposed copies for the NT kernel
@@ -104,59 +104,81 @@ class LstmStack:
         base = "%s/rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/" % (self.scope, l)
         return base + "kernel", base + "bias"
 
-    def forward(self, x, lens):
+    @staticmethod
+    def _v(buf, *shape):
+        """Leading part of a preallocated buffer viewed with a (smaller) shape: row plans use [T][P][..] of [T][M][..]."""
+        n = 1
+        for d in shape:
+            n *= d
+        return buf.view(-1)[:n].view(*shape)
+
+    def forward(self, x, lens, plan=None):
         """x [T][M][Kin] bf16 time-major (or a (hi, lo) pair in "high" precision); lens [M] int32.
+        plan: ops.RowPlan of this batch - x is then [T][plan.P][Kin] in slot order and every buffer of the
+        stack is used with plan.P rows per time slab; the returned state is in the original row order.
         Returns S [M, 2LH] f32."""
-        tw, H, L, T, M = self.tw, self.H, self.L, self.T, self.M
+        tw, H, L, T = self.tw, self.H, self.L, self.T
+        M = plan.P if plan is not None else self.M
+        self.plan, self.Mrun = plan, M
+        if plan is not None:
+            lens = plan.lens
+            if plan.rows[0] < self.M:
+                self.S.zero_()                       # final state of the rows no step touches (length 0)
+        hb = [self._v(h, T + 1, M, H) for h in self.hbuf]
+        gates = [self._v(g, T, M, H, 2) for g in self.gates] if self.training else [None] * L
+        c_all = [self._v(c, T + 1, M, H) for c in self.c_all] if self.training else [None] * L
+        self._hb = hb
         if isinstance(x, tuple):        # split-bf16 parity mode: hi.hi + hi.lo + lo.hi in every step
             x_hi, x_lo = x
             self.x_in, self.lens = x_hi, lens
             if not hasattr(self, "hbuf_lo"):
-                self.hbuf_lo = [torch.empty_like(h) for h in self.hbuf]
+                self.hbuf_lo = [torch.zeros_like(h) for h in self.hbuf]
+            hl = [self._v(h, T + 1, M, H) for h in self.hbuf_lo]
             inp, inp_lo = x_hi, x_lo
             for l in range(L):
                 kn, bn = self.names(l)
                 ops.lstm_layer_fwd_hp(inp, inp_lo, tw.shadow_fwd[kn], tw.shadow_lo[kn], tw.store.p(bn), lens, T, M,
-                                      self.kin[l], H, self.hbuf[l], self.hbuf_lo[l],
+                                      self.kin[l], H, hb[l], hl[l],
                                       self.S[:, (2 * l) * H:], self.S[:, (2 * l + 1) * H:], 2 * L * H,
-                                      self.gates[l] if self.training else None, self.c_all[l] if self.training else None)
-                inp, inp_lo = self.hbuf[l][1:], self.hbuf_lo[l][1:]
+                                      gates[l], c_all[l], plan=plan)
+                inp, inp_lo = hb[l][1:], hl[l][1:]
             return self.S
         self.x_in, self.lens = x, lens
         inp = x
         for l in range(L):
             kn, bn = self.names(l)
             ops.lstm_layer_fwd(inp, tw.shadow_fwd[kn], tw.store.p(bn), lens, T, M, self.kin[l], H,
-                               self.hbuf[l], self.S[:, (2 * l) * H:], self.S[:, (2 * l + 1) * H:], 2 * L * H,
-                               self.gates[l] if self.training else None, self.c_all[l] if self.training else None,
-                               hoist=self.hoist[l], zx_ws=self.zx)
-            inp = self.hbuf[l][1:]
+                               hb[l], self.S[:, (2 * l) * H:], self.S[:, (2 * l + 1) * H:], 2 * L * H,
+                               gates[l], c_all[l], hoist=self.hoist[l], zx_ws=self.zx, plan=plan)
+            inp = hb[l][1:]
         return self.S
 
     def profile_fwd_layers(self, reps=3):
-        """Bench helper: time each layer's forward launch sequence with events on
-        the current stream.  Returns [(ms_per_call, step_launches, gemm_flops)] per
-        layer; flops are the algorithmic 2*M*4H*K of the per-step GEMMs (t=0 has
-        no recurrent half)."""
-        tw, H, T, M = self.tw, self.H, self.T, self.M
+        """Bench helper: time each layer's forward launch sequence (of the last forward() call, same row
+        plan) with events on the current stream.  Returns [(ms_per_call, step_launches, gemm_flops)] per
+        layer; flops are the algorithmic 2*rows_t*4H*K of the per-step GEMMs over the rows each step
+        runs on (t=0 has no recurrent half)."""
+        tw, H, T, M, plan = self.tw, self.H, self.T, self.Mrun, self.plan
+        rows = plan.rows if plan is not None else [M] * T
         res = []
         inp = self.x_in
         for l in range(self.L):
             kn, bn = self.names(l)
-            args = (inp, tw.shadow_fwd[kn], tw.store.p(bn), self.lens, T, M, self.kin[l], H, self.hbuf[l],
-                    self.S[:, (2 * l) * H:], self.S[:, (2 * l + 1) * H:], 2 * self.L * H,
-                    self.gates[l] if self.training else None, self.c_all[l] if self.training else None)
-            ops.lstm_layer_fwd(*args, hoist=self.hoist[l], zx_ws=self.zx)
+            gates = self._v(self.gates[l], T, M, H, 2) if self.training else None
+            c_all = self._v(self.c_all[l], T + 1, M, H) if self.training else None
+            args = (inp, tw.shadow_fwd[kn], tw.store.p(bn), self.lens, T, M, self.kin[l], H, self._hb[l],
+                    self.S[:, (2 * l) * H:], self.S[:, (2 * l + 1) * H:], 2 * self.L * H, gates, c_all)
+            ops.lstm_layer_fwd(*args, hoist=self.hoist[l], zx_ws=self.zx, plan=plan)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(reps):
-                ops.lstm_layer_fwd(*args, hoist=self.hoist[l], zx_ws=self.zx)
+                ops.lstm_layer_fwd(*args, hoist=self.hoist[l], zx_ws=self.zx, plan=plan)
             e1.record()
             e1.synchronize()
             kx = 0 if self.hoist[l] else self.kin[l]
-            flops = 2.0 * M * 4 * H * (kx * T + H * (T - 1))
-            res.append((e0.elapsed_time(e1) / reps, T, flops))
-            inp = self.hbuf[l][1:]
+            flops = sum(2.0 * r * 4 * H * (kx + (H if t > 0 else 0)) for t, r in enumerate(rows))
+            res.append((e0.elapsed_time(e1) / reps, sum(1 for r in rows if r > 0), flops))
+            inp = self._hb[l][1:]
         return res
 
     def backward(self, dS, need_dx, aux=None):
@@ -164,24 +186,29 @@ class LstmStack:
         buffer; returns dX [T*M, Kin] f32 (gradient wrt the stack input) if need_dx.
         aux: optional side stream for the weight-gradient products, which nothing on the BPTT
         critical path waits for; the caller joins it before using the gradients."""
-        tw, H, L, T, M = self.tw, self.H, self.L, self.T, self.M
+        tw, H, L, T, plan = self.tw, self.H, self.L, self.T, self.plan
+        M = self.Mrun                                               # rows per time slab in this batch's layout
+        assert plan is None or not need_dx, "dX of a row-planned stack would be in slot order"
         dh_above = None
         dx_out = None
         main = torch.cuda.current_stream(tw.device)
+        use_tn = (T * M) % 32 == 0 and all(k % 8 == 0 for k in self.kin)
+        assert use_tn or not self.use_tn or M == self.M
         for l in range(L - 1, -1, -1):
             kn, bn = self.names(l)
             w = tw.shadow_bwd[kn]                                   # [kin+H][4H] bf16, 4H axis gate-interleaved
             kin = self.kin[l]
             KP = self.KP
-            dz = self.dz[l]
-            ops.lstm_layer_bwd(w, self.lens, T, M, kin, H, self.gates[l], self.c_all[l],
+            dz = self._v(self.dz[l], T, M, 4 * H)
+            ops.lstm_layer_bwd(w, self.lens, T, M, kin, H, self._v(self.gates[l], T, M, H, 2), self._v(self.c_all[l], T + 1, M, H),
                                dS[:, (2 * l) * H:], dS[:, (2 * l + 1) * H:], 2 * L * H,
-                               dh_above, self.dc_ws, dz)
+                               dh_above, self._v(self.dc_ws, M, H), dz, plan=plan)
             dz2 = dz.view(T * M, 4 * H)
             # gradient wrt the layer input, all T at once (hoisted): dX = dz . Wx^T
             if l > 0:
-                ops.gemm_nt(dz2, w, T * M, kin, 4 * H, self.dx[l])
-                dh_above = self.dx[l]
+                dxl = self._v(self.dx[l], T * M, kin)
+                ops.gemm_nt(dz2, w, T * M, kin, 4 * H, dxl)
+                dh_above = dxl
             elif need_dx:
                 if self.dx[0] is None:
                     self.dx[0] = torch.empty((T * M, kin), dtype=F32, device=tw.device)
@@ -196,9 +223,9 @@ class LstmStack:
                 side = aux
             with torch.cuda.stream(side):
                 gW = tw.store.g(kn)                                     # [4H][kin+H] f32
-                layer_in = (self.x_in if l == 0 else self.hbuf[l - 1][1:]).reshape(T * M, kin)
-                h_prev = self.hbuf[l][:T].reshape(T * M, H)
-                if self.use_tn:
+                layer_in = (self.x_in if l == 0 else self._hb[l - 1][1:]).reshape(T * M, kin)
+                h_prev = self._hb[l][:T].reshape(T * M, H)
+                if use_tn:
                     # "TN" products straight from the row-major activations (transpose reads in the kernel);
                     # the gate-interleaved rows of the product are stored in TF gate order
                     ops.gemm_tn(dz2, layer_in, 4 * H, kin, T * M, gW, row_interleave_H=H, ldc=kin + H)
@@ -460,16 +487,17 @@ class HLstmTower(TowerBase):
         return self.moe.gate_logits
 
     # ---- forward ------------------------------------------------------------
-    def forward(self, x_view, len_l1, len_l2):
+    def forward(self, x_view, len_l1, len_l2, plan_l1=None):
         """x_view [Lc][C*B][F] bf16 (ops.l2norm_chunk); lengths from ops.frame_counts.
+        plan_l1: ops.RowPlan of the L1 chunk rows (x_view is then [Lc][plan.P][F], from l2norm_chunk(plan1=..)).
         Returns (state [B, 2LH] f32, predictions [B, V] f32)."""
         high = isinstance(x_view, tuple)
         if high and self.precision != "high":
             raise ValueError("(hi, lo) input needs tower.set_precision('high')")
-        B = (x_view[0] if high else x_view).shape[1] // self.C
+        B = int(len_l2.shape[0])
         if B != self.B:
             self._alloc(B)
-        S1 = self.l1.forward(x_view, len_l1)
+        S1 = self.l1.forward(x_view, len_l1, plan_l1)
         if high:
             if not hasattr(self, "S1_lo") or self.S1_lo.shape != self.S1_bf.shape:
                 self.S1_lo = torch.empty_like(self.S1_bf)

@@ -6,6 +6,8 @@ CPU or eager-PyTorch fallback; CPU tensors are rejected.
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 
 from . import _lib
@@ -98,22 +100,69 @@ def rowsum_bf16(x, R, C, out):
 
 
 # ---------------------------------------------------------------------------
-def l2norm_chunk(x_raw, num_chunks, every_n=None, num_chunks_student=None, num_frames=None, normalize=True, split=False):
+class RowPlan:
+    """Row order of one LSTM stack for one batch (evc_sort_rows_by_len): rows sorted by sequence length,
+    longest first, so that the rows active at step t are the prefix [0, rows[t]) and the length-0 rows
+    (frames beyond num_frames) drop out of every kernel.
+
+    pos / inv / lens  device int32 [M]: slot of each row, row of each slot, length of each slot
+    P                 rows kept per time slab (rows[0] rounded up to 32, at most M): all [T][M][..] buffers
+                      of the stack are used as [T][P][..]
+    rows              host list [T]: rows[t] = #{len > t}, computed from the HOST copy of the lengths (the
+                      launch geometry depends on it; a device->host read would stall the stream)
+    """
+
+    def __init__(self, lens_dev, lens_host, T):
+        import numpy as np
+        lens_host = np.asarray(lens_host)
+        M = int(lens_dev.shape[0])
+        assert lens_host.shape == (M,)
+        self.M, self.T = M, T
+        hist = np.bincount(np.clip(lens_host, 0, T), minlength=T + 1)
+        self.rows = [int(M - hist[:t + 1].sum()) for t in range(T)]         # rows with len > t
+        self.P = min(M, max(32, round_up(self.rows[0], 32)))
+        self.rows_c = (C.c_int32 * T)(*self.rows)
+        dev = lens_dev.device
+        self.pos = torch.empty(M, dtype=torch.int32, device=dev)
+        self.inv = torch.empty(M, dtype=torch.int32, device=dev)
+        self.lens = torch.empty(M, dtype=torch.int32, device=dev)
+        _lib.call("evc_sort_rows_by_len", _p(lens_dev), M, T, _p(self.pos), _p(self.inv), _p(self.lens), _stream())
+
+
+def host_frame_counts(num_frames_host, every_n, num_chunks, chunk_len, max_frames=300):
+    """Host (numpy) twin of evc_frame_counts, bit-identical: (n_used int64 [B], len_l1 int32 [C*B], len_l2 int32 [B])."""
+    import numpy as np
+    n = np.asarray(num_frames_host).astype(np.int64)
+    if every_n > 1:
+        S = max_frames // every_n
+        n = np.trunc(n.astype(np.float64) / float(max_frames) * float(S)).astype(np.int64)
+    l1 = np.clip(n[None, :] - chunk_len * np.arange(num_chunks, dtype=np.int64)[:, None], 0, chunk_len).astype(np.int32).reshape(-1)
+    l2 = np.ceil(n.astype(np.float32) / np.float32(chunk_len)).astype(np.int32)
+    return n, l1, l2
+
+
+def l2norm_chunk(x_raw, num_chunks, every_n=None, num_chunks_student=None, num_frames=None, normalize=True, split=False,
+                 plan1=None, plan2=None):
     """a1+a2.  x_raw [B,T,F] f32 (or uint8 with num_frames).  Returns the
-    teacher view [Lc][C*B][F] bf16 and (if every_n) the student view."""
+    teacher view [Lc][C*B][F] bf16 and (if every_n) the student view; with row plans the views are
+    [Lc][plan.P][F] in slot order."""
     B, T, F = x_raw.shape
     dev = x_raw.device
-    out1 = torch.empty((T // num_chunks, num_chunks * B, F), dtype=BF16, device=dev)
+    rows1 = plan1.P if plan1 is not None else num_chunks * B
+    out1 = torch.empty((T // num_chunks, rows1, F), dtype=BF16, device=dev)
     out2 = None
+    rows2 = 0
     if every_n:
         S = T // every_n
-        out2 = torch.empty((S // num_chunks_student, num_chunks_student * B, F), dtype=BF16, device=dev)
+        rows2 = plan2.P if plan2 is not None else num_chunks_student * B
+        out2 = torch.empty((S // num_chunks_student, rows2, F), dtype=BF16, device=dev)
     is_u8 = x_raw.dtype == torch.uint8
     lo1 = torch.empty_like(out1) if split else None
     lo2 = torch.empty_like(out2) if (split and out2 is not None) else None
     _lib.call("evc_l2norm_chunk_fwd", None if is_u8 else _p(x_raw), _p(x_raw) if is_u8 else None, _p(num_frames),
               B, T, F, num_chunks, _p(out1), every_n or 1, num_chunks_student or 1, _p(out2), 1 if normalize else 0,
-              _p(lo1), _p(lo2), _stream())
+              _p(lo1), _p(lo2), _p(plan1.pos) if plan1 is not None else None, rows1,
+              _p(plan2.pos) if plan2 is not None else None, rows2, _stream())
     if split:      # (hi, lo) pairs for the "high" precision forward
         return (out1, lo1), ((out2, lo2) if out2 is not None else None)
     return out1, out2
@@ -131,21 +180,26 @@ def frame_counts(num_frames, every_n, num_chunks, chunk_len, max_frames=300):
 
 
 # ---------------------------------------------------------------------------
+def _plan_args(plan):
+    return (_p(plan.inv), plan.rows_c) if plan is not None else (None, None)
+
+
 def lstm_layer_fwd(x, wT, bias, lens, T, M, Kin, H, hbuf, c_state, h_state, ld_state,
-                   gates=None, c_all=None, hoist=False, zx_ws=None):
+                   gates=None, c_all=None, hoist=False, zx_ws=None, plan=None):
+    """With a RowPlan: M = plan.P, lens = plan.lens, all [T][M][..] operands in slot order."""
     _lib.call("evc_lstm_layer_fwd", _p(x), _p(wT), _p(bias), _p(lens), T, M, Kin, H, 1 if hoist else 0, _p(zx_ws),
-              _p(hbuf), _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_all), _stream())
+              _p(hbuf), _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_all), *_plan_args(plan), _stream())
 
 
 def lstm_layer_fwd_hp(x, x_lo, wT, wT_lo, bias, lens, T, M, Kin, H, hbuf, hbuf_lo, c_state, h_state, ld_state,
-                      gates=None, c_all=None):
+                      gates=None, c_all=None, plan=None):
     _lib.call("evc_lstm_layer_fwd_hp", _p(x), _p(x_lo), _p(wT), _p(wT_lo), _p(bias), _p(lens), T, M, Kin, H,
-              _p(hbuf), _p(hbuf_lo), _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_all), _stream())
+              _p(hbuf), _p(hbuf_lo), _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_all), *_plan_args(plan), _stream())
 
 
-def lstm_layer_bwd(w_il, lens, T, M, Kin, H, gates, c_all, dS_c, dS_h, ld_dS, dh_above, dc_ws, dz4):
+def lstm_layer_bwd(w_il, lens, T, M, Kin, H, gates, c_all, dS_c, dS_h, ld_dS, dh_above, dc_ws, dz4, plan=None):
     _lib.call("evc_lstm_layer_bwd", _p(w_il), _p(lens), T, M, Kin, H, _p(gates), _p(c_all), _p(dS_c), _p(dS_h), ld_dS,
-              _p(dh_above), _p(dc_ws), _p(dz4), _stream())
+              _p(dh_above), _p(dc_ws), _p(dz4), *_plan_args(plan), _stream())
 
 
 # ---------------------------------------------------------------------------

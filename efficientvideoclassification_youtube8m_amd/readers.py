@@ -234,7 +234,8 @@ class InputPipeline(object):
     (allow_smaller_final_batch=True, cs/train.py:175)."""
 
     def __init__(self, reader, data_pattern, batch_size, num_epochs=None, num_readers=1, shuffle=True, seed=None,
-                 device=None, rank=0, world_size=1, prefetch=3, what="training", reuse_host_buffers=False):
+                 device=None, rank=0, world_size=1, prefetch=3, what="training", reuse_host_buffers=False,
+                 with_host_counts=False):
         files = sorted(glob.glob(data_pattern)) if isinstance(data_pattern, str) else list(data_pattern)
         if not files:
             raise IOError("Unable to find " + what + " files. data_pattern='" + str(data_pattern) + "'.")   # cs/train.py:155-157
@@ -264,6 +265,9 @@ class InputPipeline(object):
         # prefetch + 2 further batches have been drawn (saves the page faults of a new 88 MB buffer per batch)
         self._reuse = reuse_host_buffers
         self._copy_stream, self._staged, self._started = None, None, False
+        # with_host_counts: batches carry a 5th element, num_frames as a numpy array (the training graph derives
+        # its launch geometry from it without reading the device copy back)
+        self._with_host = with_host_counts
 
     # -- host buffers ---------------------------------------------------------------------------------
     def _buffers(self):
@@ -332,6 +336,7 @@ class InputPipeline(object):
             return None
         b, buf = got
         ids = [_id_str(r) for r in buf["ids"].numpy()[:b]]
+        n_host = buf["n"].numpy()[:b].copy()
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(self.device)
         with torch.cuda.stream(self._copy_stream):
@@ -339,7 +344,7 @@ class InputPipeline(object):
             ev = torch.cuda.Event()
             ev.record(self._copy_stream)
         buf["event"] = ev                                            # the pinned buffers are reusable once it has fired
-        return ids, out, ev
+        return ids, out + ((n_host,) if self._with_host else ()), ev
 
     def __next__(self):
         if self.device is None:
@@ -348,7 +353,8 @@ class InputPipeline(object):
                 self._pool.shutdown(wait=False)
                 raise StopIteration
             b, buf = got
-            return [_id_str(r) for r in buf["ids"].numpy()[:b]], buf["x"][:b], buf["y"][:b], buf["n"][:b]
+            extra = (buf["n"].numpy()[:b].copy(),) if self._with_host else ()
+            return ([_id_str(r) for r in buf["ids"].numpy()[:b]], buf["x"][:b], buf["y"][:b], buf["n"][:b]) + extra
         import torch
         if not self._started:
             self._started, self._staged = True, self._stage()
@@ -360,7 +366,7 @@ class InputPipeline(object):
         ids, out, ev = cur
         main = torch.cuda.current_stream(self.device)
         main.wait_event(ev)
-        for t in out:
+        for t in out[:3]:
             t.record_stream(main)                                    # allocated on the copy stream, consumed on the caller's
         return (ids,) + out
 

@@ -71,7 +71,8 @@ def build_graph(model, label_loss_fn, feature_size, batch_size, every_n, device,
 
 def synthetic_batches(batch_size, feature_size, device, videos_per_epoch, num_epochs, seed):
     """Synthetic stand-in for get_input_data_tensors (cs/train.py:129-176): uint8
-    features dequantised by the input kernel, n ~ U{120..300}, ~3 labels/video."""
+    features dequantised by the input kernel, n ~ U{120..300}, ~3 labels/video.
+    Yields (features, labels, num_frames, num_frames on the host)."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     T = FLAGS.max_num_frames
@@ -84,7 +85,7 @@ def synthetic_batches(batch_size, feature_size, device, videos_per_epoch, num_ep
             n = torch.randint(min(120, T), T + 1, (b,), generator=g, device=device, dtype=torch.int32)
             labels = torch.zeros((b, NUM_CLASSES), dtype=torch.uint8, device=device)
             labels.scatter_(1, torch.randint(0, NUM_CLASSES, (b, 3), generator=g, device=device), 1)
-            yield q, labels, n
+            yield q, labels, n, n.cpu().numpy()
 
 
 def get_reader():
@@ -103,7 +104,8 @@ def get_input_data(data_pattern, batch_size, feature_size, device, num_epochs, s
         return synthetic_batches(batch_size, feature_size, device, FLAGS.synthetic_videos, num_epochs, seed), None
     logging.info("Using batch size of %d for training.", batch_size)
     pipe = readers.get_input_data_tensors(get_reader(), data_pattern, batch_size=batch_size, num_epochs=num_epochs,
-                                          num_readers=FLAGS.num_readers, seed=seed, device=device, rank=rank, world_size=world)
+                                          num_readers=FLAGS.num_readers, seed=seed, device=device, rank=rank, world_size=world,
+                                          with_host_counts=True)
     logging.info("Number of training files / records on this rank: %d / %d.", len(pipe.index), pipe.num_records)
     return (b[1:] for b in pipe), pipe.num_batches
 
@@ -203,9 +205,9 @@ def main(argv=None):
     logging.info("%s: Entering training loop.", task)
     start, last_save, it = time.time(), time.time(), 0
     is_distill = isinstance(graph, DistillGraph)
-    for q, labels, n in data:
+    for q, labels, n, n_host in data:
         t0 = time.time()
-        out = graph.step(q, labels, n) if is_distill else graph.step(dequantize_masked(q, n), labels, n)
+        out = graph.step(q, labels, n, num_frames_host=n_host) if is_distill else graph.step(dequantize_masked(q, n), labels, n)
         it += 1
         if rank == 0 and it % max(1, FLAGS.log_every) == 0:
             pred = out.get("predictions", out.get("student_predictions"))

@@ -34,7 +34,8 @@ def get_input_evaluation_tensors(reader, data_pattern, batch_size=1024, num_read
     """cs/validate.py:70-104."""
     logging.info("Using batch size of " + str(batch_size) + " for evaluation.")
     try:
-        pipe = readers.get_input_evaluation_tensors(reader, data_pattern, batch_size=batch_size, num_readers=num_readers, device=device)
+        pipe = readers.get_input_evaluation_tensors(reader, data_pattern, batch_size=batch_size, num_readers=num_readers, device=device,
+                                                    with_host_counts=True)
     except IOError as e:
         if "Unable to find" in str(e):
             raise IOError("Unable to find the evaluation files.")
@@ -55,8 +56,8 @@ def build_graph(reader, model, batch_size, device, student_only=False):
 
 def _batches(reader, device):
     if FLAGS.eval_data_pattern == "synthetic":
-        for i, (q, y, n) in enumerate(synthetic_batches(FLAGS.batch_size, sum(reader.feature_sizes), device, FLAGS.synthetic_videos, 1, 4321)):
-            yield ["syn%06d" % (i * FLAGS.batch_size + j) for j in range(q.shape[0])], q, y, n
+        for i, (q, y, n, nh) in enumerate(synthetic_batches(FLAGS.batch_size, sum(reader.feature_sizes), device, FLAGS.synthetic_videos, 1, 4321)):
+            yield ["syn%06d" % (i * FLAGS.batch_size + j) for j in range(q.shape[0])], q, y, n, nh
     else:
         for b in get_input_evaluation_tensors(reader, FLAGS.eval_data_pattern, FLAGS.batch_size, FLAGS.num_readers, device):
             yield b
@@ -79,9 +80,9 @@ def evaluation_loop(graph, reader, label_loss_fn, summary_writer, evl_metrics, l
     evl_metrics.clear()
     examples_processed, total_example_per_sec = 0, []
     fused_ce = isinstance(label_loss_fn, losses.CrossEntropyLoss)
-    for ids, q, labels, n in _batches(reader, device):
+    for ids, q, labels, n, n_host in _batches(reader, device):
         batch_start_time = time.time()
-        out = graph.step(q, labels, n)
+        out = graph.step(q, labels, n, num_frames_host=n_host)
         predictions_val = out["predictions"].cpu().numpy()              # the fetch: D2H + sync
         labels_val = labels.cpu().numpy().astype(np.float32)
         loss_val = float(out["loss"]) if fused_ce else float(label_loss_fn.calculate_loss(out["predictions"], labels))

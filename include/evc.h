@@ -59,12 +59,25 @@ int evc_check_device(int dev);
  * t >= num_frames[b] forced to zero (cs/readers.py:170-173); x_raw is ignored.
  * normalize = 0 skips the l2-normalisation (input already normalised by the
  * caller, as create_model() receives it at cs/train.py:282-284): cast + re-layout only.
+ * Row plans (evc_sort_rows_by_len): with row_pos1 != NULL the teacher image is [T/C1][rows1][F] and chunk row
+ * m goes to slot row_pos1[m]; rows whose slot is >= rows1 (length-0 rows) are neither read nor written.
+ * row_pos2 / rows2: the same for the student image.
  */
 int evc_l2norm_chunk_fwd(const float* x_raw, const uint8_t* x_u8, const int32_t* num_frames,
                          int B, int T, int F,
                          int C1, evc_bf16* out1,
                          int every_n, int C2, evc_bf16* out2, int normalize,
-                         evc_bf16* out1_lo, evc_bf16* out2_lo /* split-bf16 low halves or NULL */, void* stream);
+                         evc_bf16* out1_lo, evc_bf16* out2_lo /* split-bf16 low halves or NULL */,
+                         const int32_t* row_pos1, int rows1, const int32_t* row_pos2, int rows2, void* stream);
+
+/* Row plan of an LSTM stack: stable counting sort of its M rows by sequence length, longest first
+ * (0 <= len <= max_len <= 63, M <= 65535).  pos[m] = slot of row m, inv[slot] = row, len_sorted[slot] =
+ * len[inv[slot]].  In slot order the rows active at step t are the prefix [0, #{len > t}): the step kernels
+ * below take that count per step (rows_per_step, a HOST array the caller derives from the same lengths) and
+ * never touch the padding rows that tf.nn.dynamic_rnn masks (cs/frame_level_models.py:232-235: ~28% of the
+ * chunk rows of a YouTube-8M batch have length 0). */
+int evc_sort_rows_by_len(const int32_t* len, int M, int max_len, int32_t* pos, int32_t* inv, int32_t* len_sorted,
+                         void* stream);
 
 /* a2 (integer part, bit-exact): num_frames_student = int64(float64(n)/300*S)
  * cs/train.py:263-264; and the per-chunk L1 lengths / L2 length of
@@ -113,11 +126,15 @@ int evc_gemm_tn(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, 
  * Epilogue layout: the MFMA is issued with the weight fragment first, so a lane holds 4
  * consecutive units of one row and every state / tape / h access is an 8-16 byte vector access
  * (c_state, h_state, bias 16-byte aligned; ld_state % 4 == 0).
+ * Row plan (both NULL = none): rows_per_step [T] HOST int32, non-increasing: step t runs on rows
+ *        [0, rows_per_step[t]) only (rows sorted by length, len = len_sorted); row_map [M] device int32 =
+ *        the row of c_state / h_state that slot m writes (inv of evc_sort_rows_by_len).  Rows beyond
+ *        rows_per_step[0] are not touched at all: the caller zeroes their final state.
  */
 int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const float* bias, const int32_t* len,
                        int T, int M, int Kin, int H, int hoist, float* zx_ws,
                        evc_bf16* hbuf, float* c_state, float* h_state, int64_t ld_state,
-                       void* gates, float* c_all, void* stream);
+                       void* gates, float* c_all, const int32_t* row_map, const int32_t* rows_per_step, void* stream);
 
 /* "High" precision variant of evc_lstm_layer_fwd: every bf16 operand comes as hi + lo halves
  * (evc_cast_f32_to_bf16_split / evc_l2norm_chunk_fwd's lo outputs) and the step issues
@@ -127,7 +144,7 @@ int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const float* bias,
 int evc_lstm_layer_fwd_hp(const evc_bf16* x, const evc_bf16* x_lo, const evc_bf16* wT, const evc_bf16* wT_lo,
                           const float* bias, const int32_t* len, int T, int M, int Kin, int H,
                           evc_bf16* hbuf, evc_bf16* hbuf_lo, float* c_state, float* h_state, int64_t ld_state,
-                          void* gates, float* c_all, void* stream);
+                          void* gates, float* c_all, const int32_t* row_map, const int32_t* rows_per_step, void* stream);
 
 /* BPTT of the above (what tf.gradients builds inside
  * slim.learning.create_train_op, cs/train.py:329-334,413-418).
@@ -140,10 +157,14 @@ int evc_lstm_layer_fwd_hp(const evc_bf16* x, const evc_bf16* x_lo, const evc_bf1
  *        t >= len); viewed as [T*M][4H] it is the A operand of dz . W^T with w_il.
  *        (evc_transpose_to_bf16(dz4, ..., interleave_H=-H) gives dz^T in TF gate order for the
  *        weight-gradient GEMM; writing it from this kernel's epilogue was measured 2.4x slower.)
+ * Row plan (see evc_lstm_layer_fwd): rows_per_step [T] host counts, row_map = the row of dS_c / dS_h of each
+ *        slot.  Every dz4 row is still written (zeros beyond the active prefix), because the
+ *        weight-gradient products contract over all T*M rows.
  */
 int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int T, int M, int Kin, int H,
                        const void* gates, const float* c_all, const float* dS_c, const float* dS_h, int64_t ld_dS,
-                       const float* dh_above, float* dc_ws, evc_bf16* dz4, void* stream);
+                       const float* dh_above, float* dc_ws, evc_bf16* dz4,
+                       const int32_t* row_map, const int32_t* rows_per_step, void* stream);
 
 /* ---- layout helpers --------------------------------------------------------
  * out[c][r] = in[r][c], r < R, c < C; out has ld_out >= Rpad columns and

@@ -289,3 +289,99 @@ def test_gemm_tn_and_colsum(ops, M, N, K, il):
     if il:
         cref = cref.reshape(M // 4, 4).T.reshape(M)
     assert np.max(np.abs(cs.cpu().double().numpy() - cref)) < 1e-3 * (np.abs(A).sum(0).max() + 1)
+
+
+@pytest.mark.parametrize("M,T", [(40, 15), (5120, 15), (1280, 6), (7000, 31)])
+def test_sort_rows_and_host_counts(ops, M, T):
+    """evc_sort_rows_by_len = numpy's stable argsort by descending length (integer work: exact)."""
+    rng = np.random.default_rng(M + T)
+    lens = rng.integers(0, T + 1, size=M).astype(np.int32)
+    lens[rng.random(M) < 0.3] = 0
+    ld = torch.from_numpy(lens).to(DEV)
+    plan = ops.RowPlan(ld, lens, T)
+    inv_ref = np.argsort(-lens.astype(np.int64), kind="stable")
+    assert np.array_equal(plan.inv.cpu().numpy(), inv_ref)
+    pos = plan.pos.cpu().numpy()
+    assert np.array_equal(pos[inv_ref], np.arange(M)) and np.array_equal(plan.lens.cpu().numpy(), lens[inv_ref])
+    assert plan.rows == [int((lens > t).sum()) for t in range(T)]
+    assert plan.P == min(M, max(32, (plan.rows[0] + 31) // 32 * 32))
+    # host twin of the frame-count kernel (bit-exact)
+    n = rng.integers(0, 301, size=64).astype(np.int32)
+    for every_n, C, Lc in ((1, 20, 15), (10, 5, 6), (6, 5, 10), (3, 5, 20)):
+        got = ops.frame_counts(torch.from_numpy(n).to(DEV), every_n, C, Lc)
+        ref = ops.host_frame_counts(n, every_n, C, Lc)
+        for g, r in zip(got, ref):
+            assert np.array_equal(g.cpu().numpy(), r)
+
+
+def test_l2norm_chunk_with_row_plans(ops):
+    B, T, F = 6, 300, 1152
+    q, x, n, _ = mm.synthetic_batch(B, seed=8, dtype=np.float32)
+    n[0], n[1] = 300, 7
+    qd, nd = torch.from_numpy(q).to(DEV), torch.from_numpy(n).to(DEV)
+    _, l1, _ = ops.frame_counts(nd, 1, 20, 15)
+    _, l1s, _ = ops.frame_counts(nd, 10, 5, 6)
+    p1 = ops.RowPlan(l1, ops.host_frame_counts(n, 1, 20, 15)[1], 15)
+    p2 = ops.RowPlan(l1s, ops.host_frame_counts(n, 10, 5, 6)[1], 6)
+    assert p1.P < 20 * B and p1.P % 32 == 0
+    r1, r2 = ops.l2norm_chunk(qd, 20, 10, 5, num_frames=nd)                        # plain layout
+    o1, o2 = ops.l2norm_chunk(qd, 20, 10, 5, num_frames=nd, plan1=p1, plan2=p2)   # slot layout
+    assert o1.shape == (15, p1.P, F) and o2.shape == (6, p2.P, F)
+    inv1, inv2 = p1.inv.cpu().numpy(), p2.inv.cpu().numpy()
+    live1, live2 = p1.rows[0], p2.rows[0]
+    assert torch.equal(o1[:, :live1], r1[:, torch.from_numpy(inv1[:live1]).to(DEV).long()])
+    assert torch.equal(o2[:, :live2], r2[:, torch.from_numpy(inv2[:live2]).to(DEV).long()])
+    assert bool((r1[:, torch.from_numpy(inv1[live1:]).to(DEV).long()] == 0).all())     # what was dropped is all padding
+
+
+@pytest.mark.parametrize("M,T,Kin,H", [(640, 5, 64, 128), (5120, 4, 128, 128), (200, 6, 64, 64)])
+def test_lstm_layer_with_row_plan_matches_plain(ops, M, T, Kin, H):
+    """Forward + BPTT on length-sorted rows (padding rows skipped) give the plain-layout results."""
+    rng = np.random.default_rng(M + T)
+    lens = rng.integers(0, T + 1, size=M).astype(np.int32)
+    lens[rng.random(M) < 0.3] = 0
+    lens[:2] = [T, 0]
+    x = to_bf16(rng.standard_normal((T, M, Kin)) * 0.5)
+    wT = to_bf16(mm.glorot_uniform(rng, (4 * H, Kin + H)) * 2.0)
+    w_il = torch.empty((Kin + H, 4 * H), dtype=torch.bfloat16, device=DEV)
+    ops.transpose_to_bf16(wT, 4 * H, Kin + H, w_il, 4 * H, interleave_H=H)
+    b = torch.from_numpy((rng.standard_normal(4 * H) * 0.1).astype(np.float32)).to(DEV)
+    ln = torch.from_numpy(lens).to(DEV)
+    dS = torch.from_numpy(rng.standard_normal((M, 2 * H)).astype(np.float32)).to(DEV)
+    dha = torch.from_numpy((rng.standard_normal((T, M, H)) * 0.3).astype(np.float32)).to(DEV)
+
+    def run(plan):
+        P = plan.P if plan is not None else M
+        if plan is not None:
+            idx = plan.inv[:P].long()
+            xs, dh, lens_d = x[:, idx].contiguous(), dha[:, idx].contiguous(), plan.lens
+        else:
+            xs, dh, lens_d = x, dha, ln
+        hbuf = torch.zeros((T + 1, P, H), dtype=torch.bfloat16, device=DEV)
+        S = torch.zeros((M, 2 * H), dtype=torch.float32, device=DEV)
+        gates = torch.empty((T, P, H, 2), dtype=torch.int32, device=DEV)
+        c_all = torch.full((T + 1, P, H), float("nan"), dtype=torch.float32, device=DEV)
+        ops.lstm_layer_fwd(xs, wT, b, lens_d, T, P, Kin, H, hbuf, S[:, :H], S[:, H:], 2 * H, gates, c_all, plan=plan)
+        dz4 = torch.full((T, P, 4 * H), float("nan"), dtype=torch.bfloat16, device=DEV)
+        dcw = torch.empty((P, H), dtype=torch.float32, device=DEV)
+        ops.lstm_layer_bwd(w_il, lens_d, T, P, Kin, H, gates, c_all, dS[:, :H], dS[:, H:], 2 * H, dh, dcw, dz4, plan=plan)
+        assert bool(torch.isfinite(dz4.float()).all())
+        dW = torch.empty((4 * H, Kin), dtype=torch.float32, device=DEV)
+        if (T * P) % 32 == 0:
+            ops.gemm_tn(dz4.view(T * P, 4 * H), xs.reshape(T * P, Kin), 4 * H, Kin, T * P, dW, row_interleave_H=H)
+        return S, hbuf, dz4, dW
+
+    S0, h0, dz0, dW0 = run(None)
+    plan = ops.RowPlan(ln, lens, T)
+    S1, h1, dz1, dW1 = run(plan)
+    assert torch.equal(S0, S1)                                  # same per-row arithmetic, original row order
+    live = plan.rows[0]
+    idx = plan.inv[:live].long()
+    for t in range(T):
+        rt = plan.rows[t]
+        assert torch.equal(h1[t + 1, :rt], h0[t + 1, idx[:rt]])
+        assert torch.equal(dz1[t, :rt], dz0[t, idx[:rt]])
+        assert bool((dz1[t, rt:] == 0).all())                   # every dz row is written: zeros beyond the active prefix
+    if (T * plan.P) % 32 == 0 and (T * M) % 32 == 0:
+        sc = dW0.abs().max().item() + 1e-6
+        assert (dW0 - dW1).abs().max().item() / sc < 1e-5      # same products, different summation order
