@@ -109,6 +109,7 @@ typedef TileCfg<128, 1, 128, 2, 2> CfgPlainBig;   // 128x128, 4 waves, 4x4 MFMA 
 typedef TileCfg<64, 1, 64, 2, 2> CfgPlainSmall;   // 64x64 for skinny problems
 typedef TileCfg<32, 1, 32, 2, 2> CfgPlainTiny;    // 32x32: M ~ batch recurrent steps (256 workgroups at M=256, H=1024)
 typedef TileCfg2<256, 1, 256, 2, 4, 5, true> CfgPlainV2;   // 256x256, 8 waves (2x4), 128x64 per wave, 5-deep ring (160 KiB)
+typedef TileCfg2<256, 1, 64, 2, 4, 5, true> CfgTallV2;     // 256x64: M <= 256 (batch-row) products against a long weight matrix
 
 template <class Cfg>
 static inline void launch_gemm(GemmOperands p, StoreParams s, int K, int splits, hipStream_t st) {
@@ -132,6 +133,19 @@ extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
   p.A1lo = p.A2lo = p.Blo = nullptr;
   StoreParams s{C, ldc, M, N, bias, out_bf16, accumulate, 1, 0};
   hipStream_t st = (hipStream_t)stream;
+  // M <= 256 (one row tile: the MoE head on a batch of videos, [B, K] x [N, K]^T with N or K ~ 14k): the product
+  // streams the weight matrix once from HBM, so it wants ~256 workgroups pulling at the same time and a deep
+  // load pipeline rather than a square tile: 256x64 tiles, K split until ~256 workgroups exist.
+  if (M <= 256 && N >= 1024 && K >= 1024 && forced_tile() == 0) {
+    const int tn = ceil_div(N, 64);
+    int splits = out_bf16 ? 1 : 256 / tn;
+    if (splits > K / 1024) splits = K / 1024;
+    if (splits < 1) splits = 1;
+    if (splits > 1 && !accumulate) EVC_CHECK_HIP(hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st));
+    launch_gemm<CfgTallV2>(p, s, K, splits, st);
+    EVC_LAUNCH_CHECK();
+    return EVC_OK;
+  }
   // Split-K: a long-K product with too few 256x256 tiles to fill the 256 CUs (the weight-gradient
   // GEMMs: M=4H, N~1-2K, K = T*M rows) is cut along K; partial tiles are summed with f32 atomics
   // into a zeroed C (63 MB of atomic traffic at ~1.3 TB/s << the ~0.7 ms it saves per GEMM).
@@ -220,7 +234,7 @@ extern "C" int evc_gemm_tn(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
   GemmOperandsT p{A, lda, B, ldb, M, N, K / 32};
   const int tm = ceil_div(M, CfgPlainV2::BM), tn = ceil_div(N, CfgPlainV2::BU);
   int splits = 256 / (tm * tn);
-  if (splits > K / 2048) splits = K / 2048;     // keep >= 64 K steps per split
+  if (splits > K / 2048) splits = K / 2048;     // keep >= 64 K steps per split (K/1024 measured no faster)
   if (splits < 1) splits = 1;
   StoreParamsT s{C, ldc, M, N, row_interleave_H, accumulate, splits, ceil_div(p.nk, splits)};
   if (splits > 1 && !accumulate) EVC_CHECK_HIP(hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st));
@@ -495,6 +509,70 @@ struct LstmBwdParams {
   int M, H;
 };
 
+// Gate derivative of one (row, 4 consecutive units): dh[4] = what flowed back through the recurrent
+// product; writes dz (4 x 8 bytes), carries dc in dc_ws.
+__device__ __forceinline__ void lstm_bwd_tail(const LstmBwdParams& e, const int m, const int u, const float (&dh_in)[4]) {
+  const int H = e.H;
+  const int ln = e.len[m];
+  const long hu = (long)m * H + u;
+  uint4* dzp = (uint4*)(e.dz4 + hu);            // 4 units x 8 bytes = 2 x 16 bytes
+  if (e.t >= ln) {  // inactive: state passes through, no gate gradient
+    dzp[0] = make_uint4(0u, 0u, 0u, 0u);
+    dzp[1] = make_uint4(0u, 0u, 0u, 0u);
+    return;
+  }
+  const bool last = (e.t == ln - 1);
+  float dh[4] = {dh_in[0], dh_in[1], dh_in[2], dh_in[3]};
+  float4 dcv;
+  if (last) {
+    const long su = (long)(e.row_map ? e.row_map[m] : m) * e.ld_dS + u;
+    const float4 hv = *(const float4*)(e.dS_h + su);   // nothing flows back from later (inactive) steps
+    dh[0] = hv.x; dh[1] = hv.y; dh[2] = hv.z; dh[3] = hv.w;
+    dcv = *(const float4*)(e.dS_c + su);
+  } else {
+    dcv = *(const float4*)(e.dc_ws + hu);
+  }
+  if (e.dh_above) {
+    const float4 a = *(const float4*)(e.dh_above + hu);
+    dh[0] += a.x; dh[1] += a.y; dh[2] += a.z; dh[3] += a.w;
+  }
+  const float dci[4] = {dcv.x, dcv.y, dcv.z, dcv.w};
+  const uint4* gp = (const uint4*)(e.gates + hu);
+  const uint4 g01 = gp[0], g23 = gp[1];
+  const uint2 recs[4] = {make_uint2(g01.x, g01.y), make_uint2(g01.z, g01.w), make_uint2(g23.x, g23.y), make_uint2(g23.z, g23.w)};
+  const float4 cnv = *(const float4*)(e.c_new + hu);
+  float4 cov = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e.c_old) cov = *(const float4*)(e.c_old + hu);
+  const float cna[4] = {cnv.x, cnv.y, cnv.z, cnv.w}, coa[4] = {cov.x, cov.y, cov.z, cov.w};
+  float dcn[4];
+  uint2 dzr[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const uint2 rec = recs[r];
+    const float gi = __uint_as_float(rec.x << 16), gj = __uint_as_float(rec.x & 0xffff0000u);
+    const float gf = __uint_as_float(rec.y << 16), go = __uint_as_float(rec.y & 0xffff0000u);
+    const float tcv = tanhf_(cna[r]);
+    const float cp = coa[r];
+    const float dc = dci[r] + dh[r] * go * (1.f - tcv * tcv);
+    dcn[r] = dc * gf;
+    dzr[r] = make_uint2(pack_bf16x2(dc * gj * gi * (1.f - gi), dc * gi * (1.f - gj * gj)),
+                        pack_bf16x2(dc * cp * gf * (1.f - gf), dh[r] * tcv * go * (1.f - go)));
+  }
+  *(float4*)(e.dc_ws + hu) = make_float4(dcn[0], dcn[1], dcn[2], dcn[3]);
+  dzp[0] = make_uint4(dzr[0].x, dzr[0].y, dzr[1].x, dzr[1].y);
+  dzp[1] = make_uint4(dzr[2].x, dzr[2].y, dzr[3].x, dzr[3].y);
+}
+
+// tiles entirely beyond the active prefix (row plan): dz = 0, no GEMM
+template <int BM, int BU, int NT>
+__device__ __forceinline__ void lstm_bwd_zero_tile(const LstmBwdParams& e, int m0, int u0) {
+  const int cols = min(BU, e.H - u0) / 2;                  // 16-byte pieces (2 units) per row
+  for (int i = threadIdx.x; i < BM * cols; i += NT) {
+    const int m = m0 + i / cols, u = u0 + (i % cols) * 2;
+    if (m < e.M) *(uint4*)(e.dz4 + (long)m * e.H + u) = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::NT) void lstm_bwd_step_kernel(GemmOperands p, LstmBwdParams e, int tiles_m, int tiles_n) {
   static_assert(Cfg::G == 1, "bwd step is a plain GEMM over the H units");
@@ -503,13 +581,8 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_bwd_step_kernel(GemmOperands p, 
   int tm, tn;
   tile_of(id, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * Cfg::BM, u0 = tn * Cfg::BU;
-  const int H = e.H;
-  if (m0 >= e.m_active) {     // no active row in this tile (row plan: active rows are a prefix): dz = 0, no GEMM
-    const int cols = min(Cfg::BU, H - u0) / 2;                  // 16-byte pieces (2 units) per row
-    for (int i = threadIdx.x; i < Cfg::BM * cols; i += Cfg::NT) {
-      const int m = m0 + i / cols, u = u0 + (i % cols) * 2;
-      if (m < e.M) *(uint4*)(e.dz4 + (long)m * H + u) = make_uint4(0u, 0u, 0u, 0u);
-    }
+  if (m0 >= e.m_active) {
+    lstm_bwd_zero_tile<Cfg::BM, Cfg::BU, Cfg::NT>(e, m0, u0);
     return;
   }
   f32x4 acc[Cfg::MI][1][Cfg::NI];
@@ -518,59 +591,109 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_bwd_step_kernel(GemmOperands p, 
 #pragma unroll
   for (int ni = 0; ni < Cfg::NI; ++ni) {
     const int u = u0 + tc.unit0 + ni * 16;
-    if (u >= H) continue;
+    if (u >= e.H) continue;
 #pragma unroll
     for (int mi = 0; mi < Cfg::MI; ++mi) {
       const int m = m0 + tc.row0 + mi * 16;
       if (m >= e.M) continue;
-      const int ln = e.len[m];
-      const long hu = (long)m * H + u;
-      uint4* dzp = (uint4*)(e.dz4 + hu);            // 4 units x 8 bytes = 2 x 16 bytes
-      if (e.t >= ln) {  // inactive: state passes through, no gate gradient
-        dzp[0] = make_uint4(0u, 0u, 0u, 0u);
-        dzp[1] = make_uint4(0u, 0u, 0u, 0u);
-        continue;
-      }
-      const bool last = (e.t == ln - 1);
-      float dh[4] = {acc[mi][0][ni][0], acc[mi][0][ni][1], acc[mi][0][ni][2], acc[mi][0][ni][3]};
-      float4 dcv;
-      if (last) {
-        const long su = (long)(e.row_map ? e.row_map[m] : m) * e.ld_dS + u;
-        const float4 hv = *(const float4*)(e.dS_h + su);   // nothing flows back from later (inactive) steps
-        dh[0] = hv.x; dh[1] = hv.y; dh[2] = hv.z; dh[3] = hv.w;
-        dcv = *(const float4*)(e.dS_c + su);
-      } else {
-        dcv = *(const float4*)(e.dc_ws + hu);
-      }
-      if (e.dh_above) {
-        const float4 a = *(const float4*)(e.dh_above + hu);
-        dh[0] += a.x; dh[1] += a.y; dh[2] += a.z; dh[3] += a.w;
-      }
-      const float dci[4] = {dcv.x, dcv.y, dcv.z, dcv.w};
-      const uint4* gp = (const uint4*)(e.gates + hu);
-      const uint4 g01 = gp[0], g23 = gp[1];
-      const uint2 recs[4] = {make_uint2(g01.x, g01.y), make_uint2(g01.z, g01.w), make_uint2(g23.x, g23.y), make_uint2(g23.z, g23.w)};
-      const float4 cnv = *(const float4*)(e.c_new + hu);
-      float4 cov = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e.c_old) cov = *(const float4*)(e.c_old + hu);
-      const float cna[4] = {cnv.x, cnv.y, cnv.z, cnv.w}, coa[4] = {cov.x, cov.y, cov.z, cov.w};
-      float dcn[4];
-      uint2 dzr[4];
+      const float dh[4] = {acc[mi][0][ni][0], acc[mi][0][ni][1], acc[mi][0][ni][2], acc[mi][0][ni][3]};
+      lstm_bwd_tail(e, m, u, dh);
+    }
+  }
+}
+
+// "Skinny" BPTT step for M ~ batch (the L2 stacks: 256 rows, K = 4H = 4096): with a 32x32 tile per
+// workgroup the LDS-staged loops above are latency-bound (64 dependent load->barrier->MFMA rounds, ~30 us
+// for 2 GFLOP).  Here the K range is split over the KW waves of the workgroup and every wave loads its MFMA
+// fragments STRAIGHT from global memory into registers (for v_mfma_f32_16x16x32_bf16 lane l supplies row
+// l&15, k = 8*(l>>4)..+7 = one aligned 16-byte load): no LDS staging, no barrier in the loop, DEPTH K steps
+// of loads in flight per wave.  The KW partial 32x32 tiles meet in LDS once, then 256 threads run the tail.
+template <int KW, int DEPTH>
+__global__ __launch_bounds__(64 * KW) void lstm_bwd_step_skinny_kernel(GemmOperands p, LstmBwdParams e, int tiles_m, int tiles_n) {
+  constexpr int NT = 64 * KW;
+  __shared__ float part[KW][32][36];                 // [wave][row][unit] (+4 pad: conflict-free float4 rows)
+  const int nwg = tiles_m * tiles_n;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int tm = id % tiles_m, tn = id / tiles_m;    // consecutive ids (one XCD) share the B panel of a unit tile
+  const int m0 = tm * 32, u0 = tn * 32;
+  if (m0 >= e.m_active) {
+    lstm_bwd_zero_tile<32, 32, NT>(e, m0, u0);
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int nk = p.nk1;                              // 32-wide K steps
+  const int per = (nk + KW - 1) / KW;
+  const int k0 = min(wave * per, max(nk - 1, 0)), k1 = min(nk, wave * per + per);   // k0 clamped: idle waves still load in bounds
+  const bf16_t* ap[2];
+  const bf16_t* bp[2];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const uint2 rec = recs[r];
-        const float gi = __uint_as_float(rec.x << 16), gj = __uint_as_float(rec.x & 0xffff0000u);
-        const float gf = __uint_as_float(rec.y << 16), go = __uint_as_float(rec.y & 0xffff0000u);
-        const float tcv = tanhf_(cna[r]);
-        const float cp = coa[r];
-        const float dc = dci[r] + dh[r] * go * (1.f - tcv * tcv);
-        dcn[r] = dc * gf;
-        dzr[r] = make_uint2(pack_bf16x2(dc * gj * gi * (1.f - gi), dc * gi * (1.f - gj * gj)),
-                            pack_bf16x2(dc * cp * gf * (1.f - gf), dh[r] * tcv * go * (1.f - go)));
+  for (int i = 0; i < 2; ++i) {
+    const int m = min(m0 + i * 16 + fr, p.M - 1), u = min(u0 + i * 16 + fr, p.Nu - 1);
+    ap[i] = p.A1 + (long)m * p.lda1 + fq * 8 + (long)k0 * 32;
+    bp[i] = p.B + (long)u * p.ldb + fq * 8 + (long)k0 * 32;
+  }
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 fa[DEPTH][2], fb[DEPTH][2];
+  const int n = k1 - k0;                             // this wave's K steps (wave-uniform, may be <= 0)
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) {
+    const int kk = min(d, max(n - 1, 0));            // clamped: surplus loads re-read a valid step
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      fa[d][i] = *(const bf16x8*)(ap[i] + (long)kk * 32);
+      fb[d][i] = *(const bf16x8*)(bp[i] + (long)kk * 32);
+    }
+  }
+  for (int k = 0; k < n; k += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      if (k + d < n) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[d][i], fb[d][j], acc[i][j], 0, 0, 0);
       }
-      *(float4*)(e.dc_ws + hu) = make_float4(dcn[0], dcn[1], dcn[2], dcn[3]);
-      dzp[0] = make_uint4(dzr[0].x, dzr[0].y, dzr[1].x, dzr[1].y);
-      dzp[1] = make_uint4(dzr[2].x, dzr[2].y, dzr[3].x, dzr[3].y);
+#ifndef EVC_ABLATE_SKINNY_LOADS
+      const int kn = min(k + d + DEPTH, max(n - 1, 0));
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[d][i] = *(const bf16x8*)(ap[i] + (long)kn * 32);
+        fb[d][i] = *(const bf16x8*)(bp[i] + (long)kn * 32);
+      }
+#endif
+    }
+  }
+  // acc[i][j][r]: row = i*16 + fq*4 + r (A row), unit = j*16 + fr (B row)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[wave][i * 16 + fq * 4 + r][j * 16 + fr] = acc[i][j][r];
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    const int row = threadIdx.x >> 3, ug = (threadIdx.x & 7) * 4;
+    float4 s = *(const float4*)&part[0][row][ug];
+#pragma unroll
+    for (int w = 1; w < KW; ++w) {
+      const float4 v = *(const float4*)&part[w][row][ug];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const int m = m0 + row, u = u0 + ug;
+    if (m < e.M && u < e.H) {
+      const float dh[4] = {s.x, s.y, s.z, s.w};
+#ifdef EVC_ABLATE_SKINNY_TAIL
+      *(float4*)(e.dc_ws + (long)m * e.H + u) = s;
+#else
+      lstm_bwd_tail(e, m, u, dh);
+#endif
     }
   }
 }
@@ -614,7 +737,8 @@ extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int 
       const double c = tile_cost((long)ceil_div(ma, bm[i]) * ceil_div(H, bn[i]), bm[i], bn[i], 1, cf[i]);
       if (c < bc) { bc = c; pick = i; }
     }
-    if (forced_tile()) pick = forced_tile() - 1;          // debug: 1 -> 192, 2 -> 160, 3 -> 128, 4 -> v1 64, 5 -> v1 32
+    if ((long)ceil_div(ma, 32) * ceil_div(H, 32) <= 512) pick = 5;   // M ~ batch: K split over the waves, fragments straight from global
+    if (forced_tile()) pick = forced_tile() - 1;          // debug: 1 -> 192, 2 -> 160, 3 -> 128, 4 -> v1 64, 5 -> v1 32, 6 -> skinny
     GemmOperands p;
     p.M = M; p.Nu = H; p.group_stride = 0; p.nk1 = p.nk2 = 0;
     p.A1lo = p.A2lo = p.Blo = nullptr;
@@ -637,6 +761,12 @@ extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int 
       case 1: launch_lstm_bwd<CfgBwdV2_160>(p, e, k1, st); break;
       case 2: launch_lstm_bwd<CfgBwdV2_128>(p, e, k1, st); break;
       case 4: launch_lstm_bwd<CfgPlainTiny>(p, e, k1, st); break;
+      case 5: {
+        p.nk1 = k1 / 32;
+        const int tm = ceil_div(M, 32), tn = ceil_div(H, 32);
+        hipLaunchKernelGGL((lstm_bwd_step_skinny_kernel<8, 4>), dim3(tm * tn), dim3(512), 0, st, p, e, tm, tn);
+        break;
+      }
       default: launch_lstm_bwd<CfgPlainSmall>(p, e, k1, st); break;
     }
   }

@@ -182,12 +182,14 @@ __device__ __forceinline__ void gemm_mainloop_v2(const GemmOperands& p, const in
                                            // being read and the slot whose reads may still be pending)
   auto wait_landed = [&](int outstanding_stages) {   // wave-uniform small switch; only the tail leaves the first arm
     if (outstanding_stages >= AHEAD) wait_vmcnt<AHEAD * Cfg::PER>();
+    else if (outstanding_stages == 5) wait_vmcnt<5 * Cfg::PER>();
+    else if (outstanding_stages == 4) wait_vmcnt<4 * Cfg::PER>();
     else if (outstanding_stages == 3) wait_vmcnt<3 * Cfg::PER>();
     else if (outstanding_stages == 2) wait_vmcnt<2 * Cfg::PER>();
     else if (outstanding_stages == 1) wait_vmcnt<Cfg::PER>();
     else wait_vmcnt<0>();
   };
-  static_assert(AHEAD >= 1 && AHEAD <= 4, "ring depth 3..6");
+  static_assert(AHEAD >= 1 && AHEAD <= 6, "ring depth 3..8");
 
   // ---- prologue: STAGES-1 K steps in flight ----
 #pragma unroll

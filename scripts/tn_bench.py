@@ -1,0 +1,27 @@
+"""TN GEMM (weight-gradient shapes) timings."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from efficientvideoclassification_youtube8m_amd import ops  # noqa: E402
+
+dev = "cuda:0"
+shapes = [(4096, 1152, 56640), (4096, 1024, 56640), (4096, 4096, 5120), (4096, 1024, 5120), (4096, 1152, 6144), (4096, 1024, 6144),
+          (4096, 4096, 1280), (4096, 1024, 1280), (4096, 1152, 76800), (4096, 2176, 56640)]
+for M, N, K in shapes:
+    A = (torch.randn(K, M, device=dev) * 0.1).to(torch.bfloat16)
+    B = (torch.randn(K, N, device=dev) * 0.1).to(torch.bfloat16)
+    C = torch.empty(M, N, device=dev)
+    for _ in range(2):
+        ops.gemm_tn(A, B, M, N, K, C)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        ops.gemm_tn(A, B, M, N, K, C)
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    print("TN M=%d N=%d K=%d: %.1f us  %.0f TF/s" % (M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9))

@@ -380,8 +380,10 @@ def test_lstm_layer_with_row_plan_matches_plain(ops, M, T, Kin, H):
     for t in range(T):
         rt = plan.rows[t]
         assert torch.equal(h1[t + 1, :rt], h0[t + 1, idx[:rt]])
-        assert torch.equal(dz1[t, :rt], dz0[t, idx[:rt]])
+        # the BPTT tile (and with it the K summation order) may differ between the two row counts: 1 bf16 ulp
+        a, b = dz1[t, :rt].float(), dz0[t, idx[:rt]].float()
+        assert (a - b).abs().max().item() <= 2.0 ** -7 * b.abs().max().item() + 1e-12
         assert bool((dz1[t, rt:] == 0).all())                   # every dz row is written: zeros beyond the active prefix
     if (T * plan.P) % 32 == 0 and (T * M) % 32 == 0:
         sc = dW0.abs().max().item() + 1e-6
-        assert (dW0 - dW1).abs().max().item() / sc < 1e-5      # same products, different summation order
+        assert (dW0 - dW1).abs().max().item() / sc < 1e-3      # dz within one bf16 ulp, different summation order
