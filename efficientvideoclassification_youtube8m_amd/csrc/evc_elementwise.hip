@@ -1002,7 +1002,15 @@ extern "C" int evc_framepool_max_bwd(const float* dpooled, const int32_t* argmax
 }
 
 __global__ void fill_kernel(float* p, long n, float v) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+  const long stride = (long)gridDim.x * blockDim.x, tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if ((((uintptr_t)p) & 15) == 0) {      // 16-byte stores over the aligned body, scalar tail
+    const long n4 = n >> 2;
+    const float4 v4 = make_float4(v, v, v, v);
+    for (long i = tid; i < n4; i += stride) ((float4*)p)[i] = v4;
+    for (long i = (n4 << 2) + tid; i < n; i += stride) p[i] = v;
+  } else {
+    for (long i = tid; i < n; i += stride) p[i] = v;
+  }
 }
 extern "C" int evc_fill_f32(float* p, int64_t n, float value, void* stream) {
   EVC_REQUIRE(n > 0, EVC_ERR_BAD_SHAPE, "evc_fill_f32: n");

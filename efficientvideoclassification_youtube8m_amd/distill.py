@@ -135,7 +135,7 @@ class DistillGraph:
         if self.device.type == "cuda":
             # four streams that measurably overlap (streams.py); the step never runs on the default stream
             self._main, self._side, self._aux_t, self._aux_s = concurrent_streams(self.device, 4)
-            self._ev_fwd, self._ev_student = torch.cuda.Event(), torch.cuda.Event()
+            self._ev_fwd, self._ev_student, self._ev_in = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
 
     # ---- data-parallel gradient reduction -------------------------------------
     def _reduce_tower(self, tower, moe_first):
@@ -227,6 +227,19 @@ class DistillGraph:
         l2c = self.reg_pen * 1e-8
         self._teacher_applied = self._student_applied = False
         two_streams = self.teacher is not None and need_student and self.overlap_towers
+        side = self._side if two_streams else main
+        if need_student and two_streams:
+            # The student's forward needs only its own inputs and weights: it starts right away, next to the
+            # teacher's forward (whose L2 / MoE tail is a chain of small launches that leaves most CUs idle);
+            # only its distillation losses wait for the teacher's outputs.
+            self._ev_in.record(main)
+            side.wait_event(self._ev_in)
+            with torch.cuda.stream(side):
+                mark("student_start", side)
+                n_s, l1s, l2s, plan_s = sp
+                s_state, s_pred = self.student.forward(xs, l1s, l2s, plan_s)
+                ops.ce_loss(s_pred, labels_u8, self.losses[3:4], self._dp_s, grad_scale=sc["ce"] / B)
+                mark("student_fwd_done", side)
         if self.teacher is not None:
             l1, l2, plan_t = tp
             t_state, t_pred = self.teacher.forward(xt, l1, l2, plan_t)
@@ -235,15 +248,15 @@ class DistillGraph:
                 self._ev_fwd.record(main)
             mark("teacher_fwd_done", main)
         if need_student:
-            side = self._side if two_streams else main
             if two_streams:
                 side.wait_event(self._ev_fwd)
             with torch.cuda.stream(side):
-                mark("student_start", side)
-                n_s, l1s, l2s, plan_s = sp
-                s_state, s_pred = self.student.forward(xs, l1s, l2s, plan_s)
-                ops.ce_loss(s_pred, labels_u8, self.losses[3:4], self._dp_s, grad_scale=sc["ce"] / B)
-                mark("student_fwd_done", side)
+                if not two_streams:
+                    mark("student_start", side)
+                    n_s, l1s, l2s, plan_s = sp
+                    s_state, s_pred = self.student.forward(xs, l1s, l2s, plan_s)
+                    ops.ce_loss(s_pred, labels_u8, self.losses[3:4], self._dp_s, grad_scale=sc["ce"] / B)
+                    mark("student_fwd_done", side)
                 ds = None
                 if self.teacher is not None:
                     if self._ds_s is None or self._ds_s.shape != s_state.shape:

@@ -227,9 +227,12 @@ class LstmStack:
                 h_prev = self._hb[l][:T].reshape(T * M, H)
                 if use_tn:
                     # "TN" products straight from the row-major activations (transpose reads in the kernel);
-                    # the gate-interleaved rows of the product are stored in TF gate order
-                    ops.gemm_tn(dz2, layer_in, 4 * H, kin, T * M, gW, row_interleave_H=H, ldc=kin + H)
-                    ops.gemm_tn(dz2, h_prev, 4 * H, H, T * M, gW[:, kin:], row_interleave_H=H, ldc=kin + H)
+                    # the gate-interleaved rows of the product are stored in TF gate order.  The split-K partial
+                    # tiles are added with atomics: one contiguous fill of the whole gradient, then accumulate
+                    # (instead of a pitched 2-D memset inside each call).
+                    ops.fill_f32(gW, 0.0)
+                    ops.gemm_tn(dz2, layer_in, 4 * H, kin, T * M, gW, row_interleave_H=H, ldc=kin + H, accumulate=True)
+                    ops.gemm_tn(dz2, h_prev, 4 * H, H, T * M, gW[:, kin:], row_interleave_H=H, ldc=kin + H, accumulate=True)
                     ops.colsum_bf16(dz2, T * M, 4 * H, tw.store.g(bn), deinterleave_H=H)
                 else:   # T*M not a multiple of 32: transposed copies + NT products
                     ops.transpose_to_bf16(dz2, T * M, 4 * H, self.dzT, KP, interleave_H=-H)
@@ -402,7 +405,8 @@ class TowerBase:
         if refresh:
             for k in names:
                 if k in self.shadow_bwd:
-                    p, sb = self.store.p(k), self.shadow_bwd[k]
+                    # from the bf16 forward shadow Adam just wrote (same rounding, half the bytes of the f32 master)
+                    p, sb = self.shadow_fwd[k], self.shadow_bwd[k]
                     il = p.shape[0] // 4 if k.endswith("basic_lstm_cell/kernel") else 0
                     ops.transpose_to_bf16(p, p.shape[0], p.shape[1], sb, sb.shape[1], interleave_H=il)
 

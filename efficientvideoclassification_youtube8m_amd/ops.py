@@ -56,6 +56,12 @@ def gemm_tn(A, B, M, N, K, out, row_interleave_H=0, accumulate=False, lda=None, 
     return out
 
 
+def fill_f32(t, value):
+    """Contiguous f32 fill (one streaming kernel; hipMemset2D on a pitched view is several times slower)."""
+    assert t.dtype == F32 and t.is_contiguous()
+    _lib.call("evc_fill_f32", _p(t), t.numel(), float(value), _stream())
+
+
 def colsum_bf16(x, R, C, out, deinterleave_H=0):
     _lib.call("evc_colsum_bf16", _p(x), x.stride(0), R, C, deinterleave_H, _p(out), _stream())
     return out
