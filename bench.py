@@ -140,9 +140,10 @@ def main():
     losses = graph.loss_report()
 
     # ---- roofline of the dominant kernel: the fused LSTM forward step of the teacher's L1 ---------
-    # lstm_fwd_step_kernel<TileCfg2<320,4,64,2,4,4,false>> (30 launches per iteration, the largest
-    # FLOP share).  Live timing with events on the launch stream around each layer's 15-step launch
-    # sequence; algorithmic FLOPs = 2*M*4H*K of each step GEMM.
+    # lstm_fwd_step_kernel<TileCfg2<BM,4,64,..>> (30 launches per iteration, the largest FLOP share of the
+    # recurrent path).  Live timing with events on the launch stream around each layer's 15-step launch
+    # sequence (the row plan of the last timed batch); algorithmic FLOPs = 2*rows_t*4H*K of each step GEMM
+    # over the rows that step runs on.
     tower = graph.teacher if graph.teacher is not None else graph.student
     ms = launches = flops = 0.0
     for (m, nl, fl) in tower.l1.profile_fwd_layers(reps=3):
@@ -157,8 +158,8 @@ def main():
         mfma_busy = round(pmc["mfma"]["mfma_busy_fraction"], 4)
     except Exception:
         pass
-    roofline = {"bound": "mfma", "kernel": "lstm_fwd_step_kernel<TileCfg2<320,4,64,2,4,4,false>>" if graph.teacher is not None
-                else "lstm_fwd_step_kernel (student L1)", "achieved": round(achieved, 2),
+    roofline = {"bound": "mfma", "kernel": "lstm_fwd_step_kernel<TileCfg2<BM,4,64,2,4,..>> (teacher L1; BM = 224..320 per launch from the active rows)"
+                if graph.teacher is not None else "lstm_fwd_step_kernel (student L1)", "achieved": round(achieved, 2),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                 "traffic": traffic, "mfma_busy_pmc": mfma_busy, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": int(launches),
                 "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 2)}
