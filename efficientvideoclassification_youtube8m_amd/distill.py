@@ -85,6 +85,13 @@ class GradReducer:
         self._pending.append(torch.distributed.all_reduce(flat[lo:hi], op=torch.distributed.ReduceOp.SUM,
                                                           group=self.pg, async_op=True))
 
+    def reduce_async(self, flat, lo, hi):
+        """All-reduce of flat[lo:hi] issued after the work queued on the current stream; returns the work handle
+        (its .wait() makes the current stream - not the host - wait), or None on a single rank."""
+        if self.world == 1 or hi <= lo:
+            return None
+        return torch.distributed.all_reduce(flat[lo:hi], op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=True)
+
     def wait(self):
         for w in self._pending:
             w.wait()
@@ -265,11 +272,14 @@ class DistillGraph:
                                      grad_scale=sc["kl"], accumulate_grad=True)
                     ops.rep_loss(t_state, s_state, self.losses[1:2], self._ds_s, grad_scale=self.rep_w * sc["rep"])
                     ds = self._ds_s
-                early = (lr, self.clip, l2c) if (apply and self.overlap_towers and self.world == 1 and self._aux_s is not None) else None
+                early = (lr, self.clip, l2c) if (apply and self.overlap_towers and self._aux_s is not None) else None
+                st_s = self.student.store
                 self.student.backward(ds, self._dp_s,
-                                      on_moe_grads_ready=lambda: self._reduce_tower(self.student, True),
-                                      aux=self._aux_s if self.overlap_towers else None, early_apply=early)
-                self._reduce_tower(self.student, False)
+                                      on_moe_grads_ready=None if early else (lambda: self._reduce_tower(self.student, True)),
+                                      aux=self._aux_s if self.overlap_towers else None, early_apply=early,
+                                      reduce_fn=(lambda lo, hi: self.reducer.reduce_async(st_s.grad, lo, hi)) if early else None)
+                if not early:
+                    self._reduce_tower(self.student, False)
                 self._student_applied = early is not None
                 mark("student_done", side)
                 if two_streams:
@@ -285,11 +295,14 @@ class DistillGraph:
         if self.teacher is not None:
             # weight-gradient GEMMs and the per-group clip+Adam go to an aux stream, under the BPTT chain
             # (the tower's outputs t_state / t_pred are separate buffers, untouched by the update)
-            early = (lr, self.clip, l2c) if (apply and self.overlap_towers and self.world == 1 and self._aux_t is not None) else None
+            early = (lr, self.clip, l2c) if (apply and self.overlap_towers and self._aux_t is not None) else None
+            st_t = self.teacher.store
             self.teacher.backward(None, self._dp_t,
-                                  on_moe_grads_ready=lambda: self._reduce_tower(self.teacher, True),
-                                  aux=self._aux_t if self.overlap_towers else None, early_apply=early)
-            self._reduce_tower(self.teacher, False)
+                                  on_moe_grads_ready=None if early else (lambda: self._reduce_tower(self.teacher, True)),
+                                  aux=self._aux_t if self.overlap_towers else None, early_apply=early,
+                                  reduce_fn=(lambda lo, hi: self.reducer.reduce_async(st_t.grad, lo, hi)) if early else None)
+            if not early:
+                self._reduce_tower(self.teacher, False)
             mark("teacher_bwd_done", main)
             out.update(predictions=t_pred, teacher_state=t_state, loss=self.losses[0])
             self._teacher_applied = early is not None

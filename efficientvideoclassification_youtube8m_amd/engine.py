@@ -520,15 +520,34 @@ class HLstmTower(TowerBase):
         l1 = [k for k in self.names if k.startswith("RNN_L1/")]
         return moe, l2, l1
 
-    def backward(self, dstate, dpred, on_moe_grads_ready=None, aux=None, early_apply=None):
+    def grad_segments(self):
+        """(lo, hi) element ranges of the flat gradient buffer per variable group: (MoE, L2, L1)."""
+        st = self.store
+        l2_lo = st.offsets[next(k for k in self.names if k.startswith("RNN_L2/"))]
+        moe_lo = st.offsets[self.GATES]
+        return (moe_lo, st.total), (l2_lo, moe_lo), (0, l2_lo)
+
+    def backward(self, dstate, dpred, on_moe_grads_ready=None, aux=None, early_apply=None, reduce_fn=None):
         """dstate [B,2LH] f32 or None (gradient on the returned state), dpred [B,V] f32.
         Fills self.store.grad (every segment is overwritten).
         aux: side stream that takes the weight-gradient GEMMs (and, with early_apply =
         (lr, clip, l2_coeff), the clip+Adam of each variable group as soon as its gradients are final)
-        off the BPTT critical path; it is joined into the current stream before returning."""
+        off the BPTT critical path; it is joined into the current stream before returning.
+        reduce_fn(lo, hi) -> work handle or None: data-parallel all-reduce of a gradient segment; with
+        early_apply each group is reduced on the aux stream right after its gradients are final and updated
+        as soon as the collective has finished (the MoE segment - 2/3 of the bytes - travels under the BPTT)."""
         assert self.training
         main = torch.cuda.current_stream(self.device)
         g_moe, g_l2, g_l1 = self.param_groups()
+        seg_moe, seg_l2, seg_l1 = self.grad_segments()
+
+        def reduce_then_apply(names, seg):
+            if reduce_fn is not None:
+                h = reduce_fn(*seg)
+                if h is not None:
+                    h.wait()                                           # the aux stream waits for the collective, not the host
+            self.apply_group(names, *early_apply)
+
         dS2 = self.moe.backward(dpred, dstate)
         if on_moe_grads_ready is not None:
             on_moe_grads_ready()
@@ -538,16 +557,16 @@ class HLstmTower(TowerBase):
             ev.record(main)
             aux.wait_event(ev)
             with torch.cuda.stream(aux):
-                self.apply_group(g_moe, *early_apply)                  # 2/3 of the parameters, under the LSTM BPTT
+                reduce_then_apply(g_moe, seg_moe)                      # 2/3 of the parameters, under the LSTM BPTT
         dS1 = self.l2.backward(dS2, need_dx=True, aux=aux)              # [C*B][2LH] = d(L1 final state)
         if aux is not None and early_apply is not None:
             with torch.cuda.stream(aux):                               # after L2's weight-gradient GEMMs (same stream)
-                self.apply_group(g_l2, *early_apply)
+                reduce_then_apply(g_l2, seg_l2)
         self.l1.backward(dS1, need_dx=False, aux=aux)
         if aux is not None:
             if early_apply is not None:
                 with torch.cuda.stream(aux):
-                    self.apply_group(g_l1, *early_apply)
+                    reduce_then_apply(g_l1, seg_l1)
             ev = torch.cuda.Event()
             ev.record(aux)
             main.wait_event(ev)
