@@ -135,3 +135,40 @@ def test_high_precision_mode_after_training_steps():
     print("trained-state parity (pred err, state err, |state| max):", errs)
     assert errs["high"][0] < 1e-3 and errs["high"][1] < 1e-3 * max(1.0, errs["high"][2])
     assert errs["high"][0] < errs["bf16"][0]
+
+
+@pytest.mark.parametrize("frames", [[1, 14, 15, 16, 150, 299, 300], [300], [1], [0, 300, 0, 7], [300] * 8, [3] * 8])
+def test_extreme_frame_counts_with_row_plans(frames):
+    """Row plans at the edges: single video, every row alive, almost every row dead, zero-length videos."""
+    from efficientvideoclassification_youtube8m_amd import smoke
+    from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
+    B, F, H, V = len(frames), 64, 64, 24
+    q, x, n, labels = mm.synthetic_batch(B, seed=5 + B, feature_size=F, vocab_size=V, dtype=np.float32)
+    n[:] = frames
+    x[np.arange(300)[None, :] >= n[:, None]] = 0.0
+    g = DistillGraph(B, every_n=10, feature_size=F, vocab_size=V, lstm_cells=H, device=DEV, seed=2)
+    assert g.row_plans
+    out = g.step(torch.from_numpy(x).to(DEV), torch.from_numpy(labels.astype(np.uint8)).to(DEV), torch.from_numpy(n).to(DEV),
+                 apply=False, num_frames_host=n)
+    teacher, student = smoke.tower_params_numpy(g.teacher), smoke.tower_params_numpy(g.student)
+    ref = mm.teacher_student_step(x.astype(np.float64), n, labels, teacher, student, 10, with_grads=True)
+    assert np.abs(out["predictions"].cpu().numpy() - ref["teacher_predictions"]).max() < 1e-3
+    assert np.abs(out["student_predictions"].cpu().numpy() - ref["student_predictions"]).max() < 1e-3
+    assert np.abs(out["teacher_state"].cpu().numpy() - ref["teacher_state"]).max() < 2e-2
+    for tower, key in ((g.teacher, "teacher_grads"), (g.student, "student_grads")):
+        got = smoke.tower_grads_numpy(tower)
+        for k in mm.HLSTM_PARAM_ORDER:
+            gref = ref[key][k]
+            if k in ("classifier/gates/weights", "classifier/experts/weights"):
+                gref = gref - 2.0 * 1e-8 * smoke.tower_params_numpy(tower)[k]   # l2 term is folded in at apply time
+            assert np.isfinite(got[k]).all()
+            if np.abs(gref).max() > 1e-12:
+                assert _rel(got[k], gref) < 4e-2, (tower.scope, k, _rel(got[k], gref))
+            else:
+                assert np.abs(got[k]).max() < 1e-9
+    # the same step without row plans gives the same states (same per-row arithmetic)
+    g2 = DistillGraph(B, every_n=10, feature_size=F, vocab_size=V, lstm_cells=H, device=DEV, seed=2)
+    g2.row_plans = False
+    out2 = g2.step(torch.from_numpy(x).to(DEV), torch.from_numpy(labels.astype(np.uint8)).to(DEV), torch.from_numpy(n).to(DEV),
+                   apply=False, num_frames_host=n)
+    assert torch.equal(out["teacher_state"], out2["teacher_state"]) and torch.equal(out["student_state"], out2["student_state"])
