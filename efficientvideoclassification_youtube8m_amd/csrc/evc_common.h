@@ -37,21 +37,29 @@ void evc_set_error(const char* fmt, ...);
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
 // round-to-nearest-even; NaN stays NaN (plain cast semantics, see guide "Correctness boundaries")
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// f32 -> bf16, round to nearest even: gfx950's v_cvt_pk_bf16_f32 (one instruction; a software
+// add-and-shift rounding costs ~6 VALU instructions per value in the epilogues)
+typedef __bf16 evc_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float evc_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2_hw(float lo, float hi) {   // lo in bits 0-15
+  const evc_f32x2_t v = {lo, hi};
+  const evc_bf16x2_t r = __builtin_convertvector(v, evc_bf16x2_t);
+  return *(const uint32_t*)&r;
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2_hw(f, 0.0f) & 0xffffu); }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
-// tanh via exp: exact to ~1e-7 relative on the range the LSTM uses
+// v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division sequence hipcc emits for `/` without fast-math:
+// the gate tails evaluate 5 of these per (row, unit) and were VALU-bound on them.
+__device__ __forceinline__ float rcpf_(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoidf_(float x) { return rcpf_(1.0f + __expf(-x)); }
+// tanh via exp: exact to ~2e-7 relative on the range the LSTM uses
 __device__ __forceinline__ float tanhf_(float x) {
   float ax = fabsf(x);
   float e = __expf(-2.0f * ax);
-  float t = (1.0f - e) / (1.0f + e);
+  float t = (1.0f - e) * rcpf_(1.0f + e);
   return copysignf(t, x);
 }
+
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

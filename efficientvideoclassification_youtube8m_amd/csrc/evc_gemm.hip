@@ -260,9 +260,7 @@ struct LstmFwdParams {
   int M, H;
 };
 
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
-}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) { return pack_bf16x2_hw(lo, hi); }
 
 template <class Cfg, bool SPLIT = false>
 __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, LstmFwdParams e, int tiles_m, int tiles_n) {
@@ -597,7 +595,11 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_bwd_step_kernel(GemmOperands p, 
       const int m = m0 + tc.row0 + mi * 16;
       if (m >= e.M) continue;
       const float dh[4] = {acc[mi][0][ni][0], acc[mi][0][ni][1], acc[mi][0][ni][2], acc[mi][0][ni][3]};
+#ifdef EVC_ABLATE_BWD_EPI     // debug build: main loop only (keep the accumulators alive, store nothing)
+      asm volatile("" :: "v"(dh[0]), "v"(dh[1]), "v"(dh[2]), "v"(dh[3]));
+#else
       lstm_bwd_tail(e, m, u, dh);
+#endif
     }
   }
 }
