@@ -74,7 +74,7 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_nt_kernel(GemmOperands p, StoreP
   }
   const int id = xcd_remap(bid, nwg);
   int tm, tn;
-  tile_of(id, tiles_m, tiles_n, tm, tn);
+  tile_of(id, tiles_m, tiles_n, tm, tn, s.splits > 1 ? patch_rows(nwg, tiles_n) : 8);
   const int m0 = tm * Cfg::BM, u0 = tn * Cfg::BU;
   f32x4 acc[Cfg::MI][Cfg::G][Cfg::NI];
   run_mainloop<Cfg, Cfg::G>(p, m0, u0, acc);
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_tn_kernel(GemmOperandsT p, Store
   }
   const int id = xcd_remap(bid, nwg);
   int tm, tn;
-  tile_of(id, tiles_m, tiles_n, tm, tn);
+  tile_of(id, tiles_m, tiles_n, tm, tn, s.splits > 1 ? patch_rows(nwg, tiles_n) : 8);
   const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BU;
   f32x4 acc[Cfg::MI][1][Cfg::NI];
   gemm_mainloop_tn<Cfg>(p, m0, n0, lds_dyn, acc);
@@ -217,8 +217,12 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_tn_kernel(GemmOperandsT p, Store
         const int mo = s.row_il_H > 0 ? (m & 3) * s.row_il_H + (m >> 2) : m;
         float* cp = s.C + (long)mo * s.ldc + n;
         const float v = acc[mi][0][ni][r];
+#ifdef EVC_ABLATE_TN_ATOMICS     // debug build: plain stores instead of the split-K atomics (wrong sums, timing only)
+        *cp = v;
+#else
         if (s.splits > 1) atomicAdd(cp, v);
         else *cp = s.accumulate ? *cp + v : v;
+#endif
       }
     }
 }
@@ -234,7 +238,7 @@ extern "C" int evc_gemm_tn(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
   GemmOperandsT p{A, lda, B, ldb, M, N, K / 32};
   const int tm = ceil_div(M, CfgPlainV2::BM), tn = ceil_div(N, CfgPlainV2::BU);
   int splits = 256 / (tm * tn);
-  if (splits > K / 2048) splits = K / 2048;     // keep >= 64 K steps per split (K/1024 measured no faster)
+  if (splits > K / 1024) splits = K / 1024;     // keep >= 32 K steps per split
   if (splits < 1) splits = 1;
   StoreParamsT s{C, ldc, M, N, row_interleave_H, accumulate, splits, ceil_div(p.nk, splits)};
   if (splits > 1 && !accumulate) EVC_CHECK_HIP(hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st));

@@ -58,14 +58,25 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // inside the group, so any 32-64 consecutive ids - the workgroups resident on one XCD at a
 // time - form a compact ~8x4..8x8 patch that shares A row-panels AND B column-panels in that
 // XCD's L2 (12-16 panel fetches per K step instead of 33-65).  Bijective for any grid.
-__device__ __forceinline__ void tile_of(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
-  constexpr int GROUP_M = 8;
+__device__ __forceinline__ void tile_of(int id, int tiles_m, int tiles_n, int& tm, int& tn, const int GROUP_M = 8) {
   const int per_group = GROUP_M * tiles_n;
   const int g = id / per_group, r = id - g * per_group;
   const int first_m = g * GROUP_M;
   const int rows = min(tiles_m - first_m, GROUP_M);
   tm = first_m + r % rows;
   tn = r / rows;
+}
+
+// Rows of the tile patch one XCD works on at a time when a launch has `nwg` tiles (per K split): the nwg/8
+// consecutive ids of an XCD should form a gm x gn patch with gm + gn small (gm A panels + gn B panels are
+// fetched into that XCD's L2 per K step).  8 is right for >= 256 tiles (8x4 patches); a split-K launch with 64
+// tiles per split has only 8 tiles per XCD and split: 2x4 (6 panels) instead of 8x1 (9 panels).
+__device__ __forceinline__ int patch_rows(int nwg, int tiles_n) {
+  const int per = max(1, nwg >> 3);
+  int gm = 1;
+  while (gm * gm * 4 <= per) gm <<= 1;          // largest power of two with gm^2 <= per
+  while (gm < per && per / gm > tiles_n) gm <<= 1;
+  return min(gm, 8);
 }
 
 // SWAP = true issues the MFMA with the B fragment as its first operand: the accumulator tile is then
