@@ -258,8 +258,7 @@ struct LstmFwdParams {
   bf16_t* hout;                      // [M][H] slab t+1 (row-major: next step's A operand)
   bf16_t* hout_lo;                   // low-order half of h_t (split-bf16 parity mode) or NULL
   uint2* gates;                      // [M][H] 8-byte records of slab t (or NULL): bf16 {i, j, f, o}
-  const float* c_in; float* c_out;   // cell state before / after this step: slabs t and t+1 of c_all, or the
-                                     // in-place c_state buffer when no history is kept (c_in == NULL at t == 0)
+  bf16_t* c_hist;                    // slab t+1 of the bf16 cell-state history [M][H] (c after this step), or NULL
   const int* row_map;                // slot -> row of c_state / h_state (row plan, evc_sort_rows_by_len) or NULL
   int M, H;
 };
@@ -307,7 +306,6 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, 
         }
         continue;
       }
-      const long cu = e.gates ? hu : su;      // c history slabs are dense [M][H]; the in-place buffer has stride ld_state
       float zi[4], zj[4], zf[4], zo[4];
       const float bia[4] = {bi.x, bi.y, bi.z, bi.w}, bja[4] = {bj.x, bj.y, bj.z, bj.w};
       const float bfa[4] = {bf.x, bf.y, bf.z, bf.w}, boa[4] = {bo.x, bo.y, bo.z, bo.w};
@@ -325,7 +323,7 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, 
         zo[0] += d.x; zo[1] += d.y; zo[2] += d.z; zo[3] += d.w;
       }
       float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);     // zero initial state (no memset of the state buffers)
-      if (e.t > 0) cv = *(const float4*)(e.c_in + cu);
+      if (e.t > 0) cv = *(const float4*)(e.c_state + su);    // the running f32 cell state lives in c_state, in place
       const float co[4] = {cv.x, cv.y, cv.z, cv.w};
       float cn[4], hn[4];
       uint2 rec[4];
@@ -337,11 +335,9 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, 
         rec[r] = make_uint2(pack_bf16x2(gi, gj), pack_bf16x2(gf, go));
       }
       const float4 cnv = make_float4(cn[0], cn[1], cn[2], cn[3]);
-      *(float4*)(e.c_out + cu) = cnv;
-      if (e.t == ln - 1) {                             // the returned state is the one after step len-1
-        *(float4*)(e.h_state + su) = make_float4(hn[0], hn[1], hn[2], hn[3]);
-        if (e.gates) *(float4*)(e.c_state + su) = cnv;
-      }
+      *(float4*)(e.c_state + su) = cnv;               // rows stop updating at t = len: what stays is the returned state
+      if (e.c_hist) *(uint2*)(e.c_hist + hu) = make_uint2(pack_bf16x2(cn[0], cn[1]), pack_bf16x2(cn[2], cn[3]));
+      if (e.t == ln - 1) *(float4*)(e.h_state + su) = make_float4(hn[0], hn[1], hn[2], hn[3]);
       *(uint2*)(e.hout + hu) = make_uint2(pack_bf16x2(hn[0], hn[1]), pack_bf16x2(hn[2], hn[3]));
       if (SPLIT) {
         float lo[4];
@@ -397,14 +393,14 @@ static inline int pick_fwd_tile(int rows, int H) {
 static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const float* bias, const int32_t* len,
                                int T, int M, int Kin, int H, int hoist, float* zx_ws,
                                evc_bf16* hbuf, float* c_state, float* h_state, int64_t ld_state,
-                               void* gates, float* c_all,
+                               void* gates, evc_bf16* c_all,
                                const evc_bf16* x_lo, const evc_bf16* wT_lo, evc_bf16* hbuf_lo,
                                const int32_t* row_map, const int32_t* rows_per_step, void* stream);
 
 extern "C" int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const float* bias, const int32_t* len,
                                   int T, int M, int Kin, int H, int hoist, float* zx_ws,
                                   evc_bf16* hbuf, float* c_state, float* h_state, int64_t ld_state,
-                                  void* gates, float* c_all, const int32_t* row_map, const int32_t* rows_per_step,
+                                  void* gates, evc_bf16* c_all, const int32_t* row_map, const int32_t* rows_per_step,
                                   void* stream) {
   return lstm_layer_fwd_impl(x, wT, bias, len, T, M, Kin, H, hoist, zx_ws, hbuf, c_state, h_state, ld_state, gates, c_all,
                              nullptr, nullptr, nullptr, row_map, rows_per_step, stream);
@@ -413,7 +409,7 @@ extern "C" int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const f
 extern "C" int evc_lstm_layer_fwd_hp(const evc_bf16* x, const evc_bf16* x_lo, const evc_bf16* wT, const evc_bf16* wT_lo,
                                      const float* bias, const int32_t* len, int T, int M, int Kin, int H,
                                      evc_bf16* hbuf, evc_bf16* hbuf_lo, float* c_state, float* h_state, int64_t ld_state,
-                                     void* gates, float* c_all, const int32_t* row_map, const int32_t* rows_per_step,
+                                     void* gates, evc_bf16* c_all, const int32_t* row_map, const int32_t* rows_per_step,
                                      void* stream) {
   EVC_REQUIRE(x_lo && wT_lo && hbuf_lo, EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd_hp: the low-order halves are required");
   return lstm_layer_fwd_impl(x, wT, bias, len, T, M, Kin, H, 0, nullptr, hbuf, c_state, h_state, ld_state, gates, c_all,
@@ -423,7 +419,7 @@ extern "C" int evc_lstm_layer_fwd_hp(const evc_bf16* x, const evc_bf16* x_lo, co
 static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const float* bias, const int32_t* len,
                                int T, int M, int Kin, int H, int hoist, float* zx_ws,
                                evc_bf16* hbuf, float* c_state, float* h_state, int64_t ld_state,
-                               void* gates, float* c_all,
+                               void* gates, evc_bf16* c_all,
                                const evc_bf16* x_lo, const evc_bf16* wT_lo, evc_bf16* hbuf_lo,
                                const int32_t* row_map, const int32_t* rows_per_step, void* stream) {
   const bool split = x_lo != nullptr;
@@ -434,8 +430,8 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
   EVC_REQUIRE(ld_state % 4 == 0 && ((uintptr_t)c_state % 16) == 0 && ((uintptr_t)h_state % 16) == 0 && ((uintptr_t)bias % 16) == 0 &&
               ((uintptr_t)hbuf % 8) == 0, EVC_ERR_BAD_ALIGN, "evc_lstm_layer_fwd: state/bias/hbuf must allow 16-byte vector access");
   EVC_REQUIRE((gates == nullptr) == (c_all == nullptr), EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd: gates and c_all go together");
-  EVC_REQUIRE(!gates || (((uintptr_t)gates % 16) == 0 && ((uintptr_t)c_all % 16) == 0), EVC_ERR_BAD_ALIGN,
-              "evc_lstm_layer_fwd: gates / c_all must be 16-byte aligned");
+  EVC_REQUIRE(!gates || (((uintptr_t)gates % 16) == 0 && ((uintptr_t)c_all % 8) == 0), EVC_ERR_BAD_ALIGN,
+              "evc_lstm_layer_fwd: gates must be 16-byte, c_all 8-byte aligned");
   if (rows_per_step)
     for (int t = 0; t < T; ++t)
       EVC_REQUIRE(rows_per_step[t] >= 0 && rows_per_step[t] <= M && (t == 0 || rows_per_step[t] <= rows_per_step[t - 1]), EVC_ERR_BAD_ARG,
@@ -474,8 +470,7 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
     e.hout = hbuf + (long)(t + 1) * M * H;
     e.hout_lo = split ? hbuf_lo + (long)(t + 1) * M * H : nullptr;
     e.gates = gates ? (uint2*)gates + (long)t * M * H : nullptr;
-    if (c_all) { e.c_in = c_all + (long)t * M * H; e.c_out = c_all + (long)(t + 1) * M * H; }   // slab t+1 = c after step t
-    else { e.c_in = c_state; e.c_out = c_state; }
+    e.c_hist = c_all ? c_all + (long)(t + 1) * M * H : nullptr;      // slab t+1 = c after step t
     e.row_map = row_map;
     e.M = Mt; e.H = H;
     if (split) { launch_lstm_fwd<CfgLstmSmall, true>(p, e, k1, k2, st); continue; }   // parity mode: v1 64-row tiles, 3 MFMA products
@@ -501,7 +496,7 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
 struct LstmBwdParams {
   const int* len; int t;
   const uint2* gates;       // slab t   [M][H] bf16 {i, j, f, o}
-  const float* c_new; const float* c_old;   // slabs t+1 / t of c_all (c_old == NULL at t == 0)
+  const bf16_t* c_new; const bf16_t* c_old;   // slabs t+1 / t of the bf16 cell-state history (c_old == NULL at t == 0)
   const float* dS_c; const float* dS_h; long ld_dS;
   const float* dh_above;    // slab t [M][H] or NULL
   float* dc_ws;             // [M][H]
@@ -542,10 +537,13 @@ __device__ __forceinline__ void lstm_bwd_tail(const LstmBwdParams& e, const int 
   const uint4* gp = (const uint4*)(e.gates + hu);
   const uint4 g01 = gp[0], g23 = gp[1];
   const uint2 recs[4] = {make_uint2(g01.x, g01.y), make_uint2(g01.z, g01.w), make_uint2(g23.x, g23.y), make_uint2(g23.z, g23.w)};
-  const float4 cnv = *(const float4*)(e.c_new + hu);
-  float4 cov = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (e.c_old) cov = *(const float4*)(e.c_old + hu);
-  const float cna[4] = {cnv.x, cnv.y, cnv.z, cnv.w}, coa[4] = {cov.x, cov.y, cov.z, cov.w};
+  const uint2 cnq = *(const uint2*)(e.c_new + hu);
+  uint2 coq = make_uint2(0u, 0u);
+  if (e.c_old) coq = *(const uint2*)(e.c_old + hu);
+  const float cna[4] = {__uint_as_float(cnq.x << 16), __uint_as_float(cnq.x & 0xffff0000u),
+                        __uint_as_float(cnq.y << 16), __uint_as_float(cnq.y & 0xffff0000u)};
+  const float coa[4] = {__uint_as_float(coq.x << 16), __uint_as_float(coq.x & 0xffff0000u),
+                        __uint_as_float(coq.y << 16), __uint_as_float(coq.y & 0xffff0000u)};
   float dcn[4];
   uint2 dzr[4];
 #pragma unroll
@@ -716,11 +714,11 @@ typedef TileCfg2<160, 1, 128, 2, 4, 5, true> CfgBwdV2_160;
 typedef TileCfg2<192, 1, 128, 2, 4, 5, true> CfgBwdV2_192;
 
 extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int T, int M, int Kin, int H,
-                                  const void* gates, const float* c_all, const float* dS_c, const float* dS_h, int64_t ld_dS,
+                                  const void* gates, const evc_bf16* c_all, const float* dS_c, const float* dS_h, int64_t ld_dS,
                                   const float* dh_above, float* dc_ws, evc_bf16* dz4,
                                   const int32_t* row_map, const int32_t* rows_per_step, void* stream) {
   EVC_REQUIRE(T > 0 && M > 0 && H > 0 && Kin > 0 && H % 64 == 0, EVC_ERR_BAD_SHAPE, "evc_lstm_layer_bwd: bad shape");
-  EVC_REQUIRE(gates && c_all && ((uintptr_t)gates % 16) == 0 && ((uintptr_t)c_all % 16) == 0 && ((uintptr_t)dz4 % 16) == 0,
+  EVC_REQUIRE(gates && c_all && ((uintptr_t)gates % 16) == 0 && ((uintptr_t)c_all % 8) == 0 && ((uintptr_t)dz4 % 16) == 0,
               EVC_ERR_BAD_ALIGN, "evc_lstm_layer_bwd: gates/c_all/dz4 alignment");
   EVC_REQUIRE(ld_dS % 4 == 0 && ((uintptr_t)dS_c % 16) == 0 && ((uintptr_t)dS_h % 16) == 0 && ((uintptr_t)dc_ws % 16) == 0 &&
               (!dh_above || ((uintptr_t)dh_above % 16) == 0), EVC_ERR_BAD_ALIGN, "evc_lstm_layer_bwd: f32 operands must allow 16-byte vector access");

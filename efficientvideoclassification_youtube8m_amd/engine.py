@@ -86,9 +86,9 @@ class LstmStack:
             self.zx = torch.empty((T * M, 4 * H), dtype=F32, device=dev)
         self.training = training
         if training:
-            # history for BPTT: 8-byte gate records {i,j,f,o bf16} and the cell state after every step
+            # history for BPTT: 8-byte gate records {i,j,f,o bf16} and the (bf16) cell state after every step
             self.gates = [torch.empty((T, M, H, 2), dtype=torch.int32, device=dev) for _ in range(L)]
-            self.c_all = [torch.empty((T + 1, M, H), dtype=F32, device=dev) for _ in range(L)]
+            self.c_all = [torch.empty((T + 1, M, H), dtype=BF16, device=dev) for _ in range(L)]
             self.KP = ops.round_up(T * M, 64)
             self.dz = [torch.zeros((T, M, 4 * H), dtype=BF16, device=dev) for _ in range(L)]   # gate-interleaved [T][M][H][4];
             # one per layer so a layer's weight-gradient GEMMs (aux stream) can run under the next layer's BPTT

@@ -118,11 +118,12 @@ int evc_gemm_tn(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, 
  * hbuf [(T+1)][M][H] bf16: slab 0 is zero-filled here, slab t+1 = h_t (0 where t >= len)
  * c_state/h_state: f32 final state columns, row stride ld_state (so they can
  *        point into the [M, 2*L*H] state tensor concat([c0,h0,c1,h1]));
- *        zero for len == 0.
+ *        zero for len == 0.  c_state doubles as the running f32 cell state: it is read and rewritten in
+ *        place by every active step (a row stops updating at t = len, which leaves the returned state);
+ *        h_state is written once, at t = len-1.
  * gates [T][M][H] 8-byte records (bf16 post-activation i, j, f, o) and
- * c_all [(T+1)][M][H] f32 (slab t+1 = cell state after step t; slab 0 is never read) are the
- *        history kept for the backward pass; both NULL = inference (c_state is then updated in
- *        place each step; with history it is written once, at t = len-1).
+ * c_all [(T+1)][M][H] bf16 (slab t+1 = cell state after step t, rounded; slab 0 is never read) are the
+ *        history kept for the backward pass (12 bytes per element and step); both NULL = inference.
  * Epilogue layout: the MFMA is issued with the weight fragment first, so a lane holds 4
  * consecutive units of one row and every state / tape / h access is an 8-16 byte vector access
  * (c_state, h_state, bias 16-byte aligned; ld_state % 4 == 0).
@@ -134,7 +135,7 @@ int evc_gemm_tn(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, 
 int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const float* bias, const int32_t* len,
                        int T, int M, int Kin, int H, int hoist, float* zx_ws,
                        evc_bf16* hbuf, float* c_state, float* h_state, int64_t ld_state,
-                       void* gates, float* c_all, const int32_t* row_map, const int32_t* rows_per_step, void* stream);
+                       void* gates, evc_bf16* c_all, const int32_t* row_map, const int32_t* rows_per_step, void* stream);
 
 /* "High" precision variant of evc_lstm_layer_fwd: every bf16 operand comes as hi + lo halves
  * (evc_cast_f32_to_bf16_split / evc_l2norm_chunk_fwd's lo outputs) and the step issues
@@ -144,7 +145,7 @@ int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const float* bias,
 int evc_lstm_layer_fwd_hp(const evc_bf16* x, const evc_bf16* x_lo, const evc_bf16* wT, const evc_bf16* wT_lo,
                           const float* bias, const int32_t* len, int T, int M, int Kin, int H,
                           evc_bf16* hbuf, evc_bf16* hbuf_lo, float* c_state, float* h_state, int64_t ld_state,
-                          void* gates, float* c_all, const int32_t* row_map, const int32_t* rows_per_step, void* stream);
+                          void* gates, evc_bf16* c_all, const int32_t* row_map, const int32_t* rows_per_step, void* stream);
 
 /* BPTT of the above (what tf.gradients builds inside
  * slim.learning.create_train_op, cs/train.py:329-334,413-418).
@@ -162,7 +163,7 @@ int evc_lstm_layer_fwd_hp(const evc_bf16* x, const evc_bf16* x_lo, const evc_bf1
  *        weight-gradient products contract over all T*M rows.
  */
 int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int T, int M, int Kin, int H,
-                       const void* gates, const float* c_all, const float* dS_c, const float* dS_h, int64_t ld_dS,
+                       const void* gates, const evc_bf16* c_all, const float* dS_c, const float* dS_h, int64_t ld_dS,
                        const float* dh_above, float* dc_ws, evc_bf16* dz4,
                        const int32_t* row_map, const int32_t* rows_per_step, void* stream);
 

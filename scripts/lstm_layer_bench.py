@@ -44,7 +44,7 @@ b = torch.zeros(4 * H, device=dev)
 hbuf = torch.zeros((T + 1, P, H), dtype=torch.bfloat16, device=dev)
 S = torch.zeros((M, 2 * H), device=dev)
 gates = torch.empty((T, P, H, 2), dtype=torch.int32, device=dev)
-c_all = torch.zeros((T + 1, P, H), device=dev)
+c_all = torch.zeros((T + 1, P, H), dtype=torch.bfloat16, device=dev)
 dz4 = torch.zeros((T, P, 4 * H), dtype=torch.bfloat16, device=dev)
 dcw = torch.empty((P, H), device=dev)
 dS = torch.randn(M, 2 * H, device=dev)

@@ -72,7 +72,7 @@ def test_lstm_layer_fwd_and_bwd(ops, M, T, Kin, H, hoist):
     hbuf = torch.full((T + 1, M, H), float("nan"), dtype=torch.bfloat16, device=DEV)
     S = torch.full((M, 2 * H), float("nan"), dtype=torch.float32, device=DEV)
     gates = torch.empty((T, M, H, 2), dtype=torch.int32, device=DEV)
-    c_all = torch.full((T + 1, M, H), float("nan"), dtype=torch.float32, device=DEV)
+    c_all = torch.full((T + 1, M, H), float("nan"), dtype=torch.bfloat16, device=DEV)
     KP = ops.round_up(T * M, 64)
     zx = torch.empty((T * M, 4 * H), dtype=torch.float32, device=DEV) if hoist else None
     ops.lstm_layer_fwd(xt, wT, b, ln, T, M, Kin, H, hbuf, S[:, :H], S[:, H:], 2 * H, gates, c_all, hoist=hoist, zx_ws=zx)
@@ -360,7 +360,7 @@ def test_lstm_layer_with_row_plan_matches_plain(ops, M, T, Kin, H):
         hbuf = torch.zeros((T + 1, P, H), dtype=torch.bfloat16, device=DEV)
         S = torch.zeros((M, 2 * H), dtype=torch.float32, device=DEV)
         gates = torch.empty((T, P, H, 2), dtype=torch.int32, device=DEV)
-        c_all = torch.full((T + 1, P, H), float("nan"), dtype=torch.float32, device=DEV)
+        c_all = torch.full((T + 1, P, H), float("nan"), dtype=torch.bfloat16, device=DEV)
         ops.lstm_layer_fwd(xs, wT, b, lens_d, T, P, Kin, H, hbuf, S[:, :H], S[:, H:], 2 * H, gates, c_all, plan=plan)
         dz4 = torch.full((T, P, 4 * H), float("nan"), dtype=torch.bfloat16, device=DEV)
         dcw = torch.empty((P, H), dtype=torch.float32, device=DEV)
