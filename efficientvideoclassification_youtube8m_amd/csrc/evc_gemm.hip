@@ -498,7 +498,7 @@ struct LstmBwdParams {
   const uint2* gates;       // slab t   [M][H] bf16 {i, j, f, o}
   const bf16_t* c_new; const bf16_t* c_old;   // slabs t+1 / t of the bf16 cell-state history (c_old == NULL at t == 0)
   const float* dS_c; const float* dS_h; long ld_dS;
-  const float* dh_above;    // slab t [M][H] or NULL
+  const bf16_t* dh_above;   // slab t [M][H] bf16 (dX of the layer above) or NULL
   float* dc_ws;             // [M][H]
   uint2* dz4;               // slab t [M][H] gate-interleaved: 4 bf16 (dz_i, dz_j, dz_f, dz_o) per (row, unit)
   const int* row_map;       // slot -> row of dS_c / dS_h (row plan) or NULL
@@ -530,8 +530,9 @@ __device__ __forceinline__ void lstm_bwd_tail(const LstmBwdParams& e, const int 
     dcv = *(const float4*)(e.dc_ws + hu);
   }
   if (e.dh_above) {
-    const float4 a = *(const float4*)(e.dh_above + hu);
-    dh[0] += a.x; dh[1] += a.y; dh[2] += a.z; dh[3] += a.w;
+    const uint2 a = *(const uint2*)(e.dh_above + hu);
+    dh[0] += __uint_as_float(a.x << 16); dh[1] += __uint_as_float(a.x & 0xffff0000u);
+    dh[2] += __uint_as_float(a.y << 16); dh[3] += __uint_as_float(a.y & 0xffff0000u);
   }
   const float dci[4] = {dcv.x, dcv.y, dcv.z, dcv.w};
   const uint4* gp = (const uint4*)(e.gates + hu);
@@ -715,13 +716,13 @@ typedef TileCfg2<192, 1, 128, 2, 4, 5, true> CfgBwdV2_192;
 
 extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int T, int M, int Kin, int H,
                                   const void* gates, const evc_bf16* c_all, const float* dS_c, const float* dS_h, int64_t ld_dS,
-                                  const float* dh_above, float* dc_ws, evc_bf16* dz4,
+                                  const evc_bf16* dh_above, float* dc_ws, evc_bf16* dz4,
                                   const int32_t* row_map, const int32_t* rows_per_step, void* stream) {
   EVC_REQUIRE(T > 0 && M > 0 && H > 0 && Kin > 0 && H % 64 == 0, EVC_ERR_BAD_SHAPE, "evc_lstm_layer_bwd: bad shape");
   EVC_REQUIRE(gates && c_all && ((uintptr_t)gates % 16) == 0 && ((uintptr_t)c_all % 8) == 0 && ((uintptr_t)dz4 % 16) == 0,
               EVC_ERR_BAD_ALIGN, "evc_lstm_layer_bwd: gates/c_all/dz4 alignment");
   EVC_REQUIRE(ld_dS % 4 == 0 && ((uintptr_t)dS_c % 16) == 0 && ((uintptr_t)dS_h % 16) == 0 && ((uintptr_t)dc_ws % 16) == 0 &&
-              (!dh_above || ((uintptr_t)dh_above % 16) == 0), EVC_ERR_BAD_ALIGN, "evc_lstm_layer_bwd: f32 operands must allow 16-byte vector access");
+              (!dh_above || ((uintptr_t)dh_above % 8) == 0), EVC_ERR_BAD_ALIGN, "evc_lstm_layer_bwd: f32 operands must allow 16-byte vector access");
   if (rows_per_step)
     for (int t = 0; t < T; ++t)
       EVC_REQUIRE(rows_per_step[t] >= 0 && rows_per_step[t] <= M && (t == 0 || rows_per_step[t] <= rows_per_step[t - 1]), EVC_ERR_BAD_ARG,

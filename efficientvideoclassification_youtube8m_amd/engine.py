@@ -98,7 +98,8 @@ class LstmStack:
                 self.xT = torch.empty((max(self.kin), self.KP), dtype=BF16, device=dev)
                 self.hT_ws = torch.empty((H, self.KP), dtype=BF16, device=dev)
             self.dc_ws = torch.empty((M, H), dtype=F32, device=dev)
-            self.dx = [torch.empty((T * M, self.kin[l]), dtype=F32, device=dev) if (l > 0) else None for l in range(L)]
+            # dX of layer l > 0 = the dh arriving at layer l-1: bf16 (read once per BPTT step of the layer below)
+            self.dx = [torch.empty((T * M, self.kin[l]), dtype=BF16, device=dev) if (l > 0) else None for l in range(L)]
 
     def names(self, l):
         base = "%s/rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/" % (self.scope, l)

@@ -152,7 +152,8 @@ int evc_lstm_layer_fwd_hp(const evc_bf16* x, const evc_bf16* x_lo, const evc_bf1
  * w_il [Kin+H][4H] bf16 = kernel in TF layout with the 4H axis GATE-INTERLEAVED
  *        (column u*4+g holds TF column g*H+u; evc_transpose_to_bf16(..., interleave_H=H))
  * dS_c/dS_h: f32 gradient wrt the final c/h state, row stride ld_dS
- * dh_above [T][M][H] f32 or NULL: gradient arriving at h_t from the layer above
+ * dh_above [T][M][H] bf16 or NULL: gradient arriving at h_t from the layer above (its dX = dz . Wx^T,
+ *        evc_gemm_nt with bf16 output)
  * dc_ws [M][H] f32 scratch.
  * dz4  [T][M][H][4] bf16 out: gate pre-activation gradients, gate-interleaved (0 where
  *        t >= len); viewed as [T*M][4H] it is the A operand of dz . W^T with w_il.
@@ -164,7 +165,7 @@ int evc_lstm_layer_fwd_hp(const evc_bf16* x, const evc_bf16* x_lo, const evc_bf1
  */
 int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int T, int M, int Kin, int H,
                        const void* gates, const evc_bf16* c_all, const float* dS_c, const float* dS_h, int64_t ld_dS,
-                       const float* dh_above, float* dc_ws, evc_bf16* dz4,
+                       const evc_bf16* dh_above, float* dc_ws, evc_bf16* dz4,
                        const int32_t* row_map, const int32_t* rows_per_step, void* stream);
 
 /* ---- layout helpers --------------------------------------------------------

@@ -48,7 +48,7 @@ c_all = torch.zeros((T + 1, P, H), dtype=torch.bfloat16, device=dev)
 dz4 = torch.zeros((T, P, 4 * H), dtype=torch.bfloat16, device=dev)
 dcw = torch.empty((P, H), device=dev)
 dS = torch.randn(M, 2 * H, device=dev)
-dha = torch.randn(T, P, H, device=dev) * 0.1
+dha = (torch.randn(T, P, H, device=dev) * 0.1).to(torch.bfloat16)
 lens_d = plan.lens if plan else ld
 
 

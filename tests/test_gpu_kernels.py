@@ -88,10 +88,10 @@ def test_lstm_layer_fwd_and_bwd(ops, M, T, Kin, H, hoist):
 
     # ---- backward ----
     dS = rng.standard_normal((M, 2 * H))
-    dh_above = rng.standard_normal((T, M, H)) * 0.3
+    dh_above = bf16_round(rng.standard_normal((T, M, H)) * 0.3)      # the upper layer's dX arrives as bf16
     dx_ref, grads_ref = _bwd_ref(x, lens, kernel, bias, dS, dh_above)
     dSt = torch.from_numpy(dS.astype(np.float32)).to(DEV)
-    dha = torch.from_numpy(dh_above.astype(np.float32)).to(DEV)
+    dha = to_bf16(dh_above)
     dz4 = torch.full((T, M, 4 * H), float("nan"), dtype=torch.bfloat16, device=DEV)
     dcw = torch.empty((M, H), dtype=torch.float32, device=DEV)
     ops.lstm_layer_bwd(w_il, ln, T, M, Kin, H, gates, c_all, dSt[:, :H], dSt[:, H:], 2 * H, dha, dcw, dz4)
@@ -348,7 +348,7 @@ def test_lstm_layer_with_row_plan_matches_plain(ops, M, T, Kin, H):
     b = torch.from_numpy((rng.standard_normal(4 * H) * 0.1).astype(np.float32)).to(DEV)
     ln = torch.from_numpy(lens).to(DEV)
     dS = torch.from_numpy(rng.standard_normal((M, 2 * H)).astype(np.float32)).to(DEV)
-    dha = torch.from_numpy((rng.standard_normal((T, M, H)) * 0.3).astype(np.float32)).to(DEV)
+    dha = to_bf16(rng.standard_normal((T, M, H)) * 0.3)
 
     def run(plan):
         P = plan.P if plan is not None else M
