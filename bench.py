@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--all_full", action="store_true", help="every video has 300 frames (no padding)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_videos", type=int, default=8)
+    ap.add_argument("--no_fused_moe", action="store_true", help="debug: materialise the MoE weight gradients (A/B of evc_moe_grad_update)")
     ap.add_argument("--no_overlap", action="store_true", help="debug: everything on one stream (solo kernel times for profiling)")
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic batches cycled through (HBM resident)")
     args = ap.parse_args()
@@ -114,6 +115,10 @@ def main():
     # geometry of the length-sorted L1 stacks is derived from them, see ops.RowPlan)
     n_host = [p[1].cpu().numpy() for p in pool]
     graph = DistillGraph(B, every_n=args.every_n, mode=args.mode, device=device, seed=7, overlap_towers=not args.no_overlap)
+    if args.no_fused_moe:
+        for tw in (graph.teacher, graph.student):
+            if tw is not None:
+                tw.fused_moe_update = False
 
     def barrier():
         if world > 1:

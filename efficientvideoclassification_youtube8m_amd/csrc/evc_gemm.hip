@@ -2,6 +2,7 @@
 // (forward, with the gate tail in the epilogue) and fused BPTT step.
 #include "gemm_core_tn.h"
 #include <mutex>
+#include <vector>
 #include <stdlib.h>
 
 // A kernel is instantiated either on a v1 tile (TileCfg: static 2-stage LDS, K steps of 64)
@@ -25,11 +26,21 @@ __device__ __forceinline__ void run_mainloop(const GemmOperands& p, int m0, int 
 // K-step granularity of a config (v1 walks 64-wide tiles, v2 32-wide)
 template <class Cfg> static inline int kdiv() { return is_v2<Cfg>::value ? 32 : 64; }
 
+// v2 tiles use more dynamic LDS than the 64 KiB default: raise the limit once per kernel (keyed by the
+// kernel's address - two kernels of one signature share this template instantiation).
+static inline void allow_big_lds(const void* kern, int bytes) {
+  static std::mutex mu;
+  static std::vector<const void*> done;
+  std::lock_guard<std::mutex> lk(mu);
+  for (const void* k : done) if (k == kern) return;
+  (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  done.push_back(kern);
+}
+
 template <class Cfg, class Kern, class... Args>
 static inline void launch_cfg(Kern kern, int grid, hipStream_t st, Args... args) {
   if (is_v2<Cfg>::value) {
-    static std::once_flag once;
-    std::call_once(once, [&] { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES); });
+    allow_big_lds((const void*)kern, Cfg::LDS_BYTES);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, args...);
   } else {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::NT), 0, st, args...);
@@ -243,6 +254,153 @@ extern "C" int evc_gemm_tn(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
   StoreParamsT s{C, ldc, M, N, row_interleave_H, accumulate, splits, ceil_div(p.nk, splits)};
   if (splits > 1 && !accumulate) EVC_CHECK_HIP(hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st));
   launch_cfg<CfgPlainV2>(gemm_tn_kernel<CfgPlainV2>, tm * tn * splits, st, p, s, tm, tn);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// ===========================================================================
+// MoE weight update without materialising the gradient.
+// The gradient of a MoE weight matrix W [V][K] (stored as the forward GEMM's B operand) is the outer
+// product dlogits^T . x over the batch rows: rank = batch.  Writing it (4 B/param), reading it for the
+// norm (4+4) and again for Adam, then transposing the updated weights for the backward shadow costs 46
+// bytes per parameter of HBM traffic for 96.6 M parameters per tower.  Here the [256 x 256] gradient tile is
+// recomputed from the factors (8 K steps of the TN loop) in each of two passes:
+//   pass 1: sum (g + l2 p)^2 and sum p^2 per workgroup -> partials (summed in a fixed order afterwards)
+//   pass 2: per-tensor clip + TF-Adam in the epilogue: reads p, m, v, writes p, m, v, the bf16 forward
+//           shadow and - through an LDS transpose - the bf16 transposed shadow: 30 bytes per parameter.
+// Under data parallelism the factors of all ranks are all-gathered (14 MB per rank) instead of all-reducing
+// the 386 MB gradient; the contraction then simply runs over world x batch rows.
+// ===========================================================================
+struct MoeUpdateParams {
+  float* p; float* m; float* v;        // [V][K] f32, row stride K
+  bf16_t* p_bf16;                      // forward shadow [V][K]
+  bf16_t* pT_bf16; long ldT;           // transposed shadow [K][ldT], ldT >= V
+  float* partial;                      // pass 1 out: [workgroups][2]
+  const float* sums;                   // pass 2 in: sums[0] = sum (g + l2 p)^2 of this tensor
+  int V, K;
+  float l2, clip, lr_t, b1, b2, eps;
+};
+
+template <class Cfg, int PASS>
+__global__ __launch_bounds__(Cfg::NT) void moe_update_kernel(GemmOperandsT p, MoeUpdateParams u, int tiles_m, int tiles_n) {
+  const int nwg = tiles_m * tiles_n;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  int tm, tn;
+  tile_of(id, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BU;
+  f32x4 acc[Cfg::MI][1][Cfg::NI];
+  gemm_mainloop_tn<Cfg, true>(p, m0, n0, lds_dyn, acc);
+  TileCoordsT<Cfg> tc;
+  const int K = u.K;
+  if (PASS == 1) {
+    float sg = 0.f, sp = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < Cfg::MI; ++mi) {
+      const int vr = m0 + tc.row0 + mi * 16;
+#pragma unroll
+      for (int ni = 0; ni < Cfg::NI; ++ni) {
+        const int k = n0 + tc.unit0 + ni * 16;
+        if (vr >= u.V || k >= K) continue;
+        const float4 pv = *(const float4*)(u.p + (long)vr * K + k);
+        const float pa[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float w = acc[mi][0][ni][r] + u.l2 * pa[r];
+          sg += w * w;
+          sp += pa[r] * pa[r];
+        }
+      }
+    }
+    sg = wave_sum(sg);
+    sp = wave_sum(sp);
+    __syncthreads();                                   // the LDS ring is free now
+    float* red = (float*)lds_dyn;
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wave * 2] = sg; red[wave * 2 + 1] = sp; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float a = 0.f, b = 0.f;
+      for (int w = 0; w < Cfg::NT / 64; ++w) { a += red[w * 2]; b += red[w * 2 + 1]; }
+      u.partial[2 * blockIdx.x] = a;
+      u.partial[2 * blockIdx.x + 1] = b;
+    }
+    return;
+  }
+  float scale = 1.f;
+  if (u.clip > 0.f) scale = u.clip / fmaxf(sqrtf(u.sums[0]), u.clip);      // tf.clip_by_norm
+  __syncthreads();                                     // every wave is done with the ring: reuse it for the transpose
+  constexpr int PITCH = Cfg::BM + 8;                   // bf16 elements per k row of the [BU k][BM v] image (+16 B: bank spread)
+  bf16_t* tile = (bf16_t*)lds_dyn;
+  static_assert((long)Cfg::BU * PITCH * 2 <= Cfg::LDS_BYTES, "transpose image must fit the ring");
+#pragma unroll
+  for (int mi = 0; mi < Cfg::MI; ++mi) {
+    const int vl = tc.row0 + mi * 16, vr = m0 + vl;
+#pragma unroll
+    for (int ni = 0; ni < Cfg::NI; ++ni) {
+      const int kl = tc.unit0 + ni * 16, k = n0 + kl;
+      bf16_t pb[4] = {0, 0, 0, 0};
+      if (vr < u.V && k < K) {
+        const long o = (long)vr * K + k;
+        const float4 pv = *(const float4*)(u.p + o), mv = *(const float4*)(u.m + o), vv = *(const float4*)(u.v + o);
+        const float pa[4] = {pv.x, pv.y, pv.z, pv.w}, ma[4] = {mv.x, mv.y, mv.z, mv.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+        float pn[4], mn[4], vn[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                 // same operation order as clip_adam_kernel
+          const float gc = (acc[mi][0][ni][r] + u.l2 * pa[r]) * scale;
+          mn[r] = u.b1 * ma[r] + (1.f - u.b1) * gc;
+          vn[r] = u.b2 * va[r] + (1.f - u.b2) * gc * gc;
+          pn[r] = pa[r] - u.lr_t * mn[r] / (sqrtf(vn[r]) + u.eps);
+          pb[r] = f32_to_bf16(pn[r]);
+        }
+        *(float4*)(u.p + o) = make_float4(pn[0], pn[1], pn[2], pn[3]);
+        *(float4*)(u.m + o) = make_float4(mn[0], mn[1], mn[2], mn[3]);
+        *(float4*)(u.v + o) = make_float4(vn[0], vn[1], vn[2], vn[3]);
+        *(uint2*)(u.p_bf16 + o) = make_uint2((uint32_t)pb[0] | ((uint32_t)pb[1] << 16), (uint32_t)pb[2] | ((uint32_t)pb[3] << 16));
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tile[(kl + r) * PITCH + vl] = pb[r];
+    }
+  }
+  __syncthreads();
+  // rows k of the transposed shadow: one wave-instruction moves a whole 256-v row (4 bf16 per lane)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int v4 = m0 + lane * 4;
+  for (int kl = wave; kl < Cfg::BU; kl += Cfg::NT / 64) {
+    const int k = n0 + kl;
+    if (k >= K || v4 >= u.V) continue;                 // V % 4 == 0: a lane's 4 rows are all valid or all not
+    const uint2 q = *(const uint2*)(tile + kl * PITCH + lane * 4);
+    *(uint2*)(u.pT_bf16 + (long)k * u.ldT + v4) = q;
+  }
+}
+
+__global__ void moe_update_finalize_kernel(const float* partial, int n, float* sums) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {           // fixed summation order: run-to-run identical
+    float a = 0.f, b = 0.f;
+    for (int i = 0; i < n; ++i) { a += partial[2 * i]; b += partial[2 * i + 1]; }
+    sums[0] += a;
+    sums[1] += b;
+  }
+}
+
+extern "C" int evc_moe_grad_update(const evc_bf16* dlogits, int64_t ld_dlogits, const evc_bf16* x, int64_t ldx, int rows,
+                                   int V, int K, float* p, float* m, float* v, evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT,
+                                   float l2_coeff, float* sums, float* partial_ws, float clip_norm, float lr_t,
+                                   float beta1, float beta2, float eps, void* stream) {
+  EVC_REQUIRE(rows > 0 && rows % 32 == 0 && V > 0 && V % 4 == 0 && K > 0 && K % 8 == 0, EVC_ERR_BAD_SHAPE,
+              "evc_moe_grad_update: rows=%d (%%32), V=%d (%%4), K=%d (%%8)", rows, V, K);
+  EVC_REQUIRE(ld_dlogits % 8 == 0 && ld_dlogits >= V && ldx % 8 == 0 && ldT % 4 == 0 && ldT >= V &&
+              ((uintptr_t)dlogits % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)p % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
+              ((uintptr_t)v % 16) == 0 && ((uintptr_t)p_bf16 % 8) == 0 && ((uintptr_t)pT_bf16 % 8) == 0, EVC_ERR_BAD_ALIGN,
+              "evc_moe_grad_update: operand alignment / leading dimensions");
+  hipStream_t st = (hipStream_t)stream;
+  typedef CfgPlainV2 Cfg;
+  const int Vp = (int)(ld_dlogits < ((V + 7) / 8) * 8 ? ld_dlogits : ((V + 7) / 8) * 8);   // A columns the loop may touch (%8)
+  GemmOperandsT g{dlogits, ld_dlogits, x, ldx, Vp, K, rows / 32};
+  const int tm = ceil_div(V, Cfg::BM), tn = ceil_div(K, Cfg::BU);
+  MoeUpdateParams u{p, m, v, p_bf16, pT_bf16, ldT, partial_ws, sums, V, K, l2_coeff, clip_norm, lr_t, beta1, beta2, eps};
+  launch_cfg<Cfg>(moe_update_kernel<Cfg, 1>, tm * tn, st, g, u, tm, tn);
+  hipLaunchKernelGGL(moe_update_finalize_kernel, dim3(1), dim3(64), 0, st, (const float*)partial_ws, tm * tn, sums);
+  launch_cfg<Cfg>(moe_update_kernel<Cfg, 2>, tm * tn, st, g, u, tm, tn);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }

@@ -31,7 +31,10 @@ struct GemmOperandsT {
 
 __device__ __forceinline__ int tn_h(int row) { return (((row >> 3) & 1) << 2) | (row & 3); }
 
-template <class Cfg>
+// SWAP = true issues the MFMA with the B fragment first: the accumulator tile is transposed - lane l holds
+// row (A column) m = l&15 and 4 consecutive columns n = (l>>4)*4 + reg (TileCoordsT) - so an epilogue that
+// walks n fastest gets 16-byte vector accesses to row-major [M][N] arrays.
+template <class Cfg, bool SWAP = false>
 __device__ __forceinline__ void gemm_mainloop_tn(GemmOperandsT p, const int m0, const int n0, char* lds,
                                                  f32x4 (&acc)[Cfg::MI][1][Cfg::NI]) {
   static_assert(Cfg::G == 1 && Cfg::PIPE && !Cfg::RAGGED, "TN loop: plain tiles, pipelined, even staging");
@@ -126,7 +129,8 @@ __device__ __forceinline__ void gemm_mainloop_tn(GemmOperandsT p, const int m0, 
     for (int mi = 0; mi < Cfg::MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < Cfg::NI; ++ni)
-        acc[mi][0][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[ni], acc[mi][0][ni], 0, 0, 0);
+        acc[mi][0][ni] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][0][ni], 0, 0, 0)
+                              : __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[ni], acc[mi][0][ni], 0, 0, 0);
   };
   auto end_of_step = [&]() {   // see gemm_core_v2.h: retire the LDS reads explicitly, nothing loop-carried for hipcc
     __builtin_amdgcn_sched_barrier(0);

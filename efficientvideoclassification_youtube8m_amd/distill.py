@@ -92,6 +92,16 @@ class GradReducer:
             return None
         return torch.distributed.all_reduce(flat[lo:hi], op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=True)
 
+    def all_gather_rows(self, t):
+        """[rows, cols] bf16 (contiguous) of every rank stacked along the rows, in rank order (the collective
+        moves raw bytes: gloo has neither bfloat16 nor int16)."""
+        if self.world == 1:
+            return t
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        parts = list(out.view(torch.uint8).chunk(self.world, dim=0))
+        torch.distributed.all_gather(parts, t.contiguous().view(torch.uint8), group=self.pg)
+        return out
+
     def wait(self):
         for w in self._pending:
             w.wait()
@@ -277,7 +287,8 @@ class DistillGraph:
                 self.student.backward(ds, self._dp_s,
                                       on_moe_grads_ready=None if early else (lambda: self._reduce_tower(self.student, True)),
                                       aux=self._aux_s if self.overlap_towers else None, early_apply=early,
-                                      reduce_fn=(lambda lo, hi: self.reducer.reduce_async(st_s.grad, lo, hi)) if early else None)
+                                      reduce_fn=(lambda lo, hi: self.reducer.reduce_async(st_s.grad, lo, hi)) if (early and self.world > 1) else None,
+                                      gather_fn=self.reducer.all_gather_rows if (early and self.world > 1) else None)
                 if not early:
                     self._reduce_tower(self.student, False)
                 self._student_applied = early is not None
@@ -300,7 +311,8 @@ class DistillGraph:
             self.teacher.backward(None, self._dp_t,
                                   on_moe_grads_ready=None if early else (lambda: self._reduce_tower(self.teacher, True)),
                                   aux=self._aux_t if self.overlap_towers else None, early_apply=early,
-                                  reduce_fn=(lambda lo, hi: self.reducer.reduce_async(st_t.grad, lo, hi)) if early else None)
+                                  reduce_fn=(lambda lo, hi: self.reducer.reduce_async(st_t.grad, lo, hi)) if (early and self.world > 1) else None,
+                                  gather_fn=self.reducer.all_gather_rows if (early and self.world > 1) else None)
             if not early:
                 self._reduce_tower(self.teacher, False)
             mark("teacher_bwd_done", main)

@@ -267,15 +267,19 @@ class MoeHead:
     def alloc(self, B, training):
         dev, K, V, Mx = self.tw.device, self.K, self.V, self.Mx
         self.B = B
-        self.x_bf = torch.empty((B, K), dtype=BF16, device=dev)
+        self.Br = ops.round_up(B, 32)                                   # rows of the factor images (zero rows pad): TN contraction
+        self.x_full = torch.zeros((self.Br, K), dtype=BF16, device=dev)
+        self.x_bf = self.x_full[:B]
         self.gate_logits = torch.empty((B, V * (Mx + 1)), dtype=F32, device=dev)
         self.expert_logits = torch.empty((B, V * Mx), dtype=F32, device=dev)
         self.pred = torch.empty((B, V), dtype=F32, device=dev)
         self.rowsum = torch.empty((B,), dtype=F32, device=dev)
         if training:
             self.Bp = ops.round_up(B, 64)
-            self.dgl = torch.zeros((B, ops.round_up(V * (Mx + 1), 64)), dtype=BF16, device=dev)   # pad cols stay 0
-            self.del_ = torch.zeros((B, ops.round_up(V * Mx, 64)), dtype=BF16, device=dev)
+            self.dgl_full = torch.zeros((self.Br, ops.round_up(V * (Mx + 1), 64)), dtype=BF16, device=dev)   # pad rows / cols stay 0
+            self.del_full = torch.zeros((self.Br, ops.round_up(V * Mx, 64)), dtype=BF16, device=dev)
+            self.dgl, self.del_ = self.dgl_full[:B], self.del_full[:B]
+            self.partial_ws = torch.empty(2 * ((V * (Mx + 1) + 255) // 256) * ((K + 255) // 256), dtype=F32, device=dev)
             self.dglT = torch.empty((V * (Mx + 1), self.Bp), dtype=BF16, device=dev)
             self.delT = torch.empty((V * Mx, self.Bp), dtype=BF16, device=dev)
             self.xT = torch.empty((K, self.Bp), dtype=BF16, device=dev)
@@ -300,8 +304,36 @@ class MoeHead:
         ops.moe_tail_fwd(self.gate_logits, self.expert_logits, B, V, Mx, self.pred, self.rowsum)
         return self.pred
 
-    def backward(self, dpred, dx_init=None):
-        """Returns dx [B,K] f32 (= dx_init + MoE contribution) and writes the three weight grads."""
+    def can_fuse_update(self):
+        """evc_moe_grad_update's shape constraints (the reference sizes satisfy them: 14148, 9432, 4096)."""
+        return (self.V * (self.Mx + 1)) % 4 == 0 and (self.V * self.Mx) % 4 == 0 and self.K % 8 == 0
+
+    def fused_update(self, lr_t, clip_norm, l2_coeff, beta1=0.9, beta2=0.999, eps=1e-8, gather_fn=None):
+        """Weight gradient + per-tensor clip + TF-Adam + both bf16 shadows of the two MoE weight matrices from the
+        factors dlogits / x left by backward(weight_grads=False), without materialising the gradients
+        (evc_moe_grad_update); the expert biases go the ordinary way (column sums, then clip + Adam).
+        gather_fn (data parallel): all-gathers a [rows, cols] bf16 factor image over the ranks along the rows -
+        the contraction over world x batch rows IS the summed gradient, so no gradient all-reduce is needed."""
+        tw, V, Mx, K = self.tw, self.V, self.Mx, self.K
+        dgl, del_, x = self.dgl_full, self.del_full, self.x_full
+        if gather_fn is not None:
+            dgl, del_, x = gather_fn(dgl), gather_fn(del_), gather_fn(x)
+        rows = x.shape[0]
+        idx = {k: i for i, k in enumerate(tw.names)}
+        st = tw.store
+        for name, dlog, Vn in ((self.GATES, dgl, V * (Mx + 1)), (self.EXPERTS, del_, V * Mx)):
+            ops.moe_grad_update(dlog, x, rows, Vn, K, st.p(name), st.view(st.m, name), st.view(st.v, name),
+                                tw.shadow_fwd[name], tw.shadow_bwd[name], l2_coeff if name in tw.l2_names else 0.0,
+                                tw.sums[idx[name]], self.partial_ws, clip_norm, lr_t, beta1, beta2, eps)
+        gb = st.g(self.EBIAS)
+        ops.colsum_bf16(del_, rows, V * Mx, gb)
+        ops.grad_sqnorm(gb, st.p(self.EBIAS), 0.0, tw.sums[idx[self.EBIAS]])
+        ops.clip_adam_step(st.p(self.EBIAS), gb, st.view(st.m, self.EBIAS), st.view(st.v, self.EBIAS), 0.0,
+                           tw.sums[idx[self.EBIAS]], clip_norm, lr_t, beta1, beta2, eps)
+
+    def backward(self, dpred, dx_init=None, weight_grads=True):
+        """Returns dx [B,K] f32 (= dx_init + MoE contribution) and writes the three weight grads
+        (weight_grads=False: leaves only the factors for fused_update)."""
         tw, B, V, Mx, K = self.tw, self.B, self.V, self.Mx, self.K
         ops.moe_tail_bwd(self.gate_logits, self.expert_logits, dpred, B, V, Mx, self.dgl, self.del_)
         V3p, V2p = self.dgl.shape[1], self.del_.shape[1]
@@ -311,6 +343,8 @@ class MoeHead:
             self.dx.copy_(dx_init)
             ops.gemm_nt(self.dgl, tw.shadow_bwd[self.GATES], B, K, V3p, self.dx, accumulate=True)
         ops.gemm_nt(self.del_, tw.shadow_bwd[self.EXPERTS], B, K, V2p, self.dx, accumulate=True)
+        if not weight_grads:
+            return self.dx
         Bp = self.Bp
         ops.transpose_to_bf16(self.dgl, B, V * (Mx + 1), self.dglT, Bp)
         ops.transpose_to_bf16(self.del_, B, V * Mx, self.delT, Bp)
@@ -528,7 +562,9 @@ class HLstmTower(TowerBase):
         moe_lo = st.offsets[self.GATES]
         return (moe_lo, st.total), (l2_lo, moe_lo), (0, l2_lo)
 
-    def backward(self, dstate, dpred, on_moe_grads_ready=None, aux=None, early_apply=None, reduce_fn=None):
+    fused_moe_update = True      # recompute the rank-B MoE gradient inside the Adam step instead of materialising it
+
+    def backward(self, dstate, dpred, on_moe_grads_ready=None, aux=None, early_apply=None, reduce_fn=None, gather_fn=None):
         """dstate [B,2LH] f32 or None (gradient on the returned state), dpred [B,V] f32.
         Fills self.store.grad (every segment is overwritten).
         aux: side stream that takes the weight-gradient GEMMs (and, with early_apply =
@@ -536,7 +572,9 @@ class HLstmTower(TowerBase):
         off the BPTT critical path; it is joined into the current stream before returning.
         reduce_fn(lo, hi) -> work handle or None: data-parallel all-reduce of a gradient segment; with
         early_apply each group is reduced on the aux stream right after its gradients are final and updated
-        as soon as the collective has finished (the MoE segment - 2/3 of the bytes - travels under the BPTT)."""
+        as soon as the collective has finished.
+        gather_fn(t): data-parallel all-gather of a bf16 factor image along its rows; with it the MoE weights
+        (2/3 of the parameters) need no gradient all-reduce at all (MoeHead.fused_update)."""
         assert self.training
         main = torch.cuda.current_stream(self.device)
         g_moe, g_l2, g_l1 = self.param_groups()
@@ -549,7 +587,9 @@ class HLstmTower(TowerBase):
                     h.wait()                                           # the aux stream waits for the collective, not the host
             self.apply_group(names, *early_apply)
 
-        dS2 = self.moe.backward(dpred, dstate)
+        fuse = (aux is not None and early_apply is not None and self.fused_moe_update and self.precision == "bf16"
+                and self.moe.can_fuse_update() and (reduce_fn is None or gather_fn is not None))
+        dS2 = self.moe.backward(dpred, dstate, weight_grads=not fuse)
         if on_moe_grads_ready is not None:
             on_moe_grads_ready()
         if aux is not None and early_apply is not None:
@@ -557,8 +597,13 @@ class HLstmTower(TowerBase):
             ev = torch.cuda.Event()
             ev.record(main)
             aux.wait_event(ev)
-            with torch.cuda.stream(aux):
-                reduce_then_apply(g_moe, seg_moe)                      # 2/3 of the parameters, under the LSTM BPTT
+            with torch.cuda.stream(aux):                               # 2/3 of the parameters, under the LSTM BPTT
+                if fuse:
+                    lr, clip, l2c = early_apply
+                    t = self.adam_t
+                    self.moe.fused_update(lr * math.sqrt(1.0 - 0.999 ** t) / (1.0 - 0.9 ** t), clip, l2c, gather_fn=gather_fn)
+                else:
+                    reduce_then_apply(g_moe, seg_moe)
         dS1 = self.l2.backward(dS2, need_dx=True, aux=aux)              # [C*B][2LH] = d(L1 final state)
         if aux is not None and early_apply is not None:
             with torch.cuda.stream(aux):                               # after L2's weight-gradient GEMMs (same stream)

@@ -218,6 +218,14 @@ def moe_tail_bwd(gate_logits, expert_logits, dpred, B, V, M, dgate, dexpert):
               _p(dexpert), dexpert.stride(0), _stream())
 
 
+def moe_grad_update(dlogits, x, rows, V, K, p, m, v, p_bf16, pT_bf16, l2_coeff, sums, partial_ws, clip_norm, lr_t,
+                    beta1=0.9, beta2=0.999, eps=1e-8):
+    """Fused weight-gradient + per-tensor clip + TF-Adam of one MoE weight matrix (evc_moe_grad_update)."""
+    _lib.call("evc_moe_grad_update", _p(dlogits), dlogits.stride(0), _p(x), x.stride(0), rows, V, K, _p(p), _p(m), _p(v),
+              _p(p_bf16), _p(pT_bf16), pT_bf16.stride(0), l2_coeff, _p(sums), _p(partial_ws), clip_norm, lr_t, beta1, beta2, eps,
+              _stream())
+
+
 def ce_loss(pred, labels_u8, loss, dpred=None, grad_scale=1.0, accumulate_grad=False):
     B, V = pred.shape
     _lib.call("evc_ce_loss", _p(pred), _p(labels_u8), B, V, grad_scale, _p(loss), _p(dpred), 1 if accumulate_grad else 0, _stream())

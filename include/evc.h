@@ -168,6 +168,21 @@ int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int T, int M, i
                        const evc_bf16* dh_above, float* dc_ws, evc_bf16* dz4,
                        const int32_t* row_map, const int32_t* rows_per_step, void* stream);
 
+/* ---- a5 + a8 + a9 fused: MoE weight update without materialising the gradient ----------------
+ * d(loss)/dW of slim.fully_connected (cs/video_level_models.py:423-435) is dlogits^T . x over the batch rows:
+ * rank = batch.  For W [V][K] (stored transposed, the forward B operand) this entry point recomputes the
+ * gradient tile from the factors twice: pass 1 accumulates sum (g + l2 W)^2 and sum W^2 into sums[0..1]
+ * (fixed summation order), pass 2 applies tf.clip_by_norm(clip_norm) and the TF-Adam step in the GEMM
+ * epilogue, writing W, m, v, the bf16 forward shadow p_bf16 [V][K] and the bf16 transposed shadow
+ * pT_bf16 [K][ldT] (30 bytes of HBM traffic per parameter instead of 46 with a materialised gradient).
+ *   dlogits [rows][ld_dlogits] bf16 (columns >= V zero), x [rows][ldx] bf16, rows % 32 == 0 (zero rows pad);
+ *   under data parallelism rows = world x batch: the all-gathered factors replace the gradient all-reduce.
+ *   partial_ws: 2 * ceil(V/256) * ceil(K/256) floats of scratch.  V % 4 == 0, K % 8 == 0. */
+int evc_moe_grad_update(const evc_bf16* dlogits, int64_t ld_dlogits, const evc_bf16* x, int64_t ldx, int rows,
+                        int V, int K, float* p, float* m, float* v, evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT,
+                        float l2_coeff, float* sums, float* partial_ws, float clip_norm, float lr_t,
+                        float beta1, float beta2, float eps, void* stream);
+
 /* ---- layout helpers --------------------------------------------------------
  * out[c][r] = in[r][c], r < R, c < C; out has ld_out >= Rpad columns and
  * columns [R, Rpad) are zero-filled (Rpad % 64 == 0 keeps GEMM K aligned).
