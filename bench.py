@@ -96,10 +96,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook (tests/test_gpu_dp.py): several ranks on ONE GPU over gloo, to exercise this file's multi-rank
+    # path on a single-GPU box (RCCL refuses two ranks per device).  Never set in a real run.
+    if os.environ.get("EVC_BENCH_SHARED_GPU") == "1":
+        local_rank = 0
     if world > 1:
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("EVC_BENCH_SHARED_GPU") == "1":
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     n_gpus = world if world > 1 else 1
     device = "cuda:%d" % local_rank
     torch.cuda.set_device(local_rank)

@@ -6,6 +6,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -78,3 +79,21 @@ def test_two_rank_data_parallel_matches_single_process(tmp_path):
             worst = max(worst, d)
             assert d < 2e-4, (k, d)
     print("max weight difference single vs 2-rank:", worst)
+
+
+def test_bench_multi_rank_path_runs(tmp_path):
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank),
+    here with two ranks sharing the GPU over gloo: rank 0 prints the one JSON line with whole-job throughput."""
+    import json
+    env = dict(os.environ, EVC_BENCH_SHARED_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "16", "--pool", "2", "--no_cpu_baseline"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 32 and d["value"] > 0 and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 16 * 300 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert all(np.isfinite(v) for v in d["losses"].values())
