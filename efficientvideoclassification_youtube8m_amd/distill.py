@@ -108,6 +108,28 @@ class GradReducer:
         self._pending = []
 
 
+def frame_counts_and_plans(g, num_frames, nh, need_teacher, need_student):
+    """Frame counts (device) and the L1 row plans of both towers of graph ``g`` (DistillGraph / EvalGraph): rows
+    sorted by length so the padding rows drop out of every L1 kernel (ops.RowPlan).  Host twins of the counts
+    give the launch geometry.  Returns ((len_l1, len_l2, plan) | None, (n_student, len_l1, len_l2, plan) | None)."""
+    t = s = None
+    if need_teacher:
+        _, l1, l2 = ops.frame_counts(num_frames, 1, g.C1, g.max_frames // g.C1, g.max_frames)
+        plan = None
+        if g.row_plans:
+            _, l1h, _ = ops.host_frame_counts(nh, 1, g.C1, g.max_frames // g.C1, g.max_frames)
+            plan = ops.RowPlan(l1, l1h, g.max_frames // g.C1)
+        t = (l1, l2, plan)
+    if need_student:
+        n_s, l1s, l2s = ops.frame_counts(num_frames, g.every_n, g.C2, g.S // g.C2, g.max_frames)
+        plan = None
+        if g.row_plans:
+            _, l1h, _ = ops.host_frame_counts(nh, g.every_n, g.C2, g.S // g.C2, g.max_frames)
+            plan = ops.RowPlan(l1s, l1h, g.S // g.C2)
+        s = (n_s, l1s, l2s, plan)
+    return t, s
+
+
 class DistillGraph:
     """mode: 'teacher_student' (train.py), 'teacher' (teacher only, BASELINE cfg 2),
     'student' (train_finetune.py)."""
@@ -193,26 +215,6 @@ class DistillGraph:
             ev.record(stream)
             self.debug_marks.append((name, ev))
 
-    def _plans(self, num_frames, nh, need_teacher, need_student):
-        """Frame counts (device) and the L1 row plans of both towers: rows sorted by length so the padding
-        rows drop out of every L1 kernel (ops.RowPlan).  Host twins of the counts give the launch geometry."""
-        t = s = None
-        if need_teacher:
-            _, l1, l2 = ops.frame_counts(num_frames, 1, self.C1, self.max_frames // self.C1, self.max_frames)
-            plan = None
-            if self.row_plans:
-                _, l1h, _ = ops.host_frame_counts(nh, 1, self.C1, self.max_frames // self.C1, self.max_frames)
-                plan = ops.RowPlan(l1, l1h, self.max_frames // self.C1)
-            t = (l1, l2, plan)
-        if need_student:
-            n_s, l1s, l2s = ops.frame_counts(num_frames, self.every_n, self.C2, self.S // self.C2, self.max_frames)
-            plan = None
-            if self.row_plans:
-                _, l1h, _ = ops.host_frame_counts(nh, self.every_n, self.C2, self.S // self.C2, self.max_frames)
-                plan = ops.RowPlan(l1s, l1h, self.S // self.C2)
-            s = (n_s, l1s, l2s, plan)
-        return t, s
-
     def _step(self, x_raw, labels_u8, num_frames, apply=True, nh=None):
         """x_raw [B,300,F] f32 (or uint8), labels_u8 [B,V] uint8, num_frames [B] int32.
         Returns a dict mirroring the graph collections the reference's loop
@@ -230,7 +232,7 @@ class DistillGraph:
             self._dp_s = torch.empty((B, V), dtype=F32, device=dev)
         need_student = self.student is not None
         main = torch.cuda.current_stream(dev)
-        tp, sp = self._plans(num_frames, nh, self.teacher is not None, need_student)
+        tp, sp = frame_counts_and_plans(self, num_frames, nh, self.teacher is not None, need_student)
         xt, xs = ops.l2norm_chunk(x_raw, self.C1, self.every_n if need_student else None, self.C2,
                                   num_frames=num_frames if x_raw.dtype == torch.uint8 else None,
                                   split=self.precision == "high", plan1=tp[2] if tp else None, plan2=sp[3] if sp else None)
@@ -409,7 +411,7 @@ class EvalGraph:
         main = torch.cuda.current_stream(self.device)
         split = self.precision == "high"
         u8 = x_raw.dtype == torch.uint8
-        tp, sp = DistillGraph._plans(self, num_frames, nh, self.teacher is not None, True)
+        tp, sp = frame_counts_and_plans(self, num_frames, nh, self.teacher is not None, True)
         xt, xs = ops.l2norm_chunk(x_raw, self.C1, self.every_n, self.C2, num_frames=num_frames if u8 else None, split=split,
                                   plan1=tp[2] if tp else None, plan2=sp[3])
         self.losses.zero_()

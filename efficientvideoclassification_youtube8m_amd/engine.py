@@ -418,12 +418,16 @@ class TowerBase:
         self.adam_t += 1
         self.sums.zero_()
 
+    def adam_lr_t(self, lr, beta1=0.9, beta2=0.999):
+        """TF-Adam's bias-corrected step size at the current step count (tf.train.AdamOptimizer defaults)."""
+        t = self.adam_t
+        return lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+
     def apply_group(self, names, lr, clip_norm=1.0, l2_coeff=0.0, beta1=0.9, beta2=0.999, eps=1e-8, refresh=True):
         """Per-tensor clip_by_norm + TF-Adam for a subset of the variables (their gradients must be
         final).  slim create_train_op semantics (cs/train.py:329-334); the l2 regulariser gradient
         (regularization_penalty * 1e-8 * W) is folded into the gradient before the norm."""
-        t = self.adam_t
-        lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+        lr_t = self.adam_lr_t(lr, beta1, beta2)
         idx = {k: i for i, k in enumerate(self.names)}
         for k in names:
             l2 = l2_coeff if k in self.l2_names else 0.0
@@ -600,8 +604,7 @@ class HLstmTower(TowerBase):
             with torch.cuda.stream(aux):                               # 2/3 of the parameters, under the LSTM BPTT
                 if fuse:
                     lr, clip, l2c = early_apply
-                    t = self.adam_t
-                    self.moe.fused_update(lr * math.sqrt(1.0 - 0.999 ** t) / (1.0 - 0.9 ** t), clip, l2c, gather_fn=gather_fn)
+                    self.moe.fused_update(self.adam_lr_t(lr), clip, l2c, gather_fn=gather_fn)
                 else:
                     reduce_then_apply(g_moe, seg_moe)
         dS1 = self.l2.backward(dS2, need_dx=True, aux=aux)              # [C*B][2LH] = d(L1 final state)
