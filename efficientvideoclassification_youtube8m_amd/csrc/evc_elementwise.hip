@@ -261,9 +261,12 @@ __global__ __launch_bounds__(256) void transpose_kernel(const void* __restrict__
   const bool vec_in = (ld_in % 4 == 0) && (((uintptr_t)in) % (F32 ? 16 : 8) == 0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int r = r0 + p + 16 * i, c = c0 + q * 4;
+    // il_H > 0: the tile's rows are 64 consecutive OUTPUT columns u*4 + g, i.e. input rows g*H + u (16 units x
+    // 4 gate blocks) - so the stores below stay contiguous 8-byte vectors (scattered 2-byte stores ran at 0.8 TB/s)
+    const int ro = r0 + p + 16 * i, c = c0 + q * 4;
+    const int r = (il_H > 0 && ro < R) ? (ro & 3) * il_H + (ro >> 2) : ro;
     bf16_t v[4] = {0, 0, 0, 0};
-    if (r < R) {
+    if (ro < R) {
       if (vec_in && c + 3 < C) {
         if (F32) {
           const float4 f = *(const float4*)((const float*)in + (long)r * ld_in + c);
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const void* __restrict__
     *(ushort4*)&tile[p + 16 * i][q * 4] = make_ushort4(v[0], v[1], v[2], v[3]);
   }
   __syncthreads();
-  const bool vec_out = (ld_out % 4 == 0) && (((uintptr_t)out) % 8 == 0) && il_H <= 0;
+  const bool vec_out = (ld_out % 4 == 0) && (((uintptr_t)out) % 8 == 0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = c0 + p + 16 * i, r = r0 + q * 4;   // output row c (input column), 4 consecutive output columns r..r+3
@@ -295,9 +298,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const void* __restrict__
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int rr = r + j;
-        // il_H > 0: input row rr = g*H + u lands in output column u*4 + g (gate-interleaved K order)
-        const int ro = (il_H > 0 && rr < 4 * il_H) ? (rr % il_H) * 4 + rr / il_H : rr;
-        if (rr < Rpad) out[(long)co * ld_out + ro] = tile[q * 4 + j][cl];
+        if (rr < Rpad) out[(long)co * ld_out + rr] = tile[q * 4 + j][cl];
       }
     }
   }
