@@ -665,13 +665,16 @@ struct LstmBwdParams {
   float* dc_ws;             // [M][H]
   uint2* dz4;               // slab t [M][H] gate-interleaved: 4 bf16 (dz_i, dz_j, dz_f, dz_o) per (row, unit)
   const int* row_map;       // slot -> row of dS_c / dS_h (row plan) or NULL
+  float* db;                // [4H] bias gradient (TF gate order), accumulated with atomics over rows and steps, or NULL
   int m_active;             // rows [m_active, M) are inactive at this step: tiles entirely beyond it only zero dz
   int M, H;
 };
 
 // Gate derivative of one (row, 4 consecutive units): dh[4] = what flowed back through the recurrent
 // product; writes dz (4 x 8 bytes), carries dc in dc_ws.
-__device__ __forceinline__ void lstm_bwd_tail(const LstmBwdParams& e, const int m, const int u, const float (&dh_in)[4]) {
+// dzv[unit][gate] receives the (unrounded) f32 gate gradients - zeros for an inactive row - for the bias gradient.
+__device__ __forceinline__ void lstm_bwd_tail(const LstmBwdParams& e, const int m, const int u, const float (&dh_in)[4],
+                                              float (&dzv)[4][4]) {
   const int H = e.H;
   const int ln = e.len[m];
   const long hu = (long)m * H + u;
@@ -679,6 +682,10 @@ __device__ __forceinline__ void lstm_bwd_tail(const LstmBwdParams& e, const int 
   if (e.t >= ln) {  // inactive: state passes through, no gate gradient
     dzp[0] = make_uint4(0u, 0u, 0u, 0u);
     dzp[1] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) dzv[r][g] = 0.f;
     return;
   }
   const bool last = (e.t == ln - 1);
@@ -719,8 +726,9 @@ __device__ __forceinline__ void lstm_bwd_tail(const LstmBwdParams& e, const int 
     const float cp = coa[r];
     const float dc = dci[r] + dh[r] * go * (1.f - tcv * tcv);
     dcn[r] = dc * gf;
-    dzr[r] = make_uint2(pack_bf16x2(dc * gj * gi * (1.f - gi), dc * gi * (1.f - gj * gj)),
-                        pack_bf16x2(dc * cp * gf * (1.f - gf), dh[r] * tcv * go * (1.f - go)));
+    dzv[r][0] = dc * gj * gi * (1.f - gi); dzv[r][1] = dc * gi * (1.f - gj * gj);
+    dzv[r][2] = dc * cp * gf * (1.f - gf); dzv[r][3] = dh[r] * tcv * go * (1.f - go);
+    dzr[r] = make_uint2(pack_bf16x2(dzv[r][0], dzv[r][1]), pack_bf16x2(dzv[r][2], dzv[r][3]));
   }
   *(float4*)(e.dc_ws + hu) = make_float4(dcn[0], dcn[1], dcn[2], dcn[3]);
   dzp[0] = make_uint4(dzr[0].x, dzr[0].y, dzr[1].x, dzr[1].y);
@@ -756,6 +764,11 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_bwd_step_kernel(GemmOperands p, 
   for (int ni = 0; ni < Cfg::NI; ++ni) {
     const int u = u0 + tc.unit0 + ni * 16;
     if (u >= e.H) continue;
+    float bs[4][4];                                    // this lane's column sums over its rows: [unit][gate]
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bs[r][g] = 0.f;
 #pragma unroll
     for (int mi = 0; mi < Cfg::MI; ++mi) {
       const int m = m0 + tc.row0 + mi * 16;
@@ -764,8 +777,23 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_bwd_step_kernel(GemmOperands p, 
 #ifdef EVC_ABLATE_BWD_EPI     // debug build: main loop only (keep the accumulators alive, store nothing)
       asm volatile("" :: "v"(dh[0]), "v"(dh[1]), "v"(dh[2]), "v"(dh[3]));
 #else
-      lstm_bwd_tail(e, m, u, dh);
+      float dzv[4][4];
+      lstm_bwd_tail(e, m, u, dh, dzv);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bs[r][g] += dzv[r][g];
 #endif
+    }
+    if (e.db) {                                        // bias gradient: the 16 lanes l&15 hold 16 rows of the same 4 units
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float v = bs[r][g];
+          v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+          if ((threadIdx.x & 15) == 0) atomicAdd(e.db + (long)g * e.H + u + r, v);
+        }
     }
   }
 }
@@ -846,8 +874,13 @@ __global__ __launch_bounds__(64 * KW) void lstm_bwd_step_skinny_kernel(GemmOpera
 #pragma unroll
       for (int r = 0; r < 4; ++r) part[wave][i * 16 + fq * 4 + r][j * 16 + fr] = acc[i][j][r];
   __syncthreads();
+  const int row = (threadIdx.x >> 3) & 31, ug = (threadIdx.x & 7) * 4;
+  float dzv[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) dzv[r][g] = 0.f;
   if (threadIdx.x < 256) {
-    const int row = threadIdx.x >> 3, ug = (threadIdx.x & 7) * 4;
     float4 s = *(const float4*)&part[0][row][ug];
 #pragma unroll
     for (int w = 1; w < KW; ++w) {
@@ -857,11 +890,25 @@ __global__ __launch_bounds__(64 * KW) void lstm_bwd_step_skinny_kernel(GemmOpera
     const int m = m0 + row, u = u0 + ug;
     if (m < e.M && u < e.H) {
       const float dh[4] = {s.x, s.y, s.z, s.w};
-#ifdef EVC_ABLATE_SKINNY_TAIL
-      *(float4*)(e.dc_ws + (long)m * e.H + u) = s;
-#else
-      lstm_bwd_tail(e, m, u, dh);
-#endif
+      lstm_bwd_tail(e, m, u, dh, dzv);
+    }
+  }
+  if (e.db) {            // bias gradient (e.db is a kernel argument: uniform branch): column sums of the tile's 32 rows
+    __syncthreads();     // every partial has been read
+    float* cs = &part[0][0][0];                        // [32 rows][128 = 32 units x 4 gates]
+    if (threadIdx.x < 256) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) cs[row * 128 + (ug + r) * 4 + g] = dzv[r][g];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      float v = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 32; ++r) v += cs[r * 128 + threadIdx.x];
+      const int u = u0 + (threadIdx.x >> 2), g = threadIdx.x & 3;
+      if (u < e.H) atomicAdd(e.db + (long)g * e.H + u, v);
     }
   }
 }
@@ -881,7 +928,7 @@ typedef TileCfg2<192, 1, 128, 2, 4, 5, true> CfgBwdV2_192;
 
 extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int T, int M, int Kin, int H,
                                   const void* gates, const evc_bf16* c_all, const float* dS_c, const float* dS_h, int64_t ld_dS,
-                                  const evc_bf16* dh_above, float* dc_ws, evc_bf16* dz4,
+                                  const evc_bf16* dh_above, float* dc_ws, evc_bf16* dz4, float* db,
                                   const int32_t* row_map, const int32_t* rows_per_step, void* stream) {
   EVC_REQUIRE(T > 0 && M > 0 && H > 0 && Kin > 0 && H % 64 == 0, EVC_ERR_BAD_SHAPE, "evc_lstm_layer_bwd: bad shape");
   EVC_REQUIRE(gates && c_all && ((uintptr_t)gates % 16) == 0 && ((uintptr_t)c_all % 8) == 0 && ((uintptr_t)dz4 % 16) == 0,
@@ -924,7 +971,7 @@ extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int 
     e.dS_c = dS_c; e.dS_h = dS_h; e.ld_dS = ld_dS;
     e.dh_above = dh_above ? dh_above + (long)t * M * H : nullptr;
     e.dc_ws = dc_ws; e.dz4 = (uint2*)dz4 + (long)t * M * H;
-    e.row_map = row_map; e.m_active = Mt;
+    e.row_map = row_map; e.db = db; e.m_active = Mt;
     e.M = M; e.H = H;
     switch (pick) {
       case 0: launch_lstm_bwd<CfgBwdV2_192>(p, e, k1, st); break;

@@ -201,9 +201,11 @@ class LstmStack:
             kin = self.kin[l]
             KP = self.KP
             dz = self._v(self.dz[l], T, M, 4 * H)
+            gb = tw.store.g(bn)                                     # bias gradient: summed inside the step kernels
+            ops.fill_f32(gb, 0.0)
             ops.lstm_layer_bwd(w, self.lens, T, M, kin, H, self._v(self.gates[l], T, M, H, 2), self._v(self.c_all[l], T + 1, M, H),
                                dS[:, (2 * l) * H:], dS[:, (2 * l + 1) * H:], 2 * L * H,
-                               dh_above, self._v(self.dc_ws, M, H), dz, plan=plan)
+                               dh_above, self._v(self.dc_ws, M, H), dz, plan=plan, db=gb)
             dz2 = dz.view(T * M, 4 * H)
             # gradient wrt the layer input, all T at once (hoisted): dX = dz . Wx^T
             if l > 0:
@@ -234,7 +236,6 @@ class LstmStack:
                     ops.fill_f32(gW, 0.0)
                     ops.gemm_tn(dz2, layer_in, 4 * H, kin, T * M, gW, row_interleave_H=H, ldc=kin + H, accumulate=True)
                     ops.gemm_tn(dz2, h_prev, 4 * H, H, T * M, gW[:, kin:], row_interleave_H=H, ldc=kin + H, accumulate=True)
-                    ops.colsum_bf16(dz2, T * M, 4 * H, tw.store.g(bn), deinterleave_H=H)
                 else:   # T*M not a multiple of 32: transposed copies + NT products
                     ops.transpose_to_bf16(dz2, T * M, 4 * H, self.dzT, KP, interleave_H=-H)
                     inT = self.xT[:kin]
@@ -242,7 +243,6 @@ class LstmStack:
                     ops.transpose_to_bf16(h_prev, T * M, H, self.hT_ws, KP)
                     ops.gemm_nt(self.dzT, inT, 4 * H, kin, KP, gW, ldc=kin + H)
                     ops.gemm_nt(self.dzT, self.hT_ws, 4 * H, H, KP, gW[:, kin:], ldc=kin + H)
-                    ops.rowsum_bf16(self.dzT, 4 * H, KP, tw.store.g(bn))
         return dx_out
 
 

@@ -203,9 +203,10 @@ def lstm_layer_fwd_hp(x, x_lo, wT, wT_lo, bias, lens, T, M, Kin, H, hbuf, hbuf_l
               _p(hbuf), _p(hbuf_lo), _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_all), *_plan_args(plan), _stream())
 
 
-def lstm_layer_bwd(w_il, lens, T, M, Kin, H, gates, c_all, dS_c, dS_h, ld_dS, dh_above, dc_ws, dz4, plan=None):
+def lstm_layer_bwd(w_il, lens, T, M, Kin, H, gates, c_all, dS_c, dS_h, ld_dS, dh_above, dc_ws, dz4, plan=None, db=None):
+    """db [4H] f32: the bias gradient is accumulated into it (zero it first) - no separate column-sum pass."""
     _lib.call("evc_lstm_layer_bwd", _p(w_il), _p(lens), T, M, Kin, H, _p(gates), _p(c_all), _p(dS_c), _p(dS_h), ld_dS,
-              _p(dh_above), _p(dc_ws), _p(dz4), *_plan_args(plan), _stream())
+              _p(dh_above), _p(dc_ws), _p(dz4), _p(db), *_plan_args(plan), _stream())
 
 
 # ---------------------------------------------------------------------------

@@ -159,13 +159,15 @@ int evc_lstm_layer_fwd_hp(const evc_bf16* x, const evc_bf16* x_lo, const evc_bf1
  *        t >= len); viewed as [T*M][4H] it is the A operand of dz . W^T with w_il.
  *        (evc_transpose_to_bf16(dz4, ..., interleave_H=-H) gives dz^T in TF gate order for the
  *        weight-gradient GEMM; writing it from this kernel's epilogue was measured 2.4x slower.)
+ * db   [4H] f32 or NULL: bias gradient (TF gate order), ACCUMULATED into (caller zeroes it) with f32 atomics from
+ *        the unrounded gate gradients of every active (row, step) - BiasAddGrad without another pass over dz.
  * Row plan (see evc_lstm_layer_fwd): rows_per_step [T] host counts, row_map = the row of dS_c / dS_h of each
  *        slot.  Every dz4 row is still written (zeros beyond the active prefix), because the
  *        weight-gradient products contract over all T*M rows.
  */
 int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int T, int M, int Kin, int H,
                        const void* gates, const evc_bf16* c_all, const float* dS_c, const float* dS_h, int64_t ld_dS,
-                       const evc_bf16* dh_above, float* dc_ws, evc_bf16* dz4,
+                       const evc_bf16* dh_above, float* dc_ws, evc_bf16* dz4, float* db,
                        const int32_t* row_map, const int32_t* rows_per_step, void* stream);
 
 /* ---- a5 + a8 + a9 fused: MoE weight update without materialising the gradient ----------------

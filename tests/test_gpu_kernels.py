@@ -94,7 +94,8 @@ def test_lstm_layer_fwd_and_bwd(ops, M, T, Kin, H, hoist):
     dha = to_bf16(dh_above)
     dz4 = torch.full((T, M, 4 * H), float("nan"), dtype=torch.bfloat16, device=DEV)
     dcw = torch.empty((M, H), dtype=torch.float32, device=DEV)
-    ops.lstm_layer_bwd(w_il, ln, T, M, Kin, H, gates, c_all, dSt[:, :H], dSt[:, H:], 2 * H, dha, dcw, dz4)
+    dbk = torch.zeros(4 * H, dtype=torch.float32, device=DEV)           # bias gradient accumulated by the step kernels
+    ops.lstm_layer_bwd(w_il, ln, T, M, Kin, H, gates, c_all, dSt[:, :H], dSt[:, H:], 2 * H, dha, dcw, dz4, db=dbk)
     dzf = dz4.float().cpu().double().numpy()
     assert np.isfinite(dzf).all()
     for t in range(T):
@@ -125,6 +126,8 @@ def test_lstm_layer_fwd_and_bwd(ops, M, T, Kin, H, hoist):
     ops.rowsum_bf16(dzT, 4 * H, KP, db)
     sc = np.abs(grads_ref[0][1]).max() + 1e-6
     assert np.max(np.abs(db.cpu().double().numpy() - grads_ref[0][1])) / sc < 2e-2
+    assert np.max(np.abs(dbk.cpu().double().numpy() - grads_ref[0][1])) / sc < 2e-2      # in-kernel sum (f32, unrounded dz)
+    assert (dbk - db).abs().max().item() / sc < 5e-3
     # the shadow-weight builder produces exactly this interleaved layout
     sb = torch.empty((Kin + H, 4 * H), dtype=torch.bfloat16, device=DEV)
     ops.transpose_to_bf16(wT, 4 * H, Kin + H, sb, 4 * H, interleave_H=H)
