@@ -150,6 +150,12 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     losses = graph.loss_report()
+    # GAP@20 (cs/eval_util.py:61-79) of the last step's predictions, outside the timed region: the second half of
+    # BASELINE's metric name; on synthetic labels it only shows that the metric path runs on the step's outputs.
+    from efficientvideoclassification_youtube8m_amd import eval_util
+    tower = graph.student if graph.student is not None else graph.teacher
+    last_labels = pool[(it - 1) % len(pool)][2]
+    gap20 = float(eval_util.calculate_gap(tower.pred.float().cpu().numpy(), last_labels.float().cpu().numpy(), top_k=20))
 
     # ---- roofline of the dominant kernel: the fused LSTM forward step of the teacher's L1 ---------
     # lstm_fwd_step_kernel<TileCfg2<BM,4,64,..>> (30 launches per iteration, the largest FLOP share of the
@@ -189,7 +195,7 @@ def main():
                        "num_frames": "all 300" if args.all_full else "U{120..300}",
                        "tflop_per_step_per_gpu": round(3 * B * ((11.748 if graph.teacher else 0) + (
                            (1.525 if args.every_n == 10 else 0.833) if graph.student else 0)) / 1e3, 3)},
-            "losses": {k: round(v, 4) for k, v in losses.items()},
+            "losses": {k: round(v, 4) for k, v in losses.items()}, "gap_at_20_last_batch": round(gap20, 6),
             "roofline": roofline,
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
