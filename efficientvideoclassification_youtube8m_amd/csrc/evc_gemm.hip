@@ -247,6 +247,17 @@ extern "C" int evc_gemm_tn(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
   EVC_REQUIRE(row_interleave_H == 0 || M == 4 * row_interleave_H, EVC_ERR_BAD_SHAPE, "evc_gemm_tn: row_interleave_H needs M == 4*H");
   hipStream_t st = (hipStream_t)stream;
   GemmOperandsT p{A, lda, B, ldb, M, N, K / 32};
+  typedef TileCfg2<128, 1, 128, 2, 4, 5, true> CfgTn128;
+  // short contractions (the student's L2: K = 5 x 256 rows) on 128x128 tiles without split-K: the atomic join of
+  // 256x256 partial tiles costs more than the product itself there (81 -> 36 us at 4096 x 1024 x 1280); from
+  // K ~ 5000 on the 256x256 split-K form is faster again (92 vs 99 us)
+  if (forced_tile() == 11 || (forced_tile() == 0 && K <= 2048 && (long)ceil_div(M, 128) * ceil_div(N, 128) >= 192)) {
+    const int tm1 = ceil_div(M, 128), tn1 = ceil_div(N, 128);
+    StoreParamsT s1{C, ldc, M, N, row_interleave_H, accumulate, 1, p.nk};
+    launch_cfg<CfgTn128>(gemm_tn_kernel<CfgTn128>, tm1 * tn1, st, p, s1, tm1, tn1);
+    EVC_LAUNCH_CHECK();
+    return EVC_OK;
+  }
   const int tm = ceil_div(M, CfgPlainV2::BM), tn = ceil_div(N, CfgPlainV2::BU);
   int splits = 256 / (tm * tn);
   if (splits > K / 1024) splits = K / 1024;     // keep >= 32 K steps per split
