@@ -120,6 +120,7 @@ typedef TileCfg<128, 1, 128, 2, 2> CfgPlainBig;   // 128x128, 4 waves, 4x4 MFMA 
 typedef TileCfg<64, 1, 64, 2, 2> CfgPlainSmall;   // 64x64 for skinny problems
 typedef TileCfg<32, 1, 32, 2, 2> CfgPlainTiny;    // 32x32: M ~ batch recurrent steps (256 workgroups at M=256, H=1024)
 typedef TileCfg2<256, 1, 256, 2, 4, 5, true> CfgPlainV2;   // 256x256, 8 waves (2x4), 128x64 per wave, 5-deep ring (160 KiB)
+typedef TileCfg2<128, 1, 128, 2, 4, 5, true> CfgTn128;     // 128x128 v2 tile (80 KB ring: two workgroups per CU)
 typedef TileCfg2<256, 1, 64, 2, 4, 5, true> CfgTallV2;     // 256x64: M <= 256 (batch-row) products against a long weight matrix
 
 template <class Cfg>
@@ -303,6 +304,17 @@ __global__ __launch_bounds__(Cfg::NT) void moe_update_kernel(GemmOperandsT p, Mo
   gemm_mainloop_tn<Cfg, true>(p, m0, n0, lds_dyn, acc);
   TileCoordsT<Cfg> tc;
   const int K = u.K;
+  // Epilogue loads first, all of them (the stores of one fragment and the loads of the next go to the same
+  // arrays, so hipcc keeps them in program order and every fragment would wait for the previous one's stores:
+  // 8 x (load latency + store acknowledge) per workgroup; issued up front they overlap - 3.4 -> see DESIGN.md)
+  float4 pv[Cfg::MI][Cfg::NI];
+#pragma unroll
+  for (int mi = 0; mi < Cfg::MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < Cfg::NI; ++ni) {
+      const int vr = m0 + tc.row0 + mi * 16, k = n0 + tc.unit0 + ni * 16;
+      pv[mi][ni] = (vr < u.V && k < K) ? *(const float4*)(u.p + (long)vr * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   if (PASS == 1) {
     float sg = 0.f, sp = 0.f;
 #pragma unroll
@@ -312,8 +324,7 @@ __global__ __launch_bounds__(Cfg::NT) void moe_update_kernel(GemmOperandsT p, Mo
       for (int ni = 0; ni < Cfg::NI; ++ni) {
         const int k = n0 + tc.unit0 + ni * 16;
         if (vr >= u.V || k >= K) continue;
-        const float4 pv = *(const float4*)(u.p + (long)vr * K + k);
-        const float pa[4] = {pv.x, pv.y, pv.z, pv.w};
+        const float pa[4] = {pv[mi][ni].x, pv[mi][ni].y, pv[mi][ni].z, pv[mi][ni].w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float w = acc[mi][0][ni][r] + u.l2 * pa[r];
@@ -337,6 +348,16 @@ __global__ __launch_bounds__(Cfg::NT) void moe_update_kernel(GemmOperandsT p, Mo
     }
     return;
   }
+  float4 mv[Cfg::MI][Cfg::NI], vv[Cfg::MI][Cfg::NI];
+#pragma unroll
+  for (int mi = 0; mi < Cfg::MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < Cfg::NI; ++ni) {
+      const int vr = m0 + tc.row0 + mi * 16, k = n0 + tc.unit0 + ni * 16;
+      const bool ok = vr < u.V && k < K;
+      mv[mi][ni] = ok ? *(const float4*)(u.m + (long)vr * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      vv[mi][ni] = ok ? *(const float4*)(u.v + (long)vr * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   float scale = 1.f;
   if (u.clip > 0.f) scale = u.clip / fmaxf(sqrtf(u.sums[0]), u.clip);      // tf.clip_by_norm
   __syncthreads();                                     // every wave is done with the ring: reuse it for the transpose
@@ -352,8 +373,9 @@ __global__ __launch_bounds__(Cfg::NT) void moe_update_kernel(GemmOperandsT p, Mo
       bf16_t pb[4] = {0, 0, 0, 0};
       if (vr < u.V && k < K) {
         const long o = (long)vr * K + k;
-        const float4 pv = *(const float4*)(u.p + o), mv = *(const float4*)(u.m + o), vv = *(const float4*)(u.v + o);
-        const float pa[4] = {pv.x, pv.y, pv.z, pv.w}, ma[4] = {mv.x, mv.y, mv.z, mv.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+        const float pa[4] = {pv[mi][ni].x, pv[mi][ni].y, pv[mi][ni].z, pv[mi][ni].w};
+        const float ma[4] = {mv[mi][ni].x, mv[mi][ni].y, mv[mi][ni].z, mv[mi][ni].w};
+        const float va[4] = {vv[mi][ni].x, vv[mi][ni].y, vv[mi][ni].z, vv[mi][ni].w};
         float pn[4], mn[4], vn[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {                 // same operation order as clip_adam_kernel
@@ -373,13 +395,15 @@ __global__ __launch_bounds__(Cfg::NT) void moe_update_kernel(GemmOperandsT p, Mo
     }
   }
   __syncthreads();
-  // rows k of the transposed shadow: one wave-instruction moves a whole 256-v row (4 bf16 per lane)
+  // rows k of the transposed shadow: 4 bf16 per lane, BM/4 lanes per row, 64/(BM/4) rows per wave-instruction
+  constexpr int LPR = Cfg::BM / 4, RPW = 64 / LPR;
+  static_assert(LPR <= 64 && 64 % LPR == 0, "row of the transposed image must fit a wave");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int v4 = m0 + lane * 4;
-  for (int kl = wave; kl < Cfg::BU; kl += Cfg::NT / 64) {
+  const int v4 = m0 + (lane % LPR) * 4;
+  for (int kl = wave * RPW + lane / LPR; kl < Cfg::BU; kl += (Cfg::NT / 64) * RPW) {
     const int k = n0 + kl;
     if (k >= K || v4 >= u.V) continue;                 // V % 4 == 0: a lane's 4 rows are all valid or all not
-    const uint2 q = *(const uint2*)(tile + kl * PITCH + lane * 4);
+    const uint2 q = *(const uint2*)(tile + kl * PITCH + (lane % LPR) * 4);
     *(uint2*)(u.pT_bf16 + (long)k * u.ldT + v4) = q;
   }
 }
@@ -404,7 +428,9 @@ extern "C" int evc_moe_grad_update(const evc_bf16* dlogits, int64_t ld_dlogits, 
               ((uintptr_t)v % 16) == 0 && ((uintptr_t)p_bf16 % 8) == 0 && ((uintptr_t)pT_bf16 % 8) == 0, EVC_ERR_BAD_ALIGN,
               "evc_moe_grad_update: operand alignment / leading dimensions");
   hipStream_t st = (hipStream_t)stream;
-  typedef CfgPlainV2 Cfg;
+  // 128x128 tiles, two workgroups per CU: the kernel is a stream over W, m, v with an 8-step GEMM in front - what
+  // counts is how many epilogue loads are in flight per CU (256x256 tiles, one workgroup per CU: 3.4 TB/s)
+  typedef CfgTn128 Cfg;
   const int Vp = (int)(ld_dlogits < ((V + 7) / 8) * 8 ? ld_dlogits : ((V + 7) / 8) * 8);   // A columns the loop may touch (%8)
   GemmOperandsT g{dlogits, ld_dlogits, x, ldx, Vp, K, rows / 32};
   const int tm = ceil_div(V, Cfg::BM), tn = ceil_div(K, Cfg::BU);

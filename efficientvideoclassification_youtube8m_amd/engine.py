@@ -279,7 +279,7 @@ class MoeHead:
             self.dgl_full = torch.zeros((self.Br, ops.round_up(V * (Mx + 1), 64)), dtype=BF16, device=dev)   # pad rows / cols stay 0
             self.del_full = torch.zeros((self.Br, ops.round_up(V * Mx, 64)), dtype=BF16, device=dev)
             self.dgl, self.del_ = self.dgl_full[:B], self.del_full[:B]
-            self.partial_ws = torch.empty(2 * ((V * (Mx + 1) + 255) // 256) * ((K + 255) // 256), dtype=F32, device=dev)
+            self.partial_ws = torch.empty(2 * ((V * (Mx + 1) + 127) // 128) * ((K + 127) // 128), dtype=F32, device=dev)
             self.dglT = torch.empty((V * (Mx + 1), self.Bp), dtype=BF16, device=dev)
             self.delT = torch.empty((V * Mx, self.Bp), dtype=BF16, device=dev)
             self.xT = torch.empty((K, self.Bp), dtype=BF16, device=dev)
