@@ -12,14 +12,14 @@ template <int a, int b, int c, int d, int e, int f, bool g> struct is_v2<TileCfg
 
 extern __shared__ __attribute__((aligned(16))) char lds_dyn[];
 
-template <class Cfg, int NG, bool SWAP = false, bool SPLIT = false>
+template <class Cfg, int NG, bool SWAP = false, bool SPLIT = false, bool INIT = true>
 __device__ __forceinline__ void run_mainloop(const GemmOperands& p, int m0, int u0, f32x4 (&acc)[Cfg::MI][NG][Cfg::NI]) {
   if constexpr (is_v2<Cfg>::value) {
     static_assert(!SPLIT, "the split-bf16 parity mode runs on the v1 tiles");
-    gemm_mainloop_v2<Cfg, SWAP>(p, m0, u0, lds_dyn, acc);
+    gemm_mainloop_v2<Cfg, SWAP, INIT>(p, m0, u0, lds_dyn, acc);
   } else {
     __shared__ __attribute__((aligned(16))) char lds_static[(SPLIT ? 2 : 1) * Cfg::LDS_BYTES];   // static: keeps 2 workgroups per CU
-    gemm_mainloop<Cfg, SWAP, SPLIT>(p, m0, u0, lds_static, acc);
+    gemm_mainloop<Cfg, SWAP, SPLIT, INIT>(p, m0, u0, lds_static, acc);
   }
 }
 
@@ -469,7 +469,22 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, 
   tile_of(id, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * Cfg::BM, u0 = tn * Cfg::BU;
   f32x4 acc[Cfg::MI][4][Cfg::NI];
-  run_mainloop<Cfg, 4, true, SPLIT>(p, m0, u0, acc);     // transposed accumulators: lane = one row, 4 consecutive units
+  {   // the accumulators start from bias (+ forget_bias 1.0): its loads fly under the loop's prologue, and the tail
+      // below has no load left that hipcc could re-issue between the fragments' stores
+    TileCoordsT<Cfg> tc0;
+#pragma unroll
+    for (int ni = 0; ni < Cfg::NI; ++ni) {
+      const int u = min(u0 + tc0.unit0 + ni * 16, e.H - 4);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b = *(const float4*)(e.bias + (long)g * e.H + u);
+        const float fb = (g == 2) ? 1.0f : 0.0f;       // forget_bias
+#pragma unroll
+        for (int mi = 0; mi < Cfg::MI; ++mi) acc[mi][g][ni] = f32x4{b.x + fb, b.y + fb, b.z + fb, b.w + fb};
+      }
+    }
+  }
+  run_mainloop<Cfg, 4, true, SPLIT, false>(p, m0, u0, acc);     // transposed accumulators: lane = one row, 4 consecutive units
 #ifdef EVC_ABLATE_EPI    // debug build: main loop only (keep the accumulators alive, store nothing)
 #pragma unroll
   for (int mi = 0; mi < Cfg::MI; ++mi)
@@ -479,20 +494,34 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, 
 #endif
   TileCoordsT<Cfg> tc;
   const int H = e.H;     // H % 4 == 0 (checked on the host): a lane's 4 units never straddle H
+  // Every load of the tail is issued before the first store: the stores of one fragment and the loads of the next
+  // go to the same arrays (c_state is updated in place), so in program order hipcc must finish the stores before
+  // the next loads - with 8 fragments per lane that was 8 serial load->store round trips (21 of the 67 us).
 #pragma unroll
   for (int ni = 0; ni < Cfg::NI; ++ni) {
     const int u = u0 + tc.unit0 + ni * 16;
     if (u >= H) continue;
-    const float4 bi = *(const float4*)(e.bias + u), bj = *(const float4*)(e.bias + H + u);
-    const float4 bf = *(const float4*)(e.bias + 2 * H + u), bo = *(const float4*)(e.bias + 3 * H + u);
+    int ln[Cfg::MI], rm[Cfg::MI];
 #pragma unroll
     for (int mi = 0; mi < Cfg::MI; ++mi) {
       const int m = m0 + tc.row0 + mi * 16;
-      if (m >= e.M) continue;
-      const int ln = e.len[m];
+      const bool in = m < e.M;
+      ln[mi] = in ? e.len[m] : -1;                     // -1: row outside the launch (nothing to do, not even zeros)
+      rm[mi] = (in && e.row_map) ? e.row_map[m] : m;
+    }
+    float4 cv[Cfg::MI];
+#pragma unroll
+    for (int mi = 0; mi < Cfg::MI; ++mi) {
+      cv[mi] = make_float4(0.f, 0.f, 0.f, 0.f);        // zero initial state (no memset of the state buffers)
+      if (e.t > 0 && e.t < ln[mi]) cv[mi] = *(const float4*)(e.c_state + (long)rm[mi] * e.ld_state + u);   // running f32 cell state, in place
+    }
+#pragma unroll
+    for (int mi = 0; mi < Cfg::MI; ++mi) {
+      const int m = m0 + tc.row0 + mi * 16;
+      if (ln[mi] < 0) continue;
       const long hu = (long)m * H + u;
-      const long su = (long)(e.row_map ? e.row_map[m] : m) * e.ld_state + u;
-      if (e.t >= ln) {              // dynamic_rnn: state copied through, zero output
+      const long su = (long)rm[mi] * e.ld_state + u;
+      if (e.t >= ln[mi]) {          // dynamic_rnn: state copied through, zero output
         *(uint2*)(e.hout + hu) = make_uint2(0u, 0u);
         if (SPLIT) *(uint2*)(e.hout_lo + hu) = make_uint2(0u, 0u);
         if (e.t == 0) {             // zero-length row: its final state is the zero initial state
@@ -502,14 +531,11 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, 
         continue;
       }
       float zi[4], zj[4], zf[4], zo[4];
-      const float bia[4] = {bi.x, bi.y, bi.z, bi.w}, bja[4] = {bj.x, bj.y, bj.z, bj.w};
-      const float bfa[4] = {bf.x, bf.y, bf.z, bf.w}, boa[4] = {bo.x, bo.y, bo.z, bo.w};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        zi[r] = acc[mi][0][ni][r] + bia[r]; zj[r] = acc[mi][1][ni][r] + bja[r];
-        zf[r] = acc[mi][2][ni][r] + bfa[r] + 1.0f /* forget_bias */; zo[r] = acc[mi][3][ni][r] + boa[r];
+      for (int r = 0; r < 4; ++r) {                     // bias and forget_bias are already in the accumulators
+        zi[r] = acc[mi][0][ni][r]; zj[r] = acc[mi][1][ni][r]; zf[r] = acc[mi][2][ni][r]; zo[r] = acc[mi][3][ni][r];
       }
-      if (e.zx) {
+      if (e.zx) {                   // hoisted x-projection (small-M stacks: one or two fragments per lane)
         const float* zr = e.zx + (long)m * e.ldzx + u;
         const float4 a = *(const float4*)zr, b = *(const float4*)(zr + H), c = *(const float4*)(zr + 2 * H), d = *(const float4*)(zr + 3 * H);
         zi[0] += a.x; zi[1] += a.y; zi[2] += a.z; zi[3] += a.w;
@@ -517,9 +543,7 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, 
         zf[0] += c.x; zf[1] += c.y; zf[2] += c.z; zf[3] += c.w;
         zo[0] += d.x; zo[1] += d.y; zo[2] += d.z; zo[3] += d.w;
       }
-      float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);     // zero initial state (no memset of the state buffers)
-      if (e.t > 0) cv = *(const float4*)(e.c_state + su);    // the running f32 cell state lives in c_state, in place
-      const float co[4] = {cv.x, cv.y, cv.z, cv.w};
+      const float co[4] = {cv[mi].x, cv[mi].y, cv[mi].z, cv[mi].w};
       float cn[4], hn[4];
       uint2 rec[4];
 #pragma unroll
@@ -532,7 +556,7 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, 
       const float4 cnv = make_float4(cn[0], cn[1], cn[2], cn[3]);
       *(float4*)(e.c_state + su) = cnv;               // rows stop updating at t = len: what stays is the returned state
       if (e.c_hist) *(uint2*)(e.c_hist + hu) = make_uint2(pack_bf16x2(cn[0], cn[1]), pack_bf16x2(cn[2], cn[3]));
-      if (e.t == ln - 1) *(float4*)(e.h_state + su) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+      if (e.t == ln[mi] - 1) *(float4*)(e.h_state + su) = make_float4(hn[0], hn[1], hn[2], hn[3]);
       *(uint2*)(e.hout + hu) = make_uint2(pack_bf16x2(hn[0], hn[1]), pack_bf16x2(hn[2], hn[3]));
       if (SPLIT) {
         float lo[4];

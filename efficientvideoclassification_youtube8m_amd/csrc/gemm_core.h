@@ -84,7 +84,8 @@ __device__ __forceinline__ int patch_rows(int nwg, int tiles_n) {
 // (l>>4)*4+reg - so an epilogue that walks units fastest gets 16-byte vector accesses.
 // SPLIT = true also stages the low-order halves (LDS image [A_hi | B_hi | A_lo | B_lo] per stage) and
 // issues hi.hi + hi.lo + lo.hi per tile: f32-operand accuracy at 3x the MFMA work (parity mode).
-template <class Cfg, bool SWAP = false, bool SPLIT = false>
+// INIT = false: the caller has pre-loaded the accumulators (e.g. with a bias) - the loop only adds to them.
+template <class Cfg, bool SWAP = false, bool SPLIT = false, bool INIT = true>
 __device__ __forceinline__ void gemm_mainloop(const GemmOperands& p, const int m0, const int u0, char* lds,
                                               f32x4 (&acc)[Cfg::MI][Cfg::G][Cfg::NI]) {
   const int tid = threadIdx.x;
@@ -92,12 +93,14 @@ __device__ __forceinline__ void gemm_mainloop(const GemmOperands& p, const int m
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / Cfg::WC, wc = wave % Cfg::WC;
 
+  if (INIT) {
 #pragma unroll
-  for (int mi = 0; mi < Cfg::MI; ++mi)
+    for (int mi = 0; mi < Cfg::MI; ++mi)
 #pragma unroll
-    for (int g = 0; g < Cfg::G; ++g)
+      for (int g = 0; g < Cfg::G; ++g)
 #pragma unroll
-      for (int ni = 0; ni < Cfg::NI; ++ni) acc[mi][g][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ni = 0; ni < Cfg::NI; ++ni) acc[mi][g][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   const int nk = p.nk1 + p.nk2;
   if (nk == 0) return;

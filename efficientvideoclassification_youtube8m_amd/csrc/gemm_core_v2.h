@@ -46,7 +46,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <class Cfg, bool SWAP = false>
+template <class Cfg, bool SWAP = false, bool INIT = true>
 __device__ __forceinline__ void gemm_mainloop_v2(const GemmOperands& p, const int m0, const int u0, char* lds,
                                                  f32x4 (&acc)[Cfg::MI][Cfg::G][Cfg::NI]) {
   const int tid = threadIdx.x;
@@ -54,12 +54,14 @@ __device__ __forceinline__ void gemm_mainloop_v2(const GemmOperands& p, const in
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / Cfg::WC, wc = wave % Cfg::WC;
 
+  if (INIT) {
 #pragma unroll
-  for (int mi = 0; mi < Cfg::MI; ++mi)
+    for (int mi = 0; mi < Cfg::MI; ++mi)
 #pragma unroll
-    for (int g = 0; g < Cfg::G; ++g)
+      for (int g = 0; g < Cfg::G; ++g)
 #pragma unroll
-      for (int ni = 0; ni < Cfg::NI; ++ni) acc[mi][g][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ni = 0; ni < Cfg::NI; ++ni) acc[mi][g][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   const int nk = p.nk1 + p.nk2;   // in 32-wide K steps
   if (nk == 0) return;
