@@ -733,49 +733,67 @@ struct LstmBwdParams {
 
 // Gate derivative of one (row, 4 consecutive units): dh[4] = what flowed back through the recurrent
 // product; writes dz (4 x 8 bytes), carries dc in dc_ws.
+// What the gate derivative of one (row, 4 consecutive units) reads: loaded in one phase for all of a lane's
+// fragments (the stores of a fragment and the loads of the next hit the same arrays - dc_ws is updated in place -
+// so in program order every fragment would wait for the previous one's stores to be acknowledged).
+struct LstmBwdIn {
+  int ln;                   // sequence length of the row (-1: row outside the launch)
+  float4 dcv;               // dc arriving at this step (or the final-state gradient at t = len-1)
+  float4 dhs;               // final-state dh at t = len-1
+  uint2 dha;                // 4 bf16: dX of the layer above
+  uint4 g01, g23;           // gate records of the 4 units
+  uint2 cnq, coq;           // bf16 c after / before this step
+};
+
+__device__ __forceinline__ void lstm_bwd_load(const LstmBwdParams& e, const int m, const int u, const bool in_range, LstmBwdIn& q) {
+  q.ln = in_range ? e.len[m] : -1;
+  q.dcv = q.dhs = make_float4(0.f, 0.f, 0.f, 0.f);
+  q.dha = q.cnq = q.coq = make_uint2(0u, 0u);
+  q.g01 = q.g23 = make_uint4(0u, 0u, 0u, 0u);
+  if (e.t >= q.ln) return;                        // inactive (or outside): nothing is read
+  const long hu = (long)m * e.H + u;
+  if (e.t == q.ln - 1) {
+    const long su = (long)(e.row_map ? e.row_map[m] : m) * e.ld_dS + u;
+    q.dhs = *(const float4*)(e.dS_h + su);        // nothing flows back from later (inactive) steps
+    q.dcv = *(const float4*)(e.dS_c + su);
+  } else {
+    q.dcv = *(const float4*)(e.dc_ws + hu);
+  }
+  if (e.dh_above) q.dha = *(const uint2*)(e.dh_above + hu);
+  const uint4* gp = (const uint4*)(e.gates + hu);
+  q.g01 = gp[0]; q.g23 = gp[1];
+  q.cnq = *(const uint2*)(e.c_new + hu);
+  if (e.c_old) q.coq = *(const uint2*)(e.c_old + hu);
+}
+
+// dh_in[4] = what flowed back through the recurrent product; writes dz (4 x 8 bytes), carries dc in dc_ws.
 // dzv[unit][gate] receives the (unrounded) f32 gate gradients - zeros for an inactive row - for the bias gradient.
-__device__ __forceinline__ void lstm_bwd_tail(const LstmBwdParams& e, const int m, const int u, const float (&dh_in)[4],
-                                              float (&dzv)[4][4]) {
-  const int H = e.H;
-  const int ln = e.len[m];
-  const long hu = (long)m * H + u;
+__device__ __forceinline__ void lstm_bwd_finish(const LstmBwdParams& e, const int m, const int u, const float (&dh_in)[4],
+                                                const LstmBwdIn& q, float (&dzv)[4][4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) dzv[r][g] = 0.f;
+  if (q.ln < 0) return;
+  const long hu = (long)m * e.H + u;
   uint4* dzp = (uint4*)(e.dz4 + hu);            // 4 units x 8 bytes = 2 x 16 bytes
-  if (e.t >= ln) {  // inactive: state passes through, no gate gradient
+  if (e.t >= q.ln) {  // inactive: state passes through, no gate gradient
     dzp[0] = make_uint4(0u, 0u, 0u, 0u);
     dzp[1] = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) dzv[r][g] = 0.f;
     return;
   }
-  const bool last = (e.t == ln - 1);
   float dh[4] = {dh_in[0], dh_in[1], dh_in[2], dh_in[3]};
-  float4 dcv;
-  if (last) {
-    const long su = (long)(e.row_map ? e.row_map[m] : m) * e.ld_dS + u;
-    const float4 hv = *(const float4*)(e.dS_h + su);   // nothing flows back from later (inactive) steps
-    dh[0] = hv.x; dh[1] = hv.y; dh[2] = hv.z; dh[3] = hv.w;
-    dcv = *(const float4*)(e.dS_c + su);
-  } else {
-    dcv = *(const float4*)(e.dc_ws + hu);
-  }
+  if (e.t == q.ln - 1) { dh[0] = q.dhs.x; dh[1] = q.dhs.y; dh[2] = q.dhs.z; dh[3] = q.dhs.w; }
   if (e.dh_above) {
-    const uint2 a = *(const uint2*)(e.dh_above + hu);
-    dh[0] += __uint_as_float(a.x << 16); dh[1] += __uint_as_float(a.x & 0xffff0000u);
-    dh[2] += __uint_as_float(a.y << 16); dh[3] += __uint_as_float(a.y & 0xffff0000u);
+    dh[0] += __uint_as_float(q.dha.x << 16); dh[1] += __uint_as_float(q.dha.x & 0xffff0000u);
+    dh[2] += __uint_as_float(q.dha.y << 16); dh[3] += __uint_as_float(q.dha.y & 0xffff0000u);
   }
-  const float dci[4] = {dcv.x, dcv.y, dcv.z, dcv.w};
-  const uint4* gp = (const uint4*)(e.gates + hu);
-  const uint4 g01 = gp[0], g23 = gp[1];
-  const uint2 recs[4] = {make_uint2(g01.x, g01.y), make_uint2(g01.z, g01.w), make_uint2(g23.x, g23.y), make_uint2(g23.z, g23.w)};
-  const uint2 cnq = *(const uint2*)(e.c_new + hu);
-  uint2 coq = make_uint2(0u, 0u);
-  if (e.c_old) coq = *(const uint2*)(e.c_old + hu);
-  const float cna[4] = {__uint_as_float(cnq.x << 16), __uint_as_float(cnq.x & 0xffff0000u),
-                        __uint_as_float(cnq.y << 16), __uint_as_float(cnq.y & 0xffff0000u)};
-  const float coa[4] = {__uint_as_float(coq.x << 16), __uint_as_float(coq.x & 0xffff0000u),
-                        __uint_as_float(coq.y << 16), __uint_as_float(coq.y & 0xffff0000u)};
+  const float dci[4] = {q.dcv.x, q.dcv.y, q.dcv.z, q.dcv.w};
+  const uint2 recs[4] = {make_uint2(q.g01.x, q.g01.y), make_uint2(q.g01.z, q.g01.w), make_uint2(q.g23.x, q.g23.y), make_uint2(q.g23.z, q.g23.w)};
+  const float cna[4] = {__uint_as_float(q.cnq.x << 16), __uint_as_float(q.cnq.x & 0xffff0000u),
+                        __uint_as_float(q.cnq.y << 16), __uint_as_float(q.cnq.y & 0xffff0000u)};
+  const float coa[4] = {__uint_as_float(q.coq.x << 16), __uint_as_float(q.coq.x & 0xffff0000u),
+                        __uint_as_float(q.coq.y << 16), __uint_as_float(q.coq.y & 0xffff0000u)};
   float dcn[4];
   uint2 dzr[4];
 #pragma unroll
@@ -825,6 +843,12 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_bwd_step_kernel(GemmOperands p, 
   for (int ni = 0; ni < Cfg::NI; ++ni) {
     const int u = u0 + tc.unit0 + ni * 16;
     if (u >= e.H) continue;
+    LstmBwdIn in[Cfg::MI];                             // load phase: every fragment of this unit group
+#pragma unroll
+    for (int mi = 0; mi < Cfg::MI; ++mi) {
+      const int m = m0 + tc.row0 + mi * 16;
+      lstm_bwd_load(e, m, u, m < e.M, in[mi]);
+    }
     float bs[4][4];                                    // this lane's column sums over its rows: [unit][gate]
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -833,13 +857,12 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_bwd_step_kernel(GemmOperands p, 
 #pragma unroll
     for (int mi = 0; mi < Cfg::MI; ++mi) {
       const int m = m0 + tc.row0 + mi * 16;
-      if (m >= e.M) continue;
       const float dh[4] = {acc[mi][0][ni][0], acc[mi][0][ni][1], acc[mi][0][ni][2], acc[mi][0][ni][3]};
 #ifdef EVC_ABLATE_BWD_EPI     // debug build: main loop only (keep the accumulators alive, store nothing)
       asm volatile("" :: "v"(dh[0]), "v"(dh[1]), "v"(dh[2]), "v"(dh[3]));
 #else
       float dzv[4][4];
-      lstm_bwd_tail(e, m, u, dh, dzv);
+      lstm_bwd_finish(e, m, u, dh, in[mi], dzv);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -951,7 +974,9 @@ __global__ __launch_bounds__(64 * KW) void lstm_bwd_step_skinny_kernel(GemmOpera
     const int m = m0 + row, u = u0 + ug;
     if (m < e.M && u < e.H) {
       const float dh[4] = {s.x, s.y, s.z, s.w};
-      lstm_bwd_tail(e, m, u, dh, dzv);
+      LstmBwdIn in;
+      lstm_bwd_load(e, m, u, true, in);
+      lstm_bwd_finish(e, m, u, dh, in, dzv);
     }
   }
   if (e.db) {            // bias gradient (e.db is a kernel argument: uniform branch): column sums of the tile's 32 rows
