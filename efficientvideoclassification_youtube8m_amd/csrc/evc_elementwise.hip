@@ -320,7 +320,16 @@ extern "C" int evc_transpose_to_bf16(const void* in, int in_f32, int64_t ld_in, 
 
 __global__ void cast_kernel(const float* __restrict__ in, long ld_in, int R, int C, bf16_t* __restrict__ out, long ld_out) {
   const long n = (long)R * C;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+  const long stride = (long)gridDim.x * blockDim.x, tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ld_in == C && ld_out == C && (n & 3) == 0 && (((uintptr_t)in) & 15) == 0 && (((uintptr_t)out) & 7) == 0) {
+    // dense: 16-byte loads, 8-byte stores, no index arithmetic
+    for (long i = tid; i < (n >> 2); i += stride) {
+      const float4 f = ((const float4*)in)[i];
+      ((uint2*)out)[i] = make_uint2(pack_bf16x2_hw(f.x, f.y), pack_bf16x2_hw(f.z, f.w));
+    }
+    return;
+  }
+  for (long i = tid; i < n; i += stride) {
     const long r = i / C, c = i % C;
     out[r * ld_out + c] = f32_to_bf16(in[r * ld_in + c]);
   }

@@ -408,13 +408,22 @@ __global__ __launch_bounds__(Cfg::NT) void moe_update_kernel(GemmOperandsT p, Mo
   }
 }
 
-__global__ void moe_update_finalize_kernel(const float* partial, int n, float* sums) {
-  // one wave, fixed summation order (lane-strided partial sums, then the butterfly): run-to-run identical
+__global__ __launch_bounds__(1024) void moe_update_finalize_kernel(const float* partial, int n, float* sums) {
+  // one workgroup, fixed summation order (thread-strided partial sums, wave butterflies, then the 16 wave totals
+  // in order): run-to-run identical
+  __shared__ float wa[16], wb[16];
   float a = 0.f, b = 0.f;
-  for (int i = threadIdx.x; i < n; i += 64) { a += partial[2 * i]; b += partial[2 * i + 1]; }
+  for (int i = threadIdx.x; i < n; i += 1024) { a += partial[2 * i]; b += partial[2 * i + 1]; }
   a = wave_sum(a);
   b = wave_sum(b);
-  if (threadIdx.x == 0) { sums[0] += a; sums[1] += b; }
+  if ((threadIdx.x & 63) == 0) { wa[threadIdx.x >> 6] = a; wb[threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float sa = 0.f, sb = 0.f;
+    for (int w = 0; w < 16; ++w) { sa += wa[w]; sb += wb[w]; }
+    sums[0] += sa;
+    sums[1] += sb;
+  }
 }
 
 extern "C" int evc_moe_grad_update(const evc_bf16* dlogits, int64_t ld_dlogits, const evc_bf16* x, int64_t ldx, int rows,
@@ -436,7 +445,7 @@ extern "C" int evc_moe_grad_update(const evc_bf16* dlogits, int64_t ld_dlogits, 
   const int tm = ceil_div(V, Cfg::BM), tn = ceil_div(K, Cfg::BU);
   MoeUpdateParams u{p, m, v, p_bf16, pT_bf16, ldT, partial_ws, sums, V, K, l2_coeff, clip_norm, lr_t, beta1, beta2, eps};
   launch_cfg<Cfg>(moe_update_kernel<Cfg, 1>, tm * tn, st, g, u, tm, tn);
-  hipLaunchKernelGGL(moe_update_finalize_kernel, dim3(1), dim3(64), 0, st, (const float*)partial_ws, tm * tn, sums);
+  hipLaunchKernelGGL(moe_update_finalize_kernel, dim3(1), dim3(1024), 0, st, (const float*)partial_ws, tm * tn, sums);
   launch_cfg<Cfg>(moe_update_kernel<Cfg, 2>, tm * tn, st, g, u, tm, tn);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
