@@ -51,6 +51,12 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf
 // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division sequence hipcc emits for `/` without fast-math:
 // the gate tails evaluate 5 of these per (row, unit) and were VALU-bound on them.
 __device__ __forceinline__ float rcpf_(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sqrtf_(float x) { return __builtin_amdgcn_sqrtf(x); }   // v_sqrt_f32 (1 ulp)
+// the Adam step p - lr_t * m / (sqrt(v) + eps) of both optimizer kernels (identical rounding in the fused and
+// the plain path); 1-ulp hardware sqrt / rcp: ~1e-7 relative on an update that is itself ~1e-3 of the weight
+__device__ __forceinline__ float adam_step_(float p, float m, float v, float lr_t, float eps) {
+  return p - lr_t * m * rcpf_(sqrtf_(v) + eps);
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return rcpf_(1.0f + __expf(-x)); }
 // tanh via exp: exact to ~2e-7 relative on the range the LSTM uses
 __device__ __forceinline__ float tanhf_(float x) {

@@ -652,7 +652,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
     const float gc = (g[i] + l2 * pv) * scale;
     const float mn = b1 * m[i] + (1.f - b1) * gc;
     const float vn = b2 * v[i] + (1.f - b2) * gc * gc;
-    const float pn = pv - lr_t * mn / (sqrtf(vn) + eps);
+    const float pn = adam_step_(pv, mn, vn, lr_t, eps);
     m[i] = mn; v[i] = vn; p[i] = pn;
     if (pb) pb[i] = f32_to_bf16(pn);
   }

@@ -382,7 +382,7 @@ __global__ __launch_bounds__(Cfg::NT) void moe_update_kernel(GemmOperandsT p, Mo
           const float gc = (acc[mi][0][ni][r] + u.l2 * pa[r]) * scale;
           mn[r] = u.b1 * ma[r] + (1.f - u.b1) * gc;
           vn[r] = u.b2 * va[r] + (1.f - u.b2) * gc * gc;
-          pn[r] = pa[r] - u.lr_t * mn[r] / (sqrtf(vn[r]) + u.eps);
+          pn[r] = adam_step_(pa[r], mn[r], vn[r], u.lr_t, u.eps);
           pb[r] = f32_to_bf16(pn[r]);
         }
         *(float4*)(u.p + o) = make_float4(pn[0], pn[1], pn[2], pn[3]);
