@@ -152,6 +152,14 @@ class DistillGraph:
         self.pg = process_group
         self.reducer = GradReducer(process_group)
         self.world = self.reducer.world
+        # The student's collectives get a communicator of their own: one process group executes its collectives in
+        # issue order, so on a shared group the teacher's early factor all-gather (host-issued after the student's
+        # backward) would queue behind the student's last gradient all-reduce and hold the teacher's whole update
+        # chain back.  (new_group is collective: every rank constructs the graph.)
+        self.reducer_s = self.reducer
+        if self.world > 1 and mode == "teacher_student":
+            ranks = list(range(torch.distributed.get_world_size(process_group))) if process_group is None else None
+            self.reducer_s = GradReducer(torch.distributed.new_group(ranks) if ranks is not None else process_group)
         self.global_step = 0
         self.teacher = self.student = None
         if mode != "student":
@@ -289,8 +297,8 @@ class DistillGraph:
                 self.student.backward(ds, self._dp_s,
                                       on_moe_grads_ready=None if early else (lambda: self._reduce_tower(self.student, True)),
                                       aux=self._aux_s if self.overlap_towers else None, early_apply=early,
-                                      reduce_fn=(lambda lo, hi: self.reducer.reduce_async(st_s.grad, lo, hi)) if (early and self.world > 1) else None,
-                                      gather_fn=self.reducer.all_gather_rows if (early and self.world > 1) else None)
+                                      reduce_fn=(lambda lo, hi: self.reducer_s.reduce_async(st_s.grad, lo, hi)) if (early and self.world > 1) else None,
+                                      gather_fn=self.reducer_s.all_gather_rows if (early and self.world > 1) else None)
                 if not early:
                     self._reduce_tower(self.student, False)
                 self._student_applied = early is not None
