@@ -552,16 +552,24 @@ __global__ __launch_bounds__(256) void kl_loss_kernel(const float* __restrict__ 
                                                       float gs, float* __restrict__ loss, float* __restrict__ dps, int acc) {
   __shared__ float sh[4];
   const int b = blockIdx.x;
-  const float it = 1.f / st[b], is = 1.f / ss[b];
+  // Degenerate rows (only reached once a tower has collapsed, e.g. on random labels after a few Adam steps, where
+  // TF's log(0) / 0-division NaNs make slim's check_numerics abort the reference run): keep every value finite.
+  //  * teacher row sum below the smallest normal float: the renormalised teacher distribution is 0/0 - the row
+  //    contributes nothing (loss 0, gradient 0);
+  //  * student probabilities / row sum are clamped at FLT_MIN inside log and 1/q.
+  // Wherever the reference's result is finite these clamps are inactive.
+  const float FMIN = 1.17549435e-38f;
+  const bool t_ok = st[b] >= FMIN;
+  const float it = t_ok ? 1.f / st[b] : 0.f, is = 1.f / fmaxf(ss[b], FMIN);
   float s = 0.f;
   for (int c = threadIdx.x; c < V; c += 256) {
     const long i = (long)b * V + c;
-    const float P = pt[i] * it, q = ps[i];
+    const float P = pt[i] * it, q = fmaxf(ps[i], FMIN);
     // 0*log(0) := 0 (its limit).  TF evaluates 0*(-inf) = NaN here and slim's
     // check_numerics then aborts the reference run; see DESIGN.md "deviations".
-    if (P > 0.f) s += P * (__logf(P) - __logf(q * is));
+    if (P >= FMIN) s += P * (__logf(P) - __logf(fmaxf(q * is, FMIN)));
     if (dps) {
-      const float g = (-P / q + is) * gs;
+      const float g = t_ok ? (-P / q + is) * gs : 0.f;
       dps[i] = acc ? dps[i] + g : g;
     }
   }

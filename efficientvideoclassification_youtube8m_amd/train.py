@@ -26,6 +26,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 
 from . import eval_util, frame_level_models, losses, ops, readers, video_level_models
@@ -217,6 +218,8 @@ def main(argv=None):
                               eval_util.calculate_gap(p, y))
             if is_distill:
                 r = graph.loss_report()
+                if not all(np.isfinite(v) for v in r.values()):      # slim.learning.create_train_op's check_numerics
+                    raise FloatingPointError("LossTensor is inf or nan : %s" % r)
                 logging.info("%s: training step %d| Hit@1: %.2f| PERR: %.2f| GAP: %.2f| Teacher_Loss: %s| L_REP: %s| L_PRED: %s"
                              "| L_CE: %s", task, out["global_step"], hit, perr, gap, round(r["label_loss"], 2),
                              round(r["student_loss_state"], 2), round(r["pred_loss"], 2), round(r["student_label_loss"], 2))

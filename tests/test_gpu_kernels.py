@@ -390,3 +390,44 @@ def test_lstm_layer_with_row_plan_matches_plain(ops, M, T, Kin, H):
     if (T * plan.P) % 32 == 0 and (T * M) % 32 == 0:
         sc = dW0.abs().max().item() + 1e-6
         assert (dW0 - dW1).abs().max().item() / sc < 1e-3      # dz within one bf16 ulp, different summation order
+
+
+def test_kl_pred_loss_against_oracle_and_degenerate_rows(ops):
+    """L_PRED (cs/train.py:398-402): Categorical KL of the renormalised probabilities, summed over the batch, with
+    its gradient wrt the student probabilities; rows where the reference would produce NaN/inf stay finite."""
+    rng = np.random.default_rng(3)
+    B, V = 6, 500
+    pt = rng.random((B, V)).astype(np.float32) ** 4
+    ps = rng.random((B, V)).astype(np.float32) ** 2 + 1e-3
+    pt[0, :50] = 0.0                                   # exact zeros in the teacher: 0 * log 0 := 0
+    def kl_ref(p, q):                                  # mm.pred_kl_loss with 0 * log 0 := 0
+        P, Q = p / p.sum(1, keepdims=True), q / q.sum(1, keepdims=True)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return float(np.where(P > 0, P * (np.log(P) - np.log(Q)), 0.0).sum())
+
+    loss_ref = kl_ref(pt.astype(np.float64), ps.astype(np.float64))
+    full = pt.copy()
+    full[0, :50] = 1e-3
+    assert abs(kl_ref(full.astype(np.float64), ps.astype(np.float64)) - mm.pred_kl_loss(full.astype(np.float64), ps.astype(np.float64))) < 1e-9
+    ptd, psd = torch.from_numpy(pt).to(DEV), torch.from_numpy(ps).to(DEV)
+    loss = torch.zeros(1, device=DEV)
+    dps = torch.empty((B, V), device=DEV)
+    ops.kl_pred_loss(ptd, ptd.sum(1), psd, psd.sum(1), loss, dps)
+    assert abs(loss.item() - loss_ref) < 1e-4 * abs(loss_ref)
+    # gradient: finite differences of the oracle on a few entries
+    for (b, c) in ((1, 3), (4, 499), (0, 10)):
+        e = 1e-4 * ps[b, c]
+        up, dn = ps.astype(np.float64).copy(), ps.astype(np.float64).copy()
+        up[b, c] += e
+        dn[b, c] -= e
+        fd = (kl_ref(pt.astype(np.float64), up) - kl_ref(pt.astype(np.float64), dn)) / (2 * e)
+        assert abs(dps[b, c].item() - fd) < 2e-3 * abs(fd) + 1e-6
+    # degenerate: a collapsed teacher row (sum underflows) and student probabilities that are exactly 0
+    pt2, ps2 = pt.copy(), ps.copy()
+    pt2[2] = 1e-44
+    ps2[3, :7] = 0.0
+    ptd, psd = torch.from_numpy(pt2).to(DEV), torch.from_numpy(ps2).to(DEV)
+    loss.zero_()
+    ops.kl_pred_loss(ptd, ptd.sum(1), psd, psd.sum(1), loss, dps)
+    assert np.isfinite(loss.item()) and bool(torch.isfinite(dps).all())
+    assert bool((dps[2] == 0).all())                   # the undefined row contributes nothing
