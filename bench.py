@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_videos", type=int, default=8)
     ap.add_argument("--no_fused_moe", action="store_true", help="debug: materialise the MoE weight gradients (A/B of evc_moe_grad_update)")
+    ap.add_argument("--student_forward_early", action="store_true", help="A/B: student forward next to the teacher forward")
     ap.add_argument("--no_overlap", action="store_true", help="debug: everything on one stream (solo kernel times for profiling)")
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic batches cycled through (HBM resident)")
     args = ap.parse_args()
@@ -122,6 +123,7 @@ def main():
     # geometry of the length-sorted L1 stacks is derived from them, see ops.RowPlan)
     n_host = [p[1].cpu().numpy() for p in pool]
     graph = DistillGraph(B, every_n=args.every_n, mode=args.mode, device=device, seed=7, overlap_towers=not args.no_overlap)
+    graph.student_forward_early = args.student_forward_early
     if args.no_fused_moe:
         for tw in (graph.teacher, graph.student):
             if tw is not None:
@@ -138,6 +140,8 @@ def main():
         graph.step(x, labels, n, num_frames_host=n_host[it % len(pool)])
         it += 1
     barrier()
+    l1_stack = (graph.teacher if graph.teacher is not None else graph.student).l1
+    l1_stack.timing = []          # HIP events around the L1 forward launch sequences of the timed steps (launch stream)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         x, n, labels = pool[it % len(pool)]
@@ -153,15 +157,20 @@ def main():
 
     # ---- roofline of the dominant kernel: the fused LSTM forward step of the teacher's L1 ---------
     # lstm_fwd_step_kernel<TileCfg2<BM,4,64,..>> (30 launches per iteration, the largest FLOP share of the
-    # recurrent path).  Live timing with events on the launch stream around each layer's 15-step launch
-    # sequence (the row plan of the last timed batch); algorithmic FLOPs = 2*rows_t*4H*K of each step GEMM
-    # over the rows that step runs on.
+    # recurrent path).  Live timing with HIP events on the launch stream around each layer's 15-step launch
+    # sequence in every timed step; algorithmic FLOPs = 2*rows_t*4H*K of each step GEMM over the rows that
+    # step runs on.
     tower = graph.teacher if graph.teacher is not None else graph.student
-    ms = launches = flops = 0.0
-    for (m, nl, fl) in tower.l1.profile_fwd_layers(reps=3):
-        ms, launches, flops = ms + m, launches + nl, flops + fl
+    timing, l1_stack.timing = l1_stack.timing, None
+    ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in timing)              # over the timed region, as the kernel ran there
+    launches = sum(nl for _, _, nl, _ in timing)                          # (next to the student's forward on another stream)
+    flops = sum(fl for _, _, _, fl in timing)
     avg_ms = ms / launches
     achieved = flops / (ms * 1e-3) / 1e12
+    ms_i = launches_i = flops_i = 0.0                                     # the same launch sequences alone on the chip
+    for (m, nl, fl) in tower.l1.profile_fwd_layers(reps=3):
+        ms_i, launches_i, flops_i = ms_i + m, launches_i + nl, flops_i + fl
+    achieved_isolated = flops_i / (ms_i * 1e-3) / 1e12
     traffic = mfma_busy = None
     try:   # HBM bytes per launch / MFMA busy fraction from the committed rocprofv3 --pmc passes (profiles/)
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
@@ -180,8 +189,11 @@ def main():
     roofline = {"bound": "mfma", "kernel": "lstm_fwd_step_kernel<TileCfg2<BM,4,64,2,4,..>> (teacher L1; BM = 224..320 per launch from the active rows)"
                 if graph.teacher is not None else "lstm_fwd_step_kernel (student L1)", "achieved": round(achieved, 2),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                "traffic": traffic, "mfma_busy_pmc": mfma_busy, "avg_launch_ms": round(avg_ms, 4), "launches_per_step": int(launches),
-                "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 2)}
+                "traffic": traffic, "mfma_busy_pmc": mfma_busy, "avg_launch_ms": round(avg_ms, 4),
+                "launches_per_step": int(round(launches / max(1, args.steps))),
+                "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 2),
+                "isolated": {"achieved": round(achieved_isolated, 2), "avg_launch_ms": round(ms_i / launches_i, 4),
+                             "note": "same launch sequences re-run alone after the timed loop (no other stream active)"}}
 
     if rank == 0:
         frames = n_gpus * B * T * args.steps

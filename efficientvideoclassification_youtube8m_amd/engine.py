@@ -105,6 +105,8 @@ class LstmStack:
         base = "%s/rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/" % (self.scope, l)
         return base + "kernel", base + "bias"
 
+    timing = None      # set to a list to collect (start event, end event, launches, algorithmic flops) per layer forward
+
     @staticmethod
     def _v(buf, *shape):
         """Leading part of a preallocated buffer viewed with a (smaller) shape: row plans use [T][P][..] of [T][M][..]."""
@@ -146,11 +148,21 @@ class LstmStack:
             return self.S
         self.x_in, self.lens = x, lens
         inp = x
+        rows = plan.rows if plan is not None else [M] * T
         for l in range(L):
             kn, bn = self.names(l)
+            if self.timing is not None:                         # bench.py: live timing of the step launches of each layer
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
             ops.lstm_layer_fwd(inp, tw.shadow_fwd[kn], tw.store.p(bn), lens, T, M, self.kin[l], H,
                                hb[l], self.S[:, (2 * l) * H:], self.S[:, (2 * l + 1) * H:], 2 * L * H,
                                gates[l], c_all[l], hoist=self.hoist[l], zx_ws=self.zx, plan=plan)
+            if self.timing is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                kx = 0 if self.hoist[l] else self.kin[l]
+                flops = sum(2.0 * r * 4 * H * (kx + (H if t > 0 else 0)) for t, r in enumerate(rows))
+                self.timing.append((e0, e1, sum(1 for r in rows if r > 0), flops))
             inp = hb[l][1:]
         return self.S
 
