@@ -251,3 +251,23 @@ def test_aggregated_reader(tmp_path):
     bad = readers.YT8MAggregatedFeatureReader(feature_names=["mean_rgb", "mean_inc3"], feature_sizes=[1024, 128])
     with pytest.raises(readers.EvcIoError, match="missing"):
         list(bad.prepare_reader(p))
+
+
+def test_reader_edge_cases(tmp_path):
+    """Empty files, records without frames, more labels than fit, long ids."""
+    rd = readers.YT8MFrameFeatureReader(feature_names=["rgb", "audio"], feature_sizes=[1024, 128], max_frames=30)
+    empty = str(tmp_path / "empty.tfrecord")
+    open(empty, "wb").close()
+    assert readers.scan_tfrecord(empty, verify_crc=True)[0].size == 0
+    assert list(rd.prepare_reader(empty)) == []
+    assert list(readers.get_input_evaluation_tensors(rd, empty, batch_size=4)) == []
+    rng = np.random.default_rng(9)
+    zero = {"rgb": np.zeros((0, 1024), np.uint8), "audio": np.zeros((0, 128), np.uint8)}
+    p = str(tmp_path / "edge.tfrecord")
+    readers.write_tfrecord(p, [readers.encode_frame_example("z" * 50, [5], zero),
+                               readers.encode_frame_example("b", list(range(40)) + [4715, 99999, -1], _random_video(rng, 3))])
+    (ids, x, y, n), = list(readers.get_input_evaluation_tensors(rd, p, batch_size=8))
+    assert n.tolist() == [0, 3] and not x[0].any()
+    assert ids[0] == "z" * (readers.ID_CAP - 1) and ids[1] == "b"            # ids are cut at ID_CAP-1 bytes
+    assert np.flatnonzero(y[0].numpy()).tolist() == [5]
+    assert np.flatnonzero(y[1].numpy()).tolist() == list(range(40)) + [4715]   # out-of-range classes are dropped
