@@ -1008,6 +1008,133 @@ __global__ __launch_bounds__(64 * KW) void lstm_bwd_step_skinny_kernel(GemmOpera
   }
 }
 
+// Skinny BPTT step, second form: the same K split over the waves, but every wave stages its K slice through a
+// PRIVATE ring of LDS-DMA stages (64-wide K steps, 128-byte rows: each 1 KiB DMA instruction moves 8 full cache
+// lines, where a direct fragment load touches 16 half-used ones) and waits only on its own vmcnt - no barrier in
+// the loop, 3 stages in flight per wave.  LDS: KW x STAGES x 8 KiB rings + the partial tiles.
+template <int KW, int STAGES>
+__global__ __launch_bounds__(64 * KW) void lstm_bwd_step_skinny_lds_kernel(GemmOperands p, LstmBwdParams e, int tiles_m, int tiles_n) {
+  constexpr int NT = 64 * KW;
+  constexpr int STAGE = 8192, RING = STAGES * STAGE;                  // A 32 rows x 128 B | B 32 rows x 128 B
+  float (*part)[32][36] = (float (*)[32][36])(lds_dyn + KW * RING);   // [wave][row][unit] (+4 pad)
+  const int nwg = tiles_m * tiles_n;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int tm = id % tiles_m, tn = id / tiles_m;
+  const int m0 = tm * 32, u0 = tn * 32;
+  if (m0 >= e.m_active) {
+    lstm_bwd_zero_tile<32, 32, NT>(e, m0, u0);
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* ring = lds_dyn + wave * RING;
+  const int nk = p.nk1;                                               // 64-wide K steps
+  const int per = (nk + KW - 1) / KW;
+  const int k0 = min(wave * per, nk), k1 = min(nk, wave * per + per);
+  const int n = k1 - k0;                                              // this wave's K steps (may be 0)
+  // staging sources: chunk c = lane + i*64 -> row c>>3, physical 16-B chunk c&7 holds logical chunk (c&7)^(row&7)
+  const int lc8 = ((lane & 7) ^ ((lane >> 3) & 7)) * 8;
+  const bf16_t* asrc[4];
+  const bf16_t* bsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (lane >> 3) + i * 8;
+    const int m = min(m0 + r, p.M - 1), u = min(u0 + r, p.Nu - 1);
+    asrc[i] = p.A1 + (long)m * p.lda1 + (long)k0 * 64 + lc8;
+    bsrc[i] = p.B + (long)u * p.ldb + (long)k0 * 64 + lc8;
+  }
+  auto stage = [&](int j) {                                           // K step j of this wave -> ring slot j % STAGES
+    char* sb = ring + (j % STAGES) * STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (long)j * 64),
+                                       (__attribute__((address_space(3))) void*)(sb + i * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + (long)j * 64),
+                                       (__attribute__((address_space(3))) void*)(sb + 4096 + i * 1024), 16, 0, 0);
+  };
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < STAGES - 1; ++j)
+    if (j < n) stage(j);
+  for (int k = 0; k < n; ++k) {
+    // stage k has landed when at most the younger stages' DMAs (8 each) are outstanding
+    const int younger = min(n - 1 - k, STAGES - 2);
+    if (younger >= 2) wait_vmcnt<16>();
+    else if (younger == 1) wait_vmcnt<8>();
+    else wait_vmcnt<0>();
+    const char* sb = ring + (k % STAGES) * STAGE;
+    bf16x8 a[2][2], b[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = i * 16 + frow;
+        const int off = row * 128 + (((kk * 4 + fq) ^ (row & 7)) << 4);
+        a[kk][i] = *(const bf16x8*)(sb + off);
+        b[kk][i] = *(const bf16x8*)(sb + 4096 + off);
+      }
+    if (k + STAGES - 1 < n) stage(k + STAGES - 1);   // refills the slot read in the previous iteration (its reads have returned)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[wave][i * 16 + fq * 4 + r][j * 16 + frow] = acc[i][j][r];
+  __syncthreads();
+  const int row = (threadIdx.x >> 3) & 31, ug = (threadIdx.x & 7) * 4;
+  float dzv[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) dzv[r][g] = 0.f;
+  {
+    float4 s = *(const float4*)&part[0][row][ug];
+#pragma unroll
+    for (int w = 1; w < KW; ++w) {
+      const float4 v = *(const float4*)&part[w][row][ug];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const int m = m0 + row, u = u0 + ug;
+    if (m < e.M && u < e.H) {
+      const float dh[4] = {s.x, s.y, s.z, s.w};
+      LstmBwdIn in;
+      lstm_bwd_load(e, m, u, true, in);
+      lstm_bwd_finish(e, m, u, dh, in, dzv);
+    }
+  }
+  if (e.db) {            // bias gradient: column sums of the tile's 32 rows
+    __syncthreads();
+    float* cs = &part[0][0][0];                        // [32 rows][128 = 32 units x 4 gates]
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) cs[row * 128 + (ug + r) * 4 + g] = dzv[r][g];
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      float v = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 32; ++r) v += cs[r * 128 + threadIdx.x];
+      const int u = u0 + (threadIdx.x >> 2), g = threadIdx.x & 3;
+      if (u < e.H) atomicAdd(e.db + (long)g * e.H + u, v);
+    }
+  }
+}
+
 template <class Cfg>
 static inline void launch_lstm_bwd(GemmOperands p, const LstmBwdParams& e, int k1, hipStream_t st) {
   p.nk1 = k1 / kdiv<Cfg>();
@@ -1074,9 +1201,16 @@ extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int 
       case 2: launch_lstm_bwd<CfgBwdV2_128>(p, e, k1, st); break;
       case 4: launch_lstm_bwd<CfgPlainTiny>(p, e, k1, st); break;
       case 5: {
-        p.nk1 = k1 / 32;
         const int tm = ceil_div(M, 32), tn = ceil_div(H, 32);
-        hipLaunchKernelGGL((lstm_bwd_step_skinny_kernel<8, 4>), dim3(tm * tn), dim3(512), 0, st, p, e, tm, tn);
+        if (getenv("EVC_SKINNY_DIRECT")) {               // first form: fragments straight from global memory
+          p.nk1 = k1 / 32;
+          hipLaunchKernelGGL((lstm_bwd_step_skinny_kernel<8, 4>), dim3(tm * tn), dim3(512), 0, st, p, e, tm, tn);
+        } else {
+          constexpr int KW = 4, STG = 4, LDSB = KW * STG * 8192 + KW * 32 * 36 * 4;
+          p.nk1 = k1 / 64;
+          allow_big_lds((const void*)lstm_bwd_step_skinny_lds_kernel<KW, STG>, LDSB);
+          hipLaunchKernelGGL((lstm_bwd_step_skinny_lds_kernel<KW, STG>), dim3(tm * tn), dim3(64 * KW), LDSB, st, p, e, tm, tn);
+        }
         break;
       }
       default: launch_lstm_bwd<CfgPlainSmall>(p, e, k1, st); break;
