@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--shape", default="teacher")
 ap.add_argument("--noplan", action="store_true")
 ap.add_argument("--batch", type=int, default=256)
+ap.add_argument("--hoist", action="store_true", help="x-projection as one GEMM up front (what the engine does for M < 1024)")
 a = ap.parse_args()
 dev = "cuda:0"
 B, H = a.batch, 1024
@@ -64,7 +65,9 @@ def timeit(fn, reps=5):
     return e0.elapsed_time(e1) / reps
 
 
-fwd = timeit(lambda: ops.lstm_layer_fwd(x, wT, b, lens_d, T, P, Kin, H, hbuf, S[:, :H], S[:, H:], 2 * H, gates, c_all, plan=plan))
+zx = torch.empty((T, P, 4 * H), device=dev) if a.hoist else None
+fwd = timeit(lambda: ops.lstm_layer_fwd(x, wT, b, lens_d, T, P, Kin, H, hbuf, S[:, :H], S[:, H:], 2 * H, gates, c_all, hoist=a.hoist,
+                                        zx_ws=zx, plan=plan))
 bwd = timeit(lambda: ops.lstm_layer_bwd(w_il, lens_d, T, P, Kin, H, gates, c_all, dS[:, :H], dS[:, H:], 2 * H, dha, dcw, dz4, plan=plan))
 ffl = sum(2.0 * r * 4 * H * (Kin + (H if t else 0)) for t, r in enumerate(rows))
 bfl = sum(2.0 * r * 4 * H * H for t, r in enumerate(rows) if t < T - 1)
