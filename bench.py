@@ -101,7 +101,10 @@ def main():
     # path on a single-GPU box (RCCL refuses two ranks per device).  Never set in a real run.
     if os.environ.get("EVC_BENCH_SHARED_GPU") == "1":
         local_rank = 0
-    if world > 1:
+    # debug (scripts/rccl_one_rank.sh): EVC_DP_FORCE=1 under a one-process launcher runs the step's collectives
+    # on a one-rank RCCL communicator
+    one_rank_dp = world == 1 and os.environ.get("EVC_DP_FORCE") == "1" and "MASTER_PORT" in os.environ
+    if world > 1 or one_rank_dp:
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if os.environ.get("EVC_BENCH_SHARED_GPU") == "1":
@@ -214,7 +217,7 @@ def main():
         if n_gpus == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.every_n, args.cpu_videos)
         print(json.dumps(res))
-    if world > 1:
+    if world > 1 or one_rank_dp:
         torch.distributed.destroy_process_group()
 
 

@@ -426,12 +426,13 @@ __global__ __launch_bounds__(1024) void moe_update_finalize_kernel(const float* 
   }
 }
 
-extern "C" int evc_moe_grad_update(const evc_bf16* dlogits, int64_t ld_dlogits, const evc_bf16* x, int64_t ldx, int rows,
-                                   int V, int K, float* p, float* m, float* v, evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT,
-                                   float l2_coeff, float* sums, float* partial_ws, float clip_norm, float lr_t,
-                                   float beta1, float beta2, float eps, void* stream) {
+extern "C" int evc_moe_grad_update_phase(const evc_bf16* dlogits, int64_t ld_dlogits, const evc_bf16* x, int64_t ldx, int rows,
+                                         int V, int K, float* p, float* m, float* v, evc_bf16* p_bf16, evc_bf16* pT_bf16,
+                                         int64_t ldT, float l2_coeff, float* sums, float* partial_ws, float clip_norm,
+                                         float lr_t, float beta1, float beta2, float eps, int phase, void* stream) {
   EVC_REQUIRE(rows > 0 && rows % 32 == 0 && V > 0 && V % 4 == 0 && K > 0 && K % 8 == 0, EVC_ERR_BAD_SHAPE,
               "evc_moe_grad_update: rows=%d (%%32), V=%d (%%4), K=%d (%%8)", rows, V, K);
+  EVC_REQUIRE(phase >= 0 && phase <= 2, EVC_ERR_BAD_ARG, "evc_moe_grad_update_phase: phase=%d (0 both, 1 norms, 2 update)", phase);
   EVC_REQUIRE(ld_dlogits % 8 == 0 && ld_dlogits >= V && ldx % 8 == 0 && ldT % 4 == 0 && ldT >= V &&
               ((uintptr_t)dlogits % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)p % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
               ((uintptr_t)v % 16) == 0 && ((uintptr_t)p_bf16 % 8) == 0 && ((uintptr_t)pT_bf16 % 8) == 0, EVC_ERR_BAD_ALIGN,
@@ -444,11 +445,21 @@ extern "C" int evc_moe_grad_update(const evc_bf16* dlogits, int64_t ld_dlogits, 
   GemmOperandsT g{dlogits, ld_dlogits, x, ldx, Vp, K, rows / 32};
   const int tm = ceil_div(V, Cfg::BM), tn = ceil_div(K, Cfg::BU);
   MoeUpdateParams u{p, m, v, p_bf16, pT_bf16, ldT, partial_ws, sums, V, K, l2_coeff, clip_norm, lr_t, beta1, beta2, eps};
-  launch_cfg<Cfg>(moe_update_kernel<Cfg, 1>, tm * tn, st, g, u, tm, tn);
-  hipLaunchKernelGGL(moe_update_finalize_kernel, dim3(1), dim3(1024), 0, st, (const float*)partial_ws, tm * tn, sums);
-  launch_cfg<Cfg>(moe_update_kernel<Cfg, 2>, tm * tn, st, g, u, tm, tn);
+  if (phase != 2) {
+    launch_cfg<Cfg>(moe_update_kernel<Cfg, 1>, tm * tn, st, g, u, tm, tn);
+    hipLaunchKernelGGL(moe_update_finalize_kernel, dim3(1), dim3(1024), 0, st, (const float*)partial_ws, tm * tn, sums);
+  }
+  if (phase != 1) launch_cfg<Cfg>(moe_update_kernel<Cfg, 2>, tm * tn, st, g, u, tm, tn);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
+}
+
+extern "C" int evc_moe_grad_update(const evc_bf16* dlogits, int64_t ld_dlogits, const evc_bf16* x, int64_t ldx, int rows,
+                                   int V, int K, float* p, float* m, float* v, evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT,
+                                   float l2_coeff, float* sums, float* partial_ws, float clip_norm, float lr_t,
+                                   float beta1, float beta2, float eps, void* stream) {
+  return evc_moe_grad_update_phase(dlogits, ld_dlogits, x, ldx, rows, V, K, p, m, v, p_bf16, pT_bf16, ldT, l2_coeff, sums,
+                                   partial_ws, clip_norm, lr_t, beta1, beta2, eps, 0, stream);
 }
 
 // ===========================================================================

@@ -21,6 +21,7 @@ single-device gradient at the global batch; L_PRED is a batch *sum*
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 import torch
@@ -75,32 +76,56 @@ class GradReducer:
     def __init__(self, process_group=None):
         self.pg = process_group
         self.world = 1
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
+        init = torch.distributed.is_available() and torch.distributed.is_initialized()
+        self.rank = 0
+        if init:
             self.world = torch.distributed.get_world_size(process_group)
+            self.rank = torch.distributed.get_rank(process_group)
+        # collectives are issued when there is more than one rank; EVC_DP_FORCE=1 (debug) also issues them on a
+        # one-rank group, which runs the whole RCCL path of a step on a single-GPU box (scripts/rccl_one_rank.sh)
+        self.active = self.world > 1 or (init and os.environ.get("EVC_DP_FORCE") == "1")
         self._pending = []
 
     def reduce(self, flat, lo, hi):
-        if self.world == 1 or hi <= lo:
+        if not self.active or hi <= lo:
             return
         self._pending.append(torch.distributed.all_reduce(flat[lo:hi], op=torch.distributed.ReduceOp.SUM,
                                                           group=self.pg, async_op=True))
 
     def reduce_async(self, flat, lo, hi):
-        """All-reduce of flat[lo:hi] issued after the work queued on the current stream; returns the work handle
-        (its .wait() makes the current stream - not the host - wait), or None on a single rank."""
-        if self.world == 1 or hi <= lo:
+        """All-reduce of flat[lo:hi] in stream order: issued as a *synchronous* c10d op, which ProcessGroupNCCL
+        enqueues on the CURRENT stream (the RCCL kernel sits between the kernels that produce the gradients and the
+        ones that consume them; the host does not wait).  An async_op=True collective runs on the process group's
+        own stream instead, which shares one of the 4 hardware queues with a compute stream: its event then waits
+        for every packet already queued there - measured on a one-rank communicator, where no byte moves: 14.4
+        instead of 13.5 ms per step (scripts/dp_host_probe.py).  Returns None (nothing left to wait for)."""
+        if not self.active or hi <= lo:
             return None
-        return torch.distributed.all_reduce(flat[lo:hi], op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=True)
+        torch.distributed.all_reduce(flat[lo:hi], op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=False)
+        return None
 
     def all_gather_rows(self, t):
         """[rows, cols] bf16 (contiguous) of every rank stacked along the rows, in rank order (the collective
-        moves raw bytes: gloo has neither bfloat16 nor int16)."""
-        if self.world == 1:
+        moves raw bytes: gloo has neither bfloat16 nor int16).  Stream-ordered like reduce_async."""
+        if not self.active:
             return t
         out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        parts = list(out.view(torch.uint8).chunk(self.world, dim=0))
-        torch.distributed.all_gather(parts, t.contiguous().view(torch.uint8), group=self.pg)
+        torch.distributed.all_gather_into_tensor(out.view(torch.uint8), t.contiguous().view(torch.uint8), group=self.pg)
         return out
+
+    def all_reduce_small(self, t):
+        """In-place SUM of a few floats (the partial norm sums of a sharded tensor), stream-ordered."""
+        if self.active:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=False)
+
+    def all_gather_slabs(self, full, slab_rows):
+        """full [world * slab_rows, cols] (contiguous): rank r owns rows [r*slab_rows, (r+1)*slab_rows); every
+        rank's slab is written into every rank's `full`, stream-ordered."""
+        if not self.active:
+            return
+        assert full.is_contiguous() and full.shape[0] == self.world * slab_rows
+        own = full[self.rank * slab_rows:(self.rank + 1) * slab_rows].clone()     # (24 MB at world 8: no aliasing of in / out)
+        torch.distributed.all_gather_into_tensor(full.view(torch.uint8), own.view(torch.uint8), group=self.pg)
 
     def wait(self):
         for w in self._pending:
@@ -151,13 +176,13 @@ class DistillGraph:
         self.device = torch.device(device)
         self.pg = process_group
         self.reducer = GradReducer(process_group)
-        self.world = self.reducer.world
+        self.world, self.dp = self.reducer.world, self.reducer.active
         # The student's collectives get a communicator of their own: one process group executes its collectives in
         # issue order, so on a shared group the teacher's early factor all-gather (host-issued after the student's
         # backward) would queue behind the student's last gradient all-reduce and hold the teacher's whole update
         # chain back.  (new_group is collective: every rank constructs the graph.)
         self.reducer_s = self.reducer
-        if self.world > 1 and mode == "teacher_student":
+        if self.dp and mode == "teacher_student":
             ranks = list(range(torch.distributed.get_world_size(process_group))) if process_group is None else None
             self.reducer_s = GradReducer(torch.distributed.new_group(ranks) if ranks is not None else process_group)
         self.global_step = 0
@@ -302,8 +327,8 @@ class DistillGraph:
                 self.student.backward(ds, self._dp_s,
                                       on_moe_grads_ready=None if early else (lambda: self._reduce_tower(self.student, True)),
                                       aux=self._aux_s if self.overlap_towers else None, early_apply=early,
-                                      reduce_fn=(lambda lo, hi: self.reducer_s.reduce_async(st_s.grad, lo, hi)) if (early and self.world > 1) else None,
-                                      gather_fn=self.reducer_s.all_gather_rows if (early and self.world > 1) else None)
+                                      reduce_fn=(lambda lo, hi: self.reducer_s.reduce_async(st_s.grad, lo, hi)) if (early and self.dp) else None,
+                                      dp=self.reducer_s if (early and self.dp) else None)
                 if not early:
                     self._reduce_tower(self.student, False)
                 self._student_applied = early is not None
@@ -326,8 +351,8 @@ class DistillGraph:
             self.teacher.backward(None, self._dp_t,
                                   on_moe_grads_ready=None if early else (lambda: self._reduce_tower(self.teacher, True)),
                                   aux=self._aux_t if self.overlap_towers else None, early_apply=early,
-                                  reduce_fn=(lambda lo, hi: self.reducer.reduce_async(st_t.grad, lo, hi)) if (early and self.world > 1) else None,
-                                  gather_fn=self.reducer.all_gather_rows if (early and self.world > 1) else None)
+                                  reduce_fn=(lambda lo, hi: self.reducer.reduce_async(st_t.grad, lo, hi)) if (early and self.dp) else None,
+                                  dp=self.reducer if (early and self.dp) else None)
             if not early:
                 self._reduce_tower(self.teacher, False)
             mark("teacher_bwd_done", main)
@@ -357,11 +382,19 @@ class DistillGraph:
             self.global_step += 1
         self._teacher_applied = self._student_applied = False
 
+    def consolidate(self):
+        """Collective (every rank calls it; a no-op on one rank): the row-sharded f32 MoE weights and Adam moments
+        (MoeHead.shard) are all-gathered so that every rank holds the complete model again - before a checkpoint,
+        state_dict(), or any update that does not go through the fused data-parallel path."""
+        for tw, red in ((self.teacher, self.reducer), (self.student, self.reducer_s)):
+            if tw is not None:
+                tw.moe.consolidate(red)
+
     def loss_report(self):
         """Host floats in the order the reference logs them (cs/train.py:528-533)."""
         v = self.losses.tolist()
         rep = {k: v[i] for i, k in enumerate(self.LOSS_SLOTS)}
-        if self.world > 1:   # per-rank values -> global-batch values (means / sum)
+        if self.dp:   # per-rank values -> global-batch values (means / sum)
             t = torch.tensor([rep[k] for k in self.LOSS_SLOTS], dtype=torch.float64, device=self.device)
             torch.distributed.all_reduce(t, group=self.pg)
             t = t.tolist()

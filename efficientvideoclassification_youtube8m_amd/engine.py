@@ -320,23 +320,83 @@ class MoeHead:
         """evc_moe_grad_update's shape constraints (the reference sizes satisfy them: 14148, 9432, 4096)."""
         return (self.V * (self.Mx + 1)) % 4 == 0 and (self.V * self.Mx) % 4 == 0 and self.K % 8 == 0
 
-    def fused_update(self, lr_t, clip_norm, l2_coeff, beta1=0.9, beta2=0.999, eps=1e-8, gather_fn=None):
+    # ---- data parallel: the two weight matrices are sharded by rows over the ranks (ZeRO-1) ----------------
+    def shard(self, world, rank):
+        """Row slabs of 128-row tiles: rank r owns rows [r*slab, (r+1)*slab) of each weight matrix - their f32
+        weights and Adam moments are kept current only there; the bf16 forward shadow (re-allocated here with
+        world*slab rows so that equal slabs can be all-gathered in place) is complete on every rank."""
+        tw = self.tw
+        self.world, self.rank, self.slab, self._stale = world, rank, {}, False
+        for name, Vn in ((self.GATES, self.V * (self.Mx + 1)), (self.EXPERTS, self.V * self.Mx)):
+            tiles = (Vn + 127) // 128
+            slab = (tiles + world - 1) // world * 128
+            self.slab[name] = slab
+            old = tw.shadow_fwd[name]
+            full = torch.zeros((slab * world, self.K), dtype=BF16, device=old.device)
+            full[:Vn].copy_(old)
+            tw.shadow_fwd[name] = full[:Vn]
+            setattr(self, "_full_" + ("g" if name == self.GATES else "e"), full)
+
+    def _full(self, name):
+        return self._full_g if name == self.GATES else self._full_e
+
+    def consolidate(self, dp):
+        """Collective: brings the sharded f32 weights and Adam moments of every rank up to date (before a checkpoint,
+        an export or an evaluation that reads them)."""
+        if getattr(self, "world", 1) == 1 or not self._stale:
+            return
+        st = self.tw.store
+        for name, Vn in ((self.GATES, self.V * (self.Mx + 1)), (self.EXPERTS, self.V * self.Mx)):
+            slab = self.slab[name]
+            v0 = self.rank * slab
+            tmp = torch.zeros((slab * self.world, self.K), dtype=F32, device=self.tw.device)
+            for t in (st.p(name), st.view(st.m, name), st.view(st.v, name)):
+                if v0 < Vn:
+                    tmp[v0:min(Vn, v0 + slab)].copy_(t[v0:v0 + slab])
+                dp.all_gather_slabs(tmp, slab)
+                t.copy_(tmp[:Vn])
+        self._stale = False
+
+    def fused_update(self, lr_t, clip_norm, l2_coeff, beta1=0.9, beta2=0.999, eps=1e-8, dp=None):
         """Weight gradient + per-tensor clip + TF-Adam + both bf16 shadows of the two MoE weight matrices from the
         factors dlogits / x left by backward(weight_grads=False), without materialising the gradients
         (evc_moe_grad_update); the expert biases go the ordinary way (column sums, then clip + Adam).
-        gather_fn (data parallel): all-gathers a [rows, cols] bf16 factor image over the ranks along the rows -
-        the contraction over world x batch rows IS the summed gradient, so no gradient all-reduce is needed."""
+        dp (distill.GradReducer, data parallel): the factors are all-gathered over the ranks along the rows - the
+        contraction over world x batch rows IS the summed gradient, so no gradient all-reduce is needed - and each
+        rank updates only its row slab (shard()): phase 1 on the slab, 8-byte all-reduce of the norm sums, phase 2 on
+        the slab, all-gather of the slab's new bf16 rows, local transpose for the backward shadow.  Per rank: the
+        flops of a single-GPU update and 1/world of its HBM traffic."""
         tw, V, Mx, K = self.tw, self.V, self.Mx, self.K
         dgl, del_, x = self.dgl_full, self.del_full, self.x_full
-        if gather_fn is not None:
-            dgl, del_, x = gather_fn(dgl), gather_fn(del_), gather_fn(x)
+        if dp is not None:
+            dgl, del_, x = dp.all_gather_rows(dgl), dp.all_gather_rows(del_), dp.all_gather_rows(x)
+            if getattr(self, "world", None) != dp.world:
+                self.shard(dp.world, dp.rank)
         rows = x.shape[0]
         idx = {k: i for i, k in enumerate(tw.names)}
         st = tw.store
         for name, dlog, Vn in ((self.GATES, dgl, V * (Mx + 1)), (self.EXPERTS, del_, V * Mx)):
-            ops.moe_grad_update(dlog, x, rows, Vn, K, st.p(name), st.view(st.m, name), st.view(st.v, name),
-                                tw.shadow_fwd[name], tw.shadow_bwd[name], l2_coeff if name in tw.l2_names else 0.0,
-                                tw.sums[idx[name]], self.partial_ws, clip_norm, lr_t, beta1, beta2, eps)
+            l2 = l2_coeff if name in tw.l2_names else 0.0
+            pw, mw, vw = st.p(name), st.view(st.m, name), st.view(st.v, name)
+            if dp is None:
+                ops.moe_grad_update(dlog, x, rows, Vn, K, pw, mw, vw, tw.shadow_fwd[name], tw.shadow_bwd[name], l2,
+                                    tw.sums[idx[name]], self.partial_ws, clip_norm, lr_t, beta1, beta2, eps)
+                continue
+            slab = self.slab[name]
+            v0 = dp.rank * slab
+            vs = min(Vn, v0 + slab) - v0                                   # rows of this rank's slab (<= 0: none)
+            args = None
+            if vs > 0:
+                args = (dlog[:, v0:], x, rows, vs, K, pw[v0:], mw[v0:], vw[v0:], self._full(name)[v0:], tw.shadow_bwd[name][:, v0:],
+                        l2, tw.sums[idx[name]], self.partial_ws, clip_norm, lr_t, beta1, beta2, eps)
+                ops.moe_grad_update(*args, phase=1)
+            dp.all_reduce_small(tw.sums[idx[name]])
+            if vs > 0:
+                ops.moe_grad_update(*args, phase=2)
+            dp.all_gather_slabs(self._full(name), slab)
+            sb = tw.shadow_bwd[name]
+            ops.transpose_to_bf16(tw.shadow_fwd[name], Vn, K, sb, sb.shape[1])
+            self._stale = dp.world > 1
         gb = st.g(self.EBIAS)
         ops.colsum_bf16(del_, rows, V * Mx, gb)
         ops.grad_sqnorm(gb, st.p(self.EBIAS), 0.0, tw.sums[idx[self.EBIAS]])
@@ -505,6 +565,12 @@ class HLstmTower(TowerBase):
         self._alloc(batch_size)
 
     # ---- parameters -------------------------------------------------------
+    def state_dict(self):
+        if getattr(self.moe, "_stale", False):
+            raise RuntimeError("the MoE weights of %r are sharded over the ranks; call DistillGraph.consolidate() on "
+                               "every rank before reading them" % self.scope)
+        return super().state_dict()
+
     def _init_params(self, seed):
         """TF defaults at the reference call sites: glorot-uniform kernels /
         fully_connected weights, zero biases."""
@@ -580,7 +646,7 @@ class HLstmTower(TowerBase):
 
     fused_moe_update = True      # recompute the rank-B MoE gradient inside the Adam step instead of materialising it
 
-    def backward(self, dstate, dpred, on_moe_grads_ready=None, aux=None, early_apply=None, reduce_fn=None, gather_fn=None):
+    def backward(self, dstate, dpred, on_moe_grads_ready=None, aux=None, early_apply=None, reduce_fn=None, dp=None):
         """dstate [B,2LH] f32 or None (gradient on the returned state), dpred [B,V] f32.
         Fills self.store.grad (every segment is overwritten).
         aux: side stream that takes the weight-gradient GEMMs (and, with early_apply =
@@ -589,8 +655,8 @@ class HLstmTower(TowerBase):
         reduce_fn(lo, hi) -> work handle or None: data-parallel all-reduce of a gradient segment; with
         early_apply each group is reduced on the aux stream right after its gradients are final and updated
         as soon as the collective has finished.
-        gather_fn(t): data-parallel all-gather of a bf16 factor image along its rows; with it the MoE weights
-        (2/3 of the parameters) need no gradient all-reduce at all (MoeHead.fused_update)."""
+        dp (distill.GradReducer): with it the MoE weights (2/3 of the parameters) need no gradient all-reduce at all -
+        factor all-gather + row-sharded update (MoeHead.fused_update)."""
         assert self.training
         main = torch.cuda.current_stream(self.device)
         g_moe, g_l2, g_l1 = self.param_groups()
@@ -604,7 +670,10 @@ class HLstmTower(TowerBase):
             self.apply_group(names, *early_apply)
 
         fuse = (aux is not None and early_apply is not None and self.fused_moe_update and self.precision == "bf16"
-                and self.moe.can_fuse_update() and (reduce_fn is None or gather_fn is not None))
+                and self.moe.can_fuse_update() and (reduce_fn is None or dp is not None))
+        if not fuse and getattr(self.moe, "_stale", False):
+            raise RuntimeError("the MoE weights of %r are sharded over the ranks (fused data-parallel update); call "
+                               "DistillGraph.consolidate() on every rank before an update that is not" % self.scope)
         dS2 = self.moe.backward(dpred, dstate, weight_grads=not fuse)
         if on_moe_grads_ready is not None:
             on_moe_grads_ready()
@@ -616,7 +685,7 @@ class HLstmTower(TowerBase):
             with torch.cuda.stream(aux):                               # 2/3 of the parameters, under the LSTM BPTT
                 if fuse:
                     lr, clip, l2c = early_apply
-                    self.moe.fused_update(self.adam_lr_t(lr), clip, l2c, gather_fn=gather_fn)
+                    self.moe.fused_update(self.adam_lr_t(lr), clip, l2c, dp=dp)
                 else:
                     reduce_then_apply(g_moe, seg_moe)
         dS1 = self.l2.backward(dS2, need_dx=True, aux=aux)              # [C*B][2LH] = d(L1 final state)

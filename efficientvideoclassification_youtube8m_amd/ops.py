@@ -220,11 +220,12 @@ def moe_tail_bwd(gate_logits, expert_logits, dpred, B, V, M, dgate, dexpert):
 
 
 def moe_grad_update(dlogits, x, rows, V, K, p, m, v, p_bf16, pT_bf16, l2_coeff, sums, partial_ws, clip_norm, lr_t,
-                    beta1=0.9, beta2=0.999, eps=1e-8):
-    """Fused weight-gradient + per-tensor clip + TF-Adam of one MoE weight matrix (evc_moe_grad_update)."""
-    _lib.call("evc_moe_grad_update", _p(dlogits), dlogits.stride(0), _p(x), x.stride(0), rows, V, K, _p(p), _p(m), _p(v),
+                    beta1=0.9, beta2=0.999, eps=1e-8, phase=0):
+    """Fused weight-gradient + per-tensor clip + TF-Adam of one MoE weight matrix (evc_moe_grad_update); phase 1 / 2:
+    the norm pass / the update pass alone, for a row slab of a matrix sharded over ranks (evc_moe_grad_update_phase)."""
+    _lib.call("evc_moe_grad_update_phase", _p(dlogits), dlogits.stride(0), _p(x), x.stride(0), rows, V, K, _p(p), _p(m), _p(v),
               _p(p_bf16), _p(pT_bf16), pT_bf16.stride(0), l2_coeff, _p(sums), _p(partial_ws), clip_norm, lr_t, beta1, beta2, eps,
-              _stream())
+              phase, _stream())
 
 
 def ce_loss(pred, labels_u8, loss, dpred=None, grad_scale=1.0, accumulate_grad=False):

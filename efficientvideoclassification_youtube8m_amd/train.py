@@ -131,6 +131,8 @@ def latest_checkpoint(train_dir):
 
 
 def save_checkpoint(graph, train_dir, rank):
+    if hasattr(graph, "consolidate"):
+        graph.consolidate()                 # collective: sharded optimizer state -> complete on every rank
     if rank != 0:
         return
     os.makedirs(train_dir, exist_ok=True)

@@ -184,6 +184,17 @@ int evc_moe_grad_update(const evc_bf16* dlogits, int64_t ld_dlogits, const evc_b
                         int V, int K, float* p, float* m, float* v, evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT,
                         float l2_coeff, float* sums, float* partial_ws, float clip_norm, float lr_t,
                         float beta1, float beta2, float eps, void* stream);
+/* The same in two halves, for a weight matrix whose rows are SHARDED over data-parallel ranks (every pointer
+ * already offset to the rank's row slab [v0, v0 + V): dlogits + v0, p/m/v/p_bf16 + v0*K, pT_bf16 + v0):
+ *   phase 1: sums[0..1] += this slab's share of sum (g + l2 p)^2 and sum p^2   (then all-reduce sums: 8 bytes)
+ *   phase 2: clip (by the norm of the WHOLE tensor in sums[0]) + Adam + shadows of the slab
+ *   phase 0: both back to back (= evc_moe_grad_update).
+ * The slab's updated bf16 rows are then all-gathered; f32 p / m / v stay sharded (ZeRO-1 for 2/3 of the
+ * parameters: each rank streams 1/world of the Adam state, nothing contracts over more rows than it must). */
+int evc_moe_grad_update_phase(const evc_bf16* dlogits, int64_t ld_dlogits, const evc_bf16* x, int64_t ldx, int rows,
+                              int V, int K, float* p, float* m, float* v, evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT,
+                              float l2_coeff, float* sums, float* partial_ws, float clip_norm, float lr_t,
+                              float beta1, float beta2, float eps, int phase, void* stream);
 
 /* ---- layout helpers --------------------------------------------------------
  * out[c][r] = in[r][c], r < R, c < C; out has ld_out >= Rpad columns and

@@ -23,7 +23,7 @@ rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.ar
 torch.cuda.set_device(0)
 if world > 1:
     torch.distributed.init_process_group("gloo", init_method="tcp://127.0.0.1:" + port, rank=rank, world_size=world)
-GB, F, V = 8, 128, 40
+GB, F, V = 8, 128, 200      # MoE gates [600][256]: 5 row tiles -> slabs of 384 / 216 rows on two ranks
 q, x, n, labels = mm.synthetic_batch(GB, seed=21, feature_size=F, vocab_size=V, dtype=np.float32)
 b = GB // world
 sl = slice(rank * b, (rank + 1) * b)
@@ -33,6 +33,15 @@ for it in range(2):
     o = g.step(xd, yd, nd, num_frames_host=n[sl])
 rep = g.loss_report()
 torch.cuda.synchronize()
+if world > 1:
+    # the fused data-parallel update leaves the f32 MoE weights / moments sharded by rows: reading them must fail loudly ...
+    assert g.teacher.moe._stale and g.teacher.moe.slab[g.teacher.moe.GATES] == 384
+    try:
+        g.teacher.state_dict()
+        raise SystemExit("state_dict() of a sharded tower did not raise")
+    except RuntimeError:
+        pass
+g.consolidate()            # ... until every rank has gathered the slabs (collective; no-op on one rank)
 if rank == 0:
     sd = {}
     sd.update({k: v.cpu() for k, v in g.teacher.state_dict().items()})
