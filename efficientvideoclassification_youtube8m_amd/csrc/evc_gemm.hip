@@ -481,10 +481,10 @@ struct LstmFwdParams {
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) { return pack_bf16x2_hw(lo, hi); }
 
 template <class Cfg, bool SPLIT = false>
-__global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, LstmFwdParams e, int tiles_m, int tiles_n) {
+__device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const LstmFwdParams& e, int tiles_m, int tiles_n, int bid) {
   static_assert(Cfg::G == 4, "LSTM step needs the four gate groups");
   const int nwg = tiles_m * tiles_n;
-  const int id = xcd_remap(blockIdx.x, nwg);
+  const int id = xcd_remap(bid, nwg);
   int tm, tn;
   tile_of(id, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * Cfg::BM, u0 = tn * Cfg::BU;
@@ -591,6 +591,25 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, 
       }
     }
   }
+}
+
+template <class Cfg, bool SPLIT = false>
+__global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, LstmFwdParams e, int tiles_m, int tiles_n) {
+  lstm_fwd_step_body<Cfg, SPLIT>(p, e, tiles_m, tiles_n, blockIdx.x);
+}
+
+// Two independent steps of the same geometry in one launch (the first tiles_m*tiles_n workgroups run step a, the
+// rest step b): layer 0 at time t+1 and layer 1 at time t of a two-layer stack with M ~ batch rows - those steps are
+// latency-bound (12 us for 2 GFLOP), so the pair costs about what one of them does and the stack's chain of
+// dependent launches is T+1 long instead of 2T (evc_lstm_stack2_fwd).
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT) void lstm_fwd_pair_kernel(GemmOperands pa, LstmFwdParams ea, GemmOperands pb, LstmFwdParams eb,
+                                                                int tiles_m, int tiles_n) {
+  const int n = tiles_m * tiles_n;
+  const bool first = blockIdx.x < n;                   // workgroup-uniform: scalar selects of the two argument sets
+  const GemmOperands p = first ? pa : pb;
+  const LstmFwdParams e = first ? ea : eb;
+  lstm_fwd_step_body<Cfg, false>(p, e, tiles_m, tiles_n, first ? blockIdx.x : blockIdx.x - n);
 }
 
 typedef TileCfg<128, 4, 32, 2, 2> CfgLstmBig;    // 128 rows x 32 units x 4 gates
@@ -727,6 +746,110 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
       case 8: launch_lstm_fwd<CfgLstmV2_128>(p, e, k1, k2, st); break;
       case 9: launch_lstm_fwd<CfgLstmV2_64>(p, e, k1, k2, st); break;
       default: launch_lstm_fwd<CfgLstmSmall>(p, e, k1, k2, st); break;
+    }
+  }
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// One layer's view of a stack for evc_lstm_stack2_fwd
+struct FwdLayer {
+  const bf16_t* x; int Kin;            // [T][M][Kin] input (unused when the x-projection is hoisted)
+  const bf16_t* wT; const float* bias;
+  const float* zx;                     // hoisted x-projection [T][M][4H] or NULL
+  bf16_t* hbuf; float* c_state; float* h_state;
+  void* gates; bf16_t* c_all;
+};
+
+static inline void fwd_step_args(const FwdLayer& L, const int32_t* len, int t, int M, int H, int64_t ld_state,
+                                 GemmOperands& p, LstmFwdParams& e, int& k1, int& k2) {
+  p.M = M; p.Nu = H; p.group_stride = H; p.ldb = L.Kin + H; p.nk1 = p.nk2 = 0;
+  p.A1lo = p.A2lo = p.Blo = nullptr;
+  const bf16_t* hprev = L.hbuf + (long)t * M * H;
+  if (L.zx) {
+    p.A1 = hprev; p.lda1 = H; k1 = (t == 0) ? 0 : H; p.A2 = hprev; p.lda2 = H; k2 = 0;
+    p.B = L.wT + L.Kin;
+  } else {
+    p.A1 = L.x + (long)t * M * L.Kin; p.lda1 = L.Kin; k1 = L.Kin;
+    p.A2 = hprev; p.lda2 = H; k2 = (t == 0) ? 0 : H;
+    p.B = L.wT;
+  }
+  e.zx = L.zx ? L.zx + (long)t * M * 4 * H : nullptr; e.ldzx = 4L * H;
+  e.bias = L.bias; e.len = len; e.t = t;
+  e.c_state = L.c_state; e.h_state = L.h_state; e.ld_state = ld_state;
+  e.hout = L.hbuf + (long)(t + 1) * M * H;
+  e.hout_lo = nullptr;
+  e.gates = L.gates ? (uint2*)L.gates + (long)t * M * H : nullptr;
+  e.c_hist = L.c_all ? L.c_all + (long)(t + 1) * M * H : nullptr;
+  e.row_map = nullptr;
+  e.M = M; e.H = H;
+}
+
+template <class Cfg>
+static inline void launch_lstm_fwd_pair(GemmOperands pa, const LstmFwdParams& ea, int k1a, int k2a,
+                                        GemmOperands pb, const LstmFwdParams& eb, int k1b, int k2b, hipStream_t st) {
+  pa.nk1 = k1a / kdiv<Cfg>(); pa.nk2 = k2a / kdiv<Cfg>();
+  pb.nk1 = k1b / kdiv<Cfg>(); pb.nk2 = k2b / kdiv<Cfg>();
+  const int tm = ceil_div(ea.M, Cfg::BM), tn = ceil_div(ea.H, Cfg::BU);
+  launch_cfg<Cfg>(lstm_fwd_pair_kernel<Cfg>, 2 * tm * tn, st, pa, ea, pb, eb, tm, tn);
+}
+
+extern "C" int evc_lstm_stack2_fwd(const evc_bf16* x, const evc_bf16* wT0, const float* bias0, const evc_bf16* wT1, const float* bias1,
+                                   const int32_t* len, int T, int M, int Kin, int H, float* zx_ws,
+                                   evc_bf16* hbuf0, evc_bf16* hbuf1, float* c_state0, float* h_state0, float* c_state1,
+                                   float* h_state1, int64_t ld_state, void* gates0, evc_bf16* c_all0, void* gates1,
+                                   evc_bf16* c_all1, void* stream) {
+  EVC_REQUIRE(T > 0 && M > 0 && H > 0 && Kin > 0 && H % 64 == 0 && Kin % 64 == 0, EVC_ERR_BAD_SHAPE,
+              "evc_lstm_stack2_fwd: bad shape T=%d M=%d Kin=%d H=%d (Kin, H multiples of 64)", T, M, Kin, H);
+  EVC_REQUIRE(zx_ws && hbuf0 && hbuf1, EVC_ERR_BAD_ARG, "evc_lstm_stack2_fwd: zx_ws / hbuf0 / hbuf1 must not be NULL");
+  EVC_REQUIRE(ld_state % 4 == 0 && ((uintptr_t)c_state0 % 16) == 0 && ((uintptr_t)h_state0 % 16) == 0 && ((uintptr_t)c_state1 % 16) == 0 &&
+              ((uintptr_t)h_state1 % 16) == 0 && ((uintptr_t)bias0 % 16) == 0 && ((uintptr_t)bias1 % 16) == 0 &&
+              ((uintptr_t)hbuf0 % 8) == 0 && ((uintptr_t)hbuf1 % 8) == 0, EVC_ERR_BAD_ALIGN,
+              "evc_lstm_stack2_fwd: state/bias/hbuf must allow 16-byte vector access");
+  EVC_REQUIRE((gates0 == nullptr) == (c_all0 == nullptr) && (gates1 == nullptr) == (c_all1 == nullptr) &&
+              (gates0 == nullptr) == (gates1 == nullptr), EVC_ERR_BAD_ARG, "evc_lstm_stack2_fwd: gates and c_all go together, for both layers");
+  EVC_REQUIRE(!gates0 || (((uintptr_t)gates0 % 16) == 0 && ((uintptr_t)gates1 % 16) == 0 && ((uintptr_t)c_all0 % 8) == 0 &&
+                          ((uintptr_t)c_all1 % 8) == 0), EVC_ERR_BAD_ALIGN, "evc_lstm_stack2_fwd: gates must be 16-byte, c_all 8-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  EVC_CHECK_HIP(hipMemsetAsync(hbuf0, 0, (size_t)M * H * sizeof(bf16_t), st));       // h_{-1} = 0, both layers
+  EVC_CHECK_HIP(hipMemsetAsync(hbuf1, 0, (size_t)M * H * sizeof(bf16_t), st));
+  // layer 0: x-projection of all T steps as one GEMM (M ~ batch: a per-step product would be a sliver)
+  int rc = evc_gemm_nt(x, Kin, wT0, (int64_t)Kin + H, zx_ws, 4L * H, T * M, 4 * H, Kin, nullptr, 0, 0, stream);
+  if (rc) return rc;
+  const FwdLayer L0{x, Kin, wT0, bias0, zx_ws, hbuf0, c_state0, h_state0, gates0, c_all0};
+  // layer 1 reads layer 0's output slab t+1 as its x_t; fused [x_t | h_{t-1}] contraction (nothing to hoist: x_t
+  // exists only one launch earlier)
+  const FwdLayer L1{hbuf0 + (long)M * H, H, wT1, bias1, nullptr, hbuf1, c_state1, h_state1, gates1, c_all1};
+  const int tile = pick_fwd_tile(M, H);     // 6: v1 128 rows x 32 units, 7 (M ~ 256): v1 64 x 16; others: one step per launch
+  for (int s = 0; s <= T; ++s) {            // launch s: layer 0 step s next to layer 1 step s-1
+    GemmOperands pa, pb;
+    LstmFwdParams ea, eb;
+    int k1a = 0, k2a = 0, k1b = 0, k2b = 0;
+    const bool has_a = s < T, has_b = s >= 1;
+    if (has_a) fwd_step_args(L0, len, s, M, H, ld_state, pa, ea, k1a, k2a);
+    if (has_b) fwd_step_args(L1, len, s - 1, M, H, ld_state, pb, eb, k1b, k2b);
+    if (has_a && has_b && (tile == 6 || tile == 7)) {
+      if (tile == 6) launch_lstm_fwd_pair<CfgLstmBig>(pa, ea, k1a, k2a, pb, eb, k1b, k2b, st);
+      else launch_lstm_fwd_pair<CfgLstmSmall>(pa, ea, k1a, k2a, pb, eb, k1b, k2b, st);
+      continue;
+    }
+    for (int r = 0; r < 2; ++r) {
+      if (!(r == 0 ? has_a : has_b)) continue;
+      const GemmOperands& p = r == 0 ? pa : pb;
+      const LstmFwdParams& e = r == 0 ? ea : eb;
+      const int k1 = r == 0 ? k1a : k1b, k2 = r == 0 ? k2a : k2b;
+      switch (tile) {
+        case 0: launch_lstm_fwd<CfgLstmV2a>(p, e, k1, k2, st); break;
+        case 1: launch_lstm_fwd<CfgLstmV2_288>(p, e, k1, k2, st); break;
+        case 2: launch_lstm_fwd<CfgLstmV2b>(p, e, k1, k2, st); break;
+        case 3: launch_lstm_fwd<CfgLstmV2_224>(p, e, k1, k2, st); break;
+        case 4: launch_lstm_fwd<CfgLstmV2_192>(p, e, k1, k2, st); break;
+        case 5: launch_lstm_fwd<CfgLstmV2_160>(p, e, k1, k2, st); break;
+        case 6: launch_lstm_fwd<CfgLstmBig>(p, e, k1, k2, st); break;
+        case 8: launch_lstm_fwd<CfgLstmV2_128>(p, e, k1, k2, st); break;
+        case 9: launch_lstm_fwd<CfgLstmV2_64>(p, e, k1, k2, st); break;
+        default: launch_lstm_fwd<CfgLstmSmall>(p, e, k1, k2, st); break;
+      }
     }
   }
   EVC_LAUNCH_CHECK();

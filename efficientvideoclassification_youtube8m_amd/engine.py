@@ -26,6 +26,7 @@ and layouts of SURVEY.md Appendix C.
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -105,6 +106,7 @@ class LstmStack:
         base = "%s/rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/" % (self.scope, l)
         return base + "kernel", base + "bias"
 
+    wavefront = os.environ.get("EVC_NO_WAVEFRONT") != "1"   # two-layer M ~ batch stacks: see forward()
     timing = None      # set to a list to collect (start event, end event, launches, algorithmic flops) per layer forward
 
     @staticmethod
@@ -149,6 +151,13 @@ class LstmStack:
         self.x_in, self.lens = x, lens
         inp = x
         rows = plan.rows if plan is not None else [M] * T
+        if (L == 2 and plan is None and all(self.hoist) and self.wavefront and self.timing is None
+                and self.Kin % 64 == 0 and H % 64 == 0):
+            # M ~ batch: layer 0 step t+1 and layer 1 step t share a launch (T+1 dependent launches instead of 2T)
+            (k0, b0), (k1, b1) = self.names(0), self.names(1)
+            ops.lstm_stack2_fwd(x, tw.shadow_fwd[k0], tw.store.p(b0), tw.shadow_fwd[k1], tw.store.p(b1), lens, T, M,
+                                self.Kin, H, self.zx, hb[0], hb[1], self.S, gates, c_all)
+            return self.S
         for l in range(L):
             kn, bn = self.names(l)
             if self.timing is not None:                         # bench.py: live timing of the step launches of each layer

@@ -197,6 +197,13 @@ def lstm_layer_fwd(x, wT, bias, lens, T, M, Kin, H, hbuf, c_state, h_state, ld_s
               _p(hbuf), _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_all), *_plan_args(plan), _stream())
 
 
+def lstm_stack2_fwd(x, wT0, bias0, wT1, bias1, lens, T, M, Kin, H, zx_ws, hbuf0, hbuf1, S, gates=(None, None), c_all=(None, None)):
+    """Two-layer stack, M ~ batch rows, wavefront order (evc_lstm_stack2_fwd).  S [M][4H] f32 = [c0 | h0 | c1 | h1]."""
+    _lib.call("evc_lstm_stack2_fwd", _p(x), _p(wT0), _p(bias0), _p(wT1), _p(bias1), _p(lens), T, M, Kin, H, _p(zx_ws),
+              _p(hbuf0), _p(hbuf1), _p(S[:, 0:]), _p(S[:, H:]), _p(S[:, 2 * H:]), _p(S[:, 3 * H:]), S.stride(0),
+              _p(gates[0]), _p(c_all[0]), _p(gates[1]), _p(c_all[1]), _stream())
+
+
 def lstm_layer_fwd_hp(x, x_lo, wT, wT_lo, bias, lens, T, M, Kin, H, hbuf, hbuf_lo, c_state, h_state, ld_state,
                       gates=None, c_all=None, plan=None):
     _lib.call("evc_lstm_layer_fwd_hp", _p(x), _p(x_lo), _p(wT), _p(wT_lo), _p(bias), _p(lens), T, M, Kin, H,

@@ -134,6 +134,55 @@ def test_lstm_layer_fwd_and_bwd(ops, M, T, Kin, H, hoist):
     assert torch.equal(sb, w_il)
 
 
+@pytest.mark.parametrize("M,T,Kin,H", [(256, 5, 128, 64), (70, 6, 64, 128), (512, 3, 256, 128), (1200, 2, 64, 64)])
+def test_lstm_stack2_wavefront_fwd(ops, M, T, Kin, H):
+    """evc_lstm_stack2_fwd (layer 0 step t+1 and layer 1 step t in one launch) against the float64 oracle's 2-layer
+    MultiRNNCell and against two evc_lstm_layer_fwd calls: layer 0 bit-identical, layer 1 equal up to the rounding of
+    the hoisted vs fused x-projection."""
+    rng = np.random.default_rng(M + T + Kin + H)
+    x = bf16_round(rng.standard_normal((M, T, Kin)) * 0.5)
+    k0 = bf16_round(mm.glorot_uniform(rng, (Kin + H, 4 * H)) * 2.0)
+    k1 = bf16_round(mm.glorot_uniform(rng, (2 * H, 4 * H)) * 2.0)
+    b0 = (rng.standard_normal(4 * H) * 0.1).astype(np.float32).astype(np.float64)
+    b1 = (rng.standard_normal(4 * H) * 0.1).astype(np.float32).astype(np.float64)
+    lens = rng.integers(0, T + 1, size=M).astype(np.int32)
+    lens[:3] = [0, T, 1]
+    s_ref, _ = mm.multi_rnn_seq_fwd(x, lens, [(k0, b0), (k1, b1)])
+    xt = to_bf16(np.ascontiguousarray(x.transpose(1, 0, 2)))
+    w0, w1 = to_bf16(np.ascontiguousarray(k0.T)), to_bf16(np.ascontiguousarray(k1.T))
+    bb0, bb1 = (torch.from_numpy(b.astype(np.float32)).to(DEV) for b in (b0, b1))
+    ln = torch.from_numpy(lens).to(DEV)
+
+    def bufs():
+        hb = [torch.full((T + 1, M, H), float("nan"), dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+        S = torch.full((M, 4 * H), float("nan"), dtype=torch.float32, device=DEV)
+        g = [torch.zeros((T, M, H, 2), dtype=torch.int32, device=DEV) for _ in range(2)]
+        c = [torch.full((T + 1, M, H), float("nan"), dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+        return hb, S, g, c
+
+    zx = torch.empty((T * M, 4 * H), dtype=torch.float32, device=DEV)
+    hb, S, g, c = bufs()
+    ops.lstm_stack2_fwd(xt, w0, bb0, w1, bb1, ln, T, M, Kin, H, zx, hb[0], hb[1], S, g, c)
+    got = S.cpu().double().numpy()
+    assert np.isfinite(got).all()
+    assert np.max(np.abs(got - s_ref)) < 8e-3, np.max(np.abs(got - s_ref))
+    assert np.all(got[0] == 0)
+    # the same stack, one layer after the other
+    hb2, S2, g2, c2 = bufs()
+    ops.lstm_layer_fwd(xt, w0, bb0, ln, T, M, Kin, H, hb2[0], S2[:, :H], S2[:, H:], 4 * H, g2[0], c2[0], hoist=True, zx_ws=zx)
+    ops.lstm_layer_fwd(hb2[0][1:], w1, bb1, ln, T, M, H, H, hb2[1], S2[:, 2 * H:], S2[:, 3 * H:], 4 * H, g2[1], c2[1], hoist=True, zx_ws=zx)
+    assert torch.equal(hb[0], hb2[0]) and torch.equal(S[:, :2 * H], S2[:, :2 * H]) and torch.equal(g[0], g2[0])
+    assert torch.equal(torch.nan_to_num(c[0][1:].float()), torch.nan_to_num(c2[0][1:].float()))   # rows past their length are not written
+    assert (S[:, 2 * H:] - S2[:, 2 * H:]).abs().max().item() < 4e-3
+    assert (hb[1].float() - hb2[1].float()).abs().max().item() < 2e-2      # a bf16 ulp or two of values up to 1
+    for t in range(T):
+        assert bool((hb[1][t + 1][ln <= t] == 0).all())
+    # inference form: no tape
+    hb3, S3, _, _ = bufs()
+    ops.lstm_stack2_fwd(xt, w0, bb0, w1, bb1, ln, T, M, Kin, H, zx, hb3[0], hb3[1], S3)
+    assert torch.equal(S3, S)
+
+
 def _bwd_ref(x, lens, kernel, bias, dS, dh_above):
     """Oracle BPTT with an upper-layer gradient on the per-step outputs: emulate
     the upper layer by a 2-layer stack is overkill, so extend the oracle's

@@ -171,7 +171,10 @@ def test_extreme_frame_counts_with_row_plans(frames):
     g2.row_plans = False
     out2 = g2.step(torch.from_numpy(x).to(DEV), torch.from_numpy(labels.astype(np.uint8)).to(DEV), torch.from_numpy(n).to(DEV),
                    apply=False, num_frames_host=n)
-    assert torch.equal(out["teacher_state"], out2["teacher_state"]) and torch.equal(out["student_state"], out2["student_state"])
+    # (equal up to accumulation order: without a plan a small L1 stack takes the wavefront form, whose second layer adds
+    # the x-projection inside the MFMA accumulator instead of from a hoisted f32 product)
+    for k in ("teacher_state", "student_state"):
+        assert (out[k] - out2[k]).abs().max().item() < 1e-4 * max(1.0, out2[k].abs().max().item()), k
 
 
 def test_fused_moe_update_matches_materialised_gradient_path():
