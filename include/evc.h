@@ -150,7 +150,7 @@ int evc_lstm_layer_fwd_hp(const evc_bf16* x, const evc_bf16* x_lo, const evc_bf1
  * x-projection (one GEMM into zx_ws [T][M][4H] f32), launch s runs layer 0's step s and layer 1's step s-1 side by
  * side (they are independent, and each is latency-bound at this size), so the chain of dependent launches is T+1
  * long instead of 2T.  Layer 1 reads layer 0's output slab as its x_t in the fused [x_t | h_{t-1}] form.  Same math
- * and outputs as two evc_lstm_layer_fwd calls (cs/frame_level_models.py:348-355, a 2-layer MultiRNNCell under
+ * and outputs as two evc_lstm_layer_fwd calls (cs/frame_level_models.py:229-235,254-257 and :299-305,325-328, a 2-layer MultiRNNCell under
  * dynamic_rnn); no row plan (rows are videos).  Kin % 64 == 0, H % 64 == 0. */
 int evc_lstm_stack2_fwd(const evc_bf16* x, const evc_bf16* wT0, const float* bias0, const evc_bf16* wT1, const float* bias1,
                         const int32_t* len, int T, int M, int Kin, int H, float* zx_ws,
