@@ -122,6 +122,7 @@ typedef TileCfg<32, 1, 32, 2, 2> CfgPlainTiny;    // 32x32: M ~ batch recurrent 
 typedef TileCfg2<256, 1, 256, 2, 4, 5, true> CfgPlainV2;   // 256x256, 8 waves (2x4), 128x64 per wave, 5-deep ring (160 KiB)
 typedef TileCfg2<128, 1, 128, 2, 4, 5, true> CfgTn128;     // 128x128 v2 tile (80 KB ring: two workgroups per CU)
 typedef TileCfg2<256, 1, 64, 2, 4, 5, true> CfgTallV2;     // 256x64: M <= 256 (batch-row) products against a long weight matrix
+// (256x128 tiles + split-K 2, to halve the re-reads of the [256][K] row operand: 80 vs 61 us at N = 14148 - not the bound)
 
 template <class Cfg>
 static inline void launch_gemm(GemmOperands p, StoreParams s, int K, int splits, hipStream_t st) {
@@ -625,6 +626,7 @@ typedef TileCfg2<192, 4, 64, 2, 4, 5, true> CfgLstmV2_192;
 typedef TileCfg2<160, 4, 64, 2, 4, 5, true> CfgLstmV2_160;
 typedef TileCfg2<128, 4, 64, 2, 4, 5, true> CfgLstmV2_128;
 typedef TileCfg2<64, 4, 64, 2, 4, 5, true> CfgLstmV2_64;
+typedef TileCfg2<64, 4, 16, 4, 1, 5, true> CfgLstmV2Small;   // 64 rows x 16 units x 4 gates on the ring loop, 4 waves, 40 KB: M ~ batch steps
 
 template <class Cfg, bool SPLIT = false>
 static inline void launch_lstm_fwd(GemmOperands p, const LstmFwdParams& e, int k1, int k2, hipStream_t st) {
@@ -830,7 +832,8 @@ extern "C" int evc_lstm_stack2_fwd(const evc_bf16* x, const evc_bf16* wT0, const
     if (has_b) fwd_step_args(L1, len, s - 1, M, H, ld_state, pb, eb, k1b, k2b);
     if (has_a && has_b && (tile == 6 || tile == 7)) {
       if (tile == 6) launch_lstm_fwd_pair<CfgLstmBig>(pa, ea, k1a, k2a, pb, eb, k1b, k2b, st);
-      else launch_lstm_fwd_pair<CfgLstmSmall>(pa, ea, k1a, k2a, pb, eb, k1b, k2b, st);
+      else if (getenv("EVC_PAIR_V1")) launch_lstm_fwd_pair<CfgLstmSmall>(pa, ea, k1a, k2a, pb, eb, k1b, k2b, st);
+      else launch_lstm_fwd_pair<CfgLstmV2Small>(pa, ea, k1a, k2a, pb, eb, k1b, k2b, st);
       continue;
     }
     for (int r = 0; r < 2; ++r) {

@@ -74,3 +74,13 @@ bfl = sum(2.0 * r * 4 * H * H for t, r in enumerate(rows) if t < T - 1)
 print("tile=%s shape=%s M=%d P=%d rows[0]=%d rows[-1]=%d | fwd %.3f ms (%.1f us/step, %.0f TF/s) | bwd %.3f ms (%.1f us/step, %.0f TF/s)"
       % (os.environ.get("EVC_FORCE_TILE", "auto"), a.shape, M, P, rows[0], rows[-1], fwd, fwd / T * 1e3, ffl / fwd / 1e9,
          bwd, bwd / T * 1e3, bfl / bwd / 1e9))
+
+if a.shape == "l2":      # the two-layer wavefront form of the same stack (evc_lstm_stack2_fwd)
+    w1T = (torch.randn(4 * H, 2 * H, device=dev) * 0.02).to(torch.bfloat16)
+    hb1 = torch.zeros((T + 1, P, H), dtype=torch.bfloat16, device=dev)
+    S4 = torch.zeros((M, 4 * H), device=dev)
+    zx2 = torch.empty((T * P, 4 * H), device=dev)
+    g2 = [gates, torch.empty_like(gates)]
+    c2 = [c_all, torch.zeros_like(c_all)]
+    ms = timeit(lambda: ops.lstm_stack2_fwd(x, wT, b, w1T, b, lens_d, T, P, Kin, H, zx2, hbuf, hb1, S4, g2, c2))
+    print("stack2 wavefront fwd (2 layers, T=%d, M=%d): %.3f ms" % (T, M, ms))
