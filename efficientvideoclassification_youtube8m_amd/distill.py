@@ -195,6 +195,10 @@ class DistillGraph:
             self.S = max_frames // every_n
             self.student = HLstmTower(batch_size, self.S, num_inputs_l1_student, feature_size, vocab_size, lstm_cells,
                                       lstm_layers, num_mixtures, device, True, "model_student", seed + 1)
+        if self.dp:                      # row-shard the MoE optimizer state now, while nothing is in flight on any stream
+            for tw, red in ((self.teacher, self.reducer), (self.student, self.reducer_s)):
+                if tw is not None:
+                    tw.moe.shard(red.world, red.rank)
         self.precision = precision       # "high": split-bf16 operands in every forward GEMM (parity mode, ~3x fwd MFMA work)
         if precision == "high":
             for tw in (self.teacher, self.student):

@@ -379,7 +379,7 @@ class MoeHead:
         dgl, del_, x = self.dgl_full, self.del_full, self.x_full
         if dp is not None:
             dgl, del_, x = dp.all_gather_rows(dgl), dp.all_gather_rows(del_), dp.all_gather_rows(x)
-            if getattr(self, "world", None) != dp.world:
+            if getattr(self, "world", None) != dp.world:      # normally done once by DistillGraph.__init__ (no step in flight)
                 self.shard(dp.world, dp.rank)
         rows = x.shape[0]
         idx = {k: i for i, k in enumerate(tw.names)}
@@ -493,6 +493,8 @@ class TowerBase:
             if key in sd:
                 v.copy_(sd[key].to(self.device, F32))
         self.refresh_shadows()
+        if getattr(getattr(self, "moe", None), "_stale", False):
+            self.moe._stale = False              # every rank has just loaded the complete weights
 
     def begin_update(self):
         """Start one optimizer step (one tf.train op): bumps the Adam step count, clears the norm sums."""
