@@ -175,3 +175,56 @@ def test_data_parallel_gradient_equals_global_batch_gloo(tmp_path):
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stdout.count("-ok") == 2, r.stdout
+
+
+SHARD_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from efficientvideoclassification_youtube8m_amd.distill import GradReducer
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+red = GradReducer(None)
+assert red.active and red.world == 2 and red.rank == rank
+# factor all-gather: rows of every rank stacked in rank order (bf16 moved as raw bytes)
+t = (torch.arange(6, dtype=torch.float32).reshape(3, 2) + 100 * rank).to(torch.bfloat16)
+g = red.all_gather_rows(t)
+want = torch.cat([(torch.arange(6, dtype=torch.float32).reshape(3, 2) + 100 * r).to(torch.bfloat16) for r in range(world)])
+assert g.dtype == torch.bfloat16 and torch.equal(g, want)
+# the partial norm sums of a row-sharded tensor
+s = torch.tensor([1.0 + rank, 10.0 * (rank + 1)])
+red.all_reduce_small(s)
+assert s.tolist() == [3.0, 30.0]
+# row slabs: V = 600 rows in 128-row tiles over 2 ranks -> 384 + 216 (MoeHead.shard's rule), padded image of 768 rows
+V, K = 600, 8
+tiles = (V + 127) // 128
+slab = (tiles + world - 1) // world * 128
+assert slab == 384
+full = torch.full((slab * world, K), -1.0)
+v0 = rank * slab
+vs = min(V, v0 + slab) - v0
+assert vs == (384 if rank == 0 else 216)
+full[v0:v0 + vs] = torch.arange(v0, v0 + vs, dtype=torch.float32)[:, None].expand(vs, K)     # "this rank's updated rows"
+red.all_gather_slabs(full, slab)
+assert torch.equal(full[:V, 0], torch.arange(V, dtype=torch.float32))                      # every rank now holds every row
+# stream-ordered gradient all-reduce of a segment (synchronous c10d op; returns nothing to wait for)
+flat = torch.arange(10, dtype=torch.float32) * (rank + 1)
+assert red.reduce_async(flat, 2, 7) is None
+assert flat.tolist() == [0, 1 * (rank + 1)] + [3.0 * i for i in range(2, 7)] + [i * (rank + 1.0) for i in range(7, 10)]
+dist.destroy_process_group()
+sys.stdout.write("rank" + str(rank) + "-ok\n"); sys.stdout.flush()
+'''
+
+
+def test_sharded_update_collectives_gloo(tmp_path):
+    """world_size 2 over gloo: the collectives of the row-sharded MoE update (factor all-gather, 8-byte norm
+    all-reduce, in-place slab all-gather) and the stream-ordered gradient all-reduce, on CPU tensors."""
+    script = tmp_path / "shard_worker.py"
+    script.write_text(SHARD_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29535", str(script)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("-ok") == 2, r.stdout
