@@ -302,12 +302,13 @@ __global__ __launch_bounds__(Cfg::NT) void moe_update_kernel(GemmOperandsT p, Mo
   tile_of(id, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BU;
   f32x4 acc[Cfg::MI][1][Cfg::NI];
-  gemm_mainloop_tn<Cfg, true>(p, m0, n0, lds_dyn, acc);
   TileCoordsT<Cfg> tc;
   const int K = u.K;
   // Epilogue loads first, all of them (the stores of one fragment and the loads of the next go to the same
   // arrays, so hipcc keeps them in program order and every fragment would wait for the previous one's stores:
-  // 8 x (load latency + store acknowledge) per workgroup; issued up front they overlap - 3.4 -> see DESIGN.md)
+  // 8 x (load latency + store acknowledge) per workgroup; issued up front they overlap - 3.4 -> see DESIGN.md).
+  // The weights themselves are asked for BEFORE the factor product: they do not depend on it, and their HBM
+  // latency then runs under the 8-step loop instead of after it.
   float4 pv[Cfg::MI][Cfg::NI];
 #pragma unroll
   for (int mi = 0; mi < Cfg::MI; ++mi)
@@ -316,6 +317,7 @@ __global__ __launch_bounds__(Cfg::NT) void moe_update_kernel(GemmOperandsT p, Mo
       const int vr = m0 + tc.row0 + mi * 16, k = n0 + tc.unit0 + ni * 16;
       pv[mi][ni] = (vr < u.V && k < K) ? *(const float4*)(u.p + (long)vr * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+  gemm_mainloop_tn<Cfg, true>(p, m0, n0, lds_dyn, acc);
   if (PASS == 1) {
     float sg = 0.f, sp = 0.f;
 #pragma unroll
