@@ -616,36 +616,46 @@ extern "C" int evc_rep_loss(const float* state_t, const float* state_s, int B, i
 // ---------------------------------------------------------------------------
 // a8 + a9: regulariser, per-tensor clip, TF-Adam
 // ---------------------------------------------------------------------------
+template <bool WITH_P>
 __global__ __launch_bounds__(256) void grad_sqnorm_kernel(const float* __restrict__ g, const float* __restrict__ p, float l2,
                                                           long n, float* __restrict__ sums) {
   __shared__ float sh[4];
   float sg = 0.f, sp = 0.f;
   const long n4 = n >> 2;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-    const float4 gv = ((const float4*)g)[i], pv = ((const float4*)p)[i];
+    const float4 gv = ((const float4*)g)[i];
+    float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (WITH_P) pv = ((const float4*)p)[i];
     const float a = gv.x + l2 * pv.x, b = gv.y + l2 * pv.y, c = gv.z + l2 * pv.z, d = gv.w + l2 * pv.w;
     sg += a * a + b * b + c * c + d * d;
     sp += pv.x * pv.x + pv.y * pv.y + pv.z * pv.z + pv.w * pv.w;
   }
   for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const float a = g[i] + l2 * p[i];
+    const float pi = WITH_P ? p[i] : 0.f;
+    const float a = g[i] + l2 * pi;
     sg += a * a;
-    sp += p[i] * p[i];
+    sp += pi * pi;
   }
   sg = block_sum(sg, sh);
-  sp = block_sum(sp, sh);
-  if (threadIdx.x == 0) { atomicAdd(&sums[0], sg); atomicAdd(&sums[1], sp); }
+  if (WITH_P) sp = block_sum(sp, sh);
+  if (threadIdx.x == 0) {
+    atomicAdd(&sums[0], sg);
+    if (WITH_P) atomicAdd(&sums[1], sp);
+  }
 }
 extern "C" int evc_grad_sqnorm(const float* g, const float* p, float l2_coeff, int64_t n, float* sums, void* stream) {
   EVC_REQUIRE(n > 0, EVC_ERR_BAD_SHAPE, "evc_grad_sqnorm: n must be positive");
   EVC_REQUIRE(((uintptr_t)g % 16) == 0 && ((uintptr_t)p % 16) == 0, EVC_ERR_BAD_ALIGN, "evc_grad_sqnorm: 16-byte alignment");
+  EVC_REQUIRE(p != nullptr || l2_coeff == 0.f, EVC_ERR_BAD_ARG, "evc_grad_sqnorm: p == NULL (gradient norm only) needs l2_coeff == 0");
   const long nb = (n / 4 + 255) / 256;
   const int grid = (int)(nb < 1 ? 1 : (nb < 2048 ? nb : 2048));
-  hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, p, l2_coeff, (long)n, sums);
+  if (p) hipLaunchKernelGGL(grad_sqnorm_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, p, l2_coeff, (long)n, sums);
+  else hipLaunchKernelGGL(grad_sqnorm_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, p, 0.f, (long)n, sums);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, long n, float l2, const float* __restrict__ sums,
                                                         float clip, float lr_t, float b1, float b2, float eps,
@@ -655,7 +665,25 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
     const float nrm = sqrtf(sums[0]);
     scale = clip / fmaxf(nrm, clip);   // tf.clip_by_norm
   }
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+  const long n4 = VEC ? (n >> 2) : 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {   // 16-byte accesses
+    const float4 pv = ((const float4*)p)[i], gv = ((const float4*)g)[i], mv = ((const float4*)m)[i], vv = ((const float4*)v)[i];
+    const float pa[4] = {pv.x, pv.y, pv.z, pv.w}, ga[4] = {gv.x, gv.y, gv.z, gv.w};
+    const float ma[4] = {mv.x, mv.y, mv.z, mv.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+    float pn[4], mn[4], vn[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float gc = (ga[r] + l2 * pa[r]) * scale;
+      mn[r] = b1 * ma[r] + (1.f - b1) * gc;
+      vn[r] = b2 * va[r] + (1.f - b2) * gc * gc;
+      pn[r] = adam_step_(pa[r], mn[r], vn[r], lr_t, eps);
+    }
+    ((float4*)m)[i] = make_float4(mn[0], mn[1], mn[2], mn[3]);
+    ((float4*)v)[i] = make_float4(vn[0], vn[1], vn[2], vn[3]);
+    ((float4*)p)[i] = make_float4(pn[0], pn[1], pn[2], pn[3]);
+    if (pb) ((uint2*)pb)[i] = make_uint2(pack_bf16x2_hw(pn[0], pn[1]), pack_bf16x2_hw(pn[2], pn[3]));
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float pv = p[i];
     const float gc = (g[i] + l2 * pv) * scale;
     const float mn = b1 * m[i] + (1.f - b1) * gc;
@@ -669,10 +697,13 @@ extern "C" int evc_clip_adam_step(float* p, const float* g, float* m, float* v, 
                                   const float* sums, float clip_norm, float lr_t, float beta1, float beta2, float eps,
                                   evc_bf16* p_bf16, void* stream) {
   EVC_REQUIRE(n > 0, EVC_ERR_BAD_SHAPE, "evc_clip_adam_step: n must be positive");
-  const long nb = (n + 255) / 256;
-  const int grid = (int)(nb < 4096 ? nb : 4096);
-  hipLaunchKernelGGL(clip_adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, l2_coeff, sums,
-                     clip_norm, lr_t, beta1, beta2, eps, p_bf16);
+  const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16) == 0 && ((uintptr_t)p_bf16 % 8) == 0;
+  const long nb = ((vec ? n / 4 : n) + 255) / 256;
+  const int grid = (int)(nb < 1 ? 1 : (nb < 4096 ? nb : 4096));
+  if (vec) hipLaunchKernelGGL(clip_adam_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, l2_coeff, sums,
+                              clip_norm, lr_t, beta1, beta2, eps, p_bf16);
+  else hipLaunchKernelGGL(clip_adam_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, l2_coeff, sums,
+                          clip_norm, lr_t, beta1, beta2, eps, p_bf16);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }

@@ -408,7 +408,7 @@ class MoeHead:
             self._stale = dp.world > 1
         gb = st.g(self.EBIAS)
         ops.colsum_bf16(del_, rows, V * Mx, gb)
-        ops.grad_sqnorm(gb, st.p(self.EBIAS), 0.0, tw.sums[idx[self.EBIAS]])
+        ops.grad_sqnorm(gb, None, 0.0, tw.sums[idx[self.EBIAS]])
         ops.clip_adam_step(st.p(self.EBIAS), gb, st.view(st.m, self.EBIAS), st.view(st.v, self.EBIAS), 0.0,
                            tw.sums[idx[self.EBIAS]], clip_norm, lr_t, beta1, beta2, eps)
 
@@ -514,7 +514,8 @@ class TowerBase:
         idx = {k: i for i, k in enumerate(self.names)}
         for k in names:
             l2 = l2_coeff if k in self.l2_names else 0.0
-            ops.grad_sqnorm(self.store.g(k), self.store.p(k), l2, self.sums[idx[k]])
+            # (tensors without a regulariser: the norm pass reads the gradient only)
+            ops.grad_sqnorm(self.store.g(k), self.store.p(k) if k in self.l2_names else None, l2, self.sums[idx[k]])
         for k in names:
             l2 = l2_coeff if k in self.l2_names else 0.0
             ops.clip_adam_step(self.store.p(k), self.store.g(k), self.store.view(self.store.m, k),

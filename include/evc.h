@@ -263,7 +263,8 @@ int evc_rep_loss(const float* state_t, const float* state_s, int B, int D, float
 /* ---- a8 + a9: regulariser, per-tensor clip, TF-Adam ---------------------------
  * slim.l2_regularizer (cs/video_level_models.py:428,434) folded into the
  * gradient: g_eff = g + l2_coeff * p  (l2_coeff = regularization_penalty*1e-8).
- * Pass 1: sums[0] += sum(g_eff^2), sums[1] += sum(p^2)   (f32 device, zero first).
+ * Pass 1: sums[0] += sum(g_eff^2), sums[1] += sum(p^2)   (f32 device, zero first); p == NULL (allowed when
+ *   l2_coeff == 0: a tensor without regulariser) reads the gradient only and leaves sums[1] alone.
  * Pass 2: clip_by_norm per tensor (slim create_train_op, cs/train.py:329-334)
  *   scale = clip / max(sqrt(sums[0]), clip) (clip <= 0: no clipping), then
  *   tf.train.AdamOptimizer update with lr_t = lr*sqrt(1-b2^t)/(1-b1^t),
