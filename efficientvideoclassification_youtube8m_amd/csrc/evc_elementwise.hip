@@ -540,7 +540,9 @@ extern "C" int evc_ce_loss(const float* pred, const uint8_t* labels, int B, int 
                            float* loss, float* dpred, int accumulate_grad, void* stream) {
   EVC_REQUIRE(B > 0 && V > 0, EVC_ERR_BAD_SHAPE, "evc_ce_loss: bad shape");
   const long n = (long)B * V;
-  const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  // every block ends in one atomic on the same address, and those serialise at ~12 ns each: 2048 blocks made this a
+  // 30 us kernel for 1.2 M elements; 256 blocks (one per CU) keep the join at ~3 us
+  const int grid = (int)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);
   hipLaunchKernelGGL(ce_loss_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pred, labels, n, 1.0f / B, grad_scale, loss,
                      dpred, accumulate_grad);
   EVC_LAUNCH_CHECK();
@@ -606,7 +608,7 @@ extern "C" int evc_rep_loss(const float* state_t, const float* state_s, int B, i
                             float* loss, float* dstate_s, int accumulate_grad, void* stream) {
   EVC_REQUIRE(B > 0 && D > 0, EVC_ERR_BAD_SHAPE, "evc_rep_loss: bad shape");
   const long n = (long)B * D;
-  const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  const int grid = (int)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);     // one same-address atomic per block (see evc_ce_loss)
   hipLaunchKernelGGL(rep_loss_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, state_t, state_s, n, 1.0f / B, grad_scale,
                      loss, dstate_s, accumulate_grad);
   EVC_LAUNCH_CHECK();
@@ -648,7 +650,7 @@ extern "C" int evc_grad_sqnorm(const float* g, const float* p, float l2_coeff, i
   EVC_REQUIRE(((uintptr_t)g % 16) == 0 && ((uintptr_t)p % 16) == 0, EVC_ERR_BAD_ALIGN, "evc_grad_sqnorm: 16-byte alignment");
   EVC_REQUIRE(p != nullptr || l2_coeff == 0.f, EVC_ERR_BAD_ARG, "evc_grad_sqnorm: p == NULL (gradient norm only) needs l2_coeff == 0");
   const long nb = (n / 4 + 255) / 256;
-  const int grid = (int)(nb < 1 ? 1 : (nb < 2048 ? nb : 2048));
+  const int grid = (int)(nb < 1 ? 1 : (nb < 512 ? nb : 512));   // two blocks per CU; each ends in same-address atomics (~12 ns apiece)
   if (p) hipLaunchKernelGGL(grad_sqnorm_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, p, l2_coeff, (long)n, sums);
   else hipLaunchKernelGGL(grad_sqnorm_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, p, 0.f, (long)n, sums);
   EVC_LAUNCH_CHECK();
