@@ -173,11 +173,19 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(FLAGS.gpu)))
+    # test hook (tests/test_gpu_dp.py): several ranks on ONE GPU over gloo, to run this file's multi-rank path on a
+    # single-GPU box (RCCL refuses two ranks per device).  Never set in a real run.
+    shared_gpu = os.environ.get("EVC_TRAIN_SHARED_GPU") == "1"
+    if shared_gpu:
+        local = 0
     torch.cuda.set_device(local)
     device = "cuda:%d" % local
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=torch.device(device))
+        if shared_gpu:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=torch.device(device))
     ops.check_device(local)
     task = "/job:master/task:%d" % rank
     _, feature_sizes = GetListOfFeatureNamesAndSizes(FLAGS.feature_names, FLAGS.feature_sizes)
@@ -212,14 +220,24 @@ def main(argv=None):
         t0 = time.time()
         out = graph.step(q, labels, n, num_frames_host=n_host) if is_distill else graph.step(dequantize_masked(q, n), labels, n)
         it += 1
-        if rank == 0 and it % max(1, FLAGS.log_every) == 0:
+        logging_step = it % max(1, FLAGS.log_every) == 0
+        # loss_report() and the checkpoint decision are collective under data parallelism: every rank takes part at
+        # the logging steps, rank 0 does the logging
+        r = graph.loss_report() if (logging_step and is_distill) else None
+        save_due = time.time() - last_save > 30 * 60                           # save_model_secs (cs/train.py:500)
+        if world > 1:
+            save_due = False
+            if logging_step:
+                flag = torch.tensor([1 if time.time() - last_save > 30 * 60 else 0], device=device)
+                torch.distributed.broadcast(flag, src=0)                       # rank 0's clock decides for everyone
+                save_due = bool(flag.item())
+        if rank == 0 and logging_step:
             pred = out.get("predictions", out.get("student_predictions"))
             p, y = pred.cpu().numpy(), labels.float().cpu().numpy()           # D2H sync, as the reference's fetch does
             dt = time.time() - t0
             hit, perr, gap = (eval_util.calculate_hit_at_one(p, y), eval_util.calculate_precision_at_equal_recall_rate(p, y),
                               eval_util.calculate_gap(p, y))
             if is_distill:
-                r = graph.loss_report()
                 if not all(np.isfinite(v) for v in r.values()):      # slim.learning.create_train_op's check_numerics
                     raise FloatingPointError("LossTensor is inf or nan : %s" % r)
                 logging.info("%s: training step %d| Hit@1: %.2f| PERR: %.2f| GAP: %.2f| Teacher_Loss: %s| L_REP: %s| L_PRED: %s"
@@ -230,7 +248,7 @@ def main(argv=None):
                              hit, perr, gap, round(float(out["loss"]), 2))
             logging.info("global_step/sec: %g  Examples/Second: %g", (2 if is_distill and graph.teacher and graph.student else 1) / dt,
                          labels.shape[0] * world / dt)
-        if time.time() - last_save > 30 * 60:                                  # save_model_secs (cs/train.py:500)
+        if save_due:
             save_checkpoint(graph, FLAGS.train_dir, rank)
             last_save = time.time()
         if step_limit and it >= step_limit:
