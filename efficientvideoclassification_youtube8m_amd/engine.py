@@ -620,9 +620,11 @@ class HLstmTower(TowerBase):
         return self.moe.gate_logits
 
     # ---- forward ------------------------------------------------------------
-    def forward(self, x_view, len_l1, len_l2, plan_l1=None):
+    def forward(self, x_view, len_l1, len_l2, plan_l1=None, after_l1=None):
         """x_view [Lc][C*B][F] bf16 (ops.l2norm_chunk); lengths from ops.frame_counts.
         plan_l1: ops.RowPlan of the L1 chunk rows (x_view is then [Lc][plan.P][F], from l2norm_chunk(plan1=..)).
+        after_l1: optional callable, invoked once the L1 level has been enqueued (the L2 chain and the MoE head that
+        follow are latency-bound launches that leave most of the chip idle: a caller can start other work there).
         Returns (state [B, 2LH] f32, predictions [B, V] f32)."""
         high = isinstance(x_view, tuple)
         if high and self.precision != "high":
@@ -631,6 +633,8 @@ class HLstmTower(TowerBase):
         if B != self.B:
             self._alloc(B)
         S1 = self.l1.forward(x_view, len_l1, plan_l1)
+        if after_l1 is not None:
+            after_l1()
         if high:
             if not hasattr(self, "S1_lo") or self.S1_lo.shape != self.S1_bf.shape:
                 self.S1_lo = torch.empty_like(self.S1_bf)
