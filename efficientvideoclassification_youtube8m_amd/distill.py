@@ -496,20 +496,9 @@ class EvalGraph:
                 used += (plan_s.pos, plan_s.inv, plan_s.lens)
             for t in used:
                 t.record_stream(self._side)
-        def student_forward_mid():
-            nonlocal s_state, s_pred, n_s, l1s, l2s, plan_s
-            self._ev_in.record(main)
-            side.wait_event(self._ev_in)
-            with torch.cuda.stream(side):
-                mark("student_start", side)
-                n_s, l1s, l2s, plan_s = sp
-                s_state, s_pred = self.student.forward(xs, l1s, l2s, plan_s)
-                ops.ce_loss(s_pred, labels_u8, self.losses[3:4], self._dp_s, grad_scale=sc["ce"] / B)
-                mark("student_fwd_done", side)
-
         if self.teacher is not None:
             l1, l2, plan_t = tp
-            t_state, t_pred = self.teacher.forward(xt, l1, l2, plan_t, after_l1=student_forward_mid if mid_student else None)
+            t_state, t_pred = self.teacher.forward(xt, l1, l2, plan_t)
             out.update(teacher_state=t_state, teacher_predictions=t_pred)
         main.wait_event(self._ev_out)
         if self.teacher is not None:
