@@ -120,6 +120,7 @@ typedef TileCfg<128, 1, 128, 2, 2> CfgPlainBig;   // 128x128, 4 waves, 4x4 MFMA 
 typedef TileCfg<64, 1, 64, 2, 2> CfgPlainSmall;   // 64x64 for skinny problems
 typedef TileCfg<32, 1, 32, 2, 2> CfgPlainTiny;    // 32x32: M ~ batch recurrent steps (256 workgroups at M=256, H=1024)
 typedef TileCfg2<256, 1, 256, 2, 4, 5, true> CfgPlainV2;   // 256x256, 8 waves (2x4), 128x64 per wave, 5-deep ring (160 KiB)
+typedef TileCfg2<224, 1, 256, 2, 4, 5, true> CfgPlainV2_224;   // same, 224 rows: picked when it cuts M into fewer rounds of 256 workgroups
 typedef TileCfg2<128, 1, 128, 2, 4, 5, true> CfgTn128;     // 128x128 v2 tile (80 KB ring: two workgroups per CU)
 typedef TileCfg2<256, 1, 64, 2, 4, 5, true> CfgTallV2;     // 256x64: M <= 256 (batch-row) products against a long weight matrix
 // (256x128 tiles + split-K 2, to halve the re-reads of the [256][K] row operand: 80 vs 61 us at N = 14148 - not the bound)
@@ -178,11 +179,14 @@ extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
   }
   // per-flop cost factors measured on MI355X (scripts/gemm_bench.py): v2 ~1000 TF/s, v1 128^2 ~800, v1 64^2 ~400
   const double c_v2 = tile_cost((long)ceil_div(M, 256) * ceil_div(N, 256), 256, 256, 1, 1.0);
+  const double c_v2b = tile_cost((long)ceil_div(M, 224) * ceil_div(N, 256), 224, 256, 1, 1.01);   // e.g. 56 640 rows x 1024: 1012 tiles = 3.95 rounds instead of 888 = 3.47
   const double c_big = tile_cost((long)ceil_div(M, 128) * ceil_div(N, 128), 128, 128, 2, 1.3);
   const double c_small = tile_cost((long)ceil_div(M, 64) * ceil_div(N, 64), 64, 64, 4, 2.6);
   int pick = (c_v2 <= c_big && c_v2 <= c_small) ? 1 : (c_big <= c_small ? 2 : 3);
+  if (pick == 1 && c_v2b < c_v2) pick = 4;
   if (forced_tile()) pick = forced_tile();
-  if (pick == 1) launch_gemm<CfgPlainV2>(p, s, K, 1, st);
+  if (pick == 4) launch_gemm<CfgPlainV2_224>(p, s, K, 1, st);
+  else if (pick == 1) launch_gemm<CfgPlainV2>(p, s, K, 1, st);
   else if (pick == 2) launch_gemm<CfgPlainBig>(p, s, K, 1, st);
   else launch_gemm<CfgPlainSmall>(p, s, K, 1, st);
   EVC_LAUNCH_CHECK();
