@@ -207,3 +207,40 @@ def test_fused_moe_update_matches_materialised_gradient_path():
             assert torch.equal(sb[:, :ta.store.p(k).shape[0]], ta.store.p(k).t().bfloat16())
             assert bool((sb[:, ta.store.p(k).shape[0]:] == 0).all())
         assert torch.allclose(ta.sums, tb.sums, rtol=1e-4, atol=1e-12)
+
+
+def test_moe_update_in_two_phases_on_row_slabs_equals_the_whole():
+    """evc_moe_grad_update_phase: phase 1 on every row slab (norm sums accumulate), then phase 2 on every slab, gives
+    the weights / moments / shadows of the one-call update of the whole matrix - what the data-parallel ranks do, each
+    on its own slab, with an 8-byte all-reduce of the sums in between."""
+    from efficientvideoclassification_youtube8m_amd import ops
+    torch.manual_seed(5)
+    rows, V, K = 64, 600, 256                       # 5 row tiles: slabs of 384 and 216 rows
+    Vp = (V + 63) // 64 * 64
+    dlog = torch.zeros(rows, Vp, dtype=torch.bfloat16, device=DEV)
+    dlog[:, :V] = (torch.randn(rows, V, device=DEV) * 3e-2).to(torch.bfloat16)      # clipping active: the global norm matters
+    x = (torch.randn(rows, K, device=DEV) * 0.5).to(torch.bfloat16)
+    p0, m0, v0 = torch.randn(V, K, device=DEV) * 0.05, torch.randn(V, K, device=DEV) * 1e-3, torch.rand(V, K, device=DEV) * 1e-5
+    ws = torch.empty(2 * ((V + 127) // 128) * ((K + 127) // 128), device=DEV)
+
+    def fresh():
+        return (p0.clone(), m0.clone(), v0.clone(), torch.zeros(V, K, dtype=torch.bfloat16, device=DEV),
+                torch.zeros(K, Vp, dtype=torch.bfloat16, device=DEV), torch.zeros(2, device=DEV))
+
+    pa, ma, va, pba, pTa, sa = fresh()
+    ops.moe_grad_update(dlog, x, rows, V, K, pa, ma, va, pba, pTa, 2e-8, sa, ws, 1.0, 1e-3)
+    pb, mb, vb, pbb, pTb, sb = fresh()
+    slabs = [(0, 384), (384, 216)]
+    for phase in (1, 2):
+        for v_lo, vs in slabs:
+            ops.moe_grad_update(dlog[:, v_lo:], x, rows, vs, K, pb[v_lo:], mb[v_lo:], vb[v_lo:], pbb[v_lo:], pTb[:, v_lo:], 2e-8,
+                                sb, ws, 1.0, 1e-3, phase=phase)
+    assert sa[0].item() > 1.0                                                     # the clip is active
+    assert torch.allclose(sa, sb, rtol=1e-5)
+    assert (pa - pb).abs().max().item() < 1e-7 and (ma - mb).abs().max().item() < 1e-8 and (va - vb).abs().max().item() < 1e-10
+    assert torch.equal(pba, pa.bfloat16()) and torch.equal(pbb, pb.bfloat16())       # each run's shadows are its own weights
+    assert torch.equal(pTa[:, :V], pa.t().bfloat16()) and torch.equal(pTb[:, :V], pb.t().bfloat16())
+    assert (pba.float() - pbb.float()).abs().max().item() <= 2.0 ** -8 * pb.abs().max().item()
+    # a phase outside 0..2 is refused
+    with pytest.raises(Exception):
+        ops.moe_grad_update(dlog, x, rows, V, K, pb, mb, vb, pbb, pTb, 2e-8, sb, ws, 1.0, 1e-3, phase=3)
