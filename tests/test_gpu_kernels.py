@@ -480,3 +480,37 @@ def test_kl_pred_loss_against_oracle_and_degenerate_rows(ops):
     ops.kl_pred_loss(ptd, ptd.sum(1), psd, psd.sum(1), loss, dps)
     assert np.isfinite(loss.item()) and bool(torch.isfinite(dps).all())
     assert bool((dps[2] == 0).all())                   # the undefined row contributes nothing
+
+
+def test_clip_adam_vector_and_scalar_paths_and_gradient_only_norm(ops):
+    """evc_clip_adam_step takes 16-byte accesses when every pointer allows it and a scalar path otherwise: same
+    numbers; evc_grad_sqnorm with p == NULL reads the gradient only and leaves sums[1] alone."""
+    torch.manual_seed(3)
+    n = 4099                                             # not a multiple of 4: scalar tail in the vector path
+    base = [torch.randn(n + 1, device=DEV) * s for s in (0.1, 1.0, 1e-3)] + [torch.rand(n + 1, device=DEV) * 1e-4]
+    outs = []
+    for off in (0, 1):                                   # offset 1 breaks the 16-byte alignment -> scalar path
+        p, g, m, v = (t[:n].clone() for t in base)
+        if off:
+            p, g, m, v = (torch.cat([t.new_zeros(1), t])[1:] for t in (p, g, m, v))        # storage offset 1: 4-byte aligned only
+            assert all(t.data_ptr() % 16 != 0 for t in (p, g, m, v))
+        else:
+            p, g, m, v = (t.clone() for t in (p, g, m, v))
+            assert all(t.data_ptr() % 16 == 0 for t in (p, g, m, v))
+        pb = torch.zeros(n + 8, dtype=torch.bfloat16, device=DEV)[:n]
+        sums = torch.zeros(2, device=DEV)
+        ops.grad_sqnorm(g.clone(), None, 0.0, sums)      # (the norm pass itself requires 16-byte aligned tensors)
+        assert sums[1].item() == 0.0
+        assert abs(sums[0].item() - float((g.double() ** 2).sum())) < 1e-3 * sums[0].item()
+        ops.clip_adam_step(p, g, m, v, 0.0, sums, 1.0, 1e-3, p_bf16=pb)
+        outs.append((p.clone(), m.clone(), v.clone(), pb.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # with a regulariser the weights are read too
+    p, g = base[0][:n].clone(), base[1][:n].clone()
+    sums = torch.zeros(2, device=DEV)
+    ops.grad_sqnorm(g, p, 0.5, sums)
+    assert abs(sums[0].item() - float(((g + 0.5 * p).double() ** 2).sum())) < 1e-3 * sums[0].item()
+    assert abs(sums[1].item() - float((p.double() ** 2).sum())) < 1e-3 * sums[1].item()
+    with pytest.raises(Exception):
+        ops.grad_sqnorm(g, None, 0.5, sums)              # p == NULL needs l2_coeff == 0
