@@ -205,6 +205,7 @@ class DistillGraph:
                 if tw is not None:
                     tw.set_precision("high")
         self.losses = torch.zeros(8, dtype=F32, device=self.device)
+        self._losses_reduced = torch.zeros(8, dtype=F32, device=self.device)   # data parallel: SUM over the ranks, per step
         self._dp_t = self._dp_s = self._ds_s = None
         self.overlap_towers = overlap_towers
         self.row_plans = True        # sort the L1 chunk rows by length and skip the padding rows (ops.RowPlan)
@@ -383,6 +384,11 @@ class DistillGraph:
         if two_streams:
             main.wait_event(self._ev_student)
         self.reducer.wait()
+        if self.dp:
+            # the loss values of the global batch, as part of the step (8 floats, in stream order behind the teacher's
+            # collectives): loss_report() then needs no collective and may be called by any one rank, at any time
+            self._losses_reduced.copy_(self.losses)
+            self.reducer.all_reduce_small(self._losses_reduced)
         if apply:
             self.apply_gradients(B, lr)
         out["global_step"] = self.global_step
@@ -412,16 +418,20 @@ class DistillGraph:
             if tw is not None:
                 tw.moe.consolidate(red)
 
-    def loss_report(self):
-        """Host floats in the order the reference logs them (cs/train.py:528-533)."""
-        v = self.losses.tolist()
+    @property
+    def losses_for_report(self):
+        """Device tensor loss_report() reads (a caller that logs one step behind the GPU clones it after the step)."""
+        return self._losses_reduced if self.dp else self.losses
+
+    def loss_report(self, losses=None):
+        """Host floats in the order the reference logs them (cs/train.py:528-533), for the global batch.  Not a
+        collective (under data parallelism step() has already summed the values over the ranks).  losses: a copy of
+        losses_for_report taken after an earlier step (device or host tensor)."""
+        v = (self.losses_for_report if losses is None else losses).tolist()
         rep = {k: v[i] for i, k in enumerate(self.LOSS_SLOTS)}
-        if self.dp:   # per-rank values -> global-batch values (means / sum)
-            t = torch.tensor([rep[k] for k in self.LOSS_SLOTS], dtype=torch.float64, device=self.device)
-            torch.distributed.all_reduce(t, group=self.pg)
-            t = t.tolist()
-            rep = {"label_loss": t[0] / self.world, "student_loss_state": t[1] / self.world, "pred_loss": t[2],
-                   "student_label_loss": t[3] / self.world}
+        if self.dp:   # sums over the ranks -> global-batch means (L_PRED is a batch sum)
+            rep = {"label_loss": v[0] / self.world, "student_loss_state": v[1] / self.world, "pred_loss": v[2],
+                   "student_label_loss": v[3] / self.world}
         return rep
 
 

@@ -137,12 +137,24 @@ def average_precision(predictions, actuals, total_num_positives=None, n=None):
     return _ap_sorted(a_sorted, numpos, n)
 
 
+def _num_positives(actuals):
+    """sum(np.sum(actuals[:, i]) for i in classes) of cs/eval_util.py:73-77.  For 0/1 labels (what the data set has)
+    every partial sum is an exact small integer, so one vectorised count gives the same number; anything else takes
+    the reference's class-by-class route (4716 tiny reductions: 20 ms per batch)."""
+    if actuals.dtype == np.bool_ or np.issubdtype(actuals.dtype, np.integer):
+        return actuals.dtype.type(np.count_nonzero(actuals)) if actuals.dtype != np.bool_ else np.count_nonzero(actuals)
+    flat = actuals.reshape(-1)
+    if actuals.size < (1 << 24) and np.all((flat == 0) | (flat == 1)):
+        return actuals.dtype.type(np.count_nonzero(flat))
+    return sum(np.sum(actuals[:, i]) for i in range(actuals.shape[1]))
+
+
 def calculate_gap(predictions, actuals, top_k=20):
     """cs/eval_util.py:61-79: global average precision over each video's top_k."""
     predictions, actuals = _np(predictions), _np(actuals)
     pv, lv, idx = top_k_by_video(predictions, actuals, top_k)
     order = np.argsort(idx.reshape(-1), kind="stable")       # the reference pools class-major
-    num_pos = sum(np.sum(actuals[:, i]) for i in range(actuals.shape[1]))
+    num_pos = _num_positives(actuals)
     return average_precision(pv.reshape(-1)[order], lv.reshape(-1)[order], num_pos)
 
 
@@ -178,7 +190,7 @@ class EvaluationMetrics(object):
         self._pool_c.append(idx.reshape(-1)[order])
         class_pos = labels.sum(axis=0)
         self._class_pos += class_pos
-        self._num_pos += sum(np.sum(labels[:, i]) for i in range(labels.shape[1]))
+        self._num_pos += _num_positives(labels)
         self.num_examples += batch_size
         self.sum_hit_at_one += mean_hit_at_one * batch_size
         self.sum_perr += mean_perr * batch_size

@@ -216,43 +216,81 @@ def main(argv=None):
     logging.info("%s: Entering training loop.", task)
     start, last_save, it = time.time(), time.time(), 0
     is_distill = isinstance(graph, DistillGraph)
+    steps_per_it = 2 if is_distill and graph.teacher and graph.student else 1
+    copy_stream = torch.cuda.Stream(device=device)
+    host_bufs = {}                       # pinned staging, two alternating sets (one may still be read while the next fills)
+
+    def snapshot(out, labels, it):
+        """What the reference's sess.run fetch returns at a logging step (cs/train.py:515-526), taken WITHOUT stopping
+        the GPU: device clones in stream order (the step's output buffers are overwritten by the next step), then D2H
+        on a copy stream into pinned memory.  finish_log() reads it after the NEXT step has been enqueued, so the host
+        metrics of step k are computed while the GPU runs step k+1; the log lines are the same, one step late."""
+        pred = out.get("predictions", out.get("student_predictions")).clone()
+        lab = labels.clone()
+        loss_dev = graph.losses_for_report.clone() if is_distill else out["loss"].detach().clone().reshape(1)
+        cur = torch.cuda.current_stream(device)
+        copy_stream.wait_stream(cur)
+        slot = host_bufs.setdefault(it % 2, {})
+        with torch.cuda.stream(copy_stream):
+            if rank == 0:
+                for key, t in (("pred", pred), ("lab", lab), ("loss", loss_dev)):
+                    if key not in slot or slot[key].shape != t.shape or slot[key].dtype != t.dtype:
+                        slot[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                    slot[key].copy_(t, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(copy_stream)
+        for t in (pred, lab, loss_dev):
+            t.record_stream(copy_stream)
+        return {"slot": slot, "event": ev, "global_step": out["global_step"], "batch": labels.shape[0]}
+
+    last_log_time = [time.time(), 0]     # (wall time, iteration) of the previous log line: rates over the interval in between
+
+    def finish_log(snap, it_now):
+        if rank != 0:
+            return
+        snap["event"].synchronize()              # nothing here touches a stream that step it_now+1 has been queued on
+        r = graph.loss_report(losses=snap["slot"]["loss"]) if is_distill else None
+        p, y = snap["slot"]["pred"].numpy(), snap["slot"]["lab"].numpy().astype(np.float32)
+        hit, perr, gap = (eval_util.calculate_hit_at_one(p, y), eval_util.calculate_precision_at_equal_recall_rate(p, y),
+                          eval_util.calculate_gap(p, y))
+        if is_distill:
+            if not all(np.isfinite(v) for v in r.values()):          # slim.learning.create_train_op's check_numerics
+                raise FloatingPointError("LossTensor is inf or nan : %s" % r)
+            logging.info("%s: training step %d| Hit@1: %.2f| PERR: %.2f| GAP: %.2f| Teacher_Loss: %s| L_REP: %s| L_PRED: %s"
+                         "| L_CE: %s", task, snap["global_step"], hit, perr, gap, round(r["label_loss"], 2),
+                         round(r["student_loss_state"], 2), round(r["pred_loss"], 2), round(r["student_label_loss"], 2))
+        else:
+            logging.info("%s: training step %d| Hit@1: %.2f| PERR: %.2f| GAP: %.2f| Loss: %s", task, snap["global_step"],
+                         hit, perr, gap, round(float(snap["slot"]["loss"][0]), 2))
+        now = time.time()
+        dt = max(now - last_log_time[0], 1e-9) / max(1, it_now - last_log_time[1])
+        last_log_time[0], last_log_time[1] = now, it_now
+        logging.info("global_step/sec: %g  Examples/Second: %g", steps_per_it / dt, snap["batch"] * world / dt)
+
+    pending = None
     for q, labels, n, n_host in data:
-        t0 = time.time()
         out = graph.step(q, labels, n, num_frames_host=n_host) if is_distill else graph.step(dequantize_masked(q, n), labels, n)
         it += 1
         logging_step = it % max(1, FLAGS.log_every) == 0
-        # loss_report() and the checkpoint decision are collective under data parallelism: every rank takes part at
-        # the logging steps, rank 0 does the logging
-        r = graph.loss_report() if (logging_step and is_distill) else None
+        snap = snapshot(out, labels, it) if logging_step else None
+        if pending is not None:
+            finish_log(pending, it - 1)                                        # step it-1's metrics, under step it
+        pending = snap
+        # the checkpoint decision is collective under data parallelism: rank 0's clock decides, every 64 iterations
         save_due = time.time() - last_save > 30 * 60                           # save_model_secs (cs/train.py:500)
         if world > 1:
             save_due = False
-            if logging_step:
+            if it % 64 == 0:                                                   # (a host sync: not at every step)
                 flag = torch.tensor([1 if time.time() - last_save > 30 * 60 else 0], device=device)
-                torch.distributed.broadcast(flag, src=0)                       # rank 0's clock decides for everyone
+                torch.distributed.broadcast(flag, src=0)
                 save_due = bool(flag.item())
-        if rank == 0 and logging_step:
-            pred = out.get("predictions", out.get("student_predictions"))
-            p, y = pred.cpu().numpy(), labels.float().cpu().numpy()           # D2H sync, as the reference's fetch does
-            dt = time.time() - t0
-            hit, perr, gap = (eval_util.calculate_hit_at_one(p, y), eval_util.calculate_precision_at_equal_recall_rate(p, y),
-                              eval_util.calculate_gap(p, y))
-            if is_distill:
-                if not all(np.isfinite(v) for v in r.values()):      # slim.learning.create_train_op's check_numerics
-                    raise FloatingPointError("LossTensor is inf or nan : %s" % r)
-                logging.info("%s: training step %d| Hit@1: %.2f| PERR: %.2f| GAP: %.2f| Teacher_Loss: %s| L_REP: %s| L_PRED: %s"
-                             "| L_CE: %s", task, out["global_step"], hit, perr, gap, round(r["label_loss"], 2),
-                             round(r["student_loss_state"], 2), round(r["pred_loss"], 2), round(r["student_label_loss"], 2))
-            else:
-                logging.info("%s: training step %d| Hit@1: %.2f| PERR: %.2f| GAP: %.2f| Loss: %s", task, out["global_step"],
-                             hit, perr, gap, round(float(out["loss"]), 2))
-            logging.info("global_step/sec: %g  Examples/Second: %g", (2 if is_distill and graph.teacher and graph.student else 1) / dt,
-                         labels.shape[0] * world / dt)
         if save_due:
             save_checkpoint(graph, FLAGS.train_dir, rank)
             last_save = time.time()
         if step_limit and it >= step_limit:
             break
+    if pending is not None:
+        finish_log(pending, it)
     logging.info("%s: Done training -- epoch limit reached.", task)
     save_checkpoint(graph, FLAGS.train_dir, rank)
     logging.info("%s: Exited training loop.", task)
