@@ -82,3 +82,42 @@ def AddEpochSummary(summary_writer, global_step_val, epoch_info_dict, summary_sc
         summary_writer.flush()
     return ("epoch/eval number {0} | Avg_Hit@1: {1:.3f} | Avg_PERR: {2:.3f} "
             "| MAP: {3:.3f} | GAP: {4:.3f} | Avg_Loss: {5:3f}").format(epoch_id, avg_hit_at_one, avg_perr, mean_ap, gap, avg_loss)
+
+
+class AsyncFetcher(object):
+    """sess.run-style fetch of device tensors WITHOUT stopping the GPU: fetch() clones the tensors in stream order (the
+    graph's output buffers are overwritten by its next step) and copies the clones to pinned host memory on a copy
+    stream; result() waits for that copy only.  A loop that calls fetch() for batch k, enqueues batch k+1 and then takes
+    result() of batch k computes its host metrics while the GPU runs the next batch."""
+
+    def __init__(self, device, slots=2):
+        import torch
+        self._torch, self.device = torch, torch.device(device)
+        self._stream = torch.cuda.Stream(device=self.device)
+        self._bufs = [dict() for _ in range(slots)]
+        self._n = 0
+
+    def fetch(self, tensors):
+        """tensors: dict name -> device tensor.  Returns a handle for result()."""
+        torch = self._torch
+        clones = {k: t.detach().clone() for k, t in tensors.items()}
+        cur = torch.cuda.current_stream(self.device)
+        self._stream.wait_stream(cur)
+        slot = self._bufs[self._n % len(self._bufs)]
+        self._n += 1
+        with torch.cuda.stream(self._stream):
+            for k, t in clones.items():
+                if k not in slot or slot[k].shape != t.shape or slot[k].dtype != t.dtype:
+                    slot[k] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                slot[k].copy_(t, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._stream)
+        for t in clones.values():
+            t.record_stream(self._stream)
+        return (ev, slot, tuple(clones.keys()))
+
+    def result(self, handle):
+        """dict name -> numpy array (views of the pinned staging buffers: valid until `slots` further fetch() calls)."""
+        ev, slot, keys = handle
+        ev.synchronize()
+        return {k: slot[k].numpy() for k in keys}

@@ -80,25 +80,43 @@ def evaluation_loop(graph, reader, label_loss_fn, summary_writer, evl_metrics, l
     evl_metrics.clear()
     examples_processed, total_example_per_sec = 0, []
     fused_ce = isinstance(label_loss_fn, losses.CrossEntropyLoss)
-    for ids, q, labels, n, n_host in _batches(reader, device):
-        batch_start_time = time.time()
-        out = graph.step(q, labels, n, num_frames_host=n_host)
-        predictions_val = out["predictions"].cpu().numpy()              # the fetch: D2H + sync
-        labels_val = labels.cpu().numpy().astype(np.float32)
-        loss_val = float(out["loss"]) if fused_ce else float(label_loss_fn.calculate_loss(out["predictions"], labels))
-        seconds_per_batch = time.time() - batch_start_time
+    fetcher = utils.AsyncFetcher(device)
+    last_time = [time.time()]
+
+    def account(handle):
+        """The host side of one batch (cs/validate.py:240-282), run while the GPU already works on the next batch."""
+        nonlocal examples_processed
+        got = fetcher.result(handle)
+        predictions_val, labels_val = got["predictions"], got["labels"].astype(np.float32)
+        loss_val = float(got["loss"].reshape(-1)[0])
+        now = time.time()
+        seconds_per_batch, last_time[0] = max(now - last_time[0], 1e-9), now
         example_per_second = labels_val.shape[0] / seconds_per_batch
         total_example_per_sec.append(example_per_second)
         examples_processed += labels_val.shape[0]
         iteration_info_dict = evl_metrics.accumulate(predictions_val, labels_val, loss_val)
         iteration_info_dict["examples_per_second"] = example_per_second
         iterinfo_pre = ""
-        if "student_state_loss" in out:                                 # cs/validate.py:268-275
-            student_loss_val = float(out["student_state_loss"])
+        if "student_state_loss" in got:                                 # cs/validate.py:268-275
+            student_loss_val = float(got["student_state_loss"].reshape(-1)[0])
             iteration_info_dict["student_loss"] = student_loss_val
             iterinfo_pre = "student_loss: %f | " % student_loss_val
         iterinfo = utils.AddGlobalStepSummary(summary_writer, global_step_val, iteration_info_dict, summary_scope="Eval")
         logging.info("examples_processed: %d | %s%s", examples_processed, iterinfo_pre, iterinfo)
+
+    pending = None
+    for ids, q, labels, n, n_host in _batches(reader, device):
+        out = graph.step(q, labels, n, num_frames_host=n_host)
+        loss_t = out["loss"] if fused_ce else label_loss_fn.calculate_loss(out["predictions"], labels)
+        fetch = {"predictions": out["predictions"], "labels": labels, "loss": loss_t.reshape(1)}
+        if "student_state_loss" in out:
+            fetch["student_state_loss"] = out["student_state_loss"].reshape(1)
+        handle = fetcher.fetch(fetch)                                    # the fetch: clones + D2H on a copy stream
+        if pending is not None:
+            account(pending)                                             # batch k's metrics, under batch k+1
+        pending = handle
+    if pending is not None:
+        account(pending)
     logging.info("Done with batched inference. Now calculating global performance metrics.")
     epoch_info_dict = evl_metrics.get()
     epoch_info_dict["epoch_id"] = global_step_val
