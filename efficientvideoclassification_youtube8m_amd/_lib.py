@@ -18,7 +18,7 @@ SIGNATURES = {
     "evc_check_device": [i32],
     "evc_l2norm_chunk_fwd": [vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp, i32, vp, vp, vp, i32, vp, i32, vp],
     "evc_sort_rows_by_len": [vp, i32, i32, vp, vp, vp, vp],
-    "evc_frame_counts": [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp],
+    "evc_frame_counts": [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp],
     "evc_gemm_nt": [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i32, i32, vp],
     "evc_gemm_tn": [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp],
     "evc_colsum_bf16": [vp, i64, i32, i32, i32, vp, vp],

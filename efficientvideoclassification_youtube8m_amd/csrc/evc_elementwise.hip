@@ -148,12 +148,12 @@ extern "C" int evc_l2norm_chunk_fwd(const float* x_raw, const uint8_t* x_u8, con
 // ---------------------------------------------------------------------------
 // a2 integer part: frame counts (bit-exact vs the float64/float32 TF formulas)
 // ---------------------------------------------------------------------------
-__global__ void frame_counts_kernel(const int* __restrict__ nfr, int B, int every_n, int maxf, int C, int Lc,
+__global__ void frame_counts_kernel(const int* __restrict__ nfr, int B, int every_n, int subsampled, int maxf, int C, int Lc,
                                     long long* __restrict__ n_out, int* __restrict__ len1, int* __restrict__ len2) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   long long n = nfr[b];
-  if (every_n > 1) {
+  if (subsampled) {          // also at every_n = 1: float64 (n/300)*300 truncates to n-1 for n = 55, 79, 97, ... (kept)
     // tf.cast(tf.multiply(tf.divide(n, 300), S), tf.int64): float64 true division, truncation
     const int S = maxf / every_n;
     const double q = (double)nfr[b] / (double)maxf;
@@ -170,12 +170,12 @@ __global__ void frame_counts_kernel(const int* __restrict__ nfr, int B, int ever
   len2[b] = (int)ceilf((float)n / (float)Lc);
 }
 
-extern "C" int evc_frame_counts(const int32_t* num_frames, int B, int every_n, int max_frames_before_sampling,
+extern "C" int evc_frame_counts(const int32_t* num_frames, int B, int every_n, int subsampled, int max_frames_before_sampling,
                                 int num_chunks, int chunk_len, int64_t* n_out, int32_t* len_l1, int32_t* len_l2,
                                 void* stream) {
   EVC_REQUIRE(B > 0 && every_n > 0 && num_chunks > 0 && chunk_len > 0, EVC_ERR_BAD_SHAPE, "evc_frame_counts: bad args");
   hipLaunchKernelGGL(frame_counts_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, num_frames, B, every_n,
-                     max_frames_before_sampling, num_chunks, chunk_len, (long long*)n_out, len_l1, len_l2);
+                     subsampled, max_frames_before_sampling, num_chunks, chunk_len, (long long*)n_out, len_l1, len_l2);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }

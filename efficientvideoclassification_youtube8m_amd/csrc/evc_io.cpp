@@ -17,6 +17,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -66,39 +68,64 @@ extern "C" uint32_t evc_masked_crc32c(const uint8_t* p, int64_t n) {
   return ((c >> 15) | (c << 17)) + 0xa282ead8u;
 }
 
+// ---- files ---------------------------------------------------------------------------------------
+// Closed on every exit path, including an exception on its way to the catch clauses of the entry points below
+// (no C++ exception crosses the extern "C" boundary: a corrupt length field becomes an error code, not an abort).
+struct File {
+  FILE* f;
+  explicit File(const char* path) : f(fopen(path, "rb")) {}
+  ~File() { if (f) fclose(f); }
+  File(const File&) = delete;
+  File& operator=(const File&) = delete;
+  int64_t size() {
+    const long cur = ftell(f);
+    if (fseek(f, 0, SEEK_END) != 0) return -1;
+    const long n = ftell(f);
+    fseek(f, cur, SEEK_SET);
+    return (int64_t)n;
+  }
+};
+#define IO_GUARD_END(fn_)                                                                          \
+  catch (const std::bad_alloc&) { IO_FAIL(EVC_IO_ERR_FORMAT, fn_ ": out of memory (corrupt length field?)"); } \
+  catch (const std::exception& e) { IO_FAIL(EVC_IO_ERR_FORMAT, fn_ ": %s", e.what()); }
+
 // ---- TFRecord scan --------------------------------------------------------------------------------
-extern "C" int64_t evc_tfrecord_scan(const char* path, int64_t* offsets, int64_t* lengths, int64_t max_records, int verify_crc) {
-  FILE* f = fopen(path, "rb");
+extern "C" int64_t evc_tfrecord_scan(const char* path, int64_t* offsets, int64_t* lengths, int64_t max_records, int verify_crc) try {
+  File file(path);
+  FILE* f = file.f;
   if (!f) IO_FAIL(EVC_IO_ERR_FILE, "cannot open %s", path);
+  const int64_t fsize = file.size();
   int64_t count = 0, pos = 0;
   std::vector<uint8_t> buf;
   for (;;) {
     uint8_t hdr[12];
     const size_t got = fread(hdr, 1, 12, f);
     if (got == 0) break;
-    if (got != 12) { fclose(f); IO_FAIL(EVC_IO_ERR_FORMAT, "%s: truncated record header at %lld", path, (long long)pos); }
+    if (got != 12) { IO_FAIL(EVC_IO_ERR_FORMAT, "%s: truncated record header at %lld", path, (long long)pos); }
     uint64_t len;
     uint32_t lcrc;
     memcpy(&len, hdr, 8);
     memcpy(&lcrc, hdr + 8, 4);
-    if (verify_crc && evc_masked_crc32c(hdr, 8) != lcrc) { fclose(f); IO_FAIL(EVC_IO_ERR_FORMAT, "%s: bad length crc at %lld", path, (long long)pos); }
+    if (verify_crc && evc_masked_crc32c(hdr, 8) != lcrc) { IO_FAIL(EVC_IO_ERR_FORMAT, "%s: bad length crc at %lld", path, (long long)pos); }
+    // a record cannot be longer than what is left of the file (a corrupt length would otherwise size a buffer)
+    if (fsize >= 0 && (len > (uint64_t)fsize || pos + 12 + (int64_t)len + 4 > fsize))
+      IO_FAIL(EVC_IO_ERR_FORMAT, "%s: truncated record at %lld (claims %llu bytes, the file has %lld)", path, (long long)pos, (unsigned long long)len, (long long)fsize);
     if (offsets && count < max_records) { offsets[count] = pos + 12; lengths[count] = (int64_t)len; }
     if (verify_crc) {
       buf.resize(len + 4);
-      if (fread(buf.data(), 1, len + 4, f) != len + 4) { fclose(f); IO_FAIL(EVC_IO_ERR_FORMAT, "%s: truncated record at %lld", path, (long long)pos); }
+      if (fread(buf.data(), 1, len + 4, f) != len + 4) { IO_FAIL(EVC_IO_ERR_FORMAT, "%s: truncated record at %lld", path, (long long)pos); }
       uint32_t dcrc;
       memcpy(&dcrc, buf.data() + len, 4);
-      if (evc_masked_crc32c(buf.data(), (int64_t)len) != dcrc) { fclose(f); IO_FAIL(EVC_IO_ERR_FORMAT, "%s: bad data crc at %lld", path, (long long)pos); }
+      if (evc_masked_crc32c(buf.data(), (int64_t)len) != dcrc) { IO_FAIL(EVC_IO_ERR_FORMAT, "%s: bad data crc at %lld", path, (long long)pos); }
     } else if (fseek(f, (long)(len + 4), SEEK_CUR) != 0) {
-      fclose(f);
       IO_FAIL(EVC_IO_ERR_FORMAT, "%s: seek failed at %lld", path, (long long)pos);
     }
     pos += 12 + (int64_t)len + 4;
     ++count;
   }
-  fclose(f);
   return count;
 }
+IO_GUARD_END("evc_tfrecord_scan")
 
 // ---- protobuf wire helpers --------------------------------------------------------------------------
 struct Span { const uint8_t* p; const uint8_t* e; };
@@ -194,10 +221,11 @@ static bool feature_int64s(Span feat, std::vector<int64_t>& out) {
 extern "C" int evc_parse_yt8m_frame_example(const uint8_t* buf, int64_t len, const char* const* feature_names,
                                             const int32_t* feature_sizes, int num_features, int max_frames,
                                             uint8_t* frames_out, int32_t* num_frames_out, int64_t* labels_out,
-                                            int max_labels, int32_t* num_labels_out, char* id_out, int id_cap) {
+                                            int max_labels, int32_t* num_labels_out, char* id_out, int id_cap) try {
   if (!buf || len <= 0 || num_features <= 0 || max_frames <= 0) IO_FAIL(EVC_IO_ERR_ARG, "evc_parse_yt8m_frame_example: bad arguments");
   int row = 0;
   std::vector<int> col0(num_features);
+  std::vector<char> seen(num_features, 0);
   for (int i = 0; i < num_features; ++i) { col0[i] = row; row += feature_sizes[i]; }
   memset(frames_out, 0, (size_t)max_frames * row);      // resize_axis pads with zeros (cs/readers.py:8-43)
   if (id_out && id_cap > 0) id_out[0] = 0;
@@ -246,6 +274,7 @@ extern "C" int evc_parse_yt8m_frame_example(const uint8_t* buf, int64_t len, con
           int fi = -1;
           for (int i = 0; i < num_features; ++i) if (key == feature_names[i]) fi = i;
           if (fi < 0) continue;
+          seen[fi] = 1;
           int t = 0;
           while (fl.p < fl.e) {          // FeatureList: repeated Feature feature = 1
             uint64_t t3;
@@ -266,10 +295,15 @@ extern "C" int evc_parse_yt8m_frame_example(const uint8_t* buf, int64_t len, con
       }
     } else if (!skip_field(ex, wt)) IO_FAIL(EVC_IO_ERR_FORMAT, "SequenceExample: bad field");
   }
+  // tf.parse_single_sequence_example fails on a record that lacks any of the requested feature lists
+  // (FixedLenSequenceFeature without allow_missing, cs/readers.py:196-199): no silently zero columns
+  for (int i = 0; i < num_features; ++i)
+    if (!seen[i]) IO_FAIL(EVC_IO_ERR_FORMAT, "feature list '%s' is missing from the record", feature_names[i]);
   if (num_frames < 0) IO_FAIL(EVC_IO_ERR_FORMAT, "none of the requested features is present in the record");
   *num_frames_out = num_frames;
   return EVC_IO_OK;
 }
+IO_GUARD_END("evc_parse_yt8m_frame_example")
 
 // Feature -> float values (float_list = 2 { value = 1, packed or not })
 static bool feature_floats(Span feat, std::vector<float>& out) {
@@ -305,7 +339,7 @@ static bool feature_floats(Span feat, std::vector<float>& out) {
 extern "C" int evc_parse_yt8m_video_example(const uint8_t* buf, int64_t len, const char* const* feature_names,
                                             const int32_t* feature_sizes, int num_features, float* features_out,
                                             int64_t* labels_out, int max_labels, int32_t* num_labels_out, char* id_out,
-                                            int id_cap) {
+                                            int id_cap) try {
   if (!buf || len <= 0 || num_features <= 0) IO_FAIL(EVC_IO_ERR_ARG, "evc_parse_yt8m_video_example: bad arguments");
   std::vector<int> col0(num_features);
   std::vector<char> seen(num_features, 0);
@@ -359,64 +393,69 @@ extern "C" int evc_parse_yt8m_video_example(const uint8_t* buf, int64_t len, con
     if (!seen[i]) IO_FAIL(EVC_IO_ERR_FORMAT, "feature '%s' is missing from the record", feature_names[i]);
   return EVC_IO_OK;
 }
+IO_GUARD_END("evc_parse_yt8m_video_example")
 
 extern "C" int evc_read_yt8m_video_records(const char* path, const int64_t* offsets, const int64_t* lengths, int count,
                                            const char* const* feature_names, const int32_t* feature_sizes, int num_features,
                                            int num_classes, float* features_out, uint8_t* labels_multi_hot, char* ids_out,
-                                           int id_cap) {
-  FILE* f = fopen(path, "rb");
+                                           int id_cap) try {
+  File file(path);
+  FILE* f = file.f;
   if (!f) IO_FAIL(EVC_IO_ERR_FILE, "cannot open %s", path);
+  const int64_t fsize = file.size();
   int row = 0;
   for (int i = 0; i < num_features; ++i) row += feature_sizes[i];
   std::vector<uint8_t> buf;
   std::vector<int64_t> labels(4096);
   for (int r = 0; r < count; ++r) {
+    if (lengths[r] < 0 || offsets[r] < 0 || (fsize >= 0 && offsets[r] + lengths[r] > fsize))
+      IO_FAIL(EVC_IO_ERR_FORMAT, "%s: record %d (offset %lld, %lld bytes) lies outside the file", path, r, (long long)offsets[r], (long long)lengths[r]);
     buf.resize(lengths[r]);
-    if (fseek(f, (long)offsets[r], SEEK_SET) != 0 || fread(buf.data(), 1, lengths[r], f) != (size_t)lengths[r]) {
-      fclose(f);
+    if (fseek(f, (long)offsets[r], SEEK_SET) != 0 || fread(buf.data(), 1, lengths[r], f) != (size_t)lengths[r])
       IO_FAIL(EVC_IO_ERR_FORMAT, "%s: cannot read record %d", path, r);
-    }
     int32_t nl = 0;
     const int rc = evc_parse_yt8m_video_example(buf.data(), lengths[r], feature_names, feature_sizes, num_features,
                                                 features_out + (size_t)r * row, labels.data(), (int)labels.size(), &nl,
                                                 ids_out ? ids_out + (size_t)r * id_cap : nullptr, id_cap);
-    if (rc != EVC_IO_OK) { fclose(f); return rc; }
+    if (rc != EVC_IO_OK) return rc;
     uint8_t* mh = labels_multi_hot + (size_t)r * num_classes;   // tf.sparse_to_indicator cs/readers.py:108
     memset(mh, 0, num_classes);
     for (int i = 0; i < nl; ++i)
       if (labels[i] >= 0 && labels[i] < num_classes) mh[labels[i]] = 1;
   }
-  fclose(f);
   return EVC_IO_OK;
 }
+IO_GUARD_END("evc_read_yt8m_records")
 
 // Reads `count` records (given by offset/length) of one file and parses them into batch buffers.
 extern "C" int evc_read_yt8m_frame_records(const char* path, const int64_t* offsets, const int64_t* lengths, int count,
                                            const char* const* feature_names, const int32_t* feature_sizes, int num_features,
                                            int max_frames, int num_classes, uint8_t* frames_out, int32_t* num_frames_out,
-                                           uint8_t* labels_multi_hot, char* ids_out, int id_cap) {
-  FILE* f = fopen(path, "rb");
+                                           uint8_t* labels_multi_hot, char* ids_out, int id_cap) try {
+  File file(path);
+  FILE* f = file.f;
   if (!f) IO_FAIL(EVC_IO_ERR_FILE, "cannot open %s", path);
+  const int64_t fsize = file.size();
   int row = 0;
   for (int i = 0; i < num_features; ++i) row += feature_sizes[i];
   std::vector<uint8_t> buf;
   std::vector<int64_t> labels(4096);
   for (int r = 0; r < count; ++r) {
+    if (lengths[r] < 0 || offsets[r] < 0 || (fsize >= 0 && offsets[r] + lengths[r] > fsize))
+      IO_FAIL(EVC_IO_ERR_FORMAT, "%s: record %d (offset %lld, %lld bytes) lies outside the file", path, r, (long long)offsets[r], (long long)lengths[r]);
     buf.resize(lengths[r]);
-    if (fseek(f, (long)offsets[r], SEEK_SET) != 0 || fread(buf.data(), 1, lengths[r], f) != (size_t)lengths[r]) {
-      fclose(f);
+    if (fseek(f, (long)offsets[r], SEEK_SET) != 0 || fread(buf.data(), 1, lengths[r], f) != (size_t)lengths[r])
       IO_FAIL(EVC_IO_ERR_FORMAT, "%s: cannot read record %d", path, r);
-    }
     int32_t nl = 0;
     const int rc = evc_parse_yt8m_frame_example(buf.data(), lengths[r], feature_names, feature_sizes, num_features, max_frames,
                                                 frames_out + (size_t)r * max_frames * row, num_frames_out + r, labels.data(),
                                                 (int)labels.size(), &nl, ids_out ? ids_out + (size_t)r * id_cap : nullptr, id_cap);
-    if (rc != EVC_IO_OK) { fclose(f); return rc; }
+    if (rc != EVC_IO_OK) return rc;
     uint8_t* mh = labels_multi_hot + (size_t)r * num_classes;   // tf.sparse_to_dense(labels, (num_classes,), 1) cs/readers.py:200-204
     memset(mh, 0, num_classes);
     for (int i = 0; i < nl; ++i)
       if (labels[i] >= 0 && labels[i] < num_classes) mh[labels[i]] = 1;
   }
-  fclose(f);
   return EVC_IO_OK;
 }
+IO_GUARD_END("evc_read_yt8m_records")

@@ -146,10 +146,10 @@ def frame_counts_and_plans(g, num_frames, nh, need_teacher, need_student):
             plan = ops.RowPlan(l1, l1h, g.max_frames // g.C1)
         t = (l1, l2, plan)
     if need_student:
-        n_s, l1s, l2s = ops.frame_counts(num_frames, g.every_n, g.C2, g.S // g.C2, g.max_frames)
+        n_s, l1s, l2s = ops.frame_counts(num_frames, g.every_n, g.C2, g.S // g.C2, g.max_frames, subsampled=True)
         plan = None
         if g.row_plans:
-            _, l1h, _ = ops.host_frame_counts(nh, g.every_n, g.C2, g.S // g.C2, g.max_frames)
+            _, l1h, _ = ops.host_frame_counts(nh, g.every_n, g.C2, g.S // g.C2, g.max_frames, subsampled=True)
             plan = ops.RowPlan(l1s, l1h, g.S // g.C2)
         s = (n_s, l1s, l2s, plan)
     return t, s
@@ -272,6 +272,11 @@ class DistillGraph:
         B = x_raw.shape[0]
         V = labels_u8.shape[1]
         dev = self.device
+        if self.dp and B != self.B:
+            # every rank must step on the same number of videos: the factor all-gathers move round_up(B, 32) rows per
+            # rank and the per-rank loss scales 1/(world*B) only add up to the global-batch mean for equal B
+            raise ValueError("data-parallel step on %d videos, the graph was built for %d per rank (ragged batches are "
+                             "not allowed under data parallelism: drop the remainder)" % (B, self.B))
         if self._dp_t is None or self._dp_t.shape[0] != B:
             self._dp_t = torch.empty((B, V), dtype=F32, device=dev)
             self._dp_s = torch.empty((B, V), dtype=F32, device=dev)
@@ -554,7 +559,10 @@ class SingleTowerGraph:
         ops.ce_loss(pred, labels_u8, self.losses[0:1], self._dp, grad_scale=1.0 / (B * self.world))
         tw.backward(self._dp)
         if self.world > 1:
-            torch.distributed.all_reduce(tw.store.grad, group=self.pg)
+            # SUM of the per-rank gradients; the batch-norm scale/offset gradients are already global (their f64
+            # partial sums were all-reduced inside BatchNorm.backward) and stay out of the reduce
+            for lo, hi in tw.grad_ranges(exclude=getattr(tw, "global_grad_names", ())):
+                torch.distributed.all_reduce(tw.store.grad[lo:hi], group=self.pg)
         if apply:
             lr = exponential_decay(self.lr0, self.global_step, B * self.world, self.lr_decay_examples, self.lr_decay)
             tw.apply_gradients(lr, self.clip, self.reg_pen * 1e-8)

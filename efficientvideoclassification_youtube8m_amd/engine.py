@@ -496,6 +496,21 @@ class TowerBase:
         if getattr(getattr(self, "moe", None), "_stale", False):
             self.moe._stale = False              # every rank has just loaded the complete weights
 
+    def grad_ranges(self, exclude=()):
+        """Maximal contiguous (lo, hi) element ranges of the flat gradient buffer that cover every variable not in
+        `exclude` (the payloads of a data-parallel all-reduce)."""
+        st, out = self.store, []
+        for k in self.names:
+            if k in exclude:
+                continue
+            lo = st.offsets[k]
+            hi = lo + _align(int(math.prod(st.shapes[k])))
+            if out and out[-1][1] == lo:
+                out[-1] = (out[-1][0], hi)
+            else:
+                out.append((lo, hi))
+        return out
+
     def begin_update(self):
         """Start one optimizer step (one tf.train op): bumps the Adam step count, clears the norm sums."""
         self.adam_t += 1

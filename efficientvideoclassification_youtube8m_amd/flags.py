@@ -78,6 +78,10 @@ _define("top_k", 20, int)
 # ---- additions of this build (not in the reference) --------------------------------
 _define("max_steps", 0, int, "stop after this many iterations (0 = until the data ends)")
 _define("synthetic_videos", 2048, int, "videos per epoch when train_data_pattern is synthetic")
+_define("teacher_only", False, _bool, "HierarchicalLstmModel: train the teacher tower alone (BASELINE cfg 2; the reference "
+        "always builds the student too, also at every_n=1)")
+_define("precision", "bf16", str, "'bf16' (one MFMA product per contraction) or 'high' (split-bf16 operands, 3 products: "
+        "f32-operand accuracy in every forward GEMM)")
 _define("log_every", 1, int, "host metrics / logging period in iterations (the reference logs every step)")
 
 

@@ -135,11 +135,13 @@ class RowPlan:
         _lib.call("evc_sort_rows_by_len", _p(lens_dev), M, T, _p(self.pos), _p(self.inv), _p(self.lens), _stream())
 
 
-def host_frame_counts(num_frames_host, every_n, num_chunks, chunk_len, max_frames=300):
-    """Host (numpy) twin of evc_frame_counts, bit-identical: (n_used int64 [B], len_l1 int32 [C*B], len_l2 int32 [B])."""
+def host_frame_counts(num_frames_host, every_n, num_chunks, chunk_len, max_frames=300, subsampled=None):
+    """Host (numpy) twin of evc_frame_counts, bit-identical: (n_used int64 [B], len_l1 int32 [C*B], len_l2 int32 [B]).
+    subsampled: the student formula of cs/train.py:264 (default: every_n > 1; the student graph passes True also at
+    every_n = 1, where float64 (n/300)*300 truncates to n-1 for some n)."""
     import numpy as np
     n = np.asarray(num_frames_host).astype(np.int64)
-    if every_n > 1:
+    if (every_n > 1) if subsampled is None else subsampled:
         S = max_frames // every_n
         n = np.trunc(n.astype(np.float64) / float(max_frames) * float(S)).astype(np.int64)
     l1 = np.clip(n[None, :] - chunk_len * np.arange(num_chunks, dtype=np.int64)[:, None], 0, chunk_len).astype(np.int32).reshape(-1)
@@ -174,14 +176,15 @@ def l2norm_chunk(x_raw, num_chunks, every_n=None, num_chunks_student=None, num_f
     return out1, out2
 
 
-def frame_counts(num_frames, every_n, num_chunks, chunk_len, max_frames=300):
+def frame_counts(num_frames, every_n, num_chunks, chunk_len, max_frames=300, subsampled=None):
     """a2 integer part.  Returns (n_used int64 [B], len_l1 int32 [C*B], len_l2 int32 [B])."""
+    sub = (every_n > 1) if subsampled is None else subsampled
     B = num_frames.shape[0]
     dev = num_frames.device
     n_out = torch.empty(B, dtype=torch.int64, device=dev)
     l1 = torch.empty(num_chunks * B, dtype=torch.int32, device=dev)
     l2 = torch.empty(B, dtype=torch.int32, device=dev)
-    _lib.call("evc_frame_counts", _p(num_frames), B, every_n, max_frames, num_chunks, chunk_len, _p(n_out), _p(l1), _p(l2), _stream())
+    _lib.call("evc_frame_counts", _p(num_frames), B, every_n, 1 if sub else 0, max_frames, num_chunks, chunk_len, _p(n_out), _p(l1), _p(l2), _stream())
     return n_out, l1, l2
 
 

@@ -235,7 +235,7 @@ class InputPipeline(object):
 
     def __init__(self, reader, data_pattern, batch_size, num_epochs=None, num_readers=1, shuffle=True, seed=None,
                  device=None, rank=0, world_size=1, prefetch=3, what="training", reuse_host_buffers=False,
-                 with_host_counts=False):
+                 with_host_counts=False, drop_remainder=None):
         files = sorted(glob.glob(data_pattern)) if isinstance(data_pattern, str) else list(data_pattern)
         if not files:
             raise IOError("Unable to find " + what + " files. data_pattern='" + str(data_pattern) + "'.")   # cs/train.py:155-157
@@ -253,7 +253,12 @@ class InputPipeline(object):
                 off, ln = off[rank::world_size], ln[rank::world_size]
             self.index.append((f, off, ln))
         self.num_records = sum(len(o) for _, o, _ in self.index)
-        self.num_batches = None if num_epochs is None else -(-self.num_records * num_epochs // batch_size)
+        # Data parallelism never sees a ragged batch: ranks own different records, so a smaller final batch would
+        # differ in size between ranks (unequal collective payloads, per-rank loss scales that no longer add up to the
+        # global-batch mean).  The remainder is dropped; ranks then agree on MIN(num_batches) (train.py).
+        self.drop_remainder = (world_size > 1) if drop_remainder is None else bool(drop_remainder)
+        total = None if num_epochs is None else self.num_records * num_epochs
+        self.num_batches = None if total is None else (total // batch_size if self.drop_remainder else -(-total // batch_size))
         rng = random.Random(seed)
         refs = _record_refs([(f, len(o)) for f, o, _ in self.index], num_epochs, shuffle, num_readers, rng)
         self._refs = _shuffle_window(refs, 50 * batch_size, rng) if shuffle else refs
@@ -311,7 +316,7 @@ class InputPipeline(object):
             refs.append(r)
             if len(refs) == self.batch_size:
                 break
-        if not refs:
+        if not refs or (self.drop_remainder and len(refs) < self.batch_size):
             return False
         self._pending.append(self._pool.submit(self._fill, refs, self._next_buffers()))
         return True

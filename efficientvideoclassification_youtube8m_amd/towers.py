@@ -78,6 +78,8 @@ class DbofTower(TowerBase):
 
     CW, HW = "cluster_weights", "hidden1_weights"        # the reference's unnamed tf.Variable / Variable_1
     l2_names = (MoeHead.GATES, MoeHead.EXPERTS)
+    # gradients that BatchNorm.backward already leaves summed over the ranks (SyncBN): not part of the gradient all-reduce
+    global_grad_names = tuple("%s/%s" % (s, v) for s in ("input_bn", "cluster_bn", "hidden1_bn") for v in ("beta", "gamma"))
 
     def __init__(self, batch_size, max_frames=300, feature_size=1152, vocab_size=4716, iterations=30,
                  cluster_size=8192, hidden_size=1024, num_mixtures=2, device="cuda:0", training=True,

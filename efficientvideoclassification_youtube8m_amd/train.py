@@ -53,11 +53,14 @@ def build_graph(model, label_loss_fn, feature_size, batch_size, every_n, device,
                   regularization_penalty=FLAGS.regularization_penalty, clip_gradient_norm=FLAGS.clip_gradient_norm,
                   process_group=process_group)
     if isinstance(model, frame_level_models.HierarchicalLstmModel):
-        mode = "student" if finetune else ("teacher_student" if every_n > 1 else "teacher")
+        # every_n == 1 (the reference's default, cs/train.py:100-101) still builds and trains model_student, on all 300
+        # frames in 5 chunks of 60 (cs/train.py:262-272,349-356): global_step += 2 and the checkpoint holds both scopes.
+        # Teacher-only training (BASELINE cfg 2) is not a reference mode: it is asked for with --teacher_only.
+        mode = "student" if finetune else ("teacher" if getattr(FLAGS, "teacher_only", False) else "teacher_student")
         return DistillGraph(batch_size, every_n=every_n, mode=mode, feature_size=feature_size, vocab_size=NUM_CLASSES,
                             max_frames=FLAGS.max_num_frames, num_inputs_to_lstm=FLAGS.num_inputs_to_lstm,
                             lstm_cells=FLAGS.lstm_cells, lstm_layers=FLAGS.lstm_layers,
-                            num_mixtures=FLAGS.moe_num_mixtures, device=device, **common)
+                            num_mixtures=FLAGS.moe_num_mixtures, device=device, precision=FLAGS.precision, **common)
     if isinstance(model, frame_level_models.DbofModel):
         tw = DbofTower(batch_size, FLAGS.max_num_frames, feature_size, NUM_CLASSES, FLAGS.iterations,
                        FLAGS.dbof_cluster_size, FLAGS.dbof_hidden_size, FLAGS.moe_num_mixtures, device=device,
@@ -70,10 +73,11 @@ def build_graph(model, label_loss_fn, feature_size, batch_size, every_n, device,
                               % type(model).__name__)
 
 
-def synthetic_batches(batch_size, feature_size, device, videos_per_epoch, num_epochs, seed):
+def synthetic_batches(batch_size, feature_size, device, videos_per_epoch, num_epochs, seed, drop_remainder=False):
     """Synthetic stand-in for get_input_data_tensors (cs/train.py:129-176): uint8
     features dequantised by the input kernel, n ~ U{120..300}, ~3 labels/video.
-    Yields (features, labels, num_frames, num_frames on the host)."""
+    Yields (features, labels, num_frames, num_frames on the host).  drop_remainder (data parallel): no smaller
+    final batch."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     T = FLAGS.max_num_frames
@@ -82,6 +86,8 @@ def synthetic_batches(batch_size, feature_size, device, videos_per_epoch, num_ep
         while left > 0:
             b = min(batch_size, left)                  # allow_smaller_final_batch=True (cs/train.py:175)
             left -= b
+            if b < batch_size and drop_remainder:
+                break
             q = torch.randint(0, 256, (b, T, feature_size), generator=g, device=device, dtype=torch.uint8)
             n = torch.randint(min(120, T), T + 1, (b,), generator=g, device=device, dtype=torch.int32)
             labels = torch.zeros((b, NUM_CLASSES), dtype=torch.uint8, device=device)
@@ -102,7 +108,8 @@ def get_input_data(data_pattern, batch_size, feature_size, device, num_epochs, s
     """get_input_data_tensors (cs/train.py:129-176) -> iterator of (features uint8, labels uint8, num_frames int32)
     device tensors; ``batch_size`` is per GPU (cs/train.py:205 batch_size * num_towers)."""
     if data_pattern in ("", "synthetic"):
-        return synthetic_batches(batch_size, feature_size, device, FLAGS.synthetic_videos, num_epochs, seed), None
+        return synthetic_batches(batch_size, feature_size, device, FLAGS.synthetic_videos, num_epochs, seed,
+                                 drop_remainder=world > 1), None
     logging.info("Using batch size of %d for training.", batch_size)
     pipe = readers.get_input_data_tensors(get_reader(), data_pattern, batch_size=batch_size, num_epochs=num_epochs,
                                           num_readers=FLAGS.num_readers, seed=seed, device=device, rank=rank, world_size=world,
@@ -142,10 +149,20 @@ def save_checkpoint(graph, train_dir, rank):
             sd.update({k: v.cpu() for k, v in tw.state_dict().items()})
             sd["%s/adam" % tw.scope] = {"t": tw.adam_t, "m": tw.store.m.cpu(), "v": tw.store.v.cpu()}
     path = os.path.join(train_dir, "model.ckpt-%d.pt" % graph.global_step)
-    torch.save(sd, path)
+    # like tf.train.Saver: write to a temporary name, flush to disk, rename (a validate.py polling the directory never
+    # sees a half-written file); the temporary name does not match the model.ckpt*.pt glob
+    tmp = os.path.join(train_dir, ".tmp-%d-model.ckpt-%d" % (os.getpid(), graph.global_step))
+    with open(tmp, "wb") as f:
+        torch.save(sd, f)
+        f.flush()
+        os.fsync(f.fileno())
+    os.replace(tmp, path)
     for old in glob.glob(os.path.join(train_dir, "model.ckpt*.pt")):       # max_to_keep=1 (cs/train.py:651)
         if old != path:
-            os.remove(old)
+            try:
+                os.remove(old)
+            except FileNotFoundError:
+                pass
     return path
 
 
@@ -232,11 +249,12 @@ def main(argv=None):
         copy_stream.wait_stream(cur)
         slot = host_bufs.setdefault(it % 2, {})
         with torch.cuda.stream(copy_stream):
-            if rank == 0:
-                for key, t in (("pred", pred), ("lab", lab), ("loss", loss_dev)):
-                    if key not in slot or slot[key].shape != t.shape or slot[key].dtype != t.dtype:
-                        slot[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-                    slot[key].copy_(t, non_blocking=True)
+            # the loss values travel to the host on EVERY rank (8 floats, already summed over the ranks inside the
+            # step): the non-finite check below must stop all ranks together, not leave the others in a collective
+            for key, t in ((("pred", pred), ("lab", lab), ("loss", loss_dev)) if rank == 0 else (("loss", loss_dev),)):
+                if key not in slot or slot[key].shape != t.shape or slot[key].dtype != t.dtype:
+                    slot[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                slot[key].copy_(t, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(copy_stream)
         for t in (pred, lab, loss_dev):
@@ -246,16 +264,18 @@ def main(argv=None):
     last_log_time = [time.time(), 0]     # (wall time, iteration) of the previous log line: rates over the interval in between
 
     def finish_log(snap, it_now):
-        if rank != 0:
+        if rank != 0 and not is_distill:
             return
         snap["event"].synchronize()              # nothing here touches a stream that step it_now+1 has been queued on
         r = graph.loss_report(losses=snap["slot"]["loss"]) if is_distill else None
+        if is_distill and not all(np.isfinite(v) for v in r.values()):          # slim.learning.create_train_op's check_numerics;
+            raise FloatingPointError("LossTensor is inf or nan : %s" % r)      # same (reduced) values on every rank: all stop
+        if rank != 0:
+            return
         p, y = snap["slot"]["pred"].numpy(), snap["slot"]["lab"].numpy().astype(np.float32)
         hit, perr, gap = (eval_util.calculate_hit_at_one(p, y), eval_util.calculate_precision_at_equal_recall_rate(p, y),
                           eval_util.calculate_gap(p, y))
         if is_distill:
-            if not all(np.isfinite(v) for v in r.values()):          # slim.learning.create_train_op's check_numerics
-                raise FloatingPointError("LossTensor is inf or nan : %s" % r)
             logging.info("%s: training step %d| Hit@1: %.2f| PERR: %.2f| GAP: %.2f| Teacher_Loss: %s| L_REP: %s| L_PRED: %s"
                          "| L_CE: %s", task, snap["global_step"], hit, perr, gap, round(r["label_loss"], 2),
                          round(r["student_loss_state"], 2), round(r["pred_loss"], 2), round(r["student_label_loss"], 2))

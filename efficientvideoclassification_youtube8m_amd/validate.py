@@ -70,7 +70,13 @@ def evaluation_loop(graph, reader, label_loss_fn, summary_writer, evl_metrics, l
         logging.info("No checkpoint file found.")
         return -1, None
     logging.info("Loading checkpoint for eval: " + ck)
-    sd = torch.load(ck, map_location="cpu")
+    try:
+        sd = torch.load(ck, map_location="cpu")
+    except (FileNotFoundError, EOFError, RuntimeError, OSError) as e:
+        # the trainer replaced the file between the directory listing and the load (max_to_keep=1): not an error of
+        # this process - look again at the next poll (train.save_checkpoint itself writes atomically)
+        logging.info("checkpoint %s could not be loaded (%s); will look again.", ck, e)
+        return last_global_step_val, None
     graph.restore(sd)
     global_step_val = int(sd.get("global_step", 0))
     if global_step_val == last_global_step_val:

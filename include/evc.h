@@ -83,8 +83,10 @@ int evc_sort_rows_by_len(const int32_t* len, int M, int max_len, int32_t* pos, i
  * cs/train.py:263-264; and the per-chunk L1 lengths / L2 length of
  * cs/frame_level_models.py:238-240,256 (teacher) and :308-310,327 (student).
  * len_l1 [C*B] int32 with row m = chunk*B + b; len_l2 [B] int32.
- * n_out [B] int64 receives the (possibly sub-sampled) frame count used. */
-int evc_frame_counts(const int32_t* num_frames, int B, int every_n, int max_frames_before_sampling,
+ * n_out [B] int64 receives the (possibly sub-sampled) frame count used.
+ * subsampled != 0: the student input of cs/train.py:263-264 - the float64 formula is applied for every every_n,
+ * including 1 (where it gives n-1 for n = 55, 79, 97, 110, ...); 0: the teacher input, n as it is. */
+int evc_frame_counts(const int32_t* num_frames, int B, int every_n, int subsampled, int max_frames_before_sampling,
                      int num_chunks, int chunk_len, int64_t* n_out, int32_t* len_l1, int32_t* len_l2,
                      void* stream);
 

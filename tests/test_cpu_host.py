@@ -228,3 +228,37 @@ def test_sharded_update_collectives_gloo(tmp_path):
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stdout.count("-ok") == 2, r.stdout
+
+
+def test_grad_ranges_skip_synced_batchnorm_gradients():
+    """SingleTowerGraph all-reduces the flat gradient buffer in the contiguous ranges that leave out the batch-norm
+    gamma/beta gradients (already global after BatchNorm.backward's f64 partial-sum all-reduce: reducing them again
+    would multiply them by the world size)."""
+    import math
+    from collections import OrderedDict
+    from efficientvideoclassification_youtube8m_amd.engine import TowerBase, _align
+    from efficientvideoclassification_youtube8m_amd.towers import DbofTower
+
+    class Store:
+        pass
+
+    tw = TowerBase.__new__(TowerBase)
+    shapes = OrderedDict([("input_bn/beta", (10,)), ("input_bn/gamma", (10,)), ("cluster_weights", (7, 10)),
+                          ("cluster_bn/beta", (7,)), ("cluster_bn/gamma", (7,)), ("hidden1_weights", (5, 7)),
+                          ("hidden1_bn/beta", (5,)), ("hidden1_bn/gamma", (5,)), ("classifier/gates/weights", (9, 5)),
+                          ("classifier/experts/weights", (6, 5)), ("classifier/experts/biases", (6,))])
+    st = Store()
+    st.shapes, st.offsets, off = shapes, {}, 0
+    for k, shp in shapes.items():
+        st.offsets[k] = off
+        off += _align(int(math.prod(shp)))
+    tw.store, tw.names = st, list(shapes)
+    assert tw.grad_ranges() == [(0, off)]
+    rs = tw.grad_ranges(exclude=DbofTower.global_grad_names)
+    covered = set()
+    for lo, hi in rs:
+        covered |= set(range(lo, hi))
+    for k, shp in shapes.items():
+        inside = set(range(st.offsets[k], st.offsets[k] + int(math.prod(shp)))) <= covered
+        assert inside == (k not in DbofTower.global_grad_names), k
+    assert len(rs) == 3          # cluster_weights | hidden1_weights | the MoE block

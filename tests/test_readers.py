@@ -156,12 +156,41 @@ def test_frame_parser_errors():
     with pytest.raises(readers.EvcIoError, match="disagree"):        # tf.assert_equal cs/readers.py:225
         _parse_frame(readers.encode_frame_example("x", [1], {"rgb": rng.integers(0, 256, (5, 1024), dtype=np.uint8),
                                                              "audio": rng.integers(0, 256, (6, 128), dtype=np.uint8)}))
-    with pytest.raises(readers.EvcIoError, match="none of the requested"):
+    with pytest.raises(readers.EvcIoError, match="is missing from the record"):
         _parse_frame(readers.encode_frame_example("x", [1], {"inc3": rng.integers(0, 256, (5, 1024), dtype=np.uint8)}))
+    # ONE requested feature list absent (parse_single_sequence_example raises; zero audio columns would train silently)
+    with pytest.raises(readers.EvcIoError, match="feature list 'audio' is missing"):
+        _parse_frame(readers.encode_frame_example("x", [1], {"rgb": rng.integers(0, 256, (5, 1024), dtype=np.uint8)}))
     with pytest.raises(readers.EvcIoError):
         _parse_frame(readers.encode_frame_example("x", [1], _random_video(rng, 4))[:-3])      # truncated proto
     fr, nf, lab, vid = _parse_frame(readers.encode_frame_example("x", [], _random_video(rng, 2)))
     assert nf == 2 and lab == []
+
+
+def test_corrupt_length_field_is_an_error_not_an_abort(tmp_path):
+    """A record header that claims more bytes than the file holds (with a matching length CRC, so only the bound
+    against the file size can catch it) must come back as EvcIoError - never std::bad_alloc through the C ABI."""
+    import struct
+    lib = readers.load_io()
+    p = tmp_path / "huge.tfrecord"
+    hdr = struct.pack("<Q", 1 << 46)
+    crc = lib.evc_masked_crc32c(C.cast(C.c_char_p(hdr), C.c_void_p), 8)
+    p.write_bytes(hdr + struct.pack("<I", crc) + b"abcdefgh")
+    for verify in (True, False):
+        with pytest.raises(readers.EvcIoError, match="claims"):
+            readers.scan_tfrecord(str(p), verify_crc=verify)
+    # a (offset, length) pair outside the file handed to the batch reader
+    rng = np.random.default_rng(0)
+    good = tmp_path / "one.tfrecord"
+    readers.write_tfrecord(str(good), [readers.encode_frame_example("a", [1], _random_video(rng, 3))])
+    rd = readers.YT8MFrameFeatureReader(feature_names=["rgb", "audio"], feature_sizes=[1024, 128], max_frames=4)
+    off, ln = readers.scan_tfrecord(str(good))
+    x = np.zeros((1, 4, 1152), np.uint8); n = np.zeros(1, np.int32); y = np.zeros((1, 4716), np.uint8)
+    ids = np.zeros((1, readers.ID_CAP), np.uint8)
+    rd.read_into(str(good), off, ln, x, n, y, ids)
+    assert n[0] == 3
+    with pytest.raises(readers.EvcIoError, match="outside the file"):
+        rd.read_into(str(good), off, np.asarray([1 << 40], np.int64), x, n, y, ids)
 
 
 def test_tfrecord_scan_and_crc(tmp_path):
@@ -225,13 +254,32 @@ def test_pipeline_rank_sharding(tmp_path):
     _dataset(tmp_path, files=4, per_file=5)
     rd = readers.YT8MFrameFeatureReader(feature_names=["rgb", "audio"], feature_sizes=[1024, 128], max_frames=30)
     pat = str(tmp_path / "train*.tfrecord")
-    parts = [[i for ids, *_ in readers.get_input_data_tensors(rd, pat, 3, num_epochs=1, seed=r, rank=r, world_size=2) for i in ids]
-             for r in range(2)]
+    parts = [[i for ids, *_ in readers.get_input_data_tensors(rd, pat, 3, num_epochs=1, seed=r, rank=r, world_size=2,
+                                                              drop_remainder=False) for i in ids] for r in range(2)]
     assert len(parts[0]) == len(parts[1]) == 10 and not set(parts[0]) & set(parts[1])
     one = str(tmp_path / "train0000.tfrecord")                               # fewer files than ranks -> record sharding
-    parts = [[i for ids, *_ in readers.get_input_data_tensors(rd, one, 3, num_epochs=1, seed=r, rank=r, world_size=2) for i in ids]
-             for r in range(2)]
+    parts = [[i for ids, *_ in readers.get_input_data_tensors(rd, one, 3, num_epochs=1, seed=r, rank=r, world_size=2,
+                                                              drop_remainder=False) for i in ids] for r in range(2)]
     assert sorted(parts[0] + parts[1]) == ["v00%04d" % i for i in range(5)] and not set(parts[0]) & set(parts[1])
+
+
+def test_pipeline_never_ragged_under_data_parallelism(tmp_path):
+    """world_size > 1: every batch a rank hands out has exactly batch_size videos (the remainder is dropped) and
+    num_batches counts whole batches only, so MIN over the ranks is a step count every rank can run with equal
+    payloads (train.py).  Ranks own different numbers of records here (3 files: 2 vs 1)."""
+    _dataset(tmp_path, files=3, per_file=7)
+    rd = readers.YT8MFrameFeatureReader(feature_names=["rgb", "audio"], feature_sizes=[1024, 128], max_frames=30)
+    pat = str(tmp_path / "train*.tfrecord")
+    counts = []
+    for r in range(2):
+        pipe = readers.get_input_data_tensors(rd, pat, 4, num_epochs=1, seed=r, rank=r, world_size=2)
+        assert pipe.drop_remainder
+        sizes = [len(ids) for ids, *_ in pipe]
+        assert sizes == [4] * pipe.num_batches, (r, sizes, pipe.num_batches)
+        counts.append(pipe.num_batches)
+    assert counts == [14 // 4, 7 // 4]
+    single = readers.get_input_data_tensors(rd, pat, 4, num_epochs=1, seed=0)          # one process: smaller final batch kept
+    assert not single.drop_remainder and [len(ids) for ids, *_ in single] == [4] * 5 + [1] and single.num_batches == 6
 
 
 def test_aggregated_reader(tmp_path):
