@@ -552,6 +552,7 @@ class SingleTowerGraph:
         if isinstance(tw, DbofTower):
             if uniform is None:
                 uniform = torch.rand((B, tw.S), dtype=F32, device=self.device)
+            self.last_uniform = uniform              # the tf.random_uniform draw of this step (SampleRandomFrames)
             pred = tw.forward(x_raw, num_frames, uniform)
         else:
             pred = tw.forward(x_raw, num_frames)

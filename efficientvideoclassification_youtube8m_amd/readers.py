@@ -456,13 +456,13 @@ def write_tfrecord(path, payloads):
 
 def write_synthetic_frame_dataset(directory, num_files, videos_per_file, feature_names=("rgb", "audio"),
                                   feature_sizes=(1024, 128), num_classes=4716, min_frames=120, max_frames=300, seed=0,
-                                  prefix="train"):
+                                  prefix="train", first_file_index=0):
     """Writes a YouTube-8M-shaped data set of random videos (there is no network for the real one).
     Returns the list of files; the videos are reproducible from ``seed``."""
     os.makedirs(directory, exist_ok=True)
     rng = np.random.default_rng(seed)
     files = []
-    for fi in range(num_files):
+    for fi in range(first_file_index, first_file_index + num_files):      # (file index is part of the video ids)
         payloads = []
         for vi in range(videos_per_file):
             n = int(rng.integers(min_frames, max_frames + 1))

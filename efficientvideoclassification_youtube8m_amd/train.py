@@ -104,6 +104,9 @@ def get_reader():
     return readers.YT8MAggregatedFeatureReader(num_classes=NUM_CLASSES, feature_names=feature_names, feature_sizes=feature_sizes)
 
 
+LAST_BATCH = {"ids": None}
+
+
 def get_input_data(data_pattern, batch_size, feature_size, device, num_epochs, seed, rank=0, world=1):
     """get_input_data_tensors (cs/train.py:129-176) -> iterator of (features uint8, labels uint8, num_frames int32)
     device tensors; ``batch_size`` is per GPU (cs/train.py:205 batch_size * num_towers)."""
@@ -115,7 +118,11 @@ def get_input_data(data_pattern, batch_size, feature_size, device, num_epochs, s
                                           num_readers=FLAGS.num_readers, seed=seed, device=device, rank=rank, world_size=world,
                                           with_host_counts=True)
     logging.info("Number of training files / records on this rank: %d / %d.", len(pipe.index), pipe.num_records)
-    return (b[1:] for b in pipe), pipe.num_batches
+    def batches():
+        for b in pipe:
+            LAST_BATCH["ids"] = b[0]                     # video ids of the batch being handed out (tests, debugging)
+            yield b[1:]
+    return batches(), pipe.num_batches
 
 
 def dequantize_masked(q, n):
@@ -275,6 +282,8 @@ def main(argv=None):
         p, y = snap["slot"]["pred"].numpy(), snap["slot"]["lab"].numpy().astype(np.float32)
         hit, perr, gap = (eval_util.calculate_hit_at_one(p, y), eval_util.calculate_precision_at_equal_recall_rate(p, y),
                           eval_util.calculate_gap(p, y))
+        history.append((snap["global_step"], dict(r) if is_distill else {"loss": float(snap["slot"]["loss"][0])},
+                        {"hit_at_one": float(hit), "perr": float(perr), "gap": float(gap)}))
         if is_distill:
             logging.info("%s: training step %d| Hit@1: %.2f| PERR: %.2f| GAP: %.2f| Teacher_Loss: %s| L_REP: %s| L_PRED: %s"
                          "| L_CE: %s", task, snap["global_step"], hit, perr, gap, round(r["label_loss"], 2),
@@ -287,10 +296,12 @@ def main(argv=None):
         last_log_time[0], last_log_time[1] = now, it_now
         logging.info("global_step/sec: %g  Examples/Second: %g", steps_per_it / dt, snap["batch"] * world / dt)
 
+    history = []                         # (global_step, loss dict) of every logged step, returned to the caller
     pending = None
     for q, labels, n, n_host in data:
         out = graph.step(q, labels, n, num_frames_host=n_host) if is_distill else graph.step(dequantize_masked(q, n), labels, n)
         it += 1
+        graph.last_batch_ids = LAST_BATCH["ids"]
         logging_step = it % max(1, FLAGS.log_every) == 0
         snap = snapshot(out, labels, it) if logging_step else None
         if pending is not None:
@@ -317,6 +328,7 @@ def main(argv=None):
     print("Total time taken is " + str(time.time() - start))
     if world > 1:
         torch.distributed.destroy_process_group()
+    return {"graph": graph, "history": history, "iterations": it}
 
 
 if __name__ == "__main__":

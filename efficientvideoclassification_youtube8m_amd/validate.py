@@ -51,7 +51,8 @@ def build_graph(reader, model, batch_size, device, student_only=False):
                                   "model %s cannot be evaluated by the reference either" % type(model).__name__)
     return EvalGraph(batch_size, every_n=FLAGS.every_n, student_only=student_only, feature_size=sum(reader.feature_sizes),
                      vocab_size=reader.num_classes, max_frames=FLAGS.max_num_frames, num_inputs_to_lstm=FLAGS.num_inputs_to_lstm,
-                     lstm_cells=FLAGS.lstm_cells, lstm_layers=FLAGS.lstm_layers, num_mixtures=FLAGS.moe_num_mixtures, device=device)
+                     lstm_cells=FLAGS.lstm_cells, lstm_layers=FLAGS.lstm_layers, num_mixtures=FLAGS.moe_num_mixtures, device=device,
+                     precision=FLAGS.precision)
 
 
 def _batches(reader, device):

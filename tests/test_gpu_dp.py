@@ -137,3 +137,73 @@ def test_train_main_two_ranks(tmp_path):
     assert sd["global_step"] == 6
     assert all(torch.isfinite(v).all() for v in sd.values() if torch.is_tensor(v))
     assert "training step 6" in logs[0] and "Teacher_Loss" in logs[0]
+
+
+DBOF_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch
+from oracle import model_math as mm
+from efficientvideoclassification_youtube8m_amd.distill import SingleTowerGraph
+from efficientvideoclassification_youtube8m_amd.towers import DbofTower
+rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+torch.cuda.set_device(0)
+if world > 1:
+    torch.distributed.init_process_group("gloo", init_method="tcp://127.0.0.1:" + port, rank=rank, world_size=world)
+GB, F, V, S = 16, 128, 60, 10
+q, x, n, labels = mm.synthetic_batch(GB, seed=8, feature_size=F, vocab_size=V, dtype=np.float32)
+u = np.random.default_rng(1).random((GB, S)).astype(np.float32)
+b = GB // world
+sl = slice(rank * b, (rank + 1) * b)
+tw = DbofTower(b, 300, F, V, iterations=S, cluster_size=256, hidden_size=64, device="cuda:0", seed=3)
+rng = np.random.default_rng(4)
+for k in tw.names:                                   # non-trivial BN scale / offset so that their gradients matter
+    if k.endswith("/gamma") or k.endswith("/beta"):
+        tw.store.p(k).add_(torch.from_numpy(rng.standard_normal(tw.store.p(k).shape).astype(np.float32) * 0.2).cuda())
+g = SingleTowerGraph(tw, base_learning_rate=1e-2)
+xd = torch.from_numpy(x[sl]).cuda(); nd = torch.from_numpy(n[sl]).cuda(); yd = torch.from_numpy(labels[sl].astype(np.uint8)).cuda()
+ud = torch.from_numpy(u[sl]).cuda()
+g.step(xd, yd, nd, uniform=ud, apply=False)
+grads = {k: tw.store.g(k).clone().cpu() for k in tw.names}
+for it in range(2):
+    g.step(xd, yd, nd, uniform=ud)
+torch.cuda.synchronize()
+if rank == 0:
+    sd = {k: v.cpu() for k, v in tw.state_dict().items()}
+    torch.save({"sd": sd, "grads": grads, "global_step": g.global_step}, out)
+if world > 1:
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+'''
+
+
+def test_dbof_two_ranks_match_single_process(tmp_path):
+    """DbofTower under data parallelism (SyncBN partial sums all-reduced, gradient all-reduce WITHOUT the batch-norm
+    scale/offset segments, which are already global): gradients after one step and weights after two more equal the
+    single-process run on the whole batch.  (A second all-reduce of dgamma/dbeta would double them: their per-tensor
+    clipped Adam step would still look similar, so the gradients themselves are compared.)"""
+    outs = []
+    for world, port in ((1, 29641), (2, 29642)):
+        out = str(tmp_path / ("w%d.pt" % world))
+        code = DBOF_WORKER % {"root": ROOT}
+        procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(world), str(port), out], stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT) for r in range(world)]
+        logs = []
+        for p in procs:
+            try:
+                o, _ = p.communicate(timeout=300)
+            except subprocess.TimeoutExpired:
+                for pp in procs:
+                    pp.kill()
+                raise
+            logs.append(o.decode()[-2000:])
+        assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+        outs.append(torch.load(out))
+    a, b = outs
+    assert a["global_step"] == b["global_step"] == 2
+    for k, ga in a["grads"].items():
+        gb = b["grads"][k]
+        scale = ga.abs().max().item() + 1e-12
+        assert (ga - gb).abs().max().item() < 2e-2 * scale + 1e-7, (k, (ga - gb).abs().max().item(), scale)
+    for k, v in a["sd"].items():
+        assert (v - b["sd"][k]).abs().max().item() < 2e-3, (k, (v - b["sd"][k]).abs().max().item())

@@ -252,6 +252,15 @@ def test_l2norm_chunk_and_counts(ops):
         rl1, rl2 = mm.hlstm_chunk_lengths(ref_n, C, Lc)
         assert np.array_equal(l1.cpu().numpy().reshape(C, 301), rl1.T)
         assert np.array_equal(l2.cpu().numpy(), rl2)
+    # the student input at every_n = 1 (the reference's default) still goes through float64 (n/300)*300: n-1 for some n
+    nn = torch.arange(0, 301, dtype=torch.int32, device=DEV)
+    n_used, l1, l2 = ops.frame_counts(nn, 1, 5, 60, subsampled=True)
+    ref_n = mm.student_num_frames(np.arange(301), 1)
+    assert (ref_n != np.arange(301)).sum() == 12 and ref_n[55] == 54
+    assert np.array_equal(n_used.cpu().numpy(), ref_n)
+    assert np.array_equal(ops.host_frame_counts(np.arange(301), 1, 5, 60, subsampled=True)[0], ref_n)
+    rl1, rl2 = mm.hlstm_chunk_lengths(ref_n, 5, 60)
+    assert np.array_equal(l1.cpu().numpy().reshape(5, 301), rl1.T) and np.array_equal(l2.cpu().numpy(), rl2)
 
 
 @pytest.mark.parametrize("R,C,S", [(48, 70, 8), (1920, 256, 30)])

@@ -137,6 +137,86 @@ def test_high_precision_mode_after_training_steps():
     assert errs["high"][0] < errs["bf16"][0]
 
 
+def _trained_magnitude_weights(B, x, n, labels, lr=2e-3, max_steps=16, state_target=2.0, logit_target=8.0):
+    """Weights of trained magnitude: Adam iterations on the GPU (plain bf16 training) until the recurrent states have
+    left the +-0.05 range of the reference's initialisation (|state| > state_target) or the MoE gate logits have
+    grown past logit_target.  Returns the TF-named state dict of both towers."""
+    from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
+    g = DistillGraph(B, every_n=10, device=DEV, seed=3, base_learning_rate=lr)
+    xd, yd, nd = (torch.from_numpy(x).to(DEV), torch.from_numpy(labels.astype(np.uint8)).to(DEV), torch.from_numpy(n).to(DEV))
+    for it in range(max_steps):
+        out = g.step(xd, yd, nd, num_frames_host=n)
+        s_max = max(float(out["teacher_state"].abs().max()), float(out["student_state"].abs().max()))
+        z_max = max(float(g.teacher.moe.gate_logits.abs().max()), float(g.student.moe.gate_logits.abs().max()))
+        if s_max > state_target or z_max > logit_target:
+            break
+    print("trained-magnitude weights after %d Adam steps at lr %g: |state| %.2f |gate logit| %.2f" % (it + 1, lr, s_max, z_max))
+    sd = {}
+    sd.update(g.teacher.state_dict())
+    sd.update(g.student.state_dict())
+    torch.cuda.synchronize()
+    del g
+    torch.cuda.empty_cache()
+    return sd
+
+
+def test_real_dims_trained_magnitude_weights_both_precision_modes():
+    """The north-star tolerance (1e-3 on the logits, absolute) at the REAL model size on weights of trained magnitude,
+    in both forward modes, against the float64 oracle on the same weights and inputs:
+
+    * "high" (split-bf16 operands, 3 MFMA products per contraction; bench.py times it as `precision_modes.high`)
+      must hold 1e-3 on the gate logits, the expert logits, the states and the predictions of both towers;
+    * "bf16" (one MFMA product: the mode of bench.py's headline figure, which north_star prescribes) is bounded
+      RELATIVE to the logit magnitude: 2^-9 operand rounding over a K=4096..5120 contraction gives ~1e-3 * |z|, i.e.
+      it meets the absolute 1e-3 only while |logits| <~ 1 (the reference's initialisation: 5e-5) - asserted here
+      as 4e-3 * max(1, |z|_max) so that a regression shows, and printed."""
+    from efficientvideoclassification_youtube8m_amd import smoke
+    from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
+    B = 4
+    q, x, n, labels = mm.synthetic_batch(B, seed=91, dtype=np.float32)
+    n[0] = 300
+    x[np.arange(300)[None, :] >= n[:, None]] = 0.0
+    sd = _trained_magnitude_weights(B, x, n, labels)
+    params = {sc: {k[len(sc) + 1:]: v.double().cpu().numpy() for k, v in sd.items() if k.startswith(sc + "/")}
+              for sc in ("model", "model_student")}
+    ref = mm.teacher_student_step(x.astype(np.float64), n, labels, params["model"], params["model_student"], 10, with_grads=False)
+    ref_logits = {}
+    for sc, st in (("model", ref["teacher_state"]), ("model_student", ref["student_state"])):
+        ref_logits[sc] = (st @ params[sc]["classifier/gates/weights"],
+                          st @ params[sc]["classifier/experts/weights"] + params[sc]["classifier/experts/biases"])
+    zmax = max(float(np.abs(a).max()) for pair in ref_logits.values() for a in pair)
+    smax = max(float(np.abs(ref[k]).max()) for k in ("teacher_state", "student_state"))
+    print("trained-magnitude weights: |logit| max %.2f, |state| max %.2f" % (zmax, smax))
+    assert zmax > 1.0 and smax > 0.3, "the weights did not leave the initialisation regime"
+    xd, yd, nd = (torch.from_numpy(x).to(DEV), torch.from_numpy(labels.astype(np.uint8)).to(DEV), torch.from_numpy(n).to(DEV))
+    errs = {}
+    for prec in ("bf16", "high"):
+        g = DistillGraph(B, every_n=10, device=DEV, seed=3, precision=prec)
+        g.teacher.load_state_dict(sd)
+        g.student.load_state_dict(sd)
+        out = g.step(xd, yd, nd, apply=False, num_frames_host=n)
+        e = {}
+        for name, tw, sc, kp, ks in (("teacher", g.teacher, "model", "predictions", "teacher_state"),
+                                     ("student", g.student, "model_student", "student_predictions", "student_state")):
+            rp = ref["teacher_predictions" if name == "teacher" else "student_predictions"]
+            rs = ref[ks]
+            e[name + "_pred"] = float(np.abs(out[kp].cpu().numpy() - rp).max())
+            e[name + "_state"] = float(np.abs(out[ks].cpu().numpy() - rs).max())
+            e[name + "_gate_logits"] = float(np.abs(tw.moe.gate_logits.cpu().numpy() - ref_logits[sc][0]).max())
+            e[name + "_expert_logits"] = float(np.abs(tw.moe.expert_logits.cpu().numpy() - ref_logits[sc][1]).max())
+        errs[prec] = e
+        print("precision %-4s:" % prec, {k: "%.2e" % v for k, v in e.items()})
+        del g
+        torch.cuda.empty_cache()
+    for k, v in errs["high"].items():
+        assert v < 1e-3, ("high", k, v)
+    for k, v in errs["bf16"].items():
+        bound = 4e-3 * max(1.0, zmax if "logits" in k else (smax if "state" in k else 1.0))
+        bound = max(bound, 1e-2) if "state" in k else bound          # (cell states integrate the per-step rounding)
+        assert v < bound, ("bf16", k, v, bound)
+    assert all(errs["high"][k] < errs["bf16"][k] for k in errs["high"])
+
+
 @pytest.mark.parametrize("frames", [[1, 14, 15, 16, 150, 299, 300], [300], [1], [0, 300, 0, 7], [300] * 8, [3] * 8])
 def test_extreme_frame_counts_with_row_plans(frames):
     """Row plans at the edges: single video, every row alive, almost every row dead, zero-length videos."""

@@ -52,8 +52,10 @@ def test_train_validate_convert_finetune_eval(tmp_path):
 
     # ---- validate.py: teacher + student restored, student metrics + L_REP ----
     FLAGS.reset()
+    # (--precision high: split-bf16 operands in the evaluation forward, so that the predictions on these TRAINED weights
+    # hold the north-star 1e-3 against the float64 oracle; plain bf16 gives ~8e-3 here, see DESIGN.md "Precision")
     info = validate.main(COMMON + ["--eval_data_pattern", str(data / "validate*.tfrecord"), "--train_dir", tdir, "--batch_size", "5",
-                                   "--top_k", "20", "--run_once", "True"])
+                                   "--top_k", "20", "--run_once", "True", "--precision", "high"])
     assert info["epoch_id"] == 12
     sd = torch.load(train.latest_checkpoint(tdir))
     pred, y, (t_state, s_state) = _oracle_eval(val_files, sd, False)
@@ -62,7 +64,31 @@ def test_train_validate_convert_finetune_eval(tmp_path):
         ev.accumulate(pred[s:s + 5], y[s:s + 5], mm.cross_entropy_loss(pred[s:s + 5], y[s:s + 5]))
     want = ev.get()
     assert abs(info["avg_loss"] - want["avg_loss"]) < 1e-3 * want["avg_loss"]
-    assert abs(info["gap"] - want["gap"]) < 2e-2 and abs(info["avg_hit_at_one"] - want["avg_hit_at_one"]) < 0.15
+    # The metrics are split in two exact halves.  (1) the harness: validate.py's numbers must equal the oracle's
+    # EvaluationMetrics fed with the SAME predictions the GPU produced (same checkpoint, same records, same batches of
+    # 5, 5, 4 through the product's reader and EvalGraph).  (2) the predictions themselves against the float64 oracle.
+    from efficientvideoclassification_youtube8m_amd.distill import EvalGraph
+    eg = EvalGraph(5, every_n=10, feature_size=128, lstm_cells=64, device="cuda:0", precision="high")
+    eg.restore({k: v for k, v in sd.items() if torch.is_tensor(v)})
+    rd = readers.YT8MFrameFeatureReader(feature_names=["rgb", "audio"], feature_sizes=[64, 64], max_frames=300)
+    all_ids = [i[0] for i, *_ in rd.prepare_reader(val_files)]                     # the order _oracle_eval's rows are in
+    ev2, worst = om.EvaluationMetrics(4716, 20), 0.0
+    # (num_readers=2 as in COMMON: the two files are read round-robin, so the batches interleave them - the same
+    # deterministic composition validate.main saw; rows are matched to the oracle's through the video ids)
+    for ids, qd, yd, nd, nh in readers.get_input_evaluation_tensors(rd, str(data / "validate*.tfrecord"), 5, 2, device="cuda:0",
+                                                                    with_host_counts=True):
+        p = eg.step(qd, yd, nd, num_frames_host=nh)["predictions"].double().cpu().numpy()
+        rows = [all_ids.index(i) for i in ids]
+        worst = max(worst, float(np.abs(p - pred[rows]).max()))
+        yb = yd.double().cpu().numpy()
+        assert np.array_equal(yb, y[rows])
+        ev2.accumulate(p, yb, mm.cross_entropy_loss(p, yb))
+    print("validate predictions vs float64 oracle (high precision mode): %.2e" % worst)
+    assert worst < 1e-3                                                            # (2)
+    same = ev2.get()
+    assert abs(info["gap"] - same["gap"]) < 1e-3 and info["avg_hit_at_one"] == same["avg_hit_at_one"]       # (1)
+    assert abs(info["avg_perr"] - same["avg_perr"]) < 1e-3 and abs(info["avg_loss"] - same["avg_loss"]) < 1e-5 * same["avg_loss"]
+    FLAGS.reset()
     events = open(tdir + "events.jsonl").read()
     assert "Epoch/Eval_GAP" in events and "GlobalStep/Eval_Loss" in events
 
