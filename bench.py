@@ -10,6 +10,15 @@ One "step" = one full training iteration of cs/train.py:516-517 (teacher
 fwd+bwd+update and student fwd+bwd+update) on one batch of B=256 videos x 300
 frames x 1152 features PER GPU (weak scaling).  Inputs are resident in HBM when
 the timed region starts.  Rank 0 prints ONE JSON line.
+
+The headline (`value`, `ms_per_step`, `roofline`) is BASELINE cfg 3 in plain bf16 (one MFMA product per
+contraction, as north_star prescribes).  At N=1 the same line also carries, each timed the same way on a short run:
+  precision_modes   the same step in the split-bf16 "high" forward mode (the mode that holds the 1e-3 logit
+                    tolerance on trained-magnitude weights, tests/test_gpu_step.py) next to the bf16 figure;
+  other_configs     BASELINE cfg 2 (teacher only), cfg 5 (student only, every_n=30, B=1024), cfg 4 (DBoF + MoE,
+                    B=512, with the roofline of its cluster GEMM) and the all-300-frames worst case;
+  cpu_baseline      the PyTorch-CPU float32 restatement of the reference graph (oracle/torch_cpu.py) on the host cores.
+`--config dbof` makes cfg 4 the timed workload of the line instead (its own metric string).
 """
 import argparse
 import json
@@ -25,6 +34,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+T_FRAMES, F_FEAT, V_CLS, H_CELLS = 300, 1152, 4716, 1024
 
 
 def synthetic_inputs(B, T, F, V, seed, device, all_full):
@@ -46,35 +56,247 @@ def synthetic_inputs(B, T, F, V, seed, device, all_full):
     return x.contiguous(), n, labels
 
 
-def cpu_baseline(every_n, sample_videos=8):
-    """The oracle (numpy port of the reference graph, float32, BLAS threads = host
-    cores) timed on a bounded sample of the same workload: one full training
-    iteration (fwd + bwd of both towers + clip/Adam) on `sample_videos` videos."""
-    from oracle import model_math as mm
+# ---------------------------------------------------------------------------------------------------------------
+# GEMM FLOPs of one H-LSTM training iteration: nominal (every video counted at 300 frames,
+# train = 3 x forward) and executed (what the launches of this batch actually contract over: the length-sorted L1
+# stacks skip the padding rows - ops.RowPlan - and the hoisted backward products run on P = live rows)
+# ---------------------------------------------------------------------------------------------------------------
+def hlstm_gflop(n_host, mode, every_n, B, row_plans=True):
+    from efficientvideoclassification_youtube8m_amd import ops
+    H, F, V, K2 = H_CELLS, F_FEAT, V_CLS, 4 * H_CELLS
+    nominal = executed = 0.0
+    towers = []
+    if mode != "student":
+        towers.append((1, 20, 15, False))
+    if mode != "teacher":
+        S = 300 // every_n
+        towers.append((every_n, 5, S // 5, True))
+    for ev, C, Lc, sub in towers:
+        _, l1, _ = ops.host_frame_counts(n_host, ev, C, Lc, 300, subsampled=sub)
+        M = C * B
+        rows = [int((l1 > t).sum()) for t in range(Lc)] if row_plans else [M] * Lc
+        P = min(M, max(32, (rows[0] + 31) // 32 * 32)) if row_plans else M
+        fwd_l1 = sum(2.0 * r * 4 * H * ((F + H) + (H if t > 0 else 0) + (H if t > 0 else 0)) for t, r in enumerate(rows))
+        bptt_l1 = sum(2.0 * r * H * 4 * H * 2 for t, r in enumerate(rows) if t < Lc - 1)        # dh = dz . Wh^T, both layers
+        hoisted_l1 = 2.0 * Lc * P * 4 * H * (H + (F + H) + 2 * H)                                 # dX of layer 1 + both dW
+        fwd_l2 = C * 2.0 * B * 4 * H * ((K2 + H) + 2 * H)
+        bwd_l2 = 2.0 * fwd_l2
+        moe = 2.0 * B * K2 * V * 5
+        executed += fwd_l1 + bptt_l1 + hoisted_l1 + fwd_l2 + bwd_l2 + moe * 4                    # fwd, dx, fused update: 2 passes
+        per_video = Lc * C * 2.0 * 4 * H * (F + 3 * H) + C * 2.0 * 4 * H * (K2 + 3 * H) + 2.0 * K2 * V * 5
+        nominal += 3.0 * B * per_video
+    return nominal / 1e9, executed / 1e9
+
+
+def run_hlstm(device, rank, world, B, mode, every_n, steps, warmup, all_full=False, precision="bf16", pool=8,
+              overlap=True, fused_moe=True, student_forward_early=False, roofline=False):
+    """Times `steps` training iterations of one DistillGraph configuration (after `warmup`), inputs resident in HBM.
+    Returns a dict; with roofline=True also the live timing of the teacher's L1 forward step launches."""
+    from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
+    pool_in = [synthetic_inputs(B, T_FRAMES, F_FEAT, V_CLS, 1234 + rank + 1000 * i, device, all_full) for i in range(pool)]
+    # the frame counts also live on the host, as an input pipeline has them before the H2D copy (the launch
+    # geometry of the length-sorted L1 stacks is derived from them, see ops.RowPlan)
+    n_host = [p[1].cpu().numpy() for p in pool_in]
+    graph = DistillGraph(B, every_n=every_n, mode=mode, device=device, seed=7, overlap_towers=overlap, precision=precision)
+    graph.student_forward_early = student_forward_early
+    if not fused_moe:
+        for tw in (graph.teacher, graph.student):
+            if tw is not None:
+                tw.fused_moe_update = False
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    it = 0
+    for _ in range(warmup):
+        x, n, labels = pool_in[it % pool]
+        graph.step(x, labels, n, num_frames_host=n_host[it % pool])
+        it += 1
+    barrier()
+    l1_stack = (graph.teacher if graph.teacher is not None else graph.student).l1
+    if roofline:
+        l1_stack.timing = []      # HIP events around the L1 forward launch sequences of the timed steps (launch stream)
+    gf = [hlstm_gflop(n_host[(it + i) % pool], mode, every_n, B) for i in range(steps)]
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        x, n, labels = pool_in[it % pool]
+        graph.step(x, labels, n, num_frames_host=n_host[it % pool])
+        it += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    res = {"ms_per_step": dt / steps * 1e3, "frames_per_sec": world * B * T_FRAMES * steps / dt, "steps": steps,
+           "warmup": warmup, "batch_per_gpu": B,
+           "nominal_tflop_per_step": round(float(np.mean([g[0] for g in gf])) / 1e3, 3),
+           "executed_tflop_per_step": round(float(np.mean([g[1] for g in gf])) / 1e3, 3),
+           "losses": {k: round(v, 4) for k, v in graph.loss_report().items()}}
+    res["executed_tflops"] = round(res["executed_tflop_per_step"] / (res["ms_per_step"] * 1e-3), 1)
+    if roofline:
+        # lstm_fwd_step_kernel<TileCfg2<BM,4,64,..>> (30 launches per iteration, the largest FLOP share of the
+        # recurrent path).  Live timing with HIP events on the launch stream around each layer's 15-step launch
+        # sequence in every timed step; algorithmic FLOPs = 2*rows_t*4H*K of each step GEMM over the rows that
+        # step runs on (DESIGN.md 4.3).
+        tower = graph.teacher if graph.teacher is not None else graph.student
+        timing, l1_stack.timing = l1_stack.timing, None
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in timing)          # over the timed region, as the kernel ran there
+        launches = sum(nl for _, _, nl, _ in timing)
+        flops = sum(fl for _, _, _, fl in timing)
+        ms_i = launches_i = flops_i = 0.0                                 # the same launch sequences alone on the chip
+        for (m, nl, fl) in tower.l1.profile_fwd_layers(reps=3):
+            ms_i, launches_i, flops_i = ms_i + m, launches_i + nl, flops_i + fl
+        traffic = mfma_busy = None
+        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):    # HBM bytes / MFMA busy from the committed --pmc passes
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    pmc = json.load(f)
+                traffic = pmc["hbm_bytes_per_launch"]
+                mfma_busy = round(pmc["mfma"]["mfma_busy_fraction"], 4)
+                break
+            except Exception:
+                pass
+        achieved = flops / (ms * 1e-3) / 1e12
+        res["roofline"] = {
+            "bound": "mfma", "kernel": "lstm_fwd_step_kernel<TileCfg2<BM,4,64,2,4,..>> (teacher L1; BM = 224..320 per launch from the "
+                                       "active rows)" if graph.teacher is not None else "lstm_fwd_step_kernel (student L1)",
+            "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+            "traffic": traffic, "mfma_busy_pmc": mfma_busy, "avg_launch_ms": round(ms / launches, 4),
+            "launches_per_step": int(round(launches / max(1, steps))), "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 2),
+            "isolated": {"achieved": round(flops_i / (ms_i * 1e-3) / 1e12, 2), "avg_launch_ms": round(ms_i / launches_i, 4),
+                         "note": "same launch sequences re-run alone after the timed loop (no other stream active)"}}
+    # GAP@20 (cs/eval_util.py:61-79) of the last step's predictions, outside the timed regions: the second half of
+    # BASELINE's metric name; on synthetic labels it only shows that the metric path runs on the step's outputs.
+    from efficientvideoclassification_youtube8m_amd import eval_util
+    gap_tower = graph.student if graph.student is not None else graph.teacher
+    last_labels = pool_in[(it - 1) % pool][2]
+    res["gap_at_20_last_batch"] = round(float(eval_util.calculate_gap(gap_tower.pred.float().cpu().numpy(),
+                                                                      last_labels.float().cpu().numpy(), top_k=20)), 6)
+    del graph, pool_in
+    torch.cuda.empty_cache()
+    return res
+
+
+def run_dbof(device, rank, world, B, steps, warmup, pool=4):
+    """BASELINE cfg 4: DbofModel (cluster 8192, hidden 1024, 30 sampled frames) + MoE(2), one training step per
+    batch of B videos (cs/frame_level_models.py:108-195).  uint8 inputs resident in HBM."""
+    from efficientvideoclassification_youtube8m_amd.distill import SingleTowerGraph
+    from efficientvideoclassification_youtube8m_amd.towers import DbofTower
+    g = torch.Generator(device=device)
+    g.manual_seed(99 + rank)
+    pool_in = []
+    for i in range(pool):
+        x, n, labels = synthetic_inputs(B, T_FRAMES, F_FEAT, V_CLS, 1234 + rank + 1000 * i, device, False)
+        pool_in.append((x, n, labels, torch.rand((B, 30), generator=g, device=device)))
+    pg = None
+    tw = DbofTower(B, T_FRAMES, F_FEAT, V_CLS, 30, 8192, 1024, 2, device=device, process_group=pg)
+    graph = SingleTowerGraph(tw)
+    for i in range(warmup):
+        x, n, labels, u = pool_in[i % pool]
+        graph.step(x, labels, n, uniform=u)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    if hasattr(tw, "timing"):
+        tw.timing = []
+    t0 = time.perf_counter()
+    for i in range(steps):
+        x, n, labels, u = pool_in[(warmup + i) % pool]
+        graph.step(x, labels, n, uniform=u)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    gflop_fwd = (2.0 * B * 30 * F_FEAT * 8192 + 2.0 * B * 8192 * 1024 + 2.0 * B * 1024 * V_CLS * 5) / 1e9
+    res = {"ms_per_step": dt / steps * 1e3, "videos_per_sec": world * B * steps / dt,
+           "frames_per_sec": world * B * T_FRAMES * steps / dt, "steps": steps, "warmup": warmup, "batch_per_gpu": B,
+           "nominal_tflop_per_step": round(3 * gflop_fwd / 1e3, 4), "loss": round(float(graph.losses[0]), 4)}
+    res["nominal_tflops"] = round(res["nominal_tflop_per_step"] / (res["ms_per_step"] * 1e-3), 1)
+    timing = getattr(tw, "timing", None)
+    if timing:
+        ms = sum(e0.elapsed_time(e1) for e0, e1 in timing) / len(timing)
+        flops = 2.0 * B * 30 * F_FEAT * 8192
+        ach = flops / (ms * 1e-3) / 1e12
+        res["roofline"] = {"bound": "mfma", "kernel": "dbof_cluster_pool_kernel (cluster GEMM + BN statistics + per-video max/min)",
+                           "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                           "traffic": None, "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(flops / 1e9, 2)}
+    del graph, tw, pool_in
+    torch.cuda.empty_cache()
+    return res
+
+
+def host_cores():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU boxes show 256
+    logical CPUs but run under a 16-CPU quota: 256 BLAS threads on 16 CPUs' worth of time spin in their barriers)."""
+    cores = os.cpu_count() or 1
     try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        cores = len(os.sched_getaffinity(0))
     except Exception:
-        cores = os.cpu_count() or 1
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                       # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:     # cgroup v1
+                quota = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if quota > 0:
+                cores = min(cores, max(1, quota // period))
+        except Exception:
+            pass
+    return cores
+
+
+def cpu_baseline(every_n, batch=64, budget_s=50.0):
+    """the reference graph restated on PyTorch-CPU float32 (oracle/torch_cpu.py: one dynamic_rnn
+    per chunk, autograd BPTT, per-tensor clip, TF-Adam), all host cores, on a BOUNDED sample of the headline workload:
+    `batch` synthetic videos x 300 x 1152 per iteration (B >= 64 so that the BLAS sees a real M), one warm-up
+    iteration + up to three timed ones inside `budget_s` seconds."""
+    from oracle import model_math as mm
+    from oracle import torch_cpu as tc
+    cores = host_cores()
+    torch.set_num_threads(cores)
     rng = np.random.default_rng(7)
-    dt = np.float32
-    teacher = mm.init_hlstm_params(rng, dtype=dt)
-    student = mm.init_hlstm_params(rng, dtype=dt)
-    _, x, n, labels = mm.synthetic_batch(sample_videos, seed=1234, dtype=dt)
-    t0 = time.perf_counter()
-    out = mm.teacher_student_step(x, n, labels, teacher, student, every_n)
-    t_fb = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    mm.apply_train_op(teacher, out["teacher_grads"], {}, 1, 1e-3, 1.0)
-    mm.apply_train_op(student, out["student_grads"], {}, 1, 1e-3, 1.0)
-    t_opt = time.perf_counter() - t0
-    dtm = t_fb + t_opt
-    return {"value": sample_videos * 300 / dtm, "unit": "frames/sec", "cores": int(cores), "kind": "port",
-            "extrapolated_b256": 256 * 300 / (t_fb * 256 / sample_videos + t_opt),
-            "sample": "1 full teacher+student training iteration (float32 numpy/OpenBLAS oracle) on %d synthetic "
-                      "videos x 300 x 1152: fwd+bwd %.1f s (scales with batch) + clip/Adam of 2x143M params %.1f s "
-                      "(fixed per step); extrapolated_b256 = 76800/(fwd+bwd*256/%d + Adam)"
-                      % (sample_videos, t_fb, t_opt, sample_videos)}
+    teacher = tc.to_torch(mm.init_hlstm_params(rng, dtype=np.float32))
+    student = tc.to_torch(mm.init_hlstm_params(rng, dtype=np.float32))
+    _, x, n, labels = mm.synthetic_batch(batch, seed=1234, dtype=np.float32)
+    xt, yt = torch.from_numpy(x), torch.from_numpy(labels.astype(np.float32))
+    opt_t, opt_s = tc.Adam(teacher), tc.Adam(student)
+    t_start = time.perf_counter()
+    tc.teacher_student_iteration(xt, n, yt, teacher, student, every_n, opt_t, opt_s)         # warm-up
+    warm = time.perf_counter() - t_start
+    times = []
+    while len(times) < 3 and (not times or time.perf_counter() - t_start + np.mean(times) < budget_s):
+        t0 = time.perf_counter()
+        tc.teacher_student_iteration(xt, n, yt, teacher, student, every_n, opt_t, opt_s)
+        times.append(time.perf_counter() - t0)
+    dtm = float(np.mean(times))
+    return {"value": batch * 300 / dtm, "unit": "frames/sec", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": "%d timed full teacher+student training iterations (after 1 warm-up of %.1f s) of the PyTorch-CPU float32 "
+                      "restatement of the reference graph (oracle/torch_cpu.py: 20+1 / 5+1 dynamic_rnn loops at batch B, autograd, "
+                      "per-tensor clip, TF-Adam of 2x143M parameters) on %d synthetic videos x 300 x 1152, %.2f s per iteration"
+                      % (len(times), warm, batch, dtm),
+            "batch": batch, "iterations_timed": len(times), "sec_per_iteration": round(dtm, 3)}
+
+
+def _log(msg):
+    if os.environ.get("EVC_BENCH_VERBOSE") == "1":
+        sys.stderr.write("[bench %.1fs] %s\n" % (time.perf_counter() - _T0, msg))
+        sys.stderr.flush()
+
+
+_T0 = time.perf_counter()
 
 
 def main():
@@ -82,12 +304,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="videos per GPU")
+    ap.add_argument("--config", default="hlstm", choices=["hlstm", "dbof"], help="hlstm: BASELINE cfg 3 (the metric); dbof: cfg 4")
+    ap.add_argument("--batch", type=int, default=None, help="videos per GPU (default 256; 512 for --config dbof)")
     ap.add_argument("--every_n", type=int, default=10)
     ap.add_argument("--mode", default="teacher_student", choices=["teacher_student", "teacher", "student"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "high"])
     ap.add_argument("--all_full", action="store_true", help="every video has 300 frames (no padding)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--cpu_videos", type=int, default=8)
+    ap.add_argument("--no_secondary", action="store_true", help="skip the precision_modes / other_configs runs (N=1 only anyway)")
+    ap.add_argument("--cpu_videos", type=int, default=64)
     ap.add_argument("--no_fused_moe", action="store_true", help="debug: materialise the MoE weight gradients (A/B of evc_moe_grad_update)")
     ap.add_argument("--student_forward_early", action="store_true", help="A/B: student forward next to the teacher forward")
     ap.add_argument("--no_overlap", action="store_true", help="debug: everything on one stream (solo kernel times for profiling)")
@@ -105,6 +330,7 @@ def main():
     # on a one-rank RCCL communicator
     one_rank_dp = world == 1 and os.environ.get("EVC_DP_FORCE") == "1" and "MASTER_PORT" in os.environ
     if world > 1 or one_rank_dp:
+        # the process group comes first: nothing has touched the GPU yet (and nothing below ever re-executes this process)
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if os.environ.get("EVC_BENCH_SHARED_GPU") == "1":
@@ -116,104 +342,74 @@ def main():
     torch.cuda.set_device(local_rank)
 
     from efficientvideoclassification_youtube8m_amd import ops
-    from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
-
     ops.check_device(local_rank)
-    B, T, F, V = args.batch, 300, 1152, 4716
-    # a pool of distinct synthetic batches, all resident in HBM before the timed region
-    pool = [synthetic_inputs(B, T, F, V, 1234 + rank + 1000 * i, device, args.all_full) for i in range(args.pool)]
-    # the frame counts also live on the host, as an input pipeline has them before the H2D copy (the launch
-    # geometry of the length-sorted L1 stacks is derived from them, see ops.RowPlan)
-    n_host = [p[1].cpu().numpy() for p in pool]
-    graph = DistillGraph(B, every_n=args.every_n, mode=args.mode, device=device, seed=7, overlap_towers=not args.no_overlap)
-    graph.student_forward_early = args.student_forward_early
-    if args.no_fused_moe:
-        for tw in (graph.teacher, graph.student):
-            if tw is not None:
-                tw.fused_moe_update = False
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
+    if args.config == "dbof":
+        B = args.batch or 512
+        r = run_dbof(device, rank, world, B, args.steps, args.warmup)
+        if rank == 0:
+            res = {"metric": "frames/sec (whole node) DBoF(8192,1024)+MoE(2) training step B=512x300x1152 (BASELINE cfg 4)",
+                   "value": r["frames_per_sec"], "unit": "frames/sec", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+                   "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                   "dtype": "bf16", "data": "synthetic",
+                   "config": {"workload": "DbofModel cluster 8192, hidden 1024, 30 sampled frames, MoE(2), batch %d x 300 x 1152 per GPU" % B,
+                              "global_batch": B * n_gpus, "frames_per_video": T_FRAMES, "parallelism": "dp%d" % n_gpus},
+                   "videos_per_sec": r["videos_per_sec"], "nominal_tflop_per_step": r["nominal_tflop_per_step"], "loss": r["loss"]}
+            if "roofline" in r:
+                res["roofline"] = r["roofline"]
+            print(json.dumps(res))
+        if world > 1 or one_rank_dp:
+            torch.distributed.destroy_process_group()
+        return
 
-    it = 0
-    for _ in range(args.warmup):
-        x, n, labels = pool[it % len(pool)]
-        graph.step(x, labels, n, num_frames_host=n_host[it % len(pool)])
-        it += 1
-    barrier()
-    l1_stack = (graph.teacher if graph.teacher is not None else graph.student).l1
-    l1_stack.timing = []          # HIP events around the L1 forward launch sequences of the timed steps (launch stream)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        x, n, labels = pool[it % len(pool)]
-        graph.step(x, labels, n, num_frames_host=n_host[it % len(pool)])
-        it += 1
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    losses = graph.loss_report()
-
-    # ---- roofline of the dominant kernel: the fused LSTM forward step of the teacher's L1 ---------
-    # lstm_fwd_step_kernel<TileCfg2<BM,4,64,..>> (30 launches per iteration, the largest FLOP share of the
-    # recurrent path).  Live timing with HIP events on the launch stream around each layer's 15-step launch
-    # sequence in every timed step; algorithmic FLOPs = 2*rows_t*4H*K of each step GEMM over the rows that
-    # step runs on.
-    tower = graph.teacher if graph.teacher is not None else graph.student
-    timing, l1_stack.timing = l1_stack.timing, None
-    ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in timing)              # over the timed region, as the kernel ran there
-    launches = sum(nl for _, _, nl, _ in timing)                          # (next to the student's forward on another stream)
-    flops = sum(fl for _, _, _, fl in timing)
-    avg_ms = ms / launches
-    achieved = flops / (ms * 1e-3) / 1e12
-    ms_i = launches_i = flops_i = 0.0                                     # the same launch sequences alone on the chip
-    for (m, nl, fl) in tower.l1.profile_fwd_layers(reps=3):
-        ms_i, launches_i, flops_i = ms_i + m, launches_i + nl, flops_i + fl
-    achieved_isolated = flops_i / (ms_i * 1e-3) / 1e12
-    traffic = mfma_busy = None
-    try:   # HBM bytes per launch / MFMA busy fraction from the committed rocprofv3 --pmc passes (profiles/)
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            pmc = json.load(f)
-        traffic = pmc["hbm_bytes_per_launch"]
-        mfma_busy = round(pmc["mfma"]["mfma_busy_fraction"], 4)
-    except Exception:
-        pass
-    # GAP@20 (cs/eval_util.py:61-79) of the last step's predictions, outside the timed regions (after the live kernel
-    # timing above, which must run on a busy chip: a host-side pause first lets the clocks drop): the second half
-    # of BASELINE's metric name; on synthetic labels it only shows that the metric path runs on the step's outputs.
-    from efficientvideoclassification_youtube8m_amd import eval_util
-    gap_tower = graph.student if graph.student is not None else graph.teacher
-    last_labels = pool[(it - 1) % len(pool)][2]
-    gap20 = float(eval_util.calculate_gap(gap_tower.pred.float().cpu().numpy(), last_labels.float().cpu().numpy(), top_k=20))
-    roofline = {"bound": "mfma", "kernel": "lstm_fwd_step_kernel<TileCfg2<BM,4,64,2,4,..>> (teacher L1; BM = 224..320 per launch from the active rows)"
-                if graph.teacher is not None else "lstm_fwd_step_kernel (student L1)", "achieved": round(achieved, 2),
-                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                "traffic": traffic, "mfma_busy_pmc": mfma_busy, "avg_launch_ms": round(avg_ms, 4),
-                "launches_per_step": int(round(launches / max(1, args.steps))),
-                "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 2),
-                "isolated": {"achieved": round(achieved_isolated, 2), "avg_launch_ms": round(ms_i / launches_i, 4),
-                             "note": "same launch sequences re-run alone after the timed loop (no other stream active)"}}
+    B = args.batch or 256
+    head = run_hlstm(device, rank, world, B, args.mode, args.every_n, args.steps, args.warmup, args.all_full, args.precision,
+                     args.pool, not args.no_overlap, not args.no_fused_moe, args.student_forward_early, roofline=True)
+    _log("headline done: %.2f ms/step" % head["ms_per_step"])
+    secondary = n_gpus == 1 and not args.no_secondary and not one_rank_dp
+    extra = {}
+    if secondary:
+        s_steps, s_warm = 5, 2
+        keep = ("ms_per_step", "frames_per_sec", "steps", "warmup", "batch_per_gpu", "nominal_tflop_per_step",
+                "executed_tflop_per_step", "executed_tflops")
+        pm = {args.precision: {k: head[k] for k in keep}}
+        other = "high" if args.precision == "bf16" else "bf16"
+        r = run_hlstm(device, rank, world, B, args.mode, args.every_n, s_steps, s_warm, args.all_full, other, 4)
+        pm[other] = {k: r[k] for k in keep}
+        _log("precision mode %s done: %.2f ms/step" % (other, r["ms_per_step"]))
+        pm["bf16"]["logits_within_1e-3_of_f64_oracle"] = "at the reference's initialisation (|logit| <~ 1); ~1e-3*|logit| on trained weights"
+        pm["high"]["logits_within_1e-3_of_f64_oracle"] = "also on trained-magnitude weights (tests/test_gpu_step.py)"
+        pm["high"]["what"] = "split-bf16 operands: hi.hi + hi.lo + lo.hi, 3 MFMA products per forward contraction; backward as in bf16"
+        extra["precision_modes"] = pm
+        oc = {}
+        for name, kw in (("cfg2_teacher_only_b256", dict(B=256, mode="teacher", every_n=10)),
+                         ("cfg5_student_only_every_n30_b1024", dict(B=1024, mode="student", every_n=30)),
+                         ("cfg3_all_300_frames_b256", dict(B=256, mode="teacher_student", every_n=10, all_full=True))):
+            r = run_hlstm(device, rank, world, kw["B"], kw["mode"], kw["every_n"], s_steps, s_warm, kw.get("all_full", False), "bf16", 4)
+            oc[name] = {k: r[k] for k in keep}
+            _log("%s done: %.2f ms/step" % (name, r["ms_per_step"]))
+        r = run_dbof(device, rank, world, 512, s_steps, s_warm)
+        oc["cfg4_dbof_8192_1024_moe2_b512"] = r
+        _log("dbof done: %.2f ms/step" % r["ms_per_step"])
+        extra["other_configs"] = oc
 
     if rank == 0:
-        frames = n_gpus * B * T * args.steps
         res = {
             "metric": "frames/sec (whole node) H-LSTM teacher+student B=256x300x1152; GAP@20",
-            "value": frames / dt, "unit": "frames/sec", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "value": head["frames_per_sec"], "unit": "frames/sec", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic", "precision_mode": args.precision,
             "config": {"workload": "HierarchicalLstmModel %s every_n=%d, lstm_cells=1024x2, MoE(2), batch %d x 300 x 1152 per GPU"
                                    % (args.mode, args.every_n, B),
-                       "global_batch": B * n_gpus, "frames_per_video": T, "parallelism": "dp%d" % n_gpus,
+                       "global_batch": B * n_gpus, "frames_per_video": T_FRAMES, "parallelism": "dp%d" % n_gpus,
                        "num_frames": "all 300" if args.all_full else "U{120..300}",
-                       "tflop_per_step_per_gpu": round(3 * B * ((11.748 if graph.teacher else 0) + (
-                           (1.525 if args.every_n == 10 else 0.833) if graph.student else 0)) / 1e3, 3)},
-            "losses": {k: round(v, 4) for k, v in losses.items()}, "gap_at_20_last_batch": round(gap20, 6),
-            "roofline": roofline,
+                       "tflop_per_step_per_gpu": head["nominal_tflop_per_step"],
+                       "executed_tflop_per_step_per_gpu": head["executed_tflop_per_step"]},
+            "executed_tflops_per_gpu": head["executed_tflops"],
+            "losses": head["losses"], "gap_at_20_last_batch": head["gap_at_20_last_batch"],
+            "roofline": head["roofline"],
         }
+        res.update(extra)
         if n_gpus == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.every_n, args.cpu_videos)
         print(json.dumps(res))

@@ -239,3 +239,42 @@ def test_dbof_and_logistic_grads_finite_difference():
     W = rng.standard_normal((F, V)); b = rng.standard_normal(V)
     p, avg = mm.logistic_fwd(x, n, W, b)
     assert np.allclose(avg, x.sum(1) / n[:, None])
+
+
+def test_torch_cpu_baseline_matches_the_float64_oracle():
+    """oracle/torch_cpu.py (the float32 PyTorch-CPU restatement bench.py times as `cpu_baseline`, structured like the
+    reference graph: one dynamic_rnn per chunk at batch B, autograd) against model_math (float64, chunks folded into
+    the batch, hand-written reverse mode): losses, gradients and one clip+Adam step."""
+    import torch
+    from oracle import torch_cpu as tc
+    rng = np.random.default_rng(3)
+    B, F, H, V, every_n = 5, 12, 8, 7, 10
+    teacher = mm.init_hlstm_params(rng, F, H, 2, V)
+    student = mm.init_hlstm_params(rng, F, H, 2, V)
+    for p in (teacher, student):                     # larger weights: states well away from zero
+        for k in p:
+            p[k] = p[k] * 3.0
+    x = rng.standard_normal((B, 300, F))
+    n = np.array([300, 181, 150, 31, 9])
+    x[np.arange(300)[None] >= n[:, None]] = 0
+    y = rng.random((B, V)) > 0.6
+    ref = mm.teacher_student_step(x, n, y, teacher, student, every_n)
+    tt, ts = tc.to_torch(teacher), tc.to_torch(student)
+    opt_t, opt_s = tc.Adam(tt), tc.Adam(ts)
+    out = tc.teacher_student_iteration(torch.tensor(x, dtype=torch.float32), n, torch.tensor(y, dtype=torch.float32), tt, ts,
+                                       every_n, opt_t, opt_s)
+    for k in ("label_loss", "student_label_loss", "student_loss_state", "pred_loss"):
+        assert abs(out[k] - ref[k]) <= 1e-5 * abs(ref[k]) + 1e-7, (k, out[k], float(ref[k]))
+    for got, want in ((out["teacher_grads"], ref["teacher_grads"]), (out["student_grads"], ref["student_grads"])):
+        for k in mm.HLSTM_PARAM_ORDER:
+            g = got[k].numpy()
+            assert np.abs(g - want[k]).max() <= 1e-4 * np.abs(want[k]).max() + 1e-7, k
+    new_t = mm.apply_train_op(teacher, ref["teacher_grads"], {}, 1, 1e-3, 1.0)
+    for k in mm.HLSTM_PARAM_ORDER:
+        assert np.abs(tt[k].detach().numpy() - new_t[k]).max() < 2e-5, k        # one Adam step moves each weight by ~1e-3
+    # the single-tower modes
+    o_t = tc.teacher_student_iteration(torch.tensor(x, dtype=torch.float32), n, torch.tensor(y, dtype=torch.float32), tt, ts,
+                                       every_n, mode="teacher")
+    o_s = tc.teacher_student_iteration(torch.tensor(x, dtype=torch.float32), n, torch.tensor(y, dtype=torch.float32), tt, ts,
+                                       30, mode="student")
+    assert "student_grads" not in o_t and "teacher_grads" not in o_s and np.isfinite(o_s["student_label_loss"])
