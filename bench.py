@@ -189,8 +189,9 @@ def run_dbof(device, rank, world, B, steps, warmup, pool=4):
     g.manual_seed(99 + rank)
     pool_in = []
     for i in range(pool):
-        x, n, labels = synthetic_inputs(B, T_FRAMES, F_FEAT, V_CLS, 1234 + rank + 1000 * i, device, False)
-        pool_in.append((x, n, labels, torch.rand((B, 30), generator=g, device=device)))
+        _, n, labels = synthetic_inputs(B, T_FRAMES, F_FEAT, V_CLS, 1234 + rank + 1000 * i, device, False)
+        q = torch.randint(0, 256, (B, T_FRAMES, F_FEAT), generator=g, device=device, dtype=torch.uint8)   # as the reader delivers it
+        pool_in.append((q, n, labels, torch.rand((B, 30), generator=g, device=device)))
     pg = None
     tw = DbofTower(B, T_FRAMES, F_FEAT, V_CLS, 30, 8192, 1024, 2, device=device, process_group=pg)
     graph = SingleTowerGraph(tw)

@@ -39,7 +39,7 @@ SIGNATURES = {
     "evc_rep_loss": [vp, vp, i32, i32, f32, vp, vp, i32, vp],
     "evc_grad_sqnorm": [vp, vp, f32, i64, vp, vp],
     "evc_clip_adam_step": [vp, vp, vp, vp, i64, f32, vp, f32, f32, f32, f32, f32, vp, vp],
-    "evc_meanpool_fwd": [vp, vp, i32, i32, i32, i32, vp, vp, vp],
+    "evc_meanpool_fwd": [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp],
     "evc_sigmoid_fwd": [vp, i64, vp],
     "evc_sigmoid_bwd": [vp, vp, i64, vp, vp],
     "evc_sample_frames_gather": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp],
@@ -55,6 +55,16 @@ SIGNATURES = {
     "evc_framepool_max_fwd": [vp, i32, i32, i32, vp, vp, vp, vp],
     "evc_framepool_max_bwd": [vp, vp, i32, i32, i32, vp, vp],
     "evc_fill_f32": [vp, i64, f32, vp],
+    "evc_dbof_workspace": [i32, i32, vp, vp, vp],
+    "evc_dbof_gather": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp],
+    "evc_bn_partials_reduce": [vp, i32, i32, vp, vp],
+    "evc_bn_finalize_ema": [vp, i32, i32, vp, vp, vp, vp, f32, vp],
+    "evc_dbof_input_bn_apply": [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
+    "evc_dbof_cluster_pool_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp],
+    "evc_dbof_pool_finish": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
+    "evc_dbof_dact": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp],
+    "evc_gemm_tn_slabs": [vp, i64, vp, i64, vp, i32, i32, i32, i32, vp],
+    "evc_dbof_wgrad_finish": [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp],
 }
 EXPORTS = tuple(SIGNATURES) + ("evc_version", "evc_last_error")
 

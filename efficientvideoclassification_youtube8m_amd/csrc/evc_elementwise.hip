@@ -715,22 +715,34 @@ extern "C" int evc_clip_adam_step(float* p, const float* g, float* m, float* v, 
 // ---------------------------------------------------------------------------
 // one wave per frame, TS frame-slices per video; per-lane register accumulators, LDS
 // reduce across the 4 waves, one atomicAdd per (block, feature).
-__global__ __launch_bounds__(256) void meanpool_kernel(const float* __restrict__ x, const int* __restrict__ nfr, int T, int F,
-                                                       int normalize, float* __restrict__ avg) {
+__global__ __launch_bounds__(256) void meanpool_kernel(const float* __restrict__ x, const uint8_t* __restrict__ xq,
+                                                       const int* __restrict__ nfr, int T, int F, int normalize,
+                                                       float* __restrict__ avg) {
   __shared__ float red[4][1280];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int b = blockIdx.y, nv = F >> 2;
   float4 acc[5];
 #pragma unroll
   for (int i = 0; i < 5; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int t = blockIdx.x * 4 + w; t < T; t += gridDim.x * 4) {
-    const float4* row = (const float4*)(x + ((long)b * T + t) * F);
+  // uint8 input (the reader's representation): frames >= num_frames are padding, i.e. zero after Dequantize
+  // (cs/readers.py:170-173) - they add nothing to the sum and are not read
+  const int t_end = xq ? min(T, nfr[b]) : T;
+  for (int t = blockIdx.x * 4 + w; t < t_end; t += gridDim.x * 4) {
     float4 v[5];
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const int j = lane + i * 64;
-      v[i] = (j < nv) ? row[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < nv) {
+        if (xq) {                                      // Dequantize cs/utils.py:22-25
+          const uchar4 q = ((const uchar4*)(xq + ((long)b * T + t) * F))[j];
+          const float sc = 4.0f / 255.0f, bi = 4.0f / 512.0f - 2.0f;
+          v[i] = make_float4(q.x * sc + bi, q.y * sc + bi, q.z * sc + bi, q.w * sc + bi);
+        } else {
+          v[i] = ((const float4*)(x + ((long)b * T + t) * F))[j];
+        }
+      }
       ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
     }
     float inv = 1.f;
@@ -750,13 +762,14 @@ __global__ __launch_bounds__(256) void meanpool_kernel(const float* __restrict__
   for (int f = threadIdx.x; f < F; f += 256)
     atomicAdd(&avg[(long)b * F + f], (red[0][f] + red[1][f] + red[2][f] + red[3][f]) * invn);
 }
-extern "C" int evc_meanpool_fwd(const float* x, const int32_t* num_frames, int B, int T, int F, int normalize,
+extern "C" int evc_meanpool_fwd(const float* x, const uint8_t* x_u8, const int32_t* num_frames, int B, int T, int F, int normalize,
                                 float* avg_f32, evc_bf16* avg_bf16, void* stream) {
   EVC_REQUIRE(B > 0 && T > 0 && F > 0 && F % 4 == 0 && F <= 1280 && avg_f32, EVC_ERR_BAD_SHAPE, "evc_meanpool_fwd: bad shape");
+  EVC_REQUIRE((x != nullptr) != (x_u8 != nullptr), EVC_ERR_BAD_ARG, "evc_meanpool_fwd: exactly one of x / x_u8");
   hipStream_t st = (hipStream_t)stream;
   EVC_CHECK_HIP(hipMemsetAsync(avg_f32, 0, sizeof(float) * B * F, st));
   int ts = (T + 31) / 32;
-  hipLaunchKernelGGL(meanpool_kernel, dim3(ts, B), dim3(256), 0, st, x, num_frames, T, F, normalize, avg_f32);
+  hipLaunchKernelGGL(meanpool_kernel, dim3(ts, B), dim3(256), 0, st, x, x_u8, num_frames, T, F, normalize, avg_f32);
   EVC_LAUNCH_CHECK();
   if (avg_bf16) return evc_cast_f32_to_bf16(avg_f32, F, B, F, avg_bf16, F, stream);
   return EVC_OK;

@@ -1,16 +1,6 @@
 // GEMM-shaped kernels of the hot path: generic NT GEMM, fused LSTM step
 // (forward, with the gate tail in the epilogue) and fused BPTT step.
-#include "gemm_core_tn.h"
-#include <mutex>
-#include <vector>
-#include <stdlib.h>
-
-// A kernel is instantiated either on a v1 tile (TileCfg: static 2-stage LDS, K steps of 64)
-// or a v2 tile (TileCfg2: dynamic 4-stage LDS ring, K steps of 32).
-template <class Cfg> struct is_v2 { static constexpr bool value = false; };
-template <int a, int b, int c, int d, int e, int f, bool g> struct is_v2<TileCfg2<a, b, c, d, e, f, g>> { static constexpr bool value = true; };
-
-extern __shared__ __attribute__((aligned(16))) char lds_dyn[];
+#include "gemm_launch.h"
 
 template <class Cfg, int NG, bool SWAP = false, bool SPLIT = false, bool INIT = true>
 __device__ __forceinline__ void run_mainloop(const GemmOperands& p, int m0, int u0, f32x4 (&acc)[Cfg::MI][NG][Cfg::NI]) {
@@ -25,34 +15,6 @@ __device__ __forceinline__ void run_mainloop(const GemmOperands& p, int m0, int 
 
 // K-step granularity of a config (v1 walks 64-wide tiles, v2 32-wide)
 template <class Cfg> static inline int kdiv() { return is_v2<Cfg>::value ? 32 : 64; }
-
-// v2 tiles use more dynamic LDS than the 64 KiB default: raise the limit once per kernel (keyed by the
-// kernel's address - two kernels of one signature share this template instantiation).
-static inline void allow_big_lds(const void* kern, int bytes) {
-  static std::mutex mu;
-  static std::vector<const void*> done;
-  std::lock_guard<std::mutex> lk(mu);
-  for (const void* k : done) if (k == kern) return;
-  (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  done.push_back(kern);
-}
-
-template <class Cfg, class Kern, class... Args>
-static inline void launch_cfg(Kern kern, int grid, hipStream_t st, Args... args) {
-  if (is_v2<Cfg>::value) {
-    allow_big_lds((const void*)kern, Cfg::LDS_BYTES);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, args...);
-  } else {
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::NT), 0, st, args...);
-  }
-}
-
-// debug/benchmark override of the tile choice: EVC_FORCE_TILE = 1 (v2) | 2 (v1 128x128) | 3 (v1 64x64)
-static inline int forced_tile() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("EVC_FORCE_TILE"); v = e ? atoi(e) : 0; }
-  return v;
-}
 
 // Tile choice: a CU works through ceil(tiles/256) tiles (co-resident workgroups share its matrix
 // pipe, so residency does not shorten that), each costing area x a per-flop factor measured on
@@ -200,6 +162,7 @@ struct StoreParamsT {
   float* C; long ldc; int M, N;
   int row_il_H;                   // > 0: row m = u*4+g of the product is stored at row g*H+u (gate de-interleave)
   int accumulate, splits, ksteps_per_split;
+  long slab_stride;               // > 0: split s stores its partial tile plainly at C + s*slab_stride (no atomics; the caller sums the slabs)
 };
 
 template <class Cfg>
@@ -232,8 +195,9 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_tn_kernel(GemmOperandsT p, Store
         const int m = m0 + tc.row0 + mi * 16 + r;
         if (m >= s.M) continue;
         const int mo = s.row_il_H > 0 ? (m & 3) * s.row_il_H + (m >> 2) : m;
-        float* cp = s.C + (long)mo * s.ldc + n;
+        float* cp = s.C + (long)mo * s.ldc + n + split * s.slab_stride;
         const float v = acc[mi][0][ni][r];
+        if (s.slab_stride > 0) { *cp = v; continue; }
 #ifdef EVC_ABLATE_TN_ATOMICS     // debug build: plain stores instead of the split-K atomics (wrong sums, timing only)
         *cp = v;
 #else
@@ -259,7 +223,7 @@ extern "C" int evc_gemm_tn(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
   // K ~ 5000 on the 256x256 split-K form is faster again (92 vs 99 us)
   if (forced_tile() == 11 || (forced_tile() == 0 && K <= 2048 && (long)ceil_div(M, 128) * ceil_div(N, 128) >= 192)) {
     const int tm1 = ceil_div(M, 128), tn1 = ceil_div(N, 128);
-    StoreParamsT s1{C, ldc, M, N, row_interleave_H, accumulate, 1, p.nk};
+    StoreParamsT s1{C, ldc, M, N, row_interleave_H, accumulate, 1, p.nk, 0};
     launch_cfg<CfgTn128>(gemm_tn_kernel<CfgTn128>, tm1 * tn1, st, p, s1, tm1, tn1);
     EVC_LAUNCH_CHECK();
     return EVC_OK;
@@ -268,9 +232,28 @@ extern "C" int evc_gemm_tn(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
   int splits = 256 / (tm * tn);
   if (splits > K / 1024) splits = K / 1024;     // keep >= 32 K steps per split
   if (splits < 1) splits = 1;
-  StoreParamsT s{C, ldc, M, N, row_interleave_H, accumulate, splits, ceil_div(p.nk, splits)};
+  StoreParamsT s{C, ldc, M, N, row_interleave_H, accumulate, splits, ceil_div(p.nk, splits), 0};
   if (splits > 1 && !accumulate) EVC_CHECK_HIP(hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st));
   launch_cfg<CfgPlainV2>(gemm_tn_kernel<CfgPlainV2>, tm * tn * splits, st, p, s, tm, tn);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// Split-K into slabs: slab s (s < nslab) = the partial product over K rows [s*ceil(K/32/nslab)*32, ...), stored plainly at
+// slabs + s*M*N (row stride N).  For products whose 256x256 tiles do not fill the chip and whose result is read once by a
+// pass that can add the slabs on the way (DBoF cluster-weight gradient: 8192 x 1152 x 16384 = 160 tiles): no atomics, no memset.
+extern "C" int evc_gemm_tn_slabs(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, float* slabs, int M, int N, int K,
+                                 int nslab, void* stream) {
+  EVC_REQUIRE(M >= 8 && N >= 8 && K > 0 && M % 8 == 0 && N % 8 == 0 && K % 32 == 0 && nslab >= 1 && nslab <= K / 32, EVC_ERR_BAD_SHAPE,
+              "evc_gemm_tn_slabs: needs M %% 8 == 0, N %% 8 == 0, K %% 32 == 0, 1 <= nslab <= K/32 (M=%d N=%d K=%d nslab=%d)", M, N, K, nslab);
+  EVC_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, EVC_ERR_BAD_ALIGN,
+              "evc_gemm_tn_slabs: operands must be 16-byte aligned (lda=%ld ldb=%ld)", (long)lda, (long)ldb);
+  GemmOperandsT p{A, lda, B, ldb, M, N, K / 32};
+  const int tm = ceil_div(M, CfgPlainV2::BM), tn = ceil_div(N, CfgPlainV2::BU);
+  const int per = ceil_div(p.nk, nslab);
+  EVC_REQUIRE((long)per * (nslab - 1) < p.nk, EVC_ERR_BAD_SHAPE, "evc_gemm_tn_slabs: nslab=%d leaves an empty slab at K=%d", nslab, K);
+  StoreParamsT s{slabs, N, M, N, 0, 0, nslab, per, (long)M * N};
+  launch_cfg<CfgPlainV2>(gemm_tn_kernel<CfgPlainV2>, tm * tn * nslab, (hipStream_t)stream, p, s, tm, tn);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }

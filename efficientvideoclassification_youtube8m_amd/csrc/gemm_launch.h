@@ -1,0 +1,41 @@
+// Launch helpers shared by the GEMM-shaped translation units (evc_gemm.hip, evc_dbof.hip).
+#pragma once
+#include "gemm_core_tn.h"
+#include <mutex>
+#include <vector>
+#include <stdlib.h>
+
+// A kernel is instantiated either on a v1 tile (TileCfg: static 2-stage LDS, K steps of 64)
+// or a v2 tile (TileCfg2: dynamic 4-stage LDS ring, K steps of 32).
+template <class Cfg> struct is_v2 { static constexpr bool value = false; };
+template <int a, int b, int c, int d, int e, int f, bool g> struct is_v2<TileCfg2<a, b, c, d, e, f, g>> { static constexpr bool value = true; };
+
+extern __shared__ __attribute__((aligned(16))) char lds_dyn[];
+
+// v2 tiles use more dynamic LDS than the 64 KiB default: raise the limit once per kernel (keyed by the
+// kernel's address - two kernels of one signature share this template instantiation).
+static inline void allow_big_lds(const void* kern, int bytes) {
+  static std::mutex mu;
+  static std::vector<const void*> done;
+  std::lock_guard<std::mutex> lk(mu);
+  for (const void* k : done) if (k == kern) return;
+  (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  done.push_back(kern);
+}
+
+template <class Cfg, class Kern, class... Args>
+static inline void launch_cfg(Kern kern, int grid, hipStream_t st, Args... args) {
+  if (is_v2<Cfg>::value) {
+    allow_big_lds((const void*)kern, Cfg::LDS_BYTES);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, st, args...);
+  } else {
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Cfg::NT), 0, st, args...);
+  }
+}
+
+// debug/benchmark override of the tile choice: EVC_FORCE_TILE = 1 (v2) | 2 (v1 128x128) | 3 (v1 64x64)
+static inline int forced_tile() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("EVC_FORCE_TILE"); v = e ? atoi(e) : 0; }
+  return v;
+}

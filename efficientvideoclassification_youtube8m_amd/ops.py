@@ -265,7 +265,8 @@ def clip_adam_step(p, g, m, v, l2_coeff, sums, clip_norm, lr_t, beta1=0.9, beta2
 
 def meanpool(x, num_frames, avg_f32, avg_bf16=None, normalize=False):
     B, T, F = x.shape
-    _lib.call("evc_meanpool_fwd", _p(x), _p(num_frames), B, T, F, 1 if normalize else 0, _p(avg_f32), _p(avg_bf16), _stream())
+    is_u8 = x.dtype == torch.uint8
+    _lib.call("evc_meanpool_fwd", None if is_u8 else _p(x), _p(x) if is_u8 else None, _p(num_frames), B, T, F, 1 if normalize else 0, _p(avg_f32), _p(avg_bf16), _stream())
 
 
 def sigmoid_(z):
@@ -325,3 +326,66 @@ def framepool_max_fwd(y, B, S, Cc, pooled_f32, pooled_bf16, argmax):
 
 def framepool_max_bwd(dpooled, argmax, B, S, Cc, dy):
     _lib.call("evc_framepool_max_bwd", _p(dpooled), _p(argmax), B, S, Cc, _p(dy), _stream())
+
+
+# ---------------------------------------------------------------------------
+# DbofModel fused path (csrc/evc_dbof.hip)
+def dbof_workspace(B, S):
+    """(padded_rows, gather_part_rows, gemm_part_rows) of the padded frame layout for B videos x S sampled frames."""
+    a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+    _lib.call("evc_dbof_workspace", B, S, C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+def dbof_row_index(B, S, device=None):
+    """int64 [B, S]: row of frame s of video b in the padded frame layout (tests / debugging; the kernels compute it)."""
+    b = torch.arange(B, device=device)[:, None]
+    s = torch.arange(S, device=device)[None, :]
+    return (b >> 2) * 128 + (s >> 2) * 16 + (b & 3) * 4 + (s & 3)
+
+
+def dbof_gather(x, u, num_frames, r, idx_out=None, part=None, normalize=True):
+    B, T, F = x.shape
+    S = u.shape[1]
+    is_u8 = x.dtype == torch.uint8
+    assert is_u8 or x.dtype == F32
+    _lib.call("evc_dbof_gather", None if is_u8 else _p(x), _p(x) if is_u8 else None, _p(u), _p(num_frames), B, T, F, S,
+              1 if normalize else 0, _p(r), _p(idx_out), _p(part), _stream())
+
+
+def bn_partials_reduce(part, P, Cc, ws):
+    _lib.call("evc_bn_partials_reduce", _p(part), P, Cc, _p(ws), _stream())
+
+
+def bn_finalize_ema(ws, R_total, Cc, mean, var, moving_mean=None, moving_var=None, decay=0.999):
+    _lib.call("evc_bn_finalize_ema", _p(ws), R_total, Cc, _p(mean), _p(var), _p(moving_mean), _p(moving_var), decay, _stream())
+
+
+def dbof_input_bn_apply(r, B, S, F, mean, var, gamma, beta, r_bn, r_bn_lo=None, xhat=None):
+    _lib.call("evc_dbof_input_bn_apply", _p(r), B, S, F, _p(mean), _p(var), _p(gamma), _p(beta), _p(r_bn), _p(r_bn_lo), _p(xhat),
+              _stream())
+
+
+def dbof_cluster_pool_fwd(r_bn, wT, B, S, F, Cc, gamma, xsel, arg, act=None, part=None, r_bn_lo=None, wT_lo=None):
+    _lib.call("evc_dbof_cluster_pool_fwd", _p(r_bn), _p(r_bn_lo), _p(wT), _p(wT_lo), B, S, F, Cc, _p(gamma), _p(act), _p(part),
+              _p(xsel), _p(arg), _stream())
+
+
+def dbof_pool_finish(xsel, B, Cc, mean, var, gamma, beta, pooled_f32, pooled_bf16=None, pooled_lo=None):
+    _lib.call("evc_dbof_pool_finish", _p(xsel), B, Cc, _p(mean), _p(var), _p(gamma), _p(beta), _p(pooled_f32), _p(pooled_bf16),
+              _p(pooled_lo), _stream())
+
+
+def dbof_dact(act, dpooled, pooled, arg, mean, var, gamma, ws, R_total, B, S, Cc, dgamma=None, dbeta=None):
+    _lib.call("evc_dbof_dact", _p(act), _p(dpooled), _p(pooled), _p(arg), _p(mean), _p(var), _p(gamma), _p(ws), R_total, B, S, Cc,
+              _p(dgamma), _p(dbeta), _stream())
+
+
+def gemm_tn_slabs(A, B, M, N, K, slabs, nslab):
+    """slabs[s] [M,N] f32 = partial product of A[K,M]^T @ B[K,N] over the s-th K range."""
+    assert A.dtype == BF16 and B.dtype == BF16 and slabs.dtype == F32
+    _lib.call("evc_gemm_tn_slabs", _p(A), A.stride(0), _p(B), B.stride(0), _p(slabs), M, N, K, nslab, _stream())
+
+
+def dbof_wgrad_finish(slabs, nslab, Cc, F, W, gamma_in, dW, dgamma_in, dbeta_in=None):
+    _lib.call("evc_dbof_wgrad_finish", _p(slabs), nslab, Cc, F, _p(W), _p(gamma_in), _p(dW), _p(dgamma_in), _p(dbeta_in), _stream())

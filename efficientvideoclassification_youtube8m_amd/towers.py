@@ -73,13 +73,23 @@ class BatchNorm:
 
 
 class DbofTower(TowerBase):
-    """Deep Bag of Frames: sample S frames -> input_bn -> .Wc -> cluster_bn ->
-    relu6 -> max over frames -> .Wh -> hidden1_bn -> relu6 -> MoE."""
+    """Deep Bag of Frames: sample S frames -> input_bn -> .Wc -> cluster_bn -> relu6 -> max over frames -> .Wh ->
+    hidden1_bn -> relu6 -> MoE (cs/frame_level_models.py:108-195).
+
+    The [B*S, clusters] activation (503 MB of f32 at B=512) never exists in f32: the cluster GEMM's epilogue
+    (evc_dbof_cluster_pool_fwd) leaves the batch-norm column sums and, per (video, cluster), the frame that the
+    max-pool will select (max of sign(gamma)*x: batch-norm with a fixed-sign scale and relu6 are monotone); training
+    keeps the activation as bf16 for the backward pass, which rewrites it in place as d(activation).
+    Backward: the gradient wrt the batch-normalised input (a second 290 GFLOP product in the reference graph, whose
+    only consumers are input_bn's gamma/beta) is not formed: with G = dact^T . xhat,  dWc = gamma_in * G,
+    dgamma_in = sum_c Wc * G,  dbeta_in = 0 (evc_dbof_wgrad_finish)."""
 
     CW, HW = "cluster_weights", "hidden1_weights"        # the reference's unnamed tf.Variable / Variable_1
     l2_names = (MoeHead.GATES, MoeHead.EXPERTS)
-    # gradients that BatchNorm.backward already leaves summed over the ranks (SyncBN): not part of the gradient all-reduce
-    global_grad_names = tuple("%s/%s" % (s, v) for s in ("input_bn", "cluster_bn", "hidden1_bn") for v in ("beta", "gamma"))
+    # gradients that the batch-norm backward passes already leave summed over the ranks (SyncBN: all-reduced f64 sums): not
+    # part of the gradient all-reduce.  (input_bn's come from the rank's own G = dact^T . xhat and ARE all-reduced.)
+    global_grad_names = tuple("%s/%s" % (s, v) for s in ("cluster_bn", "hidden1_bn") for v in ("beta", "gamma"))
+    timing = None      # bench.py: set to a list to collect (start, end) events around the cluster GEMM launches
 
     def __init__(self, batch_size, max_frames=300, feature_size=1152, vocab_size=4716, iterations=30,
                  cluster_size=8192, hidden_size=1024, num_mixtures=2, device="cuda:0", training=True,
@@ -89,6 +99,8 @@ class DbofTower(TowerBase):
         self.Cc, self.Hd, self.Mx = cluster_size, hidden_size, num_mixtures
         if feature_size % 64 or cluster_size % 64 or hidden_size % 64:
             raise ValueError("feature/cluster/hidden sizes must be multiples of 64 for the MFMA GEMM tiles")
+        if iterations > 32:
+            raise ValueError("iterations=%d: the fused cluster kernel holds at most 32 sampled frames per video" % iterations)
         shapes = OrderedDict()
         shapes.update(BatchNorm.shapes("input_bn", feature_size))
         shapes[self.CW] = (cluster_size, feature_size)               # stored transposed [C][F]
@@ -124,87 +136,123 @@ class DbofTower(TowerBase):
     def _alloc(self, B):
         dev, F, S, Cc, Hd = self.device, self.F, self.S, self.Cc, self.Hd
         self.B = B
-        R = B * S
-        self.R = R
-        self.r = torch.empty((R, F), dtype=F32, device=dev)
+        self.R = B * S                                               # sampled frames of this rank's batch
+        self.Mp, self.P_in, self.P_cl = ops.dbof_workspace(B, S)     # rows of the padded frame layout / partial-sum rows
+        Mp = self.Mp
+        self.r = torch.empty((Mp, F), dtype=F32, device=dev)         # sampled, l2-normalised frames (only live slots are written / read)
         self.idx = torch.empty((B, S), dtype=torch.int32, device=dev)
-        self.r_bn = torch.empty((R, F), dtype=BF16, device=dev)
-        self.act = torch.empty((R, Cc), dtype=F32, device=dev)
+        self.part_in = torch.empty((self.P_in, 2, F), dtype=F32, device=dev)
+        self.r_bn = torch.empty((Mp, F), dtype=BF16, device=dev)
+        self.part_cl = torch.empty((self.P_cl, 2, Cc), dtype=F32, device=dev)
+        self.xsel = torch.empty((B, Cc), dtype=F32, device=dev)
+        self.arg = torch.empty((B, Cc), dtype=torch.uint8, device=dev)
+        self.Bk = ops.round_up(B, 32)                                # batch rows as a TN contraction length (zero rows pad)
         self.pooled = torch.empty((B, Cc), dtype=F32, device=dev)
-        self.pooled_bf = torch.empty((B, Cc), dtype=BF16, device=dev)
-        self.argmax = torch.empty((B, Cc), dtype=torch.int32, device=dev)
+        self.pooled_bf = torch.zeros((self.Bk, Cc), dtype=BF16, device=dev)
         self.hid = torch.empty((B, Hd), dtype=F32, device=dev)
         self.h6 = torch.empty((B, Hd), dtype=F32, device=dev)
         self.moe.alloc(B, self.training)
         if self.training:
-            self.Bp, self.Rp = ops.round_up(B, 64), ops.round_up(R, 64)
-            self.dhid_bf = torch.empty((B, Hd), dtype=BF16, device=dev)
-            self.dhidT = torch.empty((Hd, self.Bp), dtype=BF16, device=dev)
-            self.pooledT = torch.empty((Cc, self.Bp), dtype=BF16, device=dev)
+            self.xhat = torch.empty((Mp, F), dtype=BF16, device=dev)
+            self.act = torch.empty((Mp, Cc), dtype=BF16, device=dev)  # bf16 activation, rewritten in place as d(activation)
+            self.dhid_bf = torch.zeros((self.Bk, Hd), dtype=BF16, device=dev)
             self.dpooled = torch.empty((B, Cc), dtype=F32, device=dev)
-            self.dact_bf = torch.empty((R, Cc), dtype=BF16, device=dev)
-            self.dactT = torch.empty((Cc, self.Rp), dtype=BF16, device=dev)
-            self.r_bnT = torch.empty((F, self.Rp), dtype=BF16, device=dev)
-            self.dr_bn = torch.empty((R, F), dtype=F32, device=dev)
+            self.nslab = self._pick_nslab(Cc, F, Mp)
+            self.slabs = torch.empty((self.nslab, Cc, F), dtype=F32, device=dev)
+
+    @staticmethod
+    def _pick_nslab(M, N, K):
+        """Split-K factor of the cluster-weight gradient G [M][N] = dact^T . xhat over K rows: its 256x256 tiles rarely
+        fill the 256 CUs (cfg 4: 32 x 5 = 160), so K is cut into slabs that the finishing pass adds on the way.  Cost
+        model: rounds of 256 workgroups x (1/nslab) of a full-K tile, plus writing and reading nslab f32 slabs."""
+        tiles = -(-M // 256) * -(-N // 256)
+        nk = K // 32
+        t_tile = 2.0 * 256 * 256 * K / 3.9e12                       # a CU at ~40 % of its MFMA peak
+        best, best_cost = 1, None
+        for n in range(1, 9):
+            per = -(-nk // n)
+            if per * (n - 1) >= nk or per < 8:
+                continue
+            cost = -(-tiles * n // 256) * t_tile / n + (n * 2.0 * M * N * 4 / 5e12 if n > 1 else 0.0)
+            if best_cost is None or cost < best_cost * 0.97:
+                best, best_cost = n, cost
+        return best
+
+    def _bn_train_stats(self, bn, part, P, width):
+        """Column partial sums -> batch statistics of the GLOBAL batch (SyncBN) + moving averages."""
+        ops.bn_partials_reduce(part, P, width, bn.ws)
+        world = _maybe_allreduce(bn.ws, self.pg)
+        bn.R_total = self.R * world
+        ops.bn_finalize_ema(bn.ws, bn.R_total, width, bn.mean, bn.var, self.buffers[bn.scope + "/moving_mean"],
+                            self.buffers[bn.scope + "/moving_variance"])
 
     def forward(self, x, num_frames, uniform, normalize=True, is_training=True):
-        """x [B,T,F] f32 raw (normalize=True fuses tf.nn.l2_normalize of the sampled
-        frames) ; uniform [B,S] f32 in [0,1): the tf.random_uniform draw of
+        """x [B,T,F] raw frames, float32 or uint8 as the reader delivers them (Dequantize is fused; normalize=True
+        fuses tf.nn.l2_normalize of the sampled frames); uniform [B,S] f32 in [0,1): the tf.random_uniform draw of
         SampleRandomFrames, supplied by the caller so runs are reproducible."""
         B = x.shape[0]
         if B != self.B:
             self._alloc(B)
-        R, F, S, Cc, Hd = self.R, self.F, self.S, self.Cc, self.Hd
-        st = self.store
-        ops.sample_frames_gather(x, uniform, num_frames, self.r, self.idx, normalize=normalize)
-        self.bn_in.stats(self.r, R, is_training)
+        F, S, Cc, Hd = self.F, self.S, self.Cc, self.Hd
         high = self.precision == "high"
-        if high:
-            if not hasattr(self, "r_bn_f32") or self.r_bn_f32.shape[0] != R:
-                self.r_bn_f32 = torch.empty((R, F), dtype=F32, device=self.device)
-                self.r_bn_lo = torch.empty((R, F), dtype=BF16, device=self.device)
-                self.pooled_lo = torch.empty((B, Cc), dtype=BF16, device=self.device)
-            ops.bn_apply(self.r, R, F, self.bn_in.mean, self.bn_in.var, self.bn_in.gamma(), self.bn_in.beta(), False,
-                         y_f32=self.r_bn_f32)
-            ops.cast_bf16_split(self.r_bn_f32, self.r_bn, self.r_bn_lo)
-            ops.gemm_nt_split(self.r_bn, self.r_bn_lo, self.shadow_fwd[self.CW], self.shadow_lo[self.CW], R, Cc, F, self.act)
+        tape = self.training and is_training
+        ops.dbof_gather(x, uniform, num_frames, self.r, self.idx, self.part_in if is_training else None, normalize=normalize)
+        if is_training:
+            self._bn_train_stats(self.bn_in, self.part_in, self.P_in, F)
         else:
-            ops.bn_apply(self.r, R, F, self.bn_in.mean, self.bn_in.var, self.bn_in.gamma(), self.bn_in.beta(), False,
-                         y_bf16=self.r_bn)
-            ops.gemm_nt(self.r_bn, self.shadow_fwd[self.CW], R, Cc, F, self.act)
-        self.bn_cl.stats(self.act, R, is_training)
-        ops.bn_relu6_framepool_fwd(self.act, B, S, Cc, self.bn_cl.mean, self.bn_cl.var, self.bn_cl.gamma(),
-                                   self.bn_cl.beta(), self.pooled, self.pooled_bf, self.argmax)
+            self.bn_in.stats(None, self.R, False)
+        if high and (not hasattr(self, "r_bn_lo") or self.r_bn_lo.shape != self.r_bn.shape):
+            self.r_bn_lo = torch.empty_like(self.r_bn)
+            self.pooled_lo = torch.zeros_like(self.pooled_bf)
+        ops.dbof_input_bn_apply(self.r, B, S, F, self.bn_in.mean, self.bn_in.var, self.bn_in.gamma(), self.bn_in.beta(), self.r_bn,
+                                self.r_bn_lo if high else None, self.xhat if tape else None)
+        if self.timing is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        ops.dbof_cluster_pool_fwd(self.r_bn, self.shadow_fwd[self.CW], B, S, F, Cc, self.bn_cl.gamma(), self.xsel, self.arg,
+                                  act=self.act if tape else None, part=self.part_cl if is_training else None,
+                                  r_bn_lo=self.r_bn_lo if high else None, wT_lo=self.shadow_lo[self.CW] if high else None)
+        if self.timing is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.timing.append((e0, e1))
+        if is_training:
+            self._bn_train_stats(self.bn_cl, self.part_cl, self.P_cl, Cc)
+        else:
+            self.bn_cl.stats(None, self.R, False)
+        ops.dbof_pool_finish(self.xsel, B, Cc, self.bn_cl.mean, self.bn_cl.var, self.bn_cl.gamma(), self.bn_cl.beta(), self.pooled,
+                             self.pooled_bf, self.pooled_lo if high else None)
         if high:
-            ops.cast_bf16_split(self.pooled, self.pooled_bf, self.pooled_lo)
             ops.gemm_nt_split(self.pooled_bf, self.pooled_lo, self.shadow_fwd[self.HW], self.shadow_lo[self.HW], B, Hd, Cc, self.hid)
         else:
             ops.gemm_nt(self.pooled_bf, self.shadow_fwd[self.HW], B, Hd, Cc, self.hid)
         self.bn_h.stats(self.hid, B, is_training)
         ops.bn_apply(self.hid, B, Hd, self.bn_h.mean, self.bn_h.var, self.bn_h.gamma(), self.bn_h.beta(), True,
                      y_f32=self.h6)
+        self._taped = tape
         return self.moe.forward(self.h6)
 
     def backward(self, dpred, on_moe_grads_ready=None):
-        assert self.training
-        B, R, F, S, Cc, Hd = self.B, self.R, self.F, self.S, self.Cc, self.Hd
+        assert self.training and self._taped, "backward needs a training-mode forward"
+        B, F, S, Cc, Hd = self.B, self.F, self.S, self.Cc, self.Hd
         st = self.store
         dh6 = self.moe.backward(dpred)
         if on_moe_grads_ready is not None:
             on_moe_grads_ready()
         self.bn_h.backward(self.hid, dh6, B, True, dx_bf16=self.dhid_bf)
-        # hidden1 weights: dWh^T [Hd][C] = dhid^T . pooled ; dpooled = dhid . Wh^T
-        ops.transpose_to_bf16(self.dhid_bf, B, Hd, self.dhidT, self.Bp)
-        ops.transpose_to_bf16(self.pooled_bf, B, Cc, self.pooledT, self.Bp)
-        ops.gemm_nt(self.dhidT, self.pooledT, Hd, Cc, self.Bp, st.g(self.HW))
+        # hidden1 weights: dWh^T [Hd][C] = dhid^T . pooled (TN over the batch rows); dpooled = dhid . Wh^T
+        ops.gemm_tn(self.dhid_bf, self.pooled_bf, Hd, Cc, self.Bk, st.g(self.HW))
         ops.gemm_nt(self.dhid_bf, self.shadow_bwd[self.HW], B, Cc, Hd, self.dpooled)
-        # max-pool routing + relu6 mask + cluster_bn backward in one pass over act
-        self.bn_cl.backward(self.act, self.dpooled, R, True, argmax=self.argmax, S=S, dx_bf16=self.dact_bf)
-        ops.transpose_to_bf16(self.dact_bf, R, Cc, self.dactT, self.Rp)
-        ops.transpose_to_bf16(self.r_bn, R, F, self.r_bnT, self.Rp)
-        ops.gemm_nt(self.dactT, self.r_bnT, Cc, F, self.Rp, st.g(self.CW))
-        ops.gemm_nt(self.dact_bf, self.shadow_bwd[self.CW], R, F, Cc, self.dr_bn)
-        self.bn_in.backward(self.r, self.dr_bn, R, False)
+        # max-pool routing + relu6 mask + cluster_bn backward: the two batch sums need only the [B][C] selected entries
+        bn = self.bn_cl
+        ops.bn_bwd_partial(self.xsel, self.dpooled, B, Cc, bn.mean, bn.var, bn.gamma(), bn.beta(), True, bn.ws)
+        _maybe_allreduce(bn.ws, self.pg)
+        ops.dbof_dact(self.act, self.dpooled, self.pooled, self.arg, bn.mean, bn.var, bn.gamma(), bn.ws, bn.R_total, B, S, Cc,
+                      dgamma=st.g("cluster_bn/gamma"), dbeta=st.g("cluster_bn/beta"))
+        # G = dact^T . xhat in split-K slabs, then cluster weights / input_bn gradients from G
+        ops.gemm_tn_slabs(self.act, self.xhat, Cc, F, self.Mp, self.slabs, self.nslab)
+        ops.dbof_wgrad_finish(self.slabs, self.nslab, Cc, F, st.p(self.CW), self.bn_in.gamma(), st.g(self.CW),
+                              st.g("input_bn/gamma"), st.g("input_bn/beta"))
 
     @property
     def pred(self):

@@ -125,13 +125,6 @@ def get_input_data(data_pattern, batch_size, feature_size, device, num_epochs, s
     return batches(), pipe.num_batches
 
 
-def dequantize_masked(q, n):
-    """Dequantize (cs/utils.py:22-25) + zero rows >= num_frames (cs/readers.py:170-173) for the graphs whose
-    input kernel takes float32 (the LSTM graph takes the uint8 tensor directly)."""
-    keep = (torch.arange(q.shape[1], device=q.device)[None, :] < n[:, None]).unsqueeze(-1)
-    return (q.float() * (4.0 / 255.0) + (4.0 / 512.0 - 2.0)) * keep
-
-
 def _ckpt_step(path):
     name = os.path.basename(path)
     return int(name[len("model.ckpt-"):-3]) if name.startswith("model.ckpt-") else 0
@@ -299,7 +292,7 @@ def main(argv=None):
     history = []                         # (global_step, loss dict) of every logged step, returned to the caller
     pending = None
     for q, labels, n, n_host in data:
-        out = graph.step(q, labels, n, num_frames_host=n_host) if is_distill else graph.step(dequantize_masked(q, n), labels, n)
+        out = graph.step(q, labels, n, num_frames_host=n_host) if is_distill else graph.step(q, labels, n)    # uint8 features: Dequantize is fused into every input kernel
         it += 1
         graph.last_batch_ids = LAST_BATCH["ids"]
         logging_step = it % max(1, FLAGS.log_every) == 0

@@ -279,9 +279,10 @@ int evc_clip_adam_step(float* p, const float* g, float* m, float* v, int64_t n, 
 
 /* ---- a11: FrameLevelLogisticModel pooling ------------------------------------
  * cs/frame_level_models.py:72-78: sum over ALL T (padded) frames / true n.
- * x [B][T][F] f32 -> avg [B][F] f32 (required) and bf16 (GEMM operand, optional).
+ * x [B][T][F] f32, or x_u8 [B][T][F] as the reader delivers it (Dequantize cs/utils.py:22-25 fused; frames >=
+ * num_frames are padding = 0) - exactly one non-NULL -> avg [B][F] f32 (required) and bf16 (GEMM operand, optional).
  * normalize=1 fuses tf.nn.l2_normalize of every frame (cs/train.py:256) into the pooling pass. */
-int evc_meanpool_fwd(const float* x, const int32_t* num_frames, int B, int T, int F, int normalize,
+int evc_meanpool_fwd(const float* x, const uint8_t* x_u8, const int32_t* num_frames, int B, int T, int F, int normalize,
                      float* avg_f32, evc_bf16* avg_bf16, void* stream);
 /* elementwise sigmoid fwd (in place on f32 [n]) and dz = dp * p * (1-p) -> bf16 */
 int evc_sigmoid_fwd(float* z, int64_t n, void* stream);
@@ -328,6 +329,56 @@ int evc_bn_relu6_framepool_fwd(const float* act, int B, int S, int C, const floa
 int evc_framepool_max_fwd(const float* y, int B, int S, int C, float* pooled_f32, evc_bf16* pooled_bf16,
                           int32_t* argmax, void* stream);
 int evc_framepool_max_bwd(const float* dpooled, const int32_t* argmax, int B, int S, int C, float* dy, void* stream);
+
+/* ---- a10 fused: the [frames x clusters] activation never leaves the chip in f32 ---------------------------
+ * (cs/frame_level_models.py:126-167: reshape -> input_bn -> matmul(cluster_weights) -> cluster_bn -> relu6 ->
+ *  FramePooling 'max'; cs/model_utils.py:39-58,77-78).  Padded frame layout: every video owns 32 frame slots
+ * (iterations <= 32), 4 videos form a 128-row block, frame s of video b is row
+ * (b>>2)*128 + (s>>2)*16 + (b&3)*4 + (s&3); all [Mp][..] operands below use it (Mp = padded_rows). */
+/* sizes of the caller-provided buffers: padded_rows = ceil(B/4)*128; gather_part_rows / gemm_part_rows = rows of the
+ * [rows][2][width] f32 column-partial-sum buffers of evc_dbof_gather / evc_dbof_cluster_pool_fwd. */
+int evc_dbof_workspace(int B, int S, int32_t* padded_rows, int32_t* gather_part_rows, int32_t* gemm_part_rows);
+/* SampleRandomFrames + tf.nn.l2_normalize of the gathered frames into r [Mp][F] f32 (only the sampled slots are
+ * written), from x_f32 [B][T][F] or x_u8 [B][T][F] (Dequantize cs/utils.py:22-25, frames >= num_frames are padding);
+ * exactly one of the two is non-NULL.  idx_out [B][S] int32 (optional) = the int32-truncated indices.
+ * part (optional) [gather_part_rows][2][F]: per-workgroup column sums of r and r^2 for the input batch-norm. */
+int evc_dbof_gather(const float* x_f32, const uint8_t* x_u8, const float* u, const int32_t* num_frames, int B, int T,
+                    int F, int S, int normalize, float* r, int32_t* idx_out, float* part, void* stream);
+/* [P][2][C] f32 partial sums -> ws f64 [2C] (sum x | sum x^2), rows added in index order (deterministic). */
+int evc_bn_partials_reduce(const float* part, int P, int C, double* ws, void* stream);
+/* mean / biased variance from ws over R_total rows + slim.batch_norm's moving averages (optional), one launch. */
+int evc_bn_finalize_ema(const double* ws, int R_total, int C, float* mean, float* var, float* moving_mean,
+                        float* moving_var, float decay, void* stream);
+/* input_bn applied: r -> r_bn = gamma*xhat+beta (bf16, + low half r_bn_lo for the split-bf16 mode, optional) and
+ * xhat (bf16, optional: the operand of the weight-gradient product); empty frame slots are written as zeros. */
+int evc_dbof_input_bn_apply(const float* r, int B, int S, int F, const float* mean, const float* var, const float* gamma,
+                            const float* beta, evc_bf16* r_bn, evc_bf16* r_bn_lo, evc_bf16* xhat, void* stream);
+/* act = r_bn . wT^T  (wT [C][F] bf16 = cluster_weights transposed) on 256x256 MFMA tiles with the epilogue
+ *   part [gemm_part_rows][2][C]  column sums of act, act^2 over each 128-row half tile (NULL: evaluation)
+ *   xsel [B][C], arg [B][C]      per (video, cluster): the max over the sampled frames of sign(gamma)*act, stored as
+ *                                the selected act itself, and its frame slot (first maximum wins)
+ *   act [Mp][C] bf16             the activation for the backward pass (NULL: not kept).
+ * r_bn_lo / wT_lo non-NULL: split-bf16 operands (hi.hi + hi.lo + lo.hi). */
+int evc_dbof_cluster_pool_fwd(const evc_bf16* r_bn, const evc_bf16* r_bn_lo, const evc_bf16* wT, const evc_bf16* wT_lo,
+                              int B, int S, int F, int C, const float* gamma, evc_bf16* act, float* part, float* xsel,
+                              uint8_t* arg, void* stream);
+/* pooled = relu6(gamma*(xsel-mean)*rsqrt(var+1e-3)+beta): f32, bf16 (optional), bf16 low half (optional). */
+int evc_dbof_pool_finish(const float* xsel, int B, int C, const float* mean, const float* var, const float* gamma,
+                         const float* beta, float* pooled_f32, evc_bf16* pooled_bf16, evc_bf16* pooled_lo, void* stream);
+/* backward of max-pool + relu6 + cluster_bn, in place on act [Mp][C] bf16 (-> dact).  ws f64 [2C] = sum d, sum d*xhat
+ * over the [B][C] selected entries (evc_bn_bwd_partial on xsel / dpooled with R = B), all-reduced under data
+ * parallelism; R_total = sampled frames of the global batch.  dgamma / dbeta [C] (optional) receive cluster_bn's own
+ * gradients (= the two sums). */
+int evc_dbof_dact(evc_bf16* act, const float* dpooled, const float* pooled, const uint8_t* arg, const float* mean,
+                  const float* var, const float* gamma, const double* ws, int R_total, int B, int S, int C, float* dgamma,
+                  float* dbeta, void* stream);
+/* evc_gemm_tn with the K range cut into nslab partial products stored plainly at slabs + s*M*N (no atomics). */
+int evc_gemm_tn_slabs(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, float* slabs, int M, int N, int K,
+                      int nslab, void* stream);
+/* G = sum of the slabs [nslab][C][F] (= dact^T . xhat): dW[c][f] = gamma_in[f]*G, dgamma_in[f] = sum_c W[c][f]*G,
+ * dbeta_in = 0 (the batch-norm backward's output sums to zero over the batch). */
+int evc_dbof_wgrad_finish(const float* slabs, int nslab, int C, int F, const float* W, const float* gamma_in, float* dW,
+                          float* dgamma_in, float* dbeta_in, void* stream);
 
 /* utility: out[i] = value for n floats (avoids torch for tiny fills inside C loops) */
 int evc_fill_f32(float* p, int64_t n, float value, void* stream);

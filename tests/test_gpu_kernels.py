@@ -523,3 +523,144 @@ def test_clip_adam_vector_and_scalar_paths_and_gradient_only_norm(ops):
     assert abs(sums[1].item() - float((p.double() ** 2).sum())) < 1e-3 * sums[1].item()
     with pytest.raises(Exception):
         ops.grad_sqnorm(g, None, 0.5, sums)              # p == NULL needs l2_coeff == 0
+
+
+@pytest.mark.parametrize("B,S,F,C,u8", [(6, 8, 64, 128, False), (9, 30, 128, 320, True), (37, 30, 1152, 512, True)])
+def test_dbof_fused_kernels_against_oracle(ops, B, S, F, C, u8):
+    """csrc/evc_dbof.hip piece by piece (cs/frame_level_models.py:126-167, cs/model_utils.py:39-58,77-78): gather into the
+    padded frame layout + column sums, input batch-norm, the cluster GEMM's statistics / max-pool epilogue (both signs of
+    gamma), pool finish, the in-place max-pool/relu6/batch-norm backward, the slab TN product and the weight-gradient finish."""
+    rng = np.random.default_rng(B * 1000 + C)
+    T = 40
+    q = rng.integers(0, 256, (B, T, F), dtype=np.uint8)
+    n = rng.integers(1, T + 1, B).astype(np.int32)
+    n[0] = T
+    if B > 3:
+        n[3] = 0                                             # an empty video: every sample is frame 0 = padding
+    x = mm.dequantize(q.astype(np.float64)) * (np.arange(T)[None, :, None] < n[:, None, None])
+    u = rng.random((B, S)).astype(np.float32)
+    xin_d = torch.from_numpy(q).to(DEV) if u8 else torch.from_numpy(x.astype(np.float32)).to(DEV)
+    nd, ud = torch.from_numpy(n).to(DEV), torch.from_numpy(u).to(DEV)
+    Mp, P_in, P_cl = ops.dbof_workspace(B, S)
+    assert Mp == (B + 3) // 4 * 128
+    rows = ops.dbof_row_index(B, S).numpy()                   # [B, S] -> padded row
+    assert len(set(rows.reshape(-1).tolist())) == B * S and rows.max() < Mp
+
+    # ---- gather ----
+    r = torch.full((Mp, F), float("nan"), device=DEV)
+    idx = torch.empty((B, S), dtype=torch.int32, device=DEV)
+    part = torch.empty((P_in, 2, F), device=DEV)
+    ops.dbof_gather(xin_d, ud, nd, r, idx, part)
+    ref_idx = mm.sample_random_frames_index(u, n)
+    assert np.array_equal(idx.cpu().numpy(), ref_idx)        # int32 truncation, bit-exact
+    g = mm.l2_normalize(x[np.arange(B)[:, None], np.clip(ref_idx, 0, T - 1)], 2)          # [B, S, F]
+    rr = r.cpu().numpy()
+    assert np.abs(rr[rows] - g).max() < 2e-6
+    live = np.zeros(Mp, bool)
+    live[rows.reshape(-1)] = True
+    assert np.isnan(rr[~live]).all()                          # empty frame slots are neither written nor read
+    ws = torch.empty(2 * F, dtype=torch.float64, device=DEV)
+    ops.bn_partials_reduce(part, P_in, F, ws)
+    g2 = g.reshape(-1, F)
+    assert np.allclose(ws.cpu().numpy()[:F], g2.sum(0), atol=1e-4) and np.allclose(ws.cpu().numpy()[F:], (g2 ** 2).sum(0), atol=1e-4)
+    mean, var = torch.empty(F, device=DEV), torch.empty(F, device=DEV)
+    mov_m, mov_v = torch.zeros(F, device=DEV), torch.ones(F, device=DEV)
+    ops.bn_finalize_ema(ws, B * S, F, mean, var, mov_m, mov_v)
+    assert np.allclose(mean.cpu().numpy(), g2.mean(0), atol=1e-6) and np.allclose(var.cpu().numpy(), g2.var(0), atol=1e-7)
+    assert np.allclose(mov_m.cpu().numpy(), 0.001 * g2.mean(0), atol=1e-8) and np.allclose(mov_v.cpu().numpy(), 1 - 0.001 * (1 - g2.var(0)), atol=1e-7)
+
+    # ---- input batch-norm ----
+    ga_in = (1 + 0.3 * rng.standard_normal(F)).astype(np.float32)
+    be_in = (0.2 * rng.standard_normal(F)).astype(np.float32)
+    r_bn = torch.full((Mp, F), 7.0, dtype=torch.bfloat16, device=DEV)
+    xhat = torch.full((Mp, F), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.dbof_input_bn_apply(r, B, S, F, mean, var, torch.from_numpy(ga_in).to(DEV), torch.from_numpy(be_in).to(DEV), r_bn, None, xhat)
+    xh_ref = (g2 - g2.mean(0)) / np.sqrt(g2.var(0) + 1e-3)
+    xh = xhat.float().cpu().numpy()
+    rb = r_bn.float().cpu().numpy()
+    assert np.abs(xh[rows].reshape(-1, F) - xh_ref).max() <= 2 ** -8 * np.abs(xh_ref).max() + 1e-6
+    assert np.abs(rb[rows].reshape(-1, F) - (xh_ref * ga_in + be_in)).max() <= 2 ** -8 * (np.abs(xh_ref).max() * 1.9 + 1)
+    assert not xh[~live].any() and not rb[~live].any()        # empty slots contribute nothing to the contractions
+
+    # ---- cluster GEMM + statistics + selection (both gamma signs) ----
+    W = (rng.standard_normal((C, F)) / np.sqrt(F)).astype(np.float32)
+    Wd = torch.from_numpy(W).to(DEV).bfloat16()
+    ga_cl = (1 + 0.3 * rng.standard_normal(C)).astype(np.float32)
+    ga_cl[::3] *= -1                                          # negative scales select the MINIMUM over the frames
+    be_cl = (0.5 * rng.standard_normal(C) + 1.0).astype(np.float32)
+    ga_d, be_d = torch.from_numpy(ga_cl).to(DEV), torch.from_numpy(be_cl).to(DEV)
+    act = torch.full((Mp, C), 7.0, dtype=torch.bfloat16, device=DEV)
+    part_cl = torch.full((P_cl, 2, C), float("nan"), device=DEV)
+    xsel = torch.empty((B, C), device=DEV)
+    arg = torch.empty((B, C), dtype=torch.uint8, device=DEV)
+    ops.dbof_cluster_pool_fwd(r_bn, Wd, B, S, F, C, ga_d, xsel, arg, act=act, part=part_cl)
+    a_ref = rb.astype(np.float64) @ Wd.float().cpu().numpy().astype(np.float64).T                # exact product of the bf16 operands
+    a_live = a_ref[rows]                                                                         # [B, S, C]
+    got_act = act.float().cpu().numpy()
+    assert np.abs(got_act - a_ref).max() <= 2 ** -8 * np.abs(a_ref).max() + 1e-5
+    wsc = torch.empty(2 * C, dtype=torch.float64, device=DEV)
+    ops.bn_partials_reduce(part_cl, P_cl, C, wsc)
+    assert np.allclose(wsc.cpu().numpy()[:C], a_live.sum((0, 1)), atol=2e-3) and np.allclose(wsc.cpu().numpy()[C:], (a_live ** 2).sum((0, 1)), rtol=1e-5, atol=2e-3)
+    sgn = np.where(ga_cl >= 0, 1.0, -1.0)
+    sel_ref = (a_live * sgn).max(1) * sgn                                                        # max for gamma >= 0, min otherwise
+    xs = xsel.cpu().numpy()
+    assert np.abs(xs - sel_ref).max() < 2e-5 * max(1.0, np.abs(sel_ref).max())
+    ar = arg.cpu().numpy().astype(np.int64)
+    assert ar.max() < S
+    picked = np.take_along_axis(a_live, ar[:, None, :], 1)[:, 0, :]
+    assert np.abs(picked - sel_ref).max() < 2e-5 * max(1.0, np.abs(sel_ref).max())               # the slot holds the selected value
+    mean_c, var_c = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ops.bn_finalize_ema(wsc, B * S, C, mean_c, var_c)
+    a2 = a_live.reshape(-1, C)
+    assert np.allclose(mean_c.cpu().numpy(), a2.mean(0), atol=1e-5) and np.allclose(var_c.cpu().numpy(), a2.var(0), rtol=1e-4, atol=1e-6)
+    # evaluation form: nothing kept, no statistics - same selection
+    xsel2, arg2 = torch.empty_like(xsel), torch.empty_like(arg)
+    ops.dbof_cluster_pool_fwd(r_bn, Wd, B, S, F, C, ga_d, xsel2, arg2)
+    assert torch.equal(xsel2, xsel) and torch.equal(arg2, arg)
+
+    # ---- pooled = relu6(bn(selected)) = max over frames of relu6(bn(act)) ----
+    pooled = torch.empty((B, C), device=DEV)
+    pooled_bf = torch.empty((B, C), dtype=torch.bfloat16, device=DEV)
+    ops.dbof_pool_finish(xsel, B, C, mean_c, var_c, ga_d, be_d, pooled, pooled_bf)
+    mu, rstd = a2.mean(0), 1 / np.sqrt(a2.var(0) + 1e-3)
+    y = mm.relu6((a_live - mu) * rstd * ga_cl + be_cl)
+    assert np.abs(pooled.cpu().numpy() - y.max(1)).max() < 1e-4
+    assert torch.equal(pooled_bf, pooled.bfloat16())
+
+    # ---- backward: d(act) in place ----
+    dpooled = rng.standard_normal((B, C)).astype(np.float32)
+    dp_d = torch.from_numpy(dpooled).to(DEV)
+    wsb = torch.empty(2 * C, dtype=torch.float64, device=DEV)
+    ops.bn_bwd_partial(xsel, dp_d, B, C, mean_c, var_c, ga_d, be_d, True, wsb)
+    pl = pooled.cpu().numpy()
+    dmask = dpooled * ((pl > 0) & (pl < 6))
+    xh_sel = (xs - mu) * rstd
+    assert np.allclose(wsb.cpu().numpy()[:C], dmask.sum(0), atol=1e-4) and np.allclose(wsb.cpu().numpy()[C:], (dmask * xh_sel).sum(0), atol=1e-3)
+    dgam, dbet = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ops.dbof_dact(act, dp_d, pooled, arg, mean_c, var_c, ga_d, wsb, B * S, B, S, C, dgam, dbet)
+    d_full = np.zeros((B, S, C))
+    np.put_along_axis(d_full, ar[:, None, :], dmask[:, None, :], 1)
+    xh_act = (got_act[rows] - mu) * rstd                       # the kernel reads the bf16 activation it stored
+    R = B * S
+    dact_ref = ga_cl * rstd * (d_full - dmask.sum(0) / R - xh_act * (dmask * xh_sel).sum(0) / R)
+    dact = act.float().cpu().numpy()
+    assert np.abs(dact[rows] - dact_ref).max() <= 2 ** -8 * np.abs(dact_ref).max() + 1e-6
+    assert not dact[~live].any()
+    assert np.allclose(dbet.cpu().numpy(), dmask.sum(0), atol=1e-4) and np.allclose(dgam.cpu().numpy(), (dmask * xh_sel).sum(0), atol=1e-3)
+
+    # ---- G = dact^T . xhat in slabs, then dWc / dgamma_in ----
+    G_ref = dact.astype(np.float64).T @ xh.astype(np.float64)
+    Wm = torch.from_numpy(W).to(DEV)
+    for nslab in (1, 3):
+        if Mp // 32 < nslab * 2:
+            continue
+        slabs = torch.full((nslab, C, F), float("nan"), device=DEV)
+        ops.gemm_tn_slabs(act, xhat, C, F, Mp, slabs, nslab)
+        assert np.abs(slabs.sum(0).cpu().numpy() - G_ref).max() <= 1e-4 * np.abs(G_ref).max() + 1e-5
+        dW, dg_in, db_in = torch.empty((C, F), device=DEV), torch.full((F,), 9.0, device=DEV), torch.full((F,), 9.0, device=DEV)
+        ops.dbof_wgrad_finish(slabs, nslab, C, F, Wm, torch.from_numpy(ga_in).to(DEV), dW, dg_in, db_in)
+        assert np.abs(dW.cpu().numpy() - ga_in * G_ref).max() <= 1e-4 * np.abs(G_ref).max() * 2 + 1e-5
+        assert np.abs(dg_in.cpu().numpy() - (W * G_ref).sum(0)).max() <= 1e-4 * np.abs((W * G_ref).sum(0)).max() + 1e-4
+        assert not db_in.cpu().numpy().any()
+    with pytest.raises(Exception, match="at most 32"):
+        ops.dbof_workspace(B, 33)
