@@ -64,7 +64,7 @@ SIGNATURES = {
     "evc_dbof_pool_finish": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
     "evc_dbof_dact": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp],
     "evc_gemm_tn_slabs": [vp, i64, vp, i64, vp, i32, i32, i32, i32, vp],
-    "evc_dbof_wgrad_finish": [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp],
+    "evc_dbof_wgrad_finish": [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp],
 }
 EXPORTS = tuple(SIGNATURES) + ("evc_version", "evc_last_error")
 

@@ -529,26 +529,47 @@ class SingleTowerGraph:
     FrameLevelLogisticModel).  The reference's train.py cannot run these
     (it unpacks the H-LSTM tuple, cs/train.py:282 - SURVEY.md Appendix D-8);
     this follows the upstream starter-code semantics it was forked from:
-    final_loss = regularization_penalty*reg + CE, one train op, global_step += 1."""
+    final_loss = regularization_penalty*reg + CE, one train op, global_step += 1.
+
+    Update: the MoE head's two weight matrices go through MoeHead.fused_update (gradient recomputed from its
+    rank-B factors inside the clip + Adam pass) whenever the step also applies; the other variables through
+    clip_by_norm + TF-Adam on the materialised gradients.
+    Data parallel: the gradients of each backward stage (MoE bias -> hidden layer -> cluster layer) are all-reduced on
+    a side stream as soon as the stage is final, under the rest of the backward pass; the MoE weights need no gradient
+    all-reduce at all (factor all-gather + row-sharded update, as in DistillGraph); batch-norm statistics and the
+    batch-norm scale/offset gradients of cluster_bn / hidden1_bn are global through the all-reduced f64 sums."""
 
     def __init__(self, tower, base_learning_rate=0.001, learning_rate_decay=1.0, learning_rate_decay_examples=4000000,
                  regularization_penalty=2.0, clip_gradient_norm=1.0, process_group=None):
         self.tower, self.device = tower, tower.device
         self.lr0, self.lr_decay, self.lr_decay_examples = base_learning_rate, learning_rate_decay, learning_rate_decay_examples
         self.reg_pen, self.clip, self.pg = regularization_penalty, clip_gradient_norm, process_group
-        self.world = 1
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            self.world = torch.distributed.get_world_size(process_group)
+        self.reducer = GradReducer(process_group)
+        self.world, self.dp = self.reducer.world, self.reducer.active
         self.global_step = 0
         self.losses = torch.zeros(4, dtype=F32, device=self.device)
         self._dp = None
+        self.moe = getattr(tower, "moe", None)
+        self.fused_moe_update = True
+        if self.dp and self.moe is not None and self.moe.can_fuse_update():
+            self.moe.shard(self.reducer.world, self.reducer.rank)      # while nothing is in flight
+        self._aux = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+
+    def consolidate(self):
+        """Collective (no-op on one rank): complete f32 MoE weights / moments on every rank (before a checkpoint)."""
+        if self.moe is not None:
+            self.moe.consolidate(self.reducer)
 
     def step(self, x_raw, labels_u8, num_frames, uniform=None, apply=True):
+        """x_raw [B,T,F] float32 or uint8 (as the reader delivers it: Dequantize is fused into the input kernels)."""
         from .towers import DbofTower
         B, V = labels_u8.shape
         if self._dp is None or self._dp.shape[0] != B:
             self._dp = torch.empty((B, V), dtype=F32, device=self.device)
         tw = self.tower
+        if self.dp and B != tw.B:
+            raise ValueError("data-parallel step on %d videos, the tower was built for %d per rank (ragged batches are not "
+                             "allowed under data parallelism: drop the remainder)" % (B, tw.B))
         if isinstance(tw, DbofTower):
             if uniform is None:
                 uniform = torch.rand((B, tw.S), dtype=F32, device=self.device)
@@ -558,14 +579,37 @@ class SingleTowerGraph:
             pred = tw.forward(x_raw, num_frames)
         self.losses.zero_()
         ops.ce_loss(pred, labels_u8, self.losses[0:1], self._dp, grad_scale=1.0 / (B * self.world))
-        tw.backward(self._dp)
-        if self.world > 1:
-            # SUM of the per-rank gradients; the batch-norm scale/offset gradients are already global (their f64
-            # partial sums were all-reduced inside BatchNorm.backward) and stay out of the reduce
-            for lo, hi in tw.grad_ranges(exclude=getattr(tw, "global_grad_names", ())):
-                torch.distributed.all_reduce(tw.store.grad[lo:hi], group=self.pg)
+        fuse = (apply and self.fused_moe_update and self.moe is not None and self.moe.can_fuse_update()
+                and tw.precision == "bf16")
+        if self.moe is not None and not fuse and getattr(self.moe, "_stale", False):
+            raise RuntimeError("the MoE weights are sharded over the ranks (fused data-parallel update); call consolidate() "
+                               "on every rank before a step that does not apply through it")
+        main = torch.cuda.current_stream(self.device)
+        stages = tw.grad_stages()
+        fused_names = (self.moe.GATES, self.moe.EXPERTS, self.moe.EBIAS) if fuse else ()    # (the bias gradient comes from the same factors)
+        skip = tuple(getattr(tw, "global_grad_names", ())) + fused_names
+
+        def on_stage(i):
+            # data parallel: SUM of this stage's per-rank gradients on the side stream, in stream order behind the kernels
+            # that produced them; batch-norm gradients that are already global and the fused MoE weights stay out
+            if not self.dp:
+                return
+            self._aux.wait_stream(main)
+            with torch.cuda.stream(self._aux):
+                for lo, hi in tw.grad_ranges(exclude=skip, only=stages[i]):
+                    self.reducer.reduce_async(tw.store.grad, lo, hi)
+
+        tw.backward(self._dp, moe_weight_grads=not fuse, on_stage=on_stage)
+        if self.dp:
+            main.wait_stream(self._aux)
         if apply:
             lr = exponential_decay(self.lr0, self.global_step, B * self.world, self.lr_decay_examples, self.lr_decay)
-            tw.apply_gradients(lr, self.clip, self.reg_pen * 1e-8)
+            l2c = self.reg_pen * 1e-8
+            if fuse:
+                tw.begin_update()
+                self.moe.fused_update(tw.adam_lr_t(lr), self.clip, l2c, dp=self.reducer if self.dp else None)
+                tw.apply_group([k for k in tw.names if k not in fused_names], lr, self.clip, l2c)
+            else:
+                tw.apply_gradients(lr, self.clip, l2c)
             self.global_step += 1
         return {"predictions": pred, "loss": self.losses[0], "global_step": self.global_step}

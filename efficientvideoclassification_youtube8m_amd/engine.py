@@ -474,6 +474,9 @@ class TowerBase:
 
     def state_dict(self):
         """TF-named, TF-layout copies (2-D weights are stored transposed internally)."""
+        if getattr(getattr(self, "moe", None), "_stale", False):
+            raise RuntimeError("the MoE weights of %r are sharded over the ranks; call consolidate() on the graph on "
+                               "every rank before reading them" % self.scope)
         out = OrderedDict()
         for k in self.names:
             p = self.store.p(k)
@@ -496,12 +499,12 @@ class TowerBase:
         if getattr(getattr(self, "moe", None), "_stale", False):
             self.moe._stale = False              # every rank has just loaded the complete weights
 
-    def grad_ranges(self, exclude=()):
-        """Maximal contiguous (lo, hi) element ranges of the flat gradient buffer that cover every variable not in
-        `exclude` (the payloads of a data-parallel all-reduce)."""
+    def grad_ranges(self, exclude=(), only=None):
+        """Maximal contiguous (lo, hi) element ranges of the flat gradient buffer that cover every variable (of `only`,
+        if given) not in `exclude` (the payloads of a data-parallel all-reduce)."""
         st, out = self.store, []
         for k in self.names:
-            if k in exclude:
+            if k in exclude or (only is not None and k not in only):
                 continue
             lo = st.offsets[k]
             hi = lo + _align(int(math.prod(st.shapes[k])))
@@ -592,12 +595,6 @@ class HLstmTower(TowerBase):
         self._alloc(batch_size)
 
     # ---- parameters -------------------------------------------------------
-    def state_dict(self):
-        if getattr(self.moe, "_stale", False):
-            raise RuntimeError("the MoE weights of %r are sharded over the ranks; call DistillGraph.consolidate() on "
-                               "every rank before reading them" % self.scope)
-        return super().state_dict()
-
     def _init_params(self, seed):
         """TF defaults at the reference call sites: glorot-uniform kernels /
         fully_connected weights, zero biases."""

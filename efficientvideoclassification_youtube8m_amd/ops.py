@@ -387,5 +387,8 @@ def gemm_tn_slabs(A, B, M, N, K, slabs, nslab):
     _lib.call("evc_gemm_tn_slabs", _p(A), A.stride(0), _p(B), B.stride(0), _p(slabs), M, N, K, nslab, _stream())
 
 
-def dbof_wgrad_finish(slabs, nslab, Cc, F, W, gamma_in, dW, dgamma_in, dbeta_in=None):
-    _lib.call("evc_dbof_wgrad_finish", _p(slabs), nslab, Cc, F, _p(W), _p(gamma_in), _p(dW), _p(dgamma_in), _p(dbeta_in), _stream())
+def dbof_wgrad_finish(slabs, nslab, Cc, F, W, gamma_in, dW, dgamma_in, dbeta_in=None, part_ws=None):
+    if part_ws is None:
+        part_ws = torch.empty(((Cc + 7) // 8, F), dtype=F32, device=dW.device)
+    _lib.call("evc_dbof_wgrad_finish", _p(slabs), nslab, Cc, F, _p(W), _p(gamma_in), _p(dW), _p(dgamma_in), _p(dbeta_in), _p(part_ws),
+              _stream())

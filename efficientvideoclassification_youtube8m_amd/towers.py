@@ -159,6 +159,7 @@ class DbofTower(TowerBase):
             self.dpooled = torch.empty((B, Cc), dtype=F32, device=dev)
             self.nslab = self._pick_nslab(Cc, F, Mp)
             self.slabs = torch.empty((self.nslab, Cc, F), dtype=F32, device=dev)
+            self.wgrad_ws = torch.empty(((Cc + 7) // 8, F), dtype=F32, device=dev)
 
     @staticmethod
     def _pick_nslab(M, N, K):
@@ -232,16 +233,30 @@ class DbofTower(TowerBase):
         self._taped = tape
         return self.moe.forward(self.h6)
 
-    def backward(self, dpred, on_moe_grads_ready=None):
+    def grad_stages(self):
+        """Variable names in the order their gradients become final during backward(): (moe, hidden, cluster)."""
+        moe = [MoeHead.GATES, MoeHead.EXPERTS, MoeHead.EBIAS]
+        hidden = [self.HW, "hidden1_bn/beta", "hidden1_bn/gamma"]
+        cluster = [k for k in self.names if k not in moe and k not in hidden]
+        return moe, hidden, cluster
+
+    def backward(self, dpred, on_moe_grads_ready=None, moe_weight_grads=True, on_stage=None):
+        """moe_weight_grads=False: the two MoE weight gradients are not materialised (MoeHead.fused_update recomputes
+        them from the factors inside the clip + Adam pass).  on_stage(i): called when the gradients of grad_stages()[i]
+        are final (a data-parallel caller starts that stage's all-reduce there, under the rest of the backward pass)."""
         assert self.training and self._taped, "backward needs a training-mode forward"
         B, F, S, Cc, Hd = self.B, self.F, self.S, self.Cc, self.Hd
         st = self.store
-        dh6 = self.moe.backward(dpred)
+        dh6 = self.moe.backward(dpred, weight_grads=moe_weight_grads)
         if on_moe_grads_ready is not None:
             on_moe_grads_ready()
+        if on_stage is not None:
+            on_stage(0)
         self.bn_h.backward(self.hid, dh6, B, True, dx_bf16=self.dhid_bf)
         # hidden1 weights: dWh^T [Hd][C] = dhid^T . pooled (TN over the batch rows); dpooled = dhid . Wh^T
         ops.gemm_tn(self.dhid_bf, self.pooled_bf, Hd, Cc, self.Bk, st.g(self.HW))
+        if on_stage is not None:
+            on_stage(1)
         ops.gemm_nt(self.dhid_bf, self.shadow_bwd[self.HW], B, Cc, Hd, self.dpooled)
         # max-pool routing + relu6 mask + cluster_bn backward: the two batch sums need only the [B][C] selected entries
         bn = self.bn_cl
@@ -252,7 +267,9 @@ class DbofTower(TowerBase):
         # G = dact^T . xhat in split-K slabs, then cluster weights / input_bn gradients from G
         ops.gemm_tn_slabs(self.act, self.xhat, Cc, F, self.Mp, self.slabs, self.nslab)
         ops.dbof_wgrad_finish(self.slabs, self.nslab, Cc, F, st.p(self.CW), self.bn_in.gamma(), st.g(self.CW),
-                              st.g("input_bn/gamma"), st.g("input_bn/beta"))
+                              st.g("input_bn/gamma"), st.g("input_bn/beta"), part_ws=self.wgrad_ws)
+        if on_stage is not None:
+            on_stage(2)
 
     @property
     def pred(self):
@@ -310,7 +327,10 @@ class LogisticTower(TowerBase):
         ops.sigmoid_(self.pred)
         return self.pred
 
-    def backward(self, dpred, on_moe_grads_ready=None):
+    def grad_stages(self):
+        return ([self.W, self.Bn],)
+
+    def backward(self, dpred, on_moe_grads_ready=None, moe_weight_grads=True, on_stage=None):
         B, V, F = self.B, self.V, self.F
         ops.sigmoid_bwd(self.pred, dpred, self.dz)
         ops.transpose_to_bf16(self.dz, B, V, self.dzT, self.Bp)
@@ -319,3 +339,5 @@ class LogisticTower(TowerBase):
         ops.rowsum_bf16(self.dzT, V, self.Bp, self.store.g(self.Bn))
         if on_moe_grads_ready is not None:
             on_moe_grads_ready()
+        if on_stage is not None:
+            on_stage(0)

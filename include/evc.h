@@ -376,9 +376,10 @@ int evc_dbof_dact(evc_bf16* act, const float* dpooled, const float* pooled, cons
 int evc_gemm_tn_slabs(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, float* slabs, int M, int N, int K,
                       int nslab, void* stream);
 /* G = sum of the slabs [nslab][C][F] (= dact^T . xhat): dW[c][f] = gamma_in[f]*G, dgamma_in[f] = sum_c W[c][f]*G,
- * dbeta_in = 0 (the batch-norm backward's output sums to zero over the batch). */
+ * dbeta_in = 0 (the batch-norm backward's output sums to zero over the batch).  part_ws: [ceil(C/8)][F] f32 scratch
+ * (per-block column sums, added in block order: run-to-run identical). */
 int evc_dbof_wgrad_finish(const float* slabs, int nslab, int C, int F, const float* W, const float* gamma_in, float* dW,
-                          float* dgamma_in, float* dbeta_in, void* stream);
+                          float* dgamma_in, float* dbeta_in, float* part_ws, void* stream);
 
 /* utility: out[i] = value for n floats (avoids torch for tiny fills inside C loops) */
 int evc_fill_f32(float* p, int64_t n, float value, void* stream);

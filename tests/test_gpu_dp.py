@@ -168,6 +168,7 @@ grads = {k: tw.store.g(k).clone().cpu() for k in tw.names}
 for it in range(2):
     g.step(xd, yd, nd, uniform=ud)
 torch.cuda.synchronize()
+g.consolidate()            # the fused data-parallel MoE update leaves the f32 weights sharded by rows (collective; no-op on one rank)
 if rank == 0:
     sd = {k: v.cpu() for k, v in tw.state_dict().items()}
     torch.save({"sd": sd, "grads": grads, "global_step": g.global_step}, out)
