@@ -145,25 +145,29 @@ extern "C" int evc_dbof_gather(const float* x_f32, const uint8_t* x_u8, const fl
 
 // Column partial sums [P][2][C] f32 (row p: sum x, then sum x^2) -> ws f64 [2C], rows added in index order
 // (run-to-run identical statistics; under data parallelism ws is what the ranks all-reduce).
-__global__ __launch_bounds__(256) void partials_to_f64_kernel(const float* __restrict__ part, int P, int C, double* __restrict__ ws) {
-  // block = 64 columns x 4 row phases; phase y adds rows y, y+4, ... in order, the four phase sums are added in order
-  __shared__ double sh[2][4][64];
+__global__ __launch_bounds__(1024) void partials_to_f64_kernel(const float* __restrict__ part, int P, int C, double* __restrict__ ws) {
+  // block = 64 columns x 16 row phases; phase y adds rows y, y+16, ... in order, the phase sums are added in phase order
+  __shared__ double sh[2][16][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
   double s = 0.0, q = 0.0;
-  if (c < C)
-    for (int p = ty; p < P; p += 4) { s += part[((long)p * 2) * C + c]; q += part[((long)p * 2 + 1) * C + c]; }
+  if (c < C) {
+#pragma unroll 4
+    for (int p = ty; p < P; p += 16) { s += part[((long)p * 2) * C + c]; q += part[((long)p * 2 + 1) * C + c]; }
+  }
   sh[0][ty][tx] = s;
   sh[1][ty][tx] = q;
   __syncthreads();
-  if (ty == 0 && c < C) {
-    ws[c] = ((sh[0][0][tx] + sh[0][1][tx]) + sh[0][2][tx]) + sh[0][3][tx];
-    ws[C + c] = ((sh[1][0][tx] + sh[1][1][tx]) + sh[1][2][tx]) + sh[1][3][tx];
+  if (ty < 2 && c < C) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += sh[ty][i][tx];
+    ws[ty * C + c] = t;
   }
 }
 extern "C" int evc_bn_partials_reduce(const float* part, int P, int C, double* ws, void* stream) {
   EVC_REQUIRE(P > 0 && C > 0 && part && ws, EVC_ERR_BAD_SHAPE, "evc_bn_partials_reduce: bad args");
-  hipLaunchKernelGGL(partials_to_f64_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, P, C, ws);
+  hipLaunchKernelGGL(partials_to_f64_kernel, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)stream, part, P, C, ws);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }

@@ -122,6 +122,25 @@ extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
     EVC_LAUNCH_CHECK();
     return EVC_OK;
   }
+  // A few hundred rows against a long K with few output columns (DBoF: hidden layer [512 x 8192] . [1024 x 8192]^T, the MoE
+  // head's dX at batch 512 with K = 14148 / 9432): eight 256x256 tiles cannot be split far enough to fill the chip (K/2048
+  // splits = 32-48 workgroups, measured 105 us for 8.6 GFLOP).  128x128 ring tiles at two workgroups per CU instead, K split
+  // until ~512 workgroups exist (>= 16 K steps each): the partial tiles are joined by f32 atomics into a zeroed C.
+  {
+    const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
+    if (!out_bf16 && M > 256 && t128 <= 128 && K >= 4096 && forced_tile() == 0) {
+      const int nk = K / 32;
+      int splits = (int)(512 / t128);
+      if (splits > nk / 16) splits = nk / 16;
+      while (splits > 1 && (long)ceil_div(nk, splits) * (splits - 1) >= nk) --splits;     // no empty split
+      if (splits > 1) {
+        if (!accumulate) EVC_CHECK_HIP(hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st));
+        launch_gemm<CfgTn128>(p, s, K, splits, st);
+        EVC_LAUNCH_CHECK();
+        return EVC_OK;
+      }
+    }
+  }
   // Split-K: a long-K product with too few 256x256 tiles to fill the 256 CUs (the weight-gradient
   // GEMMs: M=4H, N~1-2K, K = T*M rows) is cut along K; partial tiles are summed with f32 atomics
   // into a zeroed C (63 MB of atomic traffic at ~1.3 TB/s << the ~0.7 ms it saves per GEMM).
