@@ -70,8 +70,21 @@ def dp_loss_scales(world):
 
 
 class GradReducer:
-    """Bucketed asynchronous gradient all-reduce (SUM) on slices of a flat buffer.
-    backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests."""
+    """Gradient all-reduce (SUM) on slices of a flat buffer and the collectives of the row-sharded MoE update.
+    backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
+
+    Two ways to place the collectives (both give the same numbers; chosen per process by EVC_DP_SERIAL_COMM):
+
+    * default - every collective is a synchronous c10d op issued from inside the compute stream it belongs to, so the
+      RCCL kernel sits in stream order between the kernels that produce and consume its data; the student tower uses a
+      communicator of its own (DistillGraph), two communicators may be in flight on two streams at once.
+    * EVC_DP_SERIAL_COMM=1 - the conservative form for a first run on real xGMI: ONE communicator for everything and ONE
+      stream (`serial_stream`, shared by all reducers of the process) that every collective is funnelled through -
+      the issuing stream's work so far is awaited by event, the collective runs on the serial stream, the issuing stream
+      waits for it by event.  RCCL kernels of this process then execute strictly in host issue order (identical on all
+      ranks), never two at once; compute on the other streams still overlaps them."""
+
+    _serial_stream = None           # one per process
 
     def __init__(self, process_group=None):
         self.pg = process_group
@@ -84,10 +97,30 @@ class GradReducer:
         # collectives are issued when there is more than one rank; EVC_DP_FORCE=1 (debug) also issues them on a
         # one-rank group, which runs the whole RCCL path of a step on a single-GPU box (scripts/rccl_one_rank.sh)
         self.active = self.world > 1 or (init and os.environ.get("EVC_DP_FORCE") == "1")
+        self.serial = self.active and serial_comm() and torch.cuda.is_available()
         self._pending = []
+
+    def _run(self, fn, *tensors):
+        """Issue one collective: in stream order on the current stream, or through the process-wide serial stream."""
+        if not self.serial:
+            return fn()
+        cur = torch.cuda.current_stream()
+        if GradReducer._serial_stream is None:
+            GradReducer._serial_stream = torch.cuda.Stream()
+        ss = GradReducer._serial_stream
+        ss.wait_stream(cur)
+        with torch.cuda.stream(ss):
+            out = fn()
+        for t in tensors + ((out,) if torch.is_tensor(out) else ()):
+            t.record_stream(ss)
+        cur.wait_stream(ss)
+        return out
 
     def reduce(self, flat, lo, hi):
         if not self.active or hi <= lo:
+            return
+        if self.serial:
+            self.reduce_async(flat, lo, hi)
             return
         self._pending.append(torch.distributed.all_reduce(flat[lo:hi], op=torch.distributed.ReduceOp.SUM,
                                                           group=self.pg, async_op=True))
@@ -101,7 +134,8 @@ class GradReducer:
         instead of 13.5 ms per step (scripts/dp_host_probe.py).  Returns None (nothing left to wait for)."""
         if not self.active or hi <= lo:
             return None
-        torch.distributed.all_reduce(flat[lo:hi], op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=False)
+        seg = flat[lo:hi]
+        self._run(lambda: torch.distributed.all_reduce(seg, op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=False), seg)
         return None
 
     def all_gather_rows(self, t):
@@ -109,14 +143,18 @@ class GradReducer:
         moves raw bytes: gloo has neither bfloat16 nor int16).  Stream-ordered like reduce_async."""
         if not self.active:
             return t
-        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        torch.distributed.all_gather_into_tensor(out.view(torch.uint8), t.contiguous().view(torch.uint8), group=self.pg)
-        return out
+        t = t.contiguous()
+
+        def go():
+            out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            torch.distributed.all_gather_into_tensor(out.view(torch.uint8), t.view(torch.uint8), group=self.pg)
+            return out
+        return self._run(go, t)
 
     def all_reduce_small(self, t):
         """In-place SUM of a few floats (the partial norm sums of a sharded tensor), stream-ordered."""
         if self.active:
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=False)
+            self._run(lambda: torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=False), t)
 
     def all_gather_slabs(self, full, slab_rows):
         """full [world * slab_rows, cols] (contiguous): rank r owns rows [r*slab_rows, (r+1)*slab_rows); every
@@ -124,13 +162,22 @@ class GradReducer:
         if not self.active:
             return
         assert full.is_contiguous() and full.shape[0] == self.world * slab_rows
-        own = full[self.rank * slab_rows:(self.rank + 1) * slab_rows].clone()     # (24 MB at world 8: no aliasing of in / out)
-        torch.distributed.all_gather_into_tensor(full.view(torch.uint8), own.view(torch.uint8), group=self.pg)
+
+        def go():
+            own = full[self.rank * slab_rows:(self.rank + 1) * slab_rows].clone()     # (24 MB at world 8: no aliasing of in / out)
+            torch.distributed.all_gather_into_tensor(full.view(torch.uint8), own.view(torch.uint8), group=self.pg)
+            return own
+        self._run(go, full)
 
     def wait(self):
         for w in self._pending:
             w.wait()
         self._pending = []
+
+
+def serial_comm():
+    """EVC_DP_SERIAL_COMM=1: one communicator, one collective at a time (see GradReducer)."""
+    return os.environ.get("EVC_DP_SERIAL_COMM") == "1"
 
 
 def frame_counts_and_plans(g, num_frames, nh, need_teacher, need_student):
@@ -182,7 +229,7 @@ class DistillGraph:
         # backward) would queue behind the student's last gradient all-reduce and hold the teacher's whole update
         # chain back.  (new_group is collective: every rank constructs the graph.)
         self.reducer_s = self.reducer
-        if self.dp and mode == "teacher_student":
+        if self.dp and mode == "teacher_student" and not serial_comm():
             ranks = list(range(torch.distributed.get_world_size(process_group))) if process_group is None else None
             self.reducer_s = GradReducer(torch.distributed.new_group(ranks) if ranks is not None else process_group)
         self.global_step = 0

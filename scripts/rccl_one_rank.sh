@@ -2,9 +2,28 @@
 # The data-parallel step on ONE GPU with a one-rank RCCL communicator (EVC_DP_FORCE=1): every collective of the
 # step (per-group gradient all-reduces on the side streams, the MoE factor all-gathers, the student's own
 # communicator, the loss all-reduce) goes through RCCL; the result must match the plain single-GPU run.
+# Runs both placements of the collectives (distill.GradReducer): in stream order on two communicators (default) and
+# EVC_DP_SERIAL_COMM=1 (one communicator, one collective at a time), then the plain single-GPU step.
+#   bash scripts/rccl_one_rank.sh [out-file]      (default gpurun_out/rccl_one_rank.txt; copy to profiles/ to keep)
 set -e
 cd "$(dirname "$0")/.."
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-EVC_DP_FORCE=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
-    bench.py --gpus 1 --steps ${STEPS:-10} --warmup 3 --no_cpu_baseline
-python bench.py --gpus 1 --steps ${STEPS:-10} --warmup 3 --no_cpu_baseline
+OUT=${1:-gpurun_out/rccl_one_rank.txt}
+mkdir -p "$(dirname "$OUT")"
+: > "$OUT"
+run() {   # label, env assignments..., then the rest
+  local label=$1; shift
+  echo "== $label" | tee -a "$OUT"
+  env "$@" | python3 -c "
+import json, sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l)
+        print('ms_per_step %.3f  frames/s %.0f  losses %s' % (d['ms_per_step'], d['value'], d['losses']))" | tee -a "$OUT"
+}
+ARGS="bench.py --gpus 1 --steps ${STEPS:-10} --warmup 3 --no_cpu_baseline --no_secondary"
+run "one-rank RCCL, collectives in stream order, student on its own communicator (default)" EVC_DP_FORCE=1 \
+    python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 $ARGS
+run "one-rank RCCL, EVC_DP_SERIAL_COMM=1 (one communicator, one collective at a time)" EVC_DP_FORCE=1 EVC_DP_SERIAL_COMM=1 \
+    python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 $ARGS
+run "no process group (plain single-GPU step)" python3 $ARGS

@@ -55,10 +55,10 @@ if world > 1:
 '''
 
 
-def _run(world, out, port):
+def _run(world, out, port, env=None):
     code = WORKER % {"root": ROOT}
     procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(world), str(port), out], stdout=subprocess.PIPE,
-                              stderr=subprocess.STDOUT) for r in range(world)]
+                              stderr=subprocess.STDOUT, env=dict(os.environ, **(env or {}))) for r in range(world)]
     logs = []
     for p in procs:
         try:
@@ -71,10 +71,12 @@ def _run(world, out, port):
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
 
 
-def test_two_rank_data_parallel_matches_single_process(tmp_path):
+@pytest.mark.parametrize("serial", ["0", "1"])
+def test_two_rank_data_parallel_matches_single_process(tmp_path, serial):
+    """serial = "1": EVC_DP_SERIAL_COMM - one communicator, every collective funnelled through one stream."""
     one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
     _run(1, one, 29611)
-    _run(2, two, 29612)
+    _run(2, two, 29612 + int(serial), env={"EVC_DP_SERIAL_COMM": serial})
     a, b = torch.load(one), torch.load(two)
     assert a["global_step"] == b["global_step"] == 4
     for k in ("label_loss", "student_loss_state", "pred_loss", "student_label_loss"):
