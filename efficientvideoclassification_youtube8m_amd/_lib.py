@@ -24,7 +24,7 @@ SIGNATURES = {
     "evc_colsum_bf16": [vp, i64, i32, i32, i32, vp, vp],
     "evc_lstm_layer_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp],
     "evc_lstm_layer_fwd_hp": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp],
-    "evc_lstm_layer_bwd": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp],
+    "evc_lstm_layer_bwd": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "evc_transpose_to_bf16": [vp, i32, i64, i32, i32, vp, i64, i32, i32, vp],
     "evc_cast_f32_to_bf16": [vp, i64, i32, i32, vp, i64, vp],
     "evc_cast_f32_to_bf16_split": [vp, i64, i32, i32, vp, vp, i64, vp],
@@ -55,6 +55,7 @@ SIGNATURES = {
     "evc_framepool_max_fwd": [vp, i32, i32, i32, vp, vp, vp, vp],
     "evc_framepool_max_bwd": [vp, vp, i32, i32, i32, vp, vp],
     "evc_fill_f32": [vp, i64, f32, vp],
+    "evc_lstm_stack2_bwd": [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "evc_dbof_workspace": [i32, i32, vp, vp, vp],
     "evc_dbof_gather": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp],
     "evc_bn_partials_reduce": [vp, i32, i32, vp, vp],

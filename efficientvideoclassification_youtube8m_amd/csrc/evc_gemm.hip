@@ -883,6 +883,8 @@ struct LstmBwdParams {
   float* db;                // [4H] bias gradient (TF gate order), accumulated with atomics over rows and steps, or NULL
   int m_active;             // rows [m_active, M) are inactive at this step: tiles entirely beyond it only zero dz
   int M, H;
+  int fused_above;          // 1: the accumulator also holds the gradient from the layer above (second K segment, wavefront):
+                            // at a row's last step the final-state gradient is ADDED to it instead of replacing it
 };
 
 // Gate derivative of one (row, 4 consecutive units): dh[4] = what flowed back through the recurrent
@@ -937,7 +939,10 @@ __device__ __forceinline__ void lstm_bwd_finish(const LstmBwdParams& e, const in
     return;
   }
   float dh[4] = {dh_in[0], dh_in[1], dh_in[2], dh_in[3]};
-  if (e.t == q.ln - 1) { dh[0] = q.dhs.x; dh[1] = q.dhs.y; dh[2] = q.dhs.z; dh[3] = q.dhs.w; }
+  if (e.t == q.ln - 1) {     // nothing flows back through the recurrent product from the (inactive) later steps: dz_{t+1} of this row is 0
+    if (e.fused_above) { dh[0] += q.dhs.x; dh[1] += q.dhs.y; dh[2] += q.dhs.z; dh[3] += q.dhs.w; }
+    else { dh[0] = q.dhs.x; dh[1] = q.dhs.y; dh[2] = q.dhs.z; dh[3] = q.dhs.w; }
+  }
   if (e.dh_above) {
     dh[0] += __uint_as_float(q.dha.x << 16); dh[1] += __uint_as_float(q.dha.x & 0xffff0000u);
     dh[2] += __uint_as_float(q.dha.y << 16); dh[3] += __uint_as_float(q.dha.y & 0xffff0000u);
@@ -978,11 +983,14 @@ __device__ __forceinline__ void lstm_bwd_zero_tile(const LstmBwdParams& e, int m
   }
 }
 
-template <class Cfg>
-__global__ __launch_bounds__(Cfg::NT) void lstm_bwd_step_kernel(GemmOperands p, LstmBwdParams e, int tiles_m, int tiles_n) {
+// BATCH_LOADS: issue the epilogue loads of all MI fragments of a unit group before the first store (one workgroup per CU:
+// the only way to overlap them); false: fragment by fragment (fewer registers: the pair kernel runs two workgroups per CU
+// and hides the round trips behind the other workgroup's main loop)
+template <class Cfg, bool BATCH_LOADS = true>
+__device__ __forceinline__ void lstm_bwd_step_body(const GemmOperands& p, const LstmBwdParams& e, int bid, int tiles_m, int tiles_n) {
   static_assert(Cfg::G == 1, "bwd step is a plain GEMM over the H units");
   const int nwg = tiles_m * tiles_n;
-  const int id = xcd_remap(blockIdx.x, nwg);
+  const int id = xcd_remap(bid, nwg);
   int tm, tn;
   tile_of(id, tiles_m, tiles_n, tm, tn);
   const int m0 = tm * Cfg::BM, u0 = tn * Cfg::BU;
@@ -997,11 +1005,13 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_bwd_step_kernel(GemmOperands p, 
   for (int ni = 0; ni < Cfg::NI; ++ni) {
     const int u = u0 + tc.unit0 + ni * 16;
     if (u >= e.H) continue;
-    LstmBwdIn in[Cfg::MI];                             // load phase: every fragment of this unit group
+    LstmBwdIn in[BATCH_LOADS ? Cfg::MI : 1];            // load phase: every fragment of this unit group
+    if constexpr (BATCH_LOADS) {
 #pragma unroll
-    for (int mi = 0; mi < Cfg::MI; ++mi) {
-      const int m = m0 + tc.row0 + mi * 16;
-      lstm_bwd_load(e, m, u, m < e.M, in[mi]);
+      for (int mi = 0; mi < Cfg::MI; ++mi) {
+        const int m = m0 + tc.row0 + mi * 16;
+        lstm_bwd_load(e, m, u, m < e.M, in[mi]);
+      }
     }
     float bs[4][4];                                    // this lane's column sums over its rows: [unit][gate]
 #pragma unroll
@@ -1016,7 +1026,8 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_bwd_step_kernel(GemmOperands p, 
       asm volatile("" :: "v"(dh[0]), "v"(dh[1]), "v"(dh[2]), "v"(dh[3]));
 #else
       float dzv[4][4];
-      lstm_bwd_finish(e, m, u, dh, in[mi], dzv);
+      if constexpr (!BATCH_LOADS) lstm_bwd_load(e, m, u, m < e.M, in[0]);
+      lstm_bwd_finish(e, m, u, dh, in[BATCH_LOADS ? mi : 0], dzv);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -1034,6 +1045,27 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_bwd_step_kernel(GemmOperands p, 
         }
     }
   }
+}
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT) void lstm_bwd_step_kernel(GemmOperands p, LstmBwdParams e, int tiles_m, int tiles_n) {
+  lstm_bwd_step_body<Cfg>(p, e, blockIdx.x, tiles_m, tiles_n);
+}
+
+// BPTT wavefront of a two-layer stack: layer 0's step t+1 and layer 1's step t are independent, so one launch runs
+// both (workgroup-uniform choice between two argument sets).  Layer 0's role contracts [dz0_{t+2} | dz1_{t+1}] with
+// [Wh0 ; Wx1] (K = 8H: the gradient arriving from the layer above is the second K segment instead of a hoisted
+// dX product whose bf16 result is re-read by every step), layer 1's role is the plain step.  Role a (the longer K)
+// owns the first `na` workgroups.  Twice the tiles of a single step per launch: with 128x128 tiles (80 KB of LDS)
+// two workgroups share a CU and one's gate-derivative epilogue runs under the other's main loop.
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT, 4) void lstm_bwd_pair_kernel(GemmOperands pa, LstmBwdParams ea, int tma, GemmOperands pb,
+                                                                LstmBwdParams eb, int tmb, int tiles_n) {
+  const int na = tma * tiles_n;
+  const bool first = (int)blockIdx.x < na;           // workgroup-uniform: scalar selects, one copy of the code
+  const GemmOperands p = first ? pa : pb;
+  const LstmBwdParams e = first ? ea : eb;
+  lstm_bwd_step_body<Cfg, false>(p, e, first ? blockIdx.x : blockIdx.x - na, first ? tma : tmb, tiles_n);
 }
 
 // "Skinny" BPTT step for M ~ batch (the L2 stacks: 256 rows, K = 4H = 4096): with a 32x32 tile per
@@ -1296,8 +1328,13 @@ typedef TileCfg2<192, 1, 128, 2, 4, 5, true> CfgBwdV2_192;
 extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int T, int M, int Kin, int H,
                                   const void* gates, const evc_bf16* c_all, const float* dS_c, const float* dS_h, int64_t ld_dS,
                                   const evc_bf16* dh_above, float* dc_ws, evc_bf16* dz4, float* db,
-                                  const int32_t* row_map, const int32_t* rows_per_step, void* stream) {
+                                  const int32_t* row_map, const int32_t* rows_per_step, const evc_bf16* dz_above,
+                                  const evc_bf16* w_above, void* stream) {
   EVC_REQUIRE(T > 0 && M > 0 && H > 0 && Kin > 0 && H % 64 == 0, EVC_ERR_BAD_SHAPE, "evc_lstm_layer_bwd: bad shape");
+  EVC_REQUIRE((dz_above != nullptr) == (w_above != nullptr) && !(dz_above && dh_above), EVC_ERR_BAD_ARG,
+              "evc_lstm_layer_bwd: dz_above and w_above come together, and instead of dh_above");
+  EVC_REQUIRE(!dz_above || (((uintptr_t)dz_above % 16) == 0 && ((uintptr_t)w_above % 16) == 0 && H % 128 == 0), EVC_ERR_BAD_ALIGN,
+              "evc_lstm_layer_bwd: dz_above / w_above must be 16-byte aligned, H %% 128 == 0");
   EVC_REQUIRE(gates && c_all && ((uintptr_t)gates % 16) == 0 && ((uintptr_t)c_all % 8) == 0 && ((uintptr_t)dz4 % 16) == 0,
               EVC_ERR_BAD_ALIGN, "evc_lstm_layer_bwd: gates/c_all/dz4 alignment");
   EVC_REQUIRE(ld_dS % 4 == 0 && ((uintptr_t)dS_c % 16) == 0 && ((uintptr_t)dS_h % 16) == 0 && ((uintptr_t)dc_ws % 16) == 0 &&
@@ -1323,6 +1360,7 @@ extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int 
     }
     if ((long)ceil_div(ma, 32) * ceil_div(H, 32) <= 512) pick = 5;   // M ~ batch: K split over the waves, fragments straight from global
     if (forced_tile()) pick = forced_tile() - 1;          // debug: 1 -> 192, 2 -> 160, 3 -> 128, 4 -> v1 64, 5 -> v1 32, 6 -> skinny
+    if (dz_above && pick > 2) pick = 2;                   // the two-matrix K walk (B2) exists in the ring loop only
     GemmOperands p;
     p.M = M; p.Nu = H; p.group_stride = 0; p.nk1 = p.nk2 = 0;
     p.A1lo = p.A2lo = p.Blo = nullptr;
@@ -1330,6 +1368,11 @@ extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int 
     p.A2 = p.A1; p.lda2 = p.lda1;
     p.B = w_il + (long)Kin * 4 * H; p.ldb = 4L * H;   // rows Kin..Kin+H of the kernel = Wh [H][4H], same K order
     const int k1 = (t == T - 1) ? 0 : 4 * H;
+    if (dz_above) {      // [dz_{t+1} | dz_above_t] . [Wh ; Wx_above]^T: the upper layer's dX is contracted here (K = 8H)
+      p.A2 = dz_above + (long)t * M * 4 * H;
+      p.nk2 = 4 * H / 32;
+      p.B2 = w_above;
+    }
     LstmBwdParams e;
     e.len = len; e.t = t;
     e.gates = (const uint2*)gates + (long)t * M * H;
@@ -1339,7 +1382,7 @@ extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int 
     e.dh_above = dh_above ? dh_above + (long)t * M * H : nullptr;
     e.dc_ws = dc_ws; e.dz4 = (uint2*)dz4 + (long)t * M * H;
     e.row_map = row_map; e.db = db; e.m_active = Mt;
-    e.M = M; e.H = H;
+    e.M = M; e.H = H; e.fused_above = dz_above ? 1 : 0;
     switch (pick) {
       case 0: launch_lstm_bwd<CfgBwdV2_192>(p, e, k1, st); break;
       case 1: launch_lstm_bwd<CfgBwdV2_160>(p, e, k1, st); break;
@@ -1360,6 +1403,78 @@ extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int 
       }
       default: launch_lstm_bwd<CfgPlainSmall>(p, e, k1, st); break;
     }
+  }
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// ===========================================================================
+// Two-layer stack, BPTT in wavefront order (see lstm_bwd_pair_kernel): T + 1 dependent launches instead of 2T + the
+// hoisted dX product of the upper layer.  Layer 0 has input width Kin0, layer 1 input width H; both kernels in the
+// backward layout [in+H][4H] (4H axis gate-interleaved).  dS [M][4H] f32 = d(final state) as [c0 | h0 | c1 | h1].
+// ===========================================================================
+extern "C" int evc_lstm_stack2_bwd(const evc_bf16* w_il0, const evc_bf16* w_il1, const int32_t* len, int T, int M, int Kin0, int H,
+                                   const void* gates0, const evc_bf16* c_all0, const void* gates1, const evc_bf16* c_all1,
+                                   const float* dS, int64_t ld_dS, float* dc_ws0, float* dc_ws1, evc_bf16* dz0, evc_bf16* dz1,
+                                   float* db0, float* db1, const int32_t* row_map, const int32_t* rows_per_step, void* stream) {
+  EVC_REQUIRE(T > 0 && M > 0 && H > 0 && Kin0 > 0 && H % 128 == 0, EVC_ERR_BAD_SHAPE, "evc_lstm_stack2_bwd: bad shape (H %% 128)");
+  EVC_REQUIRE(gates0 && gates1 && c_all0 && c_all1 && dz0 && dz1 && dc_ws0 && dc_ws1 && dS, EVC_ERR_BAD_ARG, "evc_lstm_stack2_bwd: null operand");
+  EVC_REQUIRE(ld_dS % 4 == 0 && ((uintptr_t)dS % 16) == 0 && ((uintptr_t)dc_ws0 % 16) == 0 && ((uintptr_t)dc_ws1 % 16) == 0 &&
+              ((uintptr_t)dz0 % 16) == 0 && ((uintptr_t)dz1 % 16) == 0, EVC_ERR_BAD_ALIGN, "evc_lstm_stack2_bwd: 16-byte alignment");
+  if (rows_per_step)
+    for (int t = 0; t < T; ++t)
+      EVC_REQUIRE(rows_per_step[t] >= 0 && rows_per_step[t] <= M && (t == 0 || rows_per_step[t] <= rows_per_step[t - 1]), EVC_ERR_BAD_ARG,
+                  "evc_lstm_stack2_bwd: rows_per_step[%d]=%d must be non-increasing and within [0, M=%d]", t, rows_per_step[t], M);
+  typedef CfgBwdV2_128 Cfg;
+  hipStream_t st = (hipStream_t)stream;
+  const long slab = (long)M * H;
+  const int tn = ceil_div(H, Cfg::BU), tm = ceil_div(M, Cfg::BM);
+  auto base = [&](GemmOperands& p) {
+    p.M = M; p.Nu = H; p.group_stride = 0; p.nk1 = p.nk2 = 0;
+    p.A1lo = p.A2lo = p.Blo = nullptr; p.B2 = nullptr;
+    p.lda1 = p.lda2 = 4L * H; p.ldb = 4L * H;
+  };
+  auto tail = [&](LstmBwdParams& e, int layer, int t) {
+    e.len = len; e.t = t;
+    e.gates = (const uint2*)(layer ? gates1 : gates0) + (long)t * slab;
+    const evc_bf16* ca = layer ? c_all1 : c_all0;
+    e.c_new = ca + (long)(t + 1) * slab;
+    e.c_old = t > 0 ? ca + (long)t * slab : nullptr;
+    e.dS_c = dS + (long)(2 * layer) * H; e.dS_h = dS + (long)(2 * layer + 1) * H; e.ld_dS = ld_dS;
+    e.dh_above = nullptr;
+    e.dc_ws = layer ? dc_ws1 : dc_ws0;
+    e.dz4 = (uint2*)(layer ? dz1 : dz0) + (long)t * slab;
+    e.row_map = row_map; e.db = layer ? db1 : db0;
+    e.m_active = rows_per_step ? rows_per_step[t] : M;
+    e.M = M; e.H = H;
+    e.fused_above = layer == 0;
+  };
+  for (int i = 0; i <= T; ++i) {
+    const int t1 = T - 1 - i, t0 = T - i;            // layer 1 runs step t1, layer 0 step t0 = t1 + 1
+    GemmOperands pa, pb;
+    LstmBwdParams ea, eb;
+    const bool has_a = t0 <= T - 1, has_b = t1 >= 0;
+    if (has_a) {                                      // layer 0, step t0: [dz0_{t0+1} | dz1_{t0}] . [Wh0 ; Wx1]^T
+      base(pa);
+      pa.A1 = dz0 + (long)(t0 + 1 < T ? t0 + 1 : t0) * slab * 4;
+      pa.nk1 = (t0 == T - 1) ? 0 : 4 * H / 32;
+      pa.A2 = dz1 + (long)t0 * slab * 4;
+      pa.nk2 = 4 * H / 32;
+      pa.B = w_il0 + (long)Kin0 * 4 * H;              // Wh0: rows Kin0 .. Kin0+H-1 of layer 0's kernel
+      pa.B2 = w_il1;                                  // Wx1: rows 0 .. H-1 of layer 1's kernel
+      tail(ea, 0, t0);
+    }
+    if (has_b) {                                      // layer 1, step t1: dz1_{t1+1} . Wh1^T
+      base(pb);
+      pb.A1 = dz1 + (long)(t1 + 1 < T ? t1 + 1 : t1) * slab * 4;
+      pb.nk1 = (t1 == T - 1) ? 0 : 4 * H / 32;
+      pb.A2 = pb.A1;
+      pb.B = w_il1 + (long)H * 4 * H;                 // Wh1
+      tail(eb, 1, t1);
+    }
+    if (has_a && has_b) launch_cfg<Cfg>(lstm_bwd_pair_kernel<Cfg>, 2 * tm * tn, st, pa, ea, tm, pb, eb, tm, tn);
+    else if (has_a) launch_cfg<Cfg>(lstm_bwd_step_kernel<Cfg>, tm * tn, st, pa, ea, tm, tn);
+    else launch_cfg<Cfg>(lstm_bwd_step_kernel<Cfg>, tm * tn, st, pb, eb, tm, tn);
   }
   EVC_LAUNCH_CHECK();
   return EVC_OK;

@@ -43,6 +43,10 @@ struct GemmOperands {
   int Nu;                                // valid units per group
   // split-bf16 ("high" precision): low-order halves with the same strides; x = hi + lo to ~16 bits
   const bf16_t* A1lo; const bf16_t* A2lo; const bf16_t* Blo;
+  // v2 loop only: B rows for the A2 segment start at B2 (k index restarts at 0 there) instead of continuing behind the
+  // A1 segment's columns of B - two weight matrices with the same row stride contracted back to back (the BPTT
+  // wavefront: [dz0_{t+1} | dz1_t] . [Wh0 ; Wx1]^T).  nullptr: B's k index runs on.
+  const bf16_t* B2 = nullptr;
 };
 
 // XCD-aware bijective remap of the linear workgroup id: consecutive remapped

@@ -93,7 +93,7 @@ __device__ __forceinline__ void gemm_mainloop_v2(const GemmOperands& p, const in
     b_off[i] = ((long)g * p.group_stride + gu) * p.ldb + lc8;
     b_dst[i] = live ? Cfg::A_BYTES + c0 * 16 : -1;
   }
-  const bf16_t* b_base = p.B;
+  const bf16_t* const b2 = p.B2 ? p.B2 - (long)p.nk1 * 32 : p.B;   // base such that b2 + kt*32 addresses the A2 segment's B columns
   int kt_issue = 0;   // next K step to stage
   int slot_issue = 0, slot_read = 0;   // ring slots (STAGES need not be a power of two)
 
@@ -103,6 +103,7 @@ __device__ __forceinline__ void gemm_mainloop_v2(const GemmOperands& p, const in
     const bool s1 = kt_issue < p.nk1;
     const bf16_t* ab = s1 ? p.A1 + (long)kt_issue * 32 : p.A2 + (long)(kt_issue - p.nk1) * 32;
     const long lda = s1 ? p.lda1 : p.lda2;
+    const bf16_t* b_base = (s1 ? p.B : b2) + (long)kt_issue * 32;
     char* sbase = lds + slot_issue * Cfg::STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < Cfg::ACH; ++i) {
@@ -116,7 +117,6 @@ __device__ __forceinline__ void gemm_mainloop_v2(const GemmOperands& p, const in
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_base + b_off[i]),
                                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
-    b_base += 32;
     ++kt_issue;
     slot_issue = (slot_issue + 1 == Cfg::STAGES) ? 0 : slot_issue + 1;
   };

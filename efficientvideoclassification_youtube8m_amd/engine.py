@@ -99,6 +99,7 @@ class LstmStack:
                 self.xT = torch.empty((max(self.kin), self.KP), dtype=BF16, device=dev)
                 self.hT_ws = torch.empty((H, self.KP), dtype=BF16, device=dev)
             self.dc_ws = torch.empty((M, H), dtype=F32, device=dev)
+            self.dc_ws2 = torch.empty((M, H), dtype=F32, device=dev) if L == 2 else None    # wavefront BPTT: both layers in flight
             # dX of layer l > 0 = the dh arriving at layer l-1: bf16 (read once per BPTT step of the layer below)
             self.dx = [torch.empty((T * M, self.kin[l]), dtype=BF16, device=dev) if (l > 0) else None for l in range(L)]
 
@@ -107,6 +108,14 @@ class LstmStack:
         return base + "kernel", base + "bias"
 
     wavefront = os.environ.get("EVC_NO_WAVEFRONT") != "1"   # two-layer M ~ batch stacks: see forward()
+    # two-layer stacks with many rows (the L1 levels), the gradient arriving at layer 0 from layer 1:
+    #   "off"   (default) one hoisted dX = dz1 . Wx1^T product over all T (bf16 result, re-read by layer 0's steps);
+    #   "fused" contracted inside layer 0's BPTT steps (two-matrix K walk, K = 8H, f32 accumulator);
+    #   "pair"  fused + wavefront order: layer 0's step t+1 and layer 1's step t in one launch (evc_lstm_stack2_bwd).
+    # Measured on the headline step (DESIGN.md "Measured and dropped"): 12.75 / 12.95 / 12.89 ms - the step kernels' main
+    # loops are L2->LDS-bound, so FLOPs moved into them cost more than the 1 PF/s hoisted product saves; kept for A/B runs.
+    bwd_fuse = os.environ.get("EVC_BWD_FUSE", "off")
+    bwd_wavefront = True          # (tests toggle this to compare the fused forms against the hoisted one)
     timing = None      # set to a list to collect (start event, end event, launches, algorithmic flops) per layer forward
 
     @staticmethod
@@ -216,6 +225,34 @@ class LstmStack:
         main = torch.cuda.current_stream(tw.device)
         use_tn = (T * M) % 32 == 0 and all(k % 8 == 0 for k in self.kin)
         assert use_tn or not self.use_tn or M == self.M
+        fuse_ok = L == 2 and self.bwd_wavefront and use_tn and not need_dx and M >= 1024 and H % 128 == 0
+        if fuse_ok and self.bwd_fuse == "pair":
+            (k0, b0), (k1, b1) = self.names(0), self.names(1)
+            dz = [self._v(self.dz[l], T, M, 4 * H) for l in range(2)]
+            gb = [tw.store.g(b0), tw.store.g(b1)]
+            for g in gb:
+                ops.fill_f32(g, 0.0)
+            ops.lstm_stack2_bwd(tw.shadow_bwd[k0], tw.shadow_bwd[k1], self.lens, T, M, self.kin[0], H,
+                                [self._v(self.gates[l], T, M, H, 2) for l in range(2)],
+                                [self._v(self.c_all[l], T + 1, M, H) for l in range(2)], dS,
+                                [self._v(self.dc_ws, M, H), self._v(self.dc_ws2, M, H)], dz, gb, plan=plan)
+            side = main
+            if aux is not None:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                aux.wait_event(ev)
+                side = aux
+            with torch.cuda.stream(side):
+                for l, kn in ((1, k1), (0, k0)):
+                    kin = self.kin[l]
+                    gW = tw.store.g(kn)
+                    dz2 = dz[l].view(T * M, 4 * H)
+                    layer_in = (self.x_in if l == 0 else self._hb[0][1:]).reshape(T * M, kin)
+                    h_prev = self._hb[l][:T].reshape(T * M, H)
+                    ops.fill_f32(gW, 0.0)
+                    ops.gemm_tn(dz2, layer_in, 4 * H, kin, T * M, gW, row_interleave_H=H, ldc=kin + H, accumulate=True)
+                    ops.gemm_tn(dz2, h_prev, 4 * H, H, T * M, gW[:, kin:], row_interleave_H=H, ldc=kin + H, accumulate=True)
+            return None
         for l in range(L - 1, -1, -1):
             kn, bn = self.names(l)
             w = tw.shadow_bwd[kn]                                   # [kin+H][4H] bf16, 4H axis gate-interleaved
@@ -224,12 +261,17 @@ class LstmStack:
             dz = self._v(self.dz[l], T, M, 4 * H)
             gb = tw.store.g(bn)                                     # bias gradient: summed inside the step kernels
             ops.fill_f32(gb, 0.0)
+            fused = fuse_ok and self.bwd_fuse == "fused" and l + 1 < L
             ops.lstm_layer_bwd(w, self.lens, T, M, kin, H, self._v(self.gates[l], T, M, H, 2), self._v(self.c_all[l], T + 1, M, H),
                                dS[:, (2 * l) * H:], dS[:, (2 * l + 1) * H:], 2 * L * H,
-                               dh_above, self._v(self.dc_ws, M, H), dz, plan=plan, db=gb)
+                               dh_above, self._v(self.dc_ws, M, H), dz, plan=plan, db=gb,
+                               dz_above=self._v(self.dz[l + 1], T, M, 4 * H) if fused else None,
+                               w_above=tw.shadow_bwd[self.names(l + 1)[0]] if fused else None)
             dz2 = dz.view(T * M, 4 * H)
             # gradient wrt the layer input, all T at once (hoisted): dX = dz . Wx^T
-            if l > 0:
+            if l > 0 and fuse_ok and self.bwd_fuse == "fused":
+                pass                                                # contracted inside layer l-1's steps (dz_above)
+            elif l > 0:
                 dxl = self._v(self.dx[l], T * M, kin)
                 ops.gemm_nt(dz2, w, T * M, kin, 4 * H, dxl)
                 dh_above = dxl

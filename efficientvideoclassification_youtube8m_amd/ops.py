@@ -213,10 +213,20 @@ def lstm_layer_fwd_hp(x, x_lo, wT, wT_lo, bias, lens, T, M, Kin, H, hbuf, hbuf_l
               _p(hbuf), _p(hbuf_lo), _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_all), *_plan_args(plan), _stream())
 
 
-def lstm_layer_bwd(w_il, lens, T, M, Kin, H, gates, c_all, dS_c, dS_h, ld_dS, dh_above, dc_ws, dz4, plan=None, db=None):
-    """db [4H] f32: the bias gradient is accumulated into it (zero it first) - no separate column-sum pass."""
+def lstm_layer_bwd(w_il, lens, T, M, Kin, H, gates, c_all, dS_c, dS_h, ld_dS, dh_above, dc_ws, dz4, plan=None, db=None,
+                   dz_above=None, w_above=None):
+    """db [4H] f32: the bias gradient is accumulated into it (zero it first) - no separate column-sum pass.
+    dz_above / w_above (instead of dh_above): the upper layer's gate gradients and backward-layout kernel - its dX is
+    contracted inside this layer's steps."""
     _lib.call("evc_lstm_layer_bwd", _p(w_il), _p(lens), T, M, Kin, H, _p(gates), _p(c_all), _p(dS_c), _p(dS_h), ld_dS,
-              _p(dh_above), _p(dc_ws), _p(dz4), _p(db), *_plan_args(plan), _stream())
+              _p(dh_above), _p(dc_ws), _p(dz4), _p(db), *_plan_args(plan), _p(dz_above), _p(w_above), _stream())
+
+
+def lstm_stack2_bwd(w_il0, w_il1, lens, T, M, Kin0, H, gates, c_all, dS, dc_ws, dz, db, plan=None):
+    """Two-layer stack, BPTT in wavefront order (evc_lstm_stack2_bwd).  gates / c_all / dc_ws / dz / db: per-layer pairs."""
+    _lib.call("evc_lstm_stack2_bwd", _p(w_il0), _p(w_il1), _p(lens), T, M, Kin0, H, _p(gates[0]), _p(c_all[0]), _p(gates[1]),
+              _p(c_all[1]), _p(dS), dS.stride(0), _p(dc_ws[0]), _p(dc_ws[1]), _p(dz[0]), _p(dz[1]), _p(db[0]), _p(db[1]),
+              *_plan_args(plan), _stream())
 
 
 # ---------------------------------------------------------------------------

@@ -178,11 +178,16 @@ int evc_lstm_stack2_fwd(const evc_bf16* x, const evc_bf16* wT0, const float* bia
  * Row plan (see evc_lstm_layer_fwd): rows_per_step [T] host counts, row_map = the row of dS_c / dS_h of each
  *        slot.  Every dz4 row is still written (zeros beyond the active prefix), because the
  *        weight-gradient products contract over all T*M rows.
+ * dz_above [T][M][H][4] bf16 + w_above [H][4H] bf16 (both or neither; instead of dh_above): the gate gradients of the
+ *        layer above and the x-rows of ITS kernel in the backward layout - the gradient arriving at h_t from above is
+ *        then contracted inside this layer's step, [dz_{t+1} | dz_above_t] . [Wh ; Wx_above]^T with K = 8H, kept in the
+ *        f32 accumulator (no hoisted dX product, no bf16 round trip).  Needs H % 128 == 0.
  */
 int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int T, int M, int Kin, int H,
                        const void* gates, const evc_bf16* c_all, const float* dS_c, const float* dS_h, int64_t ld_dS,
                        const evc_bf16* dh_above, float* dc_ws, evc_bf16* dz4, float* db,
-                       const int32_t* row_map, const int32_t* rows_per_step, void* stream);
+                       const int32_t* row_map, const int32_t* rows_per_step, const evc_bf16* dz_above,
+                       const evc_bf16* w_above, void* stream);
 
 /* ---- a5 + a8 + a9 fused: MoE weight update without materialising the gradient ----------------
  * d(loss)/dW of slim.fully_connected (cs/video_level_models.py:423-435) is dlogits^T . x over the batch rows:
@@ -329,6 +334,17 @@ int evc_bn_relu6_framepool_fwd(const float* act, int B, int S, int C, const floa
 int evc_framepool_max_fwd(const float* y, int B, int S, int C, float* pooled_f32, evc_bf16* pooled_bf16,
                           int32_t* argmax, void* stream);
 int evc_framepool_max_bwd(const float* dpooled, const int32_t* argmax, int B, int S, int C, float* dy, void* stream);
+
+/* Two-layer stack, BPTT in wavefront order: layer 0's step t+1 and layer 1's step t share a launch (T+1 dependent
+ * launches instead of 2T) and the gradient arriving at layer 0 from layer 1 is contracted inside layer 0's step
+ * ([dz0 | dz1] . [Wh0 ; Wx1]^T, K = 8H) instead of a hoisted dX product.  No reference counterpart: tf.gradients of
+ * cs/frame_level_models.py:221-257.  w_il0 [Kin0+H][4H], w_il1 [2H][4H] (backward layout, 4H gate-interleaved);
+ * dS [M][4H] f32 = [c0 | h0 | c1 | h1]; dz0/dz1 [T][M][H][4] bf16 out; dc_ws0/1 [M][H] f32 scratch; db0/db1 [4H]
+ * accumulated (zero them first); row_map / rows_per_step as in evc_lstm_layer_bwd.  H % 128 == 0. */
+int evc_lstm_stack2_bwd(const evc_bf16* w_il0, const evc_bf16* w_il1, const int32_t* len, int T, int M, int Kin0, int H,
+                        const void* gates0, const evc_bf16* c_all0, const void* gates1, const evc_bf16* c_all1,
+                        const float* dS, int64_t ld_dS, float* dc_ws0, float* dc_ws1, evc_bf16* dz0, evc_bf16* dz1,
+                        float* db0, float* db1, const int32_t* row_map, const int32_t* rows_per_step, void* stream);
 
 /* ---- a10 fused: the [frames x clusters] activation never leaves the chip in f32 ---------------------------
  * (cs/frame_level_models.py:126-167: reshape -> input_bn -> matmul(cluster_weights) -> cluster_bn -> relu6 ->

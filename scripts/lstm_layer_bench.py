@@ -84,3 +84,22 @@ if a.shape == "l2":      # the two-layer wavefront form of the same stack (evc_l
     c2 = [c_all, torch.zeros_like(c_all)]
     ms = timeit(lambda: ops.lstm_stack2_fwd(x, wT, b, w1T, b, lens_d, T, P, Kin, H, zx2, hbuf, hb1, S4, g2, c2))
     print("stack2 wavefront fwd (2 layers, T=%d, M=%d): %.3f ms" % (T, M, ms))
+
+if a.shape in ("teacher", "student"):      # the two-layer BPTT wavefront (evc_lstm_stack2_bwd) against two layer-wise passes + the hoisted dX product
+    w1 = torch.empty((2 * H, 4 * H), dtype=torch.bfloat16, device=dev)
+    ops.transpose_to_bf16((torch.randn(4 * H, 2 * H, device=dev) * 0.02).to(torch.bfloat16), 4 * H, 2 * H, w1, 4 * H, interleave_H=H)
+    g2, c2 = [gates, gates.clone()], [c_all, c_all.clone()]
+    dz2 = [dz4, torch.zeros_like(dz4)]
+    dc2 = [dcw, torch.empty_like(dcw)]
+    db2 = [torch.zeros(4 * H, device=dev), torch.zeros(4 * H, device=dev)]
+    dS4 = torch.randn(M, 4 * H, device=dev)
+    ms = timeit(lambda: ops.lstm_stack2_bwd(w_il, w1, lens_d, T, P, Kin, H, g2, c2, dS4, dc2, dz2, db2, plan=plan))
+    dxl = torch.empty((T * P, H), dtype=torch.bfloat16, device=dev)
+
+    def layerwise():
+        ops.lstm_layer_bwd(w1, lens_d, T, P, H, H, g2[1], c2[1], dS4[:, 2 * H:], dS4[:, 3 * H:], 4 * H, None, dc2[1], dz2[1], plan=plan)
+        ops.gemm_nt(dz2[1].view(T * P, 4 * H), w1, T * P, H, 4 * H, dxl)
+        ops.lstm_layer_bwd(w_il, lens_d, T, P, Kin, H, g2[0], c2[0], dS4[:, :H], dS4[:, H:], 4 * H, dxl.view(T, P, H), dc2[0], dz2[0], plan=plan)
+    ms2 = timeit(layerwise)
+    fl = sum(2.0 * r * 4 * H * H * (2 if t < T - 1 else 0) for t, r in enumerate(rows)) + 2.0 * sum(rows) * 4 * H * H
+    print("two-layer BPTT: wavefront %.3f ms (%.1f us/launch, %.0f TF/s) | layer-wise + hoisted dX %.3f ms" % (ms, ms / (T + 1) * 1e3, fl / ms / 1e9, ms2))

@@ -324,3 +324,41 @@ def test_moe_update_in_two_phases_on_row_slabs_equals_the_whole():
     # a phase outside 0..2 is refused
     with pytest.raises(Exception):
         ops.moe_grad_update(dlog, x, rows, V, K, pb, mb, vb, pbb, pTb, 2e-8, sb, ws, 1.0, 1e-3, phase=3)
+
+
+def test_fused_upper_layer_gradient_in_bptt_matches_hoisted_path_and_oracle():
+    """Two-layer L1 stacks with >= 1024 chunk rows contract the upper layer's dX inside the lower layer's BPTT steps
+    ([dz0_{t+1} | dz1_t] . [Wh0 ; Wx1]^T): "fused" (layer after layer, the product's default) and "pair" (wavefront order,
+    evc_lstm_stack2_bwd) against the hoisted dX product with its bf16 round trip ("off") and the float64 oracle."""
+    from efficientvideoclassification_youtube8m_amd import smoke
+    from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
+    from efficientvideoclassification_youtube8m_amd.engine import LstmStack
+    B, F, H, V = 64, 64, 128, 40                    # teacher L1: 20 x 64 = 1280 chunk rows (row-planned: fewer live)
+    q, x, n, labels = mm.synthetic_batch(B, seed=17, feature_size=F, vocab_size=V, dtype=np.float32)
+    n[:3] = (300, 1, 0)
+    n[3:40] = 300                                   # enough live chunk rows for the fused path (>= 1024)
+    x[np.arange(300)[None, :] >= n[:, None]] = 0.0
+    xd, yd, nd = (torch.from_numpy(x).to(DEV), torch.from_numpy(labels.astype(np.uint8)).to(DEV), torch.from_numpy(n).to(DEV))
+    grads = {}
+    saved = LstmStack.bwd_fuse
+    try:
+        for mode in ("fused", "pair", "off"):
+            LstmStack.bwd_fuse = mode
+            g = DistillGraph(B, every_n=10, feature_size=F, vocab_size=V, lstm_cells=H, device=DEV, seed=4)
+            g.step(xd, yd, nd, apply=False, num_frames_host=n)
+            assert g.teacher.l1.Mrun >= 1024 and g.student.l1.Mrun < 1024       # the student's L1 (5 x 64 rows) stays on the hoisted form
+            grads[mode] = smoke.tower_grads_numpy(g.teacher)
+            if mode == "fused":
+                teacher, student = smoke.tower_params_numpy(g.teacher), smoke.tower_params_numpy(g.student)
+    finally:
+        LstmStack.bwd_fuse = saved
+    ref = mm.teacher_student_step(x.astype(np.float64), n, labels, teacher, student, 10)["teacher_grads"]
+    for k in mm.HLSTM_PARAM_ORDER:
+        if not k.startswith("RNN_L1"):
+            continue
+        for mode in ("fused", "pair"):
+            a, b = grads[mode][k], grads["off"][k]
+            # (the hoisted path rounds the upper layer's dX to bf16 before adding it; the fused forms keep it in the f32 accumulator)
+            assert _rel(a, b) < 1e-2, (mode, k, _rel(a, b))
+            assert _rel(a, ref[k]) < 3e-2 and _rel(a, ref[k]) <= _rel(b, ref[k]) * 1.5 + 1e-3, (mode, k, _rel(a, ref[k]), _rel(b, ref[k]))
+        assert _rel(grads["fused"][k], grads["pair"][k]) < 1e-3, k
