@@ -126,9 +126,10 @@ extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
   // head's dX at batch 512 with K = 14148 / 9432): eight 256x256 tiles cannot be split far enough to fill the chip (K/2048
   // splits = 32-48 workgroups, measured 105 us for 8.6 GFLOP).  128x128 ring tiles at two workgroups per CU instead, K split
   // until ~512 workgroups exist (>= 16 K steps each): the partial tiles are joined by f32 atomics into a zeroed C.
+  // (M <= 512 only: streams.concurrent_streams probes with a 1024 x 1024 x 4096 product that must stay on 64 workgroups.)
   {
     const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
-    if (!out_bf16 && M > 256 && t128 <= 128 && K >= 4096 && forced_tile() == 0) {
+    if (!out_bf16 && M > 256 && M <= 512 && t128 <= 128 && K >= 4096 && forced_tile() == 0) {
       const int nk = K / 32;
       int splits = (int)(512 / t128);
       if (splits > nk / 16) splits = nk / 16;

@@ -21,6 +21,10 @@
 #pragma once
 #include "gemm_core.h"
 
+#ifndef EVC_PRIO_MODE
+#define EVC_PRIO_MODE 0     // 0: s_setprio 1 around every K step's MFMA cluster; 1: static - the second-dispatched half of the
+#endif                      // workgroup (waves 4-7) at priority 1 for the whole loop, no flips; 2: no priority changes
+
 template <int BM_, int G_, int BU_, int WR_, int WC_, int STAGES_ = 5, bool PIPE_ = true>
 struct TileCfg2 {
   static constexpr int BM = BM_, G = G_, BU = BU_, BN = G_ * BU_, WR = WR_, WC = WC_;
@@ -198,6 +202,9 @@ __device__ __forceinline__ void gemm_mainloop_v2(const GemmOperands& p, const in
   for (int i = 0; i < Cfg::STAGES - 1; ++i)
     if (i < nk) stage();
 
+#if EVC_PRIO_MODE == 1
+  if (wave >= Cfg::WR * Cfg::WC / 2) __builtin_amdgcn_s_setprio(1);
+#endif
   if constexpr (Cfg::PIPE) {
     // Software-pipelined: iteration kt makes step kt+1 visible, refills the ring, starts the
     // fragment reads of kt+1 and runs the MFMAs of step kt from registers.
@@ -207,14 +214,18 @@ __device__ __forceinline__ void gemm_mainloop_v2(const GemmOperands& p, const in
       wait_vmcnt<(AHEAD - 1) * Cfg::PER>();
       __builtin_amdgcn_s_barrier();   // step kt+1 landed for every wave; every wave has consumed step kt-1's fragments
       asm volatile("" ::: "memory");
+#if EVC_PRIO_MODE == 0
       __builtin_amdgcn_s_setprio(1);
+#endif
       stage();                        // refill step kt-1's slot with step kt+STAGES-1
       read_frags(afn, bfn);
       mfma_all(afc, bfc);
 #ifndef EVC_NO_INTERLEAVE
       interleave_pipe();
 #endif
+#if EVC_PRIO_MODE == 0
       __builtin_amdgcn_s_setprio(0);
+#endif
       end_of_step();
     };
     auto tail_step = [&](int kt, const bf16x8 (&afc)[Cfg::MI], const bf16x8 (&bfc)[Cfg::G][Cfg::NI],
