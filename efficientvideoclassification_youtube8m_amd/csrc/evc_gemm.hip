@@ -32,6 +32,55 @@ struct StoreParams {
   int splits, ksteps_per_split;   // split-K: blockIdx = split * tiles + tile; partial sums joined by f32 atomics
 };
 
+// Epilogue of the ring-tile (v2) kernels for a plain overwrite of C: every wave transposes its WM x WU sub-tile through
+// its own slice of the (idle) LDS ring and stores whole rows of the sub-tile, 16 bytes per lane.  From the accumulator
+// layout itself a store instruction touches 16-64 different lines with 2-32 bytes each, and the stores of a bf16 output
+// were issue-bound: 0.41 -> 0.33 ms on 16384 x 8192 x 1152 (DESIGN.md 4.6 has the same measurement on the DBoF kernel).
+// acc: TRANSPOSED accumulators (lane 16g + l: row mi*16 + l, columns ni*16 + 4g .. 4g+3).  ES = bytes per output element.
+template <class Cfg, int ES>
+__device__ __forceinline__ void store_tile_via_lds(f32x4 (&acc)[Cfg::MI][1][Cfg::NI], char* lds, void* C, long ldc, int M,
+                                                   int m0, int u0, const float* bias) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave / Cfg::WC, wc = wave % Cfg::WC;
+  const int l = lane & 15, g = lane >> 4;
+  constexpr int RS = Cfg::WU * ES + 16;                        // padded row: 16-byte aligned reads, <= 2-way conflicts on the writes
+  constexpr int RP_MAX = (Cfg::LDS_BYTES / (Cfg::WR * Cfg::WC)) / RS / 16 * 16;   // rows of the sub-tile per pass (multiple of 16)
+  constexpr int RP = RP_MAX >= Cfg::WM ? Cfg::WM : RP_MAX;
+  static_assert(RP >= 16, "LDS slice too small for one accumulator block");
+  constexpr int CPR = Cfg::WU * ES / 16;                       // 16-byte chunks per sub-tile row
+  constexpr int RPI = 64 / CPR;                                // rows per store instruction
+  static_assert(64 % CPR == 0 && RP % RPI == 0, "sub-tile rows must divide into whole store instructions");
+  char* wl = lds + wave * (RP * RS);
+  const int colw = u0 + wc * Cfg::WU;
+  const int rbase = m0 + wr * Cfg::WM;
+  float4 bv[Cfg::NI];
+#pragma unroll
+  for (int ni = 0; ni < Cfg::NI; ++ni)
+    bv[ni] = bias ? *(const float4*)(bias + colw + ni * 16 + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int r0 = 0; r0 < Cfg::WM; r0 += RP) {
+    if (r0 > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous pass's reads have their data (same wave, in order)
+#pragma unroll
+    for (int mi = r0 / 16; mi < (r0 + RP) / 16 && mi < Cfg::MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < Cfg::NI; ++ni) {
+        const f32x4 a = acc[mi][0][ni];
+        const float v0 = a[0] + bv[ni].x, v1 = a[1] + bv[ni].y, v2 = a[2] + bv[ni].z, v3 = a[3] + bv[ni].w;
+        char* d = wl + (mi * 16 - r0 + l) * RS + (ni * 16 + g * 4) * ES;
+        if constexpr (ES == 2) *(uint2*)d = make_uint2(pack_bf16x2_hw(v0, v1), pack_bf16x2_hw(v2, v3));
+        else *(float4*)d = make_float4(v0, v1, v2, v3);
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < RP / RPI; ++it) {
+      const int rl = it * RPI + lane / CPR;
+      const uint4 q = *(const uint4*)(wl + rl * RS + (lane % CPR) * 16);
+      const int row = rbase + r0 + rl;
+      if (row < M && r0 + rl < Cfg::WM) *(uint4*)((char*)C + ((long)row * ldc + colw) * ES + (lane % CPR) * 16) = q;
+    }
+  }
+}
+
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::NT) void gemm_nt_kernel(GemmOperands p, StoreParams s, int tiles_m, int tiles_n) {
   const int nwg = tiles_m * tiles_n;
@@ -50,32 +99,74 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_nt_kernel(GemmOperands p, StoreP
   tile_of(id, tiles_m, tiles_n, tm, tn, s.splits > 1 ? patch_rows(nwg, tiles_n) : 8);
   const int m0 = tm * Cfg::BM, u0 = tn * Cfg::BU;
   f32x4 acc[Cfg::MI][Cfg::G][Cfg::NI];
-  run_mainloop<Cfg, Cfg::G>(p, m0, u0, acc);
-  TileCoords<Cfg> tc;
-#pragma unroll
-  for (int mi = 0; mi < Cfg::MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < Cfg::NI; ++ni) {
-      const int n = u0 + tc.unit0 + ni * 16;
-      if (n >= s.N) continue;
-      const float b = (s.bias && split == 0) ? s.bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + tc.row0 + mi * 16 + r;
-        if (m >= s.M) continue;
-        float v = acc[mi][0][ni][r] + b;
-        const long o = (long)m * s.ldc + n;
-        if (s.splits > 1) {
-          atomicAdd((float*)s.C + o, v);          // one global_atomic_add_f32 per element, executed at the memory side
-        } else if (s.out_bf16) {
-          ((bf16_t*)s.C)[o] = f32_to_bf16(v);
-        } else {
-          float* cp = (float*)s.C + o;
-          if (s.accumulate) v += *cp;
-          *cp = v;
-        }
+  constexpr bool V2 = is_v2<Cfg>::value;
+  run_mainloop<Cfg, Cfg::G, V2>(p, m0, u0, acc);     // ring tiles: transposed accumulators (lane = one row, 4 consecutive columns)
+  if constexpr (V2) {
+    // plain overwrite with 16-byte-aligned rows: whole-line stores through LDS (kernel-uniform condition: one barrier)
+    const int es = s.out_bf16 ? 2 : 4;
+    const bool lds_path = s.splits == 1 && !s.accumulate && (s.ldc * es) % 16 == 0 && ((uintptr_t)s.C % 16) == 0 &&
+                          (!s.bias || ((uintptr_t)s.bias % 16) == 0);
+    const int wave = threadIdx.x >> 6, wc = wave % Cfg::WC;
+    const bool wave_cols_in = u0 + wc * Cfg::WU + Cfg::WU <= s.N;         // this wave's column span lies inside C
+    if (lds_path) {
+      __syncthreads();                                                   // every wave has read its last ring slot
+      if (wave_cols_in) {
+        if (s.out_bf16) store_tile_via_lds<Cfg, 2>(acc, lds_dyn, s.C, s.ldc, s.M, m0, u0, s.bias);
+        else store_tile_via_lds<Cfg, 4>(acc, lds_dyn, s.C, s.ldc, s.M, m0, u0, s.bias);
+        return;
       }
     }
+    TileCoordsT<Cfg> tc;                               // element-wise: split-K atomics, accumulate, ragged right edge
+#pragma unroll
+    for (int mi = 0; mi < Cfg::MI; ++mi) {
+      const int m = m0 + tc.row0 + mi * 16;
+      if (m >= s.M) continue;
+#pragma unroll
+      for (int ni = 0; ni < Cfg::NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = u0 + tc.unit0 + ni * 16 + r;
+          if (n >= s.N) continue;
+          float v = acc[mi][0][ni][r] + ((s.bias && split == 0) ? s.bias[n] : 0.f);
+          const long o = (long)m * s.ldc + n;
+          if (s.splits > 1) {
+            atomicAdd((float*)s.C + o, v);          // one global_atomic_add_f32 per element, executed at the memory side
+          } else if (s.out_bf16) {
+            ((bf16_t*)s.C)[o] = f32_to_bf16(v);
+          } else {
+            float* cp = (float*)s.C + o;
+            if (s.accumulate) v += *cp;
+            *cp = v;
+          }
+        }
+    }
+  } else {
+    TileCoords<Cfg> tc;
+#pragma unroll
+    for (int mi = 0; mi < Cfg::MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < Cfg::NI; ++ni) {
+        const int n = u0 + tc.unit0 + ni * 16;
+        if (n >= s.N) continue;
+        const float b = (s.bias && split == 0) ? s.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + tc.row0 + mi * 16 + r;
+          if (m >= s.M) continue;
+          float v = acc[mi][0][ni][r] + b;
+          const long o = (long)m * s.ldc + n;
+          if (s.splits > 1) {
+            atomicAdd((float*)s.C + o, v);          // one global_atomic_add_f32 per element, executed at the memory side
+          } else if (s.out_bf16) {
+            ((bf16_t*)s.C)[o] = f32_to_bf16(v);
+          } else {
+            float* cp = (float*)s.C + o;
+            if (s.accumulate) v += *cp;
+            *cp = v;
+          }
+        }
+      }
+  }
 }
 
 typedef TileCfg<128, 1, 128, 2, 2> CfgPlainBig;   // 128x128, 4 waves, 4x4 MFMA tiles per wave

@@ -664,3 +664,53 @@ def test_dbof_fused_kernels_against_oracle(ops, B, S, F, C, u8):
         assert not db_in.cpu().numpy().any()
     with pytest.raises(Exception, match="at most 32"):
         ops.dbof_workspace(B, 33)
+
+
+NT_STORE_WORKER = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %(root)r)
+from efficientvideoclassification_youtube8m_amd import ops
+torch.manual_seed(0)
+dev = "cuda:0"
+worst = 0.0
+for (M, N, K) in ((512, 512, 128), (777, 1000, 192), (300, 264, 64), (2000, 72, 256), (256, 4096, 1024)):
+    A = (torch.randn(M, K, device=dev) * 0.5).bfloat16()
+    B = (torch.randn(N, K, device=dev) * 0.5).bfloat16()
+    bias = torch.randn(N, device=dev)
+    ref = A.double() @ B.double().t()
+    for out_dtype in (torch.float32, torch.bfloat16):
+        for use_bias in (False, True):
+            # row stride: the natural one, and one that breaks the 16-byte row alignment (element-wise fallback)
+            for ld in (N, N + 1):
+                buf = torch.full((M, ld), 7.0, dtype=out_dtype, device=dev)
+                ops.gemm_nt(A, B, M, N, K, buf, bias=bias if use_bias else None, ldc=ld)
+                want = ref + (bias.double() if use_bias else 0.0)
+                got = buf[:, :N].double()
+                tol = (2 ** -8 if out_dtype == torch.bfloat16 else 1e-5) * want.abs().max().item() + 1e-4
+                err = (got - want).abs().max().item()
+                assert err <= tol, (M, N, K, str(out_dtype), use_bias, ld, err, tol)
+                if ld > N:
+                    assert bool((buf[:, N:] == 7.0).all()), "wrote outside the N columns"
+                worst = max(worst, err)
+    acc = torch.randn(M, N, device=dev)
+    want = acc.double() + ref
+    ops.gemm_nt(A, B, M, N, K, acc, accumulate=True)
+    assert (acc.double() - want).abs().max().item() <= 1e-5 * want.abs().max().item() + 1e-4
+print("ok", worst)
+'''
+
+
+@pytest.mark.parametrize("tile", ["0", "1", "4"])
+def test_gemm_nt_ring_tile_store_paths(tile):
+    """The ring-tile NT kernels store a plain overwrite of C through a per-wave LDS transpose (whole rows of the sub-tile, 16
+    bytes per lane) and fall back to element-wise stores for split-K / accumulate / unaligned rows / the ragged right edge:
+    f32 and bf16 outputs, bias, ragged M and N, odd row strides, on the 256x256 (EVC_FORCE_TILE=1), 224x256 (=4) and
+    automatically chosen (=0: also the 256x64 batch-row form) tiles.  One process per forced tile (the choice is read once)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("EVC_FORCE_TILE", None)
+    if tile != "0":
+        env["EVC_FORCE_TILE"] = tile
+    r = subprocess.run([sys.executable, "-c", NT_STORE_WORKER % {"root": root}], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
