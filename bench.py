@@ -136,7 +136,9 @@ def run_hlstm(device, rank, world, B, mode, every_n, steps, warmup, all_full=Fal
            "executed_tflop_per_step": round(float(np.mean([g[1] for g in gf])) / 1e3, 3),
            "losses": {k: round(v, 4) for k, v in graph.loss_report().items()}}
     res["executed_tflops"] = round(res["executed_tflop_per_step"] / (res["ms_per_step"] * 1e-3), 1)
-    if roofline:
+    if roofline and not l1_stack.timing:
+        l1_stack.timing = None                      # (the split-bf16 forward has no per-layer event hooks: no roofline object)
+    elif roofline:
         # lstm_fwd_step_kernel<TileCfg2<BM,4,64,..>> (30 launches per iteration, the largest FLOP share of the
         # recurrent path).  Live timing with HIP events on the launch stream around each layer's 15-step launch
         # sequence in every timed step; algorithmic FLOPs = 2*rows_t*4H*K of each step GEMM over the rows that
@@ -408,7 +410,7 @@ def main():
                        "executed_tflop_per_step_per_gpu": head["executed_tflop_per_step"]},
             "executed_tflops_per_gpu": head["executed_tflops"],
             "losses": head["losses"], "gap_at_20_last_batch": head["gap_at_20_last_batch"],
-            "roofline": head["roofline"],
+            "roofline": head.get("roofline"),
         }
         res.update(extra)
         if n_gpus == 1 and not args.no_cpu_baseline:

@@ -362,3 +362,34 @@ def test_fused_upper_layer_gradient_in_bptt_matches_hoisted_path_and_oracle():
             assert _rel(a, b) < 1e-2, (mode, k, _rel(a, b))
             assert _rel(a, ref[k]) < 3e-2 and _rel(a, ref[k]) <= _rel(b, ref[k]) * 1.5 + 1e-3, (mode, k, _rel(a, ref[k]), _rel(b, ref[k]))
         assert _rel(grads["fused"][k], grads["pair"][k]) < 1e-3, k
+
+
+def test_high_precision_mode_on_ring_tiles():
+    """L1 stacks with >= 1024 live chunk rows run the split-bf16 forward on the ring tiles (three passes of the loop: hi.hi +
+    hi.lo + lo.hi); below that on the v1 64-row tiles.  Both against the float64 oracle on weights scaled up so that plain
+    bf16 is visibly off."""
+    from efficientvideoclassification_youtube8m_amd import smoke
+    from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
+    B, F, H, V = 64, 64, 128, 40                    # teacher L1: 20 x 64 = 1280 chunk rows
+    q, x, n, labels = mm.synthetic_batch(B, seed=23, feature_size=F, vocab_size=V, dtype=np.float32)
+    n[3:44] = 300
+    x[np.arange(300)[None, :] >= n[:, None]] = 0.0
+    xd, yd, nd = (torch.from_numpy(x).to(DEV), torch.from_numpy(labels.astype(np.uint8)).to(DEV), torch.from_numpy(n).to(DEV))
+    errs = {}
+    for prec in ("high", "bf16"):
+        g = DistillGraph(B, every_n=10, feature_size=F, vocab_size=V, lstm_cells=H, device=DEV, seed=6, precision=prec)
+        for tw in (g.teacher, g.student):           # O(1) recurrent states: scale the LSTM kernels up
+            for k in tw.names:
+                if k.endswith("basic_lstm_cell/kernel"):
+                    tw.store.p(k).mul_(3.0)
+            tw.refresh_shadows()
+        out = g.step(xd, yd, nd, apply=False, num_frames_host=n)
+        assert g.teacher.l1.Mrun >= 1024
+        teacher, student = smoke.tower_params_numpy(g.teacher), smoke.tower_params_numpy(g.student)
+        ref = mm.teacher_student_step(x.astype(np.float64), n, labels, teacher, student, 10, with_grads=False)
+        errs[prec] = (float(np.abs(out["teacher_state"].cpu().numpy() - ref["teacher_state"]).max()),
+                      float(np.abs(out["predictions"].cpu().numpy() - ref["teacher_predictions"]).max()),
+                      float(np.abs(ref["teacher_state"]).max()))
+    print("ring-tile high precision (state err, pred err, |state|):", errs)
+    assert errs["high"][0] < 1e-4 * max(1.0, errs["high"][2]) and errs["high"][1] < 2e-5
+    assert errs["bf16"][0] > 30 * errs["high"][0]
