@@ -37,9 +37,10 @@ struct StoreParams {
 // layout itself a store instruction touches 16-64 different lines with 2-32 bytes each, and the stores of a bf16 output
 // were issue-bound: 0.41 -> 0.33 ms on 16384 x 8192 x 1152 (DESIGN.md 4.6 has the same measurement on the DBoF kernel).
 // acc: TRANSPOSED accumulators (lane 16g + l: row mi*16 + l, columns ni*16 + 4g .. 4g+3).  ES = bytes per output element.
-template <class Cfg, int ES>
-__device__ __forceinline__ void store_tile_via_lds(f32x4 (&acc)[Cfg::MI][1][Cfg::NI], char* lds, void* C, long ldc, int M,
+template <class Cfg, int ES, bool ATOMIC = false>
+__device__ __forceinline__ void store_tile_via_lds(f32x4 (&acc)[Cfg::MI][1][Cfg::NI], char* lds, void* C, long ldc, int M, int N,
                                                    int m0, int u0, const float* bias) {
+  static_assert(!ATOMIC || ES == 4, "split-K partial tiles are joined in f32");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave / Cfg::WC, wc = wave % Cfg::WC;
   const int l = lane & 15, g = lane >> 4;
@@ -47,16 +48,25 @@ __device__ __forceinline__ void store_tile_via_lds(f32x4 (&acc)[Cfg::MI][1][Cfg:
   constexpr int RP_MAX = (Cfg::LDS_BYTES / (Cfg::WR * Cfg::WC)) / RS / 16 * 16;   // rows of the sub-tile per pass (multiple of 16)
   constexpr int RP = RP_MAX >= Cfg::WM ? Cfg::WM : RP_MAX;
   static_assert(RP >= 16, "LDS slice too small for one accumulator block");
-  constexpr int CPR = Cfg::WU * ES / 16;                       // 16-byte chunks per sub-tile row
-  constexpr int RPI = 64 / CPR;                                // rows per store instruction
-  static_assert(64 % CPR == 0 && RP % RPI == 0, "sub-tile rows must divide into whole store instructions");
+  // read-back: plain stores move 16 bytes per lane (whole sub-tile rows); the split-K join moves ONE float per lane so that a
+  // wave-instruction's atomics cover contiguous runs of a row (global float atomics run at full rate on 256 contiguous bytes
+  // and ~17x slower on 64 scattered dwords - which is what the transposed accumulator layout would issue directly)
+  constexpr int CPR = ATOMIC ? Cfg::WU : Cfg::WU * ES / 16;    // lanes per sub-tile row
+  constexpr int RPI = 64 / CPR;                                // rows per instruction
+  static_assert(64 % CPR == 0 && RP % RPI == 0, "sub-tile rows must divide into whole instructions");
   char* wl = lds + wave * (RP * RS);
   const int colw = u0 + wc * Cfg::WU;
   const int rbase = m0 + wr * Cfg::WM;
   float4 bv[Cfg::NI];
 #pragma unroll
-  for (int ni = 0; ni < Cfg::NI; ++ni)
-    bv[ni] = bias ? *(const float4*)(bias + colw + ni * 16 + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int ni = 0; ni < Cfg::NI; ++ni) {
+    bv[ni] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) {
+      const int c = colw + ni * 16 + g * 4;
+      if (!ATOMIC) bv[ni] = *(const float4*)(bias + c);
+      else bv[ni] = make_float4(c < N ? bias[c] : 0.f, c + 1 < N ? bias[c + 1] : 0.f, c + 2 < N ? bias[c + 2] : 0.f, c + 3 < N ? bias[c + 3] : 0.f);
+    }
+  }
 #pragma unroll
   for (int r0 = 0; r0 < Cfg::WM; r0 += RP) {
     if (r0 > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous pass's reads have their data (same wave, in order)
@@ -74,9 +84,15 @@ __device__ __forceinline__ void store_tile_via_lds(f32x4 (&acc)[Cfg::MI][1][Cfg:
 #pragma unroll
     for (int it = 0; it < RP / RPI; ++it) {
       const int rl = it * RPI + lane / CPR;
-      const uint4 q = *(const uint4*)(wl + rl * RS + (lane % CPR) * 16);
       const int row = rbase + r0 + rl;
-      if (row < M && r0 + rl < Cfg::WM) *(uint4*)((char*)C + ((long)row * ldc + colw) * ES + (lane % CPR) * 16) = q;
+      if constexpr (ATOMIC) {
+        const int c = lane % CPR;
+        const float v = *(const float*)(wl + rl * RS + c * 4);
+        if (row < M && r0 + rl < Cfg::WM && colw + c < N) atomicAdd((float*)C + (long)row * ldc + colw + c, v);
+      } else {
+        const uint4 q = *(const uint4*)(wl + rl * RS + (lane % CPR) * 16);
+        if (row < M && r0 + rl < Cfg::WM) *(uint4*)((char*)C + ((long)row * ldc + colw) * ES + (lane % CPR) * 16) = q;
+      }
     }
   }
 }
@@ -102,21 +118,26 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_nt_kernel(GemmOperands p, StoreP
   constexpr bool V2 = is_v2<Cfg>::value;
   run_mainloop<Cfg, Cfg::G, V2>(p, m0, u0, acc);     // ring tiles: transposed accumulators (lane = one row, 4 consecutive columns)
   if constexpr (V2) {
-    // plain overwrite with 16-byte-aligned rows: whole-line stores through LDS (kernel-uniform condition: one barrier)
+    // plain overwrite with 16-byte-aligned rows, or the split-K join: through LDS (kernel-uniform conditions: one barrier)
     const int es = s.out_bf16 ? 2 : 4;
-    const bool lds_path = s.splits == 1 && !s.accumulate && (s.ldc * es) % 16 == 0 && ((uintptr_t)s.C % 16) == 0 &&
-                          (!s.bias || ((uintptr_t)s.bias % 16) == 0);
+    const bool lds_store = s.splits == 1 && !s.accumulate && (s.ldc * es) % 16 == 0 && ((uintptr_t)s.C % 16) == 0 &&
+                           (!s.bias || ((uintptr_t)s.bias % 16) == 0);
     const int wave = threadIdx.x >> 6, wc = wave % Cfg::WC;
     const bool wave_cols_in = u0 + wc * Cfg::WU + Cfg::WU <= s.N;         // this wave's column span lies inside C
-    if (lds_path) {
+    if (s.splits > 1) {
       __syncthreads();                                                   // every wave has read its last ring slot
+      store_tile_via_lds<Cfg, 4, true>(acc, lds_dyn, s.C, s.ldc, s.M, s.N, m0, u0, split == 0 ? s.bias : nullptr);
+      return;
+    }
+    if (lds_store) {
+      __syncthreads();
       if (wave_cols_in) {
-        if (s.out_bf16) store_tile_via_lds<Cfg, 2>(acc, lds_dyn, s.C, s.ldc, s.M, m0, u0, s.bias);
-        else store_tile_via_lds<Cfg, 4>(acc, lds_dyn, s.C, s.ldc, s.M, m0, u0, s.bias);
+        if (s.out_bf16) store_tile_via_lds<Cfg, 2>(acc, lds_dyn, s.C, s.ldc, s.M, s.N, m0, u0, s.bias);
+        else store_tile_via_lds<Cfg, 4>(acc, lds_dyn, s.C, s.ldc, s.M, s.N, m0, u0, s.bias);
         return;
       }
     }
-    TileCoordsT<Cfg> tc;                               // element-wise: split-K atomics, accumulate, ragged right edge
+    TileCoordsT<Cfg> tc;                               // element-wise: accumulate, unaligned rows, the ragged right edge
 #pragma unroll
     for (int mi = 0; mi < Cfg::MI; ++mi) {
       const int m = m0 + tc.row0 + mi * 16;
@@ -257,8 +278,13 @@ extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
   const double c_small = tile_cost((long)ceil_div(M, 64) * ceil_div(N, 64), 64, 64, 4, 2.6);
   int pick = (c_v2 <= c_big && c_v2 <= c_small) ? 1 : (c_big <= c_small ? 2 : 3);
   if (pick == 1 && c_v2b < c_v2) pick = 4;
+  // 128x128 ring tiles (LDS-DMA ring instead of the v1 two-stage loop): 20-25 % faster than the v1 128x128 tile while the
+  // whole product is one round of <= 256 tiles (measured: 1024 x 4096 x 4096 50 vs 63 us, 2048^3 28 vs 38, 1280 x 1024 x 4096
+  // 45 vs 58); beyond that two workgroups share a CU's L2 ingest and the v1 / 256x256 tiles win again
+  if (pick == 2 && K >= 2048 && (long)ceil_div(M, 128) * ceil_div(N, 128) <= 256) pick = 5;
   if (forced_tile()) pick = forced_tile();
-  if (pick == 4) launch_gemm<CfgPlainV2_224>(p, s, K, 1, st);
+  if (pick == 5) launch_gemm<CfgTn128>(p, s, K, 1, st);
+  else if (pick == 4) launch_gemm<CfgPlainV2_224>(p, s, K, 1, st);
   else if (pick == 1) launch_gemm<CfgPlainV2>(p, s, K, 1, st);
   else if (pick == 2) launch_gemm<CfgPlainBig>(p, s, K, 1, st);
   else launch_gemm<CfgPlainSmall>(p, s, K, 1, st);
