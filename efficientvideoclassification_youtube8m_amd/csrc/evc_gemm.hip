@@ -37,9 +37,9 @@ struct StoreParams {
 // layout itself a store instruction touches 16-64 different lines with 2-32 bytes each, and the stores of a bf16 output
 // were issue-bound: 0.41 -> 0.33 ms on 16384 x 8192 x 1152 (DESIGN.md 4.6 has the same measurement on the DBoF kernel).
 // acc: TRANSPOSED accumulators (lane 16g + l: row mi*16 + l, columns ni*16 + 4g .. 4g+3).  ES = bytes per output element.
-template <class Cfg, int ES, bool ATOMIC = false>
+template <class Cfg, int ES, bool ATOMIC = false, bool RMW = false>     // RMW: C += tile by plain 16-byte read-modify-write (f32)
 __device__ __forceinline__ void store_tile_via_lds(f32x4 (&acc)[Cfg::MI][1][Cfg::NI], char* lds, void* C, long ldc, int M, int N,
-                                                   int m0, int u0, const float* bias) {
+                                                   int m0, int u0, const float* bias, int row_il_H = 0) {
   static_assert(!ATOMIC || ES == 4, "split-K partial tiles are joined in f32");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave / Cfg::WC, wc = wave % Cfg::WC;
@@ -85,13 +85,23 @@ __device__ __forceinline__ void store_tile_via_lds(f32x4 (&acc)[Cfg::MI][1][Cfg:
     for (int it = 0; it < RP / RPI; ++it) {
       const int rl = it * RPI + lane / CPR;
       const int row = rbase + r0 + rl;
+      const long orow = row_il_H > 0 ? (long)(row & 3) * row_il_H + (row >> 2) : row;   // gate de-interleave of the TN weight gradients
       if constexpr (ATOMIC) {
         const int c = lane % CPR;
         const float v = *(const float*)(wl + rl * RS + c * 4);
-        if (row < M && r0 + rl < Cfg::WM && colw + c < N) atomicAdd((float*)C + (long)row * ldc + colw + c, v);
+        if (row < M && r0 + rl < Cfg::WM && colw + c < N) atomicAdd((float*)C + orow * ldc + colw + c, v);
       } else {
-        const uint4 q = *(const uint4*)(wl + rl * RS + (lane % CPR) * 16);
-        if (row < M && r0 + rl < Cfg::WM) *(uint4*)((char*)C + ((long)row * ldc + colw) * ES + (lane % CPR) * 16) = q;
+        uint4 q = *(const uint4*)(wl + rl * RS + (lane % CPR) * 16);
+        if (row < M && r0 + rl < Cfg::WM) {
+          uint4* cp = (uint4*)((char*)C + (orow * ldc + colw) * ES + (lane % CPR) * 16);
+          if constexpr (RMW) {
+            const float4 o = *(const float4*)cp;
+            const float4 a = *(const float4*)&q;
+            *(float4*)cp = make_float4(o.x + a.x, o.y + a.y, o.z + a.z, o.w + a.w);
+          } else {
+            *cp = q;
+          }
+        }
       }
     }
   }
@@ -319,30 +329,40 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_tn_kernel(GemmOperandsT p, Store
   tile_of(id, tiles_m, tiles_n, tm, tn, s.splits > 1 ? patch_rows(nwg, tiles_n) : 8);
   const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BU;
   f32x4 acc[Cfg::MI][1][Cfg::NI];
-  gemm_mainloop_tn<Cfg>(p, m0, n0, lds_dyn, acc);
-  TileCoords<Cfg> tc;
-#pragma unroll
-  for (int mi = 0; mi < Cfg::MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < Cfg::NI; ++ni) {
-      const int n = n0 + tc.unit0 + ni * 16;
-      if (n >= s.N) continue;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + tc.row0 + mi * 16 + r;
-        if (m >= s.M) continue;
-        const int mo = s.row_il_H > 0 ? (m & 3) * s.row_il_H + (m >> 2) : m;
-        float* cp = s.C + (long)mo * s.ldc + n + split * s.slab_stride;
-        const float v = acc[mi][0][ni][r];
-        if (s.slab_stride > 0) { *cp = v; continue; }
+  gemm_mainloop_tn<Cfg, true>(p, m0, n0, lds_dyn, acc);      // transposed accumulators: lane = one row, 4 consecutive columns
+  // Through the per-wave LDS transpose (store_tile_via_lds): whole sub-tile rows for the plain / slab stores, contiguous
+  // row runs for the split-K atomics ("accumulate" is the same join onto what C already holds).
+  float* C = s.C + split * s.slab_stride;
+  const int wave = threadIdx.x >> 6, wc = wave % Cfg::WC;
+  const bool plain = s.slab_stride > 0 || (s.splits == 1 && !s.accumulate);
+  const bool aligned = (s.ldc % 4) == 0 && ((uintptr_t)C % 16) == 0 && n0 + wc * Cfg::WU + Cfg::WU <= s.N;
+  __syncthreads();                                             // every wave has read its last ring slot
 #ifdef EVC_ABLATE_TN_ATOMICS     // debug build: plain stores instead of the split-K atomics (wrong sums, timing only)
-        *cp = v;
+  store_tile_via_lds<Cfg, 4, false>(acc, lds_dyn, C, s.ldc, s.M, s.N, m0, n0, nullptr, s.row_il_H);
 #else
-        if (s.splits > 1) atomicAdd(cp, v);
-        else *cp = s.accumulate ? *cp + v : v;
-#endif
-      }
+  if (plain && aligned) {
+    store_tile_via_lds<Cfg, 4, false>(acc, lds_dyn, C, s.ldc, s.M, s.N, m0, n0, nullptr, s.row_il_H);
+  } else if (s.splits == 1 && s.accumulate && aligned) {     // one workgroup per tile: C += tile needs no atomics
+    store_tile_via_lds<Cfg, 4, false, true>(acc, lds_dyn, C, s.ldc, s.M, s.N, m0, n0, nullptr, s.row_il_H);
+  } else if (plain) {            // ragged right edge / unaligned rows: element-wise
+    TileCoordsT<Cfg> tc;
+#pragma unroll
+    for (int mi = 0; mi < Cfg::MI; ++mi) {
+      const int m = m0 + tc.row0 + mi * 16;
+      if (m >= s.M) continue;
+      const long mo = s.row_il_H > 0 ? (long)(m & 3) * s.row_il_H + (m >> 2) : m;
+#pragma unroll
+      for (int ni = 0; ni < Cfg::NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + tc.unit0 + ni * 16 + r;
+          if (n < s.N) C[mo * s.ldc + n] = acc[mi][0][ni][r];
+        }
     }
+  } else {
+    store_tile_via_lds<Cfg, 4, true>(acc, lds_dyn, C, s.ldc, s.M, s.N, m0, n0, nullptr, s.row_il_H);
+  }
+#endif
 }
 
 extern "C" int evc_gemm_tn(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, float* C, int64_t ldc,
