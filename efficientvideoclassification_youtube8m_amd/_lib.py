@@ -42,7 +42,7 @@ SIGNATURES = {
     "evc_meanpool_fwd": [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp],
     "evc_sigmoid_fwd": [vp, i64, vp],
     "evc_sigmoid_bwd": [vp, vp, i64, vp, vp],
-    "evc_sample_frames_gather": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp],
+    "evc_sample_frames_gather": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp],
     "evc_bn_stats": [vp, i32, i32, vp, vp, vp, vp],
     "evc_bn_apply": [vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp],
     "evc_bn_relu6_bwd": [vp, vp, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp],
@@ -56,6 +56,13 @@ SIGNATURES = {
     "evc_framepool_max_bwd": [vp, vp, i32, i32, i32, vp, vp],
     "evc_fill_f32": [vp, i64, f32, vp],
     "evc_lstm_stack2_bwd": [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "evc_netvlad_softmax_fwd": [vp, i32, i32, vp, vp, vp, vp, vp, vp],
+    "evc_netvlad_softmax_bwd": [vp, vp, i32, i32, vp, vp],
+    "evc_netvlad_aggregate_fwd": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
+    "evc_netvlad_aggregate_bwd": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "evc_netvlad_dcenters": [vp, vp, i32, i32, i32, vp, vp],
+    "evc_netvlad_normalize_fwd": [vp, i32, i32, i32, vp, vp, vp, vp, vp],
+    "evc_netvlad_normalize_bwd": [vp, vp, vp, vp, i32, i32, i32, vp, vp],
     "evc_dbof_workspace": [i32, i32, vp, vp, vp],
     "evc_dbof_gather": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp],
     "evc_bn_partials_reduce": [vp, i32, i32, vp, vp],

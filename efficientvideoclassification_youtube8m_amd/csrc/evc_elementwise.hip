@@ -799,32 +799,44 @@ extern "C" int evc_sigmoid_bwd(const float* p, const float* dp, int64_t n, evc_b
 // ---------------------------------------------------------------------------
 // a10: DBoF pieces
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sample_gather_kernel(const float* __restrict__ x, const float* __restrict__ u,
-                                                            const int* __restrict__ nfr, int B, int T, int F, int S,
-                                                            int normalize, float* __restrict__ out, int* __restrict__ idx_out) {
+__global__ __launch_bounds__(256) void sample_gather_kernel(const float* __restrict__ x, const uint8_t* __restrict__ xq,
+                                                            const float* __restrict__ u, const int* __restrict__ nfr, int B, int T, int F,
+                                                            int S, int normalize, float* __restrict__ out, int* __restrict__ idx_out) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= (long)B * S) return;
   const int b = (int)(row / S);
+  const int n = nfr[b];
   // tf.cast(tf.multiply(random_uniform, tf.cast(num_frames, tf.float32)), tf.int32)
-  int idx = (int)(u[row] * (float)nfr[b]);
+  int idx = (int)(u[row] * (float)n);
   if (lane == 0 && idx_out) idx_out[row] = idx;
   idx = idx < 0 ? 0 : (idx >= T ? T - 1 : idx);
-  const float4* src = (const float4*)(x + ((long)b * T + idx) * F);
+  const bool padded = xq && idx >= n;            // uint8 input: frames >= num_frames are padding (zero after Dequantize)
   float4* dst = (float4*)(out + row * F);
+  const int F4 = F >> 2;
+  auto load = [&](int j) {
+    if (padded) return make_float4(0.f, 0.f, 0.f, 0.f);
+    if (xq) {                                    // Dequantize cs/utils.py:22-25
+      const uchar4 q = ((const uchar4*)(xq + ((long)b * T + idx) * F))[j];
+      const float sc = 4.0f / 255.0f, bi = 4.0f / 512.0f - 2.0f;
+      return make_float4(q.x * sc + bi, q.y * sc + bi, q.z * sc + bi, q.w * sc + bi);
+    }
+    return ((const float4*)(x + ((long)b * T + idx) * F))[j];
+  };
   float inv = 1.f;
   if (normalize) {   // tf.nn.l2_normalize of the gathered frame (cs/train.py:256 applied before create_model)
     float ss = 0.f;
-    for (int j = lane; j < (F >> 2); j += 64) { const float4 v = src[j]; ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+    for (int j = lane; j < F4; j += 64) { const float4 v = load(j); ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
     inv = rsqrtf(fmaxf(wave_sum(ss), 1e-12f));
   }
-  for (int j = lane; j < (F >> 2); j += 64) { float4 v = src[j]; v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv; dst[j] = v; }
+  for (int j = lane; j < F4; j += 64) { float4 v = load(j); v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv; dst[j] = v; }
 }
-extern "C" int evc_sample_frames_gather(const float* x, const float* u, const int32_t* num_frames, int B, int T, int F,
+extern "C" int evc_sample_frames_gather(const float* x, const uint8_t* x_u8, const float* u, const int32_t* num_frames, int B, int T, int F,
                                         int S, int normalize, float* out, int32_t* idx_out, void* stream) {
   EVC_REQUIRE(B > 0 && T > 0 && F > 0 && S > 0 && F % 4 == 0, EVC_ERR_BAD_SHAPE, "evc_sample_frames_gather: bad shape");
+  EVC_REQUIRE((x != nullptr) != (x_u8 != nullptr), EVC_ERR_BAD_ARG, "evc_sample_frames_gather: exactly one of x / x_u8");
   const long rows = (long)B * S;
-  hipLaunchKernelGGL(sample_gather_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, u, num_frames,
+  hipLaunchKernelGGL(sample_gather_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, x_u8, u, num_frames,
                      B, T, F, S, normalize, out, idx_out);
   EVC_LAUNCH_CHECK();
   return EVC_OK;

@@ -82,6 +82,8 @@ _define("teacher_only", False, _bool, "HierarchicalLstmModel: train the teacher 
         "always builds the student too, also at every_n=1)")
 _define("precision", "bf16", str, "'bf16' (one MFMA product per contraction) or 'high' (split-bf16 operands, 3 products: "
         "f32-operand accuracy in every forward GEMM)")
+_define("netvlad_cluster_size", 64, int, "NetVLADModel (extension): number of clusters")
+_define("netvlad_hidden_size", 1024, int, "NetVLADModel (extension): width of the hidden layer after the aggregation")
 _define("log_every", 1, int, "host metrics / logging period in iterations (the reference logs every step)")
 
 

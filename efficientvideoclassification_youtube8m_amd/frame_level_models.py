@@ -16,7 +16,7 @@ import torch
 from . import models, ops, video_level_models
 from .engine import HLstmTower
 from .flags import FLAGS
-from .towers import DbofTower, LogisticTower
+from .towers import DbofTower, LogisticTower, NetVladTower
 
 
 class FrameBatch(object):
@@ -144,10 +144,33 @@ class HierarchicalLstmModel(models.BaseModel):
 
 
 class NetVLADModel(models.BaseModel):
-    """Empty stub in the reference (cs/frame_level_models.py:341-347): returns None."""
+    """The reference's NetVLADModel is an empty stub (cs/frame_level_models.py:341-347: both methods `return`).  Here
+    `create_model` builds the NetVLAD aggregation tower (towers.NetVladTower) - an EXTENSION with its own oracle
+    (oracle/model_math.py::netvlad_fwd), there being no reference math to match; `create_model_inference` stays the
+    reference's stub (the student path of the distillation graph exists for HierarchicalLstmModel only)."""
 
-    def create_model(self, model_input, vocab_size, num_frames, **unused_params):
-        return
+    def __init__(self):
+        self.towers = {}
+
+    def create_model(self, model_input, vocab_size, num_frames, iterations=None, cluster_size=None, hidden_size=None,
+                     is_training=True, **unused_params):
+        iterations = iterations or FLAGS.iterations
+        cluster_size = cluster_size or FLAGS.netvlad_cluster_size
+        hidden_size = hidden_size or FLAGS.netvlad_hidden_size
+        _vl_check()
+        scope = unused_params.get("scope", "model")
+        B, T, F = model_input.shape
+        tw = self.towers.get(scope)
+        if tw is None:
+            tw = self.towers[scope] = NetVladTower(B, T, F, vocab_size, iterations, cluster_size, hidden_size, FLAGS.moe_num_mixtures,
+                                                   device=model_input.device, training=True, scope=scope,
+                                                   seed=unused_params.get("seed", 0))
+        nf = num_frames.reshape(-1).to(torch.int32)
+        u = unused_params.get("uniform")
+        if u is None:
+            u = torch.rand((B, iterations), dtype=torch.float32, device=model_input.device)
+        return {"predictions": tw.forward(model_input.contiguous(), nf, u, normalize=unused_params.get("normalize_input", False),
+                                          is_training=is_training)}
 
     def create_model_inference(self, model_input, vocab_size, every_n, num_frames, **unused_params):
         return

@@ -291,7 +291,9 @@ def sigmoid_bwd(p, dp, dz):
 def sample_frames_gather(x, u, num_frames, out, idx_out=None, normalize=False):
     B, T, F = x.shape
     S = u.shape[1]
-    _lib.call("evc_sample_frames_gather", _p(x), _p(u), _p(num_frames), B, T, F, S, 1 if normalize else 0, _p(out), _p(idx_out), _stream())
+    is_u8 = x.dtype == torch.uint8
+    _lib.call("evc_sample_frames_gather", None if is_u8 else _p(x), _p(x) if is_u8 else None, _p(u), _p(num_frames), B, T, F, S,
+              1 if normalize else 0, _p(out), _p(idx_out), _stream())
 
 
 def bn_stats(x, R, Cc, ws, mean, var):
@@ -402,3 +404,34 @@ def dbof_wgrad_finish(slabs, nslab, Cc, F, W, gamma_in, dW, dgamma_in, dbeta_in=
         part_ws = torch.empty(((Cc + 7) // 8, F), dtype=F32, device=dW.device)
     _lib.call("evc_dbof_wgrad_finish", _p(slabs), nslab, Cc, F, _p(W), _p(gamma_in), _p(dW), _p(dgamma_in), _p(dbeta_in), _p(part_ws),
               _stream())
+
+
+# ---------------------------------------------------------------------------
+# NetVLAD aggregation (csrc/evc_netvlad.hip; extension, see towers.NetVladTower)
+def netvlad_softmax_fwd(act, R, K, mean, var, gamma, beta, a):
+    _lib.call("evc_netvlad_softmax_fwd", _p(act), R, K, _p(mean), _p(var), _p(gamma), _p(beta), _p(a), _stream())
+
+
+def netvlad_softmax_bwd(a, da, R, K, dz):
+    _lib.call("evc_netvlad_softmax_bwd", _p(a), _p(da), R, K, _p(dz), _stream())
+
+
+def netvlad_aggregate_fwd(a, r, B, S, K, F, mean, var, gamma, beta, c2, V, asum):
+    _lib.call("evc_netvlad_aggregate_fwd", _p(a), _p(r), B, S, K, F, _p(mean), _p(var), _p(gamma), _p(beta), _p(c2), _p(V), _p(asum), _stream())
+
+
+def netvlad_aggregate_bwd(a, r, B, S, K, F, mean, var, gamma, beta, c2, dV, da, dx):
+    _lib.call("evc_netvlad_aggregate_bwd", _p(a), _p(r), B, S, K, F, _p(mean), _p(var), _p(gamma), _p(beta), _p(c2), _p(dV), _p(da), _p(dx),
+              _stream())
+
+
+def netvlad_dcenters(asum, dV, B, K, F, dc2):
+    _lib.call("evc_netvlad_dcenters", _p(asum), _p(dV), B, K, F, _p(dc2), _stream())
+
+
+def netvlad_normalize_fwd(V, B, K, F, n1, n2, Y_bf16, Y_f32=None):
+    _lib.call("evc_netvlad_normalize_fwd", _p(V), B, K, F, _p(n1), _p(n2), _p(Y_f32), _p(Y_bf16), _stream())
+
+
+def netvlad_normalize_bwd(V, n1, n2, dY, B, K, F, dV):
+    _lib.call("evc_netvlad_normalize_bwd", _p(V), _p(n1), _p(n2), _p(dY), B, K, F, _p(dV), _stream())

@@ -276,6 +276,162 @@ class DbofTower(TowerBase):
         return self.moe.pred
 
 
+class NetVladTower(TowerBase):
+    """NetVLAD aggregation tower - an EXTENSION: the reference announces NetVLAD / NeXtVLAD teacher-student variants
+    (README.md:126-127) but ships empty stubs (cs/frame_level_models.py:341-355), so there is no reference math; the
+    definition is oracle/model_math.py::netvlad_fwd ("Learnable pooling with Context Gating" NetVLAD in the frame of the
+    DBoF tower): sample S frames -> input_bn -> .Wc -> cluster_bn -> softmax over K clusters -> V[k] = sum_s a[s,k] (x_s - c2[k])
+    -> intra-normalise -> l2-normalise -> .Wh -> hidden1_bn -> relu6 -> MoE.
+    GEMM-shaped parts on the library's NT / TN kernels, the f32 pieces in csrc/evc_netvlad.hip.  V / Y are kept
+    cluster-major [B][K][F]; hidden1_weights' TF row order f*K + k is restored in state_dict()."""
+
+    CW, C2, HW = "cluster_weights", "cluster_weights2", "hidden1_weights"
+    l2_names = (MoeHead.GATES, MoeHead.EXPERTS)
+    # all three batch-norms go through BatchNorm.backward: their gamma/beta gradients are global (all-reduced f64 sums)
+    global_grad_names = tuple("%s/%s" % (s_, v) for s_ in ("input_bn", "cluster_bn", "hidden1_bn") for v in ("beta", "gamma"))
+
+    def __init__(self, batch_size, max_frames=300, feature_size=1152, vocab_size=4716, iterations=30, cluster_size=64,
+                 hidden_size=1024, num_mixtures=2, device="cuda:0", training=True, scope="model", seed=0, process_group=None):
+        self.device, self.training, self.scope, self.pg = torch.device(device), training, scope, process_group
+        self.T, self.F, self.V, self.S = max_frames, feature_size, vocab_size, iterations
+        self.Kc, self.Hd, self.Mx = cluster_size, hidden_size, num_mixtures
+        if feature_size % 64 or cluster_size % 64 or hidden_size % 64:
+            raise ValueError("feature / cluster / hidden sizes must be multiples of 64 for the MFMA GEMM tiles")
+        if iterations > 64:
+            raise ValueError("iterations=%d: the aggregation kernel holds at most 64 sampled frames per video" % iterations)
+        F, K, H = feature_size, cluster_size, hidden_size
+        shapes = OrderedDict()
+        shapes.update(BatchNorm.shapes("input_bn", F))
+        shapes[self.CW] = (K, F)                                     # stored transposed [K][F]
+        shapes.update(BatchNorm.shapes("cluster_bn", K))
+        shapes[self.C2] = (K, F)                                     # centres, stored [K][F] (tf: [1, F, K])
+        shapes[self.HW] = (H, K * F)                                 # stored transposed, columns cluster-major (k*F + f)
+        shapes.update(BatchNorm.shapes("hidden1_bn", H))
+        shapes.update(MoeHead.shapes(H, vocab_size, num_mixtures))
+        self.buffers = OrderedDict()
+        self._setup_store(shapes)
+        self.bn_in = BatchNorm(self, "input_bn", F)
+        self.bn_cl = BatchNorm(self, "cluster_bn", K)
+        self.bn_h = BatchNorm(self, "hidden1_bn", H)
+        self.moe = MoeHead(self, H, vocab_size, num_mixtures)
+        gen = torch.Generator(device="cpu")
+        gen.manual_seed(seed)
+        for k, shp in self.store.shapes.items():
+            p = self.store.p(k)
+            if k in (self.CW, self.C2):
+                p.copy_(torch.randn(shp, generator=gen, dtype=F32) / math.sqrt(F))
+            elif k == self.HW:
+                p.copy_(torch.randn(shp, generator=gen, dtype=F32) / math.sqrt(K))
+            elif len(shp) == 2:
+                lim = math.sqrt(6.0 / (shp[0] + shp[1]))
+                p.copy_((torch.rand(shp, generator=gen, dtype=F32) * 2 - 1) * lim)
+            elif k.endswith("/gamma"):
+                p.fill_(1.0)
+        self.refresh_shadows()
+        self._alloc(batch_size)
+
+    # hidden1_weights: TF layout [F*K, H] with row f*K + k  <->  internal [H][k*F + f]
+    def state_dict(self):
+        out = super().state_dict()
+        key = "%s/%s" % (self.scope, self.HW)
+        w = out[key]                                                 # [K*F (k-major), H]
+        out[key] = w.view(self.Kc, self.F, self.Hd).permute(1, 0, 2).reshape(self.F * self.Kc, self.Hd).contiguous()
+        return out
+
+    def load_state_dict(self, sd, prefix=None):
+        prefix = self.scope if prefix is None else prefix
+        key = "%s/%s" % (prefix, self.HW)
+        sd = dict(sd)
+        sd[key] = sd[key].view(self.F, self.Kc, self.Hd).permute(1, 0, 2).reshape(self.Kc * self.F, self.Hd).contiguous()
+        super().load_state_dict(sd, prefix)
+
+    def _alloc(self, B):
+        dev, F, S, K, H = self.device, self.F, self.S, self.Kc, self.Hd
+        self.B, self.R = B, B * S
+        if self.training and self.R % 32:
+            raise ValueError("batch_size x iterations = %d must be a multiple of 32 (row count of the TN weight-gradient products)" % self.R)
+        R = self.R
+        self.Bk = ops.round_up(B, 32)
+        self.r = torch.empty((R, F), dtype=F32, device=dev)
+        self.idx = torch.empty((B, S), dtype=torch.int32, device=dev)
+        self.r_bn = torch.empty((R, F), dtype=BF16, device=dev)
+        self.act = torch.empty((R, K), dtype=F32, device=dev)
+        self.a = torch.empty((R, K), dtype=F32, device=dev)
+        self.asum = torch.empty((B, K), dtype=F32, device=dev)
+        self.Vv = torch.empty((B, K, F), dtype=F32, device=dev)
+        self.n1 = torch.empty((B, K), dtype=F32, device=dev)
+        self.n2 = torch.empty((B,), dtype=F32, device=dev)
+        self.Y_bf = torch.zeros((self.Bk, K * F), dtype=BF16, device=dev)
+        self.hid = torch.empty((B, H), dtype=F32, device=dev)
+        self.h6 = torch.empty((B, H), dtype=F32, device=dev)
+        self.moe.alloc(B, self.training)
+        if self.training:
+            self.dhid_bf = torch.zeros((self.Bk, H), dtype=BF16, device=dev)
+            self.dY = torch.empty((B, K * F), dtype=F32, device=dev)
+            self.dV = torch.empty((B, K, F), dtype=F32, device=dev)
+            self.da = torch.empty((R, K), dtype=F32, device=dev)
+            self.dz = torch.empty((R, K), dtype=F32, device=dev)
+            self.dx = torch.empty((R, F), dtype=F32, device=dev)
+            self.dact_bf = torch.empty((R, K), dtype=BF16, device=dev)
+
+    def forward(self, x, num_frames, uniform, normalize=True, is_training=True):
+        """x [B,T,F] float32 or uint8 raw frames; uniform [B,S] f32 in [0,1): the frame-sampling draw."""
+        B = x.shape[0]
+        if B != self.B:
+            self._alloc(B)
+        F, S, K, H, R = self.F, self.S, self.Kc, self.Hd, self.R
+        st, bi, bc = self.store, self.bn_in, self.bn_cl
+        if self.precision != "bf16":
+            raise NotImplementedError("NetVladTower has no split-bf16 mode")
+        ops.sample_frames_gather(x, uniform, num_frames, self.r, self.idx, normalize=normalize)
+        bi.stats(self.r, R, is_training)
+        ops.bn_apply(self.r, R, F, bi.mean, bi.var, bi.gamma(), bi.beta(), False, y_bf16=self.r_bn)
+        ops.gemm_nt(self.r_bn, self.shadow_fwd[self.CW], R, K, F, self.act)
+        bc.stats(self.act, R, is_training)
+        ops.netvlad_softmax_fwd(self.act, R, K, bc.mean, bc.var, bc.gamma(), bc.beta(), self.a)
+        ops.netvlad_aggregate_fwd(self.a, self.r, B, S, K, F, bi.mean, bi.var, bi.gamma(), bi.beta(), st.p(self.C2), self.Vv, self.asum)
+        ops.netvlad_normalize_fwd(self.Vv, B, K, F, self.n1, self.n2, self.Y_bf)
+        ops.gemm_nt(self.Y_bf, self.shadow_fwd[self.HW], B, H, K * F, self.hid)
+        self.bn_h.stats(self.hid, B, is_training)
+        ops.bn_apply(self.hid, B, H, self.bn_h.mean, self.bn_h.var, self.bn_h.gamma(), self.bn_h.beta(), True, y_f32=self.h6)
+        self._taped = self.training and is_training
+        return self.moe.forward(self.h6)
+
+    def grad_stages(self):
+        moe = [MoeHead.GATES, MoeHead.EXPERTS, MoeHead.EBIAS]
+        hidden = [self.HW, "hidden1_bn/beta", "hidden1_bn/gamma"]
+        return moe, hidden, [k for k in self.names if k not in moe and k not in hidden]
+
+    def backward(self, dpred, on_moe_grads_ready=None, moe_weight_grads=True, on_stage=None):
+        assert self.training and self._taped, "backward needs a training-mode forward"
+        B, F, S, K, H, R = self.B, self.F, self.S, self.Kc, self.Hd, self.R
+        st, bi = self.store, self.bn_in
+        dh6 = self.moe.backward(dpred, weight_grads=moe_weight_grads)
+        if on_moe_grads_ready is not None:
+            on_moe_grads_ready()
+        if on_stage is not None:
+            on_stage(0)
+        self.bn_h.backward(self.hid, dh6, B, True, dx_bf16=self.dhid_bf)
+        ops.gemm_tn(self.dhid_bf, self.Y_bf, H, K * F, self.Bk, st.g(self.HW))          # dWh^T [H][K*F]
+        if on_stage is not None:
+            on_stage(1)
+        ops.gemm_nt(self.dhid_bf, self.shadow_bwd[self.HW], B, K * F, H, self.dY)
+        ops.netvlad_normalize_bwd(self.Vv, self.n1, self.n2, self.dY, B, K, F, self.dV)
+        ops.netvlad_dcenters(self.asum, self.dV, B, K, F, st.g(self.C2))
+        ops.netvlad_aggregate_bwd(self.a, self.r, B, S, K, F, bi.mean, bi.var, bi.gamma(), bi.beta(), st.p(self.C2), self.dV, self.da, self.dx)
+        ops.netvlad_softmax_bwd(self.a, self.da, R, K, self.dz)
+        self.bn_cl.backward(self.act, self.dz, R, False, dx_bf16=self.dact_bf)
+        ops.gemm_tn(self.dact_bf, self.r_bn, K, F, R, st.g(self.CW))                   # dWc^T [K][F]
+        ops.gemm_nt(self.dact_bf, self.shadow_bwd[self.CW], R, F, K, self.dx, accumulate=True)   # + dact . Wc^T
+        bi.backward(self.r, self.dx, R, False)
+        if on_stage is not None:
+            on_stage(2)
+
+    @property
+    def pred(self):
+        return self.moe.pred
+
+
 class LogisticTower(TowerBase):
     """FrameLevelLogisticModel: sigmoid(mean_frames(x) . W + b), with the
     reference's quirk that the sum runs over all (zero-padded) frames and is

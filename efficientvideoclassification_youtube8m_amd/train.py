@@ -32,7 +32,7 @@ import torch
 from . import eval_util, frame_level_models, losses, ops, readers, video_level_models
 from .distill import DistillGraph, SingleTowerGraph
 from .flags import FLAGS, GetListOfFeatureNamesAndSizes
-from .towers import DbofTower, LogisticTower
+from .towers import DbofTower, LogisticTower, NetVladTower
 
 NUM_CLASSES = 4716       # readers.YT8MFrameFeatureReader default num_classes (cs/readers.py:121)
 
@@ -66,10 +66,14 @@ def build_graph(model, label_loss_fn, feature_size, batch_size, every_n, device,
                        FLAGS.dbof_cluster_size, FLAGS.dbof_hidden_size, FLAGS.moe_num_mixtures, device=device,
                        process_group=process_group)
         return SingleTowerGraph(tw, **common)
+    if isinstance(model, frame_level_models.NetVLADModel):          # extension (the reference's class is an empty stub)
+        tw = NetVladTower(batch_size, FLAGS.max_num_frames, feature_size, NUM_CLASSES, FLAGS.iterations, FLAGS.netvlad_cluster_size,
+                          FLAGS.netvlad_hidden_size, FLAGS.moe_num_mixtures, device=device, process_group=process_group)
+        return SingleTowerGraph(tw, **common)
     if isinstance(model, frame_level_models.FrameLevelLogisticModel):
         return SingleTowerGraph(LogisticTower(batch_size, FLAGS.max_num_frames, feature_size, NUM_CLASSES, device=device),
                                 **common)
-    raise NotImplementedError("model %s has no training graph (NetVLAD/NeXtVLAD are empty stubs in the reference too)"
+    raise NotImplementedError("model %s has no training graph (NeXtVLAD is an empty stub in the reference too)"
                               % type(model).__name__)
 
 

@@ -297,8 +297,9 @@ int evc_sigmoid_bwd(const float* p, const float* dp, int64_t n, evc_bf16* dz, vo
  * SampleRandomFrames (cs/model_utils.py:39-58): idx = int32(u * float32(n));
  * gathers x[b, idx[b,s], :] -> out [B*S][F] f32.  u [B][S] f32 supplied by caller.
  * normalize=1 l2-normalises each gathered frame (cs/train.py:256: same values as
- * normalising all 300 frames first, 10x less work). */
-int evc_sample_frames_gather(const float* x, const float* u, const int32_t* num_frames, int B, int T, int F,
+ * normalising all 300 frames first, 10x less work).  x f32 or x_u8 (the reader's uint8 tensor: Dequantize fused,
+ * frames >= num_frames are padding) - exactly one non-NULL. */
+int evc_sample_frames_gather(const float* x, const uint8_t* x_u8, const float* u, const int32_t* num_frames, int B, int T, int F,
                              int S, int normalize, float* out, int32_t* idx_out, void* stream);
 /* slim.batch_norm training statistics over rows: mean[C], var[C] (biased, f64 accumulation). x [R][C] f32. */
 int evc_bn_stats(const float* x, int R, int C, double* ws /* 2*C, zeroed inside */, float* mean, float* var,
@@ -396,6 +397,29 @@ int evc_gemm_tn_slabs(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t
  * (per-block column sums, added in block order: run-to-run identical). */
 int evc_dbof_wgrad_finish(const float* slabs, int nslab, int C, int F, const float* W, const float* gamma_in, float* dW,
                           float* dgamma_in, float* dbeta_in, float* part_ws, void* stream);
+
+/* ---- NetVLAD aggregation (EXTENSION: the reference's NetVLADModel is an empty stub, cs/frame_level_models.py:341-347; the
+ * math is oracle/model_math.py::netvlad_fwd).  Sampled frames row-major [B*S][..]; V / dV / Y are [B][K][F] (cluster-major).
+ * The GEMM-shaped parts of the tower use evc_gemm_nt / evc_gemm_tn. ------------------------------------------------------ */
+/* a = softmax over the K clusters of cluster_bn(act), per sampled frame; and dz = a * (da - sum_k a*da). */
+int evc_netvlad_softmax_fwd(const float* act, int R, int K, const float* mean, const float* var, const float* gamma,
+                            const float* beta, float* a, void* stream);
+int evc_netvlad_softmax_bwd(const float* a, const float* da, int R, int K, float* dz, void* stream);
+/* V[b][k][:] = sum_s a[b,s,k] * x_bn[b,s,:] - asum[b][k] * c2[k][:], x_bn = input_bn(r) recomputed from r [B*S][F] f32 and
+ * the statistics; asum [B][K] = sum_s a.  Backward: da [B*S][K], dx_bn [B*S][F] from dV. */
+int evc_netvlad_aggregate_fwd(const float* a, const float* r, int B, int S, int K, int F, const float* mean, const float* var,
+                              const float* gamma, const float* beta, const float* c2, float* V, float* asum, void* stream);
+int evc_netvlad_aggregate_bwd(const float* a, const float* r, int B, int S, int K, int F, const float* mean, const float* var,
+                              const float* gamma, const float* beta, const float* c2, const float* dV, float* da, float* dx,
+                              void* stream);
+/* dc2[k][:] = - sum_b asum[b][k] * dV[b][k][:] */
+int evc_netvlad_dcenters(const float* asum, const float* dV, int B, int K, int F, float* dc2, void* stream);
+/* U_k = V_k / |V_k| per cluster, Y = U / |U| (tf.nn.l2_normalize, epsilon 1e-12 on the squared norms); n1 [B][K], n2 [B]
+ * are kept for the backward pass, which recomputes U and Y from V. */
+int evc_netvlad_normalize_fwd(const float* V, int B, int K, int F, float* n1, float* n2, float* Y_f32, evc_bf16* Y_bf16,
+                              void* stream);
+int evc_netvlad_normalize_bwd(const float* V, const float* n1, const float* n2, const float* dY, int B, int K, int F, float* dV,
+                              void* stream);
 
 /* utility: out[i] = value for n floats (avoids torch for tiny fills inside C loops) */
 int evc_fill_f32(float* p, int64_t n, float value, void* stream);

@@ -534,6 +534,87 @@ def dbof_bwd(dpred, cache):
     return g
 
 
+# --------------------------------------------------------------------------
+# NetVLAD (EXTENSION: the reference's NetVLADModel is an empty stub, cs/frame_level_models.py:341-347 - there is no
+# reference math for it.  This is the NetVLAD aggregation of "Learnable pooling with Context Gating" (Miech et al.) as
+# the YouTube-8M starter code lineage implements it, in the frame of this repository's DBoF tower: sampled frames ->
+# input_bn -> cluster assignment (matmul, cluster_bn, softmax) -> residual aggregation against learned centres ->
+# intra-normalisation -> l2 normalisation -> hidden layer (matmul, hidden1_bn, relu6) -> MoE.)
+# --------------------------------------------------------------------------
+def netvlad_fwd(x, num_frames, uniform, params, num_mixtures=2):
+    B = x.shape[0]
+    idx = sample_random_frames_index(uniform, num_frames)
+    S = idx.shape[1]
+    g = x[np.arange(B)[:, None], idx, :]
+    F = g.shape[2]
+    r = g.reshape(B * S, F)
+    r_bn, c_in = batch_norm_train_fwd(r, params["input_bn/gamma"], params["input_bn/beta"])
+    Wc = params["cluster_weights"]                                   # [F, K]
+    K = Wc.shape[1]
+    act = r_bn @ Wc
+    act_bn, c_cl = batch_norm_train_fwd(act, params["cluster_bn/gamma"], params["cluster_bn/beta"])
+    z = act_bn - act_bn.max(axis=1, keepdims=True)
+    e = np.exp(z)
+    a = e / e.sum(axis=1, keepdims=True)                             # soft assignment [B*S, K]
+    a3 = a.reshape(B, S, K)
+    X = r_bn.reshape(B, S, F)
+    a_sum = a3.sum(axis=1)                                           # [B, K]
+    C2 = params["cluster_weights2"]                                  # [F, K] (tf: [1, F, K])
+    V = np.einsum("bsk,bsf->bkf", a3, X) - a_sum[:, :, None] * C2.T[None]          # [B, K, F]
+    n1 = np.sqrt(np.maximum((V * V).sum(axis=2), 1e-12))             # tf.nn.l2_normalize over the feature axis, per cluster
+    U = V / n1[:, :, None]
+    Uf = U.transpose(0, 2, 1).reshape(B, F * K)                      # reshape of the [B, F, K] tensor: index f*K + k
+    n2 = np.sqrt(np.maximum((Uf * Uf).sum(axis=1), 1e-12))
+    Y = Uf / n2[:, None]
+    hid = Y @ params["hidden1_weights"]                              # [F*K, H]
+    hid_bn, c_h = batch_norm_train_fwd(hid, params["hidden1_bn/gamma"], params["hidden1_bn/beta"])
+    h6 = relu6(hid_bn)
+    pred, c_moe = moe_fwd(h6, params["classifier/gates/weights"], params["classifier/experts/weights"],
+                          params["classifier/experts/biases"], num_mixtures)
+    cache = (idx, r_bn, c_in, a3, X, a_sum, C2, V, n1, U, n2, Y, hid_bn, c_h, h6, c_moe, c_cl, (B, S, F, K), params)
+    return pred, cache
+
+
+def netvlad_bwd(dpred, cache):
+    idx, r_bn, c_in, a3, X, a_sum, C2, V, n1, U, n2, Y, hid_bn, c_h, h6, c_moe, c_cl, (B, S, F, K), params = cache
+    g = {}
+    dh6, g["classifier/gates/weights"], g["classifier/experts/weights"], g["classifier/experts/biases"] = moe_bwd(dpred, c_moe)
+    dhid_bn = dh6 * ((hid_bn > 0) & (hid_bn < 6))
+    dhid, g["hidden1_bn/gamma"], g["hidden1_bn/beta"] = batch_norm_train_bwd(dhid_bn, c_h)
+    g["hidden1_weights"] = Y.T @ dhid
+    dY = dhid @ params["hidden1_weights"].T                          # [B, F*K]
+    dUf = (dY - Y * (Y * dY).sum(axis=1, keepdims=True)) / n2[:, None]
+    dU = dUf.reshape(B, F, K).transpose(0, 2, 1)                     # [B, K, F]
+    dV = (dU - U * (U * dU).sum(axis=2, keepdims=True)) / n1[:, :, None]
+    g["cluster_weights2"] = -np.einsum("bk,bkf->fk", a_sum, dV)
+    da3 = np.einsum("bkf,bsf->bsk", dV, X) - np.einsum("bkf,fk->bk", dV, C2)[:, None, :]
+    dX = np.einsum("bsk,bkf->bsf", a3, dV)
+    a = a3.reshape(B * S, K)
+    da = da3.reshape(B * S, K)
+    dz = a * (da - (a * da).sum(axis=1, keepdims=True))              # softmax backward
+    dact, g["cluster_bn/gamma"], g["cluster_bn/beta"] = batch_norm_train_bwd(dz, c_cl)
+    g["cluster_weights"] = r_bn.T @ dact
+    dr_bn = dact @ params["cluster_weights"].T + dX.reshape(B * S, F)
+    _, g["input_bn/gamma"], g["input_bn/beta"] = batch_norm_train_bwd(dr_bn, c_in)
+    return g
+
+
+def init_netvlad_params(rng, feature_size=1152, cluster_size=64, hidden_size=1024, vocab_size=4716, num_mixtures=2,
+                        dtype=np.float64):
+    F, K, H = feature_size, cluster_size, hidden_size
+    return {
+        "input_bn/gamma": np.ones(F, dtype), "input_bn/beta": np.zeros(F, dtype),
+        "cluster_weights": (rng.standard_normal((F, K)) / math.sqrt(F)).astype(dtype),
+        "cluster_bn/gamma": np.ones(K, dtype), "cluster_bn/beta": np.zeros(K, dtype),
+        "cluster_weights2": (rng.standard_normal((F, K)) / math.sqrt(F)).astype(dtype),
+        "hidden1_weights": (rng.standard_normal((F * K, H)) / math.sqrt(K)).astype(dtype),
+        "hidden1_bn/gamma": np.ones(H, dtype), "hidden1_bn/beta": np.zeros(H, dtype),
+        "classifier/gates/weights": glorot_uniform(rng, (H, vocab_size * (num_mixtures + 1)), dtype),
+        "classifier/experts/weights": glorot_uniform(rng, (H, vocab_size * num_mixtures), dtype),
+        "classifier/experts/biases": np.zeros(vocab_size * num_mixtures, dtype),
+    }
+
+
 def bn_moving_update(moving, batch_value, decay=BN_DECAY):
     """slim.batch_norm UPDATE_OPS: moving -= (1-decay)*(moving - batch)."""
     return moving - (1.0 - decay) * (moving - batch_value)

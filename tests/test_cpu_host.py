@@ -113,7 +113,8 @@ def test_model_classes_resolve_by_name():
     assert find_class_by_name("CrossEntropyLoss", [losses]).__name__ == "CrossEntropyLoss"
     with pytest.raises(StopIteration):
         find_class_by_name("NoSuchModel", [frame_level_models, video_level_models])
-    assert frame_level_models.NetVLADModel().create_model(None, 1, None) is None      # empty stubs, as in the reference
+    assert frame_level_models.NeXtVLADModel().create_model(None, 1, None) is None     # empty stub, as in the reference
+    assert frame_level_models.NetVLADModel().create_model_inference(None, 1, 10, None) is None   # (create_model: extension, GPU tests)
 
 
 DP_WORKER = r'''

@@ -278,3 +278,39 @@ def test_torch_cpu_baseline_matches_the_float64_oracle():
     o_s = tc.teacher_student_iteration(torch.tensor(x, dtype=torch.float32), n, torch.tensor(y, dtype=torch.float32), tt, ts,
                                        30, mode="student")
     assert "student_grads" not in o_t and "teacher_grads" not in o_s and np.isfinite(o_s["student_label_loss"])
+
+
+def test_netvlad_oracle_backward_matches_finite_differences():
+    """The NetVLAD extension has no reference math (empty stub): its oracle is checked against itself - hand-written
+    reverse mode vs central finite differences of the cross-entropy loss, every parameter tensor."""
+    rng = np.random.default_rng(11)
+    B, T, F, K, H, V, S = 6, 12, 8, 5, 7, 9, 4
+    P = mm.init_netvlad_params(rng, F, K, H, V)
+    for k in P:
+        if k.endswith("gamma") or k.endswith("beta"):
+            P[k] = P[k] + 0.2 * rng.standard_normal(P[k].shape)
+    x = rng.standard_normal((B, T, F))
+    n = rng.integers(1, T + 1, B)
+    u = rng.random((B, S)).astype(np.float32)
+    y = rng.random((B, V)) > 0.6
+
+    def loss(Q):
+        p, _ = mm.netvlad_fwd(x, n, u, Q)
+        return mm.cross_entropy_loss(p, y)
+
+    pred, cache = mm.netvlad_fwd(x, n, u, P)
+    grads = mm.netvlad_bwd(mm.cross_entropy_grad(pred, y), cache)
+    assert set(grads) == set(P)
+    eps = 1e-6
+    for k in P:
+        flat = P[k].reshape(-1)
+        for j in rng.choice(flat.size, size=min(6, flat.size), replace=False):
+            old = flat[j]
+            flat[j] = old + eps
+            lp = loss(P)
+            flat[j] = old - eps
+            lm = loss(P)
+            flat[j] = old
+            fd = (lp - lm) / (2 * eps)
+            got = grads[k].reshape(-1)[j]
+            assert abs(fd - got) <= 1e-5 * max(1.0, abs(fd)) + 1e-7, (k, j, fd, got)
