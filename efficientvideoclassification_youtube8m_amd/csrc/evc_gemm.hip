@@ -1146,6 +1146,113 @@ __device__ __forceinline__ void lstm_bwd_zero_tile(const LstmBwdParams& e, int m
   }
 }
 
+// Row-major gate-derivative tail for the ring tiles (BM x 128 units, 512 threads): the accumulators (dh) go through LDS
+// and the tail then walks the tile row by row - one wave = one row of 128 units, lane = 2 consecutive units - so every
+// global access of the tail is a contiguous run over the whole wave (gate records 1 KB, dz 1 KB, dc 512 B, cell history
+// 256 B per row), GROUP rows in flight per thread.  Straight from the accumulator layout (lane = 4 units of one row, 16
+// rows per instruction) the same bytes moved in 32-64-byte pieces and the tail took 32 of the step's 70 us.
+template <class Cfg>
+__device__ __forceinline__ void lstm_bwd_tail_rowmajor(f32x4 (&acc)[Cfg::MI][1][Cfg::NI], const LstmBwdParams& e, int m0, int u0, char* lds) {
+  static_assert(Cfg::BU == 128 && Cfg::NT == 512, "row-major tail: 128-unit tiles, 8 waves");
+  constexpr int RS = Cfg::BU * 4 + 16;                        // dh rows in LDS, padded
+  static_assert(Cfg::BM * RS <= Cfg::LDS_BYTES && 8 * 128 * 4 * 4 <= Cfg::LDS_BYTES, "dh tile (then the bias-gradient partials) must fit the ring");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  {
+    const int wr = wave / Cfg::WC, wc = wave % Cfg::WC;
+    const int l = lane & 15, g = lane >> 4;
+    __syncthreads();                                           // every wave has read its last ring slot
+#pragma unroll
+    for (int mi = 0; mi < Cfg::MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < Cfg::NI; ++ni)
+        *(f32x4*)(lds + (wr * Cfg::WM + mi * 16 + l) * RS + (wc * Cfg::WU + ni * 16 + g * 4) * 4) = acc[mi][0][ni];
+    __syncthreads();
+  }
+  const int u = u0 + lane * 2;                                // this lane's two units
+  const bool u_in = u < e.H;                                  // H % 2 == 0
+  float bs[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  constexpr int GROUP = 4;                                    // rows per thread in flight (2: 67.0 us per step, 4: 65.1)
+  static_assert(Cfg::BM % (8 * GROUP) == 0, "tile rows must divide into 8 waves x GROUP");
+  for (int p0 = 0; p0 < Cfg::BM / 8; p0 += GROUP) {
+    int ln[GROUP];
+    float2 dcv[GROUP], dhs[GROUP], dhv[GROUP];
+    uint4 grec[GROUP];
+    uint32_t cn[GROUP], co[GROUP], dha[GROUP];
+#pragma unroll
+    for (int i = 0; i < GROUP; ++i) {                          // load phase
+      const int rl = (p0 + i) * 8 + wave;
+      const int m = m0 + rl;
+      ln[i] = (m < e.M && u_in) ? e.len[m] : -1;
+      dcv[i] = dhs[i] = make_float2(0.f, 0.f);
+      grec[i] = make_uint4(0u, 0u, 0u, 0u);
+      cn[i] = co[i] = dha[i] = 0u;
+      dhv[i] = *(const float2*)(lds + rl * RS + lane * 8);
+      if (e.t < ln[i]) {
+        const long hu = (long)m * e.H + u;
+        if (e.t == ln[i] - 1) {
+          const long su = (long)(e.row_map ? e.row_map[m] : m) * e.ld_dS + u;
+          dhs[i] = *(const float2*)(e.dS_h + su);
+          dcv[i] = *(const float2*)(e.dS_c + su);
+        } else {
+          dcv[i] = *(const float2*)(e.dc_ws + hu);
+        }
+        if (e.dh_above) dha[i] = *(const uint32_t*)(e.dh_above + hu);
+        grec[i] = *(const uint4*)(e.gates + hu);
+        cn[i] = *(const uint32_t*)(e.c_new + hu);
+        if (e.c_old) co[i] = *(const uint32_t*)(e.c_old + hu);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < GROUP; ++i) {                          // compute + store phase
+      if (ln[i] < 0) continue;
+      const int m = m0 + (p0 + i) * 8 + wave;
+      const long hu = (long)m * e.H + u;
+      if (e.t >= ln[i]) {                                      // inactive: state passes through, no gate gradient
+        *(uint4*)(e.dz4 + hu) = make_uint4(0u, 0u, 0u, 0u);
+        continue;
+      }
+      float dh[2] = {dhv[i].x, dhv[i].y};
+      if (e.t == ln[i] - 1) {
+        if (e.fused_above) { dh[0] += dhs[i].x; dh[1] += dhs[i].y; }
+        else { dh[0] = dhs[i].x; dh[1] = dhs[i].y; }
+      }
+      if (e.dh_above) { dh[0] += __uint_as_float(dha[i] << 16); dh[1] += __uint_as_float(dha[i] & 0xffff0000u); }
+      const float dci[2] = {dcv[i].x, dcv[i].y};
+      const uint2 recs[2] = {make_uint2(grec[i].x, grec[i].y), make_uint2(grec[i].z, grec[i].w)};
+      const float cna[2] = {__uint_as_float(cn[i] << 16), __uint_as_float(cn[i] & 0xffff0000u)};
+      const float coa[2] = {__uint_as_float(co[i] << 16), __uint_as_float(co[i] & 0xffff0000u)};
+      float dcn[2];
+      uint2 dzr[2];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const float gi = __uint_as_float(recs[r].x << 16), gj = __uint_as_float(recs[r].x & 0xffff0000u);
+        const float gf = __uint_as_float(recs[r].y << 16), go = __uint_as_float(recs[r].y & 0xffff0000u);
+        const float tcv = tanhf_(cna[r]);
+        const float dc = dci[r] + dh[r] * go * (1.f - tcv * tcv);
+        dcn[r] = dc * gf;
+        const float z0 = dc * gj * gi * (1.f - gi), z1 = dc * gi * (1.f - gj * gj);
+        const float z2 = dc * coa[r] * gf * (1.f - gf), z3 = dh[r] * tcv * go * (1.f - go);
+        bs[r][0] += z0; bs[r][1] += z1; bs[r][2] += z2; bs[r][3] += z3;
+        dzr[r] = make_uint2(pack_bf16x2(z0, z1), pack_bf16x2(z2, z3));
+      }
+      *(float2*)(e.dc_ws + hu) = make_float2(dcn[0], dcn[1]);
+      *(uint4*)(e.dz4 + hu) = make_uint4(dzr[0].x, dzr[0].y, dzr[1].x, dzr[1].y);
+    }
+  }
+  if (e.db) {      // bias gradient: the 8 waves hold partial sums of the same 128 units x 4 gates: through LDS, then one atomic per sum
+    float* red = (float*)lds;                                  // [8 waves][128 units][4 gates], over the dh tile
+    __syncthreads();                                           // every wave has read its last dh row
+    *(float4*)(red + ((wave * 128) + lane * 2) * 4) = make_float4(bs[0][0], bs[0][1], bs[0][2], bs[0][3]);
+    *(float4*)(red + ((wave * 128) + lane * 2 + 1) * 4) = make_float4(bs[1][0], bs[1][1], bs[1][2], bs[1][3]);
+    __syncthreads();
+    const int uu = threadIdx.x >> 2, gg = threadIdx.x & 3;     // 512 threads = 128 units x 4 gates
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) v += red[(w * 128 + uu) * 4 + gg];
+    if (u0 + uu < e.H) atomicAdd(e.db + (long)gg * e.H + u0 + uu, v);
+  }
+}
+
 // BATCH_LOADS: issue the epilogue loads of all MI fragments of a unit group before the first store (one workgroup per CU:
 // the only way to overlap them); false: fragment by fragment (fewer registers: the pair kernel runs two workgroups per CU
 // and hides the round trips behind the other workgroup's main loop)
@@ -1162,7 +1269,20 @@ __device__ __forceinline__ void lstm_bwd_step_body(const GemmOperands& p, const 
     return;
   }
   f32x4 acc[Cfg::MI][1][Cfg::NI];
+#ifdef EVC_ABLATE_BWD_MAIN     // debug build: epilogue only
+#pragma unroll
+  for (int mi = 0; mi < Cfg::MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < Cfg::NI; ++ni) acc[mi][0][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+#else
   run_mainloop<Cfg, 1, true>(p, m0, u0, acc);     // transposed accumulators: lane = one row, 4 consecutive units
+#endif
+#if !defined(EVC_ABLATE_BWD_EPI) && !defined(EVC_BWD_TAIL_FRAGMENTS)
+  if constexpr (is_v2<Cfg>::value && Cfg::BU == 128 && Cfg::NT == 512 && Cfg::BM % 32 == 0 && BATCH_LOADS) {
+    lstm_bwd_tail_rowmajor<Cfg>(acc, e, m0, u0, lds_dyn);
+    return;
+  }
+#endif
   TileCoordsT<Cfg> tc;
 #pragma unroll
   for (int ni = 0; ni < Cfg::NI; ++ni) {
