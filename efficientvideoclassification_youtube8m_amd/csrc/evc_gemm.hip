@@ -2,11 +2,22 @@
 // (forward, with the gate tail in the epilogue) and fused BPTT step.
 #include "gemm_launch.h"
 
-template <class Cfg, int NG, bool SWAP = false, bool SPLIT = false, bool INIT = true>
+// Loop options per kernel (gemm_core_v2.h; same-box A/B measurements in DESIGN.md 4.2)
+#ifndef EVC_FWD_LOOP_MODE
+#define EVC_FWD_LOOP_MODE (LOOP_PRODUCER | LOOP_DMA_FIRST | LOOP_NO_PRIO)   // forward step: 81.7 -> 77.4 us per step
+#endif
+#ifndef EVC_BWD_LOOP_MODE
+#define EVC_BWD_LOOP_MODE (LOOP_DMA_FIRST | LOOP_NO_PRIO)                   // BPTT step: 64.8 -> 62.1 us per step
+#endif
+#ifndef EVC_TN_LOOP_MODE
+#define EVC_TN_LOOP_MODE LOOP_PRODUCER                                      // weight-gradient products: -2 .. -5 %
+#endif
+
+template <class Cfg, int NG, bool SWAP = false, bool SPLIT = false, bool INIT = true, int MODE = EVC_LOOP_MODE_DEFAULT>
 __device__ __forceinline__ void run_mainloop(const GemmOperands& p, int m0, int u0, f32x4 (&acc)[Cfg::MI][NG][Cfg::NI]) {
   if constexpr (is_v2<Cfg>::value) {
     static_assert(!SPLIT, "the split-bf16 parity mode runs on the v1 tiles");
-    gemm_mainloop_v2<Cfg, SWAP, INIT>(p, m0, u0, lds_dyn, acc);
+    gemm_mainloop_v2<Cfg, SWAP, INIT, MODE>(p, m0, u0, lds_dyn, acc);
   } else {
     __shared__ __attribute__((aligned(16))) char lds_static[(SPLIT ? 2 : 1) * Cfg::LDS_BYTES];   // static: keeps 2 workgroups per CU
     gemm_mainloop<Cfg, SWAP, SPLIT, INIT>(p, m0, u0, lds_static, acc);
@@ -329,7 +340,7 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_tn_kernel(GemmOperandsT p, Store
   tile_of(id, tiles_m, tiles_n, tm, tn, s.splits > 1 ? patch_rows(nwg, tiles_n) : 8);
   const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BU;
   f32x4 acc[Cfg::MI][1][Cfg::NI];
-  gemm_mainloop_tn<Cfg, true>(p, m0, n0, lds_dyn, acc);      // transposed accumulators: lane = one row, 4 consecutive columns
+  gemm_mainloop_tn<Cfg, true, EVC_TN_LOOP_MODE>(p, m0, n0, lds_dyn, acc);      // transposed accumulators: lane = one row, 4 consecutive columns
   // Through the per-wave LDS transpose (store_tile_via_lds): whole sub-tile rows for the plain / slab stores, contiguous
   // row runs for the split-K atomics ("accumulate" is the same join onto what C already holds).
   float* C = s.C + split * s.slab_stride;
@@ -664,7 +675,7 @@ __device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const 
     __syncthreads();
     gemm_mainloop_v2<Cfg, true, false>(q, m0, u0, lds_dyn, acc);
   } else {
-    run_mainloop<Cfg, 4, true, SPLIT, false>(p, m0, u0, acc);   // transposed accumulators: lane = one row, 4 consecutive units
+    run_mainloop<Cfg, 4, true, SPLIT, false, EVC_FWD_LOOP_MODE>(p, m0, u0, acc);   // transposed accumulators: lane = one row, 4 consecutive units
   }
 #ifdef EVC_ABLATE_EPI    // debug build: main loop only (keep the accumulators alive, store nothing)
 #pragma unroll
@@ -1275,7 +1286,7 @@ __device__ __forceinline__ void lstm_bwd_step_body(const GemmOperands& p, const 
 #pragma unroll
     for (int ni = 0; ni < Cfg::NI; ++ni) acc[mi][0][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 #else
-  run_mainloop<Cfg, 1, true>(p, m0, u0, acc);     // transposed accumulators: lane = one row, 4 consecutive units
+  run_mainloop<Cfg, 1, true, false, true, EVC_BWD_LOOP_MODE>(p, m0, u0, acc);     // transposed accumulators: lane = one row, 4 consecutive units
 #endif
 #if !defined(EVC_ABLATE_BWD_EPI) && !defined(EVC_BWD_TAIL_FRAGMENTS)
   if constexpr (is_v2<Cfg>::value && Cfg::BU == 128 && Cfg::NT == 512 && Cfg::BM % 32 == 0 && BATCH_LOADS) {

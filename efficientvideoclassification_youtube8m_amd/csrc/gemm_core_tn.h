@@ -41,7 +41,7 @@ __device__ __forceinline__ int tn_h(int row) { return (((row >> 3) & 1) << 2) | 
 // SWAP = true issues the MFMA with the B fragment first: the accumulator tile is transposed - lane l holds
 // row (A column) m = l&15 and 4 consecutive columns n = (l>>4)*4 + reg (TileCoordsT) - so an epilogue that
 // walks n fastest gets 16-byte vector accesses to row-major [M][N] arrays.
-template <class Cfg, bool SWAP = false>
+template <class Cfg, bool SWAP = false, int MODE = 0>
 __device__ __forceinline__ void gemm_mainloop_tn(GemmOperandsT p, const int m0, const int n0, char* lds,
                                                  f32x4 (&acc)[Cfg::MI][1][Cfg::NI]) {
   static_assert(Cfg::G == 1 && Cfg::PIPE && !Cfg::RAGGED, "TN loop: plain tiles, pipelined, even staging");
@@ -59,19 +59,24 @@ __device__ __forceinline__ void gemm_mainloop_tn(GemmOperandsT p, const int m0, 
   const int nk = p.nk;
   if (nk == 0) return;
 
-  // ---- staging: chunk c = tid + i*NT -> k row c / CPR, physical chunk c % CPR ----
-  long a_off[Cfg::ACH], b_off[Cfg::BCH];
+  // ---- staging: chunk c = piece*64 + lane -> k row c / CPR, physical chunk c % CPR; piece q belongs to wave q % NPW ----
+  constexpr bool PRODUCERS = (MODE & LOOP_PRODUCER) != 0 && Cfg::NT == 512;   // waves 0..3 (one per SIMD) issue all the LDS-DMA
+  constexpr int NPW = PRODUCERS ? 4 : Cfg::NT / 64;
+  const bool producer = wave < NPW;
+  constexpr int ACH = Cfg::BM / 16 / NPW, BCH = Cfg::BN / 16 / NPW, PER = ACH + BCH;
+  static_assert(ACH * NPW * 16 == Cfg::BM && BCH * NPW * 16 == Cfg::BN, "pieces must divide over the staging waves");
+  long a_off[ACH], b_off[BCH];
 #pragma unroll
-  for (int i = 0; i < Cfg::ACH; ++i) {
-    const int c = tid + i * Cfg::NT;
+  for (int i = 0; i < ACH; ++i) {
+    const int c = ((wave % NPW) + i * NPW) * 64 + lane;
     const int row = c / ACPR, pc = c % ACPR;
     int col = m0 + ((pc ^ (tn_h(row) << 1)) << 3);
     col = col + 8 <= p.M ? col : p.M - 8;
     a_off[i] = (long)row * p.lda + col;
   }
 #pragma unroll
-  for (int i = 0; i < Cfg::BCH; ++i) {
-    const int c = tid + i * Cfg::NT;
+  for (int i = 0; i < BCH; ++i) {
+    const int c = ((wave % NPW) + i * NPW) * 64 + lane;
     const int row = c / BCPR, pc = c % BCPR;
     int col = n0 + ((pc ^ (tn_h(row) << 1)) << 3);
     col = col + 8 <= p.N ? col : p.N - 8;
@@ -85,13 +90,13 @@ __device__ __forceinline__ void gemm_mainloop_tn(GemmOperandsT p, const int m0, 
   auto stage = [&]() {
     char* sbase = lds + slot_issue * Cfg::STAGE_BYTES;
 #pragma unroll
-    for (int i = 0; i < Cfg::ACH; ++i)
+    for (int i = 0; i < ACH; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + a_off[i]),
-                                       (__attribute__((address_space(3))) void*)(sbase + (wave * 64 + i * Cfg::NT) * 16), 16, 0, EVC_TN_AUX_A);
+                                       (__attribute__((address_space(3))) void*)(sbase + ((wave % NPW) + i * NPW) * 1024), 16, 0, EVC_TN_AUX_A);
 #pragma unroll
-    for (int i = 0; i < Cfg::BCH; ++i)
+    for (int i = 0; i < BCH; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_base + b_off[i]),
-                                       (__attribute__((address_space(3))) void*)(sbase + Cfg::A_BYTES + (wave * 64 + i * Cfg::NT) * 16), 16, 0, EVC_TN_AUX_B);
+                                       (__attribute__((address_space(3))) void*)(sbase + Cfg::A_BYTES + ((wave % NPW) + i * NPW) * 1024), 16, 0, EVC_TN_AUX_B);
     a_base += a_step;
     b_base += b_step;
     slot_issue = (slot_issue + 1 == Cfg::STAGES) ? 0 : slot_issue + 1;
@@ -145,40 +150,45 @@ __device__ __forceinline__ void gemm_mainloop_tn(GemmOperandsT p, const int m0, 
   };
   constexpr int AHEAD = Cfg::STAGES - 2;
   auto wait_landed = [&](int outstanding_stages) {
-    if (outstanding_stages >= AHEAD) wait_vmcnt<AHEAD * Cfg::PER>();
-    else if (outstanding_stages == 2) wait_vmcnt<2 * Cfg::PER>();
-    else if (outstanding_stages == 1) wait_vmcnt<Cfg::PER>();
+    if (outstanding_stages >= AHEAD) wait_vmcnt<AHEAD * PER>();
+    else if (outstanding_stages == 2) wait_vmcnt<2 * PER>();
+    else if (outstanding_stages == 1) wait_vmcnt<PER>();
     else wait_vmcnt<0>();
   };
   static_assert(AHEAD == 3, "TN loop is written for the 5-deep ring");
 
+  auto run = [&](auto prod_tag) {     // one copy of the loop per role (see gemm_mainloop_v2)
+  constexpr bool PROD = decltype(prod_tag)::value;
+  auto stage_role = [&]() {
+    if constexpr (PROD) stage();
+  };
 #pragma unroll
   for (int i = 0; i < Cfg::STAGES - 1; ++i)
-    if (i < nk) stage();
+    if (i < nk) stage_role();
 
   auto full_step = [&](const bf16x8 (&afc)[Cfg::MI], const bf16x8 (&bfc)[Cfg::NI], bf16x8 (&afn)[Cfg::MI], bf16x8 (&bfn)[Cfg::NI]) {
-    wait_vmcnt<(AHEAD - 1) * Cfg::PER>();
+    if constexpr (PROD) wait_vmcnt<(AHEAD - 1) * PER>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_setprio(1);
-    stage();
+    if constexpr ((MODE & LOOP_NO_PRIO) == 0) __builtin_amdgcn_s_setprio(1);
+    stage_role();
     read_frags(afn, bfn);
     mfma_all(afc, bfc);
-    __builtin_amdgcn_s_setprio(0);
+    if constexpr ((MODE & LOOP_NO_PRIO) == 0) __builtin_amdgcn_s_setprio(0);
     end_of_step();
   };
   auto tail_step = [&](int kt, const bf16x8 (&afc)[Cfg::MI], const bf16x8 (&bfc)[Cfg::NI], bf16x8 (&afn)[Cfg::MI], bf16x8 (&bfn)[Cfg::NI]) {
     if (kt + 1 < nk) {
-      wait_landed(min(nk, kt + Cfg::STAGES - 1) - (kt + 2));
+      if constexpr (PROD) wait_landed(min(nk, kt + Cfg::STAGES - 1) - (kt + 2));
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (kt + Cfg::STAGES - 1 < nk) stage();
+      if (kt + Cfg::STAGES - 1 < nk) stage_role();
       read_frags(afn, bfn);
     }
     mfma_all(afc, bfc);
     end_of_step();
   };
-  wait_landed(min(nk, Cfg::STAGES - 1) - 1);
+  if constexpr (PROD) wait_landed(min(nk, Cfg::STAGES - 1) - 1);
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   bf16x8 afA[Cfg::MI], bfA[Cfg::NI], afB[Cfg::MI], bfB[Cfg::NI];
@@ -194,4 +204,11 @@ __device__ __forceinline__ void gemm_mainloop_tn(GemmOperandsT p, const int m0, 
     tail_step(kt + 1, afB, bfB, afA, bfA);
   }
   if (kt < nk) tail_step(kt, afA, bfA, afB, bfB);
+  };   // run
+  if constexpr (PRODUCERS) {
+    if (producer) run(std::true_type{});
+    else run(std::false_type{});
+  } else {
+    run(std::true_type{});
+  }
 }

@@ -20,10 +20,17 @@
 //  * Rows beyond M / units beyond Nu are clamped on load; K % 32 == 0.
 #pragma once
 #include "gemm_core.h"
+#include <type_traits>
 
-#ifndef EVC_PRIO_MODE
-#define EVC_PRIO_MODE 0     // 0: s_setprio 1 around every K step's MFMA cluster; 1: static - the second-dispatched half of the
-#endif                      // workgroup (waves 4-7) at priority 1 for the whole loop, no flips; 2: no priority changes
+// Loop options (template parameter MODE of the main loops, a bit mask; measured per kernel):
+//  LOOP_PRODUCER   only waves 0..3 (one per SIMD: waves i and i+4 share a SIMD) issue the LDS-DMA, twice as many pieces
+//                  each; their SIMD partners run nothing but fragment reads and MFMAs (two copies of the loop, chosen once)
+//  LOOP_DMA_FIRST  the scheduler is asked to place the LDS-DMA ahead of the fragment reads among the MFMAs of a K step
+//  LOOP_NO_PRIO    no s_setprio 1 / 0 around every K step's MFMA cluster
+constexpr int LOOP_PRODUCER = 1, LOOP_DMA_FIRST = 2, LOOP_NO_PRIO = 4;
+#ifndef EVC_LOOP_MODE_DEFAULT
+#define EVC_LOOP_MODE_DEFAULT 0
+#endif
 
 template <int BM_, int G_, int BU_, int WR_, int WC_, int STAGES_ = 5, bool PIPE_ = true>
 struct TileCfg2 {
@@ -50,7 +57,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <class Cfg, bool SWAP = false, bool INIT = true>
+template <class Cfg, bool SWAP = false, bool INIT = true, int MODE = EVC_LOOP_MODE_DEFAULT>
 __device__ __forceinline__ void gemm_mainloop_v2(const GemmOperands& p, const int m0, const int u0, char* lds,
                                                  f32x4 (&acc)[Cfg::MI][Cfg::G][Cfg::NI]) {
   const int tid = threadIdx.x;
@@ -71,25 +78,32 @@ __device__ __forceinline__ void gemm_mainloop_v2(const GemmOperands& p, const in
   if (nk == 0) return;
 
   // ---- staging: chunk c = tid + i*NT -> tile row c>>2, physical chunk c&3 ----
+  // Piece q (1 KiB = 16 tile rows) belongs to staging wave q % NPW (LOOP_PRODUCER: 4 staging waves, else all of them).
   const int lc8 = ((tid & 3) ^ swz64(tid >> 2)) * 8;
-  int a_row[Cfg::ACH];
-  long b_off[Cfg::BCH];
-  int a_dst[Cfg::ACH], b_dst[Cfg::BCH];   // wave-uniform LDS byte offsets within a stage (or the dummy sink)
+  constexpr bool PRODUCERS = (MODE & LOOP_PRODUCER) != 0 && Cfg::NT == 512;
+  constexpr int NPW = PRODUCERS ? 4 : Cfg::NT / 64;
+  const bool producer = wave < NPW;
+  constexpr int ACH = (Cfg::BM / 16 + NPW - 1) / NPW, BCH = (Cfg::BN / 16 + NPW - 1) / NPW;
+  constexpr int PER = ACH + BCH;
+  static_assert(Cfg::RAGGED || (ACH * NPW * 16 == Cfg::BM && BCH * NPW * 16 == Cfg::BN), "surplus pieces need the dummy sink");
+  int a_row[ACH];
+  long b_off[BCH];
+  int a_dst[ACH], b_dst[BCH];   // wave-uniform LDS byte offsets within a stage (or the dummy sink)
 #pragma unroll
-  for (int i = 0; i < Cfg::ACH; ++i) {
-    const int c0 = wave * 64 + i * Cfg::NT;                 // first chunk of this wave-instruction
+  for (int i = 0; i < ACH; ++i) {
+    const int c0 = ((wave % NPW) + i * NPW) * 64;           // first chunk of this wave-instruction
     const bool live = c0 < Cfg::BM * 4;                     // wave-uniform
-    int r = (tid + i * Cfg::NT) >> 2;
+    int r = (c0 + lane) >> 2;
     r = live ? r : 0;
     int gr = m0 + r;
     a_row[i] = gr < p.M ? gr : p.M - 1;
     a_dst[i] = live ? c0 * 16 : -1;
   }
 #pragma unroll
-  for (int i = 0; i < Cfg::BCH; ++i) {
-    const int c0 = wave * 64 + i * Cfg::NT;
+  for (int i = 0; i < BCH; ++i) {
+    const int c0 = ((wave % NPW) + i * NPW) * 64;
     const bool live = c0 < Cfg::BN * 4;
-    int r = (tid + i * Cfg::NT) >> 2;
+    int r = (c0 + lane) >> 2;
     r = live ? r : 0;
     const int g = r / Cfg::BU, u = r % Cfg::BU;
     int gu = u0 + u;
@@ -110,13 +124,13 @@ __device__ __forceinline__ void gemm_mainloop_v2(const GemmOperands& p, const in
     const bf16_t* b_base = (s1 ? p.B : b2) + (long)kt_issue * 32;
     char* sbase = lds + slot_issue * Cfg::STAGE_BYTES;
 #pragma unroll
-    for (int i = 0; i < Cfg::ACH; ++i) {
+    for (int i = 0; i < ACH; ++i) {
       char* dst = a_dst[i] >= 0 ? sbase + a_dst[i] : lds + Cfg::DUMMY_OFF;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ab + (long)a_row[i] * lda + lc8),
                                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < Cfg::BCH; ++i) {
+    for (int i = 0; i < BCH; ++i) {
       char* dst = b_dst[i] >= 0 ? sbase + b_dst[i] : lds + Cfg::DUMMY_OFF;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_base + b_off[i]),
                                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -170,77 +184,88 @@ __device__ __forceinline__ void gemm_mainloop_v2(const GemmOperands& p, const in
   // barrier together), leaving the matrix pipe idle.  Ask the scheduler for MFMA pairs with one
   // LDS read / one LDS-DMA between them.
   constexpr int NMFMA = Cfg::MI * Cfg::G * Cfg::NI, NREAD = Cfg::MI + Cfg::G * Cfg::NI;
+  constexpr int AHEAD = Cfg::STAGES - 2;   // K steps of LDS-DMA left in flight at a wait (ring minus the slot
+                                           // being read and the slot whose reads may still be pending)
+  auto wait_landed = [&](int outstanding_stages) {   // wave-uniform small switch; only the tail leaves the first arm
+    if (outstanding_stages >= AHEAD) wait_vmcnt<AHEAD * PER>();
+    else if (outstanding_stages == 5) wait_vmcnt<5 * PER>();
+    else if (outstanding_stages == 4) wait_vmcnt<4 * PER>();
+    else if (outstanding_stages == 3) wait_vmcnt<3 * PER>();
+    else if (outstanding_stages == 2) wait_vmcnt<2 * PER>();
+    else if (outstanding_stages == 1) wait_vmcnt<PER>();
+    else wait_vmcnt<0>();
+  };
+  static_assert(AHEAD >= 1 && AHEAD <= 6, "ring depth 3..8");
+
+  // One copy of the loop per role (LOOP_PRODUCER: waves 0..3 stage, waves 4..7 do not - a wave-uniform choice made once, so
+  // that each steady-state loop stays one branch-free basic block).
+  auto run = [&](auto prod_tag) {
+  constexpr bool PROD = decltype(prod_tag)::value;
+  constexpr bool PRIO = (MODE & LOOP_NO_PRIO) == 0;
+  constexpr int PERX = PROD ? PER : 0;               // LDS-DMA instructions this role issues per K step
+  auto stage_role = [&]() {
+    if constexpr (PROD) stage();
+  };
   auto interleave_pipe = [&]() {
-    constexpr int per = NMFMA / (NREAD + Cfg::PER) > 0 ? NMFMA / (NREAD + Cfg::PER) : 1;
+    constexpr int per = NMFMA / (NREAD + PERX) > 0 ? NMFMA / (NREAD + PERX) : 1;
+    if constexpr ((MODE & LOOP_DMA_FIRST) != 0) {
+#pragma unroll
+      for (int i = 0; i < PERX; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, per, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read (LDS-DMA)
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NREAD; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, per, 0);   // MFMA
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
     }
+    if constexpr ((MODE & LOOP_DMA_FIRST) == 0) {
 #pragma unroll
-    for (int i = 0; i < Cfg::PER; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, per, 0);
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read (LDS-DMA)
+      for (int i = 0; i < PERX; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, per, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read (LDS-DMA)
+      }
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - per * (NREAD + Cfg::PER), 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - per * (NREAD + PERX), 0);
   };
-  constexpr int AHEAD = Cfg::STAGES - 2;   // K steps of LDS-DMA left in flight at a wait (ring minus the slot
-                                           // being read and the slot whose reads may still be pending)
-  auto wait_landed = [&](int outstanding_stages) {   // wave-uniform small switch; only the tail leaves the first arm
-    if (outstanding_stages >= AHEAD) wait_vmcnt<AHEAD * Cfg::PER>();
-    else if (outstanding_stages == 5) wait_vmcnt<5 * Cfg::PER>();
-    else if (outstanding_stages == 4) wait_vmcnt<4 * Cfg::PER>();
-    else if (outstanding_stages == 3) wait_vmcnt<3 * Cfg::PER>();
-    else if (outstanding_stages == 2) wait_vmcnt<2 * Cfg::PER>();
-    else if (outstanding_stages == 1) wait_vmcnt<Cfg::PER>();
-    else wait_vmcnt<0>();
-  };
-  static_assert(AHEAD >= 1 && AHEAD <= 6, "ring depth 3..8");
-
   // ---- prologue: STAGES-1 K steps in flight ----
 #pragma unroll
   for (int i = 0; i < Cfg::STAGES - 1; ++i)
-    if (i < nk) stage();
+    if (i < nk) stage_role();
 
-#if EVC_PRIO_MODE == 1
-  if (wave >= Cfg::WR * Cfg::WC / 2) __builtin_amdgcn_s_setprio(1);
-#endif
   if constexpr (Cfg::PIPE) {
     // Software-pipelined: iteration kt makes step kt+1 visible, refills the ring, starts the
     // fragment reads of kt+1 and runs the MFMAs of step kt from registers.
     // At the wait of iteration kt the steps kt+2 .. kt+AHEAD may stay in flight.
     auto full_step = [&](const bf16x8 (&afc)[Cfg::MI], const bf16x8 (&bfc)[Cfg::G][Cfg::NI],
                          bf16x8 (&afn)[Cfg::MI], bf16x8 (&bfn)[Cfg::G][Cfg::NI]) {
-      wait_vmcnt<(AHEAD - 1) * Cfg::PER>();
+      if constexpr (PROD) wait_vmcnt<(AHEAD - 1) * PER>();
       __builtin_amdgcn_s_barrier();   // step kt+1 landed for every wave; every wave has consumed step kt-1's fragments
       asm volatile("" ::: "memory");
-#if EVC_PRIO_MODE == 0
-      __builtin_amdgcn_s_setprio(1);
-#endif
-      stage();                        // refill step kt-1's slot with step kt+STAGES-1
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+      stage_role();                   // refill step kt-1's slot with step kt+STAGES-1
       read_frags(afn, bfn);
       mfma_all(afc, bfc);
 #ifndef EVC_NO_INTERLEAVE
       interleave_pipe();
 #endif
-#if EVC_PRIO_MODE == 0
-      __builtin_amdgcn_s_setprio(0);
-#endif
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
       end_of_step();
     };
     auto tail_step = [&](int kt, const bf16x8 (&afc)[Cfg::MI], const bf16x8 (&bfc)[Cfg::G][Cfg::NI],
                          bf16x8 (&afn)[Cfg::MI], bf16x8 (&bfn)[Cfg::G][Cfg::NI]) {
       if (kt + 1 < nk) {
-        wait_landed(min(nk, kt + Cfg::STAGES - 1) - (kt + 2));
+        if constexpr (PROD) wait_landed(min(nk, kt + Cfg::STAGES - 1) - (kt + 2));
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kt + Cfg::STAGES - 1 < nk) stage();
+        if (kt + Cfg::STAGES - 1 < nk) stage_role();
         read_frags(afn, bfn);
       }
       mfma_all(afc, bfc);
       end_of_step();
     };
-    wait_landed(min(nk, Cfg::STAGES - 1) - 1);
+    if constexpr (PROD) wait_landed(min(nk, Cfg::STAGES - 1) - 1);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     bf16x8 afA[Cfg::MI], bfA[Cfg::G][Cfg::NI], afB[Cfg::MI], bfB[Cfg::G][Cfg::NI];
@@ -263,12 +288,12 @@ __device__ __forceinline__ void gemm_mainloop_v2(const GemmOperands& p, const in
     bf16x8 af[Cfg::MI], bfr[Cfg::G][Cfg::NI];
     int kt = 0;
     for (; kt + Cfg::STAGES - 1 < nk; ++kt) {
-      wait_vmcnt<(Cfg::STAGES - 2) * Cfg::PER>();
+      if constexpr (PROD) wait_vmcnt<(Cfg::STAGES - 2) * PER>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_setprio(1);
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
       read_frags(af, bfr);
-      stage();
+      stage_role();
       mfma_all(af, bfr);
 #ifndef EVC_NO_INTERLEAVE
       // B fragments + the first A fragment up front, then one MFMA row per further A read, LDS-DMA last
@@ -277,20 +302,27 @@ __device__ __forceinline__ void gemm_mainloop_v2(const GemmOperands& p, const in
       for (int i = 0; i + 1 < Cfg::MI; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, Cfg::G * Cfg::NI, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        if (i < Cfg::PER) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if (i < PERX) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
       __builtin_amdgcn_sched_group_barrier(0x008, Cfg::G * Cfg::NI, 0);
 #endif
-      __builtin_amdgcn_s_setprio(0);
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
       end_of_step();
     }
     for (; kt < nk; ++kt) {
-      wait_landed(nk - 1 - kt);
+      if constexpr (PROD) wait_landed(nk - 1 - kt);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       read_frags(af, bfr);
       mfma_all(af, bfr);
       end_of_step();
     }
+  }
+  };   // run
+  if constexpr (PRODUCERS) {
+    if (producer) run(std::true_type{});
+    else run(std::false_type{});
+  } else {
+    run(std::true_type{});
   }
 }
