@@ -714,3 +714,18 @@ def test_gemm_nt_ring_tile_store_paths(tile):
         env["EVC_FORCE_TILE"] = tile
     r = subprocess.run([sys.executable, "-c", NT_STORE_WORKER % {"root": root}], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("tile", ["1", "2", "3", "4", "5", "6", "7", "8", "9", "10"])
+def test_lstm_steps_on_every_ring_tile(tile):
+    """The fused LSTM step kernels on every ring-tile height (EVC_FORCE_TILE pins the choice: forward 1 -> 256 rows, 4 -> 320,
+    5 -> 288, 6 -> 224, 7 -> 192, 8 -> 160, 9 -> 128, 10 -> 64; BPTT 1 -> 192, 2 -> 160, 3 -> 128) against the oracle - the
+    160 / 224 / 288-row tiles have surplus staging lanes (dummy LDS sink), and the forward loop stages through four producer
+    waves.  One process per tile (the choice is read once per process)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EVC_FORCE_TILE=tile)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-x", "-q", "-m", "gpu", "-k",
+                        "(test_lstm_layer_fwd_and_bwd and (1536 or 640 or 200)) or test_lstm_layer_with_row_plan_matches_plain"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
