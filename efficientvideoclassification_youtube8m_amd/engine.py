@@ -212,6 +212,20 @@ class LstmStack:
             inp = self._hb[l][1:]
         return res
 
+    def _wgrad_tn(self, dz2, layer_in, h_prev, kin, rows, gW):
+        """gW [4H][kin+H] += dz^T . [layer_in | h_prev] (gate rows de-interleaved).  One launch over both column segments when
+        the input width allows it (kin == H, a multiple of 256: the upper layers): dz is read once and the launch has twice the
+        tiles; two launches otherwise (layer 0 of the L1 stacks: 1152 + 1024 columns = 8.5 column tiles would leave half of
+        the chip idle in the second round)."""
+        H = self.H
+        if kin == H and kin % 256 == 0 and self.fuse_wgrad:
+            ops.gemm_tn2(dz2, layer_in, kin, h_prev, H, 4 * H, rows, gW, row_interleave_H=H, accumulate=True)
+        else:
+            ops.gemm_tn(dz2, layer_in, 4 * H, kin, rows, gW, row_interleave_H=H, ldc=kin + H, accumulate=True)
+            ops.gemm_tn(dz2, h_prev, 4 * H, H, rows, gW[:, kin:], row_interleave_H=H, ldc=kin + H, accumulate=True)
+
+    fuse_wgrad = os.environ.get("EVC_NO_FUSED_WGRAD") != "1"
+
     def backward(self, dS, need_dx, aux=None):
         """dS [M, 2LH] f32.  Writes the grads of this stack's kernels/biases into the tower's grad
         buffer; returns dX [T*M, Kin] f32 (gradient wrt the stack input) if need_dx.
@@ -250,8 +264,7 @@ class LstmStack:
                     layer_in = (self.x_in if l == 0 else self._hb[0][1:]).reshape(T * M, kin)
                     h_prev = self._hb[l][:T].reshape(T * M, H)
                     ops.fill_f32(gW, 0.0)
-                    ops.gemm_tn(dz2, layer_in, 4 * H, kin, T * M, gW, row_interleave_H=H, ldc=kin + H, accumulate=True)
-                    ops.gemm_tn(dz2, h_prev, 4 * H, H, T * M, gW[:, kin:], row_interleave_H=H, ldc=kin + H, accumulate=True)
+                    self._wgrad_tn(dz2, layer_in, h_prev, kin, T * M, gW)
             return None
         for l in range(L - 1, -1, -1):
             kn, bn = self.names(l)
@@ -297,8 +310,7 @@ class LstmStack:
                     # tiles are added with atomics: one contiguous fill of the whole gradient, then accumulate
                     # (instead of a pitched 2-D memset inside each call).
                     ops.fill_f32(gW, 0.0)
-                    ops.gemm_tn(dz2, layer_in, 4 * H, kin, T * M, gW, row_interleave_H=H, ldc=kin + H, accumulate=True)
-                    ops.gemm_tn(dz2, h_prev, 4 * H, H, T * M, gW[:, kin:], row_interleave_H=H, ldc=kin + H, accumulate=True)
+                    self._wgrad_tn(dz2, layer_in, h_prev, kin, T * M, gW)
                 else:   # T*M not a multiple of 32: transposed copies + NT products
                     ops.transpose_to_bf16(dz2, T * M, 4 * H, self.dzT, KP, interleave_H=-H)
                     inT = self.xT[:kin]

@@ -56,6 +56,14 @@ def gemm_tn(A, B, M, N, K, out, row_interleave_H=0, accumulate=False, lda=None, 
     return out
 
 
+def gemm_tn2(A, B1, N1, B2, N2, M, K, out, row_interleave_H=0, accumulate=False, ldc=None):
+    """out[M, N1+N2] (+)= A[K,M]^T @ [B1[K,N1] | B2[K,N2]]: one launch for two column segments (N1 % 256 == 0)."""
+    assert A.dtype == BF16 and B1.dtype == BF16 and B2.dtype == BF16 and out.dtype == F32
+    _lib.call("evc_gemm_tn2", _p(A), A.stride(0), _p(B1), B1.stride(0), N1, _p(B2), B2.stride(0), N2, _p(out),
+              out.stride(0) if ldc is None else ldc, M, K, row_interleave_H, 1 if accumulate else 0, _stream())
+    return out
+
+
 def fill_f32(t, value):
     """Contiguous f32 fill (one streaming kernel; hipMemset2D on a pitched view is several times slower)."""
     assert t.dtype == F32 and t.is_contiguous()

@@ -352,6 +352,31 @@ def test_gemm_tn_and_colsum(ops, M, N, K, il):
     assert np.max(np.abs(cs.cpu().double().numpy() - cref)) < 1e-3 * (np.abs(A).sum(0).max() + 1)
 
 
+@pytest.mark.parametrize("M,N1,N2,K,il", [(512, 256, 256, 64, 0), (1024, 256, 264, 2560, 256), (4096, 1024, 1024, 8192, 1024),
+                                           (1024, 512, 128, 1024, 0)])
+def test_gemm_tn2_two_column_segments(ops, M, N1, N2, K, il):
+    """evc_gemm_tn2: C[:, :N1] = A^T B1, C[:, N1:] = A^T B2 in one launch (the x- and h-part of a layer's weight gradient),
+    plain / accumulate / split-K forms, ragged second segment, gate de-interleave; B1 and B2 with different row strides."""
+    rng = np.random.default_rng(M + N1 + N2 + K)
+    A = bf16_round(rng.standard_normal((K, M)) * 0.5)
+    B1 = bf16_round(rng.standard_normal((K, N1 + 8)) * 0.5)[:, :N1]       # row stride N1 + 8
+    B2 = bf16_round(rng.standard_normal((K, N2)) * 0.5)
+    ref = np.concatenate([A.T @ B1, A.T @ B2], axis=1)
+    if il:
+        ref = ref.reshape(M // 4, 4, N1 + N2).transpose(1, 0, 2).reshape(M, N1 + N2)
+    b1 = to_bf16(np.ascontiguousarray(bf16_round(np.concatenate([B1, np.zeros((K, 8))], axis=1))))[:, :N1]
+    out = torch.full((M, N1 + N2), float("nan"), dtype=torch.float32, device=DEV)
+    ops.gemm_tn2(to_bf16(A), b1, N1, to_bf16(B2), N2, M, K, out, row_interleave_H=il)
+    got = out.cpu().double().numpy()
+    scale = (np.abs(A.T) @ np.abs(np.concatenate([B1, B2], axis=1))).max() + 1.0
+    assert np.isfinite(got).all()
+    assert np.max(np.abs(got - ref)) / scale < 3e-6
+    ops.gemm_tn2(to_bf16(A), b1, N1, to_bf16(B2), N2, M, K, out, row_interleave_H=il, accumulate=True)
+    assert np.max(np.abs(out.cpu().double().numpy() - 2 * ref)) / scale < 6e-6
+    with pytest.raises(Exception):                                       # the segment boundary must fall on a tile boundary
+        ops.gemm_tn2(to_bf16(A), b1[:, :128], 128, to_bf16(B2), N2, M, K, out[:, :128 + N2])
+
+
 @pytest.mark.parametrize("M,T", [(40, 15), (5120, 15), (1280, 6), (7000, 31)])
 def test_sort_rows_and_host_counts(ops, M, T):
     """evc_sort_rows_by_len = numpy's stable argsort by descending length (integer work: exact)."""
