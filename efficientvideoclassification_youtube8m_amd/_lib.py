@@ -21,7 +21,7 @@ SIGNATURES = {
     "evc_frame_counts": [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp],
     "evc_gemm_nt": [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i32, i32, vp],
     "evc_gemm_tn": [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp],
-    "evc_gemm_tn2": [vp, i64, vp, i64, i32, vp, i64, i32, vp, i64, i32, i32, i32, i32, vp],
+    "evc_gemm_tn2": [vp, i64, vp, i64, i32, vp, i64, i32, i32, vp, i64, i32, i32, i32, i32, vp],
     "evc_colsum_bf16": [vp, i64, i32, i32, i32, vp, vp],
     "evc_lstm_layer_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp],
     "evc_lstm_layer_fwd_hp": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp],

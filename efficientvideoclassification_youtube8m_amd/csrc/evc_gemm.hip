@@ -334,11 +334,17 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_tn_kernel(GemmOperandsT p, Store
   const int id = xcd_remap(bid, nwg);
   int tm, tn;
   tile_of(id, tiles_m, tiles_n, tm, tn, s.splits > 1 ? patch_rows(nwg, tiles_n) : 8);
-  const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BU;
+  const int m0 = tm * Cfg::BM;
+  int n0 = tn * Cfg::BU;
   int nb = n0;                                                 // first column within the B segment this workgroup reads
   if (p.B2) {                                                  // two column segments (workgroup-uniform choice)
-    if (n0 >= p.N1) { p.B = p.B2; p.ldb = p.ldb2; nb = n0 - p.N1; p.N = s.N - p.N1; }
-    else p.N = p.N1;
+    if (n0 >= p.N1) {
+      p.B = p.B2; p.ldb = p.ldb2; nb = n0 - p.N1; p.N = s.N - p.N1;
+      s.N = p.c_col2 + p.N;                                    // the segment's columns in C: [c_col2, c_col2 + N2)
+      n0 = p.c_col2 + nb;
+    } else {
+      p.N = s.N = p.N1;
+    }
   }
   if (s.splits > 1) {
     const int k0 = split * s.ksteps_per_split;
@@ -384,17 +390,17 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_tn_kernel(GemmOperandsT p, Store
 }
 
 static int gemm_tn_impl(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, int N1, const evc_bf16* B2, int64_t ldb2,
-                        float* C, int64_t ldc, int M, int N, int K, int row_interleave_H, int accumulate, void* stream) {
+                        int c_col2, float* C, int64_t ldc, int M, int N, int K, int row_interleave_H, int accumulate, void* stream) {
   EVC_REQUIRE(M >= 8 && N >= 8 && K > 0 && M % 8 == 0 && N % 8 == 0 && K % 32 == 0, EVC_ERR_BAD_SHAPE,
               "evc_gemm_tn: needs M %% 8 == 0, N %% 8 == 0, K %% 32 == 0 (M=%d N=%d K=%d)", M, N, K);
   EVC_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, EVC_ERR_BAD_ALIGN,
               "evc_gemm_tn: operands must be 16-byte aligned (lda=%ld ldb=%ld)", (long)lda, (long)ldb);
   EVC_REQUIRE(row_interleave_H == 0 || M == 4 * row_interleave_H, EVC_ERR_BAD_SHAPE, "evc_gemm_tn: row_interleave_H needs M == 4*H");
-  EVC_REQUIRE(!B2 || (N1 > 0 && N1 < N && N1 % 256 == 0 && ldb2 % 8 == 0 && ((uintptr_t)B2 % 16) == 0), EVC_ERR_BAD_SHAPE,
-              "evc_gemm_tn2: N1=%d must be a multiple of 256 inside (0, N=%d), B2 16-byte aligned with ldb2 %% 8 == 0", N1, N);
+  EVC_REQUIRE(!B2 || (N1 > 0 && N1 < N && N1 % 256 == 0 && ldb2 % 8 == 0 && ((uintptr_t)B2 % 16) == 0 && c_col2 >= N1), EVC_ERR_BAD_SHAPE,
+              "evc_gemm_tn2: N1=%d must be a multiple of 256 inside (0, N=%d), B2 16-byte aligned with ldb2 %% 8 == 0, c_col2=%d >= N1", N1, N, c_col2);
   hipStream_t st = (hipStream_t)stream;
   GemmOperandsT p{A, lda, B, ldb, M, N, K / 32};
-  if (B2) { p.B2 = B2; p.ldb2 = ldb2; p.N1 = N1; }
+  if (B2) { p.B2 = B2; p.ldb2 = ldb2; p.N1 = N1; p.c_col2 = c_col2; }
   typedef TileCfg2<128, 1, 128, 2, 4, 5, true> CfgTn128;
   // short contractions (the student's L2: K = 5 x 256 rows) on 128x128 tiles without split-K: the atomic join of
   // 256x256 partial tiles costs more than the product itself there (81 -> 36 us at 4096 x 1024 x 1280); from
@@ -403,6 +409,20 @@ static int gemm_tn_impl(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64
     const int tm1 = ceil_div(M, 128), tn1 = ceil_div(N, 128);
     StoreParamsT s1{C, ldc, M, N, row_interleave_H, accumulate, 1, p.nk, 0};
     launch_cfg<CfgTn128>(gemm_tn_kernel<CfgTn128>, tm1 * tn1, st, p, s1, tm1, tn1);
+    EVC_LAUNCH_CHECK();
+    return EVC_OK;
+  }
+  // a narrow strip (N <= 128: the last 128 input columns of an L1 layer-0 kernel gradient, see engine._wgrad_tn): 128x128 tiles,
+  // K split until ~256 workgroups exist - a 256-column tile would do half of its MFMAs on columns that do not exist
+  if (forced_tile() == 0 && N <= 128 && !B2) {
+    const int tm1 = ceil_div(M, 128);
+    int splits = 256 / tm1;
+    if (splits > K / 1024) splits = K / 1024;
+    if (splits < 1) splits = 1;
+    while (splits > 1 && (long)ceil_div(p.nk, splits) * (splits - 1) >= p.nk) --splits;     // no empty split
+    StoreParamsT s1{C, ldc, M, N, row_interleave_H, accumulate, splits, ceil_div(p.nk, splits), 0};
+    if (splits > 1 && !accumulate) EVC_CHECK_HIP(hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st));
+    launch_cfg<CfgTn128>(gemm_tn_kernel<CfgTn128>, tm1 * splits, st, p, s1, tm1, 1);
     EVC_LAUNCH_CHECK();
     return EVC_OK;
   }
@@ -419,13 +439,15 @@ static int gemm_tn_impl(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64
 
 extern "C" int evc_gemm_tn(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, float* C, int64_t ldc,
                            int M, int N, int K, int row_interleave_H, int accumulate, void* stream) {
-  return gemm_tn_impl(A, lda, B, ldb, 0, nullptr, 0, C, ldc, M, N, K, row_interleave_H, accumulate, stream);
+  return gemm_tn_impl(A, lda, B, ldb, 0, nullptr, 0, 0, C, ldc, M, N, K, row_interleave_H, accumulate, stream);
 }
 
 extern "C" int evc_gemm_tn2(const evc_bf16* A, int64_t lda, const evc_bf16* B1, int64_t ldb1, int N1, const evc_bf16* B2, int64_t ldb2,
-                            int N2, float* C, int64_t ldc, int M, int K, int row_interleave_H, int accumulate, void* stream) {
+                            int N2, int c_col2, float* C, int64_t ldc, int M, int K, int row_interleave_H, int accumulate, void* stream) {
   EVC_REQUIRE(B1 && B2 && N1 > 0 && N2 > 0, EVC_ERR_BAD_ARG, "evc_gemm_tn2: two column segments are required");
-  return gemm_tn_impl(A, lda, B1, ldb1, N1, B2, ldb2, C, ldc, M, N1 + N2, K, row_interleave_H, accumulate, stream);
+  EVC_REQUIRE(accumulate || c_col2 == N1, EVC_ERR_BAD_ARG, "evc_gemm_tn2: segments that are not adjacent in C (c_col2=%d, N1=%d) need accumulate "
+              "(the split-K join adds into a C the caller has zeroed)", c_col2, N1);
+  return gemm_tn_impl(A, lda, B1, ldb1, N1, B2, ldb2, c_col2, C, ldc, M, N1 + N2, K, row_interleave_H, accumulate, stream);
 }
 
 // Split-K into slabs: slab s (s < nslab) = the partial product over K rows [s*ceil(K/32/nslab)*32, ...), stored plainly at

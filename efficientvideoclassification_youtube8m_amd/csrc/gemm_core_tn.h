@@ -37,6 +37,7 @@ struct GemmOperandsT {
   // B as two column segments (evc_gemm_tn2): product columns [0, N1) come from B, columns [N1, N) from B2 [K][ldb2];
   // N1 is a multiple of the tile width, so a workgroup's columns lie in one segment (gemm_tn_kernel picks it)
   const bf16_t* B2 = nullptr; long ldb2 = 0; int N1 = 0;
+  int c_col2 = 0;              // C column where the second segment's columns start (>= N1: the segments need not be adjacent in C)
 };
 
 __device__ __forceinline__ int tn_h(int row) { return (((row >> 3) & 1) << 2) | (row & 3); }

@@ -56,11 +56,12 @@ def gemm_tn(A, B, M, N, K, out, row_interleave_H=0, accumulate=False, lda=None, 
     return out
 
 
-def gemm_tn2(A, B1, N1, B2, N2, M, K, out, row_interleave_H=0, accumulate=False, ldc=None):
-    """out[M, N1+N2] (+)= A[K,M]^T @ [B1[K,N1] | B2[K,N2]]: one launch for two column segments (N1 % 256 == 0)."""
+def gemm_tn2(A, B1, N1, B2, N2, M, K, out, row_interleave_H=0, accumulate=False, ldc=None, c_col2=None):
+    """out[:, :N1] (+)= A[K,M]^T @ B1[K,N1], out[:, c_col2:c_col2+N2] (+)= A^T @ B2[K,N2] in one launch (N1 % 256 == 0;
+    c_col2 defaults to N1: adjacent segments)."""
     assert A.dtype == BF16 and B1.dtype == BF16 and B2.dtype == BF16 and out.dtype == F32
-    _lib.call("evc_gemm_tn2", _p(A), A.stride(0), _p(B1), B1.stride(0), N1, _p(B2), B2.stride(0), N2, _p(out),
-              out.stride(0) if ldc is None else ldc, M, K, row_interleave_H, 1 if accumulate else 0, _stream())
+    _lib.call("evc_gemm_tn2", _p(A), A.stride(0), _p(B1), B1.stride(0), N1, _p(B2), B2.stride(0), N2, N1 if c_col2 is None else c_col2,
+              _p(out), out.stride(0) if ldc is None else ldc, M, K, row_interleave_H, 1 if accumulate else 0, _stream())
     return out
 
 

@@ -389,11 +389,13 @@ int evc_dbof_pool_finish(const float* xsel, int B, int C, const float* mean, con
 int evc_dbof_dact(evc_bf16* act, const float* dpooled, const float* pooled, const uint8_t* arg, const float* mean,
                   const float* var, const float* gamma, const double* ws, int R_total, int B, int S, int C, float* dgamma,
                   float* dbeta, void* stream);
-/* evc_gemm_tn with B given as two column segments: C[:, 0:N1] from B1 [K][ldb1], C[:, N1:N1+N2] from B2 [K][ldb2] - the x- and
- * h-part of a layer's weight gradient dW^T = dz^T . [x | h_prev] in ONE launch (dz is read once, twice the tiles per launch:
- * 4096 x 2048 x 56 640 runs 1.0 ms against 2 x 0.6).  N1 % 256 == 0 (a workgroup's columns lie in one segment). */
+/* evc_gemm_tn with B given as two column segments: C[:, 0:N1] from B1 [K][ldb1], C[:, c_col2:c_col2+N2] from B2 [K][ldb2] - the
+ * x- and h-part of a layer's weight gradient dW^T = dz^T . [x | h_prev] in ONE launch (dz is read once, twice the tiles per
+ * launch: 4096 x 2048 x 56 640 runs 1.0 ms against 2 x 0.6).  N1 % 256 == 0 (a workgroup's columns lie in one segment);
+ * c_col2 >= N1 is where the second segment starts in C (c_col2 > N1, a gap the caller fills with another product, needs
+ * accumulate = 1 on a zeroed C). */
 int evc_gemm_tn2(const evc_bf16* A, int64_t lda, const evc_bf16* B1, int64_t ldb1, int N1, const evc_bf16* B2, int64_t ldb2,
-                 int N2, float* C, int64_t ldc, int M, int K, int row_interleave_H, int accumulate, void* stream);
+                 int N2, int c_col2, float* C, int64_t ldc, int M, int K, int row_interleave_H, int accumulate, void* stream);
 /* evc_gemm_tn with the K range cut into nslab partial products stored plainly at slabs + s*M*N (no atomics). */
 int evc_gemm_tn_slabs(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, float* slabs, int M, int N, int K,
                       int nslab, void* stream);

@@ -375,6 +375,19 @@ def test_gemm_tn2_two_column_segments(ops, M, N1, N2, K, il):
     assert np.max(np.abs(out.cpu().double().numpy() - 2 * ref)) / scale < 6e-6
     with pytest.raises(Exception):                                       # the segment boundary must fall on a tile boundary
         ops.gemm_tn2(to_bf16(A), b1[:, :128], 128, to_bf16(B2), N2, M, K, out[:, :128 + N2])
+    # segments that are not adjacent in C, the gap filled by a narrow strip product (engine._wgrad_tn: layer 0 of the L1 stacks)
+    G = 128
+    B3 = bf16_round(rng.standard_normal((K, G)) * 0.5)
+    wide = torch.zeros((M, N1 + G + N2), dtype=torch.float32, device=DEV)
+    ops.gemm_tn2(to_bf16(A), b1, N1, to_bf16(B2), N2, M, K, wide, row_interleave_H=il, accumulate=True, c_col2=N1 + G)
+    ops.gemm_tn(to_bf16(A), to_bf16(B3), M, G, K, wide[:, N1:N1 + G], row_interleave_H=il, ldc=N1 + G + N2, accumulate=True)
+    ref3 = A.T @ B3
+    if il:
+        ref3 = ref3.reshape(M // 4, 4, G).transpose(1, 0, 2).reshape(M, G)
+    want = np.concatenate([ref[:, :N1], ref3, ref[:, N1:]], axis=1)
+    assert np.max(np.abs(wide.cpu().double().numpy() - want)) / scale < 6e-6
+    with pytest.raises(Exception):                                       # a gap needs accumulate
+        ops.gemm_tn2(to_bf16(A), b1, N1, to_bf16(B2), N2, M, K, wide, c_col2=N1 + G)
 
 
 @pytest.mark.parametrize("M,T", [(40, 15), (5120, 15), (1280, 6), (7000, 31)])
