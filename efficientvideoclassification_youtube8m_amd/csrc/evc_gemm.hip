@@ -216,6 +216,7 @@ typedef TileCfg<64, 1, 64, 2, 2> CfgPlainSmall;   // 64x64 for skinny problems
 typedef TileCfg<32, 1, 32, 2, 2> CfgPlainTiny;    // 32x32: M ~ batch recurrent steps (256 workgroups at M=256, H=1024)
 typedef TileCfg2<256, 1, 256, 2, 4, 5, true> CfgPlainV2;   // 256x256, 8 waves (2x4), 128x64 per wave, 5-deep ring (160 KiB)
 typedef TileCfg2<224, 1, 256, 2, 4, 5, true> CfgPlainV2_224;   // same, 224 rows: picked when it cuts M into fewer rounds of 256 workgroups
+typedef TileCfg2<320, 1, 256, 2, 4, 4, false> CfgPlainV2_320;  // 320 rows (4-deep ring, single fragment set): 5120 rows = 16 x 16 tiles, ONE round of 256 workgroups instead of 320 tiles
 typedef TileCfg2<128, 1, 128, 2, 4, 5, true> CfgTn128;     // 128x128 v2 tile (80 KB ring: two workgroups per CU)
 typedef TileCfg2<256, 1, 64, 2, 4, 5, true> CfgTallV2;     // 256x64: M <= 256 (batch-row) products against a long weight matrix
 // (256x128 tiles + split-K 2, to halve the re-reads of the [256][K] row operand: 80 vs 61 us at N = 14148 - not the bound)
@@ -297,8 +298,15 @@ extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
   const double c_v2b = tile_cost((long)ceil_div(M, 224) * ceil_div(N, 256), 224, 256, 1, 1.01);   // e.g. 56 640 rows x 1024: 1012 tiles = 3.95 rounds instead of 888 = 3.47
   const double c_big = tile_cost((long)ceil_div(M, 128) * ceil_div(N, 128), 128, 128, 2, 1.3);
   const double c_small = tile_cost((long)ceil_div(M, 64) * ceil_div(N, 64), 64, 64, 4, 2.6);
-  int pick = (c_v2 <= c_big && c_v2 <= c_small) ? 1 : (c_big <= c_small ? 2 : 3);
-  if (pick == 1 && c_v2b < c_v2) pick = 4;
+  const double c_v2c = tile_cost((long)ceil_div(M, 320) * ceil_div(N, 256), 320, 256, 1, 1.03);   // the L2 hoist / dX: 5120 x 4096 x 4096 = 16 x 16 tiles
+  double c_ring = c_v2;
+  int ring = 1;
+  if (c_v2b < c_ring) { c_ring = c_v2b; ring = 4; }
+  if (c_v2c < c_ring) { c_ring = c_v2c; ring = 6; }
+  // 160 x 128 ring tiles: 1280 rows x 4096 columns (the student's L2 hoist / dX at batch 256) = 8 x 32 = 256 tiles, one round
+  const double c_160 = tile_cost((long)ceil_div(M, 160) * ceil_div(N, 128), 160, 128, 1, 1.5);
+  if (K >= 2048 && c_160 < c_ring) { c_ring = c_160; ring = 7; }
+  int pick = (c_ring <= c_big && c_ring <= c_small) ? ring : (c_big <= c_small ? 2 : 3);
   // 128x128 ring tiles (LDS-DMA ring instead of the v1 two-stage loop): 20-25 % faster than the v1 128x128 tile while the
   // whole product is one round of <= 256 tiles (measured: 1024 x 4096 x 4096 50 vs 63 us, 2048^3 28 vs 38, 1280 x 1024 x 4096
   // 45 vs 58); beyond that two workgroups share a CU's L2 ingest and the v1 / 256x256 tiles win again
@@ -306,6 +314,8 @@ extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
   if (forced_tile()) pick = forced_tile();
   if (pick == 5) launch_gemm<CfgTn128>(p, s, K, 1, st);
   else if (pick == 4) launch_gemm<CfgPlainV2_224>(p, s, K, 1, st);
+  else if (pick == 6) launch_gemm<CfgPlainV2_320>(p, s, K, 1, st);
+  else if (pick == 7) launch_gemm<TileCfg2<160, 1, 128, 2, 4, 5, true>>(p, s, K, 1, st);
   else if (pick == 1) launch_gemm<CfgPlainV2>(p, s, K, 1, st);
   else if (pick == 2) launch_gemm<CfgPlainBig>(p, s, K, 1, st);
   else launch_gemm<CfgPlainSmall>(p, s, K, 1, st);
