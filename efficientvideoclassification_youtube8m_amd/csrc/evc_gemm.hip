@@ -17,7 +17,8 @@ template <class Cfg, int NG, bool SWAP = false, bool SPLIT = false, bool INIT = 
 __device__ __forceinline__ void run_mainloop(const GemmOperands& p, int m0, int u0, f32x4 (&acc)[Cfg::MI][NG][Cfg::NI]) {
   if constexpr (is_v2<Cfg>::value) {
     static_assert(!SPLIT, "the split-bf16 parity mode runs on the v1 tiles");
-    gemm_mainloop_v2<Cfg, SWAP, INIT, MODE>(p, m0, u0, lds_dyn, acc);
+    if constexpr (is_v3<Cfg>::value) gemm_mainloop_v3<Cfg, SWAP, INIT, MODE>(p, m0, u0, lds_dyn, acc);
+    else gemm_mainloop_v2<Cfg, SWAP, INIT, MODE>(p, m0, u0, lds_dyn, acc);
   } else {
     __shared__ __attribute__((aligned(16))) char lds_static[(SPLIT ? 2 : 1) * Cfg::LDS_BYTES];   // static: keeps 2 workgroups per CU
     gemm_mainloop<Cfg, SWAP, SPLIT, INIT>(p, m0, u0, lds_static, acc);
@@ -25,7 +26,7 @@ __device__ __forceinline__ void run_mainloop(const GemmOperands& p, int m0, int 
 }
 
 // K-step granularity of a config (v1 walks 64-wide tiles, v2 32-wide)
-template <class Cfg> static inline int kdiv() { return is_v2<Cfg>::value ? 32 : 64; }
+template <class Cfg> static inline int kdiv() { return (is_v2<Cfg>::value && !is_v3<Cfg>::value) ? 32 : 64; }
 
 // Tile choice: a CU works through ceil(tiles/256) tiles (co-resident workgroups share its matrix
 // pipe, so residency does not shorten that), each costing area x a per-flop factor measured on
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_nt_kernel(GemmOperands p, StoreP
     split = bid / nwg;
     bid -= split * nwg;
     const int k0 = split * s.ksteps_per_split;
-    const int kstep = is_v2<Cfg>::value ? 32 : 64;
+    const int kstep = (is_v2<Cfg>::value && !is_v3<Cfg>::value) ? 32 : 64;
     p.A1 += (long)k0 * kstep;
     p.B += (long)k0 * kstep;
     p.nk1 = min(s.ksteps_per_split, p.nk1 - k0);
@@ -312,9 +313,12 @@ extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
   // 45 vs 58); beyond that two workgroups share a CU's L2 ingest and the v1 / 256x256 tiles win again
   if (pick == 2 && K >= 2048 && (long)ceil_div(M, 128) * ceil_div(N, 128) <= 256) pick = 5;
   if (forced_tile()) pick = forced_tile();
-  if (pick == 5) launch_gemm<CfgTn128>(p, s, K, 1, st);
+  static const bool v3 = getenv("EVC_NT_V2_LOOP") == nullptr;      // 64-wide K stages for the 128-column ring tiles (A/B switch)
+  if (pick == 5 && v3) launch_gemm<TileCfg3<128, 1, 128, 2, 4, 4>>(p, s, K, 1, st);
+  else if (pick == 5) launch_gemm<CfgTn128>(p, s, K, 1, st);
   else if (pick == 4) launch_gemm<CfgPlainV2_224>(p, s, K, 1, st);
   else if (pick == 6) launch_gemm<CfgPlainV2_320>(p, s, K, 1, st);
+  else if (pick == 7 && v3) launch_gemm<TileCfg3<160, 1, 128, 2, 4, 4>>(p, s, K, 1, st);
   else if (pick == 7) launch_gemm<TileCfg2<160, 1, 128, 2, 4, 5, true>>(p, s, K, 1, st);
   else if (pick == 1) launch_gemm<CfgPlainV2>(p, s, K, 1, st);
   else if (pick == 2) launch_gemm<CfgPlainBig>(p, s, K, 1, st);
@@ -1667,6 +1671,7 @@ static inline void launch_lstm_bwd(GemmOperands p, const LstmBwdParams& e, int k
 }
 
 typedef TileCfg2<128, 1, 128, 2, 4, 5, true> CfgBwdV2_128;   // BPTT step tiles: BM rows x 128 units, 8 waves (2x4)
+typedef TileCfg3<128, 1, 128, 2, 4, 4> CfgBwdV3_128;         // the same tile on 64-wide K stages (whole cache lines per LDS-DMA piece)
 typedef TileCfg2<160, 1, 128, 2, 4, 5, true> CfgBwdV2_160;
 typedef TileCfg2<192, 1, 128, 2, 4, 5, true> CfgBwdV2_192;
 // (128x64 and 64x128 tiles at two workgroups per CU were measured: 84-86 us vs 69 us for 128x128 at ~3800 rows -
@@ -1733,7 +1738,10 @@ extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int 
     switch (pick) {
       case 0: launch_lstm_bwd<CfgBwdV2_192>(p, e, k1, st); break;
       case 1: launch_lstm_bwd<CfgBwdV2_160>(p, e, k1, st); break;
-      case 2: launch_lstm_bwd<CfgBwdV2_128>(p, e, k1, st); break;
+      case 2:
+        if (getenv("EVC_BWD_V2_LOOP") || dz_above) launch_lstm_bwd<CfgBwdV2_128>(p, e, k1, st);   // (two-matrix K walk: nk2 is set in 32-wide steps above)
+        else launch_lstm_bwd<CfgBwdV3_128>(p, e, k1, st);
+        break;
       case 4: launch_lstm_bwd<CfgPlainTiny>(p, e, k1, st); break;
       case 5: {
         const int tm = ceil_div(M, 32), tn = ceil_div(H, 32);

@@ -1,6 +1,7 @@
 // Launch helpers shared by the GEMM-shaped translation units (evc_gemm.hip, evc_dbof.hip).
 #pragma once
 #include "gemm_core_tn.h"
+#include "gemm_core_v3.h"
 #include <mutex>
 #include <vector>
 #include <stdlib.h>
@@ -9,6 +10,10 @@
 // or a v2 tile (TileCfg2: dynamic 4-stage LDS ring, K steps of 32).
 template <class Cfg> struct is_v2 { static constexpr bool value = false; };
 template <int a, int b, int c, int d, int e, int f, bool g> struct is_v2<TileCfg2<a, b, c, d, e, f, g>> { static constexpr bool value = true; };
+// v3 tiles (TileCfg3: the ring with 64-wide K stages, gemm_core_v3.h) are ring tiles too (dynamic LDS, same epilogues)
+template <int a, int b, int c, int d, int e, int f> struct is_v2<TileCfg3<a, b, c, d, e, f>> { static constexpr bool value = true; };
+template <class Cfg> struct is_v3 { static constexpr bool value = false; };
+template <int a, int b, int c, int d, int e, int f> struct is_v3<TileCfg3<a, b, c, d, e, f>> { static constexpr bool value = true; };
 
 extern __shared__ __attribute__((aligned(16))) char lds_dyn[];
 

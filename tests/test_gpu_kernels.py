@@ -738,11 +738,11 @@ print("ok", worst)
 '''
 
 
-@pytest.mark.parametrize("tile", ["0", "1", "4", "6", "7"])
+@pytest.mark.parametrize("tile", ["0", "1", "4", "5", "6", "7"])
 def test_gemm_nt_ring_tile_store_paths(tile):
     """The ring-tile NT kernels store a plain overwrite of C through a per-wave LDS transpose (whole rows of the sub-tile, 16
     bytes per lane) and fall back to element-wise stores for split-K / accumulate / unaligned rows / the ragged right edge:
-    f32 and bf16 outputs, bias, ragged M and N, odd row strides, on the 256x256 (EVC_FORCE_TILE=1), 224x256 (=4), 320x256 (=6), 160x128 (=7) and
+    f32 and bf16 outputs, bias, ragged M and N, odd row strides, on the 256x256 (EVC_FORCE_TILE=1), 224x256 (=4), 128x128 (=5), 320x256 (=6), 160x128 (=7: both 128-column tiles on the 64-wide K stages of gemm_core_v3.h) and
     automatically chosen (=0: also the 256x64 batch-row form) tiles.  One process per forced tile (the choice is read once)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
