@@ -627,6 +627,7 @@ class SingleTowerGraph:
         self.losses.zero_()
         ops.ce_loss(pred, labels_u8, self.losses[0:1], self._dp, grad_scale=1.0 / (B * self.world))
         fuse = (apply and self.fused_moe_update and self.moe is not None and self.moe.can_fuse_update()
+                and self.moe.prefer_fused_update(self.dp)
                 and tw.precision == "bf16")
         if self.moe is not None and not fuse and getattr(self.moe, "_stale", False):
             raise RuntimeError("the MoE weights are sharded over the ranks (fused data-parallel update); call consolidate() "

@@ -390,6 +390,15 @@ class MoeHead:
         """evc_moe_grad_update's shape constraints (the reference sizes satisfy them: 14148, 9432, 4096)."""
         return (self.V * (self.Mx + 1)) % 4 == 0 and (self.V * self.Mx) % 4 == 0 and self.K % 8 == 0
 
+    FUSE_MAX_ROWS = 512
+
+    def prefer_fused_update(self, data_parallel):
+        """The fused update recomputes the rank-B gradient tile in both of its passes: 2 x 2 B V K flops against the 46 - 30
+        bytes per parameter it saves.  One MI355X: faster up to B = 256 (the headline config), even at 512, slower at 1024
+        (cfg 5 student-only: 5.15 vs 4.88 ms per step) - there the gradients are materialised.  Under data parallelism it
+        always pays (no 386 MB gradient all-reduce, each rank updates 1/world of the rows)."""
+        return data_parallel or self.B <= self.FUSE_MAX_ROWS
+
     # ---- data parallel: the two weight matrices are sharded by rows over the ranks (ZeRO-1) ----------------
     def shard(self, world, rank):
         """Row slabs of 128-row tiles: rank r owns rows [r*slab, (r+1)*slab) of each weight matrix - their f32
@@ -759,7 +768,8 @@ class HLstmTower(TowerBase):
             self.apply_group(names, *early_apply)
 
         fuse = (aux is not None and early_apply is not None and self.fused_moe_update and self.precision == "bf16"
-                and self.moe.can_fuse_update() and (reduce_fn is None or dp is not None))
+                and self.moe.can_fuse_update() and (reduce_fn is None or dp is not None)
+                and self.moe.prefer_fused_update(dp is not None))
         if not fuse and getattr(self.moe, "_stale", False):
             raise RuntimeError("the MoE weights of %r are sharded over the ranks (fused data-parallel update); call "
                                "DistillGraph.consolidate() on every rank before an update that is not" % self.scope)
