@@ -365,6 +365,8 @@ extern "C" int evc_dbof_cluster_pool_fwd(const evc_bf16* r_bn, const evc_bf16* r
                                          uint8_t* arg, void* stream) {
   EVC_REQUIRE(B > 0 && S > 0 && S <= SP && F > 0 && F % 32 == 0 && C > 0 && C % 64 == 0, EVC_ERR_BAD_SHAPE,
               "evc_dbof_cluster_pool_fwd: needs iterations <= %d, F %% 32 == 0, clusters %% 64 == 0 (S=%d F=%d C=%d)", SP, S, F, C);
+  EVC_REQUIRE(ring_operand_ok(((long)B + 3) / 4 * 4 * SP, F) && ring_operand_ok(C, F), EVC_ERR_BAD_SHAPE,
+              "evc_dbof_cluster_pool_fwd: the frame matrix or the cluster weights span 4 GiB or more (B=%d F=%d C=%d)", B, F, C);
   EVC_REQUIRE((r_bn_lo != nullptr) == (wT_lo != nullptr), EVC_ERR_BAD_ARG, "evc_dbof_cluster_pool_fwd: both low halves or none");
   const int Mp = dbof_padded_rows(B);
   GemmOperands p;

@@ -238,6 +238,8 @@ extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
   EVC_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0,
               EVC_ERR_BAD_ALIGN, "evc_gemm_nt: operands must be 16-byte aligned (lda=%ld ldb=%ld)", (long)lda, (long)ldb);
   EVC_REQUIRE(!(out_bf16 && accumulate), EVC_ERR_BAD_ARG, "evc_gemm_nt: accumulate needs f32 output");
+  EVC_REQUIRE(ring_operand_ok(M, lda) && ring_operand_ok(N, ldb), EVC_ERR_BAD_SHAPE,
+              "evc_gemm_nt: an operand spans 4 GiB or more (M=%d lda=%ld, N=%d ldb=%ld): split the product", M, (long)lda, N, (long)ldb);
   GemmOperands p;
   p.A1 = A; p.lda1 = lda; p.nk1 = 0; p.A2 = A; p.lda2 = lda; p.nk2 = 0;
   p.B = B; p.ldb = ldb; p.group_stride = 0; p.M = M; p.Nu = N;
@@ -917,6 +919,8 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
   EVC_REQUIRE(T > 0 && M > 0 && H > 0 && Kin > 0, EVC_ERR_BAD_SHAPE, "evc_lstm_layer_fwd: bad shape");
   EVC_REQUIRE(Kin % 64 == 0 && H % 64 == 0, EVC_ERR_BAD_SHAPE,
               "evc_lstm_layer_fwd: Kin=%d and H=%d must be multiples of 64", Kin, H);
+  EVC_REQUIRE(ring_operand_ok(M, Kin > H ? Kin : H) && ring_operand_ok(4L * H, (long)Kin + H), EVC_ERR_BAD_SHAPE,
+              "evc_lstm_layer_fwd: a time slab or the kernel spans 4 GiB or more (M=%d Kin=%d H=%d)", M, Kin, H);
   EVC_REQUIRE(!hoist || zx_ws, EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd: hoist needs zx_ws");
   EVC_REQUIRE(ld_state % 4 == 0 && ((uintptr_t)c_state % 16) == 0 && ((uintptr_t)h_state % 16) == 0 && ((uintptr_t)bias % 16) == 0 &&
               ((uintptr_t)hbuf % 8) == 0, EVC_ERR_BAD_ALIGN, "evc_lstm_layer_fwd: state/bias/hbuf must allow 16-byte vector access");
@@ -1042,6 +1046,8 @@ extern "C" int evc_lstm_stack2_fwd(const evc_bf16* x, const evc_bf16* wT0, const
                                    evc_bf16* c_all1, void* stream) {
   EVC_REQUIRE(T > 0 && M > 0 && H > 0 && Kin > 0 && H % 64 == 0 && Kin % 64 == 0, EVC_ERR_BAD_SHAPE,
               "evc_lstm_stack2_fwd: bad shape T=%d M=%d Kin=%d H=%d (Kin, H multiples of 64)", T, M, Kin, H);
+  EVC_REQUIRE(ring_operand_ok(M, Kin > H ? Kin : H) && ring_operand_ok(4L * H, (long)Kin + H) && ring_operand_ok(4L * H, 2L * H), EVC_ERR_BAD_SHAPE,
+              "evc_lstm_stack2_fwd: a time slab or a kernel spans 4 GiB or more (M=%d Kin=%d H=%d)", M, Kin, H);
   EVC_REQUIRE(zx_ws && hbuf0 && hbuf1, EVC_ERR_BAD_ARG, "evc_lstm_stack2_fwd: zx_ws / hbuf0 / hbuf1 must not be NULL");
   EVC_REQUIRE(ld_state % 4 == 0 && ((uintptr_t)c_state0 % 16) == 0 && ((uintptr_t)h_state0 % 16) == 0 && ((uintptr_t)c_state1 % 16) == 0 &&
               ((uintptr_t)h_state1 % 16) == 0 && ((uintptr_t)bias0 % 16) == 0 && ((uintptr_t)bias1 % 16) == 0 &&
@@ -1683,6 +1689,8 @@ extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int 
                                   const int32_t* row_map, const int32_t* rows_per_step, const evc_bf16* dz_above,
                                   const evc_bf16* w_above, void* stream) {
   EVC_REQUIRE(T > 0 && M > 0 && H > 0 && Kin > 0 && H % 64 == 0, EVC_ERR_BAD_SHAPE, "evc_lstm_layer_bwd: bad shape");
+  EVC_REQUIRE(ring_operand_ok(M, 4L * H) && ring_operand_ok(H, 4L * H), EVC_ERR_BAD_SHAPE,
+              "evc_lstm_layer_bwd: a dz time slab spans 4 GiB or more (M=%d H=%d)", M, H);
   EVC_REQUIRE((dz_above != nullptr) == (w_above != nullptr) && !(dz_above && dh_above), EVC_ERR_BAD_ARG,
               "evc_lstm_layer_bwd: dz_above and w_above come together, and instead of dh_above");
   EVC_REQUIRE(!dz_above || (((uintptr_t)dz_above % 16) == 0 && ((uintptr_t)w_above % 16) == 0 && H % 128 == 0), EVC_ERR_BAD_ALIGN,
@@ -1773,6 +1781,7 @@ extern "C" int evc_lstm_stack2_bwd(const evc_bf16* w_il0, const evc_bf16* w_il1,
                                    const float* dS, int64_t ld_dS, float* dc_ws0, float* dc_ws1, evc_bf16* dz0, evc_bf16* dz1,
                                    float* db0, float* db1, const int32_t* row_map, const int32_t* rows_per_step, void* stream) {
   EVC_REQUIRE(T > 0 && M > 0 && H > 0 && Kin0 > 0 && H % 128 == 0, EVC_ERR_BAD_SHAPE, "evc_lstm_stack2_bwd: bad shape (H %% 128)");
+  EVC_REQUIRE(ring_operand_ok(M, 4L * H) && ring_operand_ok(H, 4L * H), EVC_ERR_BAD_SHAPE, "evc_lstm_stack2_bwd: a dz time slab spans 4 GiB or more");
   EVC_REQUIRE(gates0 && gates1 && c_all0 && c_all1 && dz0 && dz1 && dc_ws0 && dc_ws1 && dS, EVC_ERR_BAD_ARG, "evc_lstm_stack2_bwd: null operand");
   EVC_REQUIRE(ld_dS % 4 == 0 && ((uintptr_t)dS % 16) == 0 && ((uintptr_t)dc_ws0 % 16) == 0 && ((uintptr_t)dc_ws1 % 16) == 0 &&
               ((uintptr_t)dz0 % 16) == 0 && ((uintptr_t)dz1 % 16) == 0, EVC_ERR_BAD_ALIGN, "evc_lstm_stack2_bwd: 16-byte alignment");

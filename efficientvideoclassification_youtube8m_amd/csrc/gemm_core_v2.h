@@ -86,8 +86,12 @@ __device__ __forceinline__ void gemm_mainloop_v2(const GemmOperands& p, const in
   constexpr int ACH = (Cfg::BM / 16 + NPW - 1) / NPW, BCH = (Cfg::BN / 16 + NPW - 1) / NPW;
   constexpr int PER = ACH + BCH;
   static_assert(Cfg::RAGGED || (ACH * NPW * 16 == Cfg::BM && BCH * NPW * 16 == Cfg::BN), "surplus pieces need the dummy sink");
+  // Every LDS-DMA is addressed as wave-uniform base + 32-bit per-lane BYTE offset (the launchers check that an operand spans
+  // less than 4 GiB, rows < 2^24, row stride < 2^24 bytes): A's offset is one full-rate 24-bit multiply-add of the row index per
+  // piece, B's is loop-invariant.  (With 64-bit pointers per piece the loop carried 6 VALU instructions per A piece, three
+  // of them quarter-rate multiplies, on the waves whose issue slots the LDS-DMA already crowds.)
   int a_row[ACH];
-  long b_off[BCH];
+  uint32_t b_vo[BCH];
   int a_dst[ACH], b_dst[BCH];   // wave-uniform LDS byte offsets within a stage (or the dummy sink)
 #pragma unroll
   for (int i = 0; i < ACH; ++i) {
@@ -108,7 +112,7 @@ __device__ __forceinline__ void gemm_mainloop_v2(const GemmOperands& p, const in
     const int g = r / Cfg::BU, u = r % Cfg::BU;
     int gu = u0 + u;
     gu = gu < p.Nu ? gu : p.Nu - 1;
-    b_off[i] = ((long)g * p.group_stride + gu) * p.ldb + lc8;
+    b_vo[i] = (uint32_t)((((long)g * p.group_stride + gu) * p.ldb + lc8) * 2);
     b_dst[i] = live ? Cfg::A_BYTES + c0 * 16 : -1;
   }
   const bf16_t* const b2 = p.B2 ? p.B2 - (long)p.nk1 * 32 : p.B;   // base such that b2 + kt*32 addresses the A2 segment's B columns
@@ -119,20 +123,21 @@ __device__ __forceinline__ void gemm_mainloop_v2(const GemmOperands& p, const in
   // hipcc's waitcnt pass can count the loop-carried LDS reads exactly.
   auto stage = [&]() {
     const bool s1 = kt_issue < p.nk1;
-    const bf16_t* ab = s1 ? p.A1 + (long)kt_issue * 32 : p.A2 + (long)(kt_issue - p.nk1) * 32;
-    const long lda = s1 ? p.lda1 : p.lda2;
-    const bf16_t* b_base = (s1 ? p.B : b2) + (long)kt_issue * 32;
+    const char* ab = (const char*)(s1 ? p.A1 + (long)kt_issue * 32 : p.A2 + (long)(kt_issue - p.nk1) * 32);
+    const uint32_t lda_b = (uint32_t)(s1 ? p.lda1 : p.lda2) * 2u;
+    const char* b_base = (const char*)((s1 ? p.B : b2) + (long)kt_issue * 32);
     char* sbase = lds + slot_issue * Cfg::STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
       char* dst = a_dst[i] >= 0 ? sbase + a_dst[i] : lds + Cfg::DUMMY_OFF;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ab + (long)a_row[i] * lda + lc8),
+      const uint32_t vo = __umul24((uint32_t)a_row[i], lda_b) + (uint32_t)(lc8 * 2);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ab + vo),
                                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
       char* dst = b_dst[i] >= 0 ? sbase + b_dst[i] : lds + Cfg::DUMMY_OFF;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_base + b_off[i]),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_base + b_vo[i]),
                                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
     ++kt_issue;

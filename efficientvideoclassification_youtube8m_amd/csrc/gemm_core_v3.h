@@ -60,8 +60,8 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
   constexpr int ACH = (Cfg::BM / 8 + NPW - 1) / NPW, BCH = (Cfg::BN / 8 + NPW - 1) / NPW;
   constexpr int PER = ACH + BCH;
   static_assert(Cfg::RAGGED || (ACH * NPW * 8 == Cfg::BM && BCH * NPW * 8 == Cfg::BN), "surplus pieces need the dummy sink");
-  int a_row[ACH];
-  long b_off[BCH];
+  int a_row[ACH];              // (addressing as in gemm_core_v2.h: wave-uniform base + 32-bit lane byte offset)
+  uint32_t b_vo[BCH];
   int a_dst[ACH], b_dst[BCH];   // wave-uniform LDS byte offsets within a stage (or the dummy sink)
 #pragma unroll
   for (int i = 0; i < ACH; ++i) {
@@ -80,7 +80,7 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
     const int g = r / Cfg::BU, u = r % Cfg::BU;
     int gu = u0 + u;
     gu = gu < p.Nu ? gu : p.Nu - 1;
-    b_off[i] = ((long)g * p.group_stride + gu) * p.ldb + lc8;
+    b_vo[i] = (uint32_t)((((long)g * p.group_stride + gu) * p.ldb + lc8) * 2);
     b_dst[i] = live ? Cfg::A_BYTES + q * 1024 : -1;
   }
   const bf16_t* const b2 = p.B2 ? p.B2 - (long)p.nk1 * 64 : p.B;   // base such that b2 + ks*64 addresses the A2 segment's B columns
@@ -89,20 +89,21 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
 
   auto stage = [&]() {                 // branch-free (scalar selects only)
     const bool s1 = ks_issue < p.nk1;
-    const bf16_t* ab = s1 ? p.A1 + (long)ks_issue * 64 : p.A2 + (long)(ks_issue - p.nk1) * 64;
-    const long lda = s1 ? p.lda1 : p.lda2;
-    const bf16_t* b_base = (s1 ? p.B : b2) + (long)ks_issue * 64;
+    const char* ab = (const char*)(s1 ? p.A1 + (long)ks_issue * 64 : p.A2 + (long)(ks_issue - p.nk1) * 64);
+    const uint32_t lda_b = (uint32_t)(s1 ? p.lda1 : p.lda2) * 2u;
+    const char* b_base = (const char*)((s1 ? p.B : b2) + (long)ks_issue * 64);
     char* sbase = lds + slot_issue * Cfg::STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
       char* dst = a_dst[i] >= 0 ? sbase + a_dst[i] : lds + Cfg::DUMMY_OFF;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ab + (long)a_row[i] * lda + lc8),
+      const uint32_t vo = __umul24((uint32_t)a_row[i], lda_b) + (uint32_t)(lc8 * 2);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ab + vo),
                                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
       char* dst = b_dst[i] >= 0 ? sbase + b_dst[i] : lds + Cfg::DUMMY_OFF;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_base + b_off[i]),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_base + b_vo[i]),
                                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
     ++ks_issue;

@@ -17,6 +17,12 @@ template <int a, int b, int c, int d, int e, int f> struct is_v3<TileCfg3<a, b, 
 
 extern __shared__ __attribute__((aligned(16))) char lds_dyn[];
 
+// The ring loops address every LDS-DMA as base + 32-bit byte offset built from a 24-bit row index and a 24-bit row stride
+// (gemm_core_v2.h): an operand of `rows` rows with leading dimension `ld` (bf16 elements) must fit that.
+static inline bool ring_operand_ok(long rows, long ld) {
+  return rows < (1L << 24) && ld * 2 < (1L << 24) && rows * ld * 2 < (1L << 32);
+}
+
 // v2 tiles use more dynamic LDS than the 64 KiB default: raise the limit once per kernel (keyed by the
 // kernel's address - two kernels of one signature share this template instantiation).
 static inline void allow_big_lds(const void* kern, int bytes) {

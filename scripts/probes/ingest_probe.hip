@@ -160,7 +160,7 @@ static void run_panel(const char* buf, int rows, long ld, int kbytes, float* sin
 
 template <int MODE, int DEPTH>
 static void run(const char* name, const char* buf, long region, int wgs, int threads, float* sink) {
-  const int iters = 200;
+  const int iters = region > 65536 ? 40 : 200;
   const int ldsb = (threads / 64) * DEPTH * 1024;
   CHECK(hipFuncSetAttribute((const void*)probe<MODE, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipEvent_t e0, e1;
@@ -200,6 +200,20 @@ int main() {
   run<0, 4>("LDS-DMA, 4 waves", buf, region, 256, 256, sink);
   run<1, 8>("registers, 4 waves", buf, region, 256, 256, sink);
   run<1, 8>("registers, 16 waves", buf, region, 256, 1024, sink);
+  {   // Infinity-Cache-resident streaming: every workgroup cycles through its own 512 KB (128 MB in all: beyond the 32 MB of L2)
+    const long big = 512 * 1024;
+    char* buf2;
+    CHECK(hipMalloc(&buf2, (size_t)256 * big));
+    CHECK(hipMemset(buf2, 1, (size_t)256 * big));
+    run<0, 2>("LDS-DMA, 512 KB regions", buf2, big, 256, 512, sink);
+    run<0, 4>("LDS-DMA, 512 KB regions", buf2, big, 256, 512, sink);
+    run<0, 8>("LDS-DMA, 512 KB regions", buf2, big, 256, 512, sink);
+    run<0, 16>("LDS-DMA, 512 KB regions", buf2, big, 256, 512, sink);
+    run<1, 8>("registers, 512 KB regions", buf2, big, 256, 512, sink);
+    run<1, 16>("registers, 512 KB regions", buf2, big, 256, 512, sink);
+    run<1, 32>("registers, 512 KB regions", buf2, big, 256, 512, sink);
+    CHECK(hipFree(buf2));
+  }
   // GEMM-like panels: 512 rows (A 256 + B 256 of a 256 x 256 tile) x 4352 bytes (K = 2176 bf16), shared by every workgroup
   run_panel<64, 2>(buf, 512, 4352, 4352, sink);
   run_panel<64, 4>(buf, 512, 4352, 4352, sink);
