@@ -69,14 +69,14 @@ __device__ __forceinline__ void gemm_mainloop_tn(GemmOperandsT p, const int m0, 
   const bool producer = wave < NPW;
   constexpr int ACH = Cfg::BM / 16 / NPW, BCH = Cfg::BN / 16 / NPW, PER = ACH + BCH;
   static_assert(ACH * NPW * 16 == Cfg::BM && BCH * NPW * 16 == Cfg::BN, "pieces must divide over the staging waves");
-  long a_off[ACH], b_off[BCH];
+  uint32_t a_vo[ACH], b_vo[BCH];      // per-lane byte offsets within a K step (the K walk is a scalar added per step: operands < 4 GiB)
 #pragma unroll
   for (int i = 0; i < ACH; ++i) {
     const int c = ((wave % NPW) + i * NPW) * 64 + lane;
     const int row = c / ACPR, pc = c % ACPR;
     int col = m0 + ((pc ^ (tn_h(row) << 1)) << 3);
     col = col + 8 <= p.M ? col : p.M - 8;
-    a_off[i] = (long)row * p.lda + col;
+    a_vo[i] = (uint32_t)(((long)row * p.lda + col) * 2);
   }
 #pragma unroll
   for (int i = 0; i < BCH; ++i) {
@@ -84,25 +84,26 @@ __device__ __forceinline__ void gemm_mainloop_tn(GemmOperandsT p, const int m0, 
     const int row = c / BCPR, pc = c % BCPR;
     int col = n0 + ((pc ^ (tn_h(row) << 1)) << 3);
     col = col + 8 <= p.N ? col : p.N - 8;
-    b_off[i] = (long)row * p.ldb + col;
+    b_vo[i] = (uint32_t)(((long)row * p.ldb + col) * 2);
   }
-  const bf16_t* a_base = p.A;
-  const bf16_t* b_base = p.B;
-  const long a_step = 32 * p.lda, b_step = 32 * p.ldb;
+  const char* const a_base = (const char*)p.A;
+  const char* const b_base = (const char*)p.B;
+  const uint32_t a_step = (uint32_t)(64 * p.lda), b_step = (uint32_t)(64 * p.ldb);   // bytes per K step of 32 rows
+  uint32_t a_k = 0, b_k = 0;
   int slot_issue = 0, slot_read = 0;
 
   auto stage = [&]() {
     char* sbase = lds + slot_issue * Cfg::STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < ACH; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + a_off[i]),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + (a_vo[i] + a_k)),
                                        (__attribute__((address_space(3))) void*)(sbase + ((wave % NPW) + i * NPW) * 1024), 16, 0, EVC_TN_AUX_A);
 #pragma unroll
     for (int i = 0; i < BCH; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_base + b_off[i]),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_base + (b_vo[i] + b_k)),
                                        (__attribute__((address_space(3))) void*)(sbase + Cfg::A_BYTES + ((wave % NPW) + i * NPW) * 1024), 16, 0, EVC_TN_AUX_B);
-    a_base += a_step;
-    b_base += b_step;
+    a_k += a_step;
+    b_k += b_step;
     slot_issue = (slot_issue + 1 == Cfg::STAGES) ? 0 : slot_issue + 1;
   };
 
@@ -123,8 +124,19 @@ __device__ __forceinline__ void gemm_mainloop_tn(GemmOperandsT p, const int m0, 
       b_rd[ni][j] = Cfg::A_BYTES + r * BROWB + ((((nc >> 3) + (pp >> 1)) ^ hs) << 4) + ((pp & 1) << 3);
     }
   }
+  // The transposing read as inline asm: through the builtin, hipcc's waitcnt pass sees an LDS read of unknown provenance
+  // behind the LDS-DMA of the same K step and puts `s_waitcnt vmcnt(0)` in front of it - every K step then waited for the
+  // DMA it had just issued (the whole ring's latency hiding gone; found in the ISA in round 2).  The asm has no memory
+  // operand; its result is retired by the explicit lgkmcnt(0) of end_of_step() before the next step's MFMAs read it.
   auto tr = [&](const char* ptr) {
+#ifdef EVC_TN_TR_BUILTIN
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)ptr);
+#else
+    const uint32_t a = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) const char*)ptr);
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(a));
+    return v;
+#endif
   };
   auto read_frags = [&](bf16x8 (&af)[Cfg::MI], bf16x8 (&bfr)[Cfg::NI]) {
     const char* sb = lds + slot_read * Cfg::STAGE_BYTES;
