@@ -182,14 +182,56 @@ __device__ __forceinline__ void gemm_mainloop_tn(GemmOperandsT p, const int m0, 
   for (int i = 0; i < Cfg::STAGES - 1; ++i)
     if (i < nk) stage_role();
 
+  // Steady-state step with the issue order written out: the transposing reads are inline asm (see tr()), which
+  // sched_group_barrier cannot name, and left to itself hipcc bunches 22 of the 24 reads of every second step behind the last
+  // MFMA, where nothing hides them.  One group = one MFMA with, in front of it, one LDS-DMA piece (producers, first PER groups)
+  // or one fragment of the next step (two reads), spread evenly; sched_barrier(0) pins the groups.
   auto full_step = [&](const bf16x8 (&afc)[Cfg::MI], const bf16x8 (&bfc)[Cfg::NI], bf16x8 (&afn)[Cfg::MI], bf16x8 (&bfn)[Cfg::NI]) {
     if constexpr (PROD) wait_vmcnt<(AHEAD - 1) * PER>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if constexpr ((MODE & LOOP_NO_PRIO) == 0) __builtin_amdgcn_s_setprio(1);
+#ifdef EVC_TN_UNORDERED
     stage_role();
     read_frags(afn, bfn);
     mfma_all(afc, bfc);
+#else
+    constexpr int NM = Cfg::MI * Cfg::NI, ND = PROD ? PER : 0, NF = Cfg::MI + Cfg::NI, NIT = ND + NF;
+    char* sbase = lds + slot_issue * Cfg::STAGE_BYTES;
+    const char* sb = lds + slot_read * Cfg::STAGE_BYTES;
+    slot_read = (slot_read + 1 == Cfg::STAGES) ? 0 : slot_read + 1;
+#pragma unroll
+    for (int gi = 0; gi < NM; ++gi) {
+#pragma unroll
+      for (int it = gi * NIT / NM; it < (gi + 1) * NIT / NM; ++it) {   // items of this group: LDS-DMA pieces first, then fragments
+        if (it < ND) {
+          if (it < ACH)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + (a_vo[it] + a_k)),
+                                             (__attribute__((address_space(3))) void*)(sbase + ((wave % NPW) + it * NPW) * 1024), 16, 0, EVC_TN_AUX_A);
+          else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_base + (b_vo[it - ACH] + b_k)),
+                                             (__attribute__((address_space(3))) void*)(sbase + Cfg::A_BYTES + ((wave % NPW) + (it - ACH) * NPW) * 1024), 16, 0, EVC_TN_AUX_B);
+        } else if (it - ND < Cfg::NI) {
+          const int f = it - ND;
+          const s16x4 lo = tr(sb + b_rd[f][0]), hi = tr(sb + b_rd[f][1]);
+          bfn[f] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        } else {
+          const int mi = it - ND - Cfg::NI;
+          const s16x4 lo = tr(sb + a_rd[mi][0]), hi = tr(sb + a_rd[mi][1]);
+          afn[mi] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+      }
+      const int mi = gi / Cfg::NI, ni = gi % Cfg::NI;
+      acc[mi][0][ni] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfc[ni], afc[mi], acc[mi][0][ni], 0, 0, 0)
+                            : __builtin_amdgcn_mfma_f32_16x16x32_bf16(afc[mi], bfc[ni], acc[mi][0][ni], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (PROD) {
+      a_k += a_step;
+      b_k += b_step;
+      slot_issue = (slot_issue + 1 == Cfg::STAGES) ? 0 : slot_issue + 1;
+    }
+#endif
     if constexpr ((MODE & LOOP_NO_PRIO) == 0) __builtin_amdgcn_s_setprio(0);
     end_of_step();
   };
