@@ -390,7 +390,7 @@ class MoeHead:
         """evc_moe_grad_update's shape constraints (the reference sizes satisfy them: 14148, 9432, 4096)."""
         return (self.V * (self.Mx + 1)) % 4 == 0 and (self.V * self.Mx) % 4 == 0 and self.K % 8 == 0
 
-    FUSE_MAX_ROWS = 512
+    FUSE_MAX_ROWS = int(os.environ.get("EVC_MOE_FUSE_MAX_ROWS", "512"))
 
     def prefer_fused_update(self, data_parallel):
         """The fused update recomputes the rank-B gradient tile in both of its passes: 2 x 2 B V K flops against the 46 - 30
