@@ -1230,7 +1230,10 @@ __device__ __forceinline__ void lstm_bwd_tail_rowmajor(f32x4 (&acc)[Cfg::MI][1][
   static_assert(Cfg::BU == 128 && Cfg::NT == 512, "row-major tail: 128-unit tiles, 8 waves");
   constexpr int RS = Cfg::BU * 4 + 16;                        // dh rows in LDS, padded
   static_assert(Cfg::BM * RS <= Cfg::LDS_BYTES && 8 * 128 * 4 * 4 <= Cfg::LDS_BYTES, "dh tile (then the bias-gradient partials) must fit the ring");
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (wave as a SCALAR: a row's length and its row_map entry are then scalar loads - counted by lgkmcnt.  As vector loads they
+  // were followed by `s_waitcnt vmcnt(0)` for the branch on the length, which also waited for every data load of the rows
+  // before: the GROUP rows "in flight" were loaded one after the other.)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   {
     const int wr = wave / Cfg::WC, wc = wave % Cfg::WC;
     const int l = lane & 15, g = lane >> 4;
@@ -1255,8 +1258,9 @@ __device__ __forceinline__ void lstm_bwd_tail_rowmajor(f32x4 (&acc)[Cfg::MI][1][
 #pragma unroll
     for (int i = 0; i < GROUP; ++i) {                          // load phase
       const int rl = (p0 + i) * 8 + wave;
-      const int m = m0 + rl;
-      ln[i] = (m < e.M && u_in) ? e.len[m] : -1;
+      const int m = m0 + rl;                                   // wave-uniform
+      const int lnm = m < e.M ? ((const __attribute__((address_space(4))) int*)e.len)[m] : -1;   // scalar load (constant address space)
+      ln[i] = u_in ? lnm : -1;
       dcv[i] = dhs[i] = make_float2(0.f, 0.f);
       grec[i] = make_uint4(0u, 0u, 0u, 0u);
       cn[i] = co[i] = dha[i] = 0u;
@@ -1264,7 +1268,7 @@ __device__ __forceinline__ void lstm_bwd_tail_rowmajor(f32x4 (&acc)[Cfg::MI][1][
       if (e.t < ln[i]) {
         const long hu = (long)m * e.H + u;
         if (e.t == ln[i] - 1) {
-          const long su = (long)(e.row_map ? e.row_map[m] : m) * e.ld_dS + u;
+          const long su = (long)(e.row_map ? ((const __attribute__((address_space(4))) int*)e.row_map)[m] : m) * e.ld_dS + u;
           dhs[i] = *(const float2*)(e.dS_h + su);
           dcv[i] = *(const float2*)(e.dS_c + su);
         } else {
@@ -1276,17 +1280,20 @@ __device__ __forceinline__ void lstm_bwd_tail_rowmajor(f32x4 (&acc)[Cfg::MI][1][
         if (e.c_old) co[i] = *(const uint32_t*)(e.c_old + hu);
       }
     }
+    // compute phase, then store phase: with the stores of row i between the computations of rows i and i+1 hipcc put
+    // `s_waitcnt vmcnt(0)` in front of every row (it cannot count across the per-row branches), i.e. every row waited for the
+    // store acknowledgements of the row before
+    float2 dcn[GROUP];
+    uint4 dzr[GROUP];
+    int what[GROUP];                                           // 0: nothing, 1: zero dz (inactive row), 2: dc + dz
 #pragma unroll
-    for (int i = 0; i < GROUP; ++i) {                          // compute + store phase
-      if (ln[i] < 0) continue;
-      const int m = m0 + (p0 + i) * 8 + wave;
-      const long hu = (long)m * e.H + u;
-      if (e.t >= ln[i]) {                                      // inactive: state passes through, no gate gradient
-        *(uint4*)(e.dz4 + hu) = make_uint4(0u, 0u, 0u, 0u);
-        continue;
-      }
+    for (int i = 0; i < GROUP; ++i) {
+      what[i] = ln[i] < 0 ? 0 : (e.t >= ln[i] ? 1 : 2);
+      dcn[i] = make_float2(0.f, 0.f);
+      dzr[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (what[i] != 2) continue;
       float dh[2] = {dhv[i].x, dhv[i].y};
-      if (e.t == ln[i] - 1) {
+      if (e.t == ln[i] - 1) {     // nothing flows back through the recurrent product from the (inactive) later steps
         if (e.fused_above) { dh[0] += dhs[i].x; dh[1] += dhs[i].y; }
         else { dh[0] = dhs[i].x; dh[1] = dhs[i].y; }
       }
@@ -1295,22 +1302,32 @@ __device__ __forceinline__ void lstm_bwd_tail_rowmajor(f32x4 (&acc)[Cfg::MI][1][
       const uint2 recs[2] = {make_uint2(grec[i].x, grec[i].y), make_uint2(grec[i].z, grec[i].w)};
       const float cna[2] = {__uint_as_float(cn[i] << 16), __uint_as_float(cn[i] & 0xffff0000u)};
       const float coa[2] = {__uint_as_float(co[i] << 16), __uint_as_float(co[i] & 0xffff0000u)};
-      float dcn[2];
-      uint2 dzr[2];
+      float dcv2[2];
+      uint2 dz2[2];
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         const float gi = __uint_as_float(recs[r].x << 16), gj = __uint_as_float(recs[r].x & 0xffff0000u);
         const float gf = __uint_as_float(recs[r].y << 16), go = __uint_as_float(recs[r].y & 0xffff0000u);
         const float tcv = tanhf_(cna[r]);
         const float dc = dci[r] + dh[r] * go * (1.f - tcv * tcv);
-        dcn[r] = dc * gf;
+        dcv2[r] = dc * gf;
         const float z0 = dc * gj * gi * (1.f - gi), z1 = dc * gi * (1.f - gj * gj);
         const float z2 = dc * coa[r] * gf * (1.f - gf), z3 = dh[r] * tcv * go * (1.f - go);
         bs[r][0] += z0; bs[r][1] += z1; bs[r][2] += z2; bs[r][3] += z3;
-        dzr[r] = make_uint2(pack_bf16x2(z0, z1), pack_bf16x2(z2, z3));
+        dz2[r] = make_uint2(pack_bf16x2(z0, z1), pack_bf16x2(z2, z3));
       }
-      *(float2*)(e.dc_ws + hu) = make_float2(dcn[0], dcn[1]);
-      *(uint4*)(e.dz4 + hu) = make_uint4(dzr[0].x, dzr[0].y, dzr[1].x, dzr[1].y);
+      dcn[i] = make_float2(dcv2[0], dcv2[1]);
+      dzr[i] = make_uint4(dz2[0].x, dz2[0].y, dz2[1].x, dz2[1].y);
+    }
+    // every load of the group has been consumed above; saying so (vmcnt(0), encoded 0x0F70) lets the stores below issue back
+    // to back - across the per-row branches hipcc otherwise keeps some load destinations "pending" and waits before each row
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+    for (int i = 0; i < GROUP; ++i) {
+      if (what[i] == 0) continue;
+      const long hu = (long)(m0 + (p0 + i) * 8 + wave) * e.H + u;
+      if (what[i] == 2) *(float2*)(e.dc_ws + hu) = dcn[i];
+      *(uint4*)(e.dz4 + hu) = dzr[i];                          // zeros for an inactive row: state passes through, no gate gradient
     }
   }
   if (e.db) {      // bias gradient: the 8 waves hold partial sums of the same 128 units x 4 gates: through LDS, then one atomic per sum
