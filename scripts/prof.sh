@@ -7,4 +7,4 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$NAME
 mkdir -p "$OUT"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o run -- python3 bench.py "$@" > "$OUT/stdout.log" 2> "$OUT/stderr.log"
-python3 scripts/profile_digest.py "$OUT/run_kernel_stats.csv" | head -${TOP:-40}
+python3 scripts/profile_digest.py "$OUT/run_kernel_trace.csv" ${TOP:-40}
