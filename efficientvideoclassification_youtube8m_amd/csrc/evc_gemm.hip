@@ -1695,6 +1695,7 @@ static inline void launch_lstm_bwd(GemmOperands p, const LstmBwdParams& e, int k
 
 typedef TileCfg2<128, 1, 128, 2, 4, 5, true> CfgBwdV2_128;   // BPTT step tiles: BM rows x 128 units, 8 waves (2x4)
 typedef TileCfg3<128, 1, 128, 2, 4, 4> CfgBwdV3_128;         // the same tile on 64-wide K stages (whole cache lines per LDS-DMA piece)
+typedef TileCfg3<64, 1, 64, 2, 4, 4> CfgBwdV3_64;            // ~1000 live rows (the student's L1 levels): 16 x 16 = 256 tiles of 64 x 64, 64 KB of LDS
 typedef TileCfg2<160, 1, 128, 2, 4, 5, true> CfgBwdV2_160;
 typedef TileCfg2<192, 1, 128, 2, 4, 5, true> CfgBwdV2_192;
 // (128x64 and 64x128 tiles at two workgroups per CU were measured: 84-86 us vs 69 us for 128x128 at ~3800 rows -
@@ -1726,17 +1727,21 @@ extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int 
     // rows: tiles beyond Mt only zero their dz rows (the weight-gradient products contract over every row)
     // Tile choice: 256 CUs work through ceil(tiles/256) tiles each.  v2 tiles (BM x 128, LDS-DMA ring) for the
     // large steps; v1 64x64 / 32x32 (several workgroups per CU, epilogues overlap main loops) for the small ones.
-    static const int bm[5] = {192, 160, 128, 64, 32}, bn[5] = {128, 128, 128, 64, 32};
-    static const double cf[5] = {1.0, 1.0, 1.02, 2.0, 1.9};   // measured: ~1000 rows x 1024 run 33 us on 32x32 tiles, 38 us on 64x64
+    // (index 5 = the skinny kernel, chosen by rule below; 6 = 64 x 64 ring tiles on 64-wide K stages)
+    static const int cand[6] = {0, 1, 2, 3, 4, 6};
+    static const int bm[7] = {192, 160, 128, 64, 32, 0, 64}, bn[7] = {128, 128, 128, 64, 32, 0, 64};
+    // measured: ~1000 rows x 1024 run 32 us on the v1 32x32 tiles, 38 us on v1 64x64, 23 us on the 64x64 ring tiles (256 tiles: one round)
+    static const double cf[7] = {1.0, 1.0, 1.02, 2.0, 1.9, 0.0, 1.36};
     int pick = 3;
     double bc = 1e300;
     const int ma = Mt > 0 ? Mt : 1;
-    for (int i = 0; i < 5; ++i) {
+    for (int ci = 0; ci < 6; ++ci) {
+      const int i = cand[ci];
       const double c = tile_cost((long)ceil_div(ma, bm[i]) * ceil_div(H, bn[i]), bm[i], bn[i], 1, cf[i]);
       if (c < bc) { bc = c; pick = i; }
     }
     if ((long)ceil_div(ma, 32) * ceil_div(H, 32) <= 512) pick = 5;   // M ~ batch: K split over the waves, fragments straight from global
-    if (forced_tile()) pick = forced_tile() - 1;          // debug: 1 -> 192, 2 -> 160, 3 -> 128, 4 -> v1 64, 5 -> v1 32, 6 -> skinny
+    if (forced_tile()) pick = forced_tile() - 1;          // debug: 1 -> 192, 2 -> 160, 3 -> 128, 4 -> v1 64, 5 -> v1 32, 6 -> skinny, 7 -> ring 64x64
     if (dz_above && pick > 2) pick = 2;                   // the two-matrix K walk (B2) exists in the ring loop only
     GemmOperands p;
     p.M = M; p.Nu = H; p.group_stride = 0; p.nk1 = p.nk2 = 0;
@@ -1768,6 +1773,7 @@ extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int 
         else launch_lstm_bwd<CfgBwdV3_128>(p, e, k1, st);
         break;
       case 4: launch_lstm_bwd<CfgPlainTiny>(p, e, k1, st); break;
+      case 6: launch_lstm_bwd<CfgBwdV3_64>(p, e, k1, st); break;
       case 5: {
         const int tm = ceil_div(M, 32), tn = ceil_div(H, 32);
         if (getenv("EVC_SKINNY_DIRECT")) {               // first form: fragments straight from global memory

@@ -755,7 +755,7 @@ def test_gemm_nt_ring_tile_store_paths(tile):
 
 
 @pytest.mark.parametrize("tile", ["1", "2", "3", "4", "5", "6", "7", "8", "9", "10"])
-def test_lstm_steps_on_every_ring_tile(tile):
+def test_lstm_steps_on_every_ring_tile(tile):  # (BPTT: 7 -> the 64 x 64 ring tile of gemm_core_v3.h)
     """The fused LSTM step kernels on every ring-tile height (EVC_FORCE_TILE pins the choice: forward 1 -> 256 rows, 4 -> 320,
     5 -> 288, 6 -> 224, 7 -> 192, 8 -> 160, 9 -> 128, 10 -> 64; BPTT 1 -> 192, 2 -> 160, 3 -> 128) against the oracle - the
     160 / 224 / 288-row tiles have surplus staging lanes (dummy LDS sink), and the forward loop stages through four producer
