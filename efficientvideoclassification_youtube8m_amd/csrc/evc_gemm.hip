@@ -856,7 +856,8 @@ typedef TileCfg2<192, 4, 64, 2, 4, 5, true> CfgLstmV2_192;
 typedef TileCfg2<160, 4, 64, 2, 4, 5, true> CfgLstmV2_160;
 typedef TileCfg2<128, 4, 64, 2, 4, 5, true> CfgLstmV2_128;
 typedef TileCfg2<64, 4, 64, 2, 4, 5, true> CfgLstmV2_64;
-typedef TileCfg2<64, 4, 16, 4, 1, 5, true> CfgLstmV2Small;   // 64 rows x 16 units x 4 gates on the ring loop, 4 waves, 40 KB: M ~ batch steps
+typedef TileCfg2<64, 4, 16, 4, 1, 5, true> CfgLstmV2Small;
+typedef TileCfg3<64, 4, 16, 4, 1, 4> CfgLstmV3Small;         // the same tile on 64-wide K stages (64 KB of LDS: still two workgroups per CU)   // 64 rows x 16 units x 4 gates on the ring loop, 4 waves, 40 KB: M ~ batch steps
 
 template <class Cfg, bool SPLIT = false>
 static inline void launch_lstm_fwd(GemmOperands p, const LstmFwdParams& e, int k1, int k2, hipStream_t st) {
@@ -1078,7 +1079,8 @@ extern "C" int evc_lstm_stack2_fwd(const evc_bf16* x, const evc_bf16* wT0, const
     if (has_a && has_b && (tile == 6 || tile == 7)) {
       if (tile == 6) launch_lstm_fwd_pair<CfgLstmBig>(pa, ea, k1a, k2a, pb, eb, k1b, k2b, st);
       else if (getenv("EVC_PAIR_V1")) launch_lstm_fwd_pair<CfgLstmSmall>(pa, ea, k1a, k2a, pb, eb, k1b, k2b, st);
-      else launch_lstm_fwd_pair<CfgLstmV2Small>(pa, ea, k1a, k2a, pb, eb, k1b, k2b, st);
+      else if (getenv("EVC_PAIR_V2")) launch_lstm_fwd_pair<CfgLstmV2Small>(pa, ea, k1a, k2a, pb, eb, k1b, k2b, st);
+      else launch_lstm_fwd_pair<CfgLstmV3Small>(pa, ea, k1a, k2a, pb, eb, k1b, k2b, st);
       continue;
     }
     for (int r = 0; r < 2; ++r) {
