@@ -255,7 +255,9 @@ extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
     if (splits > K / 1024) splits = K / 1024;
     if (splits < 1) splits = 1;
     if (splits > 1 && !accumulate) EVC_CHECK_HIP(hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st));
-    launch_gemm<CfgTallV2>(p, s, K, splits, st);
+    static const bool tall_v2 = getenv("EVC_TALL_V2") != nullptr;      // A/B: the 32-wide K stages
+    if (tall_v2) launch_gemm<CfgTallV2>(p, s, K, splits, st);
+    else launch_gemm<TileCfg3<256, 1, 64, 2, 4, 4>>(p, s, K, splits, st);   // 64-wide K stages: the [256][K] row operand is re-read from L2 by every workgroup
     EVC_LAUNCH_CHECK();
     return EVC_OK;
   }
