@@ -854,6 +854,12 @@ typedef TileCfg2<320, 4, 64, 2, 4, 4, false> CfgLstmV2a;
 typedef TileCfg2<288, 4, 64, 2, 4, 4, false> CfgLstmV2_288;
 typedef TileCfg2<256, 4, 64, 2, 4, 5, true> CfgLstmV2b;
 typedef TileCfg2<224, 4, 64, 2, 4, 5, true> CfgLstmV2_224;
+// The tall forward tiles on 64-wide K stages (gemm_core_v3.h): two stages of 60-64 KB instead of five of 30-32 KB - whole cache
+// lines per LDS-DMA piece and one barrier per 64 K columns beat the deeper ring (same-box A/B: 79.0 -> 73.9 us per step)
+typedef TileCfg3<256, 4, 64, 2, 4, 2> CfgLstmV3_256;
+typedef TileCfg3<224, 4, 64, 2, 4, 2> CfgLstmV3_224;
+typedef TileCfg3<192, 4, 64, 2, 4, 2> CfgLstmV3_192;
+typedef TileCfg3<160, 4, 64, 2, 4, 3> CfgLstmV3_160;
 typedef TileCfg2<192, 4, 64, 2, 4, 5, true> CfgLstmV2_192;
 typedef TileCfg2<160, 4, 64, 2, 4, 5, true> CfgLstmV2_160;
 typedef TileCfg2<128, 4, 64, 2, 4, 5, true> CfgLstmV2_128;
@@ -983,13 +989,14 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
       }
       continue;
     }
+    static const bool fwd_v2 = getenv("EVC_FWD_V2_LOOP") != nullptr;      // A/B: the 32-wide K stages for the 160-256-row tiles
     switch (pick_fwd_tile(Mt, H)) {
       case 0: launch_lstm_fwd<CfgLstmV2a>(p, e, k1, k2, st); break;
       case 1: launch_lstm_fwd<CfgLstmV2_288>(p, e, k1, k2, st); break;
-      case 2: launch_lstm_fwd<CfgLstmV2b>(p, e, k1, k2, st); break;
-      case 3: launch_lstm_fwd<CfgLstmV2_224>(p, e, k1, k2, st); break;
-      case 4: launch_lstm_fwd<CfgLstmV2_192>(p, e, k1, k2, st); break;
-      case 5: launch_lstm_fwd<CfgLstmV2_160>(p, e, k1, k2, st); break;
+      case 2: if (fwd_v2) launch_lstm_fwd<CfgLstmV2b>(p, e, k1, k2, st); else launch_lstm_fwd<CfgLstmV3_256>(p, e, k1, k2, st); break;
+      case 3: if (fwd_v2) launch_lstm_fwd<CfgLstmV2_224>(p, e, k1, k2, st); else launch_lstm_fwd<CfgLstmV3_224>(p, e, k1, k2, st); break;
+      case 4: if (fwd_v2) launch_lstm_fwd<CfgLstmV2_192>(p, e, k1, k2, st); else launch_lstm_fwd<CfgLstmV3_192>(p, e, k1, k2, st); break;
+      case 5: if (fwd_v2) launch_lstm_fwd<CfgLstmV2_160>(p, e, k1, k2, st); else launch_lstm_fwd<CfgLstmV3_160>(p, e, k1, k2, st); break;
       case 6: launch_lstm_fwd<CfgLstmBig>(p, e, k1, k2, st); break;
       case 8: launch_lstm_fwd<CfgLstmV2_128>(p, e, k1, k2, st); break;
       case 9: launch_lstm_fwd<CfgLstmV2_64>(p, e, k1, k2, st); break;

@@ -53,8 +53,8 @@ struct TileCfg2 {
 __device__ __forceinline__ int swz64(int row) { return (0xD2 >> (2 * ((row >> 2) & 3))) & 3; }
 
 template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+__device__ __forceinline__ void wait_vmcnt() {     // (the counter has 6 bits: a larger bound waits for 63, which is only stricter)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N > 63 ? 63 : N) : "memory");
 }
 
 template <class Cfg, bool SWAP = false, bool INIT = true, int MODE = EVC_LOOP_MODE_DEFAULT>
