@@ -252,7 +252,21 @@ struct DbofPoolParams {
   int B, S, C;
 };
 
+#ifdef EVC_DBOF_V2_LOOP
 typedef TileCfg2<256, 1, 256, 2, 4, 5, true> CfgDbof;      // 256 frame rows (8 videos) x 256 clusters, 8 waves (2 x 4)
+#else
+struct CfgDbof : TileCfg3<256, 1, 256, 2, 4, 2> {          // the same tile on two 64-wide K stages (gemm_core_v3.h: 128 KB) ...
+  static constexpr int LDS_BYTES = 160 * 1024;             // ... launched with the whole LDS: the epilogue's per-wave transpose slices need 147 KB
+};
+template <> struct is_v2<CfgDbof> { static constexpr bool value = true; };
+template <> struct is_v3<CfgDbof> { static constexpr bool value = true; };
+#endif
+
+template <class Cfg, bool INIT>
+__device__ __forceinline__ void dbof_mainloop(const GemmOperands& p, int m0, int u0, f32x4 (&acc)[Cfg::MI][1][Cfg::NI]) {
+  if constexpr (is_v3<Cfg>::value) gemm_mainloop_v3<Cfg, true, INIT>(p, m0, u0, lds_dyn, acc);
+  else gemm_mainloop_v2<Cfg, true, INIT>(p, m0, u0, lds_dyn, acc);
+}
 
 __global__ __launch_bounds__(CfgDbof::NT) void dbof_cluster_pool_kernel(GemmOperands p, DbofPoolParams e, int tiles_m, int tiles_n) {
   typedef CfgDbof Cfg;
@@ -262,16 +276,16 @@ __global__ __launch_bounds__(CfgDbof::NT) void dbof_cluster_pool_kernel(GemmOper
   tile_of(id, tiles_m, tiles_n, tm, tn, 8);
   const int m0 = tm * Cfg::BM, u0 = tn * Cfg::BU;
   f32x4 acc[Cfg::MI][1][Cfg::NI];
-  gemm_mainloop_v2<Cfg, true, true>(p, m0, u0, lds_dyn, acc);
+  dbof_mainloop<Cfg, true>(p, m0, u0, acc);
   if (p.A1lo) {                     // split-bf16 operands: + hi.lo + lo.hi (f32-operand accuracy, 3x the MFMA work)
     GemmOperands q = p;
     q.B = p.Blo;
     __syncthreads();
-    gemm_mainloop_v2<Cfg, true, false>(q, m0, u0, lds_dyn, acc);
+    dbof_mainloop<Cfg, false>(q, m0, u0, acc);
     q = p;
     q.A1 = p.A1lo;
     __syncthreads();
-    gemm_mainloop_v2<Cfg, true, false>(q, m0, u0, lds_dyn, acc);
+    dbof_mainloop<Cfg, false>(q, m0, u0, acc);
   }
   // ---- epilogue.  Transposed accumulators: lane 16g + l holds row mi*16 + l, columns ni*16 + 4g .. 4g+3 ----
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -363,14 +377,14 @@ __global__ __launch_bounds__(CfgDbof::NT) void dbof_cluster_pool_kernel(GemmOper
 extern "C" int evc_dbof_cluster_pool_fwd(const evc_bf16* r_bn, const evc_bf16* r_bn_lo, const evc_bf16* wT, const evc_bf16* wT_lo,
                                          int B, int S, int F, int C, const float* gamma, evc_bf16* act, float* part, float* xsel,
                                          uint8_t* arg, void* stream) {
-  EVC_REQUIRE(B > 0 && S > 0 && S <= SP && F > 0 && F % 32 == 0 && C > 0 && C % 64 == 0, EVC_ERR_BAD_SHAPE,
-              "evc_dbof_cluster_pool_fwd: needs iterations <= %d, F %% 32 == 0, clusters %% 64 == 0 (S=%d F=%d C=%d)", SP, S, F, C);
+  EVC_REQUIRE(B > 0 && S > 0 && S <= SP && F > 0 && F % CfgDbof::BK == 0 && C > 0 && C % 64 == 0, EVC_ERR_BAD_SHAPE,
+              "evc_dbof_cluster_pool_fwd: needs iterations <= %d, F %% 64 == 0, clusters %% 64 == 0 (S=%d F=%d C=%d)", SP, S, F, C);
   EVC_REQUIRE(ring_operand_ok(((long)B + 3) / 4 * 4 * SP, F) && ring_operand_ok(C, F), EVC_ERR_BAD_SHAPE,
               "evc_dbof_cluster_pool_fwd: the frame matrix or the cluster weights span 4 GiB or more (B=%d F=%d C=%d)", B, F, C);
   EVC_REQUIRE((r_bn_lo != nullptr) == (wT_lo != nullptr), EVC_ERR_BAD_ARG, "evc_dbof_cluster_pool_fwd: both low halves or none");
   const int Mp = dbof_padded_rows(B);
   GemmOperands p;
-  p.A1 = r_bn; p.lda1 = F; p.nk1 = F / 32; p.A2 = r_bn; p.lda2 = F; p.nk2 = 0;
+  p.A1 = r_bn; p.lda1 = F; p.nk1 = F / CfgDbof::BK; p.A2 = r_bn; p.lda2 = F; p.nk2 = 0;
   p.B = wT; p.ldb = F; p.group_stride = 0; p.M = Mp; p.Nu = C;
   p.A1lo = r_bn_lo; p.A2lo = nullptr; p.Blo = wT_lo;
   DbofPoolParams e{act, (long)C, part, gamma, xsel, arg, B, S, C};

@@ -317,11 +317,14 @@ extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
   // 45 vs 58); beyond that two workgroups share a CU's L2 ingest and the v1 / 256x256 tiles win again
   if (pick == 2 && K >= 2048 && (long)ceil_div(M, 128) * ceil_div(N, 128) <= 256) pick = 5;
   if (forced_tile()) pick = forced_tile();
+  static const bool nt_v3 = getenv("EVC_NT_BIG_V2") == nullptr;          // the 224/256-row tiles on two 64-wide stages (A/B switch: the five 32-wide ones)
   static const bool v3 = getenv("EVC_NT_V2_LOOP") == nullptr;      // 64-wide K stages for the 128-column ring tiles (A/B switch)
   if (pick == 5 && v3) launch_gemm<TileCfg3<128, 1, 128, 2, 4, 4>>(p, s, K, 1, st);
   else if (pick == 5) launch_gemm<CfgTn128>(p, s, K, 1, st);
+  else if (pick == 4 && nt_v3) launch_gemm<TileCfg3<224, 1, 256, 2, 4, 2>>(p, s, K, 1, st);
   else if (pick == 4) launch_gemm<CfgPlainV2_224>(p, s, K, 1, st);
   else if (pick == 6) launch_gemm<CfgPlainV2_320>(p, s, K, 1, st);
+  else if (pick == 1 && nt_v3) launch_gemm<TileCfg3<256, 1, 256, 2, 4, 2>>(p, s, K, 1, st);
   else if (pick == 7 && v3) launch_gemm<TileCfg3<160, 1, 128, 2, 4, 4>>(p, s, K, 1, st);
   else if (pick == 7) launch_gemm<TileCfg2<160, 1, 128, 2, 4, 5, true>>(p, s, K, 1, st);
   else if (pick == 1) launch_gemm<CfgPlainV2>(p, s, K, 1, st);
