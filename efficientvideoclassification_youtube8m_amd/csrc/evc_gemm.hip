@@ -729,15 +729,15 @@ __device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const 
   if constexpr (is_v2<Cfg>::value && SPLIT) {
     // split-bf16 operands on the ring tiles: three passes of the loop over the same accumulators, hi.hi + hi.lo + lo.hi
     // (the v1 loop stages hi and lo side by side instead; on 64-row tiles, ~3x slower per FLOP than this)
-    gemm_mainloop_v2<Cfg, true, false>(p, m0, u0, lds_dyn, acc);
+    run_mainloop<Cfg, 4, true, false, false>(p, m0, u0, acc);
     GemmOperands q = p;
     q.B = p.Blo;
     __syncthreads();                                            // every wave has read the previous pass's last ring slot
-    gemm_mainloop_v2<Cfg, true, false>(q, m0, u0, lds_dyn, acc);
+    run_mainloop<Cfg, 4, true, false, false>(q, m0, u0, acc);
     q = p;
     q.A1 = p.A1lo; q.A2 = p.A2lo;
     __syncthreads();
-    gemm_mainloop_v2<Cfg, true, false>(q, m0, u0, lds_dyn, acc);
+    run_mainloop<Cfg, 4, true, false, false>(q, m0, u0, acc);
   } else {
     run_mainloop<Cfg, 4, true, SPLIT, false, EVC_FWD_LOOP_MODE>(p, m0, u0, acc);   // transposed accumulators: lane = one row, 4 consecutive units
   }
@@ -984,8 +984,8 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
       if (Mt >= 1024 && forced_tile() == 0) {
         switch (pick_fwd_tile(Mt, H)) {
           case 0: launch_lstm_fwd<CfgLstmV2a, true>(p, e, k1, k2, st); break;
-          case 3: launch_lstm_fwd<CfgLstmV2_224, true>(p, e, k1, k2, st); break;
-          default: launch_lstm_fwd<CfgLstmV2b, true>(p, e, k1, k2, st); break;
+          case 3: launch_lstm_fwd<CfgLstmV3_224, true>(p, e, k1, k2, st); break;
+          default: launch_lstm_fwd<CfgLstmV3_256, true>(p, e, k1, k2, st); break;
         }
       } else {      // (128-row ring tiles for the student's ~900 live rows: measured no faster than the 64-row v1 tiles)
         launch_lstm_fwd<CfgLstmSmall, true>(p, e, k1, k2, st);
