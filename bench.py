@@ -139,7 +139,7 @@ def run_hlstm(device, rank, world, B, mode, every_n, steps, warmup, all_full=Fal
     if roofline and not l1_stack.timing:
         l1_stack.timing = None                      # (the split-bf16 forward has no per-layer event hooks: no roofline object)
     elif roofline:
-        # lstm_fwd_step_kernel<TileCfg2<BM,4,64,..>> (30 launches per iteration, the largest FLOP share of the
+        # lstm_fwd_step_kernel<TileCfg3<BM,4,64,..>> (30 launches per iteration, the largest FLOP share of the
         # recurrent path).  Live timing with HIP events on the launch stream around each layer's 15-step launch
         # sequence in every timed step; algorithmic FLOPs = 2*rows_t*4H*K of each step GEMM over the rows that
         # step runs on.
@@ -163,7 +163,7 @@ def run_hlstm(device, rank, world, B, mode, every_n, steps, warmup, all_full=Fal
                 pass
         achieved = flops / (ms * 1e-3) / 1e12
         res["roofline"] = {
-            "bound": "mfma", "kernel": "lstm_fwd_step_kernel<TileCfg2<BM,4,64,2,4,..>> (teacher L1; BM = 224..320 per launch from the "
+            "bound": "mfma", "kernel": "lstm_fwd_step_kernel<TileCfg3<BM,4,64,2,4,2>> (teacher L1; BM = 224..256 per launch, TileCfg2 for 288/320, from the "
                                        "active rows)" if graph.teacher is not None else "lstm_fwd_step_kernel (student L1)",
             "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
             "traffic": traffic, "mfma_busy_pmc": mfma_busy, "avg_launch_ms": round(ms / launches, 4),

@@ -11,10 +11,10 @@ from collections import defaultdict
 
 root, out = sys.argv[1], sys.argv[2]
 KERNELS = dict(a.split("=", 1) for a in sys.argv[3:]) or {
-    "lstm_fwd_step (teacher/student L1, v2 tiles)": "lstm_fwd_step_kernel<TileCfg2<",
+    "lstm_fwd_step (teacher/student L1, ring tiles)": "lstm_fwd_step_kernel<TileCfg3<",
     "lstm_bwd_step (L1 BPTT, 128x128 ring tile)": "lstm_bwd_step_kernel<TileCfg3<128",
     "gemm_tn 256x256 (weight gradients)": "gemm_tn_kernel<TileCfg2<256",
-    "gemm_nt 256x256 / 224x256 (dX, hoisted projections)": "gemm_nt_kernel<TileCfg2<2",
+    "gemm_nt 256x256 / 224x256 (dX, hoisted projections)": "gemm_nt_kernel<TileCfg3<2",
     "moe_update pass 2 (fused clip + Adam of the MoE weights)": "moe_update_kernel<TileCfg2<128, 1, 128, 2, 4, 5, true>, 2>",
     "dbof_cluster_pool (DBoF cluster GEMM + statistics + selection)": "dbof_cluster_pool_kernel",
     "dbof_dact": "dbof_dact_kernel",

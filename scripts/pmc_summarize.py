@@ -9,7 +9,7 @@ from collections import defaultdict
 
 root = sys.argv[1]
 out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01_pmc_traffic.json"
-MATCH = "lstm_fwd_step_kernel<TileCfg2<"
+MATCH = ("lstm_fwd_step_kernel<TileCfg2<", "lstm_fwd_step_kernel<TileCfg3<")     # the ring tiles (v2 / v3 stages)
 
 
 def load(sub):
@@ -18,7 +18,7 @@ def load(sub):
     dur = defaultdict(list)
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if MATCH in k:
+        if any(m in k for m in MATCH):
             per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     return per, dur
@@ -36,8 +36,8 @@ busy, gui = avg(mfma, "SQ_VALU_MFMA_BUSY_CYCLES"), avg(mfma, "GRBM_GUI_ACTIVE")
 res = {
     "source": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE; each with "
               "--kernel-trace only) of `python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline` on MI355X (scripts/pmc_collect.sh)",
-    "kernel": "lstm_fwd_step_kernel<TileCfg2<BM,4,64,2,4,..>> - the v2 tile heights the row plans select, launches per variant: "
-              + ", ".join("%s x%d" % (k.split("TileCfg2<")[1].split(">")[0].replace(" ", ""), n[k]) for k in kernels),
+    "kernel": "lstm_fwd_step_kernel<TileCfg3<BM,4,64,2,4,2>> (TileCfg2 for 288/320 rows) - the ring tile heights the row plans select, launches per variant: "
+              + ", ".join("%s x%d" % (k.split("TileCfg")[1].split(">")[0].replace(" ", ""), n[k]) for k in kernels),
     "launches_sampled": tot,
     "FETCH_SIZE_KB_avg_raw": fetch_kb,
     "WRITE_SIZE_KB_avg_raw": write_kb,
