@@ -138,7 +138,11 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_nt_kernel(GemmOperands p, StoreP
   const int m0 = tm * Cfg::BM, u0 = tn * Cfg::BU;
   f32x4 acc[Cfg::MI][Cfg::G][Cfg::NI];
   constexpr bool V2 = is_v2<Cfg>::value;
-  run_mainloop<Cfg, Cfg::G, V2>(p, m0, u0, acc);     // ring tiles: transposed accumulators (lane = one row, 4 consecutive columns)
+  // loop options (gemm_core_v2.h): producer waves + LDS-DMA first + no priority flips for every ring tile but the 320-row one
+  // (same box: L1 dX 477 -> 431 us, 1280 x 4096 x 4096 63 -> 56.5 us, MoE gates forward 48.3 -> 46 us; 5120 x 4096 x 4096 on
+  // the 320-row tile 153 -> 162 us with them)
+  constexpr int NT_MODE = Cfg::BM == 320 ? 0 : (LOOP_PRODUCER | LOOP_DMA_FIRST | LOOP_NO_PRIO);
+  run_mainloop<Cfg, Cfg::G, V2, false, true, NT_MODE>(p, m0, u0, acc);     // ring tiles: transposed accumulators (lane = one row, 4 consecutive columns)
   if constexpr (V2) {
     // plain overwrite with 16-byte-aligned rows, or the split-K join: through LDS (kernel-uniform conditions: one barrier)
     const int es = s.out_bf16 ? 2 : 4;
