@@ -391,7 +391,10 @@ def main():
             r = run_hlstm(device, rank, world, kw["B"], kw["mode"], kw["every_n"], s_steps, s_warm, kw.get("all_full", False), "bf16", 4)
             oc[name] = {k: r[k] for k in keep}
             _log("%s done: %.2f ms/step" % (name, r["ms_per_step"]))
-        r = run_dbof(device, rank, world, 512, s_steps, s_warm)
+        # (a 2 ms step: 20 steps and a pause first - right after the tens of GB of the previous configuration are freed the
+        #  driver's unmapping work can stall the queue for ~65 ms once, which a 5-step window reported as 15 ms per step)
+        time.sleep(0.5)
+        r = run_dbof(device, rank, world, 512, 20, 6)
         oc["cfg4_dbof_8192_1024_moe2_b512"] = r
         _log("dbof done: %.2f ms/step" % r["ms_per_step"])
         extra["other_configs"] = oc
