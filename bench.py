@@ -311,17 +311,23 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="videos per GPU (default 256; 512 for --config dbof)")
     ap.add_argument("--every_n", type=int, default=10)
     ap.add_argument("--mode", default="teacher_student", choices=["teacher_student", "teacher", "student"])
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "high"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "high", "split"])
     ap.add_argument("--all_full", action="store_true", help="every video has 300 frames (no padding)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_secondary", action="store_true", help="skip the precision_modes / other_configs runs (N=1 only anyway)")
     ap.add_argument("--cpu_videos", type=int, default=64)
+    ap.add_argument("--cpu_baseline_only", action="store_true", help="print only the cpu_baseline object (e.g. --cpu_videos 256 --cpu_budget 400: "
+                    "the batch SURVEY 8(d) specifies; profiles/r03_cpu_baseline_b256.json)")
+    ap.add_argument("--cpu_budget", type=float, default=50.0, help="seconds the CPU leg may take (1 warm-up + up to 3 timed iterations)")
     ap.add_argument("--no_fused_moe", action="store_true", help="debug: materialise the MoE weight gradients (A/B of evc_moe_grad_update)")
     ap.add_argument("--student_forward_early", action="store_true", help="A/B: student forward next to the teacher forward")
     ap.add_argument("--no_overlap", action="store_true", help="debug: everything on one stream (solo kernel times for profiling)")
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic batches cycled through (HBM resident)")
     args = ap.parse_args()
 
+    if args.cpu_baseline_only:
+        print(json.dumps({"cpu_baseline": cpu_baseline(args.every_n, args.cpu_videos, args.cpu_budget)}))
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -417,7 +423,7 @@ def main():
         }
         res.update(extra)
         if n_gpus == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.every_n, args.cpu_videos)
+            res["cpu_baseline"] = cpu_baseline(args.every_n, args.cpu_videos, args.cpu_budget)
         print(json.dumps(res))
     if world > 1 or one_rank_dp:
         torch.distributed.destroy_process_group()

@@ -16,7 +16,7 @@ vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 # name -> argtypes (every function returns int except the two noted below)
 SIGNATURES = {
     "evc_check_device": [i32],
-    "evc_l2norm_chunk_fwd": [vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp, i32, vp, vp, vp, i32, vp, i32, vp],
+    "evc_l2norm_chunk_fwd": [vp, vp, vp, i32, i32, i32, i32, vp, i32, i32, vp, i32, vp, vp, i32, vp, i32, vp, i32, vp],
     "evc_sort_rows_by_len": [vp, i32, i32, vp, vp, vp, vp],
     "evc_frame_counts": [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp],
     "evc_gemm_nt": [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i32, i32, vp],
@@ -24,10 +24,15 @@ SIGNATURES = {
     "evc_gemm_tn2": [vp, i64, vp, i64, i32, vp, i64, i32, i32, vp, i64, i32, i32, i32, i32, vp],
     "evc_colsum_bf16": [vp, i64, i32, i32, i32, vp, vp],
     "evc_lstm_layer_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp],
-    "evc_lstm_layer_fwd_hp": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp],
+    "evc_lstm_layer_fwd_hp": [vp, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp, vp, vp],
+    "evc_gemm_nt_split": [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, vp],
+    "evc_cast_f32_to_f16_wide": [vp, i64, i32, i32, i32, i32, vp, vp],
+    "evc_cast_f32_to_bf16_wide": [vp, i64, i32, i32, vp, i64, i32, vp],
+    "evc_lstm_layer_fwd_f16": [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp],
     "evc_lstm_layer_bwd": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "evc_transpose_to_bf16": [vp, i32, i64, i32, i32, vp, i64, i32, i32, vp],
     "evc_cast_f32_to_bf16": [vp, i64, i32, i32, vp, i64, vp],
+    "evc_cast_f32_to_f16": [vp, i64, i32, i32, vp, i64, vp],
     "evc_cast_f32_to_bf16_split": [vp, i64, i32, i32, vp, vp, i64, vp],
     "evc_rowsum_bf16": [vp, i64, i32, i32, vp, vp],
     "evc_lstm_stack2_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp],

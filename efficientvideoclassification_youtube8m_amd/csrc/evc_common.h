@@ -10,6 +10,8 @@
 typedef uint16_t bf16_t;  // raw bfloat16 bits
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef uint16_t f16_t;   // raw IEEE binary16 bits
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 
 // thread-local last-error text (evc_last_error)
 void evc_set_error(const char* fmt, ...);
@@ -47,6 +49,23 @@ __device__ __forceinline__ uint32_t pack_bf16x2_hw(float lo, float hi) {   // lo
   return *(const uint32_t*)&r;
 }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2_hw(f, 0.0f) & 0xffffu); }
+// f32 -> IEEE f16, round to nearest even (v_cvt_pk_f16_f32 / v_cvt_f16_f32); lo in bits 0-15
+typedef _Float16 evc_f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_f16x2_hw(float lo, float hi) {
+  const evc_f32x2_t v = {lo, hi};
+  const evc_f16x2_t r = __builtin_convertvector(v, evc_f16x2_t);
+  return *(const uint32_t*)&r;
+}
+__device__ __forceinline__ f16_t f32_to_f16(float f) { return (f16_t)(pack_f16x2_hw(f, 0.0f) & 0xffffu); }
+__device__ __forceinline__ float f16_to_f32(f16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+
+// One MFMA depth of the 16-bit loops: v_mfma_f32_16x16x32_bf16, or - F16 - v_mfma_f32_16x16x32_f16 on the same 16-byte
+// fragments (same rate, 11 significand bits instead of 8: the "high" precision forward of the L1 levels).
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(const bf16x8 a, const bf16x8 b, const f32x4 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 
 // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division sequence hipcc emits for `/` without fast-math:
 // the gate tails evaluate 5 of these per (row, unit) and were VALU-bound on them.

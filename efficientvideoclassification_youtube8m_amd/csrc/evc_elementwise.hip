@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void l2norm_chunk_kernel(const float* __restri
                                                            const int* __restrict__ nfr, int B, int T, int F, int C1,
                                                            bf16_t* __restrict__ out1, int every_n, int C2,
                                                            bf16_t* __restrict__ out2, int normalize,
-                                                           bf16_t* __restrict__ out1_lo, bf16_t* __restrict__ out2_lo,
+                                                           bf16_t* __restrict__ out1_lo, bf16_t* __restrict__ out2_lo, int aux_mode,
                                                            const int* __restrict__ pos1, int P1,
                                                            const int* __restrict__ pos2, int P2) {
   const int lane = threadIdx.x & 63;
@@ -109,10 +109,51 @@ __global__ __launch_bounds__(256) void l2norm_chunk_kernel(const float* __restri
       o.z = f32_to_bf16(v[i].z * inv); o.w = f32_to_bf16(v[i].w * inv);
       if (o1) ((ushort4*)o1)[j] = o;
       if (o2) ((ushort4*)o2)[j] = o;
-      if (out1_lo) {     // split-bf16 parity mode: low-order halves
+      if (out1_lo) {     // "high" precision forward: second image of each view (evc.h: aux_mode)
         ushort4 l;
-        l.x = f32_to_bf16(v[i].x * inv - bf16_to_f32(o.x)); l.y = f32_to_bf16(v[i].y * inv - bf16_to_f32(o.y));
-        l.z = f32_to_bf16(v[i].z * inv - bf16_to_f32(o.z)); l.w = f32_to_bf16(v[i].w * inv - bf16_to_f32(o.w));
+        const float xv[4] = {v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv};
+        if (aux_mode == 4) {          // wide split-bf16 image, rows of 2F: [lo | hi] (the A operand of evc_gemm_nt_split / evc_lstm_layer_fwd_hp)
+          l.x = f32_to_bf16(xv[0] - bf16_to_f32(o.x)); l.y = f32_to_bf16(xv[1] - bf16_to_f32(o.y));
+          l.z = f32_to_bf16(xv[2] - bf16_to_f32(o.z)); l.w = f32_to_bf16(xv[3] - bf16_to_f32(o.w));
+          if (o1) {
+            ushort4* w = (ushort4*)(out1_lo + off1 * 2);
+            w[j] = l; w[nv + j] = o;
+          }
+          if (o2 && out2_lo) {
+            ushort4* w = (ushort4*)(out2_lo + off2 * 2);
+            w[j] = l; w[nv + j] = o;
+          }
+          continue;
+        }
+        if (aux_mode >= 1) {          // IEEE f16 image, rows of nseg*F: [x | (x - f16(x))*64 | f16(x)/64]
+          const int nseg = aux_mode;
+          ushort4 h16, l16, s16;
+          h16.x = f32_to_f16(xv[0]); h16.y = f32_to_f16(xv[1]); h16.z = f32_to_f16(xv[2]); h16.w = f32_to_f16(xv[3]);
+          const uint16_t hb[4] = {h16.x, h16.y, h16.z, h16.w};
+          uint16_t lb[4], sb[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float hf = f16_to_f32(hb[r]);
+            lb[r] = f32_to_f16((xv[r] - hf) * 64.0f);
+            sb[r] = f32_to_f16(hf * (1.0f / 64.0f));
+          }
+          l16 = make_ushort4(lb[0], lb[1], lb[2], lb[3]); s16 = make_ushort4(sb[0], sb[1], sb[2], sb[3]);
+          if (o1) {
+            ushort4* w = (ushort4*)(out1_lo + off1 * nseg);
+            w[j] = h16;
+            if (nseg >= 2) w[nv + j] = l16;
+            if (nseg >= 3) w[2 * nv + j] = s16;
+          }
+          if (o2 && out2_lo) {
+            ushort4* w = (ushort4*)(out2_lo + off2 * nseg);
+            w[j] = h16;
+            if (nseg >= 2) w[nv + j] = l16;
+            if (nseg >= 3) w[2 * nv + j] = s16;
+          }
+          continue;
+        }
+        l.x = f32_to_bf16(xv[0] - bf16_to_f32(o.x)); l.y = f32_to_bf16(xv[1] - bf16_to_f32(o.y));
+        l.z = f32_to_bf16(xv[2] - bf16_to_f32(o.z)); l.w = f32_to_bf16(xv[3] - bf16_to_f32(o.w));
         if (o1) ((ushort4*)(out1_lo + off1))[j] = l;
         if (o2 && out2_lo) ((ushort4*)(out2_lo + off2))[j] = l;
       }
@@ -123,7 +164,7 @@ __global__ __launch_bounds__(256) void l2norm_chunk_kernel(const float* __restri
 extern "C" int evc_l2norm_chunk_fwd(const float* x_raw, const uint8_t* x_u8, const int32_t* num_frames,
                                     int B, int T, int F, int C1, evc_bf16* out1,
                                     int every_n, int C2, evc_bf16* out2, int normalize,
-                                    evc_bf16* out1_lo, evc_bf16* out2_lo,
+                                    evc_bf16* out1_lo, evc_bf16* out2_lo, int aux_mode,
                                     const int32_t* row_pos1, int rows1, const int32_t* row_pos2, int rows2, void* stream) {
   EVC_REQUIRE(B > 0 && T > 0 && F > 0 && F % 4 == 0 && F <= 1280, EVC_ERR_BAD_SHAPE,
               "evc_l2norm_chunk_fwd: F=%d must be a multiple of 4 and <= 1280", F);
@@ -133,14 +174,15 @@ extern "C" int evc_l2norm_chunk_fwd(const float* x_raw, const uint8_t* x_u8, con
                 "evc_l2norm_chunk_fwd: student view T/every_n=%d not divisible by C2=%d", T / (every_n > 0 ? every_n : 1), C2);
   }
   EVC_REQUIRE(!x_u8 || num_frames, EVC_ERR_BAD_ARG, "evc_l2norm_chunk_fwd: uint8 input needs num_frames");
+  EVC_REQUIRE(aux_mode >= 0 && aux_mode <= 4, EVC_ERR_BAD_ARG, "evc_l2norm_chunk_fwd: aux_mode=%d (0 bf16 low halves, 1..3 f16 segments, 4 wide bf16)", aux_mode);
   const long rows = (long)B * T;
   dim3 grid((unsigned)((rows + 3) / 4));
   if (x_u8)
     hipLaunchKernelGGL(l2norm_chunk_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x_raw, x_u8, num_frames, B, T, F,
-                       C1, out1, every_n > 0 ? every_n : 1, C2, out2, normalize, out1_lo, out2_lo, row_pos1, rows1, row_pos2, rows2);
+                       C1, out1, every_n > 0 ? every_n : 1, C2, out2, normalize, out1_lo, out2_lo, aux_mode, row_pos1, rows1, row_pos2, rows2);
   else
     hipLaunchKernelGGL(l2norm_chunk_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x_raw, x_u8, num_frames, B, T, F,
-                       C1, out1, every_n > 0 ? every_n : 1, C2, out2, normalize, out1_lo, out2_lo, row_pos1, rows1, row_pos2, rows2);
+                       C1, out1, every_n > 0 ? every_n : 1, C2, out2, normalize, out1_lo, out2_lo, aux_mode, row_pos1, rows1, row_pos2, rows2);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }
@@ -339,6 +381,85 @@ extern "C" int evc_cast_f32_to_bf16(const float* in, int64_t ld_in, int R, int C
   const long n = (long)R * C;
   const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   hipLaunchKernelGGL(cast_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, ld_in, R, C, out, ld_out);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+__global__ void cast_f16_kernel(const float* __restrict__ in, long ld_in, int R, int C, f16_t* __restrict__ out, long ld_out) {
+  const long n = (long)R * C;
+  const long stride = (long)gridDim.x * blockDim.x, tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ld_in == C && ld_out == C && (n & 3) == 0 && (((uintptr_t)in) & 15) == 0 && (((uintptr_t)out) & 7) == 0) {
+    for (long i = tid; i < (n >> 2); i += stride) {
+      const float4 f = ((const float4*)in)[i];
+      ((uint2*)out)[i] = make_uint2(pack_f16x2_hw(f.x, f.y), pack_f16x2_hw(f.z, f.w));
+    }
+    return;
+  }
+  for (long i = tid; i < n; i += stride) {
+    const long r = i / C, c = i % C;
+    out[r * ld_out + c] = f32_to_f16(in[r * ld_in + c]);
+  }
+}
+extern "C" int evc_cast_f32_to_f16(const float* in, int64_t ld_in, int R, int C, evc_f16* out, int64_t ld_out, void* stream) {
+  EVC_REQUIRE(R > 0 && C > 0, EVC_ERR_BAD_SHAPE, "evc_cast_f32_to_f16: bad shape");
+  const long n = (long)R * C;
+  const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(cast_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, ld_in, R, C, out, ld_out);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// IEEE f16 weight image of an LSTM kernel whose x-part is contracted as a K-extension (evc_lstm_layer_fwd_f16 on nseg x-segments):
+// out row = [f16(Wx) | f16(Wx)/64 | (Wx - f16(Wx))*64 | f16(Wh)] (the first nseg of the three x blocks), in = [Wx(Kin) | Wh(H)] f32.
+__global__ void cast_f16_wide_kernel(const float* __restrict__ in, long ld_in, int R, int Kin, int H, int nseg, f16_t* __restrict__ out) {
+  const int C = Kin + H;
+  const long n = (long)R * C, ldo = (long)nseg * Kin + H;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C;
+    const int c = (int)(i % C);
+    const float w = in[r * ld_in + c];
+    const f16_t h = f32_to_f16(w);
+    f16_t* o = out + r * ldo;
+    if (c >= Kin) { o[(long)nseg * Kin + (c - Kin)] = h; continue; }
+    o[c] = h;
+    const float hf = f16_to_f32(h);
+    if (nseg >= 2) o[Kin + c] = f32_to_f16(hf * (1.0f / 64.0f));
+    if (nseg >= 3) o[2L * Kin + c] = f32_to_f16((w - hf) * 64.0f);
+  }
+}
+extern "C" int evc_cast_f32_to_f16_wide(const float* in, int64_t ld_in, int R, int Kin, int H, int nseg, evc_f16* out, void* stream) {
+  EVC_REQUIRE(R > 0 && Kin > 0 && H >= 0 && nseg >= 1 && nseg <= 3, EVC_ERR_BAD_SHAPE, "evc_cast_f32_to_f16_wide: bad shape / nseg=%d", nseg);
+  const long n = (long)R * (Kin + H);
+  const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(cast_f16_wide_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, ld_in, R, Kin, H, nseg, out);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// wide split-bf16 image of a [R][C] f32 matrix: out row = [lo | hi] (lo_first, the A operand of evc_gemm_nt_split) or [hi | lo]
+// (its B operand), hi = bf16(x), lo = bf16(x - hi); out rows have ld_out >= 2C elements.
+__global__ void cast_split_wide_kernel(const float* __restrict__ in, long ld_in, int R, int C, bf16_t* __restrict__ out, long ld_out, int lo_first) {
+  const long n4 = (long)R * (C >> 2);
+  const int cv = C >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cv;
+    const int c = (int)(i % cv) * 4;
+    const float4 f = *(const float4*)(in + r * ld_in + c);
+    const uint32_t h0 = pack_bf16x2_hw(f.x, f.y), h1 = pack_bf16x2_hw(f.z, f.w);
+    const float l0 = f.x - __uint_as_float(h0 << 16), l1 = f.y - __uint_as_float(h0 & 0xffff0000u);
+    const float l2 = f.z - __uint_as_float(h1 << 16), l3 = f.w - __uint_as_float(h1 & 0xffff0000u);
+    bf16_t* o = out + r * ld_out + c;
+    *(uint2*)(o + (lo_first ? C : 0)) = make_uint2(h0, h1);
+    *(uint2*)(o + (lo_first ? 0 : C)) = make_uint2(pack_bf16x2_hw(l0, l1), pack_bf16x2_hw(l2, l3));
+  }
+}
+extern "C" int evc_cast_f32_to_bf16_wide(const float* in, int64_t ld_in, int R, int C, evc_bf16* out, int64_t ld_out, int lo_first, void* stream) {
+  EVC_REQUIRE(R > 0 && C > 0 && C % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0 && ld_out >= 2L * C && ((uintptr_t)in % 16) == 0 &&
+              ((uintptr_t)out % 8) == 0, EVC_ERR_BAD_SHAPE, "evc_cast_f32_to_bf16_wide: C=%d, ld_in=%ld, ld_out=%ld must be multiples of 4, ld_out >= 2C, aligned",
+              C, (long)ld_in, (long)ld_out);
+  const long n = (long)R * (C / 4);
+  const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(cast_split_wide_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, ld_in, R, C, out, ld_out, lo_first);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }

@@ -21,7 +21,7 @@ __device__ __forceinline__ void run_mainloop(const GemmOperands& p, int m0, int 
     else gemm_mainloop_v2<Cfg, SWAP, INIT, MODE>(p, m0, u0, lds_dyn, acc);
   } else {
     __shared__ __attribute__((aligned(16))) char lds_static[(SPLIT ? 2 : 1) * Cfg::LDS_BYTES];   // static: keeps 2 workgroups per CU
-    gemm_mainloop<Cfg, SWAP, SPLIT, INIT>(p, m0, u0, lds_static, acc);
+    gemm_mainloop<Cfg, SWAP, SPLIT, INIT, (MODE & LOOP_F16) != 0>(p, m0, u0, lds_static, acc);
   }
 }
 
@@ -334,6 +334,56 @@ extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
   else if (pick == 1) launch_gemm<CfgPlainV2>(p, s, K, 1, st);
   else if (pick == 2) launch_gemm<CfgPlainBig>(p, s, K, 1, st);
   else launch_gemm<CfgPlainSmall>(p, s, K, 1, st);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Split-bf16 product C = (A_hi + A_lo) . (B_hi + B_lo)^T (+ bias) to ~2^-16 as ONE launch: the three products
+// lo.hi + hi.lo + hi.hi are a K-extension of the plain loop.  A rows are the wide image [lo(K) | hi(K)]
+// (evc_cast_f32_to_bf16_wide, lo first), B rows [hi(K) | lo(K)] (hi first): segment 1 walks A's whole row against B's whole row
+// (k < K: lo.hi, k >= K: hi.lo), segment 2 walks A's hi half again against B2 = B's hi half (GemmOperands::B2 restarts B's k
+// index).  Same accumulator, one epilogue, no split-K join - against three launches that each re-staged both operands and
+// joined through C.  Ring tiles only (B2 lives in the v2 / v3 loops).
+// ---------------------------------------------------------------------------
+template <class Cfg>
+static inline void launch_gemm_seg(GemmOperands p, StoreParams s, int K, hipStream_t st) {
+  p.nk1 = 2 * K / kdiv<Cfg>(); p.nk2 = K / kdiv<Cfg>();
+  const int tm = ceil_div(s.M, Cfg::BM), tn = ceil_div(s.N, Cfg::BU);
+  s.splits = 1; s.ksteps_per_split = p.nk1;
+  launch_cfg<Cfg>(gemm_nt_kernel<Cfg>, tm * tn, st, p, s, tm, tn);
+}
+
+extern "C" int evc_gemm_nt_split(const evc_bf16* A_lohi, int64_t lda, const evc_bf16* B_hilo, int64_t ldb, float* C, int64_t ldc,
+                                 int M, int N, int K, const float* bias, void* stream) {
+  EVC_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0, EVC_ERR_BAD_SHAPE, "evc_gemm_nt_split: bad shape M=%d N=%d K=%d (K %% 64)", M, N, K);
+  EVC_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= 2L * K && ldb >= 2L * K && ((uintptr_t)A_lohi % 16) == 0 && ((uintptr_t)B_hilo % 16) == 0,
+              EVC_ERR_BAD_ALIGN, "evc_gemm_nt_split: wide operands [2K] per row, 16-byte aligned (lda=%ld ldb=%ld K=%d)", (long)lda, (long)ldb, K);
+  EVC_REQUIRE(ring_operand_ok(M, lda) && ring_operand_ok(N, ldb), EVC_ERR_BAD_SHAPE,
+              "evc_gemm_nt_split: an operand spans 4 GiB or more (M=%d lda=%ld, N=%d ldb=%ld)", M, (long)lda, N, (long)ldb);
+  GemmOperands p;
+  p.A1 = A_lohi; p.lda1 = lda; p.nk1 = 0;             // [lo | hi] against [hi | lo]
+  p.A2 = A_lohi + K; p.lda2 = lda; p.nk2 = 0;         // hi against ...
+  p.B = B_hilo; p.ldb = ldb; p.B2 = B_hilo;           // ... hi (k index restarts)
+  p.group_stride = 0; p.M = M; p.Nu = N;
+  p.A1lo = p.A2lo = p.Blo = nullptr;
+  StoreParams s{C, ldc, M, N, bias, 0, 0, 1, 0};
+  hipStream_t st = (hipStream_t)stream;
+  if (M <= 256) {                                       // batch-row products (MoE head): stream the weights once
+    launch_gemm_seg<TileCfg3<256, 1, 64, 2, 4, 4>>(p, s, K, st);
+  } else {
+    const double c256 = tile_cost((long)ceil_div(M, 256) * ceil_div(N, 256), 256, 256, 1, 1.0);
+    const double c224 = tile_cost((long)ceil_div(M, 224) * ceil_div(N, 256), 224, 256, 1, 1.01);
+    const double c320 = tile_cost((long)ceil_div(M, 320) * ceil_div(N, 256), 320, 256, 1, 1.03);
+    const double c160 = tile_cost((long)ceil_div(M, 160) * ceil_div(N, 128), 160, 128, 1, 1.5);
+    const double c128 = tile_cost((long)ceil_div(M, 128) * ceil_div(N, 128), 128, 128, 2, 1.3);
+    const double best = fmin(fmin(c256, c224), fmin(fmin(c320, c160), c128));
+    if (best == c320) launch_gemm_seg<CfgPlainV2_320>(p, s, K, st);
+    else if (best == c256) launch_gemm_seg<TileCfg3<256, 1, 256, 2, 4, 2>>(p, s, K, st);
+    else if (best == c224) launch_gemm_seg<TileCfg3<224, 1, 256, 2, 4, 2>>(p, s, K, st);
+    else if (best == c160) launch_gemm_seg<TileCfg3<160, 1, 128, 2, 4, 4>>(p, s, K, st);
+    else launch_gemm_seg<TileCfg3<128, 1, 128, 2, 4, 4>>(p, s, K, st);
+  }
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }
@@ -697,7 +747,8 @@ struct LstmFwdParams {
   const int* len; int t;
   float* c_state; float* h_state; long ld_state;
   bf16_t* hout;                      // [M][H] slab t+1 (row-major: next step's A operand)
-  bf16_t* hout_lo;                   // low-order half of h_t (split-bf16 parity mode) or NULL
+  bf16_t* hout_lo;                   // SPLIT: slab t+1 of the WIDE image [M][2H] = [lo(h_t) | hi(h_t)] (next step's split A operand);
+                                     // F16 (hout then holds IEEE f16): the bf16 copy of h_t the backward pass reads; else NULL
   uint2* gates;                      // [M][H] 8-byte records of slab t (or NULL): bf16 {i, j, f, o}
   bf16_t* c_hist;                    // slab t+1 of the bf16 cell-state history [M][H] (c after this step), or NULL
   const int* row_map;                // slot -> row of c_state / h_state (row plan, evc_sort_rows_by_len) or NULL
@@ -706,9 +757,13 @@ struct LstmFwdParams {
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) { return pack_bf16x2_hw(lo, hi); }
 
-template <class Cfg, bool SPLIT = false>
+// F16: the operands (x_t, h_{t-1}, W) are IEEE f16 and ONE v_mfma_f32_16x16x32_f16 product is issued per depth - the cost of
+// the bf16 step with 8x smaller operand rounding; h_t leaves twice, as f16 (next step's / next layer's operand) and as bf16
+// (what the BPTT products contract over).
+template <class Cfg, bool SPLIT = false, bool F16 = false>
 __device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const LstmFwdParams& e, int tiles_m, int tiles_n, int bid) {
   static_assert(Cfg::G == 4, "LSTM step needs the four gate groups");
+  static_assert(!(SPLIT && F16), "split operands are bf16 halves");
   const int nwg = tiles_m * tiles_n;
   const int id = xcd_remap(bid, nwg);
   int tm, tn;
@@ -730,21 +785,10 @@ __device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const 
       }
     }
   }
-  if constexpr (is_v2<Cfg>::value && SPLIT) {
-    // split-bf16 operands on the ring tiles: three passes of the loop over the same accumulators, hi.hi + hi.lo + lo.hi
-    // (the v1 loop stages hi and lo side by side instead; on 64-row tiles, ~3x slower per FLOP than this)
-    run_mainloop<Cfg, 4, true, false, false>(p, m0, u0, acc);
-    GemmOperands q = p;
-    q.B = p.Blo;
-    __syncthreads();                                            // every wave has read the previous pass's last ring slot
-    run_mainloop<Cfg, 4, true, false, false>(q, m0, u0, acc);
-    q = p;
-    q.A1 = p.A1lo; q.A2 = p.A2lo;
-    __syncthreads();
-    run_mainloop<Cfg, 4, true, false, false>(q, m0, u0, acc);
-  } else {
-    run_mainloop<Cfg, 4, true, SPLIT, false, EVC_FWD_LOOP_MODE>(p, m0, u0, acc);   // transposed accumulators: lane = one row, 4 consecutive units
-  }
+  // (SPLIT: the split-bf16 products hi.hi + hi.lo + lo.hi are a K-EXTENSION of the same loop - the caller hands A = [lo | hi] rows
+  //  against B = [W_hi | W_lo] rows as segment 1 and A = hi against B2 = W_hi as segment 2, evc_lstm_layer_fwd_hp - so the loop
+  //  itself is the plain one; only the epilogue differs: it writes h_t's wide [lo | hi] image for the next step.)
+  run_mainloop<Cfg, 4, true, false, false, EVC_FWD_LOOP_MODE | (F16 ? LOOP_F16 : 0)>(p, m0, u0, acc);   // transposed accumulators: lane = one row, 4 consecutive units
 #ifdef EVC_ABLATE_EPI    // debug build: main loop only (keep the accumulators alive, store nothing)
 #pragma unroll
   for (int mi = 0; mi < Cfg::MI; ++mi)
@@ -783,7 +827,12 @@ __device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const 
       const long su = (long)rm[mi] * e.ld_state + u;
       if (e.t >= ln[mi]) {          // dynamic_rnn: state copied through, zero output
         *(uint2*)(e.hout + hu) = make_uint2(0u, 0u);
-        if (SPLIT) *(uint2*)(e.hout_lo + hu) = make_uint2(0u, 0u);
+        if (F16) *(uint2*)(e.hout_lo + hu) = make_uint2(0u, 0u);
+        if (SPLIT) {
+          bf16_t* w = e.hout_lo + (long)m * 2 * H + u;
+          *(uint2*)w = make_uint2(0u, 0u);
+          *(uint2*)(w + H) = make_uint2(0u, 0u);
+        }
         if (e.t == 0) {             // zero-length row: its final state is the zero initial state
           *(float4*)(e.c_state + su) = make_float4(0.f, 0.f, 0.f, 0.f);
           *(float4*)(e.h_state + su) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -817,12 +866,19 @@ __device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const 
       *(float4*)(e.c_state + su) = cnv;               // rows stop updating at t = len: what stays is the returned state
       if (e.c_hist) *(uint2*)(e.c_hist + hu) = make_uint2(pack_bf16x2(cn[0], cn[1]), pack_bf16x2(cn[2], cn[3]));
       if (e.t == ln[mi] - 1) *(float4*)(e.h_state + su) = make_float4(hn[0], hn[1], hn[2], hn[3]);
-      *(uint2*)(e.hout + hu) = make_uint2(pack_bf16x2(hn[0], hn[1]), pack_bf16x2(hn[2], hn[3]));
+      if (F16) {
+        *(uint2*)(e.hout + hu) = make_uint2(pack_f16x2_hw(hn[0], hn[1]), pack_f16x2_hw(hn[2], hn[3]));
+        *(uint2*)(e.hout_lo + hu) = make_uint2(pack_bf16x2(hn[0], hn[1]), pack_bf16x2(hn[2], hn[3]));
+      } else {
+        *(uint2*)(e.hout + hu) = make_uint2(pack_bf16x2(hn[0], hn[1]), pack_bf16x2(hn[2], hn[3]));
+      }
       if (SPLIT) {
         float lo[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) lo[r] = hn[r] - bf16_to_f32(f32_to_bf16(hn[r]));
-        *(uint2*)(e.hout_lo + hu) = make_uint2(pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]));
+        bf16_t* w = e.hout_lo + (long)m * 2 * H + u;
+        *(uint2*)w = make_uint2(pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]));
+        *(uint2*)(w + H) = make_uint2(pack_bf16x2(hn[0], hn[1]), pack_bf16x2(hn[2], hn[3]));
       }
       if (e.gates) {
         uint4* gp = (uint4*)(e.gates + hu);            // 4 units x 8 bytes
@@ -833,9 +889,9 @@ __device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const 
   }
 }
 
-template <class Cfg, bool SPLIT = false>
+template <class Cfg, bool SPLIT = false, bool F16 = false>
 __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, LstmFwdParams e, int tiles_m, int tiles_n) {
-  lstm_fwd_step_body<Cfg, SPLIT>(p, e, tiles_m, tiles_n, blockIdx.x);
+  lstm_fwd_step_body<Cfg, SPLIT, F16>(p, e, tiles_m, tiles_n, blockIdx.x);
 }
 
 // Two independent steps of the same geometry in one launch (the first tiles_m*tiles_n workgroups run step a, the
@@ -874,11 +930,11 @@ typedef TileCfg2<64, 4, 64, 2, 4, 5, true> CfgLstmV2_64;
 typedef TileCfg2<64, 4, 16, 4, 1, 5, true> CfgLstmV2Small;
 typedef TileCfg3<64, 4, 16, 4, 1, 4> CfgLstmV3Small;         // the same tile on 64-wide K stages (64 KB of LDS: still two workgroups per CU)   // 64 rows x 16 units x 4 gates on the ring loop, 4 waves, 40 KB: M ~ batch steps
 
-template <class Cfg, bool SPLIT = false>
+template <class Cfg, bool SPLIT = false, bool F16 = false>
 static inline void launch_lstm_fwd(GemmOperands p, const LstmFwdParams& e, int k1, int k2, hipStream_t st) {
   p.nk1 = k1 / kdiv<Cfg>(); p.nk2 = k2 / kdiv<Cfg>();
   const int tm = ceil_div(e.M, Cfg::BM), tn = ceil_div(e.H, Cfg::BU);
-  launch_cfg<Cfg>(lstm_fwd_step_kernel<Cfg, SPLIT>, tm * tn, st, p, e, tm, tn);
+  launch_cfg<Cfg>(lstm_fwd_step_kernel<Cfg, SPLIT, F16>, tm * tn, st, p, e, tm, tn);
 }
 
 // forward tile for a step over `rows` rows: index into {320, 288, 256, 224, 192, 160 (v2), 128 (v1), 64 (v1), 128 (v2), 64 (v2)}
@@ -904,7 +960,7 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
                                evc_bf16* hbuf, float* c_state, float* h_state, int64_t ld_state,
                                void* gates, evc_bf16* c_all,
                                const evc_bf16* x_lo, const evc_bf16* wT_lo, evc_bf16* hbuf_lo,
-                               const int32_t* row_map, const int32_t* rows_per_step, void* stream);
+                               const int32_t* row_map, const int32_t* rows_per_step, void* stream, int f16 = 0);
 
 extern "C" int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const float* bias, const int32_t* len,
                                   int T, int M, int Kin, int H, int hoist, float* zx_ws,
@@ -915,14 +971,14 @@ extern "C" int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const f
                              nullptr, nullptr, nullptr, row_map, rows_per_step, stream);
 }
 
-extern "C" int evc_lstm_layer_fwd_hp(const evc_bf16* x, const evc_bf16* x_lo, const evc_bf16* wT, const evc_bf16* wT_lo,
-                                     const float* bias, const int32_t* len, int T, int M, int Kin, int H,
-                                     evc_bf16* hbuf, evc_bf16* hbuf_lo, float* c_state, float* h_state, int64_t ld_state,
-                                     void* gates, evc_bf16* c_all, const int32_t* row_map, const int32_t* rows_per_step,
-                                     void* stream) {
-  EVC_REQUIRE(x_lo && wT_lo && hbuf_lo, EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd_hp: the low-order halves are required");
-  return lstm_layer_fwd_impl(x, wT, bias, len, T, M, Kin, H, 0, nullptr, hbuf, c_state, h_state, ld_state, gates, c_all,
-                             x_lo, wT_lo, hbuf_lo, row_map, rows_per_step, stream);
+extern "C" int evc_lstm_layer_fwd_f16(const evc_f16* x, const evc_f16* wT, const float* bias, const int32_t* len,
+                                      int T, int M, int Kin, int H, evc_f16* hbuf, evc_bf16* hbuf_bf16,
+                                      float* c_state, float* h_state, int64_t ld_state, void* gates, evc_bf16* c_all,
+                                      const int32_t* row_map, const int32_t* rows_per_step, void* stream) {
+  EVC_REQUIRE(hbuf_bf16, EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd_f16: hbuf_bf16 (the bf16 copy of h for the backward pass) is required");
+  EVC_REQUIRE(((uintptr_t)hbuf_bf16 % 8) == 0, EVC_ERR_BAD_ALIGN, "evc_lstm_layer_fwd_f16: hbuf_bf16 must be 8-byte aligned");
+  return lstm_layer_fwd_impl((const evc_bf16*)x, (const evc_bf16*)wT, bias, len, T, M, Kin, H, 0, nullptr, (evc_bf16*)hbuf, c_state, h_state,
+                             ld_state, gates, c_all, nullptr, nullptr, hbuf_bf16, row_map, rows_per_step, stream, 1);
 }
 
 static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const float* bias, const int32_t* len,
@@ -930,8 +986,11 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
                                evc_bf16* hbuf, float* c_state, float* h_state, int64_t ld_state,
                                void* gates, evc_bf16* c_all,
                                const evc_bf16* x_lo, const evc_bf16* wT_lo, evc_bf16* hbuf_lo,
-                               const int32_t* row_map, const int32_t* rows_per_step, void* stream) {
-  const bool split = x_lo != nullptr;
+                               const int32_t* row_map, const int32_t* rows_per_step, void* stream, int f16) {
+  // f16: x, wT, hbuf hold IEEE f16 (16-bit containers of the same shapes), hbuf_lo receives the bf16 copy of every h_t
+  // (x_lo / wT_lo: unused - the split-bf16 form of a layer is evc_lstm_layer_fwd_hp below)
+  const bool split = false;
+  (void)x_lo; (void)wT_lo;
   EVC_REQUIRE(T > 0 && M > 0 && H > 0 && Kin > 0, EVC_ERR_BAD_SHAPE, "evc_lstm_layer_fwd: bad shape");
   EVC_REQUIRE(Kin % 64 == 0 && H % 64 == 0, EVC_ERR_BAD_SHAPE,
               "evc_lstm_layer_fwd: Kin=%d and H=%d must be multiples of 64", Kin, H);
@@ -952,7 +1011,7 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
   // h_{-1} = 0 (the state buffers need no clearing: step 0 treats c_old as 0 and writes the zero
   // state of the zero-length rows it covers itself; rows beyond rows_per_step[0] are the caller's)
   EVC_CHECK_HIP(hipMemsetAsync(hbuf, 0, (size_t)M * H * sizeof(bf16_t), st));
-  if (split) EVC_CHECK_HIP(hipMemsetAsync(hbuf_lo, 0, (size_t)M * H * sizeof(bf16_t), st));
+  if (split || f16) EVC_CHECK_HIP(hipMemsetAsync(hbuf_lo, 0, (size_t)M * H * sizeof(bf16_t), st));
   if (hoist) {
     int rc = evc_gemm_nt(x, Kin, wT, ldw, zx_ws, 4L * H, T * M, 4 * H, Kin, nullptr, 0, 0, stream);
     if (rc) return rc;
@@ -972,27 +1031,29 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
       p.A1 = x + (long)t * M * Kin; p.lda1 = Kin; k1 = Kin;
       p.A2 = hprev; p.lda2 = H; k2 = (t == 0) ? 0 : H;
       p.B = wT;
-      if (split) { p.A1lo = x_lo + (long)t * M * Kin; p.A2lo = hbuf_lo + (long)t * M * H; p.Blo = wT_lo; }
     }
     LstmFwdParams e;
     e.zx = hoist ? zx_ws + (long)t * M * 4 * H : nullptr; e.ldzx = 4L * H;
     e.bias = bias; e.len = len; e.t = t;
     e.c_state = c_state; e.h_state = h_state; e.ld_state = ld_state;
     e.hout = hbuf + (long)(t + 1) * M * H;
-    e.hout_lo = split ? hbuf_lo + (long)(t + 1) * M * H : nullptr;
+    e.hout_lo = (split || f16) ? hbuf_lo + (long)(t + 1) * M * H : nullptr;
     e.gates = gates ? (uint2*)gates + (long)t * M * H : nullptr;
     e.c_hist = c_all ? c_all + (long)(t + 1) * M * H : nullptr;      // slab t+1 = c after step t
     e.row_map = row_map;
     e.M = Mt; e.H = H;
-    if (split) {      // parity mode, 3 MFMA products per tile: ring tiles (three passes of the loop) for the big steps, v1 64-row tiles below
-      if (Mt >= 1024 && forced_tile() == 0) {
-        switch (pick_fwd_tile(Mt, H)) {
-          case 0: launch_lstm_fwd<CfgLstmV2a, true>(p, e, k1, k2, st); break;
-          case 3: launch_lstm_fwd<CfgLstmV3_224, true>(p, e, k1, k2, st); break;
-          default: launch_lstm_fwd<CfgLstmV3_256, true>(p, e, k1, k2, st); break;
-        }
-      } else {      // (128-row ring tiles for the student's ~900 live rows: measured no faster than the 64-row v1 tiles)
-        launch_lstm_fwd<CfgLstmSmall, true>(p, e, k1, k2, st);
+    if (f16) {        // IEEE f16 operands, one MFMA product per depth: the tiles of the bf16 step
+      switch (pick_fwd_tile(Mt, H)) {
+        case 0: launch_lstm_fwd<CfgLstmV2a, false, true>(p, e, k1, k2, st); break;
+        case 1: launch_lstm_fwd<CfgLstmV2_288, false, true>(p, e, k1, k2, st); break;
+        case 2: launch_lstm_fwd<CfgLstmV3_256, false, true>(p, e, k1, k2, st); break;
+        case 3: launch_lstm_fwd<CfgLstmV3_224, false, true>(p, e, k1, k2, st); break;
+        case 4: launch_lstm_fwd<CfgLstmV3_192, false, true>(p, e, k1, k2, st); break;
+        case 5: launch_lstm_fwd<CfgLstmV3_160, false, true>(p, e, k1, k2, st); break;
+        case 6: launch_lstm_fwd<CfgLstmBig, false, true>(p, e, k1, k2, st); break;
+        case 8: launch_lstm_fwd<CfgLstmV2_128, false, true>(p, e, k1, k2, st); break;
+        case 9: launch_lstm_fwd<CfgLstmV2_64, false, true>(p, e, k1, k2, st); break;
+        default: launch_lstm_fwd<CfgLstmSmall, false, true>(p, e, k1, k2, st); break;
       }
       continue;
     }
@@ -1009,6 +1070,54 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
       case 9: launch_lstm_fwd<CfgLstmV2_64>(p, e, k1, k2, st); break;
       default: launch_lstm_fwd<CfgLstmSmall>(p, e, k1, k2, st); break;
     }
+  }
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// "High" precision layer for the M ~ batch stacks (the L2 level): split-bf16 operands, f32-operand accuracy, as K-extensions of
+// the plain loops (see evc_gemm_nt_split).  x-projection of all T steps hoisted into one split product; step t contracts
+// [lo(h) | hi(h)] . [Wh_hi | Wh_lo]^T + hi(h) . Wh_hi^T (K = 3H) and writes h_t three times: hbuf (plain bf16 = the hi half, what
+// the backward products read) and the wide image hbuf_lohi for the next step / the next layer's x-projection.
+extern "C" int evc_lstm_layer_fwd_hp(const evc_bf16* x_lohi, const evc_bf16* wx_hilo, int64_t ldwx, const evc_bf16* wh_hilo, int64_t ldwh,
+                                     const float* bias, const int32_t* len, int T, int M, int Kin, int H, float* zx_ws,
+                                     evc_bf16* hbuf, evc_bf16* hbuf_lohi, float* c_state, float* h_state, int64_t ld_state,
+                                     void* gates, evc_bf16* c_all, void* stream) {
+  EVC_REQUIRE(T > 0 && M > 0 && H > 0 && Kin > 0 && Kin % 64 == 0 && H % 64 == 0, EVC_ERR_BAD_SHAPE,
+              "evc_lstm_layer_fwd_hp: bad shape T=%d M=%d Kin=%d H=%d (Kin, H multiples of 64)", T, M, Kin, H);
+  EVC_REQUIRE(x_lohi && wx_hilo && wh_hilo && zx_ws && hbuf && hbuf_lohi, EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd_hp: NULL operand");
+  EVC_REQUIRE(ldwx >= 2L * Kin && ldwh >= 2L * H && ldwx % 8 == 0 && ldwh % 8 == 0 && ((uintptr_t)wh_hilo % 16) == 0, EVC_ERR_BAD_ALIGN,
+              "evc_lstm_layer_fwd_hp: weight images are [4H][2Kin] / [4H][2H] (ldwx=%ld ldwh=%ld)", (long)ldwx, (long)ldwh);
+  EVC_REQUIRE(ring_operand_ok(M, 2L * H) && ring_operand_ok(4L * H, ldwh), EVC_ERR_BAD_SHAPE, "evc_lstm_layer_fwd_hp: operand spans 4 GiB or more");
+  EVC_REQUIRE(ld_state % 4 == 0 && ((uintptr_t)c_state % 16) == 0 && ((uintptr_t)h_state % 16) == 0 && ((uintptr_t)bias % 16) == 0 &&
+              ((uintptr_t)hbuf % 8) == 0 && ((uintptr_t)hbuf_lohi % 16) == 0, EVC_ERR_BAD_ALIGN,
+              "evc_lstm_layer_fwd_hp: state/bias/hbuf must allow 16-byte vector access");
+  EVC_REQUIRE((gates == nullptr) == (c_all == nullptr), EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd_hp: gates and c_all go together");
+  hipStream_t st = (hipStream_t)stream;
+  EVC_CHECK_HIP(hipMemsetAsync(hbuf, 0, (size_t)M * H * sizeof(bf16_t), st));               // h_{-1} = 0
+  EVC_CHECK_HIP(hipMemsetAsync(hbuf_lohi, 0, (size_t)M * 2 * H * sizeof(bf16_t), st));
+  int rc = evc_gemm_nt_split(x_lohi, 2L * Kin, wx_hilo, ldwx, zx_ws, 4L * H, T * M, 4 * H, Kin, nullptr, stream);
+  if (rc) return rc;
+  for (int t = 0; t < T; ++t) {
+    GemmOperands p;
+    p.M = M; p.Nu = H; p.group_stride = H; p.ldb = ldwh; p.nk1 = p.nk2 = 0;
+    p.A1lo = p.A2lo = p.Blo = nullptr;
+    const bf16_t* hw = hbuf_lohi + (long)t * M * 2 * H;
+    p.A1 = hw; p.lda1 = 2L * H; p.A2 = hw + H; p.lda2 = 2L * H;
+    p.B = wh_hilo; p.B2 = wh_hilo;
+    const int k1 = (t == 0) ? 0 : 2 * H, k2 = (t == 0) ? 0 : H;
+    LstmFwdParams e;
+    e.zx = zx_ws + (long)t * M * 4 * H; e.ldzx = 4L * H;
+    e.bias = bias; e.len = len; e.t = t;
+    e.c_state = c_state; e.h_state = h_state; e.ld_state = ld_state;
+    e.hout = hbuf + (long)(t + 1) * M * H;
+    e.hout_lo = hbuf_lohi + (long)(t + 1) * M * 2 * H;
+    e.gates = gates ? (uint2*)gates + (long)t * M * H : nullptr;
+    e.c_hist = c_all ? c_all + (long)(t + 1) * M * H : nullptr;
+    e.row_map = nullptr;
+    e.M = M; e.H = H;
+    if (M >= 1024) launch_lstm_fwd<CfgLstmV3_256, true>(p, e, k1, k2, st);
+    else launch_lstm_fwd<CfgLstmV3Small, true>(p, e, k1, k2, st);
   }
   EVC_LAUNCH_CHECK();
   return EVC_OK;

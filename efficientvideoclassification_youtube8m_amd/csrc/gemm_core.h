@@ -89,9 +89,11 @@ __device__ __forceinline__ int patch_rows(int nwg, int tiles_n) {
 // SPLIT = true also stages the low-order halves (LDS image [A_hi | B_hi | A_lo | B_lo] per stage) and
 // issues hi.hi + hi.lo + lo.hi per tile: f32-operand accuracy at 3x the MFMA work (parity mode).
 // INIT = false: the caller has pre-loaded the accumulators (e.g. with a bias) - the loop only adds to them.
-template <class Cfg, bool SWAP = false, bool SPLIT = false, bool INIT = true>
+// F16 = true: the operands are IEEE f16 (one v_mfma_f32_16x16x32_f16 per depth; not with SPLIT).
+template <class Cfg, bool SWAP = false, bool SPLIT = false, bool INIT = true, bool F16 = false>
 __device__ __forceinline__ void gemm_mainloop(const GemmOperands& p, const int m0, const int u0, char* lds,
                                               f32x4 (&acc)[Cfg::MI][Cfg::G][Cfg::NI]) {
+  static_assert(!(SPLIT && F16), "split operands are bf16 halves");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -242,8 +244,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmOperands& p, const int m
         for (int g = 0; g < Cfg::G; ++g)
 #pragma unroll
           for (int ni = 0; ni < Cfg::NI; ++ni)
-            acc[mi][g][ni] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[g][ni], af[mi], acc[mi][g][ni], 0, 0, 0)
-                                  : __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[g][ni], acc[mi][g][ni], 0, 0, 0);
+            acc[mi][g][ni] = SWAP ? mfma16<F16>(bfr[g][ni], af[mi], acc[mi][g][ni]) : mfma16<F16>(af[mi], bfr[g][ni], acc[mi][g][ni]);
     }
     __syncthreads();
     cur ^= 1;

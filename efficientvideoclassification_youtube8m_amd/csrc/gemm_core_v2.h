@@ -27,7 +27,8 @@
 //                  each; their SIMD partners run nothing but fragment reads and MFMAs (two copies of the loop, chosen once)
 //  LOOP_DMA_FIRST  the scheduler is asked to place the LDS-DMA ahead of the fragment reads among the MFMAs of a K step
 //  LOOP_NO_PRIO    no s_setprio 1 / 0 around every K step's MFMA cluster
-constexpr int LOOP_PRODUCER = 1, LOOP_DMA_FIRST = 2, LOOP_NO_PRIO = 4;
+//  LOOP_F16       the operands are IEEE f16: v_mfma_f32_16x16x32_f16 instead of _bf16 (staging and LDS image are the same)
+constexpr int LOOP_PRODUCER = 1, LOOP_DMA_FIRST = 2, LOOP_NO_PRIO = 4, LOOP_F16 = 8;
 #ifndef EVC_LOOP_MODE_DEFAULT
 #define EVC_LOOP_MODE_DEFAULT 0
 #endif
@@ -173,8 +174,8 @@ __device__ __forceinline__ void gemm_mainloop_v2(const GemmOperands& p, const in
       for (int g = 0; g < Cfg::G; ++g)
 #pragma unroll
         for (int ni = 0; ni < Cfg::NI; ++ni)
-          acc[mi][g][ni] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[g][ni], af[mi], acc[mi][g][ni], 0, 0, 0)
-                                : __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[g][ni], acc[mi][g][ni], 0, 0, 0);
+          acc[mi][g][ni] = SWAP ? mfma16<(MODE & LOOP_F16) != 0>(bfr[g][ni], af[mi], acc[mi][g][ni])
+                                : mfma16<(MODE & LOOP_F16) != 0>(af[mi], bfr[g][ni], acc[mi][g][ni]);
   };
   auto end_of_step = [&]() {
     // The next step's fragment reads were issued BEFORE these MFMAs and have landed long before

@@ -141,8 +141,8 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
       for (int g = 0; g < Cfg::G; ++g)
 #pragma unroll
         for (int ni = 0; ni < Cfg::NI; ++ni)
-          acc[mi][g][ni] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[g][ni], af[mi], acc[mi][g][ni], 0, 0, 0)
-                                : __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr[g][ni], acc[mi][g][ni], 0, 0, 0);
+          acc[mi][g][ni] = SWAP ? mfma16<(MODE & LOOP_F16) != 0>(bfr[g][ni], af[mi], acc[mi][g][ni])
+                                : mfma16<(MODE & LOOP_F16) != 0>(af[mi], bfr[g][ni], acc[mi][g][ni]);
   };
   auto end_of_step = [&]() {          // see gemm_core_v2.h: retire the LDS reads explicitly, nothing loop-carried for hipcc
     __builtin_amdgcn_sched_barrier(0);

@@ -85,9 +85,29 @@ class GradReducer:
       ranks), never two at once; compute on the other streams still overlaps them."""
 
     _serial_stream = None           # one per process
+    # Accounting for bench.py's N > 1 line (class-wide: every reducer of the process adds to it):
+    #   stats[kind] = [collectives issued, payload bytes handed to them]     (always on: two integer adds per call)
+    #   timing = None | list of (kind, bytes, start event, end event) recorded on the stream the collective runs on
+    stats = {}
+    timing = None
 
-    def __init__(self, process_group=None):
+    @staticmethod
+    def wire_bytes(kind, payload, world):
+        """Bytes one rank sends (= receives) for a ring collective over `world` ranks: all-reduce 2 (w-1)/w of the payload,
+        all-gather (w-1) times its own part (payload = the part this rank contributes)."""
+        if world <= 1:
+            return 0.0
+        return 2.0 * (world - 1) / world * payload if kind.startswith("all_reduce") else float(world - 1) * payload
+
+    def __init__(self, process_group=None, grad_dtype=None):
         self.pg = process_group
+        # gradient all-reduce payload type for the LSTM segments: "f32" (default) or "bf16" (EVC_DP_GRAD_DTYPE=bf16): half the
+        # bytes on xGMI - for configurations whose step is shorter than their f32 all-reduce (cfg 5: 4.4 ms step, 187 MB per
+        # tower) - at one bf16 rounding of each rank's gradient (2^-9 relative; the sum itself runs in RCCL's bf16 arithmetic)
+        self.grad_dtype = grad_dtype or os.environ.get("EVC_DP_GRAD_DTYPE", "f32")
+        if self.grad_dtype not in ("f32", "bf16"):
+            raise ValueError("EVC_DP_GRAD_DTYPE / grad_dtype must be f32 or bf16, not %r" % self.grad_dtype)
+        self._bf16_ws = None
         self.world = 1
         init = torch.distributed.is_available() and torch.distributed.is_initialized()
         self.rank = 0
@@ -100,8 +120,21 @@ class GradReducer:
         self.serial = self.active and serial_comm() and torch.cuda.is_available()
         self._pending = []
 
-    def _run(self, fn, *tensors):
+    def _run(self, fn, *tensors, kind="collective", nbytes=0):
         """Issue one collective: in stream order on the current stream, or through the process-wide serial stream."""
+        st = GradReducer.stats.setdefault(kind, [0, 0])
+        st[0] += 1
+        st[1] += int(nbytes)
+        if GradReducer.timing is not None and torch.cuda.is_available():
+            inner = fn
+
+            def fn():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = inner()
+                e1.record()
+                GradReducer.timing.append((kind, int(nbytes), e0, e1))
+                return out
         if not self.serial:
             return fn()
         cur = torch.cuda.current_stream()
@@ -135,7 +168,28 @@ class GradReducer:
         if not self.active or hi <= lo:
             return None
         seg = flat[lo:hi]
-        self._run(lambda: torch.distributed.all_reduce(seg, op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=False), seg)
+        if self.grad_dtype == "bf16":
+            return self._reduce_bf16(seg)
+        self._run(lambda: torch.distributed.all_reduce(seg, op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=False), seg,
+                  kind="all_reduce_grad_f32", nbytes=seg.numel() * 4)
+        return None
+
+    def _reduce_bf16(self, seg):
+        """seg (f32) <- SUM over the ranks of bf16(seg): the payload crosses the fabric as bf16.  (gloo has no bfloat16: the CPU
+        tests reduce the bf16-rounded values in f32 - the same per-rank rounding, an exact sum.)"""
+        n = seg.numel()
+        if self._bf16_ws is None or self._bf16_ws.numel() < n or self._bf16_ws.device != seg.device:
+            self._bf16_ws = torch.empty(n, dtype=torch.bfloat16, device=seg.device)
+        ws = self._bf16_ws[:n]
+        ws.copy_(seg)
+        if torch.distributed.get_backend(self.pg) == "gloo":
+            seg.copy_(ws)
+            self._run(lambda: torch.distributed.all_reduce(seg, op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=False), seg,
+                      kind="all_reduce_grad_bf16", nbytes=n * 2)
+            return None
+        self._run(lambda: torch.distributed.all_reduce(ws, op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=False), ws,
+                  kind="all_reduce_grad_bf16", nbytes=n * 2)
+        seg.copy_(ws)
         return None
 
     def all_gather_rows(self, t):
@@ -149,12 +203,13 @@ class GradReducer:
             out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
             torch.distributed.all_gather_into_tensor(out.view(torch.uint8), t.view(torch.uint8), group=self.pg)
             return out
-        return self._run(go, t)
+        return self._run(go, t, kind="all_gather_factors", nbytes=t.numel() * t.element_size())
 
     def all_reduce_small(self, t):
         """In-place SUM of a few floats (the partial norm sums of a sharded tensor), stream-ordered."""
         if self.active:
-            self._run(lambda: torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=False), t)
+            self._run(lambda: torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=False), t,
+                      kind="all_reduce_small", nbytes=t.numel() * t.element_size())
 
     def all_gather_slabs(self, full, slab_rows):
         """full [world * slab_rows, cols] (contiguous): rank r owns rows [r*slab_rows, (r+1)*slab_rows); every
@@ -167,7 +222,7 @@ class GradReducer:
             own = full[self.rank * slab_rows:(self.rank + 1) * slab_rows].clone()     # (24 MB at world 8: no aliasing of in / out)
             torch.distributed.all_gather_into_tensor(full.view(torch.uint8), own.view(torch.uint8), group=self.pg)
             return own
-        self._run(go, full)
+        self._run(go, full, kind="all_gather_slabs", nbytes=slab_rows * full.shape[1] * full.element_size())
 
     def wait(self):
         for w in self._pending:
@@ -178,6 +233,15 @@ class GradReducer:
 def serial_comm():
     """EVC_DP_SERIAL_COMM=1: one communicator, one collective at a time (see GradReducer)."""
     return os.environ.get("EVC_DP_SERIAL_COMM") == "1"
+
+
+def dp_timeout():
+    """Process-group timeout for init_process_group (bench.py, train.py): a collective that has not completed after this long
+    makes the watchdog abort the process - a wedged first contact with the fabric ends non-zero in minutes instead of sitting in
+    the launcher's window (c10d's default is 10 minutes).  EVC_DP_TIMEOUT_S, default 120 s; the longest legitimate wait is a
+    peer's checkpoint write or its first-step allocations."""
+    import datetime
+    return datetime.timedelta(seconds=float(os.environ.get("EVC_DP_TIMEOUT_S", "120")))
 
 
 def frame_counts_and_plans(g, num_frames, nh, need_teacher, need_student):
@@ -246,16 +310,17 @@ class DistillGraph:
             for tw, red in ((self.teacher, self.reducer), (self.student, self.reducer_s)):
                 if tw is not None:
                     tw.moe.shard(red.world, red.rank)
-        self.precision = precision       # "high": split-bf16 operands in every forward GEMM (parity mode, ~3x fwd MFMA work)
-        if precision == "high":
+        self.precision = precision       # engine.TowerBase.precision: "bf16" | "high" (1e-3 at trained magnitudes) | "split" (uniform)
+        if precision != "bf16":
             for tw in (self.teacher, self.student):
                 if tw is not None:
-                    tw.set_precision("high")
+                    tw.set_precision(precision)
         self.losses = torch.zeros(8, dtype=F32, device=self.device)
         self._losses_reduced = torch.zeros(8, dtype=F32, device=self.device)   # data parallel: SUM over the ranks, per step
         self._dp_t = self._dp_s = self._ds_s = None
         self.overlap_towers = overlap_towers
-        self.row_plans = True        # sort the L1 chunk rows by length and skip the padding rows (ops.RowPlan)
+        self.row_plans = precision != "split"   # sort the L1 chunk rows by length and skip the padding rows (ops.RowPlan);
+        # (the uniform split-bf16 layers run on every row)
         # True: the student's forward starts next to the teacher's forward instead of after it.  Measured 0.1 ms/step
         # faster, but the teacher's fused forward steps then share the chip (67 -> 84 us per launch): off by default so
         # that the step's dominant kernel runs - and is measured - alone.
@@ -332,7 +397,8 @@ class DistillGraph:
         tp, sp = frame_counts_and_plans(self, num_frames, nh, self.teacher is not None, need_student)
         xt, xs = ops.l2norm_chunk(x_raw, self.C1, self.every_n if need_student else None, self.C2,
                                   num_frames=num_frames if x_raw.dtype == torch.uint8 else None,
-                                  split=self.precision == "high", plan1=tp[2] if tp else None, plan2=sp[3] if sp else None)
+                                  split=(self.teacher or self.student).input_split(), plan1=tp[2] if tp else None,
+                                  plan2=sp[3] if sp else None, f16_segments=HLstmTower.f16_x_segments)
         self.losses.zero_()
         out = {}
         mark = self._mark
@@ -507,14 +573,14 @@ class EvalGraph:
         self.student = HLstmTower(batch_size, self.S, num_inputs_l1_student, feature_size, vocab_size, lstm_cells,
                                   lstm_layers, num_mixtures, device, False, "model_student", 8)
         self.precision = precision
-        if precision == "high":
+        if precision != "bf16":
             for tw in (self.teacher, self.student):
                 if tw is not None:
-                    tw.set_precision("high")
+                    tw.set_precision(precision)
         self.losses = torch.zeros(4, dtype=F32, device=self.device)
         self._main, self._side = concurrent_streams(self.device, 4)[:2]
         self._ev_in, self._ev_out = torch.cuda.Event(), torch.cuda.Event()
-        self.row_plans = True
+        self.row_plans = precision != "split"
 
     def restore(self, state_dict):
         """saver_teacher / saver_student .restore (cs/validate.py:350-384): the 11 variables of each tower by name."""
@@ -539,11 +605,11 @@ class EvalGraph:
         """Returns predictions (student), student_label_loss, student_state_loss (teacher_student only) - the
         tensors cs/validate.py:240 fetches.  The two towers are independent: they run on two streams."""
         main = torch.cuda.current_stream(self.device)
-        split = self.precision == "high"
+        split = self.student.input_split()
         u8 = x_raw.dtype == torch.uint8
         tp, sp = frame_counts_and_plans(self, num_frames, nh, self.teacher is not None, True)
         xt, xs = ops.l2norm_chunk(x_raw, self.C1, self.every_n, self.C2, num_frames=num_frames if u8 else None, split=split,
-                                  plan1=tp[2] if tp else None, plan2=sp[3])
+                                  plan1=tp[2] if tp else None, plan2=sp[3], f16_segments=HLstmTower.f16_x_segments)
         self.losses.zero_()
         out = {}
         self._ev_in.record(main)

@@ -142,24 +142,53 @@ class LstmStack:
         gates = [self._v(g, T, M, H, 2) for g in self.gates] if self.training else [None] * L
         c_all = [self._v(c, T + 1, M, H) for c in self.c_all] if self.training else [None] * L
         self._hb = hb
-        if isinstance(x, tuple):        # split-bf16 parity mode: hi.hi + hi.lo + lo.hi in every step
-            x_hi, x_lo = x
-            self.x_in, self.lens = x_hi, lens
-            if not hasattr(self, "hbuf_lo"):
-                self.hbuf_lo = [torch.zeros_like(h) for h in self.hbuf]
-            hl = [self._v(h, T + 1, M, H) for h in self.hbuf_lo]
-            inp, inp_lo = x_hi, x_lo
+        rows = plan.rows if plan is not None else [M] * T
+        if isinstance(x, tuple) and x[1].dtype == ops.F16:
+            # "high" precision, many-row (L1) stacks: IEEE f16 operands, ONE MFMA product per depth - the cost of the bf16 step
+            # at 2^-12 operand rounding (scripts/precision_budget.py: L1 states within ~3e-5 of float64 at trained magnitudes).
+            # x = (bf16 image, f16 image): the bf16 one and the bf16 copies of h stay the operands of the backward products.
+            x_bf, x16 = x
+            self.x_in, self.lens = x_bf, lens
+            if not hasattr(self, "hbuf16"):
+                self.hbuf16 = [torch.zeros(h.shape, dtype=ops.F16, device=h.device) for h in self.hbuf]
+            h16 = [self._v(h, T + 1, M, H) for h in self.hbuf16]
+            inp = x16
             for l in range(L):
                 kn, bn = self.names(l)
-                ops.lstm_layer_fwd_hp(inp, inp_lo, tw.shadow_fwd[kn], tw.shadow_lo[kn], tw.store.p(bn), lens, T, M,
-                                      self.kin[l], H, hb[l], hl[l],
-                                      self.S[:, (2 * l) * H:], self.S[:, (2 * l + 1) * H:], 2 * L * H,
-                                      gates[l], c_all[l], plan=plan)
-                inp, inp_lo = hb[l][1:], hl[l][1:]
+                if self.timing is not None:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                kx = inp.shape[-1]          # layer 0: nseg*F (K-extended x-part, tower.f16_x_segments), above: H
+                assert tw.shadow16[kn].shape[1] == kx + H
+                ops.lstm_layer_fwd_f16(inp, tw.shadow16[kn], tw.store.p(bn), lens, T, M, kx, H, h16[l], hb[l],
+                                       self.S[:, (2 * l) * H:], self.S[:, (2 * l + 1) * H:], 2 * L * H,
+                                       gates[l], c_all[l], plan=plan)
+                if self.timing is not None:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()
+                    flops = sum(2.0 * r * 4 * H * (self.kin[l] + (H if t > 0 else 0)) for t, r in enumerate(rows))
+                    self.timing.append((e0, e1, sum(1 for r in rows if r > 0), flops))
+                inp = h16[l][1:]
+            return self.S
+        if isinstance(x, tuple):        # split-bf16 operands, K-extended loops (the M ~ batch L2 stacks of the "high" mode)
+            x_bf, x_w = x               # plain bf16 image (backward operand) and the wide [lo | hi] image [T][M][2Kin]
+            assert plan is None, "the split-bf16 layers take no row plan (M ~ batch stacks)"
+            self.x_in, self.lens = x_bf, lens
+            if not hasattr(self, "hbuf_w"):
+                self.hbuf_w = [torch.zeros((self.T + 1, self.M, 2 * H), dtype=BF16, device=h.device) for h in self.hbuf]
+            if self.zx is None:
+                self.zx = torch.empty((self.T * self.M, 4 * H), dtype=F32, device=self.S.device)
+            hw = [self._v(h, T + 1, M, 2 * H) for h in self.hbuf_w]
+            inp = x_w
+            for l in range(L):
+                kn, bn = self.names(l)
+                ops.lstm_layer_fwd_hp(inp, tw.shadow_wx[kn], tw.shadow_wh[kn], tw.store.p(bn), lens, T, M, self.kin[l], H,
+                                      self.zx, hb[l], hw[l], self.S[:, (2 * l) * H:], self.S[:, (2 * l + 1) * H:], 2 * L * H,
+                                      gates[l], c_all[l])
+                inp = hw[l][1:]
             return self.S
         self.x_in, self.lens = x, lens
         inp = x
-        rows = plan.rows if plan is not None else [M] * T
         if (L == 2 and plan is None and all(self.hoist) and self.wavefront and self.timing is None
                 and self.Kin % 64 == 0 and H % 64 == 0):
             # M ~ batch: layer 0 step t+1 and layer 1 step t share a launch (T+1 dependent launches instead of 2T)
@@ -369,7 +398,17 @@ class MoeHead:
 
     def forward(self, x):
         tw, B, V, Mx, K = self.tw, self.B, self.V, self.Mx, self.K
-        if getattr(tw, "precision", "bf16") == "high":
+        if getattr(tw, "precision", "bf16") != "bf16" and hasattr(tw, "shadow_w"):
+            # split-bf16 operands, one K-extended launch per product (ops.gemm_nt_split_wide)
+            if not hasattr(self, "x_w") or self.x_w.shape[0] != B:
+                self.x_w = torch.empty((B, 2 * K), dtype=BF16, device=x.device)
+            ops.cast_bf16(x, self.x_bf)                                 # the backward / fused-update factor
+            ops.cast_bf16_wide(x, self.x_w, lo_first=True)
+            ops.gemm_nt_split_wide(self.x_w, tw.shadow_w[self.GATES], B, V * (Mx + 1), K, self.gate_logits)
+            ops.gemm_nt_split_wide(self.x_w, tw.shadow_w[self.EXPERTS], B, V * Mx, K, self.expert_logits, bias=tw.store.p(self.EBIAS))
+            ops.moe_tail_fwd(self.gate_logits, self.expert_logits, B, V, Mx, self.pred, self.rowsum)
+            return self.pred
+        if getattr(tw, "precision", "bf16") != "bf16":                 # towers that keep separate hi / lo shadows (DBoF, logistic)
             if not hasattr(self, "x_lo") or self.x_lo.shape != self.x_bf.shape:
                 self.x_lo = torch.empty_like(self.x_bf)
             ops.cast_bf16_split(x, self.x_bf, self.x_lo)
@@ -476,6 +515,9 @@ class MoeHead:
             sb = tw.shadow_bwd[name]
             ops.transpose_to_bf16(tw.shadow_fwd[name], Vn, K, sb, sb.shape[1])
             self._stale = dp.world > 1
+        if tw.precision != "bf16":           # (single process only, see HLstmTower.backward) the update wrote the hi halves
+            for name in (self.GATES, self.EXPERTS):
+                tw._refresh_high(name)
         gb = st.g(self.EBIAS)
         ops.colsum_bf16(del_, rows, V * Mx, gb)
         ops.grad_sqnorm(gb, None, 0.0, tw.sums[idx[self.EBIAS]])
@@ -522,20 +564,39 @@ class TowerBase:
         self.adam_t = 0
         self.sums = torch.zeros((len(self.names), 2), dtype=F32, device=self.device)
 
-    precision = "bf16"     # "high": split-bf16 (hi+lo operands, 3 MFMA products) in the forward GEMMs
+    # "bf16": one bf16 MFMA product per contraction.  "high": the forward GEMMs hold north_star's 1e-3 on trained-magnitude
+    # weights - per-product operand formats chosen by the measured error budget.  "split": split-bf16 operands
+    # (f32-operand accuracy, 3 products) in EVERY forward GEMM - the uniform parity mode, for towers without a budgeted
+    # layout "high" means the same.
+    precision = "bf16"
+    PRECISIONS = ("bf16", "high", "split")
 
     def set_precision(self, precision):
-        assert precision in ("bf16", "high")
+        if precision not in self.PRECISIONS:
+            raise ValueError("%s: precision %r is not one of %s" % (type(self).__name__, precision, self.PRECISIONS))
+        if getattr(self, "_high_alloc", None) not in (None, precision) and precision != "bf16":
+            raise ValueError("the operand shadows of this tower were laid out for precision %r" % self._high_alloc)
         self.precision = precision
-        if precision == "high" and not hasattr(self, "shadow_lo"):
-            self.shadow_lo = {k: torch.zeros_like(v) for k, v in self.shadow_fwd.items()}
+        if precision != "bf16" and not hasattr(self, "shadow_lo"):
+            self._high_alloc = precision
+            self._alloc_high_shadows()
         self.refresh_shadows()
+
+    def _alloc_high_shadows(self):
+        """Default: every 2-D weight gets a separate low-order bf16 shadow (hi.hi + hi.lo + lo.hi as three products)."""
+        self.shadow_lo = {k: torch.zeros_like(v) for k, v in self.shadow_fwd.items()}
+
+    def _refresh_high(self, k):
+        """The "high" mode's forward operand(s) of weight k from the f32 master (which the bf16 forward shadow must already
+        match: Adam's kernel or cast_bf16 wrote it)."""
+        ops.cast_bf16_split(self.store.p(k), self.shadow_fwd[k], self.shadow_lo[k])
 
     def refresh_shadows(self, fwd=True):
         for k in self.shadow_fwd:
             p = self.store.p(k)
-            if self.precision == "high":
-                ops.cast_bf16_split(p, self.shadow_fwd[k], self.shadow_lo[k])
+            if self.precision != "bf16":
+                ops.cast_bf16(p, self.shadow_fwd[k])
+                self._refresh_high(k)
             elif fwd:
                 ops.cast_bf16(p, self.shadow_fwd[k])
             sb = self.shadow_bwd[k]
@@ -609,10 +670,10 @@ class TowerBase:
             ops.clip_adam_step(self.store.p(k), self.store.g(k), self.store.view(self.store.m, k),
                                self.store.view(self.store.v, k), l2, self.sums[idx[k]], clip_norm, lr_t, beta1, beta2, eps,
                                p_bf16=self.shadow_fwd.get(k))
-        if self.precision == "high":
+        if self.precision != "bf16":
             for k in names:
                 if k in self.shadow_fwd:
-                    ops.cast_bf16_split(self.store.p(k), self.shadow_fwd[k], self.shadow_lo[k])
+                    self._refresh_high(k)
         if refresh:
             for k in names:
                 if k in self.shadow_bwd:
@@ -664,6 +725,47 @@ class HLstmTower(TowerBase):
         self._init_params(seed)
         self._alloc(batch_size)
 
+    # ---- "high" precision operands (budget measured by scripts/precision_budget.py) ----------------------
+    # L1 level (85 % of the forward flops): IEEE f16 operands, ONE MFMA product per depth; layer 0's x-part as a K-extension
+    # over f16_x_segments segments of the input (2: + x_lo . Wx, 3: + x . Wx_lo) - the rounding of the input frames is the
+    # one term of the whole forward that 2^-12 does not cover.  L2 level + MoE head: split-bf16, K-extended loops.
+    f16_x_segments = int(os.environ.get("EVC_HIGH_X_SEGMENTS", "2"))
+
+    def input_split(self):
+        """The `split` argument of ops.l2norm_chunk that produces this tower's L1 input."""
+        return {"bf16": False, "high": "f16", "split": "wide"}[self.precision]
+
+    def _alloc_high_shadows(self):
+        dev, H, F, K = self.device, self.H, self.F, self.K
+        self.shadow_lo = {}                                              # (no separate low-order shadows in this tower)
+        self.shadow16, self.shadow_wx, self.shadow_wh, self.shadow_w = {}, {}, {}, {}
+        for k, shp in self.store.shapes.items():
+            if len(shp) != 2:
+                continue
+            if k.startswith("RNN_L1/") and self.precision == "high":
+                nin = shp[1] - H
+                wide = (self.f16_x_segments * nin + H) if "cell_0" in k else shp[1]
+                self.shadow16[k] = torch.zeros((shp[0], wide), dtype=ops.F16, device=dev)
+            elif k.startswith("RNN_L"):                                 # L2 level ("split": the L1 level too)
+                nin = shp[1] - H
+                self.shadow_wx[k] = torch.zeros((shp[0], 2 * nin), dtype=BF16, device=dev)
+                self.shadow_wh[k] = torch.zeros((shp[0], 2 * H), dtype=BF16, device=dev)
+            else:
+                self.shadow_w[k] = torch.zeros((shp[0], 2 * shp[1]), dtype=BF16, device=dev)
+
+    def _refresh_high(self, k):
+        p, H = self.store.p(k), self.H
+        if k in self.shadow16:
+            nin = p.shape[1] - H
+            nseg = (self.shadow16[k].shape[1] - H) // nin
+            ops.cast_f16_wide(p, nin, H, nseg, self.shadow16[k])
+        elif k in self.shadow_wx:
+            nin = p.shape[1] - H
+            ops.cast_bf16_wide(p[:, :nin], self.shadow_wx[k], lo_first=False)
+            ops.cast_bf16_wide(p[:, nin:], self.shadow_wh[k], lo_first=False)
+        else:
+            ops.cast_bf16_wide(p, self.shadow_w[k], lo_first=False)
+
     # ---- parameters -------------------------------------------------------
     def _init_params(self, seed):
         """TF defaults at the reference call sites: glorot-uniform kernels /
@@ -709,21 +811,25 @@ class HLstmTower(TowerBase):
         follow are latency-bound launches that leave most of the chip idle: a caller can start other work there).
         Returns (state [B, 2LH] f32, predictions [B, V] f32)."""
         high = isinstance(x_view, tuple)
-        if high and self.precision != "high":
-            raise ValueError("(hi, lo) input needs tower.set_precision('high')")
+        if high != (self.precision != "bf16"):
+            raise ValueError("precision %r takes %s" % (self.precision, "an image pair from ops.l2norm_chunk(..., split=tower.input_split())"
+                                                        if self.precision != "bf16" else "the plain bf16 image"))
+        if high and (x_view[1].dtype == ops.F16) != (self.precision == "high"):
+            raise ValueError("precision 'high' takes (bf16, IEEE f16) images, 'split' (bf16, wide [lo | hi] bf16) images: "
+                             "ops.l2norm_chunk(..., split=tower.input_split(), f16_segments=tower.f16_x_segments)")
         B = int(len_l2.shape[0])
         if B != self.B:
             self._alloc(B)
         S1 = self.l1.forward(x_view, len_l1, plan_l1)
         if after_l1 is not None:
             after_l1()
+        ops.cast_bf16(S1, self.S1_bf)                                  # = L2 input [C][B][2LH] (in "high": the backward operand)
         if high:
-            if not hasattr(self, "S1_lo") or self.S1_lo.shape != self.S1_bf.shape:
-                self.S1_lo = torch.empty_like(self.S1_bf)
-            ops.cast_bf16_split(S1, self.S1_bf, self.S1_lo)
-            S2 = self.l2.forward((self.S1_bf.view(self.C, B, self.K), self.S1_lo.view(self.C, B, self.K)), len_l2)
+            if not hasattr(self, "S1_w") or self.S1_w.shape[0] != self.S1_bf.shape[0]:
+                self.S1_w = torch.empty((self.C * B, 2 * self.K), dtype=BF16, device=self.device)
+            ops.cast_bf16_wide(S1, self.S1_w, lo_first=True)
+            S2 = self.l2.forward((self.S1_bf.view(self.C, B, self.K), self.S1_w.view(self.C, B, 2 * self.K)), len_l2)
         else:
-            ops.cast_bf16(S1, self.S1_bf)                              # = L2 input [C][B][2LH]
             S2 = self.l2.forward(self.S1_bf.view(self.C, B, self.K), len_l2)
         return S2, self.moe.forward(S2)
 
@@ -767,7 +873,8 @@ class HLstmTower(TowerBase):
                     h.wait()                                           # the aux stream waits for the collective, not the host
             self.apply_group(names, *early_apply)
 
-        fuse = (aux is not None and early_apply is not None and self.fused_moe_update and self.precision == "bf16"
+        fuse = (aux is not None and early_apply is not None and self.fused_moe_update
+                and (self.precision == "bf16" or dp is None)      # "high" under data parallelism: the lo halves of the row slabs are not gathered
                 and self.moe.can_fuse_update() and (reduce_fn is None or dp is not None)
                 and self.moe.prefer_fused_update(dp is not None))
         if not fuse and getattr(self.moe, "_stale", False):

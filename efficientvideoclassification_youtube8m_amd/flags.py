@@ -80,8 +80,9 @@ _define("max_steps", 0, int, "stop after this many iterations (0 = until the dat
 _define("synthetic_videos", 2048, int, "videos per epoch when train_data_pattern is synthetic")
 _define("teacher_only", False, _bool, "HierarchicalLstmModel: train the teacher tower alone (BASELINE cfg 2; the reference "
         "always builds the student too, also at every_n=1)")
-_define("precision", "bf16", str, "'bf16' (one MFMA product per contraction) or 'high' (split-bf16 operands, 3 products: "
-        "f32-operand accuracy in every forward GEMM)")
+_define("precision", "bf16", str, "'bf16' (one bf16 MFMA product per forward contraction), 'high' (holds 1e-3 on logits at trained "
+        "magnitudes: f16 operands for the L1 level with a K-extended input part, split-bf16 for the L2 level and the MoE head) or "
+        "'split' (split-bf16 operands, f32-operand accuracy, in every forward GEMM)")
 _define("netvlad_cluster_size", 64, int, "NetVLADModel (extension): number of clusters")
 _define("netvlad_hidden_size", 1024, int, "NetVLADModel (extension): width of the hidden layer after the aggregation")
 _define("log_every", 1, int, "host metrics / logging period in iterations (the reference logs every step)")

@@ -13,6 +13,7 @@ import torch
 from . import _lib
 
 BF16 = torch.bfloat16
+F16 = torch.float16
 F32 = torch.float32
 
 
@@ -94,6 +95,39 @@ def cast_bf16(x, out=None):
     return out
 
 
+def cast_f16(x, out):
+    """out = f16(x), round to nearest even, for a 2-D f32 tensor (the f16 weight shadows of lstm_layer_fwd_f16)."""
+    assert x.dtype == F32 and out.dtype == F16 and x.dim() == 2
+    _lib.call("evc_cast_f32_to_f16", _p(x), x.stride(0), x.shape[0], x.shape[1], _p(out), out.stride(0), _stream())
+    return out
+
+
+def cast_f16_wide(w, Kin, H, nseg, out):
+    """f16 image of an LSTM kernel w [R][Kin+H] f32 for a K-extended x-part: out [R][nseg*Kin + H] =
+    [f16(Wx) | f16(Wx)/64 | (Wx - f16(Wx))*64 | f16(Wh)] (first nseg x blocks)."""
+    assert w.dtype == F32 and out.dtype == F16 and w.shape[1] == Kin + H and out.shape == (w.shape[0], nseg * Kin + H) and out.is_contiguous()
+    _lib.call("evc_cast_f32_to_f16_wide", _p(w), w.stride(0), w.shape[0], Kin, H, nseg, _p(out), _stream())
+    return out
+
+
+def cast_bf16_wide(x, out, lo_first):
+    """Wide split-bf16 image of a 2-D f32 tensor: out rows [lo | hi] (lo_first: the A operand of gemm_nt_split_wide) or
+    [hi | lo] (its B operand)."""
+    R, Cc = x.shape
+    assert x.dtype == F32 and out.dtype == BF16 and out.shape[0] == R and out.shape[1] >= 2 * Cc
+    _lib.call("evc_cast_f32_to_bf16_wide", _p(x), x.stride(0), R, Cc, _p(out), out.stride(0), 1 if lo_first else 0, _stream())
+    return out
+
+
+def gemm_nt_split_wide(A_lohi, B_hilo, M, N, K, out, bias=None):
+    """out[M,N] f32 = (A_hi + A_lo) @ (B_hi + B_lo)^T (+ bias) to ~2^-16 as ONE K-extended launch (evc_gemm_nt_split):
+    A_lohi rows [lo(K) | hi(K)], B_hilo rows [hi(K) | lo(K)]."""
+    assert A_lohi.dtype == BF16 and B_hilo.dtype == BF16 and out.dtype == F32
+    _lib.call("evc_gemm_nt_split", _p(A_lohi), A_lohi.stride(0), _p(B_hilo), B_hilo.stride(0), _p(out), out.stride(0), M, N, K,
+              _p(bias), _stream())
+    return out
+
+
 def cast_bf16_split(x, hi, lo):
     """hi = bf16(x), lo = bf16(x - hi) for a 2-D f32 tensor (split-bf16 operands)."""
     R, Cc = x.shape
@@ -159,10 +193,13 @@ def host_frame_counts(num_frames_host, every_n, num_chunks, chunk_len, max_frame
 
 
 def l2norm_chunk(x_raw, num_chunks, every_n=None, num_chunks_student=None, num_frames=None, normalize=True, split=False,
-                 plan1=None, plan2=None):
+                 plan1=None, plan2=None, f16_segments=1):
     """a1+a2.  x_raw [B,T,F] f32 (or uint8 with num_frames).  Returns the
     teacher view [Lc][C*B][F] bf16 and (if every_n) the student view; with row plans the views are
-    [Lc][plan.P][F] in slot order."""
+    [Lc][plan.P][F] in slot order.  split: True -> (bf16, bf16 low half) pairs; "f16" -> (bf16, IEEE f16 image) pairs (the
+    operands of the "high" precision L1 forward; the bf16 image stays the operand of the backward products) - the f16 image
+    has rows of f16_segments*F: [f16(x) | (x - f16(x))*64 | f16(x)/64], the K-extended x operand of lstm_layer_fwd_f16;
+    "wide" -> (bf16, wide bf16 image with rows [lo | hi] of 2F) pairs, the input of lstm_layer_fwd_hp."""
     B, T, F = x_raw.shape
     dev = x_raw.device
     rows1 = plan1.P if plan1 is not None else num_chunks * B
@@ -174,13 +211,16 @@ def l2norm_chunk(x_raw, num_chunks, every_n=None, num_chunks_student=None, num_f
         rows2 = plan2.P if plan2 is not None else num_chunks_student * B
         out2 = torch.empty((S // num_chunks_student, rows2, F), dtype=BF16, device=dev)
     is_u8 = x_raw.dtype == torch.uint8
-    lo1 = torch.empty_like(out1) if split else None
-    lo2 = torch.empty_like(out2) if (split and out2 is not None) else None
+    aux_dt = F16 if split == "f16" else BF16
+    nseg = f16_segments if split == "f16" else (2 if split == "wide" else 1)
+    aux_mode = nseg if split == "f16" else (4 if split == "wide" else 0)
+    lo1 = torch.empty(out1.shape[:2] + (nseg * F,), dtype=aux_dt, device=dev) if split else None
+    lo2 = torch.empty(out2.shape[:2] + (nseg * F,), dtype=aux_dt, device=dev) if (split and out2 is not None) else None
     _lib.call("evc_l2norm_chunk_fwd", None if is_u8 else _p(x_raw), _p(x_raw) if is_u8 else None, _p(num_frames),
               B, T, F, num_chunks, _p(out1), every_n or 1, num_chunks_student or 1, _p(out2), 1 if normalize else 0,
-              _p(lo1), _p(lo2), _p(plan1.pos) if plan1 is not None else None, rows1,
+              _p(lo1), _p(lo2), aux_mode, _p(plan1.pos) if plan1 is not None else None, rows1,
               _p(plan2.pos) if plan2 is not None else None, rows2, _stream())
-    if split:      # (hi, lo) pairs for the "high" precision forward
+    if split:      # image pairs for the "high" / "split" precision forward
         return (out1, lo1), ((out2, lo2) if out2 is not None else None)
     return out1, out2
 
@@ -209,6 +249,14 @@ def lstm_layer_fwd(x, wT, bias, lens, T, M, Kin, H, hbuf, c_state, h_state, ld_s
               _p(hbuf), _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_all), *_plan_args(plan), _stream())
 
 
+def lstm_layer_fwd_f16(x16, wT16, bias, lens, T, M, Kin, H, hbuf16, hbuf_bf, c_state, h_state, ld_state,
+                       gates=None, c_all=None, plan=None):
+    """lstm_layer_fwd on IEEE f16 operands (one f16 MFMA product per depth); hbuf16 f16, hbuf_bf the bf16 copy of h."""
+    assert x16.dtype == F16 and wT16.dtype == F16 and hbuf16.dtype == F16 and hbuf_bf.dtype == BF16
+    _lib.call("evc_lstm_layer_fwd_f16", _p(x16), _p(wT16), _p(bias), _p(lens), T, M, Kin, H, _p(hbuf16), _p(hbuf_bf),
+              _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_all), *_plan_args(plan), _stream())
+
+
 def lstm_stack2_fwd(x, wT0, bias0, wT1, bias1, lens, T, M, Kin, H, zx_ws, hbuf0, hbuf1, S, gates=(None, None), c_all=(None, None)):
     """Two-layer stack, M ~ batch rows, wavefront order (evc_lstm_stack2_fwd).  S [M][4H] f32 = [c0 | h0 | c1 | h1]."""
     _lib.call("evc_lstm_stack2_fwd", _p(x), _p(wT0), _p(bias0), _p(wT1), _p(bias1), _p(lens), T, M, Kin, H, _p(zx_ws),
@@ -216,10 +264,11 @@ def lstm_stack2_fwd(x, wT0, bias0, wT1, bias1, lens, T, M, Kin, H, zx_ws, hbuf0,
               _p(gates[0]), _p(c_all[0]), _p(gates[1]), _p(c_all[1]), _stream())
 
 
-def lstm_layer_fwd_hp(x, x_lo, wT, wT_lo, bias, lens, T, M, Kin, H, hbuf, hbuf_lo, c_state, h_state, ld_state,
-                      gates=None, c_all=None, plan=None):
-    _lib.call("evc_lstm_layer_fwd_hp", _p(x), _p(x_lo), _p(wT), _p(wT_lo), _p(bias), _p(lens), T, M, Kin, H,
-              _p(hbuf), _p(hbuf_lo), _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_all), *_plan_args(plan), _stream())
+def lstm_layer_fwd_hp(x_lohi, wx_hilo, wh_hilo, bias, lens, T, M, Kin, H, zx_ws, hbuf, hbuf_lohi, c_state, h_state, ld_state,
+                      gates=None, c_all=None):
+    """Split-bf16 layer for the M ~ batch stacks (evc_lstm_layer_fwd_hp): wide [lo | hi] activations, [hi | lo] weights."""
+    _lib.call("evc_lstm_layer_fwd_hp", _p(x_lohi), _p(wx_hilo), wx_hilo.stride(0), _p(wh_hilo), wh_hilo.stride(0), _p(bias), _p(lens),
+              T, M, Kin, H, _p(zx_ws), _p(hbuf), _p(hbuf_lohi), _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_all), _stream())
 
 
 def lstm_layer_bwd(w_il, lens, T, M, Kin, H, gates, c_all, dS_c, dS_h, ld_dS, dh_above, dc_ws, dz4, plan=None, db=None,

@@ -195,7 +195,7 @@ class DbofTower(TowerBase):
         if B != self.B:
             self._alloc(B)
         F, S, Cc, Hd = self.F, self.S, self.Cc, self.Hd
-        high = self.precision == "high"
+        high = self.precision != "bf16"
         tape = self.training and is_training
         ops.dbof_gather(x, uniform, num_frames, self.r, self.idx, self.part_in if is_training else None, normalize=normalize)
         if is_training:
@@ -285,6 +285,8 @@ class NetVladTower(TowerBase):
     GEMM-shaped parts on the library's NT / TN kernels, the f32 pieces in csrc/evc_netvlad.hip.  V / Y are kept
     cluster-major [B][K][F]; hidden1_weights' TF row order f*K + k is restored in state_dict()."""
 
+    PRECISIONS = ("bf16",)             # no split-bf16 forward (set_precision refuses anything else)
+
     CW, C2, HW = "cluster_weights", "cluster_weights2", "hidden1_weights"
     l2_names = (MoeHead.GATES, MoeHead.EXPERTS)
     # all three batch-norms go through BatchNorm.backward: their gamma/beta gradients are global (all-reduced f64 sums)
@@ -341,6 +343,9 @@ class NetVladTower(TowerBase):
     def load_state_dict(self, sd, prefix=None):
         prefix = self.scope if prefix is None else prefix
         key = "%s/%s" % (prefix, self.HW)
+        if key not in sd:
+            raise KeyError("NetVladTower.load_state_dict: %r is not in the checkpoint (scope prefix %r; it holds e.g. %s)"
+                           % (key, prefix, sorted(sd)[:3]))
         sd = dict(sd)
         sd[key] = sd[key].view(self.F, self.Kc, self.Hd).permute(1, 0, 2).reshape(self.Kc * self.F, self.Hd).contiguous()
         super().load_state_dict(sd, prefix)
@@ -472,7 +477,7 @@ class LogisticTower(TowerBase):
         if B != self.B:
             self._alloc(B)
         ops.meanpool(x, num_frames, self.avg, self.avg_bf, normalize=normalize)
-        if self.precision == "high":
+        if self.precision != "bf16":
             if not hasattr(self, "avg_lo") or self.avg_lo.shape != self.avg_bf.shape:
                 self.avg_lo = torch.empty_like(self.avg_bf)
             ops.cast_bf16_split(self.avg, self.avg_bf, self.avg_lo)

@@ -43,6 +43,15 @@ def find_class_by_name(name, modules):
     return next(a for a in found if a)
 
 
+def _apply_precision(tw):
+    """--precision for the single-tower models: towers with a split-bf16 forward take it (DbofTower, LogisticTower); a tower
+    without one (NetVladTower) refuses anything but 'bf16' instead of silently ignoring the flag."""
+    if FLAGS.precision != "bf16":
+        if "high" not in getattr(tw, "PRECISIONS", ()):
+            raise ValueError("--precision %s: %s has no such forward mode" % (FLAGS.precision, type(tw).__name__))
+        tw.set_precision(FLAGS.precision)
+
+
 def build_graph(model, label_loss_fn, feature_size, batch_size, every_n, device, finetune=False, process_group=None):
     """Equivalent of cs/train.py:185-427 (and cs/train_finetune.py:185-331 when
     finetune): returns the graph object whose ``step`` runs one iteration."""
@@ -65,14 +74,17 @@ def build_graph(model, label_loss_fn, feature_size, batch_size, every_n, device,
         tw = DbofTower(batch_size, FLAGS.max_num_frames, feature_size, NUM_CLASSES, FLAGS.iterations,
                        FLAGS.dbof_cluster_size, FLAGS.dbof_hidden_size, FLAGS.moe_num_mixtures, device=device,
                        process_group=process_group)
+        _apply_precision(tw)
         return SingleTowerGraph(tw, **common)
     if isinstance(model, frame_level_models.NetVLADModel):          # extension (the reference's class is an empty stub)
         tw = NetVladTower(batch_size, FLAGS.max_num_frames, feature_size, NUM_CLASSES, FLAGS.iterations, FLAGS.netvlad_cluster_size,
                           FLAGS.netvlad_hidden_size, FLAGS.moe_num_mixtures, device=device, process_group=process_group)
+        _apply_precision(tw)
         return SingleTowerGraph(tw, **common)
     if isinstance(model, frame_level_models.FrameLevelLogisticModel):
-        return SingleTowerGraph(LogisticTower(batch_size, FLAGS.max_num_frames, feature_size, NUM_CLASSES, device=device),
-                                **common)
+        tw = LogisticTower(batch_size, FLAGS.max_num_frames, feature_size, NUM_CLASSES, device=device)
+        _apply_precision(tw)
+        return SingleTowerGraph(tw, **common)
     raise NotImplementedError("model %s has no training graph (NeXtVLAD is an empty stub in the reference too)"
                               % type(model).__name__)
 
@@ -183,6 +195,21 @@ def restore_checkpoint(graph, path):
                 tw.store.v.copy_(ad["v"])
 
 
+def agree_step_limit(max_steps, num_batches, world, device=None):
+    """Number of iterations every rank will run: None = until the data ends, an int (0 INCLUDED) = exactly that many.
+
+    Ranks own different files, so under data parallelism they agree on MIN(whole batches) up front - no rank may wait in
+    a gradient all-reduce for a peer whose input has run dry.  A rank with fewer records than one batch reports 0 whole
+    batches (drop_remainder): the agreed limit is then 0 and NO rank enters the loop (a rank that did would sit in a
+    gradient all-reduce while the empty one is already in save_checkpoint's consolidate(): mismatched collectives)."""
+    limit = int(max_steps) if max_steps else None
+    if world > 1 and num_batches is not None:
+        nb = torch.tensor([int(num_batches)], device=device)
+        torch.distributed.all_reduce(nb, op=torch.distributed.ReduceOp.MIN)
+        limit = int(nb) if limit is None else min(limit, int(nb))
+    return limit
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     finetune = "--finetune" in argv
@@ -203,10 +230,11 @@ def main(argv=None):
     device = "cuda:%d" % local
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        from .distill import dp_timeout
         if shared_gpu:
-            torch.distributed.init_process_group("gloo")
+            torch.distributed.init_process_group("gloo", timeout=dp_timeout())
         else:
-            torch.distributed.init_process_group("nccl", device_id=torch.device(device))
+            torch.distributed.init_process_group("nccl", device_id=torch.device(device), timeout=dp_timeout())
     ops.check_device(local)
     task = "/job:master/task:%d" % rank
     _, feature_sizes = GetListOfFeatureNamesAndSizes(FLAGS.feature_names, FLAGS.feature_sizes)
@@ -227,13 +255,10 @@ def main(argv=None):
         restore_checkpoint(graph, ck)
     data, num_batches = get_input_data(FLAGS.train_data_pattern, FLAGS.batch_size, feature_size, device, FLAGS.num_epochs,
                                        1234 + rank, rank, world)
-    step_limit = FLAGS.max_steps or None
-    if world > 1 and num_batches is not None:
-        # ranks own different files: agree on the common number of iterations so that no rank waits in a
-        # gradient all-reduce for a peer whose input has run dry
-        nb = torch.tensor([num_batches], device=device)
-        torch.distributed.all_reduce(nb, op=torch.distributed.ReduceOp.MIN)
-        step_limit = min(step_limit or int(nb), int(nb))
+    step_limit = agree_step_limit(FLAGS.max_steps, num_batches, world, device)
+    if step_limit == 0:
+        logging.warning("%s: a rank has fewer than one whole batch of %d records: no training step on any rank "
+                        "(give every rank at least batch_size records)", task, FLAGS.batch_size)
     logging.info("%s: Entering training loop.", task)
     start, last_save, it = time.time(), time.time(), 0
     is_distill = isinstance(graph, DistillGraph)
@@ -295,7 +320,7 @@ def main(argv=None):
 
     history = []                         # (global_step, loss dict) of every logged step, returned to the caller
     pending = None
-    for q, labels, n, n_host in data:
+    for q, labels, n, n_host in (data if step_limit != 0 else ()):
         out = graph.step(q, labels, n, num_frames_host=n_host) if is_distill else graph.step(q, labels, n)    # uint8 features: Dequantize is fused into every input kernel
         it += 1
         graph.last_batch_ids = LAST_BATCH["ids"]
@@ -315,7 +340,7 @@ def main(argv=None):
         if save_due:
             save_checkpoint(graph, FLAGS.train_dir, rank)
             last_save = time.time()
-        if step_limit and it >= step_limit:
+        if step_limit is not None and it >= step_limit:
             break
     if pending is not None:
         finish_log(pending, it)

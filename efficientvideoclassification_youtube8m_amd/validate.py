@@ -73,10 +73,12 @@ def evaluation_loop(graph, reader, label_loss_fn, summary_writer, evl_metrics, l
     logging.info("Loading checkpoint for eval: " + ck)
     try:
         sd = torch.load(ck, map_location="cpu")
-    except (FileNotFoundError, EOFError, RuntimeError, OSError) as e:
-        # the trainer replaced the file between the directory listing and the load (max_to_keep=1): not an error of
-        # this process - look again at the next poll (train.save_checkpoint itself writes atomically)
-        logging.info("checkpoint %s could not be loaded (%s); will look again.", ck, e)
+    except FileNotFoundError as e:
+        # the trainer replaced the file between the directory listing and the load (max_to_keep=1) - the only race an
+        # atomic writer (train.save_checkpoint: temp file, fsync, os.replace) leaves; look again at the next poll.
+        # Anything else (a corrupt or incompatible file) is an error of THIS checkpoint and propagates: polling it
+        # forever - or ending a --run_once evaluation with no result and no failure - would hide it.
+        logging.info("checkpoint %s disappeared before it could be loaded (%s); will look again.", ck, e)
         return last_global_step_val, None
     graph.restore(sd)
     global_step_val = int(sd.get("global_step", 0))

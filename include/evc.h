@@ -39,6 +39,7 @@ extern "C" {
 #define EVC_VERSION 100
 
 typedef uint16_t evc_bf16;
+typedef uint16_t evc_f16;   /* raw IEEE binary16 bits (the "high" precision forward operands of the L1 levels) */
 
 int evc_version(void);
 const char* evc_last_error(void);
@@ -67,7 +68,15 @@ int evc_l2norm_chunk_fwd(const float* x_raw, const uint8_t* x_u8, const int32_t*
                          int B, int T, int F,
                          int C1, evc_bf16* out1,
                          int every_n, int C2, evc_bf16* out2, int normalize,
-                         evc_bf16* out1_lo, evc_bf16* out2_lo /* split-bf16 low halves or NULL */,
+                         evc_bf16* out1_lo, evc_bf16* out2_lo /* second image of each view or NULL: see aux_f16 */,
+                         int aux_mode /* 0: the split-bf16 low halves bf16(x - bf16(x)), rows of F;
+                                         1..3: IEEE f16 images with rows of aux_mode*F = the first aux_mode of the segments
+                                         [f16(x) | (x - f16(x))*64 | f16(x)/64] - against kernel rows [f16(W) | f16(W)/64 |
+                                         (W - f16(W))*64] (evc_cast_f32_to_f16_wide) a plain f16 contraction over the wide rows
+                                         adds the x_lo.W_hi (2) and x_hi.W_lo (3) corrections; the 64s keep both low-order
+                                         factors in f16's normal range;
+                                         4: wide split-bf16 images, rows of 2F = [bf16(x - bf16(x)) | bf16(x)] - the [lo | hi]
+                                         operand of evc_lstm_layer_fwd_hp */,
                          const int32_t* row_pos1, int rows1, const int32_t* row_pos2, int rows2, void* stream);
 
 /* Row plan of an LSTM stack: stable counting sort of its M rows by sequence length, longest first
@@ -139,15 +148,30 @@ int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const float* bias,
                        evc_bf16* hbuf, float* c_state, float* h_state, int64_t ld_state,
                        void* gates, evc_bf16* c_all, const int32_t* row_map, const int32_t* rows_per_step, void* stream);
 
-/* "High" precision variant of evc_lstm_layer_fwd: every bf16 operand comes as hi + lo halves
- * (evc_cast_f32_to_bf16_split / evc_l2norm_chunk_fwd's lo outputs) and the step issues
- * hi.hi + hi.lo + lo.hi MFMAs (f32-operand accuracy, ~3x the matrix work); hbuf_lo receives the
- * low half of every h_t.  Always the fused [x_t | h] form.  Used to hold the 1e-3 parity
- * tolerance when states / activations are O(1) or larger (after training). */
-int evc_lstm_layer_fwd_hp(const evc_bf16* x, const evc_bf16* x_lo, const evc_bf16* wT, const evc_bf16* wT_lo,
-                          const float* bias, const int32_t* len, int T, int M, int Kin, int H,
-                          evc_bf16* hbuf, evc_bf16* hbuf_lo, float* c_state, float* h_state, int64_t ld_state,
-                          void* gates, evc_bf16* c_all, const int32_t* row_map, const int32_t* rows_per_step, void* stream);
+/* "High" precision layer for stacks with M ~ batch rows (the L2 level): split-bf16 operands - x = hi + lo to ~2^-16, products
+ * lo.hi + hi.lo + hi.hi (the lo.lo term is below f32 noise) - contracted as K-EXTENSIONS of the plain bf16 loops (see
+ * evc_gemm_nt_split): f32-operand accuracy at 3x the MFMA depth, same kernels, same epilogues.
+ * x_lohi  [T][M][2Kin]  wide input image, rows [lo | hi] (evc_cast_f32_to_bf16_wide, lo_first = 1);
+ * wx_hilo [4H] rows [hi(Kin) | lo(Kin)] of the kernel's x-part, row stride ldwx; wh_hilo [4H] rows [hi(H) | lo(H)] of its h-part;
+ * zx_ws   [T][M][4H] f32: the x-projection of all T steps, hoisted into ONE split product;
+ * hbuf    [(T+1)][M][H] bf16: h_t rounded (= the hi half), what the backward products read;
+ * hbuf_lohi [(T+1)][M][2H]: the wide image [lo | hi] of every h_t - the next step's operand and the next layer's x_lohi.
+ * Everything else as evc_lstm_layer_fwd (cs/frame_level_models.py:252-257: dynamic_rnn over the L1 final states); no row plan. */
+int evc_lstm_layer_fwd_hp(const evc_bf16* x_lohi, const evc_bf16* wx_hilo, int64_t ldwx, const evc_bf16* wh_hilo, int64_t ldwh,
+                          const float* bias, const int32_t* len, int T, int M, int Kin, int H, float* zx_ws,
+                          evc_bf16* hbuf, evc_bf16* hbuf_lohi, float* c_state, float* h_state, int64_t ld_state,
+                          void* gates, evc_bf16* c_all, void* stream);
+/* evc_lstm_layer_fwd on IEEE f16 operands: x [T][M][Kin], wT [4H][Kin+H] and hbuf [(T+1)][M][H] hold f16 and each step issues
+ * ONE v_mfma_f32_16x16x32_f16 product per depth (the cost of the bf16 step; operand rounding 2^-12 instead of 2^-9).  Always the
+ * fused [x_t | h] form.  An x-part that needs more than 2^-12 (layer 0 of the L1 level: scripts/precision_budget.py) is handed
+ * over as a K-extension: x rows of nseg*F from evc_l2norm_chunk_fwd (aux_mode = nseg), kernel rows from
+ * evc_cast_f32_to_f16_wide(nseg), Kin = nseg*F here.  hbuf_bf16 [(T+1)][M][H] receives the bf16 copy of every h_t: the operand of the backward products
+ * (whose gradients need bf16's range).  Everything else as evc_lstm_layer_fwd (same dynamic_rnn semantics,
+ * cs/frame_level_models.py:221-250). */
+int evc_lstm_layer_fwd_f16(const evc_f16* x, const evc_f16* wT, const float* bias, const int32_t* len,
+                           int T, int M, int Kin, int H, evc_f16* hbuf, evc_bf16* hbuf_bf16,
+                           float* c_state, float* h_state, int64_t ld_state, void* gates, evc_bf16* c_all,
+                           const int32_t* row_map, const int32_t* rows_per_step, void* stream);
 /* A TWO-layer stack with M ~ batch rows (the L2 level: M = videos) in wavefront order: after layer 0's hoisted
  * x-projection (one GEMM into zx_ws [T][M][4H] f32), launch s runs layer 0's step s and layer 1's step s-1 side by
  * side (they are independent, and each is latency-bound at this size), so the chain of dependent launches is T+1
@@ -227,6 +251,19 @@ int evc_transpose_to_bf16(const void* in, int in_f32, int64_t ld_in, int R, int 
                           evc_bf16* out, int64_t ld_out, int Rpad, int interleave_H, void* stream);
 /* out_bf16[i] = bf16(in_f32[i]) for a [R, C] matrix (ld_in, ld_out). */
 int evc_cast_f32_to_bf16(const float* in, int64_t ld_in, int R, int C, evc_bf16* out, int64_t ld_out, void* stream);
+/* out_f16[i] = f16(in_f32[i]), round to nearest even (the f16 weight shadows of evc_lstm_layer_fwd_f16). */
+int evc_cast_f32_to_f16(const float* in, int64_t ld_in, int R, int C, evc_f16* out, int64_t ld_out, void* stream);
+/* f16 image of an LSTM kernel [R][Kin+H] (f32, row stride ld_in) for a K-extended x-part: out [R][nseg*Kin + H] =
+ * [f16(Wx) | f16(Wx)/64 | (Wx - f16(Wx))*64 | f16(Wh)] keeping the first nseg (1..3) x blocks. */
+int evc_cast_f32_to_f16_wide(const float* in, int64_t ld_in, int R, int Kin, int H, int nseg, evc_f16* out, void* stream);
+/* wide split-bf16 image of a [R][C] f32 matrix: out rows [lo | hi] (lo_first = 1: the A operand of evc_gemm_nt_split) or
+ * [hi | lo] (0: its B operand); hi = bf16(x), lo = bf16(x - hi); C % 4 == 0, ld_out >= 2C. */
+int evc_cast_f32_to_bf16_wide(const float* in, int64_t ld_in, int R, int C, evc_bf16* out, int64_t ld_out, int lo_first, void* stream);
+/* C[M,N] = (A_hi + A_lo) . (B_hi + B_lo)^T (+ bias), f32 out, to ~2^-16 relative, as ONE K-extended launch of the plain NT
+ * loop: A_lohi rows [lo(K) | hi(K)] (lda >= 2K), B_hilo rows [hi(K) | lo(K)] (ldb >= 2K); K % 64 == 0.  The "high" precision
+ * form of the MoE head (cs/video_level_models.py:423-435) and of the L2 level's hoisted input projection. */
+int evc_gemm_nt_split(const evc_bf16* A_lohi, int64_t lda, const evc_bf16* B_hilo, int64_t ldb, float* C, int64_t ldc,
+                      int M, int N, int K, const float* bias, void* stream);
 /* split-bf16 cast: hi = bf16(x), lo = bf16(x - hi).  Three NT products (hi.hi + hi.lo + lo.hi, via
  * evc_gemm_nt with accumulate) then reproduce an f32-operand GEMM to ~2^-16 relative: the
  * "high" precision forward mode for models whose activations are O(1) (DBoF after batch-norm). */

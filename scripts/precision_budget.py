@@ -1,0 +1,214 @@
+"""Error budget of the forward pass per contraction (CPU experiment, no GPU needed).
+
+Which products of the H-LSTM forward need split operands to hold north_star's 1e-3 on logits / states / predictions
+at trained-magnitude weights?  Emulates the MFMA operand types on the CPU: both operands of a product are rounded to
+the chosen 16-bit type (bf16 or f16), the contraction itself runs in float64 (the MFMA accumulates in f32; its own
+rounding is ~1e-6 and not the question here); "x3" = operands kept exact (hi.hi + hi.lo + lo.hi leaves ~2^-17).
+Products: L1 cell_0, L1 cell_1 (the teacher's 300 / student's 30 frame steps: 85 % of the forward flops), L2 cell_0
+(hoisted input projection + recurrent part), L2 cell_1, the MoE head.
+
+Weights of trained magnitude as in tests/test_gpu_step.py::_trained_magnitude_weights: Adam iterations at lr 2e-3 from
+the reference's initialisation (oracle/torch_cpu.py) until |state| > 2 or |gate logit| > 8.
+
+    python scripts/precision_budget.py [--batch 4] [--save /tmp/w.pt]
+"""
+import argparse
+import itertools
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from oracle import model_math as mm          # noqa: E402
+from oracle import torch_cpu as tc           # noqa: E402
+
+
+def rnd(a, kind):
+    if kind == "x3":
+        return a
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16}[kind]
+    return a.to(torch.float32).to(dt).to(torch.float64)
+
+
+def _parts(kind):
+    """A layer's kind: one name for every operand, or a dict ax / ah / wx / wh (activation / weight, x-part / h-part)."""
+    if isinstance(kind, dict):
+        return kind["ax"], kind["ah"], kind["wx"], kind["wh"]
+    return kind, kind, kind, kind
+
+
+def stack_fwd(x, lengths, layers, kinds):
+    """x [M, T, F] float64, layers [(kernel, bias)], kinds per layer -> final state [M, 2LH] (c0 h0 c1 h1)."""
+    M, T, _ = x.shape
+    H = layers[0][1].shape[0] // 4
+    c = [x.new_zeros((M, H)) for _ in layers]
+    h = [x.new_zeros((M, H)) for _ in layers]
+    wq = []
+    for l, (k, _) in enumerate(layers):
+        ax, ah, wx, wh = _parts(kinds[l])
+        nin = k.shape[0] - H
+        wq.append(torch.cat([rnd(k[:nin], wx), rnd(k[nin:], wh)], 0))
+    for t in range(T):
+        active = (lengths > t).unsqueeze(1)
+        if not bool(active.any()):
+            break
+        inp = x[:, t]
+        for l, (_, bias) in enumerate(layers):
+            ax, ah, _, _ = _parts(kinds[l])
+            a = torch.cat([rnd(inp, ax), rnd(h[l], ah)], 1)
+            z = a @ wq[l] + bias
+            i, j, f, o = z.split(H, 1)
+            cn = c[l] * torch.sigmoid(f + 1.0) + torch.sigmoid(i) * torch.tanh(j)
+            hn = torch.tanh(cn) * torch.sigmoid(o)
+            c[l] = torch.where(active, cn, c[l])
+            h[l] = torch.where(active, hn, h[l])
+            inp = hn
+    return torch.cat([s for l in range(len(layers)) for s in (c[l], h[l])], 1)
+
+
+def tower_fwd(x, n, p, num_chunks, kinds):
+    """kinds: dict L1c0, L1c1, L2c0, L2c1, moe -> 'bf16' | 'f16' | 'x3'."""
+    B, T, F = x.shape
+    Lc = T // num_chunks
+    l1, l2 = tc._layers(p, "RNN_L1", 2), tc._layers(p, "RNN_L2", 2)
+    xc = x.reshape(B, num_chunks, Lc, F).permute(1, 0, 2, 3).reshape(num_chunks * B, Lc, F)       # row = chunk*B + b
+    ln = torch.stack([torch.clamp(n - Lc * i, 0, Lc) for i in range(num_chunks)], 0).reshape(-1)
+    s1 = stack_fwd(xc, ln, l1, (kinds["L1c0"], kinds["L1c1"]))
+    l2_in = s1.reshape(num_chunks, B, -1).permute(1, 0, 2)
+    len2 = torch.ceil(n.to(torch.float32) / float(Lc)).to(torch.int64)
+    state = stack_fwd(l2_in, len2, l2, (kinds["L2c0"], kinds["L2c1"]))
+    sq = rnd(state, kinds["moe"])
+    gl = sq @ rnd(p["classifier/gates/weights"], kinds["moe"])
+    el = sq @ rnd(p["classifier/experts/weights"], kinds["moe"]) + p["classifier/experts/biases"]
+    V = el.shape[1] // 2
+    g = torch.softmax(gl.reshape(B * V, 3), 1)
+    pred = (g[:, :2] * torch.sigmoid(el.reshape(B * V, 2))).sum(1).reshape(B, V)
+    return dict(state=state, gate_logits=gl, expert_logits=el, pred=pred)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--seed", type=int, default=91)
+    ap.add_argument("--lr", type=float, default=2e-3)
+    ap.add_argument("--max_steps", type=int, default=16)
+    ap.add_argument("--save", default="")
+    ap.add_argument("--load", default="")
+    ap.add_argument("--only", default="", help="run only the configurations whose label contains this string")
+    ap.add_argument("--gpu", action="store_true", help="weights from the GPU training of tests/test_gpu_step.py::_trained_magnitude_weights "
+                    "(run on the GPU box); also prints the errors of the real kernels in both precision modes")
+    a = ap.parse_args()
+    torch.set_num_threads(8)
+    B = a.batch
+    q, x, n, labels = mm.synthetic_batch(B, seed=a.seed, dtype=np.float32)
+    n[0] = 300
+    x[np.arange(300)[None, :] >= n[:, None]] = 0.0
+    if a.gpu:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+        import test_gpu_step as tgs
+        sd = tgs._trained_magnitude_weights(B, x, n, labels)
+        teacher = {k[len("model/"):]: v.float().cpu() for k, v in sd.items() if k.startswith("model/")}
+        student = {k[len("model_student/"):]: v.float().cpu() for k, v in sd.items() if k.startswith("model_student/")}
+    elif a.load:
+        teacher, student = torch.load(a.load)
+    else:
+        rng = np.random.default_rng(3)
+        teacher = tc.to_torch(mm.init_hlstm_params(rng, dtype=np.float32))
+        student = tc.to_torch(mm.init_hlstm_params(rng, dtype=np.float32))
+        ot, os_ = tc.Adam(teacher, lr=a.lr), tc.Adam(student, lr=a.lr)
+        xt, yt = torch.from_numpy(x), torch.from_numpy(labels.astype(np.float32))
+        for it in range(a.max_steps):
+            t0 = time.time()
+            tc.teacher_student_iteration(xt, n, yt, teacher, student, 10, ot, os_)
+            with torch.no_grad():
+                st, _ = tc.hlstm_fwd(tc.l2_normalize(xt), n, teacher, 20)
+                zmax = float((st @ teacher["classifier/gates/weights"]).abs().max())
+                smax = float(st.abs().max())
+            print("iteration %d: |state| %.2f |gate logit| %.2f (%.0f s)" % (it + 1, smax, zmax, time.time() - t0), flush=True)
+            if smax > 2.0 or zmax > 8.0:
+                break
+        if a.save:
+            torch.save((teacher, student), a.save)
+    with torch.no_grad():
+        xd = tc.l2_normalize(torch.from_numpy(x)).double()
+        nt = torch.as_tensor(n, dtype=torch.int64)
+        S = 30
+        n_s = torch.as_tensor(np.trunc(n.astype(np.float64) / 300.0 * S).astype(np.int64))
+        xs = xd[:, ::10][:, :S]
+        towers = (("teacher", {k: v.detach().double() for k, v in teacher.items()}, xd, nt, 20),
+                  ("student", {k: v.detach().double() for k, v in student.items()}, xs, n_s, 5))
+        exact = dict(L1c0="x3", L1c1="x3", L2c0="x3", L2c1="x3", moe="x3")
+        ref = {name: tower_fwd(xx, nn, p, ch, exact) for name, p, xx, nn, ch in towers}
+        for name in ref:
+            print("%s: |state| %.2f |gate logit| %.2f |expert logit| %.2f" % (
+                name, ref[name]["state"].abs().max(), ref[name]["gate_logits"].abs().max(), ref[name]["expert_logits"].abs().max()))
+        configs = [
+            ("all bf16", dict(L1c0="bf16", L1c1="bf16", L2c0="bf16", L2c1="bf16", moe="bf16")),
+            ("all f16", dict(L1c0="f16", L1c1="f16", L2c0="f16", L2c1="f16", moe="f16")),
+            ("moe only bf16", dict(exact, moe="bf16")),
+            ("moe only f16", dict(exact, moe="f16")),
+            ("L1 bf16, rest x3", dict(exact, L1c0="bf16", L1c1="bf16")),
+            ("L1 f16, rest x3", dict(exact, L1c0="f16", L1c1="f16")),
+            ("L1c0 bf16, rest x3", dict(exact, L1c0="bf16")),
+            ("L1c1 bf16, rest x3", dict(exact, L1c1="bf16")),
+            ("L1c0 f16, rest x3", dict(exact, L1c0="f16")),
+            ("L1c1 f16, rest x3", dict(exact, L1c1="f16")),
+            ("L2 bf16, rest x3", dict(exact, L2c0="bf16", L2c1="bf16")),
+            ("L2 f16, rest x3", dict(exact, L2c0="f16", L2c1="f16")),
+            ("L1+L2 f16, moe x3", dict(L1c0="f16", L1c1="f16", L2c0="f16", L2c1="f16", moe="x3")),
+        ]
+        def c0(**kw):
+            d = dict(ax="x3", ah="x3", wx="x3", wh="x3")
+            d.update(kw)
+            return dict(exact, L1c0=d)
+        configs += [
+            ("L1c0 f16: x-part only", c0(ax="f16", wx="f16")),
+            ("L1c0 f16: h-part only", c0(ah="f16", wh="f16")),
+            ("L1c0 f16: weights only", c0(wx="f16", wh="f16")),
+            ("L1c0 f16: activ. only", c0(ax="f16", ah="f16")),
+            ("L1c0 f16: Wx only", c0(wx="f16")),
+            ("L1c0 f16: x only", c0(ax="f16")),
+            ("L1c0 f16: Wh only", c0(wh="f16")),
+            ("L1c0 f16: h only", c0(ah="f16")),
+        ]
+        f16h = dict(ax="x3", ah="f16", wx="x3", wh="f16")
+        configs += [
+            ("PLAN c0 x-part x3 + h f16, c1 f16", dict(exact, L1c0=f16h, L1c1="f16")),
+            ("PLAN c0 x split only (Wx f16)", dict(exact, L1c0=dict(f16h, wx="f16"), L1c1="f16")),
+        ]
+        if a.only:
+            configs = [c for c in configs if a.only in c[0]]
+        if a.gpu:
+            from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
+            dev = "cuda:0"
+            xg, yg, ng = torch.from_numpy(x).to(dev), torch.from_numpy(labels.astype(np.uint8)).to(dev), torch.from_numpy(n).to(dev)
+            for prec in ("bf16", "high"):
+                g = DistillGraph(B, every_n=10, device=dev, seed=3, precision=prec)
+                g.teacher.load_state_dict(sd)
+                g.student.load_state_dict(sd)
+                out = g.step(xg, yg, ng, apply=False, num_frames_host=n)
+                row = []
+                for name, tw, ks, kp in (("teacher", g.teacher, "teacher_state", "predictions"), ("student", g.student, "student_state", "student_predictions")):
+                    row.append("%s state %.1e gate %.1e expert %.1e pred %.1e" % (
+                        name[0], (out[ks].double().cpu() - ref[name]["state"]).abs().max(),
+                        (tw.moe.gate_logits.double().cpu() - ref[name]["gate_logits"]).abs().max(),
+                        (tw.moe.expert_logits.double().cpu() - ref[name]["expert_logits"]).abs().max(),
+                        (out[kp].double().cpu() - ref[name]["pred"]).abs().max()))
+                print("%-22s %s" % ("KERNELS " + prec, " | ".join(row)), flush=True)
+                del g
+                torch.cuda.empty_cache()
+        for label, kinds in configs:
+            row = []
+            for name, p, xx, nn, ch in towers:
+                out = tower_fwd(xx, nn, p, ch, kinds)
+                row.append("%s state %.1e gate %.1e expert %.1e pred %.1e" % (
+                    name[0], (out["state"] - ref[name]["state"]).abs().max(), (out["gate_logits"] - ref[name]["gate_logits"]).abs().max(),
+                    (out["expert_logits"] - ref[name]["expert_logits"]).abs().max(), (out["pred"] - ref[name]["pred"]).abs().max()))
+            print("%-22s %s" % (label, " | ".join(row)), flush=True)
+
+
+if __name__ == "__main__":
+    main()

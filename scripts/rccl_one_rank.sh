@@ -6,6 +6,7 @@
 # EVC_DP_SERIAL_COMM=1 (one communicator, one collective at a time), then the plain single-GPU step.
 #   bash scripts/rccl_one_rank.sh [out-file]      (default gpurun_out/rccl_one_rank.txt; copy to profiles/ to keep)
 set -e
+set -o pipefail
 cd "$(dirname "$0")/.."
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 OUT=${1:-gpurun_out/rccl_one_rank.txt}
@@ -16,10 +17,14 @@ run() {   # label, env assignments..., then the rest
   echo "== $label" | tee -a "$OUT"
   env "$@" | python3 -c "
 import json, sys
+seen = 0
 for l in sys.stdin:
     if l.startswith('{'):
         d = json.loads(l)
-        print('ms_per_step %.3f  frames/s %.0f  losses %s' % (d['ms_per_step'], d['value'], d['losses']))" | tee -a "$OUT"
+        seen += 1
+        print('ms_per_step %.3f  frames/s %.0f  losses %s' % (d['ms_per_step'], d['value'], d['losses']))
+        print('LOSSES ' + json.dumps(d['losses'], sort_keys=True))
+sys.exit(0 if seen == 1 else 3)" | tee -a "$OUT"      # a crashed run prints no JSON line: fail here (pipefail), not silently
 }
 ARGS="bench.py --gpus 1 --steps ${STEPS:-10} --warmup 3 --no_cpu_baseline --no_secondary"
 run "one-rank RCCL, collectives in stream order, student on its own communicator (default)" EVC_DP_FORCE=1 \
@@ -27,3 +32,14 @@ run "one-rank RCCL, collectives in stream order, student on its own communicator
 run "one-rank RCCL, EVC_DP_SERIAL_COMM=1 (one communicator, one collective at a time)" EVC_DP_FORCE=1 EVC_DP_SERIAL_COMM=1 \
     python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 $ARGS
 run "no process group (plain single-GPU step)" python3 $ARGS
+# the three runs train on the same synthetic batches: their reported losses must agree (bf16 kernels, different
+# summation orders of the reduced losses: 1e-3 relative)
+python3 - "$OUT" <<'PY'
+import json, sys
+rows = [json.loads(l[len("LOSSES "):]) for l in open(sys.argv[1]) if l.startswith("LOSSES ")]
+assert len(rows) == 3, "expected three runs, saw %d" % len(rows)
+for k, v in rows[2].items():
+    for r in rows[:2]:
+        assert abs(r[k] - v) <= 1e-3 * max(1.0, abs(v)), ("losses differ from the plain single-GPU run", k, r[k], v)
+print("losses of the three runs agree")
+PY

@@ -213,6 +213,28 @@ assert torch.equal(full[:V, 0], torch.arange(V, dtype=torch.float32))           
 flat = torch.arange(10, dtype=torch.float32) * (rank + 1)
 assert red.reduce_async(flat, 2, 7) is None
 assert flat.tolist() == [0, 1 * (rank + 1)] + [3.0 * i for i in range(2, 7)] + [i * (rank + 1.0) for i in range(7, 10)]
+# bf16 gradient payload (EVC_DP_GRAD_DTYPE=bf16 / grad_dtype="bf16"): every rank's segment is rounded to bf16 once, the sum
+# arrives back in f32 - within 2^-9 of the f32 reduce per element (gloo: exact sum of the rounded values)
+redb = GradReducer(None, grad_dtype="bf16")
+g = torch.linspace(-3.0, 3.0, 1000) * (1.0 + 0.37 * rank) + 1e-3 * rank
+want32 = sum(torch.linspace(-3.0, 3.0, 1000) * (1.0 + 0.37 * r) + 1e-3 * r for r in range(world))
+wantb = sum((torch.linspace(-3.0, 3.0, 1000) * (1.0 + 0.37 * r) + 1e-3 * r).bfloat16().float() for r in range(world))
+flatb = torch.cat([torch.full((5,), 7.0), g.clone(), torch.full((3,), -7.0)])
+assert redb.reduce_async(flatb, 5, 1005) is None
+assert torch.equal(flatb[:5], torch.full((5,), 7.0)) and torch.equal(flatb[1005:], torch.full((3,), -7.0))      # outside the segment: untouched
+assert torch.allclose(flatb[5:1005], wantb, rtol=0, atol=1e-6)
+assert float((flatb[5:1005] - want32).abs().max()) <= 2.0 ** -8 * float(want32.abs().max())
+assert GradReducer.stats["all_reduce_grad_bf16"] == [1, 2000] and GradReducer.stats["all_reduce_grad_f32"][1] == 5 * 4
+assert GradReducer.wire_bytes("all_reduce_grad_f32", 800.0, 8) == 1400.0 and GradReducer.wire_bytes("all_gather_slabs", 100.0, 8) == 700.0
+# iteration-count agreement (train.agree_step_limit): MIN over the ranks; a rank without one whole batch makes it 0 on
+# EVERY rank (0 is a limit, not "no limit": the loop is skipped everywhere, nobody is left alone in an all-reduce)
+from efficientvideoclassification_youtube8m_amd.train import agree_step_limit
+assert agree_step_limit(0, 5 + rank, world) == 5
+assert agree_step_limit(3, 5 + rank, world) == 3
+assert agree_step_limit(9, 5 + rank, world) == 5
+lim = agree_step_limit(0, 4 if rank == 0 else 0, world)
+assert lim == 0 and lim is not None
+assert agree_step_limit(7, None, world) == 7 and agree_step_limit(0, None, world) is None
 dist.destroy_process_group()
 sys.stdout.write("rank" + str(rank) + "-ok\n"); sys.stdout.flush()
 '''
@@ -263,3 +285,43 @@ def test_grad_ranges_skip_synced_batchnorm_gradients():
         inside = set(range(st.offsets[k], st.offsets[k] + int(math.prod(shp)))) <= covered
         assert inside == (k not in DbofTower.global_grad_names), k
     assert len(rs) == 3          # cluster_weights | hidden1_weights | the MoE block
+
+
+TIMEOUT_WORKER = r'''
+import os, sys, time
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+from efficientvideoclassification_youtube8m_amd.distill import dp_timeout
+rank = int(os.environ["RANK"])
+assert dp_timeout().total_seconds() == 4.0
+dist.init_process_group("gloo", timeout=dp_timeout())
+t = torch.ones(4)
+dist.all_reduce(t)                      # first contact works
+assert t.tolist() == [2.0] * 4
+if rank == 1:
+    time.sleep(12)                      # a wedged peer: never joins the second collective in time
+    os._exit(0)
+t0 = time.time()
+try:
+    dist.all_reduce(t)
+    sys.stdout.write("rank0-no-timeout\n")
+except Exception as e:
+    sys.stdout.write("rank0-timeout-after-%%.0fs %%s\n" %% (time.time() - t0, type(e).__name__))
+sys.stdout.flush()
+os._exit(0)
+'''
+
+
+def test_process_group_timeout_ends_a_wedged_collective(tmp_path):
+    """bench.py / train.py create their process group with distill.dp_timeout() (EVC_DP_TIMEOUT_S, default 120 s instead of
+    c10d's 10 minutes): a collective whose peer never arrives raises after that time instead of holding the launcher's whole
+    window.  Two gloo ranks, the second one stalls."""
+    script = tmp_path / "timeout_worker.py"
+    script.write_text(TIMEOUT_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", EVC_DP_TIMEOUT_S="4")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29537", str(script)],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert "rank0-timeout-after" in r.stdout and "no-timeout" not in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    waited = float(r.stdout.split("rank0-timeout-after-")[1].split("s")[0])
+    assert 2.0 <= waited <= 11.0, r.stdout

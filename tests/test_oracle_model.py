@@ -165,6 +165,41 @@ def test_known_answer_initial_losses():
     assert out["pred_loss"] / B < 0.01                                 # L_PRED 0.01 at B=256 => tiny per video
     assert 0.0 < out["student_loss_state"] < 10.0   # L_REP 1.16 in the log on real data; data-dependent
 
+def test_known_answer_second_logged_iteration():
+    """README.md:116,121 - the only reference-held evidence about the UPDATE (cs/train.py:329-334,413-418,516-533): after one
+    iteration (both train ops, per-tensor clip_by_norm(1.0) + Adam(1e-3)) on a fresh batch of 256 the log reads
+
+        training step 2| ... Teacher_Loss: 1914.09| L_REP: 1.16| L_PRED: 0.01| L_CE: 1914.1
+        training step 4| ... Teacher_Loss: 1908.12| L_REP: 1.52| L_PRED: 0.01| L_CE: 1913.41
+
+    i.e. the teacher's CE falls by ~6, the student's several times less (~0.7: its clipped update also serves 2 L_REP + L_PRED),
+    L_REP rises (the towers move apart once both are updated), L_PRED stays ~0, and `global_step` advances by 2 per iteration
+    (both create_train_op's increment the shared counter).  Two iterations of the CPU restatement (oracle/torch_cpu.py) on fresh
+    synthetic batches reproduce that pattern; the magnitudes are data-dependent (the log is YouTube-8M at batch 256, this is
+    uint8-uniform noise at batch 16), so the assertions are the signs and the ordering, with loose bands around the logged sizes."""
+    from oracle import torch_cpu as tc
+    torch.set_num_threads(min(8, torch.get_num_threads()))
+    rng = np.random.default_rng(5)
+    teacher = tc.to_torch(mm.init_hlstm_params(rng, dtype=np.float32))
+    student = tc.to_torch(mm.init_hlstm_params(rng, dtype=np.float32))
+    opt_t, opt_s = tc.Adam(teacher, lr=1e-3), tc.Adam(student, lr=1e-3)
+    B, logged, global_step = 16, [], 0
+    for it in range(2):
+        _, x, n, y = mm.synthetic_batch(B, seed=100 + it, dtype=np.float32)      # a FRESH batch per iteration, like the input queue
+        out = tc.teacher_student_iteration(torch.from_numpy(x), n, torch.from_numpy(y.astype(np.float32)), teacher, student, 10,
+                                           opt_t, opt_s)
+        global_step += 2                                                         # two train ops per sess.run (Appendix D-2)
+        logged.append((global_step, out["label_loss"], out["student_loss_state"], out["pred_loss"] / B, out["student_label_loss"]))
+    (s0, t0, rep0, kl0, ce0), (s1, t1, rep1, kl1, ce1) = logged
+    print("iteration log (global_step, Teacher_Loss, L_REP, L_PRED per video, L_CE):", logged)
+    assert (s0, s1) == (2, 4) and opt_t.t == 2 and opt_s.t == 2
+    assert abs(t0 - 1914.1) / 1914.1 < 0.005 and abs(ce0 - 1914.1) / 1914.1 < 0.005      # README.md:116
+    d_teacher, d_student = t0 - t1, ce0 - ce1
+    assert 1.0 < d_teacher < 40.0, d_teacher                  # logged: 5.97
+    assert 0.0 < d_student < d_teacher / 2.5, (d_student, d_teacher)     # logged: 0.69 = 8.7x less
+    assert rep1 > rep0 > 0.0                                  # logged: 1.16 -> 1.52
+    assert 0.0 <= kl0 < 0.01 and 0.0 <= kl1 < 0.05            # logged 0.01 for the batch SUM of 256 videos
+
 
 def test_every_n_index_lists_and_counts():
     assert mm.every_n_indices(10) == list(range(0, 300, 10)) and len(mm.every_n_indices(10)) == 30  # README.md:100-102
