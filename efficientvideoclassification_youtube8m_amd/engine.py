@@ -117,6 +117,26 @@ class LstmStack:
     bwd_fuse = os.environ.get("EVC_BWD_FUSE", "off")
     bwd_wavefront = True          # (tests toggle this to compare the fused forms against the hoisted one)
     timing = None      # set to a list to collect (start event, end event, launches, algorithmic flops) per layer forward
+    timing_bwd = None  # set to {"bwd_step": [], "dx_nt": [], "wgrad_tn": []} to collect the same per backward launch sequence
+
+    def _timed(self, kind, launches, flops, stream=None):
+        """Context manager: HIP events on `stream` (default: current) around a launch sequence, kept in timing_bwd[kind]."""
+        stack = self
+
+        class _T:
+            def __enter__(self_):
+                self_.on = stack.timing_bwd is not None and kind in stack.timing_bwd
+                if self_.on:
+                    self_.e0 = torch.cuda.Event(enable_timing=True)
+                    self_.e0.record(stream) if stream is not None else self_.e0.record()
+
+            def __exit__(self_, *exc):
+                if self_.on:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record(stream) if stream is not None else e1.record()
+                    stack.timing_bwd[kind].append((self_.e0, e1, launches, flops))
+                return False
+        return _T()
 
     @staticmethod
     def _v(buf, *shape):
@@ -311,18 +331,22 @@ class LstmStack:
             gb = tw.store.g(bn)                                     # bias gradient: summed inside the step kernels
             ops.fill_f32(gb, 0.0)
             fused = fuse_ok and self.bwd_fuse == "fused" and l + 1 < L
-            ops.lstm_layer_bwd(w, self.lens, T, M, kin, H, self._v(self.gates[l], T, M, H, 2), self._v(self.c_all[l], T + 1, M, H),
-                               dS[:, (2 * l) * H:], dS[:, (2 * l + 1) * H:], 2 * L * H,
-                               dh_above, self._v(self.dc_ws, M, H), dz, plan=plan, db=gb,
-                               dz_above=self._v(self.dz[l + 1], T, M, 4 * H) if fused else None,
-                               w_above=tw.shadow_bwd[self.names(l + 1)[0]] if fused else None)
+            rows = plan.rows if plan is not None else [M] * T
+            # BPTT step t contracts dh_t = dz_{t+1} . Wh^T over the rows live at t+1 (the last step has no recurrent product)
+            with self._timed("bwd_step", sum(1 for r in rows if r > 0), sum(2.0 * r * H * 4 * H for r in rows[1:])):
+                ops.lstm_layer_bwd(w, self.lens, T, M, kin, H, self._v(self.gates[l], T, M, H, 2), self._v(self.c_all[l], T + 1, M, H),
+                                   dS[:, (2 * l) * H:], dS[:, (2 * l + 1) * H:], 2 * L * H,
+                                   dh_above, self._v(self.dc_ws, M, H), dz, plan=plan, db=gb,
+                                   dz_above=self._v(self.dz[l + 1], T, M, 4 * H) if fused else None,
+                                   w_above=tw.shadow_bwd[self.names(l + 1)[0]] if fused else None)
             dz2 = dz.view(T * M, 4 * H)
             # gradient wrt the layer input, all T at once (hoisted): dX = dz . Wx^T
             if l > 0 and fuse_ok and self.bwd_fuse == "fused":
                 pass                                                # contracted inside layer l-1's steps (dz_above)
             elif l > 0:
                 dxl = self._v(self.dx[l], T * M, kin)
-                ops.gemm_nt(dz2, w, T * M, kin, 4 * H, dxl)
+                with self._timed("dx_nt", 1, 2.0 * T * M * kin * 4 * H):
+                    ops.gemm_nt(dz2, w, T * M, kin, 4 * H, dxl)
                 dh_above = dxl
             elif need_dx:
                 if self.dx[0] is None:
@@ -346,7 +370,8 @@ class LstmStack:
                     # tiles are added with atomics: one contiguous fill of the whole gradient, then accumulate
                     # (instead of a pitched 2-D memset inside each call).
                     ops.fill_f32(gW, 0.0)
-                    self._wgrad_tn(dz2, layer_in, h_prev, kin, T * M, gW)
+                    with self._timed("wgrad_tn", 1, 2.0 * T * M * 4 * H * (kin + H), stream=side):
+                        self._wgrad_tn(dz2, layer_in, h_prev, kin, T * M, gW)
                 else:   # T*M not a multiple of 32: transposed copies + NT products
                     ops.transpose_to_bf16(dz2, T * M, 4 * H, self.dzT, KP, interleave_H=-H)
                     inT = self.xT[:kin]

@@ -325,3 +325,41 @@ def test_process_group_timeout_ends_a_wedged_collective(tmp_path):
     assert "rank0-timeout-after" in r.stdout and "no-timeout" not in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
     waited = float(r.stdout.split("rank0-timeout-after-")[1].split("s")[0])
     assert 2.0 <= waited <= 11.0, r.stdout
+
+
+def test_bench_rank_supervisor_falls_back_to_the_serial_placement(tmp_path, monkeypatch, capfd):
+    """bench.py under N > 1: each rank's supervisor (a process that never touches the GPU) runs the benchmark in a child and, when
+    that child dies or overstays its wall limit, starts one more child with EVC_DP_SERIAL_COMM=1 on another rendezvous port -
+    exercised here with stand-in children: one that fails fast, one that hangs, one that succeeds at once."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    child = tmp_path / "child.py"
+    child.write_text("import os, sys, time\n"
+                     "mode = sys.argv[1]\n"
+                     "serial = os.environ.get('EVC_DP_SERIAL_COMM') == '1'\n"
+                     "assert os.environ['EVC_BENCH_CHILD'] == '1'\n"
+                     "print('child attempt', os.environ['EVC_BENCH_ATTEMPT'], 'serial', serial, 'port', os.environ['MASTER_PORT'],\n"
+                     "      'agent_store', os.environ.get('TORCHELASTIC_USE_AGENT_STORE'), flush=True)\n"
+                     "if mode == 'ok' or serial:\n"
+                     "    sys.exit(0)\n"
+                     "if mode == 'hang':\n"
+                     "    time.sleep(60)\n"
+                     "sys.exit(3)\n")
+    monkeypatch.setenv("MASTER_PORT", "29600")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("TORCHELASTIC_USE_AGENT_STORE", "True")
+    monkeypatch.setenv("EVC_BENCH_ATTEMPT_S", "3")
+    monkeypatch.delenv("EVC_DP_SERIAL_COMM", raising=False)
+    assert bench.supervise_ranks(["ok"], script=str(child)) == 0
+    out = capfd.readouterr()
+    assert out.out.count("child attempt") == 1 and "attempt 0 serial False port 29600 agent_store True" in out.out
+    for mode in ("fail", "hang"):
+        assert bench.supervise_ranks([mode], script=str(child)) == 0
+        out = capfd.readouterr()
+        assert "attempt 0 serial False port 29600" in out.out and "attempt 1 serial True port 29617 agent_store None" in out.out, out.out
+        assert "retrying with the serial placement" in out.err
+    monkeypatch.setenv("EVC_DP_SERIAL_COMM", "1")            # already conservative: one attempt only
+    assert bench.supervise_ranks(["ok"], script=str(child)) == 0
+    assert capfd.readouterr().out.count("child attempt") == 1

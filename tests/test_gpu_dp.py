@@ -92,6 +92,38 @@ def test_two_rank_data_parallel_matches_single_process(tmp_path, serial):
     print("max weight difference single vs 2-rank:", worst)
 
 
+def test_two_rank_bf16_gradient_payload_bounds_its_effect_on_the_update(tmp_path):
+    """EVC_DP_GRAD_DTYPE=bf16: the LSTM gradient segments cross the fabric as bf16 (half the bytes: for the configurations whose
+    step is shorter than their f32 all-reduce, cfg 5).  Each rank's gradient is rounded once (2^-9 relative) before the sum.
+    What that does to the update, two iterations of Adam(1e-3) against the f32-payload run on the same two ranks: Adam's first
+    steps move every weight by ~lr * sign(g), so an element whose summed gradient is smaller than the rounding of its two
+    summands can flip and land a whole update (1e-3 per iteration) away - the MAX difference is therefore of the order of
+    the update itself; the bound that means something is how many elements do that and the RMS: asserted < 2 % of the
+    elements further than 2e-4 (the f32 two-rank tolerance) and an RMS difference below 15 % of one update (5 % / 20 % for the
+    bias vectors, 256 elements each, where two or three flipped elements already show)."""
+    f32, b16 = str(tmp_path / "f32.pt"), str(tmp_path / "bf16.pt")
+    _run(2, f32, 29641)
+    _run(2, b16, 29642, env={"EVC_DP_GRAD_DTYPE": "bf16"})
+    a, b = torch.load(f32), torch.load(b16)
+    assert a["global_step"] == b["global_step"] == 4
+    for k in ("label_loss", "student_loss_state", "pred_loss", "student_label_loss"):
+        assert abs(a["losses"][k] - b["losses"][k]) <= 2e-3 * abs(a["losses"][k]) + 1e-6, (k, a["losses"], b["losses"])
+    worst, moved, report = 0.0, 0, {}
+    for k, v in a.items():
+        if torch.is_tensor(v) and v.dtype == torch.float32 and v.numel() > 1:
+            d = (v - b[k]).abs()
+            worst = max(worst, d.max().item())
+            moved += int(d.max().item() > 0)
+            far = float((d > 2e-4).float().mean())
+            rms = float(d.square().mean().sqrt())
+            report[k.split("/", 1)[1]] = (round(far, 5), rms)
+            assert d.max().item() < 2.5e-3, (k, d.max().item())               # at most a flipped update in both iterations
+            small = v.numel() < 10000
+            assert far < (0.05 if small else 0.02) and rms < (2e-4 if small else 1.5e-4), (k, far, rms)
+    assert moved > 0, "the bf16 payload changed nothing: the option did not reach the reducer"
+    print("f32 vs bf16 gradient payload after two iterations: max |dw| %.2e; (share > 2e-4, rms) per tensor: %s" % (worst, report))
+
+
 def test_bench_multi_rank_path_runs(tmp_path):
     """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank),
     here with two ranks sharing the GPU over gloo: rank 0 prints the one JSON line with whole-job throughput."""
@@ -108,6 +140,14 @@ def test_bench_multi_rank_path_runs(tmp_path):
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 32 and d["value"] > 0 and d["scaling"] == "weak"
     assert abs(d["value"] - 2 * 16 * 300 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert all(np.isfinite(v) for v in d["losses"].values())
+    # the N > 1 line names the placement of the collectives and accounts for what they move (per step, rank 0)
+    dp = d["dp"]
+    assert dp["world"] == 2 and dp["attempt"] == 0 and dp["grad_dtype"] == "f32" and "two communicators" in dp["placement"]
+    col = dp["collectives"]
+    lstm_params = 17309696 + 29368320                                  # L1 + L2 kernels and biases of one tower
+    assert abs(col["all_reduce_grad_f32"]["payload_mb_per_step"] - 2 * lstm_params * 4 / 1e6) < 0.5      # both towers, f32
+    assert col["all_gather_slabs"]["calls_per_step"] == 4 and col["all_gather_factors"]["calls_per_step"] == 6
+    assert dp["wire_mb_per_rank_per_step"] > 0 and dp["collective_event_ms_per_step"] > 0
 
 
 def test_train_main_two_ranks(tmp_path):
