@@ -513,11 +513,30 @@ def dbof_fwd(x, num_frames, uniform, params, num_mixtures=2):
     return pred, cache
 
 
-def dbof_bwd(dpred, cache):
+def dbof_bwd(dpred, cache, routing=None):
+    """routing (tests only): (argmax [B, C] int, cluster relu6 mask at the selected entries [B, C] bool, hidden relu6 mask [B, Hd]
+    bool) - the discrete decisions of ANOTHER implementation of the same forward.  relu6 kinks and max-pool ties are decided on
+    values that differ by that implementation's rounding; with its decisions imposed the two gradients are the same smooth
+    function and can be compared tightly (the decisions themselves are compared separately, against the margins)."""
     idx, r, r_bn, c_in, act_bn, c_cl, am, pooled, hid_bn, c_h, h6, c_moe, (B, S, C), params = cache
     g = {}
     dh6, g["classifier/gates/weights"], g["classifier/experts/weights"], g["classifier/experts/biases"] = \
         moe_bwd(dpred, c_moe)
+    if routing is not None:
+        am_r, mask_sel, mask_h = routing
+        dhid_bn = dh6 * mask_h
+        dhid, g["hidden1_bn/gamma"], g["hidden1_bn/beta"] = batch_norm_train_bwd(dhid_bn, c_h)
+        g["hidden1_weights"] = pooled.T @ dhid
+        dpooled = dhid @ params["hidden1_weights"].T
+        da3 = np.zeros((B, S, C), dpooled.dtype)
+        bi, ci = np.meshgrid(np.arange(B), np.arange(C), indexing="ij")
+        da3[bi, am_r, ci] = dpooled * mask_sel
+        dact_bn = da3.reshape(B * S, C)
+        dact, g["cluster_bn/gamma"], g["cluster_bn/beta"] = batch_norm_train_bwd(dact_bn, c_cl)
+        g["cluster_weights"] = r_bn.T @ dact
+        dr_bn = dact @ params["cluster_weights"].T
+        _, g["input_bn/gamma"], g["input_bn/beta"] = batch_norm_train_bwd(dr_bn, c_in)
+        return g
     dhid_bn = dh6 * ((hid_bn > 0) & (hid_bn < 6))
     dhid, g["hidden1_bn/gamma"], g["hidden1_bn/beta"] = batch_norm_train_bwd(dhid_bn, c_h)
     g["hidden1_weights"] = pooled.T @ dhid

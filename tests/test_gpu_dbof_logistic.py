@@ -26,10 +26,16 @@ def _rel(a, b):
 @pytest.mark.parametrize("B,F,C,Hd,V,S,tol", [(6, 64, 128, 64, 40, 8, 8e-3), (9, 128, 256, 64, 33, 30, 8e-3),
                                                  (64, 1152, 8192, 1024, 4716, 30, 5e-3)])
 def test_dbof_forward_backward(B, F, C, Hd, V, S, tol):
-    """DBoF feeds O(1) batch-normalised activations and O(1/sqrt(K)) weights to the bf16 GEMMs,
-    so the 2^-9 operand rounding shows up at ~2e-3 in the probabilities (measured 2.3e-3 at the
-    BASELINE cfg-4 dims).  This is ABOVE north_star's 1e-3: DESIGN.md lists it as an open gap
-    (split-bf16 parity mode).  The tolerance here pins the current behaviour."""
+    """DBoF feeds O(1) batch-normalised activations and O(1/sqrt(K)) weights to the bf16 GEMMs, so the 2^-9 operand rounding
+    shows up at ~2e-3 in the probabilities (measured 2.3e-3 at the BASELINE cfg-4 dims) - above north_star's 1e-3; the
+    "high" (split-bf16) forward checked at the end of this test closes that gap (5.6e-6 at cfg-4 dims) and is what bench.py
+    times as other_configs.cfg4.high.  `tol` pins the bf16 behaviour.
+
+    Gradients: relu6 kinks and max-pool ties are DECISIONS taken on values that carry the forward's bf16 rounding; one flipped
+    decision moves a whole dy.  So (1) the tower's decisions (argmax frame per (video, cluster), relu6 masks of both layers) are
+    compared with the oracle's: they may differ only where the oracle's margin is within the rounding of the compared values
+    (0.06 on O(1..6) activations) and on few entries; (2) the gradients are compared with the oracle's reverse mode run on the
+    TOWER'S decisions - the same smooth function on both sides - at relative L2 < 3e-2 per tensor."""
     from efficientvideoclassification_youtube8m_amd.towers import DbofTower
     rng = np.random.default_rng(B + C)
     q, x, n, labels = mm.synthetic_batch(B, seed=B, feature_size=F, vocab_size=V, dtype=np.float32)
@@ -47,19 +53,48 @@ def test_dbof_forward_backward(B, F, C, Hd, V, S, tol):
     err = np.abs(_np(pred) - ref_pred).max()
     print('dbof pred err %.2e' % err)
     assert err < tol
+    # ---- (1) the discrete decisions -------------------------------------------------------------------------------
+    act_bn, am_ref, pooled_ref, hid_bn = cache[4], cache[6], cache[7], cache[8]
+    a3 = mm.relu6(act_bn).reshape(B, S, C)
+    am_gpu = tw.arg.cpu().numpy().astype(np.int64)[:B, :C]
+    pooled_gpu, h6_gpu = _np(tw.pooled), _np(tw.h6)
+    bi, ci = np.meshgrid(np.arange(B), np.arange(C), indexing="ij")
+    differ = am_gpu != am_ref
+    margin = pooled_ref - a3[bi, am_gpu, ci]                  # how far below the oracle's maximum the tower's choice lies
+    assert margin.min() >= 0.0 and float(differ.mean()) < 0.05, float(differ.mean())
+    assert margin[differ].max(initial=0.0) < 0.06, margin[differ].max(initial=0.0)       # only near-ties (or saturated: both 0 / 6)
+    mask_sel_ref = (pooled_ref > 0) & (pooled_ref < 6)
+    mask_sel_gpu = (pooled_gpu > 0) & (pooled_gpu < 6)
+    dk = np.minimum(np.abs(pooled_ref), np.abs(pooled_ref - 6.0))                         # distance of the oracle's value to a kink
+    flips = mask_sel_gpu != mask_sel_ref
+    assert float(flips.mean()) < 0.02 and dk[flips].max(initial=0.0) < 0.06, (float(flips.mean()), dk[flips].max(initial=0.0))
+    mask_h_ref = (hid_bn > 0) & (hid_bn < 6)
+    mask_h_gpu = (h6_gpu > 0) & (h6_gpu < 6)
+    dkh = np.minimum(np.abs(hid_bn), np.abs(hid_bn - 6.0))
+    flips_h = mask_h_gpu != mask_h_ref
+    assert float(flips_h.mean()) < 0.02 and dkh[flips_h].max(initial=0.0) < 0.06, (float(flips_h.mean()), dkh[flips_h].max(initial=0.0))
+    # ---- (2) the gradients on the tower's decisions ------------------------------------------------------------------
     dp = mm.cross_entropy_grad(ref_pred, labels)
     tw.backward(torch.from_numpy(dp.astype(np.float32)).to(DEV))
-    gref = mm.dbof_bwd(dp, cache)
+    gref = mm.dbof_bwd(dp, cache, routing=(am_gpu, mask_sel_gpu, mask_h_gpu))
+    gplain = mm.dbof_bwd(dp, cache)
+    worst = {}
     for k, g in gref.items():
         got = tw.store.g(k)
         got = _np(got.t() if got.dim() == 2 else got)
-        # relu6 / max-pool masks can flip on values within bf16 rounding of 0, 6 or a tie, which moves
-        # single entries by a whole dy; judge each tensor by its relative L2 error (some are
-        # analytically zero: cluster_bn/beta is cancelled by hidden1_bn's mean subtraction).
+        scale = np.linalg.norm(gplain[k]) + np.linalg.norm(g)
+        if k.endswith("/beta"):
+            # A beta of a batch-norm that feeds matmul + batch-norm is cancelled by the next layer's mean subtraction wherever
+            # the relu6 in between does not saturate: its gradient is a sum of terms that cancel - analytically zero for
+            # input_bn (the tower writes exact zeros), zero or small for cluster_bn depending on the masks.
+            # Judge it on the scale of the same layer's gamma gradient (the same terms without the cancellation).
+            ref_scale = max(np.abs(g).max(), np.abs(gref[k[:-5] + "/gamma"]).max())
+            assert np.abs(got - g).max() < 3e-2 * ref_scale, (k, np.abs(got - g).max(), ref_scale)
+            continue
         l2 = float(np.linalg.norm(got - g) / (np.linalg.norm(g) + 1e-30))
-        # (1% flipped relu6 masks = 10% relative L2; the kernels themselves are checked to 1e-4 in
-        #  test_gpu_kernels.py::test_batchnorm_relu6_pool_kernels)
-        assert l2 < 0.3 or np.abs(got - g).max() < 2e-3, (k, l2, np.abs(got - g).max())
+        worst[k] = round(l2, 4)
+        assert l2 < 3e-2, (k, l2, np.abs(got - g).max())
+    print("dbof gradient relative L2 on the tower's routing:", worst)
     # moving averages: moving -= (1-0.999)*(moving - batch)
     mu = cache[3][3]
     assert np.allclose(_np(tw.buffers["input_bn/moving_mean"]), 0.001 * mu, rtol=1e-3, atol=1e-7)

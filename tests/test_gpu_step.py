@@ -170,7 +170,8 @@ def test_real_dims_trained_magnitude_weights_both_precision_modes():
     * "bf16" (one MFMA product: the mode of bench.py's headline figure, which north_star prescribes) is bounded
       RELATIVE to the logit magnitude: 2^-9 operand rounding over a K=4096..5120 contraction gives ~1e-3 * |z|, i.e.
       it meets the absolute 1e-3 only while |logits| <~ 1 (the reference's initialisation: 5e-5) - asserted here
-      as 4e-3 * max(1, |z|_max) so that a regression shows, and printed."""
+      as 2.5e-3 * max(1, |z|_max) so that a regression shows (measured over the boxes and the run-to-run different weights of
+      round 3: 1.3e-3 .. 1.9e-3 of |z|_max on the logits), and printed."""
     from efficientvideoclassification_youtube8m_amd import smoke
     from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
     B = 4
@@ -212,7 +213,7 @@ def test_real_dims_trained_magnitude_weights_both_precision_modes():
     for k, v in errs["high"].items():
         assert v < 1e-3, ("high", k, v)
     for k, v in errs["bf16"].items():
-        bound = 4e-3 * max(1.0, zmax if "logits" in k else (smax if "state" in k else 1.0))
+        bound = 2.5e-3 * max(1.0, zmax if "logits" in k else (smax if "state" in k else 1.0))
         bound = max(bound, 1e-2) if "state" in k else bound          # (cell states integrate the per-step rounding)
         assert v < bound, ("bf16", k, v, bound)
     assert all(errs["high"][k] < errs["bf16"][k] for k in errs["high"])
