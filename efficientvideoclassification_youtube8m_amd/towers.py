@@ -15,11 +15,22 @@ from . import ops
 from .engine import BF16, F32, MoeHead, TowerBase
 
 
+_reducers = {}
+
+
 def _maybe_allreduce(t, group):
+    """SUM of the f64 batch-norm partial sums over the ranks (SyncBN), in place; returns the world size.  Goes through a
+    distill.GradReducer of the group like every other collective of a step: in stream order on the current stream by default,
+    funnelled through the process-wide serial stream under EVC_DP_SERIAL_COMM=1 (so that mode really has ONE collective in
+    flight at a time, SyncBN included), and counted in GradReducer.stats."""
     if torch.distributed.is_available() and torch.distributed.is_initialized() and \
             torch.distributed.get_world_size(group) > 1:
-        torch.distributed.all_reduce(t, group=group)
-        return torch.distributed.get_world_size(group)
+        from .distill import GradReducer                     # (distill imports this module's towers lazily too)
+        red = _reducers.get(id(group))
+        if red is None:
+            red = _reducers[id(group)] = GradReducer(group)
+        red.all_reduce_small(t)
+        return red.world
     return 1
 
 
