@@ -1241,7 +1241,8 @@ struct LstmBwdParams {
   const bf16_t* c_new; const bf16_t* c_old;   // slabs t+1 / t of the bf16 cell-state history (c_old == NULL at t == 0)
   const float* dS_c; const float* dS_h; long ld_dS;
   const bf16_t* dh_above;   // slab t [M][H] bf16 (dX of the layer above) or NULL
-  float* dc_ws;             // [M][H]
+  float* dc_ws;             // [M][H] f32 (dc_bf16: the same buffer holding [M][H] bf16): the carried cell-state gradient
+  int dc_bf16;              // 1: dc crosses the launch boundary as bf16 (EVC_BWD_DC_BF16=1: -15 of the step's 113 MB; A/B switch)
   uint2* dz4;               // slab t [M][H] gate-interleaved: 4 bf16 (dz_i, dz_j, dz_f, dz_o) per (row, unit)
   const int* row_map;       // slot -> row of dS_c / dS_h (row plan) or NULL
   float* db;                // [4H] bias gradient (TF gate order), accumulated with atomics over rows and steps, or NULL
@@ -1250,6 +1251,12 @@ struct LstmBwdParams {
   int fused_above;          // 1: the accumulator also holds the gradient from the layer above (second K segment, wavefront):
                             // at a row's last step the final-state gradient is ADDED to it instead of replacing it
 };
+
+static inline int bwd_dc_bf16() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("EVC_BWD_DC_BF16"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v;
+}
 
 // Gate derivative of one (row, 4 consecutive units): dh[4] = what flowed back through the recurrent
 // product; writes dz (4 x 8 bytes), carries dc in dc_ws.
@@ -1277,7 +1284,12 @@ __device__ __forceinline__ void lstm_bwd_load(const LstmBwdParams& e, const int 
     q.dhs = *(const float4*)(e.dS_h + su);        // nothing flows back from later (inactive) steps
     q.dcv = *(const float4*)(e.dS_c + su);
   } else {
-    q.dcv = *(const float4*)(e.dc_ws + hu);
+    if (e.dc_bf16) {
+      const uint2 d = *(const uint2*)((const bf16_t*)e.dc_ws + hu);
+      q.dcv = make_float4(__uint_as_float(d.x << 16), __uint_as_float(d.x & 0xffff0000u), __uint_as_float(d.y << 16), __uint_as_float(d.y & 0xffff0000u));
+    } else {
+      q.dcv = *(const float4*)(e.dc_ws + hu);
+    }
   }
   if (e.dh_above) q.dha = *(const uint2*)(e.dh_above + hu);
   const uint4* gp = (const uint4*)(e.gates + hu);
@@ -1332,7 +1344,8 @@ __device__ __forceinline__ void lstm_bwd_finish(const LstmBwdParams& e, const in
     dzv[r][2] = dc * cp * gf * (1.f - gf); dzv[r][3] = dh[r] * tcv * go * (1.f - go);
     dzr[r] = make_uint2(pack_bf16x2(dzv[r][0], dzv[r][1]), pack_bf16x2(dzv[r][2], dzv[r][3]));
   }
-  *(float4*)(e.dc_ws + hu) = make_float4(dcn[0], dcn[1], dcn[2], dcn[3]);
+  if (e.dc_bf16) *(uint2*)((bf16_t*)e.dc_ws + hu) = make_uint2(pack_bf16x2(dcn[0], dcn[1]), pack_bf16x2(dcn[2], dcn[3]));
+  else *(float4*)(e.dc_ws + hu) = make_float4(dcn[0], dcn[1], dcn[2], dcn[3]);
   dzp[0] = make_uint4(dzr[0].x, dzr[0].y, dzr[1].x, dzr[1].y);
   dzp[1] = make_uint4(dzr[2].x, dzr[2].y, dzr[3].x, dzr[3].y);
 }
@@ -1399,7 +1412,12 @@ __device__ __forceinline__ void lstm_bwd_tail_rowmajor(f32x4 (&acc)[Cfg::MI][1][
           dhs[i] = *(const float2*)(e.dS_h + su);
           dcv[i] = *(const float2*)(e.dS_c + su);
         } else {
-          dcv[i] = *(const float2*)(e.dc_ws + hu);
+          if (e.dc_bf16) {
+            const uint32_t d = *(const uint32_t*)((const bf16_t*)e.dc_ws + hu);
+            dcv[i] = make_float2(__uint_as_float(d << 16), __uint_as_float(d & 0xffff0000u));
+          } else {
+            dcv[i] = *(const float2*)(e.dc_ws + hu);
+          }
         }
         if (e.dh_above) dha[i] = *(const uint32_t*)(e.dh_above + hu);
         grec[i] = *(const uint4*)(e.gates + hu);
@@ -1453,7 +1471,10 @@ __device__ __forceinline__ void lstm_bwd_tail_rowmajor(f32x4 (&acc)[Cfg::MI][1][
     for (int i = 0; i < GROUP; ++i) {
       if (what[i] == 0) continue;
       const long hu = (long)(m0 + (p0 + i) * 8 + wave) * e.H + u;
-      if (what[i] == 2) *(float2*)(e.dc_ws + hu) = dcn[i];
+      if (what[i] == 2) {
+        if (e.dc_bf16) *(uint32_t*)((bf16_t*)e.dc_ws + hu) = pack_bf16x2(dcn[i].x, dcn[i].y);
+        else *(float2*)(e.dc_ws + hu) = dcn[i];
+      }
       *(uint4*)(e.dz4 + hu) = dzr[i];                          // zeros for an inactive row: state passes through, no gate gradient
     }
   }
@@ -1890,6 +1911,7 @@ extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int 
     e.dS_c = dS_c; e.dS_h = dS_h; e.ld_dS = ld_dS;
     e.dh_above = dh_above ? dh_above + (long)t * M * H : nullptr;
     e.dc_ws = dc_ws; e.dz4 = (uint2*)dz4 + (long)t * M * H;
+    e.dc_bf16 = bwd_dc_bf16();
     e.row_map = row_map; e.db = db; e.m_active = Mt;
     e.M = M; e.H = H; e.fused_above = dz_above ? 1 : 0;
     switch (pick) {
@@ -1957,6 +1979,7 @@ extern "C" int evc_lstm_stack2_bwd(const evc_bf16* w_il0, const evc_bf16* w_il1,
     e.dS_c = dS + (long)(2 * layer) * H; e.dS_h = dS + (long)(2 * layer + 1) * H; e.ld_dS = ld_dS;
     e.dh_above = nullptr;
     e.dc_ws = layer ? dc_ws1 : dc_ws0;
+    e.dc_bf16 = bwd_dc_bf16();
     e.dz4 = (uint2*)(layer ? dz1 : dz0) + (long)t * slab;
     e.row_map = row_map; e.db = layer ? db1 : db0;
     e.m_active = rows_per_step ? rows_per_step[t] : M;

@@ -179,6 +179,22 @@ def main():
             ("PLAN c0 x-part x3 + h f16, c1 f16", dict(exact, L1c0=f16h, L1c1="f16")),
             ("PLAN c0 x split only (Wx f16)", dict(exact, L1c0=dict(f16h, wx="f16"), L1c1="f16")),
         ]
+        ex = dict(ax="x3", ah="x3", wx="x3", wh="x3")
+        plan = dict(exact, L1c0=f16h, L1c1="f16")
+        for kind in ("f16", "bf16"):
+            configs += [
+                ("L2 parts %s: c0 x-part" % kind, dict(exact, L2c0=dict(ex, ax=kind, wx=kind))),
+                ("L2 parts %s: c0 h-part" % kind, dict(exact, L2c0=dict(ex, ah=kind, wh=kind))),
+                ("L2 parts %s: c1 x-part" % kind, dict(exact, L2c1=dict(ex, ax=kind, wx=kind))),
+                ("L2 parts %s: c1 h-part" % kind, dict(exact, L2c1=dict(ex, ah=kind, wh=kind))),
+                ("L2 parts %s: all h-parts" % kind, dict(exact, L2c0=dict(ex, ah=kind, wh=kind), L2c1=dict(ex, ah=kind, wh=kind))),
+                ("L2 parts %s: c1 whole" % kind, dict(exact, L2c1=kind)),
+            ]
+        configs += [
+            ("L2 parts PLAN+L2 h-parts f16", dict(plan, L2c0=dict(ex, ah="f16", wh="f16"), L2c1=dict(ex, ah="f16", wh="f16"))),
+            ("L2 parts PLAN+L2 c1 f16, c0 h f16", dict(plan, L2c0=dict(ex, ah="f16", wh="f16"), L2c1="f16")),
+            ("L2 parts PLAN+L2 all f16", dict(plan, L2c0="f16", L2c1="f16")),
+        ]
         if a.only:
             configs = [c for c in configs if a.only in c[0]]
         if a.gpu:
