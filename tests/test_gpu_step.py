@@ -14,6 +14,14 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
+L2_TOL = 1.2e-2     # relative L2 of a gradient tensor: bf16 operands in the backward GEMMs, measured 2e-3 .. 8e-3 (printed by the tests)
+
+
+def _rel2(a, b):
+    """Relative L2 error of a whole tensor (the max-based _rel is dominated by the bf16 rounding of single large entries)."""
+    return float(np.linalg.norm(np.asarray(a, np.float64) - b) / (np.linalg.norm(b) + 1e-30))
+
+
 @pytest.mark.parametrize("batch", [6, 8])     # 6: ragged row counts (NT + transposes); 8: T*M % 32 == 0 (TN weight-gradient GEMMs)
 def test_small_step_forward_backward_update(batch):
     from efficientvideoclassification_youtube8m_amd import smoke
@@ -28,6 +36,7 @@ def test_small_step_forward_backward_update(batch):
                 gref = gref - 2.0 * 1e-8 * smoke.tower_params_numpy(tower)[k]   # l2 term is folded in at apply time
             r = _rel(got[k], gref)
             assert r < 3e-2, (tower.scope, k, r)
+            assert _rel2(got[k], gref) < L2_TOL, (tower.scope, k, _rel2(got[k], gref))
     # apply: per-tensor clip + TF-Adam, global_step += 2
     p_before = {t.scope: smoke.tower_params_numpy(t) for t in (g.teacher, g.student)}
     grads = {t.scope: smoke.tower_grads_numpy(t) for t in (g.teacher, g.student)}
@@ -170,8 +179,8 @@ def test_real_dims_trained_magnitude_weights_both_precision_modes():
     * "bf16" (one MFMA product: the mode of bench.py's headline figure, which north_star prescribes) is bounded
       RELATIVE to the logit magnitude: 2^-9 operand rounding over a K=4096..5120 contraction gives ~1e-3 * |z|, i.e.
       it meets the absolute 1e-3 only while |logits| <~ 1 (the reference's initialisation: 5e-5) - asserted here
-      as 2.5e-3 * max(1, |z|_max) so that a regression shows (measured over the boxes and the run-to-run different weights of
-      round 3: 1.3e-3 .. 1.9e-3 of |z|_max on the logits), and printed."""
+      as 3e-3 * max(1, |z|_max) so that a regression shows (measured over the boxes and the run-to-run different weights of
+      round 3 - the training that produces them sums with atomics -: 1.2e-3 .. 1.9e-3 of |z|_max on the logits), and printed."""
     from efficientvideoclassification_youtube8m_amd import smoke
     from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
     B = 4
@@ -213,7 +222,7 @@ def test_real_dims_trained_magnitude_weights_both_precision_modes():
     for k, v in errs["high"].items():
         assert v < 1e-3, ("high", k, v)
     for k, v in errs["bf16"].items():
-        bound = 2.5e-3 * max(1.0, zmax if "logits" in k else (smax if "state" in k else 1.0))
+        bound = 3e-3 * max(1.0, zmax if "logits" in k else (smax if "state" in k else 1.0))
         bound = max(bound, 1e-2) if "state" in k else bound          # (cell states integrate the per-step rounding)
         assert v < bound, ("bf16", k, v, bound)
     assert all(errs["high"][k] < errs["bf16"][k] for k in errs["high"])
