@@ -164,18 +164,26 @@ def run_hlstm(device, rank, world, B, mode, every_n, steps, warmup, all_full=Fal
         from efficientvideoclassification_youtube8m_amd.distill import serial_comm
         timing, GradReducer.timing = GradReducer.timing, None
         w = max(world, 1)
+        sim = GradReducer._sim() if world == 1 else None
+        if sim is not None:
+            w = sim[3]
         per_kind = {}
         for kind, (calls, nbytes) in sorted(GradReducer.stats.items()):
             ms_k = sum(e0.elapsed_time(e1) for k, _, e0, e1 in timing if k == kind)
+            wire = GradReducer.wire_bytes(kind, nbytes / steps, w)
+            if sim is not None and kind == "all_gather_slabs":
+                wire = (w - 1.0) / w * nbytes / steps
             per_kind[kind] = {"calls_per_step": round(calls / steps, 2), "payload_mb_per_step": round(nbytes / steps / 1e6, 3),
-                              "wire_mb_per_rank_per_step": round(GradReducer.wire_bytes(kind, nbytes / steps, w) / 1e6, 3),
-                              "event_ms_per_step": round(ms_k / steps, 4)}
+                              "wire_mb_per_rank_per_step": round(wire / 1e6, 3), "event_ms_per_step": round(ms_k / steps, 4)}
         res["dp"] = {"placement": "EVC_DP_SERIAL_COMM=1: one communicator, every collective funnelled through one stream" if serial_comm()
                      else "stream order, teacher and student towers on two communicators",
                      "attempt": int(os.environ.get("EVC_BENCH_ATTEMPT", "0")), "grad_dtype": graph.reducer.grad_dtype, "world": world,
                      "collectives": per_kind,
                      "wire_mb_per_rank_per_step": round(sum(v["wire_mb_per_rank_per_step"] for v in per_kind.values()), 2),
                      "collective_event_ms_per_step": round(sum(v["event_ms_per_step"] for v in per_kind.values()), 3),
+                     "sim": None if sim is None else {"busbw_gbps": sim[0], "blocks": sim[1], "lds_kb_per_block": sim[2], "world": sim[3],
+                                                      "what": "one GPU, one-rank communicator: after every collective a stand-in kernel holds `blocks` "
+                                                              "workgroups (256 threads, LDS as given) for wire bytes / busbw + 20 us"},
                      "note": "event_ms = HIP events around each collective on the stream it runs on (rank 0): kernel time incl. waiting for "
                              "the peers; the collectives of the two towers and the compute streams overlap, so the sum is not a share of the step"}
     if roofline and not l1_stack.timing:

@@ -61,6 +61,7 @@ SIGNATURES = {
     "evc_framepool_max_fwd": [vp, i32, i32, i32, vp, vp, vp, vp],
     "evc_framepool_max_bwd": [vp, vp, i32, i32, i32, vp, vp],
     "evc_fill_f32": [vp, i64, f32, vp],
+    "evc_debug_occupy": [i32, i32, i32, C.c_double, vp],
     "evc_lstm_stack2_bwd": [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "evc_netvlad_softmax_fwd": [vp, i32, i32, vp, vp, vp, vp, vp, vp],
     "evc_netvlad_softmax_bwd": [vp, vp, i32, i32, vp, vp],

@@ -1215,3 +1215,25 @@ extern "C" int evc_fill_f32(float* p, int64_t n, float value, void* stream) {
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Measurement aid (scripts/dp_occupancy_sim.sh): a stand-in for a collective's kernel on a one-GPU box.  `blocks`
+// workgroups of `threads` threads, each holding `lds_bytes` of LDS, stay resident for `microseconds` (constant 100 MHz clock) and
+// do nothing else - what an RCCL kernel with that many channels does to the compute streams while its bytes are on the wire: it
+// holds CUs (a workgroup that owns LDS keeps the 160 KB ring tiles of the GEMM kernels off its CU), not HBM bandwidth.
+// ---------------------------------------------------------------------------
+__global__ void occupy_kernel(long long ticks) {
+  extern __shared__ char occ_lds[];
+  if (threadIdx.x == 0) occ_lds[0] = 0;
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+  if (occ_lds[0] == 1) occ_lds[1] = 2;     // (keeps the LDS allocation alive)
+}
+extern "C" int evc_debug_occupy(int blocks, int threads, int lds_bytes, double microseconds, void* stream) {
+  EVC_REQUIRE(blocks > 0 && blocks <= 1024 && threads >= 64 && threads <= 1024 && lds_bytes >= 0 && lds_bytes <= 160 * 1024 && microseconds >= 0,
+              EVC_ERR_BAD_ARG, "evc_debug_occupy: blocks=%d threads=%d lds=%d us=%g", blocks, threads, lds_bytes, microseconds);
+  if (lds_bytes > 64 * 1024) (void)hipFuncSetAttribute((const void*)occupy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(threads), lds_bytes, (hipStream_t)stream, (long long)(microseconds * 100.0));
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}

@@ -92,6 +92,15 @@ class GradReducer:
     timing = None
 
     @staticmethod
+    def _sim():
+        """EVC_DP_SIM=<busbw GB/s>:<blocks>:<LDS KB per block>[:<world>] -> (busbw, blocks, lds_kb, world) or None."""
+        v = os.environ.get("EVC_DP_SIM")
+        if not v:
+            return None
+        f = v.split(":")
+        return float(f[0]), int(f[1]), int(f[2]), int(f[3]) if len(f) > 3 else 8
+
+    @staticmethod
     def wire_bytes(kind, payload, world):
         """Bytes one rank sends (= receives) for a ring collective over `world` ranks: all-reduce 2 (w-1)/w of the payload,
         all-gather (w-1) times its own part (payload = the part this rank contributes)."""
@@ -125,6 +134,23 @@ class GradReducer:
         st = GradReducer.stats.setdefault(kind, [0, 0])
         st[0] += 1
         st[1] += int(nbytes)
+        sim = GradReducer._sim()
+        if sim is not None and self.world == 1 and torch.cuda.is_available():
+            # one-GPU stand-in for the fabric (EVC_DP_SIM, scripts/dp_occupancy_sim.sh): after the (empty) one-rank collective a kernel
+            # with an RCCL-like footprint holds `blocks` CUs for the time the bytes would spend on the wire at `busbw`
+            busbw, blocks, lds_kb, w = sim
+            if kind == "all_gather_slabs":
+                wire = (w - 1.0) / w * nbytes          # (at one rank the "slab" is the whole matrix)
+            else:
+                wire = GradReducer.wire_bytes(kind, nbytes, w)
+            us = wire / (busbw * 1e9) * 1e6 + 20.0       # + a launch / rendezvous latency
+            real = fn
+
+            def fn():
+                out = real()
+                from . import _lib
+                _lib.call("evc_debug_occupy", blocks, 256, lds_kb * 1024, us, torch.cuda.current_stream().cuda_stream)
+                return out
         if GradReducer.timing is not None and torch.cuda.is_available():
             inner = fn
 

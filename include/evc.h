@@ -467,6 +467,9 @@ int evc_netvlad_normalize_bwd(const float* V, const float* n1, const float* n2, 
 
 /* utility: out[i] = value for n floats (avoids torch for tiny fills inside C loops) */
 int evc_fill_f32(float* p, int64_t n, float value, void* stream);
+/* Measurement aid, not part of the path: `blocks` workgroups of `threads` threads with `lds_bytes` of LDS each stay resident for
+ * `microseconds` - the footprint of a collective's kernel on the compute units, for the one-GPU stand-in runs of DESIGN.md 6.1. */
+int evc_debug_occupy(int blocks, int threads, int lds_bytes, double microseconds, void* stream);
 
 #ifdef __cplusplus
 }
