@@ -13,15 +13,14 @@
 #define EVC_TN_LOOP_MODE LOOP_PRODUCER                                      // weight-gradient products: -2 .. -5 %
 #endif
 
-template <class Cfg, int NG, bool SWAP = false, bool SPLIT = false, bool INIT = true, int MODE = EVC_LOOP_MODE_DEFAULT>
+template <class Cfg, int NG, bool SWAP = false, bool INIT = true, int MODE = EVC_LOOP_MODE_DEFAULT>
 __device__ __forceinline__ void run_mainloop(const GemmOperands& p, int m0, int u0, f32x4 (&acc)[Cfg::MI][NG][Cfg::NI]) {
   if constexpr (is_v2<Cfg>::value) {
-    static_assert(!SPLIT, "the split-bf16 parity mode runs on the v1 tiles");
     if constexpr (is_v3<Cfg>::value) gemm_mainloop_v3<Cfg, SWAP, INIT, MODE>(p, m0, u0, lds_dyn, acc);
     else gemm_mainloop_v2<Cfg, SWAP, INIT, MODE>(p, m0, u0, lds_dyn, acc);
   } else {
-    __shared__ __attribute__((aligned(16))) char lds_static[(SPLIT ? 2 : 1) * Cfg::LDS_BYTES];   // static: keeps 2 workgroups per CU
-    gemm_mainloop<Cfg, SWAP, SPLIT, INIT, (MODE & LOOP_F16) != 0>(p, m0, u0, lds_static, acc);
+    __shared__ __attribute__((aligned(16))) char lds_static[Cfg::LDS_BYTES];   // static: keeps 2 workgroups per CU
+    gemm_mainloop<Cfg, SWAP, INIT, (MODE & LOOP_F16) != 0>(p, m0, u0, lds_static, acc);
   }
 }
 
@@ -142,7 +141,7 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_nt_kernel(GemmOperands p, StoreP
   // (same box: L1 dX 477 -> 431 us, 1280 x 4096 x 4096 63 -> 56.5 us, MoE gates forward 48.3 -> 46 us; 5120 x 4096 x 4096 on
   // the 320-row tile 153 -> 162 us with them)
   constexpr int NT_MODE = Cfg::BM == 320 ? 0 : (LOOP_PRODUCER | LOOP_DMA_FIRST | LOOP_NO_PRIO);
-  run_mainloop<Cfg, Cfg::G, V2, false, true, NT_MODE>(p, m0, u0, acc);     // ring tiles: transposed accumulators (lane = one row, 4 consecutive columns)
+  run_mainloop<Cfg, Cfg::G, V2, true, NT_MODE>(p, m0, u0, acc);     // ring tiles: transposed accumulators (lane = one row, 4 consecutive columns)
   if constexpr (V2) {
     // plain overwrite with 16-byte-aligned rows, or the split-K join: through LDS (kernel-uniform conditions: one barrier)
     const int es = s.out_bf16 ? 2 : 4;
@@ -788,7 +787,7 @@ __device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const 
   // (SPLIT: the split-bf16 products hi.hi + hi.lo + lo.hi are a K-EXTENSION of the same loop - the caller hands A = [lo | hi] rows
   //  against B = [W_hi | W_lo] rows as segment 1 and A = hi against B2 = W_hi as segment 2, evc_lstm_layer_fwd_hp - so the loop
   //  itself is the plain one; only the epilogue differs: it writes h_t's wide [lo | hi] image for the next step.)
-  run_mainloop<Cfg, 4, true, false, false, EVC_FWD_LOOP_MODE | (F16 ? LOOP_F16 : 0)>(p, m0, u0, acc);   // transposed accumulators: lane = one row, 4 consecutive units
+  run_mainloop<Cfg, 4, true, false, EVC_FWD_LOOP_MODE | (F16 ? LOOP_F16 : 0)>(p, m0, u0, acc);   // transposed accumulators: lane = one row, 4 consecutive units
 #ifdef EVC_ABLATE_EPI    // debug build: main loop only (keep the accumulators alive, store nothing)
 #pragma unroll
   for (int mi = 0; mi < Cfg::MI; ++mi)
@@ -958,8 +957,7 @@ static inline int pick_fwd_tile(int rows, int H) {
 static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const float* bias, const int32_t* len,
                                int T, int M, int Kin, int H, int hoist, float* zx_ws,
                                evc_bf16* hbuf, float* c_state, float* h_state, int64_t ld_state,
-                               void* gates, evc_bf16* c_all,
-                               const evc_bf16* x_lo, const evc_bf16* wT_lo, evc_bf16* hbuf_lo,
+                               void* gates, evc_bf16* c_all, evc_bf16* hbuf_bf16,
                                const int32_t* row_map, const int32_t* rows_per_step, void* stream, int f16 = 0);
 
 extern "C" int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const float* bias, const int32_t* len,
@@ -968,7 +966,7 @@ extern "C" int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const f
                                   void* gates, evc_bf16* c_all, const int32_t* row_map, const int32_t* rows_per_step,
                                   void* stream) {
   return lstm_layer_fwd_impl(x, wT, bias, len, T, M, Kin, H, hoist, zx_ws, hbuf, c_state, h_state, ld_state, gates, c_all,
-                             nullptr, nullptr, nullptr, row_map, rows_per_step, stream);
+                             nullptr, row_map, rows_per_step, stream);
 }
 
 extern "C" int evc_lstm_layer_fwd_f16(const evc_f16* x, const evc_f16* wT, const float* bias, const int32_t* len,
@@ -978,19 +976,16 @@ extern "C" int evc_lstm_layer_fwd_f16(const evc_f16* x, const evc_f16* wT, const
   EVC_REQUIRE(hbuf_bf16, EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd_f16: hbuf_bf16 (the bf16 copy of h for the backward pass) is required");
   EVC_REQUIRE(((uintptr_t)hbuf_bf16 % 8) == 0, EVC_ERR_BAD_ALIGN, "evc_lstm_layer_fwd_f16: hbuf_bf16 must be 8-byte aligned");
   return lstm_layer_fwd_impl((const evc_bf16*)x, (const evc_bf16*)wT, bias, len, T, M, Kin, H, 0, nullptr, (evc_bf16*)hbuf, c_state, h_state,
-                             ld_state, gates, c_all, nullptr, nullptr, hbuf_bf16, row_map, rows_per_step, stream, 1);
+                             ld_state, gates, c_all, hbuf_bf16, row_map, rows_per_step, stream, 1);
 }
 
 static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const float* bias, const int32_t* len,
                                int T, int M, int Kin, int H, int hoist, float* zx_ws,
                                evc_bf16* hbuf, float* c_state, float* h_state, int64_t ld_state,
-                               void* gates, evc_bf16* c_all,
-                               const evc_bf16* x_lo, const evc_bf16* wT_lo, evc_bf16* hbuf_lo,
+                               void* gates, evc_bf16* c_all, evc_bf16* hbuf_bf16,
                                const int32_t* row_map, const int32_t* rows_per_step, void* stream, int f16) {
-  // f16: x, wT, hbuf hold IEEE f16 (16-bit containers of the same shapes), hbuf_lo receives the bf16 copy of every h_t
-  // (x_lo / wT_lo: unused - the split-bf16 form of a layer is evc_lstm_layer_fwd_hp below)
-  const bool split = false;
-  (void)x_lo; (void)wT_lo;
+  // f16: x, wT, hbuf hold IEEE f16 (16-bit containers of the same shapes), hbuf_bf16 receives the bf16 copy of every h_t
+  // (the split-bf16 form of a layer is evc_lstm_layer_fwd_hp below)
   EVC_REQUIRE(T > 0 && M > 0 && H > 0 && Kin > 0, EVC_ERR_BAD_SHAPE, "evc_lstm_layer_fwd: bad shape");
   EVC_REQUIRE(Kin % 64 == 0 && H % 64 == 0, EVC_ERR_BAD_SHAPE,
               "evc_lstm_layer_fwd: Kin=%d and H=%d must be multiples of 64", Kin, H);
@@ -1011,7 +1006,7 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
   // h_{-1} = 0 (the state buffers need no clearing: step 0 treats c_old as 0 and writes the zero
   // state of the zero-length rows it covers itself; rows beyond rows_per_step[0] are the caller's)
   EVC_CHECK_HIP(hipMemsetAsync(hbuf, 0, (size_t)M * H * sizeof(bf16_t), st));
-  if (split || f16) EVC_CHECK_HIP(hipMemsetAsync(hbuf_lo, 0, (size_t)M * H * sizeof(bf16_t), st));
+  if (f16) EVC_CHECK_HIP(hipMemsetAsync(hbuf_bf16, 0, (size_t)M * H * sizeof(bf16_t), st));
   if (hoist) {
     int rc = evc_gemm_nt(x, Kin, wT, ldw, zx_ws, 4L * H, T * M, 4 * H, Kin, nullptr, 0, 0, stream);
     if (rc) return rc;
@@ -1037,7 +1032,7 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
     e.bias = bias; e.len = len; e.t = t;
     e.c_state = c_state; e.h_state = h_state; e.ld_state = ld_state;
     e.hout = hbuf + (long)(t + 1) * M * H;
-    e.hout_lo = (split || f16) ? hbuf_lo + (long)(t + 1) * M * H : nullptr;
+    e.hout_lo = f16 ? hbuf_bf16 + (long)(t + 1) * M * H : nullptr;
     e.gates = gates ? (uint2*)gates + (long)t * M * H : nullptr;
     e.c_hist = c_all ? c_all + (long)(t + 1) * M * H : nullptr;      // slab t+1 = c after step t
     e.row_map = row_map;
@@ -1514,7 +1509,7 @@ __device__ __forceinline__ void lstm_bwd_step_body(const GemmOperands& p, const 
 #pragma unroll
     for (int ni = 0; ni < Cfg::NI; ++ni) acc[mi][0][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 #else
-  run_mainloop<Cfg, 1, true, false, true, EVC_BWD_LOOP_MODE>(p, m0, u0, acc);     // transposed accumulators: lane = one row, 4 consecutive units
+  run_mainloop<Cfg, 1, true, true, EVC_BWD_LOOP_MODE>(p, m0, u0, acc);     // transposed accumulators: lane = one row, 4 consecutive units
 #endif
 #if !defined(EVC_ABLATE_BWD_EPI) && !defined(EVC_BWD_TAIL_FRAGMENTS)
   if constexpr (is_v2<Cfg>::value && Cfg::BU == 128 && Cfg::NT == 512 && Cfg::BM % 32 == 0 && BATCH_LOADS) {

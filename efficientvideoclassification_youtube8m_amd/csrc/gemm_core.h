@@ -86,14 +86,13 @@ __device__ __forceinline__ int patch_rows(int nwg, int tiles_n) {
 // SWAP = true issues the MFMA with the B fragment as its first operand: the accumulator tile is then
 // TRANSPOSED - lane l holds column (row of A) l&15 and 4 consecutive rows (units of B)
 // (l>>4)*4+reg - so an epilogue that walks units fastest gets 16-byte vector accesses.
-// SPLIT = true also stages the low-order halves (LDS image [A_hi | B_hi | A_lo | B_lo] per stage) and
-// issues hi.hi + hi.lo + lo.hi per tile: f32-operand accuracy at 3x the MFMA work (parity mode).
+// (Split-bf16 products are K-extensions of this same loop since round 3 - evc_gemm_nt_split - on the ring loops; the variant that
+// staged hi and lo halves side by side here is gone.)
 // INIT = false: the caller has pre-loaded the accumulators (e.g. with a bias) - the loop only adds to them.
 // F16 = true: the operands are IEEE f16 (one v_mfma_f32_16x16x32_f16 per depth; not with SPLIT).
-template <class Cfg, bool SWAP = false, bool SPLIT = false, bool INIT = true, bool F16 = false>
+template <class Cfg, bool SWAP = false, bool INIT = true, bool F16 = false>
 __device__ __forceinline__ void gemm_mainloop(const GemmOperands& p, const int m0, const int u0, char* lds,
                                               f32x4 (&acc)[Cfg::MI][Cfg::G][Cfg::NI]) {
-  static_assert(!(SPLIT && F16), "split operands are bf16 halves");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -134,30 +133,17 @@ __device__ __forceinline__ void gemm_mainloop(const GemmOperands& p, const int m
   }
   const bf16_t* a_base;
   const bf16_t* b_base = p.B;
-  long a_lo_delta = 0;                                  // element offset from the hi to the lo array of the current segment
-  const long b_lo_delta = SPLIT ? (p.Blo - p.B) : 0;
   {
     const bool s1 = p.nk1 > 0;
     a_base = s1 ? p.A1 : p.A2;
-    if (SPLIT) a_lo_delta = s1 ? (p.A1lo - p.A1) : (p.A2lo - p.A2);
     const long lda = s1 ? p.lda1 : p.lda2;
 #pragma unroll
     for (int i = 0; i < Cfg::ACH; ++i) a_off[i] = (long)a_row[i] * lda + lc8;
   }
-  constexpr int STAGE_ALL = SPLIT ? 2 * Cfg::STAGE_BYTES : Cfg::STAGE_BYTES;
+  constexpr int STAGE_ALL = Cfg::STAGE_BYTES;
 
   auto stage = [&](int buf) {
     char* sbase = lds + buf * STAGE_ALL;
-    if (SPLIT) {
-#pragma unroll
-      for (int i = 0; i < Cfg::ACH; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + a_lo_delta + a_off[i]),
-                                         (__attribute__((address_space(3))) void*)(sbase + Cfg::STAGE_BYTES + (wave * 64 + i * Cfg::NT) * 16), 16, 0, 0);
-#pragma unroll
-      for (int i = 0; i < Cfg::BCH; ++i)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_base + b_lo_delta + b_off[i]),
-                                         (__attribute__((address_space(3))) void*)(sbase + Cfg::STAGE_BYTES + Cfg::A_BYTES + (wave * 64 + i * Cfg::NT) * 16), 16, 0, 0);
-    }
 #pragma unroll
     for (int i = 0; i < Cfg::ACH; ++i) {
       char* dst = sbase + (wave * 64 + i * Cfg::NT) * 16;  // wave-uniform; HW adds lane*16
@@ -195,7 +181,6 @@ __device__ __forceinline__ void gemm_mainloop(const GemmOperands& p, const int m
     if (kt + 1 < nk) {
       if (kt + 1 == p.nk1) {  // crossing from A1 to A2 (wave-uniform, at most once)
         a_base = p.A2;
-        if (SPLIT) a_lo_delta = p.A2lo - p.A2;
 #pragma unroll
         for (int i = 0; i < Cfg::ACH; ++i) a_off[i] = (long)a_row[i] * p.lda2 + lc8;
       }
@@ -206,32 +191,6 @@ __device__ __forceinline__ void gemm_mainloop(const GemmOperands& p, const int m
     for (int ks = 0; ks < 2; ++ks) {
       const int ch = ((ks * 4 + fq) ^ sw) * 16;
       bf16x8 af[Cfg::MI], bfr[Cfg::G][Cfg::NI];
-      if (SPLIT) {   // low-order products first (smallest terms), then the plain hi.hi pass below
-        bf16x8 al[Cfg::MI], bl[Cfg::G][Cfg::NI];
-#pragma unroll
-        for (int mi = 0; mi < Cfg::MI; ++mi) {
-          af[mi] = *(const bf16x8*)(sb + a_rd[mi] + ch);
-          al[mi] = *(const bf16x8*)(sb + Cfg::STAGE_BYTES + a_rd[mi] + ch);
-        }
-#pragma unroll
-        for (int g = 0; g < Cfg::G; ++g)
-#pragma unroll
-          for (int ni = 0; ni < Cfg::NI; ++ni) {
-            bfr[g][ni] = *(const bf16x8*)(sb + b_rd[g][ni] + ch);
-            bl[g][ni] = *(const bf16x8*)(sb + Cfg::STAGE_BYTES + b_rd[g][ni] + ch);
-          }
-#pragma unroll
-        for (int mi = 0; mi < Cfg::MI; ++mi)
-#pragma unroll
-          for (int g = 0; g < Cfg::G; ++g)
-#pragma unroll
-            for (int ni = 0; ni < Cfg::NI; ++ni) {
-              acc[mi][g][ni] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[g][ni], af[mi], acc[mi][g][ni], 0, 0, 0)
-                                    : __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bl[g][ni], acc[mi][g][ni], 0, 0, 0);
-              acc[mi][g][ni] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[g][ni], al[mi], acc[mi][g][ni], 0, 0, 0)
-                                    : __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bfr[g][ni], acc[mi][g][ni], 0, 0, 0);
-            }
-      }
 #pragma unroll
       for (int mi = 0; mi < Cfg::MI; ++mi) af[mi] = *(const bf16x8*)(sb + a_rd[mi] + ch);
 #pragma unroll
