@@ -363,3 +363,56 @@ def test_bench_rank_supervisor_falls_back_to_the_serial_placement(tmp_path, monk
     monkeypatch.setenv("EVC_DP_SERIAL_COMM", "1")            # already conservative: one attempt only
     assert bench.supervise_ranks(["ok"], script=str(child)) == 0
     assert capfd.readouterr().out.count("child attempt") == 1
+
+
+WORLD4_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+from efficientvideoclassification_youtube8m_amd.distill import GradReducer, dp_loss_scales
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+red = GradReducer(None)
+assert red.active and red.world == 4
+# MoeHead.shard's slab rule with a rank that owns NO rows: V = 300 rows in 128-row tiles over 4 ranks -> 3 tiles, slab = 128:
+# ranks 0, 1 own 128 rows, rank 2 owns 44, rank 3 none (the update kernels are skipped there, the collectives are not)
+V, K = 300, 8
+tiles = (V + 127) // 128
+slab = (tiles + world - 1) // world * 128
+assert slab == 128
+v0 = rank * slab
+vs = min(V, v0 + slab) - v0
+assert vs == [128, 128, 44, -84][rank]
+full = torch.full((slab * world, K), -1.0)
+if vs > 0:
+    full[v0:v0 + vs] = torch.arange(v0, v0 + vs, dtype=torch.float32)[:, None].expand(vs, K)
+red.all_gather_slabs(full, slab)
+assert torch.equal(full[:V, 0], torch.arange(V, dtype=torch.float32))
+sums = torch.tensor([float(max(vs, 0)), 1.0])               # partial norm sums: the empty rank contributes zeros / its share
+red.all_reduce_small(sums)
+assert sums.tolist() == [300.0, 4.0]
+# factor all-gather: rank order along the rows
+t = torch.full((2, 3), float(rank)).to(torch.bfloat16)
+g = red.all_gather_rows(t)
+assert g.shape == (8, 3) and g[:, 0].float().tolist() == [0, 0, 1, 1, 2, 2, 3, 3]
+# loss scales: batch means 1/world, the L_PRED batch sum 1
+sc = dp_loss_scales(world)
+assert sc == {"ce": 0.25, "rep": 0.25, "kl": 1.0}
+assert GradReducer.wire_bytes("all_reduce_grad_f32", 1000.0, world) == 1500.0 and GradReducer.wire_bytes("all_gather_factors", 10.0, world) == 30.0
+dist.destroy_process_group()
+sys.stdout.write("rank" + str(rank) + "-ok\n"); sys.stdout.flush()
+'''
+
+
+def test_sharded_update_collectives_world_4_with_an_empty_rank(tmp_path):
+    """world_size 4 over gloo: the row-slab rule leaves the last rank without rows when the tiles do not go round (V = 300:
+    3 tiles of 128 rows over 4 ranks) - that rank skips the update kernels but takes part in every collective; slabs, norm sums and
+    factor images still assemble correctly on all ranks."""
+    script = tmp_path / "world4_worker.py"
+    script.write_text(WORLD4_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4",
+                        "--master-addr", "127.0.0.1", "--master-port", "29539", str(script)],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("-ok") == 4, r.stdout
