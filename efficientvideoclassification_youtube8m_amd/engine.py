@@ -282,11 +282,14 @@ class LstmStack:
 
     fuse_wgrad = os.environ.get("EVC_NO_FUSED_WGRAD") != "1"
 
-    def backward(self, dS, need_dx, aux=None):
+    def backward(self, dS, need_dx, aux=None, on_layer_grads=None):
         """dS [M, 2LH] f32.  Writes the grads of this stack's kernels/biases into the tower's grad
         buffer; returns dX [T*M, Kin] f32 (gradient wrt the stack input) if need_dx.
         aux: optional side stream for the weight-gradient products, which nothing on the BPTT
-        critical path waits for; the caller joins it before using the gradients."""
+        critical path waits for; the caller joins it before using the gradients.
+        on_layer_grads(l): called on the stream that holds layer l's weight-gradient products, right after they are enqueued -
+        that layer's kernel and bias gradients are final in stream order (the upper layer first): the caller can reduce and
+        apply them there while the lower layer's BPTT still runs."""
         tw, H, L, T, plan = self.tw, self.H, self.L, self.T, self.plan
         M = self.Mrun                                               # rows per time slab in this batch's layout
         assert plan is None or not need_dx, "dX of a row-planned stack would be in slot order"
@@ -321,7 +324,15 @@ class LstmStack:
                     h_prev = self._hb[l][:T].reshape(T * M, H)
                     ops.fill_f32(gW, 0.0)
                     self._wgrad_tn(dz2, layer_in, h_prev, kin, T * M, gW)
+                    if on_layer_grads is not None:
+                        on_layer_grads(l)
             return None
+        if fuse_ok and self.bwd_fuse == "fused" and on_layer_grads is not None:
+            # the lower layer's steps read the upper layer's backward shadow (w_above): no layer may be updated before the end
+            deferred, user_cb = [], on_layer_grads
+            on_layer_grads = deferred.append
+        else:
+            deferred = user_cb = None
         for l in range(L - 1, -1, -1):
             kn, bn = self.names(l)
             w = tw.shadow_bwd[kn]                                   # [kin+H][4H] bf16, 4H axis gate-interleaved
@@ -379,6 +390,11 @@ class LstmStack:
                     ops.transpose_to_bf16(h_prev, T * M, H, self.hT_ws, KP)
                     ops.gemm_nt(self.dzT, inT, 4 * H, kin, KP, gW, ldc=kin + H)
                     ops.gemm_nt(self.dzT, self.hT_ws, 4 * H, H, KP, gW[:, kin:], ldc=kin + H)
+                if on_layer_grads is not None:
+                    on_layer_grads(l)
+                if deferred is not None and l == 0:
+                    for ll in deferred:
+                        user_cb(ll)
         return dx_out
 
 
@@ -919,15 +935,25 @@ class HLstmTower(TowerBase):
                     self.moe.fused_update(self.adam_lr_t(lr), clip, l2c, dp=dp)
                 else:
                     reduce_then_apply(g_moe, seg_moe)
-        dS1 = self.l2.backward(dS2, need_dx=True, aux=aux)              # [C*B][2LH] = d(L1 final state)
-        if aux is not None and early_apply is not None:
-            with torch.cuda.stream(aux):                               # after L2's weight-gradient GEMMs (same stream)
-                reduce_then_apply(g_l2, seg_l2)
-        self.l1.backward(dS1, need_dx=False, aux=aux)
+        # Per LAYER: as soon as a layer's weight-gradient products are enqueued on the aux stream its kernel + bias gradients are
+        # final there - reduce (data parallel) and clip + Adam them right behind, under the BPTT of the layer below.  Only the
+        # LOWEST layer of the L1 level is left for the end of the step (round 3; before, a level's four tensors waited for its
+        # last product: the upper layer's update - and, data parallel, its all-reduce - sat in the serial tail of the step).
+        per_layer = aux is not None and early_apply is not None
+        st = self.store
+
+        def layer_cb(stack):
+            def cb(l):
+                kn, bn = stack.names(l)
+                lo = st.offsets[kn]
+                hi = st.offsets[bn] + _align(int(math.prod(st.shapes[bn])))
+                assert lo < hi and st.offsets[bn] > lo, "a layer's kernel and bias are adjacent in the gradient buffer"
+                reduce_then_apply([kn, bn], (lo, hi))
+            return cb if per_layer else None
+
+        dS1 = self.l2.backward(dS2, need_dx=True, aux=aux, on_layer_grads=layer_cb(self.l2))   # [C*B][2LH] = d(L1 final state)
+        self.l1.backward(dS1, need_dx=False, aux=aux, on_layer_grads=layer_cb(self.l1))
         if aux is not None:
-            if early_apply is not None:
-                with torch.cuda.stream(aux):
-                    reduce_then_apply(g_l1, seg_l1)
             ev = torch.cuda.Event()
             ev.record(aux)
             main.wait_event(ev)
