@@ -149,10 +149,12 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_nt_kernel(GemmOperands p, StoreP
                            (!s.bias || ((uintptr_t)s.bias % 16) == 0);
     const int wave = threadIdx.x >> 6, wc = wave % Cfg::WC;
     const bool wave_cols_in = u0 + wc * Cfg::WU + Cfg::WU <= s.N;         // this wave's column span lies inside C
-    if (s.splits > 1) {
-      __syncthreads();                                                   // every wave has read its last ring slot
-      store_tile_via_lds<Cfg, 4, true>(acc, lds_dyn, s.C, s.ldc, s.M, s.N, m0, u0, split == 0 ? s.bias : nullptr);
-      return;
+    if constexpr (Cfg::WU <= 64) {                                       // (wider wave tiles are never launched with a K split)
+      if (s.splits > 1) {
+        __syncthreads();                                                 // every wave has read its last ring slot
+        store_tile_via_lds<Cfg, 4, true>(acc, lds_dyn, s.C, s.ldc, s.M, s.N, m0, u0, split == 0 ? s.bias : nullptr);
+        return;
+      }
     }
     if (lds_store) {
       __syncthreads();
@@ -322,6 +324,9 @@ extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
   if (forced_tile()) pick = forced_tile();
   static const bool nt_v3 = getenv("EVC_NT_BIG_V2") == nullptr;          // the 224/256-row tiles on two 64-wide stages (A/B switch: the five 32-wide ones)
   static const bool v3 = getenv("EVC_NT_V2_LOOP") == nullptr;      // 64-wide K stages for the 128-column ring tiles (A/B switch)
+#ifdef EVC_EXPERIMENT_4WAVE
+  if (pick == 12) { launch_gemm<TileCfg3<256, 1, 256, 2, 2, 2>>(p, s, K, 1, st); EVC_LAUNCH_CHECK(); return EVC_OK; }   // 4 waves, 128 x 128 per wave
+#endif
   if (pick == 5 && v3) launch_gemm<TileCfg3<128, 1, 128, 2, 4, 4>>(p, s, K, 1, st);
   else if (pick == 5) launch_gemm<CfgTn128>(p, s, K, 1, st);
   else if (pick == 4 && nt_v3) launch_gemm<TileCfg3<224, 1, 256, 2, 4, 2>>(p, s, K, 1, st);
