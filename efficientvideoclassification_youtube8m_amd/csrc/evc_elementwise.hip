@@ -436,6 +436,31 @@ extern "C" int evc_cast_f32_to_f16_wide(const float* in, int64_t ld_in, int R, i
   return EVC_OK;
 }
 
+// IEEE f16 image of an LSTM kernel with BOTH parts K-extended by the weights' low-order halves (evc_lstm_stack2_fwd_f16, upper layer):
+// out row = [f16(Wx) | (Wx - f16(Wx))*64 | f16(Wh) | (Wh - f16(Wh))*64] (2Kin + 2H), in = [Wx(Kin) | Wh(H)] f32.
+__global__ void cast_f16_wlo_kernel(const float* __restrict__ in, long ld_in, int R, int Kin, int H, f16_t* __restrict__ out) {
+  const int C = Kin + H;
+  const long n = (long)R * C, ldo = 2L * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C;
+    const int c = (int)(i % C);
+    const float w = in[r * ld_in + c];
+    const f16_t h = f32_to_f16(w);
+    const f16_t l = f32_to_f16((w - f16_to_f32(h)) * 64.0f);
+    f16_t* o = out + r * ldo;
+    if (c < Kin) { o[c] = h; o[Kin + c] = l; }
+    else { o[2L * Kin + (c - Kin)] = h; o[2L * Kin + H + (c - Kin)] = l; }
+  }
+}
+extern "C" int evc_cast_f32_to_f16_wlo(const float* in, int64_t ld_in, int R, int Kin, int H, evc_f16* out, void* stream) {
+  EVC_REQUIRE(R > 0 && Kin > 0 && H > 0, EVC_ERR_BAD_SHAPE, "evc_cast_f32_to_f16_wlo: bad shape");
+  const long n = (long)R * (Kin + H);
+  const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(cast_f16_wlo_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, ld_in, R, Kin, H, out);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
 // wide split-bf16 image of a [R][C] f32 matrix: out row = [lo | hi] (lo_first, the A operand of evc_gemm_nt_split) or [hi | lo]
 // (its B operand), hi = bf16(x), lo = bf16(x - hi); out rows have ld_out >= 2C elements.
 __global__ void cast_split_wide_kernel(const float* __restrict__ in, long ld_in, int R, int C, bf16_t* __restrict__ out, long ld_out, int lo_first) {

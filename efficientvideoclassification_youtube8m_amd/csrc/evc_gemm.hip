@@ -118,7 +118,7 @@ __device__ __forceinline__ void store_tile_via_lds(f32x4 (&acc)[Cfg::MI][1][Cfg:
   }
 }
 
-template <class Cfg>
+template <class Cfg, bool F16 = false>
 __global__ __launch_bounds__(Cfg::NT) void gemm_nt_kernel(GemmOperands p, StoreParams s, int tiles_m, int tiles_n) {
   const int nwg = tiles_m * tiles_n;
   int bid = blockIdx.x, split = 0;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_nt_kernel(GemmOperands p, StoreP
   // loop options (gemm_core_v2.h): producer waves + LDS-DMA first + no priority flips for every ring tile but the 320-row one
   // (same box: L1 dX 477 -> 431 us, 1280 x 4096 x 4096 63 -> 56.5 us, MoE gates forward 48.3 -> 46 us; 5120 x 4096 x 4096 on
   // the 320-row tile 153 -> 162 us with them)
-  constexpr int NT_MODE = Cfg::BM == 320 ? 0 : (LOOP_PRODUCER | LOOP_DMA_FIRST | LOOP_NO_PRIO);
+  constexpr int NT_MODE = (Cfg::BM == 320 ? 0 : (LOOP_PRODUCER | LOOP_DMA_FIRST | LOOP_NO_PRIO)) | (F16 ? LOOP_F16 : 0);
   run_mainloop<Cfg, Cfg::G, V2, true, NT_MODE>(p, m0, u0, acc);     // ring tiles: transposed accumulators (lane = one row, 4 consecutive columns)
   if constexpr (V2) {
     // plain overwrite with 16-byte-aligned rows, or the split-K join: through LDS (kernel-uniform conditions: one barrier)
@@ -350,6 +350,38 @@ extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
 // index).  Same accumulator, one epilogue, no split-K join - against three launches that each re-staged both operands and
 // joined through C.  Ring tiles only (B2 lives in the v2 / v3 loops).
 // ---------------------------------------------------------------------------
+// C[M,N] f32 = A . B^T on IEEE f16 operands (one f16 MFMA product per depth): the hoisted input projection of the "high" mode's L2
+// level (evc_lstm_stack2_fwd_f16).  Ring tiles, no K split.
+template <class Cfg>
+static inline void launch_gemm_f16(GemmOperands p, StoreParams s, int K, hipStream_t st) {
+  p.nk1 = K / kdiv<Cfg>();
+  const int tm = ceil_div(s.M, Cfg::BM), tn = ceil_div(s.N, Cfg::BU);
+  s.splits = 1; s.ksteps_per_split = p.nk1;
+  launch_cfg<Cfg>(gemm_nt_kernel<Cfg, true>, tm * tn, st, p, s, tm, tn);
+}
+static int gemm_nt_f16(const evc_f16* A, int64_t lda, const evc_f16* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, void* stream) {
+  EVC_REQUIRE(M > 0 && N > 0 && K > 0 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0,
+              EVC_ERR_BAD_SHAPE, "f16 product: M=%d N=%d K=%d (K %% 64), operands 16-byte aligned", M, N, K);
+  EVC_REQUIRE(ring_operand_ok(M, lda) && ring_operand_ok(N, ldb), EVC_ERR_BAD_SHAPE, "f16 product: an operand spans 4 GiB or more");
+  GemmOperands p;
+  p.A1 = (const bf16_t*)A; p.lda1 = lda; p.nk1 = 0; p.A2 = p.A1; p.lda2 = lda; p.nk2 = 0;
+  p.B = (const bf16_t*)B; p.ldb = ldb; p.group_stride = 0; p.M = M; p.Nu = N;
+  p.A1lo = p.A2lo = p.Blo = nullptr;
+  StoreParams s{C, ldc, M, N, nullptr, 0, 0, 1, 0};
+  hipStream_t st = (hipStream_t)stream;
+  const double c320 = tile_cost((long)ceil_div(M, 320) * ceil_div(N, 256), 320, 256, 1, 1.03);
+  const double c256 = tile_cost((long)ceil_div(M, 256) * ceil_div(N, 256), 256, 256, 1, 1.0);
+  const double c160 = tile_cost((long)ceil_div(M, 160) * ceil_div(N, 128), 160, 128, 1, 1.5);
+  const double c128 = tile_cost((long)ceil_div(M, 128) * ceil_div(N, 128), 128, 128, 2, 1.3);
+  const double best = fmin(fmin(c320, c256), fmin(c160, c128));
+  if (best == c320) launch_gemm_f16<CfgPlainV2_320>(p, s, K, st);
+  else if (best == c256) launch_gemm_f16<TileCfg3<256, 1, 256, 2, 4, 2>>(p, s, K, st);
+  else if (best == c160) launch_gemm_f16<TileCfg3<160, 1, 128, 2, 4, 4>>(p, s, K, st);
+  else launch_gemm_f16<TileCfg3<128, 1, 128, 2, 4, 4>>(p, s, K, st);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
 template <class Cfg>
 static inline void launch_gemm_seg(GemmOperands p, StoreParams s, int K, hipStream_t st) {
   p.nk1 = 2 * K / kdiv<Cfg>(); p.nk2 = K / kdiv<Cfg>();
@@ -757,6 +789,8 @@ struct LstmFwdParams {
   bf16_t* c_hist;                    // slab t+1 of the bf16 cell-state history [M][H] (c after this step), or NULL
   const int* row_map;                // slot -> row of c_state / h_state (row plan, evc_sort_rows_by_len) or NULL
   int M, H;
+  int h_wide = 0;                    // F16 only: hout rows are WIDE, [M][2H] = [f16(h_t) | f16(h_t)/64] - the activation operand of a
+                                     // contraction whose weights are K-extended by their low-order halves (evc_lstm_stack2_fwd_f16)
 };
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) { return pack_bf16x2_hw(lo, hi); }
@@ -829,8 +863,10 @@ __device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const 
       if (ln[mi] < 0) continue;
       const long hu = (long)m * H + u;
       const long su = (long)rm[mi] * e.ld_state + u;
+      const long hw = (F16 && e.h_wide) ? (long)m * 2 * H + u : hu;     // (F16: position in a wide h image)
       if (e.t >= ln[mi]) {          // dynamic_rnn: state copied through, zero output
-        *(uint2*)(e.hout + hu) = make_uint2(0u, 0u);
+        *(uint2*)(e.hout + hw) = make_uint2(0u, 0u);
+        if (F16 && e.h_wide) *(uint2*)(e.hout + hw + H) = make_uint2(0u, 0u);
         if (F16) *(uint2*)(e.hout_lo + hu) = make_uint2(0u, 0u);
         if (SPLIT) {
           bf16_t* w = e.hout_lo + (long)m * 2 * H + u;
@@ -871,7 +907,13 @@ __device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const 
       if (e.c_hist) *(uint2*)(e.c_hist + hu) = make_uint2(pack_bf16x2(cn[0], cn[1]), pack_bf16x2(cn[2], cn[3]));
       if (e.t == ln[mi] - 1) *(float4*)(e.h_state + su) = make_float4(hn[0], hn[1], hn[2], hn[3]);
       if (F16) {
-        *(uint2*)(e.hout + hu) = make_uint2(pack_f16x2_hw(hn[0], hn[1]), pack_f16x2_hw(hn[2], hn[3]));
+        const uint32_t p01 = pack_f16x2_hw(hn[0], hn[1]), p23 = pack_f16x2_hw(hn[2], hn[3]);
+        *(uint2*)(e.hout + hw) = make_uint2(p01, p23);
+        if (e.h_wide) {             // f16(h)/64: the operand of the weights' low-order halves (scaled by 64)
+          const float s0 = f16_to_f32((f16_t)(p01 & 0xffffu)) * (1.0f / 64.0f), s1 = f16_to_f32((f16_t)(p01 >> 16)) * (1.0f / 64.0f);
+          const float s2 = f16_to_f32((f16_t)(p23 & 0xffffu)) * (1.0f / 64.0f), s3 = f16_to_f32((f16_t)(p23 >> 16)) * (1.0f / 64.0f);
+          *(uint2*)(e.hout + hw + H) = make_uint2(pack_f16x2_hw(s0, s1), pack_f16x2_hw(s2, s3));
+        }
         *(uint2*)(e.hout_lo + hu) = make_uint2(pack_bf16x2(hn[0], hn[1]), pack_bf16x2(hn[2], hn[3]));
       } else {
         *(uint2*)(e.hout + hu) = make_uint2(pack_bf16x2(hn[0], hn[1]), pack_bf16x2(hn[2], hn[3]));
@@ -902,14 +944,14 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, 
 // rest step b): layer 0 at time t+1 and layer 1 at time t of a two-layer stack with M ~ batch rows - those steps are
 // latency-bound (12 us for 2 GFLOP), so the pair costs about what one of them does and the stack's chain of
 // dependent launches is T+1 long instead of 2T (evc_lstm_stack2_fwd).
-template <class Cfg>
+template <class Cfg, bool F16 = false>
 __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_pair_kernel(GemmOperands pa, LstmFwdParams ea, GemmOperands pb, LstmFwdParams eb,
                                                                 int tiles_m, int tiles_n) {
   const int n = tiles_m * tiles_n;
   const bool first = blockIdx.x < n;                   // workgroup-uniform: scalar selects of the two argument sets
   const GemmOperands p = first ? pa : pb;
   const LstmFwdParams e = first ? ea : eb;
-  lstm_fwd_step_body<Cfg, false>(p, e, tiles_m, tiles_n, first ? blockIdx.x : blockIdx.x - n);
+  lstm_fwd_step_body<Cfg, false, F16>(p, e, tiles_m, tiles_n, first ? blockIdx.x : blockIdx.x - n);
 }
 
 typedef TileCfg<128, 4, 32, 2, 2> CfgLstmBig;    // 128 rows x 32 units x 4 gates
@@ -1156,13 +1198,13 @@ static inline void fwd_step_args(const FwdLayer& L, const int32_t* len, int t, i
   e.M = M; e.H = H;
 }
 
-template <class Cfg>
+template <class Cfg, bool F16 = false>
 static inline void launch_lstm_fwd_pair(GemmOperands pa, const LstmFwdParams& ea, int k1a, int k2a,
                                         GemmOperands pb, const LstmFwdParams& eb, int k1b, int k2b, hipStream_t st) {
   pa.nk1 = k1a / kdiv<Cfg>(); pa.nk2 = k2a / kdiv<Cfg>();
   pb.nk1 = k1b / kdiv<Cfg>(); pb.nk2 = k2b / kdiv<Cfg>();
   const int tm = ceil_div(ea.M, Cfg::BM), tn = ceil_div(ea.H, Cfg::BU);
-  launch_cfg<Cfg>(lstm_fwd_pair_kernel<Cfg>, 2 * tm * tn, st, pa, ea, pb, eb, tm, tn);
+  launch_cfg<Cfg>(lstm_fwd_pair_kernel<Cfg, F16>, 2 * tm * tn, st, pa, ea, pb, eb, tm, tn);
 }
 
 extern "C" int evc_lstm_stack2_fwd(const evc_bf16* x, const evc_bf16* wT0, const float* bias0, const evc_bf16* wT1, const float* bias1,
@@ -1226,6 +1268,82 @@ extern "C" int evc_lstm_stack2_fwd(const evc_bf16* x, const evc_bf16* wT0, const
         default: launch_lstm_fwd<CfgLstmSmall>(p, e, k1, k2, st); break;
       }
     }
+  }
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// evc_lstm_stack2_fwd on IEEE f16 operands, with the UPPER layer's weights K-extended by their low-order halves - the "high"
+// precision form of the L2 level (M = videos).  The error budget (scripts/precision_budget.py) says what this level needs: f16
+// (2^-12) is enough for every activation and for layer 0's weights; the one term it does not cover is the ROUNDING OF THE UPPER
+// LAYER'S WEIGHTS, the same error at every one of the 20 steps into a cell state that integrates it (6e-4 on the states).  So
+// layer 1 contracts [h0_t | h0_t/64 | h1_{t-1} | h1_{t-1}/64] . [Wx | (Wx - f16(Wx))*64 | Wh | (Wh - f16(Wh))*64]^T (K = 4H instead
+// of 2H; split-bf16 would be 6H in three passes), layer 0 runs plain f16 with its x-projection hoisted into one f16 product.
+// h rows are WIDE, [f16(h) | f16(h)/64] (2H), written by the step epilogue together with the bf16 copy the backward pass reads.
+// Same wavefront as evc_lstm_stack2_fwd: launch s = layer 0 step s next to layer 1 step s-1.
+extern "C" int evc_lstm_stack2_fwd_f16(const evc_f16* x, const evc_f16* wT0, const float* bias0, const evc_f16* wT1_wlo, const float* bias1,
+                                       const int32_t* len, int T, int M, int Kin, int H, float* zx_ws,
+                                       evc_f16* h0_wide, evc_f16* h1_wide, evc_bf16* hbuf0, evc_bf16* hbuf1,
+                                       float* c_state0, float* h_state0, float* c_state1, float* h_state1, int64_t ld_state,
+                                       void* gates0, evc_bf16* c_all0, void* gates1, evc_bf16* c_all1, void* stream) {
+  EVC_REQUIRE(T > 0 && M > 0 && H > 0 && Kin > 0 && H % 64 == 0 && Kin % 64 == 0, EVC_ERR_BAD_SHAPE,
+              "evc_lstm_stack2_fwd_f16: bad shape T=%d M=%d Kin=%d H=%d (Kin, H multiples of 64)", T, M, Kin, H);
+  EVC_REQUIRE(x && wT0 && wT1_wlo && zx_ws && h0_wide && h1_wide && hbuf0 && hbuf1, EVC_ERR_BAD_ARG, "evc_lstm_stack2_fwd_f16: NULL operand");
+  EVC_REQUIRE(ring_operand_ok(M, 2L * H) && ring_operand_ok(4L * H, 4L * H) && ring_operand_ok(4L * H, (long)Kin + H), EVC_ERR_BAD_SHAPE,
+              "evc_lstm_stack2_fwd_f16: an operand spans 4 GiB or more");
+  EVC_REQUIRE(ld_state % 4 == 0 && ((uintptr_t)c_state0 % 16) == 0 && ((uintptr_t)h_state0 % 16) == 0 && ((uintptr_t)c_state1 % 16) == 0 &&
+              ((uintptr_t)h_state1 % 16) == 0 && ((uintptr_t)bias0 % 16) == 0 && ((uintptr_t)bias1 % 16) == 0 && ((uintptr_t)h0_wide % 16) == 0 &&
+              ((uintptr_t)h1_wide % 16) == 0 && ((uintptr_t)hbuf0 % 8) == 0 && ((uintptr_t)hbuf1 % 8) == 0, EVC_ERR_BAD_ALIGN,
+              "evc_lstm_stack2_fwd_f16: state/bias/h buffers must allow 16-byte vector access");
+  EVC_REQUIRE((gates0 == nullptr) == (c_all0 == nullptr) && (gates1 == nullptr) == (c_all1 == nullptr) && (gates0 == nullptr) == (gates1 == nullptr),
+              EVC_ERR_BAD_ARG, "evc_lstm_stack2_fwd_f16: gates and c_all go together, for both layers");
+  hipStream_t st = (hipStream_t)stream;
+  EVC_CHECK_HIP(hipMemsetAsync(h0_wide, 0, (size_t)M * 2 * H * sizeof(f16_t), st));        // h_{-1} = 0, both layers, both images
+  EVC_CHECK_HIP(hipMemsetAsync(h1_wide, 0, (size_t)M * 2 * H * sizeof(f16_t), st));
+  EVC_CHECK_HIP(hipMemsetAsync(hbuf0, 0, (size_t)M * H * sizeof(bf16_t), st));
+  EVC_CHECK_HIP(hipMemsetAsync(hbuf1, 0, (size_t)M * H * sizeof(bf16_t), st));
+  int rc = gemm_nt_f16(x, Kin, wT0, (int64_t)Kin + H, zx_ws, 4L * H, T * M, 4 * H, Kin, stream);
+  if (rc) return rc;
+  for (int s = 0; s <= T; ++s) {            // launch s: layer 0 step s next to layer 1 step s-1
+    GemmOperands pa, pb;
+    LstmFwdParams ea, eb;
+    int k1a = 0, k2a = 0, k1b = 0, k2b = 0;
+    const bool has_a = s < T, has_b = s >= 1;
+    if (has_a) {                             // layer 0, step s: zx + h0_{s-1} . Wh0^T (plain f16, K = H of the wide rows)
+      const int t = s;
+      pa.M = M; pa.Nu = H; pa.group_stride = H; pa.ldb = (long)Kin + H; pa.nk1 = pa.nk2 = 0;
+      pa.A1lo = pa.A2lo = pa.Blo = nullptr;
+      const bf16_t* hprev = (const bf16_t*)h0_wide + (long)t * M * 2 * H;
+      pa.A1 = hprev; pa.lda1 = 2L * H; k1a = (t == 0) ? 0 : H; pa.A2 = hprev; pa.lda2 = 2L * H; k2a = 0;
+      pa.B = (const bf16_t*)wT0 + Kin;
+      ea.zx = zx_ws + (long)t * M * 4 * H; ea.ldzx = 4L * H;
+      ea.bias = bias0; ea.len = len; ea.t = t;
+      ea.c_state = c_state0; ea.h_state = h_state0; ea.ld_state = ld_state;
+      ea.hout = (bf16_t*)h0_wide + (long)(t + 1) * M * 2 * H; ea.h_wide = 1;
+      ea.hout_lo = hbuf0 + (long)(t + 1) * M * H;
+      ea.gates = gates0 ? (uint2*)gates0 + (long)t * M * H : nullptr;
+      ea.c_hist = c_all0 ? c_all0 + (long)(t + 1) * M * H : nullptr;
+      ea.row_map = nullptr; ea.M = M; ea.H = H;
+    }
+    if (has_b) {                             // layer 1, step s-1: [h0_t | h0_t/64 | h1_{t-1} | h1_{t-1}/64] . [Wx | Wx_lo*64 | Wh | Wh_lo*64]^T
+      const int t = s - 1;
+      pb.M = M; pb.Nu = H; pb.group_stride = H; pb.ldb = 4L * H; pb.nk1 = pb.nk2 = 0;
+      pb.A1lo = pb.A2lo = pb.Blo = nullptr;
+      pb.A1 = (const bf16_t*)h0_wide + (long)(t + 1) * M * 2 * H; pb.lda1 = 2L * H; k1b = 2 * H;
+      pb.A2 = (const bf16_t*)h1_wide + (long)t * M * 2 * H; pb.lda2 = 2L * H; k2b = (t == 0) ? 0 : 2 * H;
+      pb.B = (const bf16_t*)wT1_wlo;
+      eb.zx = nullptr; eb.ldzx = 0;
+      eb.bias = bias1; eb.len = len; eb.t = t;
+      eb.c_state = c_state1; eb.h_state = h_state1; eb.ld_state = ld_state;
+      eb.hout = (bf16_t*)h1_wide + (long)(t + 1) * M * 2 * H; eb.h_wide = 1;
+      eb.hout_lo = hbuf1 + (long)(t + 1) * M * H;
+      eb.gates = gates1 ? (uint2*)gates1 + (long)t * M * H : nullptr;
+      eb.c_hist = c_all1 ? c_all1 + (long)(t + 1) * M * H : nullptr;
+      eb.row_map = nullptr; eb.M = M; eb.H = H;
+    }
+    if (has_a && has_b) launch_lstm_fwd_pair<CfgLstmV3Small, true>(pa, ea, k1a, k2a, pb, eb, k1b, k2b, st);
+    else if (has_a) launch_lstm_fwd<CfgLstmV3Small, false, true>(pa, ea, k1a, k2a, st);
+    else launch_lstm_fwd<CfgLstmV3Small, false, true>(pb, eb, k1b, k2b, st);
   }
   EVC_LAUNCH_CHECK();
   return EVC_OK;

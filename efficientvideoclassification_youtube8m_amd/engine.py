@@ -169,6 +169,18 @@ class LstmStack:
             # x = (bf16 image, f16 image): the bf16 one and the bf16 copies of h stay the operands of the backward products.
             x_bf, x16 = x
             self.x_in, self.lens = x_bf, lens
+            if self.scope == "RNN_L2" and L == 2 and plan is None:
+                # M ~ batch (the L2 level): wavefront pair launches on f16 operands, the upper layer's weights K-extended by their
+                # low-order halves (ops.lstm_stack2_fwd_f16); wide [h | h/64] f16 images + the bf16 copies for the backward pass
+                if not hasattr(self, "hbuf16w"):
+                    self.hbuf16w = [torch.zeros((self.T + 1, self.M, 2 * H), dtype=ops.F16, device=h.device) for h in self.hbuf]
+                if self.zx is None:
+                    self.zx = torch.empty((self.T * self.M, 4 * H), dtype=F32, device=self.S.device)
+                hw = [self._v(h, T + 1, M, 2 * H) for h in self.hbuf16w]
+                (k0, b0), (k1, b1) = self.names(0), self.names(1)
+                ops.lstm_stack2_fwd_f16(x16, tw.shadow16[k0], tw.store.p(b0), tw.shadow16[k1], tw.store.p(b1), lens, T, M, self.Kin, H,
+                                        self.zx, hw[0], hw[1], hb[0], hb[1], self.S, gates, c_all)
+                return self.S
             if not hasattr(self, "hbuf16"):
                 self.hbuf16 = [torch.zeros(h.shape, dtype=ops.F16, device=h.device) for h in self.hbuf]
             h16 = [self._v(h, T + 1, M, H) for h in self.hbuf16]
@@ -769,7 +781,9 @@ class HLstmTower(TowerBase):
     # ---- "high" precision operands (budget measured by scripts/precision_budget.py) ----------------------
     # L1 level (85 % of the forward flops): IEEE f16 operands, ONE MFMA product per depth; layer 0's x-part as a K-extension
     # over f16_x_segments segments of the input (2: + x_lo . Wx, 3: + x . Wx_lo) - the rounding of the input frames is the
-    # one term of the whole forward that 2^-12 does not cover.  L2 level + MoE head: split-bf16, K-extended loops.
+    # one term of that level that 2^-12 does not cover.  L2 level (two layers): f16 in the wavefront pair launches, the UPPER
+    # layer's weights K-extended by their low-order halves (their rounding is that level's one such term).  MoE head (and an L2
+    # level of any other depth): split-bf16, K-extended loops.
     f16_x_segments = int(os.environ.get("EVC_HIGH_X_SEGMENTS", "2"))
 
     def input_split(self):
@@ -787,6 +801,9 @@ class HLstmTower(TowerBase):
                 nin = shp[1] - H
                 wide = (self.f16_x_segments * nin + H) if "cell_0" in k else shp[1]
                 self.shadow16[k] = torch.zeros((shp[0], wide), dtype=ops.F16, device=dev)
+            elif k.startswith("RNN_L2/") and self.precision == "high" and self.L == 2:
+                # f16 L2 level (ops.lstm_stack2_fwd_f16): layer 0 plain, layer 1 [Wx | Wx_lo*64 | Wh | Wh_lo*64]
+                self.shadow16[k] = torch.zeros((shp[0], shp[1] if "cell_0" in k else 2 * shp[1]), dtype=ops.F16, device=dev)
             elif k.startswith("RNN_L"):                                 # L2 level ("split": the L1 level too)
                 nin = shp[1] - H
                 self.shadow_wx[k] = torch.zeros((shp[0], 2 * nin), dtype=BF16, device=dev)
@@ -796,7 +813,9 @@ class HLstmTower(TowerBase):
 
     def _refresh_high(self, k):
         p, H = self.store.p(k), self.H
-        if k in self.shadow16:
+        if k in self.shadow16 and k.startswith("RNN_L2/") and "cell_1" in k:
+            ops.cast_f16_wlo(p, p.shape[1] - H, H, self.shadow16[k])
+        elif k in self.shadow16:
             nin = p.shape[1] - H
             nseg = (self.shadow16[k].shape[1] - H) // nin
             ops.cast_f16_wide(p, nin, H, nseg, self.shadow16[k])
@@ -865,7 +884,12 @@ class HLstmTower(TowerBase):
         if after_l1 is not None:
             after_l1()
         ops.cast_bf16(S1, self.S1_bf)                                  # = L2 input [C][B][2LH] (in "high": the backward operand)
-        if high:
+        if high and self.precision == "high" and self.L == 2:          # f16 L2 level (error budget: DESIGN.md 7)
+            if not hasattr(self, "S1_16") or self.S1_16.shape[0] != self.S1_bf.shape[0]:
+                self.S1_16 = torch.empty((self.C * B, self.K), dtype=ops.F16, device=self.device)
+            ops.cast_f16(S1, self.S1_16)
+            S2 = self.l2.forward((self.S1_bf.view(self.C, B, self.K), self.S1_16.view(self.C, B, self.K)), len_l2)
+        elif high:
             if not hasattr(self, "S1_w") or self.S1_w.shape[0] != self.S1_bf.shape[0]:
                 self.S1_w = torch.empty((self.C * B, 2 * self.K), dtype=BF16, device=self.device)
             ops.cast_bf16_wide(S1, self.S1_w, lo_first=True)

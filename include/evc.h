@@ -172,6 +172,18 @@ int evc_lstm_layer_fwd_f16(const evc_f16* x, const evc_f16* wT, const float* bia
                            int T, int M, int Kin, int H, evc_f16* hbuf, evc_bf16* hbuf_bf16,
                            float* c_state, float* h_state, int64_t ld_state, void* gates, evc_bf16* c_all,
                            const int32_t* row_map, const int32_t* rows_per_step, void* stream);
+/* evc_lstm_stack2_fwd (below) on IEEE f16 operands, the "high" precision form of the L2 level: layer 0 plain f16 (x-projection
+ * hoisted into one f16 product), layer 1 with its kernel K-extended by the weights' low-order halves - wT1_wlo [4H] rows
+ * [f16(Wx) | (Wx - f16(Wx))*64 | f16(Wh) | (Wh - f16(Wh))*64] (evc_cast_f32_to_f16_wlo) against activation rows [h | h/64] - because
+ * the rounding of the upper layer's weights is the one error of this level that f16 does not cover (the same error at every step
+ * into an integrating cell state; scripts/precision_budget.py).  x [T][M][Kin] f16, wT0 [4H][Kin+H] f16; h0_wide / h1_wide
+ * [(T+1)][M][2H] f16 = [f16(h_t) | f16(h_t)/64] per row, hbuf0 / hbuf1 [(T+1)][M][H] bf16 = the copies the backward products read.
+ * Same wavefront, math and outputs as evc_lstm_stack2_fwd (cs/frame_level_models.py:252-257). */
+int evc_lstm_stack2_fwd_f16(const evc_f16* x, const evc_f16* wT0, const float* bias0, const evc_f16* wT1_wlo, const float* bias1,
+                            const int32_t* len, int T, int M, int Kin, int H, float* zx_ws,
+                            evc_f16* h0_wide, evc_f16* h1_wide, evc_bf16* hbuf0, evc_bf16* hbuf1,
+                            float* c_state0, float* h_state0, float* c_state1, float* h_state1, int64_t ld_state,
+                            void* gates0, evc_bf16* c_all0, void* gates1, evc_bf16* c_all1, void* stream);
 /* A TWO-layer stack with M ~ batch rows (the L2 level: M = videos) in wavefront order: after layer 0's hoisted
  * x-projection (one GEMM into zx_ws [T][M][4H] f32), launch s runs layer 0's step s and layer 1's step s-1 side by
  * side (they are independent, and each is latency-bound at this size), so the chain of dependent launches is T+1
@@ -256,6 +268,9 @@ int evc_cast_f32_to_f16(const float* in, int64_t ld_in, int R, int C, evc_f16* o
 /* f16 image of an LSTM kernel [R][Kin+H] (f32, row stride ld_in) for a K-extended x-part: out [R][nseg*Kin + H] =
  * [f16(Wx) | f16(Wx)/64 | (Wx - f16(Wx))*64 | f16(Wh)] keeping the first nseg (1..3) x blocks. */
 int evc_cast_f32_to_f16_wide(const float* in, int64_t ld_in, int R, int Kin, int H, int nseg, evc_f16* out, void* stream);
+/* f16 image of an LSTM kernel [R][Kin+H] with both parts K-extended by the weights' low-order halves: out [R][2Kin + 2H] =
+ * [f16(Wx) | (Wx - f16(Wx))*64 | f16(Wh) | (Wh - f16(Wh))*64] (the upper layer of evc_lstm_stack2_fwd_f16). */
+int evc_cast_f32_to_f16_wlo(const float* in, int64_t ld_in, int R, int Kin, int H, evc_f16* out, void* stream);
 /* wide split-bf16 image of a [R][C] f32 matrix: out rows [lo | hi] (lo_first = 1: the A operand of evc_gemm_nt_split) or
  * [hi | lo] (0: its B operand); hi = bf16(x), lo = bf16(x - hi); C % 4 == 0, ld_out >= 2C. */
 int evc_cast_f32_to_bf16_wide(const float* in, int64_t ld_in, int R, int C, evc_bf16* out, int64_t ld_out, int lo_first, void* stream);

@@ -190,6 +190,24 @@ def main():
                 ("L2 parts %s: all h-parts" % kind, dict(exact, L2c0=dict(ex, ah=kind, wh=kind), L2c1=dict(ex, ah=kind, wh=kind))),
                 ("L2 parts %s: c1 whole" % kind, dict(exact, L2c1=kind)),
             ]
+        for lay in ("L2c0", "L2c1"):
+            for part in ("ax", "ah", "wx", "wh"):
+                configs.append(("L2 fine f16: %s %s only" % (lay, part), dict(exact, **{lay: dict(ex, **{part: "f16"})})))
+        # candidate: the whole L2 level on f16 with the ACTIVATION operands exact (K-extended by their low halves), weights f16
+        act_ext = dict(ax="x3", ah="x3", wx="f16", wh="f16")
+        configs += [
+            ("L2 fine PLAN + L2 f16 weights, exact activations", dict(plan, L2c0=act_ext, L2c1=act_ext)),
+            ("L2 fine PLAN + L2 f16, only c1 h exact", dict(plan, L2c0="f16", L2c1=dict(ax="f16", ah="x3", wx="f16", wh="f16"))),
+            ("L2 fine PLAN + L2 f16, c1 h and c0 h exact", dict(plan, L2c0=dict(ax="f16", ah="x3", wx="f16", wh="f16"),
+                                                                 L2c1=dict(ax="f16", ah="x3", wx="f16", wh="f16"))),
+            ("L2 fine PLAN + L2 f16, all activations exact but c0 x", dict(plan, L2c0=dict(ax="f16", ah="x3", wx="f16", wh="f16"), L2c1=act_ext)),
+        ]
+        w_ext = dict(ax="f16", ah="f16", wx="x3", wh="x3")
+        configs += [
+            ("L2 fine PLAN2: c0 f16, c1 f16 acts + exact weights", dict(plan, L2c0="f16", L2c1=w_ext)),
+            ("L2 fine PLAN2b: c0 and c1 f16 acts + exact weights", dict(plan, L2c0=w_ext, L2c1=w_ext)),
+            ("L2 fine PLAN2c: c0 f16 but Wh exact, c1 exact weights", dict(plan, L2c0=dict(ax="f16", ah="f16", wx="f16", wh="x3"), L2c1=w_ext)),
+        ]
         configs += [
             ("L2 parts PLAN+L2 h-parts f16", dict(plan, L2c0=dict(ex, ah="f16", wh="f16"), L2c1=dict(ex, ah="f16", wh="f16"))),
             ("L2 parts PLAN+L2 c1 f16, c0 h f16", dict(plan, L2c0=dict(ex, ah="f16", wh="f16"), L2c1="f16")),
