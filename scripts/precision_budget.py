@@ -80,9 +80,10 @@ def tower_fwd(x, n, p, num_chunks, kinds):
     l2_in = s1.reshape(num_chunks, B, -1).permute(1, 0, 2)
     len2 = torch.ceil(n.to(torch.float32) / float(Lc)).to(torch.int64)
     state = stack_fwd(l2_in, len2, l2, (kinds["L2c0"], kinds["L2c1"]))
-    sq = rnd(state, kinds["moe"])
-    gl = sq @ rnd(p["classifier/gates/weights"], kinds["moe"])
-    el = sq @ rnd(p["classifier/experts/weights"], kinds["moe"]) + p["classifier/experts/biases"]
+    mk = kinds["moe"] if isinstance(kinds["moe"], tuple) else (kinds["moe"], kinds["moe"])       # (activation kind, weight kind)
+    sq = rnd(state, mk[0])
+    gl = sq @ rnd(p["classifier/gates/weights"], mk[1])
+    el = sq @ rnd(p["classifier/experts/weights"], mk[1]) + p["classifier/experts/biases"]
     V = el.shape[1] // 2
     g = torch.softmax(gl.reshape(B * V, 3), 1)
     pred = (g[:, :2] * torch.sigmoid(el.reshape(B * V, 2))).sum(1).reshape(B, V)
@@ -202,6 +203,9 @@ def main():
                                                                  L2c1=dict(ax="f16", ah="x3", wx="f16", wh="f16"))),
             ("L2 fine PLAN + L2 f16, all activations exact but c0 x", dict(plan, L2c0=dict(ax="f16", ah="x3", wx="f16", wh="f16"), L2c1=act_ext)),
         ]
+        configs += [("MOE fine: %s" % k, v) for k, v in (
+            ("x f16, W exact", dict(exact, moe=("f16", "x3"))), ("x exact, W f16", dict(exact, moe=("x3", "f16"))),
+            ("x bf16, W exact", dict(exact, moe=("bf16", "x3"))), ("x exact, W bf16", dict(exact, moe=("x3", "bf16"))))]
         w_ext = dict(ax="f16", ah="f16", wx="x3", wh="x3")
         configs += [
             ("L2 fine PLAN2: c0 f16, c1 f16 acts + exact weights", dict(plan, L2c0="f16", L2c1=w_ext)),

@@ -139,6 +139,45 @@ def test_cfg3_headline_batch_256_properties():
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# --lstm_layers 1: the reference's flag DEFAULT (cs/frame_level_models.py:39; its launchers pass 2)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["bf16", "high", "split"])
+def test_single_layer_stacks_all_precisions(precision):
+    """One BasicLSTMCell per level (state = [c | h], 2H wide; L2 input and MoE input 2H): teacher + student step against the
+    float64 oracle - forward in every precision mode (the "high" mode's f16 wavefront needs two layers: a one-layer L2 level takes
+    the split-bf16 layer instead), gradients and the update in bf16."""
+    from efficientvideoclassification_youtube8m_amd import smoke
+    from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
+    B, F, H, V = 8, 128, 128, 40
+    q, x, n, labels = mm.synthetic_batch(B, seed=12, feature_size=F, vocab_size=V, dtype=np.float32)
+    g = DistillGraph(B, every_n=10, feature_size=F, vocab_size=V, lstm_cells=H, lstm_layers=1, device=DEV, seed=4, precision=precision)
+    assert g.teacher.L == 1 and g.teacher.K == 2 * H
+    for tw in (g.teacher, g.student):               # O(0.3) states so that the modes differ visibly
+        for k in tw.names:
+            if k.endswith("basic_lstm_cell/kernel"):
+                tw.store.p(k).mul_(2.0)
+        tw.refresh_shadows()
+    out = g.step(*_dev(x, n, labels), apply=False, num_frames_host=n)
+    teacher, student = smoke.tower_params_numpy(g.teacher), smoke.tower_params_numpy(g.student)
+    ref = mm.teacher_student_step(x.astype(np.float64), n, labels, teacher, student, 10, num_layers=1, with_grads=True)
+    e_s = np.abs(out["teacher_state"].cpu().numpy() - ref["teacher_state"]).max()
+    e_p = np.abs(out["predictions"].cpu().numpy() - ref["teacher_predictions"]).max()
+    e_ps = np.abs(out["student_predictions"].cpu().numpy() - ref["student_predictions"]).max()
+    print("lstm_layers=1 %s: teacher state err %.2e, pred err %.2e, student pred err %.2e" % (precision, e_s, e_p, e_ps))
+    tol_s, tol_p = {"bf16": (2e-2, 2e-3), "high": (2e-3, 2e-4), "split": (1e-4, 2e-5)}[precision]
+    assert e_s < tol_s and e_p < tol_p and e_ps < tol_p
+    for tower, key in ((g.teacher, "teacher_grads"), (g.student, "student_grads")):
+        got = smoke.tower_grads_numpy(tower)
+        for k in got:
+            gref = ref[key][k]
+            if k in ("classifier/gates/weights", "classifier/experts/weights"):
+                gref = gref - 2.0 * 1e-8 * smoke.tower_params_numpy(tower)[k]
+            assert _rel(got[k], gref) < 4e-2, (tower.scope, k, _rel(got[k], gref))
+    g.apply_gradients(B)
+    assert g.global_step == 2
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # cfg 2: teacher only
 # ---------------------------------------------------------------------------------------------------------------
 def test_cfg2_teacher_only_real_dims():
