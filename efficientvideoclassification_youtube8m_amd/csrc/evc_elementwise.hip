@@ -411,27 +411,32 @@ extern "C" int evc_cast_f32_to_f16(const float* in, int64_t ld_in, int R, int C,
 
 // IEEE f16 weight image of an LSTM kernel whose x-part is contracted as a K-extension (evc_lstm_layer_fwd_f16 on nseg x-segments):
 // out row = [f16(Wx) | f16(Wx)/64 | (Wx - f16(Wx))*64 | f16(Wh)] (the first nseg of the three x blocks), in = [Wx(Kin) | Wh(H)] f32.
-__global__ void cast_f16_wide_kernel(const float* __restrict__ in, long ld_in, int R, int Kin, int H, int nseg, f16_t* __restrict__ out) {
+__global__ void cast_f16_wide_kernel(const float* __restrict__ in, long ld_in, int R, int Kin, int H, int nseg, int h_ext, f16_t* __restrict__ out) {
   const int C = Kin + H;
-  const long n = (long)R * C, ldo = (long)nseg * Kin + H;
+  const long n = (long)R * C, ldo = (long)nseg * Kin + (h_ext ? 2L : 1L) * H;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const long r = i / C;
     const int c = (int)(i % C);
     const float w = in[r * ld_in + c];
     const f16_t h = f32_to_f16(w);
-    f16_t* o = out + r * ldo;
-    if (c >= Kin) { o[(long)nseg * Kin + (c - Kin)] = h; continue; }
-    o[c] = h;
     const float hf = f16_to_f32(h);
+    f16_t* o = out + r * ldo;
+    if (c >= Kin) {
+      o[(long)nseg * Kin + (c - Kin)] = h;
+      if (h_ext) o[(long)nseg * Kin + H + (c - Kin)] = f32_to_f16((w - hf) * 64.0f);
+      continue;
+    }
+    o[c] = h;
     if (nseg >= 2) o[Kin + c] = f32_to_f16(hf * (1.0f / 64.0f));
     if (nseg >= 3) o[2L * Kin + c] = f32_to_f16((w - hf) * 64.0f);
   }
 }
-extern "C" int evc_cast_f32_to_f16_wide(const float* in, int64_t ld_in, int R, int Kin, int H, int nseg, evc_f16* out, void* stream) {
-  EVC_REQUIRE(R > 0 && Kin > 0 && H >= 0 && nseg >= 1 && nseg <= 3, EVC_ERR_BAD_SHAPE, "evc_cast_f32_to_f16_wide: bad shape / nseg=%d", nseg);
+extern "C" int evc_cast_f32_to_f16_wide(const float* in, int64_t ld_in, int R, int Kin, int H, int nseg, int h_ext, evc_f16* out, void* stream) {
+  EVC_REQUIRE(R > 0 && Kin > 0 && H >= 0 && nseg >= 1 && nseg <= 3 && (h_ext == 0 || h_ext == 1), EVC_ERR_BAD_SHAPE,
+              "evc_cast_f32_to_f16_wide: bad shape / nseg=%d / h_ext=%d", nseg, h_ext);
   const long n = (long)R * (Kin + H);
   const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-  hipLaunchKernelGGL(cast_f16_wide_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, ld_in, R, Kin, H, nseg, out);
+  hipLaunchKernelGGL(cast_f16_wide_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, ld_in, R, Kin, H, nseg, h_ext, out);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }

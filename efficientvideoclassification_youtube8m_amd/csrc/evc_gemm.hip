@@ -1005,7 +1005,7 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
                                int T, int M, int Kin, int H, int hoist, float* zx_ws,
                                evc_bf16* hbuf, float* c_state, float* h_state, int64_t ld_state,
                                void* gates, evc_bf16* c_all, evc_bf16* hbuf_bf16,
-                               const int32_t* row_map, const int32_t* rows_per_step, void* stream, int f16 = 0);
+                               const int32_t* row_map, const int32_t* rows_per_step, void* stream, int f16 = 0, int64_t ldx = 0, int h_wide = 0);
 
 extern "C" int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const float* bias, const int32_t* len,
                                   int T, int M, int Kin, int H, int hoist, float* zx_ws,
@@ -1016,29 +1016,34 @@ extern "C" int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const f
                              nullptr, row_map, rows_per_step, stream);
 }
 
-extern "C" int evc_lstm_layer_fwd_f16(const evc_f16* x, const evc_f16* wT, const float* bias, const int32_t* len,
-                                      int T, int M, int Kin, int H, evc_f16* hbuf, evc_bf16* hbuf_bf16,
+extern "C" int evc_lstm_layer_fwd_f16(const evc_f16* x, int64_t ldx, const evc_f16* wT, const float* bias, const int32_t* len,
+                                      int T, int M, int Kin, int H, evc_f16* hbuf, int h_wide, evc_bf16* hbuf_bf16,
                                       float* c_state, float* h_state, int64_t ld_state, void* gates, evc_bf16* c_all,
                                       const int32_t* row_map, const int32_t* rows_per_step, void* stream) {
   EVC_REQUIRE(hbuf_bf16, EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd_f16: hbuf_bf16 (the bf16 copy of h for the backward pass) is required");
   EVC_REQUIRE(((uintptr_t)hbuf_bf16 % 8) == 0, EVC_ERR_BAD_ALIGN, "evc_lstm_layer_fwd_f16: hbuf_bf16 must be 8-byte aligned");
+  EVC_REQUIRE(ldx >= Kin && ldx % 8 == 0 && (h_wide == 0 || h_wide == 1), EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd_f16: ldx=%ld (>= Kin=%d, %%8), h_wide=%d",
+              (long)ldx, Kin, h_wide);
   return lstm_layer_fwd_impl((const evc_bf16*)x, (const evc_bf16*)wT, bias, len, T, M, Kin, H, 0, nullptr, (evc_bf16*)hbuf, c_state, h_state,
-                             ld_state, gates, c_all, hbuf_bf16, row_map, rows_per_step, stream, 1);
+                             ld_state, gates, c_all, hbuf_bf16, row_map, rows_per_step, stream, 1, ldx, h_wide);
 }
 
 static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const float* bias, const int32_t* len,
                                int T, int M, int Kin, int H, int hoist, float* zx_ws,
                                evc_bf16* hbuf, float* c_state, float* h_state, int64_t ld_state,
                                void* gates, evc_bf16* c_all, evc_bf16* hbuf_bf16,
-                               const int32_t* row_map, const int32_t* rows_per_step, void* stream, int f16) {
-  // f16: x, wT, hbuf hold IEEE f16 (16-bit containers of the same shapes), hbuf_bf16 receives the bf16 copy of every h_t
-  // (the split-bf16 form of a layer is evc_lstm_layer_fwd_hp below)
+                               const int32_t* row_map, const int32_t* rows_per_step, void* stream, int f16, int64_t ldx, int h_wide) {
+  // f16: x, wT, hbuf hold IEEE f16 (16-bit containers), hbuf_bf16 receives the bf16 copy of every h_t; ldx = row stride of x
+  // (0: Kin); h_wide: hbuf rows are [h | h/64] (2H) and the kernel's h-part is [Wh | Wh_lo*64] (2H): the recurrent weights
+  // K-extended by their low-order halves.  (The split-bf16 form of a layer is evc_lstm_layer_fwd_hp below.)
+  if (ldx == 0) ldx = Kin;
+  const long ldh = h_wide ? 2L * H : H;            // row stride of hbuf = K of the recurrent part
   EVC_REQUIRE(T > 0 && M > 0 && H > 0 && Kin > 0, EVC_ERR_BAD_SHAPE, "evc_lstm_layer_fwd: bad shape");
   EVC_REQUIRE(Kin % 64 == 0 && H % 64 == 0, EVC_ERR_BAD_SHAPE,
               "evc_lstm_layer_fwd: Kin=%d and H=%d must be multiples of 64", Kin, H);
-  EVC_REQUIRE(ring_operand_ok(M, Kin > H ? Kin : H) && ring_operand_ok(4L * H, (long)Kin + H), EVC_ERR_BAD_SHAPE,
+  EVC_REQUIRE(ring_operand_ok(M, ldx > ldh ? ldx : ldh) && ring_operand_ok(4L * H, (long)Kin + ldh), EVC_ERR_BAD_SHAPE,
               "evc_lstm_layer_fwd: a time slab or the kernel spans 4 GiB or more (M=%d Kin=%d H=%d)", M, Kin, H);
-  EVC_REQUIRE(!hoist || zx_ws, EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd: hoist needs zx_ws");
+  EVC_REQUIRE(!hoist || (zx_ws && !h_wide && ldx == Kin), EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd: hoist needs zx_ws (and plain operands)");
   EVC_REQUIRE(ld_state % 4 == 0 && ((uintptr_t)c_state % 16) == 0 && ((uintptr_t)h_state % 16) == 0 && ((uintptr_t)bias % 16) == 0 &&
               ((uintptr_t)hbuf % 8) == 0, EVC_ERR_BAD_ALIGN, "evc_lstm_layer_fwd: state/bias/hbuf must allow 16-byte vector access");
   EVC_REQUIRE((gates == nullptr) == (c_all == nullptr), EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd: gates and c_all go together");
@@ -1049,10 +1054,10 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
       EVC_REQUIRE(rows_per_step[t] >= 0 && rows_per_step[t] <= M && (t == 0 || rows_per_step[t] <= rows_per_step[t - 1]), EVC_ERR_BAD_ARG,
                   "evc_lstm_layer_fwd: rows_per_step[%d]=%d must be non-increasing and within [0, M=%d]", t, rows_per_step[t], M);
   hipStream_t st = (hipStream_t)stream;
-  const long ldw = Kin + H;
+  const long ldw = Kin + ldh;
   // h_{-1} = 0 (the state buffers need no clearing: step 0 treats c_old as 0 and writes the zero
   // state of the zero-length rows it covers itself; rows beyond rows_per_step[0] are the caller's)
-  EVC_CHECK_HIP(hipMemsetAsync(hbuf, 0, (size_t)M * H * sizeof(bf16_t), st));
+  EVC_CHECK_HIP(hipMemsetAsync(hbuf, 0, (size_t)M * ldh * sizeof(bf16_t), st));
   if (f16) EVC_CHECK_HIP(hipMemsetAsync(hbuf_bf16, 0, (size_t)M * H * sizeof(bf16_t), st));
   if (hoist) {
     int rc = evc_gemm_nt(x, Kin, wT, ldw, zx_ws, 4L * H, T * M, 4 * H, Kin, nullptr, 0, 0, stream);
@@ -1064,21 +1069,21 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
     GemmOperands p;
     p.M = Mt; p.Nu = H; p.group_stride = H; p.ldb = ldw; p.nk1 = p.nk2 = 0;
     p.A1lo = p.A2lo = p.Blo = nullptr;
-    const bf16_t* hprev = hbuf + (long)t * M * H;
+    const bf16_t* hprev = hbuf + (long)t * M * ldh;
     int k1, k2;
     if (hoist) {
       p.A1 = hprev; p.lda1 = H; k1 = (t == 0) ? 0 : H; p.A2 = hprev; p.lda2 = H; k2 = 0;
       p.B = wT + Kin;
     } else {
-      p.A1 = x + (long)t * M * Kin; p.lda1 = Kin; k1 = Kin;
-      p.A2 = hprev; p.lda2 = H; k2 = (t == 0) ? 0 : H;
+      p.A1 = x + (long)t * M * ldx; p.lda1 = ldx; k1 = Kin;
+      p.A2 = hprev; p.lda2 = ldh; k2 = (t == 0) ? 0 : (int)ldh;
       p.B = wT;
     }
     LstmFwdParams e;
     e.zx = hoist ? zx_ws + (long)t * M * 4 * H : nullptr; e.ldzx = 4L * H;
     e.bias = bias; e.len = len; e.t = t;
     e.c_state = c_state; e.h_state = h_state; e.ld_state = ld_state;
-    e.hout = hbuf + (long)(t + 1) * M * H;
+    e.hout = hbuf + (long)(t + 1) * M * ldh; e.h_wide = h_wide;
     e.hout_lo = f16 ? hbuf_bf16 + (long)(t + 1) * M * H : nullptr;
     e.gates = gates ? (uint2*)gates + (long)t * M * H : nullptr;
     e.c_hist = c_all ? c_all + (long)(t + 1) * M * H : nullptr;      // slab t+1 = c after step t

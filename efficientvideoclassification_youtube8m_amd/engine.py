@@ -181,26 +181,28 @@ class LstmStack:
                 ops.lstm_stack2_fwd_f16(x16, tw.shadow16[k0], tw.store.p(b0), tw.shadow16[k1], tw.store.p(b1), lens, T, M, self.Kin, H,
                                         self.zx, hw[0], hw[1], hb[0], hb[1], self.S, gates, c_all)
                 return self.S
+            wide = [l in tw.f16_wh_ext_layers for l in range(L)]        # layers whose recurrent weights are K-extended (wide h rows)
             if not hasattr(self, "hbuf16"):
-                self.hbuf16 = [torch.zeros(h.shape, dtype=ops.F16, device=h.device) for h in self.hbuf]
-            h16 = [self._v(h, T + 1, M, H) for h in self.hbuf16]
-            inp = x16
+                self.hbuf16 = [torch.zeros((self.T + 1, self.M, (2 if wide[l] else 1) * H), dtype=ops.F16, device=self.hbuf[l].device)
+                               for l in range(L)]
+            h16 = [self._v(self.hbuf16[l], T + 1, M, (2 if wide[l] else 1) * H) for l in range(L)]
+            inp, ldx = x16, x16.shape[-1]
             for l in range(L):
                 kn, bn = self.names(l)
                 if self.timing is not None:
                     e0 = torch.cuda.Event(enable_timing=True)
                     e0.record()
-                kx = inp.shape[-1]          # layer 0: nseg*F (K-extended x-part, tower.f16_x_segments), above: H
-                assert tw.shadow16[kn].shape[1] == kx + H
+                kx = x16.shape[-1] if l == 0 else H     # layer 0: nseg*F (K-extended x-part, tower.f16_x_segments); above: H of the (wide) rows below
+                assert tw.shadow16[kn].shape[1] == kx + (2 if wide[l] else 1) * H
                 ops.lstm_layer_fwd_f16(inp, tw.shadow16[kn], tw.store.p(bn), lens, T, M, kx, H, h16[l], hb[l],
                                        self.S[:, (2 * l) * H:], self.S[:, (2 * l + 1) * H:], 2 * L * H,
-                                       gates[l], c_all[l], plan=plan)
+                                       gates[l], c_all[l], plan=plan, ldx=ldx, h_wide=wide[l])
                 if self.timing is not None:
                     e1 = torch.cuda.Event(enable_timing=True)
                     e1.record()
                     flops = sum(2.0 * r * 4 * H * (self.kin[l] + (H if t > 0 else 0)) for t, r in enumerate(rows))
                     self.timing.append((e0, e1, sum(1 for r in rows if r > 0), flops))
-                inp = h16[l][1:]
+                inp, ldx = h16[l][1:], h16[l].shape[-1]
             return self.S
         if isinstance(x, tuple):        # split-bf16 operands, K-extended loops (the M ~ batch L2 stacks of the "high" mode)
             x_bf, x_w = x               # plain bf16 image (backward operand) and the wide [lo | hi] image [T][M][2Kin]
@@ -784,7 +786,11 @@ class HLstmTower(TowerBase):
     # one term of that level that 2^-12 does not cover.  L2 level (two layers): f16 in the wavefront pair launches, the UPPER
     # layer's weights K-extended by their low-order halves (their rounding is that level's one such term).  MoE head (and an L2
     # level of any other depth): split-bf16, K-extended loops.
-    f16_x_segments = int(os.environ.get("EVC_HIGH_X_SEGMENTS", "2"))
+    f16_x_segments = int(os.environ.get("EVC_HIGH_X_SEGMENTS", "3"))
+    # L1 layers whose RECURRENT weights are K-extended by their low-order halves ([h | h/64] . [Wh | Wh_lo*64]^T): layer 0 - the
+    # rounding of Wh0 is, after the input frames, the largest and most draw-dependent term of the level (5e-4 on the logits on
+    # some trained weights, scripts/precision_budget.py "ROBUST" runs).  EVC_HIGH_L1_WH_EXT: comma list of layers ("" = none).
+    f16_wh_ext_layers = tuple(int(v) for v in os.environ.get("EVC_HIGH_L1_WH_EXT", "0").split(",") if v.strip() != "")
 
     def input_split(self):
         """The `split` argument of ops.l2norm_chunk that produces this tower's L1 input."""
@@ -799,7 +805,8 @@ class HLstmTower(TowerBase):
                 continue
             if k.startswith("RNN_L1/") and self.precision == "high":
                 nin = shp[1] - H
-                wide = (self.f16_x_segments * nin + H) if "cell_0" in k else shp[1]
+                layer = int(k.split("cell_")[1].split("/")[0])
+                wide = (self.f16_x_segments if layer == 0 else 1) * nin + (2 if layer in self.f16_wh_ext_layers else 1) * H
                 self.shadow16[k] = torch.zeros((shp[0], wide), dtype=ops.F16, device=dev)
             elif k.startswith("RNN_L2/") and self.precision == "high" and self.L == 2:
                 # f16 L2 level (ops.lstm_stack2_fwd_f16): layer 0 plain, layer 1 [Wx | Wx_lo*64 | Wh | Wh_lo*64]
@@ -817,8 +824,10 @@ class HLstmTower(TowerBase):
             ops.cast_f16_wlo(p, p.shape[1] - H, H, self.shadow16[k])
         elif k in self.shadow16:
             nin = p.shape[1] - H
-            nseg = (self.shadow16[k].shape[1] - H) // nin
-            ops.cast_f16_wide(p, nin, H, nseg, self.shadow16[k])
+            layer = int(k.split("cell_")[1].split("/")[0])
+            h_ext = k.startswith("RNN_L1/") and layer in self.f16_wh_ext_layers
+            nseg = (self.shadow16[k].shape[1] - (2 if h_ext else 1) * H) // nin
+            ops.cast_f16_wide(p, nin, H, nseg, self.shadow16[k], h_ext=h_ext)
         elif k in self.shadow_wx:
             nin = p.shape[1] - H
             ops.cast_bf16_wide(p[:, :nin], self.shadow_wx[k], lo_first=False)

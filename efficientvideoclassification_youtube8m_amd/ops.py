@@ -102,11 +102,12 @@ def cast_f16(x, out):
     return out
 
 
-def cast_f16_wide(w, Kin, H, nseg, out):
-    """f16 image of an LSTM kernel w [R][Kin+H] f32 for a K-extended x-part: out [R][nseg*Kin + H] =
-    [f16(Wx) | f16(Wx)/64 | (Wx - f16(Wx))*64 | f16(Wh)] (first nseg x blocks)."""
-    assert w.dtype == F32 and out.dtype == F16 and w.shape[1] == Kin + H and out.shape == (w.shape[0], nseg * Kin + H) and out.is_contiguous()
-    _lib.call("evc_cast_f32_to_f16_wide", _p(w), w.stride(0), w.shape[0], Kin, H, nseg, _p(out), _stream())
+def cast_f16_wide(w, Kin, H, nseg, out, h_ext=False):
+    """f16 image of an LSTM kernel w [R][Kin+H] f32 for K-extended operands: out [R][nseg*Kin + (2 if h_ext else 1)*H] =
+    [f16(Wx) | f16(Wx)/64 | (Wx - f16(Wx))*64 | f16(Wh) | (Wh - f16(Wh))*64] (first nseg x blocks; the last block with h_ext)."""
+    assert w.dtype == F32 and out.dtype == F16 and w.shape[1] == Kin + H and out.is_contiguous()
+    assert out.shape == (w.shape[0], nseg * Kin + (2 if h_ext else 1) * H)
+    _lib.call("evc_cast_f32_to_f16_wide", _p(w), w.stride(0), w.shape[0], Kin, H, nseg, 1 if h_ext else 0, _p(out), _stream())
     return out
 
 
@@ -258,11 +259,13 @@ def lstm_layer_fwd(x, wT, bias, lens, T, M, Kin, H, hbuf, c_state, h_state, ld_s
 
 
 def lstm_layer_fwd_f16(x16, wT16, bias, lens, T, M, Kin, H, hbuf16, hbuf_bf, c_state, h_state, ld_state,
-                       gates=None, c_all=None, plan=None):
-    """lstm_layer_fwd on IEEE f16 operands (one f16 MFMA product per depth); hbuf16 f16, hbuf_bf the bf16 copy of h."""
+                       gates=None, c_all=None, plan=None, ldx=None, h_wide=False):
+    """lstm_layer_fwd on IEEE f16 operands (one f16 MFMA product per depth); hbuf16 f16 (h_wide: rows [h | h/64] of 2H against a
+    kernel whose h-part is [Wh | Wh_lo*64]), hbuf_bf the bf16 copy of h; ldx: row stride of x16 (default Kin)."""
     assert x16.dtype == F16 and wT16.dtype == F16 and hbuf16.dtype == F16 and hbuf_bf.dtype == BF16
-    _lib.call("evc_lstm_layer_fwd_f16", _p(x16), _p(wT16), _p(bias), _p(lens), T, M, Kin, H, _p(hbuf16), _p(hbuf_bf),
-              _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_all), *_plan_args(plan), _stream())
+    assert wT16.shape[1] == Kin + (2 if h_wide else 1) * H
+    _lib.call("evc_lstm_layer_fwd_f16", _p(x16), Kin if ldx is None else ldx, _p(wT16), _p(bias), _p(lens), T, M, Kin, H, _p(hbuf16),
+              1 if h_wide else 0, _p(hbuf_bf), _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_all), *_plan_args(plan), _stream())
 
 
 def lstm_stack2_fwd(x, wT0, bias0, wT1, bias1, lens, T, M, Kin, H, zx_ws, hbuf0, hbuf1, S, gates=(None, None), c_all=(None, None)):

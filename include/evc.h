@@ -168,8 +168,12 @@ int evc_lstm_layer_fwd_hp(const evc_bf16* x_lohi, const evc_bf16* wx_hilo, int64
  * evc_cast_f32_to_f16_wide(nseg), Kin = nseg*F here.  hbuf_bf16 [(T+1)][M][H] receives the bf16 copy of every h_t: the operand of the backward products
  * (whose gradients need bf16's range).  Everything else as evc_lstm_layer_fwd (same dynamic_rnn semantics,
  * cs/frame_level_models.py:221-250). */
-int evc_lstm_layer_fwd_f16(const evc_f16* x, const evc_f16* wT, const float* bias, const int32_t* len,
-                           int T, int M, int Kin, int H, evc_f16* hbuf, evc_bf16* hbuf_bf16,
+int evc_lstm_layer_fwd_f16(const evc_f16* x, int64_t ldx /* row stride of x (>= Kin): a wide h image of the layer below has 2H */,
+                           const evc_f16* wT, const float* bias, const int32_t* len,
+                           int T, int M, int Kin, int H, evc_f16* hbuf,
+                           int h_wide /* 1: hbuf rows are [f16(h) | f16(h)/64] (2H) and the kernel's h-part is [f16(Wh) | (Wh - f16(Wh))*64]:
+                                         the recurrent weights K-extended by their low-order halves (wT rows: Kin + 2H) */,
+                           evc_bf16* hbuf_bf16,
                            float* c_state, float* h_state, int64_t ld_state, void* gates, evc_bf16* c_all,
                            const int32_t* row_map, const int32_t* rows_per_step, void* stream);
 /* evc_lstm_stack2_fwd (below) on IEEE f16 operands, the "high" precision form of the L2 level: layer 0 plain f16 (x-projection
@@ -266,8 +270,9 @@ int evc_cast_f32_to_bf16(const float* in, int64_t ld_in, int R, int C, evc_bf16*
 /* out_f16[i] = f16(in_f32[i]), round to nearest even (the f16 weight shadows of evc_lstm_layer_fwd_f16). */
 int evc_cast_f32_to_f16(const float* in, int64_t ld_in, int R, int C, evc_f16* out, int64_t ld_out, void* stream);
 /* f16 image of an LSTM kernel [R][Kin+H] (f32, row stride ld_in) for a K-extended x-part: out [R][nseg*Kin + H] =
- * [f16(Wx) | f16(Wx)/64 | (Wx - f16(Wx))*64 | f16(Wh)] keeping the first nseg (1..3) x blocks. */
-int evc_cast_f32_to_f16_wide(const float* in, int64_t ld_in, int R, int Kin, int H, int nseg, evc_f16* out, void* stream);
+ * [f16(Wx) | f16(Wx)/64 | (Wx - f16(Wx))*64 | f16(Wh) | (Wh - f16(Wh))*64] keeping the first nseg (1..3) x blocks and, with
+ * h_ext = 1, the low-order block of the h-part (evc_lstm_layer_fwd_f16 with h_wide = 1). */
+int evc_cast_f32_to_f16_wide(const float* in, int64_t ld_in, int R, int Kin, int H, int nseg, int h_ext, evc_f16* out, void* stream);
 /* f16 image of an LSTM kernel [R][Kin+H] with both parts K-extended by the weights' low-order halves: out [R][2Kin + 2H] =
  * [f16(Wx) | (Wx - f16(Wx))*64 | f16(Wh) | (Wh - f16(Wh))*64] (the upper layer of evc_lstm_stack2_fwd_f16). */
 int evc_cast_f32_to_f16_wlo(const float* in, int64_t ld_in, int R, int Kin, int H, evc_f16* out, void* stream);

@@ -207,6 +207,32 @@ def main():
             ("x f16, W exact", dict(exact, moe=("f16", "x3"))), ("x exact, W f16", dict(exact, moe=("x3", "f16"))),
             ("x bf16, W exact", dict(exact, moe=("bf16", "x3"))), ("x exact, W bf16", dict(exact, moe=("x3", "bf16"))))]
         w_ext = dict(ax="f16", ah="f16", wx="x3", wh="x3")
+        c0_2 = dict(ax="x3", ah="f16", wx="f16", wh="f16")          # L1 layer 0: input frames exact (2 segments)
+        c0_3 = dict(ax="x3", ah="f16", wx="x3", wh="f16")           # ... + Wx exact (3 segments)
+        c0_3h = dict(ax="x3", ah="f16", wx="x3", wh="x3")           # ... + Wh exact
+        l2_f16 = dict(L2c0="f16", L2c1=w_ext)
+        configs += [("ROBUST %s" % k, v) for k, v in (
+            ("A  L1c0 x-ext | L1c1 f16 | L2 f16+c1 W-ext", dict(exact, L1c0=c0_2, L1c1="f16", **l2_f16)),
+            ("B  L1c0 x,Wx-ext | L1c1 f16 | L2 f16+c1 W-ext", dict(exact, L1c0=c0_3, L1c1="f16", **l2_f16)),
+            ("C  L1c0 x,Wx-ext | L1c1 f16 | L2 exact", dict(exact, L1c0=c0_3, L1c1="f16")),
+            ("D  L1c0 x-ext | L1c1 f16 | L2 exact", dict(exact, L1c0=c0_2, L1c1="f16")),
+            ("E  L1c0 x,Wx-ext | L1c1 W-ext | L2 f16+c1 W-ext", dict(exact, L1c0=c0_3, L1c1=w_ext, **l2_f16)),
+            ("F  L1c0 x,Wx,Wh-ext | L1c1 f16 | L2 f16+c1 W-ext", dict(exact, L1c0=c0_3h, L1c1="f16", **l2_f16)),
+            ("G  L1 weights exact (acts f16, x exact) | L2 f16+c1 W-ext", dict(exact, L1c0=c0_3h, L1c1=w_ext, **l2_f16)),
+            ("F2 L1c0 x,Wh-ext (Wx f16) | L1c1 f16 | L2 f16+c1 W-ext", dict(exact, L1c0=dict(ax="x3", ah="f16", wx="f16", wh="x3"), L1c1="f16", **l2_f16)),
+            ("F3 L1c0 x,Wx,Wh-ext | L1c1 Wh-ext | L2 f16+c1 W-ext", dict(exact, L1c0=c0_3h, L1c1=dict(ax="f16", ah="f16", wx="f16", wh="x3"), **l2_f16)),
+            ("F4 L1c0 x,Wh-ext (Wx f16) | L1c1 Wh-ext | L2 f16+c1 W-ext", dict(exact, L1c0=dict(ax="x3", ah="f16", wx="f16", wh="x3"),
+                                                                            L1c1=dict(ax="f16", ah="f16", wx="f16", wh="x3"), **l2_f16)),
+            ("F5 L1c0 x,Wh-ext | L1c1 W-ext (Wx,Wh) | L2 f16+c1 W-ext", dict(exact, L1c0=dict(ax="x3", ah="f16", wx="f16", wh="x3"), L1c1=w_ext, **l2_f16)),
+            ("FG L1 weights exact, acts f16, x exact | L2 f16+c1 W-ext", dict(exact, L1c0=c0_3h, L1c1=w_ext, **l2_f16)),
+            ("FS all LSTM weights exact, acts f16, x exact", dict(exact, L1c0=c0_3h, L1c1=w_ext, L2c0=w_ext, L2c1=w_ext)),
+            ("FT L1 exact | L2 f16+c1 W-ext", dict(exact, **l2_f16)),
+            ("H  only L2 f16+c1 W-ext (L1 exact)", dict(exact, **l2_f16)),
+            ("I  only L1c1 f16", dict(exact, L1c1="f16")),
+            ("J  only L1c0 Wh f16", dict(exact, L1c0=dict(ax="x3", ah="x3", wx="x3", wh="f16"))),
+            ("K  only L1c0 h f16", dict(exact, L1c0=dict(ax="x3", ah="f16", wx="x3", wh="x3"))),
+            ("L  only L1c0 Wx f16", dict(exact, L1c0=dict(ax="x3", ah="x3", wx="f16", wh="x3"))),
+        )]
         configs += [
             ("L2 fine PLAN2: c0 f16, c1 f16 acts + exact weights", dict(plan, L2c0="f16", L2c1=w_ext)),
             ("L2 fine PLAN2b: c0 and c1 f16 acts + exact weights", dict(plan, L2c0=w_ext, L2c1=w_ext)),

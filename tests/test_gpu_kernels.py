@@ -350,6 +350,49 @@ def test_lstm_stack2_fwd_f16_weight_lo_extension(ops, M, T, Kin, H):
     print("stack2 f16: state err %.2e (oracle with f16-rounded layer-1 kernel: %.2e away from the exact one)" % (err, np.max(np.abs(s_rounded - s_ref))))
 
 
+@pytest.mark.parametrize("M,T,Kin,H", [(256, 6, 64, 64), (1536, 4, 192, 256), (640, 15, 128, 128)])
+def test_lstm_layer_fwd_f16_recurrent_weights_extended(ops, M, T, Kin, H):
+    """evc_lstm_layer_fwd_f16 with h_wide = 1: the recurrent weights K-extended by their low-order halves - h rows [f16(h) |
+    f16(h)/64] against kernel rows [f16(Wx) | f16(Wh) | (Wh - f16(Wh))*64] (evc_cast_f32_to_f16_wide, h_ext) - next to the plain f16
+    layer on the same f32 kernel, both against the float64 oracle with the x-part f16-rounded and the h-part EXACT: the extended
+    layer must be the closer one and within the f16 activation bound; its wide image must be [h | h/64]; a strided x (ldx > Kin)
+    reads the same rows."""
+    rng = np.random.default_rng(M + T + Kin + H + 11)
+    f16r = lambda a: torch.from_numpy(np.asarray(a, np.float32)).half().double().numpy()
+    x = f16r(rng.standard_normal((M, T, Kin)) * 0.5)
+    kernel = (mm.glorot_uniform(rng, (Kin + H, 4 * H)) * 3.0).astype(np.float32)
+    k_ref = kernel.astype(np.float64).copy()
+    k_ref[:Kin] = f16r(kernel[:Kin])
+    bias = (rng.standard_normal(4 * H) * 0.1).astype(np.float32)
+    lens = rng.integers(0, T + 1, size=M).astype(np.int32)
+    lens[:3] = [0, T, 1]
+    s_ref, _ = mm.multi_rnn_seq_fwd(x, lens, [(k_ref, bias.astype(np.float64))])
+    # x with a row stride of Kin + 64 (as a wide h image of a layer below would have)
+    xs = torch.zeros((T, M, Kin + 64), dtype=torch.float16, device=DEV)
+    xs[:, :, :Kin] = torch.from_numpy(np.ascontiguousarray(x.transpose(1, 0, 2)).astype(np.float32)).half().to(DEV)
+    kT = torch.from_numpy(np.ascontiguousarray(kernel.T)).to(DEV)
+    b, ln = torch.from_numpy(bias).to(DEV), torch.from_numpy(lens).to(DEV)
+    errs = {}
+    for wide in (True, False):
+        w = torch.empty((4 * H, Kin + (2 if wide else 1) * H), dtype=torch.float16, device=DEV)
+        ops.cast_f16_wide(kT, Kin, H, 1, w, h_ext=wide)
+        h16 = torch.full((T + 1, M, (2 if wide else 1) * H), float("nan"), dtype=torch.float16, device=DEV)
+        hbf = torch.full((T + 1, M, H), float("nan"), dtype=torch.bfloat16, device=DEV)
+        S = torch.full((M, 2 * H), float("nan"), dtype=torch.float32, device=DEV)
+        ops.lstm_layer_fwd_f16(xs, w, b, ln, T, M, Kin, H, h16, hbf, S[:, :H], S[:, H:], 2 * H, ldx=Kin + 64, h_wide=wide)
+        got = S.cpu().double().numpy()
+        assert np.isfinite(got).all() and np.all(got[0] == 0)
+        errs[wide] = float(np.max(np.abs(got - s_ref)))
+        hn = h16.float().cpu().numpy()
+        assert np.max(np.abs(hn[:, :, :H] - hbf.float().cpu().numpy())) <= 2.0 ** -8
+        if wide:
+            assert np.max(np.abs(hn[:, :, H:] * 64.0 - hn[:, :, :H])) <= 64 * 2.0 ** -25
+            hi = kT.half()
+            assert torch.equal(w[:, :Kin + H], hi) and torch.equal(w[:, Kin + H:], ((kT[:, Kin:] - hi[:, Kin:].float()) * 64.0).half())
+    print("f16 layer, exact-Wh oracle: state err with the recurrent weights extended %.2e, plain f16 %.2e" % (errs[True], errs[False]))
+    assert errs[True] < 8e-4 and errs[True] <= errs[False] * 1.05
+
+
 @pytest.mark.parametrize("M,T,Kin,H", [(256, 5, 128, 64), (70, 6, 64, 128), (512, 3, 256, 128), (1200, 2, 64, 64)])
 def test_lstm_stack2_wavefront_fwd(ops, M, T, Kin, H):
     """evc_lstm_stack2_fwd (layer 0 step t+1 and layer 1 step t in one launch) against the float64 oracle's 2-layer
