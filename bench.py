@@ -520,8 +520,8 @@ def main():
         pm["bf16"]["logits_within_1e-3_of_f64_oracle"] = "at the reference's initialisation (|logit| <~ 1); ~1e-3*|logit| on trained weights"
         pm["high"]["logits_within_1e-3_of_f64_oracle"] = "also on trained-magnitude weights (tests/test_gpu_step.py)"
         pm["high"]["what"] = ("forward operands chosen by a measured error budget (scripts/precision_budget.py, DESIGN.md 7): L1 level on IEEE f16 "
-                              "(one MFMA product per depth) with layer 0 K-extended by the low-order halves of the frames and of its weights; L2 level on "
-                              "f16 in the wavefront pair launches with the upper layer's weights K-extended by their low-order halves; MoE head "
+                              "(one MFMA product per depth) with every LSTM weight - and the input frames - K-extended by the low-order halves, activations f16; "
+                              "L2 level in the wavefront pair launches; student tower plain f16; MoE head "
                               "split-bf16 (hi.hi + hi.lo + lo.hi as one K-extended launch per product); backward as in bf16")
         extra["precision_modes"] = pm
         oc = {}

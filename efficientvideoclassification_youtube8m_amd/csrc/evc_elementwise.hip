@@ -441,6 +441,31 @@ extern "C" int evc_cast_f32_to_f16_wide(const float* in, int64_t ld_in, int R, i
   return EVC_OK;
 }
 
+// K-extended f16 image of an ACTIVATION matrix [R][C] f32: out rows [f16(x) | (x - f16(x))*64 | f16(x)/64] (the first nseg segments) -
+// what evc_l2norm_chunk_fwd's aux_mode writes for the input frames, for any other operand (the L2 level's input: the L1 states).
+__global__ void cast_f16_segs_kernel(const float* __restrict__ in, long ld_in, int R, int C, int nseg, f16_t* __restrict__ out) {
+  const long n = (long)R * C, ldo = (long)nseg * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C;
+    const int c = (int)(i % C);
+    const float x = in[r * ld_in + c];
+    const f16_t h = f32_to_f16(x);
+    const float hf = f16_to_f32(h);
+    f16_t* o = out + r * ldo;
+    o[c] = h;
+    if (nseg >= 2) o[C + c] = f32_to_f16((x - hf) * 64.0f);
+    if (nseg >= 3) o[2L * C + c] = f32_to_f16(hf * (1.0f / 64.0f));
+  }
+}
+extern "C" int evc_cast_f32_to_f16_segs(const float* in, int64_t ld_in, int R, int C, int nseg, evc_f16* out, void* stream) {
+  EVC_REQUIRE(R > 0 && C > 0 && nseg >= 1 && nseg <= 3, EVC_ERR_BAD_SHAPE, "evc_cast_f32_to_f16_segs: bad shape / nseg=%d", nseg);
+  const long n = (long)R * C;
+  const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(cast_f16_segs_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, ld_in, R, C, nseg, out);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
 // IEEE f16 image of an LSTM kernel with BOTH parts K-extended by the weights' low-order halves (evc_lstm_stack2_fwd_f16, upper layer):
 // out row = [f16(Wx) | (Wx - f16(Wx))*64 | f16(Wh) | (Wh - f16(Wh))*64] (2Kin + 2H), in = [Wx(Kin) | Wh(H)] f32.
 __global__ void cast_f16_wlo_kernel(const float* __restrict__ in, long ld_in, int R, int Kin, int H, f16_t* __restrict__ out) {

@@ -1286,7 +1286,8 @@ extern "C" int evc_lstm_stack2_fwd(const evc_bf16* x, const evc_bf16* wT0, const
 // of 2H; split-bf16 would be 6H in three passes), layer 0 runs plain f16 with its x-projection hoisted into one f16 product.
 // h rows are WIDE, [f16(h) | f16(h)/64] (2H), written by the step epilogue together with the bf16 copy the backward pass reads.
 // Same wavefront as evc_lstm_stack2_fwd: launch s = layer 0 step s next to layer 1 step s-1.
-extern "C" int evc_lstm_stack2_fwd_f16(const evc_f16* x, const evc_f16* wT0, const float* bias0, const evc_f16* wT1_wlo, const float* bias1,
+extern "C" int evc_lstm_stack2_fwd_f16(const evc_f16* x, int x_segments, const evc_f16* wT0, int h0_ext, const float* bias0,
+                                       const evc_f16* wT1_wlo, const float* bias1,
                                        const int32_t* len, int T, int M, int Kin, int H, float* zx_ws,
                                        evc_f16* h0_wide, evc_f16* h1_wide, evc_bf16* hbuf0, evc_bf16* hbuf1,
                                        float* c_state0, float* h_state0, float* c_state1, float* h_state1, int64_t ld_state,
@@ -1294,7 +1295,11 @@ extern "C" int evc_lstm_stack2_fwd_f16(const evc_f16* x, const evc_f16* wT0, con
   EVC_REQUIRE(T > 0 && M > 0 && H > 0 && Kin > 0 && H % 64 == 0 && Kin % 64 == 0, EVC_ERR_BAD_SHAPE,
               "evc_lstm_stack2_fwd_f16: bad shape T=%d M=%d Kin=%d H=%d (Kin, H multiples of 64)", T, M, Kin, H);
   EVC_REQUIRE(x && wT0 && wT1_wlo && zx_ws && h0_wide && h1_wide && hbuf0 && hbuf1, EVC_ERR_BAD_ARG, "evc_lstm_stack2_fwd_f16: NULL operand");
-  EVC_REQUIRE(ring_operand_ok(M, 2L * H) && ring_operand_ok(4L * H, 4L * H) && ring_operand_ok(4L * H, (long)Kin + H), EVC_ERR_BAD_SHAPE,
+  EVC_REQUIRE(x_segments >= 1 && x_segments <= 3 && (h0_ext == 0 || h0_ext == 1), EVC_ERR_BAD_ARG, "evc_lstm_stack2_fwd_f16: x_segments=%d h0_ext=%d",
+              x_segments, h0_ext);
+  const long Kx = (long)x_segments * Kin;              // K of the hoisted x-projection (K-extended input: evc_cast_f32_to_f16_segs)
+  const long ldw0 = Kx + (h0_ext ? 2L : 1L) * H;       // row of layer 0's kernel image (evc_cast_f32_to_f16_wide)
+  EVC_REQUIRE(ring_operand_ok(M, 2L * H) && ring_operand_ok(4L * H, 4L * H) && ring_operand_ok(4L * H, 3L * Kin + 2L * H), EVC_ERR_BAD_SHAPE,
               "evc_lstm_stack2_fwd_f16: an operand spans 4 GiB or more");
   EVC_REQUIRE(ld_state % 4 == 0 && ((uintptr_t)c_state0 % 16) == 0 && ((uintptr_t)h_state0 % 16) == 0 && ((uintptr_t)c_state1 % 16) == 0 &&
               ((uintptr_t)h_state1 % 16) == 0 && ((uintptr_t)bias0 % 16) == 0 && ((uintptr_t)bias1 % 16) == 0 && ((uintptr_t)h0_wide % 16) == 0 &&
@@ -1307,20 +1312,20 @@ extern "C" int evc_lstm_stack2_fwd_f16(const evc_f16* x, const evc_f16* wT0, con
   EVC_CHECK_HIP(hipMemsetAsync(h1_wide, 0, (size_t)M * 2 * H * sizeof(f16_t), st));
   EVC_CHECK_HIP(hipMemsetAsync(hbuf0, 0, (size_t)M * H * sizeof(bf16_t), st));
   EVC_CHECK_HIP(hipMemsetAsync(hbuf1, 0, (size_t)M * H * sizeof(bf16_t), st));
-  int rc = gemm_nt_f16(x, Kin, wT0, (int64_t)Kin + H, zx_ws, 4L * H, T * M, 4 * H, Kin, stream);
+  int rc = gemm_nt_f16(x, Kx, wT0, ldw0, zx_ws, 4L * H, T * M, 4 * H, (int)Kx, stream);
   if (rc) return rc;
   for (int s = 0; s <= T; ++s) {            // launch s: layer 0 step s next to layer 1 step s-1
     GemmOperands pa, pb;
     LstmFwdParams ea, eb;
     int k1a = 0, k2a = 0, k1b = 0, k2b = 0;
     const bool has_a = s < T, has_b = s >= 1;
-    if (has_a) {                             // layer 0, step s: zx + h0_{s-1} . Wh0^T (plain f16, K = H of the wide rows)
+    if (has_a) {                             // layer 0, step s: zx + h0_{s-1} . Wh0^T (K = H of the wide rows; h0_ext: all 2H against [Wh | Wh_lo*64])
       const int t = s;
-      pa.M = M; pa.Nu = H; pa.group_stride = H; pa.ldb = (long)Kin + H; pa.nk1 = pa.nk2 = 0;
+      pa.M = M; pa.Nu = H; pa.group_stride = H; pa.ldb = ldw0; pa.nk1 = pa.nk2 = 0;
       pa.A1lo = pa.A2lo = pa.Blo = nullptr;
       const bf16_t* hprev = (const bf16_t*)h0_wide + (long)t * M * 2 * H;
-      pa.A1 = hprev; pa.lda1 = 2L * H; k1a = (t == 0) ? 0 : H; pa.A2 = hprev; pa.lda2 = 2L * H; k2a = 0;
-      pa.B = (const bf16_t*)wT0 + Kin;
+      pa.A1 = hprev; pa.lda1 = 2L * H; k1a = (t == 0) ? 0 : (h0_ext ? 2 * H : H); pa.A2 = hprev; pa.lda2 = 2L * H; k2a = 0;
+      pa.B = (const bf16_t*)wT0 + Kx;
       ea.zx = zx_ws + (long)t * M * 4 * H; ea.ldzx = 4L * H;
       ea.bias = bias0; ea.len = len; ea.t = t;
       ea.c_state = c_state0; ea.h_state = h_state0; ea.ld_state = ld_state;

@@ -270,6 +270,19 @@ def dp_timeout():
     return datetime.timedelta(seconds=float(os.environ.get("EVC_DP_TIMEOUT_S", "120")))
 
 
+def student_light(student, precision):
+    """The "high" precision layout of the STUDENT tower: plain f16 on its L1 level (no K-extensions).  It runs 6 steps per chunk
+    over 5 chunks where the teacher runs 15 over 20, so the rounding terms the teacher's layout extends have no time
+    to build up: all-f16 leaves 1e-4 on its logits (the teacher: up to 1e-3) - and the extensions would cost its six L1 layer-0
+    launches 2.5x their depth.  Only for students of at most 30 frames (every_n >= 10).  It reads the first segment of the shared K-extended input image.  EVC_HIGH_STUDENT_LIGHT=0: the
+    teacher's layout for both."""
+    if (student is not None and precision == "high" and student.T <= 30       # (every_n >= 10; a longer student takes the teacher's layout)
+            and os.environ.get("EVC_HIGH_STUDENT_LIGHT", "1") != "0"):
+        student.f16_x_segments = 1
+        student.f16_wh_ext_layers = ()
+        student.f16_wx_ext_layers = ()
+
+
 def frame_counts_and_plans(g, num_frames, nh, need_teacher, need_student):
     """Frame counts (device) and the L1 row plans of both towers of graph ``g`` (DistillGraph / EvalGraph): rows
     sorted by length so the padding rows drop out of every L1 kernel (ops.RowPlan).  Host twins of the counts
@@ -337,6 +350,7 @@ class DistillGraph:
                 if tw is not None:
                     tw.moe.shard(red.world, red.rank)
         self.precision = precision       # engine.TowerBase.precision: "bf16" | "high" (1e-3 at trained magnitudes) | "split" (uniform)
+        student_light(self.student, precision)
         if precision != "bf16":
             for tw in (self.teacher, self.student):
                 if tw is not None:
@@ -424,7 +438,8 @@ class DistillGraph:
         xt, xs = ops.l2norm_chunk(x_raw, self.C1, self.every_n if need_student else None, self.C2,
                                   num_frames=num_frames if x_raw.dtype == torch.uint8 else None,
                                   split=(self.teacher or self.student).input_split(), plan1=tp[2] if tp else None,
-                                  plan2=sp[3] if sp else None, f16_segments=HLstmTower.f16_x_segments)
+                                  plan2=sp[3] if sp else None,
+                                  f16_segments=max(t.f16_x_segments for t in (self.teacher, self.student) if t is not None))
         self.losses.zero_()
         out = {}
         mark = self._mark
@@ -599,6 +614,7 @@ class EvalGraph:
         self.student = HLstmTower(batch_size, self.S, num_inputs_l1_student, feature_size, vocab_size, lstm_cells,
                                   lstm_layers, num_mixtures, device, False, "model_student", 8)
         self.precision = precision
+        student_light(self.student, precision)
         if precision != "bf16":
             for tw in (self.teacher, self.student):
                 if tw is not None:
@@ -635,7 +651,8 @@ class EvalGraph:
         u8 = x_raw.dtype == torch.uint8
         tp, sp = frame_counts_and_plans(self, num_frames, nh, self.teacher is not None, True)
         xt, xs = ops.l2norm_chunk(x_raw, self.C1, self.every_n, self.C2, num_frames=num_frames if u8 else None, split=split,
-                                  plan1=tp[2] if tp else None, plan2=sp[3], f16_segments=HLstmTower.f16_x_segments)
+                                  plan1=tp[2] if tp else None, plan2=sp[3],
+                                  f16_segments=max(t.f16_x_segments for t in (self.teacher, self.student) if t is not None))
         self.losses.zero_()
         out = {}
         self._ev_in.record(main)

@@ -179,7 +179,8 @@ class LstmStack:
                 hw = [self._v(h, T + 1, M, 2 * H) for h in self.hbuf16w]
                 (k0, b0), (k1, b1) = self.names(0), self.names(1)
                 ops.lstm_stack2_fwd_f16(x16, tw.shadow16[k0], tw.store.p(b0), tw.shadow16[k1], tw.store.p(b1), lens, T, M, self.Kin, H,
-                                        self.zx, hw[0], hw[1], hb[0], hb[1], self.S, gates, c_all)
+                                        self.zx, hw[0], hw[1], hb[0], hb[1], self.S, gates, c_all,
+                                        x_segments=tw.f16_l2_x_segments, h0_ext=tw.f16_l2_h0_ext)
                 return self.S
             wide = [l in tw.f16_wh_ext_layers for l in range(L)]        # layers whose recurrent weights are K-extended (wide h rows)
             if not hasattr(self, "hbuf16"):
@@ -192,7 +193,10 @@ class LstmStack:
                 if self.timing is not None:
                     e0 = torch.cuda.Event(enable_timing=True)
                     e0.record()
-                kx = x16.shape[-1] if l == 0 else H     # layer 0: nseg*F (K-extended x-part, tower.f16_x_segments); above: H of the (wide) rows below
+                # layer 0: the first f16_x_segments of the image's segments (a tower may use fewer than the image holds); above: H of
+                # the (wide) rows of the layer below
+                kx = tw.f16_x_segments * self.Kin if l == 0 else (2 * H if l in tw.f16_wx_ext_layers else H)
+                assert kx <= ldx, "a layer whose input weights are extended needs wide rows [h | h/64] from the layer below"
                 assert tw.shadow16[kn].shape[1] == kx + (2 if wide[l] else 1) * H
                 ops.lstm_layer_fwd_f16(inp, tw.shadow16[kn], tw.store.p(bn), lens, T, M, kx, H, h16[l], hb[l],
                                        self.S[:, (2 * l) * H:], self.S[:, (2 * l + 1) * H:], 2 * L * H,
@@ -790,7 +794,16 @@ class HLstmTower(TowerBase):
     # L1 layers whose RECURRENT weights are K-extended by their low-order halves ([h | h/64] . [Wh | Wh_lo*64]^T): layer 0 - the
     # rounding of Wh0 is, after the input frames, the largest and most draw-dependent term of the level (5e-4 on the logits on
     # some trained weights, scripts/precision_budget.py "ROBUST" runs).  EVC_HIGH_L1_WH_EXT: comma list of layers ("" = none).
-    f16_wh_ext_layers = tuple(int(v) for v in os.environ.get("EVC_HIGH_L1_WH_EXT", "0").split(",") if v.strip() != "")
+    f16_wh_ext_layers = tuple(int(v) for v in os.environ.get("EVC_HIGH_L1_WH_EXT", "0,1").split(",") if v.strip() != "")
+    # upper L1 layers whose INPUT weights are extended too ([h_below | h_below/64] . [Wx | Wx_lo*64]^T; needs the layer below wide and the
+    # layer itself in f16_wh_ext_layers): with "0,1" / "1" every LSTM weight of the level is exact and only the f16 rounding of the
+    # activations is left (the "FZ" layout of scripts/precision_budget.py: mean 2.0e-4, max 3.5e-4 on the logits)
+    f16_wx_ext_layers = tuple(int(v) for v in os.environ.get("EVC_HIGH_L1_WX_EXT", "1").split(",") if v.strip() != "")
+    # L2 level, layer 0: segments of its input (the L1 states; after the upper layer's weights their f16 rounding is the level's
+    # largest term on the LOGITS: 1.2e-4) in the hoisted product, and its recurrent weights extended - free inside the pair
+    # launches, whose time the upper layer's K = 4H sets
+    f16_l2_x_segments = int(os.environ.get("EVC_HIGH_L2_X_SEGMENTS", "2"))
+    f16_l2_h0_ext = os.environ.get("EVC_HIGH_L2_H0_EXT", "1") != "0"
 
     def input_split(self):
         """The `split` argument of ops.l2norm_chunk that produces this tower's L1 input."""
@@ -806,11 +819,13 @@ class HLstmTower(TowerBase):
             if k.startswith("RNN_L1/") and self.precision == "high":
                 nin = shp[1] - H
                 layer = int(k.split("cell_")[1].split("/")[0])
-                wide = (self.f16_x_segments if layer == 0 else 1) * nin + (2 if layer in self.f16_wh_ext_layers else 1) * H
-                self.shadow16[k] = torch.zeros((shp[0], wide), dtype=ops.F16, device=dev)
+                xw = self.f16_x_segments * nin if layer == 0 else (2 if layer in self.f16_wx_ext_layers else 1) * nin
+                self.shadow16[k] = torch.zeros((shp[0], xw + (2 if layer in self.f16_wh_ext_layers else 1) * H), dtype=ops.F16, device=dev)
             elif k.startswith("RNN_L2/") and self.precision == "high" and self.L == 2:
-                # f16 L2 level (ops.lstm_stack2_fwd_f16): layer 0 plain, layer 1 [Wx | Wx_lo*64 | Wh | Wh_lo*64]
-                self.shadow16[k] = torch.zeros((shp[0], shp[1] if "cell_0" in k else 2 * shp[1]), dtype=ops.F16, device=dev)
+                # f16 L2 level (ops.lstm_stack2_fwd_f16): layer 0 [Wx segments | Wh (| Wh_lo*64)], layer 1 [Wx | Wx_lo*64 | Wh | Wh_lo*64]
+                nin = shp[1] - H
+                w0 = self.f16_l2_x_segments * nin + (2 if self.f16_l2_h0_ext else 1) * H
+                self.shadow16[k] = torch.zeros((shp[0], w0 if "cell_0" in k else 2 * shp[1]), dtype=ops.F16, device=dev)
             elif k.startswith("RNN_L"):                                 # L2 level ("split": the L1 level too)
                 nin = shp[1] - H
                 self.shadow_wx[k] = torch.zeros((shp[0], 2 * nin), dtype=BF16, device=dev)
@@ -822,10 +837,16 @@ class HLstmTower(TowerBase):
         p, H = self.store.p(k), self.H
         if k in self.shadow16 and k.startswith("RNN_L2/") and "cell_1" in k:
             ops.cast_f16_wlo(p, p.shape[1] - H, H, self.shadow16[k])
+        elif k in self.shadow16 and k.startswith("RNN_L1/") and "cell_0" not in k and int(k.split("cell_")[1].split("/")[0]) in self.f16_wx_ext_layers:
+            layer = int(k.split("cell_")[1].split("/")[0])          # upper L1 layer with its INPUT weights extended: [Wx | Wx_lo*64 | Wh (| Wh_lo*64)]
+            if layer in self.f16_wh_ext_layers:
+                ops.cast_f16_wlo(p, p.shape[1] - H, H, self.shadow16[k])
+            else:
+                raise NotImplementedError("EVC_HIGH_L1_WX_EXT layers must also be in EVC_HIGH_L1_WH_EXT")
         elif k in self.shadow16:
             nin = p.shape[1] - H
             layer = int(k.split("cell_")[1].split("/")[0])
-            h_ext = k.startswith("RNN_L1/") and layer in self.f16_wh_ext_layers
+            h_ext = (layer in self.f16_wh_ext_layers) if k.startswith("RNN_L1/") else self.f16_l2_h0_ext
             nseg = (self.shadow16[k].shape[1] - (2 if h_ext else 1) * H) // nin
             ops.cast_f16_wide(p, nin, H, nseg, self.shadow16[k], h_ext=h_ext)
         elif k in self.shadow_wx:
@@ -894,10 +915,11 @@ class HLstmTower(TowerBase):
             after_l1()
         ops.cast_bf16(S1, self.S1_bf)                                  # = L2 input [C][B][2LH] (in "high": the backward operand)
         if high and self.precision == "high" and self.L == 2:          # f16 L2 level (error budget: DESIGN.md 7)
-            if not hasattr(self, "S1_16") or self.S1_16.shape[0] != self.S1_bf.shape[0]:
-                self.S1_16 = torch.empty((self.C * B, self.K), dtype=ops.F16, device=self.device)
-            ops.cast_f16(S1, self.S1_16)
-            S2 = self.l2.forward((self.S1_bf.view(self.C, B, self.K), self.S1_16.view(self.C, B, self.K)), len_l2)
+            ns = self.f16_l2_x_segments
+            if not hasattr(self, "S1_16") or self.S1_16.shape != (self.C * B, ns * self.K):
+                self.S1_16 = torch.empty((self.C * B, ns * self.K), dtype=ops.F16, device=self.device)
+            ops.cast_f16_segs(S1, ns, self.S1_16)
+            S2 = self.l2.forward((self.S1_bf.view(self.C, B, self.K), self.S1_16.view(self.C, B, ns * self.K)), len_l2)
         elif high:
             if not hasattr(self, "S1_w") or self.S1_w.shape[0] != self.S1_bf.shape[0]:
                 self.S1_w = torch.empty((self.C * B, 2 * self.K), dtype=BF16, device=self.device)

@@ -111,6 +111,13 @@ def cast_f16_wide(w, Kin, H, nseg, out, h_ext=False):
     return out
 
 
+def cast_f16_segs(x, nseg, out):
+    """K-extended f16 image of a 2-D f32 activation matrix: out [R][nseg*C] = [f16(x) | (x - f16(x))*64 | f16(x)/64] (first nseg)."""
+    assert x.dtype == F32 and out.dtype == F16 and out.shape == (x.shape[0], nseg * x.shape[1]) and out.is_contiguous()
+    _lib.call("evc_cast_f32_to_f16_segs", _p(x), x.stride(0), x.shape[0], x.shape[1], nseg, _p(out), _stream())
+    return out
+
+
 def cast_f16_wlo(w, Kin, H, out):
     """f16 image of an LSTM kernel w [R][Kin+H] f32 with both parts K-extended by the weights' low-order halves:
     out [R][2Kin + 2H] = [f16(Wx) | (Wx - f16(Wx))*64 | f16(Wh) | (Wh - f16(Wh))*64] (upper layer of lstm_stack2_fwd_f16)."""
@@ -276,11 +283,13 @@ def lstm_stack2_fwd(x, wT0, bias0, wT1, bias1, lens, T, M, Kin, H, zx_ws, hbuf0,
 
 
 def lstm_stack2_fwd_f16(x16, wT0_16, bias0, wT1_wlo, bias1, lens, T, M, Kin, H, zx_ws, h0_wide, h1_wide, hbuf0, hbuf1, S,
-                        gates=(None, None), c_all=(None, None)):
+                        gates=(None, None), c_all=(None, None), x_segments=1, h0_ext=False):
     """Two-layer stack, M ~ batch rows, wavefront order, IEEE f16 operands with the upper layer's weights K-extended by their
     low-order halves (evc_lstm_stack2_fwd_f16).  h*_wide [(T+1)][M][2H] f16, hbuf* [(T+1)][M][H] bf16; S [M][4H] f32."""
     assert x16.dtype == F16 and wT0_16.dtype == F16 and wT1_wlo.dtype == F16 and h0_wide.dtype == F16 and hbuf0.dtype == BF16
-    _lib.call("evc_lstm_stack2_fwd_f16", _p(x16), _p(wT0_16), _p(bias0), _p(wT1_wlo), _p(bias1), _p(lens), T, M, Kin, H, _p(zx_ws),
+    assert x16.shape[-1] == x_segments * Kin and wT0_16.shape[1] == x_segments * Kin + (2 if h0_ext else 1) * H
+    _lib.call("evc_lstm_stack2_fwd_f16", _p(x16), x_segments, _p(wT0_16), 1 if h0_ext else 0, _p(bias0), _p(wT1_wlo), _p(bias1), _p(lens),
+              T, M, Kin, H, _p(zx_ws),
               _p(h0_wide), _p(h1_wide), _p(hbuf0), _p(hbuf1), _p(S[:, 0:]), _p(S[:, H:]), _p(S[:, 2 * H:]), _p(S[:, 3 * H:]), S.stride(0),
               _p(gates[0]), _p(c_all[0]), _p(gates[1]), _p(c_all[1]), _stream())
 

@@ -180,10 +180,15 @@ int evc_lstm_layer_fwd_f16(const evc_f16* x, int64_t ldx /* row stride of x (>= 
  * hoisted into one f16 product), layer 1 with its kernel K-extended by the weights' low-order halves - wT1_wlo [4H] rows
  * [f16(Wx) | (Wx - f16(Wx))*64 | f16(Wh) | (Wh - f16(Wh))*64] (evc_cast_f32_to_f16_wlo) against activation rows [h | h/64] - because
  * the rounding of the upper layer's weights is the one error of this level that f16 does not cover (the same error at every step
- * into an integrating cell state; scripts/precision_budget.py).  x [T][M][Kin] f16, wT0 [4H][Kin+H] f16; h0_wide / h1_wide
+ * into an integrating cell state; scripts/precision_budget.py).  Layer 0 may be K-extended too: its input (the L1 states) in
+ * x_segments segments [f16(x) | (x - f16(x))*64 | f16(x)/64] against [Wx | Wx/64 | Wx_lo*64] (the hoisted product, K = x_segments*Kin)
+ * and, with h0_ext, its recurrent weights [Wh | Wh_lo*64] against the whole wide h row - free inside the pair launches, whose time
+ * the upper layer's K = 4H sets.  x [T][M][x_segments*Kin] f16; h0_wide / h1_wide
  * [(T+1)][M][2H] f16 = [f16(h_t) | f16(h_t)/64] per row, hbuf0 / hbuf1 [(T+1)][M][H] bf16 = the copies the backward products read.
  * Same wavefront, math and outputs as evc_lstm_stack2_fwd (cs/frame_level_models.py:252-257). */
-int evc_lstm_stack2_fwd_f16(const evc_f16* x, const evc_f16* wT0, const float* bias0, const evc_f16* wT1_wlo, const float* bias1,
+int evc_lstm_stack2_fwd_f16(const evc_f16* x, int x_segments /* x rows: x_segments*Kin, evc_cast_f32_to_f16_segs */,
+                            const evc_f16* wT0, int h0_ext /* wT0 rows: evc_cast_f32_to_f16_wide(x_segments, h0_ext) */, const float* bias0,
+                            const evc_f16* wT1_wlo, const float* bias1,
                             const int32_t* len, int T, int M, int Kin, int H, float* zx_ws,
                             evc_f16* h0_wide, evc_f16* h1_wide, evc_bf16* hbuf0, evc_bf16* hbuf1,
                             float* c_state0, float* h_state0, float* c_state1, float* h_state1, int64_t ld_state,
@@ -273,6 +278,8 @@ int evc_cast_f32_to_f16(const float* in, int64_t ld_in, int R, int C, evc_f16* o
  * [f16(Wx) | f16(Wx)/64 | (Wx - f16(Wx))*64 | f16(Wh) | (Wh - f16(Wh))*64] keeping the first nseg (1..3) x blocks and, with
  * h_ext = 1, the low-order block of the h-part (evc_lstm_layer_fwd_f16 with h_wide = 1). */
 int evc_cast_f32_to_f16_wide(const float* in, int64_t ld_in, int R, int Kin, int H, int nseg, int h_ext, evc_f16* out, void* stream);
+/* K-extended f16 image of an activation matrix [R][C] f32: out [R][nseg*C] = [f16(x) | (x - f16(x))*64 | f16(x)/64] (first nseg). */
+int evc_cast_f32_to_f16_segs(const float* in, int64_t ld_in, int R, int C, int nseg, evc_f16* out, void* stream);
 /* f16 image of an LSTM kernel [R][Kin+H] with both parts K-extended by the weights' low-order halves: out [R][2Kin + 2H] =
  * [f16(Wx) | (Wx - f16(Wx))*64 | f16(Wh) | (Wh - f16(Wh))*64] (the upper layer of evc_lstm_stack2_fwd_f16). */
 int evc_cast_f32_to_f16_wlo(const float* in, int64_t ld_in, int R, int Kin, int H, evc_f16* out, void* stream);

@@ -211,6 +211,7 @@ def main():
         c0_3 = dict(ax="x3", ah="f16", wx="x3", wh="f16")           # ... + Wx exact (3 segments)
         c0_3h = dict(ax="x3", ah="f16", wx="x3", wh="x3")           # ... + Wh exact
         l2_f16 = dict(L2c0="f16", L2c1=w_ext)
+        l2_f16x = dict(L2c0=dict(ax="x3", ah="f16", wx="x3", wh="x3"), L2c1=w_ext)      # + layer 0: input and weights exact (shipped)
         configs += [("ROBUST %s" % k, v) for k, v in (
             ("A  L1c0 x-ext | L1c1 f16 | L2 f16+c1 W-ext", dict(exact, L1c0=c0_2, L1c1="f16", **l2_f16)),
             ("B  L1c0 x,Wx-ext | L1c1 f16 | L2 f16+c1 W-ext", dict(exact, L1c0=c0_3, L1c1="f16", **l2_f16)),
@@ -224,6 +225,13 @@ def main():
             ("F4 L1c0 x,Wh-ext (Wx f16) | L1c1 Wh-ext | L2 f16+c1 W-ext", dict(exact, L1c0=dict(ax="x3", ah="f16", wx="f16", wh="x3"),
                                                                             L1c1=dict(ax="f16", ah="f16", wx="f16", wh="x3"), **l2_f16)),
             ("F5 L1c0 x,Wh-ext | L1c1 W-ext (Wx,Wh) | L2 f16+c1 W-ext", dict(exact, L1c0=dict(ax="x3", ah="f16", wx="f16", wh="x3"), L1c1=w_ext, **l2_f16)),
+            ("I1 only L1c1 x(=h0) f16", dict(exact, L1c1=dict(ax="f16", ah="x3", wx="x3", wh="x3"))),
+            ("I2 only L1c1 h f16", dict(exact, L1c1=dict(ax="x3", ah="f16", wx="x3", wh="x3"))),
+            ("I3 only L1c1 Wx f16", dict(exact, L1c1=dict(ax="x3", ah="x3", wx="f16", wh="x3"))),
+            ("I4 only L1c1 Wh f16", dict(exact, L1c1=dict(ax="x3", ah="x3", wx="x3", wh="f16"))),
+            ("FZ FX + L1c1 Wx,Wh exact", dict(exact, L1c0=c0_3h, L1c1=w_ext, **l2_f16x)),
+            ("FX (shipped) F with L2 layer 0 input + weights extended", dict(exact, L1c0=c0_3h, L1c1="f16", **l2_f16x)),
+            ("FY only the shipped L2 level (L1 exact)", dict(exact, **l2_f16x)),
             ("FG L1 weights exact, acts f16, x exact | L2 f16+c1 W-ext", dict(exact, L1c0=c0_3h, L1c1=w_ext, **l2_f16)),
             ("FS all LSTM weights exact, acts f16, x exact", dict(exact, L1c0=c0_3h, L1c1=w_ext, L2c0=w_ext, L2c1=w_ext)),
             ("FT L1 exact | L2 f16+c1 W-ext", dict(exact, **l2_f16)),

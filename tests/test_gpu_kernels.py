@@ -292,8 +292,8 @@ def test_lstm_layer_fwd_hp_split_layers(ops, M, T, Kin, H):
             assert np.max(np.abs(hsum[t + 1][ends] - s_ref[ends][:, H:])) < 1e-4
 
 
-@pytest.mark.parametrize("M,T,Kin,H", [(256, 5, 256, 64), (40, 6, 128, 128), (96, 20, 512, 128)])
-def test_lstm_stack2_fwd_f16_weight_lo_extension(ops, M, T, Kin, H):
+@pytest.mark.parametrize("M,T,Kin,H,ext", [(256, 5, 256, 64, False), (40, 6, 128, 128, True), (96, 20, 512, 128, False), (96, 20, 512, 128, True)])
+def test_lstm_stack2_fwd_f16_weight_lo_extension(ops, M, T, Kin, H, ext):
     """evc_lstm_stack2_fwd_f16 (the "high" precision L2 level): two layers in wavefront order on IEEE f16 operands, layer 0 plain
     (hoisted f16 x-projection), layer 1 with its weights K-extended by their low-order halves ([h | h/64] . [W | W_lo*64]^T) - against
     the float64 oracle on f16-rounded x and layer-0 kernel and the UNROUNDED f32 layer-1 kernel: the states must sit within 8e-4
@@ -313,6 +313,15 @@ def test_lstm_stack2_fwd_f16_weight_lo_extension(ops, M, T, Kin, H):
     s_rounded, _ = mm.multi_rnn_seq_fwd(x, lens, [layers[0], (f16r(k1), layers[1][1])])
     x16 = torch.from_numpy(np.ascontiguousarray(x.transpose(1, 0, 2)).astype(np.float32)).half().to(DEV)
     w0 = torch.from_numpy(np.ascontiguousarray(k0.T).astype(np.float32)).half().to(DEV)
+    x16p, w0p = x16, w0                              # plain images: the reference call for layer 0 below
+    if ext:      # layer 0 K-extended as well: input in 3 segments, recurrent weights + low halves (x and k0 are f16-exact here, so
+        #          the extra segments are zeros / scaled copies and the result must not move)
+        x16 = torch.empty((T * M, 3 * Kin), dtype=torch.float16, device=DEV)
+        ops.cast_f16_segs(x16p.float().reshape(T * M, Kin), 3, x16)
+        assert torch.equal(x16[:, :Kin], x16p.reshape(T * M, Kin)) and not bool(x16[:, Kin:2 * Kin].any())
+        x16 = x16.view(T, M, 3 * Kin)
+        w0 = torch.empty((4 * H, 3 * Kin + 2 * H), dtype=torch.float16, device=DEV)
+        ops.cast_f16_wide(w0p.float(), Kin, H, 3, w0, h_ext=True)
     w1 = torch.empty((4 * H, 4 * H), dtype=torch.float16, device=DEV)
     k1T = torch.from_numpy(np.ascontiguousarray(k1.T)).to(DEV)
     ops.cast_f16_wlo(k1T, H, H, w1)
@@ -326,7 +335,7 @@ def test_lstm_stack2_fwd_f16_weight_lo_extension(ops, M, T, Kin, H):
     gates = [torch.empty((T, M, H, 2), dtype=torch.int32, device=DEV) for _ in range(2)]
     c_all = [torch.full((T + 1, M, H), float("nan"), dtype=torch.bfloat16, device=DEV) for _ in range(2)]
     ops.lstm_stack2_fwd_f16(x16, w0, torch.from_numpy(b0).to(DEV), w1, torch.from_numpy(b1).to(DEV), torch.from_numpy(lens).to(DEV),
-                            T, M, Kin, H, zx, hw[0], hw[1], hb[0], hb[1], S, gates, c_all)
+                            T, M, Kin, H, zx, hw[0], hw[1], hb[0], hb[1], S, gates, c_all, x_segments=3 if ext else 1, h0_ext=ext)
     got = S.cpu().double().numpy()
     assert np.isfinite(got).all()
     err = np.max(np.abs(got - s_ref))
@@ -343,7 +352,7 @@ def test_lstm_stack2_fwd_f16_weight_lo_extension(ops, M, T, Kin, H):
     S0 = torch.full((M, 2 * H), float("nan"), dtype=torch.float32, device=DEV)
     h16 = torch.empty((T + 1, M, H), dtype=torch.float16, device=DEV)
     hbf = torch.empty((T + 1, M, H), dtype=torch.bfloat16, device=DEV)
-    ops.lstm_layer_fwd_f16(x16, w0, torch.from_numpy(b0).to(DEV), torch.from_numpy(lens).to(DEV), T, M, Kin, H, h16, hbf, S0[:, :H], S0[:, H:], 2 * H)
+    ops.lstm_layer_fwd_f16(x16p, w0p, torch.from_numpy(b0).to(DEV), torch.from_numpy(lens).to(DEV), T, M, Kin, H, h16, hbf, S0[:, :H], S0[:, H:], 2 * H)
     # (hoisted vs fused x-projection: the accumulation order differs by ~1e-7, which now and then flips the f16 rounding of an
     #  h entry - one f16 ulp, 2.4e-4 at |h| ~ 0.5 - and that flip travels on through the remaining steps)
     assert float((S0 - S[:, :2 * H]).abs().max()) < 8e-4
