@@ -597,6 +597,7 @@ struct MoeUpdateParams {
   float* p; float* m; float* v;        // [V][K] f32, row stride K
   bf16_t* p_bf16;                      // forward shadow [V][K]
   bf16_t* pT_bf16; long ldT;           // transposed shadow [K][ldT], ldT >= V
+  bf16_t* p_wide;                      // or NULL: wide split-bf16 image [V][2K] = [hi | lo] of the new weights (the "high" forward's operand)
   float* partial;                      // pass 1 out: [workgroups][2]
   const float* sums;                   // pass 2 in: sums[0] = sum (g + l2 p)^2 of this tensor
   int V, K;
@@ -701,6 +702,12 @@ __global__ __launch_bounds__(Cfg::NT) void moe_update_kernel(GemmOperandsT p, Mo
         *(float4*)(u.m + o) = make_float4(mn[0], mn[1], mn[2], mn[3]);
         *(float4*)(u.v + o) = make_float4(vn[0], vn[1], vn[2], vn[3]);
         *(uint2*)(u.p_bf16 + o) = make_uint2((uint32_t)pb[0] | ((uint32_t)pb[1] << 16), (uint32_t)pb[2] | ((uint32_t)pb[3] << 16));
+        if (u.p_wide) {                               // [hi | lo]: saves a pass over the f32 weights (evc_cast_f32_to_bf16_wide) per update
+          bf16_t* w = u.p_wide + (long)vr * 2 * K + k;
+          *(uint2*)w = make_uint2((uint32_t)pb[0] | ((uint32_t)pb[1] << 16), (uint32_t)pb[2] | ((uint32_t)pb[3] << 16));
+          *(uint2*)(w + K) = make_uint2(pack_bf16x2_hw(pn[0] - bf16_to_f32(pb[0]), pn[1] - bf16_to_f32(pb[1])),
+                                        pack_bf16x2_hw(pn[2] - bf16_to_f32(pb[2]), pn[3] - bf16_to_f32(pb[3])));
+        }
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) tile[(kl + r) * PITCH + vl] = pb[r];
@@ -738,10 +745,32 @@ __global__ __launch_bounds__(1024) void moe_update_finalize_kernel(const float* 
   }
 }
 
+static int moe_grad_update_impl(const evc_bf16* dlogits, int64_t ld_dlogits, const evc_bf16* x, int64_t ldx, int rows,
+                                int V, int K, float* p, float* m, float* v, evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT,
+                                float l2_coeff, float* sums, float* partial_ws, float clip_norm, float lr_t,
+                                float beta1, float beta2, float eps, int phase, evc_bf16* p_wide, void* stream);
+
+extern "C" int evc_moe_grad_update_wide(const evc_bf16* dlogits, int64_t ld_dlogits, const evc_bf16* x, int64_t ldx, int rows,
+                                        int V, int K, float* p, float* m, float* v, evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT,
+                                        evc_bf16* p_wide_hilo, float l2_coeff, float* sums, float* partial_ws, float clip_norm, float lr_t,
+                                        float beta1, float beta2, float eps, void* stream) {
+  EVC_REQUIRE(p_wide_hilo && ((uintptr_t)p_wide_hilo % 8) == 0, EVC_ERR_BAD_ARG, "evc_moe_grad_update_wide: p_wide_hilo [V][2K] (8-byte aligned) is required");
+  return moe_grad_update_impl(dlogits, ld_dlogits, x, ldx, rows, V, K, p, m, v, p_bf16, pT_bf16, ldT, l2_coeff, sums, partial_ws, clip_norm, lr_t,
+                              beta1, beta2, eps, 0, p_wide_hilo, stream);
+}
+
 extern "C" int evc_moe_grad_update_phase(const evc_bf16* dlogits, int64_t ld_dlogits, const evc_bf16* x, int64_t ldx, int rows,
-                                         int V, int K, float* p, float* m, float* v, evc_bf16* p_bf16, evc_bf16* pT_bf16,
-                                         int64_t ldT, float l2_coeff, float* sums, float* partial_ws, float clip_norm,
-                                         float lr_t, float beta1, float beta2, float eps, int phase, void* stream) {
+                                         int V, int K, float* p, float* m, float* v, evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT,
+                                         float l2_coeff, float* sums, float* partial_ws, float clip_norm, float lr_t,
+                                         float beta1, float beta2, float eps, int phase, void* stream) {
+  return moe_grad_update_impl(dlogits, ld_dlogits, x, ldx, rows, V, K, p, m, v, p_bf16, pT_bf16, ldT, l2_coeff, sums, partial_ws, clip_norm, lr_t,
+                              beta1, beta2, eps, phase, nullptr, stream);
+}
+
+static int moe_grad_update_impl(const evc_bf16* dlogits, int64_t ld_dlogits, const evc_bf16* x, int64_t ldx, int rows,
+                                int V, int K, float* p, float* m, float* v, evc_bf16* p_bf16, evc_bf16* pT_bf16,
+                                int64_t ldT, float l2_coeff, float* sums, float* partial_ws, float clip_norm,
+                                float lr_t, float beta1, float beta2, float eps, int phase, evc_bf16* p_wide, void* stream) {
   EVC_REQUIRE(rows > 0 && rows % 32 == 0 && V > 0 && V % 4 == 0 && K > 0 && K % 8 == 0, EVC_ERR_BAD_SHAPE,
               "evc_moe_grad_update: rows=%d (%%32), V=%d (%%4), K=%d (%%8)", rows, V, K);
   EVC_REQUIRE(phase >= 0 && phase <= 2, EVC_ERR_BAD_ARG, "evc_moe_grad_update_phase: phase=%d (0 both, 1 norms, 2 update)", phase);
@@ -756,7 +785,7 @@ extern "C" int evc_moe_grad_update_phase(const evc_bf16* dlogits, int64_t ld_dlo
   const int Vp = (int)(ld_dlogits < ((V + 7) / 8) * 8 ? ld_dlogits : ((V + 7) / 8) * 8);   // A columns the loop may touch (%8)
   GemmOperandsT g{dlogits, ld_dlogits, x, ldx, Vp, K, rows / 32};
   const int tm = ceil_div(V, Cfg::BM), tn = ceil_div(K, Cfg::BU);
-  MoeUpdateParams u{p, m, v, p_bf16, pT_bf16, ldT, partial_ws, sums, V, K, l2_coeff, clip_norm, lr_t, beta1, beta2, eps};
+  MoeUpdateParams u{p, m, v, p_bf16, pT_bf16, ldT, p_wide, partial_ws, sums, V, K, l2_coeff, clip_norm, lr_t, beta1, beta2, eps};
   if (phase != 2) {
     launch_cfg<Cfg>(moe_update_kernel<Cfg, 1>, tm * tn, st, g, u, tm, tn);
     hipLaunchKernelGGL(moe_update_finalize_kernel, dim3(1), dim3(1024), 0, st, (const float*)partial_ws, tm * tn, sums);

@@ -552,12 +552,15 @@ class MoeHead:
         rows = x.shape[0]
         idx = {k: i for i, k in enumerate(tw.names)}
         st = tw.store
+        refreshed_wide = False
         for name, dlog, Vn in ((self.GATES, dgl, V * (Mx + 1)), (self.EXPERTS, del_, V * Mx)):
             l2 = l2_coeff if name in tw.l2_names else 0.0
             pw, mw, vw = st.p(name), st.view(st.m, name), st.view(st.v, name)
             if dp is None:
+                wide = getattr(tw, "shadow_w", {}).get(name) if tw.precision != "bf16" else None     # "high": [hi | lo] from the same epilogue
                 ops.moe_grad_update(dlog, x, rows, Vn, K, pw, mw, vw, tw.shadow_fwd[name], tw.shadow_bwd[name], l2,
-                                    tw.sums[idx[name]], self.partial_ws, clip_norm, lr_t, beta1, beta2, eps)
+                                    tw.sums[idx[name]], self.partial_ws, clip_norm, lr_t, beta1, beta2, eps, p_wide=wide)
+                refreshed_wide = refreshed_wide or wide is not None
                 continue
             slab = self.slab[name]
             v0 = dp.rank * slab
@@ -574,7 +577,7 @@ class MoeHead:
             sb = tw.shadow_bwd[name]
             ops.transpose_to_bf16(tw.shadow_fwd[name], Vn, K, sb, sb.shape[1])
             self._stale = dp.world > 1
-        if tw.precision != "bf16":           # (single process only, see HLstmTower.backward) the update wrote the hi halves
+        if tw.precision != "bf16" and not refreshed_wide:     # towers with separate hi / lo shadows: the update wrote the hi halves only
             for name in (self.GATES, self.EXPERTS):
                 tw._refresh_high(name)
         gb = st.g(self.EBIAS)

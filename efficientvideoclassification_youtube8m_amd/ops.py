@@ -328,9 +328,16 @@ def moe_tail_bwd(gate_logits, expert_logits, dpred, B, V, M, dgate, dexpert):
 
 
 def moe_grad_update(dlogits, x, rows, V, K, p, m, v, p_bf16, pT_bf16, l2_coeff, sums, partial_ws, clip_norm, lr_t,
-                    beta1=0.9, beta2=0.999, eps=1e-8, phase=0):
+                    beta1=0.9, beta2=0.999, eps=1e-8, phase=0, p_wide=None):
     """Fused weight-gradient + per-tensor clip + TF-Adam of one MoE weight matrix (evc_moe_grad_update); phase 1 / 2:
-    the norm pass / the update pass alone, for a row slab of a matrix sharded over ranks (evc_moe_grad_update_phase)."""
+    the norm pass / the update pass alone, for a row slab of a matrix sharded over ranks (evc_moe_grad_update_phase).
+    p_wide [V][2K] bf16 (phase 0 only): also receives the wide [hi | lo] split image of the new weights (evc_moe_grad_update_wide)."""
+    if p_wide is not None:
+        assert phase == 0 and p_wide.dtype == BF16 and p_wide.shape == (V, 2 * K) and p_wide.is_contiguous()
+        _lib.call("evc_moe_grad_update_wide", _p(dlogits), dlogits.stride(0), _p(x), x.stride(0), rows, V, K, _p(p), _p(m), _p(v),
+                  _p(p_bf16), _p(pT_bf16), pT_bf16.stride(0), _p(p_wide), l2_coeff, _p(sums), _p(partial_ws), clip_norm, lr_t,
+                  beta1, beta2, eps, _stream())
+        return
     _lib.call("evc_moe_grad_update_phase", _p(dlogits), dlogits.stride(0), _p(x), x.stride(0), rows, V, K, _p(p), _p(m), _p(v),
               _p(p_bf16), _p(pT_bf16), pT_bf16.stride(0), l2_coeff, _p(sums), _p(partial_ws), clip_norm, lr_t, beta1, beta2, eps,
               phase, _stream())

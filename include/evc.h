@@ -259,6 +259,13 @@ int evc_moe_grad_update_phase(const evc_bf16* dlogits, int64_t ld_dlogits, const
                               int V, int K, float* p, float* m, float* v, evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT,
                               float l2_coeff, float* sums, float* partial_ws, float clip_norm, float lr_t,
                               float beta1, float beta2, float eps, int phase, void* stream);
+/* evc_moe_grad_update that ALSO writes the wide split-bf16 image of the new weights, p_wide_hilo [V][2K] = [bf16(W) | bf16(W - bf16(W))]
+ * (the B operand of evc_gemm_nt_split, the "high" precision forward of the MoE head) from the update's epilogue - instead of a
+ * separate pass over the f32 weights (evc_cast_f32_to_bf16_wide) after every update. */
+int evc_moe_grad_update_wide(const evc_bf16* dlogits, int64_t ld_dlogits, const evc_bf16* x, int64_t ldx, int rows,
+                             int V, int K, float* p, float* m, float* v, evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT,
+                             evc_bf16* p_wide_hilo, float l2_coeff, float* sums, float* partial_ws, float clip_norm, float lr_t,
+                             float beta1, float beta2, float eps, void* stream);
 
 /* ---- layout helpers --------------------------------------------------------
  * out[c][r] = in[r][c], r < R, c < C; out has ld_out >= Rpad columns and

@@ -26,9 +26,22 @@ from oracle import model_math as mm          # noqa: E402
 from oracle import torch_cpu as tc           # noqa: E402
 
 
+def fp8(a, scale):
+    """OCP e4m3 image of a * scale, back in a's units (what the MX-scaled MFMA contracts: v_mfma_scale_f32_16x16x128_f8f6f4)."""
+    return (a.to(torch.float32) * scale).to(torch.float8_e4m3fn).to(torch.float64) / scale
+
+
+def fp8_scale(a):
+    """Power of two that puts max|a| just under e4m3's 448 (the per-tensor e8m0 exponent the kernel gets)."""
+    m = float(a.abs().max())
+    return 2.0 ** np.floor(np.log2(448.0 / m)) if m > 0 else 1.0
+
+
 def rnd(a, kind):
     if kind == "x3":
         return a
+    if kind == "f16+8":      # weights only: the f16 image; the fp8 low-order half is contracted separately (stack_fwd)
+        kind = "f16"
     dt = {"bf16": torch.bfloat16, "f16": torch.float16}[kind]
     return a.to(torch.float32).to(dt).to(torch.float64)
 
@@ -46,11 +59,19 @@ def stack_fwd(x, lengths, layers, kinds):
     H = layers[0][1].shape[0] // 4
     c = [x.new_zeros((M, H)) for _ in layers]
     h = [x.new_zeros((M, H)) for _ in layers]
-    wq = []
+    wq, wlo8 = [], []
     for l, (k, _) in enumerate(layers):
         ax, ah, wx, wh = _parts(kinds[l])
         nin = k.shape[0] - H
         wq.append(torch.cat([rnd(k[:nin], wx), rnd(k[nin:], wh)], 0))
+        lo = torch.zeros_like(k)       # fp8 low-order halves (kind "f16+8"): W - f16(W) as e4m3 under one power-of-two scale per matrix
+        if wx == "f16+8":
+            d = k[:nin] - rnd(k[:nin], "f16")
+            lo[:nin] = fp8(d, fp8_scale(d))
+        if wh == "f16+8":
+            d = k[nin:] - rnd(k[nin:], "f16")
+            lo[nin:] = fp8(d, fp8_scale(d))
+        wlo8.append(lo if (wx == "f16+8" or wh == "f16+8") else None)
     for t in range(T):
         active = (lengths > t).unsqueeze(1)
         if not bool(active.any()):
@@ -60,6 +81,8 @@ def stack_fwd(x, lengths, layers, kinds):
             ax, ah, _, _ = _parts(kinds[l])
             a = torch.cat([rnd(inp, ax), rnd(h[l], ah)], 1)
             z = a @ wq[l] + bias
+            if wlo8[l] is not None:      # the low-order term on fp8 images of the activations (x 2^7: |h| <= 1, |x| <= 1)
+                z = z + fp8(torch.cat([inp, h[l]], 1), 128.0) @ wlo8[l]
             i, j, f, o = z.split(H, 1)
             cn = c[l] * torch.sigmoid(f + 1.0) + torch.sigmoid(i) * torch.tanh(j)
             hn = torch.tanh(cn) * torch.sigmoid(o)
@@ -230,6 +253,14 @@ def main():
             ("I3 only L1c1 Wx f16", dict(exact, L1c1=dict(ax="x3", ah="x3", wx="f16", wh="x3"))),
             ("I4 only L1c1 Wh f16", dict(exact, L1c1=dict(ax="x3", ah="x3", wx="x3", wh="f16"))),
             ("FZ FX + L1c1 Wx,Wh exact", dict(exact, L1c0=c0_3h, L1c1=w_ext, **l2_f16x)),
+            ("FZ8 FZ with the L1 weights' low-order halves in fp8", dict(exact, L1c0=dict(ax="x3", ah="f16", wx="f16+8", wh="f16+8"),
+                                                                         L1c1=dict(ax="f16", ah="f16", wx="f16+8", wh="f16+8"), **l2_f16x)),
+            ("FZ9 FZ8 + L2 weights' low-order halves in fp8", dict(exact, L1c0=dict(ax="x3", ah="f16", wx="f16+8", wh="f16+8"),
+                                                                         L1c1=dict(ax="f16", ah="f16", wx="f16+8", wh="f16+8"),
+                                                                         L2c0=dict(ax="x3", ah="f16", wx="f16+8", wh="f16+8"),
+                                                                         L2c1=dict(ax="f16", ah="f16", wx="f16+8", wh="f16+8"))),
+            ("W16 only the L1 weights f16 (activations exact)", dict(exact, L1c0=dict(ex, wx="f16", wh="f16"), L1c1=dict(ex, wx="f16", wh="f16"))),
+            ("W16+8 only the L1 weights f16 + fp8 low-order halves", dict(exact, L1c0=dict(ex, wx="f16+8", wh="f16+8"), L1c1=dict(ex, wx="f16+8", wh="f16+8"))),
             ("FX (shipped) F with L2 layer 0 input + weights extended", dict(exact, L1c0=c0_3h, L1c1="f16", **l2_f16x)),
             ("FY only the shipped L2 level (L1 exact)", dict(exact, **l2_f16x)),
             ("FG L1 weights exact, acts f16, x exact | L2 f16+c1 W-ext", dict(exact, L1c0=c0_3h, L1c1=w_ext, **l2_f16)),

@@ -300,6 +300,31 @@ def test_fused_moe_update_matches_materialised_gradient_path():
         assert torch.allclose(ta.sums, tb.sums, rtol=1e-4, atol=1e-12)
 
 
+def test_fused_moe_update_writes_the_wide_split_image_in_high_precision():
+    """"high" precision, one process: the fused MoE update's epilogue also writes the wide [hi | lo] split-bf16 image of the new
+    weights (evc_moe_grad_update_wide) - the operand of the next forward's split products - instead of a separate pass over
+    the f32 weights; after two training iterations it must be exactly what evc_cast_f32_to_bf16_wide makes of the master weights,
+    and the weights themselves must equal the bf16-mode run's (the update arithmetic does not depend on the forward mode's shadows
+    beyond the forward values: compared loosely, the two forwards differ)."""
+    from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
+    B, F, H, V = 8, 64, 64, 100
+    q, x, n, labels = mm.synthetic_batch(B, seed=33, feature_size=F, vocab_size=V, dtype=np.float32)
+    xd, nd, yd = torch.from_numpy(q).to(DEV), torch.from_numpy(n).to(DEV), torch.from_numpy(labels.astype(np.uint8)).to(DEV)
+    g = DistillGraph(B, every_n=10, feature_size=F, vocab_size=V, lstm_cells=H, device=DEV, seed=4, precision="high")
+    for _ in range(2):
+        g.step(xd, yd, nd, num_frames_host=n)
+    torch.cuda.synchronize()
+    for tw in (g.teacher, g.student):
+        for k in (tw.GATES, tw.EXPERTS):
+            p = tw.store.p(k)
+            K = p.shape[1]
+            hi = p.bfloat16()
+            assert torch.equal(tw.shadow_w[k][:, :K], hi), (tw.scope, k)
+            assert torch.equal(tw.shadow_w[k][:, K:], (p - hi.float()).bfloat16()), (tw.scope, k)
+            assert torch.equal(tw.shadow_fwd[k], hi)
+    assert all(np.isfinite(v) for v in g.loss_report().values())
+
+
 def test_moe_update_in_two_phases_on_row_slabs_equals_the_whole():
     """evc_moe_grad_update_phase: phase 1 on every row slab (norm sums accumulate), then phase 2 on every slab, gives
     the weights / moments / shadows of the one-call update of the whole matrix - what the data-parallel ranks do, each
