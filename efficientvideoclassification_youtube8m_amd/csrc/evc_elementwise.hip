@@ -125,6 +125,35 @@ __global__ __launch_bounds__(256) void l2norm_chunk_kernel(const float* __restri
           }
           continue;
         }
+        if (aux_mode == 5) {          // rows of 4F bytes: [f16(x) (F halfwords) | e4m3(x 2^7) (F bytes) | e4m3((x - f16(x)) 2^18) (F bytes)] - the x rows of
+                                      // evc_lstm_layer_fwd_f16_fp8lo (the low-order half of x: |.| <= 2^-12 |x|, against e4m3(Wx 2^6) - same 2^24 in all)
+          ushort4 h16;
+          h16.x = f32_to_f16(xv[0]); h16.y = f32_to_f16(xv[1]); h16.z = f32_to_f16(xv[2]); h16.w = f32_to_f16(xv[3]);
+          const uint16_t hb[4] = {h16.x, h16.y, h16.z, h16.w};
+          float c8[4], l8[4];           // (|x| <= 1 after l2norm; raw inputs are clamped: codes above 448 are NaN in OCP e4m3)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            c8[r] = fminf(fmaxf(xv[r] * 128.0f, -448.f), 448.f);
+            l8[r] = fminf(fmaxf((xv[r] - f16_to_f32(hb[r])) * 262144.0f, -448.f), 448.f);
+          }
+          int w8 = __builtin_amdgcn_cvt_pk_fp8_f32(c8[0], c8[1], 0, false);
+          w8 = __builtin_amdgcn_cvt_pk_fp8_f32(c8[2], c8[3], w8, true);
+          int v8 = __builtin_amdgcn_cvt_pk_fp8_f32(l8[0], l8[1], 0, false);
+          v8 = __builtin_amdgcn_cvt_pk_fp8_f32(l8[2], l8[3], v8, true);
+          if (o1) {
+            bf16_t* row = out1_lo + (off1 / F) * (2L * F);      // (off1 = row * F)
+            ((ushort4*)row)[j] = h16;
+            ((int*)(row + F))[j] = w8;
+            ((int*)(row + F))[nv + j] = v8;
+          }
+          if (o2 && out2_lo) {
+            bf16_t* row = out2_lo + (off2 / F) * (2L * F);
+            ((ushort4*)row)[j] = h16;
+            ((int*)(row + F))[j] = w8;
+            ((int*)(row + F))[nv + j] = v8;
+          }
+          continue;
+        }
         if (aux_mode >= 1) {          // IEEE f16 image, rows of nseg*F: [x | (x - f16(x))*64 | f16(x)/64]
           const int nseg = aux_mode;
           ushort4 h16, l16, s16;
@@ -174,7 +203,8 @@ extern "C" int evc_l2norm_chunk_fwd(const float* x_raw, const uint8_t* x_u8, con
                 "evc_l2norm_chunk_fwd: student view T/every_n=%d not divisible by C2=%d", T / (every_n > 0 ? every_n : 1), C2);
   }
   EVC_REQUIRE(!x_u8 || num_frames, EVC_ERR_BAD_ARG, "evc_l2norm_chunk_fwd: uint8 input needs num_frames");
-  EVC_REQUIRE(aux_mode >= 0 && aux_mode <= 4, EVC_ERR_BAD_ARG, "evc_l2norm_chunk_fwd: aux_mode=%d (0 bf16 low halves, 1..3 f16 segments, 4 wide bf16)", aux_mode);
+  EVC_REQUIRE(aux_mode >= 0 && aux_mode <= 5, EVC_ERR_BAD_ARG, "evc_l2norm_chunk_fwd: aux_mode=%d (0 bf16 low halves, 1..3 f16 segments, 4 wide bf16, 5 f16 + two e4m3 images)", aux_mode);
+  EVC_REQUIRE(aux_mode != 5 || F % 32 == 0, EVC_ERR_BAD_SHAPE, "evc_l2norm_chunk_fwd: aux_mode 5 needs F %% 32 == 0 (16-byte aligned row parts), F=%d", F);
   const long rows = (long)B * T;
   dim3 grid((unsigned)((rows + 3) / 4));
   if (x_u8)
@@ -437,6 +467,49 @@ extern "C" int evc_cast_f32_to_f16_wide(const float* in, int64_t ld_in, int R, i
   const long n = (long)R * (Kin + H);
   const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   hipLaunchKernelGGL(cast_f16_wide_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, ld_in, R, Kin, H, nseg, h_ext, out);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// Low-order halves of an f32 matrix next to its f16 image, as OCP e4m3: lo(w) = e4m3(clamp((w - f16(w)) * 2^lo_exp, +-448)) - the B8 operand
+// of evc_lstm_layer_fwd_f16_fp8lo (|w - f16(w)| <= 2^-12 |w|: with lo_exp = 17 weights up to |w| < 4 stay below 448 and those above ~2^-13 keep
+// 3-4 significant bits of their low-order half).  hi_cols > 0 (the layer that reads the input frames): behind the first hi_cols columns'
+// low-order halves comes a full-value image of those columns, hi(w) = e4m3(clamp(w * 2^hi_exp)) - what the INPUT's low-order half
+// e4m3((x - f16(x)) 2^18) is contracted against: out rows [lo(W[:, :hi_cols]) | hi(W[:, :hi_cols]) | lo(W[:, hi_cols:])].
+__global__ void cast_fp8_lo_kernel(const float* __restrict__ in, long ld_in, int R, int C, float lo_scale, int hi_cols, float hi_scale,
+                                   uint8_t* __restrict__ out, long ld_out) {
+  const int c4 = C >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)R * c4; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / c4;
+    const int c = (int)(i - r * c4) * 4;
+    const float4 v = *(const float4*)(in + r * ld_in + c);
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    float d[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = fminf(fmaxf((x[k] - f16_to_f32(f32_to_f16(x[k]))) * lo_scale, -448.f), 448.f);
+    int w8 = __builtin_amdgcn_cvt_pk_fp8_f32(d[0], d[1], 0, false);
+    w8 = __builtin_amdgcn_cvt_pk_fp8_f32(d[2], d[3], w8, true);
+    *(int*)(out + r * ld_out + (c < hi_cols ? c : c + hi_cols)) = w8;
+    if (c < hi_cols) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) d[k] = fminf(fmaxf(x[k] * hi_scale, -448.f), 448.f);
+      int h8 = __builtin_amdgcn_cvt_pk_fp8_f32(d[0], d[1], 0, false);
+      h8 = __builtin_amdgcn_cvt_pk_fp8_f32(d[2], d[3], h8, true);
+      *(int*)(out + r * ld_out + hi_cols + c) = h8;
+    }
+  }
+}
+
+extern "C" int evc_cast_f32_to_fp8_lo(const float* in, int64_t ld_in, int R, int C, int lo_exp, int hi_cols, int hi_exp, uint8_t* out, int64_t ld_out,
+                                      void* stream) {
+  EVC_REQUIRE(R > 0 && C > 0 && C % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 4) == 0,
+              EVC_ERR_BAD_ALIGN, "evc_cast_f32_to_fp8_lo: C=%d, ld_in=%ld, ld_out=%ld must be multiples of 4 (16-byte loads, 4-byte stores)", C, (long)ld_in, (long)ld_out);
+  EVC_REQUIRE(lo_exp >= 0 && lo_exp <= 60 && hi_cols >= 0 && hi_cols <= C && hi_cols % 4 == 0 && hi_exp >= -30 && hi_exp <= 30 && ld_out >= (long)C + hi_cols,
+              EVC_ERR_BAD_ARG, "evc_cast_f32_to_fp8_lo: lo_exp=%d hi_cols=%d (%%4, <= C) hi_exp=%d ld_out=%ld (>= C + hi_cols)", lo_exp, hi_cols, hi_exp, (long)ld_out);
+  const long n = (long)R * (C / 4);
+  const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+  hipLaunchKernelGGL(cast_fp8_lo_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, ld_in, R, C, ldexpf(1.0f, lo_exp), hi_cols,
+                     ldexpf(1.0f, hi_exp), out, ld_out);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }

@@ -818,8 +818,10 @@ struct LstmFwdParams {
   bf16_t* c_hist;                    // slab t+1 of the bf16 cell-state history [M][H] (c after this step), or NULL
   const int* row_map;                // slot -> row of c_state / h_state (row plan, evc_sort_rows_by_len) or NULL
   int M, H;
-  int h_wide = 0;                    // F16 only: hout rows are WIDE, [M][2H] = [f16(h_t) | f16(h_t)/64] - the activation operand of a
-                                     // contraction whose weights are K-extended by their low-order halves (evc_lstm_stack2_fwd_f16)
+  int h_wide = 0;                    // F16 only: 1 = hout rows are WIDE, [M][2H] = [f16(h_t) | f16(h_t)/64] - the activation operand of a
+                                     // contraction whose weights are K-extended by their low-order halves (evc_lstm_stack2_fwd_f16);
+                                     // 2 = hout rows are [f16(h_t) (H halfwords) | e4m3(h_t * 2^7) (H bytes)], row stride 3H bytes - the
+                                     // operands of a step whose low-order weight halves are contracted in fp8 (evc_lstm_layer_fwd_f16_fp8lo)
 };
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) { return pack_bf16x2_hw(lo, hi); }
@@ -827,10 +829,11 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) { return pac
 // F16: the operands (x_t, h_{t-1}, W) are IEEE f16 and ONE v_mfma_f32_16x16x32_f16 product is issued per depth - the cost of
 // the bf16 step with 8x smaller operand rounding; h_t leaves twice, as f16 (next step's / next layer's operand) and as bf16
 // (what the BPTT products contract over).
-template <class Cfg, bool SPLIT = false, bool F16 = false>
+template <class Cfg, bool SPLIT = false, bool F16 = false, bool FP8 = false>
 __device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const LstmFwdParams& e, int tiles_m, int tiles_n, int bid) {
   static_assert(Cfg::G == 4, "LSTM step needs the four gate groups");
   static_assert(!(SPLIT && F16), "split operands are bf16 halves");
+  static_assert(!FP8 || (F16 && is_v3<Cfg>::value), "the e4m3 tail rides behind f16 stages of the 64-wide ring loop");
   const int nwg = tiles_m * tiles_n;
   const int id = xcd_remap(bid, nwg);
   int tm, tn;
@@ -855,7 +858,7 @@ __device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const 
   // (SPLIT: the split-bf16 products hi.hi + hi.lo + lo.hi are a K-EXTENSION of the same loop - the caller hands A = [lo | hi] rows
   //  against B = [W_hi | W_lo] rows as segment 1 and A = hi against B2 = W_hi as segment 2, evc_lstm_layer_fwd_hp - so the loop
   //  itself is the plain one; only the epilogue differs: it writes h_t's wide [lo | hi] image for the next step.)
-  run_mainloop<Cfg, 4, true, false, EVC_FWD_LOOP_MODE | (F16 ? LOOP_F16 : 0)>(p, m0, u0, acc);   // transposed accumulators: lane = one row, 4 consecutive units
+  run_mainloop<Cfg, 4, true, false, EVC_FWD_LOOP_MODE | (F16 ? LOOP_F16 : 0) | (FP8 ? LOOP_FP8_TAIL : 0)>(p, m0, u0, acc);   // transposed accumulators: lane = one row, 4 consecutive units
 #ifdef EVC_ABLATE_EPI    // debug build: main loop only (keep the accumulators alive, store nothing)
 #pragma unroll
   for (int mi = 0; mi < Cfg::MI; ++mi)
@@ -892,10 +895,12 @@ __device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const 
       if (ln[mi] < 0) continue;
       const long hu = (long)m * H + u;
       const long su = (long)rm[mi] * e.ld_state + u;
-      const long hw = (F16 && e.h_wide) ? (long)m * 2 * H + u : hu;     // (F16: position in a wide h image)
+      const long hw = FP8 ? (long)m * (3 * H / 2) + u : (F16 && e.h_wide) ? (long)m * 2 * H + u : hu;     // (F16: position in a wide h image)
+      uint32_t* const h8 = FP8 ? (uint32_t*)((char*)(e.hout + (long)m * (3 * H / 2) + H) + u) : nullptr;     // (FP8: the row's e4m3 part)
       if (e.t >= ln[mi]) {          // dynamic_rnn: state copied through, zero output
         *(uint2*)(e.hout + hw) = make_uint2(0u, 0u);
-        if (F16 && e.h_wide) *(uint2*)(e.hout + hw + H) = make_uint2(0u, 0u);
+        if (FP8) *h8 = 0u;
+        else if (F16 && e.h_wide) *(uint2*)(e.hout + hw + H) = make_uint2(0u, 0u);
         if (F16) *(uint2*)(e.hout_lo + hu) = make_uint2(0u, 0u);
         if (SPLIT) {
           bf16_t* w = e.hout_lo + (long)m * 2 * H + u;
@@ -938,7 +943,11 @@ __device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const 
       if (F16) {
         const uint32_t p01 = pack_f16x2_hw(hn[0], hn[1]), p23 = pack_f16x2_hw(hn[2], hn[3]);
         *(uint2*)(e.hout + hw) = make_uint2(p01, p23);
-        if (e.h_wide) {             // f16(h)/64: the operand of the weights' low-order halves (scaled by 64)
+        if (FP8) {                  // e4m3(h * 2^7): the activation operand of the weights' low-order halves (|h| < 1: no saturation)
+          int w8 = __builtin_amdgcn_cvt_pk_fp8_f32(hn[0] * 128.0f, hn[1] * 128.0f, 0, false);
+          w8 = __builtin_amdgcn_cvt_pk_fp8_f32(hn[2] * 128.0f, hn[3] * 128.0f, w8, true);
+          *h8 = (uint32_t)w8;
+        } else if (e.h_wide) {      // f16(h)/64: the operand of the weights' low-order halves (scaled by 64)
           const float s0 = f16_to_f32((f16_t)(p01 & 0xffffu)) * (1.0f / 64.0f), s1 = f16_to_f32((f16_t)(p01 >> 16)) * (1.0f / 64.0f);
           const float s2 = f16_to_f32((f16_t)(p23 & 0xffffu)) * (1.0f / 64.0f), s3 = f16_to_f32((f16_t)(p23 >> 16)) * (1.0f / 64.0f);
           *(uint2*)(e.hout + hw + H) = make_uint2(pack_f16x2_hw(s0, s1), pack_f16x2_hw(s2, s3));
@@ -964,9 +973,9 @@ __device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const 
   }
 }
 
-template <class Cfg, bool SPLIT = false, bool F16 = false>
+template <class Cfg, bool SPLIT = false, bool F16 = false, bool FP8 = false>
 __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, LstmFwdParams e, int tiles_m, int tiles_n) {
-  lstm_fwd_step_body<Cfg, SPLIT, F16>(p, e, tiles_m, tiles_n, blockIdx.x);
+  lstm_fwd_step_body<Cfg, SPLIT, F16, FP8>(p, e, tiles_m, tiles_n, blockIdx.x);
 }
 
 // Two independent steps of the same geometry in one launch (the first tiles_m*tiles_n workgroups run step a, the
@@ -1005,11 +1014,11 @@ typedef TileCfg2<64, 4, 64, 2, 4, 5, true> CfgLstmV2_64;
 typedef TileCfg2<64, 4, 16, 4, 1, 5, true> CfgLstmV2Small;
 typedef TileCfg3<64, 4, 16, 4, 1, 4> CfgLstmV3Small;         // the same tile on 64-wide K stages (64 KB of LDS: still two workgroups per CU)   // 64 rows x 16 units x 4 gates on the ring loop, 4 waves, 40 KB: M ~ batch steps
 
-template <class Cfg, bool SPLIT = false, bool F16 = false>
+template <class Cfg, bool SPLIT = false, bool F16 = false, bool FP8 = false>
 static inline void launch_lstm_fwd(GemmOperands p, const LstmFwdParams& e, int k1, int k2, hipStream_t st) {
   p.nk1 = k1 / kdiv<Cfg>(); p.nk2 = k2 / kdiv<Cfg>();
   const int tm = ceil_div(e.M, Cfg::BM), tn = ceil_div(e.H, Cfg::BU);
-  launch_cfg<Cfg>(lstm_fwd_step_kernel<Cfg, SPLIT, F16>, tm * tn, st, p, e, tm, tn);
+  launch_cfg<Cfg>(lstm_fwd_step_kernel<Cfg, SPLIT, F16, FP8>, tm * tn, st, p, e, tm, tn);
 }
 
 // forward tile for a step over `rows` rows: index into {320, 288, 256, 224, 192, 160 (v2), 128 (v1), 64 (v1), 128 (v2), 64 (v2)}
@@ -1145,6 +1154,96 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
       case 8: launch_lstm_fwd<CfgLstmV2_128>(p, e, k1, k2, st); break;
       case 9: launch_lstm_fwd<CfgLstmV2_64>(p, e, k1, k2, st); break;
       default: launch_lstm_fwd<CfgLstmSmall>(p, e, k1, k2, st); break;
+    }
+  }
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// forward tile among the 64-wide ring tiles only (the e4m3 tail lives in gemm_core_v3.h): 0..3 = 256 / 224 / 192 / 160 rows
+static inline int pick_fwd_tile_v3(int rows, int H) {
+  static const int bm[4] = {256, 224, 192, 160};
+  static const double cf[4] = {1.0, 1.02, 1.04, 1.08};
+  int best = 0;
+  double bc = 1e300;
+  for (int i = 0; i < 4; ++i) {
+    const double c = tile_cost((long)ceil_div(rows, bm[i]) * ceil_div(H, 64), bm[i], 256, 1, cf[i]);
+    if (c < bc) { bc = c; best = i; }
+  }
+  const int f = forced_tile();        // debug: 1 -> 256, 6 -> 224, 7 -> 192, 8 -> 160
+  if (f == 1) best = 0; else if (f == 6) best = 1; else if (f == 7) best = 2; else if (f == 8) best = 3;
+  return best;
+}
+
+// "High" precision L1 layer with the weights' low-order halves contracted in fp8: per step
+//   z = [x16 | h16] . [W16x | W16h]^T  (IEEE f16, v_mfma_f32_16x16x32_f16)  +  2^-(7 + w8_scale_exp) [x8 | h8] . [W8x | W8h]^T  (OCP e4m3,
+//   v_mfma_scale_f32_16x16x128_f8f6f4: per K element twice the MFMA rate)
+// with W8 = e4m3((W - f16(W)) 2^w8_scale_exp) (evc_cast_f32_to_fp8_lo), x8 = e4m3(x 2^7) and h8 = e4m3(h 2^7): the weights are exact to
+// ~2^-15 relative instead of f16's 2^-11, for half the MFMA time of K-extending them by f16 low-order halves.  x rows: kx16 halfwords at
+// the row start (any K-extension of the input the caller likes, against the first kx16 columns of wT16) and kx8 e4m3 bytes at byte
+// offset x8_off of the same row (row stride ldx halfwords); hbuf rows [T+1][M]: [f16(h_t) (H halfwords) | e4m3(h_t 2^7) (H bytes)] (3H
+// bytes: what the next layer takes as its x rows with kx16 = H, x8_off = 2H, kx8 = H); wT16 [4H][kx16 + H] f16, wT8 [4H][kx8 + H] bytes.
+extern "C" int evc_lstm_layer_fwd_f16_fp8lo(const evc_f16* x, int64_t ldx, int kx16, int64_t x8_off, int kx8, const evc_f16* wT16,
+                                            const uint8_t* wT8, int w8_scale_exp, const float* bias, const int32_t* len,
+                                            int T, int M, int H, evc_f16* hbuf, evc_bf16* hbuf_bf16, float* c_state, float* h_state,
+                                            int64_t ld_state, void* gates, evc_bf16* c_all, const int32_t* row_map,
+                                            const int32_t* rows_per_step, void* stream) {
+  EVC_REQUIRE(T > 0 && M > 0 && H > 0 && kx16 > 0 && kx8 > 0, EVC_ERR_BAD_SHAPE, "evc_lstm_layer_fwd_f16_fp8lo: bad shape");
+  EVC_REQUIRE(kx16 % 64 == 0 && H % 128 == 0 && kx8 % 128 == 0 && kx8 >= 384, EVC_ERR_BAD_SHAPE,
+              "evc_lstm_layer_fwd_f16_fp8lo: kx16=%d (%%64), H=%d (%%128), kx8=%d (%%128, >= 384: the ring must be full of e4m3 stages at t = 0)", kx16, H, kx8);
+  EVC_REQUIRE(x && wT16 && wT8 && hbuf && hbuf_bf16 && bias && len, EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd_f16_fp8lo: NULL operand");
+  EVC_REQUIRE(ldx % 8 == 0 && x8_off % 16 == 0 && ldx >= kx16 && ldx * 2 >= x8_off + kx8 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)wT16 % 16) == 0 &&
+              ((uintptr_t)wT8 % 16) == 0 && ((uintptr_t)hbuf % 16) == 0 && ((uintptr_t)hbuf_bf16 % 8) == 0, EVC_ERR_BAD_ALIGN,
+              "evc_lstm_layer_fwd_f16_fp8lo: ldx=%ld (%%8), x8_off=%ld (%%16), 16-byte aligned operands", (long)ldx, (long)x8_off);
+  EVC_REQUIRE(w8_scale_exp >= 0 && w8_scale_exp <= 60, EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd_f16_fp8lo: w8_scale_exp=%d", w8_scale_exp);
+  const long ldh = 3L * H / 2;                       // halfwords per hbuf row
+  EVC_REQUIRE(ring_operand_ok(M, ldx > ldh ? ldx : ldh) && ring_operand_ok(4L * H, (long)kx16 + H), EVC_ERR_BAD_SHAPE,
+              "evc_lstm_layer_fwd_f16_fp8lo: a time slab or the kernel spans 4 GiB or more");
+  EVC_REQUIRE(ld_state % 4 == 0 && ((uintptr_t)c_state % 16) == 0 && ((uintptr_t)h_state % 16) == 0 && ((uintptr_t)bias % 16) == 0, EVC_ERR_BAD_ALIGN,
+              "evc_lstm_layer_fwd_f16_fp8lo: state/bias must allow 16-byte vector access");
+  EVC_REQUIRE((gates == nullptr) == (c_all == nullptr), EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd_f16_fp8lo: gates and c_all go together");
+  EVC_REQUIRE(!gates || (((uintptr_t)gates % 16) == 0 && ((uintptr_t)c_all % 8) == 0), EVC_ERR_BAD_ALIGN,
+              "evc_lstm_layer_fwd_f16_fp8lo: gates must be 16-byte, c_all 8-byte aligned");
+  if (rows_per_step)
+    for (int t = 0; t < T; ++t)
+      EVC_REQUIRE(rows_per_step[t] >= 0 && rows_per_step[t] <= M && (t == 0 || rows_per_step[t] <= rows_per_step[t - 1]), EVC_ERR_BAD_ARG,
+                  "evc_lstm_layer_fwd_f16_fp8lo: rows_per_step[%d]=%d must be non-increasing and within [0, M=%d]", t, rows_per_step[t], M);
+  hipStream_t st = (hipStream_t)stream;
+  const bf16_t* xb = (const bf16_t*)x;
+  bf16_t* hb = (bf16_t*)hbuf;
+  EVC_CHECK_HIP(hipMemsetAsync(hb, 0, (size_t)M * ldh * sizeof(bf16_t), st));            // h_{-1} = 0 (both parts of the rows)
+  EVC_CHECK_HIP(hipMemsetAsync(hbuf_bf16, 0, (size_t)M * H * sizeof(bf16_t), st));
+  for (int t = 0; t < T; ++t) {
+    const int Mt = rows_per_step ? rows_per_step[t] : M;
+    if (Mt == 0) break;
+    GemmOperands p;
+    p.M = Mt; p.Nu = H; p.group_stride = H; p.nk1 = p.nk2 = 0;
+    p.A1lo = p.A2lo = p.Blo = nullptr;
+    const bf16_t* xt = xb + (long)t * M * ldx;
+    const bf16_t* hprev = hb + (long)t * M * ldh;
+    p.A1 = xt; p.lda1 = ldx;
+    p.A2 = hprev; p.lda2 = ldh;
+    p.B = (const bf16_t*)wT16; p.ldb = (long)kx16 + H;
+    p.A3 = (const uint8_t*)xt + x8_off; p.lda3 = ldx * 2; p.nk3 = kx8 / 128;
+    p.A4 = (const uint8_t*)(hprev + H); p.lda4 = ldh * 2; p.nk4 = t == 0 ? 0 : H / 128;
+    p.B8 = wT8; p.ldb8 = (long)kx8 + H;
+    p.scale8_exp = -(7 + w8_scale_exp);
+    const int k1 = kx16, k2 = t == 0 ? 0 : H;
+    LstmFwdParams e;
+    e.zx = nullptr; e.ldzx = 0;
+    e.bias = bias; e.len = len; e.t = t;
+    e.c_state = c_state; e.h_state = h_state; e.ld_state = ld_state;
+    e.hout = hb + (long)(t + 1) * M * ldh; e.h_wide = 2;
+    e.hout_lo = hbuf_bf16 + (long)(t + 1) * M * H;
+    e.gates = gates ? (uint2*)gates + (long)t * M * H : nullptr;
+    e.c_hist = c_all ? c_all + (long)(t + 1) * M * H : nullptr;
+    e.row_map = row_map;
+    e.M = Mt; e.H = H;
+    switch (pick_fwd_tile_v3(Mt, H)) {
+      case 0: launch_lstm_fwd<CfgLstmV3_256, false, true, true>(p, e, k1, k2, st); break;
+      case 1: launch_lstm_fwd<CfgLstmV3_224, false, true, true>(p, e, k1, k2, st); break;
+      case 2: launch_lstm_fwd<CfgLstmV3_192, false, true, true>(p, e, k1, k2, st); break;
+      default: launch_lstm_fwd<CfgLstmV3_160, false, true, true>(p, e, k1, k2, st); break;
     }
   }
   EVC_LAUNCH_CHECK();

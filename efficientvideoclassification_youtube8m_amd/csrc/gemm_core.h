@@ -47,6 +47,14 @@ struct GemmOperands {
   // A1 segment's columns of B - two weight matrices with the same row stride contracted back to back (the BPTT
   // wavefront: [dz0_{t+1} | dz1_t] . [Wh0 ; Wx1]^T).  nullptr: B's k index runs on.
   const bf16_t* B2 = nullptr;
+  // v3 loop with LOOP_FP8_TAIL only: behind the nk1 + nk2 16-bit stages come nk3 + nk4 stages of 128 OCP e4m3 BYTES per row -
+  // A3 rows (row stride lda3 BYTES), then A4 rows, against B8 rows (row stride ldb8 bytes, row index as for B; B8's k index
+  // runs on from the A3 segment into the A4 segment) - contracted by v_mfma_scale_f32_16x16x128_f8f6f4 (per K element twice
+  // the rate of the 16-bit stages) with every product scaled by 2^scale8_exp: the "high" mode's low-order weight halves.
+  const uint8_t* A3 = nullptr; long lda3 = 0; int nk3 = 0;
+  const uint8_t* A4 = nullptr; long lda4 = 0; int nk4 = 0;
+  const uint8_t* B8 = nullptr; long ldb8 = 0;
+  int scale8_exp = 0;
 };
 
 // XCD-aware bijective remap of the linear workgroup id: consecutive remapped

@@ -28,7 +28,9 @@
 //  LOOP_DMA_FIRST  the scheduler is asked to place the LDS-DMA ahead of the fragment reads among the MFMAs of a K step
 //  LOOP_NO_PRIO    no s_setprio 1 / 0 around every K step's MFMA cluster
 //  LOOP_F16       the operands are IEEE f16: v_mfma_f32_16x16x32_f16 instead of _bf16 (staging and LDS image are the same)
-constexpr int LOOP_PRODUCER = 1, LOOP_DMA_FIRST = 2, LOOP_NO_PRIO = 4, LOOP_F16 = 8;
+//  LOOP_FP8_TAIL  (v3 loop only) the 16-bit stages are followed by stages of 128 e4m3 bytes per row on the MX-scaled MFMA
+//                 (GemmOperands::A3 / A4 / B8); needs nk1 + nk2 >= 1 and nk3 + nk4 >= STAGES
+constexpr int LOOP_PRODUCER = 1, LOOP_DMA_FIRST = 2, LOOP_NO_PRIO = 4, LOOP_F16 = 8, LOOP_FP8_TAIL = 16;
 #ifndef EVC_LOOP_MODE_DEFAULT
 #define EVC_LOOP_MODE_DEFAULT 0
 #endif

@@ -14,8 +14,19 @@
 //    only barrier of the trip and refills the slot of the stage just consumed - STAGES-1 stages stay in flight.
 //  * operands, column groups, SWAP, clamping and the MODE options as in gemm_core_v2.h; K % 64 == 0 (nk1 / nk2 count 64-wide
 //    stages here).
+//  * LOOP_FP8_TAIL: after the 16-bit stages the ring carries on with stages of 128 e4m3 BYTES per row (GemmOperands::A3 / A4 /
+//    B8: the same 128-byte LDS rows, the same LDS-DMA pieces, the same swizzle).  One v_mfma_scale_f32_16x16x128_f8f6f4 per
+//    fragment pair takes BOTH 16-byte chunks of a lane's row (chunks fq and 4 + fq; the K position of an operand byte is the
+//    same function of lane group and register byte for A and B - scripts/probes/fp8_mfma_probe.hip - so the pairs meet) and runs
+//    1.77x as long as one 16-bit MFMA for 4x the K.  The two halves of such a trip split the tile's ROW fragments instead of
+//    the stage's K range: half 1 multiplies the lower row fragments while the upper ones are read, half 2 (behind the barrier
+//    and the refill) the upper ones while the next stage's lower row fragments and - column group by column group, as its last
+//    MFMA has been issued - its B fragments are read: the same register budget as the 16-bit trips.
 #pragma once
 #include "gemm_core_v2.h"
+
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v8i_t __attribute__((ext_vector_type(8)));
 
 template <int BM_, int G_, int BU_, int WR_, int WC_, int STAGES_ = 4>
 struct TileCfg3 {
@@ -49,7 +60,9 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
 #pragma unroll
         for (int ni = 0; ni < Cfg::NI; ++ni) acc[mi][g][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const int nk = p.nk1 + p.nk2;   // in 64-wide stages
+  constexpr bool FP8 = (MODE & LOOP_FP8_TAIL) != 0;
+  const int nkf = p.nk1 + p.nk2;                       // 16-bit stages (64 elements wide)
+  const int nk = nkf + (FP8 ? p.nk3 + p.nk4 : 0);      // + e4m3 stages (128 elements wide)
   if (nk == 0) return;
 
   // ---- staging: piece q (1 KiB) = tile rows 8q .. 8q+7, 128 bytes each; lane -> row lane>>3, physical chunk lane&7 ----
@@ -61,7 +74,7 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
   constexpr int PER = ACH + BCH;
   static_assert(Cfg::RAGGED || (ACH * NPW * 8 == Cfg::BM && BCH * NPW * 8 == Cfg::BN), "surplus pieces need the dummy sink");
   int a_row[ACH];              // (addressing as in gemm_core_v2.h: wave-uniform base + 32-bit lane byte offset)
-  uint32_t b_vo[BCH];
+  uint32_t b_vo[BCH];          // FP8: the B row index (two row strides: the byte offset is formed per stage, as for A)
   int a_dst[ACH], b_dst[BCH];   // wave-uniform LDS byte offsets within a stage (or the dummy sink)
 #pragma unroll
   for (int i = 0; i < ACH; ++i) {
@@ -80,7 +93,7 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
     const int g = r / Cfg::BU, u = r % Cfg::BU;
     int gu = u0 + u;
     gu = gu < p.Nu ? gu : p.Nu - 1;
-    b_vo[i] = (uint32_t)((((long)g * p.group_stride + gu) * p.ldb + lc8) * 2);
+    b_vo[i] = FP8 ? (uint32_t)((long)g * p.group_stride + gu) : (uint32_t)((((long)g * p.group_stride + gu) * p.ldb + lc8) * 2);
     b_dst[i] = live ? Cfg::A_BYTES + q * 1024 : -1;
   }
   const bf16_t* const b2 = p.B2 ? p.B2 - (long)p.nk1 * 64 : p.B;   // base such that b2 + ks*64 addresses the A2 segment's B columns
@@ -90,8 +103,18 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
   auto stage = [&]() {                 // branch-free (scalar selects only)
     const bool s1 = ks_issue < p.nk1;
     const char* ab = (const char*)(s1 ? p.A1 + (long)ks_issue * 64 : p.A2 + (long)(ks_issue - p.nk1) * 64);
-    const uint32_t lda_b = (uint32_t)(s1 ? p.lda1 : p.lda2) * 2u;
+    uint32_t lda_b = (uint32_t)(s1 ? p.lda1 : p.lda2) * 2u;
     const char* b_base = (const char*)((s1 ? p.B : b2) + (long)ks_issue * 64);
+    uint32_t ldb_b = (uint32_t)p.ldb * 2u;
+    if constexpr (FP8) {               // stages behind the 16-bit ones: rows of 128 e4m3 bytes
+      const int k8 = ks_issue - nkf;
+      const bool f = k8 < 0, s3 = k8 < p.nk3;
+      const char* ab8 = s3 ? (const char*)p.A3 + (long)k8 * 128 : (const char*)p.A4 + (long)(k8 - p.nk3) * 128;
+      ab = f ? ab : ab8;
+      lda_b = f ? lda_b : (uint32_t)(s3 ? p.lda3 : p.lda4);
+      b_base = f ? b_base : (const char*)p.B8 + (long)k8 * 128;
+      ldb_b = f ? ldb_b : (uint32_t)p.ldb8;
+    }
     char* sbase = lds + slot_issue * Cfg::STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
@@ -103,7 +126,8 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
       char* dst = b_dst[i] >= 0 ? sbase + b_dst[i] : lds + Cfg::DUMMY_OFF;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_base + b_vo[i]),
+      const uint32_t vo = FP8 ? __umul24(b_vo[i], ldb_b) + (uint32_t)(lc8 * 2) : b_vo[i];
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_base + vo),
                                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
     ++ks_issue;
@@ -114,24 +138,23 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
   // (chunk (4 + fq) ^ s = (fq ^ s) ^ 4 for fq < 4)
   const int frow = lane & 15, fq = lane >> 4;
   const int fch = (fq ^ (frow & 7)) * 16;      // tile rows start on multiples of 16 -> row & 7 == frow & 7
-  int a_rd[Cfg::MI], b_rd[Cfg::G][Cfg::NI];
-#pragma unroll
-  for (int mi = 0; mi < Cfg::MI; ++mi) a_rd[mi] = (wr * Cfg::WM + mi * 16 + frow) * 128 + fch;
-#pragma unroll
-  for (int g = 0; g < Cfg::G; ++g)
-#pragma unroll
-    for (int ni = 0; ni < Cfg::NI; ++ni)
-      b_rd[g][ni] = Cfg::A_BYTES + (g * Cfg::BU + wc * Cfg::WU + ni * 16 + frow) * 128 + fch;
+  // one base per operand and K half; fragment (mi | g, ni) sits a COMPILE-TIME multiple of 128 bytes behind it (adding a multiple of
+  // 128 commutes with flipping bit 6): immediates of the ds_read instead of one address register per fragment and half
+  const int a_rd0 = (wr * Cfg::WM + frow) * 128 + fch, b_rd0 = Cfg::A_BYTES + (wc * Cfg::WU + frow) * 128 + fch;
+  const int a_rd1 = a_rd0 ^ 64, b_rd1 = b_rd0 ^ 64;
+  auto a_off = [](const int mi) { return mi * 16 * 128; };
+  auto b_off = [](const int g, const int ni) { return (g * Cfg::BU + ni * 16) * 128; };
 
   auto read_half = [&](const int kb, bf16x8 (&af)[Cfg::MI], bf16x8 (&bfr)[Cfg::G][Cfg::NI]) {   // reads half kb of ring slot slot_read
     const char* sb = lds + slot_read * Cfg::STAGE_BYTES;
-    const int x = kb << 6;
+    const char* pa = sb + (kb ? a_rd1 : a_rd0);
+    const char* pb = sb + (kb ? b_rd1 : b_rd0);
 #pragma unroll
     for (int g = 0; g < Cfg::G; ++g)
 #pragma unroll
-      for (int ni = 0; ni < Cfg::NI; ++ni) bfr[g][ni] = *(const bf16x8*)(sb + (b_rd[g][ni] ^ x));
+      for (int ni = 0; ni < Cfg::NI; ++ni) bfr[g][ni] = *(const bf16x8*)(pb + b_off(g, ni));
 #pragma unroll
-    for (int mi = 0; mi < Cfg::MI; ++mi) af[mi] = *(const bf16x8*)(sb + (a_rd[mi] ^ x));
+    for (int mi = 0; mi < Cfg::MI; ++mi) af[mi] = *(const bf16x8*)(pa + a_off(mi));
   };
   auto next_slot = [&]() { slot_read = (slot_read + 1 == Cfg::STAGES) ? 0 : slot_read + 1; };
   auto mfma_all = [&](const bf16x8 (&af)[Cfg::MI], const bf16x8 (&bfr)[Cfg::G][Cfg::NI]) {
@@ -201,8 +224,9 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
   read_half(0, afA, bfA);
   __builtin_amdgcn_s_waitcnt(0xC07F);   // enter the loop with no LDS read pending
 
-  int j = 0;
-  for (; j + Cfg::STAGES < nk; ++j) {   // steady state: stage j+STAGES exists, so every trip refills
+  // one steady-state trip over a 16-bit stage (a later stage exists and is refilled into the slot this trip frees);
+  // prefetch: read the first half of the next stage's fragments behind the barrier (false: the next stage is an e4m3 stage)
+  auto trip16 = [&](auto prefetch_tag) {
     // first half: its partner fragments are in the stage being read - no wait, no barrier
     if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
     read_half(1, afB, bfB);
@@ -212,34 +236,251 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
 #endif
     if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     end_of_step();
-    // second half: stage j+1 must have landed; after the barrier every wave has read all of stage j -> refill its slot
+    // second half: the next stage must have landed; after the barrier every wave has read all of this stage -> refill its slot
     if constexpr (PROD) wait_vmcnt<AHEAD * PER>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
     stage_role();
     next_slot();
-    read_half(0, afA, bfA);
+    if constexpr (decltype(prefetch_tag)::value) read_half(0, afA, bfA);
     mfma_all(afB, bfB);
 #ifndef EVC_NO_INTERLEAVE
-    interleave(std::integral_constant<int, PERX>{});
+    if constexpr (decltype(prefetch_tag)::value) interleave(std::integral_constant<int, PERX>{});
 #endif
     if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     end_of_step();
-  }
-  for (; j < nk; ++j) {                 // last STAGES stages: no refills
-    read_half(1, afB, bfB);
-    mfma_all(afA, bfA);
-    end_of_step();
-    if (j + 1 < nk) {
+  };
+
+  int j = 0;
+  if constexpr (!FP8) {
+    for (; j + Cfg::STAGES < nk; ++j) trip16(std::true_type{});   // steady state: stage j+STAGES exists, so every trip refills
+    for (; j < nk; ++j) {                 // last STAGES stages: no refills
+      read_half(1, afB, bfB);
+      mfma_all(afA, bfA);
+      end_of_step();
+      if (j + 1 < nk) {
+        if constexpr (PROD) wait_landed(nk - (j + 2));
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        next_slot();
+        read_half(0, afA, bfA);
+      }
+      mfma_all(afB, bfB);
+      end_of_step();
+    }
+  } else {
+    // ---- 16-bit stages (every one of them is followed by >= STAGES more stages: all trips refill), then the e4m3 stages ----
+    for (; j + 1 < nkf; ++j) trip16(std::true_type{});
+    trip16(std::false_type{});
+    ++j;
+#ifdef EVC_FP8_GROUPS4
+    // Row fragments in four groups of 1-2 (sizes differ by at most one, larger first), two register sets: group q+1 is read while
+    // group q multiplies; all B fragments of the stage stay in registers.  The barrier sits in front of the LAST group (its reads
+    // were the stage's last): behind it the refill, the next stage's group 0 and - column group by column group, as its last MFMA
+    // has been issued - the next stage's B fragments.
+    constexpr int QB = Cfg::MI / 4, QR = Cfg::MI % 4;
+    static_assert(QB >= 1 && QB + (QR ? 1 : 0) <= 2, "e4m3 trips: 4..8 row fragments per wave");
+    constexpr int QS0 = QB + (QR > 0), QS1 = QB + (QR > 1), QS2 = QB + (QR > 2), QS3 = QB;
+    constexpr int QO1 = QS0, QO2 = QS0 + QS1, QO3 = QS0 + QS1 + QS2;
+    v8i_t aE[2], aO[2], b8[Cfg::G][Cfg::NI];                    // even / odd groups
+    const int sc_first = 127 + p.scale8_exp, sc_second = 127;   // e8m0 scale bytes: the whole factor rides on the first operand
+    auto rd8 = [&](const int base0, const int base1, const int off) -> v8i_t {   // both 16-byte chunks of this lane's row in ring slot slot_read
+      const char* sb = lds + slot_read * Cfg::STAGE_BYTES;
+      const v4i_t lo = *(const v4i_t*)(sb + base0 + off), hi = *(const v4i_t*)(sb + base1 + off);
+      return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto mfma8 = [&](const v8i_t& a, const v8i_t& b, f32x4& c) {
+      c = SWAP ? __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b, a, c, 0, 0, 0, sc_first, 0, sc_second)
+               : __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, sc_first, 0, sc_second);
+    };
+    auto rd_group = [&](auto off_tag, auto n_tag, v8i_t (&dst)[2]) {
+      constexpr int o = decltype(off_tag)::value, n = decltype(n_tag)::value;
+#pragma unroll
+      for (int i = 0; i < n; ++i) dst[i] = rd8(a_rd0, a_rd1, a_off(o + i));
+    };
+    auto mul_group = [&](auto off_tag, auto n_tag, const v8i_t (&src)[2], auto reload_tag) {   // column group by column group
+      constexpr int o = decltype(off_tag)::value, n = decltype(n_tag)::value;
+      constexpr bool reload = decltype(reload_tag)::value;
+#pragma unroll
+      for (int g = 0; g < Cfg::G; ++g)
+#pragma unroll
+        for (int ni = 0; ni < Cfg::NI; ++ni) {
+#pragma unroll
+          for (int i = 0; i < n; ++i) mfma8(src[i], b8[g][ni], acc[o + i][g][ni]);
+          if constexpr (reload) b8[g][ni] = rd8(b_rd0, b_rd1, b_off(g, ni));
+        }
+    };
+    auto pattern = [&](auto nmfma_tag, auto nread_tag, auto ndma_tag) {   // LDS-DMAs and fragment reads spread behind the MFMAs
+      constexpr int nm = decltype(nmfma_tag)::value, nr = decltype(nread_tag)::value, nd = decltype(ndma_tag)::value;
+      constexpr int rper = (nr + nm - 1) / nm, dper = (nd + nm - 1) / nm;
+#pragma unroll
+      for (int i = 0; i < nm; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (dper > 0) __builtin_amdgcn_sched_group_barrier(0x020, dper, 0);
+        if constexpr (rper > 0) __builtin_amdgcn_sched_group_barrier(0x100, rper, 0);
+      }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    constexpr int GN = Cfg::G * Cfg::NI;
+    // the first e4m3 stage's group 0 and B fragments (once per launch: nothing to hide these reads behind)
+    rd_group(I0{}, std::integral_constant<int, QS0>{}, aE);
+#pragma unroll
+    for (int g = 0; g < Cfg::G; ++g)
+#pragma unroll
+      for (int ni = 0; ni < Cfg::NI; ++ni) b8[g][ni] = rd8(b_rd0, b_rd1, b_off(g, ni));
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    auto first_groups = [&]() {           // groups 0..2 multiply while groups 1..3 are read
+      rd_group(std::integral_constant<int, QO1>{}, std::integral_constant<int, QS1>{}, aO);
+      mul_group(I0{}, std::integral_constant<int, QS0>{}, aE, std::false_type{});
+#ifndef EVC_NO_INTERLEAVE
+      pattern(std::integral_constant<int, QS0 * GN>{}, std::integral_constant<int, 2 * QS1>{}, I0{});
+#endif
+      end_of_step();
+      rd_group(std::integral_constant<int, QO2>{}, std::integral_constant<int, QS2>{}, aE);
+      mul_group(std::integral_constant<int, QO1>{}, std::integral_constant<int, QS1>{}, aO, std::false_type{});
+#ifndef EVC_NO_INTERLEAVE
+      pattern(std::integral_constant<int, QS1 * GN>{}, std::integral_constant<int, 2 * QS2>{}, I0{});
+#endif
+      end_of_step();
+      rd_group(std::integral_constant<int, QO3>{}, std::integral_constant<int, QS3>{}, aO);
+      mul_group(std::integral_constant<int, QO2>{}, std::integral_constant<int, QS2>{}, aE, std::false_type{});
+#ifndef EVC_NO_INTERLEAVE
+      pattern(std::integral_constant<int, QS2 * GN>{}, std::integral_constant<int, 2 * QS3>{}, I0{});
+#endif
+      end_of_step();                      // every fragment of this stage is in registers
+    };
+    for (; j + Cfg::STAGES < nk; ++j) {   // steady state
+      first_groups();
+      if constexpr (PROD) wait_vmcnt<AHEAD * PER>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      stage_role();
+      next_slot();
+      rd_group(I0{}, std::integral_constant<int, QS0>{}, aE);
+      mul_group(std::integral_constant<int, QO3>{}, std::integral_constant<int, QS3>{}, aO, std::true_type{});
+#ifndef EVC_NO_INTERLEAVE
+      pattern(std::integral_constant<int, QS3 * GN>{}, std::integral_constant<int, 2 * (QS0 + GN)>{}, std::integral_constant<int, PERX>{});
+#endif
+      end_of_step();
+    }
+    for (; j + 1 < nk; ++j) {             // last STAGES stages: no refills
+      first_groups();
       if constexpr (PROD) wait_landed(nk - (j + 2));
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       next_slot();
-      read_half(0, afA, bfA);
+      rd_group(I0{}, std::integral_constant<int, QS0>{}, aE);
+      mul_group(std::integral_constant<int, QO3>{}, std::integral_constant<int, QS3>{}, aO, std::true_type{});
+      end_of_step();
     }
-    mfma_all(afB, bfB);
+    first_groups();
+    mul_group(std::integral_constant<int, QO3>{}, std::integral_constant<int, QS3>{}, aO, std::false_type{});
     end_of_step();
+#else
+    // Two halves per trip, split by the tile's ROW fragments (the 16-bit trips split the stage's K range): half 1 multiplies the lower
+    // row fragments while the upper ones are read; behind the barrier and the refill, half 2 multiplies the upper ones while the next
+    // stage's lower row fragments and - column group by column group, as its last MFMA has been issued - its B fragments are read.
+    constexpr int ML = (Cfg::MI + 1) / 2, MH = Cfg::MI - ML;
+    static_assert(MH >= 1, "e4m3 trips: at least two row fragments per wave");
+    v8i_t aL[ML], aH[MH], b8[Cfg::G][Cfg::NI];
+    const int sc_first = 127 + p.scale8_exp, sc_second = 127;   // e8m0 scale bytes: the whole factor rides on the first operand
+    auto rd8 = [&](const int base0, const int base1, const int off) -> v8i_t {   // both 16-byte chunks of this lane's row in ring slot slot_read
+      const char* sb = lds + slot_read * Cfg::STAGE_BYTES;
+      const v4i_t lo = *(const v4i_t*)(sb + base0 + off), hi = *(const v4i_t*)(sb + base1 + off);
+      return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto mfma8 = [&](const v8i_t& a, const v8i_t& b, f32x4& c) {
+      c = SWAP ? __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b, a, c, 0, 0, 0, sc_first, 0, sc_second)
+               : __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, sc_first, 0, sc_second);
+    };
+    auto rd_lower = [&]() {
+#pragma unroll
+      for (int mi = 0; mi < ML; ++mi) aL[mi] = rd8(a_rd0, a_rd1, a_off(mi));
+    };
+    auto lower = [&]() {                  // half 1: upper row fragments arrive under the lower ones' MFMAs
+#pragma unroll
+      for (int mi = 0; mi < MH; ++mi) aH[mi] = rd8(a_rd0, a_rd1, a_off(ML + mi));
+#pragma unroll
+      for (int g = 0; g < Cfg::G; ++g)
+#pragma unroll
+        for (int ni = 0; ni < Cfg::NI; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < ML; ++mi) mfma8(aL[mi], b8[g][ni], acc[mi][g][ni]);
+    };
+    auto upper = [&](auto reload_tag) {   // half 2; a B fragment is re-read (next stage) once its last MFMA is out
+#pragma unroll
+      for (int g = 0; g < Cfg::G; ++g)
+#pragma unroll
+        for (int ni = 0; ni < Cfg::NI; ++ni) {
+#pragma unroll
+          for (int mi = 0; mi < MH; ++mi) mfma8(aH[mi], b8[g][ni], acc[ML + mi][g][ni]);
+          if constexpr (decltype(reload_tag)::value) b8[g][ni] = rd8(b_rd0, b_rd1, b_off(g, ni));
+        }
+    };
+    auto pattern = [&](auto nmfma_tag, auto nread_tag, auto ndma_tag) {   // LDS-DMAs and fragment reads spread behind the MFMAs
+      constexpr int nm = decltype(nmfma_tag)::value, nr = decltype(nread_tag)::value, nd = decltype(ndma_tag)::value;
+      constexpr int rper = (nr + nm - 1) / nm, dper = (nd + nm - 1) / nm;
+#pragma unroll
+      for (int i = 0; i < nm; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (dper > 0) __builtin_amdgcn_sched_group_barrier(0x020, dper, 0);
+        if constexpr (rper > 0) __builtin_amdgcn_sched_group_barrier(0x100, rper, 0);
+      }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    constexpr int GN = Cfg::G * Cfg::NI;
+    // the first e4m3 stage's lower row fragments and B fragments (once per launch: nothing to hide these reads behind)
+    rd_lower();
+#pragma unroll
+    for (int g = 0; g < Cfg::G; ++g)
+#pragma unroll
+      for (int ni = 0; ni < Cfg::NI; ++ni) b8[g][ni] = rd8(b_rd0, b_rd1, b_off(g, ni));
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    auto half1 = [&]() {
+      lower();
+#ifndef EVC_NO_INTERLEAVE
+      pattern(std::integral_constant<int, ML * GN>{}, std::integral_constant<int, 2 * MH>{}, I0{});
+#endif
+      // hipcc otherwise SINKS these MFMAs below the barrier (their results are first read a trip later): all 32 of a trip then sit
+      // behind the barrier, the reads of both halves stand alone in front of an lgkmcnt(0), and the two waves of a SIMD - in step
+      // through the barrier - wait for LDS together
+#pragma unroll
+      for (int mi = 0; mi < ML; ++mi)
+#pragma unroll
+        for (int g = 0; g < Cfg::G; ++g)
+#pragma unroll
+          for (int ni = 0; ni < Cfg::NI; ++ni) asm volatile("" : "+v"(acc[mi][g][ni]));
+      end_of_step();                      // every fragment of this stage is in registers
+    };
+    for (; j + Cfg::STAGES < nk; ++j) {   // steady state
+      half1();
+      if constexpr (PROD) wait_vmcnt<AHEAD * PER>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      stage_role();
+      next_slot();
+      rd_lower();
+      upper(std::true_type{});
+#ifndef EVC_NO_INTERLEAVE
+      pattern(std::integral_constant<int, MH * GN>{}, std::integral_constant<int, 2 * (ML + GN)>{}, std::integral_constant<int, PERX>{});
+#endif
+      end_of_step();
+    }
+    for (; j + 1 < nk; ++j) {             // last STAGES stages: no refills
+      half1();
+      if constexpr (PROD) wait_landed(nk - (j + 2));
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      next_slot();
+      rd_lower();
+      upper(std::true_type{});
+      end_of_step();
+    }
+    half1();
+    upper(std::false_type{});
+    end_of_step();
+#endif
   }
   };   // run
   if constexpr (PRODUCERS) {

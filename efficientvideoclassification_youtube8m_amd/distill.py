@@ -281,6 +281,18 @@ def student_light(student, precision):
         student.f16_x_segments = 1
         student.f16_wh_ext_layers = ()
         student.f16_wx_ext_layers = ()
+        student.f16_fp8_lo = False
+
+
+def input_image_args(*towers):
+    """f16_segments / fp8_tail of ops.l2norm_chunk for the towers that share one input image: the widest K-extension any of them
+    contracts (a tower may read fewer segments than the rows hold); with a tower on the fp8 L1 level the rows are its 5F-byte ones."""
+    tw = [t for t in towers if t is not None]
+    fp8 = any(t.fp8_lo() for t in tw)
+    if fp8:
+        assert all(t.fp8_lo() or t.f16_x_segments == 1 for t in tw), "towers sharing an fp8 input image read its plain f16 part"
+        return dict(f16_segments=1, fp8_tail=True)
+    return dict(f16_segments=max(t.f16_x_segments for t in tw))
 
 
 def frame_counts_and_plans(g, num_frames, nh, need_teacher, need_student):
@@ -439,7 +451,7 @@ class DistillGraph:
                                   num_frames=num_frames if x_raw.dtype == torch.uint8 else None,
                                   split=(self.teacher or self.student).input_split(), plan1=tp[2] if tp else None,
                                   plan2=sp[3] if sp else None,
-                                  f16_segments=max(t.f16_x_segments for t in (self.teacher, self.student) if t is not None))
+                                  **input_image_args(self.teacher, self.student))
         self.losses.zero_()
         out = {}
         mark = self._mark
@@ -652,7 +664,7 @@ class EvalGraph:
         tp, sp = frame_counts_and_plans(self, num_frames, nh, self.teacher is not None, True)
         xt, xs = ops.l2norm_chunk(x_raw, self.C1, self.every_n, self.C2, num_frames=num_frames if u8 else None, split=split,
                                   plan1=tp[2] if tp else None, plan2=sp[3],
-                                  f16_segments=max(t.f16_x_segments for t in (self.teacher, self.student) if t is not None))
+                                  **input_image_args(self.teacher, self.student))
         self.losses.zero_()
         out = {}
         self._ev_in.record(main)

@@ -182,6 +182,29 @@ class LstmStack:
                                         self.zx, hw[0], hw[1], hb[0], hb[1], self.S, gates, c_all,
                                         x_segments=tw.f16_l2_x_segments, h0_ext=tw.f16_l2_h0_ext)
                 return self.S
+            if self.scope == "RNN_L1" and tw.fp8_lo():
+                # weights' low-order halves in fp8 (ops.lstm_layer_fwd_f16_fp8lo): h rows [f16(h) | e4m3(h 2^7)] of 3H bytes; layer 0 reads
+                # the [f16(x) | e4m3(x 2^7) | e4m3(x_lo 2^18)] rows of ops.l2norm_chunk(fp8_tail=True), the layers above the h rows of the layer below
+                if not hasattr(self, "hbuf16"):
+                    self.hbuf16 = [torch.zeros((self.T + 1, self.M, 3 * H // 2), dtype=ops.F16, device=self.hbuf[l].device) for l in range(L)]
+                h16 = [self._v(self.hbuf16[l], T + 1, M, 3 * H // 2) for l in range(L)]
+                assert x16.shape[-1] == 2 * self.Kin, "the fp8 L1 level takes ops.l2norm_chunk(..., f16_segments=1, fp8_tail=True) rows"
+                inp, ldx, kx16, x8_off, kx8 = x16, x16.shape[-1], self.Kin, 2 * self.Kin, 2 * self.Kin
+                for l in range(L):
+                    kn, bn = self.names(l)
+                    if self.timing is not None:
+                        e0 = torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                    ops.lstm_layer_fwd_f16_fp8lo(inp, ldx, kx16, x8_off, kx8, tw.shadow16[kn], tw.shadow8[kn], tw.store.p(bn), lens, T, M, H,
+                                                 h16[l], hb[l], self.S[:, (2 * l) * H:], self.S[:, (2 * l + 1) * H:], 2 * L * H,
+                                                 gates[l], c_all[l], plan=plan)
+                    if self.timing is not None:
+                        e1 = torch.cuda.Event(enable_timing=True)
+                        e1.record()
+                        flops = sum(2.0 * r * 4 * H * (self.kin[l] + (H if t > 0 else 0)) for t, r in enumerate(rows))
+                        self.timing.append((e0, e1, sum(1 for r in rows if r > 0), flops))
+                    inp, ldx, kx16, x8_off, kx8 = h16[l][1:], 3 * H // 2, H, 2 * H, H
+                return self.S
             wide = [l in tw.f16_wh_ext_layers for l in range(L)]        # layers whose recurrent weights are K-extended (wide h rows)
             if not hasattr(self, "hbuf16"):
                 self.hbuf16 = [torch.zeros((self.T + 1, self.M, (2 if wide[l] else 1) * H), dtype=ops.F16, device=self.hbuf[l].device)
@@ -808,6 +831,17 @@ class HLstmTower(TowerBase):
     f16_l2_x_segments = int(os.environ.get("EVC_HIGH_L2_X_SEGMENTS", "2"))
     f16_l2_h0_ext = os.environ.get("EVC_HIGH_L2_H0_EXT", "1") != "0"
 
+    # L1 level with the LOW-ORDER HALVES of the weights - and of the input frames - contracted in fp8 (ops.lstm_layer_fwd_f16_fp8lo) instead of
+    # f16 K-extensions: per step [x | h] . [Wx | Wh]^T in f16 + [e4m3(x) | e4m3(x_lo) | e4m3(h)] . [e4m3(Wx_lo) | e4m3(Wx) | e4m3(Wh_lo)]^T on the
+    # MX-scaled MFMA - every weight and the input exact to ~2^-15 for half the MFMA time of the f16 extensions (scripts/precision_budget.py:
+    # the weight term of the error budget 3.7e-5 -> 9e-7 on the logits, the input term 5.3e-5 -> 1e-6).
+    # Needs F, H multiples of 128 and >= 384; EVC_HIGH_FP8_LO=0: the f16 K-extensions above (the round-3 "FZ" layout).
+    f16_fp8_lo = os.environ.get("EVC_HIGH_FP8_LO", "1") != "0"
+
+    def fp8_lo(self):
+        """True if this tower's L1 level runs on ops.lstm_layer_fwd_f16_fp8lo."""
+        return (self.precision == "high" and self.f16_fp8_lo and self.F % 128 == 0 and self.H % 128 == 0 and self.F >= 384 and self.H >= 384)
+
     def input_split(self):
         """The `split` argument of ops.l2norm_chunk that produces this tower's L1 input."""
         return {"bf16": False, "high": "f16", "split": "wide"}[self.precision]
@@ -815,11 +849,16 @@ class HLstmTower(TowerBase):
     def _alloc_high_shadows(self):
         dev, H, F, K = self.device, self.H, self.F, self.K
         self.shadow_lo = {}                                              # (no separate low-order shadows in this tower)
-        self.shadow16, self.shadow_wx, self.shadow_wh, self.shadow_w = {}, {}, {}, {}
+        self.shadow16, self.shadow_wx, self.shadow_wh, self.shadow_w, self.shadow8 = {}, {}, {}, {}, {}
         for k, shp in self.store.shapes.items():
             if len(shp) != 2:
                 continue
-            if k.startswith("RNN_L1/") and self.precision == "high":
+            if k.startswith("RNN_L1/") and self.fp8_lo():
+                nin = shp[1] - H
+                layer = int(k.split("cell_")[1].split("/")[0])
+                self.shadow16[k] = torch.zeros(shp, dtype=ops.F16, device=dev)
+                self.shadow8[k] = torch.zeros((shp[0], shp[1] + (nin if layer == 0 else 0)), dtype=torch.uint8, device=dev)
+            elif k.startswith("RNN_L1/") and self.precision == "high":
                 nin = shp[1] - H
                 layer = int(k.split("cell_")[1].split("/")[0])
                 xw = self.f16_x_segments * nin if layer == 0 else (2 if layer in self.f16_wx_ext_layers else 1) * nin
@@ -838,7 +877,10 @@ class HLstmTower(TowerBase):
 
     def _refresh_high(self, k):
         p, H = self.store.p(k), self.H
-        if k in self.shadow16 and k.startswith("RNN_L2/") and "cell_1" in k:
+        if k in self.shadow8:                # L1 level, fp8 low-order halves: f16(W) + e4m3((W - f16(W)) 2^17) (layer 0: + e4m3(Wx 2^6) for the input's)
+            ops.cast_f16(p, self.shadow16[k])
+            ops.cast_fp8_lo(p, self.shadow8[k], hi_cols=self.shadow8[k].shape[1] - p.shape[1])
+        elif k in self.shadow16 and k.startswith("RNN_L2/") and "cell_1" in k:
             ops.cast_f16_wlo(p, p.shape[1] - H, H, self.shadow16[k])
         elif k in self.shadow16 and k.startswith("RNN_L1/") and "cell_0" not in k and int(k.split("cell_")[1].split("/")[0]) in self.f16_wx_ext_layers:
             layer = int(k.split("cell_")[1].split("/")[0])          # upper L1 layer with its INPUT weights extended: [Wx | Wx_lo*64 | Wh (| Wh_lo*64)]

@@ -126,6 +126,19 @@ def cast_f16_wlo(w, Kin, H, out):
     return out
 
 
+FP8_W_SCALE_EXP = 17       # e4m3((W - f16(W)) * 2^17): |W| < 4 never clamps, weights above ~2^-13 keep 3-4 bits of their low-order half
+FP8_WX_HI_EXP = 6          # e4m3(Wx * 2^6) against e4m3((x - f16(x)) * 2^18): the same 2^24 as 2^7 * 2^17
+
+
+def cast_fp8_lo(w, out, hi_cols=0, scale_exp=FP8_W_SCALE_EXP, hi_exp=FP8_WX_HI_EXP):
+    """out uint8 = e4m3(clamp((w - f16(w)) * 2^scale_exp)): the low-order halves of a weight matrix next to its f16 image (the wT8 operand of
+    lstm_layer_fwd_f16_fp8lo).  hi_cols > 0: out [R][C + hi_cols] = [lo(W[:, :hi_cols]) | e4m3(W[:, :hi_cols] * 2^hi_exp) | lo(W[:, hi_cols:])] -
+    the layer that reads the input frames contracts the input's low-order half against the full-value image."""
+    assert w.dtype == F32 and out.dtype == torch.uint8 and w.dim() == 2 and out.shape == (w.shape[0], w.shape[1] + hi_cols)
+    _lib.call("evc_cast_f32_to_fp8_lo", _p(w), w.stride(0), w.shape[0], w.shape[1], scale_exp, hi_cols, hi_exp, _p(out), out.stride(0), _stream())
+    return out
+
+
 def cast_bf16_wide(x, out, lo_first):
     """Wide split-bf16 image of a 2-D f32 tensor: out rows [lo | hi] (lo_first: the A operand of gemm_nt_split_wide) or
     [hi | lo] (its B operand)."""
@@ -209,13 +222,15 @@ def host_frame_counts(num_frames_host, every_n, num_chunks, chunk_len, max_frame
 
 
 def l2norm_chunk(x_raw, num_chunks, every_n=None, num_chunks_student=None, num_frames=None, normalize=True, split=False,
-                 plan1=None, plan2=None, f16_segments=1):
+                 plan1=None, plan2=None, f16_segments=1, fp8_tail=False):
     """a1+a2.  x_raw [B,T,F] f32 (or uint8 with num_frames).  Returns the
     teacher view [Lc][C*B][F] bf16 and (if every_n) the student view; with row plans the views are
     [Lc][plan.P][F] in slot order.  split: True -> (bf16, bf16 low half) pairs; "f16" -> (bf16, IEEE f16 image) pairs (the
     operands of the "high" precision L1 forward; the bf16 image stays the operand of the backward products) - the f16 image
     has rows of f16_segments*F: [f16(x) | (x - f16(x))*64 | f16(x)/64], the K-extended x operand of lstm_layer_fwd_f16;
-    "wide" -> (bf16, wide bf16 image with rows [lo | hi] of 2F) pairs, the input of lstm_layer_fwd_hp."""
+    "wide" -> (bf16, wide bf16 image with rows [lo | hi] of 2F) pairs, the input of lstm_layer_fwd_hp.
+    fp8_tail (with split "f16", f16_segments 1): the f16 image's rows are 2F halfwords = [f16(x) | e4m3(x 2^7) (F bytes) | e4m3((x - f16(x)) 2^18)
+    (F bytes)], the x rows of lstm_layer_fwd_f16_fp8lo (evc_l2norm_chunk_fwd aux_mode 5)."""
     B, T, F = x_raw.shape
     dev = x_raw.device
     rows1 = plan1.P if plan1 is not None else num_chunks * B
@@ -230,8 +245,12 @@ def l2norm_chunk(x_raw, num_chunks, every_n=None, num_chunks_student=None, num_f
     aux_dt = F16 if split == "f16" else BF16
     nseg = f16_segments if split == "f16" else (2 if split == "wide" else 1)
     aux_mode = nseg if split == "f16" else (4 if split == "wide" else 0)
-    lo1 = torch.empty(out1.shape[:2] + (nseg * F,), dtype=aux_dt, device=dev) if split else None
-    lo2 = torch.empty(out2.shape[:2] + (nseg * F,), dtype=aux_dt, device=dev) if (split and out2 is not None) else None
+    wrow = nseg * F
+    if fp8_tail:
+        assert split == "f16" and f16_segments == 1 and F % 32 == 0, "fp8_tail: the f16 image + two e4m3 images, F % 32 == 0"
+        aux_mode, wrow = 5, 2 * F
+    lo1 = torch.empty(out1.shape[:2] + (wrow,), dtype=aux_dt, device=dev) if split else None
+    lo2 = torch.empty(out2.shape[:2] + (wrow,), dtype=aux_dt, device=dev) if (split and out2 is not None) else None
     _lib.call("evc_l2norm_chunk_fwd", None if is_u8 else _p(x_raw), _p(x_raw) if is_u8 else None, _p(num_frames),
               B, T, F, num_chunks, _p(out1), every_n or 1, num_chunks_student or 1, _p(out2), 1 if normalize else 0,
               _p(lo1), _p(lo2), aux_mode, _p(plan1.pos) if plan1 is not None else None, rows1,
@@ -273,6 +292,17 @@ def lstm_layer_fwd_f16(x16, wT16, bias, lens, T, M, Kin, H, hbuf16, hbuf_bf, c_s
     assert wT16.shape[1] == Kin + (2 if h_wide else 1) * H
     _lib.call("evc_lstm_layer_fwd_f16", _p(x16), Kin if ldx is None else ldx, _p(wT16), _p(bias), _p(lens), T, M, Kin, H, _p(hbuf16),
               1 if h_wide else 0, _p(hbuf_bf), _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_all), *_plan_args(plan), _stream())
+
+
+def lstm_layer_fwd_f16_fp8lo(x16, ldx, kx16, x8_off, kx8, wT16, wT8, bias, lens, T, M, H, hbuf16, hbuf_bf, c_state, h_state, ld_state,
+                             gates=None, c_all=None, plan=None, w8_scale_exp=FP8_W_SCALE_EXP):
+    """lstm_layer_fwd_f16 with the weights' low-order halves contracted in fp8 (evc_lstm_layer_fwd_f16_fp8lo): x16 rows of ldx halfwords
+    (kx16 halfwords of f16 operand at the row start, kx8 e4m3 bytes at byte offset x8_off), wT16 [4H][kx16 + H] f16, wT8 [4H][kx8 + H]
+    uint8 (cast_fp8_lo), hbuf16 [(T+1)][M][3H/2] f16 containers = rows [f16(h) | e4m3(h 2^7)], hbuf_bf the bf16 copy of h."""
+    assert x16.dtype == F16 and wT16.dtype == F16 and wT8.dtype == torch.uint8 and hbuf16.dtype == F16 and hbuf_bf.dtype == BF16
+    assert wT16.shape == (4 * H, kx16 + H) and wT8.shape == (4 * H, kx8 + H) and wT16.is_contiguous() and wT8.is_contiguous()
+    _lib.call("evc_lstm_layer_fwd_f16_fp8lo", _p(x16), ldx, kx16, x8_off, kx8, _p(wT16), _p(wT8), w8_scale_exp, _p(bias), _p(lens), T, M, H,
+              _p(hbuf16), _p(hbuf_bf), _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_all), *_plan_args(plan), _stream())
 
 
 def lstm_stack2_fwd(x, wT0, bias0, wT1, bias1, lens, T, M, Kin, H, zx_ws, hbuf0, hbuf1, S, gates=(None, None), c_all=(None, None)):

@@ -36,7 +36,7 @@ extern "C" {
 #define EVC_ERR_HIP (-4)
 #define EVC_ERR_BAD_ARG (-5)
 
-#define EVC_VERSION 101   /* 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
+#define EVC_VERSION 102   /* 102: evc_lstm_layer_fwd_f16_fp8lo, evc_cast_f32_to_fp8_lo, aux_mode 5, evc_moe_grad_update_wide; 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
 
 typedef uint16_t evc_bf16;
 typedef uint16_t evc_f16;   /* raw IEEE binary16 bits (the "high" precision forward operands of the L1 levels) */
@@ -76,7 +76,9 @@ int evc_l2norm_chunk_fwd(const float* x_raw, const uint8_t* x_u8, const int32_t*
                                          adds the x_lo.W_hi (2) and x_hi.W_lo (3) corrections; the 64s keep both low-order
                                          factors in f16's normal range;
                                          4: wide split-bf16 images, rows of 2F = [bf16(x - bf16(x)) | bf16(x)] - the [lo | hi]
-                                         operand of evc_lstm_layer_fwd_hp */,
+                                         operand of evc_lstm_layer_fwd_hp;
+                                         5: rows of 4F bytes = [f16(x) (F halfwords) | e4m3(x 2^7) (F bytes) | e4m3((x - f16(x)) 2^18) (F bytes)] -
+                                         the x rows of evc_lstm_layer_fwd_f16_fp8lo (F % 32 == 0; out*_lo then hold 2F halfwords per row) */,
                          const int32_t* row_pos1, int rows1, const int32_t* row_pos2, int rows2, void* stream);
 
 /* Row plan of an LSTM stack: stable counting sort of its M rows by sequence length, longest first
@@ -176,6 +178,24 @@ int evc_lstm_layer_fwd_f16(const evc_f16* x, int64_t ldx /* row stride of x (>= 
                            evc_bf16* hbuf_bf16,
                            float* c_state, float* h_state, int64_t ld_state, void* gates, evc_bf16* c_all,
                            const int32_t* row_map, const int32_t* rows_per_step, void* stream);
+/* evc_lstm_layer_fwd_f16 with every weight of the layer exact to ~2^-15: per step
+ *   z = [x16 | h16] . [W16x | W16h]^T (IEEE f16)  +  2^-(7 + w8_scale_exp) [x8 | h8] . [W8x | W8h]^T (OCP e4m3 on
+ *   v_mfma_scale_f32_16x16x128_f8f6f4: per K element twice the MFMA rate of the 16-bit products)
+ * with W8 = e4m3((W - f16(W)) 2^w8_scale_exp) from evc_cast_f32_to_fp8_lo, x8 = e4m3(x 2^7), h8 = e4m3(h_t 2^7).  The f16 rounding of a
+ * WEIGHT is the same at every time step and in every chunk and enters the integrating cell states coherently (the term
+ * that decides whether 1e-3 on the logits holds on trained weights); K-extending the weights by f16 low-order halves (h_wide = 1 above)
+ * costs a second f16 product per depth, the e4m3 term half of that.  x rows (row stride ldx halfwords): kx16 halfwords at the row start -
+ * the f16 operand against the first kx16 columns of wT16 - and kx8 e4m3 bytes at byte offset x8_off (layer 0: the rows of
+ * evc_l2norm_chunk_fwd's aux_mode 5, kx16 = F, x8_off = 2F, kx8 = 2F = [e4m3(x 2^7) | e4m3((x - f16(x)) 2^18)] against wT8 columns
+ * [lo(Wx) | e4m3(Wx 2^6)] - the second pair is the rounding of the INPUT, the one activation term f16 does not cover; upper
+ * layers: the hbuf rows of the layer below, kx16 = H, x8_off = 2H, kx8 = H).  hbuf [(T+1)][M] rows of 3H bytes: [f16(h_t) (H halfwords) | e4m3(h_t 2^7) (H bytes)]; wT16 [4H][kx16 + H] f16,
+ * wT8 [4H][kx8 + H] bytes.  H % 128 == 0, kx8 % 128 == 0, kx8 >= 384, kx16 % 64 == 0.  Everything else as evc_lstm_layer_fwd_f16
+ * (cs/frame_level_models.py:221-250). */
+int evc_lstm_layer_fwd_f16_fp8lo(const evc_f16* x, int64_t ldx, int kx16, int64_t x8_off, int kx8, const evc_f16* wT16,
+                                 const uint8_t* wT8, int w8_scale_exp, const float* bias, const int32_t* len,
+                                 int T, int M, int H, evc_f16* hbuf, evc_bf16* hbuf_bf16, float* c_state, float* h_state,
+                                 int64_t ld_state, void* gates, evc_bf16* c_all, const int32_t* row_map,
+                                 const int32_t* rows_per_step, void* stream);
 /* evc_lstm_stack2_fwd (below) on IEEE f16 operands, the "high" precision form of the L2 level: layer 0 plain f16 (x-projection
  * hoisted into one f16 product), layer 1 with its kernel K-extended by the weights' low-order halves - wT1_wlo [4H] rows
  * [f16(Wx) | (Wx - f16(Wx))*64 | f16(Wh) | (Wh - f16(Wh))*64] (evc_cast_f32_to_f16_wlo) against activation rows [h | h/64] - because
@@ -279,6 +299,12 @@ int evc_transpose_to_bf16(const void* in, int in_f32, int64_t ld_in, int R, int 
                           evc_bf16* out, int64_t ld_out, int Rpad, int interleave_H, void* stream);
 /* out_bf16[i] = bf16(in_f32[i]) for a [R, C] matrix (ld_in, ld_out). */
 int evc_cast_f32_to_bf16(const float* in, int64_t ld_in, int R, int C, evc_bf16* out, int64_t ld_out, void* stream);
+/* lo(w) = e4m3(clamp((w - f16(w)) * 2^lo_exp, +-448)) (OCP e4m3fn, round to nearest even) for a [R][C] f32 matrix: the low-order halves of a
+ * weight matrix next to its f16 image, the wT8 operand of evc_lstm_layer_fwd_f16_fp8lo (lo_exp 17: |w| < 4 never clamps).  hi_cols > 0: out
+ * rows are [lo(W[:, :hi_cols]) | hi(W[:, :hi_cols]) | lo(W[:, hi_cols:])] with hi(w) = e4m3(clamp(w * 2^hi_exp)) - the columns the INPUT's
+ * low-order half e4m3((x - f16(x)) 2^18) (evc_l2norm_chunk_fwd aux_mode 5) is contracted against (hi_exp 6: the same 2^24 as 7 + 17). */
+int evc_cast_f32_to_fp8_lo(const float* in, int64_t ld_in, int R, int C, int lo_exp, int hi_cols, int hi_exp, uint8_t* out, int64_t ld_out,
+                           void* stream);
 /* out_f16[i] = f16(in_f32[i]), round to nearest even (the f16 weight shadows of evc_lstm_layer_fwd_f16). */
 int evc_cast_f32_to_f16(const float* in, int64_t ld_in, int R, int C, evc_f16* out, int64_t ld_out, void* stream);
 /* f16 image of an LSTM kernel [R][Kin+H] (f32, row stride ld_in) for a K-extended x-part: out [R][nseg*Kin + H] =

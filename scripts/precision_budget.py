@@ -83,6 +83,10 @@ def stack_fwd(x, lengths, layers, kinds):
             z = a @ wq[l] + bias
             if wlo8[l] is not None:      # the low-order term on fp8 images of the activations (x 2^7: |h| <= 1, |x| <= 1)
                 z = z + fp8(torch.cat([inp, h[l]], 1), 128.0) @ wlo8[l]
+            if ax == "f16+8":            # the INPUT's low-order half in fp8 against an fp8 image of the weights: e4m3((x - f16(x)) 2^18) . e4m3(Wx 2^6)
+                d = inp - rnd(inp, "f16")
+                nin = inp.shape[1]
+                z = z + fp8(d, 2.0 ** 18) @ fp8(layers[l][0][:nin], fp8_scale(layers[l][0][:nin]))
             i, j, f, o = z.split(H, 1)
             cn = c[l] * torch.sigmoid(f + 1.0) + torch.sigmoid(i) * torch.tanh(j)
             hn = torch.tanh(cn) * torch.sigmoid(o)
@@ -259,6 +263,10 @@ def main():
                                                                          L1c1=dict(ax="f16", ah="f16", wx="f16+8", wh="f16+8"),
                                                                          L2c0=dict(ax="x3", ah="f16", wx="f16+8", wh="f16+8"),
                                                                          L2c1=dict(ax="f16", ah="f16", wx="f16+8", wh="f16+8"))),
+            ("X16 only the L1c0 input f16", dict(exact, L1c0=dict(ex, ax="f16"))),
+            ("X16+8 only the L1c0 input f16 + fp8 x fp8 low-order term", dict(exact, L1c0=dict(ex, ax="f16+8"))),
+            ("FZ8X FZ8 with the input's low-order half in fp8 too", dict(exact, L1c0=dict(ax="f16+8", ah="f16", wx="f16+8", wh="f16+8"),
+                                                                         L1c1=dict(ax="f16", ah="f16", wx="f16+8", wh="f16+8"), **l2_f16x)),
             ("W16 only the L1 weights f16 (activations exact)", dict(exact, L1c0=dict(ex, wx="f16", wh="f16"), L1c1=dict(ex, wx="f16", wh="f16"))),
             ("W16+8 only the L1 weights f16 + fp8 low-order halves", dict(exact, L1c0=dict(ex, wx="f16+8", wh="f16+8"), L1c1=dict(ex, wx="f16+8", wh="f16+8"))),
             ("FX (shipped) F with L2 layer 0 input + weights extended", dict(exact, L1c0=c0_3h, L1c1="f16", **l2_f16x)),

@@ -1,5 +1,9 @@
 """Kernel-level parity: each HIP entry point (through the C ABI) against the
 numpy oracle on seeded inputs.  Run on the MI355X box: pytest -m gpu."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -357,6 +361,151 @@ def test_lstm_stack2_fwd_f16_weight_lo_extension(ops, M, T, Kin, H, ext):
     #  h entry - one f16 ulp, 2.4e-4 at |h| ~ 0.5 - and that flip travels on through the remaining steps)
     assert float((S0 - S[:, :2 * H]).abs().max()) < 8e-4
     print("stack2 f16: state err %.2e (oracle with f16-rounded layer-1 kernel: %.2e away from the exact one)" % (err, np.max(np.abs(s_rounded - s_ref))))
+
+
+def _e4m3(a, scale):
+    """torch's OCP e4m3fn rounding (nearest even, the reference for the hardware's v_cvt_pk_fp8_f32) of a * scale, clamped to +-448."""
+    return (a.float() * scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+
+
+def test_fp8_low_order_weight_cast_and_input_rows(ops):
+    """evc_cast_f32_to_fp8_lo = e4m3(clamp((w - f16(w)) 2^17)) bit for bit against torch's float8_e4m3fn (values over eleven decades,
+    including ones whose low-order half underflows e4m3 and ones that clamp), and with hi_cols its three-block rows [lo(Wx) | e4m3(Wx 2^6) |
+    lo(Wh)]; evc_l2norm_chunk_fwd aux_mode 5 writes rows [f16(x) | e4m3(x 2^7) | e4m3((x - f16(x)) 2^18)]: the first part is the f16 image,
+    the bytes are the e4m3 images of the normalised values and of their f16 remainders (compared through torch's rounding of the f16 +
+    low-order reconstruction of the two-segment image, allowing one code step where the f32 value sits on a rounding boundary)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(11)
+    w = (torch.rand((132, 256), generator=g) * 2 - 1) * torch.logspace(-9, 1, 256)[None, :]
+    w[5, :8] = torch.tensor([3.99, -3.99, 7.5, -100.0, 0.0, 1.0, -1.0, 2.0 ** -20])
+    zero_ok = lambda got, ref: bool(((got == ref) | (((got & 0x7f) == 0) & ((ref & 0x7f) == 0))).all())    # +0 / -0 codes of exact zeros
+    out = torch.zeros((132, 256), dtype=torch.uint8, device=DEV)
+    ops.cast_fp8_lo(w.to(DEV), out)
+    ref = _e4m3(w - w.half().float(), 2.0 ** ops.FP8_W_SCALE_EXP).view(torch.uint8)
+    got = out.cpu()
+    assert zero_ok(got, ref), int((got != ref).sum())
+    assert int((got & 0x7f).max()) <= 0x7e                      # never the NaN code
+    out3 = torch.zeros((132, 256 + 64), dtype=torch.uint8, device=DEV)
+    ops.cast_fp8_lo(w.to(DEV), out3, hi_cols=64)
+    g3 = out3.cpu()
+    assert torch.equal(g3[:, :64], got[:, :64]) and torch.equal(g3[:, 128:], got[:, 64:])
+    assert zero_ok(g3[:, 64:128], _e4m3(w[:, :64], 2.0 ** ops.FP8_WX_HI_EXP).view(torch.uint8))
+    B, T, F, C1, C2, every_n = 3, 60, 128, 4, 2, 10
+    q, x, n, _ = mm.synthetic_batch(B, seed=3, max_frames=T, feature_size=F, vocab_size=8, dtype=np.float32)
+    for inp, nf in ((torch.from_numpy(x).to(DEV), None), (torch.from_numpy(q).to(DEV), torch.from_numpy(n).to(DEV))):
+        (t_bf, t_w2), (s_bf, s_w2) = ops.l2norm_chunk(inp, C1, every_n, C2, num_frames=nf, split="f16", f16_segments=2)
+        (t_bf5, t_5), (s_bf5, s_5) = ops.l2norm_chunk(inp, C1, every_n, C2, num_frames=nf, split="f16", fp8_tail=True)
+        assert t_5.shape == t_w2.shape[:2] + (2 * F,) and s_5.shape == s_w2.shape[:2] + (2 * F,)
+        assert torch.equal(t_bf, t_bf5) and torch.equal(s_bf, s_bf5)
+        for w2, w5 in ((t_w2, t_5), (s_w2, s_5)):
+            assert torch.equal(w5[:, :, :F], w2[:, :, :F])
+            b8 = w5[:, :, F:].contiguous().view(torch.uint8)
+            assert b8.shape[-1] == 2 * F
+            xlo = w2[:, :, F:].float() / 64.0                              # x - f16(x) to f16's precision of the remainder
+            xv = w2[:, :, :F].float() + xlo                                # the normalised f32 values to ~2^-22
+            for part, want in ((b8[:, :, :F], _e4m3(xv, 128.0)), (b8[:, :, F:], _e4m3(xlo, 2.0 ** 18))):
+                d = (part.to(torch.int16) - want.view(torch.uint8).to(torch.int16)).abs()
+                d = torch.where((part & 0x7f) + (want.view(torch.uint8) & 0x7f) == 0, torch.zeros_like(d), d)       # +0 / -0
+                assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 3e-2, (int(d.max()), float((d > 0).float().mean()))
+
+
+@pytest.mark.parametrize("M,T,Kin,H,tile", [(512, 4, 384, 384, 0), (1100, 3, 1152, 512, 0), (700, 5, 384, 384, 6), (390, 3, 512, 384, 7), (330, 3, 384, 384, 8)])
+def test_lstm_layer_fwd_f16_fp8_low_order_weights(M, T, Kin, H, tile):
+    """evc_lstm_layer_fwd_f16_fp8lo (two stacked layers: layer 0 on input rows [f16(x) | e4m3(x 2^7) | e4m3(x_lo 2^18)], layer 1 on layer 0's
+    h rows [f16(h) | e4m3(h 2^7)]): per step z = [x | h] . [Wx | Wh]^T in f16 + 2^-24 [x8 | x_lo8 | h8] . [e4m3(Wx_lo 2^17) | e4m3(Wx 2^6) |
+    e4m3(Wh_lo 2^17)]^T on the MX-scaled fp8 MFMA.  Against the float64 oracle with EXACT weights and exact x: what is left is the f16 rounding of h (the
+    same bound as the f16 layer with extended weights, 8e-4) - and next to the plain f16 layer on the same kernel it must be the
+    closer one.  Every ring tile the launcher can pick (EVC_FORCE_TILE in a child process: 256 / 224 / 192 / 160 rows), rows that end
+    early, a row plan."""
+    code = _FP8LO_CHILD % dict(M=M, T=T, Kin=Kin, H=H)
+    env = dict(os.environ)
+    if tile:
+        env["EVC_FORCE_TILE"] = str(tile)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    print(r.stdout.strip().splitlines()[-1])
+
+
+_FP8LO_CHILD = r"""
+import numpy as np, torch
+from oracle import model_math as mm
+from efficientvideoclassification_youtube8m_amd import ops
+DEV = "cuda:0"
+M, T, Kin, H = %(M)d, %(T)d, %(Kin)d, %(H)d
+rng = np.random.default_rng(M + T + Kin + H)
+x = (rng.standard_normal((M, T, Kin)) * 0.05).astype(np.float32)
+x /= np.maximum(1.0, np.abs(x).max())
+k0 = (mm.glorot_uniform(rng, (Kin + H, 4 * H)) * 3.0).astype(np.float32)
+k1 = (mm.glorot_uniform(rng, (2 * H, 4 * H)) * 3.0).astype(np.float32)
+b0 = (rng.standard_normal(4 * H) * 0.1).astype(np.float32)
+b1 = (rng.standard_normal(4 * H) * 0.1).astype(np.float32)
+lens = rng.integers(0, T + 1, size=M).astype(np.int32)
+lens[:3] = [0, T, 1]
+s_ref, _ = mm.multi_rnn_seq_fwd(x.astype(np.float64), lens, [(k0.astype(np.float64), b0.astype(np.float64)), (k1.astype(np.float64), b1.astype(np.float64))])
+# input rows [f16(x) | e4m3(x 2^7) | e4m3((x - f16(x)) 2^18)], time-major; next to them the two-segment f16 rows [f16(x) | (x - f16(x)) 64]
+xt = torch.from_numpy(np.ascontiguousarray(x.transpose(1, 0, 2))).to(DEV)
+rows = torch.zeros((T, M, 2 * Kin), dtype=torch.float16, device=DEV)
+hi = xt.half()
+rows[:, :, :Kin] = hi
+rows[:, :, Kin:3 * Kin // 2] = (xt * 128.0).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.float16)
+rows[:, :, 3 * Kin // 2:] = ((xt - hi.float()) * 2.0 ** 18).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.float16)
+rows2 = torch.zeros((T, M, 2 * Kin), dtype=torch.float16, device=DEV)
+rows2[:, :, :Kin] = hi
+rows2[:, :, Kin:] = ((xt - hi.float()) * 64.0).half()
+ln = torch.from_numpy(lens).to(DEV)
+def run(plan):
+    S = torch.full((M, 4 * H), float("nan"), dtype=torch.float32, device=DEV)
+    inp, ldx, kx16, x8_off, kx8 = rows, 2 * Kin, Kin, 2 * Kin, 2 * Kin
+    lens_run, Mrun = ln, M
+    if plan is not None:          # slot order: rows sorted by length, the length-0 rows dropped
+        live = plan.rows[0]
+        inp = torch.zeros((T, plan.P, 2 * Kin), dtype=torch.float16, device=DEV)
+        inp[:, :live] = rows[:, plan.inv[:live].long()]
+        lens_run, Mrun = plan.lens, plan.P
+        S.zero_()
+    for l, (k, b) in enumerate(((k0, b0), (k1, b1))):
+        kT = torch.from_numpy(np.ascontiguousarray(k.T)).to(DEV)
+        nin = k.shape[0] - H
+        w16 = torch.empty((4 * H, nin + H), dtype=torch.float16, device=DEV)
+        ops.cast_f16(kT, w16)
+        w8 = torch.empty((4 * H, kx8 + H), dtype=torch.uint8, device=DEV)
+        ops.cast_fp8_lo(kT, w8, hi_cols=kx8 - nin)
+        h16 = torch.full((T + 1, Mrun, 3 * H // 2), float("nan"), dtype=torch.float16, device=DEV)
+        hbf = torch.full((T + 1, Mrun, H), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ops.lstm_layer_fwd_f16_fp8lo(inp, ldx, kx16, x8_off, kx8, w16, w8, torch.from_numpy(b).to(DEV), lens_run, T, Mrun, H, h16, hbf,
+                                     S[:, 2 * l * H:], S[:, (2 * l + 1) * H:], 4 * H, plan=plan)
+        if plan is None:          # (with a plan the rows beyond a step's active prefix are never written)
+            hn = h16[:, :, :H].float()
+            assert float((hn - hbf.float()).abs().max()) <= 2.0 ** -8
+            h8 = h16[:, :, H:].contiguous().view(torch.uint8)
+            want = (hn * 128.0).to(torch.float8_e4m3fn).view(torch.uint8)       # (from the f16 image: one code step of slack on boundaries)
+            d = (h8.to(torch.int16) - want.to(torch.int16)).abs()
+            assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 2e-2, (int(d.max()), float((d > 0).float().mean()))
+        inp, ldx, kx16, x8_off, kx8 = h16[1:], 3 * H // 2, H, 2 * H, H
+    return S.cpu().double().numpy()
+got = run(None)
+assert np.isfinite(got).all() and np.all(got[0] == 0)
+err = float(np.max(np.abs(got - s_ref)))
+# the plain f16 layers on the same kernels (x exact through its two segments there too)
+S = torch.full((M, 4 * H), float("nan"), dtype=torch.float32, device=DEV)
+inp, ldx, kx = rows2, 2 * Kin, 2 * Kin
+for l, (k, b) in enumerate(((k0, b0), (k1, b1))):
+    kT = torch.from_numpy(np.ascontiguousarray(k.T)).to(DEV)
+    nin = k.shape[0] - H
+    w16 = torch.empty((4 * H, kx + H), dtype=torch.float16, device=DEV)
+    ops.cast_f16_wide(kT, nin, H, kx // nin, w16, h_ext=False)
+    h16 = torch.full((T + 1, M, H), float("nan"), dtype=torch.float16, device=DEV)
+    hbf = torch.full((T + 1, M, H), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.lstm_layer_fwd_f16(inp, w16, torch.from_numpy(b).to(DEV), ln, T, M, kx, H, h16, hbf, S[:, 2 * l * H:], S[:, (2 * l + 1) * H:], 4 * H, ldx=ldx)
+    inp, ldx, kx = h16[1:], H, H
+err16 = float(np.max(np.abs(S.cpu().double().numpy() - s_ref)))
+# a row plan: rows sorted by length, the padding rows dropped - the same states in the original row order
+gp = run(ops.RowPlan(ln, lens, T))
+assert float(np.max(np.abs(gp - got))) < 1e-6
+print("fp8lo two-layer stack M=%%d T=%%d Kin=%%d H=%%d: state err %%.2e (plain f16 layers %%.2e)" %% (M, T, Kin, H, err, err16))
+assert err < 8e-4 and err <= err16 * 1.05, (err, err16)
+"""
 
 
 @pytest.mark.parametrize("M,T,Kin,H", [(256, 6, 64, 64), (1536, 4, 192, 256), (640, 15, 128, 128)])
