@@ -223,7 +223,14 @@ def run_hlstm(device, rank, world, B, mode, every_n, steps, warmup, all_full=Fal
             "traffic": None if f16 else traffic, "traffic_source": None if f16 else pmc_src, "mfma_busy_pmc": None if f16 else mfma_busy,
             "avg_launch_ms": round(ms / launches, 4),
             "launches_per_step": int(round(launches / max(1, steps))), "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 2)}
-        if f16:
+        if f16 and tower.fp8_lo():
+            res["roofline"]["kernel"] = ("lstm_fwd_step_kernel<TileCfg3<BM,4,64,2,4,2>, F16, FP8> (teacher L1; BM = 160..256 per launch from the active rows): "
+                                         "f16 stages, then e4m3 stages on v_mfma_scale_f32_16x16x128_f8f6f4")
+            res["roofline"]["note"] = ("algorithmic FLOPs count K = Kin + H once, priced against the dense bf16/f16 peak; executed: that contraction on IEEE f16 "
+                                       "operands plus the low-order halves of every weight (and of the input frames in layer 0) on OCP e4m3 operands - K = "
+                                       "2 Kin + H (layer 0) / Kin + H (layer 1) more at twice the MFMA rate, i.e. %.2fx the algorithmic MFMA time over both layers "
+                                       "(round 3's f16 K-extensions: 2.27x)" % (1.0 + 0.5 * (2.0 * F_FEAT + 3.0 * H_CELLS) / (F_FEAT + 3.0 * H_CELLS)))
+        elif f16:
             res["roofline"]["note"] = ("IEEE f16 operands (same MFMA rate as bf16: priced against the same dense peak); algorithmic FLOPs count "
                                        "K = Kin + H once - layer 0 executes its input part %dx (K-extension by the low-order half), i.e. "
                                        "%.2fx the algorithmic MFMA work over both layers" % (
@@ -520,8 +527,9 @@ def main():
         pm["bf16"]["logits_within_1e-3_of_f64_oracle"] = "at the reference's initialisation (|logit| <~ 1); ~1e-3*|logit| on trained weights"
         pm["high"]["logits_within_1e-3_of_f64_oracle"] = "also on trained-magnitude weights (tests/test_gpu_step.py)"
         pm["high"]["what"] = ("forward operands chosen by a measured error budget (scripts/precision_budget.py, DESIGN.md 7): L1 level on IEEE f16 "
-                              "(one MFMA product per depth) with every LSTM weight - and the input frames - K-extended by the low-order halves, activations f16; "
-                              "L2 level in the wavefront pair launches; student tower plain f16; MoE head "
+                              "(one MFMA product per depth) plus the low-order halves of every LSTM weight - and of the input frames - as OCP e4m3 "
+                              "operands on the MX-scaled MFMA (twice the rate; EVC_HIGH_FP8_LO=0: as f16 K-extensions, round 3), activations f16; "
+                              "L2 level f16 with K-extended weights in the wavefront pair launches; student tower plain f16; MoE head "
                               "split-bf16 (hi.hi + hi.lo + lo.hi as one K-extended launch per product); backward as in bf16")
         extra["precision_modes"] = pm
         oc = {}

@@ -2,7 +2,7 @@
 # Spread of the "high" precision layouts over the weights the precision test can draw (its GPU training sums with atomics: every
 # run ends on different weights).  N draws; per draw the emulated teacher-logit error (= the kernels' error, to the digit) of each
 # candidate layout (scripts/precision_budget.py "ROBUST" configurations); summary = mean / max per layout.  DESIGN.md 7.
-#   bash scripts/precision_robustness.sh [draws] [out-file]
+#   [ONLY="ROBUST FZ"] bash scripts/precision_robustness.sh [draws] [out-file]      (ONLY: substring filter of the layouts emulated)
 set -u
 cd "$(dirname "$0")/.."
 N=${1:-8}
@@ -10,7 +10,7 @@ OUT=${2:-gpurun_out/precision_robustness.txt}
 mkdir -p "$(dirname "$OUT")"
 : > "$OUT.raw"
 for i in $(seq 1 $N); do
-  python3 scripts/precision_budget.py --gpu --only "ROBUST" 2>&1 | grep "ROBUST\|KERNELS high" | cut -c1-150 >> "$OUT.raw"
+  python3 scripts/precision_budget.py --gpu --only "${ONLY:-ROBUST}" 2>&1 | grep "ROBUST\|KERNELS high" | cut -c1-150 >> "$OUT.raw"
   echo "---" >> "$OUT.raw"
 done
 python3 - "$OUT.raw" > "$OUT" <<'PY'
