@@ -42,7 +42,9 @@ SIGNATURES = {
     "evc_cast_f32_to_f16_wlo": [vp, i64, i32, i32, i32, vp, vp],
     "evc_lstm_stack2_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp],
     "evc_moe_grad_update": [vp, i64, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, i64, f32, vp, vp, f32, f32, f32, f32, f32, vp],
-    "evc_moe_grad_update_wide": [vp, i64, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp, f32, vp, vp, f32, f32, f32, f32, f32, vp],
+    "evc_moe_grad_update_wide": [vp, i64, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, f32, vp, vp, f32, f32, f32, f32, f32, vp],
+    "evc_gemm_nt_f16_fp8": [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp, vp],
+    "evc_cast_f32_to_f16_fp8x": [vp, i64, i32, i32, i32, i32, vp, vp],
     "evc_moe_grad_update_phase": [vp, i64, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, i64, f32, vp, vp, f32, f32, f32, f32, f32, i32, vp],
     "evc_moe_tail_fwd": [vp, vp, i32, i32, i32, vp, vp, vp],
     "evc_moe_tail_bwd": [vp, vp, vp, i32, i32, i32, vp, i64, vp, i64, vp],

@@ -471,6 +471,46 @@ extern "C" int evc_cast_f32_to_f16_wide(const float* in, int64_t ld_in, int R, i
   return EVC_OK;
 }
 
+// Activation rows for evc_gemm_nt_f16_fp8: out rows of 4C bytes = [f16(x) (C halfwords) | e4m3(x 2^hi_exp) (C bytes) | e4m3((x - f16(x)) 2^lo_exp) (C bytes)]
+// (the layout evc_l2norm_chunk_fwd's aux_mode 5 writes for the input frames, for any other operand: the state in front of the MoE head).
+__global__ void cast_f16_fp8x_kernel(const float* __restrict__ in, long ld_in, int R, int C, float hi_scale, float lo_scale, bf16_t* __restrict__ out) {
+  const int c4 = C >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)R * c4; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / c4;
+    const int j = (int)(i - r * c4);
+    const float4 v = *(const float4*)(in + r * ld_in + j * 4);
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    const uint32_t h01 = pack_f16x2_hw(x[0], x[1]), h23 = pack_f16x2_hw(x[2], x[3]);
+    const float hf[4] = {f16_to_f32((f16_t)(h01 & 0xffffu)), f16_to_f32((f16_t)(h01 >> 16)), f16_to_f32((f16_t)(h23 & 0xffffu)), f16_to_f32((f16_t)(h23 >> 16))};
+    float a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      a[k] = fminf(fmaxf(x[k] * hi_scale, -448.f), 448.f);
+      b[k] = fminf(fmaxf((x[k] - hf[k]) * lo_scale, -448.f), 448.f);
+    }
+    int wa = __builtin_amdgcn_cvt_pk_fp8_f32(a[0], a[1], 0, false);
+    wa = __builtin_amdgcn_cvt_pk_fp8_f32(a[2], a[3], wa, true);
+    int wb = __builtin_amdgcn_cvt_pk_fp8_f32(b[0], b[1], 0, false);
+    wb = __builtin_amdgcn_cvt_pk_fp8_f32(b[2], b[3], wb, true);
+    bf16_t* row = out + r * 2L * C;
+    ((uint2*)row)[j] = make_uint2(h01, h23);
+    ((int*)(row + C))[j] = wa;
+    ((int*)(row + C))[c4 + j] = wb;
+  }
+}
+
+extern "C" int evc_cast_f32_to_f16_fp8x(const float* in, int64_t ld_in, int R, int C, int hi_exp, int lo_exp, evc_f16* out, void* stream) {
+  EVC_REQUIRE(R > 0 && C > 0 && C % 32 == 0 && ld_in % 4 == 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0, EVC_ERR_BAD_ALIGN,
+              "evc_cast_f32_to_f16_fp8x: C=%d (%%32: 16-byte aligned row parts), ld_in=%ld (%%4), 16-byte aligned buffers", C, (long)ld_in);
+  EVC_REQUIRE(hi_exp >= -30 && hi_exp <= 30 && lo_exp >= 0 && lo_exp <= 60, EVC_ERR_BAD_ARG, "evc_cast_f32_to_f16_fp8x: hi_exp=%d lo_exp=%d", hi_exp, lo_exp);
+  const long n = (long)R * (C / 4);
+  const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+  hipLaunchKernelGGL(cast_f16_fp8x_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, ld_in, R, C, ldexpf(1.0f, hi_exp), ldexpf(1.0f, lo_exp),
+                     (bf16_t*)out);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
 // Low-order halves of an f32 matrix next to its f16 image, as OCP e4m3: lo(w) = e4m3(clamp((w - f16(w)) * 2^lo_exp, +-448)) - the B8 operand
 // of evc_lstm_layer_fwd_f16_fp8lo (|w - f16(w)| <= 2^-12 |w|: with lo_exp = 17 weights up to |w| < 4 stay below 448 and those above ~2^-13 keep
 // 3-4 significant bits of their low-order half).  hi_cols > 0 (the layer that reads the input frames): behind the first hi_cols columns'

@@ -118,8 +118,9 @@ __device__ __forceinline__ void store_tile_via_lds(f32x4 (&acc)[Cfg::MI][1][Cfg:
   }
 }
 
-template <class Cfg, bool F16 = false>
+template <class Cfg, bool F16 = false, bool FP8 = false>
 __global__ __launch_bounds__(Cfg::NT) void gemm_nt_kernel(GemmOperands p, StoreParams s, int tiles_m, int tiles_n) {
+  static_assert(!FP8 || (F16 && is_v3<Cfg>::value), "the e4m3 tail rides behind f16 stages of the 64-wide ring loop");
   const int nwg = tiles_m * tiles_n;
   int bid = blockIdx.x, split = 0;
   if (s.splits > 1) {               // this workgroup's K range (wave-uniform)
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_nt_kernel(GemmOperands p, StoreP
   // loop options (gemm_core_v2.h): producer waves + LDS-DMA first + no priority flips for every ring tile but the 320-row one
   // (same box: L1 dX 477 -> 431 us, 1280 x 4096 x 4096 63 -> 56.5 us, MoE gates forward 48.3 -> 46 us; 5120 x 4096 x 4096 on
   // the 320-row tile 153 -> 162 us with them)
-  constexpr int NT_MODE = (Cfg::BM == 320 ? 0 : (LOOP_PRODUCER | LOOP_DMA_FIRST | LOOP_NO_PRIO)) | (F16 ? LOOP_F16 : 0);
+  constexpr int NT_MODE = (Cfg::BM == 320 ? 0 : (LOOP_PRODUCER | LOOP_DMA_FIRST | LOOP_NO_PRIO)) | (F16 ? LOOP_F16 : 0) | (FP8 ? LOOP_FP8_TAIL : 0);
   run_mainloop<Cfg, Cfg::G, V2, true, NT_MODE>(p, m0, u0, acc);     // ring tiles: transposed accumulators (lane = one row, 4 consecutive columns)
   if constexpr (V2) {
     // plain overwrite with 16-byte-aligned rows, or the split-K join: through LDS (kernel-uniform conditions: one barrier)
@@ -424,6 +425,44 @@ extern "C" int evc_gemm_nt_split(const evc_bf16* A_lohi, int64_t lda, const evc_
   return EVC_OK;
 }
 
+// C [M][N] f32 = A16 . B16^T (IEEE f16, K16 deep) + 2^scale_exp A8 . B8^T (OCP e4m3 bytes, K8 deep) + bias in ONE launch: a product whose
+// low-order corrections ride behind its f16 stages on the MX-scaled MFMA (gemm_core_v3.h LOOP_FP8_TAIL) - the "high" precision MoE head:
+// [f16(x)] . [f16(W)]^T + 2^-24 [e4m3(x 2^6) | e4m3((x - f16(x)) 2^17)] . [e4m3((W - f16(W)) 2^18) | e4m3(W 2^7)]^T leaves ~2.5e-5 on
+// logits of magnitude 8 (f16 alone: 8e-4; scripts/precision_budget.py "MOE fine") for 2/3 of the operand bytes of the split-bf16
+// K-extension (evc_gemm_nt_split).  lda / ldb in halfwords, lda8 / ldb8 in bytes.
+template <class Cfg>
+static inline void launch_gemm_f16_fp8(GemmOperands p, StoreParams s, int K16, int K8, hipStream_t st) {
+  p.nk1 = K16 / 64; p.nk2 = 0; p.nk3 = K8 / 128; p.nk4 = 0;
+  const int tm = ceil_div(s.M, Cfg::BM), tn = ceil_div(s.N, Cfg::BU);
+  s.splits = 1; s.ksteps_per_split = p.nk1;
+  launch_cfg<Cfg>(gemm_nt_kernel<Cfg, true, true>, tm * tn, st, p, s, tm, tn);
+}
+
+extern "C" int evc_gemm_nt_f16_fp8(const evc_f16* A16, int64_t lda, const uint8_t* A8, int64_t lda8, const evc_f16* B16, int64_t ldb,
+                                   const uint8_t* B8, int64_t ldb8, float* C, int64_t ldc, int M, int N, int K16, int K8, int scale_exp,
+                                   const float* bias, void* stream) {
+  EVC_REQUIRE(M > 0 && N > 0 && K16 >= 64 && K16 % 64 == 0 && K8 >= 512 && K8 % 128 == 0, EVC_ERR_BAD_SHAPE,
+              "evc_gemm_nt_f16_fp8: bad shape M=%d N=%d K16=%d (%%64, >= 64) K8=%d (%%128, >= 512)", M, N, K16, K8);
+  EVC_REQUIRE(A16 && A8 && B16 && B8 && C, EVC_ERR_BAD_ARG, "evc_gemm_nt_f16_fp8: NULL operand");
+  EVC_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda8 % 16 == 0 && ldb8 % 16 == 0 && lda >= K16 && ldb >= K16 && lda8 >= K8 && ldb8 >= K8 &&
+              ((uintptr_t)A16 % 16) == 0 && ((uintptr_t)B16 % 16) == 0 && ((uintptr_t)A8 % 16) == 0 && ((uintptr_t)B8 % 16) == 0, EVC_ERR_BAD_ALIGN,
+              "evc_gemm_nt_f16_fp8: 16-byte aligned operands and row strides (lda=%ld ldb=%ld lda8=%ld ldb8=%ld)", (long)lda, (long)ldb, (long)lda8, (long)ldb8);
+  EVC_REQUIRE(scale_exp >= -60 && scale_exp <= 60, EVC_ERR_BAD_ARG, "evc_gemm_nt_f16_fp8: scale_exp=%d", scale_exp);
+  EVC_REQUIRE(ring_operand_ok(M, lda) && ring_operand_ok(N, ldb) && ring_operand_ok(M, (lda8 + 1) / 2) && ring_operand_ok(N, (ldb8 + 1) / 2), EVC_ERR_BAD_SHAPE,
+              "evc_gemm_nt_f16_fp8: an operand spans 4 GiB or more");
+  GemmOperands p;
+  p.A1 = (const bf16_t*)A16; p.lda1 = lda; p.nk1 = 0; p.A2 = p.A1; p.lda2 = lda; p.nk2 = 0;
+  p.B = (const bf16_t*)B16; p.ldb = ldb; p.group_stride = 0; p.M = M; p.Nu = N;
+  p.A1lo = p.A2lo = p.Blo = nullptr;
+  p.A3 = A8; p.lda3 = lda8; p.A4 = A8; p.lda4 = lda8; p.B8 = B8; p.ldb8 = ldb8; p.scale8_exp = scale_exp;
+  StoreParams s{C, ldc, M, N, bias, 0, 0, 1, 0};
+  hipStream_t st = (hipStream_t)stream;
+  if (M <= 256) launch_gemm_f16_fp8<TileCfg3<256, 1, 64, 2, 4, 4>>(p, s, K16, K8, st);     // batch-row products: stream the weights once
+  else launch_gemm_f16_fp8<TileCfg3<256, 1, 256, 2, 4, 2>>(p, s, K16, K8, st);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
 // ===========================================================================
 // TN GEMM: C[M,N] (+)= A^T . B with A [K][lda], B [K][ldb] (weight gradients without transposes)
 // ===========================================================================
@@ -597,7 +636,9 @@ struct MoeUpdateParams {
   float* p; float* m; float* v;        // [V][K] f32, row stride K
   bf16_t* p_bf16;                      // forward shadow [V][K]
   bf16_t* pT_bf16; long ldT;           // transposed shadow [K][ldT], ldT >= V
-  bf16_t* p_wide;                      // or NULL: wide split-bf16 image [V][2K] = [hi | lo] of the new weights (the "high" forward's operand)
+  bf16_t* p_wide;                      // or NULL: wide split-bf16 image [V][2K] = [hi | lo] of the new weights (the "split" forward's operand)
+  bf16_t* p_f16; uint8_t* p_fp8;       // or NULL: IEEE f16 image [V][K] and e4m3 image [V][2K] = [e4m3((w - f16(w)) lo_scale) | e4m3(w hi_scale)] of the
+  float lo_scale, hi_scale;            // new weights (the "high" forward's operands: evc_gemm_nt_f16_fp8)
   float* partial;                      // pass 1 out: [workgroups][2]
   const float* sums;                   // pass 2 in: sums[0] = sum (g + l2 p)^2 of this tensor
   int V, K;
@@ -702,6 +743,24 @@ __global__ __launch_bounds__(Cfg::NT) void moe_update_kernel(GemmOperandsT p, Mo
         *(float4*)(u.m + o) = make_float4(mn[0], mn[1], mn[2], mn[3]);
         *(float4*)(u.v + o) = make_float4(vn[0], vn[1], vn[2], vn[3]);
         *(uint2*)(u.p_bf16 + o) = make_uint2((uint32_t)pb[0] | ((uint32_t)pb[1] << 16), (uint32_t)pb[2] | ((uint32_t)pb[3] << 16));
+        if (u.p_f16) {                                // f16 + e4m3 images: saves the passes over the f32 weights (evc_cast_f32_to_f16 / _fp8_lo) per update
+          const uint32_t h01 = pack_f16x2_hw(pn[0], pn[1]), h23 = pack_f16x2_hw(pn[2], pn[3]);
+          *(uint2*)(u.p_f16 + o) = make_uint2(h01, h23);
+          const float hf[4] = {f16_to_f32((f16_t)(h01 & 0xffffu)), f16_to_f32((f16_t)(h01 >> 16)), f16_to_f32((f16_t)(h23 & 0xffffu)), f16_to_f32((f16_t)(h23 >> 16))};
+          float lo8[4], hi8[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            lo8[r] = fminf(fmaxf((pn[r] - hf[r]) * u.lo_scale, -448.f), 448.f);
+            hi8[r] = fminf(fmaxf(pn[r] * u.hi_scale, -448.f), 448.f);
+          }
+          int wl = __builtin_amdgcn_cvt_pk_fp8_f32(lo8[0], lo8[1], 0, false);
+          wl = __builtin_amdgcn_cvt_pk_fp8_f32(lo8[2], lo8[3], wl, true);
+          int wh = __builtin_amdgcn_cvt_pk_fp8_f32(hi8[0], hi8[1], 0, false);
+          wh = __builtin_amdgcn_cvt_pk_fp8_f32(hi8[2], hi8[3], wh, true);
+          uint8_t* w8 = u.p_fp8 + (long)vr * 2 * K + k;
+          *(int*)w8 = wl;
+          *(int*)(w8 + K) = wh;
+        }
         if (u.p_wide) {                               // [hi | lo]: saves a pass over the f32 weights (evc_cast_f32_to_bf16_wide) per update
           bf16_t* w = u.p_wide + (long)vr * 2 * K + k;
           *(uint2*)w = make_uint2((uint32_t)pb[0] | ((uint32_t)pb[1] << 16), (uint32_t)pb[2] | ((uint32_t)pb[3] << 16));
@@ -748,15 +807,22 @@ __global__ __launch_bounds__(1024) void moe_update_finalize_kernel(const float* 
 static int moe_grad_update_impl(const evc_bf16* dlogits, int64_t ld_dlogits, const evc_bf16* x, int64_t ldx, int rows,
                                 int V, int K, float* p, float* m, float* v, evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT,
                                 float l2_coeff, float* sums, float* partial_ws, float clip_norm, float lr_t,
-                                float beta1, float beta2, float eps, int phase, evc_bf16* p_wide, void* stream);
+                                float beta1, float beta2, float eps, int phase, evc_bf16* p_wide, evc_f16* p_f16, uint8_t* p_fp8, int lo_exp, int hi_exp,
+                                void* stream);
 
 extern "C" int evc_moe_grad_update_wide(const evc_bf16* dlogits, int64_t ld_dlogits, const evc_bf16* x, int64_t ldx, int rows,
                                         int V, int K, float* p, float* m, float* v, evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT,
-                                        evc_bf16* p_wide_hilo, float l2_coeff, float* sums, float* partial_ws, float clip_norm, float lr_t,
+                                        evc_bf16* p_wide_hilo, evc_f16* p_f16, uint8_t* p_fp8, int fp8_lo_exp, int fp8_hi_exp,
+                                        float l2_coeff, float* sums, float* partial_ws, float clip_norm, float lr_t,
                                         float beta1, float beta2, float eps, void* stream) {
-  EVC_REQUIRE(p_wide_hilo && ((uintptr_t)p_wide_hilo % 8) == 0, EVC_ERR_BAD_ARG, "evc_moe_grad_update_wide: p_wide_hilo [V][2K] (8-byte aligned) is required");
+  EVC_REQUIRE(p_wide_hilo || p_f16, EVC_ERR_BAD_ARG, "evc_moe_grad_update_wide: p_wide_hilo [V][2K] or p_f16 [V][K] + p_fp8 [V][2K] is required");
+  EVC_REQUIRE(!p_wide_hilo || ((uintptr_t)p_wide_hilo % 8) == 0, EVC_ERR_BAD_ALIGN, "evc_moe_grad_update_wide: p_wide_hilo must be 8-byte aligned");
+  EVC_REQUIRE((p_f16 == nullptr) == (p_fp8 == nullptr) && (!p_f16 || (((uintptr_t)p_f16 % 8) == 0 && ((uintptr_t)p_fp8 % 4) == 0)), EVC_ERR_BAD_ARG,
+              "evc_moe_grad_update_wide: p_f16 (8-byte aligned) and p_fp8 (4-byte aligned) go together");
+  EVC_REQUIRE(!p_f16 || (fp8_lo_exp >= 0 && fp8_lo_exp <= 60 && fp8_hi_exp >= -30 && fp8_hi_exp <= 30), EVC_ERR_BAD_ARG,
+              "evc_moe_grad_update_wide: fp8_lo_exp=%d fp8_hi_exp=%d", fp8_lo_exp, fp8_hi_exp);
   return moe_grad_update_impl(dlogits, ld_dlogits, x, ldx, rows, V, K, p, m, v, p_bf16, pT_bf16, ldT, l2_coeff, sums, partial_ws, clip_norm, lr_t,
-                              beta1, beta2, eps, 0, p_wide_hilo, stream);
+                              beta1, beta2, eps, 0, p_wide_hilo, p_f16, p_fp8, fp8_lo_exp, fp8_hi_exp, stream);
 }
 
 extern "C" int evc_moe_grad_update_phase(const evc_bf16* dlogits, int64_t ld_dlogits, const evc_bf16* x, int64_t ldx, int rows,
@@ -764,13 +830,14 @@ extern "C" int evc_moe_grad_update_phase(const evc_bf16* dlogits, int64_t ld_dlo
                                          float l2_coeff, float* sums, float* partial_ws, float clip_norm, float lr_t,
                                          float beta1, float beta2, float eps, int phase, void* stream) {
   return moe_grad_update_impl(dlogits, ld_dlogits, x, ldx, rows, V, K, p, m, v, p_bf16, pT_bf16, ldT, l2_coeff, sums, partial_ws, clip_norm, lr_t,
-                              beta1, beta2, eps, phase, nullptr, stream);
+                              beta1, beta2, eps, phase, nullptr, nullptr, nullptr, 0, 0, stream);
 }
 
 static int moe_grad_update_impl(const evc_bf16* dlogits, int64_t ld_dlogits, const evc_bf16* x, int64_t ldx, int rows,
                                 int V, int K, float* p, float* m, float* v, evc_bf16* p_bf16, evc_bf16* pT_bf16,
                                 int64_t ldT, float l2_coeff, float* sums, float* partial_ws, float clip_norm,
-                                float lr_t, float beta1, float beta2, float eps, int phase, evc_bf16* p_wide, void* stream) {
+                                float lr_t, float beta1, float beta2, float eps, int phase, evc_bf16* p_wide, evc_f16* p_f16, uint8_t* p_fp8,
+                                int lo_exp, int hi_exp, void* stream) {
   EVC_REQUIRE(rows > 0 && rows % 32 == 0 && V > 0 && V % 4 == 0 && K > 0 && K % 8 == 0, EVC_ERR_BAD_SHAPE,
               "evc_moe_grad_update: rows=%d (%%32), V=%d (%%4), K=%d (%%8)", rows, V, K);
   EVC_REQUIRE(phase >= 0 && phase <= 2, EVC_ERR_BAD_ARG, "evc_moe_grad_update_phase: phase=%d (0 both, 1 norms, 2 update)", phase);
@@ -785,7 +852,8 @@ static int moe_grad_update_impl(const evc_bf16* dlogits, int64_t ld_dlogits, con
   const int Vp = (int)(ld_dlogits < ((V + 7) / 8) * 8 ? ld_dlogits : ((V + 7) / 8) * 8);   // A columns the loop may touch (%8)
   GemmOperandsT g{dlogits, ld_dlogits, x, ldx, Vp, K, rows / 32};
   const int tm = ceil_div(V, Cfg::BM), tn = ceil_div(K, Cfg::BU);
-  MoeUpdateParams u{p, m, v, p_bf16, pT_bf16, ldT, p_wide, partial_ws, sums, V, K, l2_coeff, clip_norm, lr_t, beta1, beta2, eps};
+  MoeUpdateParams u{p, m, v, p_bf16, pT_bf16, ldT, p_wide, (bf16_t*)p_f16, p_fp8, ldexpf(1.0f, lo_exp), ldexpf(1.0f, hi_exp),
+                    partial_ws, sums, V, K, l2_coeff, clip_norm, lr_t, beta1, beta2, eps};
   if (phase != 2) {
     launch_cfg<Cfg>(moe_update_kernel<Cfg, 1>, tm * tn, st, g, u, tm, tn);
     hipLaunchKernelGGL(moe_update_finalize_kernel, dim3(1), dim3(1024), 0, st, (const float*)partial_ws, tm * tn, sums);

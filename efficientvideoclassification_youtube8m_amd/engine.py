@@ -480,6 +480,17 @@ class MoeHead:
 
     def forward(self, x):
         tw, B, V, Mx, K = self.tw, self.B, self.V, self.Mx, self.K
+        if getattr(tw, "precision", "bf16") == "high" and self.GATES in getattr(tw, "shadow_w8", {}):
+            # f16 product + both low-order corrections as e4m3 operands behind it in the same launch (ops.gemm_nt_f16_fp8)
+            if not hasattr(self, "x_rows") or self.x_rows.shape[0] != B:
+                self.x_rows = torch.empty((B, 2 * K), dtype=ops.F16, device=x.device)
+            ops.cast_bf16(x, self.x_bf)                                 # the backward / fused-update factor
+            ops.cast_f16_fp8x(x, self.x_rows)
+            ops.gemm_nt_f16_fp8(self.x_rows, tw.shadow_w16[self.GATES], tw.shadow_w8[self.GATES], B, V * (Mx + 1), K, self.gate_logits)
+            ops.gemm_nt_f16_fp8(self.x_rows, tw.shadow_w16[self.EXPERTS], tw.shadow_w8[self.EXPERTS], B, V * Mx, K, self.expert_logits,
+                                bias=tw.store.p(self.EBIAS))
+            ops.moe_tail_fwd(self.gate_logits, self.expert_logits, B, V, Mx, self.pred, self.rowsum)
+            return self.pred
         if getattr(tw, "precision", "bf16") != "bf16" and hasattr(tw, "shadow_w"):
             # split-bf16 operands, one K-extended launch per product (ops.gemm_nt_split_wide)
             if not hasattr(self, "x_w") or self.x_w.shape[0] != B:
@@ -580,10 +591,12 @@ class MoeHead:
             l2 = l2_coeff if name in tw.l2_names else 0.0
             pw, mw, vw = st.p(name), st.view(st.m, name), st.view(st.v, name)
             if dp is None:
-                wide = getattr(tw, "shadow_w", {}).get(name) if tw.precision != "bf16" else None     # "high": [hi | lo] from the same epilogue
+                hi = tw.precision != "bf16"                 # the non-bf16 forward's operand images come out of the same epilogue
+                wide = getattr(tw, "shadow_w", {}).get(name) if hi else None             # "split": [hi | lo]
+                w16, w8 = (getattr(tw, "shadow_w16", {}).get(name), getattr(tw, "shadow_w8", {}).get(name)) if hi else (None, None)   # "high": f16 + e4m3
                 ops.moe_grad_update(dlog, x, rows, Vn, K, pw, mw, vw, tw.shadow_fwd[name], tw.shadow_bwd[name], l2,
-                                    tw.sums[idx[name]], self.partial_ws, clip_norm, lr_t, beta1, beta2, eps, p_wide=wide)
-                refreshed_wide = refreshed_wide or wide is not None
+                                    tw.sums[idx[name]], self.partial_ws, clip_norm, lr_t, beta1, beta2, eps, p_wide=wide, p_f16=w16, p_fp8=w8)
+                refreshed_wide = refreshed_wide or wide is not None or w16 is not None
                 continue
             slab = self.slab[name]
             v0 = dp.rank * slab
@@ -837,6 +850,9 @@ class HLstmTower(TowerBase):
     # the weight term of the error budget 3.7e-5 -> 9e-7 on the logits, the input term 5.3e-5 -> 1e-6).
     # Needs F, H multiples of 128 and >= 384; EVC_HIGH_FP8_LO=0: the f16 K-extensions above (the round-3 "FZ" layout).
     f16_fp8_lo = os.environ.get("EVC_HIGH_FP8_LO", "1") != "0"
+    # MoE head in "high": f16 product + both low-order corrections as e4m3 operands behind it in the same launch (ops.gemm_nt_f16_fp8) instead of
+    # the split-bf16 K-extension; needs K % 128 == 0, K >= 512 (same switch; not touched by distill.student_light, which is about the L1 level)
+    moe_f16_fp8 = os.environ.get("EVC_HIGH_MOE_FP8", os.environ.get("EVC_HIGH_FP8_LO", "1")) != "0"
 
     def fp8_lo(self):
         """True if this tower's L1 level runs on ops.lstm_layer_fwd_f16_fp8lo."""
@@ -850,6 +866,7 @@ class HLstmTower(TowerBase):
         dev, H, F, K = self.device, self.H, self.F, self.K
         self.shadow_lo = {}                                              # (no separate low-order shadows in this tower)
         self.shadow16, self.shadow_wx, self.shadow_wh, self.shadow_w, self.shadow8 = {}, {}, {}, {}, {}
+        self.shadow_w16, self.shadow_w8 = {}, {}                      # MoE head in "high": f16(W) and [e4m3(W_lo) | e4m3(W)] (ops.gemm_nt_f16_fp8)
         for k, shp in self.store.shapes.items():
             if len(shp) != 2:
                 continue
@@ -872,12 +889,18 @@ class HLstmTower(TowerBase):
                 nin = shp[1] - H
                 self.shadow_wx[k] = torch.zeros((shp[0], 2 * nin), dtype=BF16, device=dev)
                 self.shadow_wh[k] = torch.zeros((shp[0], 2 * H), dtype=BF16, device=dev)
+            elif self.precision == "high" and self.moe_f16_fp8 and shp[1] % 128 == 0 and shp[1] >= 512:
+                self.shadow_w16[k] = torch.zeros(shp, dtype=ops.F16, device=dev)
+                self.shadow_w8[k] = torch.zeros((shp[0], 2 * shp[1]), dtype=torch.uint8, device=dev)
             else:
                 self.shadow_w[k] = torch.zeros((shp[0], 2 * shp[1]), dtype=BF16, device=dev)
 
     def _refresh_high(self, k):
         p, H = self.store.p(k), self.H
-        if k in self.shadow8:                # L1 level, fp8 low-order halves: f16(W) + e4m3((W - f16(W)) 2^17) (layer 0: + e4m3(Wx 2^6) for the input's)
+        if k in self.shadow_w8:              # MoE head: f16(W) + [e4m3((W - f16(W)) 2^18) | e4m3(W 2^7)]
+            ops.cast_f16(p, self.shadow_w16[k])
+            ops.cast_fp8_lo(p, self.shadow_w8[k], hi_cols=p.shape[1], scale_exp=ops.FP8_MOE["w_lo_exp"], hi_exp=ops.FP8_MOE["w_hi_exp"])
+        elif k in self.shadow8:              # L1 level, fp8 low-order halves: f16(W) + e4m3((W - f16(W)) 2^17) (layer 0: + e4m3(Wx 2^6) for the input's)
             ops.cast_f16(p, self.shadow16[k])
             ops.cast_fp8_lo(p, self.shadow8[k], hi_cols=self.shadow8[k].shape[1] - p.shape[1])
         elif k in self.shadow16 and k.startswith("RNN_L2/") and "cell_1" in k:

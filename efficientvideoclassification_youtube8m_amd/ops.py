@@ -139,6 +139,26 @@ def cast_fp8_lo(w, out, hi_cols=0, scale_exp=FP8_W_SCALE_EXP, hi_exp=FP8_WX_HI_E
     return out
 
 
+FP8_MOE = dict(x_hi_exp=6, x_lo_exp=17, w_lo_exp=18, w_hi_exp=7)     # e4m3 scales of the "high" MoE head: |state| < 7, |W| < 3.5 never clamp; 6 + 18 = 17 + 7 = 24
+
+
+def cast_f16_fp8x(x, out, hi_exp=FP8_MOE["x_hi_exp"], lo_exp=FP8_MOE["x_lo_exp"]):
+    """out [R][2C] f16 containers = rows [f16(x) | e4m3(x 2^hi_exp) (C bytes) | e4m3((x - f16(x)) 2^lo_exp) (C bytes)]: the A operands of gemm_nt_f16_fp8."""
+    assert x.dtype == F32 and x.dim() == 2 and out.dtype == F16 and out.shape == (x.shape[0], 2 * x.shape[1]) and out.is_contiguous()
+    _lib.call("evc_cast_f32_to_f16_fp8x", _p(x), x.stride(0), x.shape[0], x.shape[1], hi_exp, lo_exp, _p(out), _stream())
+    return out
+
+
+def gemm_nt_f16_fp8(a_rows, w16, w8, M, N, K, out, bias=None, scale_exp=-24):
+    """out [M][N] f32 = f16(x) . f16(W)^T + 2^scale_exp [e4m3(x ..) | e4m3(x_lo ..)] . w8^T (+ bias): a_rows [M][2K] from cast_f16_fp8x, w16 [N][K]
+    f16, w8 [N][2K] uint8 = [e4m3(W_lo ..) | e4m3(W ..)] (evc_gemm_nt_f16_fp8: the "high" precision MoE head)."""
+    assert a_rows.dtype == F16 and a_rows.shape == (M, 2 * K) and w16.dtype == F16 and w16.shape == (N, K) and w8.dtype == torch.uint8 and w8.shape == (N, 2 * K)
+    assert out.dtype == F32 and a_rows.is_contiguous() and w16.is_contiguous() and w8.is_contiguous()
+    _lib.call("evc_gemm_nt_f16_fp8", _p(a_rows), 2 * K, a_rows.data_ptr() + 2 * K, 4 * K, _p(w16), K, _p(w8), 2 * K, _p(out), out.stride(0),
+              M, N, K, 2 * K, scale_exp, _p(bias), _stream())
+    return out
+
+
 def cast_bf16_wide(x, out, lo_first):
     """Wide split-bf16 image of a 2-D f32 tensor: out rows [lo | hi] (lo_first: the A operand of gemm_nt_split_wide) or
     [hi | lo] (its B operand)."""
@@ -358,15 +378,19 @@ def moe_tail_bwd(gate_logits, expert_logits, dpred, B, V, M, dgate, dexpert):
 
 
 def moe_grad_update(dlogits, x, rows, V, K, p, m, v, p_bf16, pT_bf16, l2_coeff, sums, partial_ws, clip_norm, lr_t,
-                    beta1=0.9, beta2=0.999, eps=1e-8, phase=0, p_wide=None):
+                    beta1=0.9, beta2=0.999, eps=1e-8, phase=0, p_wide=None, p_f16=None, p_fp8=None):
     """Fused weight-gradient + per-tensor clip + TF-Adam of one MoE weight matrix (evc_moe_grad_update); phase 1 / 2:
     the norm pass / the update pass alone, for a row slab of a matrix sharded over ranks (evc_moe_grad_update_phase).
-    p_wide [V][2K] bf16 (phase 0 only): also receives the wide [hi | lo] split image of the new weights (evc_moe_grad_update_wide)."""
-    if p_wide is not None:
-        assert phase == 0 and p_wide.dtype == BF16 and p_wide.shape == (V, 2 * K) and p_wide.is_contiguous()
+    p_wide [V][2K] bf16 / p_f16 [V][K] f16 + p_fp8 [V][2K] uint8 (phase 0 only): also receive the forward operand images of the new weights
+    (evc_moe_grad_update_wide: the wide [hi | lo] split image / the f16 image and [e4m3(W_lo) | e4m3(W)])."""
+    if p_wide is not None or p_f16 is not None:
+        assert phase == 0 and (p_wide is None or (p_wide.dtype == BF16 and p_wide.shape == (V, 2 * K) and p_wide.is_contiguous()))
+        assert (p_f16 is None) == (p_fp8 is None)
+        if p_f16 is not None:
+            assert p_f16.dtype == F16 and p_f16.shape == (V, K) and p_fp8.dtype == torch.uint8 and p_fp8.shape == (V, 2 * K) and p_f16.is_contiguous() and p_fp8.is_contiguous()
         _lib.call("evc_moe_grad_update_wide", _p(dlogits), dlogits.stride(0), _p(x), x.stride(0), rows, V, K, _p(p), _p(m), _p(v),
-                  _p(p_bf16), _p(pT_bf16), pT_bf16.stride(0), _p(p_wide), l2_coeff, _p(sums), _p(partial_ws), clip_norm, lr_t,
-                  beta1, beta2, eps, _stream())
+                  _p(p_bf16), _p(pT_bf16), pT_bf16.stride(0), _p(p_wide), _p(p_f16), _p(p_fp8), FP8_MOE["w_lo_exp"], FP8_MOE["w_hi_exp"],
+                  l2_coeff, _p(sums), _p(partial_ws), clip_norm, lr_t, beta1, beta2, eps, _stream())
         return
     _lib.call("evc_moe_grad_update_phase", _p(dlogits), dlogits.stride(0), _p(x), x.stride(0), rows, V, K, _p(p), _p(m), _p(v),
               _p(p_bf16), _p(pT_bf16), pT_bf16.stride(0), l2_coeff, _p(sums), _p(partial_ws), clip_norm, lr_t, beta1, beta2, eps,

@@ -36,7 +36,7 @@ extern "C" {
 #define EVC_ERR_HIP (-4)
 #define EVC_ERR_BAD_ARG (-5)
 
-#define EVC_VERSION 102   /* 102: evc_lstm_layer_fwd_f16_fp8lo, evc_cast_f32_to_fp8_lo, aux_mode 5, evc_moe_grad_update_wide; 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
+#define EVC_VERSION 102   /* 102: evc_lstm_layer_fwd_f16_fp8lo, evc_gemm_nt_f16_fp8, evc_cast_f32_to_fp8_lo, evc_cast_f32_to_f16_fp8x, aux_mode 5, evc_moe_grad_update_wide; 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
 
 typedef uint16_t evc_bf16;
 typedef uint16_t evc_f16;   /* raw IEEE binary16 bits (the "high" precision forward operands of the L1 levels) */
@@ -279,12 +279,14 @@ int evc_moe_grad_update_phase(const evc_bf16* dlogits, int64_t ld_dlogits, const
                               int V, int K, float* p, float* m, float* v, evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT,
                               float l2_coeff, float* sums, float* partial_ws, float clip_norm, float lr_t,
                               float beta1, float beta2, float eps, int phase, void* stream);
-/* evc_moe_grad_update that ALSO writes the wide split-bf16 image of the new weights, p_wide_hilo [V][2K] = [bf16(W) | bf16(W - bf16(W))]
- * (the B operand of evc_gemm_nt_split, the "high" precision forward of the MoE head) from the update's epilogue - instead of a
- * separate pass over the f32 weights (evc_cast_f32_to_bf16_wide) after every update. */
+/* evc_moe_grad_update that ALSO writes, from the update's epilogue, the forward operand images of the new weights the non-bf16 precision
+ * modes contract - instead of separate passes over the f32 weights after every update: p_wide_hilo [V][2K] = [bf16(W) | bf16(W - bf16(W))]
+ * (the B operand of evc_gemm_nt_split: "split" mode) and / or p_f16 [V][K] = f16(W) with p_fp8 [V][2K] = [e4m3((W - f16(W)) 2^fp8_lo_exp) |
+ * e4m3(W 2^fp8_hi_exp)] (the B16 / B8 operands of evc_gemm_nt_f16_fp8: "high" mode).  Either may be NULL, not both. */
 int evc_moe_grad_update_wide(const evc_bf16* dlogits, int64_t ld_dlogits, const evc_bf16* x, int64_t ldx, int rows,
                              int V, int K, float* p, float* m, float* v, evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT,
-                             evc_bf16* p_wide_hilo, float l2_coeff, float* sums, float* partial_ws, float clip_norm, float lr_t,
+                             evc_bf16* p_wide_hilo, evc_f16* p_f16, uint8_t* p_fp8, int fp8_lo_exp, int fp8_hi_exp,
+                             float l2_coeff, float* sums, float* partial_ws, float clip_norm, float lr_t,
                              float beta1, float beta2, float eps, void* stream);
 
 /* ---- layout helpers --------------------------------------------------------
@@ -324,6 +326,18 @@ int evc_cast_f32_to_bf16_wide(const float* in, int64_t ld_in, int R, int C, evc_
  * form of the MoE head (cs/video_level_models.py:423-435) and of the L2 level's hoisted input projection. */
 int evc_gemm_nt_split(const evc_bf16* A_lohi, int64_t lda, const evc_bf16* B_hilo, int64_t ldb, float* C, int64_t ldc,
                       int M, int N, int K, const float* bias, void* stream);
+/* C [M][N] f32 = A16 . B16^T (IEEE f16, K16 deep) + 2^scale_exp A8 . B8^T (OCP e4m3 bytes, K8 deep) + bias in ONE launch: a product with its
+ * low-order corrections behind its f16 stages on v_mfma_scale_f32_16x16x128_f8f6f4 (per K element twice the MFMA rate, half the operand
+ * bytes).  The "high" precision MoE head (cs/video_level_models.py:423-448 at f32-operand accuracy): A rows from
+ * evc_cast_f32_to_f16_fp8x(hi_exp 6, lo_exp 17) = [f16(x) | e4m3(x 2^6) | e4m3((x - f16(x)) 2^17)], B16 = f16(W), B8 = [e4m3((W - f16(W)) 2^18) |
+ * e4m3(W 2^7)] (evc_cast_f32_to_fp8_lo with hi_cols = K, or the epilogue of evc_moe_grad_update_wide), scale_exp = -24: 2.5e-5 on logits of
+ * magnitude 8 (f16 alone 8e-4, bf16 4e-3).  lda / ldb in halfwords, lda8 / ldb8 in bytes (multiples of 16); K16 % 64 == 0, K8 % 128 == 0, K8 >= 512. */
+int evc_gemm_nt_f16_fp8(const evc_f16* A16, int64_t lda, const uint8_t* A8, int64_t lda8, const evc_f16* B16, int64_t ldb,
+                        const uint8_t* B8, int64_t ldb8, float* C, int64_t ldc, int M, int N, int K16, int K8, int scale_exp,
+                        const float* bias, void* stream);
+/* out rows of 4C bytes = [f16(x) (C halfwords) | e4m3(x 2^hi_exp) (C bytes) | e4m3((x - f16(x)) 2^lo_exp) (C bytes)] for an f32 matrix [R][C]
+ * (C % 32 == 0): the A16 / A8 operands of evc_gemm_nt_f16_fp8 (A16 = out, lda = 2C halfwords; A8 = (uint8_t*)out + 2C, lda8 = 4C bytes). */
+int evc_cast_f32_to_f16_fp8x(const float* in, int64_t ld_in, int R, int C, int hi_exp, int lo_exp, evc_f16* out, void* stream);
 /* split-bf16 cast: hi = bf16(x), lo = bf16(x - hi).  Three NT products (hi.hi + hi.lo + lo.hi, via
  * evc_gemm_nt with accumulate) then reproduce an f32-operand GEMM to ~2^-16 relative: the
  * "high" precision forward mode for models whose activations are O(1) (DBoF after batch-norm). */

@@ -108,9 +108,18 @@ def tower_fwd(x, n, p, num_chunks, kinds):
     len2 = torch.ceil(n.to(torch.float32) / float(Lc)).to(torch.int64)
     state = stack_fwd(l2_in, len2, l2, (kinds["L2c0"], kinds["L2c1"]))
     mk = kinds["moe"] if isinstance(kinds["moe"], tuple) else (kinds["moe"], kinds["moe"])       # (activation kind, weight kind)
-    sq = rnd(state, mk[0])
-    gl = sq @ rnd(p["classifier/gates/weights"], mk[1])
-    el = sq @ rnd(p["classifier/experts/weights"], mk[1]) + p["classifier/experts/biases"]
+    if mk[0] == "f16+8":      # f16 product + both low-order corrections in fp8: e4m3(x 2^6) . e4m3(W_lo 2^18) + e4m3(x_lo 2^17) . e4m3(W 2^7)
+        x16, xlo = rnd(state, "f16"), state - rnd(state, "f16")
+
+        def head(w):
+            w16 = rnd(w, "f16")
+            return x16 @ w16 + fp8(state, 64.0) @ fp8(w - w16, 2.0 ** 18) + fp8(xlo, 2.0 ** 17) @ fp8(w, 128.0)
+        gl = head(p["classifier/gates/weights"])
+        el = head(p["classifier/experts/weights"]) + p["classifier/experts/biases"]
+    else:
+        sq = rnd(state, mk[0])
+        gl = sq @ rnd(p["classifier/gates/weights"], mk[1])
+        el = sq @ rnd(p["classifier/experts/weights"], mk[1]) + p["classifier/experts/biases"]
     V = el.shape[1] // 2
     g = torch.softmax(gl.reshape(B * V, 3), 1)
     pred = (g[:, :2] * torch.sigmoid(el.reshape(B * V, 2))).sum(1).reshape(B, V)
@@ -231,6 +240,7 @@ def main():
             ("L2 fine PLAN + L2 f16, all activations exact but c0 x", dict(plan, L2c0=dict(ax="f16", ah="x3", wx="f16", wh="f16"), L2c1=act_ext)),
         ]
         configs += [("MOE fine: %s" % k, v) for k, v in (
+            ("f16 + fp8 low-order corrections of x and W", dict(exact, moe=("f16+8", "f16+8"))), ("f16 both", dict(exact, moe="f16")),
             ("x f16, W exact", dict(exact, moe=("f16", "x3"))), ("x exact, W f16", dict(exact, moe=("x3", "f16"))),
             ("x bf16, W exact", dict(exact, moe=("bf16", "x3"))), ("x exact, W bf16", dict(exact, moe=("x3", "bf16"))))]
         w_ext = dict(ax="f16", ah="f16", wx="x3", wh="x3")

@@ -409,6 +409,42 @@ def test_fp8_low_order_weight_cast_and_input_rows(ops):
                 assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 3e-2, (int(d.max()), float((d > 0).float().mean()))
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 1416, 512), (64, 4716 * 3, 4096), (200, 700, 1024), (600, 520, 512)])
+def test_gemm_nt_f16_fp8_product_with_low_order_corrections(ops, M, N, K):
+    """evc_gemm_nt_f16_fp8 = f16(x) . f16(W)^T + 2^-24 [e4m3(x 2^6) | e4m3(x_lo 2^17)] . [e4m3(W_lo 2^18) | e4m3(W 2^7)]^T + bias in one launch (the
+    "high" precision MoE head), operands from evc_cast_f32_to_f16_fp8x / evc_cast_f32_to_f16 / evc_cast_f32_to_fp8_lo(hi_cols = K): against the
+    float64 product of the f32 operands it must be >= 10x closer than the plain f16 product (the corrections remove the 2^-12 operand
+    rounding to ~2^-16) and within 1e-4 of the largest |logit|; the activation rows have the documented layout; batch-row (M <= 256) and
+    256 x 256 tiles, ragged N."""
+    rng = np.random.default_rng(M + N + K)
+    x = (rng.standard_normal((M, K)) * 1.3).astype(np.float32)
+    w = (rng.standard_normal((N, K)) * 0.04).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + bias
+    xd, wd, bd = torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV), torch.from_numpy(bias).to(DEV)
+    rows = torch.empty((M, 2 * K), dtype=torch.float16, device=DEV)
+    ops.cast_f16_fp8x(xd, rows)
+    assert torch.equal(rows[:, :K], xd.half())
+    b8 = rows[:, K:].contiguous().view(torch.uint8)
+    e = ops.FP8_MOE
+    zero_ok = lambda got, want: bool(((got == want) | (((got & 0x7f) == 0) & ((want & 0x7f) == 0))).all())
+    assert zero_ok(b8[:, :K], _e4m3(xd, 2.0 ** e["x_hi_exp"]).view(torch.uint8))
+    assert zero_ok(b8[:, K:], _e4m3(xd - xd.half().float(), 2.0 ** e["x_lo_exp"]).view(torch.uint8))
+    w16 = torch.empty((N, K), dtype=torch.float16, device=DEV)
+    ops.cast_f16(wd, w16)
+    w8 = torch.empty((N, 2 * K), dtype=torch.uint8, device=DEV)
+    ops.cast_fp8_lo(wd, w8, hi_cols=K, scale_exp=e["w_lo_exp"], hi_exp=e["w_hi_exp"])
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    ops.gemm_nt_f16_fp8(rows, w16, w8, M, N, K, out, bias=bd)
+    got = out.cpu().double().numpy()
+    assert np.isfinite(got).all()
+    err = np.max(np.abs(got - ref))
+    plain = xd.half().double().cpu().numpy() @ wd.half().double().cpu().numpy().T + bias
+    err16 = np.max(np.abs(plain - ref))
+    print("gemm_nt_f16_fp8 %dx%dx%d: max err %.2e (plain f16 product %.2e), |z| max %.1f" % (M, N, K, err, err16, np.abs(ref).max()))
+    assert err < 1e-4 * max(1.0, np.abs(ref).max()) and err * 10 < err16, (err, err16)
+
+
 @pytest.mark.parametrize("M,T,Kin,H,tile", [(512, 4, 384, 384, 0), (1100, 3, 1152, 512, 0), (700, 5, 384, 384, 6), (390, 3, 512, 384, 7), (330, 3, 384, 384, 8)])
 def test_lstm_layer_fwd_f16_fp8_low_order_weights(M, T, Kin, H, tile):
     """evc_lstm_layer_fwd_f16_fp8lo (two stacked layers: layer 0 on input rows [f16(x) | e4m3(x 2^7) | e4m3(x_lo 2^18)], layer 1 on layer 0's

@@ -300,14 +300,15 @@ def test_fused_moe_update_matches_materialised_gradient_path():
         assert torch.allclose(ta.sums, tb.sums, rtol=1e-4, atol=1e-12)
 
 
-def test_fused_moe_update_writes_the_wide_split_image_in_high_precision():
-    """"high" precision, one process: the fused MoE update's epilogue also writes the wide [hi | lo] split-bf16 image of the new
-    weights (evc_moe_grad_update_wide) - the operand of the next forward's split products - instead of a separate pass over
-    the f32 weights; after two training iterations it must be exactly what evc_cast_f32_to_bf16_wide makes of the master weights,
-    and the weights themselves must equal the bf16-mode run's (the update arithmetic does not depend on the forward mode's shadows
-    beyond the forward values: compared loosely, the two forwards differ)."""
+@pytest.mark.parametrize("H", [64, 128])
+def test_fused_moe_update_writes_the_forward_operand_images_in_high_precision(H):
+    """"high" precision, one process: the fused MoE update's epilogue also writes the forward operand images of the new weights
+    (evc_moe_grad_update_wide) instead of separate passes over the f32 weights - H = 64 (K = 256): the wide [hi | lo] split-bf16 image
+    (the split-bf16 head: K is below the e4m3 head's 512); H = 128 (K = 512): the f16 image and [e4m3(W_lo 2^18) | e4m3(W 2^7)] of
+    ops.gemm_nt_f16_fp8.  After two training iterations they must be exactly what the cast kernels make of the master weights."""
+    from efficientvideoclassification_youtube8m_amd import ops
     from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
-    B, F, H, V = 8, 64, 64, 100
+    B, F, V = 8, 64, 100
     q, x, n, labels = mm.synthetic_batch(B, seed=33, feature_size=F, vocab_size=V, dtype=np.float32)
     xd, nd, yd = torch.from_numpy(q).to(DEV), torch.from_numpy(n).to(DEV), torch.from_numpy(labels.astype(np.uint8)).to(DEV)
     g = DistillGraph(B, every_n=10, feature_size=F, vocab_size=V, lstm_cells=H, device=DEV, seed=4, precision="high")
@@ -319,9 +320,17 @@ def test_fused_moe_update_writes_the_wide_split_image_in_high_precision():
             p = tw.store.p(k)
             K = p.shape[1]
             hi = p.bfloat16()
-            assert torch.equal(tw.shadow_w[k][:, :K], hi), (tw.scope, k)
-            assert torch.equal(tw.shadow_w[k][:, K:], (p - hi.float()).bfloat16()), (tw.scope, k)
             assert torch.equal(tw.shadow_fwd[k], hi)
+            if H == 64:
+                assert k in tw.shadow_w and k not in tw.shadow_w8
+                assert torch.equal(tw.shadow_w[k][:, :K], hi), (tw.scope, k)
+                assert torch.equal(tw.shadow_w[k][:, K:], (p - hi.float()).bfloat16()), (tw.scope, k)
+            else:
+                assert k in tw.shadow_w8 and k not in tw.shadow_w
+                assert torch.equal(tw.shadow_w16[k], p.half()), (tw.scope, k)
+                want = torch.empty_like(tw.shadow_w8[k])
+                ops.cast_fp8_lo(p, want, hi_cols=K, scale_exp=ops.FP8_MOE["w_lo_exp"], hi_exp=ops.FP8_MOE["w_hi_exp"])
+                assert torch.equal(tw.shadow_w8[k], want), (tw.scope, k)
     assert all(np.isfinite(v) for v in g.loss_report().values())
 
 
