@@ -1050,14 +1050,14 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, 
 // rest step b): layer 0 at time t+1 and layer 1 at time t of a two-layer stack with M ~ batch rows - those steps are
 // latency-bound (12 us for 2 GFLOP), so the pair costs about what one of them does and the stack's chain of
 // dependent launches is T+1 long instead of 2T (evc_lstm_stack2_fwd).
-template <class Cfg, bool F16 = false>
+template <class Cfg, bool F16 = false, bool FP8 = false>
 __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_pair_kernel(GemmOperands pa, LstmFwdParams ea, GemmOperands pb, LstmFwdParams eb,
                                                                 int tiles_m, int tiles_n) {
   const int n = tiles_m * tiles_n;
   const bool first = blockIdx.x < n;                   // workgroup-uniform: scalar selects of the two argument sets
   const GemmOperands p = first ? pa : pb;
   const LstmFwdParams e = first ? ea : eb;
-  lstm_fwd_step_body<Cfg, false, F16>(p, e, tiles_m, tiles_n, first ? blockIdx.x : blockIdx.x - n);
+  lstm_fwd_step_body<Cfg, false, F16, FP8>(p, e, tiles_m, tiles_n, first ? blockIdx.x : blockIdx.x - n);
 }
 
 typedef TileCfg<128, 4, 32, 2, 2> CfgLstmBig;    // 128 rows x 32 units x 4 gates
@@ -1399,13 +1399,13 @@ static inline void fwd_step_args(const FwdLayer& L, const int32_t* len, int t, i
   e.M = M; e.H = H;
 }
 
-template <class Cfg, bool F16 = false>
+template <class Cfg, bool F16 = false, bool FP8 = false>
 static inline void launch_lstm_fwd_pair(GemmOperands pa, const LstmFwdParams& ea, int k1a, int k2a,
                                         GemmOperands pb, const LstmFwdParams& eb, int k1b, int k2b, hipStream_t st) {
   pa.nk1 = k1a / kdiv<Cfg>(); pa.nk2 = k2a / kdiv<Cfg>();
   pb.nk1 = k1b / kdiv<Cfg>(); pb.nk2 = k2b / kdiv<Cfg>();
   const int tm = ceil_div(ea.M, Cfg::BM), tn = ceil_div(ea.H, Cfg::BU);
-  launch_cfg<Cfg>(lstm_fwd_pair_kernel<Cfg, F16>, 2 * tm * tn, st, pa, ea, pb, eb, tm, tn);
+  launch_cfg<Cfg>(lstm_fwd_pair_kernel<Cfg, F16, FP8>, 2 * tm * tn, st, pa, ea, pb, eb, tm, tn);
 }
 
 extern "C" int evc_lstm_stack2_fwd(const evc_bf16* x, const evc_bf16* wT0, const float* bias0, const evc_bf16* wT1, const float* bias1,
@@ -1550,6 +1550,96 @@ extern "C" int evc_lstm_stack2_fwd_f16(const evc_f16* x, int x_segments, const e
     if (has_a && has_b) launch_lstm_fwd_pair<CfgLstmV3Small, true>(pa, ea, k1a, k2a, pb, eb, k1b, k2b, st);
     else if (has_a) launch_lstm_fwd<CfgLstmV3Small, false, true>(pa, ea, k1a, k2a, st);
     else launch_lstm_fwd<CfgLstmV3Small, false, true>(pb, eb, k1b, k2b, st);
+  }
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// evc_lstm_stack2_fwd_f16 with the low-order halves of the recurrent weights of layer 0 and of all weights of layer 1 contracted as e4m3
+// operands behind the f16 stages of the same (pair) launches (LOOP_FP8_TAIL) instead of f16 K-extensions: layer 1 walks 32 f16 + 16 e4m3
+// stages instead of 64 f16 ones (H = 1024) - these steps are bound by their chain of dependent stages.  x [T][M][x_segments Kin] f16
+// (K-extended input of the hoisted product, as before); wT0 [4H][x_segments Kin + H] f16 = [Wx segments | f16(Wh)], wT0_8 [4H][H] bytes =
+// e4m3((Wh - f16(Wh)) 2^w8_scale_exp); wT1 [4H][2H] f16, wT1_8 [4H][2H] bytes; h0_rows / h1_rows [(T+1)][M] rows of 3H bytes = [f16(h) |
+// e4m3(h 2^7)].  H % 128 == 0, H >= 512.
+extern "C" int evc_lstm_stack2_fwd_f16_fp8lo(const evc_f16* x, int x_segments, const evc_f16* wT0, const uint8_t* wT0_8, const float* bias0,
+                                             const evc_f16* wT1, const uint8_t* wT1_8, int w8_scale_exp, const float* bias1,
+                                             const int32_t* len, int T, int M, int Kin, int H, float* zx_ws,
+                                             evc_f16* h0_rows, evc_f16* h1_rows, evc_bf16* hbuf0, evc_bf16* hbuf1,
+                                             float* c_state0, float* h_state0, float* c_state1, float* h_state1, int64_t ld_state,
+                                             void* gates0, evc_bf16* c_all0, void* gates1, evc_bf16* c_all1, void* stream) {
+  EVC_REQUIRE(T > 0 && M > 0 && H >= 512 && Kin > 0 && H % 128 == 0 && Kin % 64 == 0, EVC_ERR_BAD_SHAPE,
+              "evc_lstm_stack2_fwd_f16_fp8lo: bad shape T=%d M=%d Kin=%d (%%64) H=%d (%%128, >= 512)", T, M, Kin, H);
+  EVC_REQUIRE(x && wT0 && wT0_8 && wT1 && wT1_8 && zx_ws && h0_rows && h1_rows && hbuf0 && hbuf1, EVC_ERR_BAD_ARG, "evc_lstm_stack2_fwd_f16_fp8lo: NULL operand");
+  EVC_REQUIRE(x_segments >= 1 && x_segments <= 3 && w8_scale_exp >= 0 && w8_scale_exp <= 60, EVC_ERR_BAD_ARG,
+              "evc_lstm_stack2_fwd_f16_fp8lo: x_segments=%d w8_scale_exp=%d", x_segments, w8_scale_exp);
+  const long Kx = (long)x_segments * Kin;
+  const long ldw0 = Kx + H, ldh = 3L * H / 2;
+  EVC_REQUIRE(ring_operand_ok(M, ldh) && ring_operand_ok(4L * H, ldw0) && ring_operand_ok(4L * H, 2L * H), EVC_ERR_BAD_SHAPE,
+              "evc_lstm_stack2_fwd_f16_fp8lo: an operand spans 4 GiB or more");
+  EVC_REQUIRE(ld_state % 4 == 0 && ((uintptr_t)c_state0 % 16) == 0 && ((uintptr_t)h_state0 % 16) == 0 && ((uintptr_t)c_state1 % 16) == 0 &&
+              ((uintptr_t)h_state1 % 16) == 0 && ((uintptr_t)bias0 % 16) == 0 && ((uintptr_t)bias1 % 16) == 0 && ((uintptr_t)h0_rows % 16) == 0 &&
+              ((uintptr_t)h1_rows % 16) == 0 && ((uintptr_t)hbuf0 % 8) == 0 && ((uintptr_t)hbuf1 % 8) == 0 && ((uintptr_t)wT0_8 % 16) == 0 &&
+              ((uintptr_t)wT1_8 % 16) == 0 && ((uintptr_t)wT0 % 16) == 0 && ((uintptr_t)wT1 % 16) == 0, EVC_ERR_BAD_ALIGN,
+              "evc_lstm_stack2_fwd_f16_fp8lo: state/bias/h buffers and weight images must allow 16-byte vector access");
+  EVC_REQUIRE((gates0 == nullptr) == (c_all0 == nullptr) && (gates1 == nullptr) == (c_all1 == nullptr) && (gates0 == nullptr) == (gates1 == nullptr),
+              EVC_ERR_BAD_ARG, "evc_lstm_stack2_fwd_f16_fp8lo: gates and c_all go together, for both layers");
+  hipStream_t st = (hipStream_t)stream;
+  bf16_t* h0r = (bf16_t*)h0_rows;
+  bf16_t* h1r = (bf16_t*)h1_rows;
+  EVC_CHECK_HIP(hipMemsetAsync(h0r, 0, (size_t)M * ldh * sizeof(bf16_t), st));        // h_{-1} = 0, both layers, every image
+  EVC_CHECK_HIP(hipMemsetAsync(h1r, 0, (size_t)M * ldh * sizeof(bf16_t), st));
+  EVC_CHECK_HIP(hipMemsetAsync(hbuf0, 0, (size_t)M * H * sizeof(bf16_t), st));
+  EVC_CHECK_HIP(hipMemsetAsync(hbuf1, 0, (size_t)M * H * sizeof(bf16_t), st));
+  int rc = gemm_nt_f16(x, Kx, wT0, ldw0, zx_ws, 4L * H, T * M, 4 * H, (int)Kx, stream);
+  if (rc) return rc;
+  for (int s = 0; s <= T; ++s) {            // launch s: layer 0 step s next to layer 1 step s-1
+    GemmOperands pa, pb;
+    LstmFwdParams ea, eb;
+    int k1a = 0, k1b = 0, k2b = 0;
+    const bool has_a = s < T, has_b = s >= 1;
+    if (has_a) {                             // layer 0, step s: zx + h0_{s-1} . Wh0^T (f16) + 2^-(7+e) e4m3(h0_{s-1}) . e4m3(lo(Wh0))^T
+      const int t = s;
+      pa.M = M; pa.Nu = H; pa.group_stride = H; pa.ldb = ldw0; pa.nk1 = pa.nk2 = 0;
+      pa.A1lo = pa.A2lo = pa.Blo = nullptr;
+      const bf16_t* hprev = h0r + (long)t * M * ldh;
+      pa.A1 = hprev; pa.lda1 = ldh; k1a = (t == 0) ? 0 : H; pa.A2 = hprev; pa.lda2 = ldh;
+      pa.B = (const bf16_t*)wT0 + Kx;
+      pa.A3 = (const uint8_t*)(hprev + H); pa.lda3 = ldh * 2; pa.nk3 = (t == 0) ? 0 : H / 128;
+      pa.A4 = pa.A3; pa.lda4 = pa.lda3; pa.nk4 = 0;
+      pa.B8 = wT0_8; pa.ldb8 = H; pa.scale8_exp = -(7 + w8_scale_exp);
+      ea.zx = zx_ws + (long)t * M * 4 * H; ea.ldzx = 4L * H;
+      ea.bias = bias0; ea.len = len; ea.t = t;
+      ea.c_state = c_state0; ea.h_state = h_state0; ea.ld_state = ld_state;
+      ea.hout = h0r + (long)(t + 1) * M * ldh; ea.h_wide = 2;
+      ea.hout_lo = hbuf0 + (long)(t + 1) * M * H;
+      ea.gates = gates0 ? (uint2*)gates0 + (long)t * M * H : nullptr;
+      ea.c_hist = c_all0 ? c_all0 + (long)(t + 1) * M * H : nullptr;
+      ea.row_map = nullptr; ea.M = M; ea.H = H;
+    }
+    if (has_b) {                             // layer 1, step s-1: [h0_t | h1_{t-1}] . [Wx | Wh]^T (f16) + the same rows' e4m3 parts against e4m3(lo([Wx | Wh]))
+      const int t = s - 1;
+      pb.M = M; pb.Nu = H; pb.group_stride = H; pb.ldb = 2L * H; pb.nk1 = pb.nk2 = 0;
+      pb.A1lo = pb.A2lo = pb.Blo = nullptr;
+      const bf16_t* xin = h0r + (long)(t + 1) * M * ldh;
+      const bf16_t* hprev = h1r + (long)t * M * ldh;
+      pb.A1 = xin; pb.lda1 = ldh; k1b = H;
+      pb.A2 = hprev; pb.lda2 = ldh; k2b = (t == 0) ? 0 : H;
+      pb.B = (const bf16_t*)wT1;
+      pb.A3 = (const uint8_t*)(xin + H); pb.lda3 = ldh * 2; pb.nk3 = H / 128;
+      pb.A4 = (const uint8_t*)(hprev + H); pb.lda4 = ldh * 2; pb.nk4 = (t == 0) ? 0 : H / 128;
+      pb.B8 = wT1_8; pb.ldb8 = 2L * H; pb.scale8_exp = -(7 + w8_scale_exp);
+      eb.zx = nullptr; eb.ldzx = 0;
+      eb.bias = bias1; eb.len = len; eb.t = t;
+      eb.c_state = c_state1; eb.h_state = h_state1; eb.ld_state = ld_state;
+      eb.hout = h1r + (long)(t + 1) * M * ldh; eb.h_wide = 2;
+      eb.hout_lo = hbuf1 + (long)(t + 1) * M * H;
+      eb.gates = gates1 ? (uint2*)gates1 + (long)t * M * H : nullptr;
+      eb.c_hist = c_all1 ? c_all1 + (long)(t + 1) * M * H : nullptr;
+      eb.row_map = nullptr; eb.M = M; eb.H = H;
+    }
+    if (has_a && has_b) launch_lstm_fwd_pair<CfgLstmV3Small, true, true>(pa, ea, k1a, 0, pb, eb, k1b, k2b, st);
+    else if (has_a) launch_lstm_fwd<CfgLstmV3Small, false, true, true>(pa, ea, k1a, 0, st);
+    else launch_lstm_fwd<CfgLstmV3Small, false, true, true>(pb, eb, k1b, k2b, st);
   }
   EVC_LAUNCH_CHECK();
   return EVC_OK;

@@ -382,8 +382,9 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
     // row fragments while the upper ones are read; behind the barrier and the refill, half 2 multiplies the upper ones while the next
     // stage's lower row fragments and - column group by column group, as its last MFMA has been issued - its B fragments are read.
     constexpr int ML = (Cfg::MI + 1) / 2, MH = Cfg::MI - ML;
-    static_assert(MH >= 1, "e4m3 trips: at least two row fragments per wave");
-    v8i_t aL[ML], aH[MH], b8[Cfg::G][Cfg::NI];
+    // (a wave with ONE row fragment - the 64-row tiles of the M ~ batch stacks - has no upper half: half 1 multiplies everything, half 2
+    //  only re-reads; those steps are bound by the chain of dependent stages, and an e4m3 stage covers twice the K of a 16-bit one)
+    v8i_t aL[ML], aH[MH > 0 ? MH : 1], b8[Cfg::G][Cfg::NI];
     const int sc_first = 127 + p.scale8_exp, sc_second = 127;   // e8m0 scale bytes: the whole factor rides on the first operand
     auto rd8 = [&](const int base0, const int base1, const int off) -> v8i_t {   // both 16-byte chunks of this lane's row in ring slot slot_read
       const char* sb = lds + slot_read * Cfg::STAGE_BYTES;
@@ -420,7 +421,7 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
     };
     auto pattern = [&](auto nmfma_tag, auto nread_tag, auto ndma_tag) {   // LDS-DMAs and fragment reads spread behind the MFMAs
       constexpr int nm = decltype(nmfma_tag)::value, nr = decltype(nread_tag)::value, nd = decltype(ndma_tag)::value;
-      constexpr int rper = (nr + nm - 1) / nm, dper = (nd + nm - 1) / nm;
+      constexpr int rper = nm > 0 ? (nr + nm - 1) / nm : 0, dper = nm > 0 ? (nd + nm - 1) / nm : 0;
 #pragma unroll
       for (int i = 0; i < nm; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);

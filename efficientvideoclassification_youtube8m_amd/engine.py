@@ -172,10 +172,19 @@ class LstmStack:
             if self.scope == "RNN_L2" and L == 2 and plan is None:
                 # M ~ batch (the L2 level): wavefront pair launches on f16 operands, the upper layer's weights K-extended by their
                 # low-order halves (ops.lstm_stack2_fwd_f16); wide [h | h/64] f16 images + the bf16 copies for the backward pass
-                if not hasattr(self, "hbuf16w"):
-                    self.hbuf16w = [torch.zeros((self.T + 1, self.M, 2 * H), dtype=ops.F16, device=h.device) for h in self.hbuf]
                 if self.zx is None:
                     self.zx = torch.empty((self.T * self.M, 4 * H), dtype=F32, device=self.S.device)
+                (k0, b0), (k1, b1) = self.names(0), self.names(1)
+                if k1 in tw.shadow8:      # weights' low-order halves as e4m3 operands in the same launches (ops.lstm_stack2_fwd_f16_fp8lo)
+                    if not hasattr(self, "hrows16"):
+                        self.hrows16 = [torch.zeros((self.T + 1, self.M, 3 * H // 2), dtype=ops.F16, device=h.device) for h in self.hbuf]
+                    hr = [self._v(h, T + 1, M, 3 * H // 2) for h in self.hrows16]
+                    ops.lstm_stack2_fwd_f16_fp8lo(x16, tw.shadow16[k0], tw.shadow8[k0], tw.store.p(b0), tw.shadow16[k1], tw.shadow8[k1], tw.store.p(b1),
+                                                  lens, T, M, self.Kin, H, self.zx, hr[0], hr[1], hb[0], hb[1], self.S, gates, c_all,
+                                                  x_segments=tw.f16_l2_x_segments)
+                    return self.S
+                if not hasattr(self, "hbuf16w"):
+                    self.hbuf16w = [torch.zeros((self.T + 1, self.M, 2 * H), dtype=ops.F16, device=h.device) for h in self.hbuf]
                 hw = [self._v(h, T + 1, M, 2 * H) for h in self.hbuf16w]
                 (k0, b0), (k1, b1) = self.names(0), self.names(1)
                 ops.lstm_stack2_fwd_f16(x16, tw.shadow16[k0], tw.store.p(b0), tw.shadow16[k1], tw.store.p(b1), lens, T, M, self.Kin, H,
@@ -853,6 +862,8 @@ class HLstmTower(TowerBase):
     # MoE head in "high": f16 product + both low-order corrections as e4m3 operands behind it in the same launch (ops.gemm_nt_f16_fp8) instead of
     # the split-bf16 K-extension; needs K % 128 == 0, K >= 512 (same switch; not touched by distill.student_light, which is about the L1 level)
     moe_f16_fp8 = os.environ.get("EVC_HIGH_MOE_FP8", os.environ.get("EVC_HIGH_FP8_LO", "1")) != "0"
+    # L2 level (two layers) in "high": the same for layer 0's recurrent weights and all of layer 1's (ops.lstm_stack2_fwd_f16_fp8lo); H % 128 == 0, H >= 512
+    l2_fp8_lo = os.environ.get("EVC_HIGH_L2_FP8", os.environ.get("EVC_HIGH_FP8_LO", "1")) != "0"
 
     def fp8_lo(self):
         """True if this tower's L1 level runs on ops.lstm_layer_fwd_f16_fp8lo."""
@@ -880,6 +891,15 @@ class HLstmTower(TowerBase):
                 layer = int(k.split("cell_")[1].split("/")[0])
                 xw = self.f16_x_segments * nin if layer == 0 else (2 if layer in self.f16_wx_ext_layers else 1) * nin
                 self.shadow16[k] = torch.zeros((shp[0], xw + (2 if layer in self.f16_wh_ext_layers else 1) * H), dtype=ops.F16, device=dev)
+            elif k.startswith("RNN_L2/") and self.precision == "high" and self.L == 2 and self.l2_fp8_lo and H % 128 == 0 and H >= 512:
+                # f16 L2 level with e4m3 low-order halves (ops.lstm_stack2_fwd_f16_fp8lo): layer 0 [Wx segments | f16(Wh)] + lo(Wh), layer 1 f16(W) + lo(W)
+                nin = shp[1] - H
+                if "cell_0" in k:
+                    self.shadow16[k] = torch.zeros((shp[0], self.f16_l2_x_segments * nin + H), dtype=ops.F16, device=dev)
+                    self.shadow8[k] = torch.zeros((shp[0], H), dtype=torch.uint8, device=dev)
+                else:
+                    self.shadow16[k] = torch.zeros(shp, dtype=ops.F16, device=dev)
+                    self.shadow8[k] = torch.zeros(shp, dtype=torch.uint8, device=dev)
             elif k.startswith("RNN_L2/") and self.precision == "high" and self.L == 2:
                 # f16 L2 level (ops.lstm_stack2_fwd_f16): layer 0 [Wx segments | Wh (| Wh_lo*64)], layer 1 [Wx | Wx_lo*64 | Wh | Wh_lo*64]
                 nin = shp[1] - H
@@ -900,6 +920,14 @@ class HLstmTower(TowerBase):
         if k in self.shadow_w8:              # MoE head: f16(W) + [e4m3((W - f16(W)) 2^18) | e4m3(W 2^7)]
             ops.cast_f16(p, self.shadow_w16[k])
             ops.cast_fp8_lo(p, self.shadow_w8[k], hi_cols=p.shape[1], scale_exp=ops.FP8_MOE["w_lo_exp"], hi_exp=ops.FP8_MOE["w_hi_exp"])
+        elif k in self.shadow8 and k.startswith("RNN_L2/"):     # L2 level, fp8 low-order halves
+            nin = p.shape[1] - H
+            if "cell_0" in k:
+                ops.cast_f16_wide(p, nin, H, self.f16_l2_x_segments, self.shadow16[k], h_ext=False)
+                ops.cast_fp8_lo(p[:, nin:], self.shadow8[k])
+            else:
+                ops.cast_f16(p, self.shadow16[k])
+                ops.cast_fp8_lo(p, self.shadow8[k])
         elif k in self.shadow8:              # L1 level, fp8 low-order halves: f16(W) + e4m3((W - f16(W)) 2^17) (layer 0: + e4m3(Wx 2^6) for the input's)
             ops.cast_f16(p, self.shadow16[k])
             ops.cast_fp8_lo(p, self.shadow8[k], hi_cols=self.shadow8[k].shape[1] - p.shape[1])

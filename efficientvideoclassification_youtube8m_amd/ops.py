@@ -344,6 +344,21 @@ def lstm_stack2_fwd_f16(x16, wT0_16, bias0, wT1_wlo, bias1, lens, T, M, Kin, H, 
               _p(gates[0]), _p(c_all[0]), _p(gates[1]), _p(c_all[1]), _stream())
 
 
+def lstm_stack2_fwd_f16_fp8lo(x16, wT0_16, wT0_8, bias0, wT1_16, wT1_8, bias1, lens, T, M, Kin, H, zx_ws, h0_rows, h1_rows, hbuf0, hbuf1, S,
+                              gates=(None, None), c_all=(None, None), x_segments=1, w8_scale_exp=FP8_W_SCALE_EXP):
+    """lstm_stack2_fwd_f16 with the low-order halves of layer 0's recurrent weights and of layer 1's weights as e4m3 operands behind the f16
+    stages of the same launches (evc_lstm_stack2_fwd_f16_fp8lo).  wT0_16 [4H][x_segments Kin + H], wT0_8 [4H][H], wT1_16 / wT1_8 [4H][2H];
+    h*_rows [(T+1)][M][3H/2] f16 containers = rows [f16(h) | e4m3(h 2^7)]; hbuf* [(T+1)][M][H] bf16; S [M][4H] f32."""
+    assert x16.dtype == F16 and wT0_16.dtype == F16 and wT1_16.dtype == F16 and wT0_8.dtype == torch.uint8 and wT1_8.dtype == torch.uint8
+    assert x16.shape[-1] == x_segments * Kin and wT0_16.shape == (4 * H, x_segments * Kin + H) and wT0_8.shape == (4 * H, H)
+    assert wT1_16.shape == (4 * H, 2 * H) and wT1_8.shape == (4 * H, 2 * H) and h0_rows.dtype == F16 and hbuf0.dtype == BF16
+    assert all(t.is_contiguous() for t in (wT0_16, wT0_8, wT1_16, wT1_8))
+    _lib.call("evc_lstm_stack2_fwd_f16_fp8lo", _p(x16), x_segments, _p(wT0_16), _p(wT0_8), _p(bias0), _p(wT1_16), _p(wT1_8), w8_scale_exp, _p(bias1),
+              _p(lens), T, M, Kin, H, _p(zx_ws), _p(h0_rows), _p(h1_rows), _p(hbuf0), _p(hbuf1),
+              _p(S[:, 0:]), _p(S[:, H:]), _p(S[:, 2 * H:]), _p(S[:, 3 * H:]), S.stride(0),
+              _p(gates[0]), _p(c_all[0]), _p(gates[1]), _p(c_all[1]), _stream())
+
+
 def lstm_layer_fwd_hp(x_lohi, wx_hilo, wh_hilo, bias, lens, T, M, Kin, H, zx_ws, hbuf, hbuf_lohi, c_state, h_state, ld_state,
                       gates=None, c_all=None):
     """Split-bf16 layer for the M ~ batch stacks (evc_lstm_layer_fwd_hp): wide [lo | hi] activations, [hi | lo] weights."""

@@ -36,7 +36,7 @@ extern "C" {
 #define EVC_ERR_HIP (-4)
 #define EVC_ERR_BAD_ARG (-5)
 
-#define EVC_VERSION 102   /* 102: evc_lstm_layer_fwd_f16_fp8lo, evc_gemm_nt_f16_fp8, evc_cast_f32_to_fp8_lo, evc_cast_f32_to_f16_fp8x, aux_mode 5, evc_moe_grad_update_wide; 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
+#define EVC_VERSION 102   /* 102: evc_lstm_layer_fwd_f16_fp8lo, evc_lstm_stack2_fwd_f16_fp8lo, evc_gemm_nt_f16_fp8, evc_cast_f32_to_fp8_lo, evc_cast_f32_to_f16_fp8x, aux_mode 5, evc_moe_grad_update_wide; 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
 
 typedef uint16_t evc_bf16;
 typedef uint16_t evc_f16;   /* raw IEEE binary16 bits (the "high" precision forward operands of the L1 levels) */
@@ -213,6 +213,18 @@ int evc_lstm_stack2_fwd_f16(const evc_f16* x, int x_segments /* x rows: x_segmen
                             evc_f16* h0_wide, evc_f16* h1_wide, evc_bf16* hbuf0, evc_bf16* hbuf1,
                             float* c_state0, float* h_state0, float* c_state1, float* h_state1, int64_t ld_state,
                             void* gates0, evc_bf16* c_all0, void* gates1, evc_bf16* c_all1, void* stream);
+/* evc_lstm_stack2_fwd_f16 with the low-order halves of layer 0's recurrent weights and of all of layer 1's weights contracted as e4m3
+ * operands behind the f16 stages of the same (pair) launches instead of f16 K-extensions (see evc_lstm_layer_fwd_f16_fp8lo): layer 1 walks
+ * 32 f16 + 16 e4m3 stages instead of 64 f16 ones at H = 1024 - the M ~ batch steps are bound by their chain of dependent stages.
+ * x [T][M][x_segments Kin] f16 (K-extended input of the hoisted product); wT0 [4H][x_segments Kin + H] f16 = [Wx segments | f16(Wh)],
+ * wT0_8 [4H][H] = e4m3((Wh - f16(Wh)) 2^w8_scale_exp); wT1 [4H][2H] f16, wT1_8 [4H][2H]; h0_rows / h1_rows [(T+1)][M] rows of 3H bytes =
+ * [f16(h) | e4m3(h 2^7)].  H % 128 == 0, H >= 512. */
+int evc_lstm_stack2_fwd_f16_fp8lo(const evc_f16* x, int x_segments, const evc_f16* wT0, const uint8_t* wT0_8, const float* bias0,
+                                  const evc_f16* wT1, const uint8_t* wT1_8, int w8_scale_exp, const float* bias1,
+                                  const int32_t* len, int T, int M, int Kin, int H, float* zx_ws,
+                                  evc_f16* h0_rows, evc_f16* h1_rows, evc_bf16* hbuf0, evc_bf16* hbuf1,
+                                  float* c_state0, float* h_state0, float* c_state1, float* h_state1, int64_t ld_state,
+                                  void* gates0, evc_bf16* c_all0, void* gates1, evc_bf16* c_all1, void* stream);
 /* A TWO-layer stack with M ~ batch rows (the L2 level: M = videos) in wavefront order: after layer 0's hoisted
  * x-projection (one GEMM into zx_ws [T][M][4H] f32), launch s runs layer 0's step s and layer 1's step s-1 side by
  * side (they are independent, and each is latency-bound at this size), so the chain of dependent launches is T+1

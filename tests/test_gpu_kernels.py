@@ -409,6 +409,69 @@ def test_fp8_low_order_weight_cast_and_input_rows(ops):
                 assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 3e-2, (int(d.max()), float((d > 0).float().mean()))
 
 
+@pytest.mark.parametrize("M,T,Kin,H,nseg", [(96, 6, 512, 512, 1), (256, 20, 1024, 512, 2), (40, 5, 256, 640, 2)])
+def test_lstm_stack2_fwd_f16_fp8_low_order_weights(ops, M, T, Kin, H, nseg):
+    """evc_lstm_stack2_fwd_f16_fp8lo (the "high" precision L2 level with e4m3 low-order halves): two layers in wavefront order, layer 0 =
+    hoisted f16 x-projection (input in nseg segments) + [f16(h0)] . f16(Wh0)^T + e4m3 correction, layer 1 = [h0 | h1] . [Wx | Wh]^T in f16 +
+    e4m3 corrections of both weight blocks - against the float64 oracle on the UNROUNDED f32 kernels (x f16-exact): within the f16 activation
+    bound (8e-4) and no further from it than evc_lstm_stack2_fwd_f16 with every weight K-extended by f16 low-order halves; h rows are
+    [f16(h) | e4m3(h 2^7)], the bf16 copies roundings of the same values."""
+    rng = np.random.default_rng(M + T + Kin + H + 17)
+    f16r = lambda a: torch.from_numpy(np.asarray(a, np.float32)).half().double().numpy()
+    x = f16r(rng.standard_normal((M, T, Kin)) * 0.5)
+    k0 = (mm.glorot_uniform(rng, (Kin + H, 4 * H)) * 2.0).astype(np.float32)
+    k0[:Kin] = f16r(k0[:Kin]).astype(np.float32)          # (the input weights are not extended in either form: keep them f16-exact)
+    k1 = (mm.glorot_uniform(rng, (2 * H, 4 * H)) * 2.0).astype(np.float32)
+    b0 = (rng.standard_normal(4 * H) * 0.1).astype(np.float32)
+    b1 = (rng.standard_normal(4 * H) * 0.1).astype(np.float32)
+    lens = rng.integers(0, T + 1, size=M).astype(np.int32)
+    lens[:3] = [0, T, 1]
+    s_ref, _ = mm.multi_rnn_seq_fwd(x, lens, [(k0.astype(np.float64), b0.astype(np.float64)), (k1.astype(np.float64), b1.astype(np.float64))])
+    x16p = torch.from_numpy(np.ascontiguousarray(x.transpose(1, 0, 2)).astype(np.float32)).half().to(DEV)
+    x16 = torch.empty((T * M, nseg * Kin), dtype=torch.float16, device=DEV)
+    ops.cast_f16_segs(x16p.float().reshape(T * M, Kin), nseg, x16)
+    x16 = x16.view(T, M, nseg * Kin)
+    k0T, k1T = torch.from_numpy(np.ascontiguousarray(k0.T)).to(DEV), torch.from_numpy(np.ascontiguousarray(k1.T)).to(DEV)
+    bd0, bd1, ln = torch.from_numpy(b0).to(DEV), torch.from_numpy(b1).to(DEV), torch.from_numpy(lens).to(DEV)
+    zx = torch.empty((T * M, 4 * H), dtype=torch.float32, device=DEV)
+    hb = [torch.full((T + 1, M, H), float("nan"), dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+    # e4m3 form
+    w0 = torch.empty((4 * H, nseg * Kin + H), dtype=torch.float16, device=DEV)
+    ops.cast_f16_wide(k0T, Kin, H, nseg, w0, h_ext=False)
+    w0_8 = torch.empty((4 * H, H), dtype=torch.uint8, device=DEV)
+    ops.cast_fp8_lo(k0T[:, Kin:], w0_8)
+    w1 = torch.empty((4 * H, 2 * H), dtype=torch.float16, device=DEV)
+    ops.cast_f16(k1T, w1)
+    w1_8 = torch.empty((4 * H, 2 * H), dtype=torch.uint8, device=DEV)
+    ops.cast_fp8_lo(k1T, w1_8)
+    hr = [torch.full((T + 1, M, 3 * H // 2), float("nan"), dtype=torch.float16, device=DEV) for _ in range(2)]
+    S = torch.full((M, 4 * H), float("nan"), dtype=torch.float32, device=DEV)
+    ops.lstm_stack2_fwd_f16_fp8lo(x16, w0, w0_8, bd0, w1, w1_8, bd1, ln, T, M, Kin, H, zx, hr[0], hr[1], hb[0], hb[1], S, x_segments=nseg)
+    got = S.cpu().double().numpy()
+    assert np.isfinite(got).all() and np.all(got[0] == 0)
+    err = np.max(np.abs(got - s_ref))
+    for l in range(2):
+        hn, hbn = hr[l][:, :, :H].float(), hb[l].float()
+        assert bool((hn[0] == 0).all()) and float((hn - hbn).abs().max()) <= 2.0 ** -8
+        h8 = hr[l][:, :, H:].contiguous().view(torch.uint8)
+        d = (h8.to(torch.int16) - (hn * 128.0).to(torch.float8_e4m3fn).view(torch.uint8).to(torch.int16)).abs()
+        assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 2e-2
+        for t in range(T):
+            dead = torch.from_numpy(lens <= t).to(DEV)
+            assert bool((hn[t + 1][dead] == 0).all()) and bool((h8[t + 1][dead] == 0).all())
+    # f16 K-extension form on the same kernels
+    w0e = torch.empty((4 * H, nseg * Kin + 2 * H), dtype=torch.float16, device=DEV)
+    ops.cast_f16_wide(k0T, Kin, H, nseg, w0e, h_ext=True)
+    w1e = torch.empty((4 * H, 4 * H), dtype=torch.float16, device=DEV)
+    ops.cast_f16_wlo(k1T, H, H, w1e)
+    hw = [torch.full((T + 1, M, 2 * H), float("nan"), dtype=torch.float16, device=DEV) for _ in range(2)]
+    S2 = torch.full((M, 4 * H), float("nan"), dtype=torch.float32, device=DEV)
+    ops.lstm_stack2_fwd_f16(x16, w0e, bd0, w1e, bd1, ln, T, M, Kin, H, zx, hw[0], hw[1], hb[0], hb[1], S2, x_segments=nseg, h0_ext=True)
+    err_ext = np.max(np.abs(S2.cpu().double().numpy() - s_ref))
+    print("stack2 f16 + e4m3 low-order halves: state err %.2e (f16 K-extensions %.2e)" % (err, err_ext))
+    assert err < 8e-4 and err <= err_ext * 1.3 + 2e-5, (err, err_ext)
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 1416, 512), (64, 4716 * 3, 4096), (200, 700, 1024), (600, 520, 512)])
 def test_gemm_nt_f16_fp8_product_with_low_order_corrections(ops, M, N, K):
     """evc_gemm_nt_f16_fp8 = f16(x) . f16(W)^T + 2^-24 [e4m3(x 2^6) | e4m3(x_lo 2^17)] . [e4m3(W_lo 2^18) | e4m3(W 2^7)]^T + bias in one launch (the
