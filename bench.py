@@ -491,7 +491,7 @@ def main():
 
     if args.config == "dbof":
         B = args.batch or 512
-        r = run_dbof(device, rank, world, B, args.steps, args.warmup)
+        r = run_dbof(device, rank, world, B, args.steps, args.warmup, precision=args.precision)
         if rank == 0:
             res = {"metric": "frames/sec (whole node) DBoF(8192,1024)+MoE(2) training step B=512x300x1152 (BASELINE cfg 4)",
                    "value": r["frames_per_sec"], "unit": "frames/sec", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -549,7 +549,8 @@ def main():
         rh = run_dbof(device, rank, world, 512, 20, 10, precision="high")          # the mode that holds 1e-3 on its predictions (bf16: 2.3e-3)
         oc["cfg4_dbof_8192_1024_moe2_b512"]["high"] = {k: rh[k] for k in ("ms_per_step", "videos_per_sec", "frames_per_sec", "steps", "warmup", "loss")
                                                       if k in rh}
-        oc["cfg4_dbof_8192_1024_moe2_b512"]["high"]["what"] = ("split-bf16 operands (hi.hi + hi.lo + lo.hi) in the cluster, hidden and MoE products: "
+        oc["cfg4_dbof_8192_1024_moe2_b512"]["high"]["what"] = ("IEEE f16 operands with both operands' low-order corrections as OCP e4m3 stages behind them in the same launch "
+                                                               "(cluster, hidden and MoE products; EVC_HIGH_FP8_LO=0: three split-bf16 products per contraction): "
                                                                   "predictions 5.6e-6 from the float64 oracle at these dims (tests/test_gpu_dbof_logistic.py)")
         _log("dbof high done: %.2f ms/step" % rh["ms_per_step"])
         extra["other_configs"] = oc

@@ -85,6 +85,8 @@ SIGNATURES = {
     "evc_bn_finalize_ema": [vp, i32, i32, vp, vp, vp, vp, f32, vp],
     "evc_dbof_input_bn_apply": [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
     "evc_dbof_cluster_pool_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp],
+    "evc_dbof_input_bn_apply_f16fp8": [vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp],
+    "evc_dbof_cluster_pool_fwd_f16fp8": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp],
     "evc_dbof_pool_finish": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
     "evc_dbof_dact": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp],
     "evc_gemm_tn_slabs": [vp, i64, vp, i64, vp, i32, i32, i32, i32, vp],

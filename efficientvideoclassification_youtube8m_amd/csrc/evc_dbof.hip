@@ -240,6 +240,62 @@ extern "C" int evc_dbof_input_bn_apply(const float* r, int B, int S, int F, cons
   return EVC_OK;
 }
 
+// K3 for the "high" precision forward on f16 + e4m3 operands (evc_dbof_cluster_pool_fwd_f16fp8): rows of 4F bytes
+// [f16(y) (F halfwords) | e4m3(y 2^hi_exp) (F bytes) | e4m3((y - f16(y)) 2^lo_exp) (F bytes)], y = gamma*xhat+beta; xhat as in K3.
+__global__ __launch_bounds__(256) void dbof_input_bn_apply_f16fp8_kernel(const float* __restrict__ r, int Mp, int B, int S, int F,
+                                                                         const float* __restrict__ mean, const float* __restrict__ var,
+                                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                         bf16_t* __restrict__ rows, float hi_scale, float lo_scale,
+                                                                         bf16_t* __restrict__ xhat) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= Mp) return;
+  const int w = row & 127;
+  const int s = (w >> 4) * 4 + (w & 3), b = (row >> 7) * 4 + ((w >> 2) & 3);
+  const bool live = b < B && s < S;
+  const int F4 = F >> 2;
+  bf16_t* out = rows + (long)row * 2 * F;
+  for (int j = lane; j < F4; j += 64) {
+    uint2 o = make_uint2(0u, 0u), oh = make_uint2(0u, 0u);
+    int w8 = 0, v8 = 0;
+    if (live) {
+      const float4 v = ((const float4*)(r + (long)row * F))[j];
+      const float4 mu = ((const float4*)mean)[j], va = ((const float4*)var)[j], ga = ((const float4*)gamma)[j], be = ((const float4*)beta)[j];
+      const float h[4] = {(v.x - mu.x) * rsqrtf(va.x + 1e-3f), (v.y - mu.y) * rsqrtf(va.y + 1e-3f), (v.z - mu.z) * rsqrtf(va.z + 1e-3f),
+                          (v.w - mu.w) * rsqrtf(va.w + 1e-3f)};
+      const float y[4] = {h[0] * ga.x + be.x, h[1] * ga.y + be.y, h[2] * ga.z + be.z, h[3] * ga.w + be.w};
+      o = make_uint2(pack_f16x2_hw(y[0], y[1]), pack_f16x2_hw(y[2], y[3]));
+      oh = make_uint2(pack_bf16x2_hw(h[0], h[1]), pack_bf16x2_hw(h[2], h[3]));
+      const float yf[4] = {f16_to_f32((f16_t)(o.x & 0xffffu)), f16_to_f32((f16_t)(o.x >> 16)), f16_to_f32((f16_t)(o.y & 0xffffu)), f16_to_f32((f16_t)(o.y >> 16))};
+      float a[4], c[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        a[k] = fminf(fmaxf(y[k] * hi_scale, -448.f), 448.f);
+        c[k] = fminf(fmaxf((y[k] - yf[k]) * lo_scale, -448.f), 448.f);
+      }
+      w8 = __builtin_amdgcn_cvt_pk_fp8_f32(a[0], a[1], 0, false);
+      w8 = __builtin_amdgcn_cvt_pk_fp8_f32(a[2], a[3], w8, true);
+      v8 = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], 0, false);
+      v8 = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], v8, true);
+    }
+    ((uint2*)out)[j] = o;
+    ((int*)(out + F))[j] = w8;
+    ((int*)(out + F))[F4 + j] = v8;
+    if (xhat) ((uint2*)(xhat + (long)row * F))[j] = oh;
+  }
+}
+extern "C" int evc_dbof_input_bn_apply_f16fp8(const float* r, int B, int S, int F, const float* mean, const float* var, const float* gamma,
+                                              const float* beta, evc_f16* r_rows, int hi_exp, int lo_exp, evc_bf16* xhat, void* stream) {
+  EVC_REQUIRE(B > 0 && S > 0 && S <= SP && F > 0 && F % 32 == 0 && r && r_rows && ((uintptr_t)r_rows % 16) == 0, EVC_ERR_BAD_SHAPE,
+              "evc_dbof_input_bn_apply_f16fp8: bad args (F %% 32 == 0: 16-byte aligned row parts)");
+  EVC_REQUIRE(hi_exp >= -30 && hi_exp <= 30 && lo_exp >= 0 && lo_exp <= 60, EVC_ERR_BAD_ARG, "evc_dbof_input_bn_apply_f16fp8: hi_exp=%d lo_exp=%d", hi_exp, lo_exp);
+  const int Mp = dbof_padded_rows(B);
+  hipLaunchKernelGGL(dbof_input_bn_apply_f16fp8_kernel, dim3((Mp + 3) / 4), dim3(256), 0, (hipStream_t)stream, r, Mp, B, S, F, mean, var, gamma,
+                     beta, (bf16_t*)r_rows, ldexpf(1.0f, hi_exp), ldexpf(1.0f, lo_exp), xhat);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // K4: the cluster GEMM with the statistics / max-pool epilogue
 // ---------------------------------------------------------------------------------------------------------------
@@ -262,13 +318,15 @@ template <> struct is_v2<CfgDbof> { static constexpr bool value = true; };
 template <> struct is_v3<CfgDbof> { static constexpr bool value = true; };
 #endif
 
-template <class Cfg, bool INIT>
+template <class Cfg, bool INIT, int EXTRA = 0>
 __device__ __forceinline__ void dbof_mainloop(const GemmOperands& p, int m0, int u0, f32x4 (&acc)[Cfg::MI][1][Cfg::NI]) {
-  constexpr int MODE = LOOP_DMA_FIRST | LOOP_NO_PRIO;      // (producer waves: 1.80 -> 2.30 ms per step here; these two: 1.80 -> 1.79)
+  constexpr int MODE = LOOP_DMA_FIRST | LOOP_NO_PRIO | EXTRA;      // (producer waves: 1.80 -> 2.30 ms per step here; these two: 1.80 -> 1.79)
   if constexpr (is_v3<Cfg>::value) gemm_mainloop_v3<Cfg, true, INIT, MODE>(p, m0, u0, lds_dyn, acc);
   else gemm_mainloop_v2<Cfg, true, INIT, MODE>(p, m0, u0, lds_dyn, acc);
 }
 
+// FP8: IEEE f16 operands with both operands' low-order corrections as e4m3 stages behind them (LOOP_FP8_TAIL; the "high" precision forward)
+template <bool FP8>
 __global__ __launch_bounds__(CfgDbof::NT) void dbof_cluster_pool_kernel(GemmOperands p, DbofPoolParams e, int tiles_m, int tiles_n) {
   typedef CfgDbof Cfg;
   const int nwg = tiles_m * tiles_n;
@@ -277,8 +335,8 @@ __global__ __launch_bounds__(CfgDbof::NT) void dbof_cluster_pool_kernel(GemmOper
   tile_of(id, tiles_m, tiles_n, tm, tn, 8);
   const int m0 = tm * Cfg::BM, u0 = tn * Cfg::BU;
   f32x4 acc[Cfg::MI][1][Cfg::NI];
-  dbof_mainloop<Cfg, true>(p, m0, u0, acc);
-  if (p.A1lo) {                     // split-bf16 operands: + hi.lo + lo.hi (f32-operand accuracy, 3x the MFMA work)
+  dbof_mainloop<Cfg, true, FP8 ? (LOOP_F16 | LOOP_FP8_TAIL) : 0>(p, m0, u0, acc);
+  if (!FP8 && p.A1lo) {             // split-bf16 operands: + hi.lo + lo.hi (f32-operand accuracy, 3x the MFMA work)
     GemmOperands q = p;
     q.B = p.Blo;
     __syncthreads();
@@ -390,10 +448,39 @@ extern "C" int evc_dbof_cluster_pool_fwd(const evc_bf16* r_bn, const evc_bf16* r
   p.A1lo = r_bn_lo; p.A2lo = nullptr; p.Blo = wT_lo;
   DbofPoolParams e{act, (long)C, part, gamma, xsel, arg, B, S, C};
   const int tm = ceil_div(Mp, CfgDbof::BM), tn = ceil_div(C, CfgDbof::BU);
-  launch_cfg<CfgDbof>(dbof_cluster_pool_kernel, tm * tn, (hipStream_t)stream, p, e, tm, tn);
+  launch_cfg<CfgDbof>(dbof_cluster_pool_kernel<false>, tm * tn, (hipStream_t)stream, p, e, tm, tn);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }
+
+#ifndef EVC_DBOF_V2_LOOP
+// The cluster GEMM on f16 operands with both operands' low-order corrections as e4m3 operands behind the f16 stages of the same launch
+// (evc_gemm_nt_f16_fp8's arithmetic with this kernel's epilogue): r_rows from evc_dbof_input_bn_apply_f16fp8 (rows of 4F bytes), wT16 [C][F]
+// f16, wT8 [C][2F] = [e4m3((W - f16(W)) 2^w_lo_exp) | e4m3(W 2^w_hi_exp)] (evc_cast_f32_to_fp8_lo, hi_cols = F); scale_exp = -(x_hi_exp +
+// w_lo_exp) = -(x_lo_exp + w_hi_exp).  2 x the MFMA time of the bf16 product instead of the split-bf16 form's 3 x.  F % 128 == 0.
+extern "C" int evc_dbof_cluster_pool_fwd_f16fp8(const evc_f16* r_rows, const evc_f16* wT16, const uint8_t* wT8, int scale_exp,
+                                                int B, int S, int F, int C, const float* gamma, evc_bf16* act, float* part, float* xsel,
+                                                uint8_t* arg, void* stream) {
+  EVC_REQUIRE(B > 0 && S > 0 && S <= SP && F >= 256 && F % 128 == 0 && C > 0 && C % 64 == 0, EVC_ERR_BAD_SHAPE,
+              "evc_dbof_cluster_pool_fwd_f16fp8: needs iterations <= %d, F %% 128 == 0 (>= 256), clusters %% 64 == 0 (S=%d F=%d C=%d)", SP, S, F, C);
+  EVC_REQUIRE(r_rows && wT16 && wT8 && ((uintptr_t)r_rows % 16) == 0 && ((uintptr_t)wT16 % 16) == 0 && ((uintptr_t)wT8 % 16) == 0, EVC_ERR_BAD_ALIGN,
+              "evc_dbof_cluster_pool_fwd_f16fp8: 16-byte aligned operands");
+  EVC_REQUIRE(ring_operand_ok(((long)B + 3) / 4 * 4 * SP, 2L * F) && ring_operand_ok(C, F), EVC_ERR_BAD_SHAPE,
+              "evc_dbof_cluster_pool_fwd_f16fp8: the frame matrix or the cluster weights span 4 GiB or more (B=%d F=%d C=%d)", B, F, C);
+  const int Mp = dbof_padded_rows(B);
+  GemmOperands p;
+  p.A1 = (const bf16_t*)r_rows; p.lda1 = 2L * F; p.nk1 = F / 64; p.A2 = p.A1; p.lda2 = p.lda1; p.nk2 = 0;
+  p.B = (const bf16_t*)wT16; p.ldb = F; p.group_stride = 0; p.M = Mp; p.Nu = C;
+  p.A1lo = p.A2lo = p.Blo = nullptr;
+  p.A3 = (const uint8_t*)r_rows + 2L * F; p.lda3 = 4L * F; p.nk3 = 2 * F / 128; p.A4 = p.A3; p.lda4 = p.lda3; p.nk4 = 0;
+  p.B8 = wT8; p.ldb8 = 2L * F; p.scale8_exp = scale_exp;
+  DbofPoolParams e{act, (long)C, part, gamma, xsel, arg, B, S, C};
+  const int tm = ceil_div(Mp, CfgDbof::BM), tn = ceil_div(C, CfgDbof::BU);
+  launch_cfg<CfgDbof>(dbof_cluster_pool_kernel<true>, tm * tn, (hipStream_t)stream, p, e, tm, tn);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // K6: pooled = relu6(gamma * (x_sel - mean) * rsqrt(var + eps) + beta)   [B][C]

@@ -41,6 +41,7 @@ static inline double tile_cost(long tiles, int bm, int bn, int /*occ*/, double c
 struct StoreParams {
   void* C; long ldc; int M, N; const float* bias; int out_bf16; int accumulate;
   int splits, ksteps_per_split;   // split-K: blockIdx = split * tiles + tile; partial sums joined by f32 atomics
+  int ksteps8_per_split = 0;      // (FP8 kernels: e4m3 stages per split - a split takes the same share of both stage ranges)
 };
 
 // Epilogue of the ring-tile (v2) kernels for a plain overwrite of C: every wave transposes its WM x WU sub-tile through
@@ -131,6 +132,12 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_nt_kernel(GemmOperands p, StoreP
     p.A1 += (long)k0 * kstep;
     p.B += (long)k0 * kstep;
     p.nk1 = min(s.ksteps_per_split, p.nk1 - k0);
+    if constexpr (FP8) {
+      const int k8 = split * s.ksteps8_per_split;
+      p.A3 += (long)k8 * 128;
+      p.B8 += (long)k8 * 128;
+      p.nk3 = min(s.ksteps8_per_split, p.nk3 - k8);
+    }
   }
   const int id = xcd_remap(bid, nwg);
   int tm, tn;
@@ -431,11 +438,11 @@ extern "C" int evc_gemm_nt_split(const evc_bf16* A_lohi, int64_t lda, const evc_
 // logits of magnitude 8 (f16 alone: 8e-4; scripts/precision_budget.py "MOE fine") for 2/3 of the operand bytes of the split-bf16
 // K-extension (evc_gemm_nt_split).  lda / ldb in halfwords, lda8 / ldb8 in bytes.
 template <class Cfg>
-static inline void launch_gemm_f16_fp8(GemmOperands p, StoreParams s, int K16, int K8, hipStream_t st) {
+static inline void launch_gemm_f16_fp8(GemmOperands p, StoreParams s, int K16, int K8, int splits, hipStream_t st) {
   p.nk1 = K16 / 64; p.nk2 = 0; p.nk3 = K8 / 128; p.nk4 = 0;
   const int tm = ceil_div(s.M, Cfg::BM), tn = ceil_div(s.N, Cfg::BU);
-  s.splits = 1; s.ksteps_per_split = p.nk1;
-  launch_cfg<Cfg>(gemm_nt_kernel<Cfg, true, true>, tm * tn, st, p, s, tm, tn);
+  s.splits = splits; s.ksteps_per_split = p.nk1 / splits; s.ksteps8_per_split = p.nk3 / splits;     // (splits divides both: chosen so below)
+  launch_cfg<Cfg>(gemm_nt_kernel<Cfg, true, true>, tm * tn * splits, st, p, s, tm, tn);
 }
 
 extern "C" int evc_gemm_nt_f16_fp8(const evc_f16* A16, int64_t lda, const uint8_t* A8, int64_t lda8, const evc_f16* B16, int64_t ldb,
@@ -457,8 +464,19 @@ extern "C" int evc_gemm_nt_f16_fp8(const evc_f16* A16, int64_t lda, const uint8_
   p.A3 = A8; p.lda3 = lda8; p.A4 = A8; p.lda4 = lda8; p.B8 = B8; p.ldb8 = ldb8; p.scale8_exp = scale_exp;
   StoreParams s{C, ldc, M, N, bias, 0, 0, 1, 0};
   hipStream_t st = (hipStream_t)stream;
-  if (M <= 256) launch_gemm_f16_fp8<TileCfg3<256, 1, 64, 2, 4, 4>>(p, s, K16, K8, st);     // batch-row products: stream the weights once
-  else launch_gemm_f16_fp8<TileCfg3<256, 1, 256, 2, 4, 2>>(p, s, K16, K8, st);
+  if (M <= 512) {      // batch-row products (MoE head, DBoF hidden layer): 256 x 64 tiles stream the weights once; few column tiles and a long K
+                       // (512 x 1024 x 8192: 32 tiles) are cut along K until ~256 workgroups exist - every split takes the same share of the f16
+                       // and of the e4m3 stages (>= 4 of each: a full ring), the partial tiles are joined by f32 atomics into a zeroed C
+    const int tiles = ceil_div(M, 256) * ceil_div(N, 64), nk16 = K16 / 64, nk8 = K8 / 128;
+    int splits = 1;
+    while (splits < 16 && tiles * splits * 2 <= 256 && nk16 % (splits * 2) == 0 && nk8 % (splits * 2) == 0 && nk16 / (splits * 2) >= 4 &&
+           nk8 / (splits * 2) >= 4)
+      splits *= 2;
+    if (splits > 1) EVC_CHECK_HIP(hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st));
+    launch_gemm_f16_fp8<TileCfg3<256, 1, 64, 2, 4, 4>>(p, s, K16, K8, splits, st);
+  } else {
+    launch_gemm_f16_fp8<TileCfg3<256, 1, 256, 2, 4, 2>>(p, s, K16, K8, 1, st);
+  }
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }

@@ -547,6 +547,25 @@ def dbof_cluster_pool_fwd(r_bn, wT, B, S, F, Cc, gamma, xsel, arg, act=None, par
               _p(xsel), _p(arg), _stream())
 
 
+FP8_DBOF_CLUSTER = dict(x_hi_exp=5, x_lo_exp=16, w_lo_exp=19, w_hi_exp=8)   # batch-normalised frames |y| < 14, cluster weights |W| < 1.75: 5 + 19 = 16 + 8 = 24
+
+
+def dbof_input_bn_apply_f16fp8(r, B, S, F, mean, var, gamma, beta, r_rows, xhat=None, e=FP8_DBOF_CLUSTER):
+    """dbof_input_bn_apply writing rows [f16(y) | e4m3(y 2^x_hi_exp) | e4m3((y - f16(y)) 2^x_lo_exp)] (r_rows [Mp][2F] f16 containers)."""
+    assert r_rows.dtype == F16 and r_rows.shape[1] == 2 * F and r_rows.is_contiguous()
+    _lib.call("evc_dbof_input_bn_apply_f16fp8", _p(r), B, S, F, _p(mean), _p(var), _p(gamma), _p(beta), _p(r_rows), e["x_hi_exp"], e["x_lo_exp"],
+              _p(xhat), _stream())
+
+
+def dbof_cluster_pool_fwd_f16fp8(r_rows, wT16, wT8, B, S, F, Cc, gamma, xsel, arg, act=None, part=None, e=FP8_DBOF_CLUSTER):
+    """dbof_cluster_pool_fwd on f16 + e4m3 operands (evc_dbof_cluster_pool_fwd_f16fp8): wT16 [C][F] f16, wT8 [C][2F] uint8 from
+    cast_fp8_lo(W, hi_cols=F, scale_exp=w_lo_exp, hi_exp=w_hi_exp)."""
+    assert r_rows.dtype == F16 and wT16.dtype == F16 and wT16.shape == (Cc, F) and wT8.dtype == torch.uint8 and wT8.shape == (Cc, 2 * F)
+    assert e["x_hi_exp"] + e["w_lo_exp"] == e["x_lo_exp"] + e["w_hi_exp"]
+    _lib.call("evc_dbof_cluster_pool_fwd_f16fp8", _p(r_rows), _p(wT16), _p(wT8), -(e["x_hi_exp"] + e["w_lo_exp"]), B, S, F, Cc, _p(gamma),
+              _p(act), _p(part), _p(xsel), _p(arg), _stream())
+
+
 def dbof_pool_finish(xsel, B, Cc, mean, var, gamma, beta, pooled_f32, pooled_bf16=None, pooled_lo=None):
     _lib.call("evc_dbof_pool_finish", _p(xsel), B, Cc, _p(mean), _p(var), _p(gamma), _p(beta), _p(pooled_f32), _p(pooled_bf16),
               _p(pooled_lo), _stream())

@@ -172,6 +172,30 @@ class DbofTower(TowerBase):
             self.slabs = torch.empty((self.nslab, Cc, F), dtype=F32, device=dev)
             self.wgrad_ws = torch.empty(((Cc + 7) // 8, F), dtype=F32, device=dev)
 
+    # "high" precision on f16 + e4m3 operands (both operands' roundings corrected behind the f16 stages of the same launches: ops.gemm_nt_f16_fp8,
+    # ops.dbof_cluster_pool_fwd_f16fp8) when every contraction length is a multiple of 128; EVC_HIGH_FP8_LO=0 or other sizes: the
+    # separate hi / lo shadows and three split-bf16 products per contraction (also what precision "split" means here).
+    def _alloc_high_shadows(self):
+        import os
+        dims_ok = self.F % 128 == 0 and self.F >= 256 and self.Cc % 128 == 0 and self.Cc >= 512 and self.Hd % 128 == 0 and self.Hd >= 512
+        if self.precision == "high" and dims_ok and os.environ.get("EVC_HIGH_FP8_LO", "1") != "0":
+            self.shadow_lo, self.shadow_w16, self.shadow_w8 = {}, {}, {}
+            for k in (self.CW, self.HW, MoeHead.GATES, MoeHead.EXPERTS):
+                shp = self.store.shapes[k]
+                self.shadow_w16[k] = torch.zeros(shp, dtype=ops.F16, device=self.device)
+                self.shadow_w8[k] = torch.zeros((shp[0], 2 * shp[1]), dtype=torch.uint8, device=self.device)
+        else:
+            super()._alloc_high_shadows()
+
+    def _refresh_high(self, k):
+        if k in getattr(self, "shadow_w8", {}):
+            e = ops.FP8_DBOF_CLUSTER if k == self.CW else ops.FP8_MOE
+            p = self.store.p(k)
+            ops.cast_f16(p, self.shadow_w16[k])
+            ops.cast_fp8_lo(p, self.shadow_w8[k], hi_cols=p.shape[1], scale_exp=e["w_lo_exp"], hi_exp=e["w_hi_exp"])
+        else:
+            super()._refresh_high(k)
+
     @staticmethod
     def _pick_nslab(M, N, K):
         """Split-K factor of the cluster-weight gradient G [M][N] = dact^T . xhat over K rows: its 256x256 tiles rarely
@@ -213,17 +237,29 @@ class DbofTower(TowerBase):
             self._bn_train_stats(self.bn_in, self.part_in, self.P_in, F)
         else:
             self.bn_in.stats(None, self.R, False)
-        if high and (not hasattr(self, "r_bn_lo") or self.r_bn_lo.shape != self.r_bn.shape):
+        fp8 = high and self.CW in getattr(self, "shadow_w8", {})      # "high" on f16 + e4m3 operands (else: three split-bf16 products)
+        if fp8 and (not hasattr(self, "r_rows") or self.r_rows.shape[0] != self.r_bn.shape[0]):
+            self.r_rows = torch.empty((self.Mp, 2 * F), dtype=ops.F16, device=self.r_bn.device)
+            self.pooled_rows = torch.empty((B, 2 * Cc), dtype=ops.F16, device=self.r_bn.device)
+        if high and not fp8 and (not hasattr(self, "r_bn_lo") or self.r_bn_lo.shape != self.r_bn.shape):
             self.r_bn_lo = torch.empty_like(self.r_bn)
             self.pooled_lo = torch.zeros_like(self.pooled_bf)
-        ops.dbof_input_bn_apply(self.r, B, S, F, self.bn_in.mean, self.bn_in.var, self.bn_in.gamma(), self.bn_in.beta(), self.r_bn,
-                                self.r_bn_lo if high else None, self.xhat if tape else None)
+        if fp8:
+            ops.dbof_input_bn_apply_f16fp8(self.r, B, S, F, self.bn_in.mean, self.bn_in.var, self.bn_in.gamma(), self.bn_in.beta(), self.r_rows,
+                                           self.xhat if tape else None)
+        else:
+            ops.dbof_input_bn_apply(self.r, B, S, F, self.bn_in.mean, self.bn_in.var, self.bn_in.gamma(), self.bn_in.beta(), self.r_bn,
+                                    self.r_bn_lo if high else None, self.xhat if tape else None)
         if self.timing is not None:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        ops.dbof_cluster_pool_fwd(self.r_bn, self.shadow_fwd[self.CW], B, S, F, Cc, self.bn_cl.gamma(), self.xsel, self.arg,
-                                  act=self.act if tape else None, part=self.part_cl if is_training else None,
-                                  r_bn_lo=self.r_bn_lo if high else None, wT_lo=self.shadow_lo[self.CW] if high else None)
+        if fp8:
+            ops.dbof_cluster_pool_fwd_f16fp8(self.r_rows, self.shadow_w16[self.CW], self.shadow_w8[self.CW], B, S, F, Cc, self.bn_cl.gamma(),
+                                             self.xsel, self.arg, act=self.act if tape else None, part=self.part_cl if is_training else None)
+        else:
+            ops.dbof_cluster_pool_fwd(self.r_bn, self.shadow_fwd[self.CW], B, S, F, Cc, self.bn_cl.gamma(), self.xsel, self.arg,
+                                      act=self.act if tape else None, part=self.part_cl if is_training else None,
+                                      r_bn_lo=self.r_bn_lo if high else None, wT_lo=self.shadow_lo[self.CW] if high else None)
         if self.timing is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
@@ -233,8 +269,11 @@ class DbofTower(TowerBase):
         else:
             self.bn_cl.stats(None, self.R, False)
         ops.dbof_pool_finish(self.xsel, B, Cc, self.bn_cl.mean, self.bn_cl.var, self.bn_cl.gamma(), self.bn_cl.beta(), self.pooled,
-                             self.pooled_bf, self.pooled_lo if high else None)
-        if high:
+                             self.pooled_bf, self.pooled_lo if (high and not fp8) else None)
+        if fp8:          # pooled in [0, 6] (relu6): the MoE head's scales fit (6 * 2^6 = 384 < 448)
+            ops.cast_f16_fp8x(self.pooled, self.pooled_rows)
+            ops.gemm_nt_f16_fp8(self.pooled_rows, self.shadow_w16[self.HW], self.shadow_w8[self.HW], B, Hd, Cc, self.hid)
+        elif high:
             ops.gemm_nt_split(self.pooled_bf, self.pooled_lo, self.shadow_fwd[self.HW], self.shadow_lo[self.HW], B, Hd, Cc, self.hid)
         else:
             ops.gemm_nt(self.pooled_bf, self.shadow_fwd[self.HW], B, Hd, Cc, self.hid)

@@ -502,6 +502,17 @@ int evc_dbof_input_bn_apply(const float* r, int B, int S, int F, const float* me
 int evc_dbof_cluster_pool_fwd(const evc_bf16* r_bn, const evc_bf16* r_bn_lo, const evc_bf16* wT, const evc_bf16* wT_lo,
                               int B, int S, int F, int C, const float* gamma, evc_bf16* act, float* part, float* xsel,
                               uint8_t* arg, void* stream);
+/* The "high" precision forward of the two entries above on f16 + e4m3 operands (both operands' roundings corrected as e4m3 stages behind the f16
+ * stages of the same launch: evc_gemm_nt_f16_fp8's arithmetic, 2x the MFMA time of the bf16 product instead of the split-bf16 form's 3x):
+ * evc_dbof_input_bn_apply_f16fp8 writes r_rows [Mp] rows of 4F bytes = [f16(y) | e4m3(y 2^hi_exp) | e4m3((y - f16(y)) 2^lo_exp)], y = the
+ * batch-normalised frame (and xhat as above); evc_dbof_cluster_pool_fwd_f16fp8 contracts them against wT16 [C][F] = f16(W) and wT8 [C][2F] =
+ * [e4m3((W - f16(W)) 2^w_lo_exp) | e4m3(W 2^w_hi_exp)] (evc_cast_f32_to_fp8_lo with hi_cols = F), scale_exp = -(hi_exp + w_lo_exp) =
+ * -(lo_exp + w_hi_exp); epilogue and outputs as evc_dbof_cluster_pool_fwd.  F % 128 == 0 (cs/frame_level_models.py:149-160). */
+int evc_dbof_input_bn_apply_f16fp8(const float* r, int B, int S, int F, const float* mean, const float* var, const float* gamma,
+                                   const float* beta, evc_f16* r_rows, int hi_exp, int lo_exp, evc_bf16* xhat, void* stream);
+int evc_dbof_cluster_pool_fwd_f16fp8(const evc_f16* r_rows, const evc_f16* wT16, const uint8_t* wT8, int scale_exp,
+                                     int B, int S, int F, int C, const float* gamma, evc_bf16* act, float* part, float* xsel,
+                                     uint8_t* arg, void* stream);
 /* pooled = relu6(gamma*(xsel-mean)*rsqrt(var+1e-3)+beta): f32, bf16 (optional), bf16 low half (optional). */
 int evc_dbof_pool_finish(const float* xsel, int B, int C, const float* mean, const float* var, const float* gamma,
                          const float* beta, float* pooled_f32, evc_bf16* pooled_bf16, evc_bf16* pooled_lo, void* stream);

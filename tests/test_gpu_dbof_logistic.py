@@ -28,8 +28,8 @@ def _rel(a, b):
 def test_dbof_forward_backward(B, F, C, Hd, V, S, tol):
     """DBoF feeds O(1) batch-normalised activations and O(1/sqrt(K)) weights to the bf16 GEMMs, so the 2^-9 operand rounding
     shows up at ~2e-3 in the probabilities (measured 2.3e-3 at the BASELINE cfg-4 dims) - above north_star's 1e-3; the
-    "high" (split-bf16) forward checked at the end of this test closes that gap (5.6e-6 at cfg-4 dims) and is what bench.py
-    times as other_configs.cfg4.high.  `tol` pins the bf16 behaviour.
+    "high" forward checked at the end of this test closes that gap (split-bf16: 5.6e-6 at cfg-4 dims; f16 + e4m3 corrections of both
+    operands, the default at cfg-4 dims: ~1e-5) and is what bench.py times as other_configs.cfg4.high.  `tol` pins the bf16 behaviour.
 
     Gradients: relu6 kinks and max-pool ties are DECISIONS taken on values that carry the forward's bf16 rounding; one flipped
     decision moves a whole dy.  So (1) the tower's decisions (argmax frame per (video, cluster), relu6 masks of both layers) are
@@ -100,8 +100,10 @@ def test_dbof_forward_backward(B, F, C, Hd, V, S, tol):
     assert np.allclose(_np(tw.buffers["input_bn/moving_mean"]), 0.001 * mu, rtol=1e-3, atol=1e-7)
     var = cache[5][4]
     assert np.allclose(_np(tw.buffers["cluster_bn/moving_variance"]), 1 - 0.001 * (1 - var), rtol=1e-3, atol=1e-6)
-    # "high" precision forward (split-bf16 operands): the north-star 1e-3 holds with O(1) activations
+    # "high" precision forward: the north-star 1e-3 holds with O(1) activations - split-bf16 operands (three products per contraction) at
+    # the small sizes, f16 + e4m3 corrections of both operands in one launch per contraction where every K is a multiple of 128 (cfg 4)
     tw.set_precision("high")
+    assert (tw.CW in getattr(tw, "shadow_w8", {})) == (F % 128 == 0 and F >= 256 and C >= 512 and Hd >= 512)
     pred_h = tw.forward(torch.from_numpy(x).to(DEV), torch.from_numpy(n).to(DEV), torch.from_numpy(u).to(DEV))
     err_h = np.abs(_np(pred_h) - ref_pred).max()
     print('dbof pred err (high precision) %.2e' % err_h)

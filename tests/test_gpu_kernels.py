@@ -472,7 +472,7 @@ def test_lstm_stack2_fwd_f16_fp8_low_order_weights(ops, M, T, Kin, H, nseg):
     assert err < 8e-4 and err <= err_ext * 1.3 + 2e-5, (err, err_ext)
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 1416, 512), (64, 4716 * 3, 4096), (200, 700, 1024), (600, 520, 512)])
+@pytest.mark.parametrize("M,N,K", [(256, 1416, 512), (64, 4716 * 3, 4096), (200, 700, 1024), (600, 520, 512), (512, 1024, 8192)])
 def test_gemm_nt_f16_fp8_product_with_low_order_corrections(ops, M, N, K):
     """evc_gemm_nt_f16_fp8 = f16(x) . f16(W)^T + 2^-24 [e4m3(x 2^6) | e4m3(x_lo 2^17)] . [e4m3(W_lo 2^18) | e4m3(W 2^7)]^T + bias in one launch (the
     "high" precision MoE head), operands from evc_cast_f32_to_f16_fp8x / evc_cast_f32_to_f16 / evc_cast_f32_to_fp8_lo(hi_cols = K): against the
