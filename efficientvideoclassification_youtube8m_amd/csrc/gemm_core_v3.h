@@ -274,110 +274,6 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
     for (; j + 1 < nkf; ++j) trip16(std::true_type{});
     trip16(std::false_type{});
     ++j;
-#ifdef EVC_FP8_GROUPS4
-    // Row fragments in four groups of 1-2 (sizes differ by at most one, larger first), two register sets: group q+1 is read while
-    // group q multiplies; all B fragments of the stage stay in registers.  The barrier sits in front of the LAST group (its reads
-    // were the stage's last): behind it the refill, the next stage's group 0 and - column group by column group, as its last MFMA
-    // has been issued - the next stage's B fragments.
-    constexpr int QB = Cfg::MI / 4, QR = Cfg::MI % 4;
-    static_assert(QB >= 1 && QB + (QR ? 1 : 0) <= 2, "e4m3 trips: 4..8 row fragments per wave");
-    constexpr int QS0 = QB + (QR > 0), QS1 = QB + (QR > 1), QS2 = QB + (QR > 2), QS3 = QB;
-    constexpr int QO1 = QS0, QO2 = QS0 + QS1, QO3 = QS0 + QS1 + QS2;
-    v8i_t aE[2], aO[2], b8[Cfg::G][Cfg::NI];                    // even / odd groups
-    const int sc_first = 127 + p.scale8_exp, sc_second = 127;   // e8m0 scale bytes: the whole factor rides on the first operand
-    auto rd8 = [&](const int base0, const int base1, const int off) -> v8i_t {   // both 16-byte chunks of this lane's row in ring slot slot_read
-      const char* sb = lds + slot_read * Cfg::STAGE_BYTES;
-      const v4i_t lo = *(const v4i_t*)(sb + base0 + off), hi = *(const v4i_t*)(sb + base1 + off);
-      return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    };
-    auto mfma8 = [&](const v8i_t& a, const v8i_t& b, f32x4& c) {
-      c = SWAP ? __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b, a, c, 0, 0, 0, sc_first, 0, sc_second)
-               : __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, sc_first, 0, sc_second);
-    };
-    auto rd_group = [&](auto off_tag, auto n_tag, v8i_t (&dst)[2]) {
-      constexpr int o = decltype(off_tag)::value, n = decltype(n_tag)::value;
-#pragma unroll
-      for (int i = 0; i < n; ++i) dst[i] = rd8(a_rd0, a_rd1, a_off(o + i));
-    };
-    auto mul_group = [&](auto off_tag, auto n_tag, const v8i_t (&src)[2], auto reload_tag) {   // column group by column group
-      constexpr int o = decltype(off_tag)::value, n = decltype(n_tag)::value;
-      constexpr bool reload = decltype(reload_tag)::value;
-#pragma unroll
-      for (int g = 0; g < Cfg::G; ++g)
-#pragma unroll
-        for (int ni = 0; ni < Cfg::NI; ++ni) {
-#pragma unroll
-          for (int i = 0; i < n; ++i) mfma8(src[i], b8[g][ni], acc[o + i][g][ni]);
-          if constexpr (reload) b8[g][ni] = rd8(b_rd0, b_rd1, b_off(g, ni));
-        }
-    };
-    auto pattern = [&](auto nmfma_tag, auto nread_tag, auto ndma_tag) {   // LDS-DMAs and fragment reads spread behind the MFMAs
-      constexpr int nm = decltype(nmfma_tag)::value, nr = decltype(nread_tag)::value, nd = decltype(ndma_tag)::value;
-      constexpr int rper = (nr + nm - 1) / nm, dper = (nd + nm - 1) / nm;
-#pragma unroll
-      for (int i = 0; i < nm; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if constexpr (dper > 0) __builtin_amdgcn_sched_group_barrier(0x020, dper, 0);
-        if constexpr (rper > 0) __builtin_amdgcn_sched_group_barrier(0x100, rper, 0);
-      }
-    };
-    using I0 = std::integral_constant<int, 0>;
-    constexpr int GN = Cfg::G * Cfg::NI;
-    // the first e4m3 stage's group 0 and B fragments (once per launch: nothing to hide these reads behind)
-    rd_group(I0{}, std::integral_constant<int, QS0>{}, aE);
-#pragma unroll
-    for (int g = 0; g < Cfg::G; ++g)
-#pragma unroll
-      for (int ni = 0; ni < Cfg::NI; ++ni) b8[g][ni] = rd8(b_rd0, b_rd1, b_off(g, ni));
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    auto first_groups = [&]() {           // groups 0..2 multiply while groups 1..3 are read
-      rd_group(std::integral_constant<int, QO1>{}, std::integral_constant<int, QS1>{}, aO);
-      mul_group(I0{}, std::integral_constant<int, QS0>{}, aE, std::false_type{});
-#ifndef EVC_NO_INTERLEAVE
-      pattern(std::integral_constant<int, QS0 * GN>{}, std::integral_constant<int, 2 * QS1>{}, I0{});
-#endif
-      end_of_step();
-      rd_group(std::integral_constant<int, QO2>{}, std::integral_constant<int, QS2>{}, aE);
-      mul_group(std::integral_constant<int, QO1>{}, std::integral_constant<int, QS1>{}, aO, std::false_type{});
-#ifndef EVC_NO_INTERLEAVE
-      pattern(std::integral_constant<int, QS1 * GN>{}, std::integral_constant<int, 2 * QS2>{}, I0{});
-#endif
-      end_of_step();
-      rd_group(std::integral_constant<int, QO3>{}, std::integral_constant<int, QS3>{}, aO);
-      mul_group(std::integral_constant<int, QO2>{}, std::integral_constant<int, QS2>{}, aE, std::false_type{});
-#ifndef EVC_NO_INTERLEAVE
-      pattern(std::integral_constant<int, QS2 * GN>{}, std::integral_constant<int, 2 * QS3>{}, I0{});
-#endif
-      end_of_step();                      // every fragment of this stage is in registers
-    };
-    for (; j + Cfg::STAGES < nk; ++j) {   // steady state
-      first_groups();
-      if constexpr (PROD) wait_vmcnt<AHEAD * PER>();
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      stage_role();
-      next_slot();
-      rd_group(I0{}, std::integral_constant<int, QS0>{}, aE);
-      mul_group(std::integral_constant<int, QO3>{}, std::integral_constant<int, QS3>{}, aO, std::true_type{});
-#ifndef EVC_NO_INTERLEAVE
-      pattern(std::integral_constant<int, QS3 * GN>{}, std::integral_constant<int, 2 * (QS0 + GN)>{}, std::integral_constant<int, PERX>{});
-#endif
-      end_of_step();
-    }
-    for (; j + 1 < nk; ++j) {             // last STAGES stages: no refills
-      first_groups();
-      if constexpr (PROD) wait_landed(nk - (j + 2));
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      next_slot();
-      rd_group(I0{}, std::integral_constant<int, QS0>{}, aE);
-      mul_group(std::integral_constant<int, QO3>{}, std::integral_constant<int, QS3>{}, aO, std::true_type{});
-      end_of_step();
-    }
-    first_groups();
-    mul_group(std::integral_constant<int, QO3>{}, std::integral_constant<int, QS3>{}, aO, std::false_type{});
-    end_of_step();
-#else
     // Two halves per trip, split by the tile's ROW fragments (the 16-bit trips split the stage's K range): half 1 multiplies the lower
     // row fragments while the upper ones are read; behind the barrier and the refill, half 2 multiplies the upper ones while the next
     // stage's lower row fragments and - column group by column group, as its last MFMA has been issued - its B fragments are read.
@@ -481,7 +377,6 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
     half1();
     upper(std::false_type{});
     end_of_step();
-#endif
   }
   };   // run
   if constexpr (PRODUCERS) {
