@@ -5,7 +5,7 @@ only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
 ``cpu_baseline`` leg may import it, and there only as the checker / the timed
 CPU baseline - never as a fallback for the HIP path.
 
-Parity status: **parity unpinned at the TensorFlow boundary.**  The reference
+Parity status: **parity unpinned at the TensorFlow boundary.**  (`lowprec.py`: the operand formats of the "high" precision forward - IEEE f16, OCP e4m3 - pinned on torch.float16 / torch.float8_e4m3fn, tests/test_oracle_lowprec.py.)  The reference
 (`/root/reference/code_student_uniform/*.py`) is Python-2.7 + TensorFlow-1.3
 graph wiring; its arithmetic lives in TensorFlow, which is not vendored, not
 installed and not installable here, and the reference ships no tests or golden

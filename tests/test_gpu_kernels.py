@@ -504,8 +504,15 @@ def test_gemm_nt_f16_fp8_product_with_low_order_corrections(ops, M, N, K):
     err = np.max(np.abs(got - ref))
     plain = xd.half().double().cpu().numpy() @ wd.half().double().cpu().numpy().T + bias
     err16 = np.max(np.abs(plain - ref))
-    print("gemm_nt_f16_fp8 %dx%dx%d: max err %.2e (plain f16 product %.2e), |z| max %.1f" % (M, N, K, err, err16, np.abs(ref).max()))
+    # the numpy restatement of the same operand roundings (oracle/lowprec.py, float64 accumulation): the kernel differs from it only by
+    # its f32 accumulation
+    from oracle import lowprec as lp
+    emu = lp.corrected_product(x, w, e["x_hi_exp"], e["x_lo_exp"], e["w_lo_exp"], e["w_hi_exp"]) + bias
+    d_emu = np.max(np.abs(got - emu))
+    print("gemm_nt_f16_fp8 %dx%dx%d: max err %.2e (plain f16 product %.2e; vs the numpy restatement %.2e), |z| max %.1f" % (
+        M, N, K, err, err16, d_emu, np.abs(ref).max()))
     assert err < 1e-4 * max(1.0, np.abs(ref).max()) and err * 10 < err16, (err, err16)
+    assert d_emu < 2e-5 * max(1.0, np.abs(ref).max()), d_emu
 
 
 @pytest.mark.parametrize("M,T,Kin,H,tile", [(512, 4, 384, 384, 0), (1100, 3, 1152, 512, 0), (700, 5, 384, 384, 6), (390, 3, 512, 384, 7), (330, 3, 384, 384, 8)])
