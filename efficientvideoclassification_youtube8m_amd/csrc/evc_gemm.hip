@@ -2147,7 +2147,8 @@ template <int KW, int STAGES>
 __global__ __launch_bounds__(64 * KW) void lstm_bwd_step_skinny_lds_kernel(GemmOperands p, LstmBwdParams e, int tiles_m, int tiles_n) {
   constexpr int NT = 64 * KW;
   constexpr int STAGE = 8192, RING = STAGES * STAGE;                  // A 32 rows x 128 B | B 32 rows x 128 B
-  float (*part)[32][36] = (float (*)[32][36])(lds_dyn + KW * RING);   // [wave][row][unit] (+4 pad)
+  float (*part)[32][36] = (float (*)[32][36])lds_dyn;                 // [wave][row][unit] (+4 pad): ALIASES the rings (18 KB of KW x RING >= 64 KB),
+                                                                      // written behind a barrier once every wave has left its loop
   const int nwg = tiles_m * tiles_n;
   const int id = xcd_remap(blockIdx.x, nwg);
   const int tm = id % tiles_m, tn = id / tiles_m;
@@ -2220,6 +2221,7 @@ __global__ __launch_bounds__(64 * KW) void lstm_bwd_step_skinny_lds_kernel(GemmO
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
   }
+  __syncthreads();               // every wave's last fragment reads have returned: the rings are free
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -2361,10 +2363,21 @@ extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int 
           p.nk1 = k1 / 32;
           hipLaunchKernelGGL((lstm_bwd_step_skinny_kernel<8, 4>), dim3(tm * tn), dim3(512), 0, st, p, e, tm, tn);
         } else {
-          constexpr int KW = 4, STG = 4, LDSB = KW * STG * 8192 + KW * 32 * 36 * 4;
+          // ring depth per wave / waves per workgroup (LDS = waves x depth x 8 KiB; the partial tiles alias the rings).  Two stages = 64 KiB:
+          // ALONE the step is a little slower than with four (one stage in flight per wave instead of three), but in the training step
+          // these launches run next to the other towers' / the optimizer's workgroups, and a 64 KiB workgroup finds room on a CU that a
+          // 146 KiB one has to wait for: 10.37 -> 10.15-10.23 ms per step (same box, alternating runs; three stages: no change)
+          static const int stg = getenv("EVC_SKINNY_STAGES") ? atoi(getenv("EVC_SKINNY_STAGES")) : 2;
           p.nk1 = k1 / 64;
-          allow_big_lds((const void*)lstm_bwd_step_skinny_lds_kernel<KW, STG>, LDSB);
-          hipLaunchKernelGGL((lstm_bwd_step_skinny_lds_kernel<KW, STG>), dim3(tm * tn), dim3(64 * KW), LDSB, st, p, e, tm, tn);
+#define EVC_SKINNY_LAUNCH(KW_, STG_)                                                                                              \
+  do {                                                                                                                          \
+    allow_big_lds((const void*)lstm_bwd_step_skinny_lds_kernel<KW_, STG_>, KW_ * STG_ * 8192);                                  \
+    hipLaunchKernelGGL((lstm_bwd_step_skinny_lds_kernel<KW_, STG_>), dim3(tm * tn), dim3(64 * KW_), KW_ * STG_ * 8192, st, p, e, tm, tn); \
+  } while (0)
+          if (stg == 3) EVC_SKINNY_LAUNCH(4, 3);           // (four waves: the tail's thread -> (row, unit) map is written for 256 threads)
+          else if (stg == 4) EVC_SKINNY_LAUNCH(4, 4);
+          else EVC_SKINNY_LAUNCH(4, 2);
+#undef EVC_SKINNY_LAUNCH
         }
         break;
       }
