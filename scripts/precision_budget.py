@@ -1,4 +1,5 @@
-"""Error budget of the forward pass per contraction (CPU experiment, no GPU needed).
+"""Error budget of the forward pass per contraction (CPU experiment, no GPU needed).  ANALYSIS TOOL, not part of the product path: like the
+tests it drives the oracle (oracle/model_math.py, oracle/torch_cpu.py) as the float64 reference.
 
 Which products of the H-LSTM forward need split operands to hold north_star's 1e-3 on logits / states / predictions
 at trained-magnitude weights?  Emulates the MFMA operand types on the CPU: both operands of a product are rounded to
