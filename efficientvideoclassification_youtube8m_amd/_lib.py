@@ -44,6 +44,9 @@ SIGNATURES = {
     "evc_lstm_stack2_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp],
     "evc_moe_grad_update": [vp, i64, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, i64, f32, vp, vp, f32, f32, f32, f32, f32, vp],
     "evc_moe_grad_update_wide": [vp, i64, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, f32, vp, vp, f32, f32, f32, f32, f32, vp],
+    "evc_gram_slabs": [vp, i64, i32, i32, i32, vp, vp],
+    "evc_moe_grad_norms": [vp, i32, vp, i32, i32, vp, i64, vp, i64, vp, i32, i32, f32, vp, vp, vp, vp],
+    "evc_moe_grad_update_apply": [vp, i64, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, f32, vp, vp, f32, f32, f32, f32, f32, vp, vp],
     "evc_gemm_nt_f16_fp8": [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp, vp],
     "evc_cast_f32_to_f16_fp8x": [vp, i64, i32, i32, i32, i32, vp, vp],
     "evc_moe_grad_update_phase": [vp, i64, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, i64, f32, vp, vp, f32, f32, f32, f32, f32, i32, vp],
@@ -71,6 +74,8 @@ SIGNATURES = {
     "evc_framepool_max_bwd": [vp, vp, i32, i32, i32, vp, vp],
     "evc_fill_f32": [vp, i64, f32, vp],
     "evc_debug_occupy": [i32, i32, i32, C.c_double, vp],
+    "evc_stream_create_cu_mask": [vp, i32, vp],
+    "evc_stream_destroy": [vp],
     "evc_lstm_stack2_bwd": [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "evc_netvlad_softmax_fwd": [vp, i32, i32, vp, vp, vp, vp, vp, vp],
     "evc_netvlad_softmax_bwd": [vp, vp, i32, i32, vp, vp],

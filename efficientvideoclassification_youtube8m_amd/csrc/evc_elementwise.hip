@@ -1405,3 +1405,19 @@ extern "C" int evc_debug_occupy(int blocks, int threads, int lds_bytes, double m
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }
+
+extern "C" int evc_stream_create_cu_mask(const unsigned* mask, int words, void** stream_out) {
+  EVC_REQUIRE(mask != nullptr && stream_out != nullptr && words > 0 && words <= 32, EVC_ERR_BAD_ARG, "evc_stream_create_cu_mask: words=%d", words);
+  hipStream_t s = nullptr;
+  hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask);
+  EVC_REQUIRE(e == hipSuccess, EVC_ERR_HIP, "hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
+  *stream_out = (void*)s;
+  return EVC_OK;
+}
+
+extern "C" int evc_stream_destroy(void* stream) {
+  EVC_REQUIRE(stream != nullptr, EVC_ERR_BAD_ARG, "evc_stream_destroy: null stream");
+  hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  EVC_REQUIRE(e == hipSuccess, EVC_ERR_HIP, "hipStreamDestroy: %s", hipGetErrorString(e));
+  return EVC_OK;
+}

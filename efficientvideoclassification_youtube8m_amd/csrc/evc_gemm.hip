@@ -658,6 +658,7 @@ struct MoeUpdateParams {
   bf16_t* p_f16; uint8_t* p_fp8;       // or NULL: IEEE f16 image [V][K] and e4m3 image [V][2K] = [e4m3((w - f16(w)) lo_scale) | e4m3(w hi_scale)] of the
   float lo_scale, hi_scale;            // new weights (the "high" forward's operands: evc_gemm_nt_f16_fp8)
   float* partial;                      // pass 1 out: [workgroups][2]
+  float* wsq_partial;                  // or NULL; pass 2 out: [workgroups][2] = {sum of the new weights squared, 0}
   const float* sums;                   // pass 2 in: sums[0] = sum (g + l2 p)^2 of this tensor
   int V, K;
   float l2, clip, lr_t, b1, b2, eps;
@@ -732,6 +733,7 @@ __global__ __launch_bounds__(Cfg::NT) void moe_update_kernel(GemmOperandsT p, Mo
     }
   float scale = 1.f;
   if (u.clip > 0.f) scale = u.clip / fmaxf(sqrtf(u.sums[0]), u.clip);      // tf.clip_by_norm
+  float wsq = 0.f;                                     // sum of the NEW weights squared (the next update's |W|^2: evc_moe_grad_norms)
   __syncthreads();                                     // every wave is done with the ring: reuse it for the transpose
   constexpr int PITCH = Cfg::BM + 8;                   // bf16 elements per k row of the [BU k][BM v] image (+16 B: bank spread)
   bf16_t* tile = (bf16_t*)lds_dyn;
@@ -756,6 +758,7 @@ __global__ __launch_bounds__(Cfg::NT) void moe_update_kernel(GemmOperandsT p, Mo
           vn[r] = u.b2 * va[r] + (1.f - u.b2) * gc * gc;
           pn[r] = adam_step_(pa[r], mn[r], vn[r], u.lr_t, u.eps);
           pb[r] = f32_to_bf16(pn[r]);
+          wsq += pn[r] * pn[r];
         }
         *(float4*)(u.p + o) = make_float4(pn[0], pn[1], pn[2], pn[3]);
         *(float4*)(u.m + o) = make_float4(mn[0], mn[1], mn[2], mn[3]);
@@ -802,9 +805,22 @@ __global__ __launch_bounds__(Cfg::NT) void moe_update_kernel(GemmOperandsT p, Mo
     const uint2 q = *(const uint2*)(tile + kl * PITCH + (lane % LPR) * 4);
     *(uint2*)(u.pT_bf16 + (long)k * u.ldT + v4) = q;
   }
+  if (u.wsq_partial) {                                 // per-workgroup partial, summed in a fixed order by moe_update_finalize_kernel
+    wsq = wave_sum(wsq);
+    __syncthreads();                                   // the transpose image has been read
+    float* red = (float*)lds_dyn;
+    if ((threadIdx.x & 63) == 0) red[wave] = wsq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float a = 0.f;
+      for (int w = 0; w < Cfg::NT / 64; ++w) a += red[w];
+      u.wsq_partial[2 * blockIdx.x] = a;
+      u.wsq_partial[2 * blockIdx.x + 1] = 0.f;
+    }
+  }
 }
 
-__global__ __launch_bounds__(1024) void moe_update_finalize_kernel(const float* partial, int n, float* sums) {
+__global__ __launch_bounds__(1024) void moe_update_finalize_kernel(const float* partial, int n, float* sums, int assign) {
   // one workgroup, fixed summation order (thread-strided partial sums, wave butterflies, then the 16 wave totals
   // in order): run-to-run identical
   __shared__ float wa[16], wb[16];
@@ -817,8 +833,8 @@ __global__ __launch_bounds__(1024) void moe_update_finalize_kernel(const float* 
   if (threadIdx.x == 0) {
     float sa = 0.f, sb = 0.f;
     for (int w = 0; w < 16; ++w) { sa += wa[w]; sb += wb[w]; }
-    sums[0] += sa;
-    sums[1] += sb;
+    if (assign) { sums[0] = sa; sums[1] = sb; }
+    else { sums[0] += sa; sums[1] += sb; }
   }
 }
 
@@ -826,7 +842,7 @@ static int moe_grad_update_impl(const evc_bf16* dlogits, int64_t ld_dlogits, con
                                 int V, int K, float* p, float* m, float* v, evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT,
                                 float l2_coeff, float* sums, float* partial_ws, float clip_norm, float lr_t,
                                 float beta1, float beta2, float eps, int phase, evc_bf16* p_wide, evc_f16* p_f16, uint8_t* p_fp8, int lo_exp, int hi_exp,
-                                void* stream);
+                                void* stream, float* wsq_out = nullptr);
 
 extern "C" int evc_moe_grad_update_wide(const evc_bf16* dlogits, int64_t ld_dlogits, const evc_bf16* x, int64_t ldx, int rows,
                                         int V, int K, float* p, float* m, float* v, evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT,
@@ -855,7 +871,7 @@ static int moe_grad_update_impl(const evc_bf16* dlogits, int64_t ld_dlogits, con
                                 int V, int K, float* p, float* m, float* v, evc_bf16* p_bf16, evc_bf16* pT_bf16,
                                 int64_t ldT, float l2_coeff, float* sums, float* partial_ws, float clip_norm,
                                 float lr_t, float beta1, float beta2, float eps, int phase, evc_bf16* p_wide, evc_f16* p_f16, uint8_t* p_fp8,
-                                int lo_exp, int hi_exp, void* stream) {
+                                int lo_exp, int hi_exp, void* stream, float* wsq_out) {
   EVC_REQUIRE(rows > 0 && rows % 32 == 0 && V > 0 && V % 4 == 0 && K > 0 && K % 8 == 0, EVC_ERR_BAD_SHAPE,
               "evc_moe_grad_update: rows=%d (%%32), V=%d (%%4), K=%d (%%8)", rows, V, K);
   EVC_REQUIRE(phase >= 0 && phase <= 2, EVC_ERR_BAD_ARG, "evc_moe_grad_update_phase: phase=%d (0 both, 1 norms, 2 update)", phase);
@@ -870,15 +886,35 @@ static int moe_grad_update_impl(const evc_bf16* dlogits, int64_t ld_dlogits, con
   const int Vp = (int)(ld_dlogits < ((V + 7) / 8) * 8 ? ld_dlogits : ((V + 7) / 8) * 8);   // A columns the loop may touch (%8)
   GemmOperandsT g{dlogits, ld_dlogits, x, ldx, Vp, K, rows / 32};
   const int tm = ceil_div(V, Cfg::BM), tn = ceil_div(K, Cfg::BU);
+  EVC_REQUIRE(wsq_out == nullptr || phase == 2, EVC_ERR_BAD_ARG, "evc_moe_grad_update_apply: wsq_out goes with the update pass alone");
   MoeUpdateParams u{p, m, v, p_bf16, pT_bf16, ldT, p_wide, (bf16_t*)p_f16, p_fp8, ldexpf(1.0f, lo_exp), ldexpf(1.0f, hi_exp),
-                    partial_ws, sums, V, K, l2_coeff, clip_norm, lr_t, beta1, beta2, eps};
+                    partial_ws, wsq_out ? partial_ws : nullptr, sums, V, K, l2_coeff, clip_norm, lr_t, beta1, beta2, eps};
   if (phase != 2) {
     launch_cfg<Cfg>(moe_update_kernel<Cfg, 1>, tm * tn, st, g, u, tm, tn);
-    hipLaunchKernelGGL(moe_update_finalize_kernel, dim3(1), dim3(1024), 0, st, (const float*)partial_ws, tm * tn, sums);
+    hipLaunchKernelGGL(moe_update_finalize_kernel, dim3(1), dim3(1024), 0, st, (const float*)partial_ws, tm * tn, sums, 0);
   }
   if (phase != 1) launch_cfg<Cfg>(moe_update_kernel<Cfg, 2>, tm * tn, st, g, u, tm, tn);
+  if (wsq_out) hipLaunchKernelGGL(moe_update_finalize_kernel, dim3(1), dim3(1024), 0, st, (const float*)partial_ws, tm * tn, wsq_out, 1);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
+}
+
+// The update pass alone (clip scale from sums[0], which evc_moe_grad_norms has filled), with any of the forward operand images of
+// evc_moe_grad_update_wide (all three may be NULL: plain bf16) and wsq_out[0] = sum of the NEW weights squared (wsq_out[1] = 0):
+// the |W|^2 term of the next update's norm.
+extern "C" int evc_moe_grad_update_apply(const evc_bf16* dlogits, int64_t ld_dlogits, const evc_bf16* x, int64_t ldx, int rows,
+                                         int V, int K, float* p, float* m, float* v, evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT,
+                                         evc_bf16* p_wide_hilo, evc_f16* p_f16, uint8_t* p_fp8, int fp8_lo_exp, int fp8_hi_exp,
+                                         float l2_coeff, const float* sums, float* partial_ws, float clip_norm, float lr_t,
+                                         float beta1, float beta2, float eps, float* wsq_out, void* stream) {
+  EVC_REQUIRE(wsq_out != nullptr, EVC_ERR_BAD_ARG, "evc_moe_grad_update_apply: wsq_out is required");
+  EVC_REQUIRE(!p_wide_hilo || ((uintptr_t)p_wide_hilo % 8) == 0, EVC_ERR_BAD_ALIGN, "evc_moe_grad_update_apply: p_wide_hilo must be 8-byte aligned");
+  EVC_REQUIRE((p_f16 == nullptr) == (p_fp8 == nullptr) && (!p_f16 || (((uintptr_t)p_f16 % 8) == 0 && ((uintptr_t)p_fp8 % 4) == 0)), EVC_ERR_BAD_ARG,
+              "evc_moe_grad_update_apply: p_f16 (8-byte aligned) and p_fp8 (4-byte aligned) go together");
+  EVC_REQUIRE(!p_f16 || (fp8_lo_exp >= 0 && fp8_lo_exp <= 60 && fp8_hi_exp >= -30 && fp8_hi_exp <= 30), EVC_ERR_BAD_ARG,
+              "evc_moe_grad_update_apply: fp8_lo_exp=%d fp8_hi_exp=%d", fp8_lo_exp, fp8_hi_exp);
+  return moe_grad_update_impl(dlogits, ld_dlogits, x, ldx, rows, V, K, p, m, v, p_bf16, pT_bf16, ldT, l2_coeff, (float*)sums, partial_ws, clip_norm, lr_t,
+                              beta1, beta2, eps, 2, p_wide_hilo, p_f16, p_fp8, fp8_lo_exp, fp8_hi_exp, stream, wsq_out);
 }
 
 extern "C" int evc_moe_grad_update(const evc_bf16* dlogits, int64_t ld_dlogits, const evc_bf16* x, int64_t ldx, int rows,

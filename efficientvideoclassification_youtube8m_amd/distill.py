@@ -380,9 +380,23 @@ class DistillGraph:
         # True: the student's forward starts when the teacher's L1 level has been enqueued, next to the teacher's L2 chain /
         # MoE head (latency-bound launches).  Measured 13.01 -> 12.88 ms/step with the teacher's L1 steps unaffected.
         self.student_forward_after_l1 = os.environ.get("EVC_STUDENT_AFTER_L1", "1") == "1"
+        if os.environ.get("EVC_STUDENT_EARLY") is not None:
+            self.student_forward_early = os.environ["EVC_STUDENT_EARLY"] == "1"
+        # Cross-step deferral (one process): the MoE-head and L2-level updates of step k are enqueued at the start of step k+1,
+        # under its L1 forward, instead of under step k's BPTT chain (HLstmTower.backward(defer=True)).  Whoever reads the
+        # weights between two steps calls flush() first (state_dict() / consolidate() / apply_gradients() do).
+        self.defer_updates = os.environ.get("EVC_DEFER_UPDATES", "0") == "1"
+        self._opt_t = self._opt_s = None
         if self.device.type == "cuda":
             # four streams that measurably overlap (streams.py); the step never runs on the default stream
             self._main, self._side, self._aux_t, self._aux_s = concurrent_streams(self.device, 4)
+            # experiment: the optimizer launches on a CU-masked stream of their own - EVC_OPT_CU_MASK=<CUs per XCD>[:<first>]
+            m = os.environ.get("EVC_OPT_CU_MASK")
+            if m:
+                from .streams import cu_masked_stream
+                f = [int(v) for v in m.split(":")]
+                self._opt_t = cu_masked_stream(self.device, f[0], f[1] if len(f) > 1 else 0)
+                self._opt_s = self._opt_t if os.environ.get("EVC_OPT_CU_MASK_SHARED", "1") == "1" else cu_masked_stream(self.device, f[0], f[1] if len(f) > 1 else 0)
             self._ev_fwd, self._ev_student, self._ev_in = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
 
     # ---- data-parallel gradient reduction -------------------------------------
@@ -452,6 +466,9 @@ class DistillGraph:
                                   split=(self.teacher or self.student).input_split(), plan1=tp[2] if tp else None,
                                   plan2=sp[3] if sp else None,
                                   **input_image_args(self.teacher, self.student))
+        for tw in (self.teacher, self.student):     # step k-1's deferred MoE / L2-level updates: now, under this step's L1 forward
+            if tw is not None:
+                tw.run_deferred()
         self.losses.zero_()
         out = {}
         mark = self._mark
@@ -522,7 +539,8 @@ class DistillGraph:
                                       on_moe_grads_ready=None if early else (lambda: self._reduce_tower(self.student, True)),
                                       aux=self._aux_s if self.overlap_towers else None, early_apply=early,
                                       reduce_fn=(lambda lo, hi: self.reducer_s.reduce_async(st_s.grad, lo, hi)) if (early and self.dp) else None,
-                                      dp=self.reducer_s if (early and self.dp) else None)
+                                      dp=self.reducer_s if (early and self.dp) else None, defer=self.defer_updates and not self.dp,
+                                      opt=self._opt_s)
                 if not early:
                     self._reduce_tower(self.student, False)
                 self._student_applied = early is not None
@@ -546,7 +564,8 @@ class DistillGraph:
                                   on_moe_grads_ready=None if early else (lambda: self._reduce_tower(self.teacher, True)),
                                   aux=self._aux_t if self.overlap_towers else None, early_apply=early,
                                   reduce_fn=(lambda lo, hi: self.reducer.reduce_async(st_t.grad, lo, hi)) if (early and self.dp) else None,
-                                  dp=self.reducer if (early and self.dp) else None)
+                                  dp=self.reducer if (early and self.dp) else None, defer=self.defer_updates and not self.dp,
+                                  opt=self._opt_t)
             if not early:
                 self._reduce_tower(self.teacher, False)
             mark("teacher_bwd_done", main)
@@ -561,13 +580,27 @@ class DistillGraph:
             self._losses_reduced.copy_(self.losses)
             self.reducer.all_reduce_small(self._losses_reduced)
         if apply:
-            self.apply_gradients(B, lr)
+            self._apply_gradients(B, lr)
         out["global_step"] = self.global_step
         return out
+
+    def flush(self):
+        """Enqueue and join the deferred updates of the last step (defer_updates): afterwards every weight, moment and operand
+        shadow of both towers is current in the order of the caller's stream.  Cheap no-op when nothing is pending."""
+        if self.device.type != "cuda":
+            return
+        cur = torch.cuda.current_stream(self.device)
+        for tw in (self.teacher, self.student):
+            if tw is not None:
+                tw.wait_deferred(cur)
 
     def apply_gradients(self, batch_size, lr=None):
         """Runs whichever train op has not been applied inside step(); each one increments
         global_step (cs/train.py:332,416 -> += 2 per iteration, README.md:116,121)."""
+        self.flush()
+        self._apply_gradients(batch_size, lr)
+
+    def _apply_gradients(self, batch_size, lr=None):
         l2c = self.reg_pen * 1e-8
         if lr is None:
             lr = exponential_decay(self.lr0, self.global_step, batch_size * self.world, self.lr_decay_examples, self.lr_decay)
@@ -585,6 +618,7 @@ class DistillGraph:
         """Collective (every rank calls it; a no-op on one rank): the row-sharded f32 MoE weights and Adam moments
         (MoeHead.shard) are all-gathered so that every rank holds the complete model again - before a checkpoint,
         state_dict(), or any update that does not go through the fused data-parallel path."""
+        self.flush()
         for tw, red in ((self.teacher, self.reducer), (self.student, self.reducer_s)):
             if tw is not None:
                 tw.moe.consolidate(red)

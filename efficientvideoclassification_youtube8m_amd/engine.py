@@ -400,6 +400,7 @@ class LstmStack:
                                    dh_above, self._v(self.dc_ws, M, H), dz, plan=plan, db=gb,
                                    dz_above=self._v(self.dz[l + 1], T, M, 4 * H) if fused else None,
                                    w_above=tw.shadow_bwd[self.names(l + 1)[0]] if fused else None)
+            ops.mark("%s:%s_bptt%d_done" % (tw.scope, self.scope, l))
             dz2 = dz.view(T * M, 4 * H)
             # gradient wrt the layer input, all T at once (hoisted): dX = dz . Wx^T
             if l > 0 and fuse_ok and self.bwd_fuse == "fused":
@@ -712,6 +713,8 @@ class TowerBase:
 
     def state_dict(self):
         """TF-named, TF-layout copies (2-D weights are stored transposed internally)."""
+        if hasattr(self, "flush_deferred"):
+            self.flush_deferred()
         if getattr(getattr(self, "moe", None), "_stale", False):
             raise RuntimeError("the MoE weights of %r are sharded over the ranks; call consolidate() on the graph on "
                                "every rank before reading them" % self.scope)
@@ -725,6 +728,8 @@ class TowerBase:
 
     def load_state_dict(self, sd, prefix=None):
         prefix = self.scope if prefix is None else prefix
+        if hasattr(self, "flush_deferred"):
+            self.flush_deferred()
         for k in self.names:
             src = sd["%s/%s" % (prefix, k)].to(self.device, F32)
             p = self.store.p(k)
@@ -762,11 +767,14 @@ class TowerBase:
         t = self.adam_t
         return lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
 
-    def apply_group(self, names, lr, clip_norm=1.0, l2_coeff=0.0, beta1=0.9, beta2=0.999, eps=1e-8, refresh=True):
+    def apply_group(self, names, lr, clip_norm=1.0, l2_coeff=0.0, beta1=0.9, beta2=0.999, eps=1e-8, refresh=True, lr_t=None):
         """Per-tensor clip_by_norm + TF-Adam for a subset of the variables (their gradients must be
         final).  slim create_train_op semantics (cs/train.py:329-334); the l2 regulariser gradient
-        (regularization_penalty * 1e-8 * W) is folded into the gradient before the norm."""
-        lr_t = self.adam_lr_t(lr, beta1, beta2)
+        (regularization_penalty * 1e-8 * W) is folded into the gradient before the norm.
+        lr_t: the bias-corrected step size of the optimizer step the gradients belong to (a deferred group is applied after
+        the next begin_update() has already bumped the step count)."""
+        if lr_t is None:
+            lr_t = self.adam_lr_t(lr, beta1, beta2)
         idx = {k: i for i, k in enumerate(self.names)}
         for k in names:
             l2 = l2_coeff if k in self.l2_names else 0.0
@@ -1006,7 +1014,11 @@ class HLstmTower(TowerBase):
         B = int(len_l2.shape[0])
         if B != self.B:
             self._alloc(B)
+        self.run_deferred()                                            # (normally already enqueued at the start of the step)
+        ops.mark(self.scope + ":fwd_begin")
         S1 = self.l1.forward(x_view, len_l1, plan_l1)
+        ops.mark(self.scope + ":l1_fwd_done")
+        self.wait_deferred()                                           # L2-level / MoE updates of the previous step (defer=True)
         if after_l1 is not None:
             after_l1()
         ops.cast_bf16(S1, self.S1_bf)                                  # = L2 input [C][B][2LH] (in "high": the backward operand)
@@ -1023,7 +1035,10 @@ class HLstmTower(TowerBase):
             S2 = self.l2.forward((self.S1_bf.view(self.C, B, self.K), self.S1_w.view(self.C, B, 2 * self.K)), len_l2)
         else:
             S2 = self.l2.forward(self.S1_bf.view(self.C, B, self.K), len_l2)
-        return S2, self.moe.forward(S2)
+        ops.mark(self.scope + ":l2_fwd_done")
+        pred = self.moe.forward(S2)
+        ops.mark(self.scope + ":moe_fwd_done")
+        return S2, pred
 
     # ---- backward -----------------------------------------------------------
     def param_groups(self):
@@ -1041,8 +1056,9 @@ class HLstmTower(TowerBase):
         return (moe_lo, st.total), (l2_lo, moe_lo), (0, l2_lo)
 
     fused_moe_update = True      # recompute the rank-B MoE gradient inside the Adam step instead of materialising it
+    _deferred, _deferred_ev, _deferred_aux = (), None, None    # backward(defer=True): closures / event / stream of the pending updates
 
-    def backward(self, dstate, dpred, on_moe_grads_ready=None, aux=None, early_apply=None, reduce_fn=None, dp=None):
+    def backward(self, dstate, dpred, on_moe_grads_ready=None, aux=None, early_apply=None, reduce_fn=None, dp=None, defer=False, opt=None):
         """dstate [B,2LH] f32 or None (gradient on the returned state), dpred [B,V] f32.
         Fills self.store.grad (every segment is overwritten).
         aux: side stream that takes the weight-gradient GEMMs (and, with early_apply =
@@ -1052,8 +1068,19 @@ class HLstmTower(TowerBase):
         early_apply each group is reduced on the aux stream right after its gradients are final and updated
         as soon as the collective has finished.
         dp (distill.GradReducer): with it the MoE weights (2/3 of the parameters) need no gradient all-reduce at all -
-        factor all-gather + row-sharded update (MoeHead.fused_update)."""
+        factor all-gather + row-sharded update (MoeHead.fused_update).
+        opt: optional stream for the optimizer launches (clip + Adam, fused MoE update) - by default they share `aux` with the
+        weight-gradient products; a CU-masked stream (streams.cu_masked_stream) confines them to a few compute units.
+        defer (with aux + early_apply, one process): the updates of the variables the NEXT forward reads last - the MoE head
+        and the L2 level - are not enqueued here but kept as closures (self._deferred): run_deferred() enqueues them on the aux
+        stream at the start of the next step, where they run under that step's L1 forward (MFMA-bound) instead of under this
+        step's memory-bound BPTT chain; forward() waits for them before the L2 level.  Same values, later in wall time
+        (cs/train.py:516-517: both train ops of an iteration read the pre-update weights - unchanged)."""
         assert self.training
+        if not isinstance(self._deferred, list):
+            self._deferred = []
+        defer = bool(defer) and aux is not None and early_apply is not None and dp is None and reduce_fn is None
+        self.flush_deferred()                       # (a caller that skipped the next forward: nothing may be pending twice)
         main = torch.cuda.current_stream(self.device)
         g_moe, g_l2, g_l1 = self.param_groups()
         seg_moe, seg_l2, seg_l1 = self.grad_segments()
@@ -1072,20 +1099,38 @@ class HLstmTower(TowerBase):
         if not fuse and getattr(self.moe, "_stale", False):
             raise RuntimeError("the MoE weights of %r are sharded over the ranks (fused data-parallel update); call "
                                "DistillGraph.consolidate() on every rank before an update that is not" % self.scope)
+        ops.mark(self.scope + ":bwd_begin")
         dS2 = self.moe.backward(dpred, dstate, weight_grads=not fuse)
+        ops.mark(self.scope + ":moe_bwd_done")
         if on_moe_grads_ready is not None:
             on_moe_grads_ready()
+        if aux is None or early_apply is None:
+            opt = None
+        ostream = opt if opt is not None else aux
         if aux is not None and early_apply is not None:
             self.begin_update()
             ev = torch.cuda.Event()
             ev.record(main)
             aux.wait_event(ev)
-            with torch.cuda.stream(aux):                               # 2/3 of the parameters, under the LSTM BPTT
+            if opt is not None:
+                opt.wait_event(ev)
+            lr_t_now = self.adam_lr_t(early_apply[0])
+            if defer:
+                self._deferred_aux = ostream
                 if fuse:
                     lr, clip, l2c = early_apply
-                    self.moe.fused_update(self.adam_lr_t(lr), clip, l2c, dp=dp)
+                    self._deferred.append(lambda: self.moe.fused_update(lr_t_now, clip, l2c, dp=None))
                 else:
-                    reduce_then_apply(g_moe, seg_moe)
+                    self._deferred.append(lambda: self.apply_group(g_moe, *early_apply, lr_t=lr_t_now))
+            else:
+                with torch.cuda.stream(ostream):                       # 2/3 of the parameters, under the LSTM BPTT
+                    ops.mark(self.scope + ":moe_update_begin")
+                    if fuse:
+                        lr, clip, l2c = early_apply
+                        self.moe.fused_update(lr_t_now, clip, l2c, dp=dp)
+                    else:
+                        reduce_then_apply(g_moe, seg_moe)
+                    ops.mark(self.scope + ":moe_update_done")
         # Per LAYER: as soon as a layer's weight-gradient products are enqueued on the aux stream its kernel + bias gradients are
         # final there - reduce (data parallel) and clip + Adam them right behind, under the BPTT of the layer below.  Only the
         # LOWEST layer of the L1 level is left for the end of the step (round 3; before, a level's four tensors waited for its
@@ -1093,18 +1138,65 @@ class HLstmTower(TowerBase):
         per_layer = aux is not None and early_apply is not None
         st = self.store
 
-        def layer_cb(stack):
+        def layer_cb(stack, deferred=False):
             def cb(l):
                 kn, bn = stack.names(l)
                 lo = st.offsets[kn]
                 hi = st.offsets[bn] + _align(int(math.prod(st.shapes[bn])))
                 assert lo < hi and st.offsets[bn] > lo, "a layer's kernel and bias are adjacent in the gradient buffer"
-                reduce_then_apply([kn, bn], (lo, hi))
+                ops.mark("%s:%s_wgrad%d_done" % (self.scope, stack.scope, l))
+                if opt is not None:                                # the gradients are final on the current (aux) stream
+                    evg = torch.cuda.Event()
+                    evg.record(torch.cuda.current_stream(self.device))
+                    opt.wait_event(evg)
+                if deferred:
+                    self._deferred.append(lambda: self.apply_group([kn, bn], *early_apply, lr_t=lr_t_now))
+                elif opt is not None:
+                    with torch.cuda.stream(opt):
+                        reduce_then_apply([kn, bn], (lo, hi))
+                        ops.mark("%s:%s_adam%d_done" % (self.scope, stack.scope, l))
+                else:
+                    reduce_then_apply([kn, bn], (lo, hi))
+                    ops.mark("%s:%s_adam%d_done" % (self.scope, stack.scope, l))
             return cb if per_layer else None
 
-        dS1 = self.l2.backward(dS2, need_dx=True, aux=aux, on_layer_grads=layer_cb(self.l2))   # [C*B][2LH] = d(L1 final state)
+        dS1 = self.l2.backward(dS2, need_dx=True, aux=aux, on_layer_grads=layer_cb(self.l2, defer))   # [C*B][2LH] = d(L1 final state)
+        ops.mark(self.scope + ":l2_bwd_done")
         self.l1.backward(dS1, need_dx=False, aux=aux, on_layer_grads=layer_cb(self.l1))
+        ops.mark(self.scope + ":l1_bwd_done")
         if aux is not None:
             ev = torch.cuda.Event()
             ev.record(aux)
             main.wait_event(ev)
+        if opt is not None:
+            ev = torch.cuda.Event()
+            ev.record(opt)
+            main.wait_event(ev)
+
+    # ---- cross-step deferral of the MoE / L2-level updates (backward(defer=True)) ----------------------------------
+    def run_deferred(self):
+        """Enqueue the pending updates of the previous backward() on the aux stream they belong to (in stream order behind that
+        step's weight-gradient products) and record the event forward() waits for before the L2 level.  No-op without any."""
+        if not self._deferred:
+            return
+        aux = self._deferred_aux
+        with torch.cuda.stream(aux):
+            ops.mark(self.scope + ":deferred_begin")
+            for fn in self._deferred:
+                fn()
+            ops.mark(self.scope + ":deferred_done")
+            self._deferred_ev = torch.cuda.Event()
+            self._deferred_ev.record(aux)
+        self._deferred = []
+
+    def wait_deferred(self, stream=None):
+        """Make `stream` (default: current) wait for the deferred updates enqueued by run_deferred()."""
+        self.run_deferred()
+        ev, self._deferred_ev = self._deferred_ev, None
+        if ev is not None:
+            (stream or torch.cuda.current_stream(self.device)).wait_event(ev)
+
+    def flush_deferred(self):
+        """run_deferred + wait on the current stream: every weight / shadow is current in stream order afterwards."""
+        if self._deferred or self._deferred_ev is not None:
+            self.wait_deferred()

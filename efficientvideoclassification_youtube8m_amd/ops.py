@@ -29,6 +29,17 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+MARKS = None     # set to a list to collect (name, stream handle, timing event) at the engine's mark() points (scripts/step_timeline.py)
+
+
+def mark(name):
+    """Timeline aid: a timing event on the current stream, kept in ops.MARKS when that is a list (else nothing happens)."""
+    if MARKS is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        MARKS.append((name, torch.cuda.current_stream().cuda_stream, ev))
+
+
 def round_up(x, m):
     return (x + m - 1) // m * m
 

@@ -66,3 +66,28 @@ def concurrent_streams(device, count=4, candidates=12, chain=24, verbose=False):
                 kept.append(s)
     _cache[key] = kept
     return kept
+
+
+_masked = []        # (keeps the raw streams alive for the life of the process)
+
+
+def cu_masked_stream(device, cus_per_xcd, first=0, xcds=8, total_cus=256):
+    """A stream whose kernels run only on `cus_per_xcd` compute units of every XCD, starting at per-XCD index `first`
+    (hipExtStreamCreateWithCUMask through evc_stream_create_cu_mask; mask bit i = CU i // xcds of XCD i % xcds).
+    Returns a torch.cuda.ExternalStream."""
+    import ctypes as C
+    from . import _lib
+    device = torch.device(device)
+    words = (total_cus + 31) // 32
+    mask = (C.c_uint32 * words)()
+    for k in range(first, first + cus_per_xcd):
+        for x in range(xcds):
+            bit = k * xcds + x
+            if bit < total_cus:
+                mask[bit // 32] |= 1 << (bit % 32)
+    out = C.c_void_p()
+    with torch.cuda.device(device):
+        _lib.call("evc_stream_create_cu_mask", C.cast(mask, C.c_void_p), words, C.cast(C.pointer(out), C.c_void_p))
+    st = torch.cuda.ExternalStream(out.value, device=device)
+    _masked.append((out.value, st))
+    return st

@@ -291,6 +291,26 @@ int evc_moe_grad_update_phase(const evc_bf16* dlogits, int64_t ld_dlogits, const
                               int V, int K, float* p, float* m, float* v, evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT,
                               float l2_coeff, float* sums, float* partial_ws, float clip_norm, float lr_t,
                               float beta1, float beta2, float eps, int phase, void* stream);
+/* The clip norm of a MoE weight gradient without a pass over the weights (one process; replaces phase 1): with the batch-row factors
+ * A = dlogits [R][V] and X [R][K] (g = A^T X), |g + l2 W|^2 = <A A^T, X X^T>_F + 2 l2 <A, logits - bias>_F + l2^2 |W|^2
+ * (csrc/evc_moe_norms.hip; per-tensor clip_by_norm of slim.learning.create_train_op, cs/train.py:329-334, on the gradient that
+ * includes the l2 regulariser's, cs/video_level_models.py:428,434).
+ *   evc_gram_slabs: slabs[s][i][j] = sum over K slab s of A[i][k] A[j][k] (S slabs of R x R f32, stored plainly, summed later in
+ *     slab order: run-to-run identical).  R % 32 == 0, Kc % 32 == 0 columns (zero padding allowed), S <= Kc / 32.
+ *   evc_moe_grad_norms: sums[0] += the norm above, sums[1] += wsq[0]; gram_a / gram_x from evc_gram_slabs of dlogits / x; logits
+ *     [B][V] f32 = the forward's X W^T (+ bias: pass it, or NULL for the gates); wsq[0] = |W|^2 of the current weights (kept by
+ *     evc_moe_grad_update_apply); part_ws: 256 floats of scratch.
+ *   evc_moe_grad_update_apply: phase 2 alone with the optional operand images of evc_moe_grad_update_wide (any may be NULL) and
+ *     wsq_out[0] = sum of the NEW weights squared, wsq_out[1] = 0 (both through partial_ws in a fixed order). */
+int evc_gram_slabs(const evc_bf16* A, int64_t lda, int R, int Kc, int S, float* slabs, void* stream);
+int evc_moe_grad_norms(const float* gram_a, int SA, const float* gram_x, int SX, int R, const evc_bf16* dlogits, int64_t ld_dlogits,
+                       const float* logits, int64_t ld_logits, const float* bias, int B, int V, float l2_coeff, const float* wsq,
+                       float* part_ws, float* sums, void* stream);
+int evc_moe_grad_update_apply(const evc_bf16* dlogits, int64_t ld_dlogits, const evc_bf16* x, int64_t ldx, int rows,
+                              int V, int K, float* p, float* m, float* v, evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT,
+                              evc_bf16* p_wide_hilo, evc_f16* p_f16, uint8_t* p_fp8, int fp8_lo_exp, int fp8_hi_exp,
+                              float l2_coeff, const float* sums, float* partial_ws, float clip_norm, float lr_t,
+                              float beta1, float beta2, float eps, float* wsq_out, void* stream);
 /* evc_moe_grad_update that ALSO writes, from the update's epilogue, the forward operand images of the new weights the non-bf16 precision
  * modes contract - instead of separate passes over the f32 weights after every update: p_wide_hilo [V][2K] = [bf16(W) | bf16(W - bf16(W))]
  * (the B operand of evc_gemm_nt_split: "split" mode) and / or p_f16 [V][K] = f16(W) with p_fp8 [V][2K] = [e4m3((W - f16(W)) 2^fp8_lo_exp) |
@@ -567,6 +587,12 @@ int evc_fill_f32(float* p, int64_t n, float value, void* stream);
 /* Measurement aid, not part of the path: `blocks` workgroups of `threads` threads with `lds_bytes` of LDS each stay resident for
  * `microseconds` - the footprint of a collective's kernel on the compute units, for the one-GPU stand-in runs of DESIGN.md 6.1. */
 int evc_debug_occupy(int blocks, int threads, int lds_bytes, double microseconds, void* stream);
+/* Scheduling aid: a HIP stream whose kernels may only run on the compute units set in `mask` (hipExtStreamCreateWithCUMask;
+ * `words` 32-bit words, bit i of the mask = CU i in the driver's XCD-interleaved enumeration, so the low 8 n bits are n CUs of
+ * each XCD).  The caller owns the stream (evc_stream_destroy).  Used by streams.cu_masked_stream for the optimizer side stream
+ * (DESIGN.md 5); the path itself never creates streams. */
+int evc_stream_create_cu_mask(const unsigned* mask, int words, void** stream_out);
+int evc_stream_destroy(void* stream);
 
 #ifdef __cplusplus
 }

@@ -300,6 +300,46 @@ def test_fused_moe_update_matches_materialised_gradient_path():
         assert torch.allclose(ta.sums, tb.sums, rtol=1e-4, atol=1e-12)
 
 
+@pytest.mark.parametrize("precision", ["bf16", "high"])
+def test_deferred_updates_equal_immediate_updates(precision):
+    """DistillGraph.defer_updates (the MoE-head and L2-level updates of step k enqueued at the start of step k+1, under its L1
+    forward) against the immediate schedule: same weights, moments and operand shadows after three iterations + flush(); the
+    state of a deferred graph is complete only after flush() (state_dict() flushes).  cs/train.py:516-517: both train ops read
+    the pre-update weights of the iteration - the deferral only moves the update later in wall time."""
+    from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
+    B, F, H, V = 8, 128, 128, 100
+    q, x, n, labels = mm.synthetic_batch(B, seed=33, feature_size=F, vocab_size=V, dtype=np.float32)
+    xd, nd, yd = torch.from_numpy(q).to(DEV), torch.from_numpy(n).to(DEV), torch.from_numpy(labels.astype(np.uint8)).to(DEV)
+    graphs = []
+    for defer in (True, False):
+        g = DistillGraph(B, every_n=10, feature_size=F, vocab_size=V, lstm_cells=H, device=DEV, seed=4, precision=precision)
+        g.defer_updates = defer
+        for _ in range(3):
+            out = g.step(xd, yd, nd, num_frames_host=n)
+        if defer:
+            assert g.teacher._deferred and g.student._deferred, "the last step's MoE / L2-level updates are still pending"
+        sd = {}
+        for tw in (g.teacher, g.student):
+            sd.update(tw.state_dict())                     # (flushes)
+        assert not g.teacher._deferred and g.teacher._deferred_ev is None
+        torch.cuda.synchronize()
+        graphs.append((g, sd, {k: float(v) for k, v in g.loss_report().items()}))
+    (a, sda, la), (b, sdb, lb) = graphs
+    assert a.global_step == b.global_step == 6
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 2e-3 * abs(lb[k]) + 1e-6, (k, la[k], lb[k])      # (atomics in the split-K joins: not bit-equal)
+    for k in sda:
+        d = (sda[k] - sdb[k]).abs().max().item()
+        assert d < 3e-4, (k, d)                            # a fraction of one Adam step (lr 1e-3)
+    for ta, tb in ((a.teacher, b.teacher), (a.student, b.student)):
+        for k in ta.names:
+            ma, mb = ta.store.view(ta.store.m, k), tb.store.view(tb.store.m, k)
+            assert (ma - mb).abs().max().item() <= 2e-2 * mb.abs().max().item() + 1e-12, k
+        for k, sh in ta.shadow_fwd.items():                # the shadows follow the masters in both schedules
+            assert torch.equal(sh, ta.store.p(k).bfloat16()), k
+        assert ta.adam_t == tb.adam_t == 3
+
+
 @pytest.mark.parametrize("H", [64, 128])
 def test_fused_moe_update_writes_the_forward_operand_images_in_high_precision(H):
     """"high" precision, one process: the fused MoE update's epilogue also writes the forward operand images of the new weights
