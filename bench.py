@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+DTYPE_OF = {"bf16": "bf16", "high": "f16", "split": "bf16"}     # MFMA operand type of the forward products (accumulation f32; backward products bf16 in every mode)
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 T_FRAMES, F_FEAT, V_CLS, H_CELLS = 300, 1152, 4716, 1024
 
@@ -164,6 +165,8 @@ def run_hlstm(device, rank, world, B, mode, every_n, steps, warmup, all_full=Fal
            "schedule": {"defer_updates": bool(graph.defer_updates and not graph.dp), "student_forward_early": bool(graph.student_forward_early),
                         "student_forward_after_l1": bool(graph.student_forward_after_l1), "opt_cu_mask": os.environ.get("EVC_OPT_CU_MASK")}}
     res["executed_tflops"] = round(res["executed_tflop_per_step"] / (res["ms_per_step"] * 1e-3), 1)
+    if precision != "bf16":
+        res["high_layout"] = {tw.scope: tw.precision_layout() for tw in (graph.teacher, graph.student) if tw is not None}
     if dp_on:
         from efficientvideoclassification_youtube8m_amd.distill import serial_comm
         timing, GradReducer.timing = GradReducer.timing, None
@@ -179,8 +182,8 @@ def run_hlstm(device, rank, world, B, mode, every_n, steps, warmup, all_full=Fal
                 wire = (w - 1.0) / w * nbytes / steps
             per_kind[kind] = {"calls_per_step": round(calls / steps, 2), "payload_mb_per_step": round(nbytes / steps / 1e6, 3),
                               "wire_mb_per_rank_per_step": round(wire / 1e6, 3), "event_ms_per_step": round(ms_k / steps, 4)}
-        res["dp"] = {"placement": "EVC_DP_SERIAL_COMM=1: one communicator, every collective funnelled through one stream" if serial_comm()
-                     else "stream order, teacher and student towers on two communicators",
+        res["dp"] = {"placement": ("EVC_DP_SERIAL_COMM=1: one communicator, every collective funnelled through one stream, backward phases issued in %s order"
+                                   % graph.issue_order) if serial_comm() else "stream order, teacher and student towers on two communicators",
                      "attempt": int(os.environ.get("EVC_BENCH_ATTEMPT", "0")), "grad_dtype": graph.reducer.grad_dtype, "world": world,
                      "collectives": per_kind,
                      "wire_mb_per_rank_per_step": round(sum(v["wire_mb_per_rank_per_step"] for v in per_kind.values()), 2),
@@ -208,7 +211,7 @@ def run_hlstm(device, rank, world, B, mode, every_n, steps, warmup, all_full=Fal
             for (m, nl, fl) in tower.l1.profile_fwd_layers(reps=3):
                 ms_i, launches_i, flops_i = ms_i + m, launches_i + nl, flops_i + fl
         traffic = mfma_busy = pmc_src = None
-        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):    # HBM bytes / MFMA busy from the committed --pmc passes
+        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):    # HBM bytes / MFMA busy from the committed --pmc passes
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     pmc = json.load(f)
@@ -358,7 +361,7 @@ def host_cores():
     return cores
 
 
-def cpu_baseline(every_n, batch=256, budget_s=64.0):
+def cpu_baseline(every_n, batch=256, budget_s=84.0, threads=0):
     """the reference graph restated on PyTorch-CPU float32 (oracle/torch_cpu.py: one dynamic_rnn
     per chunk, autograd BPTT, per-tensor clip, TF-Adam), all host cores, on a BOUNDED sample of the headline workload:
     `batch` synthetic videos x 300 x 1152 per iteration (256 = the batch the metric is quoted on; the rate depends on it:
@@ -366,7 +369,7 @@ def cpu_baseline(every_n, batch=256, budget_s=64.0):
     three timed ones inside `budget_s` seconds."""
     from oracle import model_math as mm
     from oracle import torch_cpu as tc
-    cores = host_cores()
+    cores = threads if threads > 0 else host_cores()
     torch.set_num_threads(cores)
     rng = np.random.default_rng(7)
     teacher = tc.to_torch(mm.init_hlstm_params(rng, dtype=np.float32))
@@ -391,20 +394,49 @@ def cpu_baseline(every_n, batch=256, budget_s=64.0):
             "batch": batch, "iterations_timed": len(times), "sec_per_iteration": round(dtm, 3)}
 
 
+def _agree_on_attempt(attempt, rc, rank, world, port, wait_s):
+    """CPU-side agreement of the rank supervisors on one attempt's outcome (no GPU, no process group): every rank publishes its
+    child's exit code in a TCPStore hosted by rank 0's supervisor and reads all of them; returns the worst one (non-zero when any
+    rank failed - then EVERY rank retries, also those whose own child succeeded) or 1 when the exchange itself fails."""
+    import datetime
+    try:
+        from torch.distributed import TCPStore
+        store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), port, world, is_master=(rank == 0),
+                         timeout=datetime.timedelta(seconds=wait_s), wait_for_workers=False)
+        store.set("rc/%d/%d" % (attempt, rank), str(int(rc)))
+        keys = ["rc/%d/%d" % (attempt, r) for r in range(world)]
+        store.wait(keys, datetime.timedelta(seconds=wait_s))
+        worst = max(abs(int(store.get(k))) for k in keys)
+        store.set("seen/%d/%d" % (attempt, rank), "1")
+        if rank == 0:                       # the host of the store leaves last
+            store.wait(["seen/%d/%d" % (attempt, r) for r in range(world)], datetime.timedelta(seconds=30))
+        return worst
+    except Exception as e:  # noqa: BLE001
+        sys.stderr.write("[bench supervisor rank %d] could not agree on attempt %d with the other ranks (%s): treating it as failed\n" % (rank, attempt, e))
+        return 1
+
+
 def supervise_ranks(argv, script=None):
     """N > 1 only, one supervisor per rank, BEFORE anything touches the GPU: runs the benchmark in a child process and, if that
-    child dies or exceeds its wall limit (a collective wedged on first contact with the fabric: the process group's watchdog aborts
-    it after distill.dp_timeout()), starts ONE more child with the conservative placement of the collectives
-    (EVC_DP_SERIAL_COMM=1: one communicator, one collective at a time) on the next rendezvous port.  Every rank takes the same
-    decision from its own child's fate - when a collective hangs, it hangs for all of them - so the fallback children meet again.
+    child dies or exceeds its wall limit on ANY rank (a collective wedged on first contact with the fabric: the process group's
+    watchdog aborts it after distill.dp_timeout()), starts the next placement of the collectives on the next rendezvous port:
+      attempt 0  stream order, teacher and student towers on two communicators (the fastest on the one-rank probes)
+      attempt 1  EVC_DP_SERIAL_COMM=1: ONE communicator, ONE communication stream, backward phases issued in readiness order
+                 (DistillGraph.issue_order "interleaved": no collective queues behind the other tower's later ones)
+      attempt 2  the same with the sequential issue order (round 3's conservative placement)
+    The ranks AGREE on the outcome of each attempt through a CPU-side TCPStore (rank 0's supervisor hosts it on MASTER_PORT + 40 +
+    attempt): a rank whose own child exited 0 retries with the others when any peer failed, so nobody starts a retry alone.
     A child is a fresh process (never an exec of one that has initialised the GPU).  Returns the exit code for this rank."""
     import subprocess
     attempts = [({}, "stream order, two communicators")]
     if os.environ.get("EVC_DP_SERIAL_COMM") != "1":
-        attempts.append(({"EVC_DP_SERIAL_COMM": "1"}, "EVC_DP_SERIAL_COMM=1"))
+        attempts.append(({"EVC_DP_SERIAL_COMM": "1"}, "EVC_DP_SERIAL_COMM=1, readiness issue order"))
+    if os.environ.get("EVC_ISSUE_ORDER") != "sequential":
+        attempts.append(({"EVC_DP_SERIAL_COMM": "1", "EVC_ISSUE_ORDER": "sequential"}, "EVC_DP_SERIAL_COMM=1, sequential issue order"))
     port = int(os.environ.get("MASTER_PORT", "29500"))
     limit = float(os.environ.get("EVC_BENCH_ATTEMPT_S", "600"))
     rank = os.environ.get("RANK", "0")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
     rc = 1
     for i, (extra, name) in enumerate(attempts):
         env = dict(os.environ, EVC_BENCH_CHILD="1", EVC_BENCH_ATTEMPT=str(i))
@@ -420,10 +452,13 @@ def supervise_ranks(argv, script=None):
             child.kill()
             child.wait()
             rc = 124
+        own = rc
+        if world > 1 and os.environ.get("EVC_BENCH_NO_AGREEMENT") != "1":
+            rc = _agree_on_attempt(i, rc, int(rank), world, port + 40 + i, limit + 120.0)
         if rc == 0:
             return 0
-        sys.stderr.write("[bench supervisor rank %s] attempt %d (%s) ended with code %s after %.0f s%s\n" % (
-            rank, i, name, rc, time.perf_counter() - t0, "; retrying with the serial placement" if i + 1 < len(attempts) else ""))
+        sys.stderr.write("[bench supervisor rank %s] attempt %d (%s) ended with code %s here, %s over all ranks, after %.0f s%s\n" % (
+            rank, i, name, own, rc, time.perf_counter() - t0, "; retrying with the next placement" if i + 1 < len(attempts) else ""))
         sys.stderr.flush()
     return rc or 1
 
@@ -454,8 +489,9 @@ def main():
                     "64 was the round 1-2 sample and runs 3x slower per frame (1.7 k vs 5.3 k frames/s on 16 cores: the BLAS sees a smaller M)")
     ap.add_argument("--cpu_baseline_only", action="store_true", help="print only the cpu_baseline object (e.g. --cpu_videos 256 --cpu_budget 400: "
                     "the batch SURVEY 8(d) specifies; profiles/r03_cpu_baseline_b256.json)")
-    ap.add_argument("--cpu_budget", type=float, default=64.0, help="seconds the CPU leg may take (1 warm-up + up to 3 timed iterations; "
-                    "at B = 256 on 16 cores: 17 s + 3 x 14.4 s)")
+    ap.add_argument("--cpu_threads", type=int, default=0, help="threads of the CPU leg (default: every core this process may use)")
+    ap.add_argument("--cpu_budget", type=float, default=84.0, help="seconds the CPU leg may take (1 warm-up + up to 3 timed iterations; "
+                    "at B = 256 on 16 cores: 17 s + 3 x 16 s)")
     ap.add_argument("--no_fused_moe", action="store_true", help="debug: materialise the MoE weight gradients (A/B of evc_moe_grad_update)")
     ap.add_argument("--student_forward_early", action="store_true", help="A/B: student forward next to the teacher forward")
     ap.add_argument("--no_overlap", action="store_true", help="debug: everything on one stream (solo kernel times for profiling)")
@@ -463,7 +499,7 @@ def main():
     args = ap.parse_args()
 
     if args.cpu_baseline_only:
-        print(json.dumps({"cpu_baseline": cpu_baseline(args.every_n, args.cpu_videos, args.cpu_budget)}))
+        print(json.dumps({"cpu_baseline": cpu_baseline(args.every_n, args.cpu_videos, args.cpu_budget, args.cpu_threads)}))
         return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -530,11 +566,13 @@ def main():
         _log("precision mode %s done: %.2f ms/step" % (other, r["ms_per_step"]))
         pm["bf16"]["logits_within_1e-3_of_f64_oracle"] = "at the reference's initialisation (|logit| <~ 1); ~1e-3*|logit| on trained weights"
         pm["high"]["logits_within_1e-3_of_f64_oracle"] = "also on trained-magnitude weights (tests/test_gpu_step.py)"
-        pm["high"]["what"] = ("forward operands chosen by a measured error budget (scripts/precision_budget.py, DESIGN.md 7): L1 level on IEEE f16 "
-                              "(one MFMA product per depth) plus the low-order halves of every LSTM weight - and of the input frames - as OCP e4m3 "
-                              "operands on the MX-scaled MFMA (twice the rate; EVC_HIGH_FP8_LO=0: as f16 K-extensions, round 3), activations f16; "
-                              "L2 level f16 with K-extended weights in the wavefront pair launches; student tower plain f16; MoE head "
-                              "split-bf16 (hi.hi + hi.lo + lo.hi as one K-extended launch per product); backward as in bf16")
+        pm["high"]["what"] = ("forward operands chosen by a measured error budget (scripts/precision_budget.py, DESIGN.md 7): every forward product on IEEE "
+                              "f16 operands (one MFMA product per depth) with the low-order halves of its weights as OCP e4m3 operands on the MX-scaled "
+                              "MFMA behind the f16 stages of the same launch - L1 level (evc_lstm_layer_fwd_f16_fp8lo: + the low-order half of the input "
+                              "frames), L2 level wavefront pair launches (evc_lstm_stack2_fwd_f16_fp8lo), MoE head (evc_gemm_nt_f16_fp8: both operands' "
+                              "corrections); student tower's L1 level plain f16; all operand images written by the optimizer kernels' epilogues "
+                              "(evc_lstm_adam_fused, evc_moe_grad_update_apply); backward products bf16 as in the bf16 mode")
+        pm["high"]["layout"] = r.get("high_layout") if other == "high" else head.get("high_layout")
         extra["precision_modes"] = pm
         oc = {}
         for name, kw in (("cfg2_teacher_only_b256", dict(B=256, mode="teacher", every_n=10)),
@@ -564,7 +602,7 @@ def main():
             "metric": "frames/sec (whole node) H-LSTM teacher+student B=256x300x1152; GAP@20",
             "value": head["frames_per_sec"], "unit": "frames/sec", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic", "precision_mode": args.precision,
+            "dtype": DTYPE_OF[args.precision], "data": "synthetic", "precision_mode": args.precision,
             "config": {"workload": "HierarchicalLstmModel %s every_n=%d, lstm_cells=1024x2, MoE(2), batch %d x 300 x 1152 per GPU"
                                    % (args.mode, args.every_n, B),
                        "global_batch": B * n_gpus, "frames_per_video": T_FRAMES, "parallelism": "dp%d" % n_gpus,
@@ -579,7 +617,7 @@ def main():
             res["dp"] = head["dp"]
         res.update(extra)
         if n_gpus == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.every_n, args.cpu_videos, args.cpu_budget)
+            res["cpu_baseline"] = cpu_baseline(args.every_n, args.cpu_videos, args.cpu_budget, args.cpu_threads)
         print(json.dumps(res))
     if world > 1 or one_rank_dp:
         torch.distributed.destroy_process_group()

@@ -5,7 +5,7 @@ HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="${EVC_OUT:-$HERE/../libevc_hip.so}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=default -Wno-unused-result"
-"$HIPCC" $FLAGS "$HERE/evc_gemm.hip" "$HERE/evc_elementwise.hip" "$HERE/evc_dbof.hip" "$HERE/evc_netvlad.hip" "$HERE/evc_moe_norms.hip" -o "$OUT" "$@"
+"$HIPCC" $FLAGS "$HERE/evc_gemm.hip" "$HERE/evc_elementwise.hip" "$HERE/evc_dbof.hip" "$HERE/evc_netvlad.hip" "$HERE/evc_moe_norms.hip" "$HERE/evc_optim.hip" -o "$OUT" "$@"
 echo "built $OUT"
 # Host-side input library (TFRecord / SequenceExample parsing); plain C++, no HIP.
 IO_OUT="${EVC_IO_OUT:-$HERE/../libevc_io.so}"

@@ -480,6 +480,14 @@ extern "C" int evc_dbof_cluster_pool_fwd_f16fp8(const evc_f16* r_rows, const evc
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }
+#else
+// (A/B build on the 32-wide K stages: the e4m3 tail exists in the 64-wide ring loop only.  The symbol stays exported - the ctypes
+//  table binds every entry point of include/evc.h at import - and says so when called.)
+extern "C" int evc_dbof_cluster_pool_fwd_f16fp8(const evc_f16*, const evc_f16*, const uint8_t*, int, int, int, int, int, const float*, evc_bf16*, float*,
+                                                float*, uint8_t*, void*) {
+  evc_set_error("evc_dbof_cluster_pool_fwd_f16fp8: this library was built with -DEVC_DBOF_V2_LOOP (no e4m3 stages); set EVC_HIGH_FP8_LO=0");
+  return EVC_ERR_UNSUPPORTED_ARCH;
+}
 #endif
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -73,8 +73,8 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {      // fix
   return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-// blocks [0, nbf): part[b] = sum over this block's elements of (sum_s GA_s) (sum_s GX_s)
-// blocks [nbf, nbf + nbd): part[b] = sum over this block's rows of sum_v A[r][v] (logits[r][v] - bias[v])
+// blocks [0, nbf): part[b] = sum over this block's elements of (sum_s GA_s) (sum_s GX_s)          (one element per thread at R = 256)
+// blocks [nbf, nbf + nbd): part[b] = sum over segment (b - nbf) % 4 of row (b - nbf) / 4 of A[r][v] (logits[r][v] - bias[v])
 __global__ __launch_bounds__(256) void moe_norm_partials_kernel(const float* __restrict__ ga, int SA, const float* __restrict__ gx, int SX, int R,
                                                                 const bf16_t* __restrict__ A, long lda, const float* __restrict__ logits, long ldl,
                                                                 const float* __restrict__ bias, int B, int V, int nbf, float* __restrict__ part) {
@@ -84,32 +84,42 @@ __global__ __launch_bounds__(256) void moe_norm_partials_kernel(const float* __r
   if ((int)blockIdx.x < nbf) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)nbf * 256) {
       float a = 0.f, x = 0.f;
+#pragma unroll 8
       for (int s = 0; s < SA; ++s) a += ga[(long)s * n + i];
+#pragma unroll 8
       for (int s = 0; s < SX; ++s) x += gx[(long)s * n + i];
       acc += a * x;
     }
   } else {
-    const int nbd = gridDim.x - nbf;
-    for (int r = blockIdx.x - nbf; r < B; r += nbd) {
-      const bf16_t* ar = A + (long)r * lda;
-      const float* lr = logits + (long)r * ldl;
-      for (int v = threadIdx.x; v < V; v += 256) acc += bf16_to_f32(ar[v]) * (lr[v] - (bias ? bias[v] : 0.f));
-    }
+    const int b = blockIdx.x - nbf, r = b >> 2, q = b & 3;
+    const int vq = ((V + 3) / 4 + 7) / 8 * 8;                     // columns per segment (multiple of 8: 16-byte aligned bf16 runs)
+    const int v0 = q * vq, v1 = min(V, v0 + vq);
+    const bf16_t* ar = A + (long)r * lda;
+    const float* lr = logits + (long)r * ldl;
+    for (int v = v0 + threadIdx.x; v < v1; v += 256) acc += bf16_to_f32(ar[v]) * (lr[v] - (bias ? bias[v] : 0.f));
   }
   acc = block_sum_256(acc, sh);
   if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
 
-// sums[0] += |g|^2 + 2 l2 <g, W> + l2^2 |W|^2 ; sums[1] += |W|^2 (the row layout of evc_grad_sqnorm / pass 1)
-__global__ void moe_norm_combine_kernel(const float* __restrict__ part, int nbf, int nbd, float l2, const float* __restrict__ wsq, float* __restrict__ sums) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// sums[0] += |g|^2 + 2 l2 <g, W> + l2^2 |W|^2 ; sums[1] += |W|^2 (the row layout of evc_grad_sqnorm / pass 1).  One wave; every lane
+// sums a strided share of the partials in index order, the 64 lane totals meet in a butterfly: fixed order.
+__global__ __launch_bounds__(64) void moe_norm_combine_kernel(const float* __restrict__ part, int nbf, int nbd, float l2, const float* __restrict__ wsq,
+                                                              float* __restrict__ sums) {
   double gg = 0.0, gw = 0.0;
-  for (int b = 0; b < nbf; ++b) gg += (double)part[b];
-  for (int b = 0; b < nbd; ++b) gw += (double)part[nbf + b];
-  const double w2 = (double)wsq[0];
-  const double tot = gg + 2.0 * (double)l2 * gw + (double)l2 * (double)l2 * w2;
-  sums[0] += (float)(tot > 0.0 ? tot : 0.0);
-  sums[1] += (float)w2;
+  for (int b = threadIdx.x; b < nbf; b += 64) gg += (double)part[b];
+  for (int b = threadIdx.x; b < nbd; b += 64) gw += (double)part[nbf + b];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    gg += __shfl_xor(gg, o, 64);
+    gw += __shfl_xor(gw, o, 64);
+  }
+  if (threadIdx.x == 0) {
+    const double w2 = (double)wsq[0];
+    const double tot = gg + 2.0 * (double)l2 * gw + (double)l2 * (double)l2 * w2;
+    sums[0] += (float)(tot > 0.0 ? tot : 0.0);
+    sums[1] += (float)w2;
+  }
 }
 
 extern "C" int evc_moe_grad_norms(const float* gram_a, int SA, const float* gram_x, int SX, int R, const evc_bf16* dlogits, int64_t ld_dlogits,
@@ -118,7 +128,8 @@ extern "C" int evc_moe_grad_norms(const float* gram_a, int SA, const float* gram
   EVC_REQUIRE(gram_a && gram_x && dlogits && logits && wsq && part_ws && sums, EVC_ERR_BAD_ARG, "evc_moe_grad_norms: NULL argument");
   EVC_REQUIRE(R > 0 && R % 32 == 0 && SA >= 1 && SX >= 1 && B > 0 && B <= R && V > 0 && ld_dlogits >= V && ld_logits >= V, EVC_ERR_BAD_SHAPE,
               "evc_moe_grad_norms: R=%d SA=%d SX=%d B=%d V=%d", R, SA, SX, B, V);
-  const int nbf = 64, nbd = B < 192 ? B : 192;       // part_ws: EVC_MOE_NORM_PARTS floats
+  EVC_REQUIRE(B <= 512, EVC_ERR_BAD_SHAPE, "evc_moe_grad_norms: B=%d (at most 512 batch rows; part_ws holds 256 + 4 B floats)", B);
+  const int nbf = (int)(((long)R * R / 256) < 256 ? ((long)R * R / 256) : 256), nbd = 4 * B;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(moe_norm_partials_kernel, dim3(nbf + nbd), dim3(256), 0, st, gram_a, SA, gram_x, SX, R, (const bf16_t*)dlogits, (long)ld_dlogits,
                      logits, (long)ld_logits, bias, B, V, nbf, part_ws);

@@ -175,17 +175,22 @@ class GradReducer:
         cur.wait_stream(ss)
         return out
 
-    def reduce(self, flat, lo, hi):
+    def reduce(self, flat, lo, hi, f32=True):
+        """All-reduce of flat[lo:hi] as an async c10d op, joined by wait() (the schedule without early apply).  The payload type
+        follows grad_dtype only where the caller allows it (f32=False: LSTM segments); with a bf16 payload, and under the serial
+        placement, the call goes through reduce_async (stream order) - one implementation of the dtype switch."""
         if not self.active or hi <= lo:
             return
-        if self.serial:
-            self.reduce_async(flat, lo, hi)
+        if self.serial or (self.grad_dtype == "bf16" and not f32):
+            self.reduce_async(flat, lo, hi, f32=f32)
             return
         self._pending.append(torch.distributed.all_reduce(flat[lo:hi], op=torch.distributed.ReduceOp.SUM,
                                                           group=self.pg, async_op=True))
 
-    def reduce_async(self, flat, lo, hi):
-        """All-reduce of flat[lo:hi] in stream order: issued as a *synchronous* c10d op, which ProcessGroupNCCL
+    def reduce_async(self, flat, lo, hi, f32=False):
+        """f32=True: this segment crosses the fabric as f32 whatever grad_dtype says (the MoE segment when its update is not the
+        fused one: EVC_DP_GRAD_DTYPE=bf16 is an option for the LSTM segments only).
+        All-reduce of flat[lo:hi] in stream order: issued as a *synchronous* c10d op, which ProcessGroupNCCL
         enqueues on the CURRENT stream (the RCCL kernel sits between the kernels that produce the gradients and the
         ones that consume them; the host does not wait).  An async_op=True collective runs on the process group's
         own stream instead, which shares one of the 4 hardware queues with a compute stream: its event then waits
@@ -194,7 +199,7 @@ class GradReducer:
         if not self.active or hi <= lo:
             return None
         seg = flat[lo:hi]
-        if self.grad_dtype == "bf16":
+        if self.grad_dtype == "bf16" and not f32:
             return self._reduce_bf16(seg)
         self._run(lambda: torch.distributed.all_reduce(seg, op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=False), seg,
                   kind="all_reduce_grad_f32", nbytes=seg.numel() * 4)
@@ -322,6 +327,9 @@ class DistillGraph:
     'student' (train_finetune.py)."""
 
     LOSS_SLOTS = ("label_loss", "student_loss_state", "pred_loss", "student_label_loss")
+    # host issue orders of the two towers' backward phases (HLstmTower.backward_phases: MoE head, L2 layer 1, L2 layer 0, L1 layer 1,
+    # L1 layer 0 each): letters name the tower whose next phase is issued; whatever is left afterwards is drained student first
+    ISSUE_ORDERS = {"sequential": "sssss", "interleaved": "tsstsstst"}
 
     def __init__(self, batch_size, every_n=10, mode="teacher_student", feature_size=1152, vocab_size=4716,
                  max_frames=300, num_inputs_to_lstm=20, num_inputs_l1_student=5, lstm_cells=1024, lstm_layers=2,
@@ -386,10 +394,17 @@ class DistillGraph:
         # under its L1 forward, instead of under step k's BPTT chain (HLstmTower.backward(defer=True)).  Whoever reads the
         # weights between two steps calls flush() first (state_dict() / consolidate() / apply_gradients() do).
         self.defer_updates = os.environ.get("EVC_DEFER_UPDATES", "0") == "1"
+        # one communicator for both towers (EVC_DP_SERIAL_COMM=1): issue the backward phases in readiness order, so that collectives
+        # funnelled through one stream do not wait behind the other tower's later ones; EVC_ISSUE_ORDER overrides (A/B runs)
+        self.issue_order = os.environ.get("EVC_ISSUE_ORDER", "interleaved" if (self.dp and serial_comm()) else "sequential")
+        if self.issue_order not in self.ISSUE_ORDERS:
+            raise ValueError("EVC_ISSUE_ORDER must be one of %s" % sorted(self.ISSUE_ORDERS))
         self._opt_t = self._opt_s = None
         if self.device.type == "cuda":
             # four streams that measurably overlap (streams.py); the step never runs on the default stream
             self._main, self._side, self._aux_t, self._aux_s = concurrent_streams(self.device, 4)
+            if os.environ.get("EVC_SINGLE_STREAM") == "1":     # profiling aid: the same launches, all on ONE stream (solo kernel times)
+                self._side = self._aux_t = self._aux_s = self._main
             # experiment: the optimizer launches on a CU-masked stream of their own - EVC_OPT_CU_MASK=<CUs per XCD>[:<first>]
             m = os.environ.get("EVC_OPT_CU_MASK")
             if m:
@@ -404,9 +419,9 @@ class DistillGraph:
         st = tower.store
         moe_lo = st.offsets[tower.GATES]
         if moe_first:
-            self.reducer.reduce(st.grad, moe_lo, st.total)
+            self.reducer.reduce(st.grad, moe_lo, st.total, f32=True)
         else:
-            self.reducer.reduce(st.grad, 0, moe_lo)
+            self.reducer.reduce(st.grad, 0, moe_lo, f32=False)
 
     # ---- one training iteration -----------------------------------------------
     def step(self, x_raw, labels_u8, num_frames, apply=True, num_frames_host=None):
@@ -484,7 +499,7 @@ class DistillGraph:
         # "after_l1": the student's forward starts when the teacher's L1 level is done - next to the teacher's L2 chain
         # and MoE head (small launches), not next to its L1 steps (the roofline kernel keeps the chip to itself)
         mid_student = two_streams and not early_student and self.student_forward_after_l1 and self.teacher is not None and need_student
-        s_state = s_pred = n_s = l1s = l2s = plan_s = None
+        s_state = s_pred = n_s = l1s = l2s = plan_s = gen_s = early_s = None
         if need_student and early_student:
             # The student's forward needs only its own inputs and weights: it starts right away, next to the
             # teacher's forward (whose L2 / MoE tail is a chain of small launches that leaves most CUs idle);
@@ -533,17 +548,42 @@ class DistillGraph:
                                      grad_scale=sc["kl"], accumulate_grad=True)
                     ops.rep_loss(t_state, s_state, self.losses[1:2], self._ds_s, grad_scale=self.rep_w * sc["rep"])
                     ds = self._ds_s
-                early = (lr, self.clip, l2c) if (apply and self.overlap_towers and self._aux_s is not None) else None
+                early_s = (lr, self.clip, l2c) if (apply and self.overlap_towers and self._aux_s is not None) else None
                 st_s = self.student.store
-                self.student.backward(ds, self._dp_s,
-                                      on_moe_grads_ready=None if early else (lambda: self._reduce_tower(self.student, True)),
-                                      aux=self._aux_s if self.overlap_towers else None, early_apply=early,
-                                      reduce_fn=(lambda lo, hi: self.reducer_s.reduce_async(st_s.grad, lo, hi)) if (early and self.dp) else None,
-                                      dp=self.reducer_s if (early and self.dp) else None, defer=self.defer_updates and not self.dp,
-                                      opt=self._opt_s)
-                if not early:
+                gen_s = self.student.backward_phases(
+                    ds, self._dp_s, on_moe_grads_ready=None if early_s else (lambda: self._reduce_tower(self.student, True)),
+                    aux=self._aux_s if self.overlap_towers else None, early_apply=early_s,
+                    reduce_fn=(lambda lo, hi, f32=False: self.reducer_s.reduce_async(st_s.grad, lo, hi, f32=f32)) if (early_s and self.dp) else None,
+                    dp=self.reducer_s if (early_s and self.dp) else None, defer=self.defer_updates and not self.dp, opt=self._opt_s)
+        gen_t = None
+        if self.teacher is not None:
+            # weight-gradient GEMMs and the per-group clip+Adam go to an aux stream, under the BPTT chain
+            # (the tower's outputs t_state / t_pred are separate buffers, untouched by the update)
+            early_t = (lr, self.clip, l2c) if (apply and self.overlap_towers and self._aux_t is not None) else None
+            st_t = self.teacher.store
+            gen_t = self.teacher.backward_phases(
+                None, self._dp_t, on_moe_grads_ready=None if early_t else (lambda: self._reduce_tower(self.teacher, True)),
+                aux=self._aux_t if self.overlap_towers else None, early_apply=early_t,
+                reduce_fn=(lambda lo, hi, f32=False: self.reducer.reduce_async(st_t.grad, lo, hi, f32=f32)) if (early_t and self.dp) else None,
+                dp=self.reducer if (early_t and self.dp) else None, defer=self.defer_updates and not self.dp, opt=self._opt_t)
+        # Host issue order of the two backward passes (same launches, same streams, same results): "sequential" = the student's
+        # whole backward, then the teacher's; "interleaved" = phase by phase in the order in which the phases become ready on the
+        # GPU (measured timeline, profiles/r04_timeline_default.txt) - what a ONE-communicator placement of the collectives needs
+        # so that no tower's early collective queues behind the other tower's late one.
+        gens = {"s": (gen_s, side), "t": (gen_t, main)}
+        live = {k for k, (g_, _) in gens.items() if g_ is not None}
+        order = self.ISSUE_ORDERS[self.issue_order] if (gen_s is not None and gen_t is not None) else ""
+        for who in list(order) + ["s"] * 8 + ["t"] * 8:
+            if who in live:
+                g_, st_ = gens[who]
+                with torch.cuda.stream(st_):
+                    if next(g_, self) is self:         # exhausted
+                        live.discard(who)
+        if need_student:
+            with torch.cuda.stream(side):
+                if not early_s:
                     self._reduce_tower(self.student, False)
-                self._student_applied = early is not None
+                self._student_applied = early_s is not None
                 mark("student_done", side)
                 if two_streams:
                     self._ev_student.record(side)
@@ -556,21 +596,11 @@ class DistillGraph:
             out.update(student_predictions=s_pred, student_state=s_state, num_frames_student=n_s,
                        student_loss_state=self.losses[1], pred_loss=self.losses[2], student_label_loss=self.losses[3])
         if self.teacher is not None:
-            # weight-gradient GEMMs and the per-group clip+Adam go to an aux stream, under the BPTT chain
-            # (the tower's outputs t_state / t_pred are separate buffers, untouched by the update)
-            early = (lr, self.clip, l2c) if (apply and self.overlap_towers and self._aux_t is not None) else None
-            st_t = self.teacher.store
-            self.teacher.backward(None, self._dp_t,
-                                  on_moe_grads_ready=None if early else (lambda: self._reduce_tower(self.teacher, True)),
-                                  aux=self._aux_t if self.overlap_towers else None, early_apply=early,
-                                  reduce_fn=(lambda lo, hi: self.reducer.reduce_async(st_t.grad, lo, hi)) if (early and self.dp) else None,
-                                  dp=self.reducer if (early and self.dp) else None, defer=self.defer_updates and not self.dp,
-                                  opt=self._opt_t)
-            if not early:
+            if not early_t:
                 self._reduce_tower(self.teacher, False)
             mark("teacher_bwd_done", main)
             out.update(predictions=t_pred, teacher_state=t_state, loss=self.losses[0])
-            self._teacher_applied = early is not None
+            self._teacher_applied = early_t is not None
         if two_streams:
             main.wait_event(self._ev_student)
         self.reducer.wait()

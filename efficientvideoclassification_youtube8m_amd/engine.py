@@ -40,6 +40,15 @@ def _align(n, a=16):
     return (n + a - 1) // a * a
 
 
+def _drain(gen):
+    """Run a generator to its end and return its return value."""
+    try:
+        while True:
+            next(gen)
+    except StopIteration as e:
+        return e.value
+
+
 class ParamStore:
     """Flat f32 master / grad / adam-m / adam-v buffers with named views."""
 
@@ -333,7 +342,15 @@ class LstmStack:
     fuse_wgrad = os.environ.get("EVC_NO_FUSED_WGRAD") != "1"
 
     def backward(self, dS, need_dx, aux=None, on_layer_grads=None):
-        """dS [M, 2LH] f32.  Writes the grads of this stack's kernels/biases into the tower's grad
+        """backward_layers run to its end; returns dX (or None)."""
+        return _drain(self.backward_layers(dS, need_dx, aux, on_layer_grads))
+
+    def backward_layers(self, dS, need_dx, aux=None, on_layer_grads=None):
+        """GENERATOR form of backward(): yields the layer index after each layer's launches have been enqueued (upper layer first)
+        and returns dX through StopIteration - a caller can issue other work between two layers (DistillGraph interleaves the host
+        issue of the two towers' backward passes this way).  Every resumption must happen under the stream context of the first.
+
+        dS [M, 2LH] f32.  Writes the grads of this stack's kernels/biases into the tower's grad
         buffer; returns dX [T*M, Kin] f32 (gradient wrt the stack input) if need_dx.
         aux: optional side stream for the weight-gradient products, which nothing on the BPTT
         critical path waits for; the caller joins it before using the gradients.
@@ -446,6 +463,7 @@ class LstmStack:
                 if deferred is not None and l == 0:
                     for ll in deferred:
                         user_cb(ll)
+            yield l
         return dx_out
 
 
@@ -483,6 +501,14 @@ class MoeHead:
             self.del_full = torch.zeros((self.Br, ops.round_up(V * Mx, 64)), dtype=BF16, device=dev)
             self.dgl, self.del_ = self.dgl_full[:B], self.del_full[:B]
             self.partial_ws = torch.empty(2 * ((V * (Mx + 1) + 127) // 128) * ((K + 127) // 128), dtype=F32, device=dev)
+            # Gram-matrix clip norms (ops.moe_grad_norms): K slabs of [Br][Br] f32 for dlogits (reused by both matrices) and x,
+            # per-block partial sums, and the carried |W|^2 of the two matrices (wsq[i] = {|W|^2, 0}; valid flags below)
+            self.gram_S = {"a": max(1, min(16, self.dgl_full.shape[1] // 32 // 16)), "x": max(1, min(8, K // 32 // 16))}
+            self.gram_a = torch.empty(self.gram_S["a"] * self.Br * self.Br, dtype=F32, device=dev) if self.Br <= 512 else None
+            self.gram_x = torch.empty(self.gram_S["x"] * self.Br * self.Br, dtype=F32, device=dev) if self.Br <= 512 else None
+            self.norm_part = torch.empty(256 + 4 * self.Br, dtype=F32, device=dev)
+            self.wsq = torch.zeros((2, 2), dtype=F32, device=dev)
+            self._wsq_valid = [False, False]
             self.dglT = torch.empty((V * (Mx + 1), self.Bp), dtype=BF16, device=dev)
             self.delT = torch.empty((V * Mx, self.Bp), dtype=BF16, device=dev)
             self.xT = torch.empty((K, self.Bp), dtype=BF16, device=dev)
@@ -533,6 +559,14 @@ class MoeHead:
         return (self.V * (self.Mx + 1)) % 4 == 0 and (self.V * self.Mx) % 4 == 0 and self.K % 8 == 0
 
     FUSE_MAX_ROWS = int(os.environ.get("EVC_MOE_FUSE_MAX_ROWS", "512"))
+    # one process: the clip norm of the fused update from Gram matrices of the factors instead of a pass over the weights
+    # (csrc/evc_moe_norms.hip; EVC_MOE_GRAM_NORMS=0: the two-pass form)
+    gram_norms = os.environ.get("EVC_MOE_GRAM_NORMS", "1") != "0"
+
+    def invalidate_norm_cache(self):
+        """The carried |W|^2 no longer describes the weights (they were written by something other than the fused update)."""
+        if hasattr(self, "_wsq_valid"):
+            self._wsq_valid = [False, False]
 
     def prefer_fused_update(self, data_parallel):
         """The fused update recomputes the rank-B gradient tile in both of its passes: 2 x 2 B V K flops against the 46 - 30
@@ -604,10 +638,31 @@ class MoeHead:
                 hi = tw.precision != "bf16"                 # the non-bf16 forward's operand images come out of the same epilogue
                 wide = getattr(tw, "shadow_w", {}).get(name) if hi else None             # "split": [hi | lo]
                 w16, w8 = (getattr(tw, "shadow_w16", {}).get(name), getattr(tw, "shadow_w8", {}).get(name)) if hi else (None, None)   # "high": f16 + e4m3
-                ops.moe_grad_update(dlog, x, rows, Vn, K, pw, mw, vw, tw.shadow_fwd[name], tw.shadow_bwd[name], l2,
-                                    tw.sums[idx[name]], self.partial_ws, clip_norm, lr_t, beta1, beta2, eps, p_wide=wide, p_f16=w16, p_fp8=w8)
+                if self.gram_norms and self.gram_a is not None:
+                    # clip norm from the Gram matrices of the factors + the forward logits + the carried |W|^2: no pass over W
+                    # (csrc/evc_moe_norms.hip), then the update pass alone
+                    i = 0 if name == self.GATES else 1
+                    if not self._wsq_valid[i]:
+                        self.wsq[i].zero_()
+                        ops.grad_sqnorm(pw, None, 0.0, self.wsq[i])
+                        self._wsq_valid[i] = True
+                    if i == 0:
+                        ops.gram_slabs(x, rows, K, self.gram_S["x"], self.gram_x)
+                    Sa = max(1, min(self.gram_S["a"], dlog.shape[1] // 32 // 8))
+                    ops.gram_slabs(dlog, rows, dlog.shape[1], Sa, self.gram_a)
+                    logits = self.gate_logits if i == 0 else self.expert_logits
+                    ops.moe_grad_norms(self.gram_a, Sa, self.gram_x, self.gram_S["x"], rows, dlog, logits,
+                                       None if i == 0 else st.p(self.EBIAS), self.B, Vn, l2, self.wsq[i], self.norm_part, tw.sums[idx[name]])
+                    ops.moe_grad_update_apply(dlog, x, rows, Vn, K, pw, mw, vw, tw.shadow_fwd[name], tw.shadow_bwd[name], l2,
+                                              tw.sums[idx[name]], self.partial_ws, clip_norm, lr_t, self.wsq[i], beta1, beta2, eps,
+                                              p_wide=wide, p_f16=w16, p_fp8=w8)
+                else:
+                    ops.moe_grad_update(dlog, x, rows, Vn, K, pw, mw, vw, tw.shadow_fwd[name], tw.shadow_bwd[name], l2,
+                                        tw.sums[idx[name]], self.partial_ws, clip_norm, lr_t, beta1, beta2, eps, p_wide=wide, p_f16=w16, p_fp8=w8)
+                    self._wsq_valid = [False, False]
                 refreshed_wide = refreshed_wide or wide is not None or w16 is not None
                 continue
+            self._wsq_valid = [False, False]
             slab = self.slab[name]
             v0 = dp.rank * slab
             vs = min(Vn, v0 + slab) - v0                                   # rows of this rank's slab (<= 0: none)
@@ -689,6 +744,14 @@ class TowerBase:
             self._high_alloc = precision
             self._alloc_high_shadows()
         self.refresh_shadows()
+        import logging
+        logging.getLogger("evc").info("%s: precision layout %s", getattr(self, "scope", type(self).__name__), self.precision_layout())
+
+    def precision_layout(self):
+        """The RESOLVED forward-operand layout of this tower (what the EVC_HIGH_* environment and the tower's shape made of
+        `precision`): logged by set_precision, reported by bench.py and stored with checkpoints - two processes with different
+        environments compute different forwards from the same weights and flags."""
+        return {"precision": self.precision}
 
     def _alloc_high_shadows(self):
         """Default: every 2-D weight gets a separate low-order bf16 shadow (hi.hi + hi.lo + lo.hi as three products)."""
@@ -700,6 +763,8 @@ class TowerBase:
         ops.cast_bf16_split(self.store.p(k), self.shadow_fwd[k], self.shadow_lo[k])
 
     def refresh_shadows(self, fwd=True):
+        if getattr(self, "moe", None) is not None:
+            self.moe.invalidate_norm_cache()             # (called whenever the f32 masters were written from outside)
         for k in self.shadow_fwd:
             p = self.store.p(k)
             if self.precision != "bf16":
@@ -775,27 +840,56 @@ class TowerBase:
         the next begin_update() has already bumped the step count)."""
         if lr_t is None:
             lr_t = self.adam_lr_t(lr, beta1, beta2)
+        if getattr(self, "moe", None) is not None and (MoeHead.GATES in names or MoeHead.EXPERTS in names):
+            self.moe.invalidate_norm_cache()
         idx = {k: i for i, k in enumerate(self.names)}
-        for k in names:
+        # LSTM layers: kernel + bias in two launches with every operand image written from the update pass (ops.lstm_adam_fused)
+        done = set()
+        if self.fused_lstm_adam and refresh:
+            st = self.store
+            for k in names:
+                if not k.endswith("basic_lstm_cell/kernel"):
+                    continue
+                b = k[:-len("kernel")] + "bias"
+                img = self._adam_images(k)
+                if b not in names or k not in self.shadow_bwd or img is None or self.store.shapes[k][0] % 64:
+                    continue
+                if not hasattr(self, "_sqn_ws"):
+                    self._sqn_ws = {}
+                ws = self._sqn_ws.setdefault(k, torch.empty(1028, dtype=F32, device=self.device))      # (one per layer: launches of different layers may overlap)
+                ops.lstm_adam_fused(st.p(k), st.g(k), st.view(st.m, k), st.view(st.v, k), st.p(b), st.g(b), st.view(st.m, b), st.view(st.v, b),
+                                    ws, self.sums[idx[k]], self.sums[idx[b]], clip_norm, lr_t, self.shadow_fwd[k], self.shadow_bwd[k],
+                                    beta1, beta2, eps, **img)
+                done.update((k, b))
+        rest = [k for k in names if k not in done]
+        for k in rest:
             l2 = l2_coeff if k in self.l2_names else 0.0
             # (tensors without a regulariser: the norm pass reads the gradient only)
             ops.grad_sqnorm(self.store.g(k), self.store.p(k) if k in self.l2_names else None, l2, self.sums[idx[k]])
-        for k in names:
+        for k in rest:
             l2 = l2_coeff if k in self.l2_names else 0.0
             ops.clip_adam_step(self.store.p(k), self.store.g(k), self.store.view(self.store.m, k),
                                self.store.view(self.store.v, k), l2, self.sums[idx[k]], clip_norm, lr_t, beta1, beta2, eps,
                                p_bf16=self.shadow_fwd.get(k))
         if self.precision != "bf16":
-            for k in names:
+            for k in rest:
                 if k in self.shadow_fwd:
                     self._refresh_high(k)
         if refresh:
-            for k in names:
+            for k in rest:
                 if k in self.shadow_bwd:
                     # from the bf16 forward shadow Adam just wrote (same rounding, half the bytes of the f32 master)
                     p, sb = self.shadow_fwd[k], self.shadow_bwd[k]
                     il = p.shape[0] // 4 if k.endswith("basic_lstm_cell/kernel") else 0
                     ops.transpose_to_bf16(p, p.shape[0], p.shape[1], sb, sb.shape[1], interleave_H=il)
+
+    fused_lstm_adam = os.environ.get("EVC_FUSED_LSTM_ADAM", "1") != "0"     # A/B: 0 = grad_sqnorm / clip_adam / transpose / cast launches per tensor
+
+    def _adam_images(self, k):
+        """Keyword arguments of ops.lstm_adam_fused describing the non-bf16 forward operand images of LSTM kernel k that the update pass
+        writes itself ({} in bf16), or None when this tower's layout for k has an image the fused pass does not write (the per-tensor
+        launches + _refresh_high run instead)."""
+        return {} if self.precision == "bf16" else None
 
     def apply_gradients(self, lr, clip_norm=1.0, l2_coeff=0.0, beta1=0.9, beta2=0.999, eps=1e-8):
         self.begin_update()
@@ -960,6 +1054,58 @@ class HLstmTower(TowerBase):
         else:
             ops.cast_bf16_wide(p, self.shadow_w[k], lo_first=False)
 
+    def precision_layout(self):
+        d = {"precision": self.precision}
+        if self.precision == "high":
+            d.update(l1="f16 + e4m3 low-order halves (weights, input frames)" if self.fp8_lo() else
+                     "f16, x segments %d, Wh extended in layers %s, Wx extended in layers %s" % (self.f16_x_segments, list(self.f16_wh_ext_layers), list(self.f16_wx_ext_layers)),
+                     l2=("f16 + e4m3 low-order halves, %d input segments" % self.f16_l2_x_segments) if any(k.startswith("RNN_L2/") for k in getattr(self, "shadow8", {}))
+                     else ("f16 K-extensions, %d input segments, h0_ext %s" % (self.f16_l2_x_segments, self.f16_l2_h0_ext) if self.L == 2 else "split-bf16"),
+                     moe="f16 + e4m3 corrections of both operands" if getattr(self, "shadow_w8", None) else "split-bf16 K-extension",
+                     fp8_scales=dict(w_lo_exp=ops.FP8_W_SCALE_EXP, wx_hi_exp=ops.FP8_WX_HI_EXP, **ops.FP8_MOE))
+        return d
+
+    def fp8_saturation(self, state=None):
+        """Validation aid for the "high" mode's FIXED e4m3 scales (ops.FP8_*): how many operand elements lie outside the range that
+        never clamps - their low-order correction is (partly) lost and the 1e-3 contract degrades without any other signal.
+        Counts weights of the L1 / L2 levels with |W| >= 4 (lo scale 2^17: |W - f16(W)| 2^17 <= 448), MoE weights with |W| >= 3.5
+        (2^7) and, given `state` [B, K] (the head's input of a batch), its elements with |s| >= 7 (2^6; the cell-state half of the
+        L2 state is unbounded).  Returns {name: count}; all zeros means the contract's assumptions hold.  (Diagnostic: plain
+        tensor reductions, one host sync.)"""
+        out = {}
+        if self.precision != "high":
+            return out
+        lim_w = 448.0 / 2.0 ** (ops.FP8_W_SCALE_EXP - 12 + 3)             # |W - f16(W)| <= 2^-11 |W| (half an ulp of 11 bits): 448 / 2^17 * 2^11 = 7 -> keep the documented 4
+        for k in list(getattr(self, "shadow8", {})):
+            out[k] = int((self.store.p(k).abs() >= min(4.0, lim_w * 8)).sum())
+        for k in list(getattr(self, "shadow_w8", {})):
+            out[k] = int((self.store.p(k).abs() >= 448.0 / 2.0 ** ops.FP8_MOE["w_hi_exp"]).sum())
+        if state is not None and getattr(self, "shadow_w8", None):
+            out["moe_input_state"] = int((state.abs() >= 448.0 / 2.0 ** ops.FP8_MOE["x_hi_exp"]).sum())
+        return out
+
+    def _adam_images(self, k):
+        """The "high" layouts ops.lstm_adam_fused writes from the update pass - what _refresh_high(k) would produce: L1 level f16 + e4m3
+        low-order halves (layer 0: + the full-value image of Wx), L2 level f16 (layer 0: K-extended input blocks) + e4m3 low-order
+        halves, and plain / x-extended f16 images without a recurrent extension.  None for the others (f16 K-extensions of the
+        recurrent weights, split-bf16): they keep their cast launches."""
+        if self.precision == "bf16":
+            return {}
+        p, H = self.store.p(k), self.H
+        nin = p.shape[1] - H
+        if k in self.shadow8 and k.startswith("RNN_L2/"):
+            if "cell_0" in k:
+                return dict(p_f16=self.shadow16[k], nin=nin, nseg=self.f16_l2_x_segments, p_fp8=self.shadow8[k], fp8_col0=nin, fp8_hi_cols=0)
+            return dict(p_f16=self.shadow16[k], nin=nin, nseg=1, p_fp8=self.shadow8[k], fp8_col0=0, fp8_hi_cols=0)
+        if k in self.shadow8:
+            return dict(p_f16=self.shadow16[k], nin=nin, nseg=1, p_fp8=self.shadow8[k], fp8_col0=0, fp8_hi_cols=self.shadow8[k].shape[1] - p.shape[1])
+        if k in self.shadow16 and k.startswith("RNN_L1/"):
+            layer = int(k.split("cell_")[1].split("/")[0])
+            if layer not in self.f16_wh_ext_layers and not (layer > 0 and layer in self.f16_wx_ext_layers):
+                nseg = (self.shadow16[k].shape[1] - H) // nin
+                return dict(p_f16=self.shadow16[k], nin=nin, nseg=nseg)
+        return None
+
     # ---- parameters -------------------------------------------------------
     def _init_params(self, seed):
         """TF defaults at the reference call sites: glorot-uniform kernels /
@@ -1057,9 +1203,22 @@ class HLstmTower(TowerBase):
 
     fused_moe_update = True      # recompute the rank-B MoE gradient inside the Adam step instead of materialising it
     _deferred, _deferred_ev, _deferred_aux = (), None, None    # backward(defer=True): closures / event / stream of the pending updates
+    # experiment: the fused MoE update enqueued behind the L2 level's BPTT chain + weight gradients instead of in front of them
+    # (its 80 / 48 KB workgroups hold the LDS the skinny chain kernels of the critical path are waiting for)
+    moe_update_after_l2 = os.environ.get("EVC_MOE_UPDATE_AFTER_L2") == "1"
 
-    def backward(self, dstate, dpred, on_moe_grads_ready=None, aux=None, early_apply=None, reduce_fn=None, dp=None, defer=False, opt=None):
-        """dstate [B,2LH] f32 or None (gradient on the returned state), dpred [B,V] f32.
+    def backward(self, *args, **kwargs):
+        """backward_phases run to its end."""
+        _drain(self.backward_phases(*args, **kwargs))
+
+    def backward_phases(self, dstate, dpred, on_moe_grads_ready=None, aux=None, early_apply=None, reduce_fn=None, dp=None, defer=False, opt=None):
+        """GENERATOR: yields after the MoE head's backward (+ its update / collectives) and after every LSTM layer of the L2 and L1
+        levels (upper layer first) have been enqueued - five phase boundaries at which DistillGraph can switch to the other tower, so
+        that the HOST issue order of both towers' launches and collectives follows the order in which they become ready on the GPU
+        (one-communicator placement under data parallelism: DESIGN.md 6.1).  Every resumption must happen under the same current
+        stream as the first.
+
+        dstate [B,2LH] f32 or None (gradient on the returned state), dpred [B,V] f32.
         Fills self.store.grad (every segment is overwritten).
         aux: side stream that takes the weight-gradient GEMMs (and, with early_apply =
         (lr, clip, l2_coeff), the clip+Adam of each variable group as soon as its gradients are final)
@@ -1085,9 +1244,9 @@ class HLstmTower(TowerBase):
         g_moe, g_l2, g_l1 = self.param_groups()
         seg_moe, seg_l2, seg_l1 = self.grad_segments()
 
-        def reduce_then_apply(names, seg):
+        def reduce_then_apply(names, seg, f32=False):
             if reduce_fn is not None:
-                h = reduce_fn(*seg)
+                h = reduce_fn(*seg, f32) if f32 else reduce_fn(*seg)
                 if h is not None:
                     h.wait()                                           # the aux stream waits for the collective, not the host
             self.apply_group(names, *early_apply)
@@ -1107,6 +1266,7 @@ class HLstmTower(TowerBase):
         if aux is None or early_apply is None:
             opt = None
         ostream = opt if opt is not None else aux
+        late_moe = None
         if aux is not None and early_apply is not None:
             self.begin_update()
             ev = torch.cuda.Event()
@@ -1123,14 +1283,19 @@ class HLstmTower(TowerBase):
                 else:
                     self._deferred.append(lambda: self.apply_group(g_moe, *early_apply, lr_t=lr_t_now))
             else:
-                with torch.cuda.stream(ostream):                       # 2/3 of the parameters, under the LSTM BPTT
-                    ops.mark(self.scope + ":moe_update_begin")
-                    if fuse:
-                        lr, clip, l2c = early_apply
-                        self.moe.fused_update(lr_t_now, clip, l2c, dp=dp)
-                    else:
-                        reduce_then_apply(g_moe, seg_moe)
-                    ops.mark(self.scope + ":moe_update_done")
+                def moe_update_now():
+                    with torch.cuda.stream(ostream):                   # 2/3 of the parameters, under the LSTM BPTT
+                        ops.mark(self.scope + ":moe_update_begin")
+                        if fuse:
+                            lr, clip, l2c = early_apply
+                            self.moe.fused_update(lr_t_now, clip, l2c, dp=dp)
+                        else:
+                            reduce_then_apply(g_moe, seg_moe, f32=True)    # (a bf16 gradient payload is for the LSTM segments only)
+                        ops.mark(self.scope + ":moe_update_done")
+                if self.moe_update_after_l2 and dp is None:
+                    late_moe = moe_update_now                          # (experiment: behind the L2 level's BPTT chain, see below)
+                else:
+                    moe_update_now()
         # Per LAYER: as soon as a layer's weight-gradient products are enqueued on the aux stream its kernel + bias gradients are
         # final there - reduce (data parallel) and clip + Adam them right behind, under the BPTT of the layer below.  Only the
         # LOWEST layer of the L1 level is left for the end of the step (round 3; before, a level's four tensors waited for its
@@ -1160,9 +1325,12 @@ class HLstmTower(TowerBase):
                     ops.mark("%s:%s_adam%d_done" % (self.scope, stack.scope, l))
             return cb if per_layer else None
 
-        dS1 = self.l2.backward(dS2, need_dx=True, aux=aux, on_layer_grads=layer_cb(self.l2, defer))   # [C*B][2LH] = d(L1 final state)
+        yield "moe"
+        dS1 = yield from self.l2.backward_layers(dS2, need_dx=True, aux=aux, on_layer_grads=layer_cb(self.l2, defer))   # [C*B][2LH] = d(L1 final state)
         ops.mark(self.scope + ":l2_bwd_done")
-        self.l1.backward(dS1, need_dx=False, aux=aux, on_layer_grads=layer_cb(self.l1))
+        if late_moe is not None:
+            late_moe()
+        yield from self.l1.backward_layers(dS1, need_dx=False, aux=aux, on_layer_grads=layer_cb(self.l1))
         ops.mark(self.scope + ":l1_bwd_done")
         if aux is not None:
             ev = torch.cuda.Event()

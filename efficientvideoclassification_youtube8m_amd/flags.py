@@ -81,7 +81,11 @@ _define("synthetic_videos", 2048, int, "videos per epoch when train_data_pattern
 _define("teacher_only", False, _bool, "HierarchicalLstmModel: train the teacher tower alone (BASELINE cfg 2; the reference "
         "always builds the student too, also at every_n=1)")
 _define("precision", "bf16", str, "'bf16' (one bf16 MFMA product per forward contraction), 'high' (holds 1e-3 on logits at trained "
-        "magnitudes: f16 operands for the L1 level with a K-extended input part, split-bf16 for the L2 level and the MoE head) or "
+        "magnitudes: every forward product on IEEE f16 operands with the low-order halves of its weights - for the L1 level also of the input "
+        "frames, for the MoE head of both operands - as OCP e4m3 operands on the MX-scaled MFMA behind the f16 stages of the same launch; "
+        "fixed power-of-two e4m3 scales: |x|, |h| <= 1, |W| < 4, head input |state| < 7, head weights |W| < 3.5 never clamp, larger values "
+        "saturate at 448 and only lose their correction - engine.HLstmTower.fp8_saturation() counts them; the resolved layout depends on "
+        "the EVC_HIGH_* environment and on the student's length and is logged / checkpointed as `precision_layout`) or "
         "'split' (split-bf16 operands, f32-operand accuracy, in every forward GEMM)")
 _define("netvlad_cluster_size", 64, int, "NetVLADModel (extension): number of clusters")
 _define("netvlad_hidden_size", 1024, int, "NetVLADModel (extension): width of the hidden layer after the aggregation")

@@ -423,6 +423,29 @@ def moe_grad_update(dlogits, x, rows, V, K, p, m, v, p_bf16, pT_bf16, l2_coeff, 
               phase, _stream())
 
 
+def gram_slabs(A, R, Kc, S, slabs):
+    """slabs[s] [R][R] f32 = A[:, slab s] . A[:, slab s]^T over S slabs of the first Kc columns of A (bf16, evc_gram_slabs)."""
+    assert A.dtype == BF16 and slabs.dtype == F32 and slabs.numel() >= S * R * R
+    _lib.call("evc_gram_slabs", _p(A), A.stride(0), R, Kc, S, _p(slabs), _stream())
+
+
+def moe_grad_norms(gram_a, SA, gram_x, SX, R, dlogits, logits, bias, B, V, l2_coeff, wsq, part_ws, sums):
+    """sums[0] += |dlogits^T x + l2 W|^2 from the two Gram matrices, the forward logits and the carried |W|^2 (evc_moe_grad_norms);
+    sums[1] += |W|^2."""
+    assert part_ws.numel() >= 256 + 4 * B and logits.dtype == F32
+    _lib.call("evc_moe_grad_norms", _p(gram_a), SA, _p(gram_x), SX, R, _p(dlogits), dlogits.stride(0), _p(logits), logits.stride(0),
+              _p(bias), B, V, l2_coeff, _p(wsq), _p(part_ws), _p(sums), _stream())
+
+
+def moe_grad_update_apply(dlogits, x, rows, V, K, p, m, v, p_bf16, pT_bf16, l2_coeff, sums, partial_ws, clip_norm, lr_t, wsq_out,
+                          beta1=0.9, beta2=0.999, eps=1e-8, p_wide=None, p_f16=None, p_fp8=None):
+    """The update pass of evc_moe_grad_update alone (clip scale from sums[0]) + wsq_out[0] = sum of the new weights squared."""
+    assert (p_f16 is None) == (p_fp8 is None)
+    _lib.call("evc_moe_grad_update_apply", _p(dlogits), dlogits.stride(0), _p(x), x.stride(0), rows, V, K, _p(p), _p(m), _p(v),
+              _p(p_bf16), _p(pT_bf16), pT_bf16.stride(0), _p(p_wide), _p(p_f16), _p(p_fp8), FP8_MOE["w_lo_exp"], FP8_MOE["w_hi_exp"],
+              l2_coeff, _p(sums), _p(partial_ws), clip_norm, lr_t, beta1, beta2, eps, _p(wsq_out), _stream())
+
+
 def ce_loss(pred, labels_u8, loss, dpred=None, grad_scale=1.0, accumulate_grad=False):
     B, V = pred.shape
     _lib.call("evc_ce_loss", _p(pred), _p(labels_u8), B, V, grad_scale, _p(loss), _p(dpred), 1 if accumulate_grad else 0, _stream())
@@ -441,6 +464,21 @@ def rep_loss(state_t, state_s, loss, dstate_s=None, grad_scale=1.0, accumulate_g
 
 def grad_sqnorm(g, p, l2_coeff, sums):
     _lib.call("evc_grad_sqnorm", _p(g), _p(p), l2_coeff, g.numel(), _p(sums), _stream())
+
+
+def lstm_adam_fused(p, g, m, v, pb, gb, mb, vb, part_ws, sums_w, sums_b, clip_norm, lr_t, p_bf16, pT_bf16, beta1=0.9, beta2=0.999, eps=1e-8,
+                    p_f16=None, nin=0, nseg=1, p_fp8=None, fp8_col0=0, fp8_hi_cols=0, fp8_lo_exp=FP8_W_SCALE_EXP, fp8_hi_exp=FP8_WX_HI_EXP):
+    """Clip + TF-Adam of one LSTM layer's kernel p [4H][C] and bias pb [4H] with every operand image of the new kernel written from the same
+    pass (evc_sqnorm2_partials + evc_lstm_adam_fused): bf16 forward shadow, gate-interleaved transposed bf16 backward shadow, and in "high"
+    precision the f16 image (cast_f16 / cast_f16_wide without h_ext) and the e4m3 low-order image (cast_fp8_lo of the columns from fp8_col0)."""
+    R, C = p.shape
+    assert R % 64 == 0 and p.is_contiguous() and g.is_contiguous() and part_ws.numel() >= 1025 and pT_bf16.shape[0] == C
+    assert p_f16 is None or (p_f16.dtype == F16 and p_f16.shape == (R, nseg * nin + (C - nin)) and p_f16.is_contiguous())
+    assert p_fp8 is None or (p_fp8.dtype == torch.uint8 and p_fp8.shape == (R, C - fp8_col0 + fp8_hi_cols) and p_fp8.is_contiguous())
+    _lib.call("evc_sqnorm2_partials", _p(g), g.numel(), _p(gb), gb.numel(), _p(part_ws), _stream())
+    _lib.call("evc_lstm_adam_fused", _p(p), _p(g), _p(m), _p(v), _p(pb), _p(gb), _p(mb), _p(vb), R // 4, C, _p(part_ws), _p(sums_w), _p(sums_b),
+              clip_norm, lr_t, beta1, beta2, eps, _p(p_bf16), _p(pT_bf16), pT_bf16.stride(0), _p(p_f16), p_f16.stride(0) if p_f16 is not None else 0,
+              nin, nseg, _p(p_fp8), p_fp8.stride(0) if p_fp8 is not None else 0, fp8_col0, fp8_hi_cols, fp8_lo_exp, fp8_hi_exp, _stream())
 
 
 def clip_adam_step(p, g, m, v, l2_coeff, sums, clip_norm, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, p_bf16=None):

@@ -45,7 +45,11 @@ def concurrent_streams(device, count=4, candidates=12, chain=24, verbose=False):
     with torch.cuda.device(device):
         mk = lambda *s: torch.zeros(*s, device=device, dtype=torch.bfloat16)
         bufs = [(mk(1024, 4096), mk(1024, 4096), torch.empty(1024, 1024, device=device)) for _ in range(2)]
-        cand = [torch.cuda.Stream(device) for _ in range(candidates)]
+        # EVC_MAIN_PRIORITY=1 (experiment): the first stream - the training graph's main stream, which carries the teacher's
+        # chain - is created with high priority, so its workgroups are dispatched ahead of the side streams' waiting ones
+        import os
+        hi = os.environ.get("EVC_MAIN_PRIORITY") == "1"
+        cand = [torch.cuda.Stream(device, priority=-1 if (hi and i == 0) else 0) for i in range(candidates)]
         _timed([cand[0]], bufs, 4)                                        # warm-up (module load, clocks)
         single = min(_timed([cand[0]], bufs, chain) for _ in range(2))
         kept, report = [cand[0]], []

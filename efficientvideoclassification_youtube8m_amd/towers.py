@@ -26,9 +26,9 @@ def _maybe_allreduce(t, group):
     if torch.distributed.is_available() and torch.distributed.is_initialized() and \
             torch.distributed.get_world_size(group) > 1:
         from .distill import GradReducer                     # (distill imports this module's towers lazily too)
-        red = _reducers.get(id(group))
-        if red is None:
-            red = _reducers[id(group)] = GradReducer(group)
+        red = _reducers.get(group)               # keyed by the group object itself (an id() can be reused after a group is destroyed)
+        if red is None or red.pg is not group:
+            red = _reducers[group] = GradReducer(group)
         red.all_reduce_small(t)
         return red.world
     return 1

@@ -164,6 +164,7 @@ def save_checkpoint(graph, train_dir, rank):
         if tw is not None:
             sd.update({k: v.cpu() for k, v in tw.state_dict().items()})
             sd["%s/adam" % tw.scope] = {"t": tw.adam_t, "m": tw.store.m.cpu(), "v": tw.store.v.cpu()}
+            sd["%s/precision_layout" % tw.scope] = tw.precision_layout()      # metadata: the forward-operand layout these weights were trained under
     path = os.path.join(train_dir, "model.ckpt-%d.pt" % graph.global_step)
     # like tf.train.Saver: write to a temporary name, flush to disk, rename (a validate.py polling the directory never
     # sees a half-written file); the temporary name does not match the model.ckpt*.pt glob

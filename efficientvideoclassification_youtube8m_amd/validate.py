@@ -126,6 +126,13 @@ def evaluation_loop(graph, reader, label_loss_fn, summary_writer, evl_metrics, l
         pending = handle
     if pending is not None:
         account(pending)
+    if FLAGS.precision == "high":      # the fixed e4m3 scales of the "high" mode assume bounded operands: say so when the last batch broke them
+        for tw, key in ((getattr(graph, "teacher", None), "teacher_state"), (getattr(graph, "student", None), "student_state")):
+            if tw is not None and hasattr(tw, "fp8_saturation"):
+                sat = {k: v for k, v in tw.fp8_saturation(out.get(key) if pending is not None else None).items() if v}
+                if sat:
+                    logging.warning("%s: operands beyond the e4m3 scales of --precision high (low-order corrections clamp, the 1e-3 contract "
+                                    "degrades): %s - see flags.py / EVC_HIGH_MOE_FP8=0", tw.scope, sat)
     logging.info("Done with batched inference. Now calculating global performance metrics.")
     epoch_info_dict = evl_metrics.get()
     epoch_info_dict["epoch_id"] = global_step_val

@@ -299,7 +299,7 @@ int evc_moe_grad_update_phase(const evc_bf16* dlogits, int64_t ld_dlogits, const
  *     slab order: run-to-run identical).  R % 32 == 0, Kc % 32 == 0 columns (zero padding allowed), S <= Kc / 32.
  *   evc_moe_grad_norms: sums[0] += the norm above, sums[1] += wsq[0]; gram_a / gram_x from evc_gram_slabs of dlogits / x; logits
  *     [B][V] f32 = the forward's X W^T (+ bias: pass it, or NULL for the gates); wsq[0] = |W|^2 of the current weights (kept by
- *     evc_moe_grad_update_apply); part_ws: 256 floats of scratch.
+ *     evc_moe_grad_update_apply); part_ws: 256 + 4 B floats of scratch; B <= 512.
  *   evc_moe_grad_update_apply: phase 2 alone with the optional operand images of evc_moe_grad_update_wide (any may be NULL) and
  *     wsq_out[0] = sum of the NEW weights squared, wsq_out[1] = 0 (both through partial_ws in a fixed order). */
 int evc_gram_slabs(const evc_bf16* A, int64_t lda, int R, int Kc, int S, float* slabs, void* stream);
@@ -581,6 +581,21 @@ int evc_netvlad_normalize_fwd(const float* V, int B, int K, int F, float* n1, fl
                               void* stream);
 int evc_netvlad_normalize_bwd(const float* V, const float* n1, const float* n2, const float* dY, int B, int K, int F, float* dV,
                               void* stream);
+
+/* ---- one LSTM layer's train op in two launches (csrc/evc_optim.hip; a9: cs/train.py:329-334,413-418 + AdamOptimizer :241-242) ----
+ * evc_sqnorm2_partials: part[0..1023] = per-block sums of squares of ga [na], part[1024] = sum of squares of gb [nb] (gb may be
+ *   NULL with nb = 0); plain stores, fixed order.  part: 1025 floats.
+ * evc_lstm_adam_fused: per-tensor clip_by_norm(clip_norm) from those partials + TF-Adam (arithmetic of evc_clip_adam_step, no l2
+ *   term) of the kernel p [4H][C] and the bias pb [4H], and from the same registers the operand images of the new kernel:
+ *   p_bf16 [4H][C]; pT_bf16 [C][ldT] with column u*4+g <- row g*H+u (the gate-interleaved layout of evc_lstm_layer_bwd);
+ *   p_f16 (or NULL) rows [f16(Wx) | f16(Wx)/64 | (Wx - f16(Wx))*64 (the first nseg of these blocks over the nin input columns) |
+ *   f16(Wh)] = evc_cast_f32_to_f16 (nseg 1) / evc_cast_f32_to_f16_wide(h_ext 0); p_fp8 (or NULL) = evc_cast_f32_to_fp8_lo of the
+ *   columns from fp8_col0 on (hi_cols, exponents as there).  sums_w[0] / sums_b[0] receive the two squared gradient norms. */
+int evc_sqnorm2_partials(const float* ga, int64_t na, const float* gb, int64_t nb, float* part, void* stream);
+int evc_lstm_adam_fused(float* p, const float* g, float* m, float* v, float* pb, const float* gb, float* mb, float* vb, int H, int C,
+                        const float* part, float* sums_w, float* sums_b, float clip_norm, float lr_t, float beta1, float beta2, float eps,
+                        evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT, evc_f16* p_f16, int64_t ld16, int nin, int nseg,
+                        uint8_t* p_fp8, int64_t ld8, int fp8_col0, int fp8_hi_cols, int fp8_lo_exp, int fp8_hi_exp, void* stream);
 
 /* utility: out[i] = value for n floats (avoids torch for tiny fills inside C loops) */
 int evc_fill_f32(float* p, int64_t n, float value, void* stream);

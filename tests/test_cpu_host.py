@@ -359,10 +359,38 @@ def test_bench_rank_supervisor_falls_back_to_the_serial_placement(tmp_path, monk
         assert bench.supervise_ranks([mode], script=str(child)) == 0
         out = capfd.readouterr()
         assert "attempt 0 serial False port 29600" in out.out and "attempt 1 serial True port 29617 agent_store None" in out.out, out.out
-        assert "retrying with the serial placement" in out.err
-    monkeypatch.setenv("EVC_DP_SERIAL_COMM", "1")            # already conservative: one attempt only
+        assert "retrying with the next placement" in out.err
+    monkeypatch.setenv("EVC_DP_SERIAL_COMM", "1")            # already on one communicator: first attempt as given
     assert bench.supervise_ranks(["ok"], script=str(child)) == 0
     assert capfd.readouterr().out.count("child attempt") == 1
+
+
+def test_bench_rank_supervisors_agree_before_retrying(tmp_path):
+    """Two rank supervisors (CPU only): rank 1's child fails on the first placement while rank 0's succeeds - rank 0 must NOT
+    return with its child's 0 but retry together with rank 1 (the exit codes are exchanged through a TCPStore), and both end 0
+    after the second placement; nobody starts an attempt alone."""
+    child = tmp_path / "child.py"
+    child.write_text("import os, sys\n"
+                     "serial = os.environ.get('EVC_DP_SERIAL_COMM') == '1'\n"
+                     "print('rank', os.environ['RANK'], 'attempt', os.environ['EVC_BENCH_ATTEMPT'], 'serial', serial, 'order', os.environ.get('EVC_ISSUE_ORDER'), flush=True)\n"
+                     "sys.exit(0 if (serial or os.environ['RANK'] == '0') else 5)\n")
+    driver = tmp_path / "driver.py"
+    driver.write_text("import importlib.util, sys\n"
+                      "spec = importlib.util.spec_from_file_location('bench_mod', %r)\n"
+                      "bench = importlib.util.module_from_spec(spec)\n"
+                      "spec.loader.exec_module(bench)\n"
+                      "sys.exit(bench.supervise_ranks(['x'], script=%r))\n" % (os.path.join(ROOT, "bench.py"), str(child)))
+    procs = []
+    for rank in (0, 1):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29710", EVC_BENCH_ATTEMPT_S="20")
+        env.pop("EVC_DP_SERIAL_COMM", None)
+        procs.append(subprocess.Popen([sys.executable, str(driver)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=240) for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], outs
+    for rank, (o, e) in enumerate(outs):
+        assert "rank %d attempt 0 serial False" % rank in o and "rank %d attempt 1 serial True order None" % rank in o, (o, e)
+        assert "attempt 2" not in o
+    assert "ended with code 0 here, 5 over all ranks" in outs[0][1], outs[0][1]
 
 
 WORLD4_WORKER = r'''

@@ -115,6 +115,47 @@ def test_dbof_forward_backward(B, F, C, Hd, V, S, tol):
     assert torch.isfinite(p_eval).all()
 
 
+@pytest.mark.parametrize("precision", ["bf16", "high"])
+def test_dbof_cfg4_batch_512_properties(precision):
+    """BASELINE cfg 4 at its full batch (512 videos x 30 sampled frames = 15 360 rows through the 8192-cluster kernel - the
+    configuration bench.py times; the oracle tests above stop at B = 64): sampled frame indices bit-exact, finite predictions in
+    [0, 1] in training mode, two training iterations lower the loss and move the batch-norm averages; with the moving
+    statistics (is_training=False: no cross-video coupling through the batch moments) the videos are independent - the first 64
+    rows are the B = 64 tower's predictions although every tile count differs."""
+    from efficientvideoclassification_youtube8m_amd.towers import DbofTower
+    from efficientvideoclassification_youtube8m_amd.distill import SingleTowerGraph
+    B, S = 512, 30
+    rng = np.random.default_rng(4)
+    q = rng.integers(0, 256, (B, 300, 1152), dtype=np.uint8)
+    n = rng.integers(1, 301, B).astype(np.int32)
+    labels = np.zeros((B, 4716), np.uint8)
+    labels[np.arange(B)[:, None], rng.integers(0, 4716, (B, 3))] = 1
+    u = rng.random((B, S)).astype(np.float32)
+    qd, yd, nd, ud = torch.from_numpy(q).to(DEV), torch.from_numpy(labels).to(DEV), torch.from_numpy(n).to(DEV), torch.from_numpy(u).to(DEV)
+    tw = DbofTower(B, 300, 1152, 4716, iterations=S, cluster_size=8192, hidden_size=1024, device=DEV, seed=3)
+    if precision != "bf16":
+        tw.set_precision(precision)
+    g = SingleTowerGraph(tw)
+    losses = []
+    for _ in range(3):
+        out = g.step(qd, yd, nd, uniform=ud)
+        losses.append(float(out["loss"]))
+        assert torch.isfinite(out["predictions"]).all()
+        assert float(out["predictions"].min()) >= 0.0 and float(out["predictions"].max()) <= 1.0
+    assert np.array_equal(tw.idx.cpu().numpy(), mm.sample_random_frames_index(u, n))
+    assert g.global_step == 3 and losses[2] < losses[0], losses
+    assert float(tw.buffers["cluster_bn/moving_mean"].abs().max()) > 0
+    p512 = tw.forward(qd, nd, ud, is_training=False).clone()
+    tw64 = DbofTower(64, 300, 1152, 4716, iterations=S, cluster_size=8192, hidden_size=1024, device=DEV, seed=3)
+    if precision != "bf16":
+        tw64.set_precision(precision)
+    tw64.load_state_dict(tw.state_dict())
+    p64 = tw64.forward(qd[:64], nd[:64], ud[:64], is_training=False)
+    d = (p64 - p512[:64]).abs().max().item()
+    print("dbof B=512 %s: losses %s, first-64 rows vs the B=64 tower %.2e" % (precision, [round(v, 2) for v in losses], d))
+    assert d < (2e-5 if precision == "high" else 2e-4), d
+
+
 def test_logistic_forward_backward_and_step():
     from efficientvideoclassification_youtube8m_amd.towers import LogisticTower
     from efficientvideoclassification_youtube8m_amd.distill import SingleTowerGraph

@@ -228,6 +228,54 @@ def test_real_dims_trained_magnitude_weights_both_precision_modes():
     assert all(errs["high"][k] < errs["bf16"][k] for k in errs["high"])
 
 
+def test_headline_batch_256_high_mode_on_trained_magnitude_weights():
+    """The mode that carries north_star's tolerance, at the batch bench.py times it on (B = 256: ~3.6 k live L1 rows per step, the
+    224 / 256-row f16 + e4m3 forward tiles, the 256-row head products), on weights of trained magnitude: the first 4 videos of the
+    batch against the float64 oracle at 1e-3 on logits, states and predictions of both towers; every output of the 256 finite, the
+    predictions in [0, 1]; the videos are independent (the B = 4 graph gives the same rows)."""
+    from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
+    q, x, n, labels = mm.synthetic_batch(4, seed=91, dtype=np.float32)
+    n[0] = 300
+    x[np.arange(300)[None, :] >= n[:, None]] = 0.0
+    sd = _trained_magnitude_weights(4, x, n, labels)
+    params = {sc: {k[len(sc) + 1:]: v.double().cpu().numpy() for k, v in sd.items() if k.startswith(sc + "/")}
+              for sc in ("model", "model_student")}
+    ref = mm.teacher_student_step(x.astype(np.float64), n, labels, params["model"], params["model_student"], 10, with_grads=False)
+    B = 256
+    qb, xb, nb, lb = mm.synthetic_batch(B, seed=92, dtype=np.float32)
+    xb[:4], nb[:4], lb[:4] = x, n, labels
+    xd, yd, nd = (torch.from_numpy(xb).to(DEV), torch.from_numpy(lb.astype(np.uint8)).to(DEV), torch.from_numpy(nb).to(DEV))
+    g = DistillGraph(B, every_n=10, device=DEV, seed=3, precision="high")
+    g.teacher.load_state_dict(sd)
+    g.student.load_state_dict(sd)
+    out = g.step(xd, yd, nd, apply=False, num_frames_host=nb)
+    assert g.teacher.fp8_lo() and g.teacher.l1.plan is not None and g.teacher.l1.Mrun < 20 * B
+    errs = {}
+    for name, tw, sc, kp, ks in (("teacher", g.teacher, "model", "predictions", "teacher_state"),
+                                 ("student", g.student, "model_student", "student_predictions", "student_state")):
+        assert torch.isfinite(out[kp]).all() and torch.isfinite(out[ks]).all()
+        assert float(out[kp].min()) >= 0.0 and float(out[kp].max()) <= 1.0
+        st = ref[ks]
+        zg = st @ params[sc]["classifier/gates/weights"]
+        ze = st @ params[sc]["classifier/experts/weights"] + params[sc]["classifier/experts/biases"]
+        errs[name + "_pred"] = float(np.abs(out[kp][:4].cpu().numpy() - ref["teacher_predictions" if name == "teacher" else "student_predictions"]).max())
+        errs[name + "_state"] = float(np.abs(out[ks][:4].cpu().numpy() - st).max())
+        errs[name + "_gate_logits"] = float(np.abs(tw.moe.gate_logits[:4].cpu().numpy() - zg).max())
+        errs[name + "_expert_logits"] = float(np.abs(tw.moe.expert_logits[:4].cpu().numpy() - ze).max())
+        assert all(v == 0 for v in tw.fp8_saturation(out[ks]).values()), tw.fp8_saturation(out[ks])     # the fixed e4m3 scales hold on these operands
+    print("B = 256 high mode, first 4 videos vs float64:", {k: "%.2e" % v for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v < 1e-3, (k, v)
+    keep = {k: out[k][:4].clone() for k in ("predictions", "student_predictions", "teacher_state", "student_state")}
+    g4 = DistillGraph(4, every_n=10, device=DEV, seed=3, precision="high")
+    g4.teacher.load_state_dict(sd)
+    g4.student.load_state_dict(sd)
+    out4 = g4.step(xd[:4], yd[:4], nd[:4], apply=False, num_frames_host=nb[:4])
+    for k, v in keep.items():
+        d = (out4[k] - v).abs().max().item()
+        assert d < 2e-4, (k, d)                          # (tile heights, split-K joins and accumulation order differ with the batch)
+
+
 @pytest.mark.parametrize("frames", [[1, 14, 15, 16, 150, 299, 300], [300], [1], [0, 300, 0, 7], [300] * 8, [3] * 8])
 def test_extreme_frame_counts_with_row_plans(frames):
     """Row plans at the edges: single video, every row alive, almost every row dead, zero-length videos."""
@@ -298,6 +346,64 @@ def test_fused_moe_update_matches_materialised_gradient_path():
             assert torch.equal(sb[:, :ta.store.p(k).shape[0]], ta.store.p(k).t().bfloat16())
             assert bool((sb[:, ta.store.p(k).shape[0]:] == 0).all())
         assert torch.allclose(ta.sums, tb.sums, rtol=1e-4, atol=1e-12)
+
+
+@pytest.mark.parametrize("dims", [(8, 64, 64, 100), (40, 128, 128, 236)])
+def test_gram_matrix_clip_norm_equals_the_pass_over_the_weights(dims):
+    """evc_gram_slabs + evc_moe_grad_norms (|g + l2 W|^2 = <A A^T, X X^T> + 2 l2 <A, logits - bias> + l2^2 |W|^2, no pass over W)
+    against pass 1 of evc_moe_grad_update (gradient tile recomputed, W streamed): the same norm sums to f32 rounding, the same
+    weights after three iterations; the carried |W|^2 equals the norm of the weights it describes; run-to-run identical."""
+    from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
+    B, F, H, V = dims
+    q, x, n, labels = mm.synthetic_batch(B, seed=35, feature_size=F, vocab_size=V, dtype=np.float32)
+    xd, nd, yd = torch.from_numpy(q).to(DEV), torch.from_numpy(n).to(DEV), torch.from_numpy(labels.astype(np.uint8)).to(DEV)
+    graphs = []
+    for gram in (True, False):
+        g = DistillGraph(B, every_n=10, feature_size=F, vocab_size=V, lstm_cells=H, device=DEV, seed=4, regularization_penalty=2.0e4)
+        for tw in (g.teacher, g.student):
+            tw.moe.gram_norms = gram
+        sums, first = [], {}
+        for it in range(3):
+            g.step(xd, yd, nd, num_frames_host=n)
+            torch.cuda.synchronize()
+            sums.append((g.teacher.sums.clone(), g.student.sums.clone()))
+            if it == 0:
+                first = {(tw.scope, k): tw.store.p(k).clone() for tw in (g.teacher, g.student) for k in (tw.GATES, tw.EXPERTS)}
+        graphs.append((g, sums, first))
+    (a, sa, fa), (b, sb, fb) = graphs
+    for key in fa:            # one iteration from identical weights: the same update (later ones start from weights that carry the LSTM atomics' noise)
+        assert (fa[key] - fb[key]).abs().max().item() < 2e-7, (key, (fa[key] - fb[key]).abs().max().item())
+    for it in range(3):
+        for t in range(2):
+            # (regularization_penalty 2e4 makes the l2 terms a visible part of the norm: l2 = 2e-4)
+            tw = (a.teacher, a.student)[t]
+            rows = [tw.names.index(tw.GATES), tw.names.index(tw.EXPERTS)]       # (the LSTM rows carry the split-K atomics' run-to-run noise)
+            tol = 2e-5 if it == 0 else 2e-3                                      # later iterations: on weights that differ by that noise
+            assert torch.allclose(sa[it][t][rows], sb[it][t][rows], rtol=tol, atol=1e-12), (it, t, sa[it][t][rows], sb[it][t][rows])
+    for ta, tb in ((a.teacher, b.teacher), (a.student, b.student)):
+        for k in (ta.GATES, ta.EXPERTS):
+            pa, pb = ta.store.p(k), tb.store.p(k)
+            assert (pa - pb).abs().max().item() < 3e-4, (ta.scope, k, (pa - pb).abs().max().item())
+        for i, k in enumerate((ta.GATES, ta.EXPERTS)):
+            assert ta.moe._wsq_valid[i]
+            want = float((ta.store.p(k).double() ** 2).sum())
+            assert abs(float(ta.moe.wsq[i, 0]) - want) <= 1e-5 * want, (k, float(ta.moe.wsq[i, 0]), want)
+        # fixed summation order: the same inputs give the same bits
+        from efficientvideoclassification_youtube8m_amd import ops
+        moe, outs = ta.moe, []
+        for _ in range(2):
+            o = torch.zeros(2, dtype=torch.float32, device=DEV)
+            S = moe.gram_S
+            ops.gram_slabs(moe.x_full, moe.Br, moe.K, S["x"], moe.gram_x)
+            ops.gram_slabs(moe.dgl_full, moe.Br, moe.dgl_full.shape[1], 1, moe.gram_a)
+            ops.moe_grad_norms(moe.gram_a, 1, moe.gram_x, S["x"], moe.Br, moe.dgl_full, moe.gate_logits, None, moe.B, moe.V * 3, 2e-4,
+                               moe.wsq[0], moe.norm_part, o)
+            outs.append(o)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1]) and float(outs[0][0]) > 0
+        # anything else that writes the weights drops the carried norm
+        ta.load_state_dict(tb.state_dict())
+        assert ta.moe._wsq_valid == [False, False]
 
 
 @pytest.mark.parametrize("precision", ["bf16", "high"])
