@@ -23,6 +23,7 @@ SIGNATURES = {
     "evc_gemm_tn": [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp],
     "evc_gemm_tn2": [vp, i64, vp, i64, i32, vp, i64, i32, i32, vp, i64, i32, i32, i32, i32, vp],
     "evc_colsum_bf16": [vp, i64, i32, i32, i32, vp, vp],
+    "evc_colsum_bf16_det": [vp, i64, i32, i32, i32, vp, vp, i32, vp],
     "evc_lstm_layer_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp],
     "evc_lstm_layer_fwd_hp": [vp, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp, vp, vp],
     "evc_gemm_nt_split": [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, vp],

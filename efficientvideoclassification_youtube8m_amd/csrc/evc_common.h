@@ -93,3 +93,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// EVC_DETERMINISTIC=1 (read once per process): no floating-point atomics on the training path - split-K joins are not used (one
+// workgroup per output tile), reductions that end in same-address atomics run on one block or through plain partial sums in a
+// fixed order.  Identical inputs then give identical bits run to run and box to box; what it costs is in DESIGN.md 7.
+#include <stdlib.h>
+static inline bool evc_deterministic() {
+  static const bool on = getenv("EVC_DETERMINISTIC") != nullptr && atoi(getenv("EVC_DETERMINISTIC")) != 0;
+  return on;
+}

@@ -696,6 +696,41 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
     atomicAdd(&out[co], s[k]);
   }
 }
+// The same sums without atomics (EVC_DETERMINISTIC): row block y writes its partial column sums to ws[y][C] (plain stores), a second
+// launch adds the gy partial rows in index order.
+__global__ __launch_bounds__(256) void colsum_bf16_partial_kernel(const bf16_t* __restrict__ in, long ld, int R, int C, float* __restrict__ ws) {
+  const int c8 = (blockIdx.x * 256 + threadIdx.x) * 8;
+  if (c8 >= C) return;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int r = blockIdx.y; r < R; r += gridDim.y) {
+    const uint4 q = *(const uint4*)(in + (long)r * ld + c8);
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s[2 * k] += __uint_as_float(w[k] << 16); s[2 * k + 1] += __uint_as_float(w[k] & 0xffff0000u); }
+  }
+  float* o = ws + (long)blockIdx.y * C + c8;
+  *(float4*)o = make_float4(s[0], s[1], s[2], s[3]);
+  *(float4*)(o + 4) = make_float4(s[4], s[5], s[6], s[7]);
+}
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ ws, int gy, int C, int il_H, float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int y = 0; y < gy; ++y) s += ws[(long)y * C + c];
+  out[il_H > 0 ? (c & 3) * il_H + (c >> 2) : c] = s;
+}
+extern "C" int evc_colsum_bf16_det(const evc_bf16* in, int64_t ld_in, int R, int C, int deinterleave_H, float* out, float* ws, int ws_rows, void* stream) {
+  EVC_REQUIRE(R > 0 && C > 0 && C % 8 == 0 && ld_in % 8 == 0 && ((uintptr_t)in % 16) == 0 && ws && ws_rows >= 1 && ((uintptr_t)ws % 16) == 0, EVC_ERR_BAD_SHAPE,
+              "evc_colsum_bf16_det: bad shape / workspace");
+  EVC_REQUIRE(deinterleave_H == 0 || C == 4 * deinterleave_H, EVC_ERR_BAD_SHAPE, "evc_colsum_bf16_det: deinterleave_H needs C == 4*H");
+  hipStream_t st = (hipStream_t)stream;
+  int gy = R / 64; gy = gy < 1 ? 1 : (gy > ws_rows ? ws_rows : gy);
+  hipLaunchKernelGGL(colsum_bf16_partial_kernel, dim3(ceil_div(C / 8, 256), gy), dim3(256), 0, st, (const bf16_t*)in, (long)ld_in, R, C, ws);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, (const float*)ws, gy, C, deinterleave_H, out);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
 extern "C" int evc_colsum_bf16(const evc_bf16* in, int64_t ld_in, int R, int C, int deinterleave_H, float* out, void* stream) {
   EVC_REQUIRE(R > 0 && C > 0 && C % 8 == 0 && ld_in % 8 == 0 && ((uintptr_t)in % 16) == 0, EVC_ERR_BAD_SHAPE, "evc_colsum_bf16: bad shape");
   EVC_REQUIRE(deinterleave_H == 0 || C == 4 * deinterleave_H, EVC_ERR_BAD_SHAPE, "evc_colsum_bf16: deinterleave_H needs C == 4*H");
@@ -703,6 +738,7 @@ extern "C" int evc_colsum_bf16(const evc_bf16* in, int64_t ld_in, int R, int C, 
   EVC_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float) * C, st));
   const int gx = ceil_div(C / 8, 256);
   int gy = R / 64; gy = gy < 1 ? 1 : (gy > 512 ? 512 : gy);
+  if (evc_deterministic()) gy = 1;                  // one adder per column (large R: evc_colsum_bf16_det)
   hipLaunchKernelGGL(colsum_bf16_kernel, dim3(gx, gy), dim3(256), 0, st, in, ld_in, R, C, deinterleave_H, out);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
@@ -831,7 +867,7 @@ extern "C" int evc_ce_loss(const float* pred, const uint8_t* labels, int B, int 
   const long n = (long)B * V;
   // every block ends in one atomic on the same address, and those serialise at ~12 ns each: 2048 blocks made this a
   // 30 us kernel for 1.2 M elements; 256 blocks (one per CU) keep the join at ~3 us
-  const int grid = (int)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);
+  const int grid = evc_deterministic() ? 1 : (int)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);
   hipLaunchKernelGGL(ce_loss_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pred, labels, n, 1.0f / B, grad_scale, loss,
                      dpred, accumulate_grad);
   EVC_LAUNCH_CHECK();
@@ -897,7 +933,7 @@ extern "C" int evc_rep_loss(const float* state_t, const float* state_s, int B, i
                             float* loss, float* dstate_s, int accumulate_grad, void* stream) {
   EVC_REQUIRE(B > 0 && D > 0, EVC_ERR_BAD_SHAPE, "evc_rep_loss: bad shape");
   const long n = (long)B * D;
-  const int grid = (int)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);     // one same-address atomic per block (see evc_ce_loss)
+  const int grid = evc_deterministic() ? 1 : (int)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);     // one same-address atomic per block (see evc_ce_loss)
   hipLaunchKernelGGL(rep_loss_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, state_t, state_s, n, 1.0f / B, grad_scale,
                      loss, dstate_s, accumulate_grad);
   EVC_LAUNCH_CHECK();
@@ -939,7 +975,8 @@ extern "C" int evc_grad_sqnorm(const float* g, const float* p, float l2_coeff, i
   EVC_REQUIRE(((uintptr_t)g % 16) == 0 && ((uintptr_t)p % 16) == 0, EVC_ERR_BAD_ALIGN, "evc_grad_sqnorm: 16-byte alignment");
   EVC_REQUIRE(p != nullptr || l2_coeff == 0.f, EVC_ERR_BAD_ARG, "evc_grad_sqnorm: p == NULL (gradient norm only) needs l2_coeff == 0");
   const long nb = (n / 4 + 255) / 256;
-  const int grid = (int)(nb < 1 ? 1 : (nb < 512 ? nb : 512));   // two blocks per CU; each ends in same-address atomics (~12 ns apiece)
+  int grid = (int)(nb < 1 ? 1 : (nb < 512 ? nb : 512));   // two blocks per CU; each ends in same-address atomics (~12 ns apiece)
+  if (evc_deterministic()) grid = 1;                        // one adder: fixed order (the large tensors go through evc_sqnorm2_partials)
   if (p) hipLaunchKernelGGL(grad_sqnorm_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, p, l2_coeff, (long)n, sums);
   else hipLaunchKernelGGL(grad_sqnorm_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, p, 0.f, (long)n, sums);
   EVC_LAUNCH_CHECK();

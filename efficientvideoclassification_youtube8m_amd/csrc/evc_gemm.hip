@@ -266,7 +266,7 @@ extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
     const int tn = ceil_div(N, 64);
     int splits = out_bf16 ? 1 : 256 / tn;
     if (splits > K / 1024) splits = K / 1024;
-    if (splits < 1) splits = 1;
+    if (splits < 1 || evc_deterministic()) splits = 1;
     if (splits > 1 && !accumulate) EVC_CHECK_HIP(hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st));
     static const bool tall_v2 = getenv("EVC_TALL_V2") != nullptr;      // A/B: the 32-wide K stages
     if (tall_v2) launch_gemm<CfgTallV2>(p, s, K, splits, st);
@@ -281,7 +281,7 @@ extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
   // (M <= 512 only: streams.concurrent_streams probes with a 1024 x 1024 x 4096 product that must stay on 64 workgroups.)
   {
     const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
-    if (!out_bf16 && M > 256 && M <= 512 && t128 <= 128 && K >= 4096 && forced_tile() == 0) {
+    if (!out_bf16 && M > 256 && M <= 512 && t128 <= 128 && K >= 4096 && forced_tile() == 0 && !evc_deterministic()) {
       const int nk = K / 32;
       int splits = (int)(512 / t128);
       if (splits > nk / 16) splits = nk / 16;
@@ -299,7 +299,7 @@ extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
   // into a zeroed C (63 MB of atomic traffic at ~1.3 TB/s << the ~0.7 ms it saves per GEMM).
   {
     const long t2 = (long)ceil_div(M, 256) * ceil_div(N, 256);
-    if (!out_bf16 && t2 <= 128 && K >= 8192 && forced_tile() == 0) {
+    if (!out_bf16 && t2 <= 128 && K >= 8192 && forced_tile() == 0 && !evc_deterministic()) {
       int splits = (int)(256 / t2);
       const int max_by_k = K / 2048;                  // keep >= 64 K steps per split
       if (splits > max_by_k) splits = max_by_k;
@@ -469,8 +469,8 @@ extern "C" int evc_gemm_nt_f16_fp8(const evc_f16* A16, int64_t lda, const uint8_
                        // and of the e4m3 stages (>= 4 of each: a full ring), the partial tiles are joined by f32 atomics into a zeroed C
     const int tiles = ceil_div(M, 256) * ceil_div(N, 64), nk16 = K16 / 64, nk8 = K8 / 128;
     int splits = 1;
-    while (splits < 16 && tiles * splits * 2 <= 256 && nk16 % (splits * 2) == 0 && nk8 % (splits * 2) == 0 && nk16 / (splits * 2) >= 4 &&
-           nk8 / (splits * 2) >= 4)
+    while (!evc_deterministic() && splits < 16 && tiles * splits * 2 <= 256 && nk16 % (splits * 2) == 0 && nk8 % (splits * 2) == 0 &&
+           nk16 / (splits * 2) >= 4 && nk8 / (splits * 2) >= 4)
       splits *= 2;
     if (splits > 1) EVC_CHECK_HIP(hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st));
     launch_gemm_f16_fp8<TileCfg3<256, 1, 64, 2, 4, 4>>(p, s, K16, K8, splits, st);
@@ -586,7 +586,7 @@ static int gemm_tn_impl(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64
     const int tm1 = ceil_div(M, 128);
     int splits = 256 / tm1;
     if (splits > K / 1024) splits = K / 1024;
-    if (splits < 1) splits = 1;
+    if (splits < 1 || evc_deterministic()) splits = 1;
     while (splits > 1 && (long)ceil_div(p.nk, splits) * (splits - 1) >= p.nk) --splits;     // no empty split
     StoreParamsT s1{C, ldc, M, N, row_interleave_H, accumulate, splits, ceil_div(p.nk, splits), 0};
     if (splits > 1 && !accumulate) EVC_CHECK_HIP(hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st));
@@ -597,7 +597,7 @@ static int gemm_tn_impl(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64
   const int tm = ceil_div(M, CfgPlainV2::BM), tn = ceil_div(N, CfgPlainV2::BU);
   int splits = 256 / (tm * tn);
   if (splits > K / 1024) splits = K / 1024;     // keep >= 32 K steps per split
-  if (splits < 1) splits = 1;
+  if (splits < 1 || evc_deterministic()) splits = 1;
   StoreParamsT s{C, ldc, M, N, row_interleave_H, accumulate, splits, ceil_div(p.nk, splits), 0};
   if (splits > 1 && !accumulate) EVC_CHECK_HIP(hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st));
   launch_cfg<CfgPlainV2>(gemm_tn_kernel<CfgPlainV2>, tm * tn * splits, st, p, s, tm, tn);

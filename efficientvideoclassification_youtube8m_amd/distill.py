@@ -79,12 +79,12 @@ class GradReducer:
       RCCL kernel sits in stream order between the kernels that produce and consume its data; the student tower uses a
       communicator of its own (DistillGraph), two communicators may be in flight on two streams at once.
     * EVC_DP_SERIAL_COMM=1 - the conservative form for a first run on real xGMI: ONE communicator for everything and ONE
-      stream (`serial_stream`, shared by all reducers of the process) that every collective is funnelled through -
-      the issuing stream's work so far is awaited by event, the collective runs on the serial stream, the issuing stream
-      waits for it by event.  RCCL kernels of this process then execute strictly in host issue order (identical on all
-      ranks), never two at once; compute on the other streams still overlaps them."""
+      collective in flight at a time: every collective still runs on the stream it belongs to, but first waits for the end
+      of the previous one (event chain in host issue order, identical on all ranks), and DistillGraph issues the two
+      towers' backward phases in readiness order so that the chain follows the order in which the data becomes ready.
+      RCCL kernels of this process then execute strictly one after the other; compute on the other streams overlaps them."""
 
-    _serial_stream = None           # one per process
+    _last_ev = None                 # serial placement: the event behind the last collective this process issued (any stream)
     # Accounting for bench.py's N > 1 line (class-wide: every reducer of the process adds to it):
     #   stats[kind] = [collectives issued, payload bytes handed to them]     (always on: two integer adds per call)
     #   timing = None | list of (kind, bytes, start event, end event) recorded on the stream the collective runs on
@@ -163,16 +163,17 @@ class GradReducer:
                 return out
         if not self.serial:
             return fn()
+        # ONE collective of this process at a time, in host issue order, each on the stream it belongs to: the collective waits for
+        # the end of the previous one (an event recorded behind it on ITS stream) and leaves an event for the next.  (Round 3
+        # funnelled them through a fifth stream instead - which shares one of the four hardware queues with a compute stream
+        # (streams.py) and serialised with that stream's kernels: 16.5 ms per step in the stand-in runs of DESIGN.md 6.1.)
         cur = torch.cuda.current_stream()
-        if GradReducer._serial_stream is None:
-            GradReducer._serial_stream = torch.cuda.Stream()
-        ss = GradReducer._serial_stream
-        ss.wait_stream(cur)
-        with torch.cuda.stream(ss):
-            out = fn()
-        for t in tensors + ((out,) if torch.is_tensor(out) else ()):
-            t.record_stream(ss)
-        cur.wait_stream(ss)
+        if GradReducer._last_ev is not None:
+            cur.wait_event(GradReducer._last_ev)
+        out = fn()
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        GradReducer._last_ev = ev
         return out
 
     def reduce(self, flat, lo, hi, f32=True):

@@ -407,14 +407,16 @@ class LstmStack:
             KP = self.KP
             dz = self._v(self.dz[l], T, M, 4 * H)
             gb = tw.store.g(bn)                                     # bias gradient: summed inside the step kernels
-            ops.fill_f32(gb, 0.0)
+            det = ops.DETERMINISTIC                                 # ... with f32 atomics; EVC_DETERMINISTIC=1: column sums of dz afterwards
+            if not det:
+                ops.fill_f32(gb, 0.0)
             fused = fuse_ok and self.bwd_fuse == "fused" and l + 1 < L
             rows = plan.rows if plan is not None else [M] * T
             # BPTT step t contracts dh_t = dz_{t+1} . Wh^T over the rows live at t+1 (the last step has no recurrent product)
             with self._timed("bwd_step", sum(1 for r in rows if r > 0), sum(2.0 * r * H * 4 * H for r in rows[1:])):
                 ops.lstm_layer_bwd(w, self.lens, T, M, kin, H, self._v(self.gates[l], T, M, H, 2), self._v(self.c_all[l], T + 1, M, H),
                                    dS[:, (2 * l) * H:], dS[:, (2 * l + 1) * H:], 2 * L * H,
-                                   dh_above, self._v(self.dc_ws, M, H), dz, plan=plan, db=gb,
+                                   dh_above, self._v(self.dc_ws, M, H), dz, plan=plan, db=None if det else gb,
                                    dz_above=self._v(self.dz[l + 1], T, M, 4 * H) if fused else None,
                                    w_above=tw.shadow_bwd[self.names(l + 1)[0]] if fused else None)
             ops.mark("%s:%s_bptt%d_done" % (tw.scope, self.scope, l))
@@ -443,6 +445,8 @@ class LstmStack:
                 gW = tw.store.g(kn)                                     # [4H][kin+H] f32
                 layer_in = (self.x_in if l == 0 else self._hb[l - 1][1:]).reshape(T * M, kin)
                 h_prev = self._hb[l][:T].reshape(T * M, H)
+                if det:     # fixed-order bias gradient from the (bf16) gate gradients: [T*M][H][4] -> TF order g*H+u
+                    ops.colsum_bf16(dz2, T * M, 4 * H, gb, deinterleave_H=H)
                 if use_tn:
                     # "TN" products straight from the row-major activations (transpose reads in the kernel);
                     # the gate-interleaved rows of the product are stored in TF gate order.  The split-K partial
@@ -1062,7 +1066,7 @@ class HLstmTower(TowerBase):
                      l2=("f16 + e4m3 low-order halves, %d input segments" % self.f16_l2_x_segments) if any(k.startswith("RNN_L2/") for k in getattr(self, "shadow8", {}))
                      else ("f16 K-extensions, %d input segments, h0_ext %s" % (self.f16_l2_x_segments, self.f16_l2_h0_ext) if self.L == 2 else "split-bf16"),
                      moe="f16 + e4m3 corrections of both operands" if getattr(self, "shadow_w8", None) else "split-bf16 K-extension",
-                     fp8_scales=dict(w_lo_exp=ops.FP8_W_SCALE_EXP, wx_hi_exp=ops.FP8_WX_HI_EXP, **ops.FP8_MOE))
+                     fp8_scales=dict(lstm_w_lo_exp=ops.FP8_W_SCALE_EXP, lstm_wx_hi_exp=ops.FP8_WX_HI_EXP, **{"moe_" + k: v for k, v in ops.FP8_MOE.items()}))
         return d
 
     def fp8_saturation(self, state=None):

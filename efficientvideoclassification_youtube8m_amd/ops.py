@@ -8,6 +8,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib
@@ -83,7 +85,15 @@ def fill_f32(t, value):
     _lib.call("evc_fill_f32", _p(t), t.numel(), float(value), _stream())
 
 
+DETERMINISTIC = os.environ.get("EVC_DETERMINISTIC", "0") not in ("", "0")     # (the library reads the same variable: csrc/evc_common.h)
+
+
 def colsum_bf16(x, R, C, out, deinterleave_H=0):
+    if DETERMINISTIC and R >= 128:      # no atomics: partial rows + a fixed-order finish (evc_colsum_bf16_det)
+        # (workspace from the caching allocator, which is stream-aware: the two towers call this concurrently on two streams)
+        ws = torch.empty((128, C), dtype=F32, device=x.device)
+        _lib.call("evc_colsum_bf16_det", _p(x), x.stride(0), R, C, deinterleave_H, _p(out), _p(ws), 128, _stream())
+        return out
     _lib.call("evc_colsum_bf16", _p(x), x.stride(0), R, C, deinterleave_H, _p(out), _stream())
     return out
 

@@ -597,6 +597,9 @@ int evc_lstm_adam_fused(float* p, const float* g, float* m, float* v, float* pb,
                         evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT, evc_f16* p_f16, int64_t ld16, int nin, int nseg,
                         uint8_t* p_fp8, int64_t ld8, int fp8_col0, int fp8_hi_cols, int fp8_lo_exp, int fp8_hi_exp, void* stream);
 
+/* evc_colsum_bf16 without atomics: row block y (of min(R / 64, ws_rows)) leaves its partial sums in ws[y][C] (plain stores), a
+ * second launch adds them in index order - the bias gradient from dz under EVC_DETERMINISTIC=1. */
+int evc_colsum_bf16_det(const evc_bf16* in, int64_t ld_in, int R, int C, int deinterleave_H, float* out, float* ws, int ws_rows, void* stream);
 /* utility: out[i] = value for n floats (avoids torch for tiny fills inside C loops) */
 int evc_fill_f32(float* p, int64_t n, float value, void* stream);
 /* Measurement aid, not part of the path: `blocks` workgroups of `threads` threads with `lds_bytes` of LDS each stay resident for

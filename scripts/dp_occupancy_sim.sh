@@ -29,10 +29,13 @@ import json, sys
 d = json.loads(sys.stdin.read()); print('%-64s %7.2f ms/step' % ('no process group (plain single-GPU step)', d['ms_per_step']))" | tee -a "$OUT"
 run "one-rank RCCL, no stand-in" EVC_DP_FORCE=1
 for bw in 300 150; do
-  for blocks in 8 16 32 64; do
+  for blocks in ${BLOCKS:-8 16 32 64}; do
     run "stand-in busbw $bw GB/s, $blocks WGs x 32 KB LDS (default placement)" EVC_DP_FORCE=1 EVC_DP_SIM=$bw:$blocks:32
   done
 done
 run "stand-in busbw 300 GB/s, 32 WGs x 0 KB LDS" EVC_DP_FORCE=1 EVC_DP_SIM=300:32:0
-run "stand-in busbw 300 GB/s, 32 WGs x 32 KB, serial placement" EVC_DP_FORCE=1 EVC_DP_SERIAL_COMM=1 EVC_DP_SIM=300:32:32
+run "stand-in busbw 300 GB/s, 32 WGs x 32 KB, ONE communicator, readiness issue order (round 4)" EVC_DP_FORCE=1 EVC_DP_SERIAL_COMM=1 EVC_DP_SIM=300:32:32
+run "stand-in busbw 300 GB/s, 32 WGs x 32 KB, ONE communicator, sequential issue order (round 3 serial)" EVC_DP_FORCE=1 EVC_DP_SERIAL_COMM=1 EVC_ISSUE_ORDER=sequential EVC_DP_SIM=300:32:32
+run "stand-in busbw 150 GB/s, 32 WGs x 32 KB, ONE communicator, readiness issue order" EVC_DP_FORCE=1 EVC_DP_SERIAL_COMM=1 EVC_DP_SIM=150:32:32
+run "stand-in busbw 300 GB/s, 32 WGs x 32 KB, default placement, readiness issue order" EVC_DP_FORCE=1 EVC_ISSUE_ORDER=interleaved EVC_DP_SIM=300:32:32
 run "stand-in busbw 300 GB/s, 32 WGs x 32 KB, bf16 gradients" EVC_DP_FORCE=1 EVC_DP_GRAD_DTYPE=bf16 EVC_DP_SIM=300:32:32

@@ -147,7 +147,7 @@ def main():
     if a.gpu:
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
         import test_gpu_step as tgs
-        sd = tgs._trained_magnitude_weights(B, x, n, labels)
+        sd = tgs._trained_magnitude_weights(B, x, n, labels, deterministic=os.environ.get("EVC_BUDGET_DETERMINISTIC") == "1")   # default: a fresh draw per run (margin study)
         teacher = {k[len("model/"):]: v.float().cpu() for k, v in sd.items() if k.startswith("model/")}
         student = {k[len("model_student/"):]: v.float().cpu() for k, v in sd.items() if k.startswith("model_student/")}
     elif a.load:
