@@ -218,14 +218,14 @@ def test_real_dims_trained_magnitude_weights_both_precision_modes():
     """The north-star tolerance (1e-3 on the logits, absolute) at the REAL model size on weights of trained magnitude,
     in both forward modes, against the float64 oracle on the same weights and inputs:
 
-    * "high" (bench.py times it as `precision_modes.high`; since round 3: IEEE f16 operands for the L1 level with the input part
-      K-extended by its low-order half, split-bf16 K-extensions for the L2 level and the MoE head - DESIGN.md 7)
+    * "high" (bench.py times it as `precision_modes.high`: IEEE f16 operands in every forward product with the low-order halves of
+      the weights - and of the input frames / the head's input - as e4m3 operands behind the f16 stages of the same launch)
       must hold 1e-3 on the gate logits, the expert logits, the states and the predictions of both towers;
     * "bf16" (one MFMA product: the mode of bench.py's headline figure, which north_star prescribes) is bounded
       RELATIVE to the logit magnitude: 2^-9 operand rounding over a K=4096..5120 contraction gives ~1e-3 * |z|, i.e.
       it meets the absolute 1e-3 only while |logits| <~ 1 (the reference's initialisation: 5e-5) - asserted here
-      as 3e-3 * max(1, |z|_max) so that a regression shows (measured over the boxes and the run-to-run different weights of
-      round 3 - the training that produces them sums with atomics -: 1.2e-3 .. 1.9e-3 of |z|_max on the logits), and printed."""
+      as 2e-3 * max(1, |z|_max) so that a regression shows (round 3, on run-to-run different weights: 1.2e-3 .. 1.9e-3 of |z|_max on
+      the logits; round 4, on the ONE deterministic draw of _trained_magnitude_weights: 1.45e-3), and printed."""
     from efficientvideoclassification_youtube8m_amd import smoke
     from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
     B = 4
@@ -267,7 +267,7 @@ def test_real_dims_trained_magnitude_weights_both_precision_modes():
     for k, v in errs["high"].items():
         assert v < 1e-3, ("high", k, v)
     for k, v in errs["bf16"].items():
-        bound = 3e-3 * max(1.0, zmax if "logits" in k else (smax if "state" in k else 1.0))
+        bound = 2e-3 * max(1.0, zmax if "logits" in k else (smax if "state" in k else 1.0))     # (round 4: one deterministic draw - measured 1.45e-3 |z| on the logits)
         bound = max(bound, 1e-2) if "state" in k else bound          # (cell states integrate the per-step rounding)
         assert v < bound, ("bf16", k, v, bound)
     assert all(errs["high"][k] < errs["bf16"][k] for k in errs["high"])
