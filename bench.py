@@ -611,7 +611,7 @@ def main():
                        "executed_tflop_per_step_per_gpu": head["executed_tflop_per_step"]},
             "executed_tflops_per_gpu": head["executed_tflops"],
             "losses": head["losses"], "gap_at_20_last_batch": head["gap_at_20_last_batch"],
-            "roofline": head.get("roofline"), "rooflines": head.get("rooflines"),
+            "roofline": head.get("roofline"), "rooflines": head.get("rooflines"), "schedule": head.get("schedule"),
         }
         if "dp" in head:
             res["dp"] = head["dp"]

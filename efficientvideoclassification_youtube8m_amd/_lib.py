@@ -65,6 +65,11 @@ SIGNATURES = {
     "evc_sigmoid_fwd": [vp, i64, vp],
     "evc_sigmoid_bwd": [vp, vp, i64, vp, vp],
     "evc_sample_frames_gather": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp],
+    "evc_sample_sequence_gather": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp],
+    "evc_relu6_fwd": [vp, i64, vp, vp, vp],
+    "evc_relu6_bwd": [vp, vp, i64, vp, vp, vp],
+    "evc_framepool_mean_fwd": [vp, i32, i32, i32, vp, vp, vp],
+    "evc_framepool_mean_bwd": [vp, i32, i32, i32, vp, vp],
     "evc_bn_stats": [vp, i32, i32, vp, vp, vp, vp],
     "evc_bn_apply": [vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp],
     "evc_bn_relu6_bwd": [vp, vp, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp],

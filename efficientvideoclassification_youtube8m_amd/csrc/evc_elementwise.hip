@@ -1125,6 +1125,7 @@ extern "C" int evc_sigmoid_bwd(const float* p, const float* dp, int64_t n, evc_b
 // ---------------------------------------------------------------------------
 // a10: DBoF pieces
 // ---------------------------------------------------------------------------
+template <bool SEQUENCE>
 __global__ __launch_bounds__(256) void sample_gather_kernel(const float* __restrict__ x, const uint8_t* __restrict__ xq,
                                                             const float* __restrict__ u, const int* __restrict__ nfr, int B, int T, int F,
                                                             int S, int normalize, float* __restrict__ out, int* __restrict__ idx_out) {
@@ -1133,8 +1134,17 @@ __global__ __launch_bounds__(256) void sample_gather_kernel(const float* __restr
   if (row >= (long)B * S) return;
   const int b = (int)(row / S);
   const int n = nfr[b];
-  // tf.cast(tf.multiply(random_uniform, tf.cast(num_frames, tf.float32)), tf.int32)
-  int idx = (int)(u[row] * (float)n);
+  int idx;
+  if (SEQUENCE) {
+    // SampleRandomSequence (cs/model_utils.py:22-36): start = int32(u[b] * float32(max(n - S, 0) + 1)); index = min(start + s, n - 1)
+    const int mx = n - S > 0 ? n - S : 0;
+    const int start = (int)(u[b] * (float)(mx + 1));
+    const int s_ = (int)(row - (long)b * S);
+    idx = start + s_ < n - 1 ? start + s_ : n - 1;
+  } else {
+    // tf.cast(tf.multiply(random_uniform, tf.cast(num_frames, tf.float32)), tf.int32)
+    idx = (int)(u[row] * (float)n);
+  }
   if (lane == 0 && idx_out) idx_out[row] = idx;
   idx = idx < 0 ? 0 : (idx >= T ? T - 1 : idx);
   const bool padded = xq && idx >= n;            // uint8 input: frames >= num_frames are padding (zero after Dequantize)
@@ -1162,8 +1172,87 @@ extern "C" int evc_sample_frames_gather(const float* x, const uint8_t* x_u8, con
   EVC_REQUIRE(B > 0 && T > 0 && F > 0 && S > 0 && F % 4 == 0, EVC_ERR_BAD_SHAPE, "evc_sample_frames_gather: bad shape");
   EVC_REQUIRE((x != nullptr) != (x_u8 != nullptr), EVC_ERR_BAD_ARG, "evc_sample_frames_gather: exactly one of x / x_u8");
   const long rows = (long)B * S;
-  hipLaunchKernelGGL(sample_gather_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, x_u8, u, num_frames,
+  hipLaunchKernelGGL(sample_gather_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, x_u8, u, num_frames,
                      B, T, F, S, normalize, out, idx_out);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+// SampleRandomSequence (cs/model_utils.py:11-36, --sample_random_frames False): S consecutive frames from a random start; u [B] (one draw per video)
+extern "C" int evc_sample_sequence_gather(const float* x, const uint8_t* x_u8, const float* u, const int32_t* num_frames, int B, int T, int F,
+                                          int S, int normalize, float* out, int32_t* idx_out, void* stream) {
+  EVC_REQUIRE(B > 0 && T > 0 && F > 0 && S > 0 && F % 4 == 0, EVC_ERR_BAD_SHAPE, "evc_sample_sequence_gather: bad shape");
+  EVC_REQUIRE((x != nullptr) != (x_u8 != nullptr), EVC_ERR_BAD_ARG, "evc_sample_sequence_gather: exactly one of x / x_u8");
+  const long rows = (long)B * S;
+  hipLaunchKernelGGL(sample_gather_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, x_u8, u, num_frames,
+                     B, T, F, S, normalize, out, idx_out);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// ---- a10, non-default branches (cs/frame_level_models.py:138-187 with --dbof_add_batch_norm False, cs/model_utils.py:75-76 'average'):
+// plain relu6 forward / backward on a pre-activation that already carries its bias, and mean pooling over the S frames of a video
+__global__ __launch_bounds__(256) void relu6_fwd_kernel(const float* __restrict__ x, long n, float* __restrict__ y, bf16_t* __restrict__ yb) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float v = fminf(fmaxf(x[i], 0.f), 6.f);
+    if (y) y[i] = v;
+    if (yb) yb[i] = f32_to_bf16(v);
+  }
+}
+extern "C" int evc_relu6_fwd(const float* x, int64_t n, float* y_f32, evc_bf16* y_bf16, void* stream) {
+  EVC_REQUIRE(x && n > 0 && (y_f32 || y_bf16), EVC_ERR_BAD_ARG, "evc_relu6_fwd: n=%ld", (long)n);
+  const long nb = (n + 255) / 256;
+  hipLaunchKernelGGL(relu6_fwd_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, (hipStream_t)stream, x, (long)n, y_f32, (bf16_t*)y_bf16);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+__global__ __launch_bounds__(256) void relu6_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, long n, float* __restrict__ dx,
+                                                        bf16_t* __restrict__ dxb) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float xv = x[i];
+    const float v = (xv > 0.f && xv < 6.f) ? dy[i] : 0.f;          // tf.nn.relu6 gradient: 1 strictly inside (0, 6)
+    if (dx) dx[i] = v;
+    if (dxb) dxb[i] = f32_to_bf16(v);
+  }
+}
+extern "C" int evc_relu6_bwd(const float* x, const float* dy, int64_t n, float* dx_f32, evc_bf16* dx_bf16, void* stream) {
+  EVC_REQUIRE(x && dy && n > 0 && (dx_f32 || dx_bf16), EVC_ERR_BAD_ARG, "evc_relu6_bwd: n=%ld", (long)n);
+  const long nb = (n + 255) / 256;
+  hipLaunchKernelGGL(relu6_bwd_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, (hipStream_t)stream, x, dy, (long)n, dx_f32, (bf16_t*)dx_bf16);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+// pooled[b][c] = mean over the S frames of y[b][s][c] (FramePooling 'average': tf.reduce_mean(frames, 1)); dy[b][s][c] = dpooled[b][c] / S
+__global__ __launch_bounds__(256) void framepool_mean_fwd_kernel(const float* __restrict__ y, int B, int S, int C, float* __restrict__ pooled,
+                                                                 bf16_t* __restrict__ pooled_b) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * C) return;
+  const int b = (int)(i / C), c = (int)(i % C);
+  float s = 0.f;
+  for (int f = 0; f < S; ++f) s += y[((long)b * S + f) * C + c];
+  s = s / (float)S;
+  if (pooled) pooled[i] = s;
+  if (pooled_b) pooled_b[i] = f32_to_bf16(s);
+}
+extern "C" int evc_framepool_mean_fwd(const float* y, int B, int S, int C, float* pooled_f32, evc_bf16* pooled_bf16, void* stream) {
+  EVC_REQUIRE(y && B > 0 && S > 0 && C > 0 && (pooled_f32 || pooled_bf16), EVC_ERR_BAD_ARG, "evc_framepool_mean_fwd: bad arguments");
+  hipLaunchKernelGGL(framepool_mean_fwd_kernel, dim3((unsigned)(((long)B * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, B, S, C, pooled_f32,
+                     (bf16_t*)pooled_bf16);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+__global__ __launch_bounds__(256) void framepool_mean_bwd_kernel(const float* __restrict__ dpooled, int B, int S, int C, float* __restrict__ dy) {
+  const long n = (long)B * S * C;
+  const float inv = 1.0f / (float)S;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long b = i / ((long)S * C);
+    const int c = (int)(i % C);
+    dy[i] = dpooled[b * C + c] * inv;
+  }
+}
+extern "C" int evc_framepool_mean_bwd(const float* dpooled, int B, int S, int C, float* dy, void* stream) {
+  EVC_REQUIRE(dpooled && dy && B > 0 && S > 0 && C > 0, EVC_ERR_BAD_ARG, "evc_framepool_mean_bwd: bad arguments");
+  const long nb = ((long)B * S * C + 255) / 256;
+  hipLaunchKernelGGL(framepool_mean_bwd_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, (hipStream_t)stream, dpooled, B, S, C, dy);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }

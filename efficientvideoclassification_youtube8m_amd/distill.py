@@ -795,7 +795,7 @@ class SingleTowerGraph:
 
     def step(self, x_raw, labels_u8, num_frames, uniform=None, apply=True):
         """x_raw [B,T,F] float32 or uint8 (as the reader delivers it: Dequantize is fused into the input kernels)."""
-        from .towers import DbofTower, NetVladTower
+        from .towers import DbofGenericTower, DbofTower, NetVladTower
         B, V = labels_u8.shape
         if self._dp is None or self._dp.shape[0] != B:
             self._dp = torch.empty((B, V), dtype=F32, device=self.device)
@@ -803,8 +803,8 @@ class SingleTowerGraph:
         if self.dp and B != tw.B:
             raise ValueError("data-parallel step on %d videos, the tower was built for %d per rank (ragged batches are not "
                              "allowed under data parallelism: drop the remainder)" % (B, tw.B))
-        if isinstance(tw, (DbofTower, NetVladTower)):
-            if uniform is None:
+        if isinstance(tw, (DbofTower, NetVladTower, DbofGenericTower)):
+            if uniform is None:      # (SampleRandomSequence draws one start per video: column 0 is used)
                 uniform = torch.rand((B, tw.S), dtype=F32, device=self.device)
             self.last_uniform = uniform              # the tf.random_uniform draw of this step (SampleRandomFrames)
             pred = tw.forward(x_raw, num_frames, uniform)

@@ -16,7 +16,7 @@ import torch
 from . import models, ops, video_level_models
 from .engine import HLstmTower
 from .flags import FLAGS
-from .towers import DbofTower, LogisticTower, NetVladTower
+from .towers import DbofGenericTower, DbofTower, LogisticTower, NetVladTower
 
 
 class FrameBatch(object):
@@ -66,24 +66,30 @@ class DbofModel(models.BaseModel):
         random_frames = sample_random_frames or FLAGS.sample_random_frames
         cluster_size = cluster_size or FLAGS.dbof_cluster_size
         hidden1_size = hidden_size or FLAGS.dbof_hidden_size
-        if not add_batch_norm or not random_frames:
-            raise NotImplementedError("DbofModel without batch norm / with SampleRandomSequence is not on the hot path")
-        if FLAGS.dbof_pooling_method != "max":
-            if FLAGS.dbof_pooling_method not in ("average", "none"):
-                raise ValueError("Unrecognized pooling method: %s" % FLAGS.dbof_pooling_method)   # cs/model_utils.py:83
-            raise NotImplementedError("dbof_pooling_method=%s: only 'max' (the default) is built" % FLAGS.dbof_pooling_method)
+        method = FLAGS.dbof_pooling_method
+        if method not in ("max", "average", "none"):
+            raise ValueError("Unrecognized pooling method: %s" % method)                 # cs/model_utils.py:83
+        if method == "none":
+            raise NotImplementedError("dbof_pooling_method=none: FramePooling returns [batch*iterations, clusters] (cs/model_utils.py:79-81), so "
+                                      "the predictions have batch*iterations rows against `batch` label rows - the reference's graph does not train")
         _vl_check()
         scope = unused_params.get("scope", "model")
         B, T, F = model_input.shape
         tw = self.towers.get(scope)
-        if tw is None:
+        default = bool(add_batch_norm) and bool(random_frames) and method == "max"
+        if tw is None and default:
             tw = self.towers[scope] = DbofTower(B, T, F, vocab_size, iterations, cluster_size, hidden1_size,
                                                 FLAGS.moe_num_mixtures, device=model_input.device, training=True,
                                                 scope=scope, seed=unused_params.get("seed", 0))
+        elif tw is None:     # a flag combination no launcher of the reference uses: the plain chain (towers.DbofGenericTower)
+            tw = self.towers[scope] = DbofGenericTower(B, T, F, vocab_size, iterations, cluster_size, hidden1_size,
+                                                       FLAGS.moe_num_mixtures, device=model_input.device, training=True,
+                                                       scope=scope, seed=unused_params.get("seed", 0), pooling=method,
+                                                       add_batch_norm=bool(add_batch_norm), random_frames=bool(random_frames))
         nf = num_frames.reshape(-1).to(torch.int32)
         u = unused_params.get("uniform")
         if u is None:
-            u = torch.rand((B, iterations), dtype=torch.float32, device=model_input.device)
+            u = torch.rand((B, iterations if random_frames else 1), dtype=torch.float32, device=model_input.device)
         return {"predictions": tw.forward(model_input.contiguous(), nf, u,
                                           normalize=unused_params.get("normalize_input", False), is_training=is_training)}
 
@@ -168,7 +174,7 @@ class NetVLADModel(models.BaseModel):
         nf = num_frames.reshape(-1).to(torch.int32)
         u = unused_params.get("uniform")
         if u is None:
-            u = torch.rand((B, iterations), dtype=torch.float32, device=model_input.device)
+            u = torch.rand((B, iterations if random_frames else 1), dtype=torch.float32, device=model_input.device)
         return {"predictions": tw.forward(model_input.contiguous(), nf, u, normalize=unused_params.get("normalize_input", False),
                                           is_training=is_training)}
 

@@ -19,10 +19,16 @@ def SampleRandomFrames(model_input, num_frames, num_samples, uniform=None, norma
     return out.view(B, num_samples, F)
 
 
-def SampleRandomSequence(model_input, num_frames, num_samples):
-    """cs/model_utils.py:11-36 exists in the reference but is only reached with
-    --sample_random_frames False, which no launcher uses."""
-    raise NotImplementedError("SampleRandomSequence: out of scope (SURVEY.md 8a row a10 covers SampleRandomFrames)")
+def SampleRandomSequence(model_input, num_frames, num_samples, uniform=None, normalize=False):
+    """cs/model_utils.py:11-36 (reached with --sample_random_frames False): num_samples consecutive frames from a random start,
+    start = int32(U[0,1) * float32(max(n - num_samples, 0) + 1)), indices clipped at n - 1.  ``uniform`` [B] pins the draw."""
+    B, T, F = model_input.shape
+    if uniform is None:
+        uniform = torch.rand((B,), dtype=torch.float32, device=model_input.device)
+    nf = num_frames.reshape(-1).to(torch.int32)
+    out = torch.empty((B * num_samples, F), dtype=torch.float32, device=model_input.device)
+    ops.sample_sequence_gather(model_input, uniform.reshape(-1).contiguous(), nf, num_samples, out, None, normalize=normalize)
+    return out.view(B, num_samples, F)
 
 
 def FramePooling(frames, method, **unused_params):

@@ -519,6 +519,30 @@ def sample_frames_gather(x, u, num_frames, out, idx_out=None, normalize=False):
               1 if normalize else 0, _p(out), _p(idx_out), _stream())
 
 
+def sample_sequence_gather(x, u, num_frames, S, out, idx_out=None, normalize=False):
+    """SampleRandomSequence (cs/model_utils.py:11-36): u [B] one draw per video, S consecutive frames."""
+    B, T, F = x.shape
+    is_u8 = x.dtype == torch.uint8
+    _lib.call("evc_sample_sequence_gather", None if is_u8 else _p(x), _p(x) if is_u8 else None, _p(u), _p(num_frames), B, T, F, S,
+              1 if normalize else 0, _p(out), _p(idx_out), _stream())
+
+
+def relu6_fwd(x, y_f32=None, y_bf16=None):
+    _lib.call("evc_relu6_fwd", _p(x), x.numel(), _p(y_f32), _p(y_bf16), _stream())
+
+
+def relu6_bwd(x, dy, dx_f32=None, dx_bf16=None):
+    _lib.call("evc_relu6_bwd", _p(x), _p(dy), x.numel(), _p(dx_f32), _p(dx_bf16), _stream())
+
+
+def framepool_mean_fwd(y, B, S, Cc, pooled_f32=None, pooled_bf16=None):
+    _lib.call("evc_framepool_mean_fwd", _p(y), B, S, Cc, _p(pooled_f32), _p(pooled_bf16), _stream())
+
+
+def framepool_mean_bwd(dpooled, B, S, Cc, dy):
+    _lib.call("evc_framepool_mean_bwd", _p(dpooled), B, S, Cc, _p(dy), _stream())
+
+
 def bn_stats(x, R, Cc, ws, mean, var):
     _lib.call("evc_bn_stats", _p(x), R, Cc, _p(ws), _p(mean), _p(var), _stream())
 

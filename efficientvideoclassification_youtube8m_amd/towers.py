@@ -326,6 +326,174 @@ class DbofTower(TowerBase):
         return self.moe.pred
 
 
+class DbofGenericTower(TowerBase):
+    """DbofModel with the flag values NO launcher of the reference selects (cs/frame_level_models.py:108-195): any combination of
+    --dbof_pooling_method max | average (cs/model_utils.py:75-78), --dbof_add_batch_norm True | False (cluster_biases /
+    hidden1_biases instead of the three slim.batch_norm, :158-161,181-185) and --sample_random_frames True | False
+    (SampleRandomSequence, cs/model_utils.py:11-36).  The default combination runs on DbofTower (fused cluster kernel); this tower
+    is the plain chain on the library's generic kernels - one launch per graph op group, the [B*S, clusters] activation in f32 -
+    written for parity, not for speed.  ('none' pooling: FramePooling returns [B*S, C], so the predictions have B*S rows against B
+    label rows: the reference's graph does not train with it - refused by DbofModel.create_model.)"""
+
+    PRECISIONS = ("bf16",)
+    CW, CB, HW, HB = "cluster_weights", "cluster_biases", "hidden1_weights", "hidden1_biases"
+    l2_names = (MoeHead.GATES, MoeHead.EXPERTS)
+
+    def __init__(self, batch_size, max_frames=300, feature_size=1152, vocab_size=4716, iterations=30, cluster_size=8192,
+                 hidden_size=1024, num_mixtures=2, device="cuda:0", training=True, scope="model", seed=0, process_group=None,
+                 pooling="max", add_batch_norm=True, random_frames=True):
+        if pooling not in ("max", "average"):
+            raise ValueError("Unrecognized pooling method: %s" % pooling)                  # cs/model_utils.py:83
+        self.device, self.training, self.scope, self.pg = torch.device(device), training, scope, process_group
+        self.T, self.F, self.V, self.S = max_frames, feature_size, vocab_size, iterations
+        self.Cc, self.Hd, self.Mx = cluster_size, hidden_size, num_mixtures
+        self.pooling, self.bn, self.random_frames = pooling, bool(add_batch_norm), bool(random_frames)
+        if feature_size % 64 or cluster_size % 64 or hidden_size % 64:
+            raise ValueError("feature/cluster/hidden sizes must be multiples of 64 for the MFMA GEMM tiles")
+        F, Cc, Hd = feature_size, cluster_size, hidden_size
+        shapes = OrderedDict()
+        if self.bn:
+            shapes.update(BatchNorm.shapes("input_bn", F))
+        shapes[self.CW] = (Cc, F)                                    # stored transposed [C][F]
+        if self.bn:
+            shapes.update(BatchNorm.shapes("cluster_bn", Cc))
+        else:
+            shapes[self.CB] = (Cc,)
+        shapes[self.HW] = (Hd, Cc)
+        if self.bn:
+            shapes.update(BatchNorm.shapes("hidden1_bn", Hd))
+        else:
+            shapes[self.HB] = (Hd,)
+        shapes.update(MoeHead.shapes(Hd, vocab_size, num_mixtures))
+        self.buffers = OrderedDict()
+        self._setup_store(shapes)
+        if self.bn:
+            self.bn_in, self.bn_cl, self.bn_h = BatchNorm(self, "input_bn", F), BatchNorm(self, "cluster_bn", Cc), BatchNorm(self, "hidden1_bn", Hd)
+        # batch-norm gradients leave BatchNorm.backward already summed over the ranks (all-reduced f64 sums)
+        self.global_grad_names = tuple("%s/%s" % (s_, v) for s_ in ("input_bn", "cluster_bn", "hidden1_bn") for v in ("beta", "gamma")) if self.bn else ()
+        self.moe = MoeHead(self, Hd, vocab_size, num_mixtures)
+        gen = torch.Generator(device="cpu")
+        gen.manual_seed(seed)
+        for k, shp in self.store.shapes.items():          # cs/frame_level_models.py:145-147,158-160,169-171,182-184
+            p = self.store.p(k)
+            if k in (self.CW, self.HW):
+                p.copy_(torch.randn(shp, generator=gen, dtype=F32) / math.sqrt(shp[1]))
+            elif k == self.CB:
+                p.copy_(torch.randn(shp, generator=gen, dtype=F32) / math.sqrt(F))
+            elif k == self.HB:
+                p.copy_(torch.randn(shp, generator=gen, dtype=F32) * 0.01)
+            elif len(shp) == 2:
+                lim = math.sqrt(6.0 / (shp[0] + shp[1]))
+                p.copy_((torch.rand(shp, generator=gen, dtype=F32) * 2 - 1) * lim)
+            elif k.endswith("/gamma"):
+                p.fill_(1.0)
+        self.refresh_shadows()
+        self._alloc(batch_size)
+
+    def _alloc(self, B):
+        dev, F, S, Cc, Hd = self.device, self.F, self.S, self.Cc, self.Hd
+        self.B, self.R = B, B * S
+        R = self.R
+        if self.training and R % 32:
+            raise ValueError("batch_size x iterations = %d must be a multiple of 32 (row count of the TN weight-gradient products)" % R)
+        self.Bk = ops.round_up(B, 32)
+        self.r = torch.empty((R, F), dtype=F32, device=dev)
+        self.idx = torch.empty((B, S), dtype=torch.int32, device=dev)
+        self.r_bn = torch.empty((R, F), dtype=BF16, device=dev)
+        self.act = torch.empty((R, Cc), dtype=F32, device=dev)      # pre-activation (before cluster_bn, or with its bias)
+        self.a6 = torch.empty((R, Cc), dtype=F32, device=dev)
+        self.arg = torch.empty((B, Cc), dtype=torch.int32, device=dev)
+        self.pooled = torch.empty((B, Cc), dtype=F32, device=dev)
+        self.pooled_bf = torch.zeros((self.Bk, Cc), dtype=BF16, device=dev)
+        self.hid = torch.empty((B, Hd), dtype=F32, device=dev)
+        self.h6 = torch.empty((B, Hd), dtype=F32, device=dev)
+        self.moe.alloc(B, self.training)
+        if self.training:
+            self.dhid_bf = torch.zeros((self.Bk, Hd), dtype=BF16, device=dev)
+            self.dpooled = torch.empty((B, Cc), dtype=F32, device=dev)
+            self.dy = torch.empty((R, Cc), dtype=F32, device=dev)
+            self.dact_bf = torch.empty((R, Cc), dtype=BF16, device=dev)
+            self.dx = torch.empty((R, F), dtype=F32, device=dev)
+
+    def forward(self, x, num_frames, uniform, normalize=True, is_training=True):
+        """x [B,T,F] float32 or uint8; uniform: [B,S] f32 in [0,1) (SampleRandomFrames) or [B] / [B,1] (SampleRandomSequence)."""
+        B = x.shape[0]
+        if B != self.B:
+            self._alloc(B)
+        F, S, Cc, Hd, R, st = self.F, self.S, self.Cc, self.Hd, self.R, self.store
+        if self.random_frames:
+            ops.sample_frames_gather(x, uniform, num_frames, self.r, self.idx, normalize=normalize)
+        else:
+            u1 = uniform.reshape(B, -1)[:, 0].contiguous()
+            ops.sample_sequence_gather(x, u1, num_frames, S, self.r, self.idx, normalize=normalize)
+        if self.bn:
+            bi, bc, bh = self.bn_in, self.bn_cl, self.bn_h
+            bi.stats(self.r, R, is_training)
+            ops.bn_apply(self.r, R, F, bi.mean, bi.var, bi.gamma(), bi.beta(), False, y_bf16=self.r_bn)
+            ops.gemm_nt(self.r_bn, self.shadow_fwd[self.CW], R, Cc, F, self.act)
+            bc.stats(self.act, R, is_training)
+            ops.bn_apply(self.act, R, Cc, bc.mean, bc.var, bc.gamma(), bc.beta(), True, y_f32=self.a6)
+        else:
+            ops.cast_bf16(self.r, self.r_bn)
+            ops.gemm_nt(self.r_bn, self.shadow_fwd[self.CW], R, Cc, F, self.act, bias=st.p(self.CB))
+            ops.relu6_fwd(self.act, y_f32=self.a6)
+        if self.pooling == "max":
+            ops.framepool_max_fwd(self.a6, B, S, Cc, self.pooled, self.pooled_bf, self.arg)
+        else:
+            ops.framepool_mean_fwd(self.a6, B, S, Cc, self.pooled, self.pooled_bf)
+        if self.bn:
+            ops.gemm_nt(self.pooled_bf, self.shadow_fwd[self.HW], B, Hd, Cc, self.hid)
+            bh.stats(self.hid, B, is_training)
+            ops.bn_apply(self.hid, B, Hd, bh.mean, bh.var, bh.gamma(), bh.beta(), True, y_f32=self.h6)
+        else:
+            ops.gemm_nt(self.pooled_bf, self.shadow_fwd[self.HW], B, Hd, Cc, self.hid, bias=st.p(self.HB))
+            ops.relu6_fwd(self.hid, y_f32=self.h6)
+        self._taped = self.training and is_training
+        return self.moe.forward(self.h6)
+
+    def grad_stages(self):
+        moe = [MoeHead.GATES, MoeHead.EXPERTS, MoeHead.EBIAS]
+        hidden = [k for k in (self.HW, self.HB, "hidden1_bn/beta", "hidden1_bn/gamma") if k in self.names]
+        return moe, hidden, [k for k in self.names if k not in moe and k not in hidden]
+
+    def backward(self, dpred, on_moe_grads_ready=None, moe_weight_grads=True, on_stage=None):
+        assert self.training and self._taped, "backward needs a training-mode forward"
+        B, F, S, Cc, Hd, R, st = self.B, self.F, self.S, self.Cc, self.Hd, self.R, self.store
+        dh6 = self.moe.backward(dpred, weight_grads=moe_weight_grads)
+        if on_moe_grads_ready is not None:
+            on_moe_grads_ready()
+        if on_stage is not None:
+            on_stage(0)
+        if self.bn:
+            self.bn_h.backward(self.hid, dh6, B, True, dx_bf16=self.dhid_bf)
+        else:
+            ops.relu6_bwd(self.hid, dh6, dx_bf16=self.dhid_bf[:B])
+            ops.colsum_bf16(self.dhid_bf, self.Bk, Hd, st.g(self.HB))
+        ops.gemm_tn(self.dhid_bf, self.pooled_bf, Hd, Cc, self.Bk, st.g(self.HW))          # dWh^T [Hd][C]
+        if on_stage is not None:
+            on_stage(1)
+        ops.gemm_nt(self.dhid_bf, self.shadow_bwd[self.HW], B, Cc, Hd, self.dpooled)
+        if self.pooling == "max":
+            ops.framepool_max_bwd(self.dpooled, self.arg, B, S, Cc, self.dy)
+        else:
+            ops.framepool_mean_bwd(self.dpooled, B, S, Cc, self.dy)
+        if self.bn:
+            self.bn_cl.backward(self.act, self.dy, R, True, dx_bf16=self.dact_bf)
+        else:
+            ops.relu6_bwd(self.act, self.dy, dx_bf16=self.dact_bf)
+            ops.colsum_bf16(self.dact_bf, R, Cc, st.g(self.CB))
+        ops.gemm_tn(self.dact_bf, self.r_bn, Cc, F, R, st.g(self.CW))                        # dWc^T [C][F]
+        if self.bn:
+            ops.gemm_nt(self.dact_bf, self.shadow_bwd[self.CW], R, F, Cc, self.dx)
+            self.bn_in.backward(self.r, self.dx, R, False)
+        if on_stage is not None:
+            on_stage(2)
+
+    @property
+    def pred(self):
+        return self.moe.pred
+
+
 class NetVladTower(TowerBase):
     """NetVLAD aggregation tower - an EXTENSION: the reference announces NetVLAD / NeXtVLAD teacher-student variants
     (README.md:126-127) but ships empty stubs (cs/frame_level_models.py:341-355), so there is no reference math; the

@@ -597,6 +597,18 @@ int evc_lstm_adam_fused(float* p, const float* g, float* m, float* v, float* pb,
                         evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT, evc_f16* p_f16, int64_t ld16, int nin, int nseg,
                         uint8_t* p_fp8, int64_t ld8, int fp8_col0, int fp8_hi_cols, int fp8_lo_exp, int fp8_hi_exp, void* stream);
 
+/* ---- a10, the branches no launcher of the reference selects (cs/frame_level_models.py:126-187; towers.DbofGenericTower) ----
+ * evc_sample_sequence_gather: SampleRandomSequence (cs/model_utils.py:11-36): S consecutive frames from start = int32(u[b] *
+ *   float32(max(n - S, 0) + 1)), index min(start + s, n - 1); arguments as evc_sample_frames_gather, u [B].
+ * evc_relu6_fwd / _bwd: tf.nn.relu6 on a pre-activation that already carries its bias (--dbof_add_batch_norm False) and its gradient
+ *   dy * [0 < x < 6]; f32 and / or bf16 outputs.
+ * evc_framepool_mean_fwd / _bwd: FramePooling 'average' (cs/model_utils.py:75-76): mean over the S frames of y [B][S][C]; dy = dpooled / S. */
+int evc_sample_sequence_gather(const float* x, const uint8_t* x_u8, const float* u, const int32_t* num_frames, int B, int T, int F,
+                               int S, int normalize, float* out, int32_t* idx_out, void* stream);
+int evc_relu6_fwd(const float* x, int64_t n, float* y_f32, evc_bf16* y_bf16, void* stream);
+int evc_relu6_bwd(const float* x, const float* dy, int64_t n, float* dx_f32, evc_bf16* dx_bf16, void* stream);
+int evc_framepool_mean_fwd(const float* y, int B, int S, int C, float* pooled_f32, evc_bf16* pooled_bf16, void* stream);
+int evc_framepool_mean_bwd(const float* dpooled, int B, int S, int C, float* dy, void* stream);
 /* evc_colsum_bf16 without atomics: row block y (of min(R / 64, ws_rows)) leaves its partial sums in ws[y][C] (plain stores), a
  * second launch adds them in index order - the bias gradient from dz under EVC_DETERMINISTIC=1. */
 int evc_colsum_bf16_det(const evc_bf16* in, int64_t ld_in, int R, int C, int deinterleave_H, float* out, float* ws, int ws_rows, void* stream);

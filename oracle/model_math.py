@@ -560,6 +560,78 @@ def dbof_bwd(dpred, cache, routing=None):
 # input_bn -> cluster assignment (matmul, cluster_bn, softmax) -> residual aggregation against learned centres ->
 # intra-normalisation -> l2 normalisation -> hidden layer (matmul, hidden1_bn, relu6) -> MoE.)
 # --------------------------------------------------------------------------
+def sample_random_sequence_index(uniform, num_frames, num_samples):
+    """SampleRandomSequence (cs/model_utils.py:11-36, reached with --sample_random_frames False): num_samples consecutive frames
+    from start = int32(U[0,1) * float32(max(n - num_samples, 0) + 1)), each index clipped at n - 1 (:31-32).  ``uniform`` [B]
+    (the tf.random_uniform([batch_size, 1]) draw) is injected."""
+    u = np.asarray(uniform, np.float32).reshape(-1)
+    n = np.asarray(num_frames).astype(np.int64)
+    mx = np.maximum(n - num_samples, 0)
+    start = (u * (mx + 1).astype(np.float32)).astype(np.int32).astype(np.int64)
+    return np.minimum(start[:, None] + np.arange(num_samples)[None, :], (n - 1)[:, None]).astype(np.int32)
+
+
+def dbof_general_fwd(x, num_frames, uniform, params, pooling="max", add_batch_norm=True, random_frames=True, num_mixtures=2):
+    """DbofModel.create_model (cs/frame_level_models.py:108-195) with every flag combination the reference's graph can train:
+    sample_random_frames True (SampleRandomFrames) / False (SampleRandomSequence, uniform [B]); dbof_add_batch_norm True (three
+    slim.batch_norm) / False (cluster_biases / hidden1_biases, :158-161,181-185); dbof_pooling_method 'max' / 'average'
+    (cs/model_utils.py:75-78).  ('none' returns [B*S, C]: its predictions have B*S rows against B label rows - the graph does not
+    train.)  Training mode (batch statistics)."""
+    B = x.shape[0]
+    S = np.asarray(uniform).shape[1] if random_frames else params["_iterations"]
+    idx = sample_random_frames_index(uniform, num_frames) if random_frames else sample_random_sequence_index(uniform, num_frames, S)
+    r = x[np.arange(B)[:, None], idx, :].reshape(B * S, x.shape[2])
+    c_in = c_cl = c_h = None
+    if add_batch_norm:
+        r_bn, c_in = batch_norm_train_fwd(r, params["input_bn/gamma"], params["input_bn/beta"])
+        act = r_bn @ params["cluster_weights"]
+        pre, c_cl = batch_norm_train_fwd(act, params["cluster_bn/gamma"], params["cluster_bn/beta"])
+    else:
+        r_bn = r
+        pre = r @ params["cluster_weights"] + params["cluster_biases"]
+    a3 = relu6(pre).reshape(B, S, -1)
+    am = a3.argmax(axis=1)
+    pooled = a3.max(axis=1) if pooling == "max" else a3.mean(axis=1)
+    hid = pooled @ params["hidden1_weights"]
+    if add_batch_norm:
+        hpre, c_h = batch_norm_train_fwd(hid, params["hidden1_bn/gamma"], params["hidden1_bn/beta"])
+    else:
+        hpre = hid + params["hidden1_biases"]
+    h6 = relu6(hpre)
+    pred, c_moe = moe_fwd(h6, params["classifier/gates/weights"], params["classifier/experts/weights"],
+                          params["classifier/experts/biases"], num_mixtures)
+    return pred, (idx, r_bn, c_in, pre, c_cl, am, pooled, hpre, c_h, c_moe, (B, S), params, pooling, add_batch_norm)
+
+
+def dbof_general_bwd(dpred, cache):
+    idx, r_bn, c_in, pre, c_cl, am, pooled, hpre, c_h, c_moe, (B, S), params, pooling, bn = cache
+    g = {}
+    dh6, g["classifier/gates/weights"], g["classifier/experts/weights"], g["classifier/experts/biases"] = moe_bwd(dpred, c_moe)
+    dhpre = dh6 * ((hpre > 0) & (hpre < 6))
+    if bn:
+        dhid, g["hidden1_bn/gamma"], g["hidden1_bn/beta"] = batch_norm_train_bwd(dhpre, c_h)
+    else:
+        dhid, g["hidden1_biases"] = dhpre, dhpre.sum(0)
+    g["hidden1_weights"] = pooled.T @ dhid
+    dpooled = dhid @ params["hidden1_weights"].T
+    C = dpooled.shape[1]
+    if pooling == "max":
+        da3 = np.zeros((B, S, C), dpooled.dtype)
+        bi, ci = np.meshgrid(np.arange(B), np.arange(C), indexing="ij")
+        da3[bi, am, ci] = dpooled
+    else:
+        da3 = np.repeat(dpooled[:, None, :] / S, S, axis=1)
+    dpre = da3.reshape(B * S, C) * ((pre > 0) & (pre < 6))
+    if bn:
+        dact, g["cluster_bn/gamma"], g["cluster_bn/beta"] = batch_norm_train_bwd(dpre, c_cl)
+    else:
+        dact, g["cluster_biases"] = dpre, dpre.sum(0)
+    g["cluster_weights"] = r_bn.T @ dact
+    if bn:
+        _, g["input_bn/gamma"], g["input_bn/beta"] = batch_norm_train_bwd(dact @ params["cluster_weights"].T, c_in)
+    return g
+
+
 def netvlad_fwd(x, num_frames, uniform, params, num_mixtures=2):
     B = x.shape[0]
     idx = sample_random_frames_index(uniform, num_frames)

@@ -37,7 +37,7 @@ run "no process group (plain single-GPU step)" python3 $ARGS
 # atomics moved the trajectory by a few percent after ~20 Adam iterations on noise - compared at 15 %): the two RCCL runs take the same
 # code path and must report IDENTICAL losses; the plain run computes the MoE clip norm another way (Gram matrices instead of the
 # row-slab passes: last-bit differences in a scale Adam nearly cancels) and must agree to TOL (default 5e-3; measured 2e-3 after 13 iterations)
-python3 - "$OUT" <<'PY'
+python3 - "$OUT" <<'PY' | tee "$OUT.verdict"
 import json, sys
 rows = [json.loads(l[len("LOSSES "):]) for l in open(sys.argv[1]) if l.startswith("LOSSES ")]
 import os
@@ -53,3 +53,4 @@ for k, v in rows[2].items():
         assert abs(r[k] - v) <= tol * max(1.0, abs(v)), ("losses differ from the plain single-GPU run", k, r[k], v)
 print("losses of the three runs agree (worst relative difference to the plain run %.2e, tolerance %g)" % (worst, tol))
 PY
+cat "$OUT.verdict" >> "$OUT"; rm -f "$OUT.verdict"

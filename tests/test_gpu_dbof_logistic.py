@@ -156,6 +156,90 @@ def test_dbof_cfg4_batch_512_properties(precision):
     assert d < (2e-5 if precision == "high" else 2e-4), d
 
 
+@pytest.mark.parametrize("pooling,bn,random_frames", [("average", True, True), ("max", False, True), ("max", True, False),
+                                                       ("average", False, False), ("max", True, True)])
+def test_dbof_non_default_branches(pooling, bn, random_frames):
+    """The DbofModel flag values no launcher of the reference selects - dbof_pooling_method average, dbof_add_batch_norm False
+    (cluster_biases / hidden1_biases), sample_random_frames False (SampleRandomSequence) - on towers.DbofGenericTower against the
+    float64 oracle (oracle/model_math.py::dbof_general_fwd / _bwd, itself checked against finite differences on the CPU): sampled
+    indices bit-exact, predictions, gradients by relative L2, one SingleTowerGraph training step; the default combination on the
+    same tower must agree with the fused DbofTower."""
+    from efficientvideoclassification_youtube8m_amd.towers import DbofGenericTower, DbofTower
+    from efficientvideoclassification_youtube8m_amd.distill import SingleTowerGraph
+    B, F, C, Hd, V, S = 16, 128, 256, 64, 40, 8
+    rng = np.random.default_rng(11)
+    q, x, n, labels = mm.synthetic_batch(B, seed=3, feature_size=F, vocab_size=V, dtype=np.float32)
+    n[:3] = (1, 5, 300)                                              # shorter than the sequence / full length
+    x[np.arange(300)[None, :] >= n[:, None]] = 0.0
+    tw = DbofGenericTower(B, 300, F, V, iterations=S, cluster_size=C, hidden_size=Hd, device=DEV, seed=3, pooling=pooling,
+                          add_batch_norm=bn, random_frames=random_frames)
+    for k in tw.names:                                               # non-trivial affine / bias parameters
+        if k.endswith("/gamma") or k.endswith("/beta") or k.endswith("_biases"):
+            tw.store.p(k).add_(torch.from_numpy(rng.standard_normal(tw.store.p(k).shape).astype(np.float32) * 0.2).to(DEV))
+    P = _params(tw)
+    P["_iterations"] = S
+    u = rng.random((B, S)).astype(np.float32) if random_frames else rng.random((B, 1)).astype(np.float32)
+    xd, nd, ud = torch.from_numpy(x).to(DEV), torch.from_numpy(n).to(DEV), torch.from_numpy(u).to(DEV)
+    pred = tw.forward(xd, nd, ud)
+    xn = mm.l2_normalize(x.astype(np.float64), 2)
+    ref_pred, cache = mm.dbof_general_fwd(xn, n, u if random_frames else u[:, 0], P, pooling=pooling, add_batch_norm=bn, random_frames=random_frames)
+    assert np.array_equal(tw.idx.cpu().numpy(), cache[0])            # bit-exact indices (int32 truncation / clipping)
+    err = np.abs(_np(pred) - ref_pred).max()
+    assert err < 8e-3, err
+    dp = mm.cross_entropy_grad(ref_pred, labels)
+    tw.backward(torch.from_numpy(dp.astype(np.float32)).to(DEV))
+    gref = mm.dbof_general_bwd(dp, cache)
+    worst = {}
+    for k, g in gref.items():
+        got = tw.store.g(k)
+        got = _np(got.t() if got.dim() == 2 else got)
+        if k.endswith("/beta") and np.abs(g).max() < 1e-3 * np.abs(gref[k[:-5] + "/gamma"]).max():
+            continue                                                 # (a beta cancelled by the next layer's mean subtraction: see test_dbof_forward_backward)
+        l2 = float(np.linalg.norm(got - g) / (np.linalg.norm(g) + 1e-30))
+        worst[k] = round(l2, 4)
+        assert l2 < (6e-2 if pooling == "max" else 3e-2), (k, l2)    # (max: a near-tie routed to another frame moves a whole dy)
+    print("dbof generic (%s, bn %s, random_frames %s): pred err %.2e, gradient relative L2 %s" % (pooling, bn, random_frames, err, worst))
+    if pooling == "max" and bn and random_frames:                    # the default combination: the fused tower computes the same function
+        tf_ = DbofTower(B, 300, F, V, iterations=S, cluster_size=C, hidden_size=Hd, device=DEV, seed=5)
+        tf_.load_state_dict(tw.state_dict())
+        assert (tf_.forward(xd, nd, ud) - pred).abs().max().item() < 8e-3
+    g = SingleTowerGraph(tw)
+    l0 = float(g.step(xd, torch.from_numpy(labels.astype(np.uint8)).to(DEV), nd, uniform=ud)["loss"])
+    for _ in range(3):
+        out = g.step(xd, torch.from_numpy(labels.astype(np.uint8)).to(DEV), nd, uniform=ud)
+    assert g.global_step == 4 and torch.isfinite(out["predictions"]).all() and float(out["loss"]) < l0
+
+
+def test_dbof_model_flag_surface_for_non_default_branches():
+    """DbofModel.create_model picks the generic tower for a non-default flag combination (the reference's `x or FLAG` defaults,
+    cs/frame_level_models.py:118-122), refuses 'none' pooling with the reason, and rejects an unknown method like cs/model_utils.py:83."""
+    from efficientvideoclassification_youtube8m_amd import frame_level_models as flm
+    from efficientvideoclassification_youtube8m_amd.flags import FLAGS
+    from efficientvideoclassification_youtube8m_amd.towers import DbofGenericTower
+    from efficientvideoclassification_youtube8m_amd.model_utils import SampleRandomSequence
+    q, x, n, labels = mm.synthetic_batch(8, seed=4, feature_size=64, vocab_size=24, dtype=np.float32)
+    xd, nd = torch.from_numpy(x).to(DEV), torch.from_numpy(n).to(DEV)
+    old = (FLAGS.dbof_pooling_method, FLAGS.dbof_add_batch_norm, FLAGS.sample_random_frames)
+    try:
+        FLAGS.dbof_pooling_method, FLAGS.dbof_add_batch_norm, FLAGS.sample_random_frames = "average", False, False
+        m = flm.DbofModel()
+        out = m.create_model(xd, 24, nd, iterations=8, cluster_size=128, hidden_size=64)
+        assert isinstance(m.towers["model"], DbofGenericTower) and out["predictions"].shape == (8, 24)
+        assert m.towers["model"].pooling == "average" and not m.towers["model"].bn and not m.towers["model"].random_frames
+        FLAGS.dbof_pooling_method = "none"
+        with pytest.raises(NotImplementedError):
+            flm.DbofModel().create_model(xd, 24, nd, iterations=8, cluster_size=128, hidden_size=64)
+        FLAGS.dbof_pooling_method = "attention"
+        with pytest.raises(ValueError):
+            flm.DbofModel().create_model(xd, 24, nd, iterations=8, cluster_size=128, hidden_size=64)
+    finally:
+        FLAGS.dbof_pooling_method, FLAGS.dbof_add_batch_norm, FLAGS.sample_random_frames = old
+    u = torch.tensor([0.0, 0.5, 0.999, 0.3, 0.1, 0.2, 0.7, 0.9], device=DEV)
+    seq = SampleRandomSequence(xd, nd, 5, uniform=u)
+    idx = mm.sample_random_sequence_index(u.cpu().numpy(), n, 5)
+    assert torch.equal(seq.cpu(), torch.from_numpy(x[np.arange(8)[:, None], idx, :]))
+
+
 def test_logistic_forward_backward_and_step():
     from efficientvideoclassification_youtube8m_amd.towers import LogisticTower
     from efficientvideoclassification_youtube8m_amd.distill import SingleTowerGraph

@@ -349,3 +349,50 @@ def test_netvlad_oracle_backward_matches_finite_differences():
             fd = (lp - lm) / (2 * eps)
             got = grads[k].reshape(-1)[j]
             assert abs(fd - got) <= 1e-5 * max(1.0, abs(fd)) + 1e-7, (k, j, fd, got)
+
+
+def test_dbof_general_oracle_matches_the_default_form_and_finite_differences():
+    """oracle/model_math.py::dbof_general_fwd / _bwd (every trainable flag combination of cs/frame_level_models.py:108-195): the
+    default combination reproduces dbof_fwd / dbof_bwd exactly; the non-default one (average pooling, biases instead of batch-norm,
+    SampleRandomSequence) has its hand-written reverse mode checked against central finite differences; the sequence indices
+    follow cs/model_utils.py:22-36 (start from the float32 product, clipping at n - 1)."""
+    rng = np.random.default_rng(0)
+    B, F, C, H, V, S = 4, 8, 16, 8, 6, 5
+    q, x, n, labels = mm.synthetic_batch(B, seed=1, feature_size=F, vocab_size=V, dtype=np.float64)
+    P = mm.init_dbof_params(rng, F, C, H, V)
+    u = rng.random((B, S)).astype(np.float32)
+    xn = mm.l2_normalize(x, 2)
+    p0, c0 = mm.dbof_fwd(xn, n, u, P)
+    p1, c1 = mm.dbof_general_fwd(xn, n, u, P)
+    assert np.array_equal(p0, p1)
+    dp = mm.cross_entropy_grad(p0, labels)
+    g0, g1 = mm.dbof_bwd(dp, c0), mm.dbof_general_bwd(dp, c1)
+    for k in g0:
+        assert np.allclose(g0[k], g1[k], rtol=1e-12, atol=1e-15), k
+    P2 = dict(P)
+    P2["cluster_biases"], P2["hidden1_biases"], P2["_iterations"] = rng.standard_normal(C) / np.sqrt(F), rng.standard_normal(H) * 0.01, S
+    for k in ("cluster_weights", "hidden1_weights"):
+        P2[k] = P2[k] * 3
+    u1 = rng.random(B).astype(np.float32)
+    kw = dict(pooling="average", add_batch_norm=False, random_frames=False)
+
+    def loss(P_):
+        return mm.cross_entropy_loss(mm.dbof_general_fwd(xn, n, u1, P_, **kw)[0], labels)
+    p, c = mm.dbof_general_fwd(xn, n, u1, P2, **kw)
+    g = mm.dbof_general_bwd(mm.cross_entropy_grad(p, labels), c)
+    for k in ("cluster_weights", "cluster_biases", "hidden1_weights", "hidden1_biases"):
+        a = P2[k]
+        for cnt, i in enumerate(np.ndindex(a.shape)):
+            if cnt % 7:
+                continue
+            old = a[i]
+            a[i] = old + 1e-6
+            lp = loss(P2)
+            a[i] = old - 1e-6
+            lm = loss(P2)
+            a[i] = old
+            fd = (lp - lm) / 2e-6
+            if abs(fd) > 1e-7:
+                assert abs(fd - g[k][i]) < 1e-5 * abs(fd) + 1e-9, (k, i, fd, g[k][i])
+    idx = mm.sample_random_sequence_index(np.array([0.0, 0.5, 0.999, 0.3], np.float32), np.array([300, 3, 40, 1]), 5)
+    assert idx.tolist() == [[0, 1, 2, 3, 4], [0, 1, 2, 2, 2], [35, 36, 37, 38, 39], [0, 0, 0, 0, 0]]
