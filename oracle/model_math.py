@@ -603,11 +603,18 @@ def dbof_general_fwd(x, num_frames, uniform, params, pooling="max", add_batch_no
     return pred, (idx, r_bn, c_in, pre, c_cl, am, pooled, hpre, c_h, c_moe, (B, S), params, pooling, add_batch_norm)
 
 
-def dbof_general_bwd(dpred, cache):
+def dbof_general_bwd(dpred, cache, routing=None):
+    """routing (tests only, as in dbof_bwd): (argmax [B, C] int or None, cluster relu6 mask [B*S, C] bool, hidden relu6 mask [B, Hd]
+    bool) - the discrete decisions of another implementation of the same forward, imposed so that both gradients are the same
+    smooth function (the decisions themselves are compared separately)."""
     idx, r_bn, c_in, pre, c_cl, am, pooled, hpre, c_h, c_moe, (B, S), params, pooling, bn = cache
+    mask_c, mask_h = (pre > 0) & (pre < 6), (hpre > 0) & (hpre < 6)
+    if routing is not None:
+        am = routing[0] if routing[0] is not None else am
+        mask_c, mask_h = routing[1], routing[2]
     g = {}
     dh6, g["classifier/gates/weights"], g["classifier/experts/weights"], g["classifier/experts/biases"] = moe_bwd(dpred, c_moe)
-    dhpre = dh6 * ((hpre > 0) & (hpre < 6))
+    dhpre = dh6 * mask_h
     if bn:
         dhid, g["hidden1_bn/gamma"], g["hidden1_bn/beta"] = batch_norm_train_bwd(dhpre, c_h)
     else:
@@ -621,7 +628,7 @@ def dbof_general_bwd(dpred, cache):
         da3[bi, am, ci] = dpooled
     else:
         da3 = np.repeat(dpooled[:, None, :] / S, S, axis=1)
-    dpre = da3.reshape(B * S, C) * ((pre > 0) & (pre < 6))
+    dpre = da3.reshape(B * S, C) * mask_c
     if bn:
         dact, g["cluster_bn/gamma"], g["cluster_bn/beta"] = batch_norm_train_bwd(dpre, c_cl)
     else:

@@ -188,7 +188,24 @@ def test_dbof_non_default_branches(pooling, bn, random_frames):
     assert err < 8e-3, err
     dp = mm.cross_entropy_grad(ref_pred, labels)
     tw.backward(torch.from_numpy(dp.astype(np.float32)).to(DEV))
-    gref = mm.dbof_general_bwd(dp, cache)
+    # the tower's discrete decisions (relu6 kinks, max-pool choice) are taken on bf16-rounded values: few may differ from the
+    # oracle's, and only where the oracle's value is close to the kink / the tie; the gradients are then compared on the TOWER'S
+    # decisions (the same smooth function on both sides), as in test_dbof_forward_backward
+    pre, hpre = cache[3], cache[7]
+    a6, h6 = _np(tw.a6), _np(tw.h6)
+    mask_c, mask_h = (a6 > 0) & (a6 < 6), (h6 > 0) & (h6 < 6)
+    for got_m, ref_v in ((mask_c, pre), (mask_h, hpre)):
+        flips = got_m != ((ref_v > 0) & (ref_v < 6))
+        dk = np.minimum(np.abs(ref_v), np.abs(ref_v - 6.0))
+        assert float(flips.mean()) < 0.02 and dk[flips].max(initial=0.0) < 0.08, (float(flips.mean()), dk[flips].max(initial=0.0))
+    am = None
+    if pooling == "max":
+        am = tw.arg.cpu().numpy().astype(np.int64)
+        a3 = mm.relu6(pre).reshape(B, S, C)
+        bi_, ci_ = np.meshgrid(np.arange(B), np.arange(C), indexing="ij")
+        margin = a3.max(axis=1) - a3[bi_, am, ci_]
+        assert margin.min() >= 0.0 and margin.max() < 0.08, margin.max()       # another frame only on a near-tie
+    gref = mm.dbof_general_bwd(dp, cache, routing=(am, mask_c, mask_h))
     worst = {}
     for k, g in gref.items():
         got = tw.store.g(k)
@@ -197,7 +214,7 @@ def test_dbof_non_default_branches(pooling, bn, random_frames):
             continue                                                 # (a beta cancelled by the next layer's mean subtraction: see test_dbof_forward_backward)
         l2 = float(np.linalg.norm(got - g) / (np.linalg.norm(g) + 1e-30))
         worst[k] = round(l2, 4)
-        assert l2 < (6e-2 if pooling == "max" else 3e-2), (k, l2)    # (max: a near-tie routed to another frame moves a whole dy)
+        assert l2 < 3e-2, (k, l2)                                    # bf16 operands of the backward products
     print("dbof generic (%s, bn %s, random_frames %s): pred err %.2e, gradient relative L2 %s" % (pooling, bn, random_frames, err, worst))
     if pooling == "max" and bn and random_frames:                    # the default combination: the fused tower computes the same function
         tf_ = DbofTower(B, 300, F, V, iterations=S, cluster_size=C, hidden_size=Hd, device=DEV, seed=5)
