@@ -61,6 +61,7 @@ SIGNATURES = {
     "evc_sqnorm2_partials": [vp, i64, vp, i64, vp, vp],
     "evc_lstm_adam_fused": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, f32, f32, f32, f32, f32, vp, vp, i64, vp, i64, i32, i32,
                             vp, i64, i32, i32, i32, i32, vp],
+    "evc_adam2d_fused": [vp, vp, vp, vp, i32, i32, vp, vp, f32, f32, f32, f32, f32, vp, vp, i64, vp, i64, vp, i64, i32, i32, i32, vp],
     "evc_meanpool_fwd": [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp],
     "evc_sigmoid_fwd": [vp, i64, vp],
     "evc_sigmoid_bwd": [vp, vp, i64, vp, vp],

@@ -77,10 +77,13 @@ __device__ __forceinline__ float sum_partials(const float* __restrict__ part, in
   return wave_sum(s);
 }
 
+// IL = true: an LSTM kernel [4H][C] (row g*H+u; backward shadow column u*4+g) with its bias; IL = false: any 2-D weight [R][C] stored as
+// the forward GEMM's B operand (backward shadow = its plain transpose, zero-padded to ldT columns), no bias
+template <bool IL>
 __global__ __launch_bounds__(256) void lstm_adam_fused_kernel(LstmAdamParams u) {
   __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];      // [k][u*4+g] of one 16-unit x 64-column tile
   const int t = threadIdx.x;
-  if ((int)blockIdx.x >= u.n_tiles) {                  // bias blocks: 1024 elements each
+  if (IL && (int)blockIdx.x >= u.n_tiles) {            // bias blocks: 1024 elements each
     const float ss = u.part[EVC_SQN_BLOCKS];
     const float scale = u.clip > 0.f ? u.clip / fmaxf(sqrtf(ss), u.clip) : 1.f;
     const int j = (blockIdx.x - u.n_tiles) * 1024 + t * 4;
@@ -105,12 +108,13 @@ __global__ __launch_bounds__(256) void lstm_adam_fused_kernel(LstmAdamParams u) 
   const int u0 = tr * 16, k0 = tcn * 64;
   const int c4 = t & 15, i = t >> 4;                   // this thread: unit u0 + i, columns k0 + 4 c4 .. + 3, all four gates
   const int col = k0 + c4 * 4;
-  const bool ok = col < u.C;                           // (C % 4 == 0: a lane's 4 columns are all valid or all not)
+  const bool okc = col < u.C;                          // (C % 4 == 0: a lane's 4 columns are all valid or all not)
+  auto row_of = [&](int g) { return IL ? g * u.H + u0 + i : tr * 64 + g * 16 + i; };
   float4 pv[4], gv[4], mv[4], vv[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {                        // all loads first (16 x 16 bytes in flight per lane)
-    const long o = (long)(g * u.H + u0 + i) * u.C + col;
-    if (ok) { pv[g] = *(const float4*)(u.p + o); gv[g] = *(const float4*)(u.g + o); mv[g] = *(const float4*)(u.m + o); vv[g] = *(const float4*)(u.v + o); }
+    const long o = (long)row_of(g) * u.C + col;
+    if (okc && row_of(g) < u.R) { pv[g] = *(const float4*)(u.p + o); gv[g] = *(const float4*)(u.g + o); mv[g] = *(const float4*)(u.m + o); vv[g] = *(const float4*)(u.v + o); }
     else pv[g] = gv[g] = mv[g] = vv[g] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const float ss = sum_partials(u.part, EVC_SQN_BLOCKS);
@@ -131,8 +135,8 @@ __global__ __launch_bounds__(256) void lstm_adam_fused_kernel(LstmAdamParams u) 
     }
     pbits[g][0] = pack_bf16x2_hw(pn[0], pn[1]);
     pbits[g][1] = pack_bf16x2_hw(pn[2], pn[3]);
-    if (!ok) continue;
-    const long row = (long)g * u.H + u0 + i;
+    const long row = row_of(g);
+    if (!okc || row >= u.R) continue;
     const long o = row * u.C + col;
     *(float4*)(u.m + o) = make_float4(mn[0], mn[1], mn[2], mn[3]);
     *(float4*)(u.v + o) = make_float4(vn[0], vn[1], vn[2], vn[3]);
@@ -183,13 +187,20 @@ __global__ __launch_bounds__(256) void lstm_adam_fused_kernel(LstmAdamParams u) 
       lo = (pbits[0][e >> 1] & 0xffffu) | (pbits[1][e >> 1] << 16);
       hi = (pbits[2][e >> 1] & 0xffffu) | (pbits[3][e >> 1] << 16);
     }
-    *(uint2*)&tile[c4 * 4 + e][i * 4] = make_uint2(lo, hi);
+    if (IL) {
+      *(uint2*)&tile[c4 * 4 + e][i * 4] = make_uint2(lo, hi);
+    } else {                                           // plain transpose: tile[k][local row g*16 + i]
+      tile[c4 * 4 + e][i] = (bf16_t)(lo & 0xffffu);
+      tile[c4 * 4 + e][16 + i] = (bf16_t)(lo >> 16);
+      tile[c4 * 4 + e][32 + i] = (bf16_t)(hi & 0xffffu);
+      tile[c4 * 4 + e][48 + i] = (bf16_t)(hi >> 16);
+    }
   }
   __syncthreads();
   const int kk = t >> 2, part4 = t & 3;
   if (k0 + kk < u.C) {
     const uint4 q0 = *(const uint4*)&tile[kk][part4 * 16], q1 = *(const uint4*)&tile[kk][part4 * 16 + 8];
-    bf16_t* dst = u.pT + (long)(k0 + kk) * u.ldT + (long)u0 * 4 + part4 * 16;
+    bf16_t* dst = u.pT + (long)(k0 + kk) * u.ldT + (IL ? (long)u0 * 4 : (long)tr * 64) + part4 * 16;
     *(uint4*)dst = q0;
     *(uint4*)(dst + 8) = q1;
   }
@@ -221,7 +232,36 @@ extern "C" int evc_lstm_adam_fused(float* p, const float* g, float* m, float* v,
   u.tiles_c = (C + 63) / 64;
   u.n_tiles = (H / 16) * u.tiles_c;
   const int bias_blocks = (4 * H + 1023) / 1024;
-  hipLaunchKernelGGL(lstm_adam_fused_kernel, dim3(u.n_tiles + bias_blocks), dim3(256), 0, (hipStream_t)stream, u);
+  hipLaunchKernelGGL(lstm_adam_fused_kernel<true>, dim3(u.n_tiles + bias_blocks), dim3(256), 0, (hipStream_t)stream, u);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// The same pass for a plain 2-D weight p [R][C] (stored as the forward GEMM's B operand: DBoF cluster / hidden weights): clip + TF-Adam from
+// the partials of evc_sqnorm2_partials(g, n, NULL, 0), bf16 forward shadow, transposed bf16 backward shadow pT [C][ldT] (ldT >= round_up(R, 64);
+// the pad columns are written as zeros), and the optional f16 / e4m3 images (arguments as evc_lstm_adam_fused with nin = C: no K-extension blocks).
+extern "C" int evc_adam2d_fused(float* p, const float* g, float* m, float* v, int R, int C, const float* part, float* sums_w, float clip_norm, float lr_t,
+                                float beta1, float beta2, float eps, evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT, evc_f16* p_f16, int64_t ld16,
+                                uint8_t* p_fp8, int64_t ld8, int fp8_hi_cols, int fp8_lo_exp, int fp8_hi_exp, void* stream) {
+  EVC_REQUIRE(R > 0 && C > 0 && C % 4 == 0, EVC_ERR_BAD_SHAPE, "evc_adam2d_fused: R=%d C=%d (%%4)", R, C);
+  EVC_REQUIRE(p && g && m && v && part && sums_w && p_bf16 && pT_bf16, EVC_ERR_BAD_ARG, "evc_adam2d_fused: NULL argument");
+  EVC_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0 && ((uintptr_t)p_bf16 % 8) == 0 &&
+              ((uintptr_t)pT_bf16 % 16) == 0 && ldT % 8 == 0 && ldT >= (R + 63) / 64 * 64, EVC_ERR_BAD_ALIGN, "evc_adam2d_fused: alignment / ldT=%ld (>= R rounded up to 64)", (long)ldT);
+  EVC_REQUIRE(!p_f16 || (((uintptr_t)p_f16 % 8) == 0 && ld16 % 4 == 0 && ld16 >= C), EVC_ERR_BAD_ARG, "evc_adam2d_fused: f16 image ld16=%ld", (long)ld16);
+  EVC_REQUIRE(!p_fp8 || (((uintptr_t)p_fp8 % 4) == 0 && fp8_hi_cols >= 0 && fp8_hi_cols % 4 == 0 && fp8_hi_cols <= C && ld8 % 4 == 0 && ld8 >= (long)C + fp8_hi_cols &&
+                         fp8_lo_exp >= 0 && fp8_lo_exp <= 60 && fp8_hi_exp >= -30 && fp8_hi_exp <= 30), EVC_ERR_BAD_ARG,
+              "evc_adam2d_fused: e4m3 image hi_cols=%d ld8=%ld lo_exp=%d hi_exp=%d", fp8_hi_cols, (long)ld8, fp8_lo_exp, fp8_hi_exp);
+  LstmAdamParams u;
+  u.p = p; u.g = g; u.m = m; u.v = v; u.pb = nullptr; u.gb = nullptr; u.mb = nullptr; u.vb = nullptr;
+  u.R = R; u.C = C; u.H = 0; u.part = part; u.sums_w = sums_w; u.sums_b = nullptr;
+  u.clip = clip_norm; u.lr_t = lr_t; u.b1 = beta1; u.b2 = beta2; u.eps = eps;
+  u.p_bf16 = (bf16_t*)p_bf16; u.pT = (bf16_t*)pT_bf16; u.ldT = ldT;
+  u.p16 = (f16_t*)p_f16; u.ld16 = ld16; u.nin = C; u.nseg = 1;
+  u.p8 = p_fp8; u.ld8 = ld8; u.col0 = 0; u.hi_cols = fp8_hi_cols;
+  u.lo_scale = ldexpf(1.0f, fp8_lo_exp); u.hi_scale = ldexpf(1.0f, fp8_hi_exp);
+  u.tiles_c = (C + 63) / 64;
+  u.n_tiles = ((R + 63) / 64) * u.tiles_c;
+  hipLaunchKernelGGL(lstm_adam_fused_kernel<false>, dim3(u.n_tiles), dim3(256), 0, (hipStream_t)stream, u);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }

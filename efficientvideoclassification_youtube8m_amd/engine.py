@@ -865,6 +865,19 @@ class TowerBase:
                                     ws, self.sums[idx[k]], self.sums[idx[b]], clip_norm, lr_t, self.shadow_fwd[k], self.shadow_bwd[k],
                                     beta1, beta2, eps, **img)
                 done.update((k, b))
+            # plain 2-D weights without a regulariser (DBoF cluster / hidden weights, ...): the same pass without a bias (ops.adam2d_fused)
+            for k in names:
+                if k in done or k not in self.shadow_bwd or k in self.l2_names or k.endswith("basic_lstm_cell/kernel"):
+                    continue
+                img = self._adam_images_2d(k)
+                if img is None or self.store.shapes[k][1] % 4:
+                    continue
+                if not hasattr(self, "_sqn_ws"):
+                    self._sqn_ws = {}
+                ws = self._sqn_ws.setdefault(k, torch.empty(1028, dtype=F32, device=self.device))
+                ops.adam2d_fused(st.p(k), st.g(k), st.view(st.m, k), st.view(st.v, k), ws, self.sums[idx[k]], clip_norm, lr_t,
+                                 self.shadow_fwd[k], self.shadow_bwd[k], beta1, beta2, eps, **img)
+                done.add(k)
         rest = [k for k in names if k not in done]
         for k in rest:
             l2 = l2_coeff if k in self.l2_names else 0.0
@@ -888,6 +901,19 @@ class TowerBase:
                     ops.transpose_to_bf16(p, p.shape[0], p.shape[1], sb, sb.shape[1], interleave_H=il)
 
     fused_lstm_adam = os.environ.get("EVC_FUSED_LSTM_ADAM", "1") != "0"     # A/B: 0 = grad_sqnorm / clip_adam / transpose / cast launches per tensor
+
+    def _adam_images_2d(self, k):
+        """The same for a plain 2-D weight (ops.adam2d_fused): {} in bf16; f16 + e4m3 images where this tower keeps them (shadow_w16 / shadow_w8
+        with hi_cols = the row length: ops.gemm_nt_f16_fp8's B operands); None for separate hi / lo bf16 shadows (their cast launches stay)."""
+        if self.precision == "bf16":
+            return {}
+        if k in getattr(self, "shadow_w8", {}):
+            e = self._fp8_exps(k)
+            return dict(p_f16=self.shadow_w16[k], p_fp8=self.shadow_w8[k], fp8_hi_cols=self.store.shapes[k][1], fp8_lo_exp=e["w_lo_exp"], fp8_hi_exp=e["w_hi_exp"])
+        return None
+
+    def _fp8_exps(self, k):
+        return ops.FP8_MOE
 
     def _adam_images(self, k):
         """Keyword arguments of ops.lstm_adam_fused describing the non-bf16 forward operand images of LSTM kernel k that the update pass

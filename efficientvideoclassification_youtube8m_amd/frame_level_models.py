@@ -174,7 +174,7 @@ class NetVLADModel(models.BaseModel):
         nf = num_frames.reshape(-1).to(torch.int32)
         u = unused_params.get("uniform")
         if u is None:
-            u = torch.rand((B, iterations if random_frames else 1), dtype=torch.float32, device=model_input.device)
+            u = torch.rand((B, iterations), dtype=torch.float32, device=model_input.device)
         return {"predictions": tw.forward(model_input.contiguous(), nf, u, normalize=unused_params.get("normalize_input", False),
                                           is_training=is_training)}
 

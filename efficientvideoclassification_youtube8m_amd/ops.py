@@ -491,6 +491,20 @@ def lstm_adam_fused(p, g, m, v, pb, gb, mb, vb, part_ws, sums_w, sums_b, clip_no
               nin, nseg, _p(p_fp8), p_fp8.stride(0) if p_fp8 is not None else 0, fp8_col0, fp8_hi_cols, fp8_lo_exp, fp8_hi_exp, _stream())
 
 
+def adam2d_fused(p, g, m, v, part_ws, sums_w, clip_norm, lr_t, p_bf16, pT_bf16, beta1=0.9, beta2=0.999, eps=1e-8,
+                 p_f16=None, p_fp8=None, fp8_hi_cols=0, fp8_lo_exp=FP8_W_SCALE_EXP, fp8_hi_exp=FP8_WX_HI_EXP):
+    """lstm_adam_fused for a plain 2-D weight p [R][C] without a bias (evc_sqnorm2_partials + evc_adam2d_fused): clip + TF-Adam, bf16 forward shadow,
+    transposed bf16 backward shadow (pad columns zeroed) and the optional f16 / e4m3 images, one pass over the weights."""
+    R, C = p.shape
+    assert p.is_contiguous() and g.is_contiguous() and part_ws.numel() >= 1025 and pT_bf16.shape[0] == C and pT_bf16.stride(0) >= round_up(R, 64)
+    assert p_f16 is None or (p_f16.dtype == F16 and p_f16.shape == (R, C) and p_f16.is_contiguous())
+    assert p_fp8 is None or (p_fp8.dtype == torch.uint8 and p_fp8.shape == (R, C + fp8_hi_cols) and p_fp8.is_contiguous())
+    _lib.call("evc_sqnorm2_partials", _p(g), g.numel(), None, 0, _p(part_ws), _stream())
+    _lib.call("evc_adam2d_fused", _p(p), _p(g), _p(m), _p(v), R, C, _p(part_ws), _p(sums_w), clip_norm, lr_t, beta1, beta2, eps, _p(p_bf16), _p(pT_bf16),
+              pT_bf16.stride(0), _p(p_f16), C if p_f16 is not None else 0, _p(p_fp8), p_fp8.stride(0) if p_fp8 is not None else 0, fp8_hi_cols,
+              fp8_lo_exp, fp8_hi_exp, _stream())
+
+
 def clip_adam_step(p, g, m, v, l2_coeff, sums, clip_norm, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, p_bf16=None):
     _lib.call("evc_clip_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), l2_coeff, _p(sums), clip_norm, lr_t, beta1, beta2, eps,
               _p(p_bf16), _stream())

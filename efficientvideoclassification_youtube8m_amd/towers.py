@@ -187,9 +187,12 @@ class DbofTower(TowerBase):
         else:
             super()._alloc_high_shadows()
 
+    def _fp8_exps(self, k):
+        return ops.FP8_DBOF_CLUSTER if k == self.CW else ops.FP8_MOE
+
     def _refresh_high(self, k):
         if k in getattr(self, "shadow_w8", {}):
-            e = ops.FP8_DBOF_CLUSTER if k == self.CW else ops.FP8_MOE
+            e = self._fp8_exps(k)
             p = self.store.p(k)
             ops.cast_f16(p, self.shadow_w16[k])
             ops.cast_fp8_lo(p, self.shadow_w8[k], hi_cols=p.shape[1], scale_exp=e["w_lo_exp"], hi_exp=e["w_hi_exp"])

@@ -36,7 +36,7 @@ extern "C" {
 #define EVC_ERR_HIP (-4)
 #define EVC_ERR_BAD_ARG (-5)
 
-#define EVC_VERSION 103   /* 103 (round 4): evc_sqnorm2_partials, evc_lstm_adam_fused, evc_gram_slabs, evc_moe_grad_norms, evc_moe_grad_update_apply, evc_colsum_bf16_det, evc_sample_sequence_gather, evc_relu6_fwd/bwd, evc_framepool_mean_fwd/bwd, evc_stream_create_cu_mask / evc_stream_destroy; EVC_DETERMINISTIC=1 read by the library; 102: evc_lstm_layer_fwd_f16_fp8lo, evc_lstm_stack2_fwd_f16_fp8lo, evc_gemm_nt_f16_fp8, evc_cast_f32_to_fp8_lo, evc_cast_f32_to_f16_fp8x, aux_mode 5, evc_moe_grad_update_wide; 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
+#define EVC_VERSION 103   /* 103 (round 4): evc_sqnorm2_partials, evc_lstm_adam_fused, evc_gram_slabs, evc_moe_grad_norms, evc_moe_grad_update_apply, evc_adam2d_fused, evc_colsum_bf16_det, evc_sample_sequence_gather, evc_relu6_fwd/bwd, evc_framepool_mean_fwd/bwd, evc_stream_create_cu_mask / evc_stream_destroy; EVC_DETERMINISTIC=1 read by the library; 102: evc_lstm_layer_fwd_f16_fp8lo, evc_lstm_stack2_fwd_f16_fp8lo, evc_gemm_nt_f16_fp8, evc_cast_f32_to_fp8_lo, evc_cast_f32_to_f16_fp8x, aux_mode 5, evc_moe_grad_update_wide; 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
 
 typedef uint16_t evc_bf16;
 typedef uint16_t evc_f16;   /* raw IEEE binary16 bits (the "high" precision forward operands of the L1 levels) */
@@ -612,6 +612,13 @@ int evc_framepool_mean_bwd(const float* dpooled, int B, int S, int C, float* dy,
 /* evc_colsum_bf16 without atomics: row block y (of min(R / 64, ws_rows)) leaves its partial sums in ws[y][C] (plain stores), a
  * second launch adds them in index order - the bias gradient from dz under EVC_DETERMINISTIC=1. */
 int evc_colsum_bf16_det(const evc_bf16* in, int64_t ld_in, int R, int C, int deinterleave_H, float* out, float* ws, int ws_rows, void* stream);
+/* evc_lstm_adam_fused's pass for a plain 2-D weight p [R][C] without a bias (DBoF cluster / hidden weights, the logistic model's matrix): partials from
+ * evc_sqnorm2_partials(g, R*C, NULL, 0); pT_bf16 [C][ldT] = the plain transpose, pad columns R..round_up(R, 64) written as zeros; p_f16 [R][ld16] = f16(W)
+ * and p_fp8 [R][ld8] = evc_cast_f32_to_fp8_lo(W, hi_cols) optional. */
+int evc_adam2d_fused(float* p, const float* g, float* m, float* v, int R, int C, const float* part, float* sums_w, float clip_norm, float lr_t,
+                     float beta1, float beta2, float eps, evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT, evc_f16* p_f16, int64_t ld16,
+                     uint8_t* p_fp8, int64_t ld8, int fp8_hi_cols, int fp8_lo_exp, int fp8_hi_exp, void* stream);
+
 /* utility: out[i] = value for n floats (avoids torch for tiny fills inside C loops) */
 int evc_fill_f32(float* p, int64_t n, float value, void* stream);
 /* Measurement aid, not part of the path: `blocks` workgroups of `threads` threads with `lds_bytes` of LDS each stay resident for

@@ -1174,6 +1174,40 @@ def test_fused_lstm_adam_equals_the_per_tensor_launches_and_writes_every_operand
     assert torch.equal(p2, p) and torch.equal(m2, m) and torch.equal(v2, v) and torch.equal(pb2, pb) and torch.equal(s2, sums)
 
 
+@pytest.mark.parametrize("R,C,images", [(200, 68, False), (4716, 1152, False), (1024, 8192, True), (8192, 1152, True)])
+def test_fused_adam_for_plain_2d_weights(ops, R, C, images):
+    """evc_adam2d_fused (the pass of evc_lstm_adam_fused for a plain [R][C] weight without a bias: DBoF cluster / hidden weights, the
+    logistic matrix) against grad_sqnorm + clip_adam_step + transpose (+ casts): same update up to the norm's summation order, the
+    bf16 forward shadow, the transposed backward shadow with ZERO pad columns and the f16 / e4m3 images bit-equal to casts of the new weights."""
+    torch.manual_seed(R + C)
+    p0, g0 = torch.randn(R, C, device=DEV) * 0.05, torch.randn(R, C, device=DEV) * 0.02
+    m0, v0 = torch.randn(R, C, device=DEV) * 1e-3, torch.rand(R, C, device=DEV) * 1e-5
+    Rp = (R + 63) // 64 * 64
+    kw = {}
+    if images:
+        kw = dict(p_f16=torch.zeros(R, C, dtype=torch.float16, device=DEV), p_fp8=torch.zeros(R, 2 * C, dtype=torch.uint8, device=DEV),
+                  fp8_hi_cols=C, fp8_lo_exp=19, fp8_hi_exp=8)
+    p, m, v = p0.clone(), m0.clone(), v0.clone()
+    sh_f = torch.zeros(R, C, dtype=torch.bfloat16, device=DEV)
+    sh_b = torch.full((C, Rp), 7.0, dtype=torch.bfloat16, device=DEV)          # (stale values: the pad columns must come out zero)
+    sums, ws = torch.zeros(2, device=DEV), torch.empty(1028, device=DEV)
+    ops.adam2d_fused(p, g0, m, v, ws, sums, 1.0, 3e-4, sh_f, sh_b, **kw)
+    q, qm, qv, rs, rf = p0.clone(), m0.clone(), v0.clone(), torch.zeros(2, device=DEV), torch.zeros_like(sh_f)
+    ops.grad_sqnorm(g0, None, 0.0, rs)
+    ops.clip_adam_step(q, g0, qm, qv, 0.0, rs, 1.0, 3e-4, p_bf16=rf)
+    torch.cuda.synchronize()
+    assert abs(float(sums[0]) - float(rs[0])) <= 2e-6 * float(rs[0]) and float(sums[0]) > 1.0
+    for a, b in ((p, q), (m, qm), (v, qv)):
+        assert (a - b).abs().max().item() <= 4e-6 * b.abs().max().item()
+    assert torch.equal(sh_f, p.bfloat16())
+    assert torch.equal(sh_b[:, :R], p.t().bfloat16()) and bool((sh_b[:, R:] == 0).all())
+    if images:
+        w16, w8 = torch.zeros_like(kw["p_f16"]), torch.zeros_like(kw["p_fp8"])
+        ops.cast_f16(p, w16)
+        ops.cast_fp8_lo(p, w8, hi_cols=C, scale_exp=19, hi_exp=8)
+        assert torch.equal(kw["p_f16"], w16) and torch.equal(kw["p_fp8"], w8)
+
+
 @pytest.mark.parametrize("B,S,F,C,u8", [(6, 8, 64, 128, False), (9, 30, 128, 320, True), (37, 30, 1152, 512, True)])
 def test_dbof_fused_kernels_against_oracle(ops, B, S, F, C, u8):
     """csrc/evc_dbof.hip piece by piece (cs/frame_level_models.py:126-167, cs/model_utils.py:39-58,77-78): gather into the
