@@ -311,9 +311,7 @@ struct DbofPoolParams {
 #ifdef EVC_DBOF_V2_LOOP
 typedef TileCfg2<256, 1, 256, 2, 4, 5, true> CfgDbof;      // 256 frame rows (8 videos) x 256 clusters, 8 waves (2 x 4)
 #else
-struct CfgDbof : TileCfg3<256, 1, 256, 2, 4, 2> {          // the same tile on two 64-wide K stages (gemm_core_v3.h: 128 KB) ...
-  static constexpr int LDS_BYTES = 160 * 1024;             // ... launched with the whole LDS: the epilogue's per-wave transpose slices need 147 KB
-};
+struct CfgDbof : TileCfg3<256, 1, 256, 2, 4, 2> {};        // the same tile on two 64-wide K stages (gemm_core_v3.h: 128 KB = the epilogue's eight 16 KB transpose slices)
 template <> struct is_v2<CfgDbof> { static constexpr bool value = true; };
 template <> struct is_v3<CfgDbof> { static constexpr bool value = true; };
 #endif
@@ -359,7 +357,12 @@ __global__ __launch_bounds__(CfgDbof::NT) void dbof_cluster_pool_kernel(GemmOper
     // the 0.31 ms kernel).  Each wave transposes its 128 x 64 sub-tile through its own slice of the (now idle) ring
     // instead and writes whole 128-byte lines, 16 bytes per lane.
     __syncthreads();                                           // every wave has read its last ring slot
-    constexpr int RS = Cfg::WU * 2 + 16;                       // 144-byte rows: 16-byte aligned reads, 2-way conflicts on the writes
+    // 128-byte rows, 16-byte chunk c of row r stored at chunk c ^ (r & 7) (round 4; before: 144-byte padded rows, whose ds_read_b128 lane
+    // groups - rows r .. r+3 with chunk halves 0-3 / 4-7 / 4-7 / 0-3 - overlapped in 4 of 16 slots: the 9 % LDS bank conflicts of
+    // profiles/r03_pmc_kernels_dbof.json).  Reads: slots (8 r + (c ^ r)) mod 16 of a group are 0-3 | 12-15 | 4-7 | 8-11: conflict-free; the 8-byte
+    // writes of a 16-lane group (16 rows, one chunk) land 2-way (rows r and r + 8), which ds_write_b64 absorbs.
+    constexpr int RS = Cfg::WU * 2;
+    static_assert(RS == 128, "the swizzle is written for 64-column wave tiles");
     char* wl = lds_dyn + wave * (Cfg::WM * RS);
     static_assert(8 * Cfg::WM * RS <= Cfg::LDS_BYTES, "per-wave transpose slices must fit the ring");
 #pragma unroll
@@ -367,7 +370,8 @@ __global__ __launch_bounds__(CfgDbof::NT) void dbof_cluster_pool_kernel(GemmOper
 #pragma unroll
       for (int ni = 0; ni < Cfg::NI; ++ni) {
         const f32x4 v = acc[mi][0][ni];
-        *(uint2*)(wl + (mi * 16 + l) * RS + (ni * 16 + g * 4) * 2) = make_uint2(pack_bf16x2_hw(v[0], v[1]), pack_bf16x2_hw(v[2], v[3]));
+        const int row = mi * 16 + l, chunk = ni * 2 + (g >> 1);
+        *(uint2*)(wl + row * RS + ((chunk ^ (row & 7)) << 4) + ((g & 1) << 3)) = make_uint2(pack_bf16x2_hw(v[0], v[1]), pack_bf16x2_hw(v[2], v[3]));
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this wave's own writes (LDS ops of one wave execute in order)
     const int colw = u0 + wc * Cfg::WU;
@@ -375,7 +379,7 @@ __global__ __launch_bounds__(CfgDbof::NT) void dbof_cluster_pool_kernel(GemmOper
 #pragma unroll
       for (int it = 0; it < Cfg::WM / 8; ++it) {
         const int rl = it * 8 + (lane >> 3);
-        const uint4 q = *(const uint4*)(wl + rl * RS + (lane & 7) * 16);
+        const uint4 q = *(const uint4*)(wl + rl * RS + (((lane & 7) ^ (rl & 7)) << 4));
         const int row = rbase + rl;
         if (row < p.M) *(uint4*)(e.act + (long)row * e.ld_act + colw + (lane & 7) * 8) = q;
       }

@@ -196,14 +196,20 @@ __device__ __forceinline__ void gemm_mainloop_tn(GemmOperandsT p, const int m0, 
     read_frags(afn, bfn);
     mfma_all(afc, bfc);
 #else
+    // EVC_TN_STAGGER (experiment): the waves that issue no LDS-DMA start their fragment reads SKIP MFMA groups into the step (the producers'
+    // reads come behind their LDS-DMA pieces anyway), so that the SIMD partners' LDS reads do not run in step
+#ifndef EVC_TN_STAGGER
+#define EVC_TN_STAGGER 0
+#endif
     constexpr int NM = Cfg::MI * Cfg::NI, ND = PROD ? PER : 0, NF = Cfg::MI + Cfg::NI, NIT = ND + NF;
+    constexpr int SKIP = (PRODUCERS && !PROD && EVC_TN_STAGGER < NM - NIT) ? EVC_TN_STAGGER : 0;
     char* sbase = lds + slot_issue * Cfg::STAGE_BYTES;
     const char* sb = lds + slot_read * Cfg::STAGE_BYTES;
     slot_read = (slot_read + 1 == Cfg::STAGES) ? 0 : slot_read + 1;
 #pragma unroll
     for (int gi = 0; gi < NM; ++gi) {
 #pragma unroll
-      for (int it = gi * NIT / NM; it < (gi + 1) * NIT / NM; ++it) {   // items of this group: LDS-DMA pieces first, then fragments
+      for (int it = (gi < SKIP ? 0 : (gi - SKIP) * NIT / (NM - SKIP)); it < (gi < SKIP ? 0 : (gi - SKIP + 1) * NIT / (NM - SKIP)); ++it) {   // items of this group: LDS-DMA pieces first, then fragments
         if (it < ND) {
           if (it < ACH)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + (a_vo[it] + a_k)),

@@ -188,9 +188,17 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
   auto stage_role = [&]() {
     if constexpr (PROD) stage();
   };
-  auto interleave = [&](auto ndma_tag) {   // MFMAs with one LDS read / LDS-DMA between small groups of them
+  // EVC_STAGGER_LEAD (experiment, MI355X_MICROARCH.md "Two waves per SIMD" item 9 adapted to a loop whose two halves are alike): the waves
+  // that issue no LDS-DMA (4-7: the SIMD partners of the producers) open the first half-step with LEAD bare MFMAs and read their
+  // fragments behind them, so that the partners' LDS read bursts do not start together at the barrier.
+#ifndef EVC_STAGGER_LEAD
+#define EVC_STAGGER_LEAD 0
+#endif
+  auto interleave = [&](auto ndma_tag, auto lead_tag) {   // MFMAs with one LDS read / LDS-DMA between small groups of them
     constexpr int ndma = decltype(ndma_tag)::value;
-    constexpr int per = NMFMA / (NREAD + ndma) > 0 ? NMFMA / (NREAD + ndma) : 1;
+    constexpr int lead = (decltype(lead_tag)::value < NMFMA - (NREAD + ndma)) ? decltype(lead_tag)::value : 0;
+    if constexpr (lead > 0) __builtin_amdgcn_sched_group_barrier(0x008, lead, 0);
+    constexpr int per = (NMFMA - lead) / (NREAD + ndma) > 0 ? (NMFMA - lead) / (NREAD + ndma) : 1;
     if constexpr ((MODE & LOOP_DMA_FIRST) != 0) {
 #pragma unroll
       for (int i = 0; i < ndma; ++i) {
@@ -210,7 +218,7 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - per * (NREAD + ndma), 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - lead - per * (NREAD + ndma), 0);
   };
 
   // ---- prologue: every slot of the ring in flight ----
@@ -232,7 +240,7 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
     read_half(1, afB, bfB);
     mfma_all(afA, bfA);
 #ifndef EVC_NO_INTERLEAVE
-    interleave(std::integral_constant<int, 0>{});
+    interleave(std::integral_constant<int, 0>{}, std::integral_constant<int, (PRODUCERS && !PROD) ? EVC_STAGGER_LEAD : 0>{});
 #endif
     if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     end_of_step();
@@ -246,7 +254,7 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
     if constexpr (decltype(prefetch_tag)::value) read_half(0, afA, bfA);
     mfma_all(afB, bfB);
 #ifndef EVC_NO_INTERLEAVE
-    if constexpr (decltype(prefetch_tag)::value) interleave(std::integral_constant<int, PERX>{});
+    if constexpr (decltype(prefetch_tag)::value) interleave(std::integral_constant<int, PERX>{}, std::integral_constant<int, 0>{});
 #endif
     if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     end_of_step();
