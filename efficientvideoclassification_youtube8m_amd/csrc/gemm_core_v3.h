@@ -25,6 +25,12 @@
 #pragma once
 #include "gemm_core_v2.h"
 
+#ifndef EVC_V3_AUX_A
+#define EVC_V3_AUX_A 0      // cache policy of the ring's LDS-DMA loads (2 = nt), A / B operand: measured in round 4 (dropped), default policy kept
+#endif
+#ifndef EVC_V3_AUX_B
+#define EVC_V3_AUX_B 0
+#endif
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v8i_t __attribute__((ext_vector_type(8)));
 
@@ -121,14 +127,14 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
       char* dst = a_dst[i] >= 0 ? sbase + a_dst[i] : lds + Cfg::DUMMY_OFF;
       const uint32_t vo = __umul24((uint32_t)a_row[i], lda_b) + (uint32_t)(lc8 * 2);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ab + vo),
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, EVC_V3_AUX_A);
     }
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
       char* dst = b_dst[i] >= 0 ? sbase + b_dst[i] : lds + Cfg::DUMMY_OFF;
       const uint32_t vo = FP8 ? __umul24(b_vo[i], ldb_b) + (uint32_t)(lc8 * 2) : b_vo[i];
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_base + vo),
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, EVC_V3_AUX_B);
     }
     ++ks_issue;
     slot_issue = (slot_issue + 1 == Cfg::STAGES) ? 0 : slot_issue + 1;
