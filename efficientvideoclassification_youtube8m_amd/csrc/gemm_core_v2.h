@@ -31,6 +31,10 @@
 //  LOOP_FP8_TAIL  (v3 loop only) the 16-bit stages are followed by stages of 128 e4m3 bytes per row on the MX-scaled MFMA
 //                 (GemmOperands::A3 / A4 / B8); needs nk1 + nk2 >= 1 and nk3 + nk4 >= STAGES
 constexpr int LOOP_PRODUCER = 1, LOOP_DMA_FIRST = 2, LOOP_NO_PRIO = 4, LOOP_F16 = 8, LOOP_FP8_TAIL = 16;
+//  LOOP_PREFETCH  (v3 loop with LOOP_PRODUCER, experiment of round 4) two of the waves that issue no LDS-DMA touch, per trip, one dword of every 128-byte
+//                 line of this workgroup's SHARE of the operand panels of a stage a few trips ahead (a 4-byte LDS-DMA into the sink: no destination
+//                 register), so that the producers' refill of that stage finds its lines in the XCD's L2 instead of waiting for the Infinity Cache / HBM
+constexpr int LOOP_PREFETCH = 32;
 #ifndef EVC_LOOP_MODE_DEFAULT
 #define EVC_LOOP_MODE_DEFAULT 0
 #endif

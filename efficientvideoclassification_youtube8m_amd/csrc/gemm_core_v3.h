@@ -44,7 +44,12 @@ struct TileCfg3 {
   static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
   static constexpr bool RAGGED = (BM / 8) % (NT / 64) != 0 || (BN / 8) % (NT / 64) != 0 || (BM / 8) % 4 != 0 || (BN / 8) % 4 != 0;
   static constexpr int DUMMY_OFF = STAGES * STAGE_BYTES;       // 1 KiB sink for the surplus lanes of a ragged last round
-  static constexpr int LDS_BYTES = DUMMY_OFF + (RAGGED ? 1024 : 0);
+#ifdef EVC_V3_PREFETCH_SINK
+  static constexpr bool SINK = RAGGED || DUMMY_OFF + 1024 <= 160 * 1024;     // (LOOP_PREFETCH builds: the sink also takes the prefetch dwords)
+#else
+  static constexpr bool SINK = RAGGED;
+#endif
+  static constexpr int LDS_BYTES = DUMMY_OFF + (SINK ? 1024 : 0);
   static_assert(WM % 16 == 0 && WU % 16 == 0 && BM % 8 == 0 && BN % 8 == 0, "wave tile must be a multiple of 16x16");
   static_assert(STAGES >= 2 && STAGES <= 6, "ring depth 2..6");
   static_assert(LDS_BYTES <= 160 * 1024, "exceeds the 160 KiB LDS of a CU");
@@ -187,6 +192,50 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
     else wait_vmcnt<0>();
   };
 
+  // ---- LOOP_PREFETCH: which lines this wave touches ahead of the ring.  Within an XCD's patch of tiles (tile_of: 8 row tiles x ~4 column
+  // tiles) an A row panel is shared by the column tiles, a B column panel by the row tiles: the workgroup with tn % 4 == q takes quarter q of its A
+  // rows (wave NPW), the one with tm % 8 == q eighth q of its B rows (wave NPW + 1); a share nobody takes just stays a demand miss.
+#ifndef EVC_PREFETCH_DIST
+#define EVC_PREFETCH_DIST 2
+#endif
+  constexpr bool PREFETCH = (MODE & LOOP_PREFETCH) != 0 && PRODUCERS && Cfg::SINK && !FP8;
+  long pf_off1 = -1, pf_off2 = -1;       // byte offset of this lane's row in the A1 / A2 segment (wave NPW) or in B (wave NPW + 1); -1: no duty
+  if constexpr (PREFETCH) {
+    const int tm_ = m0 / Cfg::BM, tn_ = u0 / Cfg::BU;
+    if (wave == NPW) {
+      constexpr int QA = (Cfg::BM / 4 + 7) / 8 * 8;
+      const int r = (tn_ & 3) * QA + lane;
+      if (lane < QA && r < Cfg::BM) {
+        int gr = m0 + r;
+        gr = gr < p.M ? gr : p.M - 1;
+        pf_off1 = (long)gr * p.lda1 * 2;
+        pf_off2 = (long)gr * p.lda2 * 2;
+      }
+    } else if (wave == NPW + 1) {
+      constexpr int QB = Cfg::BN / 8;
+      const int r = (tm_ & 7) * QB + lane;
+      if (lane < QB) {
+        const int g = r / Cfg::BU, u = r % Cfg::BU;
+        int gu = u0 + u;
+        gu = gu < p.Nu ? gu : p.Nu - 1;
+        pf_off1 = pf_off2 = ((long)g * p.group_stride + gu) * p.ldb * 2;
+      }
+    }
+  }
+  auto prefetch = [&](int ks) {          // one dword of every line of stage ks (wave-uniform ks; lanes without a duty are masked)
+    if constexpr (PREFETCH) {
+      if (ks < nkf && wave <= NPW + 1) {
+        const bool s1 = ks < p.nk1;
+        const char* base = wave == NPW ? (const char*)(s1 ? p.A1 + (long)ks * 64 : p.A2 + (long)(ks - p.nk1) * 64)
+                                       : (const char*)((s1 ? p.B : b2) + (long)ks * 64);
+        const long off = s1 ? pf_off1 : pf_off2;
+        if (off >= 0)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off + (lane & 31) * 4),
+                                           (__attribute__((address_space(3))) void*)(lds + Cfg::DUMMY_OFF), 4, 0, 0);
+      }
+    }
+  };
+
   auto run = [&](auto prod_tag) {     // one copy of the loop per role (LOOP_PRODUCER), each steady-state body branch-free
   constexpr bool PROD = decltype(prod_tag)::value;
   constexpr bool PRIO = (MODE & LOOP_NO_PRIO) == 0;
@@ -238,6 +287,7 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
   read_half(0, afA, bfA);
   __builtin_amdgcn_s_waitcnt(0xC07F);   // enter the loop with no LDS read pending
 
+  int j = 0;
   // one steady-state trip over a 16-bit stage (a later stage exists and is refilled into the slot this trip frees);
   // prefetch: read the first half of the next stage's fragments behind the barrier (false: the next stage is an e4m3 stage)
   auto trip16 = [&](auto prefetch_tag) {
@@ -256,6 +306,7 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
     asm volatile("" ::: "memory");
     if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
     stage_role();
+    if constexpr (!PROD) prefetch(j + Cfg::STAGES + EVC_PREFETCH_DIST);
     next_slot();
     if constexpr (decltype(prefetch_tag)::value) read_half(0, afA, bfA);
     mfma_all(afB, bfB);
@@ -266,7 +317,6 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
     end_of_step();
   };
 
-  int j = 0;
   if constexpr (!FP8) {
     for (; j + Cfg::STAGES < nk; ++j) trip16(std::true_type{});   // steady state: stage j+STAGES exists, so every trip refills
     for (; j < nk; ++j) {                 // last STAGES stages: no refills
