@@ -86,6 +86,31 @@ __device__ __forceinline__ float tanhf_(float x) {
 }
 
 
+// Stores of an epilogue by uniform base + 32-bit lane byte offset, with a cache policy (template POLICY):
+//   0  plain (the line stays dirty in the XCD's L2 and leaves at the kernel boundary: + bytes / 6 TB/s on the boundary, MI355X_MICROARCH.md "boundary")
+//   1  sc1 = write-through: the bytes leave L2 as they are stored, under the rest of the epilogue
+//   2  nt
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+template <int POLICY>
+__device__ __forceinline__ void store16(void* base, uint32_t off, u32x4_t v) {
+  if constexpr (POLICY == 1) asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(off), "v"(v), "s"(base) : "memory");
+  else if constexpr (POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(off), "v"(v), "s"(base) : "memory");
+  else *(u32x4_t*)((char*)base + off) = v;
+}
+template <int POLICY>
+__device__ __forceinline__ void store8(void* base, uint32_t off, u32x2_t v) {
+  if constexpr (POLICY == 1) asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(off), "v"(v), "s"(base) : "memory");
+  else if constexpr (POLICY == 2) asm volatile("global_store_dwordx2 %0, %1, %2 nt" ::"v"(off), "v"(v), "s"(base) : "memory");
+  else *(u32x2_t*)((char*)base + off) = v;
+}
+template <int POLICY>
+__device__ __forceinline__ void store4(void* base, uint32_t off, uint32_t v) {
+  if constexpr (POLICY == 1) asm volatile("global_store_dword %0, %1, %2 sc1" ::"v"(off), "v"(v), "s"(base) : "memory");
+  else if constexpr (POLICY == 2) asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(off), "v"(v), "s"(base) : "memory");
+  else *(uint32_t*)((char*)base + off) = v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

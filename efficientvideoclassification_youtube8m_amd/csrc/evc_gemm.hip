@@ -3,6 +3,9 @@
 #include "gemm_launch.h"
 
 // Loop options per kernel (gemm_core_v2.h; same-box A/B measurements in DESIGN.md 4.2)
+#ifndef EVC_FWD_STORE_POLICY
+#define EVC_FWD_STORE_POLICY 0      // cache policy of the forward step's epilogue stores (evc_common.h store16<>): 0 plain, 1 sc1 (write-through), 2 nt
+#endif
 #ifndef EVC_FWD_LOOP_MODE
 #define EVC_FWD_LOOP_MODE (LOOP_PRODUCER | LOOP_DMA_FIRST | LOOP_NO_PRIO)   // forward step: 81.7 -> 77.4 us per step
 #endif
@@ -957,6 +960,7 @@ __device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const 
   static_assert(!(SPLIT && F16), "split operands are bf16 halves");
   static_assert(!FP8 || (F16 && is_v3<Cfg>::value), "the e4m3 tail rides behind f16 stages of the 64-wide ring loop");
   const int nwg = tiles_m * tiles_n;
+  EVC_STAMP(p.stamp_slot, 0);
   const int id = xcd_remap(bid, nwg);
   int tm, tn;
   tile_of(id, tiles_m, tiles_n, tm, tn);
@@ -981,6 +985,7 @@ __device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const 
   //  against B = [W_hi | W_lo] rows as segment 1 and A = hi against B2 = W_hi as segment 2, evc_lstm_layer_fwd_hp - so the loop
   //  itself is the plain one; only the epilogue differs: it writes h_t's wide [lo | hi] image for the next step.)
   run_mainloop<Cfg, 4, true, false, EVC_FWD_LOOP_MODE | (F16 ? LOOP_F16 : 0) | (FP8 ? LOOP_FP8_TAIL : 0)>(p, m0, u0, acc);   // transposed accumulators: lane = one row, 4 consecutive units
+  EVC_STAMP(p.stamp_slot, 2);
 #ifdef EVC_ABLATE_EPI    // debug build: main loop only (keep the accumulators alive, store nothing)
 #pragma unroll
   for (int mi = 0; mi < Cfg::MI; ++mi)
@@ -998,10 +1003,11 @@ __device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const 
     const int u = u0 + tc.unit0 + ni * 16;
     if (u >= H) continue;
     int ln[Cfg::MI], rm[Cfg::MI];
+    const int mi_n = wave_row_frags<Cfg>::of(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) / Cfg::WC);   // (uneven row split: the fragments this wave row owns)
 #pragma unroll
     for (int mi = 0; mi < Cfg::MI; ++mi) {
       const int m = m0 + tc.row0 + mi * 16;
-      const bool in = m < e.M;
+      const bool in = m < e.M && mi < mi_n;
       ln[mi] = in ? e.len[m] : -1;                     // -1: row outside the launch (nothing to do, not even zeros)
       rm[mi] = (in && e.row_map) ? e.row_map[m] : m;
     }
@@ -1011,27 +1017,32 @@ __device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const 
       cv[mi] = make_float4(0.f, 0.f, 0.f, 0.f);        // zero initial state (no memset of the state buffers)
       if (e.t > 0 && e.t < ln[mi]) cv[mi] = *(const float4*)(e.c_state + (long)rm[mi] * e.ld_state + u);   // running f32 cell state, in place
     }
+    // stores: uniform base + 32-bit lane byte offset (a time slab is far below 4 GiB: checked by the launchers), policy EVC_FWD_STORE_POLICY
+    constexpr int SP = EVC_FWD_STORE_POLICY;
 #pragma unroll
     for (int mi = 0; mi < Cfg::MI; ++mi) {
       const int m = m0 + tc.row0 + mi * 16;
       if (ln[mi] < 0) continue;
-      const long hu = (long)m * H + u;
-      const long su = (long)rm[mi] * e.ld_state + u;
-      const long hw = FP8 ? (long)m * (3 * H / 2) + u : (F16 && e.h_wide) ? (long)m * 2 * H + u : hu;     // (F16: position in a wide h image)
-      uint32_t* const h8 = FP8 ? (uint32_t*)((char*)(e.hout + (long)m * (3 * H / 2) + H) + u) : nullptr;     // (FP8: the row's e4m3 part)
+      const uint32_t hu = (uint32_t)m * (uint32_t)H + (uint32_t)u;                      // element index in an [M][H] slab
+      const uint32_t su4 = ((uint32_t)rm[mi] * (uint32_t)e.ld_state + (uint32_t)u) * 4u;   // byte offset in c_state / h_state
+      // byte offset of this lane's 4 units in hout: FP8 rows are [f16(h) (H halfwords) | e4m3 (H bytes)] = 3H bytes, wide f16 rows 2H halfwords
+      const uint32_t hw2 = FP8 ? (uint32_t)m * (uint32_t)(3 * H) + (uint32_t)u * 2u : (F16 && e.h_wide) ? ((uint32_t)m * (uint32_t)(2 * H) + (uint32_t)u) * 2u : hu * 2u;
+      const uint32_t h8o = (uint32_t)m * (uint32_t)(3 * H) + (uint32_t)(2 * H) + (uint32_t)u;      // (FP8: the row's e4m3 part)
+      const u32x2_t z2 = {0u, 0u};
       if (e.t >= ln[mi]) {          // dynamic_rnn: state copied through, zero output
-        *(uint2*)(e.hout + hw) = make_uint2(0u, 0u);
-        if (FP8) *h8 = 0u;
-        else if (F16 && e.h_wide) *(uint2*)(e.hout + hw + H) = make_uint2(0u, 0u);
-        if (F16) *(uint2*)(e.hout_lo + hu) = make_uint2(0u, 0u);
+        store8<SP>(e.hout, hw2, z2);
+        if (FP8) store4<SP>(e.hout, h8o, 0u);
+        else if (F16 && e.h_wide) store8<SP>(e.hout, hw2 + (uint32_t)H * 2u, z2);
+        if (F16) store8<SP>(e.hout_lo, hu * 2u, z2);
         if (SPLIT) {
-          bf16_t* w = e.hout_lo + (long)m * 2 * H + u;
-          *(uint2*)w = make_uint2(0u, 0u);
-          *(uint2*)(w + H) = make_uint2(0u, 0u);
+          const uint32_t wo = ((uint32_t)m * (uint32_t)(2 * H) + (uint32_t)u) * 2u;
+          store8<SP>(e.hout_lo, wo, z2);
+          store8<SP>(e.hout_lo, wo + (uint32_t)H * 2u, z2);
         }
         if (e.t == 0) {             // zero-length row: its final state is the zero initial state
-          *(float4*)(e.c_state + su) = make_float4(0.f, 0.f, 0.f, 0.f);
-          *(float4*)(e.h_state + su) = make_float4(0.f, 0.f, 0.f, 0.f);
+          const u32x4_t z4 = {0u, 0u, 0u, 0u};
+          store16<SP>(e.c_state, su4, z4);
+          store16<SP>(e.h_state, su4, z4);
         }
         continue;
       }
@@ -1058,42 +1069,55 @@ __device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const 
         hn[r] = tanhf_(cn[r]) * go;
         rec[r] = make_uint2(pack_bf16x2(gi, gj), pack_bf16x2(gf, go));
       }
-      const float4 cnv = make_float4(cn[0], cn[1], cn[2], cn[3]);
-      *(float4*)(e.c_state + su) = cnv;               // rows stop updating at t = len: what stays is the returned state
-      if (e.c_hist) *(uint2*)(e.c_hist + hu) = make_uint2(pack_bf16x2(cn[0], cn[1]), pack_bf16x2(cn[2], cn[3]));
-      if (e.t == ln[mi] - 1) *(float4*)(e.h_state + su) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+      const u32x4_t cnv = {__float_as_uint(cn[0]), __float_as_uint(cn[1]), __float_as_uint(cn[2]), __float_as_uint(cn[3])};
+      store16<SP>(e.c_state, su4, cnv);               // rows stop updating at t = len: what stays is the returned state
+      if (e.c_hist) store8<SP>(e.c_hist, hu * 2u, u32x2_t{pack_bf16x2(cn[0], cn[1]), pack_bf16x2(cn[2], cn[3])});
+      if (e.t == ln[mi] - 1)
+        store16<SP>(e.h_state, su4, u32x4_t{__float_as_uint(hn[0]), __float_as_uint(hn[1]), __float_as_uint(hn[2]), __float_as_uint(hn[3])});
+      const u32x2_t hb = {pack_bf16x2(hn[0], hn[1]), pack_bf16x2(hn[2], hn[3])};
       if (F16) {
         const uint32_t p01 = pack_f16x2_hw(hn[0], hn[1]), p23 = pack_f16x2_hw(hn[2], hn[3]);
-        *(uint2*)(e.hout + hw) = make_uint2(p01, p23);
+        store8<SP>(e.hout, hw2, u32x2_t{p01, p23});
         if (FP8) {                  // e4m3(h * 2^7): the activation operand of the weights' low-order halves (|h| < 1: no saturation)
           int w8 = __builtin_amdgcn_cvt_pk_fp8_f32(hn[0] * 128.0f, hn[1] * 128.0f, 0, false);
           w8 = __builtin_amdgcn_cvt_pk_fp8_f32(hn[2] * 128.0f, hn[3] * 128.0f, w8, true);
-          *h8 = (uint32_t)w8;
+          store4<SP>(e.hout, h8o, (uint32_t)w8);
         } else if (e.h_wide) {      // f16(h)/64: the operand of the weights' low-order halves (scaled by 64)
           const float s0 = f16_to_f32((f16_t)(p01 & 0xffffu)) * (1.0f / 64.0f), s1 = f16_to_f32((f16_t)(p01 >> 16)) * (1.0f / 64.0f);
           const float s2 = f16_to_f32((f16_t)(p23 & 0xffffu)) * (1.0f / 64.0f), s3 = f16_to_f32((f16_t)(p23 >> 16)) * (1.0f / 64.0f);
-          *(uint2*)(e.hout + hw + H) = make_uint2(pack_f16x2_hw(s0, s1), pack_f16x2_hw(s2, s3));
+          store8<SP>(e.hout, hw2 + (uint32_t)H * 2u, u32x2_t{pack_f16x2_hw(s0, s1), pack_f16x2_hw(s2, s3)});
         }
-        *(uint2*)(e.hout_lo + hu) = make_uint2(pack_bf16x2(hn[0], hn[1]), pack_bf16x2(hn[2], hn[3]));
+        store8<SP>(e.hout_lo, hu * 2u, hb);
       } else {
-        *(uint2*)(e.hout + hu) = make_uint2(pack_bf16x2(hn[0], hn[1]), pack_bf16x2(hn[2], hn[3]));
+        store8<SP>(e.hout, hu * 2u, hb);
       }
       if (SPLIT) {
         float lo[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) lo[r] = hn[r] - bf16_to_f32(f32_to_bf16(hn[r]));
-        bf16_t* w = e.hout_lo + (long)m * 2 * H + u;
-        *(uint2*)w = make_uint2(pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]));
-        *(uint2*)(w + H) = make_uint2(pack_bf16x2(hn[0], hn[1]), pack_bf16x2(hn[2], hn[3]));
+        const uint32_t wo = ((uint32_t)m * (uint32_t)(2 * H) + (uint32_t)u) * 2u;
+        store8<SP>(e.hout_lo, wo, u32x2_t{pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3])});
+        store8<SP>(e.hout_lo, wo + (uint32_t)H * 2u, hb);
       }
-      if (e.gates) {
-        uint4* gp = (uint4*)(e.gates + hu);            // 4 units x 8 bytes
-        gp[0] = make_uint4(rec[0].x, rec[0].y, rec[1].x, rec[1].y);
-        gp[1] = make_uint4(rec[2].x, rec[2].y, rec[3].x, rec[3].y);
+      if (e.gates) {                                   // 4 units x 8 bytes
+        store16<SP>(e.gates, hu * 8u, u32x4_t{rec[0].x, rec[0].y, rec[1].x, rec[1].y});
+        store16<SP>(e.gates, hu * 8u + 16u, u32x4_t{rec[2].x, rec[2].y, rec[3].x, rec[3].y});
       }
     }
   }
+#ifdef EVC_STAMPS
+  EVC_STAMP(p.stamp_slot, 3);
+  wait_vmcnt<0>();                       // this wave's stores acknowledged
+  EVC_STAMP(p.stamp_slot, 4);
+  __syncthreads();
+  EVC_STAMP(p.stamp_slot, 5);
+#endif
 }
+#ifdef EVC_STAMPS
+extern "C" int evc_debug_read_stamps(unsigned long long* out) {     // out: [8][512][8]
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(evc_stamps), sizeof(unsigned long long) * 8 * 512 * 8) == hipSuccess ? 0 : 1;
+}
+#endif
 
 template <class Cfg, bool SPLIT = false, bool F16 = false, bool FP8 = false>
 __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, LstmFwdParams e, int tiles_m, int tiles_n) {
@@ -1127,6 +1151,10 @@ typedef TileCfg2<224, 4, 64, 2, 4, 5, true> CfgLstmV2_224;
 // lines per LDS-DMA piece and one barrier per 64 K columns beat the deeper ring (same-box A/B: 79.0 -> 73.9 us per step)
 typedef TileCfg3<256, 4, 64, 2, 4, 2> CfgLstmV3_256;
 typedef TileCfg3<224, 4, 64, 2, 4, 2> CfgLstmV3_224;
+// 240 rows = 7 row fragments on the producer waves + 8 on their SIMD partners (gemm_core_v3.h, uneven split): 3 585-3 840 live rows are 16 row tiles
+// = 256 workgroups of 240 rows instead of 15 x 16 = 240 workgroups of 256 rows (round 4)
+typedef TileCfg3<240, 4, 64, 2, 4, 2, 7> CfgLstmV3_240;
+typedef TileCfg3<224, 4, 64, 2, 4, 2, 6> CfgLstmV3_224u;      // 6 + 8 instead of 7 + 7: the producer waves issue the LDS-DMA, their partners take the extra row fragment
 typedef TileCfg3<192, 4, 64, 2, 4, 2> CfgLstmV3_192;
 typedef TileCfg3<160, 4, 64, 2, 4, 3> CfgLstmV3_160;
 typedef TileCfg2<192, 4, 64, 2, 4, 5, true> CfgLstmV2_192;
@@ -1139,25 +1167,30 @@ typedef TileCfg3<64, 4, 16, 4, 1, 4> CfgLstmV3Small;         // the same tile on
 template <class Cfg, bool SPLIT = false, bool F16 = false, bool FP8 = false>
 static inline void launch_lstm_fwd(GemmOperands p, const LstmFwdParams& e, int k1, int k2, hipStream_t st) {
   p.nk1 = k1 / kdiv<Cfg>(); p.nk2 = k2 / kdiv<Cfg>();
+#ifdef EVC_STAMPS
+  p.stamp_slot = e.t & 7;
+#endif
   const int tm = ceil_div(e.M, Cfg::BM), tn = ceil_div(e.H, Cfg::BU);
   launch_cfg<Cfg>(lstm_fwd_step_kernel<Cfg, SPLIT, F16, FP8>, tm * tn, st, p, e, tm, tn);
 }
 
 // forward tile for a step over `rows` rows: index into {320, 288, 256, 224, 192, 160 (v2), 128 (v1), 64 (v1), 128 (v2), 64 (v2)}
 static inline int pick_fwd_tile(int rows, int H) {
-  constexpr int NC = 10;
-  static const int bm[NC] = {320, 288, 256, 224, 192, 160, 128, 64, 128, 64};
-  static const int bn[NC] = {256, 256, 256, 256, 256, 256, 128, 64, 256, 256};
-  static const int bu[NC] = {64, 64, 64, 64, 64, 64, 32, 16, 64, 64};
-  static const double cf[NC] = {1.0, 1.0, 1.0, 1.02, 1.04, 1.08, 1.3, 2.6, 1.15, 1.5};   // smaller tiles: less efficient per flop
+  constexpr int NC = 11;
+  static const int bm[NC] = {320, 288, 256, 224, 192, 160, 128, 64, 128, 64, 240};
+  static const int bn[NC] = {256, 256, 256, 256, 256, 256, 128, 64, 256, 256, 256};
+  static const int bu[NC] = {64, 64, 64, 64, 64, 64, 32, 16, 64, 64, 64};
+  static const double cf[NC] = {1.0, 1.0, 1.0, 1.02, 1.04, 1.08, 1.3, 2.6, 1.15, 1.5, 1.01};   // smaller tiles: less efficient per flop
+  static const bool no240 = getenv("EVC_FWD_NO_240") != nullptr;      // A/B: the tile set of round 3
   int best = 0;
   double bc = 1e300;
   for (int i = 0; i < NC; ++i) {
+    if (i == 10 && no240) continue;
     const double c = tile_cost((long)ceil_div(rows, bm[i]) * ceil_div(H, bu[i]), bm[i], bn[i], 1, cf[i]);
     if (c < bc) { bc = c; best = i; }
   }
-  const int f = forced_tile();        // debug: 1 -> 256, 2 -> v1 128, 3 -> v1 64, 4 -> 320, 5 -> 288, 6 -> 224, 7 -> 192, 8 -> 160, 9 -> v2 128, 10 -> v2 64
-  if (f) { static const int map[11] = {0, 2, 6, 7, 0, 1, 3, 4, 5, 8, 9}; best = map[f < 11 ? f : 0]; }
+  const int f = forced_tile();        // debug: 1 -> 256, 2 -> v1 128, 3 -> v1 64, 4 -> 320, 5 -> 288, 6 -> 224, 7 -> 192, 8 -> 160, 9 -> v2 128, 10 -> v2 64, 11 -> 240
+  if (f) { static const int map[12] = {0, 2, 6, 7, 0, 1, 3, 4, 5, 8, 9, 10}; best = map[f < 12 ? f : 0]; }
   return best;
 }
 
@@ -1203,6 +1236,7 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
               "evc_lstm_layer_fwd: Kin=%d and H=%d must be multiples of 64", Kin, H);
   EVC_REQUIRE(ring_operand_ok(M, ldx > ldh ? ldx : ldh) && ring_operand_ok(4L * H, (long)Kin + ldh), EVC_ERR_BAD_SHAPE,
               "evc_lstm_layer_fwd: a time slab or the kernel spans 4 GiB or more (M=%d Kin=%d H=%d)", M, Kin, H);
+  EVC_REQUIRE(fwd_tail_ok(M, H, ld_state), EVC_ERR_BAD_SHAPE, "LSTM forward: a gate-record / state slab spans 4 GiB or more (M=%d H=%d ld_state=%ld)", M, H, (long)ld_state);
   EVC_REQUIRE(!hoist || (zx_ws && !h_wide && ldx == Kin), EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd: hoist needs zx_ws (and plain operands)");
   EVC_REQUIRE(ld_state % 4 == 0 && ((uintptr_t)c_state % 16) == 0 && ((uintptr_t)h_state % 16) == 0 && ((uintptr_t)bias % 16) == 0 &&
               ((uintptr_t)hbuf % 8) == 0, EVC_ERR_BAD_ALIGN, "evc_lstm_layer_fwd: state/bias/hbuf must allow 16-byte vector access");
@@ -1249,12 +1283,14 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
     e.c_hist = c_all ? c_all + (long)(t + 1) * M * H : nullptr;      // slab t+1 = c after step t
     e.row_map = row_map;
     e.M = Mt; e.H = H;
+    static const bool uneven224 = getenv("EVC_FWD_EVEN_224") == nullptr;      // the 224-row tile as 6 + 8 row fragments (A/B switch: 7 + 7; 58.3 -> 58.0 us per launch)
     if (f16) {        // IEEE f16 operands, one MFMA product per depth: the tiles of the bf16 step
       switch (pick_fwd_tile(Mt, H)) {
         case 0: launch_lstm_fwd<CfgLstmV2a, false, true>(p, e, k1, k2, st); break;
         case 1: launch_lstm_fwd<CfgLstmV2_288, false, true>(p, e, k1, k2, st); break;
         case 2: launch_lstm_fwd<CfgLstmV3_256, false, true>(p, e, k1, k2, st); break;
-        case 3: launch_lstm_fwd<CfgLstmV3_224, false, true>(p, e, k1, k2, st); break;
+        case 3: if (uneven224) launch_lstm_fwd<CfgLstmV3_224u, false, true>(p, e, k1, k2, st); else launch_lstm_fwd<CfgLstmV3_224, false, true>(p, e, k1, k2, st); break;
+        case 10: launch_lstm_fwd<CfgLstmV3_240, false, true>(p, e, k1, k2, st); break;
         case 4: launch_lstm_fwd<CfgLstmV3_192, false, true>(p, e, k1, k2, st); break;
         case 5: launch_lstm_fwd<CfgLstmV3_160, false, true>(p, e, k1, k2, st); break;
         case 6: launch_lstm_fwd<CfgLstmBig, false, true>(p, e, k1, k2, st); break;
@@ -1269,7 +1305,8 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
       case 0: launch_lstm_fwd<CfgLstmV2a>(p, e, k1, k2, st); break;
       case 1: launch_lstm_fwd<CfgLstmV2_288>(p, e, k1, k2, st); break;
       case 2: if (fwd_v2) launch_lstm_fwd<CfgLstmV2b>(p, e, k1, k2, st); else launch_lstm_fwd<CfgLstmV3_256>(p, e, k1, k2, st); break;
-      case 3: if (fwd_v2) launch_lstm_fwd<CfgLstmV2_224>(p, e, k1, k2, st); else launch_lstm_fwd<CfgLstmV3_224>(p, e, k1, k2, st); break;
+      case 3: if (fwd_v2) launch_lstm_fwd<CfgLstmV2_224>(p, e, k1, k2, st); else if (uneven224) launch_lstm_fwd<CfgLstmV3_224u>(p, e, k1, k2, st); else launch_lstm_fwd<CfgLstmV3_224>(p, e, k1, k2, st); break;
+      case 10: launch_lstm_fwd<CfgLstmV3_240>(p, e, k1, k2, st); break;
       case 4: if (fwd_v2) launch_lstm_fwd<CfgLstmV2_192>(p, e, k1, k2, st); else launch_lstm_fwd<CfgLstmV3_192>(p, e, k1, k2, st); break;
       case 5: if (fwd_v2) launch_lstm_fwd<CfgLstmV2_160>(p, e, k1, k2, st); else launch_lstm_fwd<CfgLstmV3_160>(p, e, k1, k2, st); break;
       case 6: launch_lstm_fwd<CfgLstmBig>(p, e, k1, k2, st); break;
@@ -1284,16 +1321,17 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
 
 // forward tile among the 64-wide ring tiles only (the e4m3 tail lives in gemm_core_v3.h): 0..3 = 256 / 224 / 192 / 160 rows
 static inline int pick_fwd_tile_v3(int rows, int H) {
-  static const int bm[4] = {256, 224, 192, 160};
-  static const double cf[4] = {1.0, 1.02, 1.04, 1.08};
+  static const int bm[5] = {256, 224, 192, 160, 240};
+  static const double cf[5] = {1.0, 1.02, 1.04, 1.08, 1.01};
+  static const bool no240 = getenv("EVC_FWD_NO_240") != nullptr;
   int best = 0;
   double bc = 1e300;
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < (no240 ? 4 : 5); ++i) {
     const double c = tile_cost((long)ceil_div(rows, bm[i]) * ceil_div(H, 64), bm[i], 256, 1, cf[i]);
     if (c < bc) { bc = c; best = i; }
   }
-  const int f = forced_tile();        // debug: 1 -> 256, 6 -> 224, 7 -> 192, 8 -> 160
-  if (f == 1) best = 0; else if (f == 6) best = 1; else if (f == 7) best = 2; else if (f == 8) best = 3;
+  const int f = forced_tile();        // debug: 1 -> 256, 6 -> 224, 7 -> 192, 8 -> 160, 11 -> 240
+  if (f == 1) best = 0; else if (f == 6) best = 1; else if (f == 7) best = 2; else if (f == 8) best = 3; else if (f == 11) best = 4;
   return best;
 }
 
@@ -1321,6 +1359,7 @@ extern "C" int evc_lstm_layer_fwd_f16_fp8lo(const evc_f16* x, int64_t ldx, int k
   const long ldh = 3L * H / 2;                       // halfwords per hbuf row
   EVC_REQUIRE(ring_operand_ok(M, ldx > ldh ? ldx : ldh) && ring_operand_ok(4L * H, (long)kx16 + H), EVC_ERR_BAD_SHAPE,
               "evc_lstm_layer_fwd_f16_fp8lo: a time slab or the kernel spans 4 GiB or more");
+  EVC_REQUIRE(fwd_tail_ok(M, H, ld_state), EVC_ERR_BAD_SHAPE, "LSTM forward: a gate-record / state slab spans 4 GiB or more (M=%d H=%d ld_state=%ld)", M, H, (long)ld_state);
   EVC_REQUIRE(ld_state % 4 == 0 && ((uintptr_t)c_state % 16) == 0 && ((uintptr_t)h_state % 16) == 0 && ((uintptr_t)bias % 16) == 0, EVC_ERR_BAD_ALIGN,
               "evc_lstm_layer_fwd_f16_fp8lo: state/bias must allow 16-byte vector access");
   EVC_REQUIRE((gates == nullptr) == (c_all == nullptr), EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd_f16_fp8lo: gates and c_all go together");
@@ -1365,6 +1404,7 @@ extern "C" int evc_lstm_layer_fwd_f16_fp8lo(const evc_f16* x, int64_t ldx, int k
       case 0: launch_lstm_fwd<CfgLstmV3_256, false, true, true>(p, e, k1, k2, st); break;
       case 1: launch_lstm_fwd<CfgLstmV3_224, false, true, true>(p, e, k1, k2, st); break;
       case 2: launch_lstm_fwd<CfgLstmV3_192, false, true, true>(p, e, k1, k2, st); break;
+      case 4: launch_lstm_fwd<CfgLstmV3_240, false, true, true>(p, e, k1, k2, st); break;
       default: launch_lstm_fwd<CfgLstmV3_160, false, true, true>(p, e, k1, k2, st); break;
     }
   }
@@ -1386,6 +1426,7 @@ extern "C" int evc_lstm_layer_fwd_hp(const evc_bf16* x_lohi, const evc_bf16* wx_
   EVC_REQUIRE(ldwx >= 2L * Kin && ldwh >= 2L * H && ldwx % 8 == 0 && ldwh % 8 == 0 && ((uintptr_t)wh_hilo % 16) == 0, EVC_ERR_BAD_ALIGN,
               "evc_lstm_layer_fwd_hp: weight images are [4H][2Kin] / [4H][2H] (ldwx=%ld ldwh=%ld)", (long)ldwx, (long)ldwh);
   EVC_REQUIRE(ring_operand_ok(M, 2L * H) && ring_operand_ok(4L * H, ldwh), EVC_ERR_BAD_SHAPE, "evc_lstm_layer_fwd_hp: operand spans 4 GiB or more");
+  EVC_REQUIRE(fwd_tail_ok(M, H, ld_state), EVC_ERR_BAD_SHAPE, "LSTM forward: a gate-record / state slab spans 4 GiB or more (M=%d H=%d ld_state=%ld)", M, H, (long)ld_state);
   EVC_REQUIRE(ld_state % 4 == 0 && ((uintptr_t)c_state % 16) == 0 && ((uintptr_t)h_state % 16) == 0 && ((uintptr_t)bias % 16) == 0 &&
               ((uintptr_t)hbuf % 8) == 0 && ((uintptr_t)hbuf_lohi % 16) == 0, EVC_ERR_BAD_ALIGN,
               "evc_lstm_layer_fwd_hp: state/bias/hbuf must allow 16-byte vector access");
@@ -1471,6 +1512,7 @@ extern "C" int evc_lstm_stack2_fwd(const evc_bf16* x, const evc_bf16* wT0, const
               "evc_lstm_stack2_fwd: bad shape T=%d M=%d Kin=%d H=%d (Kin, H multiples of 64)", T, M, Kin, H);
   EVC_REQUIRE(ring_operand_ok(M, Kin > H ? Kin : H) && ring_operand_ok(4L * H, (long)Kin + H) && ring_operand_ok(4L * H, 2L * H), EVC_ERR_BAD_SHAPE,
               "evc_lstm_stack2_fwd: a time slab or a kernel spans 4 GiB or more (M=%d Kin=%d H=%d)", M, Kin, H);
+  EVC_REQUIRE(fwd_tail_ok(M, H, ld_state), EVC_ERR_BAD_SHAPE, "LSTM forward: a gate-record / state slab spans 4 GiB or more (M=%d H=%d ld_state=%ld)", M, H, (long)ld_state);
   EVC_REQUIRE(zx_ws && hbuf0 && hbuf1, EVC_ERR_BAD_ARG, "evc_lstm_stack2_fwd: zx_ws / hbuf0 / hbuf1 must not be NULL");
   EVC_REQUIRE(ld_state % 4 == 0 && ((uintptr_t)c_state0 % 16) == 0 && ((uintptr_t)h_state0 % 16) == 0 && ((uintptr_t)c_state1 % 16) == 0 &&
               ((uintptr_t)h_state1 % 16) == 0 && ((uintptr_t)bias0 % 16) == 0 && ((uintptr_t)bias1 % 16) == 0 &&
@@ -1551,6 +1593,7 @@ extern "C" int evc_lstm_stack2_fwd_f16(const evc_f16* x, int x_segments, const e
   const long ldw0 = Kx + (h0_ext ? 2L : 1L) * H;       // row of layer 0's kernel image (evc_cast_f32_to_f16_wide)
   EVC_REQUIRE(ring_operand_ok(M, 2L * H) && ring_operand_ok(4L * H, 4L * H) && ring_operand_ok(4L * H, 3L * Kin + 2L * H), EVC_ERR_BAD_SHAPE,
               "evc_lstm_stack2_fwd_f16: an operand spans 4 GiB or more");
+  EVC_REQUIRE(fwd_tail_ok(M, H, ld_state), EVC_ERR_BAD_SHAPE, "LSTM forward: a gate-record / state slab spans 4 GiB or more (M=%d H=%d ld_state=%ld)", M, H, (long)ld_state);
   EVC_REQUIRE(ld_state % 4 == 0 && ((uintptr_t)c_state0 % 16) == 0 && ((uintptr_t)h_state0 % 16) == 0 && ((uintptr_t)c_state1 % 16) == 0 &&
               ((uintptr_t)h_state1 % 16) == 0 && ((uintptr_t)bias0 % 16) == 0 && ((uintptr_t)bias1 % 16) == 0 && ((uintptr_t)h0_wide % 16) == 0 &&
               ((uintptr_t)h1_wide % 16) == 0 && ((uintptr_t)hbuf0 % 8) == 0 && ((uintptr_t)hbuf1 % 8) == 0, EVC_ERR_BAD_ALIGN,
@@ -1630,6 +1673,7 @@ extern "C" int evc_lstm_stack2_fwd_f16_fp8lo(const evc_f16* x, int x_segments, c
   const long ldw0 = Kx + H, ldh = 3L * H / 2;
   EVC_REQUIRE(ring_operand_ok(M, ldh) && ring_operand_ok(4L * H, ldw0) && ring_operand_ok(4L * H, 2L * H), EVC_ERR_BAD_SHAPE,
               "evc_lstm_stack2_fwd_f16_fp8lo: an operand spans 4 GiB or more");
+  EVC_REQUIRE(fwd_tail_ok(M, H, ld_state), EVC_ERR_BAD_SHAPE, "LSTM forward: a gate-record / state slab spans 4 GiB or more (M=%d H=%d ld_state=%ld)", M, H, (long)ld_state);
   EVC_REQUIRE(ld_state % 4 == 0 && ((uintptr_t)c_state0 % 16) == 0 && ((uintptr_t)h_state0 % 16) == 0 && ((uintptr_t)c_state1 % 16) == 0 &&
               ((uintptr_t)h_state1 % 16) == 0 && ((uintptr_t)bias0 % 16) == 0 && ((uintptr_t)bias1 % 16) == 0 && ((uintptr_t)h0_rows % 16) == 0 &&
               ((uintptr_t)h1_rows % 16) == 0 && ((uintptr_t)hbuf0 % 8) == 0 && ((uintptr_t)hbuf1 % 8) == 0 && ((uintptr_t)wT0_8 % 16) == 0 &&
@@ -2313,6 +2357,11 @@ static inline void launch_lstm_bwd(GemmOperands p, const LstmBwdParams& e, int k
 
 typedef TileCfg2<128, 1, 128, 2, 4, 5, true> CfgBwdV2_128;   // BPTT step tiles: BM rows x 128 units, 8 waves (2x4)
 typedef TileCfg3<128, 1, 128, 2, 4, 4> CfgBwdV3_128;         // the same tile on 64-wide K stages (whole cache lines per LDS-DMA piece)
+// shallower rings for the same tile (A/B, EVC_BWD_STAGES=3 | 2): 96 / 66 KB of LDS instead of 128 - room for a 64 KB workgroup of another stream on the CU
+typedef TileCfg3<128, 1, 128, 2, 4, 3> CfgBwdV3_128s3;
+struct CfgBwdV3_128s2 : TileCfg3<128, 1, 128, 2, 4, 2> { static constexpr int LDS_BYTES = 128 * (128 * 4 + 16); };   // (the row-major tail's dh tile: 66 KB)
+template <> struct is_v2<CfgBwdV3_128s2> { static constexpr bool value = true; };
+template <> struct is_v3<CfgBwdV3_128s2> { static constexpr bool value = true; };
 typedef TileCfg3<64, 1, 64, 2, 4, 4> CfgBwdV3_64;            // ~1000 live rows (the student's L1 levels): 16 x 16 = 256 tiles of 64 x 64, 64 KB of LDS
 typedef TileCfg2<160, 1, 128, 2, 4, 5, true> CfgBwdV2_160;
 typedef TileCfg2<192, 1, 128, 2, 4, 5, true> CfgBwdV2_192;
@@ -2384,11 +2433,14 @@ extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int 
     e.dc_bf16 = bwd_dc_bf16();
     e.row_map = row_map; e.db = db; e.m_active = Mt;
     e.M = M; e.H = H; e.fused_above = dz_above ? 1 : 0;
+    static const int bwd_stages = getenv("EVC_BWD_STAGES") ? atoi(getenv("EVC_BWD_STAGES")) : 4;     // A/B: ring depth of the 128 x 128 BPTT tile
     switch (pick) {
       case 0: launch_lstm_bwd<CfgBwdV2_192>(p, e, k1, st); break;
       case 1: launch_lstm_bwd<CfgBwdV2_160>(p, e, k1, st); break;
       case 2:
         if (getenv("EVC_BWD_V2_LOOP") || dz_above) launch_lstm_bwd<CfgBwdV2_128>(p, e, k1, st);   // (two-matrix K walk: nk2 is set in 32-wide steps above)
+        else if (bwd_stages == 3) launch_lstm_bwd<CfgBwdV3_128s3>(p, e, k1, st);
+        else if (bwd_stages == 2) launch_lstm_bwd<CfgBwdV3_128s2>(p, e, k1, st);
         else launch_lstm_bwd<CfgBwdV3_128>(p, e, k1, st);
         break;
       case 4: launch_lstm_bwd<CfgPlainTiny>(p, e, k1, st); break;

@@ -20,6 +20,7 @@
 //    discarded by the epilogue), so any M, N works; K % 64 == 0 is required.
 #pragma once
 #include "evc_common.h"
+#include <type_traits>
 
 template <int BM_, int G_, int BU_, int WR_, int WC_>
 struct TileCfg {
@@ -55,6 +56,9 @@ struct GemmOperands {
   const uint8_t* A4 = nullptr; long lda4 = 0; int nk4 = 0;
   const uint8_t* B8 = nullptr; long ldb8 = 0;
   int scale8_exp = 0;
+#ifdef EVC_STAMPS
+  int stamp_slot = 0;                    // diagnostic build: which slot of evc_stamps this launch writes (gemm_core_v3.h)
+#endif
 };
 
 // XCD-aware bijective remap of the linear workgroup id: consecutive remapped
@@ -233,13 +237,21 @@ struct TileCoords {
 };
 // Same for a SWAP (transposed) accumulator: element (mi, ni, reg) is
 //   row  = wr*WM + mi*16 + (lane&15),   unit = wc*WU + ni*16 + (lane>>4)*4 + reg
+// first tile row of wave row wr = wr * stride: WM, or ROW1 where a tile splits its rows unevenly between two wave rows (gemm_core_v3.h)
+template <class Cfg, class = void> struct wave_row_stride { static constexpr int value = Cfg::WM; };
+template <class Cfg> struct wave_row_stride<Cfg, std::void_t<decltype(Cfg::ROW1)>> { static constexpr int value = Cfg::ROW1; };
+// row fragments that belong to wave row wr (the others of a lane's Cfg::MI accumulator rows are not part of the tile)
+template <class Cfg, class = void> struct wave_row_frags { static __device__ __forceinline__ int of(int) { return Cfg::MI; } };
+template <class Cfg> struct wave_row_frags<Cfg, std::void_t<decltype(Cfg::MIP)>> {
+  static __device__ __forceinline__ int of(int wr) { return wr == 0 ? Cfg::MIP : Cfg::MIC; }
+};
 template <class Cfg>
 struct TileCoordsT {
   int row0, unit0;  // add mi*16 / ni*16 + reg
   __device__ __forceinline__ TileCoordsT() {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / Cfg::WC, wc = wave % Cfg::WC;
-    row0 = wr * Cfg::WM + (lane & 15);
+    row0 = wr * wave_row_stride<Cfg>::value + (lane & 15);
     unit0 = wc * Cfg::WU + (lane >> 4) * 4;
   }
 };

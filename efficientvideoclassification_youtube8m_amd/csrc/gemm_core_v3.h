@@ -31,13 +31,26 @@
 #ifndef EVC_V3_AUX_B
 #define EVC_V3_AUX_B 0
 #endif
+#ifdef EVC_STAMPS      // diagnostic build (scripts/fwd_stamps.py): s_memrealtime (100 MHz) marks per workgroup, read back through evc_debug_read_stamps
+static __device__ unsigned long long evc_stamps[8][512][8];       // [GemmOperands::stamp_slot][workgroup][mark]
+#define EVC_STAMP(slot, k) do { if (threadIdx.x == 0 && blockIdx.x < 512) evc_stamps[(slot) & 7][blockIdx.x][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define EVC_STAMP(slot, k) do { } while (0)
+#endif
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v8i_t __attribute__((ext_vector_type(8)));
 
-template <int BM_, int G_, int BU_, int WR_, int WC_, int STAGES_ = 4>
+// MIP_ > 0: UNEVEN row split between the two wave rows (WR = 2, LOOP_PRODUCER loops): the producer waves (wave row 0: they also issue the
+// stage's LDS-DMA) take MIP_ row fragments, the other wave row the remaining BM/16 - MIP_ - the two waves of a SIMD are one of each, so the
+// SIMD's MFMA work is BM/16 fragments whatever the split, and BM moves in steps of 16 rows instead of 32 (240 = 7 + 8: DESIGN.md 4.3)
+template <int BM_, int G_, int BU_, int WR_, int WC_, int STAGES_ = 4, int MIP_ = 0>
 struct TileCfg3 {
   static constexpr int BM = BM_, G = G_, BU = BU_, BN = G_ * BU_, WR = WR_, WC = WC_;
-  static constexpr int WM = BM / WR, WU = BU / WC, MI = WM / 16, NI = WU / 16;
+  static constexpr bool UNEVEN = MIP_ > 0;
+  static constexpr int MIP = UNEVEN ? MIP_ : BM / WR / 16, MIC = UNEVEN ? BM / 16 - MIP_ : MIP;    // row fragments of wave row 0 / of the other wave rows
+  static constexpr int MI = MIP > MIC ? MIP : MIC, WM = UNEVEN ? MI * 16 : BM / WR, ROW1 = UNEVEN ? MIP * 16 : WM;   // wave row wr starts at tile row wr * ROW1
+  static constexpr int WU = BU / WC, NI = WU / 16;
+  static_assert(!UNEVEN || (WR == 2 && WC == 4 && BM % 16 == 0 && MIC > 0), "uneven split: two wave rows of four waves (wave row 0 = the producers)");
   static constexpr int NT = 64 * WR * WC;
   static constexpr int BK = 64, STAGES = STAGES_;
   static constexpr bool PIPE = true;
@@ -50,7 +63,7 @@ struct TileCfg3 {
   static constexpr bool SINK = RAGGED;
 #endif
   static constexpr int LDS_BYTES = DUMMY_OFF + (SINK ? 1024 : 0);
-  static_assert(WM % 16 == 0 && WU % 16 == 0 && BM % 8 == 0 && BN % 8 == 0, "wave tile must be a multiple of 16x16");
+  static_assert((UNEVEN || BM % (16 * WR) == 0) && WU % 16 == 0 && BM % 8 == 0 && BN % 8 == 0, "wave tile must be a multiple of 16x16");
   static_assert(STAGES >= 2 && STAGES <= 6, "ring depth 2..6");
   static_assert(LDS_BYTES <= 160 * 1024, "exceeds the 160 KiB LDS of a CU");
 };
@@ -151,12 +164,14 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
   const int fch = (fq ^ (frow & 7)) * 16;      // tile rows start on multiples of 16 -> row & 7 == frow & 7
   // one base per operand and K half; fragment (mi | g, ni) sits a COMPILE-TIME multiple of 128 bytes behind it (adding a multiple of
   // 128 commutes with flipping bit 6): immediates of the ds_read instead of one address register per fragment and half
-  const int a_rd0 = (wr * Cfg::WM + frow) * 128 + fch, b_rd0 = Cfg::A_BYTES + (wc * Cfg::WU + frow) * 128 + fch;
+  const int a_rd0 = (wr * Cfg::ROW1 + frow) * 128 + fch, b_rd0 = Cfg::A_BYTES + (wc * Cfg::WU + frow) * 128 + fch;
   const int a_rd1 = a_rd0 ^ 64, b_rd1 = b_rd0 ^ 64;
   auto a_off = [](const int mi) { return mi * 16 * 128; };
   auto b_off = [](const int g, const int ni) { return (g * Cfg::BU + ni * 16) * 128; };
 
-  auto read_half = [&](const int kb, bf16x8 (&af)[Cfg::MI], bf16x8 (&bfr)[Cfg::G][Cfg::NI]) {   // reads half kb of ring slot slot_read
+  // (mi_tag: the row fragments of the calling wave's role - Cfg::MI unless the tile splits its rows unevenly)
+  auto read_half = [&](auto mi_tag, const int kb, bf16x8 (&af)[Cfg::MI], bf16x8 (&bfr)[Cfg::G][Cfg::NI]) {   // reads half kb of ring slot slot_read
+    constexpr int MIr = decltype(mi_tag)::value;
     const char* sb = lds + slot_read * Cfg::STAGE_BYTES;
     const char* pa = sb + (kb ? a_rd1 : a_rd0);
     const char* pb = sb + (kb ? b_rd1 : b_rd0);
@@ -165,12 +180,12 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
 #pragma unroll
       for (int ni = 0; ni < Cfg::NI; ++ni) bfr[g][ni] = *(const bf16x8*)(pb + b_off(g, ni));
 #pragma unroll
-    for (int mi = 0; mi < Cfg::MI; ++mi) af[mi] = *(const bf16x8*)(pa + a_off(mi));
+    for (int mi = 0; mi < MIr; ++mi) af[mi] = *(const bf16x8*)(pa + a_off(mi));
   };
   auto next_slot = [&]() { slot_read = (slot_read + 1 == Cfg::STAGES) ? 0 : slot_read + 1; };
-  auto mfma_all = [&](const bf16x8 (&af)[Cfg::MI], const bf16x8 (&bfr)[Cfg::G][Cfg::NI]) {
+  auto mfma_all = [&](auto mi_tag, const bf16x8 (&af)[Cfg::MI], const bf16x8 (&bfr)[Cfg::G][Cfg::NI]) {
 #pragma unroll
-    for (int mi = 0; mi < Cfg::MI; ++mi)
+    for (int mi = 0; mi < decltype(mi_tag)::value; ++mi)
 #pragma unroll
       for (int g = 0; g < Cfg::G; ++g)
 #pragma unroll
@@ -182,7 +197,6 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0xC07F);
   };
-  constexpr int NMFMA = Cfg::MI * Cfg::G * Cfg::NI, NREAD = Cfg::MI + Cfg::G * Cfg::NI;
   constexpr int AHEAD = Cfg::STAGES - 2;     // stages that may stay in flight while the next one is awaited
   auto wait_landed = [&](int outstanding_stages) {   // wave-uniform small switch
     if (outstanding_stages >= 4) wait_vmcnt<4 * PER>();
@@ -240,6 +254,10 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
   constexpr bool PROD = decltype(prod_tag)::value;
   constexpr bool PRIO = (MODE & LOOP_NO_PRIO) == 0;
   constexpr int PERX = PROD ? PER : 0;
+  static_assert(!Cfg::UNEVEN || PRODUCERS, "an uneven row split needs the producer / consumer roles of LOOP_PRODUCER");
+  constexpr int MIr = Cfg::UNEVEN ? (PROD ? Cfg::MIP : Cfg::MIC) : Cfg::MI;      // row fragments of this role
+  using MIT = std::integral_constant<int, MIr>;
+  constexpr int NMFMA = MIr * Cfg::G * Cfg::NI, NREAD = MIr + Cfg::G * Cfg::NI;
   auto stage_role = [&]() {
     if constexpr (PROD) stage();
   };
@@ -283,8 +301,9 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
   if constexpr (PROD) wait_landed(min(nk, Cfg::STAGES) - 1);
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  EVC_STAMP(p.stamp_slot, 1);
   bf16x8 afA[Cfg::MI], bfA[Cfg::G][Cfg::NI], afB[Cfg::MI], bfB[Cfg::G][Cfg::NI];
-  read_half(0, afA, bfA);
+  read_half(MIT{}, 0, afA, bfA);
   __builtin_amdgcn_s_waitcnt(0xC07F);   // enter the loop with no LDS read pending
 
   int j = 0;
@@ -293,8 +312,8 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
   auto trip16 = [&](auto prefetch_tag) {
     // first half: its partner fragments are in the stage being read - no wait, no barrier
     if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
-    read_half(1, afB, bfB);
-    mfma_all(afA, bfA);
+    read_half(MIT{}, 1, afB, bfB);
+    mfma_all(MIT{}, afA, bfA);
 #ifndef EVC_NO_INTERLEAVE
     interleave(std::integral_constant<int, 0>{}, std::integral_constant<int, (PRODUCERS && !PROD) ? EVC_STAGGER_LEAD : 0>{});
 #endif
@@ -308,8 +327,8 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
     stage_role();
     if constexpr (!PROD) prefetch(j + Cfg::STAGES + EVC_PREFETCH_DIST);
     next_slot();
-    if constexpr (decltype(prefetch_tag)::value) read_half(0, afA, bfA);
-    mfma_all(afB, bfB);
+    if constexpr (decltype(prefetch_tag)::value) read_half(MIT{}, 0, afA, bfA);
+    mfma_all(MIT{}, afB, bfB);
 #ifndef EVC_NO_INTERLEAVE
     if constexpr (decltype(prefetch_tag)::value) interleave(std::integral_constant<int, PERX>{}, std::integral_constant<int, 0>{});
 #endif
@@ -320,17 +339,17 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
   if constexpr (!FP8) {
     for (; j + Cfg::STAGES < nk; ++j) trip16(std::true_type{});   // steady state: stage j+STAGES exists, so every trip refills
     for (; j < nk; ++j) {                 // last STAGES stages: no refills
-      read_half(1, afB, bfB);
-      mfma_all(afA, bfA);
+      read_half(MIT{}, 1, afB, bfB);
+      mfma_all(MIT{}, afA, bfA);
       end_of_step();
       if (j + 1 < nk) {
         if constexpr (PROD) wait_landed(nk - (j + 2));
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         next_slot();
-        read_half(0, afA, bfA);
+        read_half(MIT{}, 0, afA, bfA);
       }
-      mfma_all(afB, bfB);
+      mfma_all(MIT{}, afB, bfB);
       end_of_step();
     }
   } else {
@@ -341,7 +360,7 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
     // Two halves per trip, split by the tile's ROW fragments (the 16-bit trips split the stage's K range): half 1 multiplies the lower
     // row fragments while the upper ones are read; behind the barrier and the refill, half 2 multiplies the upper ones while the next
     // stage's lower row fragments and - column group by column group, as its last MFMA has been issued - its B fragments are read.
-    constexpr int ML = (Cfg::MI + 1) / 2, MH = Cfg::MI - ML;
+    constexpr int ML = (MIr + 1) / 2, MH = MIr - ML;
     // (a wave with ONE row fragment - the 64-row tiles of the M ~ batch stacks - has no upper half: half 1 multiplies everything, half 2
     //  only re-reads; those steps are bound by the chain of dependent stages, and an e4m3 stage covers twice the K of a 16-bit one)
     v8i_t aL[ML], aH[MH > 0 ? MH : 1], b8[Cfg::G][Cfg::NI];

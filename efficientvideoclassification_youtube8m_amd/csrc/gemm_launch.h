@@ -11,14 +11,19 @@
 template <class Cfg> struct is_v2 { static constexpr bool value = false; };
 template <int a, int b, int c, int d, int e, int f, bool g> struct is_v2<TileCfg2<a, b, c, d, e, f, g>> { static constexpr bool value = true; };
 // v3 tiles (TileCfg3: the ring with 64-wide K stages, gemm_core_v3.h) are ring tiles too (dynamic LDS, same epilogues)
-template <int a, int b, int c, int d, int e, int f> struct is_v2<TileCfg3<a, b, c, d, e, f>> { static constexpr bool value = true; };
+template <int a, int b, int c, int d, int e, int f, int g> struct is_v2<TileCfg3<a, b, c, d, e, f, g>> { static constexpr bool value = true; };
 template <class Cfg> struct is_v3 { static constexpr bool value = false; };
-template <int a, int b, int c, int d, int e, int f> struct is_v3<TileCfg3<a, b, c, d, e, f>> { static constexpr bool value = true; };
+template <int a, int b, int c, int d, int e, int f, int g> struct is_v3<TileCfg3<a, b, c, d, e, f, g>> { static constexpr bool value = true; };
 
 extern __shared__ __attribute__((aligned(16))) char lds_dyn[];
 
 // The ring loops address every LDS-DMA as base + 32-bit byte offset built from a 24-bit row index and a 24-bit row stride
 // (gemm_core_v2.h): an operand of `rows` rows with leading dimension `ld` (bf16 elements) must fit that.
+// the forward step's epilogue addresses its stores as base + 32-bit byte offset: gate records [rows][H] x 8 B, state rows (row_map is a
+// permutation of [0, rows)) of ld_state floats, h rows of up to 3H bytes / 2H halfwords (the wide images)
+static inline bool fwd_tail_ok(long rows, long H, long ld_state) {
+  return rows * H * 8 + 32 < (1L << 32) && rows * ld_state * 4 < (1L << 32);
+}
 static inline bool ring_operand_ok(long rows, long ld) {
   return rows < (1L << 24) && ld * 2 < (1L << 24) && rows * ld * 2 < (1L << 32);
 }

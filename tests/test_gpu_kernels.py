@@ -523,14 +523,14 @@ def test_gemm_nt_f16_fp8_product_with_low_order_corrections(ops, M, N, K):
     assert d_emu < 2e-5 * max(1.0, np.abs(ref).max()), d_emu
 
 
-@pytest.mark.parametrize("M,T,Kin,H,tile", [(512, 4, 384, 384, 0), (1100, 3, 1152, 512, 0), (700, 5, 384, 384, 6), (390, 3, 512, 384, 7), (330, 3, 384, 384, 8)])
+@pytest.mark.parametrize("M,T,Kin,H,tile", [(512, 4, 384, 384, 0), (1100, 3, 1152, 512, 0), (700, 5, 384, 384, 6), (390, 3, 512, 384, 7), (330, 3, 384, 384, 8), (730, 4, 384, 384, 11)])
 def test_lstm_layer_fwd_f16_fp8_low_order_weights(M, T, Kin, H, tile):
     """evc_lstm_layer_fwd_f16_fp8lo (two stacked layers: layer 0 on input rows [f16(x) | e4m3(x 2^7) | e4m3(x_lo 2^18)], layer 1 on layer 0's
     h rows [f16(h) | e4m3(h 2^7)]): per step z = [x | h] . [Wx | Wh]^T in f16 + 2^-24 [x8 | x_lo8 | h8] . [e4m3(Wx_lo 2^17) | e4m3(Wx 2^6) |
     e4m3(Wh_lo 2^17)]^T on the MX-scaled fp8 MFMA.  Against the float64 oracle with EXACT weights and exact x: what is left is the f16 rounding of h (the
     same bound as the f16 layer with extended weights, 8e-4) - and next to the plain f16 layer on the same kernel it must be the
     closer one.  Every ring tile the launcher can pick (EVC_FORCE_TILE in a child process: 256 / 224 / 192 / 160 rows), rows that end
-    early, a row plan."""
+    early, a row plan.  Tile 11 = 240 rows split 7 + 8 row fragments between the two wave rows (gemm_core_v3.h, uneven split)."""
     code = _FP8LO_CHILD % dict(M=M, T=T, Kin=Kin, H=H)
     env = dict(os.environ)
     if tile:
@@ -1399,10 +1399,10 @@ def test_gemm_nt_ring_tile_store_paths(tile):
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
-@pytest.mark.parametrize("tile", ["1", "2", "3", "4", "5", "6", "7", "8", "9", "10"])
+@pytest.mark.parametrize("tile", ["1", "2", "3", "4", "5", "6", "7", "8", "9", "10", "11"])
 def test_lstm_steps_on_every_ring_tile(tile):  # (BPTT: 7 -> the 64 x 64 ring tile of gemm_core_v3.h)
     """The fused LSTM step kernels on every ring-tile height (EVC_FORCE_TILE pins the choice: forward 1 -> 256 rows, 4 -> 320,
-    5 -> 288, 6 -> 224, 7 -> 192, 8 -> 160, 9 -> 128, 10 -> 64; BPTT 1 -> 192, 2 -> 160, 3 -> 128) against the oracle - the
+    5 -> 288, 6 -> 224, 7 -> 192, 8 -> 160, 9 -> 128, 10 -> 64, 11 -> 240 = 7 + 8 row fragments on the two wave rows; BPTT 1 -> 192, 2 -> 160, 3 -> 128) against the oracle - the
     160 / 224 / 288-row tiles have surplus staging lanes (dummy LDS sink), and the forward loop stages through four producer
     waves.  One process per tile (the choice is read once per process)."""
     import os, subprocess, sys
