@@ -10,7 +10,11 @@ rows = []
 for r in csv.DictReader(open(sys.argv[1])):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))))
 rows.sort()
-starts = [s for s, e, n, g in rows if n.startswith("l2norm_chunk")]
+starts = [s for s, e, n, g in rows if n.startswith("l2norm_chunk")]       # first kernel of an H-LSTM training step
+if len(starts) < 3:
+    starts = [s for s, e, n, g in rows if n.startswith("dbof_gather")]      # ... of a DBoF step (bench.py --config dbof)
+if len(starts) < 3:
+    sys.exit("profile_digest: fewer than three training steps in the trace (no l2norm_chunk / dbof_gather launches)")
 t0, t1 = starts[-3], starts[-2]
 agg = defaultdict(lambda: [0, 0])
 for s, e, n, g in rows:

@@ -13,7 +13,7 @@ def short(name):
     name = re.sub(r"^void ", "", name)
     m = re.match(r"([A-Za-z_0-9:]+)(<.*)?\(", name)
     base = m.group(1) if m else name[:40]
-    cfg = re.search(r"TileCfg2?<([0-9, a-z]+)>", name)
+    cfg = re.search(r"TileCfg[23]?<([0-9, a-z]+)>", name)
     return base.split("::")[-1] + ("<" + cfg.group(1).replace(" ", "") + ">" if cfg else "")
 
 
