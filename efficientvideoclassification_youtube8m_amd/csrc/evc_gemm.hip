@@ -2359,6 +2359,7 @@ typedef TileCfg2<128, 1, 128, 2, 4, 5, true> CfgBwdV2_128;   // BPTT step tiles:
 typedef TileCfg3<128, 1, 128, 2, 4, 4> CfgBwdV3_128;         // the same tile on 64-wide K stages (whole cache lines per LDS-DMA piece)
 // shallower rings for the same tile (A/B, EVC_BWD_STAGES=3 | 2): 96 / 66 KB of LDS instead of 128 - room for a 64 KB workgroup of another stream on the CU
 typedef TileCfg3<128, 1, 128, 2, 4, 3> CfgBwdV3_128s3;
+typedef TileCfg3<128, 1, 128, 2, 4, 5> CfgBwdV3_128s5;        // (and a deeper one: the whole 160 KB)
 struct CfgBwdV3_128s2 : TileCfg3<128, 1, 128, 2, 4, 2> { static constexpr int LDS_BYTES = 128 * (128 * 4 + 16); };   // (the row-major tail's dh tile: 66 KB)
 template <> struct is_v2<CfgBwdV3_128s2> { static constexpr bool value = true; };
 template <> struct is_v3<CfgBwdV3_128s2> { static constexpr bool value = true; };
@@ -2440,6 +2441,7 @@ extern "C" int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int 
       case 2:
         if (getenv("EVC_BWD_V2_LOOP") || dz_above) launch_lstm_bwd<CfgBwdV2_128>(p, e, k1, st);   // (two-matrix K walk: nk2 is set in 32-wide steps above)
         else if (bwd_stages == 3) launch_lstm_bwd<CfgBwdV3_128s3>(p, e, k1, st);
+        else if (bwd_stages == 5) launch_lstm_bwd<CfgBwdV3_128s5>(p, e, k1, st);
         else if (bwd_stages == 2) launch_lstm_bwd<CfgBwdV3_128s2>(p, e, k1, st);
         else launch_lstm_bwd<CfgBwdV3_128>(p, e, k1, st);
         break;
