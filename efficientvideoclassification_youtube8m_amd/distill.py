@@ -574,12 +574,18 @@ class DistillGraph:
         gens = {"s": (gen_s, side), "t": (gen_t, main)}
         live = {k for k, (g_, _) in gens.items() if g_ is not None}
         order = self.ISSUE_ORDERS[self.issue_order] if (gen_s is not None and gen_t is not None) else ""
-        for who in list(order) + ["s"] * 8 + ["t"] * 8:
+        def resume(who):
+            g_, st_ = gens[who]
+            with torch.cuda.stream(st_):
+                if next(g_, self) is self:             # exhausted
+                    live.discard(who)
+        for who in order:                              # the scripted part (written for two LSTM layers per level) ...
             if who in live:
-                g_, st_ = gens[who]
-                with torch.cuda.stream(st_):
-                    if next(g_, self) is self:         # exhausted
-                        live.discard(who)
+                resume(who)
+        for who in ("s", "t"):                         # ... then each tower to its end, whatever --lstm_layers says: a tower needs
+            while who in live:                         # 2 * lstm_layers + 2 resumptions, and an unfinished generator would silently
+                resume(who)                            # skip the lowest layers' BPTT, weight gradients, Adam and the final stream joins
+        assert not live
         if need_student:
             with torch.cuda.stream(side):
                 if not early_s:

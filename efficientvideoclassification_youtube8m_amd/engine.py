@@ -566,6 +566,35 @@ class MoeHead:
     # one process: the clip norm of the fused update from Gram matrices of the factors instead of a pass over the weights
     # (csrc/evc_moe_norms.hip; EVC_MOE_GRAM_NORMS=0: the two-pass form)
     gram_norms = os.environ.get("EVC_MOE_GRAM_NORMS", "1") != "0"
+    gram_force = True if os.environ.get("EVC_MOE_GRAM_NORMS") == "1" else None     # unset: chosen by shape (use_gram_norms)
+
+    @staticmethod
+    def gram_slab_count(cols, want):
+        """Largest S <= want that evc_gram_slabs accepts for `cols` columns (a multiple of 32; no empty last slab), 0 if none."""
+        if cols <= 0 or cols % 32:
+            return 0
+        nk = cols // 32
+        for S in range(max(1, min(want, nk)), 0, -1):
+            if ((nk + S - 1) // S) * (S - 1) < nk:
+                return S
+        return 0
+
+    def use_gram_norms(self, rows, Vn, cols):
+        """Gram-matrix clip norm or pass 1 over the weights, by shape (round 5).  Pass 1 streams Vn x K f32 weights and recomputes the
+        rank-`rows` gradient tile; the Gram route costs ~3.5 small launches per matrix plus 2 rows^2 (cols + K/2) flops on a
+        fragments-from-global kernel - it grows with rows^2, pass 1 with K.  Constants fitted to both measured points
+        (profiles/r04_bench_kernel_stats_default.csv: rows 256, K 4096 - Gram 0.16 vs pass 1 0.36 ms per tower;
+        profiles/r04_bench_dbof_kernel_stats.csv: rows 512, K 1024 - Gram 0.16 vs pass 1 0.06 ms).  EVC_MOE_GRAM_NORMS=0 / 1 forces."""
+        if not self.gram_norms or self.gram_a is None:
+            return False
+        K = self.K
+        if rows % 32 or rows > 1024 or self.gram_slab_count(K, self.gram_S["x"]) == 0 or self.gram_slab_count(cols, self.gram_S["a"]) == 0:
+            return False                     # evc_gram_slabs would refuse the shape: the two-pass form takes anything the fused update takes
+        if self.gram_force is not None:
+            return self.gram_force
+        pass1 = Vn * K * 4.0 / 4.0e12 + 2.0 * rows * Vn * K / 5.0e14
+        gram = 42e-6 + 2.0 * rows * rows * (cols + 0.5 * K) / 1.2e14
+        return gram < pass1
 
     def invalidate_norm_cache(self):
         """The carried |W|^2 no longer describes the weights (they were written by something other than the fused update)."""
@@ -635,6 +664,7 @@ class MoeHead:
         idx = {k: i for i, k in enumerate(tw.names)}
         st = tw.store
         refreshed_wide = False
+        self._gram_x_fresh = False          # X . X^T of this step's factor: computed by the first matrix that takes the Gram route
         for name, dlog, Vn in ((self.GATES, dgl, V * (Mx + 1)), (self.EXPERTS, del_, V * Mx)):
             l2 = l2_coeff if name in tw.l2_names else 0.0
             pw, mw, vw = st.p(name), st.view(st.m, name), st.view(st.v, name)
@@ -642,20 +672,22 @@ class MoeHead:
                 hi = tw.precision != "bf16"                 # the non-bf16 forward's operand images come out of the same epilogue
                 wide = getattr(tw, "shadow_w", {}).get(name) if hi else None             # "split": [hi | lo]
                 w16, w8 = (getattr(tw, "shadow_w16", {}).get(name), getattr(tw, "shadow_w8", {}).get(name)) if hi else (None, None)   # "high": f16 + e4m3
-                if self.gram_norms and self.gram_a is not None:
+                if self.use_gram_norms(rows, Vn, dlog.shape[1]):
                     # clip norm from the Gram matrices of the factors + the forward logits + the carried |W|^2: no pass over W
                     # (csrc/evc_moe_norms.hip), then the update pass alone
                     i = 0 if name == self.GATES else 1
+                    Sx = self.gram_slab_count(K, self.gram_S["x"])
                     if not self._wsq_valid[i]:
                         self.wsq[i].zero_()
                         ops.grad_sqnorm(pw, None, 0.0, self.wsq[i])
                         self._wsq_valid[i] = True
-                    if i == 0:
-                        ops.gram_slabs(x, rows, K, self.gram_S["x"], self.gram_x)
-                    Sa = max(1, min(self.gram_S["a"], dlog.shape[1] // 32 // 8))
+                    if i == 0 or not self._gram_x_fresh:
+                        ops.gram_slabs(x, rows, K, Sx, self.gram_x)
+                        self._gram_x_fresh = True
+                    Sa = self.gram_slab_count(dlog.shape[1], max(1, min(self.gram_S["a"], dlog.shape[1] // 32 // 8)))
                     ops.gram_slabs(dlog, rows, dlog.shape[1], Sa, self.gram_a)
                     logits = self.gate_logits if i == 0 else self.expert_logits
-                    ops.moe_grad_norms(self.gram_a, Sa, self.gram_x, self.gram_S["x"], rows, dlog, logits,
+                    ops.moe_grad_norms(self.gram_a, Sa, self.gram_x, Sx, rows, dlog, logits,
                                        None if i == 0 else st.p(self.EBIAS), self.B, Vn, l2, self.wsq[i], self.norm_part, tw.sums[idx[name]])
                     ops.moe_grad_update_apply(dlog, x, rows, Vn, K, pw, mw, vw, tw.shadow_fwd[name], tw.shadow_bwd[name], l2,
                                               tw.sums[idx[name]], self.partial_ws, clip_norm, lr_t, self.wsq[i], beta1, beta2, eps,
@@ -663,7 +695,7 @@ class MoeHead:
                 else:
                     ops.moe_grad_update(dlog, x, rows, Vn, K, pw, mw, vw, tw.shadow_fwd[name], tw.shadow_bwd[name], l2,
                                         tw.sums[idx[name]], self.partial_ws, clip_norm, lr_t, beta1, beta2, eps, p_wide=wide, p_f16=w16, p_fp8=w8)
-                    self._wsq_valid = [False, False]
+                    self._wsq_valid[0 if name == self.GATES else 1] = False      # this matrix's carried |W|^2 is stale now
                 refreshed_wide = refreshed_wide or wide is not None or w16 is not None
                 continue
             self._wsq_valid = [False, False]
