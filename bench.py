@@ -13,12 +13,21 @@ the timed region starts.  Rank 0 prints ONE JSON line.
 
 The headline (`value`, `ms_per_step`, `roofline`) is BASELINE cfg 3 in plain bf16 (one MFMA product per
 contraction, as north_star prescribes).  At N=1 the same line also carries, each timed the same way on a short run:
-  precision_modes   the same step in the split-bf16 "high" forward mode (the mode that holds the 1e-3 logit
-                    tolerance on trained-magnitude weights, tests/test_gpu_step.py) next to the bf16 figure;
+  precision_modes   the same step in the "high" forward mode (IEEE f16 operands + low-order corrections on the MX-scaled MFMA,
+                    DESIGN.md 7: the mode that holds the 1e-3 logit tolerance on trained-magnitude weights,
+                    tests/test_gpu_step.py) next to the bf16 figure;
   other_configs     BASELINE cfg 2 (teacher only), cfg 5 (student only, every_n=30, B=1024), cfg 4 (DBoF + MoE,
                     B=512, with the roofline of its cluster GEMM) and the all-300-frames worst case;
   cpu_baseline      the PyTorch-CPU float32 restatement of the reference graph (oracle/torch_cpu.py) on the host cores.
 `--config dbof` makes cfg 4 the timed workload of the line instead (its own metric string).
+
+Every timed figure carries `ms_per_step` (mean over the K timed steps: wall clock between the two barriers, what the
+driver's own clock checks), `ms_per_step_median` / `ms_per_step_max` (HIP events on the caller's stream after every step) and
+`stall_suspected` (max > 3 x median: one queue stall inside the window moved the mean - read the median).
+
+`--gpus N` means N: under a launcher (WORLD_SIZE set) it must equal the world; without one and N > 1 this process - which
+never touches the GPU - starts N rank supervisors itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, each supervising its
+benchmark child exactly as under a launcher).
 """
 import argparse
 import json
@@ -36,6 +45,37 @@ import torch  # noqa: E402
 DTYPE_OF = {"bf16": "bf16", "high": "f16", "split": "bf16"}     # MFMA operand type of the forward products (accumulation f32; backward products bf16 in every mode)
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 T_FRAMES, F_FEAT, V_CLS, H_CELLS = 300, 1152, 4716, 1024
+
+
+def step_stats(per_step_ms):
+    """Robust companions of the mean: median and maximum of the per-step times and a flag for a window that contains a stall
+    (one step > 3 x the median: e.g. the ~30-65 ms the driver's unmapping work can hold the queue right after tens of GB were
+    freed - such a step moves the mean of a 20-step window of 2 ms steps by 2x and says nothing about the kernels)."""
+    a = sorted(float(v) for v in per_step_ms)
+    if not a:
+        return {"ms_per_step_median": None, "ms_per_step_max": None, "stall_suspected": False}
+    n = len(a)
+    med = a[n // 2] if n % 2 else 0.5 * (a[n // 2 - 1] + a[n // 2])
+    return {"ms_per_step_median": round(med, 4), "ms_per_step_max": round(a[-1], 4), "stall_suspected": bool(a[-1] > 3.0 * med)}
+
+
+STAT_KEYS = ("ms_per_step_median", "ms_per_step_max", "stall_suspected")
+
+
+class StepClock:
+    """HIP events on the caller's stream: one before the first timed step, one after every step (graph.step() joins the graph's
+    streams back into the caller's before it returns).  Recording costs ~2 us of host time per step and no GPU work."""
+
+    def __init__(self):
+        self.ev = []
+
+    def tick(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.ev.append(e)
+
+    def per_step_ms(self):              # after a synchronize
+        return [a.elapsed_time(b) for a, b in zip(self.ev[:-1], self.ev[1:])]
 
 
 def synthetic_inputs(B, T, F, V, seed, device, all_full):
@@ -135,30 +175,26 @@ def run_hlstm(device, rank, world, B, mode, every_n, steps, warmup, all_full=Fal
         l1_stack.timing = []      # HIP events around the L1 forward launch sequences of the timed steps (launch stream)
         l1_stack.timing_bwd = {"bwd_step": [], "dx_nt": [], "wgrad_tn": []}      # ... and around the backward ones
     gf = [hlstm_gflop(n_host[(it + i) % pool], mode, every_n, B) for i in range(steps)]
-    step_events = [] if os.environ.get("EVC_BENCH_STEP_EVENTS") == "1" else None      # debug: when did each step finish?
-    if step_events is not None:
-        step_events.append(torch.cuda.Event(enable_timing=True))
-        step_events[-1].record()
+    clock = StepClock()
+    clock.tick()
     t0 = time.perf_counter()
     for _ in range(steps):
         x, n, labels = pool_in[it % pool]
         graph.step(x, labels, n, num_frames_host=n_host[it % pool])
         it += 1
-        if step_events is not None:
-            step_events.append(torch.cuda.Event(enable_timing=True))
-            step_events[-1].record()
+        clock.tick()
     graph.flush()              # defer_updates: the last step's MoE / L2-level updates are enqueued and joined INSIDE the timed region
     barrier()
     dt = time.perf_counter() - t0
-    if step_events is not None:
-        sys.stderr.write("[bench] per-step ms (events on the caller's stream): %s\n" % " ".join(
-            "%.1f" % a.elapsed_time(b) for a, b in zip(step_events[:-1], step_events[1:])))
+    per_step = clock.per_step_ms()
+    if os.environ.get("EVC_BENCH_STEP_EVENTS") == "1":
+        sys.stderr.write("[bench] per-step ms (events on the caller's stream): %s\n" % " ".join("%.1f" % v for v in per_step))
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     res = {"ms_per_step": dt / steps * 1e3, "frames_per_sec": world * B * T_FRAMES * steps / dt, "steps": steps,
-           "warmup": warmup, "batch_per_gpu": B,
+           "warmup": warmup, "batch_per_gpu": B, **step_stats(per_step),
            "nominal_tflop_per_step": round(float(np.mean([g[0] for g in gf])) / 1e3, 3),
            "executed_tflop_per_step": round(float(np.mean([g[1] for g in gf])) / 1e3, 3),
            "losses": {k: round(v, 4) for k, v in graph.loss_report().items()},
@@ -185,6 +221,9 @@ def run_hlstm(device, rank, world, B, mode, every_n, steps, warmup, all_full=Fal
         res["dp"] = {"placement": ("EVC_DP_SERIAL_COMM=1: one communicator, every collective funnelled through one stream, backward phases issued in %s order"
                                    % graph.issue_order) if serial_comm() else "stream order, teacher and student towers on two communicators",
                      "attempt": int(os.environ.get("EVC_BENCH_ATTEMPT", "0")), "grad_dtype": graph.reducer.grad_dtype, "world": world,
+                     "process_group": {"backend": torch.distributed.get_backend(), "ranks": torch.distributed.get_world_size(),
+                                       "what": "nccl = RCCL (one rank per GPU); gloo only under the EVC_BENCH_SHARED_GPU test hook",
+                                       "launched_by": "bench.py --gpus N itself" if os.environ.get("EVC_BENCH_SELF_LAUNCHED") == "1" else "launcher"},
                      "collectives": per_kind,
                      "wire_mb_per_rank_per_step": round(sum(v["wire_mb_per_rank_per_step"] for v in per_kind.values()), 2),
                      "collective_event_ms_per_step": round(sum(v["event_ms_per_step"] for v in per_kind.values()), 3),
@@ -297,6 +336,12 @@ def run_dbof(device, rank, world, B, steps, warmup, pool=4, precision="bf16"):
     if precision != "bf16":
         tw.set_precision(precision)
     graph = SingleTowerGraph(tw)
+    # settle (as run_hlstm; before the warm-up, never inside the timed region): one pass over the pool, so that no timed step is the
+    # first use of a kernel instantiation (40-80 ms once: code-object load + hipFuncSetAttribute) or of an allocator block
+    for i in range(pool):
+        x, n, labels, u = pool_in[i]
+        graph.step(x, labels, n, uniform=u)
+    torch.cuda.synchronize()
     for i in range(warmup):
         x, n, labels, u = pool_in[i % pool]
         graph.step(x, labels, n, uniform=u)
@@ -305,14 +350,18 @@ def run_dbof(device, rank, world, B, steps, warmup, pool=4, precision="bf16"):
     torch.cuda.synchronize()
     if hasattr(tw, "timing"):
         tw.timing = []
+    clock = StepClock()
+    clock.tick()
     t0 = time.perf_counter()
     for i in range(steps):
         x, n, labels, u = pool_in[(warmup + i) % pool]
         graph.step(x, labels, n, uniform=u)
+        clock.tick()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    per_step = clock.per_step_ms()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -320,6 +369,7 @@ def run_dbof(device, rank, world, B, steps, warmup, pool=4, precision="bf16"):
     gflop_fwd = (2.0 * B * 30 * F_FEAT * 8192 + 2.0 * B * 8192 * 1024 + 2.0 * B * 1024 * V_CLS * 5) / 1e9
     res = {"ms_per_step": dt / steps * 1e3, "videos_per_sec": world * B * steps / dt,
            "frames_per_sec": world * B * T_FRAMES * steps / dt, "steps": steps, "warmup": warmup, "batch_per_gpu": B,
+           **step_stats(per_step),
            "nominal_tflop_per_step": round(3 * gflop_fwd / 1e3, 4), "loss": round(float(graph.losses[0]), 4)}
     res["nominal_tflops"] = round(res["nominal_tflop_per_step"] / (res["ms_per_step"] * 1e-3), 1)
     timing = getattr(tw, "timing", None)
@@ -333,6 +383,41 @@ def run_dbof(device, rank, world, B, steps, warmup, pool=4, precision="bf16"):
     del graph, tw, pool_in
     torch.cuda.empty_cache()
     return res
+
+
+def retime_on_stall(run):
+    """Secondary configurations only (the headline times exactly the K steps it was asked for): a window with a stall in it is
+    measured once more and the first attempt's figures stay in the line next to the second's."""
+    r = run()
+    if r.get("stall_suspected"):
+        first = {k: r[k] for k in ("ms_per_step",) + STAT_KEYS}
+        time.sleep(0.5)
+        r = run()
+        r["retimed_after_stall"] = first
+    return r
+
+
+def self_launch(n, argv, script=None):
+    """`python bench.py --gpus N` without a launcher (N > 1, WORLD_SIZE unset): this process - it has not touched the GPU and never
+    will - starts one rank supervisor per GPU as fresh children (never an exec) with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; each
+    of them supervises its benchmark child exactly as under torch.distributed.run (supervise_ranks).  Returns the worst exit code."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket() as sk:                      # a free port: +16..+18 (fallback rendezvous) and +40..+42 (agreement stores) follow it
+            sk.bind(("127.0.0.1", 0))
+            port = str(min(sk.getsockname()[1], 65000))
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port, EVC_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env))
+    worst = 0
+    for pr in procs:
+        rc = pr.wait()
+        worst = worst if rc == 0 else (rc if worst == 0 else worst)
+    return worst
 
 
 def host_cores():
@@ -501,9 +586,18 @@ def main():
     if args.cpu_baseline_only:
         print(json.dumps({"cpu_baseline": cpu_baseline(args.every_n, args.cpu_videos, args.cpu_budget, args.cpu_threads)}))
         return
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))     # (this process never touches the GPU)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks: the line's n_gpus would not be what was asked "
+                         "for; start it with --nproc-per-node %d (or without a launcher: bench.py starts the ranks itself)\n"
+                         % (args.gpus, world, args.gpus))
+        sys.exit(2)
     if world > 1 and os.environ.get("EVC_BENCH_CHILD") != "1" and os.environ.get("EVC_BENCH_NO_SUPERVISOR") != "1":
         sys.exit(supervise_ranks(sys.argv[1:]))            # (this process never touches the GPU)
     # test hook (tests/test_gpu_dp.py): several ranks on ONE GPU over gloo, to exercise this file's multi-rank
@@ -535,8 +629,8 @@ def main():
         if rank == 0:
             res = {"metric": "frames/sec (whole node) DBoF(8192,1024)+MoE(2) training step B=512x300x1152 (BASELINE cfg 4)",
                    "value": r["frames_per_sec"], "unit": "frames/sec", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-                   "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                   "dtype": "bf16", "data": "synthetic",
+                   "ms_per_step": r["ms_per_step"], **{k: r[k] for k in STAT_KEYS}, "higher_is_better": True, "scaling": "weak",
+                   "vs_baseline": None, "dtype": DTYPE_OF[args.precision], "precision_mode": args.precision, "data": "synthetic",
                    "config": {"workload": "DbofModel cluster 8192, hidden 1024, 30 sampled frames, MoE(2), batch %d x 300 x 1152 per GPU" % B,
                               "global_batch": B * n_gpus, "frames_per_video": T_FRAMES, "parallelism": "dp%d" % n_gpus},
                    "videos_per_sec": r["videos_per_sec"], "nominal_tflop_per_step": r["nominal_tflop_per_step"], "loss": r["loss"]}
@@ -555,12 +649,12 @@ def main():
     extra = {}
     if secondary:
         s_steps, s_warm = 5, 2
-        keep = ("ms_per_step", "frames_per_sec", "steps", "warmup", "batch_per_gpu", "nominal_tflop_per_step",
-                "executed_tflop_per_step", "executed_tflops")
-        pm = {args.precision: {k: head[k] for k in keep}}
+        keep = ("ms_per_step",) + STAT_KEYS + ("frames_per_sec", "steps", "warmup", "batch_per_gpu", "nominal_tflop_per_step",
+                                                 "executed_tflop_per_step", "executed_tflops", "retimed_after_stall")
+        pm = {args.precision: {k: head[k] for k in keep if k in head}}
         other = "high" if args.precision == "bf16" else "bf16"
-        r = run_hlstm(device, rank, world, B, args.mode, args.every_n, 10, 3, args.all_full, other, 4, roofline=True)
-        pm[other] = {k: r[k] for k in keep}
+        r = retime_on_stall(lambda: run_hlstm(device, rank, world, B, args.mode, args.every_n, 10, 3, args.all_full, other, 4, roofline=True))
+        pm[other] = {k: r[k] for k in keep if k in r}
         if "roofline" in r:
             pm[other]["roofline"] = r["roofline"]
         _log("precision mode %s done: %.2f ms/step" % (other, r["ms_per_step"]))
@@ -578,19 +672,20 @@ def main():
         for name, kw in (("cfg2_teacher_only_b256", dict(B=256, mode="teacher", every_n=10)),
                          ("cfg5_student_only_every_n30_b1024", dict(B=1024, mode="student", every_n=30)),
                          ("cfg3_all_300_frames_b256", dict(B=256, mode="teacher_student", every_n=10, all_full=True))):
-            r = run_hlstm(device, rank, world, kw["B"], kw["mode"], kw["every_n"], s_steps, s_warm, kw.get("all_full", False), "bf16", 4)
-            oc[name] = {k: r[k] for k in keep}
+            r = retime_on_stall(lambda: run_hlstm(device, rank, world, kw["B"], kw["mode"], kw["every_n"], s_steps, s_warm,
+                                                  kw.get("all_full", False), "bf16", 4))
+            oc[name] = {k: r[k] for k in keep if k in r}
             _log("%s done: %.2f ms/step" % (name, r["ms_per_step"]))
         # (a 2 ms step: 20 steps and a pause first - right after the tens of GB of the previous configuration are freed the
         #  driver's unmapping work can stall the queue for ~65 ms once, which a 5-step window reported as 15 ms per step)
         time.sleep(0.5)
-        r = run_dbof(device, rank, world, 512, 20, 6)
+        r = retime_on_stall(lambda: run_dbof(device, rank, world, 512, 20, 6))
         oc["cfg4_dbof_8192_1024_moe2_b512"] = r
         _log("dbof done: %.2f ms/step" % r["ms_per_step"])
         time.sleep(1.0)
-        rh = run_dbof(device, rank, world, 512, 20, 10, precision="high")          # the mode that holds 1e-3 on its predictions (bf16: 2.3e-3)
-        oc["cfg4_dbof_8192_1024_moe2_b512"]["high"] = {k: rh[k] for k in ("ms_per_step", "videos_per_sec", "frames_per_sec", "steps", "warmup", "loss")
-                                                      if k in rh}
+        rh = retime_on_stall(lambda: run_dbof(device, rank, world, 512, 20, 10, precision="high"))   # the mode that holds 1e-3 on its predictions (bf16: 2.3e-3)
+        oc["cfg4_dbof_8192_1024_moe2_b512"]["high"] = {k: rh[k] for k in ("ms_per_step",) + STAT_KEYS + ("videos_per_sec", "frames_per_sec", "steps", "warmup",
+                                                                                                      "loss", "retimed_after_stall") if k in rh}
         oc["cfg4_dbof_8192_1024_moe2_b512"]["high"]["what"] = ("IEEE f16 operands with both operands' low-order corrections as OCP e4m3 stages behind them in the same launch "
                                                                "(cluster, hidden and MoE products; EVC_HIGH_FP8_LO=0: three split-bf16 products per contraction): "
                                                                   "predictions 5.6e-6 from the float64 oracle at these dims (tests/test_gpu_dbof_logistic.py)")
@@ -601,8 +696,8 @@ def main():
         res = {
             "metric": "frames/sec (whole node) H-LSTM teacher+student B=256x300x1152; GAP@20",
             "value": head["frames_per_sec"], "unit": "frames/sec", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": DTYPE_OF[args.precision], "data": "synthetic", "precision_mode": args.precision,
+            "ms_per_step": head["ms_per_step"], **{k: head[k] for k in STAT_KEYS}, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": DTYPE_OF[args.precision], "data": "synthetic", "precision_mode": args.precision,
             "config": {"workload": "HierarchicalLstmModel %s every_n=%d, lstm_cells=1024x2, MoE(2), batch %d x 300 x 1152 per GPU"
                                    % (args.mode, args.every_n, B),
                        "global_batch": B * n_gpus, "frames_per_video": T_FRAMES, "parallelism": "dp%d" % n_gpus,

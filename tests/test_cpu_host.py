@@ -393,6 +393,77 @@ def test_bench_rank_supervisors_agree_before_retrying(tmp_path):
     assert "ended with code 0 here, 5 over all ranks" in outs[0][1], outs[0][1]
 
 
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def test_bench_figures_flag_a_stall_in_the_timed_window():
+    """One 30 ms stall inside a 20-step window of 2 ms steps (round 4's driver read cfg 4 as 3.45 ms that way): the mean moves by
+    1.7x, the median does not, and the line says so; a clean window is not flagged; a flagged secondary configuration is timed once
+    more with the first attempt kept in the line."""
+    bench = _load_bench()
+    steps = [1.9] * 19 + [31.0]
+    st = bench.step_stats(steps)
+    assert st["stall_suspected"] is True and st["ms_per_step_max"] == 31.0 and abs(st["ms_per_step_median"] - 1.9) < 1e-9
+    assert sum(steps) / len(steps) > 1.7 * st["ms_per_step_median"]
+    clean = bench.step_stats([10.1, 10.3, 10.2, 10.6, 10.0])
+    assert clean == {"ms_per_step_median": 10.2, "ms_per_step_max": 10.6, "stall_suspected": False}
+    assert bench.step_stats([5.0, 5.0, 14.9])["stall_suspected"] is False and bench.step_stats([5.0, 5.0, 15.1])["stall_suspected"] is True
+    assert set(bench.STAT_KEYS) == set(st)
+    runs = []
+
+    def fake_run():
+        runs.append(1)
+        first = len(runs) == 1
+        return dict(ms_per_step=3.4 if first else 1.9, **bench.step_stats(steps if first else [1.9] * 20))
+
+    r = bench.retime_on_stall(fake_run)
+    assert len(runs) == 2 and r["ms_per_step"] == 1.9 and r["stall_suspected"] is False
+    assert r["retimed_after_stall"] == {"ms_per_step": 3.4, "ms_per_step_median": 1.9, "ms_per_step_max": 31.0, "stall_suspected": True}
+    runs.clear()
+    r = bench.retime_on_stall(lambda: (runs.append(1), dict(ms_per_step=1.9, **bench.step_stats([1.9] * 20)))[1])
+    assert len(runs) == 1 and "retimed_after_stall" not in r
+
+
+def test_bench_gpus_flag_means_n(tmp_path):
+    """`--gpus N` is the number of ranks in the line: under a launcher it must equal WORLD_SIZE (exit 2 with the reason otherwise);
+    without one, N > 1 makes bench.py start N rank processes itself - fresh children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+    set (stand-in children here; the real path runs in tests/test_gpu_dp.py)."""
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=300)
+    assert r.returncode == 2 and "--gpus 2" in r.stderr and "WORLD_SIZE=4" in r.stderr and r.stdout == ""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 2 and "--gpus 1" in r.stderr
+    bench = _load_bench()
+    child = tmp_path / "rank.py"
+    child.write_text("import os, sys\n"
+                     "print('rank %s/%s local %s at %s:%s self %s args %s' % (os.environ['RANK'], os.environ['WORLD_SIZE'], os.environ['LOCAL_RANK'],\n"
+                     "      os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'], os.environ['EVC_BENCH_SELF_LAUNCHED'], ' '.join(sys.argv[1:])), flush=True)\n"
+                     "sys.exit(7 if (sys.argv[-1] == 'fail' and os.environ['RANK'] == '2') else 0)\n")
+    driver = tmp_path / "driver.py"
+    driver.write_text("import importlib.util, os, sys\n"
+                      "os.environ.pop('WORLD_SIZE', None); os.environ.pop('MASTER_PORT', None)\n"
+                      "spec = importlib.util.spec_from_file_location('bench_mod', %r)\n"
+                      "bench = importlib.util.module_from_spec(spec)\n"
+                      "spec.loader.exec_module(bench)\n"
+                      "sys.exit(bench.self_launch(3, ['--gpus', '3', sys.argv[1]], script=%r))\n" % (os.path.join(ROOT, "bench.py"), str(child)))
+    for mode, rc in (("ok", 0), ("fail", 7)):
+        r = subprocess.run([sys.executable, str(driver), mode], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode == rc, (r.stdout, r.stderr)
+        lines = sorted(l for l in r.stdout.splitlines() if l.startswith("rank "))
+        assert len(lines) == 3
+        ports = {l.split(" at 127.0.0.1:")[1].split()[0] for l in lines}
+        assert len(ports) == 1 and 1024 < int(ports.pop()) <= 65000
+        for i, l in enumerate(lines):
+            assert l.startswith("rank %d/3 local %d at 127.0.0.1:" % (i, i)) and l.endswith("self 1 args --gpus 3 %s" % mode), l
+
+
 WORLD4_WORKER = r'''
 import os, sys
 sys.path.insert(0, %(root)r)
