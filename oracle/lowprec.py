@@ -15,7 +15,18 @@ What a kernel must reproduce is the OPERAND rounding - the accumulation is f32 e
 
 The reference computes these contractions in float32 (tf.matmul / BasicLSTMCell: cs/frame_level_models.py:221-257,
 cs/video_level_models.py:423-448): the corrected product is a cheaper way to the same number within ~2^-16 relative, not a
-different algorithm."""
+different algorithm.
+
+Round 5 adds the OCP FP6 format e2m3 (the same MFMA opcode takes it at twice the e4m3 rate; scripts/probes/fp6_mfma_probe.hip):
+
+  e2m3_round(a)          sign, 2 exponent bits (bias 1), 3 mantissa bits, no infinity / NaN: +-{0, 0.125 .. 0.875 (subnormal), 1 .. 1.875,
+                         2 .. 3.75, 4 .. 7.5}; round to nearest even, saturating at +-7.5
+  e2m3_encode / decode   the 6-bit codes (pinned on the full 64-entry table in tests/test_oracle_lowprec.py)
+  pack_fp6 / unpack_fp6  32 codes -> 24 bytes, element i at bits 6i .. 6i+5 (little-endian): what one MFMA lane holds
+  row_scale_exp(m)       the per-row power of two s (an e8m0 exponent, 127 + s on the device) that puts a row maximum m into [4, 8):
+                         e2m3 has no range to spare, so every operand row carries its own scale (free on the MX-scaled MFMA: the
+                         scale operands are per lane = per row)
+  corrected_product6(..) f16(x) . f16(W)^T + the two low-order corrections on e2m3 operands with per-row scales"""
 import numpy as np
 
 
@@ -44,4 +55,77 @@ def corrected_product(x, w, x_hi_exp, x_lo_exp, w_lo_exp, w_hi_exp, correct_x=Tr
     z = z + (e4m3_round(x * 2.0 ** x_hi_exp) @ e4m3_round((w - w16) * 2.0 ** w_lo_exp).T) * 2.0 ** -(x_hi_exp + w_lo_exp)
     if correct_x:
         z = z + (e4m3_round((x - x16) * 2.0 ** x_lo_exp) @ e4m3_round(w * 2.0 ** w_hi_exp).T) * 2.0 ** -(x_lo_exp + w_hi_exp)
+    return z
+
+
+# ---- OCP FP6 e2m3 ------------------------------------------------------------------------------------------------------------
+E2M3_MAX = 7.5
+
+
+def e2m3_decode(codes):
+    """6-bit codes (s eeee mmm -> s ee mmm) -> float64."""
+    c = np.asarray(codes, np.int64)
+    s, e, m = (c >> 5) & 1, (c >> 3) & 3, c & 7
+    mag = np.where(e == 0, m * 0.125, (1.0 + m / 8.0) * 2.0 ** (e - 1.0))
+    return np.where(s == 1, -mag, mag)
+
+
+def e2m3_encode(a):
+    """Round to nearest even on the e2m3 grid, saturating at +-7.5; -0 encodes as +0 (magnitude code 0 keeps the sign bit clear)."""
+    a = np.asarray(a, np.float64)
+    mag = np.minimum(np.abs(a), E2M3_MAX)
+    # uniform grids per range: step 1/8 below 2, 1/4 in [2, 4), 1/2 in [4, 7.5]; np.rint rounds half to even, and the first code of a
+    # range is even, so ties at a range boundary go the right way
+    code = np.where(mag < 2.0, np.rint(mag * 8.0), np.where(mag < 4.0, 8.0 + np.rint(mag * 4.0), 16.0 + np.rint(mag * 2.0)))
+    code = np.minimum(code, 31.0).astype(np.int64)
+    return np.where((a < 0) & (code > 0), code | 32, code)
+
+
+def e2m3_round(a):
+    return e2m3_decode(e2m3_encode(a))
+
+
+def pack_fp6(codes):
+    """codes [..., 32 n] (6-bit ints) -> uint8 [..., 24 n]: element i of each 32-block at bits 6i .. 6i+5 of the block's 192 bits."""
+    c = np.asarray(codes, np.uint64)
+    assert c.shape[-1] % 32 == 0
+    blk = c.reshape(c.shape[:-1] + (c.shape[-1] // 4, 4))                 # 4 codes = 24 bits = 3 bytes
+    w = blk[..., 0] | (blk[..., 1] << np.uint64(6)) | (blk[..., 2] << np.uint64(12)) | (blk[..., 3] << np.uint64(18))
+    out = np.stack([(w >> np.uint64(8 * i)) & np.uint64(255) for i in range(3)], -1).astype(np.uint8)
+    return out.reshape(c.shape[:-1] + (c.shape[-1] // 4 * 3,))
+
+
+def unpack_fp6(b):
+    b = np.asarray(b, np.uint64)
+    assert b.shape[-1] % 3 == 0
+    t = b.reshape(b.shape[:-1] + (b.shape[-1] // 3, 3))
+    w = t[..., 0] | (t[..., 1] << np.uint64(8)) | (t[..., 2] << np.uint64(16))
+    out = np.stack([(w >> np.uint64(6 * i)) & np.uint64(63) for i in range(4)], -1).astype(np.int64)
+    return out.reshape(b.shape[:-1] + (b.shape[-1] // 3 * 4,))
+
+
+def row_scale_exp(absmax):
+    """Per-row scale exponent s: absmax * 2^s in [4, 8) (values above 7.5 saturate: at most half a step of that range); rows of zeros
+    get s = 0.  Integer array."""
+    m = np.asarray(absmax, np.float64)
+    return np.where(m > 0, 2 - np.floor(np.log2(np.where(m > 0, m, 1.0))), 0).astype(np.int64)
+
+
+def e2m3_rows(a, exp=None):
+    """The e2m3 image of a [R][K] under one power-of-two scale per row, back in a's units; exp: given per-row exponents (e.g. derived
+    from a bound instead of the row's own maximum) or None = row_scale_exp(max |a| of the row)."""
+    a = np.asarray(a, np.float64)
+    if exp is None:
+        exp = row_scale_exp(np.max(np.abs(a), axis=-1))
+    sc = 2.0 ** np.asarray(exp, np.float64)[..., None]
+    return e2m3_round(a * sc) / sc
+
+
+def corrected_product6(x, w, correct_x=True):
+    """x [M][K], w [N][K]: the f16 product plus the low-order corrections on e2m3 operands, every operand row under its own scale."""
+    x, w = np.asarray(x, np.float64), np.asarray(w, np.float64)
+    x16, w16 = f16_round(x), f16_round(w)
+    z = x16 @ w16.T + e2m3_rows(x) @ e2m3_rows(w - w16).T
+    if correct_x:
+        z = z + e2m3_rows(x - x16) @ e2m3_rows(w).T
     return z

@@ -38,10 +38,47 @@ def fp8_scale(a):
     return 2.0 ** np.floor(np.log2(448.0 / m)) if m > 0 else 1.0
 
 
+def e2m3(v):
+    """OCP FP6 e2m3 (round to nearest even, saturating at 7.5) of v, elementwise (oracle/lowprec.py::e2m3_round in torch)."""
+    mag = v.abs().clamp(max=7.5)
+    q = torch.where(mag < 2.0, torch.round(mag * 8.0) / 8.0, torch.where(mag < 4.0, torch.round(mag * 4.0) / 4.0, torch.round(mag * 2.0) / 2.0))
+    return torch.sign(v) * q
+
+
+def fp6_rows(a, dim):
+    """e2m3 image of a with one power-of-two scale per slice along `dim` (the slice maximum lands in [4, 8)), back in a's units:
+    per weight row / per frame - the per-lane scale operands of v_mfma_scale_f32_16x16x128_f8f6f4."""
+    m = a.abs().amax(dim=dim, keepdim=True)
+    sc = 2.0 ** torch.where(m > 0, 2.0 - torch.floor(torch.log2(torch.where(m > 0, m, torch.ones_like(m)))), torch.zeros_like(m))
+    return e2m3(a * sc) / sc
+
+
+H6_SCALE = float(os.environ.get("EVC_BUDGET_H6_SCALE", "8"))     # fixed scale of the e2m3 image of h (|h| <= 1; 8: |h| > 0.94 saturates)
+
+
+def e3m2(v):
+    """OCP FP6 e3m2 ("bf6": 3 exponent bits, bias 3, 2 mantissa bits; subnormal step 2^-4, max 28), round to nearest even, saturating."""
+    mag = v.abs().clamp(max=28.0)
+    e = torch.floor(torch.log2(torch.where(mag > 0, mag, torch.ones_like(mag)))).clamp(min=-2.0, max=4.0)
+    step = 2.0 ** (e - 2.0)
+    return torch.sign(v) * torch.round(mag / step) * step
+
+
+H6_FORMAT = os.environ.get("EVC_BUDGET_H6_FORMAT", "e3m2")       # format of the e-image of h: its values crowd near 0 with a tail to +-1, which
+# wants exponent range, not mantissa (e2m3 under ONE fixed scale leaves 15 % relative error at |h| ~ 0.03: measured 1.5e-5 on the logits
+# per corrected term instead of 1e-6)
+
+
+def fp6_fixed(a, scale):
+    if H6_FORMAT == "e3m2":
+        return e3m2(a * 16.0) / 16.0
+    return e2m3(a * scale) / scale
+
+
 def rnd(a, kind):
     if kind == "x3":
         return a
-    if kind == "f16+8":      # weights only: the f16 image; the fp8 low-order half is contracted separately (stack_fwd)
+    if kind in ("f16+8", "f16+6"):      # weights only: the f16 image; the fp8 / fp6 low-order half is contracted separately (stack_fwd)
         kind = "f16"
     dt = {"bf16": torch.bfloat16, "f16": torch.float16}[kind]
     return a.to(torch.float32).to(dt).to(torch.float64)
@@ -72,7 +109,11 @@ def stack_fwd(x, lengths, layers, kinds):
         if wh == "f16+8":
             d = k[nin:] - rnd(k[nin:], "f16")
             lo[nin:] = fp8(d, fp8_scale(d))
-        wlo8.append(lo if (wx == "f16+8" or wh == "f16+8") else None)
+        if wx == "f16+6":               # e2m3, one scale per weight row (= per output column of the TF kernel) and segment
+            lo[:nin] = fp6_rows(k[:nin] - rnd(k[:nin], "f16"), 0)
+        if wh == "f16+6":
+            lo[nin:] = fp6_rows(k[nin:] - rnd(k[nin:], "f16"), 0)
+        wlo8.append(lo if (wx in ("f16+8", "f16+6") or wh in ("f16+8", "f16+6")) else None)
     for t in range(T):
         active = (lengths > t).unsqueeze(1)
         if not bool(active.any()):
@@ -82,8 +123,17 @@ def stack_fwd(x, lengths, layers, kinds):
             ax, ah, _, _ = _parts(kinds[l])
             a = torch.cat([rnd(inp, ax), rnd(h[l], ah)], 1)
             z = a @ wq[l] + bias
-            if wlo8[l] is not None:      # the low-order term on fp8 images of the activations (x 2^7: |h| <= 1, |x| <= 1)
+            _, _, wxk, whk = _parts(kinds[l])
+            if wlo8[l] is not None and "f16+6" in (wxk, whk):      # e2m3 images of the activations: the input frames under one scale per
+                # frame (layer 0; layer 1's input is the h of the layer below), h under a fixed scale
+                a6 = torch.cat([fp6_rows(inp, 1) if l == 0 else fp6_fixed(inp, H6_SCALE), fp6_fixed(h[l], H6_SCALE)], 1)
+                z = z + a6 @ wlo8[l]
+            elif wlo8[l] is not None:      # the low-order term on fp8 images of the activations (x 2^7: |h| <= 1, |x| <= 1)
                 z = z + fp8(torch.cat([inp, h[l]], 1), 128.0) @ wlo8[l]
+            if ax == "f16+6":            # the INPUT's low-order half in e2m3 against an e2m3 image of the weights, both under per-row scales
+                d = inp - rnd(inp, "f16")
+                nin = inp.shape[1]
+                z = z + fp6_rows(d, 1) @ fp6_rows(layers[l][0][:nin], 0)
             if ax == "f16+8":            # the INPUT's low-order half in fp8 against an fp8 image of the weights: e4m3((x - f16(x)) 2^18) . e4m3(Wx 2^6)
                 d = inp - rnd(inp, "f16")
                 nin = inp.shape[1]
@@ -278,6 +328,16 @@ def main():
             ("X16+8 only the L1c0 input f16 + fp8 x fp8 low-order term", dict(exact, L1c0=dict(ex, ax="f16+8"))),
             ("FZ8X FZ8 with the input's low-order half in fp8 too", dict(exact, L1c0=dict(ax="f16+8", ah="f16", wx="f16+8", wh="f16+8"),
                                                                          L1c1=dict(ax="f16", ah="f16", wx="f16+8", wh="f16+8"), **l2_f16x)),
+            ("DBG6 c0 wx", dict(exact, L1c0=dict(ex, wx="f16+6"))), ("DBG6 c0 wh", dict(exact, L1c0=dict(ex, wh="f16+6"))), ("DBG6 c1 wx", dict(exact, L1c1=dict(ex, wx="f16+6"))), ("DBG6 c1 wh", dict(exact, L1c1=dict(ex, wh="f16+6"))),
+            ("DBG8 c0 wx", dict(exact, L1c0=dict(ex, wx="f16+8"))), ("DBG8 c1 wh", dict(exact, L1c1=dict(ex, wh="f16+8"))),
+            ("W16+6 only the L1 weights f16 + e2m3 low-order halves (per-row scales)", dict(exact, L1c0=dict(ex, wx="f16+6", wh="f16+6"), L1c1=dict(ex, wx="f16+6", wh="f16+6"))),
+            ("X16+6 only the L1c0 input f16 + e2m3 x e2m3 low-order term", dict(exact, L1c0=dict(ex, ax="f16+6"))),
+            ("FZ6X FZ8X with the L1 level's corrections in e2m3", dict(exact, L1c0=dict(ax="f16+6", ah="f16", wx="f16+6", wh="f16+6"),
+                                                                       L1c1=dict(ax="f16", ah="f16", wx="f16+6", wh="f16+6"), **l2_f16x)),
+            ("FZ6A FZ6X + L2 weights' low-order halves in e2m3", dict(exact, L1c0=dict(ax="f16+6", ah="f16", wx="f16+6", wh="f16+6"),
+                                                                      L1c1=dict(ax="f16", ah="f16", wx="f16+6", wh="f16+6"),
+                                                                      L2c0=dict(ax="x3", ah="f16", wx="x3", wh="f16+6"),
+                                                                      L2c1=dict(ax="f16", ah="f16", wx="f16+6", wh="f16+6"))),
             ("W16 only the L1 weights f16 (activations exact)", dict(exact, L1c0=dict(ex, wx="f16", wh="f16"), L1c1=dict(ex, wx="f16", wh="f16"))),
             ("W16+8 only the L1 weights f16 + fp8 low-order halves", dict(exact, L1c0=dict(ex, wx="f16+8", wh="f16+8"), L1c1=dict(ex, wx="f16+8", wh="f16+8"))),
             ("FX (shipped) F with L2 layer 0 input + weights extended", dict(exact, L1c0=c0_3h, L1c1="f16", **l2_f16x)),

@@ -393,6 +393,33 @@ def test_fused_moe_update_matches_materialised_gradient_path():
         assert torch.allclose(ta.sums, tb.sums, rtol=1e-4, atol=1e-12)
 
 
+def test_moe_clip_norm_route_is_chosen_by_shape():
+    """MoeHead.use_gram_norms (round 5): the Gram route at the headline's head (256 rows, K = 4096), pass 1 over the weights at cfg 4's
+    (512 rows, K = 1024: the Gram products grow with rows^2, pass 1 with K - round 4 paid +0.10 ms per cfg-4 step for taking the Gram route
+    everywhere), never a shape evc_gram_slabs would refuse, and the environment override."""
+    from efficientvideoclassification_youtube8m_amd.engine import MoeHead
+
+    class _Tw:
+        device = DEV
+    for B, K, want in ((256, 4096, True), (512, 1024, False), (256, 1024, False), (512, 4096, True)):
+        m = MoeHead(_Tw(), K, 4716, 2)
+        m.alloc(B, True)
+        got = [m.use_gram_norms(m.Br, Vn, cols) for Vn, cols in ((4716 * 3, m.dgl_full.shape[1]), (4716 * 2, m.del_full.shape[1]))]
+        assert got == [want, want], (B, K, got)
+    m = MoeHead(_Tw(), 4096, 4716, 2)
+    m.alloc(256, True)
+    assert m.use_gram_norms(256, 14148, 14176 - 16) is False             # 14160 columns: not a multiple of 32 -> the two-pass form
+    assert MoeHead.gram_slab_count(14176, 16) == 16 and MoeHead.gram_slab_count(32 * 10, 9) in range(1, 10) and MoeHead.gram_slab_count(40, 4) == 0
+    for cols, want_s in ((32 * 10, 9), (32 * 17, 16), (32 * 33, 16)):
+        S = MoeHead.gram_slab_count(cols, want_s)
+        nk = cols // 32
+        assert S >= 1 and ((nk + S - 1) // S) * (S - 1) < nk                # no empty last slab
+    m.gram_force = False
+    assert m.use_gram_norms(256, 14148, m.dgl_full.shape[1]) is False
+    m.gram_force = True
+    assert m.use_gram_norms(256, 14148, m.dgl_full.shape[1]) is True
+
+
 @pytest.mark.parametrize("dims", [(8, 64, 64, 100), (40, 128, 128, 236)])
 def test_gram_matrix_clip_norm_equals_the_pass_over_the_weights(dims):
     """evc_gram_slabs + evc_moe_grad_norms (|g + l2 W|^2 = <A A^T, X X^T> + 2 l2 <A, logits - bias> + l2^2 |W|^2, no pass over W)
@@ -407,6 +434,7 @@ def test_gram_matrix_clip_norm_equals_the_pass_over_the_weights(dims):
         g = DistillGraph(B, every_n=10, feature_size=F, vocab_size=V, lstm_cells=H, device=DEV, seed=4, regularization_penalty=2.0e4)
         for tw in (g.teacher, g.student):
             tw.moe.gram_norms = gram
+            tw.moe.gram_force = True if gram else None           # (by shape these small heads would take pass 1: MoeHead.use_gram_norms)
         sums, first = [], {}
         for it in range(3):
             g.step(xd, yd, nd, num_frames_host=n)
