@@ -130,6 +130,7 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
     uint32_t lda_b = (uint32_t)(s1 ? p.lda1 : p.lda2) * 2u;
     const char* b_base = (const char*)((s1 ? p.B : b2) + (long)ks_issue * 64);
     uint32_t ldb_b = (uint32_t)p.ldb * 2u;
+    uint32_t chunk_b = (uint32_t)(lc8 * 2);
     if constexpr (FP8) {               // stages behind the 16-bit ones: rows of 128 e4m3 bytes
       const int k8 = ks_issue - nkf;
       const bool f = k8 < 0, s3 = k8 < p.nk3;
@@ -138,19 +139,27 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
       lda_b = f ? lda_b : (uint32_t)(s3 ? p.lda3 : p.lda4);
       b_base = f ? b_base : (const char*)p.B8 + (long)k8 * 128;
       ldb_b = f ? ldb_b : (uint32_t)p.ldb8;
+#ifdef EVC_ABLATE_FP6   // TIMING ablation (wrong results): what an e2m3 tail could cost - the e-stages fetch DENSE stage-major rows of 96 bytes
+      // (lanes 6, 7 of a row repeat chunk 5: 96 of the 128 bytes per row come from memory) and the MFMAs run in the FP6 formats
+      ab = f ? ab : (s3 ? (const char*)p.A3 + (long)k8 * p.M * 96 : (const char*)p.A4 + (long)(k8 - p.nk3) * p.M * 96);
+      lda_b = f ? lda_b : 96u;
+      b_base = f ? b_base : (const char*)p.B8 + (long)k8 * (4 * p.group_stride) * 96;
+      ldb_b = f ? ldb_b : 96u;
+      chunk_b = f ? (uint32_t)(lc8 * 2) : (uint32_t)(min(lc8 / 8, 5) * 16);
+#endif
     }
     char* sbase = lds + slot_issue * Cfg::STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
       char* dst = a_dst[i] >= 0 ? sbase + a_dst[i] : lds + Cfg::DUMMY_OFF;
-      const uint32_t vo = __umul24((uint32_t)a_row[i], lda_b) + (uint32_t)(lc8 * 2);
+      const uint32_t vo = __umul24((uint32_t)a_row[i], lda_b) + chunk_b;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ab + vo),
                                        (__attribute__((address_space(3))) void*)dst, 16, 0, EVC_V3_AUX_A);
     }
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
       char* dst = b_dst[i] >= 0 ? sbase + b_dst[i] : lds + Cfg::DUMMY_OFF;
-      const uint32_t vo = FP8 ? __umul24(b_vo[i], ldb_b) + (uint32_t)(lc8 * 2) : b_vo[i];
+      const uint32_t vo = FP8 ? __umul24(b_vo[i], ldb_b) + chunk_b : b_vo[i];
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_base + vo),
                                        (__attribute__((address_space(3))) void*)dst, 16, 0, EVC_V3_AUX_B);
     }
@@ -370,9 +379,14 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
       const v4i_t lo = *(const v4i_t*)(sb + base0 + off), hi = *(const v4i_t*)(sb + base1 + off);
       return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     };
+#ifdef EVC_ABLATE_FP6
+    constexpr int FMT8 = 2;             // e2m3 (timing ablation)
+#else
+    constexpr int FMT8 = 0;             // e4m3
+#endif
     auto mfma8 = [&](const v8i_t& a, const v8i_t& b, f32x4& c) {
-      c = SWAP ? __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b, a, c, 0, 0, 0, sc_first, 0, sc_second)
-               : __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, sc_first, 0, sc_second);
+      c = SWAP ? __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b, a, c, FMT8, FMT8, 0, sc_first, 0, sc_second)
+               : __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, FMT8, FMT8, 0, sc_first, 0, sc_second);
     };
     auto rd_lower = [&]() {
 #pragma unroll
