@@ -124,6 +124,7 @@ static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 // fixed order.  Identical inputs then give identical bits run to run and box to box; what it costs is in DESIGN.md 7.
 #include <stdlib.h>
 static inline bool evc_deterministic() {
-  static const bool on = getenv("EVC_DETERMINISTIC") != nullptr && atoi(getenv("EVC_DETERMINISTIC")) != 0;
+  // the same rule as ops.DETERMINISTIC in Python: set, not empty and not "0" (so "true" / "yes" switch BOTH sides on, never one of them)
+  static const bool on = [] { const char* e = getenv("EVC_DETERMINISTIC"); return e != nullptr && e[0] != '\0' && !(e[0] == '0' && e[1] == '\0'); }();
   return on;
 }

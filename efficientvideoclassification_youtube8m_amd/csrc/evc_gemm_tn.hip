@@ -172,7 +172,7 @@ extern "C" int evc_gemm_tn_slabs(const evc_bf16* A, int64_t lda, const evc_bf16*
 // ===========================================================================
 struct MoeUpdateParams {
   float* p; float* m; float* v;        // [V][K] f32, row stride K
-  bf16_t* p_bf16;                      // forward shadow [V][K]
+  bf16_t* p_bf16;                      // forward shadow [V][K], or NULL (round 5: a "high" tower's forward reads the f16 + e4m3 images, not this one)
   bf16_t* pT_bf16; long ldT;           // transposed shadow [K][ldT], ldT >= V
   bf16_t* p_wide;                      // or NULL: wide split-bf16 image [V][2K] = [hi | lo] of the new weights (the "split" forward's operand)
   bf16_t* p_f16; uint8_t* p_fp8;       // or NULL: IEEE f16 image [V][K] and e4m3 image [V][2K] = [e4m3((w - f16(w)) lo_scale) | e4m3(w hi_scale)] of the
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(Cfg::NT) void moe_update_kernel(GemmOperandsT p, Mo
         *(float4*)(u.p + o) = make_float4(pn[0], pn[1], pn[2], pn[3]);
         *(float4*)(u.m + o) = make_float4(mn[0], mn[1], mn[2], mn[3]);
         *(float4*)(u.v + o) = make_float4(vn[0], vn[1], vn[2], vn[3]);
-        *(uint2*)(u.p_bf16 + o) = make_uint2((uint32_t)pb[0] | ((uint32_t)pb[1] << 16), (uint32_t)pb[2] | ((uint32_t)pb[3] << 16));
+        if (u.p_bf16) *(uint2*)(u.p_bf16 + o) = make_uint2((uint32_t)pb[0] | ((uint32_t)pb[1] << 16), (uint32_t)pb[2] | ((uint32_t)pb[3] << 16));
         if (u.p_f16) {                                // f16 + e4m3 images: saves the passes over the f32 weights (evc_cast_f32_to_f16 / _fp8_lo) per update
           const uint32_t h01 = pack_f16x2_hw(pn[0], pn[1]), h23 = pack_f16x2_hw(pn[2], pn[3]);
           *(uint2*)(u.p_f16 + o) = make_uint2(h01, h23);

@@ -567,6 +567,7 @@ class MoeHead:
     # (csrc/evc_moe_norms.hip; EVC_MOE_GRAM_NORMS=0: the two-pass form)
     gram_norms = os.environ.get("EVC_MOE_GRAM_NORMS", "1") != "0"
     gram_force = True if os.environ.get("EVC_MOE_GRAM_NORMS") == "1" else None     # unset: chosen by shape (use_gram_norms)
+    skip_stale_fwd_shadow = os.environ.get("EVC_HIGH_KEEP_BF16_SHADOW", "0") != "1"
 
     @staticmethod
     def gram_slab_count(cols, want):
@@ -672,6 +673,9 @@ class MoeHead:
                 hi = tw.precision != "bf16"                 # the non-bf16 forward's operand images come out of the same epilogue
                 wide = getattr(tw, "shadow_w", {}).get(name) if hi else None             # "split": [hi | lo]
                 w16, w8 = (getattr(tw, "shadow_w16", {}).get(name), getattr(tw, "shadow_w8", {}).get(name)) if hi else (None, None)   # "high": f16 + e4m3
+                # the bf16 forward shadow is not an operand of a "high" head (forward: f16 + e4m3 images; backward: the transposed shadow):
+                # 2 of the update's 34 bytes per parameter not written; set_precision("bf16") / refresh_shadows() rebuild it from the masters
+                pfwd = None if (w16 is not None and self.skip_stale_fwd_shadow) else tw.shadow_fwd[name]
                 if self.use_gram_norms(rows, Vn, dlog.shape[1]):
                     # clip norm from the Gram matrices of the factors + the forward logits + the carried |W|^2: no pass over W
                     # (csrc/evc_moe_norms.hip), then the update pass alone
@@ -689,11 +693,11 @@ class MoeHead:
                     logits = self.gate_logits if i == 0 else self.expert_logits
                     ops.moe_grad_norms(self.gram_a, Sa, self.gram_x, Sx, rows, dlog, logits,
                                        None if i == 0 else st.p(self.EBIAS), self.B, Vn, l2, self.wsq[i], self.norm_part, tw.sums[idx[name]])
-                    ops.moe_grad_update_apply(dlog, x, rows, Vn, K, pw, mw, vw, tw.shadow_fwd[name], tw.shadow_bwd[name], l2,
+                    ops.moe_grad_update_apply(dlog, x, rows, Vn, K, pw, mw, vw, pfwd, tw.shadow_bwd[name], l2,
                                               tw.sums[idx[name]], self.partial_ws, clip_norm, lr_t, self.wsq[i], beta1, beta2, eps,
                                               p_wide=wide, p_f16=w16, p_fp8=w8)
                 else:
-                    ops.moe_grad_update(dlog, x, rows, Vn, K, pw, mw, vw, tw.shadow_fwd[name], tw.shadow_bwd[name], l2,
+                    ops.moe_grad_update(dlog, x, rows, Vn, K, pw, mw, vw, pfwd, tw.shadow_bwd[name], l2,
                                         tw.sums[idx[name]], self.partial_ws, clip_norm, lr_t, beta1, beta2, eps, p_wide=wide, p_f16=w16, p_fp8=w8)
                     self._wsq_valid[0 if name == self.GATES else 1] = False      # this matrix's carried |W|^2 is stale now
                 refreshed_wide = refreshed_wide or wide is not None or w16 is not None

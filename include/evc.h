@@ -275,7 +275,9 @@ int evc_lstm_layer_bwd(const evc_bf16* w_il, const int32_t* len, int T, int M, i
  * pT_bf16 [K][ldT] (30 bytes of HBM traffic per parameter instead of 46 with a materialised gradient).
  *   dlogits [rows][ld_dlogits] bf16 (columns >= V zero), x [rows][ldx] bf16, rows % 32 == 0 (zero rows pad);
  *   under data parallelism rows = world x batch: the all-gathered factors replace the gradient all-reduce.
- *   partial_ws: 2 * ceil(V/128) * ceil(K/128) floats of scratch.  V % 4 == 0, K % 8 == 0. */
+ *   partial_ws: 2 * ceil(V/128) * ceil(K/128) floats of scratch.  V % 4 == 0, K % 8 == 0.
+ *   p_bf16 may be NULL (here and in the _wide / _phase / _apply forms): the forward shadow is then not written - a caller whose forward
+ *   reads other operand images of W (the f16 + e4m3 images of _wide) saves 2 of the 34 bytes per parameter. */
 int evc_moe_grad_update(const evc_bf16* dlogits, int64_t ld_dlogits, const evc_bf16* x, int64_t ldx, int rows,
                         int V, int K, float* p, float* m, float* v, evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT,
                         float l2_coeff, float* sums, float* partial_ws, float clip_norm, float lr_t,

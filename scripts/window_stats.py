@@ -11,7 +11,11 @@ for r in csv.DictReader(open(sys.argv[1])):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
 nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
-starts = [s for s, e, n in rows if "l2norm_chunk_kernel" in n]
+starts = [s for s, e, n in rows if "l2norm_chunk_kernel" in n]            # first kernel of an H-LSTM training step
+if len(starts) < nsteps + 1:
+    starts = [s for s, e, n in rows if "dbof_gather" in n]                # ... of a DBoF step (bench.py --config dbof)
+if len(starts) < nsteps + 1:
+    sys.exit("window_stats: fewer than %d training steps in the trace (no l2norm_chunk / dbof_gather launches)" % (nsteps + 1))
 t0, t1 = starts[-1 - nsteps], starts[-1]
 agg = defaultdict(list)
 for s, e, n in rows:

@@ -569,7 +569,11 @@ def test_fused_moe_update_writes_the_forward_operand_images_in_high_precision(H)
             p = tw.store.p(k)
             K = p.shape[1]
             hi = p.bfloat16()
-            assert torch.equal(tw.shadow_fwd[k], hi)
+            if H == 64:
+                assert torch.equal(tw.shadow_fwd[k], hi)
+            else:       # (round 5) a head that reads f16 + e4m3 images has no use for the bf16 forward shadow: the update no longer writes
+                # it (2 of 34 bytes per parameter); refresh_shadows() / set_precision("bf16") rebuild it from the masters - checked below
+                assert not torch.equal(tw.shadow_fwd[k], hi)
             if H == 64:
                 assert k in tw.shadow_w and k not in tw.shadow_w8
                 assert torch.equal(tw.shadow_w[k][:, :K], hi), (tw.scope, k)
@@ -581,6 +585,10 @@ def test_fused_moe_update_writes_the_forward_operand_images_in_high_precision(H)
                 ops.cast_fp8_lo(p, want, hi_cols=K, scale_exp=ops.FP8_MOE["w_lo_exp"], hi_exp=ops.FP8_MOE["w_hi_exp"])
                 assert torch.equal(tw.shadow_w8[k], want), (tw.scope, k)
     assert all(np.isfinite(v) for v in g.loss_report().values())
+    for tw in (g.teacher, g.student):           # back to bf16: every forward shadow is rebuilt from the masters
+        tw.set_precision("bf16")
+        for k in (tw.GATES, tw.EXPERTS):
+            assert torch.equal(tw.shadow_fwd[k], tw.store.p(k).bfloat16())
 
 
 def test_moe_update_in_two_phases_on_row_slabs_equals_the_whole():
