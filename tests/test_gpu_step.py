@@ -545,6 +545,9 @@ def test_deferred_updates_equal_immediate_updates(precision):
             ma, mb = ta.store.view(ta.store.m, k), tb.store.view(tb.store.m, k)
             assert (ma - mb).abs().max().item() <= 2e-2 * mb.abs().max().item() + 1e-12, k
         for k, sh in ta.shadow_fwd.items():                # the shadows follow the masters in both schedules
+            if k in getattr(ta, "shadow_w16", {}):         # ("high" head on f16 + e4m3 images: its bf16 forward shadow is not kept current, round 5)
+                assert torch.equal(ta.shadow_w16[k], ta.store.p(k).half()), k
+                continue
             assert torch.equal(sh, ta.store.p(k).bfloat16()), k
         assert ta.adam_t == tb.adam_t == 3
 
