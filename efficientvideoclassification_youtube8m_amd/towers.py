@@ -336,9 +336,11 @@ class DbofGenericTower(TowerBase):
     (SampleRandomSequence, cs/model_utils.py:11-36).  The default combination runs on DbofTower (fused cluster kernel); this tower
     is the plain chain on the library's generic kernels - one launch per graph op group, the [B*S, clusters] activation in f32 -
     written for parity, not for speed.  ('none' pooling: FramePooling returns [B*S, C], so the predictions have B*S rows against B
-    label rows: the reference's graph does not train with it - refused by DbofModel.create_model.)"""
+    label rows: the reference's graph does not train with it - refused by DbofModel.create_model.)
+    Precision (round 5): "high" = "split" here - the cluster, hidden and MoE products as split-bf16 (hi.hi + hi.lo + lo.hi, f32-operand
+    accuracy: three launches per contraction on separate hi / lo shadows, TowerBase's default layout), so that these branches too have a
+    mode inside north_star's 1e-3; the backward products stay bf16 as in every mode."""
 
-    PRECISIONS = ("bf16",)
     CW, CB, HW, HB = "cluster_weights", "cluster_biases", "hidden1_weights", "hidden1_biases"
     l2_names = (MoeHead.GATES, MoeHead.EXPERTS)
 
@@ -429,27 +431,39 @@ class DbofGenericTower(TowerBase):
         else:
             u1 = uniform.reshape(B, -1)[:, 0].contiguous()
             ops.sample_sequence_gather(x, u1, num_frames, S, self.r, self.idx, normalize=normalize)
+        hp = self.precision != "bf16"              # split-bf16 forward products (the operands' low-order halves in r_lo / pooled_lo / shadow_lo)
+        if hp and (not hasattr(self, "r_lo") or self.r_lo.shape != self.r_bn.shape):
+            self.r_f32 = torch.empty((R, F), dtype=F32, device=x.device)
+            self.r_lo = torch.empty_like(self.r_bn)
+            self.pooled_lo = torch.zeros_like(self.pooled_bf)
+
+        def product(a_hi, a_lo, a_f32, k, M, N, K, out, bias=None):
+            if hp:
+                ops.cast_bf16_split(a_f32, a_hi[:M], a_lo[:M])
+                ops.gemm_nt_split(a_hi, a_lo, self.shadow_fwd[k], self.shadow_lo[k], M, N, K, out, bias=bias)
+            else:
+                ops.gemm_nt(a_hi, self.shadow_fwd[k], M, N, K, out, bias=bias)
         if self.bn:
             bi, bc, bh = self.bn_in, self.bn_cl, self.bn_h
             bi.stats(self.r, R, is_training)
-            ops.bn_apply(self.r, R, F, bi.mean, bi.var, bi.gamma(), bi.beta(), False, y_bf16=self.r_bn)
-            ops.gemm_nt(self.r_bn, self.shadow_fwd[self.CW], R, Cc, F, self.act)
+            ops.bn_apply(self.r, R, F, bi.mean, bi.var, bi.gamma(), bi.beta(), False, y_f32=self.r_f32 if hp else None, y_bf16=self.r_bn)
+            product(self.r_bn, self.r_lo if hp else None, self.r_f32 if hp else None, self.CW, R, Cc, F, self.act)
             bc.stats(self.act, R, is_training)
             ops.bn_apply(self.act, R, Cc, bc.mean, bc.var, bc.gamma(), bc.beta(), True, y_f32=self.a6)
         else:
             ops.cast_bf16(self.r, self.r_bn)
-            ops.gemm_nt(self.r_bn, self.shadow_fwd[self.CW], R, Cc, F, self.act, bias=st.p(self.CB))
+            product(self.r_bn, self.r_lo if hp else None, self.r, self.CW, R, Cc, F, self.act, bias=st.p(self.CB))
             ops.relu6_fwd(self.act, y_f32=self.a6)
         if self.pooling == "max":
             ops.framepool_max_fwd(self.a6, B, S, Cc, self.pooled, self.pooled_bf, self.arg)
         else:
             ops.framepool_mean_fwd(self.a6, B, S, Cc, self.pooled, self.pooled_bf)
         if self.bn:
-            ops.gemm_nt(self.pooled_bf, self.shadow_fwd[self.HW], B, Hd, Cc, self.hid)
+            product(self.pooled_bf, self.pooled_lo if hp else None, self.pooled, self.HW, B, Hd, Cc, self.hid)
             bh.stats(self.hid, B, is_training)
             ops.bn_apply(self.hid, B, Hd, bh.mean, bh.var, bh.gamma(), bh.beta(), True, y_f32=self.h6)
         else:
-            ops.gemm_nt(self.pooled_bf, self.shadow_fwd[self.HW], B, Hd, Cc, self.hid, bias=st.p(self.HB))
+            product(self.pooled_bf, self.pooled_lo if hp else None, self.pooled, self.HW, B, Hd, Cc, self.hid, bias=st.p(self.HB))
             ops.relu6_fwd(self.hid, y_f32=self.h6)
         self._taped = self.training and is_training
         return self.moe.forward(self.h6)

@@ -156,14 +156,16 @@ def test_dbof_cfg4_batch_512_properties(precision):
     assert d < (2e-5 if precision == "high" else 2e-4), d
 
 
+@pytest.mark.parametrize("precision", ["bf16", "high"])
 @pytest.mark.parametrize("pooling,bn,random_frames", [("average", True, True), ("max", False, True), ("max", True, False),
                                                        ("average", False, False), ("max", True, True)])
-def test_dbof_non_default_branches(pooling, bn, random_frames):
+def test_dbof_non_default_branches(pooling, bn, random_frames, precision):
     """The DbofModel flag values no launcher of the reference selects - dbof_pooling_method average, dbof_add_batch_norm False
     (cluster_biases / hidden1_biases), sample_random_frames False (SampleRandomSequence) - on towers.DbofGenericTower against the
     float64 oracle (oracle/model_math.py::dbof_general_fwd / _bwd, itself checked against finite differences on the CPU): sampled
     indices bit-exact, predictions, gradients by relative L2, one SingleTowerGraph training step; the default combination on the
-    same tower must agree with the fused DbofTower."""
+    same tower must agree with the fused DbofTower.  precision "high" (round 5: split-bf16 forward products on this tower) holds
+    north_star's 1e-3 on the predictions of every branch; bf16 is bounded at 8e-3."""
     from efficientvideoclassification_youtube8m_amd.towers import DbofGenericTower, DbofTower
     from efficientvideoclassification_youtube8m_amd.distill import SingleTowerGraph
     B, F, C, Hd, V, S = 16, 128, 256, 64, 40, 8
@@ -176,6 +178,8 @@ def test_dbof_non_default_branches(pooling, bn, random_frames):
     for k in tw.names:                                               # non-trivial affine / bias parameters
         if k.endswith("/gamma") or k.endswith("/beta") or k.endswith("_biases"):
             tw.store.p(k).add_(torch.from_numpy(rng.standard_normal(tw.store.p(k).shape).astype(np.float32) * 0.2).to(DEV))
+    if precision != "bf16":
+        tw.set_precision(precision)
     P = _params(tw)
     P["_iterations"] = S
     u = rng.random((B, S)).astype(np.float32) if random_frames else rng.random((B, 1)).astype(np.float32)
@@ -185,7 +189,7 @@ def test_dbof_non_default_branches(pooling, bn, random_frames):
     ref_pred, cache = mm.dbof_general_fwd(xn, n, u if random_frames else u[:, 0], P, pooling=pooling, add_batch_norm=bn, random_frames=random_frames)
     assert np.array_equal(tw.idx.cpu().numpy(), cache[0])            # bit-exact indices (int32 truncation / clipping)
     err = np.abs(_np(pred) - ref_pred).max()
-    assert err < 8e-3, err
+    assert err < (1e-3 if precision == "high" else 8e-3), err       # (high: measured ~1e-5; 1e-3 is north_star's bound)
     dp = mm.cross_entropy_grad(ref_pred, labels)
     tw.backward(torch.from_numpy(dp.astype(np.float32)).to(DEV))
     # the tower's discrete decisions (relu6 kinks, max-pool choice) are taken on bf16-rounded values: few may differ from the
@@ -215,11 +219,13 @@ def test_dbof_non_default_branches(pooling, bn, random_frames):
         l2 = float(np.linalg.norm(got - g) / (np.linalg.norm(g) + 1e-30))
         worst[k] = round(l2, 4)
         assert l2 < 3e-2, (k, l2)                                    # bf16 operands of the backward products
-    print("dbof generic (%s, bn %s, random_frames %s): pred err %.2e, gradient relative L2 %s" % (pooling, bn, random_frames, err, worst))
+    print("dbof generic (%s, bn %s, random_frames %s, %s): pred err %.2e, gradient relative L2 %s" % (pooling, bn, random_frames, precision, err, worst))
     if pooling == "max" and bn and random_frames:                    # the default combination: the fused tower computes the same function
         tf_ = DbofTower(B, 300, F, V, iterations=S, cluster_size=C, hidden_size=Hd, device=DEV, seed=5)
         tf_.load_state_dict(tw.state_dict())
-        assert (tf_.forward(xd, nd, ud) - pred).abs().max().item() < 8e-3
+        if precision != "bf16":
+            tf_.set_precision(precision)
+        assert (tf_.forward(xd, nd, ud) - pred).abs().max().item() < (1e-3 if precision == "high" else 8e-3)
     g = SingleTowerGraph(tw)
     l0 = float(g.step(xd, torch.from_numpy(labels.astype(np.uint8)).to(DEV), nd, uniform=ud)["loss"])
     for _ in range(3):
