@@ -323,28 +323,12 @@ __device__ __forceinline__ void dbof_mainloop(const GemmOperands& p, int m0, int
   else gemm_mainloop_v2<Cfg, true, INIT, MODE>(p, m0, u0, lds_dyn, acc);
 }
 
-// FP8: IEEE f16 operands with both operands' low-order corrections as e4m3 stages behind them (LOOP_FP8_TAIL; the "high" precision forward)
-template <bool FP8>
-__global__ __launch_bounds__(CfgDbof::NT) void dbof_cluster_pool_kernel(GemmOperands p, DbofPoolParams e, int tiles_m, int tiles_n) {
-  typedef CfgDbof Cfg;
-  const int nwg = tiles_m * tiles_n;
-  const int id = xcd_remap(blockIdx.x, nwg);
-  int tm, tn;
-  tile_of(id, tiles_m, tiles_n, tm, tn, 8);
-  const int m0 = tm * Cfg::BM, u0 = tn * Cfg::BU;
-  f32x4 acc[Cfg::MI][1][Cfg::NI];
-  dbof_mainloop<Cfg, true, FP8 ? (LOOP_F16 | LOOP_FP8_TAIL) : 0>(p, m0, u0, acc);
-  if (!FP8 && p.A1lo) {             // split-bf16 operands: + hi.lo + lo.hi (f32-operand accuracy, 3x the MFMA work)
-    GemmOperands q = p;
-    q.B = p.Blo;
-    __syncthreads();
-    dbof_mainloop<Cfg, false>(q, m0, u0, acc);
-    q = p;
-    q.A1 = p.A1lo;
-    __syncthreads();
-    dbof_mainloop<Cfg, false>(q, m0, u0, acc);
-  }
-  // ---- epilogue.  Transposed accumulators: lane 16g + l holds row mi*16 + l, columns ni*16 + 4g .. 4g+3 ----
+// ---- epilogue of one output tile.  Transposed accumulators: lane 16g + l holds row mi*16 + l, columns ni*16 + 4g .. 4g+3 ----
+// SLICE_ROWS = rows of a wave's transpose slice: Cfg::WM (the whole 128 x 64 sub-tile at once, in the idle ring at `scratch`: the one-tile
+// kernels) or 32 (four passes through a 4 KB slice BEHIND the ring: the tile walk, whose ring is already filling with the next tile).
+template <class Cfg, int SLICE_ROWS>
+__device__ __forceinline__ void dbof_tile_epilogue(const GemmOperands& p, const DbofPoolParams& e, f32x4 (&acc)[Cfg::MI][1][Cfg::NI],
+                                                   const int tm, const int m0, const int u0, char* scratch) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave / Cfg::WC, wc = wave % Cfg::WC;
   const int l = lane & 15, g = lane >> 4, j = l & 3;
@@ -354,34 +338,36 @@ __global__ __launch_bounds__(CfgDbof::NT) void dbof_cluster_pool_kernel(GemmOper
   if (e.act) {
     // bf16 activation for the backward pass.  The accumulator layout gives a lane 4 consecutive columns of 16 different
     // rows per block: stored directly, every wave-instruction touches 16 lines with 32 bytes each (measured: +0.21 ms on
-    // the 0.31 ms kernel).  Each wave transposes its 128 x 64 sub-tile through its own slice of the (now idle) ring
-    // instead and writes whole 128-byte lines, 16 bytes per lane.
-    __syncthreads();                                           // every wave has read its last ring slot
+    // the 0.31 ms kernel).  Each wave transposes its 128 x 64 sub-tile through its own LDS slice instead and writes whole
+    // 128-byte lines, 16 bytes per lane.  (The caller has passed the barrier behind the main loop's last LDS reads.)
     // 128-byte rows, 16-byte chunk c of row r stored at chunk c ^ (r & 7) (round 4; before: 144-byte padded rows, whose ds_read_b128 lane
     // groups - rows r .. r+3 with chunk halves 0-3 / 4-7 / 4-7 / 0-3 - overlapped in 4 of 16 slots: the 9 % LDS bank conflicts of
     // profiles/r03_pmc_kernels_dbof.json).  Reads: slots (8 r + (c ^ r)) mod 16 of a group are 0-3 | 12-15 | 4-7 | 8-11: conflict-free; the 8-byte
     // writes of a 16-lane group (16 rows, one chunk) land 2-way (rows r and r + 8), which ds_write_b64 absorbs.
     constexpr int RS = Cfg::WU * 2;
     static_assert(RS == 128, "the swizzle is written for 64-column wave tiles");
-    char* wl = lds_dyn + wave * (Cfg::WM * RS);
-    static_assert(8 * Cfg::WM * RS <= Cfg::LDS_BYTES, "per-wave transpose slices must fit the ring");
-#pragma unroll
-    for (int mi = 0; mi < Cfg::MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < Cfg::NI; ++ni) {
-        const f32x4 v = acc[mi][0][ni];
-        const int row = mi * 16 + l, chunk = ni * 2 + (g >> 1);
-        *(uint2*)(wl + row * RS + ((chunk ^ (row & 7)) << 4) + ((g & 1) << 3)) = make_uint2(pack_bf16x2_hw(v[0], v[1]), pack_bf16x2_hw(v[2], v[3]));
-      }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this wave's own writes (LDS ops of one wave execute in order)
+    static_assert(SLICE_ROWS % 16 == 0 && Cfg::WM % SLICE_ROWS == 0, "whole accumulator blocks per pass");
+    char* wl = scratch + wave * (SLICE_ROWS * RS);
     const int colw = u0 + wc * Cfg::WU;
-    if (colw < e.C) {
 #pragma unroll
-      for (int it = 0; it < Cfg::WM / 8; ++it) {
-        const int rl = it * 8 + (lane >> 3);
-        const uint4 q = *(const uint4*)(wl + rl * RS + (((lane & 7) ^ (rl & 7)) << 4));
-        const int row = rbase + rl;
-        if (row < p.M) *(uint4*)(e.act + (long)row * e.ld_act + colw + (lane & 7) * 8) = q;
+    for (int r0 = 0; r0 < Cfg::WM; r0 += SLICE_ROWS) {          // (LDS operations of one wave execute in order: a pass's writes cannot overtake the previous pass's reads)
+#pragma unroll
+      for (int mi = r0 / 16; mi < (r0 + SLICE_ROWS) / 16; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < Cfg::NI; ++ni) {
+          const f32x4 v = acc[mi][0][ni];
+          const int row = mi * 16 - r0 + l, chunk = ni * 2 + (g >> 1);
+          *(uint2*)(wl + row * RS + ((chunk ^ (row & 7)) << 4) + ((g & 1) << 3)) = make_uint2(pack_bf16x2_hw(v[0], v[1]), pack_bf16x2_hw(v[2], v[3]));
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's own writes
+      if (colw < e.C) {
+#pragma unroll
+        for (int it = 0; it < SLICE_ROWS / 8; ++it) {
+          const int rl = it * 8 + (lane >> 3);
+          const uint4 q = *(const uint4*)(wl + rl * RS + (((lane & 7) ^ (rl & 7)) << 4));
+          const int row = rbase + r0 + rl;
+          if (row < p.M) *(uint4*)(e.act + (long)row * e.ld_act + colw + (lane & 7) * 8) = q;
+        }
       }
     }
   }
@@ -437,6 +423,63 @@ __global__ __launch_bounds__(CfgDbof::NT) void dbof_cluster_pool_kernel(GemmOper
   }
 }
 
+// FP8: IEEE f16 operands with both operands' low-order corrections as e4m3 stages behind them (LOOP_FP8_TAIL; the "high" precision forward)
+template <bool FP8>
+__global__ __launch_bounds__(CfgDbof::NT) void dbof_cluster_pool_kernel(GemmOperands p, DbofPoolParams e, int tiles_m, int tiles_n) {
+  typedef CfgDbof Cfg;
+  const int nwg = tiles_m * tiles_n;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  int tm, tn;
+  tile_of(id, tiles_m, tiles_n, tm, tn, 8);
+  const int m0 = tm * Cfg::BM, u0 = tn * Cfg::BU;
+  f32x4 acc[Cfg::MI][1][Cfg::NI];
+  dbof_mainloop<Cfg, true, FP8 ? (LOOP_F16 | LOOP_FP8_TAIL) : 0>(p, m0, u0, acc);
+  if (!FP8 && p.A1lo) {             // split-bf16 operands: + hi.lo + lo.hi (f32-operand accuracy, 3x the MFMA work)
+    GemmOperands q = p;
+    q.B = p.Blo;
+    __syncthreads();
+    dbof_mainloop<Cfg, false>(q, m0, u0, acc);
+    q = p;
+    q.A1 = p.A1lo;
+    __syncthreads();
+    dbof_mainloop<Cfg, false>(q, m0, u0, acc);
+  }
+  if (e.act) __syncthreads();                                  // every wave has read its last ring slot: the ring is the transpose scratch
+  static_assert(8 * Cfg::WM * Cfg::WU * 2 <= Cfg::LDS_BYTES, "per-wave transpose slices must fit the ring");
+  dbof_tile_epilogue<Cfg, Cfg::WM>(p, e, acc, tm, m0, u0, lds_dyn);
+}
+
+// Tile walk (round 5; plain bf16 operands): one workgroup per CU walks the row tiles of ONE column panel of W_c.  Once every wave has left
+// the ring, the first two stages of the NEXT tile are issued (gemm_mainloop_v3 PHASE 1) and land under this tile's statistics / arg-max / tape
+// epilogue, whose transpose goes through 4 KB per wave BEHIND the ring (four passes of 32 rows) - 7 of 8 ring fills leave the critical path.
+// Panel tn lives on XCD tn % 8 (workgroup b runs on XCD b % 8): a column panel of W_c is fetched by one L2 instead of eight; the `walkers`
+// workgroups of a panel start on different row tiles and the XCD's panels walk the rows in step, so a row panel of the frames is in that L2
+// for all of them.
+struct CfgDbofWalk : CfgDbof { static constexpr int RING_BYTES = CfgDbof::LDS_BYTES, LDS_BYTES = RING_BYTES + 8 * 32 * 128; };
+template <> struct is_v2<CfgDbofWalk> { static constexpr bool value = true; };
+template <> struct is_v3<CfgDbofWalk> { static constexpr bool value = true; };
+static_assert(CfgDbofWalk::LDS_BYTES <= 160 * 1024, "ring + eight 4 KB transpose slices");
+
+__global__ __launch_bounds__(CfgDbof::NT) void dbof_cluster_pool_walk_kernel(GemmOperands p, DbofPoolParams e, int tiles_m, int tiles_n,
+                                                                             int panels_per_xcd, int walkers) {
+  typedef CfgDbof Cfg;
+  constexpr int MODE = LOOP_DMA_FIRST | LOOP_NO_PRIO;
+  const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+  const int tn = (i % panels_per_xcd) * 8 + xcd;
+  int tm = i / panels_per_xcd;
+  if (tn >= tiles_n || tm >= tiles_m) return;                   // (workgroup-uniform)
+  const int u0 = tn * Cfg::BU;
+  f32x4 acc[Cfg::MI][1][Cfg::NI];
+  gemm_mainloop_v3<Cfg, true, true, MODE, 1>(p, tm * Cfg::BM, u0, lds_dyn, acc);
+  for (; tm < tiles_m; tm += walkers) {
+    const int m0 = tm * Cfg::BM;
+    gemm_mainloop_v3<Cfg, true, true, MODE, 2>(p, m0, u0, lds_dyn, acc);
+    __syncthreads();                                             // every wave has read its last ring slot
+    if (tm + walkers < tiles_m) gemm_mainloop_v3<Cfg, true, true, MODE, 1>(p, (tm + walkers) * Cfg::BM, u0, lds_dyn, acc);
+    dbof_tile_epilogue<Cfg, 32>(p, e, acc, tm, m0, u0, lds_dyn + CfgDbofWalk::RING_BYTES);
+  }
+}
+
 extern "C" int evc_dbof_cluster_pool_fwd(const evc_bf16* r_bn, const evc_bf16* r_bn_lo, const evc_bf16* wT, const evc_bf16* wT_lo,
                                          int B, int S, int F, int C, const float* gamma, evc_bf16* act, float* part, float* xsel,
                                          uint8_t* arg, void* stream) {
@@ -452,6 +495,19 @@ extern "C" int evc_dbof_cluster_pool_fwd(const evc_bf16* r_bn, const evc_bf16* r
   p.A1lo = r_bn_lo; p.A2lo = nullptr; p.Blo = wT_lo;
   DbofPoolParams e{act, (long)C, part, gamma, xsel, arg, B, S, C};
   const int tm = ceil_div(Mp, CfgDbof::BM), tn = ceil_div(C, CfgDbof::BU);
+#ifndef EVC_DBOF_V2_LOOP
+  // tile walk: plain bf16 operands and enough tiles to give 256 workgroups several each (EVC_DBOF_WALK=0: one tile per workgroup, A/B)
+  const char* wenv = getenv("EVC_DBOF_WALK");                    // (read per call: the tests switch it; 2 = also below 512 tiles)
+  const int walk_on = wenv ? atoi(wenv) : 1;
+  const int ppx = ceil_div(tn, 8);                               // column panels per XCD
+  if (walk_on && !r_bn_lo && ppx <= 32 && ((long)tm * tn >= 512 || walk_on == 2)) {
+    int walkers = 32 / ppx;                                      // 32 workgroups (= CUs) per XCD
+    walkers = walkers < tm ? walkers : tm;
+    launch_cfg<CfgDbofWalk>(dbof_cluster_pool_walk_kernel, 8 * ppx * walkers, (hipStream_t)stream, p, e, tm, tn, ppx, walkers);
+    EVC_LAUNCH_CHECK();
+    return EVC_OK;
+  }
+#endif
   launch_cfg<CfgDbof>(dbof_cluster_pool_kernel<false>, tm * tn, (hipStream_t)stream, p, e, tm, tn);
   EVC_LAUNCH_CHECK();
   return EVC_OK;

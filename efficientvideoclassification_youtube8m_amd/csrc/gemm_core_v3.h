@@ -68,7 +68,12 @@ struct TileCfg3 {
   static_assert(LDS_BYTES <= 160 * 1024, "exceeds the 160 KiB LDS of a CU");
 };
 
-template <class Cfg, bool SWAP = false, bool INIT = true, int MODE = EVC_LOOP_MODE_DEFAULT>
+// PHASE (round 5, persistent kernels that walk several output tiles per workgroup): 0 = the whole loop; 1 = ONLY issue the first
+// min(nk, STAGES) stages of tile (m0, u0) and return (acc untouched) - called for the NEXT tile once every wave has left the ring
+// (a barrier), so that the ring fills under the current tile's epilogue; 2 = the loop for a tile whose first stages were issued by a
+// PHASE-1 call (same p, m0, u0): nothing is issued in the prologue and the first wait is vmcnt(0) - the wave's epilogue stores were
+// issued after those stages and a counted wait would count them instead.
+template <class Cfg, bool SWAP = false, bool INIT = true, int MODE = EVC_LOOP_MODE_DEFAULT, int PHASE = 0>
 __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const int m0, const int u0, char* lds,
                                                  f32x4 (&acc)[Cfg::MI][Cfg::G][Cfg::NI]) {
   const int tid = threadIdx.x;
@@ -76,7 +81,8 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / Cfg::WC, wc = wave % Cfg::WC;
 
-  if (INIT) {
+  static_assert(PHASE == 0 || (MODE & LOOP_FP8_TAIL) == 0, "tile walks: 16-bit stages only");
+  if (INIT && PHASE != 1) {
 #pragma unroll
     for (int mi = 0; mi < Cfg::MI; ++mi)
 #pragma unroll
@@ -147,10 +153,20 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
       ldb_b = f ? ldb_b : 96u;
       chunk_b = f ? (uint32_t)(lc8 * 2) : (uint32_t)(min(lc8 / 8, 5) * 16);
 #endif
+#ifdef EVC_ABLATE_E_HOT   // TIMING ablation (wrong results): every row of an e-stage fetches row 0's bytes - L2-hot lines, the same LDS-DMA count
+      lda_b = f ? lda_b : 0u;
+      ldb_b = f ? ldb_b : 0u;
+#endif
     }
+#ifdef EVC_ABLATE_E_NOA   // TIMING ablation (wrong results): the e-stages issue their B pieces only (half the LDS-DMA instructions)
+    const bool skip_a = FP8 && ks_issue >= nkf;
+#else
+    constexpr bool skip_a = false;
+#endif
     char* sbase = lds + slot_issue * Cfg::STAGE_BYTES;
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
+      if (skip_a) break;
       char* dst = a_dst[i] >= 0 ? sbase + a_dst[i] : lds + Cfg::DUMMY_OFF;
       const uint32_t vo = __umul24((uint32_t)a_row[i], lda_b) + chunk_b;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ab + vo),
@@ -304,10 +320,17 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
   };
 
   // ---- prologue: every slot of the ring in flight ----
+  if constexpr (PHASE != 2) {
 #pragma unroll
-  for (int i = 0; i < Cfg::STAGES; ++i)
-    if (i < nk) stage_role();
-  if constexpr (PROD) wait_landed(min(nk, Cfg::STAGES) - 1);
+    for (int i = 0; i < Cfg::STAGES; ++i)
+      if (i < nk) stage_role();
+    if constexpr (PHASE == 1) return;
+    if constexpr (PROD) wait_landed(min(nk, Cfg::STAGES) - 1);
+  } else {                             // issued by the PHASE-1 call: only the bookkeeping
+    ks_issue = min(nk, Cfg::STAGES);
+    slot_issue = ks_issue == Cfg::STAGES ? 0 : ks_issue;
+    if constexpr (PROD) wait_vmcnt<0>();
+  }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   EVC_STAMP(p.stamp_slot, 1);

@@ -1208,6 +1208,45 @@ def test_fused_adam_for_plain_2d_weights(ops, R, C, images):
         assert torch.equal(kw["p_f16"], w16) and torch.equal(kw["p_fp8"], w8)
 
 
+@pytest.mark.parametrize("B,F,C", [(320, 128, 2304), (260, 256, 1024), (36, 192, 8192)])
+def test_dbof_cluster_tile_walk_equals_one_tile_per_workgroup(ops, B, F, C, monkeypatch):
+    """Round 5: evc_dbof_cluster_pool_fwd walks several row tiles of one W_c column panel per workgroup (the next tile's first ring stages
+    issued under the current tile's epilogue, the tape transposed through 4 KB per wave behind the ring) when there are >= 512 tiles.  Forced
+    here at smaller shapes (EVC_DBOF_WALK=2) against the one-tile-per-workgroup kernel (EVC_DBOF_WALK=0): the same arithmetic in the same
+    order, so the tape, the selected activations, the frame slots and the statistics partials must be IDENTICAL - ragged walks (40 row
+    tiles over 16 walkers, 17 over 8), K of two, four and three stages, column panels that do not fill the last XCD."""
+    S = 30
+    rng = np.random.default_rng(B + C)
+    Mp, P_in, P_cl = ops.dbof_workspace(B, S)
+    rows = torch.from_numpy(ops.dbof_row_index(B, S).numpy().reshape(-1)).to(DEV)
+    r_bn = torch.zeros((Mp, F), dtype=torch.bfloat16, device=DEV)
+    r_bn[rows] = torch.from_numpy(rng.standard_normal((B * S, F)).astype(np.float32)).to(DEV).bfloat16()
+    W = torch.from_numpy((rng.standard_normal((C, F)) / np.sqrt(F)).astype(np.float32)).to(DEV).bfloat16()
+    ga = (1 + 0.3 * rng.standard_normal(C)).astype(np.float32)
+    ga[::3] *= -1
+    ga_d = torch.from_numpy(ga).to(DEV)
+    outs = []
+    for mode in ("2", "0", "2"):
+        monkeypatch.setenv("EVC_DBOF_WALK", mode)
+        act = torch.full((Mp, C), 7.0, dtype=torch.bfloat16, device=DEV)
+        part = torch.full((P_cl, 2, C), float("nan"), device=DEV)
+        xsel = torch.full((B, C), float("nan"), device=DEV)
+        arg = torch.full((B, C), 255, dtype=torch.uint8, device=DEV)
+        ops.dbof_cluster_pool_fwd(r_bn, W, B, S, F, C, ga_d, xsel, arg, act=act, part=part)
+        xs2 = torch.full((B, C), float("nan"), device=DEV)
+        ar2 = torch.full((B, C), 255, dtype=torch.uint8, device=DEV)
+        ops.dbof_cluster_pool_fwd(r_bn, W, B, S, F, C, ga_d, xs2, ar2)              # evaluation form: no tape, no partials
+        torch.cuda.synchronize()
+        outs.append((act, part, xsel, arg, xs2, ar2))
+    for a, b in ((outs[0], outs[1]), (outs[0], outs[2])):
+        for name, x, y in zip(("act", "part", "xsel", "arg", "xsel (eval)", "arg (eval)"), a, b):
+            assert torch.equal(x.view(torch.uint8) if x.dtype != torch.uint8 else x, y.view(torch.uint8) if y.dtype != torch.uint8 else y), name
+    act, part, xsel, arg = outs[0][:4]
+    ref = r_bn.float() @ W.float().t()                                             # the tape against a plain product of the same bf16 operands
+    assert (act.float() - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item() + 1e-4
+    assert torch.isfinite(xsel).all() and int(arg.max()) < S and torch.equal(outs[0][2], outs[0][4]) and torch.equal(outs[0][3], outs[0][5])
+
+
 @pytest.mark.parametrize("B,S,F,C,u8", [(6, 8, 64, 128, False), (9, 30, 128, 320, True), (37, 30, 1152, 512, True)])
 def test_dbof_fused_kernels_against_oracle(ops, B, S, F, C, u8):
     """csrc/evc_dbof.hip piece by piece (cs/frame_level_models.py:126-167, cs/model_utils.py:39-58,77-78): gather into the
