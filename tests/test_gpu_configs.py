@@ -177,6 +177,42 @@ def test_single_layer_stacks_all_precisions(precision):
     assert g.global_step == 2
 
 
+@pytest.mark.parametrize("L,order", [(3, "sequential"), (4, "sequential"), (4, "interleaved"), (6, "interleaved")])
+def test_deep_stacks_run_every_backward_phase(L, order, monkeypatch):
+    """--lstm_layers >= 3 (the backward issue loop resumed each tower's phase generator a FIXED number of times - enough for two
+    layers per level - and left the lowest layers' BPTT, weight gradients, Adam and the final stream joins undone without an error from
+    four layers on, six in the interleaved order): one training step in the overlapped schedule against the float64 oracle's gradients for
+    EVERY variable of both towers, and every variable must have moved after the update."""
+    from efficientvideoclassification_youtube8m_amd import smoke
+    from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
+    monkeypatch.setenv("EVC_ISSUE_ORDER", order)
+    B, F, H, V = 8, 64, 64, 24
+    q, x, n, labels = mm.synthetic_batch(B, seed=14, feature_size=F, vocab_size=V, dtype=np.float32)
+    g = DistillGraph(B, every_n=10, feature_size=F, vocab_size=V, lstm_cells=H, lstm_layers=L, device=DEV, seed=4)
+    assert g.teacher.L == L and g.teacher.K == 2 * L * H and g.issue_order == order
+    for tw in (g.teacher, g.student):
+        for k in tw.names:
+            if k.endswith("basic_lstm_cell/kernel"):
+                tw.store.p(k).mul_(1.5)
+        tw.refresh_shadows()
+    teacher, student = smoke.tower_params_numpy(g.teacher), smoke.tower_params_numpy(g.student)
+    before = {(tw.scope, k): tw.store.p(k).clone() for tw in (g.teacher, g.student) for k in tw.names}
+    out = g.step(*_dev(x, n, labels), num_frames_host=n)            # apply=True: the updates run inside the step, on the aux streams
+    torch.cuda.synchronize()
+    ref = mm.teacher_student_step(x.astype(np.float64), n, labels, teacher, student, 10, num_layers=L, with_grads=True)
+    assert np.abs(out["predictions"].cpu().numpy() - ref["teacher_predictions"]).max() < 4e-3
+    for tower, key in ((g.teacher, "teacher_grads"), (g.student, "student_grads")):
+        got = smoke.tower_grads_numpy(tower)
+        assert len([k for k in got if k.endswith("kernel")]) == 2 * L
+        for k in got:
+            if k in ("classifier/gates/weights", "classifier/experts/weights"):
+                continue                                              # (fused update: their gradient is never materialised)
+            assert _rel(got[k], ref[key][k]) < 6e-2, (tower.scope, k, _rel(got[k], ref[key][k]))
+        for k in tower.names:
+            assert not torch.equal(tower.store.p(k), before[(tower.scope, k)]), (tower.scope, k, "was not updated")
+    assert g.global_step == 2 and all(np.isfinite(v) for v in g.loss_report().values())
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # cfg 2: teacher only
 # ---------------------------------------------------------------------------------------------------------------
