@@ -481,14 +481,17 @@ __global__ __launch_bounds__(64 * KW) void lstm_bwd_step_skinny_kernel(GemmOpera
 // PRIVATE ring of LDS-DMA stages (64-wide K steps, 128-byte rows: each 1 KiB DMA instruction moves 8 full cache
 // lines, where a direct fragment load touches 16 half-used ones) and waits only on its own vmcnt - no barrier in
 // the loop, 3 stages in flight per wave.  LDS: KW x STAGES x 8 KiB rings + the partial tiles.
-template <int KW, int STAGES>
-__global__ __launch_bounds__(64 * KW) void lstm_bwd_step_skinny_lds_kernel(GemmOperands p, LstmBwdParams e, int tiles_m, int tiles_n) {
+// TWO_SEG (round 5, the wavefront pair launches of the M ~ batch stacks): K walks nk1 steps of A1 against B, then nk2 steps of A2 against B2
+// (B2's k index restarts at 0; B2 == NULL: B's runs on) - layer 0's step with the gradient from the layer above contracted in the same
+// launch, [dz0_{t+1} | dz1_t] . [Wh0 ; Wx1]^T.  The wave's K slice may lie in either segment or straddle them (scalar selects per step).
+template <int KW, int STAGES, bool TWO_SEG>
+__device__ __forceinline__ void lstm_bwd_skinny_lds_body(const GemmOperands& p, const LstmBwdParams& e, const int tiles_m, const int tiles_n, const int bid) {
   constexpr int NT = 64 * KW;
   constexpr int STAGE = 8192, RING = STAGES * STAGE;                  // A 32 rows x 128 B | B 32 rows x 128 B
   float (*part)[32][36] = (float (*)[32][36])lds_dyn;                 // [wave][row][unit] (+4 pad): ALIASES the rings (18 KB of KW x RING >= 64 KB),
                                                                       // written behind a barrier once every wave has left its loop
   const int nwg = tiles_m * tiles_n;
-  const int id = xcd_remap(blockIdx.x, nwg);
+  const int id = xcd_remap(bid, nwg);
   const int tm = id % tiles_m, tn = id / tiles_m;
   const int m0 = tm * 32, u0 = tn * 32;
   if (m0 >= e.m_active) {
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(64 * KW) void lstm_bwd_step_skinny_lds_kernel(GemmO
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   char* ring = lds_dyn + wave * RING;
-  const int nk = p.nk1;                                               // 64-wide K steps
+  const int nk = TWO_SEG ? p.nk1 + p.nk2 : p.nk1;                     // 64-wide K steps
   const int per = (nk + KW - 1) / KW;
   const int k0 = min(wave * per, nk), k1 = min(nk, wave * per + per);
   const int n = k1 - k0;                                              // this wave's K steps (may be 0)
@@ -506,23 +509,33 @@ __global__ __launch_bounds__(64 * KW) void lstm_bwd_step_skinny_lds_kernel(GemmO
   const int lc8 = ((lane & 7) ^ ((lane >> 3) & 7)) * 8;
   const bf16_t* asrc[4];
   const bf16_t* bsrc[4];
+  long a2off[4], boff[4];                                             // TWO_SEG: the lane's row offsets into A2 / B2
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = (lane >> 3) + i * 8;
     const int m = min(m0 + r, p.M - 1), u = min(u0 + r, p.Nu - 1);
     asrc[i] = p.A1 + (long)m * p.lda1 + (long)k0 * 64 + lc8;
     bsrc[i] = p.B + (long)u * p.ldb + (long)k0 * 64 + lc8;
+    a2off[i] = (long)m * p.lda2 + lc8;
+    boff[i] = (long)u * p.ldb + lc8;
   }
+  const bf16_t* const b2 = (TWO_SEG && p.B2) ? p.B2 : p.B + (long)p.nk1 * 64;
   auto stage = [&](int j) {                                           // K step j of this wave -> ring slot j % STAGES
     char* sb = ring + (j % STAGES) * STAGE;
+    const int kk = k0 + j;
+    const bool s2 = TWO_SEG && kk >= p.nk1;                           // wave-uniform
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + (long)j * 64),
+    for (int i = 0; i < 4; ++i) {
+      const bf16_t* src = s2 ? p.A2 + a2off[i] + (long)(kk - p.nk1) * 64 : asrc[i] + (long)j * 64;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sb + i * 1024), 16, 0, 0);
+    }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + (long)j * 64),
+    for (int i = 0; i < 4; ++i) {
+      const bf16_t* src = s2 ? b2 + boff[i] + (long)(kk - p.nk1) * 64 : bsrc[i] + (long)j * 64;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sb + 4096 + i * 1024), 16, 0, 0);
+    }
   };
   f32x4 acc[2][2];
 #pragma unroll
@@ -604,6 +617,25 @@ __global__ __launch_bounds__(64 * KW) void lstm_bwd_step_skinny_lds_kernel(GemmO
       if (u < e.H) atomicAdd(e.db + (long)g * e.H + u, v);
     }
   }
+}
+
+template <int KW, int STAGES>
+__global__ __launch_bounds__(64 * KW) void lstm_bwd_step_skinny_lds_kernel(GemmOperands p, LstmBwdParams e, int tiles_m, int tiles_n) {
+  lstm_bwd_skinny_lds_body<KW, STAGES, false>(p, e, tiles_m, tiles_n, blockIdx.x);
+}
+
+// Two independent steps in one launch (the first tiles_m*tiles_n workgroups run step a, the rest step b): layer 0's step t+1 - with the
+// gradient from layer 1 contracted in its own K walk - and layer 1's step t of a two-layer M ~ batch stack.  These steps are chains of
+// dependent ~12 us launches; at 64 KB of LDS two of their workgroups share a CU, so the stack's BPTT is T + 1 dependent launches instead of
+// 2 T + a hoisted dX product (the forward twin: lstm_fwd_pair_kernel).
+template <int KW, int STAGES>
+__global__ __launch_bounds__(64 * KW) void lstm_bwd_skinny_pair_kernel(GemmOperands pa, LstmBwdParams ea, GemmOperands pb, LstmBwdParams eb,
+                                                                       int tiles_m, int tiles_n) {
+  const int n = tiles_m * tiles_n;
+  const bool first = blockIdx.x < n;                   // workgroup-uniform
+  const GemmOperands p = first ? pa : pb;
+  const LstmBwdParams e = first ? ea : eb;
+  lstm_bwd_skinny_lds_body<KW, STAGES, true>(p, e, tiles_m, tiles_n, first ? blockIdx.x : blockIdx.x - n);
 }
 
 template <class Cfg>
@@ -757,7 +789,14 @@ extern "C" int evc_lstm_stack2_bwd(const evc_bf16* w_il0, const evc_bf16* w_il1,
   typedef CfgBwdV2_128 Cfg;
   hipStream_t st = (hipStream_t)stream;
   const long slab = (long)M * H;
-  const int tn = ceil_div(H, Cfg::BU), tm = ceil_div(M, Cfg::BM);
+  const bool skinny = M <= 512;                      // M ~ batch stacks (the L2 levels): 32 x 32 tiles, K split over four waves, 64 KB of LDS
+  const int kdv = skinny ? 64 : 32;                  // K step of the loop the launch runs on
+  const int tn = skinny ? ceil_div(H, 32) : ceil_div(H, Cfg::BU), tm = skinny ? ceil_div(M, 32) : ceil_div(M, Cfg::BM);
+  constexpr int SKW = 4, SSTG = 2;
+  if (skinny) {
+    allow_big_lds((const void*)lstm_bwd_skinny_pair_kernel<SKW, SSTG>, SKW * SSTG * 8192);
+    allow_big_lds((const void*)lstm_bwd_step_skinny_lds_kernel<SKW, SSTG>, SKW * SSTG * 8192);
+  }
   auto base = [&](GemmOperands& p) {
     p.M = M; p.Nu = H; p.group_stride = 0; p.nk1 = p.nk2 = 0;
     p.A1lo = p.A2lo = p.Blo = nullptr; p.B2 = nullptr;
@@ -787,9 +826,9 @@ extern "C" int evc_lstm_stack2_bwd(const evc_bf16* w_il0, const evc_bf16* w_il1,
     if (has_a) {                                      // layer 0, step t0: [dz0_{t0+1} | dz1_{t0}] . [Wh0 ; Wx1]^T
       base(pa);
       pa.A1 = dz0 + (long)(t0 + 1 < T ? t0 + 1 : t0) * slab * 4;
-      pa.nk1 = (t0 == T - 1) ? 0 : 4 * H / 32;
+      pa.nk1 = (t0 == T - 1) ? 0 : 4 * H / kdv;
       pa.A2 = dz1 + (long)t0 * slab * 4;
-      pa.nk2 = 4 * H / 32;
+      pa.nk2 = 4 * H / kdv;
       pa.B = w_il0 + (long)Kin0 * 4 * H;              // Wh0: rows Kin0 .. Kin0+H-1 of layer 0's kernel
       pa.B2 = w_il1;                                  // Wx1: rows 0 .. H-1 of layer 1's kernel
       tail(ea, 0, t0);
@@ -797,10 +836,17 @@ extern "C" int evc_lstm_stack2_bwd(const evc_bf16* w_il0, const evc_bf16* w_il1,
     if (has_b) {                                      // layer 1, step t1: dz1_{t1+1} . Wh1^T
       base(pb);
       pb.A1 = dz1 + (long)(t1 + 1 < T ? t1 + 1 : t1) * slab * 4;
-      pb.nk1 = (t1 == T - 1) ? 0 : 4 * H / 32;
+      pb.nk1 = (t1 == T - 1) ? 0 : 4 * H / kdv;
       pb.A2 = pb.A1;
       pb.B = w_il1 + (long)H * 4 * H;                 // Wh1
       tail(eb, 1, t1);
+    }
+    if (skinny) {
+      constexpr int LDS = SKW * SSTG * 8192;
+      if (has_a && has_b) hipLaunchKernelGGL((lstm_bwd_skinny_pair_kernel<SKW, SSTG>), dim3(2 * tm * tn), dim3(64 * SKW), LDS, st, pa, ea, pb, eb, tm, tn);
+      else if (has_a) hipLaunchKernelGGL((lstm_bwd_skinny_pair_kernel<SKW, SSTG>), dim3(tm * tn), dim3(64 * SKW), LDS, st, pa, ea, pa, ea, tm, tn);   // (two-segment body, one role)
+      else hipLaunchKernelGGL((lstm_bwd_step_skinny_lds_kernel<SKW, SSTG>), dim3(tm * tn), dim3(64 * SKW), LDS, st, pb, eb, tm, tn);
+      continue;
     }
     if (has_a && has_b) launch_cfg<Cfg>(lstm_bwd_pair_kernel<Cfg>, 2 * tm * tn, st, pa, ea, tm, pb, eb, tm, tn);
     else if (has_a) launch_cfg<Cfg>(lstm_bwd_step_kernel<Cfg>, tm * tn, st, pa, ea, tm, tn);

@@ -125,6 +125,11 @@ class LstmStack:
     # loops are L2->LDS-bound, so FLOPs moved into them cost more than the 1 PF/s hoisted product saves; kept for A/B runs.
     bwd_fuse = os.environ.get("EVC_BWD_FUSE", "off")
     bwd_wavefront = True          # (tests toggle this to compare the fused forms against the hoisted one)
+    # M ~ batch two-layer stacks: wavefront BPTT on the skinny pair launches.  Built and measured in round 5 (same box, alternating): ALONE the
+    # teacher's chain takes 453 instead of 507 us and the student's 119 instead of 144 (scripts/l2_bwd_bench.py), the training step 10.26 instead
+    # of 10.07-10.13 ms - a pair launch wants two 64 KB workgroups on every CU at once and waits longer for them beside the other streams' tiles
+    # than two 256-workgroup launches do, and layer 1's weight gradients / update no longer run under layer 0's chain.  Off; EVC_L2_BWD_PAIR=1.
+    small_pair = os.environ.get("EVC_L2_BWD_PAIR", "0") == "1"
     timing = None      # set to a list to collect (start event, end event, launches, algorithmic flops) per layer forward
     timing_bwd = None  # set to {"bwd_step": [], "dx_nt": [], "wgrad_tn": []} to collect the same per backward launch sequence
 
@@ -366,7 +371,12 @@ class LstmStack:
         use_tn = (T * M) % 32 == 0 and all(k % 8 == 0 for k in self.kin)
         assert use_tn or not self.use_tn or M == self.M
         fuse_ok = L == 2 and self.bwd_wavefront and use_tn and not need_dx and M >= 1024 and H % 128 == 0
-        if fuse_ok and self.bwd_fuse == "pair":
+        # M ~ batch stacks (the L2 levels; round 5): BPTT in wavefront order on the skinny pair launches - layer 0's step t+1 (the gradient from
+        # layer 1 contracted in its own K walk) and layer 1's step t in ONE launch: T + 1 dependent launches instead of 2 T + the hoisted dX
+        # product of layer 1.  Not under EVC_DETERMINISTIC (the pair launches sum their bias gradients with atomics).  EVC_L2_BWD_PAIR=0: A/B.
+        small_pair = (L == 2 and self.small_pair and use_tn and M <= 512 and H % 128 == 0 and plan is None and not ops.DETERMINISTIC
+                      and self.dc_ws2 is not None)
+        if small_pair or (fuse_ok and self.bwd_fuse == "pair"):
             (k0, b0), (k1, b1) = self.names(0), self.names(1)
             dz = [self._v(self.dz[l], T, M, 4 * H) for l in range(2)]
             gb = [tw.store.g(b0), tw.store.g(b1)]
@@ -393,7 +403,14 @@ class LstmStack:
                     self._wgrad_tn(dz2, layer_in, h_prev, kin, T * M, gW)
                     if on_layer_grads is not None:
                         on_layer_grads(l)
-            return None
+            if need_dx:       # gradient wrt the stack's input (the L2 levels: it flows on into the L1 level's final states), from layer 0's dz alone
+                if self.dx[0] is None:
+                    self.dx[0] = torch.empty((T * M, self.kin[0]), dtype=F32, device=tw.device)
+                ops.gemm_nt(dz[0].view(T * M, 4 * H), tw.shadow_bwd[k0], T * M, self.kin[0], 4 * H, self.dx[0])
+                dx_out = self.dx[0]
+            yield 1
+            yield 0
+            return dx_out
         if fuse_ok and self.bwd_fuse == "fused" and on_layer_grads is not None:
             # the lower layer's steps read the upper layer's backward shadow (w_above): no layer may be updated before the end
             deferred, user_cb = [], on_layer_grads

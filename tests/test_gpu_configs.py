@@ -213,6 +213,46 @@ def test_deep_stacks_run_every_backward_phase(L, order, monkeypatch):
     assert g.global_step == 2 and all(np.isfinite(v) for v in g.loss_report().values())
 
 
+@pytest.mark.parametrize("B,H", [(8, 128), (40, 256)])
+def test_l2_level_bptt_wavefront_pair_launches_equal_the_layer_by_layer_chain(B, H):
+    """Round 5: the M ~ batch two-layer stacks (the L2 levels) run BPTT in wavefront order - layer 0's step t+1, with the gradient from
+    layer 1 contracted in its own K walk, and layer 1's step t in ONE launch of the skinny kernel (evc_lstm_stack2_bwd at M <= 512): T + 1
+    dependent launches instead of 2 T + a hoisted dX product.  Same batch, same weights, both forms: every gradient of both towers against
+    the float64 oracle and against each other (the layer-by-layer form rounds layer 1's dX to bf16 before layer 0 adds it, the pair form keeps
+    it in the f32 accumulator: they differ by that rounding, not more), and the L1 level's gradients - which take the L2 level's dX - too."""
+    from efficientvideoclassification_youtube8m_amd import smoke
+    from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
+    F, V = 128, 40
+    q, x, n, labels = mm.synthetic_batch(B, seed=21, feature_size=F, vocab_size=V, dtype=np.float32)
+    n[0], n[1] = 300, 7                                               # a full video and one that ends inside the first chunk
+    x[np.arange(300)[None, :] >= n[:, None]] = 0.0
+    g = DistillGraph(B, every_n=10, feature_size=F, vocab_size=V, lstm_cells=H, device=DEV, seed=4)
+    for tw in (g.teacher, g.student):
+        for k in tw.names:
+            if k.endswith("basic_lstm_cell/kernel"):
+                tw.store.p(k).mul_(1.5)
+        tw.refresh_shadows()
+    teacher, student = smoke.tower_params_numpy(g.teacher), smoke.tower_params_numpy(g.student)
+    ref = mm.teacher_student_step(x.astype(np.float64), n, labels, teacher, student, 10, with_grads=True)
+    got = {}
+    for pair in (True, False):
+        for tw in (g.teacher, g.student):
+            tw.l2.small_pair = pair                                   # (off by default: faster alone, slower inside the training step - engine.py)
+        g.step(*_dev(x, n, labels), apply=False, num_frames_host=n)
+        torch.cuda.synchronize()
+        got[pair] = {tw.scope: smoke.tower_grads_numpy(tw) for tw in (g.teacher, g.student)}
+    for tower, key in ((g.teacher, "teacher_grads"), (g.student, "student_grads")):
+        for k in got[True][tower.scope]:
+            gref = ref[key][k]
+            if k in ("classifier/gates/weights", "classifier/experts/weights"):
+                gref = gref - 2.0 * 1e-8 * smoke.tower_params_numpy(tower)[k]
+            a, b = got[True][tower.scope][k], got[False][tower.scope][k]
+            assert _rel2(a, gref) < 3e-2 and _rel2(b, gref) < 3e-2, (tower.scope, k, _rel2(a, gref), _rel2(b, gref))
+            assert _rel2(a, b) < 1e-2, (tower.scope, k, _rel2(a, b))
+            if "RNN_L2" in k:
+                assert _rel2(a, gref) < 1.5 * _rel2(b, gref) + 2e-3, (tower.scope, k, _rel2(a, gref), _rel2(b, gref))   # never worse than the form it replaces
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # cfg 2: teacher only
 # ---------------------------------------------------------------------------------------------------------------
