@@ -16,7 +16,7 @@ KERNELS = dict(a.split("=", 1) for a in sys.argv[3:]) or {
     "gemm_tn 256x256 (weight gradients)": "gemm_tn_kernel<TileCfg2<256",
     "gemm_nt 256x256 / 224x256 (dX, hoisted projections)": "gemm_nt_kernel<TileCfg3<2",
     "moe_update pass 2 (fused clip + Adam of the MoE weights)": "moe_update_kernel<TileCfg2<128, 1, 128, 2, 4, 5, true>, 2>",
-    "dbof_cluster_pool (DBoF cluster GEMM + statistics + selection)": "dbof_cluster_pool_kernel",
+    "dbof_cluster_pool (DBoF cluster GEMM + statistics + selection; round 5: the tile walk)": "dbof_cluster_pool_",
     "dbof_dact": "dbof_dact_kernel",
 }
 
