@@ -36,7 +36,7 @@ extern "C" {
 #define EVC_ERR_HIP (-4)
 #define EVC_ERR_BAD_ARG (-5)
 
-#define EVC_VERSION 103   /* 103 (round 4): evc_sqnorm2_partials, evc_lstm_adam_fused, evc_gram_slabs, evc_moe_grad_norms, evc_moe_grad_update_apply, evc_adam2d_fused, evc_colsum_bf16_det, evc_sample_sequence_gather, evc_relu6_fwd/bwd, evc_framepool_mean_fwd/bwd, evc_stream_create_cu_mask / evc_stream_destroy; EVC_DETERMINISTIC=1 read by the library; 102: evc_lstm_layer_fwd_f16_fp8lo, evc_lstm_stack2_fwd_f16_fp8lo, evc_gemm_nt_f16_fp8, evc_cast_f32_to_fp8_lo, evc_cast_f32_to_f16_fp8x, aux_mode 5, evc_moe_grad_update_wide; 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
+#define EVC_VERSION 104   /* 104 (round 5): no new entry points; evc_moe_grad_update* accept p_bf16 == NULL (forward shadow not written), evc_lstm_stack2_bwd runs M <= 512 stacks on the skinny pair launches, evc_dbof_cluster_pool_fwd walks tiles (EVC_DBOF_WALK), EVC_DETERMINISTIC parsed as "set, not empty, not 0"; 103 (round 4): evc_sqnorm2_partials, evc_lstm_adam_fused, evc_gram_slabs, evc_moe_grad_norms, evc_moe_grad_update_apply, evc_adam2d_fused, evc_colsum_bf16_det, evc_sample_sequence_gather, evc_relu6_fwd/bwd, evc_framepool_mean_fwd/bwd, evc_stream_create_cu_mask / evc_stream_destroy; EVC_DETERMINISTIC=1 read by the library; 102: evc_lstm_layer_fwd_f16_fp8lo, evc_lstm_stack2_fwd_f16_fp8lo, evc_gemm_nt_f16_fp8, evc_cast_f32_to_fp8_lo, evc_cast_f32_to_f16_fp8x, aux_mode 5, evc_moe_grad_update_wide; 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
 
 typedef uint16_t evc_bf16;
 typedef uint16_t evc_f16;   /* raw IEEE binary16 bits (the "high" precision forward operands of the L1 levels) */
@@ -486,7 +486,9 @@ int evc_framepool_max_bwd(const float* dpooled, const int32_t* argmax, int B, in
  * ([dz0 | dz1] . [Wh0 ; Wx1]^T, K = 8H) instead of a hoisted dX product.  No reference counterpart: tf.gradients of
  * cs/frame_level_models.py:221-257.  w_il0 [Kin0+H][4H], w_il1 [2H][4H] (backward layout, 4H gate-interleaved);
  * dS [M][4H] f32 = [c0 | h0 | c1 | h1]; dz0/dz1 [T][M][H][4] bf16 out; dc_ws0/1 [M][H] f32 scratch; db0/db1 [4H]
- * accumulated (zero them first); row_map / rows_per_step as in evc_lstm_layer_bwd.  H % 128 == 0. */
+ * accumulated (zero them first); row_map / rows_per_step as in evc_lstm_layer_bwd.  H % 128 == 0.
+ * M <= 512 (the M ~ batch stacks of the L2 levels; round 5): the same wavefront on the skinny kernel's pair launches (32 x 32 tiles, K split
+ * over four waves, 64 KB of LDS: two workgroups per CU); M > 512: 128 x 128 ring tiles. */
 int evc_lstm_stack2_bwd(const evc_bf16* w_il0, const evc_bf16* w_il1, const int32_t* len, int T, int M, int Kin0, int H,
                         const void* gates0, const evc_bf16* c_all0, const void* gates1, const evc_bf16* c_all1,
                         const float* dS, int64_t ld_dS, float* dc_ws0, float* dc_ws1, evc_bf16* dz0, evc_bf16* dz1,
@@ -520,7 +522,10 @@ int evc_dbof_input_bn_apply(const float* r, int B, int S, int F, const float* me
  *   xsel [B][C], arg [B][C]      per (video, cluster): the max over the sampled frames of sign(gamma)*act, stored as
  *                                the selected act itself, and its frame slot (first maximum wins)
  *   act [Mp][C] bf16             the activation for the backward pass (NULL: not kept).
- * r_bn_lo / wT_lo non-NULL: split-bf16 operands (hi.hi + hi.lo + lo.hi). */
+ * r_bn_lo / wT_lo non-NULL: split-bf16 operands (hi.hi + hi.lo + lo.hi).
+ * Plain operands and >= 512 output tiles (round 5): one workgroup per CU walks the row tiles of one column panel of wT (the next tile's first
+ * ring stages are issued under the current tile's epilogue; a panel is fetched by one XCD's L2) - the same arithmetic in the same order as one
+ * tile per workgroup, bit-identical results; EVC_DBOF_WALK=0 switches it off, 2 forces it at any tile count (tests). */
 int evc_dbof_cluster_pool_fwd(const evc_bf16* r_bn, const evc_bf16* r_bn_lo, const evc_bf16* wT, const evc_bf16* wT_lo,
                               int B, int S, int F, int C, const float* gamma, evc_bf16* act, float* part, float* xsel,
                               uint8_t* arg, void* stream);
