@@ -250,7 +250,7 @@ def run_hlstm(device, rank, world, B, mode, every_n, steps, warmup, all_full=Fal
             for (m, nl, fl) in tower.l1.profile_fwd_layers(reps=3):
                 ms_i, launches_i, flops_i = ms_i + m, launches_i + nl, flops_i + fl
         traffic = mfma_busy = pmc_src = None
-        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):    # HBM bytes / MFMA busy from the committed --pmc passes
+        for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):    # HBM bytes / MFMA busy from the committed --pmc passes
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     pmc = json.load(f)
@@ -377,7 +377,9 @@ def run_dbof(device, rank, world, B, steps, warmup, pool=4, precision="bf16"):
         ms = sum(e0.elapsed_time(e1) for e0, e1 in timing) / len(timing)
         flops = 2.0 * B * 30 * F_FEAT * 8192
         ach = flops / (ms * 1e-3) / 1e12
-        res["roofline"] = {"bound": "mfma", "kernel": "dbof_cluster_pool_kernel (cluster GEMM + BN statistics + per-video max/min)",
+        res["roofline"] = {"bound": "mfma", "kernel": ("dbof_cluster_pool_walk_kernel (cluster GEMM + BN statistics + per-video max/min; one workgroup per CU walks the row "
+                                                       "tiles of one W_c column panel)" if precision == "bf16" else
+                                                       "dbof_cluster_pool_kernel<FP8> (f16 stages + e4m3 correction stages, cluster GEMM + BN statistics + per-video max/min)"),
                            "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                            "traffic": None, "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(flops / 1e9, 2)}
     del graph, tw, pool_in
