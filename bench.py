@@ -263,8 +263,11 @@ def run_hlstm(device, rank, world, B, mode, every_n, steps, warmup, all_full=Fal
         achieved = flops / (ms * 1e-3) / 1e12
         f16 = precision != "bf16"
         res["roofline"] = {
-            "bound": "mfma", "kernel": ("lstm_fwd_step_kernel<TileCfg3<BM,4,64,2,4,2>%s> (teacher L1; BM = 224..256 per launch, TileCfg2 for 288/320, from the "
-                                        "active rows)" % (", F16" if f16 else "")) if graph.teacher is not None else "lstm_fwd_step_kernel (student L1)",
+            "bound": "mfma", "kernel": (("lstm_fwd_walk2_kernel<TileCfg3<BM,4,64,2,4,2>> (teacher L1; one launch = layer 0's step s + layer 1's step s-1, every workgroup walks "
+                                         "both tiles; BM = 224..256 per launch from the active rows; lstm_fwd_step_kernel for 288/320-row launches)")
+                                        if (not f16 and getattr(l1_stack, "fwd_walk2", False) and l1_stack.L == 2) else
+                                        ("lstm_fwd_step_kernel<TileCfg3<BM,4,64,2,4,2>%s> (teacher L1; BM = 224..256 per launch, TileCfg2 for 288/320, from the "
+                                         "active rows)" % (", F16" if f16 else ""))) if graph.teacher is not None else "lstm_fwd_step_kernel (student L1)",
             "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
             "traffic": None if f16 else traffic, "traffic_source": None if f16 else pmc_src, "mfma_busy_pmc": None if f16 else mfma_busy,
             "avg_launch_ms": round(ms / launches, 4),

@@ -42,6 +42,7 @@ SIGNATURES = {
     "evc_lstm_stack2_fwd_f16": [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp],
     "evc_cast_f32_to_f16_segs": [vp, i64, i32, i32, i32, vp, vp],
     "evc_cast_f32_to_f16_wlo": [vp, i64, i32, i32, i32, vp, vp],
+    "evc_lstm_level2_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp],
     "evc_lstm_stack2_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp],
     "evc_moe_grad_update": [vp, i64, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, i64, f32, vp, vp, f32, f32, f32, f32, f32, vp],
     "evc_moe_grad_update_wide": [vp, i64, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, f32, vp, vp, f32, f32, f32, f32, f32, vp],

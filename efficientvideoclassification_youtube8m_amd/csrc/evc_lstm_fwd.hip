@@ -26,20 +26,11 @@ struct LstmFwdParams {
 // F16: the operands (x_t, h_{t-1}, W) are IEEE f16 and ONE v_mfma_f32_16x16x32_f16 product is issued per depth - the cost of
 // the bf16 step with 8x smaller operand rounding; h_t leaves twice, as f16 (next step's / next layer's operand) and as bf16
 // (what the BPTT products contract over).
-template <class Cfg, bool SPLIT = false, bool F16 = false, bool FP8 = false>
-__device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const LstmFwdParams& e, int tiles_m, int tiles_n, int bid) {
-  static_assert(Cfg::G == 4, "LSTM step needs the four gate groups");
-  static_assert(!(SPLIT && F16), "split operands are bf16 halves");
-  static_assert(!FP8 || (F16 && is_v3<Cfg>::value), "the e4m3 tail rides behind f16 stages of the 64-wide ring loop");
-  const int nwg = tiles_m * tiles_n;
-  EVC_STAMP(p.stamp_slot, 0);
-  const int id = xcd_remap(bid, nwg);
-  int tm, tn;
-  tile_of(id, tiles_m, tiles_n, tm, tn);
-  const int m0 = tm * Cfg::BM, u0 = tn * Cfg::BU;
-  f32x4 acc[Cfg::MI][4][Cfg::NI];
-  {   // the accumulators start from bias (+ forget_bias 1.0): its loads fly under the loop's prologue, and the tail
-      // below has no load left that hipcc could re-issue between the fragments' stores
+// the accumulators start from bias (+ forget_bias 1.0): its loads fly under the loop's prologue, and the tail
+// has no load left that hipcc could re-issue between the fragments' stores
+template <class Cfg>
+__device__ __forceinline__ void lstm_fwd_acc_bias(const LstmFwdParams& e, const int u0, f32x4 (&acc)[Cfg::MI][4][Cfg::NI]) {
+  {
     TileCoordsT<Cfg> tc0;
 #pragma unroll
     for (int ni = 0; ni < Cfg::NI; ++ni) {
@@ -53,11 +44,12 @@ __device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const 
       }
     }
   }
-  // (SPLIT: the split-bf16 products hi.hi + hi.lo + lo.hi are a K-EXTENSION of the same loop - the caller hands A = [lo | hi] rows
-  //  against B = [W_hi | W_lo] rows as segment 1 and A = hi against B2 = W_hi as segment 2, evc_lstm_layer_fwd_hp - so the loop
-  //  itself is the plain one; only the epilogue differs: it writes h_t's wide [lo | hi] image for the next step.)
-  run_mainloop<Cfg, 4, true, false, EVC_FWD_LOOP_MODE | (F16 ? LOOP_F16 : 0) | (FP8 ? LOOP_FP8_TAIL : 0)>(p, m0, u0, acc);   // transposed accumulators: lane = one row, 4 consecutive units
-  EVC_STAMP(p.stamp_slot, 2);
+}
+
+// gate tail of one tile: sigma / tanh, c' = c f + i j, h' = tanh(c') o, masking, the stores (transposed accumulators: lane = one row, 4 units)
+template <class Cfg, bool SPLIT, bool F16, bool FP8>
+__device__ __forceinline__ void lstm_fwd_epilogue(const GemmOperands& p, const LstmFwdParams& e, const int m0, const int u0,
+                                                  f32x4 (&acc)[Cfg::MI][4][Cfg::NI]) {
 #ifdef EVC_ABLATE_EPI    // debug build: main loop only (keep the accumulators alive, store nothing)
 #pragma unroll
   for (int mi = 0; mi < Cfg::MI; ++mi)
@@ -185,6 +177,63 @@ __device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const 
   EVC_STAMP(p.stamp_slot, 5);
 #endif
 }
+
+template <class Cfg, bool SPLIT = false, bool F16 = false, bool FP8 = false>
+__device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const LstmFwdParams& e, int tiles_m, int tiles_n, int bid) {
+  static_assert(Cfg::G == 4, "LSTM step needs the four gate groups");
+  static_assert(!(SPLIT && F16), "split operands are bf16 halves");
+  static_assert(!FP8 || (F16 && is_v3<Cfg>::value), "the e4m3 tail rides behind f16 stages of the 64-wide ring loop");
+  const int nwg = tiles_m * tiles_n;
+  EVC_STAMP(p.stamp_slot, 0);
+  const int id = xcd_remap(bid, nwg);
+  int tm, tn;
+  tile_of(id, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * Cfg::BM, u0 = tn * Cfg::BU;
+  f32x4 acc[Cfg::MI][4][Cfg::NI];
+  lstm_fwd_acc_bias<Cfg>(e, u0, acc);
+  // (SPLIT: the split-bf16 products hi.hi + hi.lo + lo.hi are a K-EXTENSION of the same loop - the caller hands A = [lo | hi] rows
+  //  against B = [W_hi | W_lo] rows as segment 1 and A = hi against B2 = W_hi as segment 2, evc_lstm_layer_fwd_hp - so the loop
+  //  itself is the plain one; only the epilogue differs: it writes h_t's wide [lo | hi] image for the next step.)
+  run_mainloop<Cfg, 4, true, false, EVC_FWD_LOOP_MODE | (F16 ? LOOP_F16 : 0) | (FP8 ? LOOP_FP8_TAIL : 0)>(p, m0, u0, acc);   // transposed accumulators: lane = one row, 4 consecutive units
+  EVC_STAMP(p.stamp_slot, 2);
+  lstm_fwd_epilogue<Cfg, SPLIT, F16, FP8>(p, e, m0, u0, acc);
+}
+
+// Two tiles per workgroup (round 5; bf16, the 64-wide ring tiles): layer 0's step s and layer 1's step s-1 of a two-layer L1 level are
+// independent, so one launch runs both - every workgroup computes tile (tm, tn) of step a, then the same tile of step b.  Once every wave
+// has left the ring, the first stages of tile b are issued (gemm_mainloop_v3 PHASE 1) and land under tile a's gate tail (which needs no
+// LDS); tile b's loop starts on them (PHASE 2).  Per pair of steps that is one ring fill and one kernel boundary less.
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT) void lstm_fwd_walk2_kernel(GemmOperands pa, LstmFwdParams ea, int tiles_ma, GemmOperands pb, LstmFwdParams eb,
+                                                                 int tiles_mb, int tiles_n) {
+  static_assert(is_v3<Cfg>::value && Cfg::G == 4, "tile walk: the 64-wide ring tiles");
+  constexpr int MODE = EVC_FWD_LOOP_MODE;
+  const int tiles_m = tiles_ma > tiles_mb ? tiles_ma : tiles_mb;
+  const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  int tm, tn;
+  tile_of(id, tiles_m, tiles_n, tm, tn);
+  const int m0 = tm * Cfg::BM, u0 = tn * Cfg::BU;
+  const bool has_a = tm < tiles_ma, has_b = tm < tiles_mb;          // workgroup-uniform
+  f32x4 acc[Cfg::MI][4][Cfg::NI];
+  if (has_a) {
+    lstm_fwd_acc_bias<Cfg>(ea, u0, acc);
+    gemm_mainloop_v3<Cfg, true, false, MODE, 0>(pa, m0, u0, lds_dyn, acc);
+    if (has_b) {
+      __syncthreads();                                              // every wave has read its last ring slot
+      gemm_mainloop_v3<Cfg, true, false, MODE, 1>(pb, m0, u0, lds_dyn, acc);
+    }
+    lstm_fwd_epilogue<Cfg, false, false, false>(pa, ea, m0, u0, acc);
+    if (has_b) {
+      lstm_fwd_acc_bias<Cfg>(eb, u0, acc);
+      gemm_mainloop_v3<Cfg, true, false, MODE, 2>(pb, m0, u0, lds_dyn, acc);
+      lstm_fwd_epilogue<Cfg, false, false, false>(pb, eb, m0, u0, acc);
+    }
+  } else if (has_b) {
+    lstm_fwd_acc_bias<Cfg>(eb, u0, acc);
+    gemm_mainloop_v3<Cfg, true, false, MODE, 0>(pb, m0, u0, lds_dyn, acc);
+    lstm_fwd_epilogue<Cfg, false, false, false>(pb, eb, m0, u0, acc);
+  }
+}
 #ifdef EVC_STAMPS
 extern "C" int evc_debug_read_stamps(unsigned long long* out) {     // out: [8][512][8]
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(evc_stamps), sizeof(unsigned long long) * 8 * 512 * 8) == hipSuccess ? 0 : 1;
@@ -264,6 +313,25 @@ static inline int pick_fwd_tile(int rows, int H) {
   const int f = forced_tile();        // debug: 1 -> 256, 2 -> v1 128, 3 -> v1 64, 4 -> 320, 5 -> 288, 6 -> 224, 7 -> 192, 8 -> 160, 9 -> v2 128, 10 -> v2 64, 11 -> 240
   if (f) { static const int map[12] = {0, 2, 6, 7, 0, 1, 3, 4, 5, 8, 9, 10}; best = map[f < 12 ? f : 0]; }
   return best;
+}
+
+// one bf16 forward step on the tile the cost model picks for Mt rows
+static inline void launch_fwd_step_bf16(const GemmOperands& p, const LstmFwdParams& e, int k1, int k2, int Mt, int H, hipStream_t st) {
+  static const bool uneven224 = getenv("EVC_FWD_EVEN_224") == nullptr;      // the 224-row tile as 6 + 8 row fragments (A/B switch: 7 + 7; 58.3 -> 58.0 us per launch)
+  static const bool fwd_v2 = getenv("EVC_FWD_V2_LOOP") != nullptr;          // A/B: the 32-wide K stages for the 160-256-row tiles
+  switch (pick_fwd_tile(Mt, H)) {
+    case 0: launch_lstm_fwd<CfgLstmV2a>(p, e, k1, k2, st); break;
+    case 1: launch_lstm_fwd<CfgLstmV2_288>(p, e, k1, k2, st); break;
+    case 2: if (fwd_v2) launch_lstm_fwd<CfgLstmV2b>(p, e, k1, k2, st); else launch_lstm_fwd<CfgLstmV3_256>(p, e, k1, k2, st); break;
+    case 3: if (fwd_v2) launch_lstm_fwd<CfgLstmV2_224>(p, e, k1, k2, st); else if (uneven224) launch_lstm_fwd<CfgLstmV3_224u>(p, e, k1, k2, st); else launch_lstm_fwd<CfgLstmV3_224>(p, e, k1, k2, st); break;
+    case 10: launch_lstm_fwd<CfgLstmV3_240>(p, e, k1, k2, st); break;
+    case 4: if (fwd_v2) launch_lstm_fwd<CfgLstmV2_192>(p, e, k1, k2, st); else launch_lstm_fwd<CfgLstmV3_192>(p, e, k1, k2, st); break;
+    case 5: if (fwd_v2) launch_lstm_fwd<CfgLstmV2_160>(p, e, k1, k2, st); else launch_lstm_fwd<CfgLstmV3_160>(p, e, k1, k2, st); break;
+    case 6: launch_lstm_fwd<CfgLstmBig>(p, e, k1, k2, st); break;
+    case 8: launch_lstm_fwd<CfgLstmV2_128>(p, e, k1, k2, st); break;
+    case 9: launch_lstm_fwd<CfgLstmV2_64>(p, e, k1, k2, st); break;
+    default: launch_lstm_fwd<CfgLstmSmall>(p, e, k1, k2, st); break;
+  }
 }
 
 static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const float* bias, const int32_t* len,
@@ -372,20 +440,96 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
       }
       continue;
     }
-    static const bool fwd_v2 = getenv("EVC_FWD_V2_LOOP") != nullptr;      // A/B: the 32-wide K stages for the 160-256-row tiles
-    switch (pick_fwd_tile(Mt, H)) {
-      case 0: launch_lstm_fwd<CfgLstmV2a>(p, e, k1, k2, st); break;
-      case 1: launch_lstm_fwd<CfgLstmV2_288>(p, e, k1, k2, st); break;
-      case 2: if (fwd_v2) launch_lstm_fwd<CfgLstmV2b>(p, e, k1, k2, st); else launch_lstm_fwd<CfgLstmV3_256>(p, e, k1, k2, st); break;
-      case 3: if (fwd_v2) launch_lstm_fwd<CfgLstmV2_224>(p, e, k1, k2, st); else if (uneven224) launch_lstm_fwd<CfgLstmV3_224u>(p, e, k1, k2, st); else launch_lstm_fwd<CfgLstmV3_224>(p, e, k1, k2, st); break;
-      case 10: launch_lstm_fwd<CfgLstmV3_240>(p, e, k1, k2, st); break;
-      case 4: if (fwd_v2) launch_lstm_fwd<CfgLstmV2_192>(p, e, k1, k2, st); else launch_lstm_fwd<CfgLstmV3_192>(p, e, k1, k2, st); break;
-      case 5: if (fwd_v2) launch_lstm_fwd<CfgLstmV2_160>(p, e, k1, k2, st); else launch_lstm_fwd<CfgLstmV3_160>(p, e, k1, k2, st); break;
-      case 6: launch_lstm_fwd<CfgLstmBig>(p, e, k1, k2, st); break;
-      case 8: launch_lstm_fwd<CfgLstmV2_128>(p, e, k1, k2, st); break;
-      case 9: launch_lstm_fwd<CfgLstmV2_64>(p, e, k1, k2, st); break;
-      default: launch_lstm_fwd<CfgLstmSmall>(p, e, k1, k2, st); break;
+    launch_fwd_step_bf16(p, e, k1, k2, Mt, H, st);
+  }
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// ===========================================================================
+// Two-layer L1 level (many rows, row plans), bf16: layer 0's step s and layer 1's step s-1 in ONE launch whose workgroups walk both tiles
+// (lstm_fwd_walk2_kernel) - T + 1 launches instead of 2 T, one ring fill and one kernel boundary less per pair of steps; both layers contract
+// [x_t | h_{t-1}] . W^T in one K walk (layer 1's x_t is layer 0's output slab).  Same arithmetic as two evc_lstm_layer_fwd calls: bit-identical
+// results.  Launches whose tile is not one of the 64-wide ring tiles (224 / 240 / 256 rows) run as two separate launches.
+// ===========================================================================
+template <class Cfg>
+static inline void launch_lstm_fwd_walk2(GemmOperands pa, const LstmFwdParams& ea, int k1a, int k2a, GemmOperands pb, const LstmFwdParams& eb,
+                                         int k1b, int k2b, hipStream_t st) {
+  pa.nk1 = k1a / 64; pa.nk2 = k2a / 64;
+  pb.nk1 = k1b / 64; pb.nk2 = k2b / 64;
+  const int tma = ceil_div(ea.M, Cfg::BM), tmb = ceil_div(eb.M, Cfg::BM), tn = ceil_div(ea.H, Cfg::BU);
+  launch_cfg<Cfg>(lstm_fwd_walk2_kernel<Cfg>, (tma > tmb ? tma : tmb) * tn, st, pa, ea, tma, pb, eb, tmb, tn);
+}
+
+extern "C" int evc_lstm_level2_fwd(const evc_bf16* x, const evc_bf16* wT0, const float* bias0, const evc_bf16* wT1, const float* bias1,
+                                   const int32_t* len, int T, int M, int Kin, int H, evc_bf16* hbuf0, evc_bf16* hbuf1,
+                                   float* c_state0, float* h_state0, float* c_state1, float* h_state1, int64_t ld_state,
+                                   void* gates0, evc_bf16* c_all0, void* gates1, evc_bf16* c_all1,
+                                   const int32_t* row_map, const int32_t* rows_per_step, void* stream) {
+  EVC_REQUIRE(T > 0 && M > 0 && H > 0 && Kin > 0 && Kin % 64 == 0 && H % 64 == 0, EVC_ERR_BAD_SHAPE,
+              "evc_lstm_level2_fwd: bad shape T=%d M=%d Kin=%d H=%d (Kin, H multiples of 64)", T, M, Kin, H);
+  EVC_REQUIRE(ring_operand_ok(M, Kin > H ? Kin : H) && ring_operand_ok(4L * H, (long)Kin + H) && ring_operand_ok(4L * H, 2L * H), EVC_ERR_BAD_SHAPE,
+              "evc_lstm_level2_fwd: a time slab or a kernel spans 4 GiB or more (M=%d Kin=%d H=%d)", M, Kin, H);
+  EVC_REQUIRE(fwd_tail_ok(M, H, ld_state), EVC_ERR_BAD_SHAPE, "LSTM forward: a gate-record / state slab spans 4 GiB or more (M=%d H=%d ld_state=%ld)", M, H, (long)ld_state);
+  EVC_REQUIRE(x && wT0 && wT1 && bias0 && bias1 && len && hbuf0 && hbuf1 && c_state0 && h_state0 && c_state1 && h_state1, EVC_ERR_BAD_ARG,
+              "evc_lstm_level2_fwd: NULL operand");
+  EVC_REQUIRE(ld_state % 4 == 0 && ((uintptr_t)c_state0 % 16) == 0 && ((uintptr_t)h_state0 % 16) == 0 && ((uintptr_t)c_state1 % 16) == 0 &&
+              ((uintptr_t)h_state1 % 16) == 0 && ((uintptr_t)bias0 % 16) == 0 && ((uintptr_t)bias1 % 16) == 0 &&
+              ((uintptr_t)hbuf0 % 8) == 0 && ((uintptr_t)hbuf1 % 8) == 0, EVC_ERR_BAD_ALIGN,
+              "evc_lstm_level2_fwd: state/bias/hbuf must allow 16-byte vector access");
+  EVC_REQUIRE((gates0 == nullptr) == (c_all0 == nullptr) && (gates1 == nullptr) == (c_all1 == nullptr) && (gates0 == nullptr) == (gates1 == nullptr),
+              EVC_ERR_BAD_ARG, "evc_lstm_level2_fwd: gates and c_all go together, for both layers");
+  EVC_REQUIRE(!gates0 || (((uintptr_t)gates0 % 16) == 0 && ((uintptr_t)gates1 % 16) == 0 && ((uintptr_t)c_all0 % 8) == 0 && ((uintptr_t)c_all1 % 8) == 0),
+              EVC_ERR_BAD_ALIGN, "evc_lstm_level2_fwd: gates must be 16-byte, c_all 8-byte aligned");
+  if (rows_per_step)
+    for (int t = 0; t < T; ++t)
+      EVC_REQUIRE(rows_per_step[t] >= 0 && rows_per_step[t] <= M && (t == 0 || rows_per_step[t] <= rows_per_step[t - 1]), EVC_ERR_BAD_ARG,
+                  "evc_lstm_level2_fwd: rows_per_step[%d]=%d must be non-increasing and within [0, M=%d]", t, rows_per_step[t], M);
+  hipStream_t st = (hipStream_t)stream;
+  EVC_CHECK_HIP(hipMemsetAsync(hbuf0, 0, (size_t)M * H * sizeof(bf16_t), st));       // h_{-1} = 0, both layers
+  EVC_CHECK_HIP(hipMemsetAsync(hbuf1, 0, (size_t)M * H * sizeof(bf16_t), st));
+  static const bool uneven224 = getenv("EVC_FWD_EVEN_224") == nullptr;
+  auto step_args = [&](int layer, int t, GemmOperands& p, LstmFwdParams& e, int& k1, int& k2) {
+    const int kin = layer ? H : Kin;
+    const evc_bf16* xin = layer ? hbuf0 + (long)(t + 1) * M * H : x + (long)t * M * Kin;        // layer 1's x_t = layer 0's output slab t+1
+    evc_bf16* hb = layer ? hbuf1 : hbuf0;
+    p = GemmOperands();
+    p.M = rows_per_step ? rows_per_step[t] : M; p.Nu = H; p.group_stride = H; p.ldb = (long)kin + H; p.nk1 = p.nk2 = 0;
+    p.A1lo = p.A2lo = p.Blo = nullptr;
+    p.A1 = xin; p.lda1 = kin; k1 = kin;
+    p.A2 = hb + (long)t * M * H; p.lda2 = H; k2 = (t == 0) ? 0 : H;
+    p.B = layer ? wT1 : wT0;
+    e = LstmFwdParams();
+    e.zx = nullptr; e.ldzx = 4L * H;
+    e.bias = layer ? bias1 : bias0; e.len = len; e.t = t;
+    e.c_state = layer ? c_state1 : c_state0; e.h_state = layer ? h_state1 : h_state0; e.ld_state = ld_state;
+    e.hout = hb + (long)(t + 1) * M * H; e.h_wide = 0; e.hout_lo = nullptr;
+    void* gt = layer ? gates1 : gates0;
+    evc_bf16* ca = layer ? c_all1 : c_all0;
+    e.gates = gt ? (uint2*)gt + (long)t * M * H : nullptr;
+    e.c_hist = ca ? ca + (long)(t + 1) * M * H : nullptr;
+    e.row_map = row_map;
+    e.M = p.M; e.H = H;
+  };
+  for (int s = 0; s <= T; ++s) {
+    GemmOperands pa, pb;
+    LstmFwdParams ea, eb;
+    int k1a = 0, k2a = 0, k1b = 0, k2b = 0;
+    bool has_a = s < T, has_b = s >= 1;
+    if (has_a) { step_args(0, s, pa, ea, k1a, k2a); has_a = ea.M > 0; }
+    if (has_b) { step_args(1, s - 1, pb, eb, k1b, k2b); has_b = eb.M > 0; }
+    if (has_a && has_b) {
+      const int pick = pick_fwd_tile(eb.M, H);                       // layer 1 runs the earlier step: at least as many rows as layer 0
+      if (pick == 2) { launch_lstm_fwd_walk2<CfgLstmV3_256>(pa, ea, k1a, k2a, pb, eb, k1b, k2b, st); continue; }
+      if (pick == 10) { launch_lstm_fwd_walk2<CfgLstmV3_240>(pa, ea, k1a, k2a, pb, eb, k1b, k2b, st); continue; }
+      if (pick == 3) {
+        if (uneven224) launch_lstm_fwd_walk2<CfgLstmV3_224u>(pa, ea, k1a, k2a, pb, eb, k1b, k2b, st);
+        else launch_lstm_fwd_walk2<CfgLstmV3_224>(pa, ea, k1a, k2a, pb, eb, k1b, k2b, st);
+        continue;
+      }
     }
+    if (has_a) launch_fwd_step_bf16(pa, ea, k1a, k2a, ea.M, H, st);
+    if (has_b) launch_fwd_step_bf16(pb, eb, k1b, k2b, eb.M, H, st);
   }
   EVC_LAUNCH_CHECK();
   return EVC_OK;

@@ -117,6 +117,7 @@ class LstmStack:
         return base + "kernel", base + "bias"
 
     wavefront = os.environ.get("EVC_NO_WAVEFRONT") != "1"   # two-layer M ~ batch stacks: see forward()
+    fwd_walk2 = os.environ.get("EVC_FWD_WALK2", "1") != "0"   # two-layer many-row stacks (bf16): two tiles per workgroup, T + 1 launches (A/B: 0)
     # two-layer stacks with many rows (the L1 levels), the gradient arriving at layer 0 from layer 1:
     #   "off"   (default) one hoisted dX = dz1 . Wx1^T product over all T (bf16 result, re-read by layer 0's steps);
     #   "fused" contracted inside layer 0's BPTT steps (two-matrix K walk, K = 8H, f32 accumulator);
@@ -280,6 +281,22 @@ class LstmStack:
             ops.lstm_stack2_fwd(x, tw.shadow_fwd[k0], tw.store.p(b0), tw.shadow_fwd[k1], tw.store.p(b1), lens, T, M,
                                 self.Kin, H, self.zx, hb[0], hb[1], self.S, gates, c_all)
             return self.S
+        if L == 2 and self.fwd_walk2 and not any(self.hoist) and self.Kin % 64 == 0 and H % 64 == 0:
+            # many-row two-layer levels (L1; round 5): layer 0's step s and layer 1's step s-1 in one launch whose workgroups walk both tiles
+            # (ops.lstm_level2_fwd): T + 1 launches instead of 2 T, the second tile's ring fill under the first tile's gate tail; same bits
+            (k0, b0), (k1, b1) = self.names(0), self.names(1)
+            if self.timing is not None:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+            ops.lstm_level2_fwd(x, tw.shadow_fwd[k0], tw.store.p(b0), tw.shadow_fwd[k1], tw.store.p(b1), lens, T, M, self.Kin, H,
+                                hb[0], hb[1], self.S, gates, c_all, plan=plan)
+            if self.timing is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                flops = sum(2.0 * r * 4 * H * (self.kin[l] + (H if t > 0 else 0)) for l in range(2) for t, r in enumerate(rows))
+                live = sum(1 for r in rows if r > 0)
+                self.timing.append((e0, e1, live + 1 if live else 0, flops))
+            return self.S
         for l in range(L):
             kn, bn = self.names(l)
             if self.timing is not None:                         # bench.py: live timing of the step launches of each layer
@@ -306,6 +323,22 @@ class LstmStack:
         rows = plan.rows if plan is not None else [M] * T
         res = []
         inp = self.x_in
+        if self.L == 2 and self.fwd_walk2 and not any(self.hoist) and self.Kin % 64 == 0 and H % 64 == 0:      # the launches forward() issues: the two-tile walk
+            (k0, b0), (k1, b1) = self.names(0), self.names(1)
+            gates = [self._v(self.gates[l], T, M, H, 2) if self.training else None for l in range(2)]
+            c_all = [self._v(self.c_all[l], T + 1, M, H) if self.training else None for l in range(2)]
+            args = (inp, tw.shadow_fwd[k0], tw.store.p(b0), tw.shadow_fwd[k1], tw.store.p(b1), self.lens, T, M, self.Kin, H, self._hb[0], self._hb[1],
+                    self.S, gates, c_all)
+            ops.lstm_level2_fwd(*args, plan=plan)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                ops.lstm_level2_fwd(*args, plan=plan)
+            e1.record()
+            e1.synchronize()
+            flops = sum(2.0 * r * 4 * H * (self.kin[l] + (H if t > 0 else 0)) for l in range(2) for t, r in enumerate(rows))
+            live = sum(1 for r in rows if r > 0)
+            return [(e0.elapsed_time(e1) / reps, live + 1 if live else 0, flops)]
         for l in range(self.L):
             kn, bn = self.names(l)
             gates = self._v(self.gates[l], T, M, H, 2) if self.training else None

@@ -346,6 +346,15 @@ def lstm_layer_fwd_f16_fp8lo(x16, ldx, kx16, x8_off, kx8, wT16, wT8, bias, lens,
               _p(hbuf16), _p(hbuf_bf), _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_all), *_plan_args(plan), _stream())
 
 
+def lstm_level2_fwd(x, wT0, bias0, wT1, bias1, lens, T, M, Kin, H, hbuf0, hbuf1, S, gates=(None, None), c_all=(None, None), plan=None):
+    """Two-layer L1 level in bf16, layer 0's step s and layer 1's step s-1 per launch (evc_lstm_level2_fwd): the results of two
+    lstm_layer_fwd calls, bit for bit.  S [rows][4H] f32 = [c0 | h0 | c1 | h1]; with a RowPlan M = plan.P, lens = plan.lens."""
+    assert x.dtype == BF16 and wT0.dtype == BF16 and wT1.dtype == BF16 and hbuf0.dtype == BF16 and hbuf1.dtype == BF16
+    _lib.call("evc_lstm_level2_fwd", _p(x), _p(wT0), _p(bias0), _p(wT1), _p(bias1), _p(lens), T, M, Kin, H, _p(hbuf0), _p(hbuf1),
+              _p(S[:, 0:]), _p(S[:, H:]), _p(S[:, 2 * H:]), _p(S[:, 3 * H:]), S.stride(0),
+              _p(gates[0]), _p(c_all[0]), _p(gates[1]), _p(c_all[1]), *_plan_args(plan), _stream())
+
+
 def lstm_stack2_fwd(x, wT0, bias0, wT1, bias1, lens, T, M, Kin, H, zx_ws, hbuf0, hbuf1, S, gates=(None, None), c_all=(None, None)):
     """Two-layer stack, M ~ batch rows, wavefront order (evc_lstm_stack2_fwd).  S [M][4H] f32 = [c0 | h0 | c1 | h1]."""
     _lib.call("evc_lstm_stack2_fwd", _p(x), _p(wT0), _p(bias0), _p(wT1), _p(bias1), _p(lens), T, M, Kin, H, _p(zx_ws),

@@ -36,7 +36,7 @@ extern "C" {
 #define EVC_ERR_HIP (-4)
 #define EVC_ERR_BAD_ARG (-5)
 
-#define EVC_VERSION 104   /* 104 (round 5): no new entry points; evc_moe_grad_update* accept p_bf16 == NULL (forward shadow not written), evc_lstm_stack2_bwd runs M <= 512 stacks on the skinny pair launches, evc_dbof_cluster_pool_fwd walks tiles (EVC_DBOF_WALK), EVC_DETERMINISTIC parsed as "set, not empty, not 0"; 103 (round 4): evc_sqnorm2_partials, evc_lstm_adam_fused, evc_gram_slabs, evc_moe_grad_norms, evc_moe_grad_update_apply, evc_adam2d_fused, evc_colsum_bf16_det, evc_sample_sequence_gather, evc_relu6_fwd/bwd, evc_framepool_mean_fwd/bwd, evc_stream_create_cu_mask / evc_stream_destroy; EVC_DETERMINISTIC=1 read by the library; 102: evc_lstm_layer_fwd_f16_fp8lo, evc_lstm_stack2_fwd_f16_fp8lo, evc_gemm_nt_f16_fp8, evc_cast_f32_to_fp8_lo, evc_cast_f32_to_f16_fp8x, aux_mode 5, evc_moe_grad_update_wide; 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
+#define EVC_VERSION 104   /* 104 (round 5): evc_lstm_level2_fwd; evc_moe_grad_update* accept p_bf16 == NULL (forward shadow not written), evc_lstm_stack2_bwd runs M <= 512 stacks on the skinny pair launches, evc_dbof_cluster_pool_fwd walks tiles (EVC_DBOF_WALK), EVC_DETERMINISTIC parsed as "set, not empty, not 0"; 103 (round 4): evc_sqnorm2_partials, evc_lstm_adam_fused, evc_gram_slabs, evc_moe_grad_norms, evc_moe_grad_update_apply, evc_adam2d_fused, evc_colsum_bf16_det, evc_sample_sequence_gather, evc_relu6_fwd/bwd, evc_framepool_mean_fwd/bwd, evc_stream_create_cu_mask / evc_stream_destroy; EVC_DETERMINISTIC=1 read by the library; 102: evc_lstm_layer_fwd_f16_fp8lo, evc_lstm_stack2_fwd_f16_fp8lo, evc_gemm_nt_f16_fp8, evc_cast_f32_to_fp8_lo, evc_cast_f32_to_f16_fp8x, aux_mode 5, evc_moe_grad_update_wide; 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
 
 typedef uint16_t evc_bf16;
 typedef uint16_t evc_f16;   /* raw IEEE binary16 bits (the "high" precision forward operands of the L1 levels) */
@@ -480,6 +480,18 @@ int evc_bn_relu6_framepool_fwd(const float* act, int B, int S, int C, const floa
 int evc_framepool_max_fwd(const float* y, int B, int S, int C, float* pooled_f32, evc_bf16* pooled_bf16,
                           int32_t* argmax, void* stream);
 int evc_framepool_max_bwd(const float* dpooled, const int32_t* argmax, int B, int S, int C, float* dy, void* stream);
+
+/* Two-layer L1 level (many rows, row plans), bf16 - HierarchicalLstmModel's MultiRNNCell of two BasicLSTMCells over one chunk of frames
+ * (cs/frame_level_models.py:221-257, tf.nn.dynamic_rnn :247,255): what two evc_lstm_layer_fwd calls compute (layer 1 reading layer 0's output
+ * slabs), as T + 1 launches - layer 0's step s and layer 1's step s-1 are independent, every workgroup walks both tiles and the second tile's
+ * first ring stages are issued under the first tile's gate tail.  Bit-identical results.  x [T][M][Kin], hbuf0 / hbuf1 [(T+1)][M][H] (slab 0 is
+ * zeroed here), states as in evc_lstm_layer_fwd with the two layers' c / h columns, gates / c_all per layer or all NULL (evaluation),
+ * row_map / rows_per_step as in evc_lstm_layer_fwd (NULL: every row at every step).  Kin % 64 == 0, H % 64 == 0. */
+int evc_lstm_level2_fwd(const evc_bf16* x, const evc_bf16* wT0, const float* bias0, const evc_bf16* wT1, const float* bias1,
+                        const int32_t* len, int T, int M, int Kin, int H, evc_bf16* hbuf0, evc_bf16* hbuf1,
+                        float* c_state0, float* h_state0, float* c_state1, float* h_state1, int64_t ld_state,
+                        void* gates0, evc_bf16* c_all0, void* gates1, evc_bf16* c_all1,
+                        const int32_t* row_map, const int32_t* rows_per_step, void* stream);
 
 /* Two-layer stack, BPTT in wavefront order: layer 0's step t+1 and layer 1's step t share a launch (T+1 dependent
  * launches instead of 2T) and the gradient arriving at layer 0 from layer 1 is contracted inside layer 0's step

@@ -1032,6 +1032,55 @@ def test_lstm_layer_with_row_plan_matches_plain(ops, M, T, Kin, H):
         assert (dW0 - dW1).abs().max().item() / sc < 1e-3      # dz within one bf16 ulp, different summation order
 
 
+@pytest.mark.parametrize("M,T,Kin,H,planned", [(4096, 4, 192, 128, True), (5120, 5, 128, 128, True), (3840, 3, 128, 256, False), (600, 4, 128, 128, True)])
+def test_lstm_level2_fwd_two_tiles_per_workgroup_equals_two_layer_calls(ops, M, T, Kin, H, planned):
+    """Round 5: a two-layer many-row level as T + 1 launches (evc_lstm_level2_fwd) - layer 0's step s and layer 1's step s-1 in one launch
+    whose workgroups walk both tiles, the second tile's first ring stages issued under the first tile's gate tail - against two
+    evc_lstm_layer_fwd calls: the same arithmetic in the same order, so h, the states, the gate records and the cell history must be
+    IDENTICAL - on row plans whose live rows pick the 256- / 240- / 224-row ring tiles (walk), with launches that fall back to two separate
+    ones (600 rows: smaller tiles), with a step count that leaves layer 1's last step alone in its launch, and in the evaluation form
+    (no tape)."""
+    rng = np.random.default_rng(M + T)
+    lens = rng.integers(1, T + 1, size=M).astype(np.int32)
+    lens[rng.random(M) < (0.25 if planned else 0.0)] = 0
+    lens[:2] = [T, T if not planned else 0]
+    x = to_bf16(rng.standard_normal((T, M, Kin)) * 0.5)
+    w0 = to_bf16(mm.glorot_uniform(rng, (4 * H, Kin + H)) * 2.0)
+    w1 = to_bf16(mm.glorot_uniform(rng, (4 * H, 2 * H)) * 2.0)
+    b0 = torch.from_numpy((rng.standard_normal(4 * H) * 0.1).astype(np.float32)).to(DEV)
+    b1 = torch.from_numpy((rng.standard_normal(4 * H) * 0.1).astype(np.float32)).to(DEV)
+    ln = torch.from_numpy(lens).to(DEV)
+    plan = ops.RowPlan(ln, lens, T) if planned else None
+    P = plan.P if plan is not None else M
+    xs = x[:, plan.inv[:P].long()].contiguous() if plan is not None else x
+    lens_d = plan.lens if plan is not None else ln
+    for tape in (True, False):
+        outs = []
+        for walk in (False, True):
+            hb = [torch.full((T + 1, P, H), float("nan"), dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+            S = torch.full((M, 4 * H), float("nan"), dtype=torch.float32, device=DEV)
+            gates = [torch.full((T, P, H, 2), -1, dtype=torch.int32, device=DEV) if tape else None for _ in range(2)]
+            c_all = [torch.full((T + 1, P, H), float("nan"), dtype=torch.bfloat16, device=DEV) if tape else None for _ in range(2)]
+            if walk:
+                ops.lstm_level2_fwd(xs, w0, b0, w1, b1, lens_d, T, P, Kin, H, hb[0], hb[1], S, gates, c_all, plan=plan)
+            else:
+                ops.lstm_layer_fwd(xs, w0, b0, lens_d, T, P, Kin, H, hb[0], S[:, 0:], S[:, H:], 4 * H, gates[0], c_all[0], plan=plan)
+                ops.lstm_layer_fwd(hb[0][1:], w1, b1, lens_d, T, P, H, H, hb[1], S[:, 2 * H:], S[:, 3 * H:], 4 * H, gates[1], c_all[1], plan=plan)
+            torch.cuda.synchronize()
+            outs.append((hb, S, gates, c_all))
+        (ha, Sa, ga, ca), (hw, Sw, gw, cw) = outs
+        rows = plan.rows if plan is not None else [M] * T
+        live = np.nonzero(lens > 0)[0]
+        assert torch.equal(Sa[torch.from_numpy(live).to(DEV)].view(torch.int32), Sw[torch.from_numpy(live).to(DEV)].view(torch.int32)) and bool(torch.isfinite(Sw[torch.from_numpy(live).to(DEV)]).all())
+        for l in range(2):
+            assert bool((hw[l][0] == 0).all())
+            for t in range(T):
+                rt = rows[t]
+                assert torch.equal(ha[l][t + 1, :rt].view(torch.int16), hw[l][t + 1, :rt].view(torch.int16)), (l, t)
+                if tape:
+                    assert torch.equal(ga[l][t, :rt], gw[l][t, :rt]) and torch.equal(ca[l][t + 1, :rt].view(torch.int16), cw[l][t + 1, :rt].view(torch.int16)), (l, t)
+
+
 def test_kl_pred_loss_against_oracle_and_degenerate_rows(ops):
     """L_PRED (cs/train.py:398-402): Categorical KL of the renormalised probabilities, summed over the batch, with
     its gradient wrt the student probabilities; rows where the reference would produce NaN/inf stay finite."""
