@@ -203,11 +203,12 @@ __device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const 
 // independent, so one launch runs both - every workgroup computes tile (tm, tn) of step a, then the same tile of step b.  Once every wave
 // has left the ring, the first stages of tile b are issued (gemm_mainloop_v3 PHASE 1) and land under tile a's gate tail (which needs no
 // LDS); tile b's loop starts on them (PHASE 2).  Per pair of steps that is one ring fill and one kernel boundary less.
-template <class Cfg>
+template <class Cfg, bool F16 = false, bool FP8 = false>
 __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_walk2_kernel(GemmOperands pa, LstmFwdParams ea, int tiles_ma, GemmOperands pb, LstmFwdParams eb,
                                                                  int tiles_mb, int tiles_n) {
   static_assert(is_v3<Cfg>::value && Cfg::G == 4, "tile walk: the 64-wide ring tiles");
-  constexpr int MODE = EVC_FWD_LOOP_MODE;
+  static_assert(!FP8 || F16, "the e4m3 tail rides behind f16 stages");
+  constexpr int MODE = EVC_FWD_LOOP_MODE | (F16 ? LOOP_F16 : 0) | (FP8 ? LOOP_FP8_TAIL : 0);
   const int tiles_m = tiles_ma > tiles_mb ? tiles_ma : tiles_mb;
   const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   int tm, tn;
@@ -222,16 +223,18 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_walk2_kernel(GemmOperands pa
       __syncthreads();                                              // every wave has read its last ring slot
       gemm_mainloop_v3<Cfg, true, false, MODE, 1>(pb, m0, u0, lds_dyn, acc);
     }
-    lstm_fwd_epilogue<Cfg, false, false, false>(pa, ea, m0, u0, acc);
+    lstm_fwd_epilogue<Cfg, false, F16, FP8>(pa, ea, m0, u0, acc);
     if (has_b) {
+      __builtin_amdgcn_sched_barrier(0);                            // (keep tile b's address set-up out of tile a's tail: register pressure)
+      asm volatile("" ::: "memory");
       lstm_fwd_acc_bias<Cfg>(eb, u0, acc);
       gemm_mainloop_v3<Cfg, true, false, MODE, 2>(pb, m0, u0, lds_dyn, acc);
-      lstm_fwd_epilogue<Cfg, false, false, false>(pb, eb, m0, u0, acc);
+      lstm_fwd_epilogue<Cfg, false, F16, FP8>(pb, eb, m0, u0, acc);
     }
   } else if (has_b) {
     lstm_fwd_acc_bias<Cfg>(eb, u0, acc);
     gemm_mainloop_v3<Cfg, true, false, MODE, 0>(pb, m0, u0, lds_dyn, acc);
-    lstm_fwd_epilogue<Cfg, false, false, false>(pb, eb, m0, u0, acc);
+    lstm_fwd_epilogue<Cfg, false, F16, FP8>(pb, eb, m0, u0, acc);
   }
 }
 #ifdef EVC_STAMPS
@@ -452,13 +455,13 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
 // [x_t | h_{t-1}] . W^T in one K walk (layer 1's x_t is layer 0's output slab).  Same arithmetic as two evc_lstm_layer_fwd calls: bit-identical
 // results.  Launches whose tile is not one of the 64-wide ring tiles (224 / 240 / 256 rows) run as two separate launches.
 // ===========================================================================
-template <class Cfg>
+template <class Cfg, bool F16 = false, bool FP8 = false>
 static inline void launch_lstm_fwd_walk2(GemmOperands pa, const LstmFwdParams& ea, int k1a, int k2a, GemmOperands pb, const LstmFwdParams& eb,
                                          int k1b, int k2b, hipStream_t st) {
   pa.nk1 = k1a / 64; pa.nk2 = k2a / 64;
   pb.nk1 = k1b / 64; pb.nk2 = k2b / 64;
   const int tma = ceil_div(ea.M, Cfg::BM), tmb = ceil_div(eb.M, Cfg::BM), tn = ceil_div(ea.H, Cfg::BU);
-  launch_cfg<Cfg>(lstm_fwd_walk2_kernel<Cfg>, (tma > tmb ? tma : tmb) * tn, st, pa, ea, tma, pb, eb, tmb, tn);
+  launch_cfg<Cfg>(lstm_fwd_walk2_kernel<Cfg, F16, FP8>, (tma > tmb ? tma : tmb) * tn, st, pa, ea, tma, pb, eb, tmb, tn);
 }
 
 extern "C" int evc_lstm_level2_fwd(const evc_bf16* x, const evc_bf16* wT0, const float* bias0, const evc_bf16* wT1, const float* bias1,

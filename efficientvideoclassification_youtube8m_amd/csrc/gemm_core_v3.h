@@ -81,7 +81,8 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / Cfg::WC, wc = wave % Cfg::WC;
 
-  static_assert(PHASE == 0 || (MODE & LOOP_FP8_TAIL) == 0, "tile walks: 16-bit stages only");
+  // (with LOOP_FP8_TAIL the first STAGES stages of a tile are 16-bit stages too - the launchers keep nk1 >= STAGES - so the PHASE split of the
+  //  prologue is the same)
   if (INIT && PHASE != 1) {
 #pragma unroll
     for (int mi = 0; mi < Cfg::MI; ++mi)
