@@ -184,8 +184,11 @@ struct MoeUpdateParams {
   float l2, clip, lr_t, b1, b2, eps;
 };
 
+#ifndef EVC_MOE_UPD_WAVES_PER_EU
+#define EVC_MOE_UPD_WAVES_PER_EU 2      // (A/B: 4 = cap the kernel at 128 VGPRs so that two of its 80 KB workgroups share a CU)
+#endif
 template <class Cfg, int PASS>
-__global__ __launch_bounds__(Cfg::NT) void moe_update_kernel(GemmOperandsT p, MoeUpdateParams u, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(Cfg::NT, EVC_MOE_UPD_WAVES_PER_EU) void moe_update_kernel(GemmOperandsT p, MoeUpdateParams u, int tiles_m, int tiles_n) {
   const int nwg = tiles_m * tiles_n;
   const int id = xcd_remap(blockIdx.x, nwg);
   int tm, tn;
