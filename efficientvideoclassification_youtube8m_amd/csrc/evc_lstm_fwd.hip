@@ -455,12 +455,15 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
 // [x_t | h_{t-1}] . W^T in one K walk (layer 1's x_t is layer 0's output slab).  Same arithmetic as two evc_lstm_layer_fwd calls: bit-identical
 // results.  Launches whose tile is not one of the 64-wide ring tiles (224 / 240 / 256 rows) run as two separate launches.
 // ===========================================================================
+// has_a / has_b: which of the two tiles exist (a level's first launch has only layer 0's step, its last only layer 1's: the same kernel with one role,
+// so that every launch of the level carries one kernel name - the per-kernel averages of a profile then cover exactly the launches bench.py times)
 template <class Cfg, bool F16 = false, bool FP8 = false>
-static inline void launch_lstm_fwd_walk2(GemmOperands pa, const LstmFwdParams& ea, int k1a, int k2a, GemmOperands pb, const LstmFwdParams& eb,
-                                         int k1b, int k2b, hipStream_t st) {
+static inline void launch_lstm_fwd_walk2(GemmOperands pa, const LstmFwdParams& ea, int k1a, int k2a, bool has_a, GemmOperands pb, const LstmFwdParams& eb,
+                                         int k1b, int k2b, bool has_b, hipStream_t st) {
   pa.nk1 = k1a / 64; pa.nk2 = k2a / 64;
   pb.nk1 = k1b / 64; pb.nk2 = k2b / 64;
-  const int tma = ceil_div(ea.M, Cfg::BM), tmb = ceil_div(eb.M, Cfg::BM), tn = ceil_div(ea.H, Cfg::BU);
+  const int H = has_a ? ea.H : eb.H;
+  const int tma = has_a ? ceil_div(ea.M, Cfg::BM) : 0, tmb = has_b ? ceil_div(eb.M, Cfg::BM) : 0, tn = ceil_div(H, Cfg::BU);
   launch_cfg<Cfg>(lstm_fwd_walk2_kernel<Cfg, F16, FP8>, (tma > tmb ? tma : tmb) * tn, st, pa, ea, tma, pb, eb, tmb, tn);
 }
 
@@ -521,13 +524,15 @@ extern "C" int evc_lstm_level2_fwd(const evc_bf16* x, const evc_bf16* wT0, const
     bool has_a = s < T, has_b = s >= 1;
     if (has_a) { step_args(0, s, pa, ea, k1a, k2a); has_a = ea.M > 0; }
     if (has_b) { step_args(1, s - 1, pb, eb, k1b, k2b); has_b = eb.M > 0; }
-    if (has_a && has_b) {
-      const int pick = pick_fwd_tile(eb.M, H);                       // layer 1 runs the earlier step: at least as many rows as layer 0
-      if (pick == 2) { launch_lstm_fwd_walk2<CfgLstmV3_256>(pa, ea, k1a, k2a, pb, eb, k1b, k2b, st); continue; }
-      if (pick == 10) { launch_lstm_fwd_walk2<CfgLstmV3_240>(pa, ea, k1a, k2a, pb, eb, k1b, k2b, st); continue; }
+    if (has_a || has_b) {
+      const int pick = pick_fwd_tile(has_b ? eb.M : ea.M, H);        // layer 1 runs the earlier step: at least as many rows as layer 0
+      if (!has_a) { pa = pb; ea = eb; }                              // (the absent role's arguments are never read: tiles_m = 0)
+      if (!has_b) { pb = pa; eb = ea; }
+      if (pick == 2) { launch_lstm_fwd_walk2<CfgLstmV3_256>(pa, ea, k1a, k2a, has_a, pb, eb, k1b, k2b, has_b, st); continue; }
+      if (pick == 10) { launch_lstm_fwd_walk2<CfgLstmV3_240>(pa, ea, k1a, k2a, has_a, pb, eb, k1b, k2b, has_b, st); continue; }
       if (pick == 3) {
-        if (uneven224) launch_lstm_fwd_walk2<CfgLstmV3_224u>(pa, ea, k1a, k2a, pb, eb, k1b, k2b, st);
-        else launch_lstm_fwd_walk2<CfgLstmV3_224>(pa, ea, k1a, k2a, pb, eb, k1b, k2b, st);
+        if (uneven224) launch_lstm_fwd_walk2<CfgLstmV3_224u>(pa, ea, k1a, k2a, has_a, pb, eb, k1b, k2b, has_b, st);
+        else launch_lstm_fwd_walk2<CfgLstmV3_224>(pa, ea, k1a, k2a, has_a, pb, eb, k1b, k2b, has_b, st);
         continue;
       }
     }

@@ -11,7 +11,8 @@ from collections import defaultdict
 
 root, out = sys.argv[1], sys.argv[2]
 KERNELS = dict(a.split("=", 1) for a in sys.argv[3:]) or {
-    "lstm_fwd_step (teacher/student L1, ring tiles)": "lstm_fwd_step_kernel<TileCfg3<",
+    "lstm_fwd_walk2 (teacher L1, two step tiles per launch: layer 0 step s + layer 1 step s-1)": "lstm_fwd_walk2_kernel<TileCfg3<",
+    "lstm_fwd_step (one tile per launch: a level's first / last step, other tile heights)": "lstm_fwd_step_kernel<TileCfg3<",
     "lstm_bwd_step (L1 BPTT, 128x128 ring tile)": "lstm_bwd_step_kernel<TileCfg3<128",
     "gemm_tn 256x256 (weight gradients)": "gemm_tn_kernel<TileCfg2<256",
     "gemm_nt 256x256 / 224x256 (dX, hoisted projections)": "gemm_nt_kernel<TileCfg3<2",

@@ -9,7 +9,19 @@ from collections import defaultdict
 
 root = sys.argv[1]
 out = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01_pmc_traffic.json"
-MATCH = ("lstm_fwd_step_kernel<TileCfg2<", "lstm_fwd_step_kernel<TileCfg3<")     # the ring tiles (v2 / v3 stages)
+MATCH = ("lstm_fwd_step_kernel<TileCfg2<", "lstm_fwd_step_kernel<TileCfg3<")     # the ring tiles (v2 / v3 stages), one tile per workgroup
+WALK = ("lstm_fwd_walk2_kernel<TileCfg3<",)                                        # round 5: two tiles per workgroup (layer 0 step s + layer 1 step s-1)
+
+
+def _match():
+    """The walk kernel if the trace has it (then the dominant forward kernel: the one-tile launches left are a level's first and last step), else the one-tile kernels."""
+    f = glob.glob(os.path.join(root, "fetch", "*counter_collection.csv"))[0]
+    names = {r["Kernel_Name"] for r in csv.DictReader(open(f))}
+    return WALK if any(any(m in k for m in WALK) for k in names) else MATCH
+
+
+MATCH = _match()
+IS_WALK = MATCH is WALK
 
 
 def load(sub):
@@ -36,7 +48,9 @@ busy, gui = avg(mfma, "SQ_VALU_MFMA_BUSY_CYCLES"), avg(mfma, "GRBM_GUI_ACTIVE")
 res = {
     "source": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE; each with "
               "--kernel-trace only) of `python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline` on MI355X (scripts/pmc_collect.sh)",
-    "kernel": "lstm_fwd_step_kernel<TileCfg3<BM,4,64,2,4,2>> (TileCfg2 for 288/320 rows) - the ring tile heights the row plans select, launches per variant: "
+    "kernel": ("lstm_fwd_walk2_kernel<TileCfg3<BM,4,64,2,4,2>> (two tiles per workgroup and launch: layer 0's step s + layer 1's step s-1; bytes and cycles are per LAUNCH = "
+               "two step tiles) - the ring tile heights the row plans select, launches per variant: " if IS_WALK else
+               "lstm_fwd_step_kernel<TileCfg3<BM,4,64,2,4,2>> (TileCfg2 for 288/320 rows) - the ring tile heights the row plans select, launches per variant: ")
               + ", ".join("%s x%d" % (k.split("TileCfg")[1].split(">")[0].replace(" ", ""), n[k]) for k in kernels),
     "launches_sampled": tot,
     "FETCH_SIZE_KB_avg_raw": fetch_kb,
