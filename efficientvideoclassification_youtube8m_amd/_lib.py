@@ -22,6 +22,8 @@ SIGNATURES = {
     "evc_gemm_nt": [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i32, i32, vp],
     "evc_gemm_tn": [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp],
     "evc_gemm_tn2": [vp, i64, vp, i64, i32, vp, i64, i32, i32, vp, i64, i32, i32, i32, i32, vp],
+    "evc_gemm_tn2_slabs": [vp, i64, vp, i64, i32, vp, i64, i32, i32, vp, i64, i64, i32, i32, i32, i32, vp],
+    "evc_sum_slabs": [vp, i64, i32, i32, i32, i64, vp, i64, i32, vp],
     "evc_colsum_bf16": [vp, i64, i32, i32, i32, vp, vp],
     "evc_colsum_bf16_det": [vp, i64, i32, i32, i32, vp, vp, i32, vp],
     "evc_lstm_layer_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp],
@@ -55,6 +57,8 @@ SIGNATURES = {
     "evc_moe_tail_fwd": [vp, vp, i32, i32, i32, vp, vp, vp],
     "evc_moe_tail_bwd": [vp, vp, vp, i32, i32, i32, vp, i64, vp, i64, vp],
     "evc_ce_loss": [vp, vp, i32, i32, f32, vp, vp, i32, vp],
+    "evc_ce_loss_ordered": [vp, vp, i32, i32, f32, vp, vp, i32, vp, vp],
+    "evc_rep_loss_ordered": [vp, vp, i32, i32, f32, vp, vp, i32, vp, vp],
     "evc_kl_pred_loss": [vp, vp, vp, vp, i32, i32, f32, vp, vp, i32, vp],
     "evc_rep_loss": [vp, vp, i32, i32, f32, vp, vp, i32, vp],
     "evc_grad_sqnorm": [vp, vp, f32, i64, vp, vp],

@@ -842,9 +842,20 @@ extern "C" int evc_moe_tail_bwd(const float* gate_logits, const float* expert_lo
 // ---------------------------------------------------------------------------
 // a6 + a7: losses.  grid-stride, block partials, one atomic per block.
 // ---------------------------------------------------------------------------
+// part != NULL (EVC_DETERMINISTIC=1, round 5): every block leaves its partial sum in part[blockIdx.x] instead of an atomic on *loss, and
+// loss_partials_finish_kernel adds them in block order - the full grid computes the gradient (round 4 ran ONE block over the 1.2 M elements so
+// that the loss scalar had a fixed summation order: 2.5 ms per call on the critical path of the deterministic step).
+__global__ __launch_bounds__(256) void loss_partials_finish_kernel(const float* __restrict__ part, int n, float* __restrict__ loss) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += part[i];
+    *loss += s;
+  }
+}
+
 __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ p, const uint8_t* __restrict__ y, long n,
                                                       float inv_b, float gs, float* __restrict__ loss,
-                                                      float* __restrict__ dp, int acc) {
+                                                      float* __restrict__ dp, int acc, float* __restrict__ part = nullptr) {
   __shared__ float sh[4];
   float s = 0.f;
   const float eps = 10e-6f;   // cs/losses.py:92
@@ -859,19 +870,33 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const float* __restrict__ 
     }
   }
   s = block_sum(s, sh);
-  if (threadIdx.x == 0) atomicAdd(loss, s * inv_b);
+  if (threadIdx.x == 0) {
+    if (part) part[blockIdx.x] = s * inv_b;
+    else atomicAdd(loss, s * inv_b);
+  }
 }
-extern "C" int evc_ce_loss(const float* pred, const uint8_t* labels, int B, int V, float grad_scale,
-                           float* loss, float* dpred, int accumulate_grad, void* stream) {
+static int ce_loss_impl(const float* pred, const uint8_t* labels, int B, int V, float grad_scale, float* loss, float* dpred, int accumulate_grad,
+                        float* partials, void* stream) {
   EVC_REQUIRE(B > 0 && V > 0, EVC_ERR_BAD_SHAPE, "evc_ce_loss: bad shape");
   const long n = (long)B * V;
   // every block ends in one atomic on the same address, and those serialise at ~12 ns each: 2048 blocks made this a
   // 30 us kernel for 1.2 M elements; 256 blocks (one per CU) keep the join at ~3 us
-  const int grid = evc_deterministic() ? 1 : (int)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);
+  int grid = (int)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);
+  if (evc_deterministic() && !partials) grid = 1;               // no workspace: one block is the only fixed order available
   hipLaunchKernelGGL(ce_loss_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, pred, labels, n, 1.0f / B, grad_scale, loss,
-                     dpred, accumulate_grad);
+                     dpred, accumulate_grad, partials);
+  if (partials) hipLaunchKernelGGL(loss_partials_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)partials, grid, loss);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
+}
+extern "C" int evc_ce_loss(const float* pred, const uint8_t* labels, int B, int V, float grad_scale,
+                           float* loss, float* dpred, int accumulate_grad, void* stream) {
+  return ce_loss_impl(pred, labels, B, V, grad_scale, loss, dpred, accumulate_grad, nullptr, stream);
+}
+extern "C" int evc_ce_loss_ordered(const float* pred, const uint8_t* labels, int B, int V, float grad_scale,
+                                   float* loss, float* dpred, int accumulate_grad, float* partials, void* stream) {
+  EVC_REQUIRE(partials, EVC_ERR_BAD_ARG, "evc_ce_loss_ordered: partials (256 floats of scratch) is required");
+  return ce_loss_impl(pred, labels, B, V, grad_scale, loss, dpred, accumulate_grad, partials, stream);
 }
 
 __global__ __launch_bounds__(256) void kl_loss_kernel(const float* __restrict__ pt, const float* __restrict__ st,
@@ -915,7 +940,7 @@ extern "C" int evc_kl_pred_loss(const float* pred_t, const float* rowsum_t, cons
 
 __global__ __launch_bounds__(256) void rep_loss_kernel(const float* __restrict__ a, const float* __restrict__ b, long n,
                                                        float inv_b, float gs, float* __restrict__ loss,
-                                                       float* __restrict__ db, int acc) {
+                                                       float* __restrict__ db, int acc, float* __restrict__ part = nullptr) {
   __shared__ float sh[4];
   float s = 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -927,17 +952,31 @@ __global__ __launch_bounds__(256) void rep_loss_kernel(const float* __restrict__
     }
   }
   s = block_sum(s, sh);
-  if (threadIdx.x == 0) atomicAdd(loss, s * inv_b);
+  if (threadIdx.x == 0) {
+    if (part) part[blockIdx.x] = s * inv_b;
+    else atomicAdd(loss, s * inv_b);
+  }
+}
+static int rep_loss_impl(const float* state_t, const float* state_s, int B, int D, float grad_scale, float* loss, float* dstate_s,
+                         int accumulate_grad, float* partials, void* stream) {
+  EVC_REQUIRE(B > 0 && D > 0, EVC_ERR_BAD_SHAPE, "evc_rep_loss: bad shape");
+  const long n = (long)B * D;
+  int grid = (int)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);     // one same-address atomic per block (see evc_ce_loss)
+  if (evc_deterministic() && !partials) grid = 1;
+  hipLaunchKernelGGL(rep_loss_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, state_t, state_s, n, 1.0f / B, grad_scale,
+                     loss, dstate_s, accumulate_grad, partials);
+  if (partials) hipLaunchKernelGGL(loss_partials_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)partials, grid, loss);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
 }
 extern "C" int evc_rep_loss(const float* state_t, const float* state_s, int B, int D, float grad_scale,
                             float* loss, float* dstate_s, int accumulate_grad, void* stream) {
-  EVC_REQUIRE(B > 0 && D > 0, EVC_ERR_BAD_SHAPE, "evc_rep_loss: bad shape");
-  const long n = (long)B * D;
-  const int grid = evc_deterministic() ? 1 : (int)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);     // one same-address atomic per block (see evc_ce_loss)
-  hipLaunchKernelGGL(rep_loss_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, state_t, state_s, n, 1.0f / B, grad_scale,
-                     loss, dstate_s, accumulate_grad);
-  EVC_LAUNCH_CHECK();
-  return EVC_OK;
+  return rep_loss_impl(state_t, state_s, B, D, grad_scale, loss, dstate_s, accumulate_grad, nullptr, stream);
+}
+extern "C" int evc_rep_loss_ordered(const float* state_t, const float* state_s, int B, int D, float grad_scale,
+                                    float* loss, float* dstate_s, int accumulate_grad, float* partials, void* stream) {
+  EVC_REQUIRE(partials, EVC_ERR_BAD_ARG, "evc_rep_loss_ordered: partials (256 floats of scratch) is required");
+  return rep_loss_impl(state_t, state_s, B, D, grad_scale, loss, dstate_s, accumulate_grad, partials, stream);
 }
 
 // ---------------------------------------------------------------------------

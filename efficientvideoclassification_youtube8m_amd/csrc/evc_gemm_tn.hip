@@ -157,6 +157,58 @@ extern "C" int evc_gemm_tn_slabs(const evc_bf16* A, int64_t lda, const evc_bf16*
   return EVC_OK;
 }
 
+// Two column segments into slabs (EVC_DETERMINISTIC=1 weight gradients, round 5): evc_gemm_tn2's product with the K split stored as nslab plain partial
+// images instead of joined with atomics - slab s at slabs + s*slab_stride, each an [M][ldc] image like C (rows de-interleaved, the second segment
+// at column c_col2) - that evc_sum_slabs adds in slab order.  B2 == NULL: one segment of N1 columns.
+extern "C" int evc_gemm_tn2_slabs(const evc_bf16* A, int64_t lda, const evc_bf16* B1, int64_t ldb1, int N1, const evc_bf16* B2, int64_t ldb2,
+                                  int N2, int c_col2, float* slabs, int64_t ldc, int64_t slab_stride, int M, int K, int row_interleave_H,
+                                  int nslab, void* stream) {
+  const int N = N1 + (B2 ? N2 : 0);
+  EVC_REQUIRE(M >= 8 && N1 >= 8 && K > 0 && M % 8 == 0 && N % 8 == 0 && K % 32 == 0 && nslab >= 1 && nslab <= K / 32, EVC_ERR_BAD_SHAPE,
+              "evc_gemm_tn2_slabs: needs M %% 8 == 0, N %% 8 == 0, K %% 32 == 0, 1 <= nslab <= K/32 (M=%d N=%d K=%d nslab=%d)", M, N, K, nslab);
+  EVC_REQUIRE(lda % 8 == 0 && ldb1 % 8 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B1 % 16) == 0 && slabs && slab_stride >= (int64_t)M * ldc, EVC_ERR_BAD_ALIGN,
+              "evc_gemm_tn2_slabs: operands must be 16-byte aligned, slab_stride >= M * ldc");
+  EVC_REQUIRE(row_interleave_H == 0 || M == 4 * row_interleave_H, EVC_ERR_BAD_SHAPE, "evc_gemm_tn2_slabs: row_interleave_H needs M == 4*H");
+  EVC_REQUIRE(!B2 || (N1 % 256 == 0 && N2 > 0 && ldb2 % 8 == 0 && ((uintptr_t)B2 % 16) == 0 && c_col2 >= N1), EVC_ERR_BAD_SHAPE,
+              "evc_gemm_tn2_slabs: N1=%d must be a multiple of 256, B2 16-byte aligned with ldb2 %% 8 == 0, c_col2=%d >= N1", N1, c_col2);
+  GemmOperandsT p{A, lda, B1, ldb1, M, N, K / 32};
+  if (B2) { p.B2 = B2; p.ldb2 = ldb2; p.N1 = N1; p.c_col2 = c_col2; }
+  const int tm = ceil_div(M, CfgPlainV2::BM), tn = ceil_div(N, CfgPlainV2::BU);
+  const int per = ceil_div(p.nk, nslab);
+  EVC_REQUIRE((long)per * (nslab - 1) < p.nk, EVC_ERR_BAD_SHAPE, "evc_gemm_tn2_slabs: nslab=%d leaves an empty slab at K=%d", nslab, K);
+  StoreParamsT s{slabs, ldc, M, N, row_interleave_H, 0, nslab, per, slab_stride};
+  launch_cfg<CfgPlainV2>(gemm_tn_kernel<CfgPlainV2>, tm * tn * nslab, (hipStream_t)stream, p, s, tm, tn);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// C[r][c] (+)= sum over slabs s, in slab order, of slabs[s*slab_stride + r*ld + c] for r < M, c < N (N % 4 == 0, 16-byte aligned rows)
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const float* __restrict__ slabs, long slab_stride, int nslab, int M, int N4, long ld,
+                                                        float* __restrict__ C, long ldc, int accumulate) {
+  const long n = (long)M * N4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long r = i / N4, c = (i - r * N4) * 4;
+    float4 a = accumulate ? *(const float4*)(C + r * ldc + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < nslab; ++s) {
+      const float4 v = *(const float4*)(slabs + s * slab_stride + r * ld + c);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *(float4*)(C + r * ldc + c) = a;
+  }
+}
+extern "C" int evc_sum_slabs(const float* slabs, int64_t slab_stride, int nslab, int M, int N, int64_t ld, float* C, int64_t ldc, int accumulate,
+                             void* stream) {
+  EVC_REQUIRE(slabs && C && nslab >= 1 && M > 0 && N > 0 && N % 4 == 0 && ld % 4 == 0 && ldc % 4 == 0 && slab_stride % 4 == 0 &&
+              ((uintptr_t)slabs % 16) == 0 && ((uintptr_t)C % 16) == 0, EVC_ERR_BAD_SHAPE, "evc_sum_slabs: N, ld, ldc, slab_stride multiples of 4, 16-byte aligned");
+  const long n = (long)M * (N / 4);
+  long nb = (n + 255) / 256;
+  nb = nb > 2048 ? 2048 : nb;
+  hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, slabs, (long)slab_stride, nslab, M, N / 4, (long)ld, C, (long)ldc,
+                     accumulate);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
 // ===========================================================================
 // MoE weight update without materialising the gradient.
 // The gradient of a MoE weight matrix W [V][K] (stored as the forward GEMM's B operand) is the outer

@@ -365,6 +365,17 @@ class LstmStack:
         the chip idle in the second round)."""
         H = self.H
         n1 = kin // 256 * 256
+        if ops.DETERMINISTIC and rows % 32 == 0 and kin % 8 == 0:
+            # no atomics, K split kept (round 5): partial products into slabs, added in slab order (ops.gemm_tn_det) - round 4 ran these products
+            # as one workgroup per tile with the whole K (3.4 instead of 2.0 ms per step)
+            if n1 >= 256 and (kin == n1 or kin - n1 >= 8):
+                ops.gemm_tn_det(dz2, layer_in, 4 * H, n1, rows, gW, row_interleave_H=H, accumulate=True, ldc=kin + H, B2=h_prev, N2=H, c_col2=kin)
+                if kin > n1:
+                    ops.gemm_tn_det(dz2, layer_in[:, n1:], 4 * H, kin - n1, rows, gW[:, n1:kin], row_interleave_H=H, accumulate=True, ldc=kin + H)
+            else:
+                ops.gemm_tn_det(dz2, layer_in, 4 * H, kin, rows, gW, row_interleave_H=H, accumulate=True, ldc=kin + H)
+                ops.gemm_tn_det(dz2, h_prev, 4 * H, H, rows, gW[:, kin:], row_interleave_H=H, accumulate=True, ldc=kin + H)
+            return
         if kin == H and kin % 256 == 0 and self.fuse_wgrad:
             ops.gemm_tn2(dz2, layer_in, kin, h_prev, H, 4 * H, rows, gW, row_interleave_H=H, accumulate=True)
         elif self.fuse_wgrad and kin - n1 in (64, 128) and n1 >= H and rows >= 16384 and (n1 + H) % 2048 == 0:

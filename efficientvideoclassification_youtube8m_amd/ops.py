@@ -70,6 +70,24 @@ def gemm_tn(A, B, M, N, K, out, row_interleave_H=0, accumulate=False, lda=None, 
     return out
 
 
+def gemm_tn_det(A, B, M, N, K, out, row_interleave_H=0, accumulate=False, ldc=None, B2=None, N2=0, c_col2=None):
+    """out[:, :N] (and out[:, c_col2:c_col2+N2] from B2) (+)= A^T @ B without atomics and with the K split kept (EVC_DETERMINISTIC=1): partial
+    products into slabs (evc_gemm_tn2_slabs), added in slab order (evc_sum_slabs).  Scratch from the stream-aware caching allocator."""
+    assert A.dtype == BF16 and B.dtype == BF16 and out.dtype == F32
+    ldc = out.stride(0) if ldc is None else ldc
+    ntot = (c_col2 + N2) if B2 is not None else N
+    tiles = ((M + 255) // 256) * ((N + N2 + 255) // 256)
+    nslab = max(1, min(256 // max(1, tiles), K // 1024))
+    while nslab > 1 and ((K // 32 + nslab - 1) // nslab) * (nslab - 1) >= K // 32:
+        nslab -= 1
+    ws = torch.empty((nslab, M, ntot), dtype=F32, device=out.device)
+    _lib.call("evc_gemm_tn2_slabs", _p(A), A.stride(0), _p(B), B.stride(0), N, _p(B2), B2.stride(0) if B2 is not None else 0, N2,
+              (c_col2 if c_col2 is not None else N), _p(ws), ntot, M * ntot, M, K, row_interleave_H, nslab, _stream())
+    for c0, w in ((0, N),) + (((c_col2, N2),) if B2 is not None else ()):
+        _lib.call("evc_sum_slabs", _p(ws[0, :, c0:]), M * ntot, nslab, M, w, ntot, _p(out[:, c0:]), ldc, 1 if accumulate else 0, _stream())
+    return out
+
+
 def gemm_tn2(A, B1, N1, B2, N2, M, K, out, row_interleave_H=0, accumulate=False, ldc=None, c_col2=None):
     """out[:, :N1] (+)= A[K,M]^T @ B1[K,N1], out[:, c_col2:c_col2+N2] (+)= A^T @ B2[K,N2] in one launch (N1 % 256 == 0;
     c_col2 defaults to N1: adjacent segments)."""
@@ -467,6 +485,10 @@ def moe_grad_update_apply(dlogits, x, rows, V, K, p, m, v, p_bf16, pT_bf16, l2_c
 
 def ce_loss(pred, labels_u8, loss, dpred=None, grad_scale=1.0, accumulate_grad=False):
     B, V = pred.shape
+    if DETERMINISTIC:      # fixed-order loss sum from per-block partials (scratch from the stream-aware caching allocator)
+        ws = torch.empty(256, dtype=F32, device=pred.device)
+        _lib.call("evc_ce_loss_ordered", _p(pred), _p(labels_u8), B, V, grad_scale, _p(loss), _p(dpred), 1 if accumulate_grad else 0, _p(ws), _stream())
+        return
     _lib.call("evc_ce_loss", _p(pred), _p(labels_u8), B, V, grad_scale, _p(loss), _p(dpred), 1 if accumulate_grad else 0, _stream())
 
 
@@ -478,6 +500,10 @@ def kl_pred_loss(pred_t, rowsum_t, pred_s, rowsum_s, loss, dpred_s=None, grad_sc
 
 def rep_loss(state_t, state_s, loss, dstate_s=None, grad_scale=1.0, accumulate_grad=False):
     B, D = state_t.shape
+    if DETERMINISTIC:
+        ws = torch.empty(256, dtype=F32, device=state_t.device)
+        _lib.call("evc_rep_loss_ordered", _p(state_t), _p(state_s), B, D, grad_scale, _p(loss), _p(dstate_s), 1 if accumulate_grad else 0, _p(ws), _stream())
+        return
     _lib.call("evc_rep_loss", _p(state_t), _p(state_s), B, D, grad_scale, _p(loss), _p(dstate_s), 1 if accumulate_grad else 0, _stream())
 
 

@@ -36,7 +36,7 @@ extern "C" {
 #define EVC_ERR_HIP (-4)
 #define EVC_ERR_BAD_ARG (-5)
 
-#define EVC_VERSION 104   /* 104 (round 5): evc_lstm_level2_fwd; evc_moe_grad_update* accept p_bf16 == NULL (forward shadow not written), evc_lstm_stack2_bwd runs M <= 512 stacks on the skinny pair launches, evc_dbof_cluster_pool_fwd walks tiles (EVC_DBOF_WALK), EVC_DETERMINISTIC parsed as "set, not empty, not 0"; 103 (round 4): evc_sqnorm2_partials, evc_lstm_adam_fused, evc_gram_slabs, evc_moe_grad_norms, evc_moe_grad_update_apply, evc_adam2d_fused, evc_colsum_bf16_det, evc_sample_sequence_gather, evc_relu6_fwd/bwd, evc_framepool_mean_fwd/bwd, evc_stream_create_cu_mask / evc_stream_destroy; EVC_DETERMINISTIC=1 read by the library; 102: evc_lstm_layer_fwd_f16_fp8lo, evc_lstm_stack2_fwd_f16_fp8lo, evc_gemm_nt_f16_fp8, evc_cast_f32_to_fp8_lo, evc_cast_f32_to_f16_fp8x, aux_mode 5, evc_moe_grad_update_wide; 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
+#define EVC_VERSION 104   /* 104 (round 5): evc_lstm_level2_fwd, evc_ce_loss_ordered, evc_rep_loss_ordered, evc_gemm_tn2_slabs, evc_sum_slabs; evc_moe_grad_update* accept p_bf16 == NULL (forward shadow not written), evc_lstm_stack2_bwd runs M <= 512 stacks on the skinny pair launches, evc_dbof_cluster_pool_fwd walks tiles (EVC_DBOF_WALK), EVC_DETERMINISTIC parsed as "set, not empty, not 0"; 103 (round 4): evc_sqnorm2_partials, evc_lstm_adam_fused, evc_gram_slabs, evc_moe_grad_norms, evc_moe_grad_update_apply, evc_adam2d_fused, evc_colsum_bf16_det, evc_sample_sequence_gather, evc_relu6_fwd/bwd, evc_framepool_mean_fwd/bwd, evc_stream_create_cu_mask / evc_stream_destroy; EVC_DETERMINISTIC=1 read by the library; 102: evc_lstm_layer_fwd_f16_fp8lo, evc_lstm_stack2_fwd_f16_fp8lo, evc_gemm_nt_f16_fp8, evc_cast_f32_to_fp8_lo, evc_cast_f32_to_f16_fp8x, aux_mode 5, evc_moe_grad_update_wide; 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
 
 typedef uint16_t evc_bf16;
 typedef uint16_t evc_f16;   /* raw IEEE binary16 bits (the "high" precision forward operands of the L1 levels) */
@@ -404,6 +404,10 @@ int evc_moe_tail_bwd(const float* gate_logits, const float* expert_logits, const
 /* loss += scale_loss * mean_b CE ; dpred (=|+=) grad_scale * dCE/dpred. labels uint8 [B][V]. */
 int evc_ce_loss(const float* pred, const uint8_t* labels, int B, int V, float grad_scale,
                 float* loss, float* dpred, int accumulate_grad, void* stream);
+/* The same with the loss scalar summed in a FIXED order (EVC_DETERMINISTIC=1 callers, round 5): every block leaves its partial sum in
+ * partials[block] (256 floats of caller scratch) and a one-thread pass adds them in block order - the full grid still computes the gradient. */
+int evc_ce_loss_ordered(const float* pred, const uint8_t* labels, int B, int V, float grad_scale,
+                        float* loss, float* dpred, int accumulate_grad, float* partials, void* stream);
 /* loss += KL sum ; dpred_student (=|+=) grad_scale * dKL/dpS. */
 int evc_kl_pred_loss(const float* pred_t, const float* rowsum_t, const float* pred_s, const float* rowsum_s,
                      int B, int V, float grad_scale, float* loss, float* dpred_s, int accumulate_grad,
@@ -411,6 +415,9 @@ int evc_kl_pred_loss(const float* pred_t, const float* rowsum_t, const float* pr
 /* loss += mean_b sum_d (sT-sS)^2 ; dstate_s (=|+=) grad_scale * d/dsS. */
 int evc_rep_loss(const float* state_t, const float* state_s, int B, int D, float grad_scale,
                  float* loss, float* dstate_s, int accumulate_grad, void* stream);
+int evc_rep_loss_ordered(const float* state_t, const float* state_s, int B, int D, float grad_scale,
+                         float* loss, float* dstate_s, int accumulate_grad, float* partials /* 256 floats of scratch: fixed-order sum, as evc_ce_loss_ordered */,
+                         void* stream);
 
 /* ---- a8 + a9: regulariser, per-tensor clip, TF-Adam ---------------------------
  * slim.l2_regularizer (cs/video_level_models.py:428,434) folded into the
@@ -572,6 +579,14 @@ int evc_gemm_tn2(const evc_bf16* A, int64_t lda, const evc_bf16* B1, int64_t ldb
 /* evc_gemm_tn with the K range cut into nslab partial products stored plainly at slabs + s*M*N (no atomics). */
 int evc_gemm_tn_slabs(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, float* slabs, int M, int N, int K,
                       int nslab, void* stream);
+/* evc_gemm_tn2's product with the K split stored as nslab plain partial images (slab s at slabs + s*slab_stride, each laid out like C: row stride ldc,
+ * rows de-interleaved, second segment at column c_col2; B2 == NULL: one segment) and their fixed-order sum: the weight gradients of
+ * EVC_DETERMINISTIC=1 without atomics and without giving up the K split (round 5; tf.gradients' MatMul(transpose_a=True), cs/frame_level_models.py:221-257). */
+int evc_gemm_tn2_slabs(const evc_bf16* A, int64_t lda, const evc_bf16* B1, int64_t ldb1, int N1, const evc_bf16* B2, int64_t ldb2,
+                       int N2, int c_col2, float* slabs, int64_t ldc, int64_t slab_stride, int M, int K, int row_interleave_H,
+                       int nslab, void* stream);
+int evc_sum_slabs(const float* slabs, int64_t slab_stride, int nslab, int M, int N, int64_t ld, float* C, int64_t ldc, int accumulate,
+                  void* stream);
 /* G = sum of the slabs [nslab][C][F] (= dact^T . xhat): dW[c][f] = gamma_in[f]*G, dgamma_in[f] = sum_c W[c][f]*G,
  * dbeta_in = 0 (the batch-norm backward's output sums to zero over the batch).  part_ws: [ceil(C/8)][F] f32 scratch
  * (per-block column sums, added in block order: run-to-run identical). */

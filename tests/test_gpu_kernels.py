@@ -1081,6 +1081,37 @@ def test_lstm_level2_fwd_two_tiles_per_workgroup_equals_two_layer_calls(ops, M, 
                     assert torch.equal(ga[l][t, :rt], gw[l][t, :rt]) and torch.equal(ca[l][t + 1, :rt].view(torch.int16), cw[l][t + 1, :rt].view(torch.int16)), (l, t)
 
 
+@pytest.mark.parametrize("M,N1,N2,K,il", [(512, 256, 128, 4096, 128), (256, 192, 0, 2048, 0), (1024, 512, 256, 8192, 256)])
+def test_gemm_tn_det_slabs_equal_the_product_and_repeat_bit_for_bit(ops, M, N1, N2, K, il):
+    """EVC_DETERMINISTIC=1 weight gradients (round 5): the TN product with its K split kept, the partial products stored as slabs
+    (evc_gemm_tn2_slabs: two column segments, gate de-interleave, C's row stride) and added in slab order (evc_sum_slabs) instead of joined
+    with atomics - against a float64 product of the same bf16 operands, accumulating onto what C holds, and IDENTICAL bits on a second run."""
+    rng = np.random.default_rng(M + K)
+    A = to_bf16(rng.standard_normal((K, M)) * 0.1)
+    B1 = to_bf16(rng.standard_normal((K, N1)) * 0.1)
+    B2 = to_bf16(rng.standard_normal((K, N2)) * 0.1) if N2 else None
+    c2 = N1 + 64 if N2 else None                                       # the second segment lands 64 columns behind the first (layer 0: 1152 vs 1024)
+    ldc = (c2 + N2) if N2 else N1
+    C0 = torch.from_numpy(rng.standard_normal((M, ldc)).astype(np.float32)).to(DEV)
+    outs = []
+    for _ in range(2):
+        C = C0.clone()
+        ops.gemm_tn_det(A, B1, M, N1, K, C, row_interleave_H=il, accumulate=True, ldc=ldc, B2=B2, N2=N2, c_col2=c2)
+        torch.cuda.synchronize()
+        outs.append(C)
+    assert torch.equal(outs[0].view(torch.int32), outs[1].view(torch.int32))
+    ref = C0.double().cpu().numpy().copy()
+    prod1 = A.double().cpu().numpy().T @ B1.double().cpu().numpy()
+    rows = (np.arange(M) % 4) * il + np.arange(M) // 4 if il else np.arange(M)         # row u*4+g of the product -> row g*H+u
+    ref[rows, :N1] += prod1
+    if N2:
+        ref[rows, c2:c2 + N2] += A.double().cpu().numpy().T @ B2.double().cpu().numpy()
+    got = outs[0].double().cpu().numpy()
+    assert np.abs(got - ref).max() < 2e-4 * np.abs(ref).max() + 1e-4
+    if N2:
+        assert np.array_equal(got[:, N1:c2], C0.double().cpu().numpy()[:, N1:c2])    # the gap between the segments is untouched
+
+
 def test_kl_pred_loss_against_oracle_and_degenerate_rows(ops):
     """L_PRED (cs/train.py:398-402): Categorical KL of the renormalised probabilities, summed over the batch, with
     its gradient wrt the student probabilities; rows where the reference would produce NaN/inf stay finite."""
