@@ -63,6 +63,7 @@ SIGNATURES = {
     "evc_rep_loss": [vp, vp, i32, i32, f32, vp, vp, i32, vp],
     "evc_grad_sqnorm": [vp, vp, f32, i64, vp, vp],
     "evc_clip_adam_step": [vp, vp, vp, vp, i64, f32, vp, f32, f32, f32, f32, f32, vp, vp],
+    "evc_clip_adam_small": [i32, vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, vp],
     "evc_sqnorm2_partials": [vp, i64, vp, i64, vp, vp],
     "evc_lstm_adam_fused": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, f32, f32, f32, f32, f32, vp, vp, i64, vp, i64, i32, i32,
                             vp, i64, i32, i32, i32, i32, vp],

@@ -976,6 +976,15 @@ class TowerBase:
                                  self.shadow_fwd[k], self.shadow_bwd[k], beta1, beta2, eps, **img)
                 done.add(k)
         rest = [k for k in names if k not in done]
+        # small tensors without an l2 term and without operand shadows (biases, batch-norm scales / offsets): one launch for up to 16 of them
+        small = [k for k in rest if k not in self.l2_names and k not in self.shadow_fwd and self.store.p(k).numel() <= (1 << 20)]
+        if self.fused_small_adam and len(small) >= 2 and not ops.DETERMINISTIC:
+            st = self.store
+            for i in range(0, len(small), 16):
+                grp = small[i:i + 16]
+                ops.clip_adam_small([st.p(k) for k in grp], [st.g(k) for k in grp], [st.view(st.m, k) for k in grp], [st.view(st.v, k) for k in grp],
+                                    [self.sums[idx[k]] for k in grp], clip_norm, lr_t, beta1, beta2, eps)
+            rest = [k for k in rest if k not in small]
         for k in rest:
             l2 = l2_coeff if k in self.l2_names else 0.0
             # (tensors without a regulariser: the norm pass reads the gradient only)
@@ -997,6 +1006,7 @@ class TowerBase:
                     il = p.shape[0] // 4 if k.endswith("basic_lstm_cell/kernel") else 0
                     ops.transpose_to_bf16(p, p.shape[0], p.shape[1], sb, sb.shape[1], interleave_H=il)
 
+    fused_small_adam = os.environ.get("EVC_FUSED_SMALL_ADAM", "1") != "0"   # A/B: 0 = grad_sqnorm + clip_adam launches per small tensor
     fused_lstm_adam = os.environ.get("EVC_FUSED_LSTM_ADAM", "1") != "0"     # A/B: 0 = grad_sqnorm / clip_adam / transpose / cast launches per tensor
 
     def _adam_images_2d(self, k):

@@ -507,6 +507,16 @@ def rep_loss(state_t, state_s, loss, dstate_s=None, grad_scale=1.0, accumulate_g
     _lib.call("evc_rep_loss", _p(state_t), _p(state_s), B, D, grad_scale, _p(loss), _p(dstate_s), 1 if accumulate_grad else 0, _stream())
 
 
+def clip_adam_small(ps, gs, ms, vs, sums, clip_norm, lr_t, beta1=0.9, beta2=0.999, eps=1e-8):
+    """Per-tensor clip + TF-Adam of up to 16 small tensors (no l2 term) in one launch (evc_clip_adam_small): sums[i] receives {|g_i|^2, 0}."""
+    import ctypes as C
+    k = len(ps)
+    assert 1 <= k <= 16 and len(gs) == len(ms) == len(vs) == len(sums) == k
+    arr = lambda ts: (C.c_void_p * k)(*[_p(t) for t in ts])
+    n = (C.c_int64 * k)(*[t.numel() for t in ps])
+    _lib.call("evc_clip_adam_small", k, arr(ps), arr(gs), arr(ms), arr(vs), n, arr(sums), clip_norm, lr_t, beta1, beta2, eps, _stream())
+
+
 def grad_sqnorm(g, p, l2_coeff, sums):
     _lib.call("evc_grad_sqnorm", _p(g), _p(p), l2_coeff, g.numel(), _p(sums), _stream())
 

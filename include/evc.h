@@ -36,7 +36,7 @@ extern "C" {
 #define EVC_ERR_HIP (-4)
 #define EVC_ERR_BAD_ARG (-5)
 
-#define EVC_VERSION 104   /* 104 (round 5): evc_lstm_level2_fwd, evc_ce_loss_ordered, evc_rep_loss_ordered, evc_gemm_tn2_slabs, evc_sum_slabs; evc_moe_grad_update* accept p_bf16 == NULL (forward shadow not written), evc_lstm_stack2_bwd runs M <= 512 stacks on the skinny pair launches, evc_dbof_cluster_pool_fwd walks tiles (EVC_DBOF_WALK), EVC_DETERMINISTIC parsed as "set, not empty, not 0"; 103 (round 4): evc_sqnorm2_partials, evc_lstm_adam_fused, evc_gram_slabs, evc_moe_grad_norms, evc_moe_grad_update_apply, evc_adam2d_fused, evc_colsum_bf16_det, evc_sample_sequence_gather, evc_relu6_fwd/bwd, evc_framepool_mean_fwd/bwd, evc_stream_create_cu_mask / evc_stream_destroy; EVC_DETERMINISTIC=1 read by the library; 102: evc_lstm_layer_fwd_f16_fp8lo, evc_lstm_stack2_fwd_f16_fp8lo, evc_gemm_nt_f16_fp8, evc_cast_f32_to_fp8_lo, evc_cast_f32_to_f16_fp8x, aux_mode 5, evc_moe_grad_update_wide; 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
+#define EVC_VERSION 104   /* 104 (round 5): evc_lstm_level2_fwd, evc_ce_loss_ordered, evc_rep_loss_ordered, evc_gemm_tn2_slabs, evc_sum_slabs, evc_clip_adam_small; evc_moe_grad_update* accept p_bf16 == NULL (forward shadow not written), evc_lstm_stack2_bwd runs M <= 512 stacks on the skinny pair launches, evc_dbof_cluster_pool_fwd walks tiles (EVC_DBOF_WALK), EVC_DETERMINISTIC parsed as "set, not empty, not 0"; 103 (round 4): evc_sqnorm2_partials, evc_lstm_adam_fused, evc_gram_slabs, evc_moe_grad_norms, evc_moe_grad_update_apply, evc_adam2d_fused, evc_colsum_bf16_det, evc_sample_sequence_gather, evc_relu6_fwd/bwd, evc_framepool_mean_fwd/bwd, evc_stream_create_cu_mask / evc_stream_destroy; EVC_DETERMINISTIC=1 read by the library; 102: evc_lstm_layer_fwd_f16_fp8lo, evc_lstm_stack2_fwd_f16_fp8lo, evc_gemm_nt_f16_fp8, evc_cast_f32_to_fp8_lo, evc_cast_f32_to_f16_fp8x, aux_mode 5, evc_moe_grad_update_wide; 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
 
 typedef uint16_t evc_bf16;
 typedef uint16_t evc_f16;   /* raw IEEE binary16 bits (the "high" precision forward operands of the L1 levels) */
@@ -433,6 +433,12 @@ int evc_grad_sqnorm(const float* g, const float* p, float l2_coeff, int64_t n, f
 int evc_clip_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float l2_coeff,
                        const float* sums, float clip_norm, float lr_t, float beta1, float beta2, float eps,
                        evc_bf16* p_bf16, void* stream);
+/* The same two graph nodes (per-tensor clip_by_norm + Adam; cs/train.py:241-242,329-334) for up to 16 SMALL tensors without an l2 term - biases,
+ * batch-norm scales / offsets - in one launch: workgroup i computes tensor i's squared gradient norm (block sum: a fixed order), leaves
+ * sums[i] = {|g|^2, 0} and applies the update (round 5: the DBoF step spent 14 launches on 12 k parameters).  p, g, m, v, n, sums: HOST arrays of
+ * `count` device pointers / sizes (copied into the launch's arguments); n[i] <= 2^20. */
+int evc_clip_adam_small(int count, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n,
+                        float* const* sums, float clip_norm, float lr_t, float beta1, float beta2, float eps, void* stream);
 
 /* ---- a11: FrameLevelLogisticModel pooling ------------------------------------
  * cs/frame_level_models.py:72-78: sum over ALL T (padded) frames / true n.

@@ -1112,6 +1112,42 @@ def test_gemm_tn_det_slabs_equal_the_product_and_repeat_bit_for_bit(ops, M, N1, 
         assert np.array_equal(got[:, N1:c2], C0.double().cpu().numpy()[:, N1:c2])    # the gap between the segments is untouched
 
 
+def test_clip_adam_small_equals_the_per_tensor_launches(ops):
+    """Round 5: per-tensor clip_by_norm + TF-Adam of several small tensors in ONE launch (evc_clip_adam_small: workgroup i = tensor i, norm by a
+    block sum) against evc_grad_sqnorm + evc_clip_adam_step per tensor and against the float64 formula - sizes that are not multiples of 4 or 256,
+    a tensor whose norm is below the clip threshold and one above it, 16 tensors (the limit) and the error for 17."""
+    rng = np.random.default_rng(8)
+    sizes = [1152, 8192, 1, 1024, 4716 * 2, 257, 3, 64, 100, 1000, 5, 8193, 2, 640, 77, 4096]
+    lr_t, clip, b1, b2, eps = 1.3e-3, 1.0, 0.9, 0.999, 1e-8
+    P = [torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(DEV) for n in sizes]
+    G = [torch.from_numpy((rng.standard_normal(n) * (0.3 if i % 2 else 0.003)).astype(np.float32)).to(DEV) for i, n in enumerate(sizes)]
+    Mo = [torch.from_numpy((rng.standard_normal(n) * 1e-2).astype(np.float32)).to(DEV) for n in sizes]
+    Vo = [torch.from_numpy((rng.random(n) * 1e-4).astype(np.float32)).to(DEV) for n in sizes]
+    a = [[t.clone() for t in L] for L in (P, Mo, Vo)]
+    b = [[t.clone() for t in L] for L in (P, Mo, Vo)]
+    sa = torch.full((len(sizes), 2), float("nan"), device=DEV)
+    sb = torch.zeros((len(sizes), 2), device=DEV)
+    ops.clip_adam_small(a[0], G, a[1], a[2], [sa[i] for i in range(len(sizes))], clip, lr_t, b1, b2, eps)
+    for i in range(len(sizes)):
+        ops.grad_sqnorm(G[i], None, 0.0, sb[i])
+        ops.clip_adam_step(b[0][i], G[i], b[1][i], b[2][i], 0.0, sb[i], clip, lr_t, b1, b2, eps)
+    torch.cuda.synchronize()
+    assert torch.allclose(sa[:, 0], sb[:, 0], rtol=2e-6, atol=0) and bool((sa[:, 1] == 0).all())
+    for i, n in enumerate(sizes):
+        g64 = G[i].double().cpu().numpy()
+        nrm = np.sqrt((g64 ** 2).sum())
+        gc = g64 * (clip / max(nrm, clip))
+        m64 = b1 * Mo[i].double().cpu().numpy() + (1 - b1) * gc
+        v64 = b2 * Vo[i].double().cpu().numpy() + (1 - b2) * gc * gc
+        p64 = P[i].double().cpu().numpy() - lr_t * m64 / (np.sqrt(v64) + eps)
+        for got, other, want in ((a[0][i], b[0][i], p64), (a[1][i], b[1][i], m64), (a[2][i], b[2][i], v64)):
+            assert np.abs(got.double().cpu().numpy() - want).max() <= 2e-6 * (np.abs(want).max() + 1e-6) + 1e-9, (i, n)
+            assert (got - other).abs().max().item() <= 1e-6 * (other.abs().max().item() + 1e-6) + 1e-9, (i, n)
+    assert (nrm_big := float(np.sqrt(sb[1, 0].item()))) > clip and float(np.sqrt(sb[0, 0].item())) < clip, nrm_big     # both sides of the clip
+    with pytest.raises(AssertionError):                               # 17 tensors: the table of one launch holds 16
+        ops.clip_adam_small(a[0] + [a[0][0]], G + [G[0]], a[1] + [a[1][0]], a[2] + [a[2][0]], [sa[i] for i in range(16)] + [sa[0]], clip, lr_t)
+
+
 def test_kl_pred_loss_against_oracle_and_degenerate_rows(ops):
     """L_PRED (cs/train.py:398-402): Categorical KL of the renormalised probabilities, summed over the batch, with
     its gradient wrt the student probabilities; rows where the reference would produce NaN/inf stay finite."""
