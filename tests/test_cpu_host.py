@@ -414,6 +414,9 @@ def test_bench_figures_flag_a_stall_in_the_timed_window():
     assert clean == {"ms_per_step_median": 10.2, "ms_per_step_max": 10.6, "stall_suspected": False}
     assert bench.step_stats([5.0, 5.0, 14.9])["stall_suspected"] is False and bench.step_stats([5.0, 5.0, 15.1])["stall_suspected"] is True
     assert set(bench.STAT_KEYS) == set(st)
+    # time lost outside the per-step events (before the first / behind the last step): the wall-clock mean gives it away
+    assert bench.step_stats([2.1] * 20, wall_ms_per_step=2.32)["stall_suspected"] is True
+    assert bench.step_stats([2.1] * 20, wall_ms_per_step=2.15)["stall_suspected"] is False
     runs = []
 
     def fake_run():
