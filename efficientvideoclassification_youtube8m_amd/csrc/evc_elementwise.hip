@@ -439,6 +439,56 @@ extern "C" int evc_cast_f32_to_f16(const float* in, int64_t ld_in, int R, int C,
   return EVC_OK;
 }
 
+// Time-dithered f16 images of a weight tensor (round 5; DESIGN.md 7 "dither"; oracle/lowprec.py::f16_dither_images is the bit-exact
+// restatement): image t of element i is one of w's two f16 NEIGHBOURS dn <= w <= up - the upper one when the element's 32-bit phase at
+// step t, fmix32(i ^ seed_mix) + t * 0x9E3779B9 (a golden-ratio rotation per step), lies below frac * 2^32, frac = (w - dn) / (up - dn).
+// In any run of n consecutive images an element is rounded up n * frac times +- a few (2.03 measured over every run inside 20 steps): the rounding errors a recurrence integrates over its
+// steps cancel instead of adding up.  4 elements per thread; every image row-major like the input, image t at out + t * img_stride.
+__device__ __forceinline__ uint32_t fmix32_(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+__global__ __launch_bounds__(256) void cast_f16_dither_kernel(const float* __restrict__ in, long n4, int T, long img_stride, uint32_t seed_mix,
+                                                              f16_t* __restrict__ out) {
+  for (long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += (long)gridDim.x * blockDim.x) {
+    const float4 f = ((const float4*)in)[i4];
+    const float w[4] = {f.x, f.y, f.z, f.w};
+    uint32_t dn[4], up[4], thr[4], ph[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t hb = f32_to_f16(w[r]);
+      const float hf = f16_to_f32((f16_t)hb);
+      const bool zero = (hb & 0x7fffu) == 0, neg = (hb & 0x8000u) != 0;
+      const uint32_t below = zero ? 0x8001u : (neg ? hb + 1u : hb - 1u);      // next f16 towards -inf
+      const uint32_t above = zero ? 0x0001u : (neg ? hb - 1u : hb + 1u);      // next f16 towards +inf
+      dn[r] = hf > w[r] ? below : hb;
+      up[r] = hf < w[r] ? above : hb;
+      const float dnf = f16_to_f32((f16_t)dn[r]), gap = f16_to_f32((f16_t)up[r]) - dnf;
+      const float frac = gap > 0.f ? (w[r] - dnf) / gap : 0.f;                // exact: the numerator is exact, the gap a power of two (or inf: 0)
+      thr[r] = (uint32_t)fminf(frac * 4294967296.0f, 4294967040.0f);
+      ph[r] = fmix32_((uint32_t)(i4 * 4 + r) ^ seed_mix);
+    }
+    f16_t* o = out + i4 * 4;
+    for (int t = 0; t < T; ++t) {
+      const uint32_t rot = (uint32_t)t * 0x9E3779B9u;
+      uint32_t b[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) b[r] = (ph[r] + rot) < thr[r] ? up[r] : dn[r];
+      *(uint2*)(o + (long)t * img_stride) = make_uint2(b[0] | (b[1] << 16), b[2] | (b[3] << 16));
+    }
+  }
+}
+extern "C" int evc_cast_f32_to_f16_dither(const float* in, int64_t n, int T, int64_t img_stride, uint32_t seed, evc_f16* out, void* stream) {
+  EVC_REQUIRE(in && out && n > 0 && n % 4 == 0 && n < (1LL << 32) && T >= 1 && T <= 4096, EVC_ERR_BAD_SHAPE, "evc_cast_f32_to_f16_dither: n=%ld (%%4, < 2^32) T=%d", (long)n, T);
+  EVC_REQUIRE(img_stride >= n && img_stride % 4 == 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 8) == 0, EVC_ERR_BAD_ALIGN,
+              "evc_cast_f32_to_f16_dither: img_stride=%ld (>= n, %%4), in 16-byte, out 8-byte aligned", (long)img_stride);
+  const long n4 = n / 4;
+  const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+  hipLaunchKernelGGL(cast_f16_dither_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, n4, T, (long)img_stride, seed * 0x9E3779B9u, (f16_t*)out);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
 // IEEE f16 weight image of an LSTM kernel whose x-part is contracted as a K-extension (evc_lstm_layer_fwd_f16 on nseg x-segments):
 // out row = [f16(Wx) | f16(Wx)/64 | (Wx - f16(Wx))*64 | f16(Wh)] (the first nseg of the three x blocks), in = [Wx(Kin) | Wh(H)] f32.
 __global__ void cast_f16_wide_kernel(const float* __restrict__ in, long ld_in, int R, int Kin, int H, int nseg, int h_ext, f16_t* __restrict__ out) {

@@ -236,6 +236,10 @@ struct MoeUpdateParams {
   float l2, clip, lr_t, b1, b2, eps;
 };
 
+#ifndef EVC_MOE_UPD_EARLY_MV
+#define EVC_MOE_UPD_EARLY_MV 0          // (A/B, round 5: 1 = m and v asked for ahead of the factor product like p - 219 VGPRs, still one workgroup per CU;
+                                        //  measured 459-462 / 309-316 us against 442-456 / 302-305: nothing, the pass is not waiting for those loads)
+#endif
 #ifndef EVC_MOE_UPD_WAVES_PER_EU
 #define EVC_MOE_UPD_WAVES_PER_EU 2      // (A/B: 4 = cap the kernel at 128 VGPRs so that two of its 80 KB workgroups share a CU)
 #endif
@@ -262,6 +266,21 @@ __global__ __launch_bounds__(Cfg::NT, EVC_MOE_UPD_WAVES_PER_EU) void moe_update_
       const int vr = m0 + tc.row0 + mi * 16, k = n0 + tc.unit0 + ni * 16;
       pv[mi][ni] = (vr < u.V && k < K) ? *(const float4*)(u.p + (long)vr * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+#if EVC_MOE_UPD_EARLY_MV
+  // (A/B) m and v asked for up front too: the update pass owns its CU either way (184 -> 219 VGPRs, still one 8-wave workgroup)
+  float4 mv[Cfg::MI][Cfg::NI], vv[Cfg::MI][Cfg::NI];
+  if (PASS == 2) {
+#pragma unroll
+    for (int mi = 0; mi < Cfg::MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < Cfg::NI; ++ni) {
+        const int vr = m0 + tc.row0 + mi * 16, k = n0 + tc.unit0 + ni * 16;
+        const bool ok = vr < u.V && k < K;
+        mv[mi][ni] = ok ? *(const float4*)(u.m + (long)vr * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        vv[mi][ni] = ok ? *(const float4*)(u.v + (long)vr * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+  }
+#endif
   gemm_mainloop_tn<Cfg, true>(p, m0, n0, lds_dyn, acc);
   if (PASS == 1) {
     float sg = 0.f, sp = 0.f;
@@ -296,6 +315,7 @@ __global__ __launch_bounds__(Cfg::NT, EVC_MOE_UPD_WAVES_PER_EU) void moe_update_
     }
     return;
   }
+#if !EVC_MOE_UPD_EARLY_MV
   float4 mv[Cfg::MI][Cfg::NI], vv[Cfg::MI][Cfg::NI];
 #pragma unroll
   for (int mi = 0; mi < Cfg::MI; ++mi)
@@ -306,6 +326,7 @@ __global__ __launch_bounds__(Cfg::NT, EVC_MOE_UPD_WAVES_PER_EU) void moe_update_
       mv[mi][ni] = ok ? *(const float4*)(u.m + (long)vr * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
       vv[mi][ni] = ok ? *(const float4*)(u.v + (long)vr * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+#endif
   float scale = 1.f;
   if (u.clip > 0.f) scale = u.clip / fmaxf(sqrtf(u.sums[0]), u.clip);      // tf.clip_by_norm
   float wsq = 0.f;                                     // sum of the NEW weights squared (the next update's |W|^2: evc_moe_grad_norms)

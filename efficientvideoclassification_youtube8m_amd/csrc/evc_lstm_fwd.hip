@@ -90,13 +90,14 @@ __device__ __forceinline__ void lstm_fwd_epilogue(const GemmOperands& p, const L
       const uint32_t hu = (uint32_t)m * (uint32_t)H + (uint32_t)u;                      // element index in an [M][H] slab
       const uint32_t su4 = ((uint32_t)rm[mi] * (uint32_t)e.ld_state + (uint32_t)u) * 4u;   // byte offset in c_state / h_state
       // byte offset of this lane's 4 units in hout: FP8 rows are [f16(h) (H halfwords) | e4m3 (H bytes)] = 3H bytes, wide f16 rows 2H halfwords
-      const uint32_t hw2 = FP8 ? (uint32_t)m * (uint32_t)(3 * H) + (uint32_t)u * 2u : (F16 && e.h_wide) ? ((uint32_t)m * (uint32_t)(2 * H) + (uint32_t)u) * 2u : hu * 2u;
+      const bool rows8 = FP8 && e.h_wide == 2;        // (an FP8 launch with h_wide 0 - evc_lstm_layer_fwd_f16_dith, whose e4m3 stages are the input's only - writes plain f16 rows)
+      const uint32_t hw2 = rows8 ? (uint32_t)m * (uint32_t)(3 * H) + (uint32_t)u * 2u : (F16 && e.h_wide == 1) ? ((uint32_t)m * (uint32_t)(2 * H) + (uint32_t)u) * 2u : hu * 2u;
       const uint32_t h8o = (uint32_t)m * (uint32_t)(3 * H) + (uint32_t)(2 * H) + (uint32_t)u;      // (FP8: the row's e4m3 part)
       const u32x2_t z2 = {0u, 0u};
       if (e.t >= ln[mi]) {          // dynamic_rnn: state copied through, zero output
         store8<SP>(e.hout, hw2, z2);
-        if (FP8) store4<SP>(e.hout, h8o, 0u);
-        else if (F16 && e.h_wide) store8<SP>(e.hout, hw2 + (uint32_t)H * 2u, z2);
+        if (rows8) store4<SP>(e.hout, h8o, 0u);
+        else if (F16 && e.h_wide == 1) store8<SP>(e.hout, hw2 + (uint32_t)H * 2u, z2);
         if (F16) store8<SP>(e.hout_lo, hu * 2u, z2);
         if (SPLIT) {
           const uint32_t wo = ((uint32_t)m * (uint32_t)(2 * H) + (uint32_t)u) * 2u;
@@ -142,11 +143,11 @@ __device__ __forceinline__ void lstm_fwd_epilogue(const GemmOperands& p, const L
       if (F16) {
         const uint32_t p01 = pack_f16x2_hw(hn[0], hn[1]), p23 = pack_f16x2_hw(hn[2], hn[3]);
         store8<SP>(e.hout, hw2, u32x2_t{p01, p23});
-        if (FP8) {                  // e4m3(h * 2^7): the activation operand of the weights' low-order halves (|h| < 1: no saturation)
+        if (rows8) {                // e4m3(h * 2^7): the activation operand of the weights' low-order halves (|h| < 1: no saturation)
           int w8 = __builtin_amdgcn_cvt_pk_fp8_f32(hn[0] * 128.0f, hn[1] * 128.0f, 0, false);
           w8 = __builtin_amdgcn_cvt_pk_fp8_f32(hn[2] * 128.0f, hn[3] * 128.0f, w8, true);
           store4<SP>(e.hout, h8o, (uint32_t)w8);
-        } else if (e.h_wide) {      // f16(h)/64: the operand of the weights' low-order halves (scaled by 64)
+        } else if (e.h_wide == 1) { // f16(h)/64: the operand of the weights' low-order halves (scaled by 64)
           const float s0 = f16_to_f32((f16_t)(p01 & 0xffffu)) * (1.0f / 64.0f), s1 = f16_to_f32((f16_t)(p01 >> 16)) * (1.0f / 64.0f);
           const float s2 = f16_to_f32((f16_t)(p23 & 0xffffu)) * (1.0f / 64.0f), s3 = f16_to_f32((f16_t)(p23 >> 16)) * (1.0f / 64.0f);
           store8<SP>(e.hout, hw2 + (uint32_t)H * 2u, u32x2_t{pack_f16x2_hw(s0, s1), pack_f16x2_hw(s2, s3)});
@@ -341,7 +342,8 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
                                int T, int M, int Kin, int H, int hoist, float* zx_ws,
                                evc_bf16* hbuf, float* c_state, float* h_state, int64_t ld_state,
                                void* gates, evc_bf16* c_all, evc_bf16* hbuf_bf16,
-                               const int32_t* row_map, const int32_t* rows_per_step, void* stream, int f16 = 0, int64_t ldx = 0, int h_wide = 0);
+                               const int32_t* row_map, const int32_t* rows_per_step, void* stream, int f16 = 0, int64_t ldx = 0, int h_wide = 0,
+                               int64_t w_step_stride = 0);
 
 extern "C" int evc_lstm_layer_fwd(const evc_bf16* x, const evc_bf16* wT, const float* bias, const int32_t* len,
                                   int T, int M, int Kin, int H, int hoist, float* zx_ws,
@@ -368,7 +370,10 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
                                int T, int M, int Kin, int H, int hoist, float* zx_ws,
                                evc_bf16* hbuf, float* c_state, float* h_state, int64_t ld_state,
                                void* gates, evc_bf16* c_all, evc_bf16* hbuf_bf16,
-                               const int32_t* row_map, const int32_t* rows_per_step, void* stream, int f16, int64_t ldx, int h_wide) {
+                               const int32_t* row_map, const int32_t* rows_per_step, void* stream, int f16, int64_t ldx, int h_wide,
+                               int64_t w_step_stride) {
+  // w_step_stride (elements; 0 = one image): step t contracts the weight image at wT + t * w_step_stride (time-dithered f16 images,
+  // evc_lstm_layer_fwd_f16_dith)
   // f16: x, wT, hbuf hold IEEE f16 (16-bit containers), hbuf_bf16 receives the bf16 copy of every h_t; ldx = row stride of x
   // (0: Kin); h_wide: hbuf rows are [h | h/64] (2H) and the kernel's h-part is [Wh | Wh_lo*64] (2H): the recurrent weights
   // K-extended by their low-order halves.  (The split-bf16 form of a layer is evc_lstm_layer_fwd_hp below.)
@@ -414,7 +419,7 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
     } else {
       p.A1 = x + (long)t * M * ldx; p.lda1 = ldx; k1 = Kin;
       p.A2 = hprev; p.lda2 = ldh; k2 = (t == 0) ? 0 : (int)ldh;
-      p.B = wT;
+      p.B = wT + (long)t * w_step_stride;
     }
     LstmFwdParams e;
     e.zx = hoist ? zx_ws + (long)t * M * 4 * H : nullptr; e.ldzx = 4L * H;
@@ -619,6 +624,96 @@ extern "C" int evc_lstm_layer_fwd_f16_fp8lo(const evc_f16* x, int64_t ldx, int k
     e.bias = bias; e.len = len; e.t = t;
     e.c_state = c_state; e.h_state = h_state; e.ld_state = ld_state;
     e.hout = hb + (long)(t + 1) * M * ldh; e.h_wide = 2;
+    e.hout_lo = hbuf_bf16 + (long)(t + 1) * M * H;
+    e.gates = gates ? (uint2*)gates + (long)t * M * H : nullptr;
+    e.c_hist = c_all ? c_all + (long)(t + 1) * M * H : nullptr;
+    e.row_map = row_map;
+    e.M = Mt; e.H = H;
+    switch (pick_fwd_tile_v3(Mt, H)) {
+      case 0: launch_lstm_fwd<CfgLstmV3_256, false, true, true>(p, e, k1, k2, st); break;
+      case 1: launch_lstm_fwd<CfgLstmV3_224, false, true, true>(p, e, k1, k2, st); break;
+      case 2: launch_lstm_fwd<CfgLstmV3_192, false, true, true>(p, e, k1, k2, st); break;
+      case 4: launch_lstm_fwd<CfgLstmV3_240, false, true, true>(p, e, k1, k2, st); break;
+      default: launch_lstm_fwd<CfgLstmV3_160, false, true, true>(p, e, k1, k2, st); break;
+    }
+  }
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// "High" precision L1 layer on TIME-DITHERED f16 weight images (round 5; DESIGN.md 7 "dither"): step t contracts
+//   z = [x16 | h16] . W16_t^T  (IEEE f16; W16_t = image t of evc_cast_f32_to_f16_dither at wT16 + t * w16_step_stride)
+//       + 2^-scale8_exp  x8 . W8^T  (OCP e4m3 stages behind the f16 ones, kx8 > 0: the low-order half of the INPUT frames against an e4m3
+//         image of Wx - the one activation term f16 does not cover)
+// A weight's f16 rounding error is the same at every step of a chunk, so a recurrence integrates it coherently ("it is the
+// weights"); image t rounds every element down or up such that over any run of steps the round-ups match the element's position between
+// its two f16 neighbours - the errors cancel over the steps instead of adding up, and the weights' low-order halves need no stages of their
+// own (evc_lstm_layer_fwd_f16_fp8lo: 26 + 16 e4m3 stages per step pair of a two-layer level; here 9 + 0).  x rows as in
+// evc_lstm_layer_fwd_f16_fp8lo (kx16 halfwords at the row start, kx8 e4m3 bytes at byte offset x8_off; kx8 = 0: none, wT8 unused);
+// wT8: rows of ldb8 bytes whose first kx8 bytes are the e4m3 operand; hbuf [T+1][M][H] PLAIN f16 rows (the next layer's x with kx8 = 0),
+// hbuf_bf16 the bf16 copy.
+extern "C" int evc_lstm_layer_fwd_f16_dith(const evc_f16* x, int64_t ldx, int kx16, int64_t x8_off, int kx8, const evc_f16* wT16,
+                                           int64_t w16_step_stride, const uint8_t* wT8, int64_t ldb8, int scale8_exp, const float* bias,
+                                           const int32_t* len, int T, int M, int H, evc_f16* hbuf, evc_bf16* hbuf_bf16, float* c_state,
+                                           float* h_state, int64_t ld_state, void* gates, evc_bf16* c_all, const int32_t* row_map,
+                                           const int32_t* rows_per_step, void* stream) {
+  EVC_REQUIRE(T > 0 && M > 0 && H > 0 && kx16 > 0 && kx8 >= 0, EVC_ERR_BAD_SHAPE, "evc_lstm_layer_fwd_f16_dith: bad shape");
+  EVC_REQUIRE(x && wT16 && hbuf && hbuf_bf16 && bias && len, EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd_f16_dith: NULL operand");
+  EVC_REQUIRE(w16_step_stride >= 0 && w16_step_stride % 8 == 0 && ((uintptr_t)wT16 % 16) == 0, EVC_ERR_BAD_ALIGN,
+              "evc_lstm_layer_fwd_f16_dith: w16_step_stride=%ld (>= 0, %%8: every image 16-byte aligned)", (long)w16_step_stride);
+  EVC_REQUIRE(w16_step_stride == 0 || w16_step_stride >= 4L * H * ((long)kx16 + H), EVC_ERR_BAD_ARG,
+              "evc_lstm_layer_fwd_f16_dith: w16_step_stride=%ld is smaller than one [4H][kx16 + H] image", (long)w16_step_stride);
+  if (kx8 == 0) {                // no e4m3 stages: the plain f16 layer on per-step images
+    EVC_REQUIRE(ldx >= kx16 && ldx % 8 == 0 && ((uintptr_t)hbuf_bf16 % 8) == 0, EVC_ERR_BAD_ALIGN, "evc_lstm_layer_fwd_f16_dith: ldx=%ld (>= kx16=%d, %%8)", (long)ldx, kx16);
+    return lstm_layer_fwd_impl((const evc_bf16*)x, (const evc_bf16*)wT16, bias, len, T, M, kx16, H, 0, nullptr, (evc_bf16*)hbuf, c_state, h_state,
+                               ld_state, gates, c_all, hbuf_bf16, row_map, rows_per_step, stream, 1, ldx, 0, w16_step_stride);
+  }
+  EVC_REQUIRE(kx16 % 64 == 0 && H % 128 == 0 && kx8 % 128 == 0 && kx8 >= 384, EVC_ERR_BAD_SHAPE,
+              "evc_lstm_layer_fwd_f16_dith: kx16=%d (%%64), H=%d (%%128), kx8=%d (%%128, >= 384: the ring must be full of e4m3 stages at t = 0)", kx16, H, kx8);
+  EVC_REQUIRE(wT8 && ldb8 >= kx8 && ldb8 % 16 == 0 && ((uintptr_t)wT8 % 16) == 0, EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd_f16_dith: wT8 rows of ldb8=%ld bytes (>= kx8, %%16)", (long)ldb8);
+  EVC_REQUIRE(ldx % 8 == 0 && x8_off % 16 == 0 && ldx >= kx16 && ldx * 2 >= x8_off + kx8 && ((uintptr_t)x % 16) == 0 &&
+              ((uintptr_t)hbuf % 16) == 0 && ((uintptr_t)hbuf_bf16 % 8) == 0, EVC_ERR_BAD_ALIGN,
+              "evc_lstm_layer_fwd_f16_dith: ldx=%ld (%%8), x8_off=%ld (%%16), 16-byte aligned operands", (long)ldx, (long)x8_off);
+  EVC_REQUIRE(scale8_exp >= 0 && scale8_exp <= 80, EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd_f16_dith: scale8_exp=%d", scale8_exp);
+  const long ldh = H;                                // halfwords per hbuf row (plain)
+  EVC_REQUIRE(ring_operand_ok(M, ldx > ldh ? ldx : ldh) && ring_operand_ok(4L * H, (long)kx16 + H) && ring_operand_ok(4L * H, (ldb8 + 1) / 2), EVC_ERR_BAD_SHAPE,
+              "evc_lstm_layer_fwd_f16_dith: a time slab or a weight image spans 4 GiB or more");
+  EVC_REQUIRE(fwd_tail_ok(M, H, ld_state), EVC_ERR_BAD_SHAPE, "LSTM forward: a gate-record / state slab spans 4 GiB or more (M=%d H=%d ld_state=%ld)", M, H, (long)ld_state);
+  EVC_REQUIRE(ld_state % 4 == 0 && ((uintptr_t)c_state % 16) == 0 && ((uintptr_t)h_state % 16) == 0 && ((uintptr_t)bias % 16) == 0, EVC_ERR_BAD_ALIGN,
+              "evc_lstm_layer_fwd_f16_dith: state/bias must allow 16-byte vector access");
+  EVC_REQUIRE((gates == nullptr) == (c_all == nullptr), EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd_f16_dith: gates and c_all go together");
+  EVC_REQUIRE(!gates || (((uintptr_t)gates % 16) == 0 && ((uintptr_t)c_all % 8) == 0), EVC_ERR_BAD_ALIGN,
+              "evc_lstm_layer_fwd_f16_dith: gates must be 16-byte, c_all 8-byte aligned");
+  if (rows_per_step)
+    for (int t = 0; t < T; ++t)
+      EVC_REQUIRE(rows_per_step[t] >= 0 && rows_per_step[t] <= M && (t == 0 || rows_per_step[t] <= rows_per_step[t - 1]), EVC_ERR_BAD_ARG,
+                  "evc_lstm_layer_fwd_f16_dith: rows_per_step[%d]=%d must be non-increasing and within [0, M=%d]", t, rows_per_step[t], M);
+  hipStream_t st = (hipStream_t)stream;
+  const bf16_t* xb = (const bf16_t*)x;
+  bf16_t* hb = (bf16_t*)hbuf;
+  EVC_CHECK_HIP(hipMemsetAsync(hb, 0, (size_t)M * ldh * sizeof(bf16_t), st));            // h_{-1} = 0
+  EVC_CHECK_HIP(hipMemsetAsync(hbuf_bf16, 0, (size_t)M * H * sizeof(bf16_t), st));
+  for (int t = 0; t < T; ++t) {
+    const int Mt = rows_per_step ? rows_per_step[t] : M;
+    if (Mt == 0) break;
+    GemmOperands p;
+    p.M = Mt; p.Nu = H; p.group_stride = H; p.nk1 = p.nk2 = 0;
+    p.A1lo = p.A2lo = p.Blo = nullptr;
+    const bf16_t* xt = xb + (long)t * M * ldx;
+    const bf16_t* hprev = hb + (long)t * M * ldh;
+    p.A1 = xt; p.lda1 = ldx;
+    p.A2 = hprev; p.lda2 = ldh;
+    p.B = (const bf16_t*)wT16 + (long)t * w16_step_stride; p.ldb = (long)kx16 + H;
+    p.A3 = (const uint8_t*)xt + x8_off; p.lda3 = ldx * 2; p.nk3 = kx8 / 128;
+    p.A4 = p.A3; p.lda4 = p.lda3; p.nk4 = 0;                                            // no e4m3 stages of h
+    p.B8 = wT8; p.ldb8 = ldb8;
+    p.scale8_exp = -scale8_exp;
+    const int k1 = kx16, k2 = t == 0 ? 0 : H;
+    LstmFwdParams e;
+    e.zx = nullptr; e.ldzx = 0;
+    e.bias = bias; e.len = len; e.t = t;
+    e.c_state = c_state; e.h_state = h_state; e.ld_state = ld_state;
+    e.hout = hb + (long)(t + 1) * M * ldh; e.h_wide = 0;
     e.hout_lo = hbuf_bf16 + (long)(t + 1) * M * H;
     e.gates = gates ? (uint2*)gates + (long)t * M * H : nullptr;
     e.c_hist = c_all ? c_all + (long)(t + 1) * M * H : nullptr;

@@ -206,6 +206,33 @@ class LstmStack:
                                         self.zx, hw[0], hw[1], hb[0], hb[1], self.S, gates, c_all,
                                         x_segments=tw.f16_l2_x_segments, h0_ext=tw.f16_l2_h0_ext)
                 return self.S
+            if self.scope == "RNN_L1" and tw.dither():
+                # time-dithered f16 weight images (ops.lstm_layer_fwd_f16_dith, DESIGN.md 7 "dither"): step t contracts image t, whose rounding
+                # errors cancel over the steps of a chunk - no stages for the weights' low-order halves; layer 0 keeps the e4m3 stages of the
+                # INPUT's low-order half (x rows [f16(x) | e4m3(x 2^7) | e4m3(x_lo 2^18)] of ops.l2norm_chunk(fp8_tail=True) against the
+                # e4m3(Wx 2^6) block of cast_fp8_lo's image), the layers above read the plain f16 h rows of the layer below
+                if not hasattr(self, "hbuf16p"):
+                    self.hbuf16p = [torch.zeros((self.T + 1, self.M, H), dtype=ops.F16, device=self.hbuf[l].device) for l in range(L)]
+                h16 = [self._v(self.hbuf16p[l], T + 1, M, H) for l in range(L)]
+                assert x16.shape[-1] == 2 * self.Kin, "the dithered L1 level takes ops.l2norm_chunk(..., f16_segments=1, fp8_tail=True) rows"
+                inp, ldx, kx16, x8_off, kx8 = x16, x16.shape[-1], self.Kin, 3 * self.Kin, self.Kin
+                for l in range(L):
+                    kn, bn = self.names(l)
+                    w8 = tw.shadow8[kn][:, self.Kin:2 * self.Kin] if l == 0 else None      # the e4m3(Wx 2^6) block of [lo(Wx) | hi(Wx) | lo(Wh)] rows
+                    assert tw.shadow16d[kn].shape[0] >= T
+                    if self.timing is not None:
+                        e0 = torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                    ops.lstm_layer_fwd_f16_dith(inp, ldx, kx16, x8_off, kx8, tw.shadow16d[kn], w8, tw.shadow8[kn].stride(0) if l == 0 else 0,
+                                                7 + ops.FP8_W_SCALE_EXP, tw.store.p(bn), lens, T, M, H, h16[l], hb[l],
+                                                self.S[:, (2 * l) * H:], self.S[:, (2 * l + 1) * H:], 2 * L * H, gates[l], c_all[l], plan=plan)
+                    if self.timing is not None:
+                        e1 = torch.cuda.Event(enable_timing=True)
+                        e1.record()
+                        flops = sum(2.0 * r * 4 * H * (self.kin[l] + (H if t > 0 else 0)) for t, r in enumerate(rows))
+                        self.timing.append((e0, e1, sum(1 for r in rows if r > 0), flops))
+                    inp, ldx, kx16, x8_off, kx8 = h16[l][1:], H, H, 0, 0
+                return self.S
             if self.scope == "RNN_L1" and tw.fp8_lo():
                 # weights' low-order halves in fp8 (ops.lstm_layer_fwd_f16_fp8lo): h rows [f16(h) | e4m3(h 2^7)] of 3H bytes; layer 0 reads
                 # the [f16(x) | e4m3(x 2^7) | e4m3(x_lo 2^18)] rows of ops.l2norm_chunk(fp8_tail=True), the layers above the h rows of the layer below
@@ -961,6 +988,7 @@ class TowerBase:
                 ops.lstm_adam_fused(st.p(k), st.g(k), st.view(st.m, k), st.view(st.v, k), st.p(b), st.g(b), st.view(st.m, b), st.view(st.v, b),
                                     ws, self.sums[idx[k]], self.sums[idx[b]], clip_norm, lr_t, self.shadow_fwd[k], self.shadow_bwd[k],
                                     beta1, beta2, eps, **img)
+                self._after_fused_adam(k)
                 done.update((k, b))
             # plain 2-D weights without a regulariser (DBoF cluster / hidden weights, ...): the same pass without a bias (ops.adam2d_fused)
             for k in names:
@@ -1021,6 +1049,9 @@ class TowerBase:
 
     def _fp8_exps(self, k):
         return ops.FP8_MOE
+
+    def _after_fused_adam(self, k):
+        """Operand images of LSTM kernel k that ops.lstm_adam_fused does not write (HLstmTower: the time-dithered f16 images)."""
 
     def _adam_images(self, k):
         """Keyword arguments of ops.lstm_adam_fused describing the non-bf16 forward operand images of LSTM kernel k that the update pass
@@ -1105,8 +1136,22 @@ class HLstmTower(TowerBase):
     l2_fp8_lo = os.environ.get("EVC_HIGH_L2_FP8", os.environ.get("EVC_HIGH_FP8_LO", "1")) != "0"
 
     def fp8_lo(self):
-        """True if this tower's L1 level runs on ops.lstm_layer_fwd_f16_fp8lo."""
+        """True if this tower's L1 level runs on ops.lstm_layer_fwd_f16_fp8lo (or, with dither(), on ops.lstm_layer_fwd_f16_dith)."""
         return (self.precision == "high" and self.f16_fp8_lo and self.F % 128 == 0 and self.H % 128 == 0 and self.F >= 384 and self.H >= 384)
+
+    # L1 level on TIME-DITHERED f16 weight images (round 5, DESIGN.md 7 "dither"; ops.lstm_layer_fwd_f16_dith): step t of a chunk contracts
+    # image t of every L1 kernel - each element rounded down or up so that the round-ups over any run of steps match its position between
+    # its f16 neighbours.  The f16 rounding of a WEIGHT is the error a recurrence integrates coherently (the reason for the e4m3 low-order
+    # halves above); dithered over the steps it cancels instead, and the level needs no stages for the weights' low-order halves: per step
+    # pair 34 + 9 (the input's low-order half) and 32 + 0 stages instead of 34 + 26 and 32 + 16.  Costs T images per L1 kernel (15 x 35 MB
+    # for the teacher) and one pass over them per update.  EVC_HIGH_DITHER=0: the e4m3 low-order halves of every weight (rounds 3-5).
+    f16_dither = os.environ.get("EVC_HIGH_DITHER", "1") != "0"
+
+    def dither(self):
+        return self.fp8_lo() and self.f16_dither
+
+    def l1_steps(self):
+        return self.T // self.C
 
     def input_split(self):
         """The `split` argument of ops.l2norm_chunk that produces this tower's L1 input."""
@@ -1116,11 +1161,19 @@ class HLstmTower(TowerBase):
         dev, H, F, K = self.device, self.H, self.F, self.K
         self.shadow_lo = {}                                              # (no separate low-order shadows in this tower)
         self.shadow16, self.shadow_wx, self.shadow_wh, self.shadow_w, self.shadow8 = {}, {}, {}, {}, {}
+        self.shadow16d = {}                                              # L1 kernels: [T][4H][in + H] time-dithered f16 images (dither())
         self.shadow_w16, self.shadow_w8 = {}, {}                      # MoE head in "high": f16(W) and [e4m3(W_lo) | e4m3(W)] (ops.gemm_nt_f16_fp8)
         for k, shp in self.store.shapes.items():
             if len(shp) != 2:
                 continue
-            if k.startswith("RNN_L1/") and self.fp8_lo():
+            if k.startswith("RNN_L1/") and self.dither():
+                # T time-dithered f16 images; layer 0 also keeps cast_fp8_lo's [lo(Wx) | e4m3(Wx 2^6) | lo(Wh)] rows for their middle block
+                nin = shp[1] - H
+                layer = int(k.split("cell_")[1].split("/")[0])
+                self.shadow16d[k] = torch.zeros((self.l1_steps(),) + tuple(shp), dtype=ops.F16, device=dev)
+                if layer == 0:
+                    self.shadow8[k] = torch.zeros((shp[0], shp[1] + nin), dtype=torch.uint8, device=dev)
+            elif k.startswith("RNN_L1/") and self.fp8_lo():
                 nin = shp[1] - H
                 layer = int(k.split("cell_")[1].split("/")[0])
                 self.shadow16[k] = torch.zeros(shp, dtype=ops.F16, device=dev)
@@ -1159,6 +1212,10 @@ class HLstmTower(TowerBase):
         if k in self.shadow_w8:              # MoE head: f16(W) + [e4m3((W - f16(W)) 2^18) | e4m3(W 2^7)]
             ops.cast_f16(p, self.shadow_w16[k])
             ops.cast_fp8_lo(p, self.shadow_w8[k], hi_cols=p.shape[1], scale_exp=ops.FP8_MOE["w_lo_exp"], hi_exp=ops.FP8_MOE["w_hi_exp"])
+        elif k in self.shadow16d:            # L1 level, time-dithered f16 images (layer 0: + cast_fp8_lo's rows for the e4m3(Wx 2^6) block)
+            ops.cast_f16_dither(p, self.shadow16d[k], self.dither_seed(k))
+            if k in self.shadow8:
+                ops.cast_fp8_lo(p, self.shadow8[k], hi_cols=self.shadow8[k].shape[1] - p.shape[1])
         elif k in self.shadow8 and k.startswith("RNN_L2/"):     # L2 level, fp8 low-order halves
             nin = p.shape[1] - H
             if "cell_0" in k:
@@ -1194,7 +1251,8 @@ class HLstmTower(TowerBase):
     def precision_layout(self):
         d = {"precision": self.precision}
         if self.precision == "high":
-            d.update(l1="f16 + e4m3 low-order halves (weights, input frames)" if self.fp8_lo() else
+            d.update(l1=("f16 on %d time-dithered weight images per kernel + e4m3 low-order half of the input frames" % self.l1_steps()) if self.dither() else
+                     "f16 + e4m3 low-order halves (weights, input frames)" if self.fp8_lo() else
                      "f16, x segments %d, Wh extended in layers %s, Wx extended in layers %s" % (self.f16_x_segments, list(self.f16_wh_ext_layers), list(self.f16_wx_ext_layers)),
                      l2=("f16 + e4m3 low-order halves, %d input segments" % self.f16_l2_x_segments) if any(k.startswith("RNN_L2/") for k in getattr(self, "shadow8", {}))
                      else ("f16 K-extensions, %d input segments, h0_ext %s" % (self.f16_l2_x_segments, self.f16_l2_h0_ext) if self.L == 2 else "split-bf16"),
@@ -1230,6 +1288,8 @@ class HLstmTower(TowerBase):
             return {}
         p, H = self.store.p(k), self.H
         nin = p.shape[1] - H
+        if k in self.shadow16d:              # dithered L1 kernel: the update pass writes layer 0's e4m3 rows; the T images follow (_after_fused_adam)
+            return dict(p_fp8=self.shadow8[k], fp8_col0=0, fp8_hi_cols=self.shadow8[k].shape[1] - p.shape[1]) if k in self.shadow8 else {}
         if k in self.shadow8 and k.startswith("RNN_L2/"):
             if "cell_0" in k:
                 return dict(p_f16=self.shadow16[k], nin=nin, nseg=self.f16_l2_x_segments, p_fp8=self.shadow8[k], fp8_col0=nin, fp8_hi_cols=0)
@@ -1242,6 +1302,14 @@ class HLstmTower(TowerBase):
                 nseg = (self.shadow16[k].shape[1] - H) // nin
                 return dict(p_f16=self.shadow16[k], nin=nin, nseg=nseg)
         return None
+
+    def dither_seed(self, k):
+        """Seed of kernel k's dither phases: its index among this tower's variables (any fixed value does; images are a pure function of (W, seed))."""
+        return 1 + list(self.names).index(k)
+
+    def _after_fused_adam(self, k):
+        if k in getattr(self, "shadow16d", {}):
+            ops.cast_f16_dither(self.store.p(k), self.shadow16d[k], self.dither_seed(k))
 
     # ---- parameters -------------------------------------------------------
     def _init_params(self, seed):

@@ -364,6 +364,26 @@ def lstm_layer_fwd_f16_fp8lo(x16, ldx, kx16, x8_off, kx8, wT16, wT8, bias, lens,
               _p(hbuf16), _p(hbuf_bf), _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_all), *_plan_args(plan), _stream())
 
 
+def lstm_layer_fwd_f16_dith(x16, ldx, kx16, x8_off, kx8, wT16_steps, wT8, ldb8, scale8_exp, bias, lens, T, M, H, hbuf16, hbuf_bf, c_state, h_state,
+                            ld_state, gates=None, c_all=None, plan=None):
+    """lstm_layer_fwd_f16 on time-dithered weight images (evc_lstm_layer_fwd_f16_dith): wT16_steps [T'][4H][kx16 + H] f16 from cast_f16_dither
+    (T' >= T; T' == 1: one image for every step), x16 rows of ldx halfwords with kx8 e4m3 bytes at byte offset x8_off (kx8 = 0: none) against
+    the first kx8 bytes of wT8's rows (row stride ldb8; a view into a cast_fp8_lo image), every e4m3 product scaled by 2^-scale8_exp;
+    hbuf16 [(T+1)][M][H] plain f16 rows, hbuf_bf the bf16 copy of h."""
+    assert x16.dtype == F16 and wT16_steps.dtype == F16 and hbuf16.dtype == F16 and hbuf_bf.dtype == BF16
+    assert wT16_steps.dim() == 3 and wT16_steps.shape[1:] == (4 * H, kx16 + H) and wT16_steps.is_contiguous() and wT16_steps.shape[0] in (1, ) + tuple(range(T, 4097))
+    assert (kx8 == 0) == (wT8 is None) and (wT8 is None or wT8.dtype == torch.uint8)
+    stride = 0 if wT16_steps.shape[0] == 1 else wT16_steps.stride(0)
+    _lib.call("evc_lstm_layer_fwd_f16_dith", _p(x16), ldx, kx16, x8_off, kx8, _p(wT16_steps), stride, _p(wT8), ldb8, scale8_exp, _p(bias), _p(lens), T, M, H,
+              _p(hbuf16), _p(hbuf_bf), _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_all), *_plan_args(plan), _stream())
+
+
+def cast_f16_dither(p, out, seed):
+    """out [T][...p.shape] f16: the T time-dithered f16 images of the f32 tensor p (evc_cast_f32_to_f16_dither; oracle/lowprec.py::f16_dither_images)."""
+    assert p.dtype == F32 and p.is_contiguous() and out.dtype == F16 and out.is_contiguous() and out.shape[1:] == p.shape
+    _lib.call("evc_cast_f32_to_f16_dither", _p(p), p.numel(), out.shape[0], out.stride(0) if out.shape[0] > 1 else p.numel(), int(seed) & 0xFFFFFFFF, _p(out), _stream())
+
+
 def lstm_level2_fwd(x, wT0, bias0, wT1, bias1, lens, T, M, Kin, H, hbuf0, hbuf1, S, gates=(None, None), c_all=(None, None), plan=None):
     """Two-layer L1 level in bf16, layer 0's step s and layer 1's step s-1 per launch (evc_lstm_level2_fwd): the results of two
     lstm_layer_fwd calls, bit for bit.  S [rows][4H] f32 = [c0 | h0 | c1 | h1]; with a RowPlan M = plan.P, lens = plan.lens."""

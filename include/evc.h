@@ -36,7 +36,7 @@ extern "C" {
 #define EVC_ERR_HIP (-4)
 #define EVC_ERR_BAD_ARG (-5)
 
-#define EVC_VERSION 104   /* 104 (round 5): evc_lstm_level2_fwd, evc_ce_loss_ordered, evc_rep_loss_ordered, evc_gemm_tn2_slabs, evc_sum_slabs, evc_clip_adam_small; evc_moe_grad_update* accept p_bf16 == NULL (forward shadow not written), evc_lstm_stack2_bwd runs M <= 512 stacks on the skinny pair launches, evc_dbof_cluster_pool_fwd walks tiles (EVC_DBOF_WALK), EVC_DETERMINISTIC parsed as "set, not empty, not 0"; 103 (round 4): evc_sqnorm2_partials, evc_lstm_adam_fused, evc_gram_slabs, evc_moe_grad_norms, evc_moe_grad_update_apply, evc_adam2d_fused, evc_colsum_bf16_det, evc_sample_sequence_gather, evc_relu6_fwd/bwd, evc_framepool_mean_fwd/bwd, evc_stream_create_cu_mask / evc_stream_destroy; EVC_DETERMINISTIC=1 read by the library; 102: evc_lstm_layer_fwd_f16_fp8lo, evc_lstm_stack2_fwd_f16_fp8lo, evc_gemm_nt_f16_fp8, evc_cast_f32_to_fp8_lo, evc_cast_f32_to_f16_fp8x, aux_mode 5, evc_moe_grad_update_wide; 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
+#define EVC_VERSION 105   /* 105 (round 5, second session): evc_cast_f32_to_f16_dither, evc_lstm_layer_fwd_f16_dith (time-dithered f16 weight images: the "high" L1 level without stages for the weights' low-order halves); 104 (round 5): evc_lstm_level2_fwd, evc_ce_loss_ordered, evc_rep_loss_ordered, evc_gemm_tn2_slabs, evc_sum_slabs, evc_clip_adam_small; evc_moe_grad_update* accept p_bf16 == NULL (forward shadow not written), evc_lstm_stack2_bwd runs M <= 512 stacks on the skinny pair launches, evc_dbof_cluster_pool_fwd walks tiles (EVC_DBOF_WALK), EVC_DETERMINISTIC parsed as "set, not empty, not 0"; 103 (round 4): evc_sqnorm2_partials, evc_lstm_adam_fused, evc_gram_slabs, evc_moe_grad_norms, evc_moe_grad_update_apply, evc_adam2d_fused, evc_colsum_bf16_det, evc_sample_sequence_gather, evc_relu6_fwd/bwd, evc_framepool_mean_fwd/bwd, evc_stream_create_cu_mask / evc_stream_destroy; EVC_DETERMINISTIC=1 read by the library; 102: evc_lstm_layer_fwd_f16_fp8lo, evc_lstm_stack2_fwd_f16_fp8lo, evc_gemm_nt_f16_fp8, evc_cast_f32_to_fp8_lo, evc_cast_f32_to_f16_fp8x, aux_mode 5, evc_moe_grad_update_wide; 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
 
 typedef uint16_t evc_bf16;
 typedef uint16_t evc_f16;   /* raw IEEE binary16 bits (the "high" precision forward operands of the L1 levels) */
@@ -196,6 +196,22 @@ int evc_lstm_layer_fwd_f16_fp8lo(const evc_f16* x, int64_t ldx, int kx16, int64_
                                  int T, int M, int H, evc_f16* hbuf, evc_bf16* hbuf_bf16, float* c_state, float* h_state,
                                  int64_t ld_state, void* gates, evc_bf16* c_all, const int32_t* row_map,
                                  const int32_t* rows_per_step, void* stream);
+/* evc_lstm_layer_fwd_f16 on TIME-DITHERED weight images (DESIGN.md 7 "dither"): step t contracts
+ *   z = [x16 | h16] . W16_t^T (IEEE f16; W16_t = the [4H][kx16 + H] image at wT16 + t * w16_step_stride halfwords, evc_cast_f32_to_f16_dither)
+ *       + 2^-scale8_exp x8 . W8^T (OCP e4m3 stages behind the f16 ones; kx8 = 0: none)
+ * - the same BasicLSTMCell step (cs/frame_level_models.py:221-250).  The f16 rounding error of a weight is the same at every step and is
+ * integrated coherently by the cell state (what evc_lstm_layer_fwd_f16_fp8lo spends 8-9 e4m3 stages per weight block on); image t rounds
+ * each element DOWN or UP so that over any run of steps the share of round-ups equals the element's position between its two f16
+ * neighbours: the errors cancel over the steps of a chunk and the weights need no correction stages.  The e4m3 stages that remain are the
+ * input frames' low-order half (layer 0: x rows of evc_l2norm_chunk_fwd aux_mode 5, kx16 = F, x8_off = 3F, kx8 = F against the
+ * e4m3(Wx 2^6) block of evc_cast_f32_to_fp8_lo's rows: wT8 = that block's first byte, ldb8 = the row stride, scale8_exp = 18 + 6).
+ * hbuf [(T+1)][M][H] PLAIN f16 rows (an upper layer's x: kx16 = H, kx8 = 0, wT8 NULL), hbuf_bf16 the bf16 copy; w16_step_stride = 0:
+ * one image for every step.  kx16 % 64 == 0; with kx8 > 0: H % 128 == 0, kx8 % 128 == 0, kx8 >= 384, ldb8 % 16 == 0. */
+int evc_lstm_layer_fwd_f16_dith(const evc_f16* x, int64_t ldx, int kx16, int64_t x8_off, int kx8, const evc_f16* wT16,
+                                int64_t w16_step_stride, const uint8_t* wT8, int64_t ldb8, int scale8_exp, const float* bias,
+                                const int32_t* len, int T, int M, int H, evc_f16* hbuf, evc_bf16* hbuf_bf16, float* c_state,
+                                float* h_state, int64_t ld_state, void* gates, evc_bf16* c_all, const int32_t* row_map,
+                                const int32_t* rows_per_step, void* stream);
 /* evc_lstm_stack2_fwd (below) on IEEE f16 operands, the "high" precision form of the L2 level: layer 0 plain f16 (x-projection
  * hoisted into one f16 product), layer 1 with its kernel K-extended by the weights' low-order halves - wT1_wlo [4H] rows
  * [f16(Wx) | (Wx - f16(Wx))*64 | f16(Wh) | (Wh - f16(Wh))*64] (evc_cast_f32_to_f16_wlo) against activation rows [h | h/64] - because
@@ -343,6 +359,12 @@ int evc_cast_f32_to_fp8_lo(const float* in, int64_t ld_in, int R, int C, int lo_
                            void* stream);
 /* out_f16[i] = f16(in_f32[i]), round to nearest even (the f16 weight shadows of evc_lstm_layer_fwd_f16). */
 int evc_cast_f32_to_f16(const float* in, int64_t ld_in, int R, int C, evc_f16* out, int64_t ld_out, void* stream);
+/* T time-dithered f16 images of n f32 values (n % 4 == 0, n < 2^32; image t at out + t * img_stride halfwords, same element order as in):
+ * image t of element i = up if (uint32)(fmix32(i ^ seed * 0x9E3779B9) + t * 0x9E3779B9) < frac * 2^32 else dn, with dn <= in[i] <= up its
+ * two f16 neighbours (equal when in[i] is an f16 value), frac = (in[i] - dn) / (up - dn), fmix32 = murmur3's finaliser: over any run of r
+ * images an element is rounded up r * frac times +- a few (2.03 measured over every run inside 20 steps) (golden-ratio rotation of a per-element phase).  The operand of
+ * evc_lstm_layer_fwd_f16_dith; restated bit for bit by oracle/lowprec.py::f16_dither_images. */
+int evc_cast_f32_to_f16_dither(const float* in, int64_t n, int T, int64_t img_stride, uint32_t seed, evc_f16* out, void* stream);
 /* f16 image of an LSTM kernel [R][Kin+H] (f32, row stride ld_in) for a K-extended x-part: out [R][nseg*Kin + H] =
  * [f16(Wx) | f16(Wx)/64 | (Wx - f16(Wx))*64 | f16(Wh) | (Wh - f16(Wh))*64] keeping the first nseg (1..3) x blocks and, with
  * h_ext = 1, the low-order block of the h-part (evc_lstm_layer_fwd_f16 with h_wide = 1). */

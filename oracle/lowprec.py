@@ -26,7 +26,14 @@ Round 5 adds the OCP FP6 format e2m3 (the same MFMA opcode takes it at twice the
   row_scale_exp(m)       the per-row power of two s (an e8m0 exponent, 127 + s on the device) that puts a row maximum m into [4, 8):
                          e2m3 has no range to spare, so every operand row carries its own scale (free on the MX-scaled MFMA: the
                          scale operands are per lane = per row)
-  corrected_product6(..) f16(x) . f16(W)^T + the two low-order corrections on e2m3 operands with per-row scales"""
+  corrected_product6(..) f16(x) . f16(W)^T + the two low-order corrections on e2m3 operands with per-row scales
+
+Round 5 (second session): time-dithered f16 images of a recurrent layer's weights (evc_cast_f32_to_f16_dither; DESIGN.md 7, "dither"):
+
+  f16_dither_images(w, T, seed)   T IEEE f16 images of w; image t holds, per element, one of w's two f16 NEIGHBOURS (dn <= w <= up), the upper one
+                         when the element's 32-bit phase at step t - a hash of its flat index, rotated by the golden ratio per step - falls
+                         below frac = (w - dn) / (up - dn): in any run of n consecutive steps an element is rounded up n frac times +- 2, so the
+                         rounding errors a recurrence integrates over its steps cancel instead of adding up.  Integer arithmetic: bit-exact."""
 import numpy as np
 
 
@@ -129,3 +136,53 @@ def corrected_product6(x, w, correct_x=True):
     if correct_x:
         z = z + e2m3_rows(x - x16) @ e2m3_rows(w).T
     return z
+
+
+# ---- time-dithered f16 images (round 5) ---------------------------------------------------------------------------------------
+DITHER_PHI32 = 0x9E3779B9          # round(2^32 / golden ratio): the per-step rotation of an element's phase
+
+
+def _fmix32(h):
+    """murmur3's 32-bit finaliser (uint32 arrays)."""
+    h = np.asarray(h, np.uint32).copy()
+    h ^= h >> np.uint32(16)
+    h *= np.uint32(0x85EBCA6B)
+    h ^= h >> np.uint32(13)
+    h *= np.uint32(0xC2B2AE35)
+    h ^= h >> np.uint32(16)
+    return h
+
+
+def f16_neighbours(w):
+    """(dn, up) float16 arrays with dn <= w <= up, adjacent (or equal where w is an f16 value) - w taken as float32."""
+    w32 = np.asarray(w, np.float32)
+    h = w32.astype(np.float16)
+    hf = h.astype(np.float32)
+    with np.errstate(over="ignore"):
+        up = np.where(hf >= w32, h, np.nextafter(h, np.float16(np.inf)))
+        dn = np.where(hf <= w32, h, np.nextafter(h, np.float16(-np.inf)))
+    return dn.astype(np.float16), up.astype(np.float16)
+
+
+def f16_dither_threshold(w):
+    """uint32 threshold of an element: round-up share frac = (w - dn) / (up - dn) as frac * 2^32 (f32 arithmetic, saturating below 2^32)."""
+    w32 = np.asarray(w, np.float32)
+    dn, up = f16_neighbours(w32)
+    gap = up.astype(np.float32) - dn.astype(np.float32)
+    frac = np.where(gap > 0, (w32 - dn.astype(np.float32)) / np.where(gap > 0, gap, np.float32(1)), np.float32(0)).astype(np.float32)
+    return np.minimum(frac * np.float32(4294967296.0), np.float32(4294967040.0)).astype(np.uint32)
+
+
+def f16_dither_images(w, T, seed=0):
+    """w [...] float32 -> float16 [T, ...]: image t of element i (flat row-major index) = up if uint32(fmix32(i ^ seed * PHI32) + t * PHI32) < thr else dn."""
+    w32 = np.ascontiguousarray(np.asarray(w, np.float32))
+    dn, up = f16_neighbours(w32)
+    thr = f16_dither_threshold(w32).reshape(-1)
+    idx = np.arange(w32.size, dtype=np.uint32)
+    with np.errstate(over="ignore"):
+        phase = _fmix32(idx ^ np.uint32((int(seed) * DITHER_PHI32) & 0xFFFFFFFF))
+        out = np.empty((T,) + w32.shape, np.float16)
+        for t in range(T):
+            u = phase + np.uint32((t * DITHER_PHI32) & 0xFFFFFFFF)
+            out[t] = np.where((u < thr).reshape(w32.shape), up, dn)
+    return out

@@ -78,10 +78,32 @@ def fp6_fixed(a, scale):
 def rnd(a, kind):
     if kind == "x3":
         return a
+    if kind in ("f16d", "f16s"):        # weights only: per-step dithered images (stack_fwd); this is the plain image for callers outside it
+        kind = "f16"
     if kind in ("f16+8", "f16+6"):      # weights only: the f16 image; the fp8 / fp6 low-order half is contracted separately (stack_fwd)
         kind = "f16"
     dt = {"bf16": torch.bfloat16, "f16": torch.float16}[kind]
     return a.to(torch.float32).to(dt).to(torch.float64)
+
+
+def dither_setup(k, seed, T):
+    """Time-dithered f16 images of one LSTM kernel (oracle/lowprec.py::f16_dither_images = evc_cast_f32_to_f16_dither, bit for bit): the device
+    dithers the master in its stored layout [4H][in + H], so the flat element index - the phase - is taken there.  k: TF layout [in + H][4H]."""
+    from oracle import lowprec as lp
+    kt = np.ascontiguousarray(k.to(torch.float32).numpy().T)
+    im = lp.f16_dither_images(kt, T, seed)                       # [T][4H][C]
+    return torch.from_numpy(np.ascontiguousarray(im.transpose(0, 2, 1)).astype(np.float64))       # [T][C][4H]
+
+
+def stochastic_images(k, T):
+    """independent stochastic rounding per step (comparison only)"""
+    from oracle import lowprec as lp
+    w = k.to(torch.float32).numpy()
+    dn, up = lp.f16_neighbours(w)
+    gap = up.astype(np.float64) - dn.astype(np.float64)
+    frac = np.where(gap > 0, (w - dn.astype(np.float64)) / np.where(gap > 0, gap, 1.0), 0.0)
+    out = np.stack([np.where(np.random.default_rng(1000 + t).random(w.shape) < frac, up, dn).astype(np.float64) for t in range(T)], 0)
+    return torch.from_numpy(out)
 
 
 def _parts(kind):
@@ -97,10 +119,16 @@ def stack_fwd(x, lengths, layers, kinds):
     H = layers[0][1].shape[0] // 4
     c = [x.new_zeros((M, H)) for _ in layers]
     h = [x.new_zeros((M, H)) for _ in layers]
-    wq, wlo8 = [], []
+    wq, wlo8, wdith = [], [], []
     for l, (k, _) in enumerate(layers):
         ax, ah, wx, wh = _parts(kinds[l])
         nin = k.shape[0] - H
+        dith = None
+        if "f16d" in (wx, wh):
+            dith = dither_setup(k, 1 + 2 * l, T)          # (HLstmTower.dither_seed of the L1 kernels)
+        elif "f16s" in (wx, wh):
+            dith = stochastic_images(k, T)
+        wdith.append((dith, wx in ("f16d", "f16s"), wh in ("f16d", "f16s")))
         wq.append(torch.cat([rnd(k[:nin], wx), rnd(k[nin:], wh)], 0))
         lo = torch.zeros_like(k)       # fp8 low-order halves (kind "f16+8"): W - f16(W) as e4m3 under one power-of-two scale per matrix
         if wx == "f16+8":
@@ -122,7 +150,12 @@ def stack_fwd(x, lengths, layers, kinds):
         for l, (_, bias) in enumerate(layers):
             ax, ah, _, _ = _parts(kinds[l])
             a = torch.cat([rnd(inp, ax), rnd(h[l], ah)], 1)
-            z = a @ wq[l] + bias
+            wl = wq[l]
+            dith, dxp, dhp = wdith[l]
+            if dith is not None:
+                nin_l = layers[l][0].shape[0] - H
+                wl = torch.cat([dith[t][:nin_l] if dxp else wl[:nin_l], dith[t][nin_l:] if dhp else wl[nin_l:]], 0)
+            z = a @ wl + bias
             _, _, wxk, whk = _parts(kinds[l])
             if wlo8[l] is not None and "f16+6" in (wxk, whk):      # e2m3 images of the activations: the input frames under one scale per
                 # frame (layer 0; layer 1's input is the h of the layer below), h under a fixed scale
@@ -181,6 +214,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--seed", type=int, default=91)
+    ap.add_argument("--init_seed", type=int, default=3)
     ap.add_argument("--lr", type=float, default=2e-3)
     ap.add_argument("--max_steps", type=int, default=16)
     ap.add_argument("--save", default="")
@@ -203,7 +237,7 @@ def main():
     elif a.load:
         teacher, student = torch.load(a.load)
     else:
-        rng = np.random.default_rng(3)
+        rng = np.random.default_rng(a.init_seed)
         teacher = tc.to_torch(mm.init_hlstm_params(rng, dtype=np.float32))
         student = tc.to_torch(mm.init_hlstm_params(rng, dtype=np.float32))
         ot, os_ = tc.Adam(teacher, lr=a.lr), tc.Adam(student, lr=a.lr)
@@ -328,6 +362,20 @@ def main():
             ("X16+8 only the L1c0 input f16 + fp8 x fp8 low-order term", dict(exact, L1c0=dict(ex, ax="f16+8"))),
             ("FZ8X FZ8 with the input's low-order half in fp8 too", dict(exact, L1c0=dict(ax="f16+8", ah="f16", wx="f16+8", wh="f16+8"),
                                                                          L1c1=dict(ax="f16", ah="f16", wx="f16+8", wh="f16+8"), **l2_f16x)),
+            ("DITH W16d only L1 weights f16, dithered in time", dict(exact, L1c0=dict(ex, wx="f16d", wh="f16d"), L1c1=dict(ex, wx="f16d", wh="f16d"))),
+            ("DITH W16s only L1 weights f16, stochastic per step", dict(exact, L1c0=dict(ex, wx="f16s", wh="f16s"), L1c1=dict(ex, wx="f16s", wh="f16s"))),
+            ("DITH W16  only L1 weights f16 RTN", dict(exact, L1c0=dict(ex, wx="f16", wh="f16"), L1c1=dict(ex, wx="f16", wh="f16"))),
+            ("DITH W2d only the L2 weights f16 dithered", dict(exact, L2c0=dict(ex, wx="f16d", wh="f16d"), L2c1=dict(ex, wx="f16d", wh="f16d"))),
+            ("DITH W2  only the L2 weights f16 RTN", dict(exact, L2c0=dict(ex, wx="f16", wh="f16"), L2c1=dict(ex, wx="f16", wh="f16"))),
+            ("DITH FZD8X L1 W dithered, x_lo fp8 | shipped L2", dict(exact, L1c0=dict(ax="f16+8", ah="f16", wx="f16d", wh="f16d"),
+                                                                       L1c1=dict(ax="f16", ah="f16", wx="f16d", wh="f16d"), **l2_f16x)),
+            ("DITH FZDD L1 + L2 W dithered, x_lo fp8", dict(exact, L1c0=dict(ax="f16+8", ah="f16", wx="f16d", wh="f16d"),
+                                                                       L1c1=dict(ax="f16", ah="f16", wx="f16d", wh="f16d"),
+                                                                       L2c0=dict(ax="x3", ah="f16", wx="f16d", wh="f16d"), L2c1=dict(ax="f16", ah="f16", wx="f16d", wh="f16d"))),
+            ("DITH FZS8X L1 W stochastic, x_lo fp8 | shipped L2", dict(exact, L1c0=dict(ax="f16+8", ah="f16", wx="f16s", wh="f16s"),
+                                                                       L1c1=dict(ax="f16", ah="f16", wx="f16s", wh="f16s"), **l2_f16x)),
+            ("DITH A8 L1 W RTN uncorrected, x_lo fp8 | shipped L2", dict(exact, L1c0=dict(ax="f16+8", ah="f16", wx="f16", wh="f16"),
+                                                                       L1c1="f16", **l2_f16x)),
             ("DBG6 c0 wx", dict(exact, L1c0=dict(ex, wx="f16+6"))), ("DBG6 c0 wh", dict(exact, L1c0=dict(ex, wh="f16+6"))), ("DBG6 c1 wx", dict(exact, L1c1=dict(ex, wx="f16+6"))), ("DBG6 c1 wh", dict(exact, L1c1=dict(ex, wh="f16+6"))),
             ("DBG8 c0 wx", dict(exact, L1c0=dict(ex, wx="f16+8"))), ("DBG8 c1 wh", dict(exact, L1c1=dict(ex, wh="f16+8"))),
             ("W16+6 only the L1 weights f16 + e2m3 low-order halves (per-row scales)", dict(exact, L1c0=dict(ex, wx="f16+6", wh="f16+6"), L1c1=dict(ex, wx="f16+6", wh="f16+6"))),
@@ -362,7 +410,7 @@ def main():
             ("L2 parts PLAN+L2 all f16", dict(plan, L2c0="f16", L2c1="f16")),
         ]
         if a.only:
-            configs = [c for c in configs if a.only in c[0]]
+            configs = [c for c in configs if any(o in c[0] for o in a.only.split("|"))]
         if a.gpu:
             from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
             dev = "cuda:0"

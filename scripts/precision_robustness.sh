@@ -10,7 +10,7 @@ OUT=${2:-gpurun_out/precision_robustness.txt}
 mkdir -p "$(dirname "$OUT")"
 : > "$OUT.raw"
 for i in $(seq 1 $N); do
-  python3 scripts/precision_budget.py --gpu --only "${ONLY:-ROBUST}" 2>&1 | grep "ROBUST\|KERNELS high" | cut -c1-150 >> "$OUT.raw"
+  python3 scripts/precision_budget.py --gpu --only "${ONLY:-ROBUST}" 2>&1 | grep "ROBUST\|KERNELS high" | cut -c1-170 >> "$OUT.raw"
   echo "---" >> "$OUT.raw"
 done
 python3 - "$OUT.raw" > "$OUT" <<'PY'

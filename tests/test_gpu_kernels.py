@@ -622,6 +622,148 @@ assert err < 8e-4 and err <= err16 * 1.05, (err, err16)
 """
 
 
+def test_f16_dither_images_equal_the_oracle_bit_for_bit(ops):
+    """evc_cast_f32_to_f16_dither against oracle/lowprec.py::f16_dither_images: every bit of every image - values over eleven decades (f16
+    subnormals and values that underflow f16 among them), exact f16 values, zeros of both signs, a strided image stack, T = 1."""
+    from oracle import lowprec as lp
+    rng = np.random.default_rng(23)
+    w = (rng.standard_normal((260, 384)) * np.logspace(-9, 1, 384)[None, :]).astype(np.float32)
+    w[3, :10] = [0.0, -0.0, 1.0, -1.0, 2.0 ** -24, -2.0 ** -24, 3e-8, -3e-8, 6.1e-5, 65000.0]
+    wd = torch.from_numpy(w).to(DEV)
+    for T, seed in ((15, 1), (1, 9), (6, 4)):
+        out = torch.full((T,) + w.shape, float("nan"), dtype=torch.float16, device=DEV)
+        ops.cast_f16_dither(wd, out, seed)
+        ref = lp.f16_dither_images(w, T, seed)
+        got = out.cpu().numpy()
+        assert np.array_equal(got.view(np.uint16), ref.view(np.uint16)), (T, seed, int((got.view(np.uint16) != ref.view(np.uint16)).sum()))
+    pad = torch.full((4, w.size + 64), float("nan"), dtype=torch.float16, device=DEV)      # images 8 rows apart: the pad stays untouched
+    ops._lib.call("evc_cast_f32_to_f16_dither", wd.data_ptr(), w.size, 4, pad.stride(0), 3, pad.data_ptr(), ops._stream())
+    got = pad.cpu().numpy()
+    assert np.array_equal(got[:, :w.size].reshape((4,) + w.shape).view(np.uint16), lp.f16_dither_images(w, 4, 3).view(np.uint16))
+    assert np.isnan(got[:, w.size:].astype(np.float32)).all()
+
+
+@pytest.mark.parametrize("M,T,Kin,H,tile", [(512, 4, 384, 384, 0), (1100, 15, 1152, 512, 0), (700, 5, 384, 384, 6), (390, 3, 512, 384, 7), (730, 6, 384, 384, 11)])
+def test_lstm_layer_fwd_f16_on_time_dithered_weight_images(M, T, Kin, H, tile):
+    """evc_lstm_layer_fwd_f16_dith, two stacked layers: layer 0 on input rows [f16(x) | e4m3(x 2^7) | e4m3(x_lo 2^18)] - f16 stages on image t of
+    evc_cast_f32_to_f16_dither + the e4m3 stages of the input's low-order half against the e4m3(Wx 2^6) block of evc_cast_f32_to_fp8_lo's rows -
+    layer 1 on layer 0's PLAIN f16 h rows and its own images (kx8 = 0).  Against (a) a float64 step-by-step restatement with the SAME per-step
+    images (oracle/lowprec.py::f16_dither_images), f16-rounded h operands and the e4m3 correction: what is left is the f32 accumulation and
+    f16 ties of h (1.5e-4; the same restatement on images one step late must be farther); (b) the float64 oracle on the exact weights: within the f16 bound (8e-4).  Ring tiles forced in a child process,
+    rows that end early, a row plan, one image for every step (stride 0) = the plain f16 layer bit for bit."""
+    code = _DITH_CHILD % dict(M=M, T=T, Kin=Kin, H=H)
+    env = dict(os.environ)
+    if tile:
+        env["EVC_FORCE_TILE"] = str(tile)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    print(r.stdout.strip().splitlines()[-1])
+
+
+_DITH_CHILD = r"""
+import numpy as np, torch
+from oracle import model_math as mm
+from oracle import lowprec as lp
+from efficientvideoclassification_youtube8m_amd import ops
+DEV = "cuda:0"
+M, T, Kin, H = %(M)d, %(T)d, %(Kin)d, %(H)d
+rng = np.random.default_rng(M + T + Kin + H + 5)
+x = (rng.standard_normal((M, T, Kin)) * 0.05).astype(np.float32)
+x /= np.maximum(1.0, np.abs(x).max())
+k0 = (mm.glorot_uniform(rng, (Kin + H, 4 * H)) * 3.0).astype(np.float32)
+k1 = (mm.glorot_uniform(rng, (2 * H, 4 * H)) * 3.0).astype(np.float32)
+b0 = (rng.standard_normal(4 * H) * 0.1).astype(np.float32)
+b1 = (rng.standard_normal(4 * H) * 0.1).astype(np.float32)
+lens = rng.integers(0, T + 1, size=M).astype(np.int32)
+lens[:3] = [0, T, 1]
+s_ref, _ = mm.multi_rnn_seq_fwd(x.astype(np.float64), lens, [(k0.astype(np.float64), b0.astype(np.float64)), (k1.astype(np.float64), b1.astype(np.float64))])
+sig = lambda v: 1.0 / (1.0 + np.exp(-v))
+f16r = lp.f16_round
+def emulate(images):
+    # float64 restatement of what the two launches contract: per step image t of each kernel ([4H][C] layout -> TF layout), f16 operands, layer 0's e4m3 term
+    inp = x.astype(np.float64)
+    state = []
+    for l, (k, b) in enumerate(((k0, b0), (k1, b1))):
+        nin = k.shape[0] - H
+        c, h = np.zeros((M, H)), np.zeros((M, H))
+        outs = np.zeros((M, T, H))
+        w8 = lp.e4m3_round(k[:nin].astype(np.float64) * 2.0 ** ops.FP8_WX_HI_EXP) if l == 0 else None
+        for t in range(T):
+            wt = images[l][t].astype(np.float64).T                       # [C][4H]
+            xt = inp[:, t]
+            z = f16r(xt) @ wt[:nin] + f16r(h) @ wt[nin:] + b
+            if l == 0:
+                z = z + (lp.e4m3_round((xt - f16r(xt)) * 2.0 ** 18) @ w8) * 2.0 ** -(18 + ops.FP8_WX_HI_EXP)
+            i, j, f, o = np.split(z, 4, axis=1)
+            cn = c * sig(f + 1.0) + sig(i) * np.tanh(j)
+            hn = np.tanh(cn) * sig(o)
+            act = (lens > t)[:, None]
+            c, h = np.where(act, cn, c), np.where(act, hn, h)
+            outs[:, t] = np.where(act, hn, 0.0)
+        inp = outs
+        state += [c, h]
+    return np.concatenate(state, 1)
+xt = torch.from_numpy(np.ascontiguousarray(x.transpose(1, 0, 2))).to(DEV)
+rows = torch.zeros((T, M, 2 * Kin), dtype=torch.float16, device=DEV)
+hi = xt.half()
+rows[:, :, :Kin] = hi
+rows[:, :, Kin:3 * Kin // 2] = (xt * 128.0).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.float16)
+rows[:, :, 3 * Kin // 2:] = ((xt - hi.float()) * 2.0 ** 18).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.float16)
+ln = torch.from_numpy(lens).to(DEV)
+kTs = [torch.from_numpy(np.ascontiguousarray(k.T)).to(DEV) for k in (k0, k1)]
+def run(plan, n_img):
+    S = torch.full((M, 4 * H), float("nan"), dtype=torch.float32, device=DEV)
+    inp, ldx, kx16, x8_off, kx8 = rows, 2 * Kin, Kin, 3 * Kin, Kin
+    lens_run, Mrun = ln, M
+    if plan is not None:
+        live = plan.rows[0]
+        inp = torch.zeros((T, plan.P, 2 * Kin), dtype=torch.float16, device=DEV)
+        inp[:, :live] = rows[:, plan.inv[:live].long()]
+        lens_run, Mrun = plan.lens, plan.P
+        S.zero_()
+    imgs = []
+    for l, (k, b) in enumerate(((k0, b0), (k1, b1))):
+        kT = kTs[l]
+        nin = k.shape[0] - H
+        w16 = torch.empty((n_img, 4 * H, nin + H), dtype=torch.float16, device=DEV)
+        if n_img == 1:
+            ops.cast_f16(kT, w16[0])
+        else:
+            ops.cast_f16_dither(kT, w16, 3 + l)
+        imgs.append(w16)
+        w8 = None
+        if l == 0:
+            w8full = torch.empty((4 * H, nin + H + nin), dtype=torch.uint8, device=DEV)
+            ops.cast_fp8_lo(kT, w8full, hi_cols=nin)
+            w8 = w8full[:, nin:2 * nin]
+        h16 = torch.full((T + 1, Mrun, H), float("nan"), dtype=torch.float16, device=DEV)
+        hbf = torch.full((T + 1, Mrun, H), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ops.lstm_layer_fwd_f16_dith(inp, ldx, kx16, x8_off, kx8, w16, w8, w8full.stride(0) if l == 0 else 0, 18 + ops.FP8_WX_HI_EXP,
+                                    torch.from_numpy(b).to(DEV), lens_run, T, Mrun, H, h16, hbf, S[:, 2 * l * H:], S[:, (2 * l + 1) * H:], 4 * H, plan=plan)
+        if plan is None:
+            assert float((h16.float() - hbf.float()).abs().max()) <= 2.0 ** -8
+        inp, ldx, kx16, x8_off, kx8 = h16[1:], H, H, 0, 0
+    return S.cpu().double().numpy(), imgs
+got, imgs = run(None, T)
+assert np.isfinite(got).all() and np.all(got[0] == 0)
+want = emulate([im.cpu().numpy() for im in imgs])
+d_emu = float(np.max(np.abs(got - want)))
+err = float(np.max(np.abs(got - s_ref)))
+gp, _ = run(ops.RowPlan(ln, lens, T), T)
+assert float(np.max(np.abs(gp - got))) < 1e-6
+# one image for every step: the round-to-nearest f16 image = layer 0 with its e4m3 input term, layer 1 the plain f16 layer
+g1, im1 = run(None, 1)
+w1 = emulate([np.repeat(im.cpu().numpy(), T, 0) for im in im1])
+d1 = float(np.max(np.abs(g1 - w1)))
+# the restatement on the WRONG images (every layer's images one step late) must be the farther one: step t really contracts image t
+d_late = float(np.max(np.abs(got - emulate([np.roll(im.cpu().numpy(), 1, 0) for im in imgs]))))
+print("dithered two-layer stack M=%%d T=%%d Kin=%%d H=%%d: vs the restatement on the same images %%.2e (images one step late: %%.2e; one image: %%.2e), vs the exact-weight oracle %%.2e" %% (M, T, Kin, H, d_emu, d_late, d1, err))
+assert d_emu < 1.5e-4 and d1 < 1.5e-4 and d_emu < d_late, (d_emu, d1, d_late)
+assert err < 8e-4, err
+"""
+
+
 @pytest.mark.parametrize("M,T,Kin,H", [(256, 6, 64, 64), (1536, 4, 192, 256), (640, 15, 128, 128)])
 def test_lstm_layer_fwd_f16_recurrent_weights_extended(ops, M, T, Kin, H):
     """evc_lstm_layer_fwd_f16 with h_wide = 1: the recurrent weights K-extended by their low-order halves - h rows [f16(h) |

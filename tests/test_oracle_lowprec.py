@@ -116,3 +116,37 @@ def test_row_scales_and_the_e2m3_corrected_product():
     e_plain = np.max(np.abs(lp.f16_round(x) @ lp.f16_round(w).T - ref))
     e_both = np.max(np.abs(lp.corrected_product6(x, w) - ref))
     assert e_both < 2e-4 and e_both * 8 < e_plain, (e_plain, e_both)
+
+
+def test_time_dithered_f16_images_round_to_the_two_neighbours_with_bounded_discrepancy():
+    """oracle/lowprec.py::f16_dither_images (the restatement of evc_cast_f32_to_f16_dither): every image element is one of the value's two f16
+    neighbours; f16 values (zero, ones, subnormal steps) are reproduced in every image; over ANY run of consecutive images the number of
+    round-ups is within 3 of (run length) x frac (2.03 measured at 20 steps) - the property that makes a recurrence's weight-rounding errors cancel over its steps - so
+    the mean of T images is far closer to w than the round-to-nearest image; images are a pure function of (w, seed) and differ between seeds."""
+    rng = np.random.default_rng(5)
+    w = (rng.standard_normal((96, 160)) * np.logspace(-7, 1, 160)[None, :]).astype(np.float32)
+    w[0, :8] = [0.0, 1.0, -1.0, 2.0 ** -24, -2.0 ** -24, 3e-8, -3e-8, 65000.0]
+    T = 20
+    im = lp.f16_dither_images(w, T, seed=7)
+    assert im.dtype == np.float16 and im.shape == (T,) + w.shape
+    dn, up = lp.f16_neighbours(w)
+    assert np.all(dn.astype(np.float64) <= w) and np.all(w <= up.astype(np.float64))
+    adjacent = (up == dn) | (np.nextafter(dn, np.float16(np.inf)) == up)
+    assert adjacent.all()
+    assert np.all((im == dn[None]) | (im == up[None]))
+    exact = w.astype(np.float16).astype(np.float32) == w
+    assert exact[0, :5].all() and np.all(im[:, exact] == w[exact].astype(np.float16)[None])
+    gap = up.astype(np.float64) - dn.astype(np.float64)
+    frac = np.where(gap > 0, (w.astype(np.float64) - dn.astype(np.float64)) / np.where(gap > 0, gap, 1.0), 0.0)
+    ups = (im == up[None]) & (gap > 0)[None]
+    worst = 0.0
+    for a in range(T):
+        c = np.cumsum(ups[a:], axis=0)
+        n = np.arange(1, T - a + 1).reshape((-1,) + (1,) * w.ndim)
+        worst = max(worst, float(np.abs(c - n * frac[None]).max()))
+    assert worst < 3.0, worst
+    err_mean = np.abs(im.astype(np.float64).mean(0) - w)[~exact]
+    err_rtn = np.abs(lp.f16_round(w) - w)[~exact]
+    assert err_mean.mean() < 0.2 * err_rtn.mean()
+    assert np.array_equal(im, lp.f16_dither_images(w, T, seed=7)) and not np.array_equal(im, lp.f16_dither_images(w, T, seed=8))
+    assert np.array_equal(im[:5], lp.f16_dither_images(w, 5, seed=7))               # image t does not depend on T
