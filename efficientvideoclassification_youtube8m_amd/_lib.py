@@ -22,6 +22,7 @@ SIGNATURES = {
     "evc_gemm_nt": [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i32, i32, vp],
     "evc_gemm_tn": [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp],
     "evc_gemm_tn2": [vp, i64, vp, i64, i32, vp, i64, i32, i32, vp, i64, i32, i32, i32, i32, vp],
+    "evc_gemm_tn2_rows": [vp, i64, vp, i64, i32, vp, i64, i32, i32, vp, i64, i32, i32, i32, vp, i32, i32, vp],
     "evc_gemm_tn2_slabs": [vp, i64, vp, i64, i32, vp, i64, i32, i32, vp, i64, i64, i32, i32, i32, i32, vp],
     "evc_sum_slabs": [vp, i64, i32, i32, i32, i64, vp, i64, i32, vp],
     "evc_colsum_bf16": [vp, i64, i32, i32, i32, vp, vp],

@@ -11,7 +11,7 @@ struct StoreParamsT {
   long slab_stride;               // > 0: split s stores its partial tile plainly at C + s*slab_stride (no atomics; the caller sums the slabs)
 };
 
-template <class Cfg>
+template <class Cfg, bool SEG = false>
 __global__ __launch_bounds__(Cfg::NT) void gemm_tn_kernel(GemmOperandsT p, StoreParamsT s, int tiles_m, int tiles_n) {
   const int nwg = tiles_m * tiles_n;
   int bid = blockIdx.x, split = 0;
@@ -34,14 +34,24 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_tn_kernel(GemmOperandsT p, Store
       p.N = s.N = p.N1;
     }
   }
-  if (s.splits > 1) {
+  if (SEG) {                                                   // K steps are counted over the LIVE steps of the segments (evc_gemm_tn2_rows)
+    int off = split * s.ksteps_per_split, sg = 0;
+    p.nk = min(s.ksteps_per_split, p.nk - off);
+#pragma unroll
+    for (int i = 0; i < 15; ++i) {                             // (constant indices: the table stays in scalar registers)
+      const bool adv = sg == i && i + 1 < p.nseg && off >= (int)p.seg_len[i];
+      off -= adv ? (int)p.seg_len[i] : 0;
+      sg += adv ? 1 : 0;
+    }
+    p.seg0 = sg; p.seg_off0 = off;
+  } else if (s.splits > 1) {
     const int k0 = split * s.ksteps_per_split;
     p.A += (long)k0 * 32 * p.lda;
     p.B += (long)k0 * 32 * p.ldb;
     p.nk = min(s.ksteps_per_split, p.nk - k0);
   }
   f32x4 acc[Cfg::MI][1][Cfg::NI];
-  gemm_mainloop_tn<Cfg, true, EVC_TN_LOOP_MODE>(p, m0, nb, lds_dyn, acc);      // transposed accumulators: lane = one row, 4 consecutive columns
+  gemm_mainloop_tn<Cfg, true, EVC_TN_LOOP_MODE, SEG>(p, m0, nb, lds_dyn, acc);      // transposed accumulators: lane = one row, 4 consecutive columns
   // Through the per-wave LDS transpose (store_tile_via_lds): whole sub-tile rows for the plain / slab stores, contiguous
   // row runs for the split-K atomics ("accumulate" is the same join onto what C already holds).
   float* C = s.C + split * s.slab_stride;
@@ -78,7 +88,8 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_tn_kernel(GemmOperandsT p, Store
 }
 
 static int gemm_tn_impl(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, int N1, const evc_bf16* B2, int64_t ldb2,
-                        int c_col2, float* C, int64_t ldc, int M, int N, int K, int row_interleave_H, int accumulate, void* stream) {
+                        int c_col2, float* C, int64_t ldc, int M, int N, int K, int row_interleave_H, int accumulate, void* stream,
+                        int slab_rows = 0, const int32_t* rows_per_slab = nullptr) {
   EVC_REQUIRE(M >= 8 && N >= 8 && K > 0 && M % 8 == 0 && N % 8 == 0 && K % 32 == 0, EVC_ERR_BAD_SHAPE,
               "evc_gemm_tn: needs M %% 8 == 0, N %% 8 == 0, K %% 32 == 0 (M=%d N=%d K=%d)", M, N, K);
   EVC_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, EVC_ERR_BAD_ALIGN,
@@ -89,6 +100,23 @@ static int gemm_tn_impl(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64
   hipStream_t st = (hipStream_t)stream;
   GemmOperandsT p{A, lda, B, ldb, M, N, K / 32};
   if (B2) { p.B2 = B2; p.ldb2 = ldb2; p.N1 = N1; p.c_col2 = c_col2; }
+  // live rows per time slab (evc_gemm_tn2_rows): the K walk covers ceil(rows / 32) steps of every slab.  More than 16 non-empty slabs, nothing
+  // dead or nothing live: the plain walk over all K rows (the dead rows of A are zeros: the same sums).
+  bool seg = false;
+  if (rows_per_slab && slab_rows > 0 && slab_rows % 32 == 0 && K % slab_rows == 0 && !evc_deterministic()) {
+    const int nslabs = K / slab_rows, slab_steps = slab_rows / 32;
+    int n = 0, total = 0;
+    bool ok = (long)nslabs * slab_steps < 65536;
+    for (int t = 0; t < nslabs && ok; ++t) {
+      int r = rows_per_slab[t] < 0 ? 0 : (rows_per_slab[t] > slab_rows ? slab_rows : rows_per_slab[t]);
+      const int steps = (r + 31) / 32;
+      if (steps == 0) continue;
+      if (n == 16) { ok = false; break; }
+      p.seg_start[n] = (unsigned short)(t * slab_steps); p.seg_len[n] = (unsigned short)steps;
+      ++n; total += steps;
+    }
+    if (ok && total > 0 && total < K / 32) { seg = true; p.nseg = n; p.nk = total; K = total * 32; }
+  }
   typedef TileCfg2<128, 1, 128, 2, 4, 5, true> CfgTn128;
   // short contractions (the student's L2: K = 5 x 256 rows) on 128x128 tiles without split-K: the atomic join of
   // 256x256 partial tiles costs more than the product itself there (81 -> 36 us at 4096 x 1024 x 1280); from
@@ -96,7 +124,8 @@ static int gemm_tn_impl(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64
   if (forced_tile() == 11 || (forced_tile() == 0 && K <= 2048 && (long)ceil_div(M, 128) * ceil_div(N, 128) >= 192)) {
     const int tm1 = ceil_div(M, 128), tn1 = ceil_div(N, 128);
     StoreParamsT s1{C, ldc, M, N, row_interleave_H, accumulate, 1, p.nk, 0};
-    launch_cfg<CfgTn128>(gemm_tn_kernel<CfgTn128>, tm1 * tn1, st, p, s1, tm1, tn1);
+    if (seg) launch_cfg<CfgTn128>(gemm_tn_kernel<CfgTn128, true>, tm1 * tn1, st, p, s1, tm1, tn1);
+    else launch_cfg<CfgTn128>(gemm_tn_kernel<CfgTn128>, tm1 * tn1, st, p, s1, tm1, tn1);
     EVC_LAUNCH_CHECK();
     return EVC_OK;
   }
@@ -110,7 +139,8 @@ static int gemm_tn_impl(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64
     while (splits > 1 && (long)ceil_div(p.nk, splits) * (splits - 1) >= p.nk) --splits;     // no empty split
     StoreParamsT s1{C, ldc, M, N, row_interleave_H, accumulate, splits, ceil_div(p.nk, splits), 0};
     if (splits > 1 && !accumulate) EVC_CHECK_HIP(hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st));
-    launch_cfg<CfgTn128>(gemm_tn_kernel<CfgTn128>, tm1 * splits, st, p, s1, tm1, 1);
+    if (seg) launch_cfg<CfgTn128>(gemm_tn_kernel<CfgTn128, true>, tm1 * splits, st, p, s1, tm1, 1);
+    else launch_cfg<CfgTn128>(gemm_tn_kernel<CfgTn128>, tm1 * splits, st, p, s1, tm1, 1);
     EVC_LAUNCH_CHECK();
     return EVC_OK;
   }
@@ -120,9 +150,27 @@ static int gemm_tn_impl(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64
   if (splits < 1 || evc_deterministic()) splits = 1;
   StoreParamsT s{C, ldc, M, N, row_interleave_H, accumulate, splits, ceil_div(p.nk, splits), 0};
   if (splits > 1 && !accumulate) EVC_CHECK_HIP(hipMemset2DAsync(C, ldc * sizeof(float), 0, (size_t)N * sizeof(float), M, st));
-  launch_cfg<CfgPlainV2>(gemm_tn_kernel<CfgPlainV2>, tm * tn * splits, st, p, s, tm, tn);
+  if (seg) launch_cfg<CfgPlainV2>(gemm_tn_kernel<CfgPlainV2, true>, tm * tn * splits, st, p, s, tm, tn);
+  else launch_cfg<CfgPlainV2>(gemm_tn_kernel<CfgPlainV2>, tm * tn * splits, st, p, s, tm, tn);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
+}
+
+// evc_gemm_tn / evc_gemm_tn2 over TIME SLABS with a live prefix (round 5): the contraction index runs over K = nslabs * slab_rows rows, slab t
+// holding rows_per_slab[t] live rows at its start (row plans: rows sorted by length, the weight-gradient products dW^T = dz^T . [x | h] of a
+// row-planned LSTM level) - the K walk covers ceil(rows / 32) steps of every slab and jumps over the rest (the teacher's L1 level: 5 % of
+// the rows).  The skipped rows of A must be zeros or the skipped rows of A and B finite garbage that the caller does not want summed; rows
+// between rows_per_slab[t] and the next multiple of 32 ARE contracted.  B2 == NULL: one column segment of N1 columns.  rows_per_slab is HOST
+// memory (read before the launch).  More than 16 non-empty slabs or EVC_DETERMINISTIC: the plain product over all K rows.
+extern "C" int evc_gemm_tn2_rows(const evc_bf16* A, int64_t lda, const evc_bf16* B1, int64_t ldb1, int N1, const evc_bf16* B2, int64_t ldb2,
+                                 int N2, int c_col2, float* C, int64_t ldc, int M, int slab_rows, int nslabs, const int32_t* rows_per_slab,
+                                 int row_interleave_H, int accumulate, void* stream) {
+  EVC_REQUIRE(B1 && N1 > 0 && slab_rows > 0 && nslabs > 0 && rows_per_slab && (long)slab_rows * nslabs < (1L << 31), EVC_ERR_BAD_ARG,
+              "evc_gemm_tn2_rows: B1, N1, slab_rows, nslabs, rows_per_slab are required");
+  EVC_REQUIRE(!B2 || N2 > 0, EVC_ERR_BAD_ARG, "evc_gemm_tn2_rows: N2=%d", N2);
+  EVC_REQUIRE(!B2 || accumulate || c_col2 == N1, EVC_ERR_BAD_ARG, "evc_gemm_tn2_rows: segments that are not adjacent in C (c_col2=%d, N1=%d) need accumulate", c_col2, N1);
+  return gemm_tn_impl(A, lda, B1, ldb1, B2 ? N1 : 0, B2, ldb2, B2 ? c_col2 : 0, C, ldc, M, N1 + (B2 ? N2 : 0), slab_rows * nslabs, row_interleave_H, accumulate,
+                      stream, slab_rows, rows_per_slab);
 }
 
 extern "C" int evc_gemm_tn(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, float* C, int64_t ldc,

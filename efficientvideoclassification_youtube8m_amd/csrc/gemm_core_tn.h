@@ -38,6 +38,11 @@ struct GemmOperandsT {
   // N1 is a multiple of the tile width, so a workgroup's columns lie in one segment (gemm_tn_kernel picks it)
   const bf16_t* B2 = nullptr; long ldb2 = 0; int N1 = 0;
   int c_col2 = 0;              // C column where the second segment's columns start (>= N1: the segments need not be adjacent in C)
+  // K as up to 16 SEGMENTS of live K steps (evc_gemm_tn2_rows, SEG loops only): the contraction index runs over time slabs of slab_rows rows of
+  // which only a prefix is live (row plans: rows sorted by length) - segment i covers K steps [seg_start[i], seg_start[i] + seg_len[i]) of
+  // the operands; nk then counts LIVE steps, and a workgroup's first step is step seg_off0 of segment seg0.
+  int nseg = 0, seg0 = 0, seg_off0 = 0;
+  unsigned short seg_start[16] = {0}, seg_len[16] = {0};
 };
 
 __device__ __forceinline__ int tn_h(int row) { return (((row >> 3) & 1) << 2) | (row & 3); }
@@ -45,8 +50,8 @@ __device__ __forceinline__ int tn_h(int row) { return (((row >> 3) & 1) << 2) | 
 // SWAP = true issues the MFMA with the B fragment first: the accumulator tile is transposed - lane l holds
 // row (A column) m = l&15 and 4 consecutive columns n = (l>>4)*4 + reg (TileCoordsT) - so an epilogue that
 // walks n fastest gets 16-byte vector accesses to row-major [M][N] arrays.
-template <class Cfg, bool SWAP = false, int MODE = 0>
-__device__ __forceinline__ void gemm_mainloop_tn(GemmOperandsT p, const int m0, const int n0, char* lds,
+template <class Cfg, bool SWAP = false, int MODE = 0, bool SEG = false>
+__device__ __forceinline__ void gemm_mainloop_tn(const GemmOperandsT& p, const int m0, const int n0, char* lds,
                                                  f32x4 (&acc)[Cfg::MI][1][Cfg::NI]) {
   static_assert(Cfg::G == 1 && Cfg::PIPE && !Cfg::RAGGED, "TN loop: plain tiles, pipelined, even staging");
   const int tid = threadIdx.x;
@@ -91,6 +96,45 @@ __device__ __forceinline__ void gemm_mainloop_tn(GemmOperandsT p, const int m0, 
   const uint32_t a_step = (uint32_t)(64 * p.lda), b_step = (uint32_t)(64 * p.ldb);   // bytes per K step of 32 rows
   uint32_t a_k = 0, b_k = 0;
   int slot_issue = 0, slot_read = 0;
+  // SEG: the K walk jumps over the dead rows at the end of every time slab.  The segment table (<= 16 entries, len << 16 | start) stays in
+  // SCALAR registers and is indexed by a chain of scalar selects - only when a segment ends (a uniform, rarely taken branch; a handful of
+  // SALU instructions per step otherwise).  (A table in one vector register read with v_readlane was tried first: it was spilled, and its
+  // reload inside the loop brought the `s_waitcnt vmcnt(0)` of DESIGN.md 4.2b back.)
+  uint32_t seg_e[16];
+  int seg = 0, seg_left = 0;
+  auto seg_entry = [&](int sidx) {
+    uint32_t e = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) e = sidx == i ? seg_e[i] : e;
+    return e;
+  };
+  if constexpr (SEG) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) seg_e[i] = ((uint32_t)p.seg_len[i] << 16) | (uint32_t)p.seg_start[i];
+    seg = p.seg0;
+    const uint32_t e = seg_entry(seg);
+    seg_left = (int)(e >> 16) - p.seg_off0;
+    a_k = ((e & 0xffffu) + (uint32_t)p.seg_off0) * a_step;
+    b_k = ((e & 0xffffu) + (uint32_t)p.seg_off0) * b_step;
+  }
+  auto advance = [&]() {               // the K walk of the staging waves: one step on, or to the first step of the next segment
+    if constexpr (SEG) {
+      seg_left -= 1;
+      if (__builtin_expect(seg_left == 0, 0)) {
+        seg += 1;
+        const uint32_t e = seg_entry(seg);
+        a_k = (e & 0xffffu) * a_step;
+        b_k = (e & 0xffffu) * b_step;
+        seg_left = (int)(e >> 16);
+      } else {
+        a_k += a_step;
+        b_k += b_step;
+      }
+    } else {
+      a_k += a_step;
+      b_k += b_step;
+    }
+  };
 
   auto stage = [&]() {
     char* sbase = lds + slot_issue * Cfg::STAGE_BYTES;
@@ -102,8 +146,7 @@ __device__ __forceinline__ void gemm_mainloop_tn(GemmOperandsT p, const int m0, 
     for (int i = 0; i < BCH; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_base + (b_vo[i] + b_k)),
                                        (__attribute__((address_space(3))) void*)(sbase + Cfg::A_BYTES + ((wave % NPW) + i * NPW) * 1024), 16, 0, EVC_TN_AUX_B);
-    a_k += a_step;
-    b_k += b_step;
+    advance();
     slot_issue = (slot_issue + 1 == Cfg::STAGES) ? 0 : slot_issue + 1;
   };
 
@@ -233,8 +276,7 @@ __device__ __forceinline__ void gemm_mainloop_tn(GemmOperandsT p, const int m0, 
       __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (PROD) {
-      a_k += a_step;
-      b_k += b_step;
+      advance();
       slot_issue = (slot_issue + 1 == Cfg::STAGES) ? 0 : slot_issue + 1;
     }
 #endif

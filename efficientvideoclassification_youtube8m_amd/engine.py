@@ -206,55 +206,43 @@ class LstmStack:
                                         self.zx, hw[0], hw[1], hb[0], hb[1], self.S, gates, c_all,
                                         x_segments=tw.f16_l2_x_segments, h0_ext=tw.f16_l2_h0_ext)
                 return self.S
-            if self.scope == "RNN_L1" and tw.dither():
-                # time-dithered f16 weight images (ops.lstm_layer_fwd_f16_dith, DESIGN.md 7 "dither"): step t contracts image t, whose rounding
-                # errors cancel over the steps of a chunk - no stages for the weights' low-order halves; layer 0 keeps the e4m3 stages of the
-                # INPUT's low-order half (x rows [f16(x) | e4m3(x 2^7) | e4m3(x_lo 2^18)] of ops.l2norm_chunk(fp8_tail=True) against the
-                # e4m3(Wx 2^6) block of cast_fp8_lo's image), the layers above read the plain f16 h rows of the layer below
-                if not hasattr(self, "hbuf16p"):
-                    self.hbuf16p = [torch.zeros((self.T + 1, self.M, H), dtype=ops.F16, device=self.hbuf[l].device) for l in range(L)]
-                h16 = [self._v(self.hbuf16p[l], T + 1, M, H) for l in range(L)]
-                assert x16.shape[-1] == 2 * self.Kin, "the dithered L1 level takes ops.l2norm_chunk(..., f16_segments=1, fp8_tail=True) rows"
-                inp, ldx, kx16, x8_off, kx8 = x16, x16.shape[-1], self.Kin, 3 * self.Kin, self.Kin
-                for l in range(L):
-                    kn, bn = self.names(l)
-                    w8 = tw.shadow8[kn][:, self.Kin:2 * self.Kin] if l == 0 else None      # the e4m3(Wx 2^6) block of [lo(Wx) | hi(Wx) | lo(Wh)] rows
-                    assert tw.shadow16d[kn].shape[0] >= T
-                    if self.timing is not None:
-                        e0 = torch.cuda.Event(enable_timing=True)
-                        e0.record()
-                    ops.lstm_layer_fwd_f16_dith(inp, ldx, kx16, x8_off, kx8, tw.shadow16d[kn], w8, tw.shadow8[kn].stride(0) if l == 0 else 0,
-                                                7 + ops.FP8_W_SCALE_EXP, tw.store.p(bn), lens, T, M, H, h16[l], hb[l],
-                                                self.S[:, (2 * l) * H:], self.S[:, (2 * l + 1) * H:], 2 * L * H, gates[l], c_all[l], plan=plan)
-                    if self.timing is not None:
-                        e1 = torch.cuda.Event(enable_timing=True)
-                        e1.record()
-                        flops = sum(2.0 * r * 4 * H * (self.kin[l] + (H if t > 0 else 0)) for t, r in enumerate(rows))
-                        self.timing.append((e0, e1, sum(1 for r in rows if r > 0), flops))
-                    inp, ldx, kx16, x8_off, kx8 = h16[l][1:], H, H, 0, 0
-                return self.S
             if self.scope == "RNN_L1" and tw.fp8_lo():
-                # weights' low-order halves in fp8 (ops.lstm_layer_fwd_f16_fp8lo): h rows [f16(h) | e4m3(h 2^7)] of 3H bytes; layer 0 reads
-                # the [f16(x) | e4m3(x 2^7) | e4m3(x_lo 2^18)] rows of ops.l2norm_chunk(fp8_tail=True), the layers above the h rows of the layer below
-                if not hasattr(self, "hbuf16"):
-                    self.hbuf16 = [torch.zeros((self.T + 1, self.M, 3 * H // 2), dtype=ops.F16, device=self.hbuf[l].device) for l in range(L)]
-                h16 = [self._v(self.hbuf16[l], T + 1, M, 3 * H // 2) for l in range(L)]
+                # f16 stages + e4m3 stages behind them in the same launches, per layer one of two forms:
+                #  * weights' low-order halves in fp8 (ops.lstm_layer_fwd_f16_fp8lo): h rows [f16(h) | e4m3(h 2^7)] of 3H bytes; layer 0 reads the
+                #    [f16(x) | e4m3(x 2^7) | e4m3(x_lo 2^18)] rows of ops.l2norm_chunk(fp8_tail=True), the layers above the h rows of the layer below;
+                #  * time-dithered f16 weight images (tw.dither_layers(), ops.lstm_layer_fwd_f16_dith, DESIGN.md 7 "dither"): step t contracts image
+                #    t, whose rounding errors cancel over the steps of a chunk - no stages for the weights' low-order halves (layer 0 keeps the
+                #    input's: the e4m3(x_lo 2^18) bytes against the e4m3(Wx 2^6) block of cast_fp8_lo's rows); plain f16 h rows.
+                dl = tw.dither_layers()
+                widths = [H if l in dl else 3 * H // 2 for l in range(L)]        # halfwords per h row
+                if getattr(self, "_hbuf16_widths", None) != widths:
+                    self.hbuf16 = [torch.zeros((self.T + 1, self.M, widths[l]), dtype=ops.F16, device=self.hbuf[l].device) for l in range(L)]
+                    self._hbuf16_widths = widths
+                h16 = [self._v(self.hbuf16[l], T + 1, M, widths[l]) for l in range(L)]
                 assert x16.shape[-1] == 2 * self.Kin, "the fp8 L1 level takes ops.l2norm_chunk(..., f16_segments=1, fp8_tail=True) rows"
-                inp, ldx, kx16, x8_off, kx8 = x16, x16.shape[-1], self.Kin, 2 * self.Kin, 2 * self.Kin
+                inp, ldx, kx16 = x16, x16.shape[-1], self.Kin
                 for l in range(L):
                     kn, bn = self.names(l)
                     if self.timing is not None:
                         e0 = torch.cuda.Event(enable_timing=True)
                         e0.record()
-                    ops.lstm_layer_fwd_f16_fp8lo(inp, ldx, kx16, x8_off, kx8, tw.shadow16[kn], tw.shadow8[kn], tw.store.p(bn), lens, T, M, H,
-                                                 h16[l], hb[l], self.S[:, (2 * l) * H:], self.S[:, (2 * l + 1) * H:], 2 * L * H,
-                                                 gates[l], c_all[l], plan=plan)
+                    if l in dl:
+                        assert tw.shadow16d[kn].shape[0] >= T
+                        w8 = tw.shadow8[kn][:, self.Kin:2 * self.Kin] if l == 0 else None      # the e4m3(Wx 2^6) block of [lo(Wx) | hi(Wx) | lo(Wh)] rows
+                        ops.lstm_layer_fwd_f16_dith(inp, ldx, kx16, 3 * self.Kin if l == 0 else 0, self.Kin if l == 0 else 0, tw.shadow16d[kn], w8,
+                                                    tw.shadow8[kn].stride(0) if l == 0 else 0, 7 + ops.FP8_W_SCALE_EXP, tw.store.p(bn), lens, T, M, H,
+                                                    h16[l], hb[l], self.S[:, (2 * l) * H:], self.S[:, (2 * l + 1) * H:], 2 * L * H, gates[l], c_all[l], plan=plan)
+                    else:
+                        x8_off, kx8 = (2 * self.Kin, 2 * self.Kin) if l == 0 else (2 * H, H)
+                        ops.lstm_layer_fwd_f16_fp8lo(inp, ldx, kx16, x8_off, kx8, tw.shadow16[kn], tw.shadow8[kn], tw.store.p(bn), lens, T, M, H,
+                                                     h16[l], hb[l], self.S[:, (2 * l) * H:], self.S[:, (2 * l + 1) * H:], 2 * L * H,
+                                                     gates[l], c_all[l], plan=plan)
                     if self.timing is not None:
                         e1 = torch.cuda.Event(enable_timing=True)
                         e1.record()
                         flops = sum(2.0 * r * 4 * H * (self.kin[l] + (H if t > 0 else 0)) for t, r in enumerate(rows))
                         self.timing.append((e0, e1, sum(1 for r in rows if r > 0), flops))
-                    inp, ldx, kx16, x8_off, kx8 = h16[l][1:], 3 * H // 2, H, 2 * H, H
+                    inp, ldx, kx16 = h16[l][1:], widths[l], H
                 return self.S
             wide = [l in tw.f16_wh_ext_layers for l in range(L)]        # layers whose recurrent weights are K-extended (wide h rows)
             if not hasattr(self, "hbuf16"):
@@ -385,7 +373,11 @@ class LstmStack:
             inp = self._hb[l][1:]
         return res
 
-    def _wgrad_tn(self, dz2, layer_in, h_prev, kin, rows, gW):
+    # A/B: 0 = the weight-gradient products of a row-planned level contract over every row of the [T][P] images (rounds 1-5) instead of
+    # skipping each time slab's dead rows (ops.gemm_tn(live_rows=...))
+    wgrad_live_rows = os.environ.get("EVC_WGRAD_LIVE_ROWS", "1") != "0"
+
+    def _wgrad_tn(self, dz2, layer_in, h_prev, kin, rows, gW, live=None):
         """gW [4H][kin+H] += dz^T . [layer_in | h_prev] (gate rows de-interleaved).  One launch over both column segments when
         the input width allows it (kin == H, a multiple of 256: the upper layers): dz is read once and the launch has twice the
         tiles; two launches otherwise (layer 0 of the L1 stacks: 1152 + 1024 columns = 8.5 column tiles would leave half of
@@ -403,17 +395,19 @@ class LstmStack:
                 ops.gemm_tn_det(dz2, layer_in, 4 * H, kin, rows, gW, row_interleave_H=H, accumulate=True, ldc=kin + H)
                 ops.gemm_tn_det(dz2, h_prev, 4 * H, H, rows, gW[:, kin:], row_interleave_H=H, accumulate=True, ldc=kin + H)
             return
+        if not self.wgrad_live_rows:
+            live = None
         if kin == H and kin % 256 == 0 and self.fuse_wgrad:
-            ops.gemm_tn2(dz2, layer_in, kin, h_prev, H, 4 * H, rows, gW, row_interleave_H=H, accumulate=True)
+            ops.gemm_tn2(dz2, layer_in, kin, h_prev, H, 4 * H, rows, gW, row_interleave_H=H, accumulate=True, live_rows=live)
         elif self.fuse_wgrad and kin - n1 in (64, 128) and n1 >= H and rows >= 16384 and (n1 + H) % 2048 == 0:
             # layer 0 of the L1 stacks (1152 = 1024 + 128 input columns): the first 1024 input columns next to the h-part as one
             # 2048-column launch, the last 128 as a narrow strip of their own (1.0 + 0.13 ms against 0.75 + 0.6 ms)
-            ops.gemm_tn2(dz2, layer_in, n1, h_prev, H, 4 * H, rows, gW, row_interleave_H=H, accumulate=True, c_col2=kin)
+            ops.gemm_tn2(dz2, layer_in, n1, h_prev, H, 4 * H, rows, gW, row_interleave_H=H, accumulate=True, c_col2=kin, live_rows=live)
             ops.gemm_tn(dz2, layer_in[:, n1:], 4 * H, kin - n1, rows, gW[:, n1:kin], row_interleave_H=H, lda=dz2.stride(0),
-                        ldb=layer_in.stride(0), ldc=kin + H, accumulate=True)
+                        ldb=layer_in.stride(0), ldc=kin + H, accumulate=True, live_rows=live)
         else:
-            ops.gemm_tn(dz2, layer_in, 4 * H, kin, rows, gW, row_interleave_H=H, ldc=kin + H, accumulate=True)
-            ops.gemm_tn(dz2, h_prev, 4 * H, H, rows, gW[:, kin:], row_interleave_H=H, ldc=kin + H, accumulate=True)
+            ops.gemm_tn(dz2, layer_in, 4 * H, kin, rows, gW, row_interleave_H=H, ldc=kin + H, accumulate=True, live_rows=live)
+            ops.gemm_tn(dz2, h_prev, 4 * H, H, rows, gW[:, kin:], row_interleave_H=H, ldc=kin + H, accumulate=True, live_rows=live)
 
     fuse_wgrad = os.environ.get("EVC_NO_FUSED_WGRAD") != "1"
 
@@ -541,8 +535,9 @@ class LstmStack:
                     # tiles are added with atomics: one contiguous fill of the whole gradient, then accumulate
                     # (instead of a pitched 2-D memset inside each call).
                     ops.fill_f32(gW, 0.0)
-                    with self._timed("wgrad_tn", 1, 2.0 * T * M * 4 * H * (kin + H), stream=side):
-                        self._wgrad_tn(dz2, layer_in, h_prev, kin, T * M, gW)
+                    # (flops of the LIVE rows: with a row plan the products skip each slab's dead rows, ops.gemm_tn(live_rows=...))
+                    with self._timed("wgrad_tn", 1, 2.0 * (sum(rows) if plan is not None else T * M) * 4 * H * (kin + H), stream=side):
+                        self._wgrad_tn(dz2, layer_in, h_prev, kin, T * M, gW, live=(rows, M) if plan is not None else None)
                 else:   # T*M not a multiple of 32: transposed copies + NT products
                     ops.transpose_to_bf16(dz2, T * M, 4 * H, self.dzT, KP, interleave_H=-H)
                     inT = self.xT[:kin]
@@ -1139,16 +1134,28 @@ class HLstmTower(TowerBase):
         """True if this tower's L1 level runs on ops.lstm_layer_fwd_f16_fp8lo (or, with dither(), on ops.lstm_layer_fwd_f16_dith)."""
         return (self.precision == "high" and self.f16_fp8_lo and self.F % 128 == 0 and self.H % 128 == 0 and self.F >= 384 and self.H >= 384)
 
-    # L1 level on TIME-DITHERED f16 weight images (round 5, DESIGN.md 7 "dither"; ops.lstm_layer_fwd_f16_dith): step t of a chunk contracts
-    # image t of every L1 kernel - each element rounded down or up so that the round-ups over any run of steps match its position between
+    # L1 layers on TIME-DITHERED f16 weight images (round 5, DESIGN.md 7 "dither"; ops.lstm_layer_fwd_f16_dith): step t of a chunk contracts
+    # image t of the layer's kernel - each element rounded down or up so that the round-ups over any run of steps match its position between
     # its f16 neighbours.  The f16 rounding of a WEIGHT is the error a recurrence integrates coherently (the reason for the e4m3 low-order
-    # halves above); dithered over the steps it cancels instead, and the level needs no stages for the weights' low-order halves: per step
-    # pair 34 + 9 (the input's low-order half) and 32 + 0 stages instead of 34 + 26 and 32 + 16.  Costs T images per L1 kernel (15 x 35 MB
-    # for the teacher) and one pass over them per update.  EVC_HIGH_DITHER=0: the e4m3 low-order halves of every weight (rounds 3-5).
-    f16_dither = os.environ.get("EVC_HIGH_DITHER", "1") != "0"
+    # halves above); dithered over the steps it largely cancels, and a dithered layer needs no stages for its weights' low-order halves
+    # (layer 1 of the teacher: 32 ring stages per step instead of 32 + 16; layer 0: 34 + 9 - the input's low-order half - instead of 34 + 26).
+    # Costs T images per dithered kernel (15 x 17 MB per teacher layer) and one pass over them per update.  What it buys and what it costs in
+    # accuracy is measured over weight draws in DESIGN.md 7 (12 draws each, teacher logits x 1e-4, real kernels): no layer dithered mean 2.1-2.3 /
+    # max 3.6-4.3 at 1.21x the bf16 step; the TOP layer dithered (default) 2.6 / 5.6 at 1.18x; both layers 4.1 / 8.3 at 1.16x - too close to
+    # the 1e-3 the mode exists for.  EVC_HIGH_DITHER_LAYERS = comma list of L1 layers (a SUFFIX of the stack: a layer on e4m3 low-order
+    # halves reads the e4m3 image of h from the layer below, which a dithered layer does not write); "" = none (rounds 3-5).
+    f16_dither_layers = tuple(int(v) for v in os.environ.get("EVC_HIGH_DITHER_LAYERS", "1").split(",") if v.strip() != "")
 
-    def dither(self):
-        return self.fp8_lo() and self.f16_dither
+    def dither_layers(self):
+        """L1 layers that run on time-dithered weight images (empty unless this tower's L1 level is the f16 + e4m3 one)."""
+        if not self.fp8_lo():
+            return ()
+        dl = tuple(sorted(set(l for l in self.f16_dither_layers if 0 <= l < self.L)))
+        if self.L == 1 and "EVC_HIGH_DITHER_LAYERS" not in os.environ:
+            dl = ()                                          # (the default names the top layer of a TWO-layer level; a one-layer level keeps its corrections)
+        if dl and dl != tuple(range(dl[0], self.L)):
+            raise ValueError("EVC_HIGH_DITHER_LAYERS=%r: the dithered L1 layers must be the top layers of the stack (a suffix of 0..%d)" % (list(dl), self.L - 1))
+        return dl
 
     def l1_steps(self):
         return self.T // self.C
@@ -1166,7 +1173,7 @@ class HLstmTower(TowerBase):
         for k, shp in self.store.shapes.items():
             if len(shp) != 2:
                 continue
-            if k.startswith("RNN_L1/") and self.dither():
+            if k.startswith("RNN_L1/") and int(k.split("cell_")[1].split("/")[0]) in self.dither_layers():
                 # T time-dithered f16 images; layer 0 also keeps cast_fp8_lo's [lo(Wx) | e4m3(Wx 2^6) | lo(Wh)] rows for their middle block
                 nin = shp[1] - H
                 layer = int(k.split("cell_")[1].split("/")[0])
@@ -1251,8 +1258,8 @@ class HLstmTower(TowerBase):
     def precision_layout(self):
         d = {"precision": self.precision}
         if self.precision == "high":
-            d.update(l1=("f16 on %d time-dithered weight images per kernel + e4m3 low-order half of the input frames" % self.l1_steps()) if self.dither() else
-                     "f16 + e4m3 low-order halves (weights, input frames)" if self.fp8_lo() else
+            d.update(l1=("f16 + e4m3 low-order halves (weights, input frames)" + ("; layers %s on %d time-dithered f16 weight images instead of their weights' low-order halves"
+                                                                                   % (list(self.dither_layers()), self.l1_steps()) if self.dither_layers() else "")) if self.fp8_lo() else
                      "f16, x segments %d, Wh extended in layers %s, Wx extended in layers %s" % (self.f16_x_segments, list(self.f16_wh_ext_layers), list(self.f16_wx_ext_layers)),
                      l2=("f16 + e4m3 low-order halves, %d input segments" % self.f16_l2_x_segments) if any(k.startswith("RNN_L2/") for k in getattr(self, "shadow8", {}))
                      else ("f16 K-extensions, %d input segments, h0_ext %s" % (self.f16_l2_x_segments, self.f16_l2_h0_ext) if self.L == 2 else "split-bf16"),

@@ -62,9 +62,22 @@ def gemm_nt(A, B, M, N, K, out, bias=None, accumulate=False, lda=None, ldb=None,
     return out
 
 
-def gemm_tn(A, B, M, N, K, out, row_interleave_H=0, accumulate=False, lda=None, ldb=None, ldc=None):
-    """out[M,N] (+)= A[K,M]^T @ B[K,N] (both row-major over K), f32 out."""
+def _slab_rows_arg(live_rows, K):
+    """(slab_rows, nslabs, host int32 array) of evc_gemm_tn2_rows from live_rows = (rows per slab [T], rows of one slab)."""
+    rows, slab = live_rows
+    assert slab % 32 == 0 and K == slab * len(rows), (K, slab, len(rows))
+    return slab, len(rows), (C.c_int32 * len(rows))(*[int(r) for r in rows])
+
+
+def gemm_tn(A, B, M, N, K, out, row_interleave_H=0, accumulate=False, lda=None, ldb=None, ldc=None, live_rows=None):
+    """out[M,N] (+)= A[K,M]^T @ B[K,N] (both row-major over K), f32 out.  live_rows = (rows [T], slab_rows): K = T slabs of slab_rows rows
+    of which the first rows[t] are live (a row-planned level) - the dead rows are skipped (evc_gemm_tn2_rows)."""
     assert A.dtype == BF16 and B.dtype == BF16 and out.dtype == F32
+    if live_rows is not None:
+        slab, ns, arr = _slab_rows_arg(live_rows, K)
+        _lib.call("evc_gemm_tn2_rows", _p(A), A.stride(0) if lda is None else lda, _p(B), B.stride(0) if ldb is None else ldb, N, None, 0, 0, 0,
+                  _p(out), out.stride(0) if ldc is None else ldc, M, slab, ns, arr, row_interleave_H, 1 if accumulate else 0, _stream())
+        return out
     _lib.call("evc_gemm_tn", _p(A), A.stride(0) if lda is None else lda, _p(B), B.stride(0) if ldb is None else ldb,
               _p(out), out.stride(0) if ldc is None else ldc, M, N, K, row_interleave_H, 1 if accumulate else 0, _stream())
     return out
@@ -88,10 +101,15 @@ def gemm_tn_det(A, B, M, N, K, out, row_interleave_H=0, accumulate=False, ldc=No
     return out
 
 
-def gemm_tn2(A, B1, N1, B2, N2, M, K, out, row_interleave_H=0, accumulate=False, ldc=None, c_col2=None):
+def gemm_tn2(A, B1, N1, B2, N2, M, K, out, row_interleave_H=0, accumulate=False, ldc=None, c_col2=None, live_rows=None):
     """out[:, :N1] (+)= A[K,M]^T @ B1[K,N1], out[:, c_col2:c_col2+N2] (+)= A^T @ B2[K,N2] in one launch (N1 % 256 == 0;
-    c_col2 defaults to N1: adjacent segments)."""
+    c_col2 defaults to N1: adjacent segments).  live_rows: as in gemm_tn."""
     assert A.dtype == BF16 and B1.dtype == BF16 and B2.dtype == BF16 and out.dtype == F32
+    if live_rows is not None:
+        slab, ns, arr = _slab_rows_arg(live_rows, K)
+        _lib.call("evc_gemm_tn2_rows", _p(A), A.stride(0), _p(B1), B1.stride(0), N1, _p(B2), B2.stride(0), N2, N1 if c_col2 is None else c_col2,
+                  _p(out), out.stride(0) if ldc is None else ldc, M, slab, ns, arr, row_interleave_H, 1 if accumulate else 0, _stream())
+        return out
     _lib.call("evc_gemm_tn2", _p(A), A.stride(0), _p(B1), B1.stride(0), N1, _p(B2), B2.stride(0), N2, N1 if c_col2 is None else c_col2,
               _p(out), out.stride(0) if ldc is None else ldc, M, K, row_interleave_H, 1 if accumulate else 0, _stream())
     return out

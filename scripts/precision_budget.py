@@ -374,6 +374,14 @@ def main():
                                                                        L2c0=dict(ax="x3", ah="f16", wx="f16d", wh="f16d"), L2c1=dict(ax="f16", ah="f16", wx="f16d", wh="f16d"))),
             ("DITH FZS8X L1 W stochastic, x_lo fp8 | shipped L2", dict(exact, L1c0=dict(ax="f16+8", ah="f16", wx="f16s", wh="f16s"),
                                                                        L1c1=dict(ax="f16", ah="f16", wx="f16s", wh="f16s"), **l2_f16x)),
+            ("DITH FZD1 layer 1 dithered, layer 0 fp8-corrected | shipped L2", dict(exact, L1c0=dict(ax="f16+8", ah="f16", wx="f16+8", wh="f16+8"),
+                                                                       L1c1=dict(ax="f16", ah="f16", wx="f16d", wh="f16d"), **l2_f16x)),
+            ("DITH FZD0 layer 0 dithered (x_lo fp8), layer 1 fp8-corrected | shipped L2", dict(exact, L1c0=dict(ax="f16+8", ah="f16", wx="f16d", wh="f16d"),
+                                                                       L1c1=dict(ax="f16", ah="f16", wx="f16+8", wh="f16+8"), **l2_f16x)),
+            ("DITH FZDh Wh parts dithered, Wx parts fp8-corrected | shipped L2", dict(exact, L1c0=dict(ax="f16+8", ah="f16", wx="f16+8", wh="f16d"),
+                                                                       L1c1=dict(ax="f16", ah="f16", wx="f16+8", wh="f16d"), **l2_f16x)),
+            ("DITH FZDx Wx parts dithered, Wh parts fp8-corrected | shipped L2", dict(exact, L1c0=dict(ax="f16+8", ah="f16", wx="f16d", wh="f16+8"),
+                                                                       L1c1=dict(ax="f16", ah="f16", wx="f16d", wh="f16+8"), **l2_f16x)),
             ("DITH A8 L1 W RTN uncorrected, x_lo fp8 | shipped L2", dict(exact, L1c0=dict(ax="f16+8", ah="f16", wx="f16", wh="f16"),
                                                                        L1c1="f16", **l2_f16x)),
             ("DBG6 c0 wx", dict(exact, L1c0=dict(ex, wx="f16+6"))), ("DBG6 c0 wh", dict(exact, L1c0=dict(ex, wh="f16+6"))), ("DBG6 c1 wx", dict(exact, L1c1=dict(ex, wx="f16+6"))), ("DBG6 c1 wh", dict(exact, L1c1=dict(ex, wh="f16+6"))),
