@@ -537,7 +537,7 @@ class LstmStack:
                     ops.fill_f32(gW, 0.0)
                     # (flops of the LIVE rows: with a row plan the products skip each slab's dead rows, ops.gemm_tn(live_rows=...))
                     with self._timed("wgrad_tn", 1, 2.0 * (sum(rows) if plan is not None else T * M) * 4 * H * (kin + H), stream=side):
-                        self._wgrad_tn(dz2, layer_in, h_prev, kin, T * M, gW, live=(rows, M) if plan is not None else None)
+                        self._wgrad_tn(dz2, layer_in, h_prev, kin, T * M, gW, live=(rows, M) if plan is not None and M % 32 == 0 else None)      # (plan.P = M when the stack has fewer rows than a multiple of 32)
                 else:   # T*M not a multiple of 32: transposed copies + NT products
                     ops.transpose_to_bf16(dz2, T * M, 4 * H, self.dzT, KP, interleave_H=-H)
                     inT = self.xT[:kin]
