@@ -1144,15 +1144,17 @@ class HLstmTower(TowerBase):
     # max 3.6-4.3 at 1.21x the bf16 step; the TOP layer dithered (default) 2.6 / 5.6 at 1.18x; both layers 4.1 / 8.3 at 1.16x - too close to
     # the 1e-3 the mode exists for.  EVC_HIGH_DITHER_LAYERS = comma list of L1 layers (a SUFFIX of the stack: a layer on e4m3 low-order
     # halves reads the e4m3 image of h from the layer below, which a dithered layer does not write); "" = none (rounds 3-5).
-    f16_dither_layers = tuple(int(v) for v in os.environ.get("EVC_HIGH_DITHER_LAYERS", "1").split(",") if v.strip() != "")
+    # Unset: the TOP layer of a level of two or more layers.
+    f16_dither_layers = (tuple(int(v) for v in os.environ["EVC_HIGH_DITHER_LAYERS"].split(",") if v.strip() != "")
+                         if "EVC_HIGH_DITHER_LAYERS" in os.environ else None)
 
     def dither_layers(self):
         """L1 layers that run on time-dithered weight images (empty unless this tower's L1 level is the f16 + e4m3 one)."""
         if not self.fp8_lo():
             return ()
+        if self.f16_dither_layers is None:                   # default: the top layer; a one-layer level keeps its corrections
+            return (self.L - 1,) if self.L >= 2 else ()
         dl = tuple(sorted(set(l for l in self.f16_dither_layers if 0 <= l < self.L)))
-        if self.L == 1 and "EVC_HIGH_DITHER_LAYERS" not in os.environ:
-            dl = ()                                          # (the default names the top layer of a TWO-layer level; a one-layer level keeps its corrections)
         if dl and dl != tuple(range(dl[0], self.L)):
             raise ValueError("EVC_HIGH_DITHER_LAYERS=%r: the dithered L1 layers must be the top layers of the stack (a suffix of 0..%d)" % (list(dl), self.L - 1))
         return dl

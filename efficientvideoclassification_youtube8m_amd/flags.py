@@ -82,7 +82,8 @@ _define("teacher_only", False, _bool, "HierarchicalLstmModel: train the teacher 
         "always builds the student too, also at every_n=1)")
 _define("precision", "bf16", str, "'bf16' (one bf16 MFMA product per forward contraction), 'high' (holds 1e-3 on logits at trained "
         "magnitudes: every forward product on IEEE f16 operands with the low-order halves of its weights - for the L1 level also of the input "
-        "frames, for the MoE head of both operands - as OCP e4m3 operands on the MX-scaled MFMA behind the f16 stages of the same launch; "
+        "frames, for the MoE head of both operands - as OCP e4m3 operands on the MX-scaled MFMA behind the f16 stages of the same launch; the top layer of the L1 level "
+        "contracts time-dithered f16 weight images instead (EVC_HIGH_DITHER_LAYERS, DESIGN.md 7); "
         "fixed power-of-two e4m3 scales: |x|, |h| <= 1, |W| < 4, head input |state| < 7, head weights |W| < 3.5 never clamp, larger values "
         "saturate at 448 and only lose their correction - engine.HLstmTower.fp8_saturation() counts them; the resolved layout depends on "
         "the EVC_HIGH_* environment and on the student's length and is logged / checkpointed as `precision_layout`) or "
