@@ -113,6 +113,9 @@ def _parts(kind):
     return kind, kind, kind, kind
 
 
+DITHER_ROW_SHIFT = None        # set by tower_fwd: int64 [M] - row r contracts image (t + shift[r]) mod T at step t (the per-chunk rotation candidate)
+
+
 def stack_fwd(x, lengths, layers, kinds):
     """x [M, T, F] float64, layers [(kernel, bias)], kinds per layer -> final state [M, 2LH] (c0 h0 c1 h1)."""
     M, T, _ = x.shape
@@ -152,10 +155,19 @@ def stack_fwd(x, lengths, layers, kinds):
             a = torch.cat([rnd(inp, ax), rnd(h[l], ah)], 1)
             wl = wq[l]
             dith, dxp, dhp = wdith[l]
-            if dith is not None:
+            if dith is not None and DITHER_ROW_SHIFT is not None and len(DITHER_ROW_SHIFT) == M:
                 nin_l = layers[l][0].shape[0] - H
-                wl = torch.cat([dith[t][:nin_l] if dxp else wl[:nin_l], dith[t][nin_l:] if dhp else wl[nin_l:]], 0)
-            z = a @ wl + bias
+                z = torch.empty((M, wl.shape[1]), dtype=a.dtype)
+                for sft in torch.unique(DITHER_ROW_SHIFT).tolist():
+                    sel = DITHER_ROW_SHIFT == sft
+                    img = dith[(t + int(sft)) % T]
+                    wls = torch.cat([img[:nin_l] if dxp else wl[:nin_l], img[nin_l:] if dhp else wl[nin_l:]], 0)
+                    z[sel] = a[sel] @ wls + bias
+            else:
+                if dith is not None:
+                    nin_l = layers[l][0].shape[0] - H
+                    wl = torch.cat([dith[t][:nin_l] if dxp else wl[:nin_l], dith[t][nin_l:] if dhp else wl[nin_l:]], 0)
+                z = a @ wl + bias
             _, _, wxk, whk = _parts(kinds[l])
             if wlo8[l] is not None and "f16+6" in (wxk, whk):      # e2m3 images of the activations: the input frames under one scale per
                 # frame (layer 0; layer 1's input is the h of the layer below), h under a fixed scale
@@ -187,7 +199,11 @@ def tower_fwd(x, n, p, num_chunks, kinds):
     l1, l2 = tc._layers(p, "RNN_L1", 2), tc._layers(p, "RNN_L2", 2)
     xc = x.reshape(B, num_chunks, Lc, F).permute(1, 0, 2, 3).reshape(num_chunks * B, Lc, F)       # row = chunk*B + b
     ln = torch.stack([torch.clamp(n - Lc * i, 0, Lc) for i in range(num_chunks)], 0).reshape(-1)
+    global DITHER_ROW_SHIFT
+    d = kinds.get("chunk_shift")          # candidate: chunk c of every video contracts image (t + c * d) mod Lc - the L2 level then integrates DIFFERENT residuals
+    DITHER_ROW_SHIFT = (torch.arange(num_chunks).repeat_interleave(B) * int(d)) % Lc if d else None
     s1 = stack_fwd(xc, ln, l1, (kinds["L1c0"], kinds["L1c1"]))
+    DITHER_ROW_SHIFT = None
     l2_in = s1.reshape(num_chunks, B, -1).permute(1, 0, 2)
     len2 = torch.ceil(n.to(torch.float32) / float(Lc)).to(torch.int64)
     state = stack_fwd(l2_in, len2, l2, (kinds["L2c0"], kinds["L2c1"]))
@@ -382,6 +398,13 @@ def main():
                                                                        L1c1=dict(ax="f16", ah="f16", wx="f16+8", wh="f16d"), **l2_f16x)),
             ("DITH FZDx Wx parts dithered, Wh parts fp8-corrected | shipped L2", dict(exact, L1c0=dict(ax="f16+8", ah="f16", wx="f16d", wh="f16+8"),
                                                                        L1c1=dict(ax="f16", ah="f16", wx="f16d", wh="f16+8"), **l2_f16x)),
+            ("DITH FZD8XC1 both layers dithered, chunk c rotated by c steps", dict(exact, L1c0=dict(ax="f16+8", ah="f16", wx="f16d", wh="f16d"),
+                                                                       L1c1=dict(ax="f16", ah="f16", wx="f16d", wh="f16d"), chunk_shift=1, **l2_f16x)),
+            ("DITH FZD8XC4 both layers dithered, chunk c rotated by 4c steps", dict(exact, L1c0=dict(ax="f16+8", ah="f16", wx="f16d", wh="f16d"),
+                                                                       L1c1=dict(ax="f16", ah="f16", wx="f16d", wh="f16d"), chunk_shift=4, **l2_f16x)),
+            ("DITH FZD8XC7 both layers dithered, chunk c rotated by 7c steps", dict(exact, L1c0=dict(ax="f16+8", ah="f16", wx="f16d", wh="f16d"),
+                                                                       L1c1=dict(ax="f16", ah="f16", wx="f16d", wh="f16d"), chunk_shift=7, **l2_f16x)),
+            ("DITH W16dC4 only L1 weights dithered, chunk c rotated by 4c steps", dict(exact, L1c0=dict(ex, wx="f16d", wh="f16d"), L1c1=dict(ex, wx="f16d", wh="f16d"), chunk_shift=4)),
             ("DITH A8 L1 W RTN uncorrected, x_lo fp8 | shipped L2", dict(exact, L1c0=dict(ax="f16+8", ah="f16", wx="f16", wh="f16"),
                                                                        L1c1="f16", **l2_f16x)),
             ("DBG6 c0 wx", dict(exact, L1c0=dict(ex, wx="f16+6"))), ("DBG6 c0 wh", dict(exact, L1c0=dict(ex, wh="f16+6"))), ("DBG6 c1 wx", dict(exact, L1c1=dict(ex, wx="f16+6"))), ("DBG6 c1 wh", dict(exact, L1c1=dict(ex, wh="f16+6"))),
