@@ -284,6 +284,24 @@ struct MoeUpdateParams {
   float l2, clip, lr_t, b1, b2, eps;
 };
 
+#ifndef EVC_ADAM_NT
+#define EVC_ADAM_NT 1       // (round 5: 1 = W, m, v of the fused MoE update - read once, written once, 5.9 GB per step - as non-temporal accesses: same box, alternated three times, 10.00 -> 9.93 ms per step; 0 = plain accesses; 2 = the bf16 shadows too - they are read again soon: 9.82 -> 9.93)
+#endif
+__device__ __forceinline__ float4 ld_stream_moe(const float* p) {
+#if EVC_ADAM_NT
+  const f32x4 v = __builtin_nontemporal_load((const f32x4*)p);
+  return make_float4(v[0], v[1], v[2], v[3]);
+#else
+  return *(const float4*)p;
+#endif
+}
+__device__ __forceinline__ void st_stream_moe(float* p, float a, float b, float c, float d) {
+#if EVC_ADAM_NT
+  __builtin_nontemporal_store(f32x4{a, b, c, d}, (f32x4*)p);
+#else
+  *(float4*)p = make_float4(a, b, c, d);
+#endif
+}
 #ifndef EVC_MOE_UPD_EARLY_MV
 #define EVC_MOE_UPD_EARLY_MV 0          // (A/B, round 5: 1 = m and v asked for ahead of the factor product like p - 219 VGPRs, still one workgroup per CU;
                                         //  measured 459-462 / 309-316 us against 442-456 / 302-305: nothing, the pass is not waiting for those loads)
@@ -312,7 +330,7 @@ __global__ __launch_bounds__(Cfg::NT, EVC_MOE_UPD_WAVES_PER_EU) void moe_update_
 #pragma unroll
     for (int ni = 0; ni < Cfg::NI; ++ni) {
       const int vr = m0 + tc.row0 + mi * 16, k = n0 + tc.unit0 + ni * 16;
-      pv[mi][ni] = (vr < u.V && k < K) ? *(const float4*)(u.p + (long)vr * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      pv[mi][ni] = (vr < u.V && k < K) ? ld_stream_moe(u.p + (long)vr * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #if EVC_MOE_UPD_EARLY_MV
   // (A/B) m and v asked for up front too: the update pass owns its CU either way (184 -> 219 VGPRs, still one 8-wave workgroup)
@@ -371,8 +389,8 @@ __global__ __launch_bounds__(Cfg::NT, EVC_MOE_UPD_WAVES_PER_EU) void moe_update_
     for (int ni = 0; ni < Cfg::NI; ++ni) {
       const int vr = m0 + tc.row0 + mi * 16, k = n0 + tc.unit0 + ni * 16;
       const bool ok = vr < u.V && k < K;
-      mv[mi][ni] = ok ? *(const float4*)(u.m + (long)vr * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-      vv[mi][ni] = ok ? *(const float4*)(u.v + (long)vr * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      mv[mi][ni] = ok ? ld_stream_moe(u.m + (long)vr * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      vv[mi][ni] = ok ? ld_stream_moe(u.v + (long)vr * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #endif
   float scale = 1.f;
@@ -404,10 +422,17 @@ __global__ __launch_bounds__(Cfg::NT, EVC_MOE_UPD_WAVES_PER_EU) void moe_update_
           pb[r] = f32_to_bf16(pn[r]);
           wsq += pn[r] * pn[r];
         }
-        *(float4*)(u.p + o) = make_float4(pn[0], pn[1], pn[2], pn[3]);
-        *(float4*)(u.m + o) = make_float4(mn[0], mn[1], mn[2], mn[3]);
-        *(float4*)(u.v + o) = make_float4(vn[0], vn[1], vn[2], vn[3]);
-        if (u.p_bf16) *(uint2*)(u.p_bf16 + o) = make_uint2((uint32_t)pb[0] | ((uint32_t)pb[1] << 16), (uint32_t)pb[2] | ((uint32_t)pb[3] << 16));
+        st_stream_moe(u.p + o, pn[0], pn[1], pn[2], pn[3]);
+        st_stream_moe(u.m + o, mn[0], mn[1], mn[2], mn[3]);
+        st_stream_moe(u.v + o, vn[0], vn[1], vn[2], vn[3]);
+        if (u.p_bf16) {
+          const u32x2_t sb = {(uint32_t)pb[0] | ((uint32_t)pb[1] << 16), (uint32_t)pb[2] | ((uint32_t)pb[3] << 16)};
+#if EVC_ADAM_NT >= 2
+          __builtin_nontemporal_store(sb, (u32x2_t*)(u.p_bf16 + o));
+#else
+          *(u32x2_t*)(u.p_bf16 + o) = sb;
+#endif
+        }
         if (u.p_f16) {                                // f16 + e4m3 images: saves the passes over the f32 weights (evc_cast_f32_to_f16 / _fp8_lo) per update
           const uint32_t h01 = pack_f16x2_hw(pn[0], pn[1]), h23 = pack_f16x2_hw(pn[2], pn[3]);
           *(uint2*)(u.p_f16 + o) = make_uint2(h01, h23);
@@ -447,7 +472,11 @@ __global__ __launch_bounds__(Cfg::NT, EVC_MOE_UPD_WAVES_PER_EU) void moe_update_
     const int k = n0 + kl;
     if (k >= K || v4 >= u.V) continue;                 // V % 4 == 0: a lane's 4 rows are all valid or all not
     const uint2 q = *(const uint2*)(tile + kl * PITCH + (lane % LPR) * 4);
+#if EVC_ADAM_NT >= 2
+    __builtin_nontemporal_store(u32x2_t{q.x, q.y}, (u32x2_t*)(u.pT_bf16 + (long)k * u.ldT + v4));
+#else
     *(uint2*)(u.pT_bf16 + (long)k * u.ldT + v4) = q;
+#endif
   }
   if (u.wsq_partial) {                                 // per-workgroup partial, summed in a fixed order by moe_update_finalize_kernel
     wsq = wave_sum(wsq);

@@ -135,6 +135,9 @@ __device__ __forceinline__ void lstm_bwd_zero_tile(const LstmBwdParams& e, int m
 // global access of the tail is a contiguous run over the whole wave (gate records 1 KB, dz 1 KB, dc 512 B, cell history
 // 256 B per row), GROUP rows in flight per thread.  Straight from the accumulator layout (lane = 4 units of one row, 16
 // rows per instruction) the same bytes moved in 32-64-byte pieces and the tail took 32 of the step's 70 us.
+#ifndef EVC_BWD_TAPE_NT
+#define EVC_BWD_TAPE_NT 0
+#endif
 template <class Cfg>
 __device__ __forceinline__ void lstm_bwd_tail_rowmajor(f32x4 (&acc)[Cfg::MI][1][Cfg::NI], const LstmBwdParams& e, int m0, int u0, char* lds) {
   static_assert(Cfg::BU == 128 && Cfg::NT == 512, "row-major tail: 128-unit tiles, 8 waves");
@@ -189,10 +192,17 @@ __device__ __forceinline__ void lstm_bwd_tail_rowmajor(f32x4 (&acc)[Cfg::MI][1][
             dcv[i] = *(const float2*)(e.dc_ws + hu);
           }
         }
+#if EVC_BWD_TAPE_NT      // (A/B: the tape - gate records, cell history, the gradient from the layer above - is read ONCE, milliseconds after it was written: non-temporal loads)
+        if (e.dh_above) dha[i] = __builtin_nontemporal_load((const uint32_t*)(e.dh_above + hu));
+        { const u32x4_t gq = __builtin_nontemporal_load((const u32x4_t*)(e.gates + hu)); grec[i] = make_uint4(gq[0], gq[1], gq[2], gq[3]); }
+        cn[i] = __builtin_nontemporal_load((const uint32_t*)(e.c_new + hu));
+        if (e.c_old) co[i] = __builtin_nontemporal_load((const uint32_t*)(e.c_old + hu));
+#else
         if (e.dh_above) dha[i] = *(const uint32_t*)(e.dh_above + hu);
         grec[i] = *(const uint4*)(e.gates + hu);
         cn[i] = *(const uint32_t*)(e.c_new + hu);
         if (e.c_old) co[i] = *(const uint32_t*)(e.c_old + hu);
+#endif
       }
     }
     // compute phase, then store phase: with the stores of row i between the computations of rows i and i+1 hipcc put

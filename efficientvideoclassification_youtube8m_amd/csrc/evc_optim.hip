@@ -79,6 +79,24 @@ __device__ __forceinline__ float sum_partials(const float* __restrict__ part, in
 
 // IL = true: an LSTM kernel [4H][C] (row g*H+u; backward shadow column u*4+g) with its bias; IL = false: any 2-D weight [R][C] stored as
 // the forward GEMM's B operand (backward shadow = its plain transpose, zero-padded to ldT columns), no bias
+#ifndef EVC_ADAM_NT
+#define EVC_ADAM_NT 1       // (round 5: 1 = the master / moment streams of the fused update - read once, written once, 3 GB per step - as non-temporal accesses: same box, alternated three times, 10.00 -> 9.93 ms per step; 0 = plain accesses; 2 = the bf16 shadows too - they are read again soon: 9.82 -> 9.93)
+#endif
+__device__ __forceinline__ float4 ld_stream(const float* p) {
+#if EVC_ADAM_NT
+  const f32x4 v = __builtin_nontemporal_load((const f32x4*)p);
+  return make_float4(v[0], v[1], v[2], v[3]);
+#else
+  return *(const float4*)p;
+#endif
+}
+__device__ __forceinline__ void st_stream(float* p, float a, float b, float c, float d) {
+#if EVC_ADAM_NT
+  __builtin_nontemporal_store(f32x4{a, b, c, d}, (f32x4*)p);
+#else
+  *(float4*)p = make_float4(a, b, c, d);
+#endif
+}
 template <bool IL>
 __global__ __launch_bounds__(256) void lstm_adam_fused_kernel(LstmAdamParams u) {
   __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];      // [k][u*4+g] of one 16-unit x 64-column tile
@@ -114,7 +132,7 @@ __global__ __launch_bounds__(256) void lstm_adam_fused_kernel(LstmAdamParams u) 
 #pragma unroll
   for (int g = 0; g < 4; ++g) {                        // all loads first (16 x 16 bytes in flight per lane)
     const long o = (long)row_of(g) * u.C + col;
-    if (okc && row_of(g) < u.R) { pv[g] = *(const float4*)(u.p + o); gv[g] = *(const float4*)(u.g + o); mv[g] = *(const float4*)(u.m + o); vv[g] = *(const float4*)(u.v + o); }
+    if (okc && row_of(g) < u.R) { pv[g] = ld_stream(u.p + o); gv[g] = ld_stream(u.g + o); mv[g] = ld_stream(u.m + o); vv[g] = ld_stream(u.v + o); }
     else pv[g] = gv[g] = mv[g] = vv[g] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const float ss = sum_partials(u.part, EVC_SQN_BLOCKS);
@@ -138,10 +156,14 @@ __global__ __launch_bounds__(256) void lstm_adam_fused_kernel(LstmAdamParams u) 
     const long row = row_of(g);
     if (!okc || row >= u.R) continue;
     const long o = row * u.C + col;
-    *(float4*)(u.m + o) = make_float4(mn[0], mn[1], mn[2], mn[3]);
-    *(float4*)(u.v + o) = make_float4(vn[0], vn[1], vn[2], vn[3]);
-    *(float4*)(u.p + o) = make_float4(pn[0], pn[1], pn[2], pn[3]);
+    st_stream(u.m + o, mn[0], mn[1], mn[2], mn[3]);
+    st_stream(u.v + o, vn[0], vn[1], vn[2], vn[3]);
+    st_stream(u.p + o, pn[0], pn[1], pn[2], pn[3]);
+#if EVC_ADAM_NT >= 2
+    __builtin_nontemporal_store(u32x2_t{pbits[g][0], pbits[g][1]}, (u32x2_t*)(u.p_bf16 + o));
+#else
     *(uint2*)(u.p_bf16 + o) = make_uint2(pbits[g][0], pbits[g][1]);
+#endif
     if (u.p16 || u.p8) {
       const uint32_t h01 = pack_f16x2_hw(pn[0], pn[1]), h23 = pack_f16x2_hw(pn[2], pn[3]);
       const float hf[4] = {f16_to_f32((f16_t)(h01 & 0xffffu)), f16_to_f32((f16_t)(h01 >> 16)), f16_to_f32((f16_t)(h23 & 0xffffu)), f16_to_f32((f16_t)(h23 >> 16))};
@@ -201,8 +223,13 @@ __global__ __launch_bounds__(256) void lstm_adam_fused_kernel(LstmAdamParams u) 
   if (k0 + kk < u.C) {
     const uint4 q0 = *(const uint4*)&tile[kk][part4 * 16], q1 = *(const uint4*)&tile[kk][part4 * 16 + 8];
     bf16_t* dst = u.pT + (long)(k0 + kk) * u.ldT + (IL ? (long)u0 * 4 : (long)tr * 64) + part4 * 16;
+#if EVC_ADAM_NT >= 2
+    __builtin_nontemporal_store(u32x4_t{q0.x, q0.y, q0.z, q0.w}, (u32x4_t*)dst);
+    __builtin_nontemporal_store(u32x4_t{q1.x, q1.y, q1.z, q1.w}, (u32x4_t*)(dst + 8));
+#else
     *(uint4*)dst = q0;
     *(uint4*)(dst + 8) = q1;
+#endif
   }
 }
 
