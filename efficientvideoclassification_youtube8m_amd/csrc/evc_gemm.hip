@@ -30,7 +30,13 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_nt_kernel(GemmOperands p, StoreP
   // loop options (gemm_core_v2.h): producer waves + LDS-DMA first + no priority flips for every ring tile but the 320-row one
   // (same box: L1 dX 477 -> 431 us, 1280 x 4096 x 4096 63 -> 56.5 us, MoE gates forward 48.3 -> 46 us; 5120 x 4096 x 4096 on
   // the 320-row tile 153 -> 162 us with them)
-  constexpr int NT_MODE = (Cfg::BM == 320 ? 0 : (LOOP_PRODUCER | LOOP_DMA_FIRST | LOOP_NO_PRIO)) | (F16 ? LOOP_F16 : 0) | (FP8 ? LOOP_FP8_TAIL : 0);
+#ifndef EVC_TALL_B_NT
+#define EVC_TALL_B_NT 1      // the weight rows of the batch-row products (256 x 64 tiles: every weight row is read by ONE workgroup) as non-temporal LDS-DMA loads
+                             // (round 5; same box, alternated three times: the MoE gates product ALONE 42.9 -> 49.3 us, the training step 9.96 -> 9.92 ms -
+                             // 193 MB of weights per product no longer evict what the other streams' kernels re-read; 0 = default policy)
+#endif
+  constexpr int NT_MODE = (Cfg::BM == 320 ? 0 : (LOOP_PRODUCER | LOOP_DMA_FIRST | LOOP_NO_PRIO)) | (F16 ? LOOP_F16 : 0) | (FP8 ? LOOP_FP8_TAIL : 0) |
+                          ((EVC_TALL_B_NT && is_v3<Cfg>::value && Cfg::BM == 256 && Cfg::BU == 64) ? LOOP_B_NT : 0);
   run_mainloop<Cfg, Cfg::G, V2, true, NT_MODE>(p, m0, u0, acc);     // ring tiles: transposed accumulators (lane = one row, 4 consecutive columns)
   if constexpr (V2) {
     // plain overwrite with 16-byte-aligned rows, or the split-K join: through LDS (kernel-uniform conditions: one barrier)

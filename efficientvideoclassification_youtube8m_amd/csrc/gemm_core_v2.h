@@ -35,6 +35,9 @@ constexpr int LOOP_PRODUCER = 1, LOOP_DMA_FIRST = 2, LOOP_NO_PRIO = 4, LOOP_F16 
 //                 line of this workgroup's SHARE of the operand panels of a stage a few trips ahead (a 4-byte LDS-DMA into the sink: no destination
 //                 register), so that the producers' refill of that stage finds its lines in the XCD's L2 instead of waiting for the Infinity Cache / HBM
 constexpr int LOOP_PREFETCH = 32;
+//  LOOP_B_NT      (v3 loop) the B operand's LDS-DMA loads are non-temporal: for products whose B rows are read by ONE workgroup each (the batch-row
+//                 products, M <= 256: one row tile) - the weight matrix streams through the chip once and should not evict what the others re-read
+constexpr int LOOP_B_NT = 64;
 #ifndef EVC_LOOP_MODE_DEFAULT
 #define EVC_LOOP_MODE_DEFAULT 0
 #endif

@@ -178,7 +178,7 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
       char* dst = b_dst[i] >= 0 ? sbase + b_dst[i] : lds + Cfg::DUMMY_OFF;
       const uint32_t vo = FP8 ? __umul24(b_vo[i], ldb_b) + chunk_b : b_vo[i];
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_base + vo),
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, EVC_V3_AUX_B);
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, (MODE & LOOP_B_NT) ? 2 : EVC_V3_AUX_B);
     }
     ++ks_issue;
     slot_issue = (slot_issue + 1 == Cfg::STAGES) ? 0 : slot_issue + 1;
