@@ -1629,12 +1629,19 @@ extern "C" int evc_framepool_max_bwd(const float* dpooled, const int32_t* argmax
   return EVC_OK;
 }
 
+#ifndef EVC_FILL_NT
+#define EVC_FILL_NT 0
+#endif
 __global__ void fill_kernel(float* p, long n, float v) {
   const long stride = (long)gridDim.x * blockDim.x, tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if ((((uintptr_t)p) & 15) == 0) {      // 16-byte stores over the aligned body, scalar tail
     const long n4 = n >> 2;
     const float4 v4 = make_float4(v, v, v, v);
+#if EVC_FILL_NT      // (A/B: the zero fills of the gradient buffers - 372 MB per step, next touched by the split-K atomics - as non-temporal stores)
+    for (long i = tid; i < n4; i += stride) __builtin_nontemporal_store(f32x4{v, v, v, v}, (f32x4*)p + i);
+#else
     for (long i = tid; i < n4; i += stride) ((float4*)p)[i] = v4;
+#endif
     for (long i = (n4 << 2) + tid; i < n; i += stride) p[i] = v;
   } else {
     for (long i = tid; i < n; i += stride) p[i] = v;
