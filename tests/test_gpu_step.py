@@ -1,5 +1,7 @@
 """End-to-end parity of the teacher+student training iteration (through the
 C ABI) against the float64 numpy oracle.  pytest -m gpu."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -592,6 +594,46 @@ def test_fused_moe_update_writes_the_forward_operand_images_in_high_precision(H)
         tw.set_precision("bf16")
         for k in (tw.GATES, tw.EXPERTS):
             assert torch.equal(tw.shadow_fwd[k], tw.store.p(k).bfloat16())
+
+
+def test_high_precision_dithered_layer_images_follow_the_weights():
+    """"high" precision at dims where the L1 level runs on f16 + e4m3 stages (F, H multiples of 128, >= 384): by default the TOP layer of the
+    teacher's L1 level contracts time-dithered weight images (engine.HLstmTower.dither_layers) - 15 images of its kernel, rebuilt behind every
+    update (evc_lstm_adam_fused + evc_cast_f32_to_f16_dither) and on load_state_dict.  After two training iterations they must be the oracle's
+    images of the NEW master weights, bit for bit (oracle/lowprec.py::f16_dither_images); layer 0 keeps its f16 + e4m3 images; the student
+    (plain f16 on its short chunks) has none; the resolved layout names the dithered layer; a dithered layer BELOW a corrected one is refused."""
+    from oracle import lowprec as lp
+    from efficientvideoclassification_youtube8m_amd import ops
+    from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
+    B, F, V, H = 8, 384, 100, 384
+    q, x, n, labels = mm.synthetic_batch(B, seed=35, feature_size=F, vocab_size=V, dtype=np.float32)
+    xd, nd, yd = torch.from_numpy(q).to(DEV), torch.from_numpy(n).to(DEV), torch.from_numpy(labels.astype(np.uint8)).to(DEV)
+    g = DistillGraph(B, every_n=10, feature_size=F, vocab_size=V, lstm_cells=H, device=DEV, seed=4, precision="high")
+    tw = g.teacher
+    if "EVC_HIGH_DITHER_LAYERS" in os.environ:
+        pytest.skip("the default layout is under test")
+    assert tw.fp8_lo() and tw.dither_layers() == (1,) and g.student.dither_layers() == ()
+    assert "layers [1] on 15 time-dithered" in tw.precision_layout()["l1"]
+    k0, k1 = (k for k in tw.names if k.startswith("RNN_L1/") and k.endswith("kernel"))
+    assert set(tw.shadow16d) == {k1} and k0 in tw.shadow16 and k0 in tw.shadow8 and k1 not in tw.shadow8
+    out = None
+    for _ in range(2):
+        out = g.step(xd, yd, nd, num_frames_host=n)
+    torch.cuda.synchronize()
+    p1 = tw.store.p(k1)
+    want = lp.f16_dither_images(p1.cpu().numpy(), tw.l1_steps(), tw.dither_seed(k1))
+    assert np.array_equal(tw.shadow16d[k1].cpu().numpy().view(np.uint16), want.view(np.uint16))
+    assert torch.equal(tw.shadow16[k0], tw.store.p(k0).half())
+    sd = tw.state_dict()
+    tw.shadow16d[k1].zero_()
+    tw.load_state_dict(sd)
+    torch.cuda.synchronize()
+    assert np.array_equal(tw.shadow16d[k1].cpu().numpy().view(np.uint16), want.view(np.uint16))
+    assert all(np.isfinite(v) for v in g.loss_report().values())
+    with pytest.raises(ValueError):                     # a dithered layer below a corrected one: refused
+        tw.f16_dither_layers = (0,)
+        tw.dither_layers()
+    tw.f16_dither_layers = None
 
 
 def test_moe_update_in_two_phases_on_row_slabs_equals_the_whole():
