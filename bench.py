@@ -674,7 +674,7 @@ def main():
                               "frames), L2 level wavefront pair launches (evc_lstm_stack2_fwd_f16_fp8lo), MoE head (evc_gemm_nt_f16_fp8: both operands' "
                               "corrections); the teacher's UPPER L1 layer on time-dithered f16 weight images instead of its weights' low-order halves "
                               "(evc_lstm_layer_fwd_f16_dith: image t of evc_cast_f32_to_f16_dither at step t - the weight rounding errors cancel over the "
-                              "steps of a chunk; EVC_HIGH_DITHER_LAYERS, DESIGN.md 7: teacher logits 2.65e-4 mean / 6.3e-4 max over 36 weight draws; EVC_HIGH_DITHER_LAYERS= for the fully corrected layout: 2.2e-4 / 4.3e-4 at 1.21x); "
+                              "steps of a chunk; EVC_HIGH_DITHER_LAYERS, DESIGN.md 7: teacher logits 2.65e-4 mean / 6.3e-4 max over 36 weight draws; EVC_HIGH_DITHER_LAYERS= for the fully corrected layout: 2.65e-4 / 6.1e-4 over 34 draws at 1.21x); "
                               "student tower's L1 level plain f16; all other operand images written by the optimizer kernels' epilogues "
                               "(evc_lstm_adam_fused, evc_moe_grad_update_apply); backward products bf16 as in the bf16 mode")
         pm["high"]["layout"] = r.get("high_layout") if other == "high" else head.get("high_layout")

@@ -1140,8 +1140,8 @@ class HLstmTower(TowerBase):
     # halves above); dithered over the steps it largely cancels, and a dithered layer needs no stages for its weights' low-order halves
     # (layer 1 of the teacher: 32 ring stages per step instead of 32 + 16; layer 0: 34 + 9 - the input's low-order half - instead of 34 + 26).
     # Costs T images per dithered kernel (15 x 17 MB per teacher layer) and one pass over them per update.  What it buys and what it costs in
-    # accuracy is measured over weight draws in DESIGN.md 7 (12 draws each, teacher logits x 1e-4, real kernels): no layer dithered mean 2.1-2.3 /
-    # max 3.6-4.3 at 1.21x the bf16 step; the TOP layer dithered (default) 2.65 / 6.3 over 36 draws at 1.18x; both layers 4.1 / 8.3 at 1.16x - too close to
+    # accuracy is measured over weight draws in DESIGN.md 7 (12 draws each, teacher logits x 1e-4, real kernels): no layer dithered mean 2.65 /
+    # max 6.1 over 34 draws at 1.21x the bf16 step; the TOP layer dithered (default) 2.65 / 6.3 over 36 draws at 1.18x; both layers 4.1 / 8.3 at 1.16x - too close to
     # the 1e-3 the mode exists for.  EVC_HIGH_DITHER_LAYERS = comma list of L1 layers (a SUFFIX of the stack: a layer on e4m3 low-order
     # halves reads the e4m3 image of h from the layer below, which a dithered layer does not write); "" = none (rounds 3-5).
     # Unset: the TOP layer of a level of two or more layers.
