@@ -449,10 +449,11 @@ __device__ __forceinline__ uint32_t fmix32_(uint32_t h) {
   return h;
 }
 __global__ __launch_bounds__(256) void cast_f16_dither_kernel(const float* __restrict__ in, long n4, int T, long img_stride, uint32_t seed_mix,
-                                                              f16_t* __restrict__ out) {
+                                                              f16_t* __restrict__ out, long row_len, long col0) {
   for (long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += (long)gridDim.x * blockDim.x) {
     const float4 f = ((const float4*)in)[i4];
     const float w[4] = {f.x, f.y, f.z, f.w};
+    const bool plain = row_len > 0 && (i4 * 4) % row_len < col0;      // columns below col0: the round-to-nearest image in every step (row_len, col0 multiples of 4)
     uint32_t dn[4], up[4], thr[4], ph[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -461,8 +462,8 @@ __global__ __launch_bounds__(256) void cast_f16_dither_kernel(const float* __res
       const bool zero = (hb & 0x7fffu) == 0, neg = (hb & 0x8000u) != 0;
       const uint32_t below = zero ? 0x8001u : (neg ? hb + 1u : hb - 1u);      // next f16 towards -inf
       const uint32_t above = zero ? 0x0001u : (neg ? hb - 1u : hb + 1u);      // next f16 towards +inf
-      dn[r] = hf > w[r] ? below : hb;
-      up[r] = hf < w[r] ? above : hb;
+      dn[r] = (hf > w[r] && !plain) ? below : hb;
+      up[r] = (hf < w[r] && !plain) ? above : hb;
       const float dnf = f16_to_f32((f16_t)dn[r]), gap = f16_to_f32((f16_t)up[r]) - dnf;
       const float frac = gap > 0.f ? (w[r] - dnf) / gap : 0.f;                // exact: the numerator is exact, the gap a power of two (or inf: 0)
       thr[r] = (uint32_t)fminf(frac * 4294967296.0f, 4294967040.0f);
@@ -478,13 +479,17 @@ __global__ __launch_bounds__(256) void cast_f16_dither_kernel(const float* __res
     }
   }
 }
-extern "C" int evc_cast_f32_to_f16_dither(const float* in, int64_t n, int T, int64_t img_stride, uint32_t seed, evc_f16* out, void* stream) {
+extern "C" int evc_cast_f32_to_f16_dither(const float* in, int64_t n, int T, int64_t img_stride, uint32_t seed, evc_f16* out, int64_t row_len, int64_t col0,
+                                          void* stream) {
   EVC_REQUIRE(in && out && n > 0 && n % 4 == 0 && n < (1LL << 32) && T >= 1 && T <= 4096, EVC_ERR_BAD_SHAPE, "evc_cast_f32_to_f16_dither: n=%ld (%%4, < 2^32) T=%d", (long)n, T);
+  EVC_REQUIRE(row_len >= 0 && col0 >= 0 && (row_len == 0 ? col0 == 0 : (row_len % 4 == 0 && col0 % 4 == 0 && col0 <= row_len && n % row_len == 0)), EVC_ERR_BAD_ARG,
+              "evc_cast_f32_to_f16_dither: row_len=%ld col0=%ld (multiples of 4, col0 <= row_len, n a multiple of row_len; 0, 0: every element dithered)", (long)row_len, (long)col0);
   EVC_REQUIRE(img_stride >= n && img_stride % 4 == 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 8) == 0, EVC_ERR_BAD_ALIGN,
               "evc_cast_f32_to_f16_dither: img_stride=%ld (>= n, %%4), in 16-byte, out 8-byte aligned", (long)img_stride);
   const long n4 = n / 4;
   const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
-  hipLaunchKernelGGL(cast_f16_dither_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, n4, T, (long)img_stride, seed * 0x9E3779B9u, (f16_t*)out);
+  hipLaunchKernelGGL(cast_f16_dither_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, n4, T, (long)img_stride, seed * 0x9E3779B9u, (f16_t*)out,
+                     (long)row_len, (long)col0);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
 }

@@ -214,7 +214,8 @@ class LstmStack:
                 #    t, whose rounding errors cancel over the steps of a chunk - no stages for the weights' low-order halves (layer 0 keeps the
                 #    input's: the e4m3(x_lo 2^18) bytes against the e4m3(Wx 2^6) block of cast_fp8_lo's rows); plain f16 h rows.
                 dl = tw.dither_layers()
-                widths = [H if l in dl else 3 * H // 2 for l in range(L)]        # halfwords per h row
+                wh0 = tw.dither_wh0()                                             # layer 0: recurrent block dithered, input block corrected
+                widths = [H if (l in dl or (l == 0 and wh0)) else 3 * H // 2 for l in range(L)]        # halfwords per h row
                 if getattr(self, "_hbuf16_widths", None) != widths:
                     self.hbuf16 = [torch.zeros((self.T + 1, self.M, widths[l]), dtype=ops.F16, device=self.hbuf[l].device) for l in range(L)]
                     self._hbuf16_widths = widths
@@ -226,7 +227,13 @@ class LstmStack:
                     if self.timing is not None:
                         e0 = torch.cuda.Event(enable_timing=True)
                         e0.record()
-                    if l in dl:
+                    if l == 0 and wh0 and 0 not in dl:
+                        # [x | h] . W16_t^T with only Wh dithered + [e4m3(x) | e4m3(x_lo)] . [lo(Wx) | e4m3(Wx 2^6)]^T: the first 2 Kin bytes of cast_fp8_lo's rows
+                        assert tw.shadow16d[kn].shape[0] >= T
+                        ops.lstm_layer_fwd_f16_dith(inp, ldx, kx16, 2 * self.Kin, 2 * self.Kin, tw.shadow16d[kn], tw.shadow8[kn], tw.shadow8[kn].stride(0),
+                                                    7 + ops.FP8_W_SCALE_EXP, tw.store.p(bn), lens, T, M, H, h16[l], hb[l],
+                                                    self.S[:, (2 * l) * H:], self.S[:, (2 * l + 1) * H:], 2 * L * H, gates[l], c_all[l], plan=plan)
+                    elif l in dl:
                         assert tw.shadow16d[kn].shape[0] >= T
                         w8 = tw.shadow8[kn][:, self.Kin:2 * self.Kin] if l == 0 else None      # the e4m3(Wx 2^6) block of [lo(Wx) | hi(Wx) | lo(Wh)] rows
                         ops.lstm_layer_fwd_f16_dith(inp, ldx, kx16, 3 * self.Kin if l == 0 else 0, self.Kin if l == 0 else 0, tw.shadow16d[kn], w8,
@@ -1159,6 +1166,18 @@ class HLstmTower(TowerBase):
             raise ValueError("EVC_HIGH_DITHER_LAYERS=%r: the dithered L1 layers must be the top layers of the stack (a suffix of 0..%d)" % (list(dl), self.L - 1))
         return dl
 
+    # ... and layer 0's RECURRENT block as well (its input block keeps the e4m3 corrections of Wx and of the input frames - the one block whose
+    # dithering costs accuracy): 34 + 18 stages instead of 34 + 26.  Needs every layer above dithered (layer 0 then writes plain h rows).
+    f16_dither_wh0 = os.environ.get("EVC_HIGH_DITHER_WH0", "0") == "1"
+
+    def dither_wh0(self):
+        return bool(self.f16_dither_wh0 and self.L >= 2 and self.fp8_lo() and self.dither_layers() == tuple(range(1, self.L)))
+
+    def dither_col0(self, k):
+        """First dithered column of L1 kernel k's images: the recurrent block only for layer 0 under dither_wh0(), else every column."""
+        layer = int(k.split("cell_")[1].split("/")[0])
+        return (self.store.shapes[k][1] - self.H) if (layer == 0 and 0 not in self.dither_layers()) else 0
+
     def l1_steps(self):
         return self.T // self.C
 
@@ -1175,7 +1194,7 @@ class HLstmTower(TowerBase):
         for k, shp in self.store.shapes.items():
             if len(shp) != 2:
                 continue
-            if k.startswith("RNN_L1/") and int(k.split("cell_")[1].split("/")[0]) in self.dither_layers():
+            if k.startswith("RNN_L1/") and (int(k.split("cell_")[1].split("/")[0]) in self.dither_layers() or (self.dither_wh0() and "cell_0/" in k)):
                 # T time-dithered f16 images; layer 0 also keeps cast_fp8_lo's [lo(Wx) | e4m3(Wx 2^6) | lo(Wh)] rows for their middle block
                 nin = shp[1] - H
                 layer = int(k.split("cell_")[1].split("/")[0])
@@ -1222,7 +1241,7 @@ class HLstmTower(TowerBase):
             ops.cast_f16(p, self.shadow_w16[k])
             ops.cast_fp8_lo(p, self.shadow_w8[k], hi_cols=p.shape[1], scale_exp=ops.FP8_MOE["w_lo_exp"], hi_exp=ops.FP8_MOE["w_hi_exp"])
         elif k in self.shadow16d:            # L1 level, time-dithered f16 images (layer 0: + cast_fp8_lo's rows for the e4m3(Wx 2^6) block)
-            ops.cast_f16_dither(p, self.shadow16d[k], self.dither_seed(k))
+            ops.cast_f16_dither(p, self.shadow16d[k], self.dither_seed(k), col0=self.dither_col0(k))
             if k in self.shadow8:
                 ops.cast_fp8_lo(p, self.shadow8[k], hi_cols=self.shadow8[k].shape[1] - p.shape[1])
         elif k in self.shadow8 and k.startswith("RNN_L2/"):     # L2 level, fp8 low-order halves
@@ -1261,7 +1280,8 @@ class HLstmTower(TowerBase):
         d = {"precision": self.precision}
         if self.precision == "high":
             d.update(l1=("f16 + e4m3 low-order halves (weights, input frames)" + ("; layers %s on %d time-dithered f16 weight images instead of their weights' low-order halves"
-                                                                                   % (list(self.dither_layers()), self.l1_steps()) if self.dither_layers() else "")) if self.fp8_lo() else
+                                                                                   % (list(self.dither_layers()), self.l1_steps()) if self.dither_layers() else "")
+                         + ("; layer 0's recurrent block dithered too" if self.dither_wh0() else "")) if self.fp8_lo() else
                      "f16, x segments %d, Wh extended in layers %s, Wx extended in layers %s" % (self.f16_x_segments, list(self.f16_wh_ext_layers), list(self.f16_wx_ext_layers)),
                      l2=("f16 + e4m3 low-order halves, %d input segments" % self.f16_l2_x_segments) if any(k.startswith("RNN_L2/") for k in getattr(self, "shadow8", {}))
                      else ("f16 K-extensions, %d input segments, h0_ext %s" % (self.f16_l2_x_segments, self.f16_l2_h0_ext) if self.L == 2 else "split-bf16"),
@@ -1318,7 +1338,7 @@ class HLstmTower(TowerBase):
 
     def _after_fused_adam(self, k):
         if k in getattr(self, "shadow16d", {}):
-            ops.cast_f16_dither(self.store.p(k), self.shadow16d[k], self.dither_seed(k))
+            ops.cast_f16_dither(self.store.p(k), self.shadow16d[k], self.dither_seed(k), col0=self.dither_col0(k))
 
     # ---- parameters -------------------------------------------------------
     def _init_params(self, seed):

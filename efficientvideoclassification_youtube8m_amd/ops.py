@@ -396,10 +396,13 @@ def lstm_layer_fwd_f16_dith(x16, ldx, kx16, x8_off, kx8, wT16_steps, wT8, ldb8, 
               _p(hbuf16), _p(hbuf_bf), _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_all), *_plan_args(plan), _stream())
 
 
-def cast_f16_dither(p, out, seed):
-    """out [T][...p.shape] f16: the T time-dithered f16 images of the f32 tensor p (evc_cast_f32_to_f16_dither; oracle/lowprec.py::f16_dither_images)."""
+def cast_f16_dither(p, out, seed, col0=0):
+    """out [T][...p.shape] f16: the T time-dithered f16 images of the f32 tensor p (evc_cast_f32_to_f16_dither; oracle/lowprec.py::f16_dither_images).
+    col0 > 0 (p 2-D): only the columns from col0 on are dithered, the others hold their round-to-nearest value in every image."""
     assert p.dtype == F32 and p.is_contiguous() and out.dtype == F16 and out.is_contiguous() and out.shape[1:] == p.shape
-    _lib.call("evc_cast_f32_to_f16_dither", _p(p), p.numel(), out.shape[0], out.stride(0) if out.shape[0] > 1 else p.numel(), int(seed) & 0xFFFFFFFF, _p(out), _stream())
+    assert col0 == 0 or (p.dim() == 2 and 0 < col0 <= p.shape[1])
+    _lib.call("evc_cast_f32_to_f16_dither", _p(p), p.numel(), out.shape[0], out.stride(0) if out.shape[0] > 1 else p.numel(), int(seed) & 0xFFFFFFFF, _p(out),
+              p.shape[1] if col0 else 0, col0, _stream())
 
 
 def lstm_level2_fwd(x, wT0, bias0, wT1, bias1, lens, T, M, Kin, H, hbuf0, hbuf1, S, gates=(None, None), c_all=(None, None), plan=None):

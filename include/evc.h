@@ -363,8 +363,11 @@ int evc_cast_f32_to_f16(const float* in, int64_t ld_in, int R, int C, evc_f16* o
  * image t of element i = up if (uint32)(fmix32(i ^ seed * 0x9E3779B9) + t * 0x9E3779B9) < frac * 2^32 else dn, with dn <= in[i] <= up its
  * two f16 neighbours (equal when in[i] is an f16 value), frac = (in[i] - dn) / (up - dn), fmix32 = murmur3's finaliser: over any run of r
  * images an element is rounded up r * frac times +- a few (2.03 measured over every run inside 20 steps) (golden-ratio rotation of a per-element phase).  The operand of
- * evc_lstm_layer_fwd_f16_dith; restated bit for bit by oracle/lowprec.py::f16_dither_images. */
-int evc_cast_f32_to_f16_dither(const float* in, int64_t n, int T, int64_t img_stride, uint32_t seed, evc_f16* out, void* stream);
+ * evc_lstm_layer_fwd_f16_dith; restated bit for bit by oracle/lowprec.py::f16_dither_images.  row_len > 0: the values are rows of row_len elements and
+ * only the columns from col0 on are dithered - the others hold their round-to-nearest f16 value in every image (a kernel whose input block keeps
+ * its e4m3 correction while its recurrent block is dithered); 0, 0: every element. */
+int evc_cast_f32_to_f16_dither(const float* in, int64_t n, int T, int64_t img_stride, uint32_t seed, evc_f16* out, int64_t row_len, int64_t col0,
+                               void* stream);
 /* f16 image of an LSTM kernel [R][Kin+H] (f32, row stride ld_in) for a K-extended x-part: out [R][nseg*Kin + H] =
  * [f16(Wx) | f16(Wx)/64 | (Wx - f16(Wx))*64 | f16(Wh) | (Wh - f16(Wh))*64] keeping the first nseg (1..3) x blocks and, with
  * h_ext = 1, the low-order block of the h-part (evc_lstm_layer_fwd_f16 with h_wide = 1). */

@@ -173,10 +173,16 @@ def f16_dither_threshold(w):
     return np.minimum(frac * np.float32(4294967296.0), np.float32(4294967040.0)).astype(np.uint32)
 
 
-def f16_dither_images(w, T, seed=0):
-    """w [...] float32 -> float16 [T, ...]: image t of element i (flat row-major index) = up if uint32(fmix32(i ^ seed * PHI32) + t * PHI32) < thr else dn."""
+def f16_dither_images(w, T, seed=0, col0=0):
+    """w [...] float32 -> float16 [T, ...]: image t of element i (flat row-major index) = up if uint32(fmix32(i ^ seed * PHI32) + t * PHI32) < thr else dn.
+    col0 > 0 (w 2-D): the columns below col0 hold their round-to-nearest f16 value in every image."""
     w32 = np.ascontiguousarray(np.asarray(w, np.float32))
     dn, up = f16_neighbours(w32)
+    if col0:
+        rtn = w32.astype(np.float16)
+        dn, up = dn.copy(), up.copy()
+        dn[:, :col0] = rtn[:, :col0]
+        up[:, :col0] = rtn[:, :col0]
     thr = f16_dither_threshold(w32).reshape(-1)
     idx = np.arange(w32.size, dtype=np.uint32)
     with np.errstate(over="ignore"):

@@ -408,6 +408,8 @@ def main():
             ("DITH FZD1L2 L1 layer 1 + L2 layer 1 dithered, the rest fp8-corrected", dict(exact, L1c0=dict(ax="f16+8", ah="f16", wx="f16+8", wh="f16+8"),
                                                                        L1c1=dict(ax="f16", ah="f16", wx="f16d", wh="f16d"),
                                                                        L2c0=dict(ax="x3", ah="f16", wx="x3", wh="x3"), L2c1=dict(ax="f16", ah="f16", wx="f16d", wh="f16d"))),
+            ("DITH FZD3 layer 1 + layer 0's Wh dithered, Wx0 + x_lo fp8-corrected | shipped L2", dict(exact, L1c0=dict(ax="f16+8", ah="f16", wx="f16+8", wh="f16d"),
+                                                                       L1c1=dict(ax="f16", ah="f16", wx="f16d", wh="f16d"), **l2_f16x)),
             ("DITH A8 L1 W RTN uncorrected, x_lo fp8 | shipped L2", dict(exact, L1c0=dict(ax="f16+8", ah="f16", wx="f16", wh="f16"),
                                                                        L1c1="f16", **l2_f16x)),
             ("DBG6 c0 wx", dict(exact, L1c0=dict(ex, wx="f16+6"))), ("DBG6 c0 wh", dict(exact, L1c0=dict(ex, wh="f16+6"))), ("DBG6 c1 wx", dict(exact, L1c1=dict(ex, wx="f16+6"))), ("DBG6 c1 wh", dict(exact, L1c1=dict(ex, wh="f16+6"))),

@@ -637,10 +637,16 @@ def test_f16_dither_images_equal_the_oracle_bit_for_bit(ops):
         got = out.cpu().numpy()
         assert np.array_equal(got.view(np.uint16), ref.view(np.uint16)), (T, seed, int((got.view(np.uint16) != ref.view(np.uint16)).sum()))
     pad = torch.full((4, w.size + 64), float("nan"), dtype=torch.float16, device=DEV)      # images 8 rows apart: the pad stays untouched
-    ops._lib.call("evc_cast_f32_to_f16_dither", wd.data_ptr(), w.size, 4, pad.stride(0), 3, pad.data_ptr(), ops._stream())
+    ops._lib.call("evc_cast_f32_to_f16_dither", wd.data_ptr(), w.size, 4, pad.stride(0), 3, pad.data_ptr(), 0, 0, ops._stream())
     got = pad.cpu().numpy()
     assert np.array_equal(got[:, :w.size].reshape((4,) + w.shape).view(np.uint16), lp.f16_dither_images(w, 4, 3).view(np.uint16))
     assert np.isnan(got[:, w.size:].astype(np.float32)).all()
+    # only the columns from col0 on dithered (a kernel whose input block keeps its correction): the others are the round-to-nearest image in every step
+    out = torch.full((5,) + w.shape, float("nan"), dtype=torch.float16, device=DEV)
+    ops.cast_f16_dither(wd, out, 2, col0=128)
+    got = out.cpu().numpy()
+    assert np.array_equal(got.view(np.uint16), lp.f16_dither_images(w, 5, 2, col0=128).view(np.uint16))
+    assert np.array_equal(got[:, :, :128].view(np.uint16), np.broadcast_to(w.astype(np.float16)[None, :, :128], (5, 260, 128)).view(np.uint16))
 
 
 @pytest.mark.parametrize("M,T,Kin,H,tile", [(512, 4, 384, 384, 0), (1100, 15, 1152, 512, 0), (700, 5, 384, 384, 6), (390, 3, 512, 384, 7), (730, 6, 384, 384, 11)])
