@@ -518,3 +518,32 @@ def test_sharded_update_collectives_world_4_with_an_empty_rank(tmp_path):
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stdout.count("-ok") == 4, r.stdout
+
+
+def test_high_precision_dither_layer_selection_rules():
+    """engine.HLstmTower.dither_layers / dither_wh0 / dither_col0 (host logic, no GPU): unset -> the TOP layer of an L1 level of two or more
+    layers; an explicit list must be a suffix of the stack (a corrected layer reads the e4m3 image of h that a dithered layer below it does
+    not write); nothing when the level is not the f16 + e4m3 one (small dims, the student's plain f16); layer 0's recurrent block only with
+    every layer above dithered, and then its images dither the columns from the input width on."""
+    import types
+    from efficientvideoclassification_youtube8m_amd.engine import HLstmTower
+
+    def tower(L, layers=None, fp8=True, wh0=False, nin=1152, H=1024):
+        t = types.SimpleNamespace(L=L, H=H, f16_dither_layers=layers, f16_dither_wh0=wh0, fp8_lo=lambda: fp8)
+        t.store = types.SimpleNamespace(shapes={"RNN_L1/rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/kernel" % l: (4 * H, (nin if l == 0 else H) + H) for l in range(L)})
+        for name in ("dither_layers", "dither_wh0", "dither_col0"):
+            setattr(t, name, types.MethodType(getattr(HLstmTower, name), t))
+        return t
+
+    assert tower(2).dither_layers() == (1,) and tower(3).dither_layers() == (2,) and tower(1).dither_layers() == ()
+    assert tower(2, fp8=False).dither_layers() == () and tower(2, layers=()).dither_layers() == ()
+    assert tower(2, layers=(0, 1)).dither_layers() == (0, 1) and tower(3, layers=(1, 2)).dither_layers() == (1, 2)
+    assert tower(2, layers=(1, 7)).dither_layers() == (1,)                       # layers the stack does not have are ignored
+    for bad in ((0,), (0, 2)):
+        with pytest.raises(ValueError):
+            tower(3, layers=bad).dither_layers()
+    k0, k1 = "RNN_L1/rnn/multi_rnn_cell/cell_0/basic_lstm_cell/kernel", "RNN_L1/rnn/multi_rnn_cell/cell_1/basic_lstm_cell/kernel"
+    t = tower(2, wh0=True)
+    assert t.dither_wh0() and t.dither_col0(k0) == 1152 and t.dither_col0(k1) == 0
+    assert not tower(2, wh0=True, layers=()).dither_wh0() and not tower(1, wh0=True).dither_wh0() and not tower(2, wh0=True, fp8=False).dither_wh0()
+    assert tower(2, layers=(0, 1), wh0=True).dither_col0(k0) == 0                # every column when layer 0 itself is dithered
