@@ -40,6 +40,9 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 // ---------------------------------------------------------------------------
 // a1 + a2: l2-normalise, sub-sample, cast, re-layout.  One wave per frame.
 // ---------------------------------------------------------------------------
+#ifndef EVC_INPUT_NT
+#define EVC_INPUT_NT 0
+#endif
 template <bool U8>
 __global__ __launch_bounds__(256) void l2norm_chunk_kernel(const float* __restrict__ x, const uint8_t* __restrict__ xq,
                                                            const int* __restrict__ nfr, int B, int T, int F, int C1,
@@ -85,7 +88,12 @@ __global__ __launch_bounds__(256) void l2norm_chunk_kernel(const float* __restri
           v[i] = make_float4(q.x * sc + bs, q.y * sc + bs, q.z * sc + bs, q.w * sc + bs);
         }
       } else {
+#if EVC_INPUT_NT       // (A/B: the f32 frame tensor - 354 MB at the headline's batch, read once at the head of every step - as non-temporal loads)
+        const f32x4 t4 = __builtin_nontemporal_load((const f32x4*)(x + row * F) + j);
+        v[i] = make_float4(t4[0], t4[1], t4[2], t4[3]);
+#else
         v[i] = ((const float4*)(x + row * F))[j];
+#endif
       }
       ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
     }
