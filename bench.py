@@ -47,18 +47,21 @@ PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MI
 T_FRAMES, F_FEAT, V_CLS, H_CELLS = 300, 1152, 4716, 1024
 
 
-def step_stats(per_step_ms, wall_ms_per_step=None):
+def step_stats(per_step_ms, wall_ms_per_step=None, span_ms_per_step=None):
     """Robust companions of the mean: median and maximum of the per-step times and a flag for a window that contains a stall
     (one step > 3 x the median: e.g. the ~30-65 ms the driver's unmapping work can hold the queue right after tens of GB were
     freed - such a step moves the mean of a 20-step window of 2 ms steps by 2x and says nothing about the kernels; or the wall-clock
-    mean more than 5 % above the mean of the per-step event times: time lost before the first or behind the last step's event -
-    seen once as +4 ms behind a 20-step window of the cfg-4 high run)."""
+    mean more than 5 % above the event span: time lost before the first or behind the last event - seen once as +4 ms behind a
+    20-step window of the cfg-4 high run).  span_ms_per_step = (event after the window's LAST enqueued work, i.e. after graph.flush() -
+    first event) / steps: the deferred updates of the last step sit behind the last per-step event by design and are not a stall;
+    wall_ms_per_step is this rank's own wall clock (before the MAX over the ranks)."""
     a = sorted(float(v) for v in per_step_ms)
     if not a:
         return {"ms_per_step_median": None, "ms_per_step_max": None, "stall_suspected": False}
     n = len(a)
     med = a[n // 2] if n % 2 else 0.5 * (a[n // 2 - 1] + a[n // 2])
-    stall = a[-1] > 3.0 * med or (wall_ms_per_step is not None and wall_ms_per_step > 1.05 * (sum(a) / n))
+    ref = span_ms_per_step if span_ms_per_step is not None else sum(a) / n
+    stall = a[-1] > 3.0 * med or (wall_ms_per_step is not None and wall_ms_per_step > 1.05 * ref)
     return {"ms_per_step_median": round(med, 4), "ms_per_step_max": round(a[-1], 4), "stall_suspected": bool(stall)}
 
 
@@ -77,8 +80,16 @@ class StepClock:
         e.record()
         self.ev.append(e)
 
+    def close(self):
+        """One more event behind everything the window enqueued after its last step's tick (graph.flush())."""
+        self.end = torch.cuda.Event(enable_timing=True)
+        self.end.record()
+
     def per_step_ms(self):              # after a synchronize
         return [a.elapsed_time(b) for a, b in zip(self.ev[:-1], self.ev[1:])]
+
+    def span_ms(self):                  # first tick -> close() (or the last tick)
+        return self.ev[0].elapsed_time(getattr(self, "end", self.ev[-1]))
 
 
 def synthetic_inputs(B, T, F, V, seed, device, all_full):
@@ -187,6 +198,9 @@ def run_hlstm(device, rank, world, B, mode, every_n, steps, warmup, all_full=Fal
         it += 1
         clock.tick()
     graph.flush()              # defer_updates: the last step's MoE / L2-level updates are enqueued and joined INSIDE the timed region
+    clock.close()
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0          # this rank's own wall clock (stall check only)
     barrier()
     dt = time.perf_counter() - t0
     per_step = clock.per_step_ms()
@@ -197,7 +211,7 @@ def run_hlstm(device, rank, world, B, mode, every_n, steps, warmup, all_full=Fal
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     res = {"ms_per_step": dt / steps * 1e3, "frames_per_sec": world * B * T_FRAMES * steps / dt, "steps": steps,
-           "warmup": warmup, "batch_per_gpu": B, **step_stats(per_step, dt / steps * 1e3),
+           "warmup": warmup, "batch_per_gpu": B, **step_stats(per_step, dt_local / steps * 1e3, clock.span_ms() / steps),
            "nominal_tflop_per_step": round(float(np.mean([g[0] for g in gf])) / 1e3, 3),
            "executed_tflop_per_step": round(float(np.mean([g[1] for g in gf])) / 1e3, 3),
            "losses": {k: round(v, 4) for k, v in graph.loss_report().items()},
@@ -363,6 +377,9 @@ def run_dbof(device, rank, world, B, steps, warmup, pool=4, precision="bf16"):
         x, n, labels, u = pool_in[(warmup + i) % pool]
         graph.step(x, labels, n, uniform=u)
         clock.tick()
+    clock.close()
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -375,7 +392,7 @@ def run_dbof(device, rank, world, B, steps, warmup, pool=4, precision="bf16"):
     gflop_fwd = (2.0 * B * 30 * F_FEAT * 8192 + 2.0 * B * 8192 * 1024 + 2.0 * B * 1024 * V_CLS * 5) / 1e9
     res = {"ms_per_step": dt / steps * 1e3, "videos_per_sec": world * B * steps / dt,
            "frames_per_sec": world * B * T_FRAMES * steps / dt, "steps": steps, "warmup": warmup, "batch_per_gpu": B,
-           **step_stats(per_step, dt / steps * 1e3),
+           **step_stats(per_step, dt_local / steps * 1e3, clock.span_ms() / steps),
            "nominal_tflop_per_step": round(3 * gflop_fwd / 1e3, 4), "loss": round(float(graph.losses[0]), 4)}
     res["nominal_tflops"] = round(res["nominal_tflop_per_step"] / (res["ms_per_step"] * 1e-3), 1)
     timing = getattr(tw, "timing", None)
@@ -722,11 +739,17 @@ def main():
         if "dp" in head:
             res["dp"] = head["dp"]
         res.update(extra)
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.every_n, args.cpu_videos, args.cpu_budget, args.cpu_threads)
-        print(json.dumps(res))
+    # The CPU leg runs on rank 0 AFTER the process group is gone (no peer waits inside a collective while rank 0 spends a minute on the
+    # host cores; the other ranks have exited by then and left the cores to it), so the N > 1 line carries cpu_baseline next to roofline too.
     if world > 1 or one_rank_dp:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.every_n, args.cpu_videos, args.cpu_budget, args.cpu_threads)
+            if n_gpus > 1:
+                res["cpu_baseline"]["sample"] += "; timed on rank 0 after destroy_process_group() (the other ranks have exited)"
+        print(json.dumps(res))
 
 
 if __name__ == "__main__":

@@ -56,6 +56,9 @@ SIGNATURES = {
     "evc_moe_grad_update_apply": [vp, i64, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, f32, vp, vp, f32, f32, f32, f32, f32, vp, vp],
     "evc_gemm_nt_f16_fp8": [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp, vp],
     "evc_cast_f32_to_f16_fp8x": [vp, i64, i32, i32, i32, i32, vp, vp],
+    "evc_absmax_partials": [vp, i64, i32, i32, vp, vp],
+    "evc_cast_f32_to_f16_fp8x_dyn": [vp, i64, i32, i32, i32, i32, vp, vp, vp],
+    "evc_gemm_nt_f16_fp8_dyn": [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp, i32, vp, vp],
     "evc_moe_grad_update_phase": [vp, i64, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, i64, f32, vp, vp, f32, f32, f32, f32, f32, i32, vp],
     "evc_moe_tail_fwd": [vp, vp, i32, i32, i32, vp, vp, vp],
     "evc_moe_tail_bwd": [vp, vp, vp, i32, i32, i32, vp, i64, vp, i64, vp],

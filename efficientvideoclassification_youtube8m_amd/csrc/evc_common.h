@@ -117,6 +117,28 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Dynamic e4m3 range (round 6): the 64 partial |x| maxima evc_absmax_partials left in `ws` -> the number of bits d >= 0 by which an e4m3 image
+// scaled by 2^hi_exp must be shifted DOWN so that its largest element stays representable (max|x| 2^(hi_exp - d) <= 448).  The writer of the image
+// (evc_cast_f32_to_f16_fp8x_dyn) and its reader (evc_gemm_nt_f16_fp8_dyn, whose product scale grows by the same d) both call this on the same 64
+// floats: d = 0 - every bit identical to the fixed-scale entries - as long as max|x| <= 448 2^-hi_exp.  Whole wave must call it (shuffles).
+#define EVC_AMAX_SLOTS 64
+__device__ __forceinline__ int fp8_range_drop(const float* __restrict__ ws, int hi_exp) {
+  const float amax = wave_max(ws[threadIdx.x & 63]);
+  if (!(amax > 0.f) || !(amax < 3.0e38f)) return 0;            // zeros / inf / NaN: nothing to rescue, keep the fixed scale
+  int k;
+  const float m = frexpf(amax, &k);                              // amax = m 2^k, m in [0.5, 1)
+  // largest e with amax 2^e <= 448 = 0.875 2^9:  e = 9 - k if m <= 0.875 else 8 - k
+  const int e = (m <= 0.875f ? 9 : 8) - k;
+  const int d = hi_exp - e;
+  return d > 0 ? (d < 40 ? d : 40) : 0;
+}
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 // EVC_DETERMINISTIC=1 (read once per process): no floating-point atomics on the training path - split-K joins are not used (one

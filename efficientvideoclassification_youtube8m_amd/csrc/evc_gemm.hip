@@ -324,9 +324,9 @@ static inline void launch_gemm_f16_fp8(GemmOperands p, StoreParams s, int K16, i
   launch_cfg<Cfg>(gemm_nt_kernel<Cfg, true, true>, tm * tn * splits, st, p, s, tm, tn);
 }
 
-extern "C" int evc_gemm_nt_f16_fp8(const evc_f16* A16, int64_t lda, const uint8_t* A8, int64_t lda8, const evc_f16* B16, int64_t ldb,
-                                   const uint8_t* B8, int64_t ldb8, float* C, int64_t ldc, int M, int N, int K16, int K8, int scale_exp,
-                                   const float* bias, void* stream) {
+static int gemm_nt_f16_fp8_impl(const evc_f16* A16, int64_t lda, const uint8_t* A8, int64_t lda8, const evc_f16* B16, int64_t ldb,
+                                const uint8_t* B8, int64_t ldb8, float* C, int64_t ldc, int M, int N, int K16, int K8, int scale_exp,
+                                const float* amax_ws, int a8_hi_exp, const float* bias, void* stream) {
   EVC_REQUIRE(M > 0 && N > 0 && K16 >= 64 && K16 % 64 == 0 && K8 >= 512 && K8 % 128 == 0, EVC_ERR_BAD_SHAPE,
               "evc_gemm_nt_f16_fp8: bad shape M=%d N=%d K16=%d (%%64, >= 64) K8=%d (%%128, >= 512)", M, N, K16, K8);
   EVC_REQUIRE(A16 && A8 && B16 && B8 && C, EVC_ERR_BAD_ARG, "evc_gemm_nt_f16_fp8: NULL operand");
@@ -341,6 +341,7 @@ extern "C" int evc_gemm_nt_f16_fp8(const evc_f16* A16, int64_t lda, const uint8_
   p.B = (const bf16_t*)B16; p.ldb = ldb; p.group_stride = 0; p.M = M; p.Nu = N;
   p.A1lo = p.A2lo = p.Blo = nullptr;
   p.A3 = A8; p.lda3 = lda8; p.A4 = A8; p.lda4 = lda8; p.B8 = B8; p.ldb8 = ldb8; p.scale8_exp = scale_exp;
+  p.amax_ws = amax_ws; p.a8_hi_exp = a8_hi_exp;
   StoreParams s{C, ldc, M, N, bias, 0, 0, 1, 0};
   hipStream_t st = (hipStream_t)stream;
   if (M <= 512) {      // batch-row products (MoE head, DBoF hidden layer): 256 x 64 tiles stream the weights once; few column tiles and a long K
@@ -358,5 +359,18 @@ extern "C" int evc_gemm_nt_f16_fp8(const evc_f16* A16, int64_t lda, const uint8_
   }
   EVC_LAUNCH_CHECK();
   return EVC_OK;
+}
+extern "C" int evc_gemm_nt_f16_fp8(const evc_f16* A16, int64_t lda, const uint8_t* A8, int64_t lda8, const evc_f16* B16, int64_t ldb,
+                                   const uint8_t* B8, int64_t ldb8, float* C, int64_t ldc, int M, int N, int K16, int K8, int scale_exp,
+                                   const float* bias, void* stream) {
+  return gemm_nt_f16_fp8_impl(A16, lda, A8, lda8, B16, ldb, B8, ldb8, C, ldc, M, N, K16, K8, scale_exp, nullptr, 0, bias, stream);
+}
+// ... with the A8 images written by evc_cast_f32_to_f16_fp8x_dyn from the same amax_ws / hi_exp: every e4m3 product is scaled by
+// 2^(scale_exp + d), d = the range shift both kernels derive from the 64 partial maxima (0 while max|x| 2^a8_hi_exp <= 448: the fixed-scale product).
+extern "C" int evc_gemm_nt_f16_fp8_dyn(const evc_f16* A16, int64_t lda, const uint8_t* A8, int64_t lda8, const evc_f16* B16, int64_t ldb,
+                                       const uint8_t* B8, int64_t ldb8, float* C, int64_t ldc, int M, int N, int K16, int K8, int scale_exp,
+                                       const float* amax_ws, int a8_hi_exp, const float* bias, void* stream) {
+  EVC_REQUIRE(amax_ws && a8_hi_exp >= -30 && a8_hi_exp <= 30, EVC_ERR_BAD_ARG, "evc_gemm_nt_f16_fp8_dyn: amax_ws=%p a8_hi_exp=%d", (const void*)amax_ws, a8_hi_exp);
+  return gemm_nt_f16_fp8_impl(A16, lda, A8, lda8, B16, ldb, B8, ldb8, C, ldc, M, N, K16, K8, scale_exp, amax_ws, a8_hi_exp, bias, stream);
 }
 

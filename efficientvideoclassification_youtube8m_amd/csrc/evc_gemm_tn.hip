@@ -106,7 +106,10 @@ static int gemm_tn_impl(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64
   if (rows_per_slab && slab_rows > 0 && slab_rows % 32 == 0 && K % slab_rows == 0 && !evc_deterministic()) {
     const int nslabs = K / slab_rows, slab_steps = slab_rows / 32;
     int n = 0, total = 0;
-    bool ok = (long)nslabs * slab_steps < 65536;
+    // the segment walk indexes both operands by 32-bit BYTE offsets from their un-advanced bases (gemm_core_tn.h: (start + off) * 64 * ld): the
+    // last K row must stay below 4 GiB in the wider operand - beyond that the plain walk (which advances the base pointers per split) runs
+    const long ld_max = lda > ldb ? (long)lda : (long)ldb;
+    bool ok = (long)nslabs * slab_steps < 65536 && (long)K * (B2 && ldb2 > ld_max ? (long)ldb2 : ld_max) * 2 < (1L << 32);
     for (int t = 0; t < nslabs && ok; ++t) {
       int r = rows_per_slab[t] < 0 ? 0 : (rows_per_slab[t] > slab_rows ? slab_rows : rows_per_slab[t]);
       const int steps = (r + 31) / 32;

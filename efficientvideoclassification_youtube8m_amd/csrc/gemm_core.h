@@ -56,6 +56,9 @@ struct GemmOperands {
   const uint8_t* A4 = nullptr; long lda4 = 0; int nk4 = 0;
   const uint8_t* B8 = nullptr; long ldb8 = 0;
   int scale8_exp = 0;
+  // dynamic range of the A8 image (round 6): 64 partial |x| maxima (evc_absmax_partials) and the exponent the image was asked for; the kernel adds
+  // fp8_range_drop(amax_ws, a8_hi_exp) to scale8_exp - the shift the writer of the image applied (evc_cast_f32_to_f16_fp8x_dyn).  nullptr: fixed scale.
+  const float* amax_ws = nullptr; int a8_hi_exp = 0;
 #ifdef EVC_STAMPS
   int stamp_slot = 0;                    // diagnostic build: which slot of evc_stamps this launch writes (gemm_core_v3.h)
 #endif

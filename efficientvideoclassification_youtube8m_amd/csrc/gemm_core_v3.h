@@ -397,7 +397,8 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
     // (a wave with ONE row fragment - the 64-row tiles of the M ~ batch stacks - has no upper half: half 1 multiplies everything, half 2
     //  only re-reads; those steps are bound by the chain of dependent stages, and an e4m3 stage covers twice the K of a 16-bit one)
     v8i_t aL[ML], aH[MH > 0 ? MH : 1], b8[Cfg::G][Cfg::NI];
-    const int sc_first = 127 + p.scale8_exp, sc_second = 127;   // e8m0 scale bytes: the whole factor rides on the first operand
+    // e8m0 scale bytes: the whole factor rides on the first operand (+ the A8 image's dynamic range shift, if it has one)
+    const int sc_first = 127 + p.scale8_exp + (p.amax_ws ? fp8_range_drop(p.amax_ws, p.a8_hi_exp) : 0), sc_second = 127;
     auto rd8 = [&](const int base0, const int base1, const int off) -> v8i_t {   // both 16-byte chunks of this lane's row in ring slot slot_read
       const char* sb = lds + slot_read * Cfg::STAGE_BYTES;
       const v4i_t lo = *(const v4i_t*)(sb + base0 + off), hi = *(const v4i_t*)(sb + base1 + off);

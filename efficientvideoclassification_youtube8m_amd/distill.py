@@ -480,7 +480,7 @@ class DistillGraph:
         xt, xs = ops.l2norm_chunk(x_raw, self.C1, self.every_n if need_student else None, self.C2,
                                   num_frames=num_frames if x_raw.dtype == torch.uint8 else None,
                                   split=(self.teacher or self.student).input_split(), plan1=tp[2] if tp else None,
-                                  plan2=sp[3] if sp else None,
+                                  plan2=sp[3] if sp else None, teacher_view=self.teacher is not None,     # (student only: the sub-sampled frames alone are read)
                                   **input_image_args(self.teacher, self.student))
         for tw in (self.teacher, self.student):     # step k-1's deferred MoE / L2-level updates: now, under this step's L1 forward
             if tw is not None:
@@ -734,7 +734,7 @@ class EvalGraph:
         u8 = x_raw.dtype == torch.uint8
         tp, sp = frame_counts_and_plans(self, num_frames, nh, self.teacher is not None, True)
         xt, xs = ops.l2norm_chunk(x_raw, self.C1, self.every_n, self.C2, num_frames=num_frames if u8 else None, split=split,
-                                  plan1=tp[2] if tp else None, plan2=sp[3],
+                                  plan1=tp[2] if tp else None, plan2=sp[3], teacher_view=self.teacher is not None,
                                   **input_image_args(self.teacher, self.student))
         self.losses.zero_()
         out = {}

@@ -90,7 +90,7 @@ class LstmStack:
         self.hbuf = [torch.zeros((T + 1, M, H), dtype=BF16, device=dev) for _ in range(L)]   # zeros: stale rows stay finite
         self.kin = [Kin] + [H] * (L - 1)
         # hoist the x-projection when the per-step GEMM is small (M ~ batch): fewer, larger GEMMs
-        self.hoist = [M < 1024 for _ in range(L)]
+        self.hoist = [M < self.HOIST_BELOW for _ in range(L)]
         self.zx = None
         if any(self.hoist):
             self.zx = torch.empty((T * M, 4 * H), dtype=F32, device=dev)
@@ -116,6 +116,7 @@ class LstmStack:
         base = "%s/rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/" % (self.scope, l)
         return base + "kernel", base + "bias"
 
+    HOIST_BELOW = int(os.environ.get("EVC_HOIST_BELOW", "1024"))     # rows below which a stack counts as "M ~ batch" (hoisted x-projection + wavefront pair launches)
     wavefront = os.environ.get("EVC_NO_WAVEFRONT") != "1"   # two-layer M ~ batch stacks: see forward()
     fwd_walk2 = os.environ.get("EVC_FWD_WALK2", "1") != "0"   # two-layer many-row stacks (bf16): two tiles per workgroup, T + 1 launches (A/B: 0)
     # two-layer stacks with many rows (the L1 levels), the gradient arriving at layer 0 from layer 1:
@@ -615,10 +616,17 @@ class MoeHead:
             if not hasattr(self, "x_rows") or self.x_rows.shape[0] != B:
                 self.x_rows = torch.empty((B, 2 * K), dtype=ops.F16, device=x.device)
             ops.cast_bf16(x, self.x_bf)                                 # the backward / fused-update factor
-            ops.cast_f16_fp8x(x, self.x_rows)
-            ops.gemm_nt_f16_fp8(self.x_rows, tw.shadow_w16[self.GATES], tw.shadow_w8[self.GATES], B, V * (Mx + 1), K, self.gate_logits)
+            # the input is the L2 state [c | h]: its cell-state half is unbounded (|c| ~ 16 after 512 training steps), so the e4m3 images take
+            # their range from this batch's max|x| (64 partial maxima; no shift - the fixed 2^6 / 2^17 - while max|x| <= 7)
+            amax = None
+            if self.dynamic_fp8_range:
+                if not hasattr(self, "x_amax"):
+                    self.x_amax = torch.zeros(ops.AMAX_SLOTS, dtype=F32, device=x.device)
+                amax = ops.absmax_partials(x, self.x_amax)
+            ops.cast_f16_fp8x(x, self.x_rows, amax_ws=amax)
+            ops.gemm_nt_f16_fp8(self.x_rows, tw.shadow_w16[self.GATES], tw.shadow_w8[self.GATES], B, V * (Mx + 1), K, self.gate_logits, amax_ws=amax)
             ops.gemm_nt_f16_fp8(self.x_rows, tw.shadow_w16[self.EXPERTS], tw.shadow_w8[self.EXPERTS], B, V * Mx, K, self.expert_logits,
-                                bias=tw.store.p(self.EBIAS))
+                                bias=tw.store.p(self.EBIAS), amax_ws=amax)
             ops.moe_tail_fwd(self.gate_logits, self.expert_logits, B, V, Mx, self.pred, self.rowsum)
             return self.pred
         if getattr(tw, "precision", "bf16") != "bf16" and hasattr(tw, "shadow_w"):
@@ -652,6 +660,7 @@ class MoeHead:
         """evc_moe_grad_update's shape constraints (the reference sizes satisfy them: 14148, 9432, 4096)."""
         return (self.V * (self.Mx + 1)) % 4 == 0 and (self.V * self.Mx) % 4 == 0 and self.K % 8 == 0
 
+    dynamic_fp8_range = os.environ.get("EVC_HIGH_DYNAMIC_RANGE", "1") != "0"     # "high" head: e4m3 range of the input state from the batch (A/B: 0 = fixed 2^6)
     FUSE_MAX_ROWS = int(os.environ.get("EVC_MOE_FUSE_MAX_ROWS", "512"))
     # one process: the clip norm of the fused update from Gram matrices of the factors instead of a pass over the weights
     # (csrc/evc_moe_norms.hip; EVC_MOE_GRAM_NORMS=0: the two-pass form)
@@ -1007,7 +1016,9 @@ class TowerBase:
                 done.add(k)
         rest = [k for k in names if k not in done]
         # small tensors without an l2 term and without operand shadows (biases, batch-norm scales / offsets): one launch for up to 16 of them
-        small = [k for k in rest if k not in self.l2_names and k not in self.shadow_fwd and self.store.p(k).numel() <= (1 << 20)]
+        # (evc_clip_adam_small runs ONE workgroup per tensor in two serial passes: sized for a few thousand elements each - anything above
+        #  SMALL_ADAM_MAX elements stays on the two full-grid launches below)
+        small = [k for k in rest if k not in self.l2_names and k not in self.shadow_fwd and self.store.p(k).numel() <= self.SMALL_ADAM_MAX]
         if self.fused_small_adam and len(small) >= 2 and not ops.DETERMINISTIC:
             st = self.store
             for i in range(0, len(small), 16):
@@ -1036,6 +1047,7 @@ class TowerBase:
                     il = p.shape[0] // 4 if k.endswith("basic_lstm_cell/kernel") else 0
                     ops.transpose_to_bf16(p, p.shape[0], p.shape[1], sb, sb.shape[1], interleave_H=il)
 
+    SMALL_ADAM_MAX = 1 << 15        # elements per tensor of the one-launch small-tensor update (evc_clip_adam_small's limit)
     fused_small_adam = os.environ.get("EVC_FUSED_SMALL_ADAM", "1") != "0"   # A/B: 0 = grad_sqnorm + clip_adam launches per small tensor
     fused_lstm_adam = os.environ.get("EVC_FUSED_LSTM_ADAM", "1") != "0"     # A/B: 0 = grad_sqnorm / clip_adam / transpose / cast launches per tensor
 
@@ -1294,7 +1306,7 @@ class HLstmTower(TowerBase):
         never clamps - their low-order correction is (partly) lost and the 1e-3 contract degrades without any other signal.
         Counts weights of the L1 / L2 levels with |W| >= 4 (lo scale 2^17: |W - f16(W)| 2^17 <= 448), MoE weights with |W| >= 3.5
         (2^7) and, given `state` [B, K] (the head's input of a batch), its elements with |s| >= 7 (2^6; the cell-state half of the
-        L2 state is unbounded).  Returns {name: count}; all zeros means the contract's assumptions hold.  (Diagnostic: plain
+        L2 state is unbounded) - under MoeHead.dynamic_fp8_range (default, round 6) the state's range follows the batch and that count is 0.  Returns {name: count}; all zeros means the contract's assumptions hold.  (Diagnostic: plain
         tensor reductions, one host sync.)"""
         out = {}
         if self.precision != "high":
@@ -1305,7 +1317,13 @@ class HLstmTower(TowerBase):
         for k in list(getattr(self, "shadow_w8", {})):
             out[k] = int((self.store.p(k).abs() >= 448.0 / 2.0 ** ops.FP8_MOE["w_hi_exp"]).sum())
         if state is not None and getattr(self, "shadow_w8", None):
-            out["moe_input_state"] = int((state.abs() >= 448.0 / 2.0 ** ops.FP8_MOE["x_hi_exp"]).sum())
+            if self.moe.dynamic_fp8_range:
+                # the head's input takes its e4m3 range from the batch (ops.absmax_partials -> fp8_range_drop): nothing can clamp; the shift is reported
+                out["moe_input_state"] = 0
+                amax = float(state.abs().max())
+                self.last_state_range = dict(absmax=amax, shift_bits=max(0, int(math.ceil(math.log2(amax / 7.0)))) if amax > 7.0 else 0)
+            else:
+                out["moe_input_state"] = int((state.abs() >= 448.0 / 2.0 ** ops.FP8_MOE["x_hi_exp"]).sum())
         return out
 
     def _adam_images(self, k):
@@ -1337,7 +1355,8 @@ class HLstmTower(TowerBase):
         return 1 + list(self.names).index(k)
 
     def _after_fused_adam(self, k):
-        if k in getattr(self, "shadow16d", {}):
+        # (only while the tower RUNS in "high": one laid out for it and switched to bf16 reads none of the T images; refresh_shadows rebuilds them on the way back)
+        if self.precision == "high" and k in getattr(self, "shadow16d", {}):
             ops.cast_f16_dither(self.store.p(k), self.shadow16d[k], self.dither_seed(k), col0=self.dither_col0(k))
 
     # ---- parameters -------------------------------------------------------

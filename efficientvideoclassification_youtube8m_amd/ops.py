@@ -199,18 +199,38 @@ def cast_fp8_lo(w, out, hi_cols=0, scale_exp=FP8_W_SCALE_EXP, hi_exp=FP8_WX_HI_E
 FP8_MOE = dict(x_hi_exp=6, x_lo_exp=17, w_lo_exp=18, w_hi_exp=7)     # e4m3 scales of the "high" MoE head: |state| < 7, |W| < 3.5 never clamp; 6 + 18 = 17 + 7 = 24
 
 
-def cast_f16_fp8x(x, out, hi_exp=FP8_MOE["x_hi_exp"], lo_exp=FP8_MOE["x_lo_exp"]):
-    """out [R][2C] f16 containers = rows [f16(x) | e4m3(x 2^hi_exp) (C bytes) | e4m3((x - f16(x)) 2^lo_exp) (C bytes)]: the A operands of gemm_nt_f16_fp8."""
+AMAX_SLOTS = 64     # EVC_AMAX_SLOTS (csrc/evc_common.h)
+
+
+def absmax_partials(x, ws):
+    """ws [64] f32 = partial maxima of |x| over a 2-D f32 tensor (evc_absmax_partials: plain stores, nothing to zero)."""
+    assert x.dtype == F32 and x.dim() == 2 and ws.dtype == F32 and ws.numel() == AMAX_SLOTS and ws.is_contiguous()
+    _lib.call("evc_absmax_partials", _p(x), x.stride(0), x.shape[0], x.shape[1], _p(ws), _stream())
+    return ws
+
+
+def cast_f16_fp8x(x, out, hi_exp=FP8_MOE["x_hi_exp"], lo_exp=FP8_MOE["x_lo_exp"], amax_ws=None):
+    """out [R][2C] f16 containers = rows [f16(x) | e4m3(x 2^hi_exp) (C bytes) | e4m3((x - f16(x)) 2^lo_exp) (C bytes)]: the A operands of gemm_nt_f16_fp8.
+    amax_ws (absmax_partials(x)): dynamic range - both e4m3 images are shifted down by the d bits the largest |x| needs to stay below 448
+    (evc_cast_f32_to_f16_fp8x_dyn; gemm_nt_f16_fp8 takes the same amax_ws / hi_exp and scales its products back up)."""
     assert x.dtype == F32 and x.dim() == 2 and out.dtype == F16 and out.shape == (x.shape[0], 2 * x.shape[1]) and out.is_contiguous()
+    if amax_ws is not None:
+        _lib.call("evc_cast_f32_to_f16_fp8x_dyn", _p(x), x.stride(0), x.shape[0], x.shape[1], hi_exp, lo_exp, _p(amax_ws), _p(out), _stream())
+        return out
     _lib.call("evc_cast_f32_to_f16_fp8x", _p(x), x.stride(0), x.shape[0], x.shape[1], hi_exp, lo_exp, _p(out), _stream())
     return out
 
 
-def gemm_nt_f16_fp8(a_rows, w16, w8, M, N, K, out, bias=None, scale_exp=-24):
+def gemm_nt_f16_fp8(a_rows, w16, w8, M, N, K, out, bias=None, scale_exp=-24, amax_ws=None, a_hi_exp=FP8_MOE["x_hi_exp"]):
     """out [M][N] f32 = f16(x) . f16(W)^T + 2^scale_exp [e4m3(x ..) | e4m3(x_lo ..)] . w8^T (+ bias): a_rows [M][2K] from cast_f16_fp8x, w16 [N][K]
-    f16, w8 [N][2K] uint8 = [e4m3(W_lo ..) | e4m3(W ..)] (evc_gemm_nt_f16_fp8: the "high" precision MoE head)."""
+    f16, w8 [N][2K] uint8 = [e4m3(W_lo ..) | e4m3(W ..)] (evc_gemm_nt_f16_fp8: the "high" precision MoE head).  amax_ws / a_hi_exp: what
+    cast_f16_fp8x(amax_ws=...) wrote a_rows with (evc_gemm_nt_f16_fp8_dyn)."""
     assert a_rows.dtype == F16 and a_rows.shape == (M, 2 * K) and w16.dtype == F16 and w16.shape == (N, K) and w8.dtype == torch.uint8 and w8.shape == (N, 2 * K)
     assert out.dtype == F32 and a_rows.is_contiguous() and w16.is_contiguous() and w8.is_contiguous()
+    if amax_ws is not None:
+        _lib.call("evc_gemm_nt_f16_fp8_dyn", _p(a_rows), 2 * K, a_rows.data_ptr() + 2 * K, 4 * K, _p(w16), K, _p(w8), 2 * K, _p(out), out.stride(0),
+                  M, N, K, 2 * K, scale_exp, _p(amax_ws), a_hi_exp, _p(bias), _stream())
+        return out
     _lib.call("evc_gemm_nt_f16_fp8", _p(a_rows), 2 * K, a_rows.data_ptr() + 2 * K, 4 * K, _p(w16), K, _p(w8), 2 * K, _p(out), out.stride(0),
               M, N, K, 2 * K, scale_exp, _p(bias), _stream())
     return out
@@ -299,7 +319,7 @@ def host_frame_counts(num_frames_host, every_n, num_chunks, chunk_len, max_frame
 
 
 def l2norm_chunk(x_raw, num_chunks, every_n=None, num_chunks_student=None, num_frames=None, normalize=True, split=False,
-                 plan1=None, plan2=None, f16_segments=1, fp8_tail=False):
+                 plan1=None, plan2=None, f16_segments=1, fp8_tail=False, teacher_view=True):
     """a1+a2.  x_raw [B,T,F] f32 (or uint8 with num_frames).  Returns the
     teacher view [Lc][C*B][F] bf16 and (if every_n) the student view; with row plans the views are
     [Lc][plan.P][F] in slot order.  split: True -> (bf16, bf16 low half) pairs; "f16" -> (bf16, IEEE f16 image) pairs (the
@@ -307,11 +327,13 @@ def l2norm_chunk(x_raw, num_chunks, every_n=None, num_chunks_student=None, num_f
     has rows of f16_segments*F: [f16(x) | (x - f16(x))*64 | f16(x)/64], the K-extended x operand of lstm_layer_fwd_f16;
     "wide" -> (bf16, wide bf16 image with rows [lo | hi] of 2F) pairs, the input of lstm_layer_fwd_hp.
     fp8_tail (with split "f16", f16_segments 1): the f16 image's rows are 2F halfwords = [f16(x) | e4m3(x 2^7) (F bytes) | e4m3((x - f16(x)) 2^18)
-    (F bytes)], the x rows of lstm_layer_fwd_f16_fp8lo (evc_l2norm_chunk_fwd aux_mode 5)."""
+    (F bytes)], the x rows of lstm_layer_fwd_f16_fp8lo (evc_l2norm_chunk_fwd aux_mode 5).
+    teacher_view=False (student-only graphs; needs every_n): the first view is None and only the sub-sampled frames of x_raw are read."""
     B, T, F = x_raw.shape
     dev = x_raw.device
-    rows1 = plan1.P if plan1 is not None else num_chunks * B
-    out1 = torch.empty((T // num_chunks, rows1, F), dtype=BF16, device=dev)
+    assert teacher_view or every_n, "l2norm_chunk: no view requested"
+    rows1 = (plan1.P if plan1 is not None else num_chunks * B) if teacher_view else 0
+    out1 = torch.empty((T // num_chunks, rows1, F), dtype=BF16, device=dev) if teacher_view else None
     out2 = None
     rows2 = 0
     if every_n:
@@ -326,14 +348,14 @@ def l2norm_chunk(x_raw, num_chunks, every_n=None, num_chunks_student=None, num_f
     if fp8_tail:
         assert split == "f16" and f16_segments == 1 and F % 32 == 0, "fp8_tail: the f16 image + two e4m3 images, F % 32 == 0"
         aux_mode, wrow = 5, 2 * F
-    lo1 = torch.empty(out1.shape[:2] + (wrow,), dtype=aux_dt, device=dev) if split else None
+    lo1 = torch.empty(out1.shape[:2] + (wrow,), dtype=aux_dt, device=dev) if (split and out1 is not None) else None
     lo2 = torch.empty(out2.shape[:2] + (wrow,), dtype=aux_dt, device=dev) if (split and out2 is not None) else None
     _lib.call("evc_l2norm_chunk_fwd", None if is_u8 else _p(x_raw), _p(x_raw) if is_u8 else None, _p(num_frames),
               B, T, F, num_chunks, _p(out1), every_n or 1, num_chunks_student or 1, _p(out2), 1 if normalize else 0,
-              _p(lo1), _p(lo2), aux_mode, _p(plan1.pos) if plan1 is not None else None, rows1,
+              _p(lo1), _p(lo2), aux_mode, _p(plan1.pos) if (plan1 is not None and teacher_view) else None, rows1,
               _p(plan2.pos) if plan2 is not None else None, rows2, _stream())
     if split:      # image pairs for the "high" / "split" precision forward
-        return (out1, lo1), ((out2, lo2) if out2 is not None else None)
+        return ((out1, lo1) if out1 is not None else None), ((out2, lo2) if out2 is not None else None)
     return out1, out2
 
 

@@ -36,7 +36,7 @@ extern "C" {
 #define EVC_ERR_HIP (-4)
 #define EVC_ERR_BAD_ARG (-5)
 
-#define EVC_VERSION 105   /* 105 (round 5, second session): evc_cast_f32_to_f16_dither, evc_lstm_layer_fwd_f16_dith (time-dithered f16 weight images: an L1 layer of the "high" mode without stages for its weights' low-order halves), evc_gemm_tn2_rows (weight-gradient products that skip the dead rows of a row-planned level's time slabs); 104 (round 5): evc_lstm_level2_fwd, evc_ce_loss_ordered, evc_rep_loss_ordered, evc_gemm_tn2_slabs, evc_sum_slabs, evc_clip_adam_small; evc_moe_grad_update* accept p_bf16 == NULL (forward shadow not written), evc_lstm_stack2_bwd runs M <= 512 stacks on the skinny pair launches, evc_dbof_cluster_pool_fwd walks tiles (EVC_DBOF_WALK), EVC_DETERMINISTIC parsed as "set, not empty, not 0"; 103 (round 4): evc_sqnorm2_partials, evc_lstm_adam_fused, evc_gram_slabs, evc_moe_grad_norms, evc_moe_grad_update_apply, evc_adam2d_fused, evc_colsum_bf16_det, evc_sample_sequence_gather, evc_relu6_fwd/bwd, evc_framepool_mean_fwd/bwd, evc_stream_create_cu_mask / evc_stream_destroy; EVC_DETERMINISTIC=1 read by the library; 102: evc_lstm_layer_fwd_f16_fp8lo, evc_lstm_stack2_fwd_f16_fp8lo, evc_gemm_nt_f16_fp8, evc_cast_f32_to_fp8_lo, evc_cast_f32_to_f16_fp8x, aux_mode 5, evc_moe_grad_update_wide; 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
+#define EVC_VERSION 106   /* 106 (round 6): evc_absmax_partials, evc_cast_f32_to_f16_fp8x_dyn, evc_gemm_nt_f16_fp8_dyn (dynamic e4m3 range of the MoE head's input state); evc_l2norm_chunk_fwd accepts out1 == NULL (student-only graphs read the sub-sampled frames only), evc_clip_adam_small limited to 2^15 elements per tensor; 105 (round 5, second session): evc_cast_f32_to_f16_dither, evc_lstm_layer_fwd_f16_dith (time-dithered f16 weight images: an L1 layer of the "high" mode without stages for its weights' low-order halves), evc_gemm_tn2_rows (weight-gradient products that skip the dead rows of a row-planned level's time slabs); 104 (round 5): evc_lstm_level2_fwd, evc_ce_loss_ordered, evc_rep_loss_ordered, evc_gemm_tn2_slabs, evc_sum_slabs, evc_clip_adam_small; evc_moe_grad_update* accept p_bf16 == NULL (forward shadow not written), evc_lstm_stack2_bwd runs M <= 512 stacks on the skinny pair launches, evc_dbof_cluster_pool_fwd walks tiles (EVC_DBOF_WALK), EVC_DETERMINISTIC parsed as "set, not empty, not 0"; 103 (round 4): evc_sqnorm2_partials, evc_lstm_adam_fused, evc_gram_slabs, evc_moe_grad_norms, evc_moe_grad_update_apply, evc_adam2d_fused, evc_colsum_bf16_det, evc_sample_sequence_gather, evc_relu6_fwd/bwd, evc_framepool_mean_fwd/bwd, evc_stream_create_cu_mask / evc_stream_destroy; EVC_DETERMINISTIC=1 read by the library; 102: evc_lstm_layer_fwd_f16_fp8lo, evc_lstm_stack2_fwd_f16_fp8lo, evc_gemm_nt_f16_fp8, evc_cast_f32_to_fp8_lo, evc_cast_f32_to_f16_fp8x, aux_mode 5, evc_moe_grad_update_wide; 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
 
 typedef uint16_t evc_bf16;
 typedef uint16_t evc_f16;   /* raw IEEE binary16 bits (the "high" precision forward operands of the L1 levels) */
@@ -63,6 +63,8 @@ int evc_check_device(int dev);
  * Row plans (evc_sort_rows_by_len): with row_pos1 != NULL the teacher image is [T/C1][rows1][F] and chunk row
  * m goes to slot row_pos1[m]; rows whose slot is >= rows1 (length-0 rows) are neither read nor written.
  * row_pos2 / rows2: the same for the student image.
+ * out1 == NULL (needs out2; out1_lo must be NULL too): a student-only graph (cs/train_finetune.py:243-318) - only the frames s*every_n
+ * of x_raw are read, nothing else of the tensor is touched.
  */
 int evc_l2norm_chunk_fwd(const float* x_raw, const uint8_t* x_u8, const int32_t* num_frames,
                          int B, int T, int F,
@@ -397,6 +399,18 @@ int evc_gemm_nt_f16_fp8(const evc_f16* A16, int64_t lda, const uint8_t* A8, int6
 /* out rows of 4C bytes = [f16(x) (C halfwords) | e4m3(x 2^hi_exp) (C bytes) | e4m3((x - f16(x)) 2^lo_exp) (C bytes)] for an f32 matrix [R][C]
  * (C % 32 == 0): the A16 / A8 operands of evc_gemm_nt_f16_fp8 (A16 = out, lda = 2C halfwords; A8 = (uint8_t*)out + 2C, lda8 = 4C bytes). */
 int evc_cast_f32_to_f16_fp8x(const float* in, int64_t ld_in, int R, int C, int hi_exp, int lo_exp, evc_f16* out, void* stream);
+/* Dynamic e4m3 range of an ACTIVATION operand (round 6; the MoE head's input is the L2 state [c0|h0|c1|h1] of cs/frame_level_models.py:255-263 and
+ * its cell-state half is unbounded: |c| ~ 16 on towers trained for 512 steps, where the fixed e4m3(x 2^6) saturates at 7).
+ *   evc_absmax_partials           ws[64] f32 = partial maxima of |x| over an f32 matrix [R][C] (plain stores: no atomics, nothing to zero)
+ *   evc_cast_f32_to_f16_fp8x_dyn  evc_cast_f32_to_f16_fp8x with both e4m3 images scaled by 2^(hi_exp - d) / 2^(lo_exp - d), d >= 0 the fewest bits
+ *                                 with max|x| 2^(hi_exp - d) <= 448
+ *   evc_gemm_nt_f16_fp8_dyn       evc_gemm_nt_f16_fp8 whose e4m3 products are scaled by 2^(scale_exp + d), the same d from the same ws / a8_hi_exp
+ * d = 0 (max|x| <= 448 2^-hi_exp) gives the bits of the fixed-scale entries. */
+int evc_absmax_partials(const float* in, int64_t ld_in, int R, int C, float* ws, void* stream);
+int evc_cast_f32_to_f16_fp8x_dyn(const float* in, int64_t ld_in, int R, int C, int hi_exp, int lo_exp, const float* amax_ws, evc_f16* out, void* stream);
+int evc_gemm_nt_f16_fp8_dyn(const evc_f16* A16, int64_t lda, const uint8_t* A8, int64_t lda8, const evc_f16* B16, int64_t ldb,
+                            const uint8_t* B8, int64_t ldb8, float* C, int64_t ldc, int M, int N, int K16, int K8, int scale_exp,
+                            const float* amax_ws, int a8_hi_exp, const float* bias, void* stream);
 /* split-bf16 cast: hi = bf16(x), lo = bf16(x - hi).  Three NT products (hi.hi + hi.lo + lo.hi, via
  * evc_gemm_nt with accumulate) then reproduce an f32-operand GEMM to ~2^-16 relative: the
  * "high" precision forward mode for models whose activations are O(1) (DBoF after batch-norm). */
@@ -461,7 +475,7 @@ int evc_clip_adam_step(float* p, const float* g, float* m, float* v, int64_t n, 
 /* The same two graph nodes (per-tensor clip_by_norm + Adam; cs/train.py:241-242,329-334) for up to 16 SMALL tensors without an l2 term - biases,
  * batch-norm scales / offsets - in one launch: workgroup i computes tensor i's squared gradient norm (block sum: a fixed order), leaves
  * sums[i] = {|g|^2, 0} and applies the update (round 5: the DBoF step spent 14 launches on 12 k parameters).  p, g, m, v, n, sums: HOST arrays of
- * `count` device pointers / sizes (copied into the launch's arguments); n[i] <= 2^20. */
+ * `count` device pointers / sizes (copied into the launch's arguments); n[i] <= 2^15 (one workgroup walks a tensor). */
 int evc_clip_adam_small(int count, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n,
                         float* const* sums, float clip_norm, float lr_t, float beta1, float beta2, float eps, void* stream);
 

@@ -65,6 +65,24 @@ def corrected_product(x, w, x_hi_exp, x_lo_exp, w_lo_exp, w_hi_exp, correct_x=Tr
     return z
 
 
+def fp8_range_drop(absmax, hi_exp):
+    """Bits d >= 0 by which an e4m3 image scaled by 2^hi_exp is shifted down so that its largest element stays representable:
+    the fewest with absmax * 2^(hi_exp - d) <= 448 (csrc/evc_common.h::fp8_range_drop, on the maximum of the 64 partial maxima)."""
+    absmax = float(absmax)
+    if not (absmax > 0.0) or not np.isfinite(absmax):
+        return 0
+    m, k = np.frexp(np.float32(absmax))
+    e = (9 if m <= 0.875 else 8) - int(k)
+    return int(min(max(hi_exp - e, 0), 40))
+
+
+def corrected_product_dyn(x, w, x_hi_exp, x_lo_exp, w_lo_exp, w_hi_exp):
+    """corrected_product with the DYNAMIC range of the activation operand (evc_cast_f32_to_f16_fp8x_dyn + evc_gemm_nt_f16_fp8_dyn):
+    both e4m3 images of x are scaled by 2^(exp - d), d = fp8_range_drop(max|x|, x_hi_exp); d = 0 is corrected_product itself."""
+    d = fp8_range_drop(np.abs(np.asarray(x, np.float32)).max(), x_hi_exp)
+    return corrected_product(x, w, x_hi_exp - d, x_lo_exp - d, w_lo_exp, w_hi_exp)
+
+
 # ---- OCP FP6 e2m3 ------------------------------------------------------------------------------------------------------------
 E2M3_MAX = 7.5
 

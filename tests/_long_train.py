@@ -1,0 +1,80 @@
+"""Helper process of the GPU tests / scripts/long_horizon.py: trains the REAL-SIZE teacher+student towers for hundreds of iterations
+under EVC_DETERMINISTIC=1 (same weights on every run and every box) and saves a TF-named checkpoint at each requested step count.
+
+    python tests/_long_train.py <out-dir> <batch> <lr> <steps,steps,...> [pool-batches]
+
+Training data: a fixed pool of `pool-batches` synthetic batches (oracle.model_math.synthetic_batch, seeds 9100..) whose labels come
+from a FIXED label function of the input (pool_batch below: the top-3 classes of a fixed random projection of the video's mean
+l2-normalised frame, + class 0 for a third of the videos) - a learnable target, so the logits keep growing with the step count the
+way they do on real data instead of collapsing onto the prior.  The first 4 videos of pool batch 0 are the ones the callers compare
+against the float64 oracle (eval_videos below).  Learning rate / clip / l2 penalty: the reference's defaults (cs/train.py:71-94).
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from oracle import model_math as mm  # noqa: E402
+
+LABEL_SEED = 4242
+
+
+def pool_batch(i, B, feature_size=1152, vocab_size=4716):
+    """(x f32 [B,300,F] zero-padded, n int32 [B], labels bool [B,V]) of pool batch i; video 0 of batch 0 has all 300 frames."""
+    q, x, n, _ = mm.synthetic_batch(B, seed=9100 + i, dtype=np.float32, feature_size=feature_size, vocab_size=vocab_size)
+    if i == 0:
+        n[0] = 300
+        x[0] = mm.dequantize(q[0].astype(np.float32))
+    x[np.arange(300)[None, :] >= n[:, None]] = 0.0
+    xn = x / np.maximum(np.sqrt((x.astype(np.float64) ** 2).sum(-1, keepdims=True)), 1e-6)
+    mean = xn.sum(1) / np.maximum(n, 1)[:, None]
+    R = np.random.default_rng(LABEL_SEED).standard_normal((feature_size, vocab_size))
+    score = mean @ R
+    labels = np.zeros((B, vocab_size), bool)
+    top = np.argsort(-score[:, 1:], axis=1)[:, :3] + 1
+    labels[np.arange(B)[:, None], top] = True
+    labels[:, 0] = score[:, 0] > np.quantile(score[:, 0], 0.7) if B > 1 else False
+    return x.astype(np.float32), n, labels
+
+
+def eval_videos(B):
+    """The 4 videos the long-horizon tests compare with the oracle: the head of pool batch 0 (seen in training: the towers' states
+    and logits on them are as large as training has made them)."""
+    x, n, labels = pool_batch(0, B)
+    return x[:4].copy(), n[:4].copy(), labels[:4].copy()
+
+
+def main():
+    import torch
+    from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
+    out_dir, B, lr = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])
+    marks = sorted(int(v) for v in sys.argv[4].split(","))
+    pool_n = int(sys.argv[5]) if len(sys.argv) > 5 else 8
+    dev = "cuda:0"
+    pool = []
+    for i in range(pool_n):
+        x, n, labels = pool_batch(i, B)
+        pool.append((torch.from_numpy(x).to(dev), torch.from_numpy(labels.astype(np.uint8)).to(dev), torch.from_numpy(n).to(dev), n))
+    g = DistillGraph(B, every_n=10, device=dev, seed=3, base_learning_rate=lr)
+    os.makedirs(out_dir, exist_ok=True)
+    for it in range(1, marks[-1] + 1):
+        xd, yd, nd, nh = pool[(it - 1) % pool_n]
+        o = g.step(xd, yd, nd, num_frames_host=nh)
+        if it in marks:
+            sd = {}
+            sd.update(g.teacher.state_dict())
+            sd.update(g.student.state_dict())
+            torch.cuda.synchronize()
+            info = dict(steps=it, losses=g.loss_report(), deterministic=os.environ.get("EVC_DETERMINISTIC"),
+                        s_max=max(float(o["teacher_state"].abs().max()), float(o["student_state"].abs().max())),
+                        z_max=max(float(g.teacher.moe.gate_logits.abs().max()), float(g.student.moe.gate_logits.abs().max()),
+                                  float(g.teacher.moe.expert_logits.abs().max()), float(g.student.moe.expert_logits.abs().max())),
+                        w_max=max(float(v.abs().max()) for v in sd.values()))
+            torch.save({"sd": {k: v.cpu() for k, v in sd.items()}, **info}, os.path.join(out_dir, "step%d.pt" % it))
+            print("step %d: |state| %.2f |logit| %.2f |W| %.3f losses %s" % (it, info["s_max"], info["z_max"], info["w_max"],
+                                                                            {k: round(v, 3) for k, v in info["losses"].items()}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -159,13 +159,17 @@ def test_bench_multi_rank_path_runs(tmp_path):
     env = dict(os.environ, EVC_BENCH_SHARED_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--batch", "16", "--pool", "2", "--no_cpu_baseline"]
+           "--batch", "16", "--pool", "2", "--cpu_videos", "2", "--cpu_budget", "8"]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 32 and d["value"] > 0 and d["scaling"] == "weak"
+    # the N > 1 line is complete: the roofline of the dominant kernel AND the CPU leg, which rank 0 times after
+    # destroy_process_group() - no peer sits in a collective meanwhile (here a 2-video sample: the leg itself is tests/test_cpu_host.py's)
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["bound"] == "mfma"
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port" and "after destroy_process_group" in d["cpu_baseline"]["sample"]
     assert abs(d["value"] - 2 * 16 * 300 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert all(np.isfinite(v) for v in d["losses"].values())
     # the N > 1 line names the placement of the collectives and accounts for what they move (per step, rank 0)

@@ -523,6 +523,67 @@ def test_gemm_nt_f16_fp8_product_with_low_order_corrections(ops, M, N, K):
     assert d_emu < 2e-5 * max(1.0, np.abs(ref).max()), d_emu
 
 
+@pytest.mark.parametrize("amp,M,N,K", [(1.3, 64, 712, 512), (9.0, 64, 712, 512), (30.0, 256, 1416, 4096), (400.0, 200, 520, 1024), (5000.0, 64, 520, 512)])
+def test_gemm_nt_f16_fp8_dynamic_range_of_the_activation_operand(ops, amp, M, N, K):
+    """The MoE head's input is the L2 state [c | h]: its cell-state half is unbounded and the fixed e4m3(x 2^6) image saturates at |x| = 7 (towers
+    trained for 512 steps: |c| ~ 16) - the correction of the weights' f16 rounding is then partly lost, silently.  evc_absmax_partials +
+    evc_cast_f32_to_f16_fp8x_dyn + evc_gemm_nt_f16_fp8_dyn shift both e4m3 images of x down by the d bits the batch's largest |x| needs and
+    scale the products back: (a) the image bytes are e4m3(x 2^(6 - d)) / e4m3(x_lo 2^(17 - d)) with d from oracle.lowprec.fp8_range_drop - no
+    byte saturated; (b) the product equals the numpy restatement of the same roundings; (c) against the float64 product it is >= 10x closer
+    than plain f16 and within 1e-4 |z| max at ANY amplitude, while the fixed-scale entry loses that once |x| > 7; (d) d = 0 (|x| <= 7)
+    reproduces the fixed-scale entry bit for bit."""
+    from oracle import lowprec as lp
+    rng = np.random.default_rng(int(amp * 10) + M + N + K)
+    x = (rng.standard_normal((M, K)) * 0.3).astype(np.float32)
+    x[:, : K // 2] *= np.float32(amp / np.abs(x[:, : K // 2]).max())          # the "cell state" half reaches +-amp, the "h" half stays small
+    w = (rng.standard_normal((N, K)) * 0.04).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + bias
+    zmax = np.abs(ref).max()
+    xd, wd, bd = torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV), torch.from_numpy(bias).to(DEV)
+    e = ops.FP8_MOE
+    ws = torch.full((ops.AMAX_SLOTS,), float("nan"), dtype=torch.float32, device=DEV)
+    ops.absmax_partials(xd, ws)
+    assert float(ws.max()) == float(np.abs(x).max()) and float(ws.min()) >= 0.0
+    d = lp.fp8_range_drop(np.abs(x).max(), e["x_hi_exp"])
+    top = float(np.abs(x).max()) * 2.0 ** (e["x_hi_exp"] - d)
+    assert (d == 0) == (np.abs(x).max() <= 7.0) and top <= 448.0 and (d == 0 or 2.0 * top > 448.0)      # the fewest bits that fit
+    rows = torch.empty((M, 2 * K), dtype=torch.float16, device=DEV)
+    ops.cast_f16_fp8x(xd, rows, amax_ws=ws)
+    assert torch.equal(rows[:, :K], xd.half())
+    b8 = rows[:, K:].contiguous().view(torch.uint8)
+    zero_ok = lambda got, want: bool(((got == want) | (((got & 0x7f) == 0) & ((want & 0x7f) == 0))).all())
+    assert zero_ok(b8[:, :K], _e4m3(xd, 2.0 ** (e["x_hi_exp"] - d)).view(torch.uint8))
+    assert zero_ok(b8[:, K:], _e4m3(xd - xd.half().float(), 2.0 ** (e["x_lo_exp"] - d)).view(torch.uint8))
+    w16 = torch.empty((N, K), dtype=torch.float16, device=DEV)
+    ops.cast_f16(wd, w16)
+    w8 = torch.empty((N, 2 * K), dtype=torch.uint8, device=DEV)
+    ops.cast_fp8_lo(wd, w8, hi_cols=K, scale_exp=e["w_lo_exp"], hi_exp=e["w_hi_exp"])
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    ops.gemm_nt_f16_fp8(rows, w16, w8, M, N, K, out, bias=bd, amax_ws=ws)
+    got = out.cpu().double().numpy()
+    err = np.max(np.abs(got - ref))
+    plain = xd.half().double().cpu().numpy() @ wd.half().double().cpu().numpy().T + bias
+    err16 = np.max(np.abs(plain - ref))
+    emu = lp.corrected_product_dyn(x, w, e["x_hi_exp"], e["x_lo_exp"], e["w_lo_exp"], e["w_hi_exp"]) + bias
+    d_emu = np.max(np.abs(got - emu))
+    # the fixed-scale entries on the same operands
+    rows_f = torch.empty_like(rows)
+    ops.cast_f16_fp8x(xd, rows_f)
+    out_f = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    ops.gemm_nt_f16_fp8(rows_f, w16, w8, M, N, K, out_f, bias=bd)
+    err_fixed = np.max(np.abs(out_f.cpu().double().numpy() - ref))
+    print("dynamic e4m3 range, |x| max %.0f (d = %d), |z| max %.1f: err %.2e (fixed 2^6 scale %.2e, plain f16 %.2e; vs the numpy restatement %.2e)"
+          % (amp, d, zmax, err, err_fixed, err16, d_emu))
+    assert np.isfinite(got).all()
+    assert err < 1e-4 * max(1.0, zmax) and err * 10 < err16, (err, err16)
+    assert d_emu < 2e-5 * max(1.0, zmax), d_emu
+    if d == 0:
+        assert torch.equal(out, out_f) and torch.equal(rows, rows_f)
+    elif amp >= 30:
+        assert err_fixed > 3 * err, (err_fixed, err)          # what the fixed scale loses to saturation
+
+
 @pytest.mark.parametrize("M,T,Kin,H,tile", [(512, 4, 384, 384, 0), (1100, 3, 1152, 512, 0), (700, 5, 384, 384, 6), (390, 3, 512, 384, 7), (330, 3, 384, 384, 8), (730, 4, 384, 384, 11)])
 def test_lstm_layer_fwd_f16_fp8_low_order_weights(M, T, Kin, H, tile):
     """evc_lstm_layer_fwd_f16_fp8lo (two stacked layers: layer 0 on input rows [f16(x) | e4m3(x 2^7) | e4m3(x_lo 2^18)], layer 1 on layer 0's
@@ -1170,6 +1231,44 @@ def test_l2norm_chunk_with_row_plans(ops):
     assert torch.equal(o1[:, :live1], r1[:, torch.from_numpy(inv1[:live1]).to(DEV).long()])
     assert torch.equal(o2[:, :live2], r2[:, torch.from_numpy(inv2[:live2]).to(DEV).long()])
     assert bool((r1[:, torch.from_numpy(inv1[live1:]).to(DEV).long()] == 0).all())     # what was dropped is all padding
+
+
+@pytest.mark.parametrize("every_n,u8", [(30, False), (30, True), (10, False), (1, True), (60, False)])
+@pytest.mark.parametrize("split", [False, "f16", "fp8", "wide"])
+def test_l2norm_chunk_student_only_reads_the_subsampled_frames(ops, every_n, u8, split):
+    """evc_l2norm_chunk_fwd with out1 == NULL (student-only graphs, cs/train_finetune.py:243-318; round 6): the student view - and its second
+    image in every "high" / "split" layout - is bit-identical to the one the two-view call writes, with and without a row plan; the frames
+    between the sub-sampled ones are never read (NaN there changes nothing: at every_n = 30 the launch touches 1/30 of the tensor)."""
+    B, T, F, C2 = 5, 300, 1152, 5
+    q, x, n, _ = mm.synthetic_batch(B, seed=40 + every_n, dtype=np.float32)
+    n[0], n[1] = 300, 31
+    x[np.arange(T)[None, :] >= n[:, None]] = 0.0
+    src = torch.from_numpy(q if u8 else x).to(DEV)
+    nd = torch.from_numpy(n).to(DEV)
+    S = T // every_n
+    kw = dict(num_frames=nd if u8 else None)
+    if split == "fp8":
+        kw.update(split="f16", f16_segments=1, fp8_tail=True)
+    elif split:
+        kw.update(split=split, f16_segments=2 if split == "f16" else 1)
+    _, l1s, _ = ops.frame_counts(nd, every_n, C2, S // C2, subsampled=True)
+    plan = ops.RowPlan(l1s, ops.host_frame_counts(n, every_n, C2, S // C2, subsampled=True)[1], S // C2)
+    for p2 in (None, plan):
+        both = ops.l2norm_chunk(src, 20, every_n, C2, plan2=p2, **kw)
+        only = ops.l2norm_chunk(src, 20, every_n, C2, plan2=p2, teacher_view=False, **kw)
+        assert only[0] is None
+        live = p2.rows[0] if p2 is not None else C2 * B          # (slots past the live rows are never written: compare the live ones)
+        for a, b in zip(both[1] if split else (both[1],), only[1] if split else (only[1],)):
+            assert a.shape == b.shape and torch.equal(a[:, :live], b[:, :live])
+    if not u8:       # poison every frame the student does not use
+        xp = src.clone()
+        mask = torch.ones(T, dtype=torch.bool, device=DEV)
+        mask[torch.arange(0, S * every_n, every_n, device=DEV)] = False
+        xp[:, mask] = float("nan")
+        got = ops.l2norm_chunk(xp, 20, every_n, C2, teacher_view=False, **kw)[1]
+        ref = ops.l2norm_chunk(src, 20, every_n, C2, teacher_view=False, **kw)[1]
+        for a, b in zip(got if split else (got,), ref if split else (ref,)):
+            assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("M,T,Kin,H", [(640, 5, 64, 128), (5120, 4, 128, 128), (200, 6, 64, 64)])
