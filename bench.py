@@ -308,9 +308,10 @@ def run_hlstm(device, rank, world, B, mode, every_n, steps, warmup, all_full=Fal
         # stream each sequence is launched on; the student tower and the optimizer run beside them on the other streams, so
         # these are the rates inside the real step, not solo rates): the fused BPTT step, the hoisted dX product of the upper
         # layer and the TN weight-gradient products.
-        names = {"bwd_step": "lstm_bwd_step_kernel<TileCfg3<128,1,128,2,4,4>> (teacher L1 BPTT: dh = dz_{t+1} . Wh^T + gate derivative tail)",
-                 "dx_nt": "gemm_nt_kernel (teacher L1 upper layer: dX = dz . Wx^T over all steps, bf16 out)",
-                 "wgrad_tn": "gemm_tn_kernel<TileCfg2<256,1,256,2,4,5>> (teacher L1: dW^T = dz^T . [x | h_prev] per layer, split-K, 1-2 launches per layer)"}
+        who = "teacher" if graph.teacher is not None else "student"
+        names = {"bwd_step": "lstm_bwd_step_kernel<TileCfg3<128,1,128,2,4,4>> (%s L1 BPTT: dh = dz_{t+1} . Wh^T + gate derivative tail)" % who,
+                 "dx_nt": "gemm_nt_kernel (%s L1 upper layer: dX = dz . Wx^T over all steps, bf16 out)" % who,
+                 "wgrad_tn": "gemm_tn_kernel<TileCfg2<256,1,256,2,4,5>> (%s L1: dW^T = dz^T . [x | h_prev] per layer, split-K, 1-2 launches per layer)" % who}
         rl = {"fwd_step": res["roofline"]}
         for kind, rows in timing_bwd.items():
             if not rows:
@@ -697,12 +698,18 @@ def main():
         pm["high"]["layout"] = r.get("high_layout") if other == "high" else head.get("high_layout")
         extra["precision_modes"] = pm
         oc = {}
-        for name, kw in (("cfg2_teacher_only_b256", dict(B=256, mode="teacher", every_n=10)),
-                         ("cfg5_student_only_every_n30_b1024", dict(B=1024, mode="student", every_n=30)),
+        # dominant = the launch sequence with the largest share of the step's kernel time in that configuration's rocprofv3 digest
+        # (profiles/r06_digest_cfg2.txt / _cfg5.txt), timed live with HIP events like the headline's forward step - by time, not by habit
+        for name, kw in (("cfg2_teacher_only_b256", dict(B=256, mode="teacher", every_n=10, dominant="bwd_step")),
+                         ("cfg5_student_only_every_n30_b1024", dict(B=1024, mode="student", every_n=30, dominant="wgrad_tn")),
                          ("cfg3_all_300_frames_b256", dict(B=256, mode="teacher_student", every_n=10, all_full=True))):
             r = retime_on_stall(lambda: run_hlstm(device, rank, world, kw["B"], kw["mode"], kw["every_n"], s_steps, s_warm,
-                                                  kw.get("all_full", False), "bf16", 4))
+                                                  kw.get("all_full", False), "bf16", 4, roofline="dominant" in kw))
             oc[name] = {k: r[k] for k in keep if k in r}
+            if "dominant" in kw and kw["dominant"] in r.get("rooflines", {}):
+                oc[name]["roofline"] = dict(r["rooflines"][kw["dominant"]], dominant_by="share of the step's kernel time (profiles/r06_digest_%s.txt)" % name.split("_")[0])
+                oc[name]["rooflines"] = {k: {kk: v[kk] for kk in ("frac", "avg_launch_ms", "launches_per_step", "algorithmic_gflop_per_launch")}
+                                         for k, v in r["rooflines"].items()}
             _log("%s done: %.2f ms/step" % (name, r["ms_per_step"]))
         # (a 2 ms step: 20 steps and a pause first - right after the tens of GB of the previous configuration are freed the
         #  driver's unmapping work can stall the queue for ~65 ms once, which a 5-step window reported as 15 ms per step)

@@ -106,7 +106,11 @@ class GradReducer:
         all-gather (w-1) times its own part (payload = the part this rank contributes)."""
         if world <= 1:
             return 0.0
-        return 2.0 * (world - 1) / world * payload if kind.startswith("all_reduce") else float(world - 1) * payload
+        if kind.startswith("all_reduce"):
+            return 2.0 * (world - 1) / world * payload
+        if kind.startswith("reduce_scatter"):          # payload = the whole buffer every rank contributes (world slabs)
+            return (world - 1.0) / world * payload
+        return float(world - 1) * payload
 
     def __init__(self, process_group=None, grad_dtype=None):
         self.pg = process_group
@@ -255,6 +259,24 @@ class GradReducer:
             torch.distributed.all_gather_into_tensor(full.view(torch.uint8), own.view(torch.uint8), group=self.pg)
             return own
         self._run(go, full, kind="all_gather_slabs", nbytes=slab_rows * full.shape[1] * full.element_size())
+
+    def reduce_scatter_rows(self, full, slab_rows):
+        """full [world * slab_rows, cols] bf16 (contiguous): this rank's contribution to every rank's slab.  Returns [slab_rows, cols] bf16 = the
+        SUM over the ranks of slab `rank` (stream-ordered).  RCCL sums in bf16 along the ring; gloo has neither bfloat16 nor reduce_scatter:
+        the CPU / shared-GPU tests all-reduce the bf16-rounded values in f32 (the same per-rank rounding, an exact sum) and round the own slab once."""
+        assert full.is_contiguous() and full.dtype == torch.bfloat16 and full.shape[0] == self.world * slab_rows
+        if not self.active:
+            return full[:slab_rows]
+
+        def go():
+            if torch.distributed.get_backend(self.pg) == "gloo":
+                f = full.float()
+                torch.distributed.all_reduce(f, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+                return f[self.rank * slab_rows:(self.rank + 1) * slab_rows].to(torch.bfloat16)
+            own = torch.empty((slab_rows, full.shape[1]), dtype=full.dtype, device=full.device)
+            torch.distributed.reduce_scatter_tensor(own, full, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            return own
+        return self._run(go, full, kind="reduce_scatter_grad_bf16", nbytes=full.numel() * 2)
 
     def wait(self):
         for w in self._pending:
@@ -824,6 +846,9 @@ class SingleTowerGraph:
         if self.moe is not None and not fuse and getattr(self.moe, "_stale", False):
             raise RuntimeError("the MoE weights are sharded over the ranks (fused data-parallel update); call consolidate() "
                                "on every rank before a step that does not apply through it")
+        # data parallel: the exchange that carries the MoE gradient is chosen by shape (MoeHead.dp_route): factor all-gather (fused update) or
+        # bf16 reduce-scatter of the materialised gradient onto the owners' slabs (sharded_update) - either way no all-reduce of those segments
+        route_rs = bool(fuse and self.dp and self.moe.dp_route(self.reducer.world) == "reduce_scatter")
         main = torch.cuda.current_stream(self.device)
         stages = tw.grad_stages()
         fused_names = (self.moe.GATES, self.moe.EXPERTS, self.moe.EBIAS) if fuse else ()    # (the bias gradient comes from the same factors)
@@ -839,7 +864,7 @@ class SingleTowerGraph:
                 for lo, hi in tw.grad_ranges(exclude=skip, only=stages[i]):
                     self.reducer.reduce_async(tw.store.grad, lo, hi)
 
-        tw.backward(self._dp, moe_weight_grads=not fuse, on_stage=on_stage)
+        tw.backward(self._dp, moe_weight_grads=(not fuse) or route_rs, on_stage=on_stage)
         if self.dp:
             main.wait_stream(self._aux)
         if apply:
@@ -847,7 +872,10 @@ class SingleTowerGraph:
             l2c = self.reg_pen * 1e-8
             if fuse:
                 tw.begin_update()
-                self.moe.fused_update(tw.adam_lr_t(lr), self.clip, l2c, dp=self.reducer if self.dp else None)
+                if route_rs:
+                    self.moe.sharded_update(tw.adam_lr_t(lr), self.clip, l2c, self.reducer)
+                else:
+                    self.moe.fused_update(tw.adam_lr_t(lr), self.clip, l2c, dp=self.reducer if self.dp else None)
                 tw.apply_group([k for k in tw.names if k not in fused_names], lr, self.clip, l2c)
             else:
                 tw.apply_gradients(lr, self.clip, l2c)

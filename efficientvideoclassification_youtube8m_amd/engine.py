@@ -116,7 +116,10 @@ class LstmStack:
         base = "%s/rnn/multi_rnn_cell/cell_%d/basic_lstm_cell/" % (self.scope, l)
         return base + "kernel", base + "bias"
 
-    HOIST_BELOW = int(os.environ.get("EVC_HOIST_BELOW", "1024"))     # rows below which a stack counts as "M ~ batch" (hoisted x-projection + wavefront pair launches)
+    # rows below which a stack counts as "M ~ batch": hoisted x-projection + wavefront pair launches.  1025 since round 6 (was 1024): cfg 5's L2 level
+    # (M = 1024 videos, K = 4096 + 1024) as ONE 172 GFLOP product + 6 pair launches instead of ten 49 us step launches at 0.25 of peak -
+    # 3.85 -> 3.68 ms per step, same box, alternating (profiles/r06_cfg5_hoist_ab.txt)
+    HOIST_BELOW = int(os.environ.get("EVC_HOIST_BELOW", "1025"))
     wavefront = os.environ.get("EVC_NO_WAVEFRONT") != "1"   # two-layer M ~ batch stacks: see forward()
     fwd_walk2 = os.environ.get("EVC_FWD_WALK2", "1") != "0"   # two-layer many-row stacks (bf16): two tiles per workgroup, T + 1 launches (A/B: 0)
     # two-layer stacks with many rows (the L1 levels), the gradient arriving at layer 0 from layer 1:
@@ -707,6 +710,72 @@ class MoeHead:
         (cfg 5 student-only: 5.15 vs 4.88 ms per step) - there the gradients are materialised.  Under data parallelism it
         always pays (no 386 MB gradient all-reduce, each rank updates 1/world of the rows)."""
         return data_parallel or self.B <= self.FUSE_MAX_ROWS
+
+    # ---- data parallel: which exchange carries the MoE weight gradient (round 6) -----------------------------------------------
+    def dp_exchange_bytes(self, world):
+        """Bytes one rank puts on the wire per step for the two MoE weight matrices, per route (ring collectives):
+        "factors"        all-gather of the three bf16 factor images [Br][N_g], [Br][N_e], [Br][K] (fused_update): (W-1) Br (N_g + N_e + K) 2 -
+                         grows with the BATCH;
+        "reduce_scatter" the locally formed gradient X^T dZ as a bf16 reduce-scatter onto the owners' row slabs (sharded_update):
+                         (W-1)/W (N_g + N_e) K 2 - a constant of the MODEL.
+        Both routes then all-gather the owners' new bf16 rows (the same bytes, not counted).  cfg 3 (B 256, K 4096, N 23 580, W 8):
+        100 vs 176 MB -> factors; cfg 5 (B 1024): 398 vs 176 MB (169 + the slab padding) -> reduce_scatter (break-even B ~ 453); cfg 4 (B 512,
+        K 1024): 177 vs 44 MB -> reduce_scatter."""
+        Ng, Ne = ops.round_up(self.V * (self.Mx + 1), 64), ops.round_up(self.V * self.Mx, 64)
+        slabs = sum((((n + 127) // 128 + world - 1) // world) * 128 * world for n in (self.V * (self.Mx + 1), self.V * self.Mx))
+        return {"factors": (world - 1) * self.Br * (Ng + Ne + self.K) * 2.0, "reduce_scatter": (world - 1.0) / world * slabs * self.K * 2.0}
+
+    def dp_route(self, world):
+        """"factors" | "reduce_scatter": the cheaper exchange by shape (dp_exchange_bytes); EVC_DP_MOE_ROUTE=factors|reduce_scatter forces one."""
+        forced = os.environ.get("EVC_DP_MOE_ROUTE", "auto")
+        if forced in ("factors", "reduce_scatter"):
+            return forced
+        b = self.dp_exchange_bytes(max(2, world))        # (a one-rank debug group: decide as for two ranks' worth of shape, no byte moves either way)
+        return "reduce_scatter" if b["reduce_scatter"] < b["factors"] else "factors"
+
+    def sharded_update(self, lr_t, clip_norm, l2_coeff, dp, beta1=0.9, beta2=0.999, eps=1e-8):
+        """Data-parallel update of the two MoE weight matrices from the MATERIALISED local gradients (backward(weight_grads=True)) - the
+        "reduce_scatter" route: bf16 image of the local gradient -> reduce-scatter onto the owners' row slabs (shard()) -> the owner's
+        per-tensor norm (8-byte all-reduce of the slab sums) + clip + TF-Adam on its slab -> all-gather of the slabs' new bf16 rows, local
+        transpose for the backward shadow.  Same ZeRO-1 state as fused_update (consolidate() serves both); the expert biases all-reduce
+        (38 KB) and update everywhere.  bf16 forward only (the "high" images of a slab are not gathered)."""
+        tw, V, Mx, K = self.tw, self.V, self.Mx, self.K
+        st = tw.store
+        idx = {k: i for i, k in enumerate(tw.names)}
+        if getattr(self, "world", None) != dp.world:
+            self.shard(dp.world, dp.rank)
+        self._wsq_valid = [False, False]
+        if not hasattr(self, "_rs_buf"):
+            self._rs_buf, self._rs_g32 = {}, {}
+        for name, Vn in ((self.GATES, V * (Mx + 1)), (self.EXPERTS, V * Mx)):
+            l2 = l2_coeff if name in tw.l2_names else 0.0
+            slab = self.slab[name]
+            if name not in self._rs_buf or self._rs_buf[name].shape[0] != slab * dp.world:
+                self._rs_buf[name] = torch.zeros((slab * dp.world, K), dtype=BF16, device=tw.device)      # rows >= Vn stay zero
+                self._rs_g32[name] = torch.empty((slab, K), dtype=F32, device=tw.device)
+            buf, g32 = self._rs_buf[name], self._rs_g32[name]
+            ops.cast_bf16(st.g(name), buf[:Vn])
+            own = dp.reduce_scatter_rows(buf, slab)
+            v0 = dp.rank * slab
+            vs = min(Vn, v0 + slab) - v0                                   # rows of this rank's slab (<= 0: none)
+            pw, mw, vw = st.p(name), st.view(st.m, name), st.view(st.v, name)
+            sums = tw.sums[idx[name]]
+            if vs > 0:
+                g32[:vs].copy_(own[:vs])
+                ops.grad_sqnorm(g32[:vs], pw[v0:v0 + vs] if l2 else None, l2, sums)
+            dp.all_reduce_small(sums)
+            if vs > 0:
+                ops.clip_adam_step(pw[v0:v0 + vs], g32[:vs], mw[v0:v0 + vs], vw[v0:v0 + vs], l2, sums, clip_norm, lr_t, beta1, beta2, eps,
+                                   p_bf16=self._full(name)[v0:v0 + vs])
+            dp.all_gather_slabs(self._full(name), slab)
+            sb = tw.shadow_bwd[name]
+            ops.transpose_to_bf16(tw.shadow_fwd[name], Vn, K, sb, sb.shape[1])
+            self._stale = dp.world > 1
+        gb = st.g(self.EBIAS)
+        dp.all_reduce_small(gb)
+        ops.grad_sqnorm(gb, None, 0.0, tw.sums[idx[self.EBIAS]])
+        ops.clip_adam_step(st.p(self.EBIAS), gb, st.view(st.m, self.EBIAS), st.view(st.v, self.EBIAS), 0.0,
+                           tw.sums[idx[self.EBIAS]], clip_norm, lr_t, beta1, beta2, eps)
 
     # ---- data parallel: the two weight matrices are sharded by rows over the ranks (ZeRO-1) ----------------
     def shard(self, world, rank):
@@ -1504,11 +1573,15 @@ class HLstmTower(TowerBase):
                     h.wait()                                           # the aux stream waits for the collective, not the host
             self.apply_group(names, *early_apply)
 
-        fuse = (aux is not None and early_apply is not None and self.fused_moe_update
+        # data parallel, bf16: which exchange carries the MoE gradient is chosen by shape (MoeHead.dp_route) - the factor all-gather of the fused
+        # update grows with the batch, the reduce-scatter of the materialised gradient does not (cfg 5, B = 1024: 398 vs 169 MB per rank and step)
+        route_rs = (dp is not None and aux is not None and early_apply is not None and self.fused_moe_update and self.precision == "bf16"
+                    and self.moe.can_fuse_update() and self.moe.dp_route(dp.world) == "reduce_scatter")
+        fuse = (aux is not None and early_apply is not None and self.fused_moe_update and not route_rs
                 and (self.precision == "bf16" or dp is None)      # "high" under data parallelism: the lo halves of the row slabs are not gathered
                 and self.moe.can_fuse_update() and (reduce_fn is None or dp is not None)
                 and self.moe.prefer_fused_update(dp is not None))
-        if not fuse and getattr(self.moe, "_stale", False):
+        if not (fuse or route_rs) and getattr(self.moe, "_stale", False):
             raise RuntimeError("the MoE weights of %r are sharded over the ranks (fused data-parallel update); call "
                                "DistillGraph.consolidate() on every rank before an update that is not" % self.scope)
         ops.mark(self.scope + ":bwd_begin")
@@ -1542,6 +1615,9 @@ class HLstmTower(TowerBase):
                         if fuse:
                             lr, clip, l2c = early_apply
                             self.moe.fused_update(lr_t_now, clip, l2c, dp=dp)
+                        elif route_rs:
+                            lr, clip, l2c = early_apply
+                            self.moe.sharded_update(lr_t_now, clip, l2c, dp)
                         else:
                             reduce_then_apply(g_moe, seg_moe, f32=True)    # (a bf16 gradient payload is for the LSTM segments only)
                         ops.mark(self.scope + ":moe_update_done")

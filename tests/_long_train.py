@@ -45,6 +45,74 @@ def eval_videos(B):
     return x[:4].copy(), n[:4].copy(), labels[:4].copy()
 
 
+def evaluate(ck, modes, B_train, dev="cuda:0"):
+    """One checkpoint of main() against the float64 oracle on eval_videos(): ({magnitudes}, {mode: {quantity: max abs error}}) - predictions, states,
+    gate / expert logits of both towers (+ the fp8_saturation() counts in "high")."""
+    import numpy as np
+    import torch
+    from oracle import model_math as mm
+    from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
+    x, n, labels = eval_videos(B_train)
+    sd = ck["sd"]
+    params = {sc: {k[len(sc) + 1:]: v.double().numpy() for k, v in sd.items() if k.startswith(sc + "/")} for sc in ("model", "model_student")}
+    ref = mm.teacher_student_step(x.astype(np.float64), n, labels, params["model"], params["model_student"], 10, with_grads=False)
+    ref_logits = {}
+    for sc, st in (("model", ref["teacher_state"]), ("model_student", ref["student_state"])):
+        ref_logits[sc] = (st @ params[sc]["classifier/gates/weights"], st @ params[sc]["classifier/experts/weights"] + params[sc]["classifier/experts/biases"])
+    mags = dict(z_teacher=max(float(np.abs(a).max()) for a in ref_logits["model"]), z_student=max(float(np.abs(a).max()) for a in ref_logits["model_student"]),
+                s_teacher=float(np.abs(ref["teacher_state"]).max()), s_student=float(np.abs(ref["student_state"]).max()),
+                w_max=max(float(v.abs().max()) for v in sd.values()))
+    xd, yd, nd = torch.from_numpy(x).to(dev), torch.from_numpy(labels.astype(np.uint8)).to(dev), torch.from_numpy(n).to(dev)
+    res = {}
+    from efficientvideoclassification_youtube8m_amd.engine import HLstmTower
+    for mode in modes:
+        # mode = precision[:option,...][@batch] - options of the "high" layout, switched in-process: nodither (every L1 layer on its weights' e4m3
+        # low-order halves), light (the student's L1 level on plain f16: the default up to round 5), fixedrange (the head's input on the fixed 2^6 scale);
+        # @batch: the 4 evaluation videos at the head of a batch of that many (the rest: synthetic_batch(seed 92))
+        spec, _, bs = mode.partition("@")
+        prec, _, opts = spec.partition(":")
+        opts = set(o for o in opts.split(",") if o)
+        B = int(bs) if bs else 4
+        saved = (HLstmTower.f16_dither_layers, os.environ.get("EVC_HIGH_STUDENT_LIGHT"))
+        from efficientvideoclassification_youtube8m_amd.engine import MoeHead
+        saved_dyn = MoeHead.dynamic_fp8_range
+        HLstmTower.f16_dither_layers = () if "nodither" in opts else saved[0]
+        os.environ["EVC_HIGH_STUDENT_LIGHT"] = "1" if "light" in opts else ("0" if "full" in opts else (saved[1] if saved[1] is not None else ""))
+        if os.environ["EVC_HIGH_STUDENT_LIGHT"] == "":
+            del os.environ["EVC_HIGH_STUDENT_LIGHT"]
+        MoeHead.dynamic_fp8_range = saved_dyn and "fixedrange" not in opts
+        xb, yb, nb, nhb = xd, yd, nd, n
+        if B > 4:
+            _, xr, nr, lr_ = mm.synthetic_batch(B - 4, seed=92, dtype=np.float32)
+            xb = torch.cat([xd, torch.from_numpy(xr).to(dev)])
+            yb = torch.cat([yd, torch.from_numpy(lr_.astype(np.uint8)).to(dev)])
+            nhb = np.concatenate([n, nr])
+            nb = torch.from_numpy(nhb).to(dev)
+        g = DistillGraph(B, every_n=10, device=dev, seed=3, precision=prec)
+        g.teacher.load_state_dict({k: v.to(dev) for k, v in sd.items()})
+        g.student.load_state_dict({k: v.to(dev) for k, v in sd.items()})
+        out = g.step(xb, yb, nb, apply=False, num_frames_host=nhb)
+        e = {}
+        for name, tw, sc, kp, ks in (("teacher", g.teacher, "model", "predictions", "teacher_state"), ("student", g.student, "model_student", "student_predictions", "student_state")):
+            e[name + "_pred"] = float(np.abs(out[kp][:4].cpu().numpy() - ref["teacher_predictions" if name == "teacher" else "student_predictions"]).max())
+            e[name + "_state"] = float(np.abs(out[ks][:4].cpu().numpy() - ref[ks]).max())
+            e[name + "_gate_logits"] = float(np.abs(tw.moe.gate_logits[:4].cpu().numpy() - ref_logits[sc][0]).max())
+            e[name + "_expert_logits"] = float(np.abs(tw.moe.expert_logits[:4].cpu().numpy() - ref_logits[sc][1]).max())
+            if prec == "high":
+                sat = {k: v for k, v in tw.fp8_saturation(out[ks]).items() if v}
+                e[name + "_saturated"] = sat
+        res[mode] = e
+        del g
+        HLstmTower.f16_dither_layers = saved[0]
+        MoeHead.dynamic_fp8_range = saved_dyn
+        if saved[1] is None:
+            os.environ.pop("EVC_HIGH_STUDENT_LIGHT", None)
+        else:
+            os.environ["EVC_HIGH_STUDENT_LIGHT"] = saved[1]
+        torch.cuda.empty_cache()
+    return mags, res
+
+
 def main():
     import torch
     from efficientvideoclassification_youtube8m_amd.distill import DistillGraph

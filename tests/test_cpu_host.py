@@ -547,3 +547,32 @@ def test_high_precision_dither_layer_selection_rules():
     assert t.dither_wh0() and t.dither_col0(k0) == 1152 and t.dither_col0(k1) == 0
     assert not tower(2, wh0=True, layers=()).dither_wh0() and not tower(1, wh0=True).dither_wh0() and not tower(2, wh0=True, fp8=False).dither_wh0()
     assert tower(2, layers=(0, 1), wh0=True).dither_col0(k0) == 0                # every column when layer 0 itself is dithered
+
+
+def test_moe_gradient_exchange_is_chosen_by_shape():
+    """MoeHead.dp_route (round 6): per rank and step the factor all-gather moves (W-1) Br (N_g + N_e + K) 2 bytes, the bf16 reduce-scatter of the
+    locally formed gradient (W-1)/W (N_g + N_e) K 2 - BASELINE cfg 3 (B 256) stays on the factors, cfg 5 (B 1024: 398 vs 176 MB with the slab padding) and cfg 4
+    (K 1024: 177 vs 44 MB) take the reduce-scatter; cfg 5's whole step then puts <= 0.68 GB per rank on the wire."""
+    from efficientvideoclassification_youtube8m_amd.engine import MoeHead
+    import efficientvideoclassification_youtube8m_amd.ops as ops
+
+    def head(B, K, V=4716, Mx=2):
+        h = MoeHead(None, K, V, Mx)
+        h.B, h.Br = B, ops.round_up(B, 32)
+        return h
+    os.environ.pop("EVC_DP_MOE_ROUTE", None)
+    c3, c5, c4 = head(256, 4096), head(1024, 4096), head(512, 1024)
+    b5 = c5.dp_exchange_bytes(8)
+    assert abs(b5["factors"] - 7 * 1024 * (14208 + 9472 + 4096) * 2) < 1 and abs(b5["factors"] / 1e6 - 398) < 1
+    assert abs(b5["reduce_scatter"] - 7 / 8 * (14 + 10) * 128 * 8 * 4096 * 2) < 1 and abs(b5["reduce_scatter"] / 1e6 - 176.2) < 0.1   # (14 + 10 row tiles of 128 rows per rank: 169 MB unpadded)
+    assert c3.dp_route(8) == "factors" and c5.dp_route(8) == "reduce_scatter" and c4.dp_route(8) == "reduce_scatter"
+    assert head(448, 4096).dp_route(8) == "factors" and head(480, 4096).dp_route(8) == "reduce_scatter"       # break-even B ~ 453
+    assert c5.dp_route(2) == "factors"                                  # two ranks: one peer's factors are fewer bytes than half a gradient
+    lstm_allreduce = 2 * 7 / 8 * (17309696 + 29368320) * 4                # the student's L1 + L2 gradient segments, f32 ring all-reduce
+    slab_gather = 7 / 8 * (14 * 128 * 8 + 10 * 128 * 8) * 4096 * 2        # the owners' new bf16 rows (either route)
+    assert (lstm_allreduce + slab_gather + b5["reduce_scatter"]) / 1e9 <= 0.68 < (lstm_allreduce + slab_gather + b5["factors"]) / 1e9
+    os.environ["EVC_DP_MOE_ROUTE"] = "factors"
+    try:
+        assert c5.dp_route(8) == "factors"
+    finally:
+        del os.environ["EVC_DP_MOE_ROUTE"]

@@ -152,6 +152,38 @@ def test_two_rank_bf16_gradient_payload_bounds_its_effect_on_the_update(tmp_path
     print("f32 vs bf16 gradient payload after two iterations: max |dw| %.2e; (share > 2e-4, rms) per tensor: %s" % (worst, report))
 
 
+def test_two_rank_moe_gradient_exchange_routes(tmp_path):
+    """The exchange that carries the MoE weight gradient under data parallelism is chosen by shape (MoeHead.dp_route, round 6): the factor
+    all-gather of the fused update grows with the batch, the bf16 reduce-scatter of the locally formed gradient onto the owners' row slabs
+    (MoeHead.sharded_update) is a constant of the model - cfg 5 (B = 1024 per rank, W = 8): 398 vs 169 MB per rank and step.  Both routes
+    forced on the same two ranks (EVC_DP_MOE_ROUTE) and the single process: the same losses; the factor route within the f32 two-rank
+    tolerance of the single process (test above); the reduce-scatter route rounds each rank's gradient to bf16 once before the sum, which
+    is bounded the way the bf16 LSTM payload is - by the share of elements further than 2e-4 and the RMS, not by the maximum (Adam's first
+    steps move every weight by ~lr * sign(g))."""
+    one, fac, rs = str(tmp_path / "one.pt"), str(tmp_path / "fac.pt"), str(tmp_path / "rs.pt")
+    _run(1, one, 29661)
+    _run(2, fac, 29662, env={"EVC_DP_MOE_ROUTE": "factors"})
+    _run(2, rs, 29663, env={"EVC_DP_MOE_ROUTE": "reduce_scatter"})
+    a, f, r = torch.load(one), torch.load(fac), torch.load(rs)
+    assert a["global_step"] == f["global_step"] == r["global_step"] == 4
+    for k in ("label_loss", "student_loss_state", "pred_loss", "student_label_loss"):
+        for other in (f, r):
+            assert abs(a["losses"][k] - other["losses"][k]) <= 2e-3 * abs(a["losses"][k]) + 1e-6, (k, a["losses"], other["losses"])
+    moved, report = 0, {}
+    for k, v in a.items():
+        if torch.is_tensor(v) and v.dtype == torch.float32 and v.numel() > 1:
+            assert (v - f[k]).abs().max().item() < 2e-4, (k, "factors route vs single process")
+            d = (v - r[k]).abs()
+            if "classifier/" in k:
+                moved += int((f[k] - r[k]).abs().max().item() > 0)
+            far, rms = float((d > 2e-4).float().mean()), float(d.square().mean().sqrt())
+            report[k.split("/", 1)[1]] = (round(far, 5), rms)
+            small = v.numel() < 10000
+            assert d.max().item() < 2.5e-3 and far < (0.05 if small else 0.02) and rms < (2e-4 if small else 1.5e-4), (k, d.max().item(), far, rms)
+    assert moved > 0, "the forced route changed nothing in the MoE weights: the switch did not reach the update"
+    print("reduce-scatter route vs single process, (share > 2e-4, rms) per tensor:", report)
+
+
 def test_bench_multi_rank_path_runs(tmp_path):
     """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank),
     here with two ranks sharing the GPU over gloo: rank 0 prints the one JSON line with whole-job throughput."""
@@ -277,18 +309,22 @@ if world > 1:
 '''
 
 
-@pytest.mark.parametrize("kind", ["dbof", "netvlad"])
+@pytest.mark.parametrize("kind", ["dbof", "netvlad", "dbof_rs"])
 def test_dbof_two_ranks_match_single_process(tmp_path, kind):
     """DbofTower under data parallelism (SyncBN partial sums all-reduced, gradient all-reduce WITHOUT the batch-norm
     scale/offset segments, which are already global): gradients after one step and weights after two more equal the
     single-process run on the whole batch.  (A second all-reduce of dgamma/dbeta would double them: their per-tensor
     clipped Adam step would still look similar, so the gradients themselves are compared.)"""
     outs = []
+    # "dbof_rs": the MoE gradient by bf16 reduce-scatter onto the owners' slabs (MoeHead.sharded_update; what cfg 4's shape picks at 8 ranks)
+    rs = kind == "dbof_rs"
+    env = dict(os.environ, EVC_DP_MOE_ROUTE="reduce_scatter") if rs else None
+    kind = "dbof" if rs else kind
     for world, port in ((1, 29641), (2, 29642)):
         out = str(tmp_path / ("w%d.pt" % world))
         code = DBOF_WORKER % {"root": ROOT}
-        procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(world), str(port + (10 if kind == "netvlad" else 0)), out, kind],
-                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+        procs = [subprocess.Popen([sys.executable, "-c", code, str(r), str(world), str(port + (10 if kind == "netvlad" else (20 if rs else 0))), out, kind],
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(world)]
         logs = []
         for p in procs:
             try:
@@ -310,4 +346,11 @@ def test_dbof_two_ranks_match_single_process(tmp_path, kind):
     # sign in the two runs - the gradient comparison above is the parity check, this one only bounds the drift)
     tol = 2e-3 if kind == "dbof" else 8e-3
     for k, v in a["sd"].items():
-        assert (v - b["sd"][k]).abs().max().item() < tol, (k, (v - b["sd"][k]).abs().max().item())
+        d = (v - b["sd"][k]).abs()
+        if rs and "classifier/" in k and v.numel() > 1000:
+            # each rank's MoE gradient is rounded to bf16 once before the sum: an element whose summed gradient is smaller than that rounding
+            # can take Adam steps (1e-2 each) of the other sign - bounded by share and RMS (as the bf16 LSTM payload above), not by the maximum
+            far, rms = float((d > tol).float().mean()), float(d.square().mean().sqrt())
+            assert d.max().item() < 4.5e-2 and far < 0.02 and rms < 1.5e-3, (k, d.max().item(), far, rms)
+            continue
+        assert d.max().item() < tol, (k, d.max().item())
