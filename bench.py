@@ -92,9 +92,11 @@ class StepClock:
         return self.ev[0].elapsed_time(getattr(self, "end", self.ev[-1]))
 
 
-def synthetic_inputs(B, T, F, V, seed, device, all_full):
+def synthetic_inputs(B, T, F, V, seed, device, all_full, as_uint8=False):
     """uint8-uniform features dequantised as cs/utils.py:22-25,
-    n ~ U{120..300} with padded rows zeroed, ~3 positives per video (+class 0 w.p. 0.3)."""
+    n ~ U{120..300} with padded rows zeroed, ~3 positives per video (+class 0 w.p. 0.3).
+    as_uint8: the frames stay the reader's uint8 quantisation (cs/readers.py:146-174 keeps them so up to the GPU; the input kernel
+    dequantises and zeroes the padding rows itself) - 88 MB instead of 354 MB per batch of 256."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     q = torch.randint(0, 256, (B, T, F), generator=g, device=device, dtype=torch.uint8)
@@ -102,8 +104,11 @@ def synthetic_inputs(B, T, F, V, seed, device, all_full):
         n = torch.full((B,), T, dtype=torch.int32, device=device)
     else:
         n = torch.randint(120, T + 1, (B,), generator=g, device=device, dtype=torch.int32)
-    x = q.float() * (4.0 / 255.0) + (4.0 / 512.0 - 2.0)
-    x[torch.arange(T, device=device)[None, :] >= n[:, None]] = 0.0
+    if as_uint8:
+        x = q
+    else:
+        x = q.float() * (4.0 / 255.0) + (4.0 / 512.0 - 2.0)
+        x[torch.arange(T, device=device)[None, :] >= n[:, None]] = 0.0
     labels = torch.zeros((B, V), dtype=torch.uint8, device=device)
     idx = torch.randint(0, V, (B, 3), generator=g, device=device)
     labels.scatter_(1, idx, 1)
@@ -144,11 +149,11 @@ def hlstm_gflop(n_host, mode, every_n, B, row_plans=True):
 
 
 def run_hlstm(device, rank, world, B, mode, every_n, steps, warmup, all_full=False, precision="bf16", pool=8,
-              overlap=True, fused_moe=True, student_forward_early=False, roofline=False):
+              overlap=True, fused_moe=True, student_forward_early=False, roofline=False, input_u8=False):
     """Times `steps` training iterations of one DistillGraph configuration (after `warmup`), inputs resident in HBM.
     Returns a dict; with roofline=True also the live timing of the teacher's L1 forward step launches."""
     from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
-    pool_in = [synthetic_inputs(B, T_FRAMES, F_FEAT, V_CLS, 1234 + rank + 1000 * i, device, all_full) for i in range(pool)]
+    pool_in = [synthetic_inputs(B, T_FRAMES, F_FEAT, V_CLS, 1234 + rank + 1000 * i, device, all_full, as_uint8=input_u8) for i in range(pool)]
     # the frame counts also live on the host, as an input pipeline has them before the H2D copy (the launch
     # geometry of the length-sorted L1 stacks is derived from them, see ops.RowPlan)
     n_host = [p[1].cpu().numpy() for p in pool_in]
@@ -227,11 +232,13 @@ def run_hlstm(device, rank, world, B, mode, every_n, steps, warmup, all_full=Fal
         sim = GradReducer._sim() if world == 1 else None
         if sim is not None:
             w = sim[3]
+        elif graph.reducer.shard_world > 1:
+            w = graph.reducer.shard_world
         per_kind = {}
         for kind, (calls, nbytes) in sorted(GradReducer.stats.items()):
             ms_k = sum(e0.elapsed_time(e1) for k, _, e0, e1 in timing if k == kind)
             wire = GradReducer.wire_bytes(kind, nbytes / steps, w)
-            if sim is not None and kind == "all_gather_slabs":
+            if sim is not None and kind == "all_gather_slabs" and graph.reducer.shard_world == 1:
                 wire = (w - 1.0) / w * nbytes / steps
             per_kind[kind] = {"calls_per_step": round(calls / steps, 2), "payload_mb_per_step": round(nbytes / steps / 1e6, 3),
                               "wire_mb_per_rank_per_step": round(wire / 1e6, 3), "event_ms_per_step": round(ms_k / steps, 4)}
@@ -244,6 +251,7 @@ def run_hlstm(device, rank, world, B, mode, every_n, steps, warmup, all_full=Fal
                      "collectives": per_kind,
                      "wire_mb_per_rank_per_step": round(sum(v["wire_mb_per_rank_per_step"] for v in per_kind.values()), 2),
                      "collective_event_ms_per_step": round(sum(v["event_ms_per_step"] for v in per_kind.values()), 3),
+                     "sim_world": graph.reducer.shard_world if graph.reducer.shard_world != max(world, 1) else None,
                      "sim": None if sim is None else {"busbw_gbps": sim[0], "blocks": sim[1], "lds_kb_per_block": sim[2], "world": sim[3],
                                                       "what": "one GPU, one-rank communicator: after every collective a stand-in kernel holds `blocks` "
                                                               "workgroups (256 threads, LDS as given) for wire bytes / busbw + 20 us"},
@@ -594,6 +602,8 @@ def main():
     ap.add_argument("--mode", default="teacher_student", choices=["teacher_student", "teacher", "student"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "high", "split"])
     ap.add_argument("--all_full", action="store_true", help="every video has 300 frames (no padding)")
+    ap.add_argument("--input", default="f32", choices=["f32", "uint8"], help="frame tensor resident in HBM: f32 (dequantised, the rounds 1-5 input) or the reader's "
+                    "uint8 quantisation (cs/readers.py:146-174: what the pipeline delivers; Dequantize fused into the input kernel)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_secondary", action="store_true", help="skip the precision_modes / other_configs runs (N=1 only anyway)")
     ap.add_argument("--cpu_videos", type=int, default=256, help="batch of the CPU leg: 256 = the batch the metric is quoted on (SURVEY 8(d)); "
@@ -669,7 +679,7 @@ def main():
 
     B = args.batch or 256
     head = run_hlstm(device, rank, world, B, args.mode, args.every_n, args.steps, args.warmup, args.all_full, args.precision,
-                     args.pool, not args.no_overlap, not args.no_fused_moe, args.student_forward_early, roofline=True)
+                     args.pool, not args.no_overlap, not args.no_fused_moe, args.student_forward_early, roofline=True, input_u8=args.input == "uint8")
     _log("headline done: %.2f ms/step" % head["ms_per_step"])
     secondary = n_gpus == 1 and not args.no_secondary and not one_rank_dp
     extra = {}
@@ -679,7 +689,8 @@ def main():
                                                  "executed_tflop_per_step", "executed_tflops", "retimed_after_stall")
         pm = {args.precision: {k: head[k] for k in keep if k in head}}
         other = "high" if args.precision == "bf16" else "bf16"
-        r = retime_on_stall(lambda: run_hlstm(device, rank, world, B, args.mode, args.every_n, 10, 3, args.all_full, other, 4, roofline=True))
+        r = retime_on_stall(lambda: run_hlstm(device, rank, world, B, args.mode, args.every_n, 10, 3, args.all_full, other, 4, roofline=True,
+                                              input_u8=args.input == "uint8"))
         pm[other] = {k: r[k] for k in keep if k in r}
         if "roofline" in r:
             pm[other]["roofline"] = r["roofline"]
@@ -698,6 +709,14 @@ def main():
         pm["high"]["layout"] = r.get("high_layout") if other == "high" else head.get("high_layout")
         extra["precision_modes"] = pm
         oc = {}
+        if args.input == "f32":      # the same step fed the reader's uint8 frames ("keep uint8 to the GPU"), both forward modes
+            u8 = {}
+            for prec in ("bf16", "high"):
+                r = retime_on_stall(lambda: run_hlstm(device, rank, world, B, args.mode, args.every_n, 10, 3, args.all_full, prec, 4, input_u8=True))
+                u8[prec] = {k: r[k] for k in keep if k in r}
+            u8["high_over_bf16"] = round(u8["high"]["ms_per_step"] / u8["bf16"]["ms_per_step"], 4)
+            oc["cfg3_uint8_input_b256"] = u8
+            _log("uint8 input done: %.2f / %.2f ms/step" % (u8["bf16"]["ms_per_step"], u8["high"]["ms_per_step"]))
         # dominant = the launch sequence with the largest share of the step's kernel time in that configuration's rocprofv3 digest
         # (profiles/r06_digest_cfg2.txt / _cfg5.txt), timed live with HIP events like the headline's forward step - by time, not by habit
         for name, kw in (("cfg2_teacher_only_b256", dict(B=256, mode="teacher", every_n=10, dominant="bwd_step")),
@@ -737,6 +756,8 @@ def main():
                                    % (args.mode, args.every_n, B),
                        "global_batch": B * n_gpus, "frames_per_video": T_FRAMES, "parallelism": "dp%d" % n_gpus,
                        "num_frames": "all 300" if args.all_full else "U{120..300}",
+                       "input": "f32 frames resident in HBM (uint8-uniform values dequantised as cs/utils.py:22-25)" if args.input == "f32" else
+                                "the reader's uint8 frames resident in HBM (Dequantize + padding zeroing fused into the input kernel)",
                        "tflop_per_step_per_gpu": head["nominal_tflop_per_step"],
                        "executed_tflop_per_step_per_gpu": head["executed_tflop_per_step"]},
             "executed_tflops_per_gpu": head["executed_tflops"],

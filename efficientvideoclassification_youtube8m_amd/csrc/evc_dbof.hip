@@ -335,6 +335,17 @@ __device__ __forceinline__ void dbof_tile_epilogue(const GemmOperands& p, const 
   const int rbase = m0 + wr * Cfg::WM;                         // first row of this wave: a multiple of 128 = 4 videos
   const int b = (rbase >> 5) + (l >> 2);                       // this lane's video
   const int lim = b < e.B ? (e.S - j + 3) >> 2 : 0;            // accumulator blocks mi < lim hold sampled frames (slot mi*4 + j < S)
+#ifdef EVC_ABLATE_DBOF_EPILOGUE      // timing ablation (profiles/r06_dbof_ablation.txt): the main loop alone, one store per lane keeps the accumulators alive
+  {
+    float keep = 0.f;                                            // (every accumulator feeds the never-taken store: no MFMA is dead code)
+#pragma unroll
+    for (int mi = 0; mi < Cfg::MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < Cfg::NI; ++ni) keep += acc[mi][0][ni][0] + acc[mi][0][ni][1] + acc[mi][0][ni][2] + acc[mi][0][ni][3];
+    if (e.S == 0x7fffffff) e.xsel[threadIdx.x] = keep;
+    return;
+  }
+#endif
   if (e.act) {
     // bf16 activation for the backward pass.  The accumulator layout gives a lane 4 consecutive columns of 16 different
     // rows per block: stored directly, every wave-instruction touches 16 lines with 32 bytes each (measured: +0.21 ms on
@@ -388,14 +399,21 @@ __device__ __forceinline__ void dbof_tile_epilogue(const GemmOperands& p, const 
       for (int mi = 0; mi < Cfg::MI; ++mi) {
         if (mi < lim) {
           const float v = acc[mi][0][ni][r];
+#ifndef EVC_ABLATE_DBOF_STATS
           sum += v;
           sq += v * v;
+#endif
+#ifndef EVC_ABLATE_DBOF_SELECT
           const float t = sgn * v;
           if (t > best) { best = t; bi = mi; }                 // strict: the first maximum wins
+#else
+          best = fmaxf(best, v);                               // (timing ablation: keeps the accumulators alive, no index / sign / tie logic)
+#endif
         }
       }
       int sidx = bi * 4 + j;
       // the video's other three lanes (same quad): maximum, ties to the smaller frame slot
+#ifndef EVC_ABLATE_DBOF_SELECT
       {
         const float ob = dpp_f<QP_XOR1>(best);
         const int oi = dpp_i<QP_XOR1>(sidx);
@@ -406,6 +424,7 @@ __device__ __forceinline__ void dbof_tile_epilogue(const GemmOperands& p, const 
         const int oi = dpp_i<QP_XOR2>(sidx);
         if (ob > best || (ob == best && oi < sidx)) { best = ob; sidx = oi; }
       }
+#endif
       xs[r] = sgn * best;
       args |= (uint32_t)(sidx & 0xff) << (8 * r);
       ssum[r] = row16_sum(sum);                                // the wave's 128 rows (4 videos) of this column
@@ -460,22 +479,25 @@ template <> struct is_v2<CfgDbofWalk> { static constexpr bool value = true; };
 template <> struct is_v3<CfgDbofWalk> { static constexpr bool value = true; };
 static_assert(CfgDbofWalk::LDS_BYTES <= 160 * 1024, "ring + eight 4 KB transpose slices");
 
+// ROWPIN (round 6, EVC_DBOF_PIN=rows): the transposed assignment - ROW tile tm lives on XCD tm % 8 and a workgroup walks the COLUMN panels of its
+// row tile: an XCD streams W_c (19 MB) instead of all frame rows (38 MB); panels_per_xcd then counts row tiles per XCD.
+template <bool ROWPIN>
 __global__ __launch_bounds__(CfgDbof::NT) void dbof_cluster_pool_walk_kernel(GemmOperands p, DbofPoolParams e, int tiles_m, int tiles_n,
                                                                              int panels_per_xcd, int walkers) {
   typedef CfgDbof Cfg;
   constexpr int MODE = LOOP_DMA_FIRST | LOOP_NO_PRIO;
   const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
-  const int tn = (i % panels_per_xcd) * 8 + xcd;
-  int tm = i / panels_per_xcd;
+  int tn = ROWPIN ? i / panels_per_xcd : (i % panels_per_xcd) * 8 + xcd;
+  int tm = ROWPIN ? (i % panels_per_xcd) * 8 + xcd : i / panels_per_xcd;
   if (tn >= tiles_n || tm >= tiles_m) return;                   // (workgroup-uniform)
-  const int u0 = tn * Cfg::BU;
   f32x4 acc[Cfg::MI][1][Cfg::NI];
-  gemm_mainloop_v3<Cfg, true, true, MODE, 1>(p, tm * Cfg::BM, u0, lds_dyn, acc);
-  for (; tm < tiles_m; tm += walkers) {
-    const int m0 = tm * Cfg::BM;
+  gemm_mainloop_v3<Cfg, true, true, MODE, 1>(p, tm * Cfg::BM, tn * Cfg::BU, lds_dyn, acc);
+  for (; tm < tiles_m && tn < tiles_n; (ROWPIN ? tn : tm) += walkers) {
+    const int m0 = tm * Cfg::BM, u0 = tn * Cfg::BU;
     gemm_mainloop_v3<Cfg, true, true, MODE, 2>(p, m0, u0, lds_dyn, acc);
     __syncthreads();                                             // every wave has read its last ring slot
-    if (tm + walkers < tiles_m) gemm_mainloop_v3<Cfg, true, true, MODE, 1>(p, (tm + walkers) * Cfg::BM, u0, lds_dyn, acc);
+    const int tm2 = ROWPIN ? tm : tm + walkers, tn2 = ROWPIN ? tn + walkers : tn;
+    if (tm2 < tiles_m && tn2 < tiles_n) gemm_mainloop_v3<Cfg, true, true, MODE, 1>(p, tm2 * Cfg::BM, tn2 * Cfg::BU, lds_dyn, acc);
     dbof_tile_epilogue<Cfg, 32>(p, e, acc, tm, m0, u0, lds_dyn + CfgDbofWalk::RING_BYTES);
   }
 }
@@ -500,10 +522,19 @@ extern "C" int evc_dbof_cluster_pool_fwd(const evc_bf16* r_bn, const evc_bf16* r
   const char* wenv = getenv("EVC_DBOF_WALK");                    // (read per call: the tests switch it; 2 = also below 512 tiles)
   const int walk_on = wenv ? atoi(wenv) : 1;
   const int ppx = ceil_div(tn, 8);                               // column panels per XCD
+  const char* penv = getenv("EVC_DBOF_PIN");                     // rows: row tiles pinned to XCDs, workgroups walk the column panels (A/B, round 6)
+  const int rpx = ceil_div(tm, 8);                               // row tiles per XCD
+  if (walk_on && !r_bn_lo && penv && penv[0] == 'r' && rpx <= 32 && ((long)tm * tn >= 512 || walk_on == 2)) {
+    int walkers = 32 / rpx;
+    walkers = walkers < tn ? walkers : tn;
+    launch_cfg<CfgDbofWalk>(dbof_cluster_pool_walk_kernel<true>, 8 * rpx * walkers, (hipStream_t)stream, p, e, tm, tn, rpx, walkers);
+    EVC_LAUNCH_CHECK();
+    return EVC_OK;
+  }
   if (walk_on && !r_bn_lo && ppx <= 32 && ((long)tm * tn >= 512 || walk_on == 2)) {
     int walkers = 32 / ppx;                                      // 32 workgroups (= CUs) per XCD
     walkers = walkers < tm ? walkers : tm;
-    launch_cfg<CfgDbofWalk>(dbof_cluster_pool_walk_kernel, 8 * ppx * walkers, (hipStream_t)stream, p, e, tm, tn, ppx, walkers);
+    launch_cfg<CfgDbofWalk>(dbof_cluster_pool_walk_kernel<false>, 8 * ppx * walkers, (hipStream_t)stream, p, e, tm, tn, ppx, walkers);
     EVC_LAUNCH_CHECK();
     return EVC_OK;
   }

@@ -130,6 +130,13 @@ class GradReducer:
         # collectives are issued when there is more than one rank; EVC_DP_FORCE=1 (debug) also issues them on a
         # one-rank group, which runs the whole RCCL path of a step on a single-GPU box (scripts/rccl_one_rank.sh)
         self.active = self.world > 1 or (init and os.environ.get("EVC_DP_FORCE") == "1")
+        # TIMING AID (scripts/dp_occupancy_sim.sh, round 6): EVC_DP_SIM_WORLD=W on a ONE-rank forced group - this process does the per-rank WORK
+        # of rank 0 of W: MoE row slabs of 1/W of the rows (MoeHead.shard), factor all-gathers replicated to W x batch rows, slab gathers /
+        # reduce-scatters on the own slab only.  The other W - 1 slabs are never updated: the step's numbers are meaningless, its kernel
+        # times are those of one rank of a W-GPU node with zero time on the wire (EVC_DP_SIM adds the wire time).  Never set in a real run.
+        self.shard_world = self.world
+        if self.world == 1 and self.active and os.environ.get("EVC_DP_SIM_WORLD"):
+            self.shard_world = max(1, int(os.environ["EVC_DP_SIM_WORLD"]))
         self.serial = self.active and serial_comm() and torch.cuda.is_available()
         self._pending = []
 
@@ -143,7 +150,7 @@ class GradReducer:
             # one-GPU stand-in for the fabric (EVC_DP_SIM, scripts/dp_occupancy_sim.sh): after the (empty) one-rank collective a kernel
             # with an RCCL-like footprint holds `blocks` CUs for the time the bytes would spend on the wire at `busbw`
             busbw, blocks, lds_kb, w = sim
-            if kind == "all_gather_slabs":
+            if kind == "all_gather_slabs" and self.shard_world == 1:
                 wire = (w - 1.0) / w * nbytes          # (at one rank the "slab" is the whole matrix)
             else:
                 wire = GradReducer.wire_bytes(kind, nbytes, w)
@@ -238,6 +245,8 @@ class GradReducer:
         def go():
             out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
             torch.distributed.all_gather_into_tensor(out.view(torch.uint8), t.view(torch.uint8), group=self.pg)
+            if self.shard_world != self.world:           # EVC_DP_SIM_WORLD: the contraction length of a W-rank gather
+                out = out.repeat(self.shard_world, *([1] * (out.dim() - 1)))
             return out
         return self._run(go, t, kind="all_gather_factors", nbytes=t.numel() * t.element_size())
 
@@ -252,11 +261,12 @@ class GradReducer:
         rank's slab is written into every rank's `full`, stream-ordered."""
         if not self.active:
             return
-        assert full.is_contiguous() and full.shape[0] == self.world * slab_rows
+        assert full.is_contiguous() and full.shape[0] == self.shard_world * slab_rows
 
         def go():
             own = full[self.rank * slab_rows:(self.rank + 1) * slab_rows].clone()     # (24 MB at world 8: no aliasing of in / out)
-            torch.distributed.all_gather_into_tensor(full.view(torch.uint8), own.view(torch.uint8), group=self.pg)
+            dst = full if self.shard_world == self.world else full[:self.world * slab_rows]      # (EVC_DP_SIM_WORLD: the own slab only)
+            torch.distributed.all_gather_into_tensor(dst.view(torch.uint8), own.view(torch.uint8), group=self.pg)
             return own
         self._run(go, full, kind="all_gather_slabs", nbytes=slab_rows * full.shape[1] * full.element_size())
 
@@ -264,7 +274,7 @@ class GradReducer:
         """full [world * slab_rows, cols] bf16 (contiguous): this rank's contribution to every rank's slab.  Returns [slab_rows, cols] bf16 = the
         SUM over the ranks of slab `rank` (stream-ordered).  RCCL sums in bf16 along the ring; gloo has neither bfloat16 nor reduce_scatter:
         the CPU / shared-GPU tests all-reduce the bf16-rounded values in f32 (the same per-rank rounding, an exact sum) and round the own slab once."""
-        assert full.is_contiguous() and full.dtype == torch.bfloat16 and full.shape[0] == self.world * slab_rows
+        assert full.is_contiguous() and full.dtype == torch.bfloat16 and full.shape[0] == self.shard_world * slab_rows
         if not self.active:
             return full[:slab_rows]
 
@@ -274,7 +284,8 @@ class GradReducer:
                 torch.distributed.all_reduce(f, op=torch.distributed.ReduceOp.SUM, group=self.pg)
                 return f[self.rank * slab_rows:(self.rank + 1) * slab_rows].to(torch.bfloat16)
             own = torch.empty((slab_rows, full.shape[1]), dtype=full.dtype, device=full.device)
-            torch.distributed.reduce_scatter_tensor(own, full, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            src = full if self.shard_world == self.world else full[:self.world * slab_rows]      # (EVC_DP_SIM_WORLD: the own slab only)
+            torch.distributed.reduce_scatter_tensor(own, src, op=torch.distributed.ReduceOp.SUM, group=self.pg)
             return own
         return self._run(go, full, kind="reduce_scatter_grad_bf16", nbytes=full.numel() * 2)
 
@@ -302,10 +313,12 @@ def student_light(student, precision):
     """The "high" precision layout of the STUDENT tower: plain f16 on its L1 level (no K-extensions).  It runs 6 steps per chunk
     over 5 chunks where the teacher runs 15 over 20, so the rounding terms the teacher's layout extends have no time
     to build up: all-f16 leaves 1e-4 on its logits (the teacher: up to 1e-3) - and the extensions would cost its six L1 layer-0
-    launches 2.5x their depth.  Only for students of at most 30 frames (every_n >= 10).  It reads the first segment of the shared K-extended input image.  EVC_HIGH_STUDENT_LIGHT=0: the
-    teacher's layout for both."""
+    launches 2.5x their depth.  Only for students of at most 30 frames (every_n >= 10).  It reads the first segment of the shared K-extended input image.
+    OFF BY DEFAULT since round 6 (EVC_HIGH_STUDENT_LIGHT=1 switches it on): true 16 steps from initialisation (9e-5 on the student's logits), not on
+    towers trained for 512 steps - 7.8e-4 .. 1.64e-3 over 12 weight draws against 3.7 .. 9.1e-4 with the teacher's layout
+    (profiles/r06_precision_robustness_long.txt), for 0.14 ms of the 11.7 ms "high" step."""
     if (student is not None and precision == "high" and student.T <= 30       # (every_n >= 10; a longer student takes the teacher's layout)
-            and os.environ.get("EVC_HIGH_STUDENT_LIGHT", "1") != "0"):
+            and os.environ.get("EVC_HIGH_STUDENT_LIGHT", "0") == "1"):
         student.f16_x_segments = 1
         student.f16_wh_ext_layers = ()
         student.f16_wx_ext_layers = ()
@@ -391,7 +404,7 @@ class DistillGraph:
         if self.dp:                      # row-shard the MoE optimizer state now, while nothing is in flight on any stream
             for tw, red in ((self.teacher, self.reducer), (self.student, self.reducer_s)):
                 if tw is not None:
-                    tw.moe.shard(red.world, red.rank)
+                    tw.moe.shard(red.shard_world, red.rank)
         self.precision = precision       # engine.TowerBase.precision: "bf16" | "high" (1e-3 at trained magnitudes) | "split" (uniform)
         student_light(self.student, precision)
         if precision != "bf16":
@@ -813,7 +826,7 @@ class SingleTowerGraph:
         self.moe = getattr(tower, "moe", None)
         self.fused_moe_update = True
         if self.dp and self.moe is not None and self.moe.can_fuse_update():
-            self.moe.shard(self.reducer.world, self.reducer.rank)      # while nothing is in flight
+            self.moe.shard(self.reducer.shard_world, self.reducer.rank)      # while nothing is in flight
         self._aux = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
 
     def consolidate(self):
@@ -848,7 +861,7 @@ class SingleTowerGraph:
                                "on every rank before a step that does not apply through it")
         # data parallel: the exchange that carries the MoE gradient is chosen by shape (MoeHead.dp_route): factor all-gather (fused update) or
         # bf16 reduce-scatter of the materialised gradient onto the owners' slabs (sharded_update) - either way no all-reduce of those segments
-        route_rs = bool(fuse and self.dp and self.moe.dp_route(self.reducer.world) == "reduce_scatter")
+        route_rs = bool(fuse and self.dp and self.moe.dp_route(self.reducer.shard_world) == "reduce_scatter")
         main = torch.cuda.current_stream(self.device)
         stages = tw.grad_stages()
         fused_names = (self.moe.GATES, self.moe.EXPERTS, self.moe.EBIAS) if fuse else ()    # (the bias gradient comes from the same factors)

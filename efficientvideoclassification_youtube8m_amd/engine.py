@@ -742,16 +742,16 @@ class MoeHead:
         tw, V, Mx, K = self.tw, self.V, self.Mx, self.K
         st = tw.store
         idx = {k: i for i, k in enumerate(tw.names)}
-        if getattr(self, "world", None) != dp.world:
-            self.shard(dp.world, dp.rank)
+        if getattr(self, "world", None) != dp.shard_world:
+            self.shard(dp.shard_world, dp.rank)
         self._wsq_valid = [False, False]
         if not hasattr(self, "_rs_buf"):
             self._rs_buf, self._rs_g32 = {}, {}
         for name, Vn in ((self.GATES, V * (Mx + 1)), (self.EXPERTS, V * Mx)):
             l2 = l2_coeff if name in tw.l2_names else 0.0
             slab = self.slab[name]
-            if name not in self._rs_buf or self._rs_buf[name].shape[0] != slab * dp.world:
-                self._rs_buf[name] = torch.zeros((slab * dp.world, K), dtype=BF16, device=tw.device)      # rows >= Vn stay zero
+            if name not in self._rs_buf or self._rs_buf[name].shape[0] != slab * dp.shard_world:
+                self._rs_buf[name] = torch.zeros((slab * dp.shard_world, K), dtype=BF16, device=tw.device)      # rows >= Vn stay zero
                 self._rs_g32[name] = torch.empty((slab, K), dtype=F32, device=tw.device)
             buf, g32 = self._rs_buf[name], self._rs_g32[name]
             ops.cast_bf16(st.g(name), buf[:Vn])
@@ -827,8 +827,8 @@ class MoeHead:
         dgl, del_, x = self.dgl_full, self.del_full, self.x_full
         if dp is not None:
             dgl, del_, x = dp.all_gather_rows(dgl), dp.all_gather_rows(del_), dp.all_gather_rows(x)
-            if getattr(self, "world", None) != dp.world:      # normally done once by DistillGraph.__init__ (no step in flight)
-                self.shard(dp.world, dp.rank)
+            if getattr(self, "world", None) != dp.shard_world:      # normally done once by DistillGraph.__init__ (no step in flight)
+                self.shard(dp.shard_world, dp.rank)
         rows = x.shape[0]
         idx = {k: i for i, k in enumerate(tw.names)}
         st = tw.store
@@ -1576,7 +1576,7 @@ class HLstmTower(TowerBase):
         # data parallel, bf16: which exchange carries the MoE gradient is chosen by shape (MoeHead.dp_route) - the factor all-gather of the fused
         # update grows with the batch, the reduce-scatter of the materialised gradient does not (cfg 5, B = 1024: 398 vs 169 MB per rank and step)
         route_rs = (dp is not None and aux is not None and early_apply is not None and self.fused_moe_update and self.precision == "bf16"
-                    and self.moe.can_fuse_update() and self.moe.dp_route(dp.world) == "reduce_scatter")
+                    and self.moe.can_fuse_update() and self.moe.dp_route(dp.shard_world) == "reduce_scatter")
         fuse = (aux is not None and early_apply is not None and self.fused_moe_update and not route_rs
                 and (self.precision == "bf16" or dp is None)      # "high" under data parallelism: the lo halves of the row slabs are not gathered
                 and self.moe.can_fuse_update() and (reduce_fn is None or dp is not None)

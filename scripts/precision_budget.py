@@ -236,6 +236,8 @@ def main():
     ap.add_argument("--save", default="")
     ap.add_argument("--load", default="")
     ap.add_argument("--only", default="", help="run only the configurations whose label contains this string")
+    ap.add_argument("--load_sd", default="", help="a checkpoint of tests/_long_train.py ({'sd': TF-named state dict of both towers}); the inputs are then "
+                    "its 4 evaluation videos (round 6: the budget at the 512-step horizon)")
     ap.add_argument("--gpu", action="store_true", help="weights from the GPU training of tests/test_gpu_step.py::_trained_magnitude_weights "
                     "(run on the GPU box); also prints the errors of the real kernels in both precision modes")
     a = ap.parse_args()
@@ -244,7 +246,15 @@ def main():
     q, x, n, labels = mm.synthetic_batch(B, seed=a.seed, dtype=np.float32)
     n[0] = 300
     x[np.arange(300)[None, :] >= n[:, None]] = 0.0
-    if a.gpu:
+    if a.load_sd:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+        import _long_train as lt
+        x, n, labels = lt.eval_videos(16)
+        B = 4
+        sd = torch.load(a.load_sd, weights_only=False)["sd"]
+        teacher = {k[len("model/"):]: v.float().cpu() for k, v in sd.items() if k.startswith("model/")}
+        student = {k[len("model_student/"):]: v.float().cpu() for k, v in sd.items() if k.startswith("model_student/")}
+    elif a.gpu:
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
         import test_gpu_step as tgs
         sd = tgs._trained_magnitude_weights(B, x, n, labels, deterministic=os.environ.get("EVC_BUDGET_DETERMINISTIC") == "1")   # default: a fresh draw per run (margin study)

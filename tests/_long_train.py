@@ -124,7 +124,7 @@ def main():
     for i in range(pool_n):
         x, n, labels = pool_batch(i, B)
         pool.append((torch.from_numpy(x).to(dev), torch.from_numpy(labels.astype(np.uint8)).to(dev), torch.from_numpy(n).to(dev), n))
-    g = DistillGraph(B, every_n=10, device=dev, seed=3, base_learning_rate=lr)
+    g = DistillGraph(B, every_n=10, device=dev, seed=int(os.environ.get("EVC_LONG_SEED", "3")), base_learning_rate=lr)     # (EVC_LONG_SEED: another deterministic draw)
     os.makedirs(out_dir, exist_ok=True)
     for it in range(1, marks[-1] + 1):
         xd, yd, nd, nh = pool[(it - 1) % pool_n]

@@ -21,8 +21,9 @@ from oracle import model_math as mm
 from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
 rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
 torch.cuda.set_device(0)
-if world > 1:
-    torch.distributed.init_process_group("gloo", init_method="tcp://127.0.0.1:" + port, rank=rank, world_size=world)
+FORCED = os.environ.get("EVC_DP_FORCE") == "1"          # a ONE-rank group whose collectives are all issued (backend from EVC_TEST_BACKEND: nccl = RCCL)
+if world > 1 or FORCED:
+    torch.distributed.init_process_group(os.environ.get("EVC_TEST_BACKEND", "gloo"), init_method="tcp://127.0.0.1:" + port, rank=rank, world_size=world)
 GB, F, V = 8, 128, 200      # MoE gates [600][256]: 5 row tiles -> slabs of 384 / 216 rows on two ranks
 q, x, n, labels = mm.synthetic_batch(GB, seed=21, feature_size=F, vocab_size=V, dtype=np.float32)
 b = GB // world
@@ -49,8 +50,10 @@ if rank == 0:
     sd.update({k: v.cpu() for k, v in g.student.state_dict().items()})
     sd["losses"] = rep
     sd["global_step"] = g.global_step
+    sd["backend"] = torch.distributed.get_backend() if (world > 1 or FORCED) else None
+    sd["dp_active"] = bool(g.dp)
     torch.save(sd, out)
-if world > 1:
+if world > 1 or FORCED:
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 '''
@@ -150,6 +153,29 @@ def test_two_rank_bf16_gradient_payload_bounds_its_effect_on_the_update(tmp_path
             assert far < (0.05 if small else 0.02) and rms < (2e-4 if small else 1.5e-4), (k, far, rms)
     assert moved > 0, "the bf16 payload changed nothing: the option did not reach the reducer"
     print("f32 vs bf16 gradient payload after two iterations: max |dw| %.2e; (share > 2e-4, rms) per tensor: %s" % (worst, report))
+
+
+@pytest.mark.parametrize("route", ["factors", "reduce_scatter"])
+def test_one_rank_rccl_group_runs_the_data_parallel_step(tmp_path, route):
+    """The data-parallel graph on backend "nccl" (= RCCL) with ONE rank (EVC_DP_FORCE=1: every collective of the step is issued on the one-rank
+    communicators - gradient all-reduces, factor all-gathers / gradient reduce-scatter, slab gathers, norm and loss sums): two iterations must
+    land on the plain single-process step's losses and weights.  RCCL refuses two ranks per device and the test box has one GPU, so this is
+    the only place where the suite loads RCCL and runs its kernels in the step's streams; the two-rank arithmetic is the gloo tests above."""
+    one, rc = str(tmp_path / "one.pt"), str(tmp_path / "rccl.pt")
+    _run(1, one, 29671)
+    _run(1, rc, 29672 + (route == "factors"), env={"EVC_DP_FORCE": "1", "EVC_TEST_BACKEND": "nccl", "EVC_DP_MOE_ROUTE": route, "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    a, b = torch.load(one), torch.load(rc)
+    assert a["backend"] is None and not a["dp_active"] and b["backend"] == "nccl" and b["dp_active"]
+    assert a["global_step"] == b["global_step"] == 4
+    for k in ("label_loss", "student_loss_state", "pred_loss", "student_label_loss"):
+        assert abs(a["losses"][k] - b["losses"][k]) <= 2e-3 * abs(a["losses"][k]) + 1e-6, (k, a["losses"], b["losses"])
+    for k, v in a.items():
+        if torch.is_tensor(v) and v.dtype == torch.float32 and v.numel() > 1:
+            d = (v - b[k]).abs()
+            if route == "reduce_scatter" and "classifier/" in k and v.numel() > 10000:      # the gradient crosses as bf16: share / RMS bound (see below)
+                assert d.max().item() < 2.5e-3 and float((d > 2e-4).float().mean()) < 0.02 and float(d.square().mean().sqrt()) < 1.5e-4, k
+            else:
+                assert d.max().item() < 2e-4, (k, d.max().item())
 
 
 def test_two_rank_moe_gradient_exchange_routes(tmp_path):
@@ -291,7 +317,7 @@ rng = np.random.default_rng(4)
 for k in tw.names:                                   # non-trivial BN scale / offset so that their gradients matter
     if k.endswith("/gamma") or k.endswith("/beta"):
         tw.store.p(k).add_(torch.from_numpy(rng.standard_normal(tw.store.p(k).shape).astype(np.float32) * 0.2).cuda())
-g = SingleTowerGraph(tw, base_learning_rate=1e-2)
+g = SingleTowerGraph(tw, base_learning_rate=float(os.environ.get("EVC_TEST_LR", "1e-2")))
 xd = torch.from_numpy(x[sl]).cuda(); nd = torch.from_numpy(n[sl]).cuda(); yd = torch.from_numpy(labels[sl].astype(np.uint8)).cuda()
 ud = torch.from_numpy(u[sl]).cuda()
 g.step(xd, yd, nd, uniform=ud, apply=False)
@@ -318,7 +344,7 @@ def test_dbof_two_ranks_match_single_process(tmp_path, kind):
     outs = []
     # "dbof_rs": the MoE gradient by bf16 reduce-scatter onto the owners' slabs (MoeHead.sharded_update; what cfg 4's shape picks at 8 ranks)
     rs = kind == "dbof_rs"
-    env = dict(os.environ, EVC_DP_MOE_ROUTE="reduce_scatter") if rs else None
+    env = dict(os.environ, EVC_DP_MOE_ROUTE="reduce_scatter", EVC_TEST_LR="1e-3") if rs else None      # (both runs, one and two ranks, at lr 1e-3)
     kind = "dbof" if rs else kind
     for world, port in ((1, 29641), (2, 29642)):
         out = str(tmp_path / ("w%d.pt" % world))
@@ -347,10 +373,14 @@ def test_dbof_two_ranks_match_single_process(tmp_path, kind):
     tol = 2e-3 if kind == "dbof" else 8e-3
     for k, v in a["sd"].items():
         d = (v - b["sd"][k]).abs()
-        if rs and "classifier/" in k and v.numel() > 1000:
-            # each rank's MoE gradient is rounded to bf16 once before the sum: an element whose summed gradient is smaller than that rounding
-            # can take Adam steps (1e-2 each) of the other sign - bounded by share and RMS (as the bf16 LSTM payload above), not by the maximum
-            far, rms = float((d > tol).float().mean()), float(d.square().mean().sqrt())
-            assert d.max().item() < 4.5e-2 and far < 0.02 and rms < 1.5e-3, (k, d.max().item(), far, rms)
+        if rs:
+            # each rank's MoE gradient is rounded to bf16 once before the sum: an element whose summed gradient is smaller than that rounding can
+            # take Adam steps (lr = 1e-3 each here) of the other sign, and the second iteration of every OTHER tensor then sees slightly different
+            # MoE weights - bounded by share and RMS (as the bf16 LSTM payload above), the maximum by a flipped update in both iterations
+            if not v.dtype.is_floating_point or v.numel() < 2:
+                continue
+            far, rms = float((d > 2e-4).float().mean()), float(d.square().mean().sqrt())
+            small = v.numel() < 10000
+            assert d.max().item() < 2.5e-3 and far < (0.08 if small else 0.02) and rms < (3e-4 if small else 1.5e-4), (k, d.max().item(), far, rms)
             continue
         assert d.max().item() < tol, (k, d.max().item())
