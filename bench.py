@@ -275,7 +275,7 @@ def run_hlstm(device, rank, world, B, mode, every_n, steps, warmup, all_full=Fal
             for (m, nl, fl) in tower.l1.profile_fwd_layers(reps=3):
                 ms_i, launches_i, flops_i = ms_i + m, launches_i + nl, flops_i + fl
         traffic = mfma_busy = pmc_src = None
-        for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):    # HBM bytes / MFMA busy from the committed --pmc passes
+        for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):    # HBM bytes / MFMA busy from the committed --pmc passes
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     pmc = json.load(f)

@@ -448,6 +448,16 @@ class DistillGraph:
                 f = [int(v) for v in m.split(":")]
                 self._opt_t = cu_masked_stream(self.device, f[0], f[1] if len(f) > 1 else 0)
                 self._opt_s = self._opt_t if os.environ.get("EVC_OPT_CU_MASK_SHARED", "1") == "1" else cu_masked_stream(self.device, f[0], f[1] if len(f) > 1 else 0)
+            # Single-tower graphs (cfg 2 teacher only, cfg 5 student only) use two of the four streams: the tower's collectives + optimizer launches
+            # take a THIRD one (the other tower's idle aux stream) instead of queueing on the aux stream between the weight-gradient products - under
+            # data parallelism that stream is the step's critical path and every byte on the wire was exposed (cfg 5 as rank 0 of 8 with stand-in
+            # collectives at 300 GB/s: 5.67 ms; profiles/r06_dp_sim_world.txt).  EVC_OPT_SPARE_STREAM=0 / 1 forces it off / on (default: under DP).
+            spare = os.environ.get("EVC_OPT_SPARE_STREAM")
+            if (spare == "1" or (spare is None and self.dp)) and os.environ.get("EVC_SINGLE_STREAM") != "1" and not m:
+                if mode == "student":
+                    self._opt_s = self._aux_t
+                elif mode == "teacher":
+                    self._opt_t = self._aux_s
             self._ev_fwd, self._ev_student, self._ev_in = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
 
     # ---- data-parallel gradient reduction -------------------------------------
