@@ -33,11 +33,12 @@ SIGNATURES = {
     "evc_cast_f32_to_f16_wide": [vp, i64, i32, i32, i32, i32, i32, vp, vp],
     "evc_cast_f32_to_bf16_wide": [vp, i64, i32, i32, vp, i64, i32, vp],
     "evc_lstm_layer_fwd_f16": [vp, i64, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, i64, vp, vp, vp, vp, vp],
-    "evc_lstm_layer_fwd_f16_fp8lo": [vp, i64, i32, i64, i32, vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp],
+    "evc_lstm_layer_fwd_f16_fp8lo": [vp, i64, i32, i64, i32, vp, vp, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp],
     "evc_lstm_layer_fwd_f16_dith": [vp, i64, i32, i64, i32, vp, i64, vp, i64, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp],
     "evc_cast_f32_to_f16_dither": [vp, i64, i32, i64, C.c_uint32, vp, i64, i64, vp],
-    "evc_lstm_stack2_fwd_f16_fp8lo": [vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp],
+    "evc_lstm_stack2_fwd_f16_fp8lo": [vp, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp],
     "evc_cast_f32_to_fp8_lo": [vp, i64, i32, i32, i32, i32, i32, vp, i64, vp],
+    "evc_cast_f32_to_fp8_lohi": [vp, i64, i32, i32, i32, i32, i32, vp, i64, vp],
     "evc_lstm_layer_bwd": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "evc_transpose_to_bf16": [vp, i32, i64, i32, i32, vp, i64, i32, i32, vp],
     "evc_cast_f32_to_bf16": [vp, i64, i32, i32, vp, i64, vp],
@@ -72,7 +73,7 @@ SIGNATURES = {
     "evc_clip_adam_small": [i32, vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, vp],
     "evc_sqnorm2_partials": [vp, i64, vp, i64, vp, vp],
     "evc_lstm_adam_fused": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, f32, f32, f32, f32, f32, vp, vp, i64, vp, i64, i32, i32,
-                            vp, i64, i32, i32, i32, i32, vp],
+                            vp, i64, i32, i32, i32, i32, i32, vp],
     "evc_adam2d_fused": [vp, vp, vp, vp, i32, i32, vp, vp, f32, f32, f32, f32, f32, vp, vp, i64, vp, i64, vp, i64, i32, i32, i32, vp],
     "evc_meanpool_fwd": [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp],
     "evc_sigmoid_fwd": [vp, i64, vp],

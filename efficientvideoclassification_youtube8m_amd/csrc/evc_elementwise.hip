@@ -637,8 +637,10 @@ extern "C" int evc_cast_f32_to_f16_fp8x_dyn(const float* in, int64_t ld_in, int 
 // 3-4 significant bits of their low-order half).  hi_cols > 0 (the layer that reads the input frames): behind the first hi_cols columns'
 // low-order halves comes a full-value image of those columns, hi(w) = e4m3(clamp(w * 2^hi_exp)) - what the INPUT's low-order half
 // e4m3((x - f16(x)) 2^18) is contracted against: out rows [lo(W[:, :hi_cols]) | hi(W[:, :hi_cols]) | lo(W[:, hi_cols:])].
+// hi_tail (round 6): the columns behind the first hi_cols get their full-value image too - rows [lo(A) | hi(A) | lo(B) | hi(B)] with A = W[:, :hi_cols],
+// B = the rest (2C bytes): what a step contracts [a8 | a_lo8 | b8 | b_lo8] activation rows against (both operands' roundings corrected).
 __global__ void cast_fp8_lo_kernel(const float* __restrict__ in, long ld_in, int R, int C, float lo_scale, int hi_cols, float hi_scale,
-                                   uint8_t* __restrict__ out, long ld_out) {
+                                   uint8_t* __restrict__ out, long ld_out, int hi_tail) {
   const int c4 = C >> 2;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)R * c4; i += (long)gridDim.x * blockDim.x) {
     const long r = i / c4;
@@ -651,28 +653,39 @@ __global__ void cast_fp8_lo_kernel(const float* __restrict__ in, long ld_in, int
     int w8 = __builtin_amdgcn_cvt_pk_fp8_f32(d[0], d[1], 0, false);
     w8 = __builtin_amdgcn_cvt_pk_fp8_f32(d[2], d[3], w8, true);
     *(int*)(out + r * ld_out + (c < hi_cols ? c : c + hi_cols)) = w8;
-    if (c < hi_cols) {
+    if (c < hi_cols || hi_tail) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) d[k] = fminf(fmaxf(x[k] * hi_scale, -448.f), 448.f);
       int h8 = __builtin_amdgcn_cvt_pk_fp8_f32(d[0], d[1], 0, false);
       h8 = __builtin_amdgcn_cvt_pk_fp8_f32(d[2], d[3], h8, true);
-      *(int*)(out + r * ld_out + hi_cols + c) = h8;
+      *(int*)(out + r * ld_out + (c < hi_cols ? hi_cols + c : (long)C + c)) = h8;      // (B part: 2 hi_cols + (C - hi_cols) + (c - hi_cols))
     }
   }
 }
 
-extern "C" int evc_cast_f32_to_fp8_lo(const float* in, int64_t ld_in, int R, int C, int lo_exp, int hi_cols, int hi_exp, uint8_t* out, int64_t ld_out,
-                                      void* stream) {
+static int cast_fp8_lo_impl(const float* in, int64_t ld_in, int R, int C, int lo_exp, int hi_cols, int hi_exp, int hi_tail, uint8_t* out, int64_t ld_out,
+                            void* stream) {
   EVC_REQUIRE(R > 0 && C > 0 && C % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 4) == 0,
               EVC_ERR_BAD_ALIGN, "evc_cast_f32_to_fp8_lo: C=%d, ld_in=%ld, ld_out=%ld must be multiples of 4 (16-byte loads, 4-byte stores)", C, (long)ld_in, (long)ld_out);
-  EVC_REQUIRE(lo_exp >= 0 && lo_exp <= 60 && hi_cols >= 0 && hi_cols <= C && hi_cols % 4 == 0 && hi_exp >= -30 && hi_exp <= 30 && ld_out >= (long)C + hi_cols,
-              EVC_ERR_BAD_ARG, "evc_cast_f32_to_fp8_lo: lo_exp=%d hi_cols=%d (%%4, <= C) hi_exp=%d ld_out=%ld (>= C + hi_cols)", lo_exp, hi_cols, hi_exp, (long)ld_out);
+  EVC_REQUIRE(lo_exp >= 0 && lo_exp <= 60 && hi_cols >= 0 && hi_cols <= C && hi_cols % 4 == 0 && hi_exp >= -30 && hi_exp <= 30 &&
+              ld_out >= (hi_tail ? 2L * C : (long)C + hi_cols), EVC_ERR_BAD_ARG,
+              "evc_cast_f32_to_fp8_lo: lo_exp=%d hi_cols=%d (%%4, <= C) hi_exp=%d ld_out=%ld (>= C + hi_cols; with hi_tail 2C)", lo_exp, hi_cols, hi_exp, (long)ld_out);
   const long n = (long)R * (C / 4);
   const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
   hipLaunchKernelGGL(cast_fp8_lo_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, ld_in, R, C, ldexpf(1.0f, lo_exp), hi_cols,
-                     ldexpf(1.0f, hi_exp), out, ld_out);
+                     ldexpf(1.0f, hi_exp), out, ld_out, hi_tail);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
+}
+extern "C" int evc_cast_f32_to_fp8_lo(const float* in, int64_t ld_in, int R, int C, int lo_exp, int hi_cols, int hi_exp, uint8_t* out, int64_t ld_out,
+                                      void* stream) {
+  return cast_fp8_lo_impl(in, ld_in, R, C, lo_exp, hi_cols, hi_exp, 0, out, ld_out, stream);
+}
+// ... with the full-value image of EVERY column: out rows [lo(W[:, :hi_cols]) | hi(W[:, :hi_cols]) | lo(W[:, hi_cols:]) | hi(W[:, hi_cols:])] (2C bytes;
+// hi_cols = 0: [lo(W) | hi(W)]) - the B8 rows of the h_lo = 1 forms of evc_lstm_layer_fwd_f16_fp8lo / evc_lstm_stack2_fwd_f16_fp8lo (round 6).
+extern "C" int evc_cast_f32_to_fp8_lohi(const float* in, int64_t ld_in, int R, int C, int lo_exp, int hi_cols, int hi_exp, uint8_t* out, int64_t ld_out,
+                                        void* stream) {
+  return cast_fp8_lo_impl(in, ld_in, R, C, lo_exp, hi_cols, hi_exp, 1, out, ld_out, stream);
 }
 
 // K-extended f16 image of an ACTIVATION matrix [R][C] f32: out rows [f16(x) | (x - f16(x))*64 | f16(x)/64] (the first nseg segments) -

@@ -19,7 +19,9 @@ struct LstmFwdParams {
   int h_wide = 0;                    // F16 only: 1 = hout rows are WIDE, [M][2H] = [f16(h_t) | f16(h_t)/64] - the activation operand of a
                                      // contraction whose weights are K-extended by their low-order halves (evc_lstm_stack2_fwd_f16);
                                      // 2 = hout rows are [f16(h_t) (H halfwords) | e4m3(h_t * 2^7) (H bytes)], row stride 3H bytes - the
-                                     // operands of a step whose low-order weight halves are contracted in fp8 (evc_lstm_layer_fwd_f16_fp8lo)
+                                     // operands of a step whose low-order weight halves are contracted in fp8 (evc_lstm_layer_fwd_f16_fp8lo);
+                                     // 3 (round 6) = 2 + the low-order half of h itself: rows of 4H bytes [f16(h_t) | e4m3(h_t 2^7) |
+                                     // e4m3((h_t - f16(h_t)) 2^18)] - contracted against [lo(W) | hi(W)] weight rows (h_lo = 1 of the same entries)
 };
 
 
@@ -90,14 +92,17 @@ __device__ __forceinline__ void lstm_fwd_epilogue(const GemmOperands& p, const L
       const uint32_t hu = (uint32_t)m * (uint32_t)H + (uint32_t)u;                      // element index in an [M][H] slab
       const uint32_t su4 = ((uint32_t)rm[mi] * (uint32_t)e.ld_state + (uint32_t)u) * 4u;   // byte offset in c_state / h_state
       // byte offset of this lane's 4 units in hout: FP8 rows are [f16(h) (H halfwords) | e4m3 (H bytes)] = 3H bytes, wide f16 rows 2H halfwords
-      const bool rows8 = FP8 && e.h_wide == 2;        // (an FP8 launch with h_wide 0 - evc_lstm_layer_fwd_f16_dith, whose e4m3 stages are the input's only - writes plain f16 rows)
-      const uint32_t hw2 = rows8 ? (uint32_t)m * (uint32_t)(3 * H) + (uint32_t)u * 2u : (F16 && e.h_wide == 1) ? ((uint32_t)m * (uint32_t)(2 * H) + (uint32_t)u) * 2u : hu * 2u;
-      const uint32_t h8o = (uint32_t)m * (uint32_t)(3 * H) + (uint32_t)(2 * H) + (uint32_t)u;      // (FP8: the row's e4m3 part)
+      const bool rows8 = FP8 && e.h_wide >= 2;        // (an FP8 launch with h_wide 0 - evc_lstm_layer_fwd_f16_dith, whose e4m3 stages are the input's only - writes plain f16 rows)
+      const bool rows8lo = FP8 && e.h_wide == 3;      // ... + the e4m3 image of h's own low-order half: rows of 4H bytes
+      const uint32_t rowb = (uint32_t)m * (uint32_t)((rows8lo ? 4 : 3) * H);
+      const uint32_t hw2 = rows8 ? rowb + (uint32_t)u * 2u : (F16 && e.h_wide == 1) ? ((uint32_t)m * (uint32_t)(2 * H) + (uint32_t)u) * 2u : hu * 2u;
+      const uint32_t h8o = rowb + (uint32_t)(2 * H) + (uint32_t)u;      // (FP8: the row's e4m3 part)
       const u32x2_t z2 = {0u, 0u};
       if (e.t >= ln[mi]) {          // dynamic_rnn: state copied through, zero output
         store8<SP>(e.hout, hw2, z2);
         if (rows8) store4<SP>(e.hout, h8o, 0u);
         else if (F16 && e.h_wide == 1) store8<SP>(e.hout, hw2 + (uint32_t)H * 2u, z2);
+        if (rows8lo) store4<SP>(e.hout, h8o + (uint32_t)H, 0u);
         if (F16) store8<SP>(e.hout_lo, hu * 2u, z2);
         if (SPLIT) {
           const uint32_t wo = ((uint32_t)m * (uint32_t)(2 * H) + (uint32_t)u) * 2u;
@@ -147,6 +152,13 @@ __device__ __forceinline__ void lstm_fwd_epilogue(const GemmOperands& p, const L
           int w8 = __builtin_amdgcn_cvt_pk_fp8_f32(hn[0] * 128.0f, hn[1] * 128.0f, 0, false);
           w8 = __builtin_amdgcn_cvt_pk_fp8_f32(hn[2] * 128.0f, hn[3] * 128.0f, w8, true);
           store4<SP>(e.hout, h8o, (uint32_t)w8);
+          if (rows8lo) {            // e4m3((h - f16(h)) 2^18): |h - f16(h)| <= 2^-12, at most 64 - against e4m3(W 2^6), the same 2^-24 as 7 + 17
+            const float l0 = (hn[0] - f16_to_f32((f16_t)(p01 & 0xffffu))) * 262144.0f, l1 = (hn[1] - f16_to_f32((f16_t)(p01 >> 16))) * 262144.0f;
+            const float l2 = (hn[2] - f16_to_f32((f16_t)(p23 & 0xffffu))) * 262144.0f, l3 = (hn[3] - f16_to_f32((f16_t)(p23 >> 16))) * 262144.0f;
+            int v8 = __builtin_amdgcn_cvt_pk_fp8_f32(l0, l1, 0, false);
+            v8 = __builtin_amdgcn_cvt_pk_fp8_f32(l2, l3, v8, true);
+            store4<SP>(e.hout, h8o + (uint32_t)H, (uint32_t)v8);
+          }
         } else if (e.h_wide == 1) { // f16(h)/64: the operand of the weights' low-order halves (scaled by 64)
           const float s0 = f16_to_f32((f16_t)(p01 & 0xffffu)) * (1.0f / 64.0f), s1 = f16_to_f32((f16_t)(p01 >> 16)) * (1.0f / 64.0f);
           const float s2 = f16_to_f32((f16_t)(p23 & 0xffffu)) * (1.0f / 64.0f), s3 = f16_to_f32((f16_t)(p23 >> 16)) * (1.0f / 64.0f);
@@ -572,8 +584,11 @@ static inline int pick_fwd_tile_v3(int rows, int H) {
 // the row start (any K-extension of the input the caller likes, against the first kx16 columns of wT16) and kx8 e4m3 bytes at byte
 // offset x8_off of the same row (row stride ldx halfwords); hbuf rows [T+1][M]: [f16(h_t) (H halfwords) | e4m3(h_t 2^7) (H bytes)] (3H
 // bytes: what the next layer takes as its x rows with kx16 = H, x8_off = 2H, kx8 = H); wT16 [4H][kx16 + H] f16, wT8 [4H][kx8 + H] bytes.
+// h_lo = 1 (round 6): the low-order half of h is corrected too - hbuf rows are 4H bytes [f16(h) | e4m3(h 2^7) | e4m3((h - f16(h)) 2^18)] and the
+// h-part of wT8's rows is [lo(Wh) | hi(Wh)] (evc_cast_f32_to_fp8_lo with hi_tail): wT8 [4H][kx8 + 2H]; a layer above reads those rows with
+// x8_off = 2H, kx8 = 2H against [lo(Wx) | hi(Wx)].
 extern "C" int evc_lstm_layer_fwd_f16_fp8lo(const evc_f16* x, int64_t ldx, int kx16, int64_t x8_off, int kx8, const evc_f16* wT16,
-                                            const uint8_t* wT8, int w8_scale_exp, const float* bias, const int32_t* len,
+                                            const uint8_t* wT8, int w8_scale_exp, int h_lo, const float* bias, const int32_t* len,
                                             int T, int M, int H, evc_f16* hbuf, evc_bf16* hbuf_bf16, float* c_state, float* h_state,
                                             int64_t ld_state, void* gates, evc_bf16* c_all, const int32_t* row_map,
                                             const int32_t* rows_per_step, void* stream) {
@@ -585,7 +600,9 @@ extern "C" int evc_lstm_layer_fwd_f16_fp8lo(const evc_f16* x, int64_t ldx, int k
               ((uintptr_t)wT8 % 16) == 0 && ((uintptr_t)hbuf % 16) == 0 && ((uintptr_t)hbuf_bf16 % 8) == 0, EVC_ERR_BAD_ALIGN,
               "evc_lstm_layer_fwd_f16_fp8lo: ldx=%ld (%%8), x8_off=%ld (%%16), 16-byte aligned operands", (long)ldx, (long)x8_off);
   EVC_REQUIRE(w8_scale_exp >= 0 && w8_scale_exp <= 60, EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd_f16_fp8lo: w8_scale_exp=%d", w8_scale_exp);
-  const long ldh = 3L * H / 2;                       // halfwords per hbuf row
+  EVC_REQUIRE(h_lo == 0 || h_lo == 1, EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd_f16_fp8lo: h_lo=%d", h_lo);
+  const long ldh = h_lo ? 2L * H : 3L * H / 2;      // halfwords per hbuf row
+  const int kh8 = h_lo ? 2 * H : H;                 // e4m3 bytes of the h-part per row
   EVC_REQUIRE(ring_operand_ok(M, ldx > ldh ? ldx : ldh) && ring_operand_ok(4L * H, (long)kx16 + H), EVC_ERR_BAD_SHAPE,
               "evc_lstm_layer_fwd_f16_fp8lo: a time slab or the kernel spans 4 GiB or more");
   EVC_REQUIRE(fwd_tail_ok(M, H, ld_state), EVC_ERR_BAD_SHAPE, "LSTM forward: a gate-record / state slab spans 4 GiB or more (M=%d H=%d ld_state=%ld)", M, H, (long)ld_state);
@@ -615,15 +632,15 @@ extern "C" int evc_lstm_layer_fwd_f16_fp8lo(const evc_f16* x, int64_t ldx, int k
     p.A2 = hprev; p.lda2 = ldh;
     p.B = (const bf16_t*)wT16; p.ldb = (long)kx16 + H;
     p.A3 = (const uint8_t*)xt + x8_off; p.lda3 = ldx * 2; p.nk3 = kx8 / 128;
-    p.A4 = (const uint8_t*)(hprev + H); p.lda4 = ldh * 2; p.nk4 = t == 0 ? 0 : H / 128;
-    p.B8 = wT8; p.ldb8 = (long)kx8 + H;
+    p.A4 = (const uint8_t*)(hprev + H); p.lda4 = ldh * 2; p.nk4 = t == 0 ? 0 : kh8 / 128;
+    p.B8 = wT8; p.ldb8 = (long)kx8 + kh8;
     p.scale8_exp = -(7 + w8_scale_exp);
     const int k1 = kx16, k2 = t == 0 ? 0 : H;
     LstmFwdParams e;
     e.zx = nullptr; e.ldzx = 0;
     e.bias = bias; e.len = len; e.t = t;
     e.c_state = c_state; e.h_state = h_state; e.ld_state = ld_state;
-    e.hout = hb + (long)(t + 1) * M * ldh; e.h_wide = 2;
+    e.hout = hb + (long)(t + 1) * M * ldh; e.h_wide = h_lo ? 3 : 2;
     e.hout_lo = hbuf_bf16 + (long)(t + 1) * M * H;
     e.gates = gates ? (uint2*)gates + (long)t * M * H : nullptr;
     e.c_hist = c_all ? c_all + (long)(t + 1) * M * H : nullptr;
@@ -977,8 +994,11 @@ extern "C" int evc_lstm_stack2_fwd_f16(const evc_f16* x, int x_segments, const e
 // (K-extended input of the hoisted product, as before); wT0 [4H][x_segments Kin + H] f16 = [Wx segments | f16(Wh)], wT0_8 [4H][H] bytes =
 // e4m3((Wh - f16(Wh)) 2^w8_scale_exp); wT1 [4H][2H] f16, wT1_8 [4H][2H] bytes; h0_rows / h1_rows [(T+1)][M] rows of 3H bytes = [f16(h) |
 // e4m3(h 2^7)].  H % 128 == 0, H >= 512.
+// h_lo = 1 (round 6): the activations' low-order halves are corrected as well - h rows of 4H bytes [f16(h) | e4m3(h 2^7) | e4m3((h - f16(h)) 2^18)],
+// wT0_8 [4H][2H] = [lo(Wh0) | hi(Wh0)], wT1_8 [4H][4H] = [lo(Wx1) | hi(Wx1) | lo(Wh1) | hi(Wh1)] (evc_cast_f32_to_fp8_lo with hi_tail): layer 1
+// walks 32 f16 + 32 e4m3 stages.
 extern "C" int evc_lstm_stack2_fwd_f16_fp8lo(const evc_f16* x, int x_segments, const evc_f16* wT0, const uint8_t* wT0_8, const float* bias0,
-                                             const evc_f16* wT1, const uint8_t* wT1_8, int w8_scale_exp, const float* bias1,
+                                             const evc_f16* wT1, const uint8_t* wT1_8, int w8_scale_exp, int h_lo, const float* bias1,
                                              const int32_t* len, int T, int M, int Kin, int H, float* zx_ws,
                                              evc_f16* h0_rows, evc_f16* h1_rows, evc_bf16* hbuf0, evc_bf16* hbuf1,
                                              float* c_state0, float* h_state0, float* c_state1, float* h_state1, int64_t ld_state,
@@ -988,8 +1008,10 @@ extern "C" int evc_lstm_stack2_fwd_f16_fp8lo(const evc_f16* x, int x_segments, c
   EVC_REQUIRE(x && wT0 && wT0_8 && wT1 && wT1_8 && zx_ws && h0_rows && h1_rows && hbuf0 && hbuf1, EVC_ERR_BAD_ARG, "evc_lstm_stack2_fwd_f16_fp8lo: NULL operand");
   EVC_REQUIRE(x_segments >= 1 && x_segments <= 3 && w8_scale_exp >= 0 && w8_scale_exp <= 60, EVC_ERR_BAD_ARG,
               "evc_lstm_stack2_fwd_f16_fp8lo: x_segments=%d w8_scale_exp=%d", x_segments, w8_scale_exp);
+  EVC_REQUIRE(h_lo == 0 || h_lo == 1, EVC_ERR_BAD_ARG, "evc_lstm_stack2_fwd_f16_fp8lo: h_lo=%d", h_lo);
   const long Kx = (long)x_segments * Kin;
-  const long ldw0 = Kx + H, ldh = 3L * H / 2;
+  const long ldw0 = Kx + H, ldh = h_lo ? 2L * H : 3L * H / 2;
+  const int kh8 = h_lo ? 2 * H : H;                 // e4m3 bytes per h row: [h8] or [h8 | h_lo8]
   EVC_REQUIRE(ring_operand_ok(M, ldh) && ring_operand_ok(4L * H, ldw0) && ring_operand_ok(4L * H, 2L * H), EVC_ERR_BAD_SHAPE,
               "evc_lstm_stack2_fwd_f16_fp8lo: an operand spans 4 GiB or more");
   EVC_REQUIRE(fwd_tail_ok(M, H, ld_state), EVC_ERR_BAD_SHAPE, "LSTM forward: a gate-record / state slab spans 4 GiB or more (M=%d H=%d ld_state=%ld)", M, H, (long)ld_state);
@@ -1021,13 +1043,13 @@ extern "C" int evc_lstm_stack2_fwd_f16_fp8lo(const evc_f16* x, int x_segments, c
       const bf16_t* hprev = h0r + (long)t * M * ldh;
       pa.A1 = hprev; pa.lda1 = ldh; k1a = (t == 0) ? 0 : H; pa.A2 = hprev; pa.lda2 = ldh;
       pa.B = (const bf16_t*)wT0 + Kx;
-      pa.A3 = (const uint8_t*)(hprev + H); pa.lda3 = ldh * 2; pa.nk3 = (t == 0) ? 0 : H / 128;
+      pa.A3 = (const uint8_t*)(hprev + H); pa.lda3 = ldh * 2; pa.nk3 = (t == 0) ? 0 : kh8 / 128;
       pa.A4 = pa.A3; pa.lda4 = pa.lda3; pa.nk4 = 0;
-      pa.B8 = wT0_8; pa.ldb8 = H; pa.scale8_exp = -(7 + w8_scale_exp);
+      pa.B8 = wT0_8; pa.ldb8 = kh8; pa.scale8_exp = -(7 + w8_scale_exp);
       ea.zx = zx_ws + (long)t * M * 4 * H; ea.ldzx = 4L * H;
       ea.bias = bias0; ea.len = len; ea.t = t;
       ea.c_state = c_state0; ea.h_state = h_state0; ea.ld_state = ld_state;
-      ea.hout = h0r + (long)(t + 1) * M * ldh; ea.h_wide = 2;
+      ea.hout = h0r + (long)(t + 1) * M * ldh; ea.h_wide = h_lo ? 3 : 2;
       ea.hout_lo = hbuf0 + (long)(t + 1) * M * H;
       ea.gates = gates0 ? (uint2*)gates0 + (long)t * M * H : nullptr;
       ea.c_hist = c_all0 ? c_all0 + (long)(t + 1) * M * H : nullptr;
@@ -1042,13 +1064,13 @@ extern "C" int evc_lstm_stack2_fwd_f16_fp8lo(const evc_f16* x, int x_segments, c
       pb.A1 = xin; pb.lda1 = ldh; k1b = H;
       pb.A2 = hprev; pb.lda2 = ldh; k2b = (t == 0) ? 0 : H;
       pb.B = (const bf16_t*)wT1;
-      pb.A3 = (const uint8_t*)(xin + H); pb.lda3 = ldh * 2; pb.nk3 = H / 128;
-      pb.A4 = (const uint8_t*)(hprev + H); pb.lda4 = ldh * 2; pb.nk4 = (t == 0) ? 0 : H / 128;
-      pb.B8 = wT1_8; pb.ldb8 = 2L * H; pb.scale8_exp = -(7 + w8_scale_exp);
+      pb.A3 = (const uint8_t*)(xin + H); pb.lda3 = ldh * 2; pb.nk3 = kh8 / 128;
+      pb.A4 = (const uint8_t*)(hprev + H); pb.lda4 = ldh * 2; pb.nk4 = (t == 0) ? 0 : kh8 / 128;
+      pb.B8 = wT1_8; pb.ldb8 = 2L * kh8; pb.scale8_exp = -(7 + w8_scale_exp);
       eb.zx = nullptr; eb.ldzx = 0;
       eb.bias = bias1; eb.len = len; eb.t = t;
       eb.c_state = c_state1; eb.h_state = h_state1; eb.ld_state = ld_state;
-      eb.hout = h1r + (long)(t + 1) * M * ldh; eb.h_wide = 2;
+      eb.hout = h1r + (long)(t + 1) * M * ldh; eb.h_wide = h_lo ? 3 : 2;
       eb.hout_lo = hbuf1 + (long)(t + 1) * M * H;
       eb.gates = gates1 ? (uint2*)gates1 + (long)t * M * H : nullptr;
       eb.c_hist = c_all1 ? c_all1 + (long)(t + 1) * M * H : nullptr;

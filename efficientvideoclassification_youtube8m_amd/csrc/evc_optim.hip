@@ -67,6 +67,7 @@ struct LstmAdamParams {
   bf16_t* pT; long ldT;                                // backward shadow [C][ldT]: column u*4+g <- row g*H+u
   f16_t* p16; long ld16; int nin, nseg;                // or NULL: f16 image rows [f16(Wx) | f16(Wx)/64 | (Wx - f16(Wx))*64 (first nseg blocks) | f16(Wh)]
   uint8_t* p8; long ld8; int col0, hi_cols;            // or NULL: e4m3 image of W[:, col0:]: [lo(first hi_cols) | hi(first hi_cols) | lo(rest)]
+  int hi_tail = 0;                                     // ... | hi(rest)] as well (evc_cast_f32_to_fp8_lohi)
   float lo_scale, hi_scale;
   int tiles_c, n_tiles;
 };
@@ -188,12 +189,12 @@ __global__ __launch_bounds__(256) void lstm_adam_fused_kernel(LstmAdamParams u) 
         w8 = __builtin_amdgcn_cvt_pk_fp8_f32(d[2], d[3], w8, true);
         uint8_t* o8 = u.p8 + row * u.ld8;
         *(int*)(o8 + (cc < u.hi_cols ? cc : cc + u.hi_cols)) = w8;
-        if (cc < u.hi_cols) {
+        if (cc < u.hi_cols || u.hi_tail) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) d[r] = fminf(fmaxf(pn[r] * u.hi_scale, -448.f), 448.f);
           int h8 = __builtin_amdgcn_cvt_pk_fp8_f32(d[0], d[1], 0, false);
           h8 = __builtin_amdgcn_cvt_pk_fp8_f32(d[2], d[3], h8, true);
-          *(int*)(o8 + u.hi_cols + cc) = h8;
+          *(int*)(o8 + (cc < u.hi_cols ? u.hi_cols + cc : (u.C - u.col0) + cc)) = h8;      // (hi_tail: behind the C - col0 columns of [lo(A) | hi(A) | lo(B)])
         }
       }
     }
@@ -236,8 +237,10 @@ __global__ __launch_bounds__(256) void lstm_adam_fused_kernel(LstmAdamParams u) 
 extern "C" int evc_lstm_adam_fused(float* p, const float* g, float* m, float* v, float* pb, const float* gb, float* mb, float* vb, int H, int C,
                                    const float* part, float* sums_w, float* sums_b, float clip_norm, float lr_t, float beta1, float beta2, float eps,
                                    evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT, evc_f16* p_f16, int64_t ld16, int nin, int nseg,
-                                   uint8_t* p_fp8, int64_t ld8, int fp8_col0, int fp8_hi_cols, int fp8_lo_exp, int fp8_hi_exp, void* stream) {
+                                   uint8_t* p_fp8, int64_t ld8, int fp8_col0, int fp8_hi_cols, int fp8_lo_exp, int fp8_hi_exp, int fp8_hi_tail, void* stream) {
   EVC_REQUIRE(H > 0 && H % 16 == 0 && C > 0 && C % 4 == 0, EVC_ERR_BAD_SHAPE, "evc_lstm_adam_fused: H=%d (%%16) C=%d (%%4)", H, C);
+  EVC_REQUIRE(fp8_hi_tail == 0 || (fp8_hi_tail == 1 && p_fp8 && ld8 >= 2L * (C - fp8_col0)), EVC_ERR_BAD_ARG,
+              "evc_lstm_adam_fused: fp8_hi_tail=%d needs p_fp8 with ld8 >= 2 (C - col0) (ld8=%ld)", fp8_hi_tail, (long)ld8);
   EVC_REQUIRE(p && g && m && v && pb && gb && mb && vb && part && sums_w && sums_b && p_bf16 && pT_bf16, EVC_ERR_BAD_ARG, "evc_lstm_adam_fused: NULL argument");
   EVC_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0 && ((uintptr_t)pb % 16) == 0 &&
               ((uintptr_t)gb % 16) == 0 && ((uintptr_t)mb % 16) == 0 && ((uintptr_t)vb % 16) == 0 && ((uintptr_t)p_bf16 % 8) == 0 &&
@@ -254,7 +257,7 @@ extern "C" int evc_lstm_adam_fused(float* p, const float* g, float* m, float* v,
   u.clip = clip_norm; u.lr_t = lr_t; u.b1 = beta1; u.b2 = beta2; u.eps = eps;
   u.p_bf16 = (bf16_t*)p_bf16; u.pT = (bf16_t*)pT_bf16; u.ldT = ldT;
   u.p16 = (f16_t*)p_f16; u.ld16 = ld16; u.nin = nin; u.nseg = nseg;
-  u.p8 = p_fp8; u.ld8 = ld8; u.col0 = fp8_col0; u.hi_cols = fp8_hi_cols;
+  u.p8 = p_fp8; u.ld8 = ld8; u.col0 = fp8_col0; u.hi_cols = fp8_hi_cols; u.hi_tail = fp8_hi_tail;
   u.lo_scale = ldexpf(1.0f, fp8_lo_exp); u.hi_scale = ldexpf(1.0f, fp8_hi_exp);
   u.tiles_c = (C + 63) / 64;
   u.n_tiles = (H / 16) * u.tiles_c;

@@ -195,12 +195,14 @@ class LstmStack:
                     self.zx = torch.empty((self.T * self.M, 4 * H), dtype=F32, device=self.S.device)
                 (k0, b0), (k1, b1) = self.names(0), self.names(1)
                 if k1 in tw.shadow8:      # weights' low-order halves as e4m3 operands in the same launches (ops.lstm_stack2_fwd_f16_fp8lo)
-                    if not hasattr(self, "hrows16"):
-                        self.hrows16 = [torch.zeros((self.T + 1, self.M, 3 * H // 2), dtype=ops.F16, device=h.device) for h in self.hbuf]
-                    hr = [self._v(h, T + 1, M, 3 * H // 2) for h in self.hrows16]
+                    al = tw.act_lo()
+                    wrow = 2 * H if al else 3 * H // 2                # containers per h row: [f16(h) | e4m3(h) (| e4m3(h_lo))]
+                    if not hasattr(self, "hrows16") or self.hrows16[0].shape[-1] != wrow:
+                        self.hrows16 = [torch.zeros((self.T + 1, self.M, wrow), dtype=ops.F16, device=h.device) for h in self.hbuf]
+                    hr = [self._v(h, T + 1, M, wrow) for h in self.hrows16]
                     ops.lstm_stack2_fwd_f16_fp8lo(x16, tw.shadow16[k0], tw.shadow8[k0], tw.store.p(b0), tw.shadow16[k1], tw.shadow8[k1], tw.store.p(b1),
                                                   lens, T, M, self.Kin, H, self.zx, hr[0], hr[1], hb[0], hb[1], self.S, gates, c_all,
-                                                  x_segments=tw.f16_l2_x_segments)
+                                                  x_segments=tw.f16_l2_x_segments, h_lo=al)
                     return self.S
                 if not hasattr(self, "hbuf16w"):
                     self.hbuf16w = [torch.zeros((self.T + 1, self.M, 2 * H), dtype=ops.F16, device=h.device) for h in self.hbuf]
@@ -219,7 +221,8 @@ class LstmStack:
                 #    input's: the e4m3(x_lo 2^18) bytes against the e4m3(Wx 2^6) block of cast_fp8_lo's rows); plain f16 h rows.
                 dl = tw.dither_layers()
                 wh0 = tw.dither_wh0()                                             # layer 0: recurrent block dithered, input block corrected
-                widths = [H if (l in dl or (l == 0 and wh0)) else 3 * H // 2 for l in range(L)]        # halfwords per h row
+                al = tw.act_lo()                                                  # rows [f16(h) | e4m3(h) | e4m3(h_lo)] (2H containers) against [lo | hi] weight rows
+                widths = [H if (l in dl or (l == 0 and wh0)) else (2 * H if al else 3 * H // 2) for l in range(L)]        # halfwords per h row
                 if getattr(self, "_hbuf16_widths", None) != widths:
                     self.hbuf16 = [torch.zeros((self.T + 1, self.M, widths[l]), dtype=ops.F16, device=self.hbuf[l].device) for l in range(L)]
                     self._hbuf16_widths = widths
@@ -244,10 +247,10 @@ class LstmStack:
                                                     tw.shadow8[kn].stride(0) if l == 0 else 0, 7 + ops.FP8_W_SCALE_EXP, tw.store.p(bn), lens, T, M, H,
                                                     h16[l], hb[l], self.S[:, (2 * l) * H:], self.S[:, (2 * l + 1) * H:], 2 * L * H, gates[l], c_all[l], plan=plan)
                     else:
-                        x8_off, kx8 = (2 * self.Kin, 2 * self.Kin) if l == 0 else (2 * H, H)
+                        x8_off, kx8 = (2 * self.Kin, 2 * self.Kin) if l == 0 else (2 * H, 2 * H if al else H)
                         ops.lstm_layer_fwd_f16_fp8lo(inp, ldx, kx16, x8_off, kx8, tw.shadow16[kn], tw.shadow8[kn], tw.store.p(bn), lens, T, M, H,
                                                      h16[l], hb[l], self.S[:, (2 * l) * H:], self.S[:, (2 * l + 1) * H:], 2 * L * H,
-                                                     gates[l], c_all[l], plan=plan)
+                                                     gates[l], c_all[l], plan=plan, h_lo=al)
                     if self.timing is not None:
                         e1 = torch.cuda.Event(enable_timing=True)
                         e1.record()
@@ -1218,6 +1221,16 @@ class HLstmTower(TowerBase):
     # L2 level (two layers) in "high": the same for layer 0's recurrent weights and all of layer 1's (ops.lstm_stack2_fwd_f16_fp8lo); H % 128 == 0, H >= 512
     l2_fp8_lo = os.environ.get("EVC_HIGH_L2_FP8", os.environ.get("EVC_HIGH_FP8_LO", "1")) != "0"
 
+    # Round 6: the ACTIVATIONS' low-order halves as e4m3 operands too (h_lo forms of the same launches).  Up to round 5 only weights (and the input
+    # frames) were corrected: "f16 is enough for every activation" held 16 steps from initialisation; on towers trained for 512 steps the uncorrected
+    # f16 rounding of h in L1 layer 0 and of both activation operands of L2 layer 1 leaves 1e-3 .. 2e-3 on the teacher's logits in half of the weight
+    # draws (profiles/r06_budget_worst_draw.txt, r06_budget_plans.txt).  h rows become [f16(h) | e4m3(h 2^7) | e4m3((h - f16(h)) 2^18)] (4H bytes)
+    # against [lo(W) | hi(W)] weight rows: every layer on the fp8lo form (L1: the non-dithered layers; L2: both).  EVC_HIGH_ACT_LO=0: the round-5 layout.
+    f16_act_lo = os.environ.get("EVC_HIGH_ACT_LO", "1") != "0"
+
+    def act_lo(self):
+        return bool(self.f16_act_lo and self.precision == "high")
+
     def fp8_lo(self):
         """True if this tower's L1 level runs on ops.lstm_layer_fwd_f16_fp8lo (or, with dither(), on ops.lstm_layer_fwd_f16_dith)."""
         return (self.precision == "high" and self.f16_fp8_lo and self.F % 128 == 0 and self.H % 128 == 0 and self.F >= 384 and self.H >= 384)
@@ -1286,7 +1299,8 @@ class HLstmTower(TowerBase):
                 nin = shp[1] - H
                 layer = int(k.split("cell_")[1].split("/")[0])
                 self.shadow16[k] = torch.zeros(shp, dtype=ops.F16, device=dev)
-                self.shadow8[k] = torch.zeros((shp[0], shp[1] + (nin if layer == 0 else 0)), dtype=torch.uint8, device=dev)
+                # [lo(Wx) | hi(Wx) (layer 0: against the input's low-order half) | lo(Wh)]; act_lo(): [lo(Wx) | hi(Wx) | lo(Wh) | hi(Wh)] in every layer
+                self.shadow8[k] = torch.zeros((shp[0], 2 * shp[1] if self.act_lo() else shp[1] + (nin if layer == 0 else 0)), dtype=torch.uint8, device=dev)
             elif k.startswith("RNN_L1/") and self.precision == "high":
                 nin = shp[1] - H
                 layer = int(k.split("cell_")[1].split("/")[0])
@@ -1295,12 +1309,13 @@ class HLstmTower(TowerBase):
             elif k.startswith("RNN_L2/") and self.precision == "high" and self.L == 2 and self.l2_fp8_lo and H % 128 == 0 and H >= 512:
                 # f16 L2 level with e4m3 low-order halves (ops.lstm_stack2_fwd_f16_fp8lo): layer 0 [Wx segments | f16(Wh)] + lo(Wh), layer 1 f16(W) + lo(W)
                 nin = shp[1] - H
+                a2 = 2 if self.act_lo() else 1                      # act_lo(): [lo | hi] per operand part
                 if "cell_0" in k:
                     self.shadow16[k] = torch.zeros((shp[0], self.f16_l2_x_segments * nin + H), dtype=ops.F16, device=dev)
-                    self.shadow8[k] = torch.zeros((shp[0], H), dtype=torch.uint8, device=dev)
+                    self.shadow8[k] = torch.zeros((shp[0], a2 * H), dtype=torch.uint8, device=dev)
                 else:
                     self.shadow16[k] = torch.zeros(shp, dtype=ops.F16, device=dev)
-                    self.shadow8[k] = torch.zeros(shp, dtype=torch.uint8, device=dev)
+                    self.shadow8[k] = torch.zeros((shp[0], a2 * shp[1]), dtype=torch.uint8, device=dev)
             elif k.startswith("RNN_L2/") and self.precision == "high" and self.L == 2:
                 # f16 L2 level (ops.lstm_stack2_fwd_f16): layer 0 [Wx segments | Wh (| Wh_lo*64)], layer 1 [Wx | Wx_lo*64 | Wh | Wh_lo*64]
                 nin = shp[1] - H
@@ -1325,14 +1340,18 @@ class HLstmTower(TowerBase):
             ops.cast_f16_dither(p, self.shadow16d[k], self.dither_seed(k), col0=self.dither_col0(k))
             if k in self.shadow8:
                 ops.cast_fp8_lo(p, self.shadow8[k], hi_cols=self.shadow8[k].shape[1] - p.shape[1])
-        elif k in self.shadow8 and k.startswith("RNN_L2/"):     # L2 level, fp8 low-order halves
+        elif k in self.shadow8 and k.startswith("RNN_L2/"):     # L2 level, fp8 low-order halves (act_lo(): + the full-value images, [lo | hi] per part)
             nin = p.shape[1] - H
+            al = self.act_lo()
             if "cell_0" in k:
                 ops.cast_f16_wide(p, nin, H, self.f16_l2_x_segments, self.shadow16[k], h_ext=False)
-                ops.cast_fp8_lo(p[:, nin:], self.shadow8[k])
+                ops.cast_fp8_lo(p[:, nin:], self.shadow8[k], hi_tail=al)
             else:
                 ops.cast_f16(p, self.shadow16[k])
-                ops.cast_fp8_lo(p, self.shadow8[k])
+                ops.cast_fp8_lo(p, self.shadow8[k], hi_cols=nin if al else 0, hi_tail=al)
+        elif k in self.shadow8 and self.act_lo():     # L1 level, every part [lo | hi]: [lo(Wx) | hi(Wx) | lo(Wh) | hi(Wh)]
+            ops.cast_f16(p, self.shadow16[k])
+            ops.cast_fp8_lo(p, self.shadow8[k], hi_cols=p.shape[1] - H, hi_tail=True)
         elif k in self.shadow8:              # L1 level, fp8 low-order halves: f16(W) + e4m3((W - f16(W)) 2^17) (layer 0: + e4m3(Wx 2^6) for the input's)
             ops.cast_f16(p, self.shadow16[k])
             ops.cast_fp8_lo(p, self.shadow8[k], hi_cols=self.shadow8[k].shape[1] - p.shape[1])
@@ -1367,6 +1386,9 @@ class HLstmTower(TowerBase):
                      l2=("f16 + e4m3 low-order halves, %d input segments" % self.f16_l2_x_segments) if any(k.startswith("RNN_L2/") for k in getattr(self, "shadow8", {}))
                      else ("f16 K-extensions, %d input segments, h0_ext %s" % (self.f16_l2_x_segments, self.f16_l2_h0_ext) if self.L == 2 else "split-bf16"),
                      moe="f16 + e4m3 corrections of both operands" if getattr(self, "shadow_w8", None) else "split-bf16 K-extension",
+                     activations=("low-order halves of h as e4m3 operands in every corrected layer (L1: the non-dithered ones; L2: both): rows [f16 | e4m3 | e4m3_lo] "
+                                  "against [lo(W) | hi(W)]" if self.act_lo() else "f16, uncorrected (round-5 layout)"),
+                     moe_input_range="from the batch (absmax -> shift)" if self.moe.dynamic_fp8_range else "fixed 2^6",
                      fp8_scales=dict(lstm_w_lo_exp=ops.FP8_W_SCALE_EXP, lstm_wx_hi_exp=ops.FP8_WX_HI_EXP, **{"moe_" + k: v for k, v in ops.FP8_MOE.items()}))
         return d
 
@@ -1406,10 +1428,13 @@ class HLstmTower(TowerBase):
         nin = p.shape[1] - H
         if k in self.shadow16d:              # dithered L1 kernel: the update pass writes layer 0's e4m3 rows; the T images follow (_after_fused_adam)
             return dict(p_fp8=self.shadow8[k], fp8_col0=0, fp8_hi_cols=self.shadow8[k].shape[1] - p.shape[1]) if k in self.shadow8 else {}
+        al = self.act_lo()
         if k in self.shadow8 and k.startswith("RNN_L2/"):
             if "cell_0" in k:
-                return dict(p_f16=self.shadow16[k], nin=nin, nseg=self.f16_l2_x_segments, p_fp8=self.shadow8[k], fp8_col0=nin, fp8_hi_cols=0)
-            return dict(p_f16=self.shadow16[k], nin=nin, nseg=1, p_fp8=self.shadow8[k], fp8_col0=0, fp8_hi_cols=0)
+                return dict(p_f16=self.shadow16[k], nin=nin, nseg=self.f16_l2_x_segments, p_fp8=self.shadow8[k], fp8_col0=nin, fp8_hi_cols=0, fp8_hi_tail=al)
+            return dict(p_f16=self.shadow16[k], nin=nin, nseg=1, p_fp8=self.shadow8[k], fp8_col0=0, fp8_hi_cols=nin if al else 0, fp8_hi_tail=al)
+        if k in self.shadow8 and al:
+            return dict(p_f16=self.shadow16[k], nin=nin, nseg=1, p_fp8=self.shadow8[k], fp8_col0=0, fp8_hi_cols=nin, fp8_hi_tail=True)
         if k in self.shadow8:
             return dict(p_f16=self.shadow16[k], nin=nin, nseg=1, p_fp8=self.shadow8[k], fp8_col0=0, fp8_hi_cols=self.shadow8[k].shape[1] - p.shape[1])
         if k in self.shadow16 and k.startswith("RNN_L1/"):

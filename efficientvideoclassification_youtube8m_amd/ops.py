@@ -187,11 +187,18 @@ FP8_W_SCALE_EXP = 17       # e4m3((W - f16(W)) * 2^17): |W| < 4 never clamps, we
 FP8_WX_HI_EXP = 6          # e4m3(Wx * 2^6) against e4m3((x - f16(x)) * 2^18): the same 2^24 as 2^7 * 2^17
 
 
-def cast_fp8_lo(w, out, hi_cols=0, scale_exp=FP8_W_SCALE_EXP, hi_exp=FP8_WX_HI_EXP):
+def cast_fp8_lo(w, out, hi_cols=0, scale_exp=FP8_W_SCALE_EXP, hi_exp=FP8_WX_HI_EXP, hi_tail=False):
     """out uint8 = e4m3(clamp((w - f16(w)) * 2^scale_exp)): the low-order halves of a weight matrix next to its f16 image (the wT8 operand of
     lstm_layer_fwd_f16_fp8lo).  hi_cols > 0: out [R][C + hi_cols] = [lo(W[:, :hi_cols]) | e4m3(W[:, :hi_cols] * 2^hi_exp) | lo(W[:, hi_cols:])] -
-    the layer that reads the input frames contracts the input's low-order half against the full-value image."""
-    assert w.dtype == F32 and out.dtype == torch.uint8 and w.dim() == 2 and out.shape == (w.shape[0], w.shape[1] + hi_cols)
+    the layer that reads the input frames contracts the input's low-order half against the full-value image.
+    hi_tail (round 6): EVERY column gets its full-value image - out [R][2C] = [lo(A) | hi(A) | lo(B) | hi(B)], A = W[:, :hi_cols], B = the rest
+    (evc_cast_f32_to_fp8_lohi: the weight rows of the h_lo forms, whose activations' low-order halves are corrected too)."""
+    assert w.dtype == F32 and out.dtype == torch.uint8 and w.dim() == 2
+    if hi_tail:
+        assert out.shape == (w.shape[0], 2 * w.shape[1])
+        _lib.call("evc_cast_f32_to_fp8_lohi", _p(w), w.stride(0), w.shape[0], w.shape[1], scale_exp, hi_cols, hi_exp, _p(out), out.stride(0), _stream())
+        return out
+    assert out.shape == (w.shape[0], w.shape[1] + hi_cols)
     _lib.call("evc_cast_f32_to_fp8_lo", _p(w), w.stride(0), w.shape[0], w.shape[1], scale_exp, hi_cols, hi_exp, _p(out), out.stride(0), _stream())
     return out
 
@@ -394,13 +401,16 @@ def lstm_layer_fwd_f16(x16, wT16, bias, lens, T, M, Kin, H, hbuf16, hbuf_bf, c_s
 
 
 def lstm_layer_fwd_f16_fp8lo(x16, ldx, kx16, x8_off, kx8, wT16, wT8, bias, lens, T, M, H, hbuf16, hbuf_bf, c_state, h_state, ld_state,
-                             gates=None, c_all=None, plan=None, w8_scale_exp=FP8_W_SCALE_EXP):
+                             gates=None, c_all=None, plan=None, w8_scale_exp=FP8_W_SCALE_EXP, h_lo=False):
     """lstm_layer_fwd_f16 with the weights' low-order halves contracted in fp8 (evc_lstm_layer_fwd_f16_fp8lo): x16 rows of ldx halfwords
     (kx16 halfwords of f16 operand at the row start, kx8 e4m3 bytes at byte offset x8_off), wT16 [4H][kx16 + H] f16, wT8 [4H][kx8 + H]
-    uint8 (cast_fp8_lo), hbuf16 [(T+1)][M][3H/2] f16 containers = rows [f16(h) | e4m3(h 2^7)], hbuf_bf the bf16 copy of h."""
+    uint8 (cast_fp8_lo), hbuf16 [(T+1)][M][3H/2] f16 containers = rows [f16(h) | e4m3(h 2^7)], hbuf_bf the bf16 copy of h.
+    h_lo: the low-order half of h corrected too - hbuf16 [(T+1)][M][2H] containers = rows [f16(h) | e4m3(h 2^7) | e4m3((h - f16(h)) 2^18)],
+    wT8 [4H][kx8 + 2H] with the h-part [lo(Wh) | hi(Wh)] (cast_fp8_lo(hi_tail=True))."""
     assert x16.dtype == F16 and wT16.dtype == F16 and wT8.dtype == torch.uint8 and hbuf16.dtype == F16 and hbuf_bf.dtype == BF16
-    assert wT16.shape == (4 * H, kx16 + H) and wT8.shape == (4 * H, kx8 + H) and wT16.is_contiguous() and wT8.is_contiguous()
-    _lib.call("evc_lstm_layer_fwd_f16_fp8lo", _p(x16), ldx, kx16, x8_off, kx8, _p(wT16), _p(wT8), w8_scale_exp, _p(bias), _p(lens), T, M, H,
+    assert wT16.shape == (4 * H, kx16 + H) and wT8.shape == (4 * H, kx8 + (2 if h_lo else 1) * H) and wT16.is_contiguous() and wT8.is_contiguous()
+    assert hbuf16.shape[-1] == (2 * H if h_lo else 3 * H // 2)
+    _lib.call("evc_lstm_layer_fwd_f16_fp8lo", _p(x16), ldx, kx16, x8_off, kx8, _p(wT16), _p(wT8), w8_scale_exp, 1 if h_lo else 0, _p(bias), _p(lens), T, M, H,
               _p(hbuf16), _p(hbuf_bf), _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_all), *_plan_args(plan), _stream())
 
 
@@ -456,15 +466,19 @@ def lstm_stack2_fwd_f16(x16, wT0_16, bias0, wT1_wlo, bias1, lens, T, M, Kin, H, 
 
 
 def lstm_stack2_fwd_f16_fp8lo(x16, wT0_16, wT0_8, bias0, wT1_16, wT1_8, bias1, lens, T, M, Kin, H, zx_ws, h0_rows, h1_rows, hbuf0, hbuf1, S,
-                              gates=(None, None), c_all=(None, None), x_segments=1, w8_scale_exp=FP8_W_SCALE_EXP):
+                              gates=(None, None), c_all=(None, None), x_segments=1, w8_scale_exp=FP8_W_SCALE_EXP, h_lo=False):
     """lstm_stack2_fwd_f16 with the low-order halves of layer 0's recurrent weights and of layer 1's weights as e4m3 operands behind the f16
     stages of the same launches (evc_lstm_stack2_fwd_f16_fp8lo).  wT0_16 [4H][x_segments Kin + H], wT0_8 [4H][H], wT1_16 / wT1_8 [4H][2H];
-    h*_rows [(T+1)][M][3H/2] f16 containers = rows [f16(h) | e4m3(h 2^7)]; hbuf* [(T+1)][M][H] bf16; S [M][4H] f32."""
+    h*_rows [(T+1)][M][3H/2] f16 containers = rows [f16(h) | e4m3(h 2^7)]; hbuf* [(T+1)][M][H] bf16; S [M][4H] f32.
+    h_lo: rows [f16(h) | e4m3(h 2^7) | e4m3((h - f16(h)) 2^18)] (2H containers), wT0_8 [4H][2H] = [lo(Wh0) | hi(Wh0)], wT1_8 [4H][4H] = [lo(Wx1) | hi(Wx1)
+    | lo(Wh1) | hi(Wh1)] (cast_fp8_lo(hi_tail=True)): the activations' low-order halves corrected as well."""
+    k8 = 2 if h_lo else 1
     assert x16.dtype == F16 and wT0_16.dtype == F16 and wT1_16.dtype == F16 and wT0_8.dtype == torch.uint8 and wT1_8.dtype == torch.uint8
-    assert x16.shape[-1] == x_segments * Kin and wT0_16.shape == (4 * H, x_segments * Kin + H) and wT0_8.shape == (4 * H, H)
-    assert wT1_16.shape == (4 * H, 2 * H) and wT1_8.shape == (4 * H, 2 * H) and h0_rows.dtype == F16 and hbuf0.dtype == BF16
+    assert x16.shape[-1] == x_segments * Kin and wT0_16.shape == (4 * H, x_segments * Kin + H) and wT0_8.shape == (4 * H, k8 * H)
+    assert wT1_16.shape == (4 * H, 2 * H) and wT1_8.shape == (4 * H, 2 * k8 * H) and h0_rows.dtype == F16 and hbuf0.dtype == BF16
+    assert h0_rows.shape[-1] == h1_rows.shape[-1] == (2 * H if h_lo else 3 * H // 2)
     assert all(t.is_contiguous() for t in (wT0_16, wT0_8, wT1_16, wT1_8))
-    _lib.call("evc_lstm_stack2_fwd_f16_fp8lo", _p(x16), x_segments, _p(wT0_16), _p(wT0_8), _p(bias0), _p(wT1_16), _p(wT1_8), w8_scale_exp, _p(bias1),
+    _lib.call("evc_lstm_stack2_fwd_f16_fp8lo", _p(x16), x_segments, _p(wT0_16), _p(wT0_8), _p(bias0), _p(wT1_16), _p(wT1_8), w8_scale_exp, 1 if h_lo else 0, _p(bias1),
               _p(lens), T, M, Kin, H, _p(zx_ws), _p(h0_rows), _p(h1_rows), _p(hbuf0), _p(hbuf1),
               _p(S[:, 0:]), _p(S[:, H:]), _p(S[:, 2 * H:]), _p(S[:, 3 * H:]), S.stride(0),
               _p(gates[0]), _p(c_all[0]), _p(gates[1]), _p(c_all[1]), _stream())
@@ -585,18 +599,18 @@ def grad_sqnorm(g, p, l2_coeff, sums):
 
 
 def lstm_adam_fused(p, g, m, v, pb, gb, mb, vb, part_ws, sums_w, sums_b, clip_norm, lr_t, p_bf16, pT_bf16, beta1=0.9, beta2=0.999, eps=1e-8,
-                    p_f16=None, nin=0, nseg=1, p_fp8=None, fp8_col0=0, fp8_hi_cols=0, fp8_lo_exp=FP8_W_SCALE_EXP, fp8_hi_exp=FP8_WX_HI_EXP):
+                    p_f16=None, nin=0, nseg=1, p_fp8=None, fp8_col0=0, fp8_hi_cols=0, fp8_lo_exp=FP8_W_SCALE_EXP, fp8_hi_exp=FP8_WX_HI_EXP, fp8_hi_tail=False):
     """Clip + TF-Adam of one LSTM layer's kernel p [4H][C] and bias pb [4H] with every operand image of the new kernel written from the same
     pass (evc_sqnorm2_partials + evc_lstm_adam_fused): bf16 forward shadow, gate-interleaved transposed bf16 backward shadow, and in "high"
     precision the f16 image (cast_f16 / cast_f16_wide without h_ext) and the e4m3 low-order image (cast_fp8_lo of the columns from fp8_col0)."""
     R, C = p.shape
     assert R % 64 == 0 and p.is_contiguous() and g.is_contiguous() and part_ws.numel() >= 1025 and pT_bf16.shape[0] == C
     assert p_f16 is None or (p_f16.dtype == F16 and p_f16.shape == (R, nseg * nin + (C - nin)) and p_f16.is_contiguous())
-    assert p_fp8 is None or (p_fp8.dtype == torch.uint8 and p_fp8.shape == (R, C - fp8_col0 + fp8_hi_cols) and p_fp8.is_contiguous())
+    assert p_fp8 is None or (p_fp8.dtype == torch.uint8 and p_fp8.shape == (R, 2 * (C - fp8_col0) if fp8_hi_tail else C - fp8_col0 + fp8_hi_cols) and p_fp8.is_contiguous())
     _lib.call("evc_sqnorm2_partials", _p(g), g.numel(), _p(gb), gb.numel(), _p(part_ws), _stream())
     _lib.call("evc_lstm_adam_fused", _p(p), _p(g), _p(m), _p(v), _p(pb), _p(gb), _p(mb), _p(vb), R // 4, C, _p(part_ws), _p(sums_w), _p(sums_b),
               clip_norm, lr_t, beta1, beta2, eps, _p(p_bf16), _p(pT_bf16), pT_bf16.stride(0), _p(p_f16), p_f16.stride(0) if p_f16 is not None else 0,
-              nin, nseg, _p(p_fp8), p_fp8.stride(0) if p_fp8 is not None else 0, fp8_col0, fp8_hi_cols, fp8_lo_exp, fp8_hi_exp, _stream())
+              nin, nseg, _p(p_fp8), p_fp8.stride(0) if p_fp8 is not None else 0, fp8_col0, fp8_hi_cols, fp8_lo_exp, fp8_hi_exp, 1 if fp8_hi_tail else 0, _stream())
 
 
 def adam2d_fused(p, g, m, v, part_ws, sums_w, clip_norm, lr_t, p_bf16, pT_bf16, beta1=0.9, beta2=0.999, eps=1e-8,

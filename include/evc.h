@@ -36,7 +36,7 @@ extern "C" {
 #define EVC_ERR_HIP (-4)
 #define EVC_ERR_BAD_ARG (-5)
 
-#define EVC_VERSION 106   /* 106 (round 6): evc_absmax_partials, evc_cast_f32_to_f16_fp8x_dyn, evc_gemm_nt_f16_fp8_dyn (dynamic e4m3 range of the MoE head's input state); evc_l2norm_chunk_fwd accepts out1 == NULL (student-only graphs read the sub-sampled frames only), evc_clip_adam_small limited to 2^15 elements per tensor; 105 (round 5, second session): evc_cast_f32_to_f16_dither, evc_lstm_layer_fwd_f16_dith (time-dithered f16 weight images: an L1 layer of the "high" mode without stages for its weights' low-order halves), evc_gemm_tn2_rows (weight-gradient products that skip the dead rows of a row-planned level's time slabs); 104 (round 5): evc_lstm_level2_fwd, evc_ce_loss_ordered, evc_rep_loss_ordered, evc_gemm_tn2_slabs, evc_sum_slabs, evc_clip_adam_small; evc_moe_grad_update* accept p_bf16 == NULL (forward shadow not written), evc_lstm_stack2_bwd runs M <= 512 stacks on the skinny pair launches, evc_dbof_cluster_pool_fwd walks tiles (EVC_DBOF_WALK), EVC_DETERMINISTIC parsed as "set, not empty, not 0"; 103 (round 4): evc_sqnorm2_partials, evc_lstm_adam_fused, evc_gram_slabs, evc_moe_grad_norms, evc_moe_grad_update_apply, evc_adam2d_fused, evc_colsum_bf16_det, evc_sample_sequence_gather, evc_relu6_fwd/bwd, evc_framepool_mean_fwd/bwd, evc_stream_create_cu_mask / evc_stream_destroy; EVC_DETERMINISTIC=1 read by the library; 102: evc_lstm_layer_fwd_f16_fp8lo, evc_lstm_stack2_fwd_f16_fp8lo, evc_gemm_nt_f16_fp8, evc_cast_f32_to_fp8_lo, evc_cast_f32_to_f16_fp8x, aux_mode 5, evc_moe_grad_update_wide; 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
+#define EVC_VERSION 106   /* 106 (round 6): evc_lstm_layer_fwd_f16_fp8lo / evc_lstm_stack2_fwd_f16_fp8lo gained h_lo (low-order half of h corrected: 4H-byte h rows), evc_cast_f32_to_fp8_lohi, evc_lstm_adam_fused gained fp8_hi_tail; evc_absmax_partials, evc_cast_f32_to_f16_fp8x_dyn, evc_gemm_nt_f16_fp8_dyn (dynamic e4m3 range of the MoE head's input state); evc_l2norm_chunk_fwd accepts out1 == NULL (student-only graphs read the sub-sampled frames only), evc_clip_adam_small limited to 2^15 elements per tensor; 105 (round 5, second session): evc_cast_f32_to_f16_dither, evc_lstm_layer_fwd_f16_dith (time-dithered f16 weight images: an L1 layer of the "high" mode without stages for its weights' low-order halves), evc_gemm_tn2_rows (weight-gradient products that skip the dead rows of a row-planned level's time slabs); 104 (round 5): evc_lstm_level2_fwd, evc_ce_loss_ordered, evc_rep_loss_ordered, evc_gemm_tn2_slabs, evc_sum_slabs, evc_clip_adam_small; evc_moe_grad_update* accept p_bf16 == NULL (forward shadow not written), evc_lstm_stack2_bwd runs M <= 512 stacks on the skinny pair launches, evc_dbof_cluster_pool_fwd walks tiles (EVC_DBOF_WALK), EVC_DETERMINISTIC parsed as "set, not empty, not 0"; 103 (round 4): evc_sqnorm2_partials, evc_lstm_adam_fused, evc_gram_slabs, evc_moe_grad_norms, evc_moe_grad_update_apply, evc_adam2d_fused, evc_colsum_bf16_det, evc_sample_sequence_gather, evc_relu6_fwd/bwd, evc_framepool_mean_fwd/bwd, evc_stream_create_cu_mask / evc_stream_destroy; EVC_DETERMINISTIC=1 read by the library; 102: evc_lstm_layer_fwd_f16_fp8lo, evc_lstm_stack2_fwd_f16_fp8lo, evc_gemm_nt_f16_fp8, evc_cast_f32_to_fp8_lo, evc_cast_f32_to_f16_fp8x, aux_mode 5, evc_moe_grad_update_wide; 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
 
 typedef uint16_t evc_bf16;
 typedef uint16_t evc_f16;   /* raw IEEE binary16 bits (the "high" precision forward operands of the L1 levels) */
@@ -193,8 +193,12 @@ int evc_lstm_layer_fwd_f16(const evc_f16* x, int64_t ldx /* row stride of x (>= 
  * layers: the hbuf rows of the layer below, kx16 = H, x8_off = 2H, kx8 = H).  hbuf [(T+1)][M] rows of 3H bytes: [f16(h_t) (H halfwords) | e4m3(h_t 2^7) (H bytes)]; wT16 [4H][kx16 + H] f16,
  * wT8 [4H][kx8 + H] bytes.  H % 128 == 0, kx8 % 128 == 0, kx8 >= 384, kx16 % 64 == 0.  Everything else as evc_lstm_layer_fwd_f16
  * (cs/frame_level_models.py:221-250). */
+/* h_lo = 1 (round 6, ABI 106): the low-order half of h is corrected as well - the uncorrected f16 rounding of the activations is what left 1e-3 .. 2e-3
+ * on the logits of towers trained for 512 steps (profiles/r06_budget_worst_draw.txt).  hbuf rows are then 4H bytes [f16(h) | e4m3(h 2^7) |
+ * e4m3((h - f16(h)) 2^18)], the h-part of wT8's rows is [lo(Wh) | hi(Wh)] (evc_cast_f32_to_fp8_lohi): wT8 [4H][kx8 + 2H]; a layer above reads those
+ * rows as its x with kx16 = H, x8_off = 2H, kx8 = 2H against [lo(Wx) | hi(Wx)].  h_lo = 0: the rows / images described above. */
 int evc_lstm_layer_fwd_f16_fp8lo(const evc_f16* x, int64_t ldx, int kx16, int64_t x8_off, int kx8, const evc_f16* wT16,
-                                 const uint8_t* wT8, int w8_scale_exp, const float* bias, const int32_t* len,
+                                 const uint8_t* wT8, int w8_scale_exp, int h_lo, const float* bias, const int32_t* len,
                                  int T, int M, int H, evc_f16* hbuf, evc_bf16* hbuf_bf16, float* c_state, float* h_state,
                                  int64_t ld_state, void* gates, evc_bf16* c_all, const int32_t* row_map,
                                  const int32_t* rows_per_step, void* stream);
@@ -237,8 +241,10 @@ int evc_lstm_stack2_fwd_f16(const evc_f16* x, int x_segments /* x rows: x_segmen
  * x [T][M][x_segments Kin] f16 (K-extended input of the hoisted product); wT0 [4H][x_segments Kin + H] f16 = [Wx segments | f16(Wh)],
  * wT0_8 [4H][H] = e4m3((Wh - f16(Wh)) 2^w8_scale_exp); wT1 [4H][2H] f16, wT1_8 [4H][2H]; h0_rows / h1_rows [(T+1)][M] rows of 3H bytes =
  * [f16(h) | e4m3(h 2^7)].  H % 128 == 0, H >= 512. */
+/* h_lo = 1 (round 6): h rows of 4H bytes as in evc_lstm_layer_fwd_f16_fp8lo, wT0_8 [4H][2H] = [lo(Wh0) | hi(Wh0)], wT1_8 [4H][4H] = [lo(Wx1) | hi(Wx1) |
+ * lo(Wh1) | hi(Wh1)]: both activation operands of layer 1 and the recurrent one of layer 0 are corrected (layer 1: 32 f16 + 32 e4m3 stages). */
 int evc_lstm_stack2_fwd_f16_fp8lo(const evc_f16* x, int x_segments, const evc_f16* wT0, const uint8_t* wT0_8, const float* bias0,
-                                  const evc_f16* wT1, const uint8_t* wT1_8, int w8_scale_exp, const float* bias1,
+                                  const evc_f16* wT1, const uint8_t* wT1_8, int w8_scale_exp, int h_lo, const float* bias1,
                                   const int32_t* len, int T, int M, int Kin, int H, float* zx_ws,
                                   evc_f16* h0_rows, evc_f16* h1_rows, evc_bf16* hbuf0, evc_bf16* hbuf1,
                                   float* c_state0, float* h_state0, float* c_state1, float* h_state1, int64_t ld_state,
@@ -359,6 +365,10 @@ int evc_cast_f32_to_bf16(const float* in, int64_t ld_in, int R, int C, evc_bf16*
  * low-order half e4m3((x - f16(x)) 2^18) (evc_l2norm_chunk_fwd aux_mode 5) is contracted against (hi_exp 6: the same 2^24 as 7 + 17). */
 int evc_cast_f32_to_fp8_lo(const float* in, int64_t ld_in, int R, int C, int lo_exp, int hi_cols, int hi_exp, uint8_t* out, int64_t ld_out,
                            void* stream);
+/* ... with the full-value image of EVERY column (round 6): out rows [lo(W[:, :hi_cols]) | hi(W[:, :hi_cols]) | lo(W[:, hi_cols:]) | hi(W[:, hi_cols:])],
+ * 2C bytes (hi_cols = 0: [lo(W) | hi(W)]) - what activation rows [a8 | a_lo8 | b8 | b_lo8] are contracted against (h_lo = 1 entries). */
+int evc_cast_f32_to_fp8_lohi(const float* in, int64_t ld_in, int R, int C, int lo_exp, int hi_cols, int hi_exp, uint8_t* out, int64_t ld_out,
+                             void* stream);
 /* out_f16[i] = f16(in_f32[i]), round to nearest even (the f16 weight shadows of evc_lstm_layer_fwd_f16). */
 int evc_cast_f32_to_f16(const float* in, int64_t ld_in, int R, int C, evc_f16* out, int64_t ld_out, void* stream);
 /* T time-dithered f16 images of n f32 values (n % 4 == 0, n < 2^32; image t at out + t * img_stride halfwords, same element order as in):
@@ -684,7 +694,8 @@ int evc_sqnorm2_partials(const float* ga, int64_t na, const float* gb, int64_t n
 int evc_lstm_adam_fused(float* p, const float* g, float* m, float* v, float* pb, const float* gb, float* mb, float* vb, int H, int C,
                         const float* part, float* sums_w, float* sums_b, float clip_norm, float lr_t, float beta1, float beta2, float eps,
                         evc_bf16* p_bf16, evc_bf16* pT_bf16, int64_t ldT, evc_f16* p_f16, int64_t ld16, int nin, int nseg,
-                        uint8_t* p_fp8, int64_t ld8, int fp8_col0, int fp8_hi_cols, int fp8_lo_exp, int fp8_hi_exp, void* stream);
+                        uint8_t* p_fp8, int64_t ld8, int fp8_col0, int fp8_hi_cols, int fp8_lo_exp, int fp8_hi_exp, int fp8_hi_tail, void* stream);
+/* (fp8_hi_tail = 1, round 6: the e4m3 image in evc_cast_f32_to_fp8_lohi's layout, ld8 >= 2 (C - fp8_col0)) */
 
 /* ---- a10, the branches no launcher of the reference selects (cs/frame_level_models.py:126-187; towers.DbofGenericTower) ----
  * evc_sample_sequence_gather: SampleRandomSequence (cs/model_utils.py:11-36): S consecutive frames from start = int32(u[b] *

@@ -29,7 +29,7 @@ from oracle import torch_cpu as tc           # noqa: E402
 
 def fp8(a, scale):
     """OCP e4m3 image of a * scale, back in a's units (what the MX-scaled MFMA contracts: v_mfma_scale_f32_16x16x128_f8f6f4)."""
-    return (a.to(torch.float32) * scale).to(torch.float8_e4m3fn).to(torch.float64) / scale
+    return (a.to(torch.float32) * scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float64) / scale     # (saturating, as v_cvt_pk_fp8_f32 after the kernels' clamp)
 
 
 def fp8_scale(a):

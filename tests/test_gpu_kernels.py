@@ -467,6 +467,27 @@ def test_lstm_stack2_fwd_f16_fp8_low_order_weights(ops, M, T, Kin, H, nseg):
         for t in range(T):
             dead = torch.from_numpy(lens <= t).to(DEV)
             assert bool((hn[t + 1][dead] == 0).all()) and bool((h8[t + 1][dead] == 0).all())
+    # h_lo (round 6): the activations' low-order halves corrected as well - rows [f16(h) | e4m3(h 2^7) | e4m3((h - f16(h)) 2^18)] against
+    # [lo(Wh0) | hi(Wh0)] / [lo(Wx1) | hi(Wx1) | lo(Wh1) | hi(Wh1)]: the "f16 activation bound" above goes too
+    w0_8l = torch.empty((4 * H, 2 * H), dtype=torch.uint8, device=DEV)
+    ops.cast_fp8_lo(k0T[:, Kin:], w0_8l, hi_tail=True)
+    assert torch.equal(w0_8l[:, :H], w0_8) and torch.equal(w0_8l[:, H:], (k0T[:, Kin:] * 64.0).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8))
+    w1_8l = torch.empty((4 * H, 4 * H), dtype=torch.uint8, device=DEV)
+    ops.cast_fp8_lo(k1T, w1_8l, hi_cols=H, hi_tail=True)
+    assert torch.equal(w1_8l[:, :H], w1_8[:, :H]) and torch.equal(w1_8l[:, 2 * H:3 * H], w1_8[:, H:])
+    hrl = [torch.full((T + 1, M, 2 * H), float("nan"), dtype=torch.float16, device=DEV) for _ in range(2)]
+    hbl = [torch.full((T + 1, M, H), float("nan"), dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+    Sl = torch.full((M, 4 * H), float("nan"), dtype=torch.float32, device=DEV)
+    ops.lstm_stack2_fwd_f16_fp8lo(x16, w0, w0_8l, bd0, w1, w1_8l, bd1, ln, T, M, Kin, H, zx, hrl[0], hrl[1], hbl[0], hbl[1], Sl, x_segments=nseg, h_lo=True)
+    got_lo = Sl.cpu().double().numpy()
+    assert np.isfinite(got_lo).all() and np.all(got_lo[0] == 0)
+    err_lo = np.max(np.abs(got_lo - s_ref))
+    for l in range(2):
+        l8 = hrl[l][:, :, 3 * H // 2:].contiguous().view(torch.float8_e4m3fn).float()
+        assert bool(torch.isfinite(l8).all()) and float(l8.abs().max()) <= 64.0 and bool((l8[0] == 0).all())
+        assert float((hrl[l][:, :, :H].float() - hr[l][:, :, :H].float()).abs().max()) < 1e-2         # (the same recurrence, closer to the oracle)
+    print("stack2 f16 + e4m3 low-order halves of the weights: state err %.2e; + of the activations (h_lo) %.2e" % (err, err_lo))
+    assert err_lo < 0.6 * err and err_lo < 3e-4, (err_lo, err)
     # f16 K-extension form on the same kernels
     w0e = torch.empty((4 * H, nseg * Kin + 2 * H), dtype=torch.float16, device=DEV)
     ops.cast_f16_wide(k0T, Kin, H, nseg, w0e, h_ext=True)
@@ -629,9 +650,10 @@ rows2 = torch.zeros((T, M, 2 * Kin), dtype=torch.float16, device=DEV)
 rows2[:, :, :Kin] = hi
 rows2[:, :, Kin:] = ((xt - hi.float()) * 64.0).half()
 ln = torch.from_numpy(lens).to(DEV)
-def run(plan):
+def run(plan, hlo=False):
     S = torch.full((M, 4 * H), float("nan"), dtype=torch.float32, device=DEV)
     inp, ldx, kx16, x8_off, kx8 = rows, 2 * Kin, Kin, 2 * Kin, 2 * Kin
+    wrow = 2 * H if hlo else 3 * H // 2           # h rows: [f16(h) | e4m3(h 2^7)] (+ e4m3((h - f16(h)) 2^18) with h_lo)
     lens_run, Mrun = ln, M
     if plan is not None:          # slot order: rows sorted by length, the length-0 rows dropped
         live = plan.rows[0]
@@ -644,20 +666,30 @@ def run(plan):
         nin = k.shape[0] - H
         w16 = torch.empty((4 * H, nin + H), dtype=torch.float16, device=DEV)
         ops.cast_f16(kT, w16)
-        w8 = torch.empty((4 * H, kx8 + H), dtype=torch.uint8, device=DEV)
-        ops.cast_fp8_lo(kT, w8, hi_cols=kx8 - nin)
-        h16 = torch.full((T + 1, Mrun, 3 * H // 2), float("nan"), dtype=torch.float16, device=DEV)
+        if hlo:                   # [lo(Wx) | hi(Wx) | lo(Wh) | hi(Wh)]: both activation operands' low-order halves are contracted against full-value images
+            w8 = torch.empty((4 * H, 2 * (nin + H)), dtype=torch.uint8, device=DEV)
+            ops.cast_fp8_lo(kT, w8, hi_cols=nin, hi_tail=True)
+            assert torch.equal(w8[:, :2 * nin], ops.cast_fp8_lo(kT, torch.empty((4 * H, 2 * nin + H), dtype=torch.uint8, device=DEV), hi_cols=nin)[:, :2 * nin])
+            assert torch.equal(w8[:, 2 * nin:2 * nin + H], ops.cast_fp8_lo(kT, torch.empty((4 * H, nin + H), dtype=torch.uint8, device=DEV))[:, nin:])
+            assert torch.equal(w8[:, 2 * nin + H:], (kT[:, nin:] * 64.0).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8))
+        else:
+            w8 = torch.empty((4 * H, kx8 + H), dtype=torch.uint8, device=DEV)
+            ops.cast_fp8_lo(kT, w8, hi_cols=kx8 - nin)
+        h16 = torch.full((T + 1, Mrun, wrow), float("nan"), dtype=torch.float16, device=DEV)
         hbf = torch.full((T + 1, Mrun, H), float("nan"), dtype=torch.bfloat16, device=DEV)
         ops.lstm_layer_fwd_f16_fp8lo(inp, ldx, kx16, x8_off, kx8, w16, w8, torch.from_numpy(b).to(DEV), lens_run, T, Mrun, H, h16, hbf,
-                                     S[:, 2 * l * H:], S[:, (2 * l + 1) * H:], 4 * H, plan=plan)
+                                     S[:, 2 * l * H:], S[:, (2 * l + 1) * H:], 4 * H, plan=plan, h_lo=hlo)
         if plan is None:          # (with a plan the rows beyond a step's active prefix are never written)
             hn = h16[:, :, :H].float()
             assert float((hn - hbf.float()).abs().max()) <= 2.0 ** -8
-            h8 = h16[:, :, H:].contiguous().view(torch.uint8)
+            h8 = h16[:, :, H:3 * H // 2].contiguous().view(torch.uint8)
+            if hlo:               # the low-order image: |h - f16(h)| 2^18 <= 64, finite, never the NaN code, and not all zero
+                l8 = h16[:, :, 3 * H // 2:].contiguous().view(torch.float8_e4m3fn).float()
+                assert bool(torch.isfinite(l8).all()) and float(l8.abs().max()) <= 64.0 and float((l8 != 0).float().mean()) > 0.3
             want = (hn * 128.0).to(torch.float8_e4m3fn).view(torch.uint8)       # (from the f16 image: one code step of slack on boundaries)
             d = (h8.to(torch.int16) - want.to(torch.int16)).abs()
             assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 2e-2, (int(d.max()), float((d > 0).float().mean()))
-        inp, ldx, kx16, x8_off, kx8 = h16[1:], 3 * H // 2, H, 2 * H, H
+        inp, ldx, kx16, x8_off, kx8 = h16[1:], wrow, H, 2 * H, (2 * H if hlo else H)
     return S.cpu().double().numpy()
 got = run(None)
 assert np.isfinite(got).all() and np.all(got[0] == 0)
@@ -678,8 +710,15 @@ err16 = float(np.max(np.abs(S.cpu().double().numpy() - s_ref)))
 # a row plan: rows sorted by length, the padding rows dropped - the same states in the original row order
 gp = run(ops.RowPlan(ln, lens, T))
 assert float(np.max(np.abs(gp - got))) < 1e-6
-print("fp8lo two-layer stack M=%%d T=%%d Kin=%%d H=%%d: state err %%.2e (plain f16 layers %%.2e)" %% (M, T, Kin, H, err, err16))
+# h_lo (round 6): the low-order half of h corrected as well - what was "left" above (the f16 rounding of h) goes too
+got_lo = run(None, hlo=True)
+assert np.isfinite(got_lo).all() and np.all(got_lo[0] == 0)
+err_lo = float(np.max(np.abs(got_lo - s_ref)))
+gp_lo = run(ops.RowPlan(ln, lens, T), hlo=True)
+assert float(np.max(np.abs(gp_lo - got_lo))) < 1e-6
+print("fp8lo two-layer stack M=%%d T=%%d Kin=%%d H=%%d: state err %%.2e (plain f16 layers %%.2e; with h_lo %%.2e)" %% (M, T, Kin, H, err, err16, err_lo))
 assert err < 8e-4 and err <= err16 * 1.05, (err, err16)
+assert err_lo < 0.5 * err and err_lo < 2e-4, (err_lo, err)
 """
 
 
@@ -1518,7 +1557,8 @@ def test_clip_adam_vector_and_scalar_paths_and_gradient_only_norm(ops):
 
 
 @pytest.mark.parametrize("H,nin,images", [(64, 64, "bf16"), (128, 384, "l1_fp8_layer0"), (128, 128, "l1_fp8_upper"), (128, 512, "l2_fp8_layer0"),
-                                          (128, 128, "f16_plain"), (1024, 1152, "l1_fp8_layer0")])
+                                          (128, 128, "f16_plain"), (1024, 1152, "l1_fp8_layer0"),
+                                          (128, 384, "lohi_l1"), (128, 512, "lohi_l2_layer0"), (128, 128, "lohi_l2_layer1"), (1024, 1152, "lohi_l1")])
 def test_fused_lstm_adam_equals_the_per_tensor_launches_and_writes_every_operand_image(ops, H, nin, images):
     """evc_sqnorm2_partials + evc_lstm_adam_fused (one layer's kernel + bias: clip, TF-Adam, bf16 forward shadow, transposed
     gate-interleaved backward shadow, f16 / e4m3 images of the "high" layouts - all from one pass) against evc_grad_sqnorm +
@@ -1534,13 +1574,15 @@ def test_fused_lstm_adam_equals_the_per_tensor_launches_and_writes_every_operand
     lr_t, clip = 3e-4, 1.0
     kw, nseg, col0, hi_cols = {}, 1, 0, 0
     F16 = torch.float16
+    tail = images.startswith("lohi")          # round 6: [lo | hi] images of every part (the h_lo forms of the forward kernels)
     if images != "bf16":
-        nseg = {"l2_fp8_layer0": 2}.get(images, 1)
+        nseg = {"l2_fp8_layer0": 2, "lohi_l2_layer0": 2}.get(images, 1)
         kw.update(p_f16=torch.zeros(R, nseg * nin + H, dtype=F16, device=DEV), nin=nin, nseg=nseg)
         if images != "f16_plain":
-            col0 = nin if images == "l2_fp8_layer0" else 0
-            hi_cols = nin if images == "l1_fp8_layer0" else 0
-            kw.update(p_fp8=torch.zeros(R, C - col0 + hi_cols, dtype=torch.uint8, device=DEV), fp8_col0=col0, fp8_hi_cols=hi_cols)
+            col0 = nin if images in ("l2_fp8_layer0", "lohi_l2_layer0") else 0
+            hi_cols = nin if images in ("l1_fp8_layer0", "lohi_l1", "lohi_l2_layer1") else 0
+            kw.update(p_fp8=torch.zeros(R, 2 * (C - col0) if tail else C - col0 + hi_cols, dtype=torch.uint8, device=DEV), fp8_col0=col0, fp8_hi_cols=hi_cols,
+                      fp8_hi_tail=tail)
     # fused
     p, g, m, v, pb, gb, mb, vb = (t.clone() for t in (p0, g0, m0, v0, pb0, gb0, mb0, vb0))
     sh_f = torch.zeros(R, C, dtype=torch.bfloat16, device=DEV)
@@ -1574,8 +1616,12 @@ def test_fused_lstm_adam_equals_the_per_tensor_launches_and_writes_every_operand
         assert torch.equal(kw["p_f16"], w16)
     if "p_fp8" in kw:
         w8 = torch.zeros_like(kw["p_fp8"])
-        ops.cast_fp8_lo(p[:, col0:], w8, hi_cols=hi_cols)
+        ops.cast_fp8_lo(p[:, col0:], w8, hi_cols=hi_cols, hi_tail=tail)
         assert torch.equal(kw["p_fp8"], w8)
+        if tail:                  # [lo(A) | hi(A) | lo(B) | hi(B)]: the hi blocks are e4m3(W 2^6) of the same columns
+            Cc = C - col0
+            hi_want = (p[:, col0:] * 64.0).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+            assert torch.equal(w8[:, hi_cols:2 * hi_cols], hi_want[:, :hi_cols]) and torch.equal(w8[:, Cc + hi_cols:], hi_want[:, hi_cols:])
     # run-to-run identical (no atomics anywhere)
     p2, m2, v2, pb2, mb2, vb2 = (t.clone() for t in (p0, m0, v0, pb0, mb0, vb0))
     s2 = torch.zeros(2, 2, device=DEV)

@@ -661,8 +661,9 @@ def test_high_precision_dithered_layer_images_follow_the_weights():
     """"high" precision at dims where the L1 level runs on f16 + e4m3 stages (F, H multiples of 128, >= 384): by default the TOP layer of the
     teacher's L1 level contracts time-dithered weight images (engine.HLstmTower.dither_layers) - 15 images of its kernel, rebuilt behind every
     update (evc_lstm_adam_fused + evc_cast_f32_to_f16_dither) and on load_state_dict.  After two training iterations they must be the oracle's
-    images of the NEW master weights, bit for bit (oracle/lowprec.py::f16_dither_images); layer 0 keeps its f16 + e4m3 images; the student
-    (plain f16 on its short chunks) has none; the resolved layout names the dithered layer; a dithered layer BELOW a corrected one is refused."""
+    images of the NEW master weights, bit for bit (oracle/lowprec.py::f16_dither_images); layer 0 keeps its f16 + e4m3 images (round 6: [lo | hi] of both
+    parts, cast_fp8_lo(hi_tail=True)); the student has the same layout on its 6-step chunks (round 6; before: plain f16); the resolved layout names the
+    dithered layer; a dithered layer BELOW a corrected one is refused."""
     from oracle import lowprec as lp
     from efficientvideoclassification_youtube8m_amd import ops
     from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
@@ -673,10 +674,11 @@ def test_high_precision_dithered_layer_images_follow_the_weights():
     tw = g.teacher
     if "EVC_HIGH_DITHER_LAYERS" in os.environ:
         pytest.skip("the default layout is under test")
-    assert tw.fp8_lo() and tw.dither_layers() == (1,) and g.student.dither_layers() == ()
+    assert tw.fp8_lo() and tw.dither_layers() == (1,) and g.student.dither_layers() == (1,)       # (round 6: the student takes the teacher's layout)
     assert "layers [1] on 15 time-dithered" in tw.precision_layout()["l1"]
     k0, k1 = (k for k in tw.names if k.startswith("RNN_L1/") and k.endswith("kernel"))
     assert set(tw.shadow16d) == {k1} and k0 in tw.shadow16 and k0 in tw.shadow8 and k1 not in tw.shadow8
+    assert tw.act_lo() and tw.shadow8[k0].shape[1] == 2 * tw.store.p(k0).shape[1]            # [lo(Wx) | hi(Wx) | lo(Wh) | hi(Wh)]
     out = None
     for _ in range(2):
         out = g.step(xd, yd, nd, num_frames_host=n)
@@ -685,6 +687,17 @@ def test_high_precision_dithered_layer_images_follow_the_weights():
     want = lp.f16_dither_images(p1.cpu().numpy(), tw.l1_steps(), tw.dither_seed(k1))
     assert np.array_equal(tw.shadow16d[k1].cpu().numpy().view(np.uint16), want.view(np.uint16))
     assert torch.equal(tw.shadow16[k0], tw.store.p(k0).half())
+    want8 = torch.empty_like(tw.shadow8[k0])                        # layer 0's e4m3 rows from the update's epilogue = the cast of the new weights
+    ops.cast_fp8_lo(tw.store.p(k0), want8, hi_cols=F, hi_tail=True)
+    assert torch.equal(tw.shadow8[k0], want8)
+    for l2k in (k for k in tw.names if k.startswith("RNN_L2/") and k.endswith("kernel")):
+        w8 = torch.empty_like(tw.shadow8[l2k])
+        pk = tw.store.p(l2k)
+        if "cell_0" in l2k:
+            ops.cast_fp8_lo(pk[:, pk.shape[1] - H:], w8, hi_tail=True)
+        else:
+            ops.cast_fp8_lo(pk, w8, hi_cols=H, hi_tail=True)
+        assert torch.equal(tw.shadow8[l2k], w8), l2k
     sd = tw.state_dict()
     tw.shadow16d[k1].zero_()
     tw.load_state_dict(sd)
