@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void l2norm_chunk_kernel(const float* __restri
                                                            bf16_t* __restrict__ out2, int normalize,
                                                            bf16_t* __restrict__ out1_lo, bf16_t* __restrict__ out2_lo, int aux_mode,
                                                            const int* __restrict__ pos1, int P1,
-                                                           const int* __restrict__ pos2, int P2) {
+                                                           const int* __restrict__ pos2, int P2,
+                                                           float* __restrict__ rs1, float* __restrict__ rs2) {
   const int lane = threadIdx.x & 63;
   long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // b*T + s
   int b, s;
@@ -144,6 +145,37 @@ __global__ __launch_bounds__(256) void l2norm_chunk_kernel(const float* __restri
           }
           continue;
         }
+        if (aux_mode == 6) {          // U8 only (round 6): rows of 3F bytes [f16(2q - 255) (F halfwords: odd integers, EXACT) | e4m3(x 2^7) (F bytes)] and one
+                                      // f32 per frame, rs = (2/255) / |x_raw|: x = rs (c + 255/256), so layer 0 contracts the integers and applies rs to its
+                                      // accumulators (evc_lstm_layer_fwd_f16_fp8lo x_int): no rounding of the input frames at all
+          ushort4 h16;
+          float c8[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) c8[r] = fminf(fmaxf(xv[r] * 128.0f, -448.f), 448.f);
+          if (U8 && !pad) {
+            const uchar4 q = ((const uchar4*)(xq + row * F))[j];
+            h16.x = f32_to_f16(2.0f * q.x - 255.0f); h16.y = f32_to_f16(2.0f * q.y - 255.0f);
+            h16.z = f32_to_f16(2.0f * q.z - 255.0f); h16.w = f32_to_f16(2.0f * q.w - 255.0f);
+          } else {
+            h16 = make_ushort4(0, 0, 0, 0);
+          }
+          int w8 = __builtin_amdgcn_cvt_pk_fp8_f32(c8[0], c8[1], 0, false);
+          w8 = __builtin_amdgcn_cvt_pk_fp8_f32(c8[2], c8[3], w8, true);
+          const float rsv = pad ? 0.f : inv * (2.0f / 255.0f);
+          if (o1) {
+            bf16_t* rowp = out1_lo + (off1 / F) * (3L * F / 2);
+            ((ushort4*)rowp)[j] = h16;
+            ((int*)(rowp + F))[j] = w8;
+            if (lane == 0 && i == 0) rs1[off1 / F] = rsv;
+          }
+          if (o2 && out2_lo) {
+            bf16_t* rowp = out2_lo + (off2 / F) * (3L * F / 2);
+            ((ushort4*)rowp)[j] = h16;
+            ((int*)(rowp + F))[j] = w8;
+            if (lane == 0 && i == 0) rs2[off2 / F] = rsv;
+          }
+          continue;
+        }
         if (aux_mode == 5) {          // rows of 4F bytes: [f16(x) (F halfwords) | e4m3(x 2^7) (F bytes) | e4m3((x - f16(x)) 2^18) (F bytes)] - the x rows of
                                       // evc_lstm_layer_fwd_f16_fp8lo (the low-order half of x: |.| <= 2^-12 |x|, against e4m3(Wx 2^6) - same 2^24 in all)
           ushort4 h16;
@@ -209,11 +241,11 @@ __global__ __launch_bounds__(256) void l2norm_chunk_kernel(const float* __restri
   }
 }
 
-extern "C" int evc_l2norm_chunk_fwd(const float* x_raw, const uint8_t* x_u8, const int32_t* num_frames,
-                                    int B, int T, int F, int C1, evc_bf16* out1,
-                                    int every_n, int C2, evc_bf16* out2, int normalize,
-                                    evc_bf16* out1_lo, evc_bf16* out2_lo, int aux_mode,
-                                    const int32_t* row_pos1, int rows1, const int32_t* row_pos2, int rows2, void* stream) {
+static int l2norm_chunk_impl(const float* x_raw, const uint8_t* x_u8, const int32_t* num_frames,
+                             int B, int T, int F, int C1, evc_bf16* out1,
+                             int every_n, int C2, evc_bf16* out2, int normalize,
+                             evc_bf16* out1_lo, evc_bf16* out2_lo, int aux_mode,
+                             const int32_t* row_pos1, int rows1, const int32_t* row_pos2, int rows2, float* rs1, float* rs2, void* stream) {
   EVC_REQUIRE(B > 0 && T > 0 && F > 0 && F % 4 == 0 && F <= 1280, EVC_ERR_BAD_SHAPE,
               "evc_l2norm_chunk_fwd: F=%d must be a multiple of 4 and <= 1280", F);
   EVC_REQUIRE(C1 > 0 && T % C1 == 0, EVC_ERR_BAD_SHAPE, "evc_l2norm_chunk_fwd: T=%d not divisible by C1=%d", T, C1);
@@ -222,20 +254,43 @@ extern "C" int evc_l2norm_chunk_fwd(const float* x_raw, const uint8_t* x_u8, con
                 "evc_l2norm_chunk_fwd: student view T/every_n=%d not divisible by C2=%d", T / (every_n > 0 ? every_n : 1), C2);
   }
   EVC_REQUIRE(!x_u8 || num_frames, EVC_ERR_BAD_ARG, "evc_l2norm_chunk_fwd: uint8 input needs num_frames");
-  EVC_REQUIRE(aux_mode >= 0 && aux_mode <= 5, EVC_ERR_BAD_ARG, "evc_l2norm_chunk_fwd: aux_mode=%d (0 bf16 low halves, 1..3 f16 segments, 4 wide bf16, 5 f16 + two e4m3 images)", aux_mode);
-  EVC_REQUIRE(aux_mode != 5 || F % 32 == 0, EVC_ERR_BAD_SHAPE, "evc_l2norm_chunk_fwd: aux_mode 5 needs F %% 32 == 0 (16-byte aligned row parts), F=%d", F);
+  EVC_REQUIRE(aux_mode >= 0 && aux_mode <= 6, EVC_ERR_BAD_ARG, "evc_l2norm_chunk_fwd: aux_mode=%d (0 bf16 low halves, 1..3 f16 segments, 4 wide bf16, 5 f16 + two e4m3 images, 6 integer frames + row scales)", aux_mode);
+  EVC_REQUIRE(aux_mode < 5 || F % 32 == 0, EVC_ERR_BAD_SHAPE, "evc_l2norm_chunk_fwd: aux_mode 5 / 6 need F %% 32 == 0 (16-byte aligned row parts), F=%d", F);
+  EVC_REQUIRE(aux_mode != 6 || (x_u8 && normalize && (!out1_lo || rs1) && (!out2_lo || rs2)), EVC_ERR_BAD_ARG,
+              "evc_l2norm_chunk_int: the integer image needs the uint8 input, normalize = 1 and a row-scale array per second image");
   EVC_REQUIRE(out1 || out2, EVC_ERR_BAD_ARG, "evc_l2norm_chunk_fwd: neither view requested");
   EVC_REQUIRE(out1 || !out1_lo, EVC_ERR_BAD_ARG, "evc_l2norm_chunk_fwd: out1_lo without out1");
   const long rows = out1 ? (long)B * T : (long)B * (T / every_n);       // out1 == NULL: only the sub-sampled frames are touched
   dim3 grid((unsigned)((rows + 3) / 4));
   if (x_u8)
     hipLaunchKernelGGL(l2norm_chunk_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x_raw, x_u8, num_frames, B, T, F,
-                       C1, out1, every_n > 0 ? every_n : 1, C2, out2, normalize, out1_lo, out2_lo, aux_mode, row_pos1, rows1, row_pos2, rows2);
+                       C1, out1, every_n > 0 ? every_n : 1, C2, out2, normalize, out1_lo, out2_lo, aux_mode, row_pos1, rows1, row_pos2, rows2, rs1, rs2);
   else
     hipLaunchKernelGGL(l2norm_chunk_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x_raw, x_u8, num_frames, B, T, F,
-                       C1, out1, every_n > 0 ? every_n : 1, C2, out2, normalize, out1_lo, out2_lo, aux_mode, row_pos1, rows1, row_pos2, rows2);
+                       C1, out1, every_n > 0 ? every_n : 1, C2, out2, normalize, out1_lo, out2_lo, aux_mode, row_pos1, rows1, row_pos2, rows2, rs1, rs2);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
+}
+extern "C" int evc_l2norm_chunk_fwd(const float* x_raw, const uint8_t* x_u8, const int32_t* num_frames,
+                                    int B, int T, int F, int C1, evc_bf16* out1,
+                                    int every_n, int C2, evc_bf16* out2, int normalize,
+                                    evc_bf16* out1_lo, evc_bf16* out2_lo, int aux_mode,
+                                    const int32_t* row_pos1, int rows1, const int32_t* row_pos2, int rows2, void* stream) {
+  EVC_REQUIRE(aux_mode != 6, EVC_ERR_BAD_ARG, "evc_l2norm_chunk_fwd: aux_mode 6 (integer frames) is evc_l2norm_chunk_int");
+  return l2norm_chunk_impl(x_raw, x_u8, num_frames, B, T, F, C1, out1, every_n, C2, out2, normalize, out1_lo, out2_lo, aux_mode, row_pos1, rows1, row_pos2, rows2,
+                           nullptr, nullptr, stream);
+}
+// The reader's uint8 frames as EXACT f16 integers (round 6, "high" precision on the input the pipeline actually delivers, cs/readers.py:146-174):
+// Dequantize (cs/utils.py:22-25) is x = (2/255) (2q - 255) + 1/128, so the l2-normalised frame is rs (c + 255/256) with c = 2q - 255 an odd integer in
+// [-255, 255] and rs = (2/255) / |x| one f32 per frame.  Second images: rows of 3F bytes [f16(c) | e4m3(x_hat 2^7)]; rs1 / rs2 [steps][rows] f32 in
+// the images' row order (0 for padded frames, whose integers are 0 too).  Layer 0 contracts c against f16(Wx) - no rounding of the input at all -
+// and applies rs to its accumulators before the recurrent part (evc_lstm_layer_fwd_f16_fp8lo with x_int).  The bf16 images are the usual ones.
+extern "C" int evc_l2norm_chunk_int(const uint8_t* x_u8, const int32_t* num_frames, int B, int T, int F, int C1, evc_bf16* out1,
+                                    int every_n, int C2, evc_bf16* out2, evc_f16* out1_int, evc_f16* out2_int, float* rs1, float* rs2,
+                                    const int32_t* row_pos1, int rows1, const int32_t* row_pos2, int rows2, void* stream) {
+  EVC_REQUIRE(x_u8 && num_frames, EVC_ERR_BAD_ARG, "evc_l2norm_chunk_int: uint8 frames and their counts are required");
+  return l2norm_chunk_impl(nullptr, x_u8, num_frames, B, T, F, C1, out1, every_n, C2, out2, 1, (evc_bf16*)out1_int, (evc_bf16*)out2_int, 6,
+                           row_pos1, rows1, row_pos2, rows2, rs1, rs2, stream);
 }
 
 // ---------------------------------------------------------------------------

@@ -191,8 +191,9 @@ __device__ __forceinline__ void lstm_fwd_epilogue(const GemmOperands& p, const L
 #endif
 }
 
-template <class Cfg, bool SPLIT = false, bool F16 = false, bool FP8 = false>
+template <class Cfg, bool SPLIT = false, bool F16 = false, bool FP8 = false, bool XINT = false>
 __device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const LstmFwdParams& e, int tiles_m, int tiles_n, int bid) {
+  static_assert(!XINT || FP8, "the integer-frame form rides on the f16 + e4m3 loop");
   static_assert(Cfg::G == 4, "LSTM step needs the four gate groups");
   static_assert(!(SPLIT && F16), "split operands are bf16 halves");
   static_assert(!FP8 || (F16 && is_v3<Cfg>::value), "the e4m3 tail rides behind f16 stages of the 64-wide ring loop");
@@ -207,7 +208,9 @@ __device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const 
   // (SPLIT: the split-bf16 products hi.hi + hi.lo + lo.hi are a K-EXTENSION of the same loop - the caller hands A = [lo | hi] rows
   //  against B = [W_hi | W_lo] rows as segment 1 and A = hi against B2 = W_hi as segment 2, evc_lstm_layer_fwd_hp - so the loop
   //  itself is the plain one; only the epilogue differs: it writes h_t's wide [lo | hi] image for the next step.)
-  run_mainloop<Cfg, 4, true, false, EVC_FWD_LOOP_MODE | (F16 ? LOOP_F16 : 0) | (FP8 ? LOOP_FP8_TAIL : 0)>(p, m0, u0, acc);   // transposed accumulators: lane = one row, 4 consecutive units
+  // (XINT, round 6: e.bias holds (255/256) colsum(f16(Wx)) here - the accumulators start from the constant term of the dequantised frames - and the
+  //  loop rescales them by the frame's factor and adds the true bias behind the x-part: LOOP_ROW_SCALE)
+  run_mainloop<Cfg, 4, true, false, EVC_FWD_LOOP_MODE | (F16 ? LOOP_F16 : 0) | (FP8 ? LOOP_FP8_TAIL : 0) | (XINT ? LOOP_ROW_SCALE : 0)>(p, m0, u0, acc);   // transposed accumulators: lane = one row, 4 consecutive units
   EVC_STAMP(p.stamp_slot, 2);
   lstm_fwd_epilogue<Cfg, SPLIT, F16, FP8>(p, e, m0, u0, acc);
 }
@@ -256,9 +259,9 @@ extern "C" int evc_debug_read_stamps(unsigned long long* out) {     // out: [8][
 }
 #endif
 
-template <class Cfg, bool SPLIT = false, bool F16 = false, bool FP8 = false>
+template <class Cfg, bool SPLIT = false, bool F16 = false, bool FP8 = false, bool XINT = false>
 __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_step_kernel(GemmOperands p, LstmFwdParams e, int tiles_m, int tiles_n) {
-  lstm_fwd_step_body<Cfg, SPLIT, F16, FP8>(p, e, tiles_m, tiles_n, blockIdx.x);
+  lstm_fwd_step_body<Cfg, SPLIT, F16, FP8, XINT>(p, e, tiles_m, tiles_n, blockIdx.x);
 }
 
 // Two independent steps of the same geometry in one launch (the first tiles_m*tiles_n workgroups run step a, the
@@ -301,14 +304,14 @@ typedef TileCfg2<64, 4, 64, 2, 4, 5, true> CfgLstmV2_64;
 typedef TileCfg2<64, 4, 16, 4, 1, 5, true> CfgLstmV2Small;
 typedef TileCfg3<64, 4, 16, 4, 1, 4> CfgLstmV3Small;         // the same tile on 64-wide K stages (64 KB of LDS: still two workgroups per CU)   // 64 rows x 16 units x 4 gates on the ring loop, 4 waves, 40 KB: M ~ batch steps
 
-template <class Cfg, bool SPLIT = false, bool F16 = false, bool FP8 = false>
+template <class Cfg, bool SPLIT = false, bool F16 = false, bool FP8 = false, bool XINT = false>
 static inline void launch_lstm_fwd(GemmOperands p, const LstmFwdParams& e, int k1, int k2, hipStream_t st) {
   p.nk1 = k1 / kdiv<Cfg>(); p.nk2 = k2 / kdiv<Cfg>();
 #ifdef EVC_STAMPS
   p.stamp_slot = e.t & 7;
 #endif
   const int tm = ceil_div(e.M, Cfg::BM), tn = ceil_div(e.H, Cfg::BU);
-  launch_cfg<Cfg>(lstm_fwd_step_kernel<Cfg, SPLIT, F16, FP8>, tm * tn, st, p, e, tm, tn);
+  launch_cfg<Cfg>(lstm_fwd_step_kernel<Cfg, SPLIT, F16, FP8, XINT>, tm * tn, st, p, e, tm, tn);
 }
 
 // forward tile for a step over `rows` rows: index into {320, 288, 256, 224, 192, 160 (v2), 128 (v1), 64 (v1), 128 (v2), 64 (v2)}
@@ -591,8 +594,11 @@ extern "C" int evc_lstm_layer_fwd_f16_fp8lo(const evc_f16* x, int64_t ldx, int k
                                             const uint8_t* wT8, int w8_scale_exp, int h_lo, const float* bias, const int32_t* len,
                                             int T, int M, int H, evc_f16* hbuf, evc_bf16* hbuf_bf16, float* c_state, float* h_state,
                                             int64_t ld_state, void* gates, evc_bf16* c_all, const int32_t* row_map,
-                                            const int32_t* rows_per_step, void* stream) {
+                                            const int32_t* rows_per_step, const float* x_row_scale, const float* x_col_const, int b8_gap, void* stream) {
   EVC_REQUIRE(T > 0 && M > 0 && H > 0 && kx16 > 0 && kx8 > 0, EVC_ERR_BAD_SHAPE, "evc_lstm_layer_fwd_f16_fp8lo: bad shape");
+  EVC_REQUIRE((x_row_scale == nullptr) == (x_col_const == nullptr) && b8_gap >= 0 && b8_gap % 128 == 0 && (x_row_scale || b8_gap == 0) &&
+              (!x_col_const || ((uintptr_t)x_col_const % 16) == 0), EVC_ERR_BAD_ARG,
+              "evc_lstm_layer_fwd_f16_fp8lo: x_row_scale and x_col_const go together (16-byte aligned), b8_gap=%d (%%128) only with them", b8_gap);
   EVC_REQUIRE(kx16 % 64 == 0 && H % 128 == 0 && kx8 % 128 == 0 && kx8 >= 384, EVC_ERR_BAD_SHAPE,
               "evc_lstm_layer_fwd_f16_fp8lo: kx16=%d (%%64), H=%d (%%128), kx8=%d (%%128, >= 384: the ring must be full of e4m3 stages at t = 0)", kx16, H, kx8);
   EVC_REQUIRE(x && wT16 && wT8 && hbuf && hbuf_bf16 && bias && len, EVC_ERR_BAD_ARG, "evc_lstm_layer_fwd_f16_fp8lo: NULL operand");
@@ -633,12 +639,15 @@ extern "C" int evc_lstm_layer_fwd_f16_fp8lo(const evc_f16* x, int64_t ldx, int k
     p.B = (const bf16_t*)wT16; p.ldb = (long)kx16 + H;
     p.A3 = (const uint8_t*)xt + x8_off; p.lda3 = ldx * 2; p.nk3 = kx8 / 128;
     p.A4 = (const uint8_t*)(hprev + H); p.lda4 = ldh * 2; p.nk4 = t == 0 ? 0 : kh8 / 128;
-    p.B8 = wT8; p.ldb8 = (long)kx8 + kh8;
+    p.B8 = wT8; p.ldb8 = (long)kx8 + b8_gap + kh8; p.b8_gap = b8_gap;
     p.scale8_exp = -(7 + w8_scale_exp);
+    if (x_row_scale) {          // integer frames: acc = acc * rs[row] + bias behind the x-part of the f16 stages; the accumulators start from x_col_const
+      p.row_scale = x_row_scale + (long)t * M; p.col_add = bias; p.g2_add = 1.0f;
+    }
     const int k1 = kx16, k2 = t == 0 ? 0 : H;
     LstmFwdParams e;
     e.zx = nullptr; e.ldzx = 0;
-    e.bias = bias; e.len = len; e.t = t;
+    e.bias = x_col_const ? x_col_const : bias; e.len = len; e.t = t;
     e.c_state = c_state; e.h_state = h_state; e.ld_state = ld_state;
     e.hout = hb + (long)(t + 1) * M * ldh; e.h_wide = h_lo ? 3 : 2;
     e.hout_lo = hbuf_bf16 + (long)(t + 1) * M * H;
@@ -646,6 +655,16 @@ extern "C" int evc_lstm_layer_fwd_f16_fp8lo(const evc_f16* x, int64_t ldx, int k
     e.c_hist = c_all ? c_all + (long)(t + 1) * M * H : nullptr;
     e.row_map = row_map;
     e.M = Mt; e.H = H;
+    if (x_row_scale) {
+      switch (pick_fwd_tile_v3(Mt, H)) {
+        case 0: launch_lstm_fwd<CfgLstmV3_256, false, true, true, true>(p, e, k1, k2, st); break;
+        case 1: launch_lstm_fwd<CfgLstmV3_224, false, true, true, true>(p, e, k1, k2, st); break;
+        case 2: launch_lstm_fwd<CfgLstmV3_192, false, true, true, true>(p, e, k1, k2, st); break;
+        case 4: launch_lstm_fwd<CfgLstmV3_240, false, true, true, true>(p, e, k1, k2, st); break;
+        default: launch_lstm_fwd<CfgLstmV3_160, false, true, true, true>(p, e, k1, k2, st); break;
+      }
+      continue;
+    }
     switch (pick_fwd_tile_v3(Mt, H)) {
       case 0: launch_lstm_fwd<CfgLstmV3_256, false, true, true>(p, e, k1, k2, st); break;
       case 1: launch_lstm_fwd<CfgLstmV3_224, false, true, true>(p, e, k1, k2, st); break;

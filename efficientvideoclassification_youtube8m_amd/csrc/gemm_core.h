@@ -59,6 +59,9 @@ struct GemmOperands {
   // dynamic range of the A8 image (round 6): 64 partial |x| maxima (evc_absmax_partials) and the exponent the image was asked for; the kernel adds
   // fp8_range_drop(amax_ws, a8_hi_exp) to scale8_exp - the shift the writer of the image applied (evc_cast_f32_to_f16_fp8x_dyn).  nullptr: fixed scale.
   const float* amax_ws = nullptr; int a8_hi_exp = 0;
+  // LOOP_ROW_SCALE (round 6): behind the A1 segment acc = acc * row_scale[row] + col_add[g * group_stride + unit] (+ g2_add for column group 2);
+  // b8_gap: bytes of B8's rows skipped between the A3 and the A4 segment's columns (a weight image that holds a block this launch does not contract)
+  const float* row_scale = nullptr; const float* col_add = nullptr; float g2_add = 0.f; long b8_gap = 0;
 #ifdef EVC_STAMPS
   int stamp_slot = 0;                    // diagnostic build: which slot of evc_stamps this launch writes (gemm_core_v3.h)
 #endif

@@ -38,6 +38,10 @@ constexpr int LOOP_PREFETCH = 32;
 //  LOOP_B_NT      (v3 loop) the B operand's LDS-DMA loads are non-temporal: for products whose B rows are read by ONE workgroup each (the batch-row
 //                 products, M <= 256: one row tile) - the weight matrix streams through the chip once and should not evict what the others re-read
 constexpr int LOOP_B_NT = 64;
+// v3 loop with LOOP_FP8_TAIL, transposed accumulators (SWAP): between the A1 and the A2 segment of the 16-bit stages every accumulator is
+// rescaled per ROW and offset per COLUMN - acc = acc * row_scale[row] + col_add[column] (GemmOperands) - the integer-frame form of an L1 layer's
+// step (round 6): the A1 segment contracts exact integers, the row scale is the frame's dequantise / l2-normalise factor.
+constexpr int LOOP_ROW_SCALE = 128;
 #ifndef EVC_LOOP_MODE_DEFAULT
 #define EVC_LOOP_MODE_DEFAULT 0
 #endif

@@ -144,7 +144,7 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
       const char* ab8 = s3 ? (const char*)p.A3 + (long)k8 * 128 : (const char*)p.A4 + (long)(k8 - p.nk3) * 128;
       ab = f ? ab : ab8;
       lda_b = f ? lda_b : (uint32_t)(s3 ? p.lda3 : p.lda4);
-      b_base = f ? b_base : (const char*)p.B8 + (long)k8 * 128;
+      b_base = f ? b_base : (const char*)p.B8 + (long)k8 * 128 + (s3 ? 0 : p.b8_gap);
       ldb_b = f ? ldb_b : (uint32_t)p.ldb8;
 #ifdef EVC_ABLATE_FP6   // TIMING ablation (wrong results): what an e2m3 tail could cost - the e-stages fetch DENSE stage-major rows of 96 bytes
       // (lanes 6, 7 of a row repeat chunk 5: 96 of the 128 bytes per row come from memory) and the MFMAs run in the FP6 formats
@@ -387,9 +387,44 @@ __device__ __forceinline__ void gemm_mainloop_v3(const GemmOperands& p, const in
     }
   } else {
     // ---- 16-bit stages (every one of them is followed by >= STAGES more stages: all trips refill), then the e4m3 stages ----
+    if constexpr ((MODE & LOOP_ROW_SCALE) != 0) {
+      static_assert(SWAP, "LOOP_ROW_SCALE is written for transposed accumulators (lane = one row, 4 consecutive units)");
+      // between two trips every MFMA of the stages before is issued into acc and the next stage's fragments are only READ: a plain VALU pass over
+      // the accumulators (MI x G x NI x 4 FMAs per lane, once per tile) is all the boundary costs
+      auto rescale = [&]() {
+        TileCoordsT<Cfg> tc;
+        float rsv[Cfg::MI];
+#pragma unroll
+        for (int mi = 0; mi < Cfg::MI; ++mi) {
+          const int m = m0 + tc.row0 + mi * 16;
+          rsv[mi] = m < p.M ? p.row_scale[m] : 0.f;
+        }
+#pragma unroll
+        for (int ni = 0; ni < Cfg::NI; ++ni) {
+          const int u = min(u0 + tc.unit0 + ni * 16, p.Nu - 4);
+#pragma unroll
+          for (int g = 0; g < Cfg::G; ++g) {
+            const float4 b = *(const float4*)(p.col_add + (long)g * p.group_stride + u);
+            const float fb = g == 2 ? p.g2_add : 0.f;
+#pragma unroll
+            for (int mi = 0; mi < Cfg::MI; ++mi) {
+              f32x4& a = acc[mi][g][ni];
+              a = f32x4{a[0] * rsv[mi] + (b.x + fb), a[1] * rsv[mi] + (b.y + fb), a[2] * rsv[mi] + (b.z + fb), a[3] * rsv[mi] + (b.w + fb)};
+            }
+          }
+        }
+      };
+      for (; j + 1 < nkf && j < p.nk1; ++j) trip16(std::true_type{});      // the A1 segment (all of it when an A2 segment follows)
+      if (j == p.nk1) rescale();                                           // ... an A2 segment follows: rescale between the two
+      for (; j + 1 < nkf; ++j) trip16(std::true_type{});
+      trip16(std::false_type{});
+      ++j;
+      if (p.nk2 == 0) rescale();                                           // no A2 segment (t = 0): behind the last 16-bit stage, before the e4m3 ones
+    } else {
     for (; j + 1 < nkf; ++j) trip16(std::true_type{});
     trip16(std::false_type{});
     ++j;
+    }
     // Two halves per trip, split by the tile's ROW fragments (the 16-bit trips split the stage's K range): half 1 multiplies the lower
     // row fragments while the upper ones are read; behind the barrier and the refill, half 2 multiplies the upper ones while the next
     // stage's lower row fragments and - column group by column group, as its last MFMA has been issued - its B fragments are read.

@@ -336,6 +336,19 @@ def input_image_args(*towers):
     return dict(f16_segments=max(t.f16_x_segments for t in tw))
 
 
+def input_views(g, x_raw, num_frames, tp, sp, need_student):
+    """The L1 input images of graph ``g``'s towers for one batch (ops.l2norm_chunk): (teacher view, student view), each the plain bf16 image or - in
+    the non-bf16 modes - a tuple (bf16 image, second image[, row scales]).  uint8 frames into "high" towers whose layer 0 is on the f16 + e4m3 form
+    take the INTEGER-frame images (ops.l2norm_chunk_int, HLstmTower.x_int: the input exact, round 6)."""
+    towers = [t for t in (g.teacher, g.student if need_student else None) if t is not None]
+    p1, p2 = (tp[2] if tp else None), (sp[3] if sp else None)
+    if x_raw.dtype == torch.uint8 and towers and all(t.precision == "high" and t.x_int() for t in towers):
+        return ops.l2norm_chunk_int(x_raw, num_frames, g.C1, g.every_n if need_student else None, g.C2, plan1=p1, plan2=p2, teacher_view=g.teacher is not None)
+    return ops.l2norm_chunk(x_raw, g.C1, g.every_n if need_student else None, g.C2, num_frames=num_frames if x_raw.dtype == torch.uint8 else None,
+                            split=towers[0].input_split(), plan1=p1, plan2=p2, teacher_view=g.teacher is not None,
+                            **input_image_args(g.teacher, g.student if need_student else None))
+
+
 def frame_counts_and_plans(g, num_frames, nh, need_teacher, need_student):
     """Frame counts (device) and the L1 row plans of both towers of graph ``g`` (DistillGraph / EvalGraph): rows
     sorted by length so the padding rows drop out of every L1 kernel (ops.RowPlan).  Host twins of the counts
@@ -522,11 +535,7 @@ class DistillGraph:
         need_student = self.student is not None
         main = torch.cuda.current_stream(dev)
         tp, sp = frame_counts_and_plans(self, num_frames, nh, self.teacher is not None, need_student)
-        xt, xs = ops.l2norm_chunk(x_raw, self.C1, self.every_n if need_student else None, self.C2,
-                                  num_frames=num_frames if x_raw.dtype == torch.uint8 else None,
-                                  split=(self.teacher or self.student).input_split(), plan1=tp[2] if tp else None,
-                                  plan2=sp[3] if sp else None, teacher_view=self.teacher is not None,     # (student only: the sub-sampled frames alone are read)
-                                  **input_image_args(self.teacher, self.student))
+        xt, xs = input_views(self, x_raw, num_frames, tp, sp, need_student)     # (student only: the sub-sampled frames alone are read)
         for tw in (self.teacher, self.student):     # step k-1's deferred MoE / L2-level updates: now, under this step's L1 forward
             if tw is not None:
                 tw.run_deferred()
@@ -778,9 +787,7 @@ class EvalGraph:
         split = self.student.input_split()
         u8 = x_raw.dtype == torch.uint8
         tp, sp = frame_counts_and_plans(self, num_frames, nh, self.teacher is not None, True)
-        xt, xs = ops.l2norm_chunk(x_raw, self.C1, self.every_n, self.C2, num_frames=num_frames if u8 else None, split=split,
-                                  plan1=tp[2] if tp else None, plan2=sp[3], teacher_view=self.teacher is not None,
-                                  **input_image_args(self.teacher, self.student))
+        xt, xs = input_views(self, x_raw, num_frames, tp, sp, True)
         self.losses.zero_()
         out = {}
         self._ev_in.record(main)

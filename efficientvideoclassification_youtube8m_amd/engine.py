@@ -186,7 +186,8 @@ class LstmStack:
             # "high" precision, many-row (L1) stacks: IEEE f16 operands, ONE MFMA product per depth - the cost of the bf16 step
             # at 2^-12 operand rounding (scripts/precision_budget.py: L1 states within ~3e-5 of float64 at trained magnitudes).
             # x = (bf16 image, f16 image): the bf16 one and the bf16 copies of h stay the operands of the backward products.
-            x_bf, x16 = x
+            x_bf, x16 = x[0], x[1]
+            x_rs = x[2] if len(x) > 2 else None      # integer-frame rows (ops.l2norm_chunk_int): the frames' row scales [T][rows] f32
             self.x_in, self.lens = x_bf, lens
             if self.scope == "RNN_L2" and L == 2 and plan is None:
                 # M ~ batch (the L2 level): wavefront pair launches on f16 operands, the upper layer's weights K-extended by their
@@ -227,7 +228,9 @@ class LstmStack:
                     self.hbuf16 = [torch.zeros((self.T + 1, self.M, widths[l]), dtype=ops.F16, device=self.hbuf[l].device) for l in range(L)]
                     self._hbuf16_widths = widths
                 h16 = [self._v(self.hbuf16[l], T + 1, M, widths[l]) for l in range(L)]
-                assert x16.shape[-1] == 2 * self.Kin, "the fp8 L1 level takes ops.l2norm_chunk(..., f16_segments=1, fp8_tail=True) rows"
+                assert x16.shape[-1] == (3 * self.Kin // 2 if x_rs is not None else 2 * self.Kin), \
+                    "the fp8 L1 level takes ops.l2norm_chunk(..., f16_segments=1, fp8_tail=True) rows (or ops.l2norm_chunk_int's)"
+                assert x_rs is None or tw.x_int(), "integer-frame rows need layer 0 on the f16 + e4m3 form (HLstmTower.x_int)"
                 inp, ldx, kx16 = x16, x16.shape[-1], self.Kin
                 for l in range(L):
                     kn, bn = self.names(l)
@@ -248,9 +251,15 @@ class LstmStack:
                                                     h16[l], hb[l], self.S[:, (2 * l) * H:], self.S[:, (2 * l + 1) * H:], 2 * L * H, gates[l], c_all[l], plan=plan)
                     else:
                         x8_off, kx8 = (2 * self.Kin, 2 * self.Kin) if l == 0 else (2 * H, 2 * H if al else H)
+                        xi, gap = None, 0
+                        if l == 0 and x_rs is not None:
+                            # integer frames: [f16(2q - 255) | e4m3(x_hat 2^7)] rows, the frame's factor applied to the accumulators behind the x-part;
+                            # no stages for the input's low-order half - the hi(Wx) block of the weight image is skipped (b8_gap)
+                            kx8, gap = self.Kin, self.Kin
+                            xi = (x_rs, tw.x_col_const[kn])
                         ops.lstm_layer_fwd_f16_fp8lo(inp, ldx, kx16, x8_off, kx8, tw.shadow16[kn], tw.shadow8[kn], tw.store.p(bn), lens, T, M, H,
                                                      h16[l], hb[l], self.S[:, (2 * l) * H:], self.S[:, (2 * l + 1) * H:], 2 * L * H,
-                                                     gates[l], c_all[l], plan=plan, h_lo=al)
+                                                     gates[l], c_all[l], plan=plan, h_lo=al, x_int=xi, b8_gap=gap)
                     if self.timing is not None:
                         e1 = torch.cuda.Event(enable_timing=True)
                         e1.record()
@@ -1231,6 +1240,26 @@ class HLstmTower(TowerBase):
     def act_lo(self):
         return bool(self.f16_act_lo and self.precision == "high")
 
+    # Round 6: on the reader's uint8 frames layer 0 contracts the EXACT integers 2q - 255 (evc_l2norm_chunk_int rows) and applies the frame's
+    # dequantise / l2-normalise factor to its accumulators (ops.lstm_layer_fwd_f16_fp8lo x_int): the f16 rounding of the input frames - whose e4m3 x e4m3
+    # correction still left 1.8e-3 on the logits of the worst 512-step draw - is gone, and so are its 9 e4m3 stages per step.  Needs layer 0 on the
+    # f16 + e4m3 form; f32 inputs keep the e4m3 correction.  EVC_HIGH_X_INT=0: always the f32-input form.
+    f16_x_int = os.environ.get("EVC_HIGH_X_INT", "1") != "0"
+
+    def x_int(self):
+        return bool(self.f16_x_int and self.fp8_lo() and 0 not in self.dither_layers() and not self.dither_wh0() and self.F % 128 == 0)
+
+    def _refresh_x_col_const(self, k):
+        """(255/256) sum_k f16(Wx[j][k]) of L1 layer 0's kernel - the constant term of the dequantised frames, from the f16 image the step contracts
+        (- 1 in the forget-gate block: the step kernels add forget_bias to whatever their accumulators start from)."""
+        if not (k.startswith("RNN_L1/") and "cell_0/" in k and k in getattr(self, "shadow16", {}) and self.x_int()):
+            return
+        if not hasattr(self, "x_col_const"):
+            self.x_col_const = {}
+        c = self.shadow16[k][:, :self.F].sum(dim=1, dtype=F32) * (255.0 / 256.0)
+        c[2 * self.H:3 * self.H] -= 1.0
+        self.x_col_const[k] = c.contiguous()
+
     def fp8_lo(self):
         """True if this tower's L1 level runs on ops.lstm_layer_fwd_f16_fp8lo (or, with dither(), on ops.lstm_layer_fwd_f16_dith)."""
         return (self.precision == "high" and self.f16_fp8_lo and self.F % 128 == 0 and self.H % 128 == 0 and self.F >= 384 and self.H >= 384)
@@ -1332,6 +1361,10 @@ class HLstmTower(TowerBase):
                 self.shadow_w[k] = torch.zeros((shp[0], 2 * shp[1]), dtype=BF16, device=dev)
 
     def _refresh_high(self, k):
+        self._refresh_high_images(k)
+        self._refresh_x_col_const(k)
+
+    def _refresh_high_images(self, k):
         p, H = self.store.p(k), self.H
         if k in self.shadow_w8:              # MoE head: f16(W) + [e4m3((W - f16(W)) 2^18) | e4m3(W 2^7)]
             ops.cast_f16(p, self.shadow_w16[k])
@@ -1389,6 +1422,8 @@ class HLstmTower(TowerBase):
                      activations=("low-order halves of h as e4m3 operands in every corrected layer (L1: the non-dithered ones; L2: both): rows [f16 | e4m3 | e4m3_lo] "
                                   "against [lo(W) | hi(W)]" if self.act_lo() else "f16, uncorrected (round-5 layout)"),
                      moe_input_range="from the batch (absmax -> shift)" if self.moe.dynamic_fp8_range else "fixed 2^6",
+                     uint8_frames=("layer 0 contracts the exact integers 2q - 255, the frame's factor applied to its accumulators (no input rounding, no "
+                                   "stages for an input low-order half)" if self.x_int() else "dequantised to f32 first: f16 image + e4m3 low-order half"),
                      fp8_scales=dict(lstm_w_lo_exp=ops.FP8_W_SCALE_EXP, lstm_wx_hi_exp=ops.FP8_WX_HI_EXP, **{"moe_" + k: v for k, v in ops.FP8_MOE.items()}))
         return d
 
@@ -1452,6 +1487,8 @@ class HLstmTower(TowerBase):
         # (only while the tower RUNS in "high": one laid out for it and switched to bf16 reads none of the T images; refresh_shadows rebuilds them on the way back)
         if self.precision == "high" and k in getattr(self, "shadow16d", {}):
             ops.cast_f16_dither(self.store.p(k), self.shadow16d[k], self.dither_seed(k), col0=self.dither_col0(k))
+        if self.precision == "high":
+            self._refresh_x_col_const(k)
 
     # ---- parameters -------------------------------------------------------
     def _init_params(self, seed):

@@ -401,17 +401,47 @@ def lstm_layer_fwd_f16(x16, wT16, bias, lens, T, M, Kin, H, hbuf16, hbuf_bf, c_s
 
 
 def lstm_layer_fwd_f16_fp8lo(x16, ldx, kx16, x8_off, kx8, wT16, wT8, bias, lens, T, M, H, hbuf16, hbuf_bf, c_state, h_state, ld_state,
-                             gates=None, c_all=None, plan=None, w8_scale_exp=FP8_W_SCALE_EXP, h_lo=False):
+                             gates=None, c_all=None, plan=None, w8_scale_exp=FP8_W_SCALE_EXP, h_lo=False, x_int=None, b8_gap=0):
     """lstm_layer_fwd_f16 with the weights' low-order halves contracted in fp8 (evc_lstm_layer_fwd_f16_fp8lo): x16 rows of ldx halfwords
     (kx16 halfwords of f16 operand at the row start, kx8 e4m3 bytes at byte offset x8_off), wT16 [4H][kx16 + H] f16, wT8 [4H][kx8 + H]
     uint8 (cast_fp8_lo), hbuf16 [(T+1)][M][3H/2] f16 containers = rows [f16(h) | e4m3(h 2^7)], hbuf_bf the bf16 copy of h.
     h_lo: the low-order half of h corrected too - hbuf16 [(T+1)][M][2H] containers = rows [f16(h) | e4m3(h 2^7) | e4m3((h - f16(h)) 2^18)],
-    wT8 [4H][kx8 + 2H] with the h-part [lo(Wh) | hi(Wh)] (cast_fp8_lo(hi_tail=True))."""
+    wT8 [4H][kx8 + 2H] with the h-part [lo(Wh) | hi(Wh)] (cast_fp8_lo(hi_tail=True)).
+    x_int = (row_scale [T][M] f32, col_const [4H] f32): the integer-frame form (x16 rows from l2norm_chunk_int: exact integers + e4m3(x_hat 2^7));
+    b8_gap: bytes of wT8's rows between the x-part this launch contracts and the h-part (the hi(Wx) block)."""
     assert x16.dtype == F16 and wT16.dtype == F16 and wT8.dtype == torch.uint8 and hbuf16.dtype == F16 and hbuf_bf.dtype == BF16
-    assert wT16.shape == (4 * H, kx16 + H) and wT8.shape == (4 * H, kx8 + (2 if h_lo else 1) * H) and wT16.is_contiguous() and wT8.is_contiguous()
+    assert wT16.shape == (4 * H, kx16 + H) and wT8.shape == (4 * H, kx8 + b8_gap + (2 if h_lo else 1) * H) and wT16.is_contiguous() and wT8.is_contiguous()
+    rs, cc = x_int if x_int is not None else (None, None)
+    assert x_int is None or (rs.dtype == F32 and cc.dtype == F32 and rs.numel() >= T * M and cc.numel() == 4 * H and rs.is_contiguous() and cc.is_contiguous())
     assert hbuf16.shape[-1] == (2 * H if h_lo else 3 * H // 2)
     _lib.call("evc_lstm_layer_fwd_f16_fp8lo", _p(x16), ldx, kx16, x8_off, kx8, _p(wT16), _p(wT8), w8_scale_exp, 1 if h_lo else 0, _p(bias), _p(lens), T, M, H,
-              _p(hbuf16), _p(hbuf_bf), _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_all), *_plan_args(plan), _stream())
+              _p(hbuf16), _p(hbuf_bf), _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_all), *_plan_args(plan), _p(rs), _p(cc), b8_gap, _stream())
+
+
+def l2norm_chunk_int(x_u8, num_frames, num_chunks, every_n=None, num_chunks_student=None, plan1=None, plan2=None, teacher_view=True):
+    """l2norm_chunk for the "high" mode on the reader's uint8 frames (evc_l2norm_chunk_int): per view (bf16 image, integer image, row scales) -
+    integer image rows of 3F/2 containers [f16(2q - 255) | e4m3(x_hat 2^7)], row scales [steps][rows] f32 with x_hat = rs (c + 255/256)."""
+    B, T, F = x_u8.shape
+    assert x_u8.dtype == torch.uint8 and F % 32 == 0 and (teacher_view or every_n)
+    dev = x_u8.device
+    rows1 = (plan1.P if plan1 is not None else num_chunks * B) if teacher_view else 0
+    L1 = T // num_chunks
+    out1 = torch.empty((L1, rows1, F), dtype=BF16, device=dev) if teacher_view else None
+    int1 = torch.empty((L1, rows1, 3 * F // 2), dtype=F16, device=dev) if teacher_view else None
+    rs1 = torch.zeros((L1, rows1), dtype=F32, device=dev) if teacher_view else None
+    out2 = int2 = rs2 = None
+    rows2 = 0
+    if every_n:
+        S = T // every_n
+        rows2 = plan2.P if plan2 is not None else num_chunks_student * B
+        L2 = S // num_chunks_student
+        out2 = torch.empty((L2, rows2, F), dtype=BF16, device=dev)
+        int2 = torch.empty((L2, rows2, 3 * F // 2), dtype=F16, device=dev)
+        rs2 = torch.zeros((L2, rows2), dtype=F32, device=dev)
+    _lib.call("evc_l2norm_chunk_int", _p(x_u8), _p(num_frames), B, T, F, num_chunks, _p(out1), every_n or 1, num_chunks_student or 1, _p(out2),
+              _p(int1), _p(int2), _p(rs1), _p(rs2), _p(plan1.pos) if (plan1 is not None and teacher_view) else None, rows1,
+              _p(plan2.pos) if plan2 is not None else None, rows2, _stream())
+    return ((out1, int1, rs1) if teacher_view else None), ((out2, int2, rs2) if every_n else None)
 
 
 def lstm_layer_fwd_f16_dith(x16, ldx, kx16, x8_off, kx8, wT16_steps, wT8, ldb8, scale8_exp, bias, lens, T, M, H, hbuf16, hbuf_bf, c_state, h_state,

@@ -36,7 +36,7 @@ extern "C" {
 #define EVC_ERR_HIP (-4)
 #define EVC_ERR_BAD_ARG (-5)
 
-#define EVC_VERSION 106   /* 106 (round 6): evc_lstm_layer_fwd_f16_fp8lo / evc_lstm_stack2_fwd_f16_fp8lo gained h_lo (low-order half of h corrected: 4H-byte h rows), evc_cast_f32_to_fp8_lohi, evc_lstm_adam_fused gained fp8_hi_tail; evc_absmax_partials, evc_cast_f32_to_f16_fp8x_dyn, evc_gemm_nt_f16_fp8_dyn (dynamic e4m3 range of the MoE head's input state); evc_l2norm_chunk_fwd accepts out1 == NULL (student-only graphs read the sub-sampled frames only), evc_clip_adam_small limited to 2^15 elements per tensor; 105 (round 5, second session): evc_cast_f32_to_f16_dither, evc_lstm_layer_fwd_f16_dith (time-dithered f16 weight images: an L1 layer of the "high" mode without stages for its weights' low-order halves), evc_gemm_tn2_rows (weight-gradient products that skip the dead rows of a row-planned level's time slabs); 104 (round 5): evc_lstm_level2_fwd, evc_ce_loss_ordered, evc_rep_loss_ordered, evc_gemm_tn2_slabs, evc_sum_slabs, evc_clip_adam_small; evc_moe_grad_update* accept p_bf16 == NULL (forward shadow not written), evc_lstm_stack2_bwd runs M <= 512 stacks on the skinny pair launches, evc_dbof_cluster_pool_fwd walks tiles (EVC_DBOF_WALK), EVC_DETERMINISTIC parsed as "set, not empty, not 0"; 103 (round 4): evc_sqnorm2_partials, evc_lstm_adam_fused, evc_gram_slabs, evc_moe_grad_norms, evc_moe_grad_update_apply, evc_adam2d_fused, evc_colsum_bf16_det, evc_sample_sequence_gather, evc_relu6_fwd/bwd, evc_framepool_mean_fwd/bwd, evc_stream_create_cu_mask / evc_stream_destroy; EVC_DETERMINISTIC=1 read by the library; 102: evc_lstm_layer_fwd_f16_fp8lo, evc_lstm_stack2_fwd_f16_fp8lo, evc_gemm_nt_f16_fp8, evc_cast_f32_to_fp8_lo, evc_cast_f32_to_f16_fp8x, aux_mode 5, evc_moe_grad_update_wide; 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
+#define EVC_VERSION 106   /* 106 (round 6): evc_l2norm_chunk_int + the x_row_scale / x_col_const / b8_gap arguments of evc_lstm_layer_fwd_f16_fp8lo (integer-frame layer 0: the uint8 input exact), evc_lstm_layer_fwd_f16_fp8lo / evc_lstm_stack2_fwd_f16_fp8lo gained h_lo (low-order half of h corrected: 4H-byte h rows), evc_cast_f32_to_fp8_lohi, evc_lstm_adam_fused gained fp8_hi_tail; evc_absmax_partials, evc_cast_f32_to_f16_fp8x_dyn, evc_gemm_nt_f16_fp8_dyn (dynamic e4m3 range of the MoE head's input state); evc_l2norm_chunk_fwd accepts out1 == NULL (student-only graphs read the sub-sampled frames only), evc_clip_adam_small limited to 2^15 elements per tensor; 105 (round 5, second session): evc_cast_f32_to_f16_dither, evc_lstm_layer_fwd_f16_dith (time-dithered f16 weight images: an L1 layer of the "high" mode without stages for its weights' low-order halves), evc_gemm_tn2_rows (weight-gradient products that skip the dead rows of a row-planned level's time slabs); 104 (round 5): evc_lstm_level2_fwd, evc_ce_loss_ordered, evc_rep_loss_ordered, evc_gemm_tn2_slabs, evc_sum_slabs, evc_clip_adam_small; evc_moe_grad_update* accept p_bf16 == NULL (forward shadow not written), evc_lstm_stack2_bwd runs M <= 512 stacks on the skinny pair launches, evc_dbof_cluster_pool_fwd walks tiles (EVC_DBOF_WALK), EVC_DETERMINISTIC parsed as "set, not empty, not 0"; 103 (round 4): evc_sqnorm2_partials, evc_lstm_adam_fused, evc_gram_slabs, evc_moe_grad_norms, evc_moe_grad_update_apply, evc_adam2d_fused, evc_colsum_bf16_det, evc_sample_sequence_gather, evc_relu6_fwd/bwd, evc_framepool_mean_fwd/bwd, evc_stream_create_cu_mask / evc_stream_destroy; EVC_DETERMINISTIC=1 read by the library; 102: evc_lstm_layer_fwd_f16_fp8lo, evc_lstm_stack2_fwd_f16_fp8lo, evc_gemm_nt_f16_fp8, evc_cast_f32_to_fp8_lo, evc_cast_f32_to_f16_fp8x, aux_mode 5, evc_moe_grad_update_wide; 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
 
 typedef uint16_t evc_bf16;
 typedef uint16_t evc_f16;   /* raw IEEE binary16 bits (the "high" precision forward operands of the L1 levels) */
@@ -201,7 +201,13 @@ int evc_lstm_layer_fwd_f16_fp8lo(const evc_f16* x, int64_t ldx, int kx16, int64_
                                  const uint8_t* wT8, int w8_scale_exp, int h_lo, const float* bias, const int32_t* len,
                                  int T, int M, int H, evc_f16* hbuf, evc_bf16* hbuf_bf16, float* c_state, float* h_state,
                                  int64_t ld_state, void* gates, evc_bf16* c_all, const int32_t* row_map,
-                                 const int32_t* rows_per_step, void* stream);
+                                 const int32_t* rows_per_step, const float* x_row_scale, const float* x_col_const, int b8_gap, void* stream);
+/* (x_row_scale / x_col_const != NULL, round 6: the INTEGER-FRAME form of the layer that reads the reader's uint8 frames - x rows from
+ * evc_l2norm_chunk_int: kx16 = F exact integers c = 2q - 255, kx8 = F bytes e4m3(x_hat 2^7) at x8_off = 2F; x_row_scale [T][M] f32 = rs of every frame
+ * row, x_col_const [4H] f32 = (255/256) sum_k f16(Wx[j][k]) (- 1 in the forget-gate block: the step kernels add forget_bias to their initial
+ * accumulators).  Behind the x-part of the f16 stages the accumulators become acc * rs[row] + bias: z = rs (c + 255/256) . f16(Wx) + ... with the input
+ * EXACT; its low-order e4m3 stages do not exist (b8_gap = the bytes of wT8's rows between the x-part's lo(Wx) block and the h-part: the hi(Wx) block
+ * of an image laid out for the f32-input form).  NULL / 0: the forms above.) */
 /* evc_lstm_layer_fwd_f16 on TIME-DITHERED weight images (DESIGN.md 7 "dither"): step t contracts
  *   z = [x16 | h16] . W16_t^T (IEEE f16; W16_t = the [4H][kx16 + H] image at wT16 + t * w16_step_stride halfwords, evc_cast_f32_to_f16_dither)
  *       + 2^-scale8_exp x8 . W8^T (OCP e4m3 stages behind the f16 ones; kx8 = 0: none)
@@ -488,6 +494,14 @@ int evc_clip_adam_step(float* p, const float* g, float* m, float* v, int64_t n, 
  * `count` device pointers / sizes (copied into the launch's arguments); n[i] <= 2^15 (one workgroup walks a tensor). */
 int evc_clip_adam_small(int count, float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n,
                         float* const* sums, float clip_norm, float lr_t, float beta1, float beta2, float eps, void* stream);
+
+/* The reader's uint8 frames as EXACT f16 integers (round 6; cs/readers.py:146-174 delivers uint8, cs/utils.py:22-25 dequantises x = (2/255)(2q - 255)
+ * + 1/128): second images with rows of 3F bytes [f16(2q - 255) (F halfwords) | e4m3(x_hat 2^7) (F bytes)] and rs1 / rs2 [steps][rows] f32 =
+ * (2/255) / |x| per frame row (0 for padded frames), x_hat = rs (c + 255/256).  out1 / out2: the usual bf16 images; row plans as
+ * evc_l2norm_chunk_fwd; out1 == NULL: student-only. */
+int evc_l2norm_chunk_int(const uint8_t* x_u8, const int32_t* num_frames, int B, int T, int F, int C1, evc_bf16* out1,
+                         int every_n, int C2, evc_bf16* out2, evc_f16* out1_int, evc_f16* out2_int, float* rs1, float* rs2,
+                         const int32_t* row_pos1, int rows1, const int32_t* row_pos2, int rows2, void* stream);
 
 /* ---- a11: FrameLevelLogisticModel pooling ------------------------------------
  * cs/frame_level_models.py:72-78: sum over ALL T (padded) frames / true n.

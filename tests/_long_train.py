@@ -38,6 +38,12 @@ def pool_batch(i, B, feature_size=1152, vocab_size=4716):
     return x.astype(np.float32), n, labels
 
 
+def eval_videos_q(B):
+    """The uint8 frames of eval_videos() (what the reader delivers; the input kernels dequantise and zero the padding rows themselves)."""
+    q, _, n, _ = mm.synthetic_batch(B, seed=9100, dtype=np.float32)
+    return q[:4].copy()
+
+
 def eval_videos(B):
     """The 4 videos the long-horizon tests compare with the oracle: the head of pool batch 0 (seen in training: the towers' states
     and logits on them are as large as training has made them)."""
@@ -68,6 +74,7 @@ def evaluate(ck, modes, B_train, dev="cuda:0"):
     for mode in modes:
         # mode = precision[:option,...][@batch] - options of the "high" layout, switched in-process: nodither (every L1 layer on its weights' e4m3
         # low-order halves), light (the student's L1 level on plain f16: the default up to round 5), fixedrange (the head's input on the fixed 2^6 scale);
+        # u8: the frames go in as the reader's uint8 quantisation (the integer-frame layer 0 of round 6; same values as the f32 frames);
         # @batch: the 4 evaluation videos at the head of a batch of that many (the rest: synthetic_batch(seed 92))
         spec, _, bs = mode.partition("@")
         prec, _, opts = spec.partition(":")
@@ -82,9 +89,11 @@ def evaluate(ck, modes, B_train, dev="cuda:0"):
             del os.environ["EVC_HIGH_STUDENT_LIGHT"]
         MoeHead.dynamic_fp8_range = saved_dyn and "fixedrange" not in opts
         xb, yb, nb, nhb = xd, yd, nd, n
+        if "u8" in opts:
+            xb = torch.from_numpy(eval_videos_q(B_train)).to(dev)
         if B > 4:
-            _, xr, nr, lr_ = mm.synthetic_batch(B - 4, seed=92, dtype=np.float32)
-            xb = torch.cat([xd, torch.from_numpy(xr).to(dev)])
+            qr, xr, nr, lr_ = mm.synthetic_batch(B - 4, seed=92, dtype=np.float32)
+            xb = torch.cat([xb, torch.from_numpy(qr if "u8" in opts else xr).to(dev)])
             yb = torch.cat([yd, torch.from_numpy(lr_.astype(np.uint8)).to(dev)])
             nhb = np.concatenate([n, nr])
             nb = torch.from_numpy(nhb).to(dev)

@@ -722,6 +722,121 @@ assert err_lo < 0.5 * err and err_lo < 2e-4, (err_lo, err)
 """
 
 
+@pytest.mark.parametrize("every_n,plans", [(10, False), (10, True), (30, True)])
+def test_l2norm_chunk_int_images_of_the_uint8_frames(ops, every_n, plans):
+    """evc_l2norm_chunk_int (round 6): the reader's uint8 frames as EXACT integers for the "high" layer 0 - per view the usual bf16 image, rows
+    [f16(2q - 255) | e4m3(x_hat 2^7)] and one f32 per frame row, rs = (2/255) / |x|: rs (c + 255/256) reproduces the l2-normalised dequantised
+    frame (cs/utils.py:22-25, cs/train.py:253-256) to f32 rounding; padded frames are all-zero rows with rs = 0; the e4m3 part equals the one of
+    the f32-input rows (aux_mode 5); student-only (teacher_view=False) gives the same student images."""
+    B, T, F, C2 = 6, 300, 1152, 5
+    q, x, n, _ = mm.synthetic_batch(B, seed=50 + every_n, dtype=np.float32)
+    n[0], n[1] = 300, 29
+    qd, nd = torch.from_numpy(q).to(DEV), torch.from_numpy(n).to(DEV)
+    S = T // every_n
+    p1 = p2 = None
+    if plans:
+        _, l1, _ = ops.frame_counts(nd, 1, 20, 15)
+        _, l1s, _ = ops.frame_counts(nd, every_n, C2, S // C2, subsampled=True)
+        p1 = ops.RowPlan(l1, ops.host_frame_counts(n, 1, 20, 15)[1], 15)
+        p2 = ops.RowPlan(l1s, ops.host_frame_counts(n, every_n, C2, S // C2, subsampled=True)[1], S // C2)
+    (b1, i1, r1), (b2, i2, r2) = ops.l2norm_chunk_int(qd, nd, 20, every_n, C2, plan1=p1, plan2=p2)
+    (f1, m1), (f2, m2) = ops.l2norm_chunk(qd, 20, every_n, C2, num_frames=nd, split="f16", f16_segments=1, fp8_tail=True, plan1=p1, plan2=p2)
+    for bf, ii, rs, fb, m5, plan, rows_all in ((b1, i1, r1, f1, m1, p1, 20 * B), (b2, i2, r2, f2, m2, p2, C2 * B)):
+        live = plan.rows[0] if plan is not None else rows_all
+        assert torch.equal(bf[:, :live], fb[:, :live])                                      # the bf16 image is the usual one
+        c = ii[:, :live, :F].float()
+        assert bool((c == c.round()).all()) and float(c.abs().max()) <= 255.0
+        x8 = ii[:, :live, F:].contiguous().view(torch.uint8)
+        x8_5 = m5[:, :live, F:3 * F // 2].contiguous().view(torch.uint8)
+        assert torch.equal(x8, x8_5)                                                          # e4m3(x_hat 2^7): the same bytes as the f32-input rows
+        xhat = rs[:, :live, None] * (c + 255.0 / 256.0)
+        dead = rs[:, :live] == 0
+        assert bool((c[dead] == 0).all())                                                     # padded frames: zero integers, zero scale
+        ref16 = m5[:, :live, :F].float()                                                      # f16(x_hat) of the f32-input rows
+        assert float((xhat - ref16)[~dead].abs().max()) <= 2.0 ** -11 * 1.001               # (|x_hat| <= 1: half an f16 ulp)
+        assert bool(((c[~dead] % 2).abs() == 1).all())                                        # odd integers 2q - 255
+    # exact reconstruction against numpy on the plain layout
+    if not plans:
+        xr = x.astype(np.float64)
+        xr[np.arange(T)[None, :] >= n[:, None]] = 0.0
+        nrm = np.sqrt((xr ** 2).sum(-1, keepdims=True))
+        xh = np.where(nrm > 0, xr / np.maximum(nrm, 1e-6), 0.0)                               # [B, T, F]
+        got = (r1[:, :, None] * (i1[:, :, :F].float() + 255.0 / 256.0)).cpu().double().numpy()  # [15][20 B][F], row = chunk * B + b
+        want = xh.reshape(B, 20, 15, F).transpose(2, 1, 0, 3).reshape(15, 20 * B, F)
+        assert np.abs(got - want).max() < 2e-7
+    only = ops.l2norm_chunk_int(qd, nd, 20, every_n, C2, plan2=p2, teacher_view=False)
+    live2 = p2.rows[0] if p2 is not None else C2 * B
+    assert only[0] is None and all(torch.equal(a[:, :live2], b[:, :live2]) for a, b in zip(only[1], (b2, i2, r2)))
+
+
+def test_lstm_layer_fwd_integer_frames_are_exact(ops):
+    """evc_lstm_layer_fwd_f16_fp8lo with x_int (round 6): layer 0 contracts the integers 2q - 255 against f16(Wx), rescales its accumulators by the
+    frame's factor behind the x-part (LOOP_ROW_SCALE) and starts them from (255/256) colsum(f16(Wx)); with the weights' and h's low-order halves in
+    e4m3 (h_lo) what is left against the float64 oracle on the EXACT dequantised, l2-normalised frames and exact weights is the corrections' own
+    quantisation: closer than the f32-input form (x rounded to f16, its low-order half in e4m3), row plans included."""
+    M, T, F, H = 700, 5, 384, 384
+    rng = np.random.default_rng(77)
+    q = rng.integers(0, 256, size=(M, T, F), dtype=np.uint8)
+    lens = rng.integers(0, T + 1, size=M).astype(np.int32)
+    lens[:3] = [0, T, 1]
+    xr = mm.dequantize(q.astype(np.float64))
+    xh = xr / np.sqrt((xr ** 2).sum(-1, keepdims=True))
+    k0 = (mm.glorot_uniform(rng, (F + H, 4 * H)) * 3.0).astype(np.float32)
+    b0 = (rng.standard_normal(4 * H) * 0.1).astype(np.float32)
+    s_ref, _ = mm.multi_rnn_seq_fwd(xh, lens, [(k0.astype(np.float64), b0.astype(np.float64))])
+    xt = torch.from_numpy(np.ascontiguousarray(xh.transpose(1, 0, 2)).astype(np.float32)).to(DEV)          # [T][M][F]
+    qt = torch.from_numpy(np.ascontiguousarray(q.transpose(1, 0, 2))).to(DEV)
+    kT = torch.from_numpy(np.ascontiguousarray(k0.T)).to(DEV)
+    w16 = torch.empty((4 * H, F + H), dtype=torch.float16, device=DEV)
+    ops.cast_f16(kT, w16)
+    w8 = torch.empty((4 * H, 2 * (F + H)), dtype=torch.uint8, device=DEV)
+    ops.cast_fp8_lo(kT, w8, hi_cols=F, hi_tail=True)
+    bd, ln = torch.from_numpy(b0).to(DEV), torch.from_numpy(lens).to(DEV)
+    # f32-input rows [f16(x) | e4m3(x 2^7) | e4m3(x_lo 2^18)] and integer rows [f16(2q - 255) | e4m3(x 2^7)] + row scales
+    rows5 = torch.zeros((T, M, 2 * F), dtype=torch.float16, device=DEV)
+    hi = xt.half()
+    rows5[:, :, :F] = hi
+    x8 = (xt * 128.0).clamp(-448, 448).to(torch.float8_e4m3fn)
+    rows5[:, :, F:3 * F // 2] = x8.view(torch.float16)
+    rows5[:, :, 3 * F // 2:] = ((xt - hi.float()) * 2.0 ** 18).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.float16)
+    rows6 = torch.zeros((T, M, 3 * F // 2), dtype=torch.float16, device=DEV)
+    rows6[:, :, :F] = (2.0 * qt.float() - 255.0).half()
+    rows6[:, :, F:] = x8.view(torch.float16)
+    nrm = torch.from_numpy(np.ascontiguousarray(np.sqrt((xr ** 2).sum(-1)).T)).to(DEV)                    # [T][M]
+    rs = ((2.0 / 255.0) / nrm).float().contiguous()
+    cc = w16[:, :F].sum(dim=1, dtype=torch.float32) * (255.0 / 256.0)
+    cc[2 * H:3 * H] -= 1.0
+    cc = cc.contiguous()
+
+    def run(int_form, plan=None):
+        src = rows6 if int_form else rows5
+        S = torch.zeros((M, 2 * H), dtype=torch.float32, device=DEV)
+        inp, lens_run, Mrun, rs_run = src, ln, M, rs
+        if plan is not None:
+            live = plan.rows[0]
+            inp = torch.zeros((T, plan.P, src.shape[-1]), dtype=torch.float16, device=DEV)
+            inp[:, :live] = src[:, plan.inv[:live].long()]
+            rs_run = torch.zeros((T, plan.P), dtype=torch.float32, device=DEV)
+            rs_run[:, :live] = rs[:, plan.inv[:live].long()]
+            lens_run, Mrun = plan.lens, plan.P
+        h16 = torch.full((T + 1, Mrun, 2 * H), float("nan"), dtype=torch.float16, device=DEV)
+        hbf = torch.full((T + 1, Mrun, H), float("nan"), dtype=torch.bfloat16, device=DEV)
+        if int_form:
+            ops.lstm_layer_fwd_f16_fp8lo(inp, 3 * F // 2, F, 2 * F, F, w16, w8, bd, lens_run, T, Mrun, H, h16, hbf, S[:, :H], S[:, H:], 2 * H, plan=plan,
+                                         h_lo=True, x_int=(rs_run, cc), b8_gap=F)
+        else:
+            ops.lstm_layer_fwd_f16_fp8lo(inp, 2 * F, F, 2 * F, 2 * F, w16, w8, bd, lens_run, T, Mrun, H, h16, hbf, S[:, :H], S[:, H:], 2 * H, plan=plan, h_lo=True)
+        return S.cpu().double().numpy()
+    e_f32 = np.abs(run(False) - s_ref).max()
+    got = run(True)
+    e_int = np.abs(got - s_ref).max()
+    plan = ops.RowPlan(ln, lens, T)
+    assert np.abs(run(True, plan) - got).max() < 1e-6
+    print("layer 0 on integer frames: state err %.2e (f32-input form with the e4m3 x_lo correction: %.2e)" % (e_int, e_f32))
+    assert np.isfinite(got).all() and np.all(got[0] == 0)
+    assert e_int < 1.5e-4 and e_int <= e_f32 * 1.05, (e_int, e_f32)
+
+
 def test_f16_dither_images_equal_the_oracle_bit_for_bit(ops):
     """evc_cast_f32_to_f16_dither against oracle/lowprec.py::f16_dither_images: every bit of every image - values over eleven decades (f16
     subnormals and values that underflow f16 among them), exact f16 values, zeros of both signs, a strided image stack, T = 1."""

@@ -690,7 +690,7 @@ def test_high_precision_dithered_layer_images_follow_the_weights():
     want8 = torch.empty_like(tw.shadow8[k0])                        # layer 0's e4m3 rows from the update's epilogue = the cast of the new weights
     ops.cast_fp8_lo(tw.store.p(k0), want8, hi_cols=F, hi_tail=True)
     assert torch.equal(tw.shadow8[k0], want8)
-    for l2k in (k for k in tw.names if k.startswith("RNN_L2/") and k.endswith("kernel")):
+    for l2k in (k for k in tw.names if k.startswith("RNN_L2/") and k.endswith("kernel") and k in tw.shadow8):      # (the L2 level's e4m3 form needs H >= 512)
         w8 = torch.empty_like(tw.shadow8[l2k])
         pk = tw.store.p(l2k)
         if "cell_0" in l2k:
