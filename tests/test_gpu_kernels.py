@@ -757,7 +757,7 @@ def test_l2norm_chunk_int_images_of_the_uint8_frames(ops, every_n, plans):
         assert bool(((c[~dead] % 2).abs() == 1).all())                                        # odd integers 2q - 255
     # exact reconstruction against numpy on the plain layout
     if not plans:
-        xr = x.astype(np.float64)
+        xr = mm.dequantize(q.astype(np.float64))            # (from q: n[0] was raised to 300 above, synthetic_batch's x is zero beyond ITS count)
         xr[np.arange(T)[None, :] >= n[:, None]] = 0.0
         nrm = np.sqrt((xr ** 2).sum(-1, keepdims=True))
         xh = np.where(nrm > 0, xr / np.maximum(nrm, 1e-6), 0.0)                               # [B, T, F]
