@@ -722,8 +722,9 @@ def main():
         for name, kw in (("cfg2_teacher_only_b256", dict(B=256, mode="teacher", every_n=10, dominant="bwd_step")),
                          ("cfg5_student_only_every_n30_b1024", dict(B=1024, mode="student", every_n=30, dominant="wgrad_tn")),
                          ("cfg3_all_300_frames_b256", dict(B=256, mode="teacher_student", every_n=10, all_full=True))):
-            r = retime_on_stall(lambda: run_hlstm(device, rank, world, kw["B"], kw["mode"], kw["every_n"], s_steps, s_warm,
-                                                  kw.get("all_full", False), "bf16", 4, roofline="dominant" in kw))
+            # (cfg 2 / cfg 5: 10 steps - a 5-step window of 4 ms steps read 3-5 % above the 20-step figure of the same box)
+            r = retime_on_stall(lambda: run_hlstm(device, rank, world, kw["B"], kw["mode"], kw["every_n"], 10 if "dominant" in kw else s_steps,
+                                                  3 if "dominant" in kw else s_warm, kw.get("all_full", False), "bf16", 4, roofline="dominant" in kw))
             oc[name] = {k: r[k] for k in keep if k in r}
             if "dominant" in kw and kw["dominant"] in r.get("rooflines", {}):
                 oc[name]["roofline"] = dict(r["rooflines"][kw["dominant"]], dominant_by="share of the step's kernel time (profiles/r06_digest_%s.txt)" % name.split("_")[0])

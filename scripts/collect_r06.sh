@@ -30,7 +30,7 @@ python scripts/pmc_summarize.py $O/pmc $O/pmc_traffic.json > $O/pmc_traffic.txt 
 python scripts/pmc_kernels.py $O/pmc $O/pmc_kernels.json > /dev/null 2>&1
 bash scripts/pmc_collect.sh $O/pmc_cfg5 --steps 3 --warmup 2 --no_cpu_baseline --no_secondary $C5 > /dev/null 2>&1
 python scripts/pmc_kernels.py $O/pmc_cfg5 $O/pmc_kernels_cfg5.json "gemm_tn 256x256 (cfg 5: weight gradients of the student's L1 / L2 levels)=gemm_tn_kernel<TileCfg2<256" \
-  "clip_adam (cfg 5: plain clip + TF-Adam of the materialised MoE gradient, B = 1024)=clip_adam_kernel" \
+  "clip_adam (cfg 5: plain clip + TF-Adam of the materialised MoE gradient at 1024 rows)=clip_adam_kernel" \
   "gemm_nt 256x256 ring 5 (cfg 5: MoE head forward products at 1024 rows)=gemm_nt_kernel<TileCfg2<256, 1, 256, 2, 4, 5, true>" \
   "gemm_nt 320x256 (cfg 5: materialised MoE gradient product)=gemm_nt_kernel<TileCfg2<320" \
   "lstm_adam_fused (cfg 5)=lstm_adam_fused_kernel" "grad_sqnorm (cfg 5)=grad_sqnorm_kernel" > /dev/null 2>&1
