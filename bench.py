@@ -300,10 +300,14 @@ def run_hlstm(device, rank, world, B, mode, every_n, steps, warmup, all_full=Fal
         if f16 and tower.fp8_lo():
             res["roofline"]["kernel"] = ("lstm_fwd_step_kernel<TileCfg3<BM,4,64,2,4,2>, F16, FP8> (teacher L1; BM = 160..256 per launch from the active rows): "
                                          "f16 stages, then e4m3 stages on v_mfma_scale_f32_16x16x128_f8f6f4")
+            k8_0 = (1.0 if input_u8 and tower.x_int() else 2.0) * F_FEAT + (2.0 if tower.act_lo() else 1.0) * H_CELLS     # e4m3 depth of layer 0
+            k8_1 = 0.0 if 1 in tower.dither_layers() else (2.0 if tower.act_lo() else 1.0) * 2 * H_CELLS               # ... of layer 1 (dithered: none)
             res["roofline"]["note"] = ("algorithmic FLOPs count K = Kin + H once, priced against the dense bf16/f16 peak; executed: that contraction on IEEE f16 "
-                                       "operands plus the low-order halves of every weight (and of the input frames in layer 0) on OCP e4m3 operands - K = "
-                                       "2 Kin + H (layer 0) / Kin + H (layer 1) more at twice the MFMA rate, i.e. %.2fx the algorithmic MFMA time over both layers "
-                                       "(round 3's f16 K-extensions: 2.27x)" % (1.0 + 0.5 * (2.0 * F_FEAT + 3.0 * H_CELLS) / (F_FEAT + 3.0 * H_CELLS)))
+                                       "operands plus e4m3 correction stages at twice the MFMA rate - layer 0: K8 = %d (low-order halves of the weights, of h%s), "
+                                       "layer 1: %s - i.e. %.2fx the algorithmic MFMA time over both layers (round 5: 1.31x, round 3's f16 K-extensions: 2.27x)"
+                                       % (k8_0, ", of the f32 input frames" if not (input_u8 and tower.x_int()) else "; the uint8 frames are contracted as exact integers",
+                                          "time-dithered f16 weight images, no e4m3 stages" if k8_1 == 0 else "K8 = %d" % k8_1,
+                                          1.0 + 0.5 * (k8_0 + k8_1) / (F_FEAT + 3.0 * H_CELLS)))
         elif f16:
             res["roofline"]["note"] = ("IEEE f16 operands (same MFMA rate as bf16: priced against the same dense peak); algorithmic FLOPs count "
                                        "K = Kin + H once - layer 0 executes its input part %dx (K-extension by the low-order half), i.e. "
@@ -696,16 +700,16 @@ def main():
             pm[other]["roofline"] = r["roofline"]
         _log("precision mode %s done: %.2f ms/step" % (other, r["ms_per_step"]))
         pm["bf16"]["logits_within_1e-3_of_f64_oracle"] = "at the reference's initialisation (|logit| <~ 1); ~1e-3*|logit| on trained weights"
-        pm["high"]["logits_within_1e-3_of_f64_oracle"] = "also on trained-magnitude weights (tests/test_gpu_step.py)"
-        pm["high"]["what"] = ("forward operands chosen by a measured error budget (scripts/precision_budget.py, DESIGN.md 7): every forward product on IEEE "
-                              "f16 operands (one MFMA product per depth) with the low-order halves of its weights as OCP e4m3 operands on the MX-scaled "
-                              "MFMA behind the f16 stages of the same launch - L1 level (evc_lstm_layer_fwd_f16_fp8lo: + the low-order half of the input "
-                              "frames), L2 level wavefront pair launches (evc_lstm_stack2_fwd_f16_fp8lo), MoE head (evc_gemm_nt_f16_fp8: both operands' "
-                              "corrections); the teacher's UPPER L1 layer on time-dithered f16 weight images instead of its weights' low-order halves "
-                              "(evc_lstm_layer_fwd_f16_dith: image t of evc_cast_f32_to_f16_dither at step t - the weight rounding errors cancel over the "
-                              "steps of a chunk; EVC_HIGH_DITHER_LAYERS, DESIGN.md 7: teacher logits 2.65e-4 mean / 6.3e-4 max over 36 weight draws; EVC_HIGH_DITHER_LAYERS= for the fully corrected layout: 2.65e-4 / 6.1e-4 over 34 draws at 1.21x); "
-                              "student tower's L1 level plain f16; all other operand images written by the optimizer kernels' epilogues "
-                              "(evc_lstm_adam_fused, evc_moe_grad_update_apply); backward products bf16 as in the bf16 mode")
+        pm["high"]["logits_within_1e-3_of_f64_oracle"] = "also on towers trained for 16 / 128 / 512 steps (tests/test_gpu_step.py::test_high_mode_holds_1e3_after_long_training)"
+        pm["high"]["what"] = ("forward operands chosen by a measured error budget (scripts/precision_budget.py, DESIGN.md 5): every forward product on IEEE "
+                              "f16 operands (one MFMA product per depth) with the low-order halves of its weights AND of its activations h (round 6) as OCP e4m3 "
+                              "operands on the MX-scaled MFMA behind the f16 stages of the same launch - L1 level (evc_lstm_layer_fwd_f16_fp8lo h_lo: + the low-order "
+                              "half of f32 input frames; uint8 frames are contracted as exact integers, other_configs.cfg3_uint8_input_b256), L2 level wavefront pair "
+                              "launches (evc_lstm_stack2_fwd_f16_fp8lo h_lo), MoE head (evc_gemm_nt_f16_fp8_dyn: both operands' corrections, the e4m3 range of the "
+                              "input state from the batch); the TOP L1 layer of both towers on time-dithered f16 weight images (evc_lstm_layer_fwd_f16_dith); all "
+                              "operand images written by the optimizer kernels' epilogues; backward products bf16 as in the bf16 mode.  Towers trained for 512 "
+                              "steps, 12 weight draws: teacher logits max 5.2e-4 (uint8 frames) / 8.5e-4 (f32 frames), student 3.5e-4 "
+                              "(profiles/r06_precision_robustness_long.txt; the round-5 layout: 2.8e-3)")
         pm["high"]["layout"] = r.get("high_layout") if other == "high" else head.get("high_layout")
         extra["precision_modes"] = pm
         oc = {}
