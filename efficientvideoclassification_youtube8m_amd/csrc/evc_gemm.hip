@@ -56,7 +56,7 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_nt_kernel(GemmOperands p, StoreP
       __syncthreads();
       if (wave_cols_in) {
         if (s.out_bf16) store_tile_via_lds<Cfg, 2>(acc, lds_dyn, s.C, s.ldc, s.M, s.N, m0, u0, s.bias);
-        else store_tile_via_lds<Cfg, 4>(acc, lds_dyn, s.C, s.ldc, s.M, s.N, m0, u0, s.bias);
+        else store_tile_via_lds<Cfg, 4>(acc, lds_dyn, s.C, s.ldc, s.M, s.N, m0, u0, s.bias, 0, s.sq_p, s.sq_l2, s.sq_out);
         return;
       }
     }
@@ -123,9 +123,14 @@ static inline void launch_gemm(GemmOperands p, StoreParams s, int K, int splits,
   launch_cfg<Cfg>(gemm_nt_kernel<Cfg>, tm * tn * splits, st, p, s, tm, tn);
 }
 
-extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, void* C, int64_t ldc,
-                           int M, int N, int K, const float* bias, int out_bf16, int accumulate, void* stream) {
+static int gemm_nt_impl(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, void* C, int64_t ldc,
+                        int M, int N, int K, const float* bias, int out_bf16, int accumulate, void* stream,
+                        const float* sq_p = nullptr, float sq_l2 = 0.f, float* sq_out = nullptr) {
   EVC_REQUIRE(M > 0 && N > 0 && K >= 0, EVC_ERR_BAD_SHAPE, "evc_gemm_nt: bad shape M=%d N=%d K=%d", M, N, K);
+  // fused squared norm: only where the product runs as ONE pass of ring tiles that store whole rows through LDS (no K split, no ragged edge)
+  EVC_REQUIRE(!sq_out || (!out_bf16 && !accumulate && !bias && M > 512 && N % 256 == 0 && K < 8192 && ldc % 4 == 0 && ((uintptr_t)C % 16) == 0 &&
+                          (!sq_p || ((uintptr_t)sq_p % 16) == 0) && forced_tile() == 0), EVC_ERR_BAD_ARG,
+              "evc_gemm_nt_sqnorm: needs a plain f32 product with M > 512, N %% 256 == 0, K < 8192, 16-byte aligned C / P (M=%d N=%d K=%d ldc=%ld)", M, N, K, (long)ldc);
   EVC_REQUIRE(K % 64 == 0, EVC_ERR_BAD_SHAPE, "evc_gemm_nt: K=%d must be a multiple of 64", K);
   EVC_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0,
               EVC_ERR_BAD_ALIGN, "evc_gemm_nt: operands must be 16-byte aligned (lda=%ld ldb=%ld)", (long)lda, (long)ldb);
@@ -137,6 +142,7 @@ extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
   p.B = B; p.ldb = ldb; p.group_stride = 0; p.M = M; p.Nu = N;
   p.A1lo = p.A2lo = p.Blo = nullptr;
   StoreParams s{C, ldc, M, N, bias, out_bf16, accumulate, 1, 0};
+  s.sq_p = sq_p; s.sq_l2 = sq_l2; s.sq_out = sq_out;
   hipStream_t st = (hipStream_t)stream;
   // M <= 256 (one row tile: the MoE head on a batch of videos, [B, K] x [N, K]^T with N or K ~ 14k): the product
   // streams the weight matrix once from HBM, so it wants ~256 workgroups pulling at the same time and a deep
@@ -208,6 +214,7 @@ extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
   // whole product is one round of <= 256 tiles (measured: 1024 x 4096 x 4096 50 vs 63 us, 2048^3 28 vs 38, 1280 x 1024 x 4096
   // 45 vs 58); beyond that two workgroups share a CU's L2 ingest and the v1 / 256x256 tiles win again
   if (pick == 2 && K >= 2048 && (long)ceil_div(M, 128) * ceil_div(N, 128) <= 256) pick = 5;
+  if (sq_out && (pick == 2 || pick == 3)) pick = ring;            // (the fused norm lives in the ring tiles' LDS store)
   if (forced_tile()) pick = forced_tile();
   static const bool nt_v3 = getenv("EVC_NT_BIG_V2") == nullptr;          // the 224/256-row tiles on two 64-wide stages (A/B switch: the five 32-wide ones)
   static const bool v3 = getenv("EVC_NT_V2_LOOP") == nullptr;      // 64-wide K stages for the 128-column ring tiles (A/B switch)
@@ -227,6 +234,19 @@ extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
   else launch_gemm<CfgPlainSmall>(p, s, K, 1, st);
   EVC_LAUNCH_CHECK();
   return EVC_OK;
+}
+extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, void* C, int64_t ldc,
+                           int M, int N, int K, const float* bias, int out_bf16, int accumulate, void* stream) {
+  return gemm_nt_impl(A, lda, B, ldb, C, ldc, M, N, K, bias, out_bf16, accumulate, stream);
+}
+// evc_gemm_nt (plain f32 output) + evc_grad_sqnorm in one pass (round 6): sums[0] += sum of (C + l2_coeff * P)^2, sums[1] += sum of P^2 over the product's elements, from
+// the tiles' stores (one f32 atomic per wave; P [M][N] f32 laid out as C, NULL with l2_coeff 0).  A weight gradient that is materialised anyway -
+// the MoE head at 1024 rows, cfg 5 - then needs no separate norm pass before its clip + Adam (8 of 40 bytes per parameter).  sums must be zeroed
+// by the caller; the order of the atomics is not fixed (EVC_DETERMINISTIC callers keep evc_grad_sqnorm).
+extern "C" int evc_gemm_nt_sqnorm(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K,
+                                  const float* P, float l2_coeff, float* sums, void* stream) {
+  EVC_REQUIRE(sums && (P || l2_coeff == 0.f), EVC_ERR_BAD_ARG, "evc_gemm_nt_sqnorm: sums must not be NULL; P == NULL needs l2_coeff == 0");
+  return gemm_nt_impl(A, lda, B, ldb, C, ldc, M, N, K, nullptr, 0, 0, stream, P, l2_coeff, sums);
 }
 
 // ---------------------------------------------------------------------------

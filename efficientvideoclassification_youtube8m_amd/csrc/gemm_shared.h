@@ -47,6 +47,8 @@ struct StoreParams {
   void* C; long ldc; int M, N; const float* bias; int out_bf16; int accumulate;
   int splits, ksteps_per_split;   // split-K: blockIdx = split * tiles + tile; partial sums joined by f32 atomics
   int ksteps8_per_split = 0;      // (FP8 kernels: e4m3 stages per split - a split takes the same share of both stage ranges)
+  // fused squared norm of the stored f32 tile (round 6, evc_gemm_nt_sqnorm): sq_out[0] += sum over the tile of (c + sq_l2 * sq_p)^2, sq_p laid out as C
+  const float* sq_p = nullptr; float sq_l2 = 0.f; float* sq_out = nullptr;
 };
 
 // Epilogue of the ring-tile (v2) kernels for a plain overwrite of C: every wave transposes its WM x WU sub-tile through
@@ -56,7 +58,9 @@ struct StoreParams {
 // acc: TRANSPOSED accumulators (lane 16g + l: row mi*16 + l, columns ni*16 + 4g .. 4g+3).  ES = bytes per output element.
 template <class Cfg, int ES, bool ATOMIC = false, bool RMW = false>     // RMW: C += tile by plain 16-byte read-modify-write (f32)
 __device__ __forceinline__ void store_tile_via_lds(f32x4 (&acc)[Cfg::MI][1][Cfg::NI], char* lds, void* C, long ldc, int M, int N,
-                                                   int m0, int u0, const float* bias, int row_il_H = 0) {
+                                                   int m0, int u0, const float* bias, int row_il_H = 0,
+                                                   const float* sq_p = nullptr, float sq_l2 = 0.f, float* sq_out = nullptr) {
+  float sq_acc = 0.f, sq_acc_p = 0.f;     // (plain f32 stores only: the tile's contribution to |C + sq_l2 * P|^2 and |P|^2, one atomic each per wave)
   static_assert(!ATOMIC || ES == 4, "split-K partial tiles are joined in f32");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave / Cfg::WC, wc = wave % Cfg::WC;
@@ -117,8 +121,28 @@ __device__ __forceinline__ void store_tile_via_lds(f32x4 (&acc)[Cfg::MI][1][Cfg:
             *(float4*)cp = make_float4(o.x + a.x, o.y + a.y, o.z + a.z, o.w + a.w);
           } else {
             *cp = q;
+            if constexpr (ES == 4) {
+              if (sq_out) {
+                float4 gq = *(const float4*)&q;
+                if (sq_p) {
+                  const float4 pv = *(const float4*)((const char*)sq_p + (orow * ldc + colw) * 4 + (lane % CPR) * 16);
+                  gq = make_float4(gq.x + sq_l2 * pv.x, gq.y + sq_l2 * pv.y, gq.z + sq_l2 * pv.z, gq.w + sq_l2 * pv.w);
+                  sq_acc_p += pv.x * pv.x + pv.y * pv.y + pv.z * pv.z + pv.w * pv.w;
+                }
+                sq_acc += gq.x * gq.x + gq.y * gq.y + gq.z * gq.z + gq.w * gq.w;
+              }
+            }
           }
         }
+      }
+    }
+  }
+  if constexpr (ES == 4 && !ATOMIC && !RMW) {
+    if (sq_out) {                 // (kernel-uniform)
+      const float t = wave_sum(sq_acc), tp = wave_sum(sq_acc_p);       // sums = {|C + l2 P|^2, |P|^2}: what evc_grad_sqnorm leaves
+      if (lane == 0) {
+        atomicAdd(sq_out, t);
+        if (sq_p) atomicAdd(sq_out + 1, tp);
       }
     }
   }

@@ -907,9 +907,12 @@ class MoeHead:
         ops.clip_adam_step(st.p(self.EBIAS), gb, st.view(st.m, self.EBIAS), st.view(st.v, self.EBIAS), 0.0,
                            tw.sums[idx[self.EBIAS]], clip_norm, lr_t, beta1, beta2, eps)
 
-    def backward(self, dpred, dx_init=None, weight_grads=True):
+    def backward(self, dpred, dx_init=None, weight_grads=True, presum_l2=None):
         """Returns dx [B,K] f32 (= dx_init + MoE contribution) and writes the three weight grads
-        (weight_grads=False: leaves only the factors for fused_update)."""
+        (weight_grads=False: leaves only the factors for fused_update).
+        presum_l2 (a float: the l2 coefficient; round 6): the two weight-gradient products also leave the per-tensor clip norms in the tower's norm rows
+        (ops.gemm_nt_sqnorm: no separate evc_grad_sqnorm pass - 8 of 40 bytes per parameter of the materialised update, cfg 5); the rows must
+        have been zeroed (TowerBase.begin_update) and apply_group() then skips the norm pass for TowerBase._presummed."""
         tw, B, V, Mx, K = self.tw, self.B, self.V, self.Mx, self.K
         ops.moe_tail_bwd(self.gate_logits, self.expert_logits, dpred, B, V, Mx, self.dgl, self.del_)
         V3p, V2p = self.dgl.shape[1], self.del_.shape[1]
@@ -925,8 +928,15 @@ class MoeHead:
         ops.transpose_to_bf16(self.dgl, B, V * (Mx + 1), self.dglT, Bp)
         ops.transpose_to_bf16(self.del_, B, V * Mx, self.delT, Bp)
         ops.transpose_to_bf16(self.x_bf, B, K, self.xT, Bp)
-        ops.gemm_nt(self.dglT, self.xT, V * (Mx + 1), K, Bp, tw.store.g(self.GATES))
-        ops.gemm_nt(self.delT, self.xT, V * Mx, K, Bp, tw.store.g(self.EXPERTS))
+        tw._presummed = set()
+        for name, aT, Vn in ((self.GATES, self.dglT, V * (Mx + 1)), (self.EXPERTS, self.delT, V * Mx)):
+            g = tw.store.g(name)
+            if presum_l2 is not None and ops.gemm_nt_sqnorm_ok(Vn, K, Bp) and g.data_ptr() % 16 == 0:
+                l2 = presum_l2 if name in tw.l2_names else 0.0
+                ops.gemm_nt_sqnorm(aT, self.xT, Vn, K, Bp, g, tw.store.p(name) if l2 else None, l2, tw.sums[list(tw.names).index(name)])
+                tw._presummed.add(name)
+            else:
+                ops.gemm_nt(aT, self.xT, Vn, K, Bp, g)
         ops.rowsum_bf16(self.delT, V * Mx, Bp, tw.store.g(self.EBIAS))
         return self.dx
 
@@ -1107,10 +1117,14 @@ class TowerBase:
                 ops.clip_adam_small([st.p(k) for k in grp], [st.g(k) for k in grp], [st.view(st.m, k) for k in grp], [st.view(st.v, k) for k in grp],
                                     [self.sums[idx[k]] for k in grp], clip_norm, lr_t, beta1, beta2, eps)
             rest = [k for k in rest if k not in small]
+        presummed = getattr(self, "_presummed", set())       # norm rows already filled by the gradient products (MoeHead.backward presum_l2)
         for k in rest:
+            if k in presummed:
+                continue
             l2 = l2_coeff if k in self.l2_names else 0.0
             # (tensors without a regulariser: the norm pass reads the gradient only)
             ops.grad_sqnorm(self.store.g(k), self.store.p(k) if k in self.l2_names else None, l2, self.sums[idx[k]])
+        self._presummed = set()
         for k in rest:
             l2 = l2_coeff if k in self.l2_names else 0.0
             ops.clip_adam_step(self.store.p(k), self.store.g(k), self.store.view(self.store.m, k),
@@ -1647,7 +1661,12 @@ class HLstmTower(TowerBase):
             raise RuntimeError("the MoE weights of %r are sharded over the ranks (fused data-parallel update); call "
                                "DistillGraph.consolidate() on every rank before an update that is not" % self.scope)
         ops.mark(self.scope + ":bwd_begin")
-        dS2 = self.moe.backward(dpred, dstate, weight_grads=not fuse)
+        early = aux is not None and early_apply is not None
+        if early:
+            self.begin_update()                     # (before the MoE backward: its gradient products may leave their clip norms in the norm rows)
+        # materialised MoE gradients that are clipped as they are (one process, or the all-reduce-free routes do not apply): norms from the products
+        presum = early_apply[2] if (early and not fuse and not route_rs and reduce_fn is None) else None
+        dS2 = self.moe.backward(dpred, dstate, weight_grads=not fuse, presum_l2=presum)
         ops.mark(self.scope + ":moe_bwd_done")
         if on_moe_grads_ready is not None:
             on_moe_grads_ready()
@@ -1656,7 +1675,6 @@ class HLstmTower(TowerBase):
         ostream = opt if opt is not None else aux
         late_moe = None
         if aux is not None and early_apply is not None:
-            self.begin_update()
             ev = torch.cuda.Event()
             ev.record(main)
             aux.wait_event(ev)

@@ -69,6 +69,19 @@ def _slab_rows_arg(live_rows, K):
     return slab, len(rows), (C.c_int32 * len(rows))(*[int(r) for r in rows])
 
 
+def gemm_nt_sqnorm(A, B, M, N, K, out, p, l2_coeff, sums):
+    """out [M,N] f32 = A[M,K] @ B[N,K]^T and sums[0] += |out + l2_coeff * p|^2 from the same pass (evc_gemm_nt_sqnorm; p laid out as out, or None with
+    l2_coeff 0; sums zeroed by the caller)."""
+    assert A.dtype == BF16 and B.dtype == BF16 and out.dtype == F32 and out.is_contiguous() and (p is None or (p.dtype == F32 and p.shape == out.shape and p.is_contiguous()))
+    _lib.call("evc_gemm_nt_sqnorm", _p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), M, N, K, _p(p), float(l2_coeff), _p(sums), _stream())
+    return out
+
+
+def gemm_nt_sqnorm_ok(M, N, K):
+    """Shapes evc_gemm_nt_sqnorm takes (one pass of ring tiles storing whole rows); never under EVC_DETERMINISTIC (its atomics arrive in any order)."""
+    return (not DETERMINISTIC) and M > 512 and N % 256 == 0 and K % 64 == 0 and K < 8192 and os.environ.get("EVC_FUSED_GRAD_NORM", "1") != "0"
+
+
 def gemm_tn(A, B, M, N, K, out, row_interleave_H=0, accumulate=False, lda=None, ldb=None, ldc=None, live_rows=None):
     """out[M,N] (+)= A[K,M]^T @ B[K,N] (both row-major over K), f32 out.  live_rows = (rows [T], slab_rows): K = T slabs of slab_rows rows
     of which the first rows[t] are live (a row-planned level) - the dead rows are skipped (evc_gemm_tn2_rows)."""

@@ -36,7 +36,7 @@ extern "C" {
 #define EVC_ERR_HIP (-4)
 #define EVC_ERR_BAD_ARG (-5)
 
-#define EVC_VERSION 106   /* 106 (round 6): evc_l2norm_chunk_int + the x_row_scale / x_col_const / b8_gap arguments of evc_lstm_layer_fwd_f16_fp8lo (integer-frame layer 0: the uint8 input exact), evc_lstm_layer_fwd_f16_fp8lo / evc_lstm_stack2_fwd_f16_fp8lo gained h_lo (low-order half of h corrected: 4H-byte h rows), evc_cast_f32_to_fp8_lohi, evc_lstm_adam_fused gained fp8_hi_tail; evc_absmax_partials, evc_cast_f32_to_f16_fp8x_dyn, evc_gemm_nt_f16_fp8_dyn (dynamic e4m3 range of the MoE head's input state); evc_l2norm_chunk_fwd accepts out1 == NULL (student-only graphs read the sub-sampled frames only), evc_clip_adam_small limited to 2^15 elements per tensor; 105 (round 5, second session): evc_cast_f32_to_f16_dither, evc_lstm_layer_fwd_f16_dith (time-dithered f16 weight images: an L1 layer of the "high" mode without stages for its weights' low-order halves), evc_gemm_tn2_rows (weight-gradient products that skip the dead rows of a row-planned level's time slabs); 104 (round 5): evc_lstm_level2_fwd, evc_ce_loss_ordered, evc_rep_loss_ordered, evc_gemm_tn2_slabs, evc_sum_slabs, evc_clip_adam_small; evc_moe_grad_update* accept p_bf16 == NULL (forward shadow not written), evc_lstm_stack2_bwd runs M <= 512 stacks on the skinny pair launches, evc_dbof_cluster_pool_fwd walks tiles (EVC_DBOF_WALK), EVC_DETERMINISTIC parsed as "set, not empty, not 0"; 103 (round 4): evc_sqnorm2_partials, evc_lstm_adam_fused, evc_gram_slabs, evc_moe_grad_norms, evc_moe_grad_update_apply, evc_adam2d_fused, evc_colsum_bf16_det, evc_sample_sequence_gather, evc_relu6_fwd/bwd, evc_framepool_mean_fwd/bwd, evc_stream_create_cu_mask / evc_stream_destroy; EVC_DETERMINISTIC=1 read by the library; 102: evc_lstm_layer_fwd_f16_fp8lo, evc_lstm_stack2_fwd_f16_fp8lo, evc_gemm_nt_f16_fp8, evc_cast_f32_to_fp8_lo, evc_cast_f32_to_f16_fp8x, aux_mode 5, evc_moe_grad_update_wide; 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
+#define EVC_VERSION 106   /* 106 (round 6): evc_gemm_nt_sqnorm, evc_l2norm_chunk_int + the x_row_scale / x_col_const / b8_gap arguments of evc_lstm_layer_fwd_f16_fp8lo (integer-frame layer 0: the uint8 input exact), evc_lstm_layer_fwd_f16_fp8lo / evc_lstm_stack2_fwd_f16_fp8lo gained h_lo (low-order half of h corrected: 4H-byte h rows), evc_cast_f32_to_fp8_lohi, evc_lstm_adam_fused gained fp8_hi_tail; evc_absmax_partials, evc_cast_f32_to_f16_fp8x_dyn, evc_gemm_nt_f16_fp8_dyn (dynamic e4m3 range of the MoE head's input state); evc_l2norm_chunk_fwd accepts out1 == NULL (student-only graphs read the sub-sampled frames only), evc_clip_adam_small limited to 2^15 elements per tensor; 105 (round 5, second session): evc_cast_f32_to_f16_dither, evc_lstm_layer_fwd_f16_dith (time-dithered f16 weight images: an L1 layer of the "high" mode without stages for its weights' low-order halves), evc_gemm_tn2_rows (weight-gradient products that skip the dead rows of a row-planned level's time slabs); 104 (round 5): evc_lstm_level2_fwd, evc_ce_loss_ordered, evc_rep_loss_ordered, evc_gemm_tn2_slabs, evc_sum_slabs, evc_clip_adam_small; evc_moe_grad_update* accept p_bf16 == NULL (forward shadow not written), evc_lstm_stack2_bwd runs M <= 512 stacks on the skinny pair launches, evc_dbof_cluster_pool_fwd walks tiles (EVC_DBOF_WALK), EVC_DETERMINISTIC parsed as "set, not empty, not 0"; 103 (round 4): evc_sqnorm2_partials, evc_lstm_adam_fused, evc_gram_slabs, evc_moe_grad_norms, evc_moe_grad_update_apply, evc_adam2d_fused, evc_colsum_bf16_det, evc_sample_sequence_gather, evc_relu6_fwd/bwd, evc_framepool_mean_fwd/bwd, evc_stream_create_cu_mask / evc_stream_destroy; EVC_DETERMINISTIC=1 read by the library; 102: evc_lstm_layer_fwd_f16_fp8lo, evc_lstm_stack2_fwd_f16_fp8lo, evc_gemm_nt_f16_fp8, evc_cast_f32_to_fp8_lo, evc_cast_f32_to_f16_fp8x, aux_mode 5, evc_moe_grad_update_wide; 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
 
 typedef uint16_t evc_bf16;
 typedef uint16_t evc_f16;   /* raw IEEE binary16 bits (the "high" precision forward operands of the L1 levels) */
@@ -110,6 +110,12 @@ int evc_frame_counts(const int32_t* num_frames, int B, int every_n, int subsampl
  * K % 64 == 0.  bias may be NULL. */
 int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, void* C, int64_t ldc,
                 int M, int N, int K, const float* bias, int out_bf16, int accumulate, void* stream);
+/* evc_gemm_nt (plain f32 output, no bias) + evc_grad_sqnorm in one pass (round 6): sums[0] += sum of (C + l2_coeff * P)^2 and sums[1] += sum of P^2 over the
+ * product's elements (what evc_grad_sqnorm leaves), from the tiles' stores (P [M][N] f32 laid out as C; NULL with l2_coeff 0).  The MoE weight gradient that is materialised at 1024 rows
+ * (cs/train.py:329-334 clip_by_norm of `MatMul(transpose_a=True)`, cs/video_level_models.py:423-435) needs no separate norm pass.  M > 512,
+ * N % 256 == 0, K < 8192; sums zeroed by the caller; atomics in arrival order (deterministic callers keep evc_grad_sqnorm). */
+int evc_gemm_nt_sqnorm(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K,
+                       const float* P, float l2_coeff, float* sums, void* stream);
 
 /* "TN" product for the weight gradients: C[M,N] (+)= A^T . B with A [K][lda] and B [K][ldb] bf16
  * (the contraction index is the ROW of both operands - dz, x and h are all [T*M rows][width]),

@@ -722,6 +722,36 @@ assert err_lo < 0.5 * err and err_lo < 2e-4, (err_lo, err)
 """
 
 
+@pytest.mark.parametrize("M,N,K,l2", [(14148, 4096, 1024, 2e-8), (9432, 4096, 1024, 0.0), (2000, 1024, 256, 0.5), (1400, 512, 4096, 1e-3)])
+def test_gemm_nt_with_the_clip_norm_from_the_same_pass(ops, M, N, K, l2):
+    """evc_gemm_nt_sqnorm (round 6; the MoE weight gradient materialised at 1024 rows, cfg 5): the product is bit-identical to evc_gemm_nt's and
+    the norm rows it leaves - {|C + l2 P|^2, |P|^2} from the tiles' stores - equal evc_grad_sqnorm's over the stored product (f32 sums in another
+    order: 1e-5 relative), with and without the l2 term; shapes it does not take are refused."""
+    torch.manual_seed(M + N + K)
+    A = (torch.randn(M, K, device=DEV) * 0.3).to(torch.bfloat16)
+    Bm = (torch.randn(N, K, device=DEV) * 0.3).to(torch.bfloat16)
+    P = torch.randn(M, N, device=DEV) * 2.0
+    assert ops.gemm_nt_sqnorm_ok(M, N, K)
+    ref = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm_nt(A, Bm, M, N, K, ref)
+    rs = torch.zeros(2, device=DEV)
+    ops.grad_sqnorm(ref, P if l2 else None, l2, rs)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    sums = torch.zeros(2, device=DEV)
+    ops.gemm_nt_sqnorm(A, Bm, M, N, K, out, P if l2 else None, l2, sums)
+    assert torch.equal(out, ref)
+    want = ((ref.double() + l2 * P.double()) ** 2).sum().item()
+    assert abs(sums[0].item() - want) <= 2e-5 * want and abs(sums[0].item() - rs[0].item()) <= 2e-5 * want, (sums, rs, want)
+    if l2:
+        wp = (P.double() ** 2).sum().item()
+        assert abs(sums[1].item() - wp) <= 2e-5 * wp and abs(rs[1].item() - wp) <= 2e-5 * wp
+    else:
+        assert sums[1].item() == 0.0
+    assert not ops.gemm_nt_sqnorm_ok(300, 4096, 1024) and not ops.gemm_nt_sqnorm_ok(2000, 1000, 1024)
+    with pytest.raises(Exception):
+        ops.gemm_nt_sqnorm(A[:300], Bm, 300, N, K, out[:300], None, 0.0, sums)
+
+
 @pytest.mark.parametrize("every_n,plans", [(10, False), (10, True), (30, True)])
 def test_l2norm_chunk_int_images_of_the_uint8_frames(ops, every_n, plans):
     """evc_l2norm_chunk_int (round 6): the reader's uint8 frames as EXACT integers for the "high" layer 0 - per view the usual bf16 image, rows
