@@ -20,7 +20,7 @@ SIGNATURES = {
     "evc_sort_rows_by_len": [vp, i32, i32, vp, vp, vp, vp],
     "evc_frame_counts": [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp],
     "evc_gemm_nt": [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i32, i32, vp],
-    "evc_gemm_nt_sqnorm": [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, f32, vp, vp],
+    "evc_gemm_nt_sqnorm": [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, f32, vp, vp, i64, vp],
     "evc_gemm_tn": [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, vp],
     "evc_gemm_tn2": [vp, i64, vp, i64, i32, vp, i64, i32, i32, vp, i64, i32, i32, i32, i32, vp],
     "evc_gemm_tn2_rows": [vp, i64, vp, i64, i32, vp, i64, i32, i32, vp, i64, i32, i32, i32, vp, i32, i32, vp],

@@ -242,11 +242,33 @@ extern "C" int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, in
 // evc_gemm_nt (plain f32 output) + evc_grad_sqnorm in one pass (round 6): sums[0] += sum of (C + l2_coeff * P)^2, sums[1] += sum of P^2 over the product's elements, from
 // the tiles' stores (one f32 atomic per wave; P [M][N] f32 laid out as C, NULL with l2_coeff 0).  A weight gradient that is materialised anyway -
 // the MoE head at 1024 rows, cfg 5 - then needs no separate norm pass before its clip + Adam (8 of 40 bytes per parameter).  sums must be zeroed
-// by the caller; the order of the atomics is not fixed (EVC_DETERMINISTIC callers keep evc_grad_sqnorm).
+// by the caller (the launch ADDS to them); every wave stores its partial pair into part_ws (>= 16 * ceil(M/128) * ceil(N/128) floats) and a one-block
+// finishing launch adds the slots in index order - no atomics, the same bits every run.
+__global__ __launch_bounds__(1024) void sum_pairs_kernel(const float* __restrict__ part, int n, float* __restrict__ sums) {
+  __shared__ float sh[2][16];
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) { a += part[2 * i]; b += part[2 * i + 1]; }     // fixed order per thread, fixed tree below
+  a = wave_sum(a); b = wave_sum(b);
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float ta = 0.f, tb = 0.f;
+    for (int i = 0; i < 16; ++i) { ta += sh[0][i]; tb += sh[1][i]; }
+    sums[0] += ta; sums[1] += tb;
+  }
+}
 extern "C" int evc_gemm_nt_sqnorm(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K,
-                                  const float* P, float l2_coeff, float* sums, void* stream) {
-  EVC_REQUIRE(sums && (P || l2_coeff == 0.f), EVC_ERR_BAD_ARG, "evc_gemm_nt_sqnorm: sums must not be NULL; P == NULL needs l2_coeff == 0");
-  return gemm_nt_impl(A, lda, B, ldb, C, ldc, M, N, K, nullptr, 0, 0, stream, P, l2_coeff, sums);
+                                  const float* P, float l2_coeff, float* sums, float* part_ws, int64_t part_ws_floats, void* stream) {
+  EVC_REQUIRE(sums && part_ws && (P || l2_coeff == 0.f), EVC_ERR_BAD_ARG, "evc_gemm_nt_sqnorm: sums / part_ws must not be NULL; P == NULL needs l2_coeff == 0");
+  // every wave of every tile owns one {|C + l2 P|^2, |P|^2} slot: at most ceil(M / 128) * ceil(N / 128) workgroups of 8 waves whatever tile is picked
+  const long slots = (long)ceil_div(M, 128) * ceil_div(N, 128) * 8;
+  EVC_REQUIRE(part_ws_floats >= 2 * slots, EVC_ERR_BAD_ARG, "evc_gemm_nt_sqnorm: part_ws holds %ld floats, %ld needed", (long)part_ws_floats, 2 * slots);
+  EVC_CHECK_HIP(hipMemsetAsync(part_ws, 0, (size_t)(2 * slots) * sizeof(float), (hipStream_t)stream));
+  const int rc = gemm_nt_impl(A, lda, B, ldb, C, ldc, M, N, K, nullptr, 0, 0, stream, P, l2_coeff, part_ws);
+  if (rc) return rc;
+  hipLaunchKernelGGL(sum_pairs_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, part_ws, (int)slots, sums);
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
 }
 
 // ---------------------------------------------------------------------------

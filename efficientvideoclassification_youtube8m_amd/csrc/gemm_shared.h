@@ -139,10 +139,13 @@ __device__ __forceinline__ void store_tile_via_lds(f32x4 (&acc)[Cfg::MI][1][Cfg:
   }
   if constexpr (ES == 4 && !ATOMIC && !RMW) {
     if (sq_out) {                 // (kernel-uniform)
-      const float t = wave_sum(sq_acc), tp = wave_sum(sq_acc_p);       // sums = {|C + l2 P|^2, |P|^2}: what evc_grad_sqnorm leaves
+      // one pair of PLAIN stores per wave into its own slot of the partials workspace (same-address atomics, ~12 ns apiece, cost the cfg-5 step
+      // 0.25 ms with 57 k of them); the caller's finishing launch adds the slots in index order: {|C + l2 P|^2, |P|^2}, the same bits every run
+      const float t = wave_sum(sq_acc), tp = wave_sum(sq_acc_p);
       if (lane == 0) {
-        atomicAdd(sq_out, t);
-        if (sq_p) atomicAdd(sq_out + 1, tp);
+        float* slot = sq_out + ((long)blockIdx.x * (Cfg::NT / 64) + wave) * 2;
+        slot[0] = t;
+        slot[1] = tp;
       }
     }
   }

@@ -933,7 +933,9 @@ class MoeHead:
             g = tw.store.g(name)
             if presum_l2 is not None and ops.gemm_nt_sqnorm_ok(Vn, K, Bp) and g.data_ptr() % 16 == 0:
                 l2 = presum_l2 if name in tw.l2_names else 0.0
-                ops.gemm_nt_sqnorm(aT, self.xT, Vn, K, Bp, g, tw.store.p(name) if l2 else None, l2, tw.sums[list(tw.names).index(name)])
+                if getattr(self, "sq_part", None) is None or self.sq_part.numel() < ops.gemm_nt_sqnorm_ws(Vn, K):
+                    self.sq_part = torch.empty(ops.gemm_nt_sqnorm_ws(V * (Mx + 1), K), dtype=F32, device=tw.device)
+                ops.gemm_nt_sqnorm(aT, self.xT, Vn, K, Bp, g, tw.store.p(name) if l2 else None, l2, tw.sums[list(tw.names).index(name)], ws=self.sq_part)
                 tw._presummed.add(name)
             else:
                 ops.gemm_nt(aT, self.xT, Vn, K, Bp, g)

@@ -69,17 +69,27 @@ def _slab_rows_arg(live_rows, K):
     return slab, len(rows), (C.c_int32 * len(rows))(*[int(r) for r in rows])
 
 
-def gemm_nt_sqnorm(A, B, M, N, K, out, p, l2_coeff, sums):
+def gemm_nt_sqnorm(A, B, M, N, K, out, p, l2_coeff, sums, ws=None):
     """out [M,N] f32 = A[M,K] @ B[N,K]^T and sums[0] += |out + l2_coeff * p|^2 from the same pass (evc_gemm_nt_sqnorm; p laid out as out, or None with
-    l2_coeff 0; sums zeroed by the caller)."""
+    l2_coeff 0; sums zeroed by the caller; ws: gemm_nt_sqnorm_ws(M, N) floats of scratch - per-wave partials summed in index order, no atomics)."""
     assert A.dtype == BF16 and B.dtype == BF16 and out.dtype == F32 and out.is_contiguous() and (p is None or (p.dtype == F32 and p.shape == out.shape and p.is_contiguous()))
-    _lib.call("evc_gemm_nt_sqnorm", _p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), M, N, K, _p(p), float(l2_coeff), _p(sums), _stream())
+    need = gemm_nt_sqnorm_ws(M, N)
+    if ws is None:                      # (callers on several streams keep their own: engine.MoeHead.sq_part)
+        ws = torch.empty(need, dtype=F32, device=out.device)
+    assert ws.dtype == F32 and ws.numel() >= need and ws.is_contiguous()
+    _lib.call("evc_gemm_nt_sqnorm", _p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), M, N, K, _p(p), float(l2_coeff), _p(sums), _p(ws), ws.numel(),
+              _stream())
     return out
 
 
+def gemm_nt_sqnorm_ws(M, N):
+    """Floats of scratch evc_gemm_nt_sqnorm needs: one {|C + l2 P|^2, |P|^2} slot per wave of every tile."""
+    return 16 * ((M + 127) // 128) * ((N + 127) // 128)
+
+
 def gemm_nt_sqnorm_ok(M, N, K):
-    """Shapes evc_gemm_nt_sqnorm takes (one pass of ring tiles storing whole rows); never under EVC_DETERMINISTIC (its atomics arrive in any order)."""
-    return (not DETERMINISTIC) and M > 512 and N % 256 == 0 and K % 64 == 0 and K < 8192 and os.environ.get("EVC_FUSED_GRAD_NORM", "1") != "0"
+    """Shapes evc_gemm_nt_sqnorm takes (one pass of ring tiles storing whole rows)."""
+    return M > 512 and N % 256 == 0 and K % 64 == 0 and K < 8192 and os.environ.get("EVC_FUSED_GRAD_NORM", "1") != "0"
 
 
 def gemm_tn(A, B, M, N, K, out, row_interleave_H=0, accumulate=False, lda=None, ldb=None, ldc=None, live_rows=None):

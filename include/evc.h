@@ -113,9 +113,10 @@ int evc_gemm_nt(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, 
 /* evc_gemm_nt (plain f32 output, no bias) + evc_grad_sqnorm in one pass (round 6): sums[0] += sum of (C + l2_coeff * P)^2 and sums[1] += sum of P^2 over the
  * product's elements (what evc_grad_sqnorm leaves), from the tiles' stores (P [M][N] f32 laid out as C; NULL with l2_coeff 0).  The MoE weight gradient that is materialised at 1024 rows
  * (cs/train.py:329-334 clip_by_norm of `MatMul(transpose_a=True)`, cs/video_level_models.py:423-435) needs no separate norm pass.  M > 512,
- * N % 256 == 0, K < 8192; sums zeroed by the caller; atomics in arrival order (deterministic callers keep evc_grad_sqnorm). */
+ * N % 256 == 0, K < 8192; the launch ADDS to sums (zeroed by the caller); part_ws: >= 16 ceil(M/128) ceil(N/128) floats of scratch - one slot per wave,
+ * summed in index order by a finishing launch (no atomics: bit-identical runs). */
 int evc_gemm_nt_sqnorm(const evc_bf16* A, int64_t lda, const evc_bf16* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K,
-                       const float* P, float l2_coeff, float* sums, void* stream);
+                       const float* P, float l2_coeff, float* sums, float* part_ws, int64_t part_ws_floats, void* stream);
 
 /* "TN" product for the weight gradients: C[M,N] (+)= A^T . B with A [K][lda] and B [K][ldb] bf16
  * (the contraction index is the ROW of both operands - dz, x and h are all [T*M rows][width]),

@@ -16,7 +16,7 @@ D=$(mktemp -d /tmp/evc_long.XXXXXX)
 for i in $(seq 1 $N); do
   rm -f $D/*.pt
   EVC_DETERMINISTIC=0 timeout 600 python3 scripts/long_horizon.py train $D 16 1e-3 $STEPS >> "$OUT.raw" 2>&1
-  timeout 600 python3 scripts/long_horizon.py eval $D "$MODES" 2>&1 | grep "^steps\|^   high" | cut -c1-260 >> "$OUT.raw"
+  timeout 600 python3 scripts/long_horizon.py eval $D "$MODES" 2>&1 | grep "^steps\|^   high\|^   split" | cut -c1-260 >> "$OUT.raw"
   echo "---" >> "$OUT.raw"
 done
 rm -rf $D
@@ -24,7 +24,7 @@ python3 - "$OUT.raw" "$N" "$STEPS" > "$OUT" <<'PY'
 import collections, re, sys
 d, order, mags = collections.defaultdict(lambda: {"t": [], "s": []}), [], []
 for l in open(sys.argv[1]):
-    m = re.match(r'\s+(high\S*)\s+t_pred \S+ t_state (\S+) t_gate (\S+) t_expert (\S+) s_pred \S+ s_state (\S+) s_gate (\S+) s_expert (\S+)(.*)', l)
+    m = re.match(r'\s+((?:high|split)\S*)\s+t_pred \S+ t_state (\S+) t_gate (\S+) t_expert (\S+) s_pred \S+ s_state (\S+) s_gate (\S+) s_expert (\S+)(.*)', l)
     if m:
         k = m.group(1)
         if k not in d:
