@@ -88,8 +88,11 @@ def gemm_nt_sqnorm_ws(M, N):
 
 
 def gemm_nt_sqnorm_ok(M, N, K):
-    """Shapes evc_gemm_nt_sqnorm takes (one pass of ring tiles storing whole rows)."""
-    return M > 512 and N % 256 == 0 and K % 64 == 0 and K < 8192 and os.environ.get("EVC_FUSED_GRAD_NORM", "1") != "0"
+    """Shapes evc_gemm_nt_sqnorm takes (one pass of ring tiles storing whole rows) - and whether to use it: OFF unless EVC_FUSED_GRAD_NORM=1.  Measured on
+    cfg 5 (the one configuration that materialises its MoE gradient), same box, alternating (profiles/r06_fused_grad_norm_ab.txt): 3.72-3.75 ms per step
+    with the norm from the product's stores against 3.61-3.63 with the separate evc_grad_sqnorm pass - reading P and squaring in the store epilogue costs
+    the two products more than the 0.19 ms pass it removes (with same-address atomics instead of per-wave partials: 3.95)."""
+    return M > 512 and N % 256 == 0 and K % 64 == 0 and K < 8192 and os.environ.get("EVC_FUSED_GRAD_NORM", "0") == "1"
 
 
 def gemm_tn(A, B, M, N, K, out, row_interleave_H=0, accumulate=False, lda=None, ldb=None, ldc=None, live_rows=None):

@@ -31,7 +31,7 @@ for l in open(sys.argv[1]):
             order.append(k)
         d[k]["t"].append(max(float(m.group(3)), float(m.group(4))))
         d[k]["s"].append(max(float(m.group(6)), float(m.group(7))))
-        if "sat {} {}" not in m.group(8):
+        if "sat" in m.group(8) and "sat {} {}" not in m.group(8):
             d[k].setdefault("sat", []).append(m.group(8).strip())
     m = re.match(r'steps\s+(\d+)\s+\|z\| teacher (\S+) student (\S+)\s+\|state\| teacher (\S+) student (\S+)', l)
     if m:

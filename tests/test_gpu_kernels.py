@@ -731,7 +731,6 @@ def test_gemm_nt_with_the_clip_norm_from_the_same_pass(ops, M, N, K, l2):
     A = (torch.randn(M, K, device=DEV) * 0.3).to(torch.bfloat16)
     Bm = (torch.randn(N, K, device=DEV) * 0.3).to(torch.bfloat16)
     P = torch.randn(M, N, device=DEV) * 2.0
-    assert ops.gemm_nt_sqnorm_ok(M, N, K)
     ref = torch.full((M, N), float("nan"), device=DEV)
     ops.gemm_nt(A, Bm, M, N, K, ref)
     rs = torch.zeros(2, device=DEV)
@@ -748,6 +747,7 @@ def test_gemm_nt_with_the_clip_norm_from_the_same_pass(ops, M, N, K, l2):
     else:
         assert sums[1].item() == 0.0
     assert not ops.gemm_nt_sqnorm_ok(300, 4096, 1024) and not ops.gemm_nt_sqnorm_ok(2000, 1000, 1024)
+    assert not ops.gemm_nt_sqnorm_ok(M, N, K) or os.environ.get("EVC_FUSED_GRAD_NORM") == "1"      # (measured slower on cfg 5: off unless asked for)
     with pytest.raises(Exception):
         ops.gemm_nt_sqnorm(A[:300], Bm, 300, N, K, out[:300], None, 0.0, sums)
 
