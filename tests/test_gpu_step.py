@@ -275,14 +275,18 @@ def test_real_dims_trained_magnitude_weights_both_precision_modes():
     assert all(errs["high"][k] < errs["bf16"][k] for k in errs["high"])
 
 
-def test_headline_batch_256_high_mode_on_trained_magnitude_weights():
+@pytest.mark.parametrize("frames", ["f32", "uint8"])
+def test_headline_batch_256_high_mode_on_trained_magnitude_weights(frames):
     """The mode that carries north_star's tolerance, at the batch bench.py times it on (B = 256: ~3.6 k live L1 rows per step, the
     224 / 256-row f16 + e4m3 forward tiles, the 256-row head products), on weights of trained magnitude: the first 4 videos of the
     batch against the float64 oracle at 1e-3 on logits, states and predictions of both towers; every output of the 256 finite, the
-    predictions in [0, 1]; the videos are independent (the B = 4 graph gives the same rows)."""
+    predictions in [0, 1]; the videos are independent (the B = 4 graph gives the same rows).  frames = "uint8" (round 6): the reader's bytes go in and
+    layer 0 of both towers contracts them as exact integers (evc_l2norm_chunk_int, HLstmTower.x_int) - the same oracle values."""
     from efficientvideoclassification_youtube8m_amd.distill import DistillGraph
     q, x, n, labels = mm.synthetic_batch(4, seed=91, dtype=np.float32)
     n[0] = 300
+    if frames == "uint8":                 # (video 0 now has 300 real frames: the oracle sees what the kernel dequantises)
+        x = mm.dequantize(q.astype(np.float32)).astype(np.float32)
     x[np.arange(300)[None, :] >= n[:, None]] = 0.0
     sd = _trained_magnitude_weights(4, x, n, labels)
     params = {sc: {k[len(sc) + 1:]: v.double().cpu().numpy() for k, v in sd.items() if k.startswith(sc + "/")}
@@ -291,12 +295,14 @@ def test_headline_batch_256_high_mode_on_trained_magnitude_weights():
     B = 256
     qb, xb, nb, lb = mm.synthetic_batch(B, seed=92, dtype=np.float32)
     xb[:4], nb[:4], lb[:4] = x, n, labels
-    xd, yd, nd = (torch.from_numpy(xb).to(DEV), torch.from_numpy(lb.astype(np.uint8)).to(DEV), torch.from_numpy(nb).to(DEV))
+    qb[:4] = q
+    xd, yd, nd = (torch.from_numpy(qb if frames == "uint8" else xb).to(DEV), torch.from_numpy(lb.astype(np.uint8)).to(DEV), torch.from_numpy(nb).to(DEV))
     g = DistillGraph(B, every_n=10, device=DEV, seed=3, precision="high")
     g.teacher.load_state_dict(sd)
     g.student.load_state_dict(sd)
     out = g.step(xd, yd, nd, apply=False, num_frames_host=nb)
     assert g.teacher.fp8_lo() and g.teacher.l1.plan is not None and g.teacher.l1.Mrun < 20 * B
+    assert g.teacher.x_int() and g.student.x_int() and g.teacher.act_lo()
     errs = {}
     for name, tw, sc, kp, ks in (("teacher", g.teacher, "model", "predictions", "teacher_state"),
                                  ("student", g.student, "model_student", "student_predictions", "student_state")):
