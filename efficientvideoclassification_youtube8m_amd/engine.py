@@ -1274,7 +1274,10 @@ class HLstmTower(TowerBase):
             self.x_col_const = {}
         c = self.shadow16[k][:, :self.F].sum(dim=1, dtype=F32) * (255.0 / 256.0)
         c[2 * self.H:3 * self.H] -= 1.0
-        self.x_col_const[k] = c.contiguous()
+        if k in self.x_col_const:            # in place: the buffer the step kernels read keeps its address (and its allocation stream)
+            self.x_col_const[k].copy_(c)
+        else:
+            self.x_col_const[k] = c.contiguous()
 
     def fp8_lo(self):
         """True if this tower's L1 level runs on ops.lstm_layer_fwd_f16_fp8lo (or, with dither(), on ops.lstm_layer_fwd_f16_dith)."""
