@@ -92,10 +92,13 @@ __device__ __forceinline__ float tanhf_(float x) {
 //   2  nt
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+// (store16: a store of more than 8 bytes reads its data registers late - a VALU write of them needs 2 wait states behind it on gfx940+, which the compiler
+//  inserts for its own stores but not behind an asm statement: the s_nop 1.  Found in round 6 with one s_or_b64 between the store and a v_or_b32 into its
+//  first data register: the tape's dword 0 of every chunk came out as that v_or's result, scripts/dbof_nt_diag.py.)
 template <int POLICY>
 __device__ __forceinline__ void store16(void* base, uint32_t off, u32x4_t v) {
-  if constexpr (POLICY == 1) asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(off), "v"(v), "s"(base) : "memory");
-  else if constexpr (POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(off), "v"(v), "s"(base) : "memory");
+  if constexpr (POLICY == 1) asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base) : "memory");
+  else if constexpr (POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base) : "memory");
   else *(u32x4_t*)((char*)base + off) = v;
 }
 template <int POLICY>

@@ -299,6 +299,10 @@ extern "C" int evc_dbof_input_bn_apply_f16fp8(const float* r, int B, int S, int 
 // ---------------------------------------------------------------------------------------------------------------
 // K4: the cluster GEMM with the statistics / max-pool epilogue
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef EVC_DBOF_ACT_POLICY
+#define EVC_DBOF_ACT_POLICY 2     // the 268 MB bf16 tape as non-temporal stores (round 6; profiles/r06_dbof_act_policy_ab.txt, same box, alternating: the cluster kernel
+                                   // in the cfg-4 step 317 -> 300 us, the step 1.70 -> 1.67 ms; sc1 write-through: no change; 0 = plain stores)
+#endif
 struct DbofPoolParams {
   bf16_t* act; long ld_act;        // [Mp][C] bf16 (training tape) or null
   float* part;                     // [2 * tiles_m][2][C] column partial sums or null (evaluation: moving statistics)
@@ -377,7 +381,14 @@ __device__ __forceinline__ void dbof_tile_epilogue(const GemmOperands& p, const 
           const int rl = it * 8 + (lane >> 3);
           const uint4 q = *(const uint4*)(wl + rl * RS + (((lane & 7) ^ (rl & 7)) << 4));
           const int row = rbase + r0 + rl;
-          if (row < p.M) *(uint4*)(e.act + (long)row * e.ld_act + colw + (lane & 7) * 8) = q;
+          if (row < p.M) {
+#if EVC_DBOF_ACT_POLICY      // A/B (round 6): the 268 MB bf16 tape leaves with a cache policy (1 = sc1 write-through, 2 = nt) instead of staying dirty in the XCD's L2
+            const u32x4_t qv = {q.x, q.y, q.z, q.w};
+            store16<EVC_DBOF_ACT_POLICY>(e.act, (uint32_t)(((long)row * e.ld_act + colw + (lane & 7) * 8) * 2), qv);
+#else
+            *(uint4*)(e.act + (long)row * e.ld_act + colw + (lane & 7) * 8) = q;
+#endif
+          }
         }
       }
     }
