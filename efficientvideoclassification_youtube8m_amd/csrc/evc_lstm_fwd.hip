@@ -85,6 +85,7 @@ __device__ __forceinline__ void lstm_fwd_epilogue(const GemmOperands& p, const L
     }
     // stores: uniform base + 32-bit lane byte offset (a time slab is far below 4 GiB: checked by the launchers), policy EVC_FWD_STORE_POLICY
     constexpr int SP = EVC_FWD_STORE_POLICY;
+    constexpr int TP = EVC_FWD_TAPE_POLICY;           // the write-once tapes of the backward pass (gate records, bf16 cell history) on their own policy
 #pragma unroll
     for (int mi = 0; mi < Cfg::MI; ++mi) {
       const int m = m0 + tc.row0 + mi * 16;
@@ -141,7 +142,7 @@ __device__ __forceinline__ void lstm_fwd_epilogue(const GemmOperands& p, const L
       }
       const u32x4_t cnv = {__float_as_uint(cn[0]), __float_as_uint(cn[1]), __float_as_uint(cn[2]), __float_as_uint(cn[3])};
       store16<SP>(e.c_state, su4, cnv);               // rows stop updating at t = len: what stays is the returned state
-      if (e.c_hist) store8<SP>(e.c_hist, hu * 2u, u32x2_t{pack_bf16x2(cn[0], cn[1]), pack_bf16x2(cn[2], cn[3])});
+      if (e.c_hist) store8<TP>(e.c_hist, hu * 2u, u32x2_t{pack_bf16x2(cn[0], cn[1]), pack_bf16x2(cn[2], cn[3])});
       if (e.t == ln[mi] - 1)
         store16<SP>(e.h_state, su4, u32x4_t{__float_as_uint(hn[0]), __float_as_uint(hn[1]), __float_as_uint(hn[2]), __float_as_uint(hn[3])});
       const u32x2_t hb = {pack_bf16x2(hn[0], hn[1]), pack_bf16x2(hn[2], hn[3])};
@@ -177,8 +178,8 @@ __device__ __forceinline__ void lstm_fwd_epilogue(const GemmOperands& p, const L
         store8<SP>(e.hout_lo, wo + (uint32_t)H * 2u, hb);
       }
       if (e.gates) {                                   // 4 units x 8 bytes
-        store16<SP>(e.gates, hu * 8u, u32x4_t{rec[0].x, rec[0].y, rec[1].x, rec[1].y});
-        store16<SP>(e.gates, hu * 8u + 16u, u32x4_t{rec[2].x, rec[2].y, rec[3].x, rec[3].y});
+        store16<TP>(e.gates, hu * 8u, u32x4_t{rec[0].x, rec[0].y, rec[1].x, rec[1].y});
+        store16<TP>(e.gates, hu * 8u + 16u, u32x4_t{rec[2].x, rec[2].y, rec[3].x, rec[3].y});
       }
     }
   }

@@ -8,6 +8,9 @@
 #ifndef EVC_FWD_STORE_POLICY
 #define EVC_FWD_STORE_POLICY 0      // cache policy of the forward step's epilogue stores (evc_common.h store16<>): 0 plain, 1 sc1 (write-through), 2 nt
 #endif
+#ifndef EVC_FWD_TAPE_POLICY
+#define EVC_FWD_TAPE_POLICY 0       // ... of its write-once tape stores alone (gate records + cell history: 36 of the 68 MB a teacher L1 launch writes)
+#endif
 #ifndef EVC_FWD_LOOP_MODE
 #define EVC_FWD_LOOP_MODE (LOOP_PRODUCER | LOOP_DMA_FIRST | LOOP_NO_PRIO)   // forward step: 81.7 -> 77.4 us per step
 #endif
