@@ -628,6 +628,12 @@ extern "C" int evc_dbof_pool_finish(const float* xsel, int B, int C, const float
 // data parallelism); empty frame slots get 0.  A workgroup owns one video x 2048 clusters: its per-column constants
 // and the video's (d, arg) stay in registers while it walks the video's 32 rows.
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef EVC_DBOF_DACT_ROWS
+#define EVC_DBOF_DACT_ROWS 32
+#endif
+#ifndef EVC_DBOF_DACT_NT
+#define EVC_DBOF_DACT_NT 1
+#endif
 __global__ __launch_bounds__(256) void dbof_dact_kernel(bf16_t* __restrict__ act, const float* __restrict__ dpooled,
                                                         const float* __restrict__ pooled, const uint8_t* __restrict__ arg,
                                                         const float* __restrict__ mean, const float* __restrict__ var,
@@ -662,24 +668,43 @@ __global__ __launch_bounds__(256) void dbof_dact_kernel(bf16_t* __restrict__ act
       if (y > 0.f && y < 6.f) { d[i] = dpooled[(long)b * C + c]; ar[i] = arg[(long)b * C + c]; }
     }
   }
-  for (int s = 0; s < SP; ++s) {
-    bf16_t* ap = act + dbof_row(b, s) * C + c0;
-    uint4 o = make_uint4(0u, 0u, 0u, 0u);
-    if (live && s < S) {
-      const uint4 q = *(const uint4*)ap;
-      const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-      uint32_t r[4];
+  // The walk is in place: written as load -> store per row, hipcc keeps each row's load behind the previous row's store (one 16-byte load in flight per lane:
+  // 3.5 TB/s).  DACT_ROWS rows are loaded before the first of them is stored (round 6; all 32 = the whole video in registers, nt loads: 0.154 -> 0.126 ms, 4.3 TB/s, profiles/r06_dbof_dact_ab.txt).
+  constexpr int DACT_ROWS = EVC_DBOF_DACT_ROWS;
+  static_assert(SP % DACT_ROWS == 0, "whole row groups");
+  for (int s0 = 0; s0 < SP; s0 += DACT_ROWS) {
+    uint4 q[DACT_ROWS];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float x0 = __uint_as_float(w[i] << 16), x1 = __uint_as_float(w[i] & 0xffff0000u);
-        const float h0 = (x0 - mu[2 * i]) * rs[2 * i], h1 = (x1 - mu[2 * i + 1]) * rs[2 * i + 1];
-        const float g0 = a[2 * i] * ((ar[2 * i] == s ? d[2 * i] : 0.f) - k1[2 * i] - h0 * k2[2 * i]);
-        const float g1 = a[2 * i + 1] * ((ar[2 * i + 1] == s ? d[2 * i + 1] : 0.f) - k1[2 * i + 1] - h1 * k2[2 * i + 1]);
-        r[i] = pack_bf16x2_hw(g0, g1);
+    for (int j = 0; j < DACT_ROWS; ++j) {
+      q[j] = make_uint4(0u, 0u, 0u, 0u);
+      if (live && s0 + j < S) {
+#if EVC_DBOF_DACT_NT
+        const u32x4_t t = __builtin_nontemporal_load((const u32x4_t*)(act + dbof_row(b, s0 + j) * C + c0));   // the tape is read once
+#else
+        const u32x4_t t = *(const u32x4_t*)(act + dbof_row(b, s0 + j) * C + c0);
+#endif
+        q[j] = make_uint4(t[0], t[1], t[2], t[3]);
       }
-      o = make_uint4(r[0], r[1], r[2], r[3]);
     }
-    *(uint4*)ap = o;
+#pragma unroll
+    for (int j = 0; j < DACT_ROWS; ++j) {
+      const int s = s0 + j;
+      uint4 o = make_uint4(0u, 0u, 0u, 0u);
+      if (live && s < S) {
+        const uint32_t w[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+        uint32_t r[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float x0 = __uint_as_float(w[i] << 16), x1 = __uint_as_float(w[i] & 0xffff0000u);
+          const float h0 = (x0 - mu[2 * i]) * rs[2 * i], h1 = (x1 - mu[2 * i + 1]) * rs[2 * i + 1];
+          const float g0 = a[2 * i] * ((ar[2 * i] == s ? d[2 * i] : 0.f) - k1[2 * i] - h0 * k2[2 * i]);
+          const float g1 = a[2 * i + 1] * ((ar[2 * i + 1] == s ? d[2 * i + 1] : 0.f) - k1[2 * i + 1] - h1 * k2[2 * i + 1]);
+          r[i] = pack_bf16x2_hw(g0, g1);
+        }
+        o = make_uint4(r[0], r[1], r[2], r[3]);
+      }
+      *(uint4*)(act + dbof_row(b, s) * C + c0) = o;
+    }
   }
 }
 extern "C" int evc_dbof_dact(evc_bf16* act, const float* dpooled, const float* pooled, const uint8_t* arg, const float* mean,
