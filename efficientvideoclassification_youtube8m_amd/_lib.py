@@ -36,6 +36,8 @@ SIGNATURES = {
     "evc_lstm_layer_fwd_f16": [vp, i64, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, i64, vp, vp, vp, vp, vp],
     "evc_lstm_layer_fwd_f16_fp8lo": [vp, i64, i32, i64, i32, vp, vp, i32, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, i32, vp],
     "evc_l2norm_chunk_int": [vp, vp, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp],
+    "evc_lstm_level2_fwd_high": [vp, i64, i32, i64, i32, vp, vp, i32, i32, vp, vp, vp, i32, vp, i64, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i64,
+                                 vp, vp, vp, vp, vp, vp, vp],
     "evc_lstm_layer_fwd_f16_dith": [vp, i64, i32, i64, i32, vp, i64, vp, i64, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp],
     "evc_cast_f32_to_f16_dither": [vp, i64, i32, i64, C.c_uint32, vp, i64, i64, vp],
     "evc_lstm_stack2_fwd_f16_fp8lo": [vp, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp],

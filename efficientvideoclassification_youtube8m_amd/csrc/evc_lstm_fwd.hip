@@ -220,12 +220,16 @@ __device__ __forceinline__ void lstm_fwd_step_body(const GemmOperands& p, const 
 // independent, so one launch runs both - every workgroup computes tile (tm, tn) of step a, then the same tile of step b.  Once every wave
 // has left the ring, the first stages of tile b are issued (gemm_mainloop_v3 PHASE 1) and land under tile a's gate tail (which needs no
 // LDS); tile b's loop starts on them (PHASE 2).  Per pair of steps that is one ring fill and one kernel boundary less.
-template <class Cfg, bool F16 = false, bool FP8 = false>
+// (round 6, the "high" L1 level: tile a = layer 0 on f16 + e4m3 stages (FP8, XINT: integer frames), tile b = the dithered upper layer on plain f16 stages
+//  (FP8B = false) - each tile's loop and gate tail in its own mode, the PHASE split as in bf16)
+template <class Cfg, bool F16 = false, bool FP8 = false, bool XINT = false, bool FP8B = FP8>
 __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_walk2_kernel(GemmOperands pa, LstmFwdParams ea, int tiles_ma, GemmOperands pb, LstmFwdParams eb,
                                                                  int tiles_mb, int tiles_n) {
   static_assert(is_v3<Cfg>::value && Cfg::G == 4, "tile walk: the 64-wide ring tiles");
-  static_assert(!FP8 || F16, "the e4m3 tail rides behind f16 stages");
-  constexpr int MODE = EVC_FWD_LOOP_MODE | (F16 ? LOOP_F16 : 0) | (FP8 ? LOOP_FP8_TAIL : 0);
+  static_assert((!FP8 && !FP8B) || F16, "the e4m3 tail rides behind f16 stages");
+  static_assert(!XINT || FP8, "the integer-frame form rides on the f16 + e4m3 loop");
+  constexpr int MODE_A = EVC_FWD_LOOP_MODE | (F16 ? LOOP_F16 : 0) | (FP8 ? LOOP_FP8_TAIL : 0) | (XINT ? LOOP_ROW_SCALE : 0);
+  constexpr int MODE_B = EVC_FWD_LOOP_MODE | (F16 ? LOOP_F16 : 0) | (FP8B ? LOOP_FP8_TAIL : 0);
   const int tiles_m = tiles_ma > tiles_mb ? tiles_ma : tiles_mb;
   const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   int tm, tn;
@@ -235,23 +239,23 @@ __global__ __launch_bounds__(Cfg::NT) void lstm_fwd_walk2_kernel(GemmOperands pa
   f32x4 acc[Cfg::MI][4][Cfg::NI];
   if (has_a) {
     lstm_fwd_acc_bias<Cfg>(ea, u0, acc);
-    gemm_mainloop_v3<Cfg, true, false, MODE, 0>(pa, m0, u0, lds_dyn, acc);
+    gemm_mainloop_v3<Cfg, true, false, MODE_A, 0>(pa, m0, u0, lds_dyn, acc);
     if (has_b) {
       __syncthreads();                                              // every wave has read its last ring slot
-      gemm_mainloop_v3<Cfg, true, false, MODE, 1>(pb, m0, u0, lds_dyn, acc);
+      gemm_mainloop_v3<Cfg, true, false, MODE_B, 1>(pb, m0, u0, lds_dyn, acc);
     }
     lstm_fwd_epilogue<Cfg, false, F16, FP8>(pa, ea, m0, u0, acc);
     if (has_b) {
       __builtin_amdgcn_sched_barrier(0);                            // (keep tile b's address set-up out of tile a's tail: register pressure)
       asm volatile("" ::: "memory");
       lstm_fwd_acc_bias<Cfg>(eb, u0, acc);
-      gemm_mainloop_v3<Cfg, true, false, MODE, 2>(pb, m0, u0, lds_dyn, acc);
-      lstm_fwd_epilogue<Cfg, false, F16, FP8>(pb, eb, m0, u0, acc);
+      gemm_mainloop_v3<Cfg, true, false, MODE_B, 2>(pb, m0, u0, lds_dyn, acc);
+      lstm_fwd_epilogue<Cfg, false, F16, FP8B>(pb, eb, m0, u0, acc);
     }
   } else if (has_b) {
     lstm_fwd_acc_bias<Cfg>(eb, u0, acc);
-    gemm_mainloop_v3<Cfg, true, false, MODE, 0>(pb, m0, u0, lds_dyn, acc);
-    lstm_fwd_epilogue<Cfg, false, F16, FP8>(pb, eb, m0, u0, acc);
+    gemm_mainloop_v3<Cfg, true, false, MODE_B, 0>(pb, m0, u0, lds_dyn, acc);
+    lstm_fwd_epilogue<Cfg, false, F16, FP8B>(pb, eb, m0, u0, acc);
   }
 }
 #ifdef EVC_STAMPS
@@ -478,14 +482,14 @@ static int lstm_layer_fwd_impl(const evc_bf16* x, const evc_bf16* wT, const floa
 // ===========================================================================
 // has_a / has_b: which of the two tiles exist (a level's first launch has only layer 0's step, its last only layer 1's: the same kernel with one role,
 // so that every launch of the level carries one kernel name - the per-kernel averages of a profile then cover exactly the launches bench.py times)
-template <class Cfg, bool F16 = false, bool FP8 = false>
+template <class Cfg, bool F16 = false, bool FP8 = false, bool XINT = false, bool FP8B = FP8>
 static inline void launch_lstm_fwd_walk2(GemmOperands pa, const LstmFwdParams& ea, int k1a, int k2a, bool has_a, GemmOperands pb, const LstmFwdParams& eb,
                                          int k1b, int k2b, bool has_b, hipStream_t st) {
   pa.nk1 = k1a / 64; pa.nk2 = k2a / 64;
   pb.nk1 = k1b / 64; pb.nk2 = k2b / 64;
   const int H = has_a ? ea.H : eb.H;
   const int tma = has_a ? ceil_div(ea.M, Cfg::BM) : 0, tmb = has_b ? ceil_div(eb.M, Cfg::BM) : 0, tn = ceil_div(H, Cfg::BU);
-  launch_cfg<Cfg>(lstm_fwd_walk2_kernel<Cfg, F16, FP8>, (tma > tmb ? tma : tmb) * tn, st, pa, ea, tma, pb, eb, tmb, tn);
+  launch_cfg<Cfg>(lstm_fwd_walk2_kernel<Cfg, F16, FP8, XINT, FP8B>, (tma > tmb ? tma : tmb) * tn, st, pa, ea, tma, pb, eb, tmb, tn);
 }
 
 extern "C" int evc_lstm_level2_fwd(const evc_bf16* x, const evc_bf16* wT0, const float* bias0, const evc_bf16* wT1, const float* bias1,
@@ -762,6 +766,144 @@ extern "C" int evc_lstm_layer_fwd_f16_dith(const evc_f16* x, int64_t ldx, int kx
       case 2: launch_lstm_fwd<CfgLstmV3_192, false, true, true>(p, e, k1, k2, st); break;
       case 4: launch_lstm_fwd<CfgLstmV3_240, false, true, true>(p, e, k1, k2, st); break;
       default: launch_lstm_fwd<CfgLstmV3_160, false, true, true>(p, e, k1, k2, st); break;
+    }
+  }
+  EVC_LAUNCH_CHECK();
+  return EVC_OK;
+}
+
+// The two-layer L1 level of the "high" mode in T + 1 launches (round 6): layer 0 as evc_lstm_layer_fwd_f16_fp8lo (f16 stages + the e4m3 stages of its
+// weights' / activations' low-order halves; integer frames with x_row_scale), layer 1 as evc_lstm_layer_fwd_f16_dith with kx8 = 0 (plain f16 stages on the
+// time-dithered image of its step), layer 0's step s and layer 1's step s-1 per launch, every workgroup walking both tiles (lstm_fwd_walk2_kernel: the second
+// tile's ring fill under the first tile's gate tail).  Same arithmetic as the two layer calls: bit-identical results.  Argument meaning as in those two
+// entries; hbuf0 rows are layer 1's x rows (row stride 2H halfwords with h_lo, else 3H/2).  Launches whose tile is not 224 / 240 / 256 rows run separately.
+extern "C" int evc_lstm_level2_fwd_high(const evc_f16* x, int64_t ldx, int kx16, int64_t x8_off, int kx8, const evc_f16* wT16_0, const uint8_t* wT8_0,
+                                        int w8_scale_exp, int h_lo, const float* bias0, const float* x_row_scale, const float* x_col_const, int b8_gap,
+                                        const evc_f16* wT16_1, int64_t w16_step_stride, const float* bias1, const int32_t* len, int T, int M, int H,
+                                        evc_f16* hbuf0, evc_bf16* hbuf0_bf16, evc_f16* hbuf1, evc_bf16* hbuf1_bf16, float* c_state0, float* h_state0,
+                                        float* c_state1, float* h_state1, int64_t ld_state, void* gates0, evc_bf16* c_all0, void* gates1, evc_bf16* c_all1,
+                                        const int32_t* row_map, const int32_t* rows_per_step, void* stream) {
+  EVC_REQUIRE(T > 0 && M > 0 && H > 0 && kx16 > 0 && kx8 > 0, EVC_ERR_BAD_SHAPE, "evc_lstm_level2_fwd_high: bad shape");
+  EVC_REQUIRE((x_row_scale == nullptr) == (x_col_const == nullptr) && b8_gap >= 0 && b8_gap % 128 == 0 && (x_row_scale || b8_gap == 0) &&
+              (!x_col_const || ((uintptr_t)x_col_const % 16) == 0), EVC_ERR_BAD_ARG,
+              "evc_lstm_level2_fwd_high: x_row_scale and x_col_const go together (16-byte aligned), b8_gap=%d (%%128) only with them", b8_gap);
+  EVC_REQUIRE(kx16 % 64 == 0 && H % 128 == 0 && kx8 % 128 == 0 && kx8 >= 384, EVC_ERR_BAD_SHAPE,
+              "evc_lstm_level2_fwd_high: kx16=%d (%%64), H=%d (%%128), kx8=%d (%%128, >= 384)", kx16, H, kx8);
+  EVC_REQUIRE(x && wT16_0 && wT8_0 && wT16_1 && hbuf0 && hbuf0_bf16 && hbuf1 && hbuf1_bf16 && bias0 && bias1 && len && c_state0 && h_state0 && c_state1 &&
+              h_state1, EVC_ERR_BAD_ARG, "evc_lstm_level2_fwd_high: NULL operand");
+  EVC_REQUIRE(ldx % 8 == 0 && x8_off % 16 == 0 && ldx >= kx16 && ldx * 2 >= x8_off + kx8 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)wT16_0 % 16) == 0 &&
+              ((uintptr_t)wT8_0 % 16) == 0 && ((uintptr_t)wT16_1 % 16) == 0 && ((uintptr_t)hbuf0 % 16) == 0 && ((uintptr_t)hbuf1 % 16) == 0 &&
+              ((uintptr_t)hbuf0_bf16 % 8) == 0 && ((uintptr_t)hbuf1_bf16 % 8) == 0, EVC_ERR_BAD_ALIGN,
+              "evc_lstm_level2_fwd_high: ldx=%ld (%%8), x8_off=%ld (%%16), 16-byte aligned operands", (long)ldx, (long)x8_off);
+  EVC_REQUIRE(w8_scale_exp >= 0 && w8_scale_exp <= 60 && (h_lo == 0 || h_lo == 1), EVC_ERR_BAD_ARG, "evc_lstm_level2_fwd_high: w8_scale_exp=%d h_lo=%d",
+              w8_scale_exp, h_lo);
+  EVC_REQUIRE(w16_step_stride >= 0 && w16_step_stride % 8 == 0 && (w16_step_stride == 0 || w16_step_stride >= 4L * H * 2 * H), EVC_ERR_BAD_ARG,
+              "evc_lstm_level2_fwd_high: w16_step_stride=%ld (0 or at least one [4H][2H] image, %%8)", (long)w16_step_stride);
+  const long ldh0 = h_lo ? 2L * H : 3L * H / 2;     // halfwords per hbuf0 row
+  const int kh8 = h_lo ? 2 * H : H;                 // e4m3 bytes of layer 0's h-part per row
+  EVC_REQUIRE(ring_operand_ok(M, ldx > ldh0 ? ldx : ldh0) && ring_operand_ok(4L * H, (long)kx16 + H) && ring_operand_ok(4L * H, 2L * H), EVC_ERR_BAD_SHAPE,
+              "evc_lstm_level2_fwd_high: a time slab or a kernel spans 4 GiB or more");
+  EVC_REQUIRE(fwd_tail_ok(M, H, ld_state), EVC_ERR_BAD_SHAPE, "LSTM forward: a gate-record / state slab spans 4 GiB or more (M=%d H=%d ld_state=%ld)", M, H, (long)ld_state);
+  EVC_REQUIRE(ld_state % 4 == 0 && ((uintptr_t)c_state0 % 16) == 0 && ((uintptr_t)h_state0 % 16) == 0 && ((uintptr_t)c_state1 % 16) == 0 &&
+              ((uintptr_t)h_state1 % 16) == 0 && ((uintptr_t)bias0 % 16) == 0 && ((uintptr_t)bias1 % 16) == 0, EVC_ERR_BAD_ALIGN,
+              "evc_lstm_level2_fwd_high: state/bias must allow 16-byte vector access");
+  EVC_REQUIRE((gates0 == nullptr) == (c_all0 == nullptr) && (gates1 == nullptr) == (c_all1 == nullptr) && (gates0 == nullptr) == (gates1 == nullptr),
+              EVC_ERR_BAD_ARG, "evc_lstm_level2_fwd_high: gates and c_all go together, for both layers");
+  EVC_REQUIRE(!gates0 || (((uintptr_t)gates0 % 16) == 0 && ((uintptr_t)gates1 % 16) == 0 && ((uintptr_t)c_all0 % 8) == 0 && ((uintptr_t)c_all1 % 8) == 0),
+              EVC_ERR_BAD_ALIGN, "evc_lstm_level2_fwd_high: gates must be 16-byte, c_all 8-byte aligned");
+  if (rows_per_step)
+    for (int t = 0; t < T; ++t)
+      EVC_REQUIRE(rows_per_step[t] >= 0 && rows_per_step[t] <= M && (t == 0 || rows_per_step[t] <= rows_per_step[t - 1]), EVC_ERR_BAD_ARG,
+                  "evc_lstm_level2_fwd_high: rows_per_step[%d]=%d must be non-increasing and within [0, M=%d]", t, rows_per_step[t], M);
+  hipStream_t st = (hipStream_t)stream;
+  const bf16_t* xb = (const bf16_t*)x;
+  bf16_t* hb0 = (bf16_t*)hbuf0;
+  bf16_t* hb1 = (bf16_t*)hbuf1;
+  EVC_CHECK_HIP(hipMemsetAsync(hb0, 0, (size_t)M * ldh0 * sizeof(bf16_t), st));          // h_{-1} = 0: every image of both layers' rows
+  EVC_CHECK_HIP(hipMemsetAsync(hbuf0_bf16, 0, (size_t)M * H * sizeof(bf16_t), st));
+  EVC_CHECK_HIP(hipMemsetAsync(hb1, 0, (size_t)M * H * sizeof(bf16_t), st));
+  EVC_CHECK_HIP(hipMemsetAsync(hbuf1_bf16, 0, (size_t)M * H * sizeof(bf16_t), st));
+  auto step0 = [&](int t, GemmOperands& p, LstmFwdParams& e, int& k1, int& k2) {          // layer 0: evc_lstm_layer_fwd_f16_fp8lo's step t
+    p = GemmOperands();
+    p.M = rows_per_step ? rows_per_step[t] : M; p.Nu = H; p.group_stride = H; p.nk1 = p.nk2 = 0;
+    p.A1lo = p.A2lo = p.Blo = nullptr;
+    const bf16_t* xt = xb + (long)t * M * ldx;
+    const bf16_t* hprev = hb0 + (long)t * M * ldh0;
+    p.A1 = xt; p.lda1 = ldx;
+    p.A2 = hprev; p.lda2 = ldh0;
+    p.B = (const bf16_t*)wT16_0; p.ldb = (long)kx16 + H;
+    p.A3 = (const uint8_t*)xt + x8_off; p.lda3 = ldx * 2; p.nk3 = kx8 / 128;
+    p.A4 = (const uint8_t*)(hprev + H); p.lda4 = ldh0 * 2; p.nk4 = t == 0 ? 0 : kh8 / 128;
+    p.B8 = wT8_0; p.ldb8 = (long)kx8 + b8_gap + kh8; p.b8_gap = b8_gap;
+    p.scale8_exp = -(7 + w8_scale_exp);
+    if (x_row_scale) { p.row_scale = x_row_scale + (long)t * M; p.col_add = bias0; p.g2_add = 1.0f; }
+    k1 = kx16; k2 = t == 0 ? 0 : H;
+    e = LstmFwdParams();
+    e.zx = nullptr; e.ldzx = 0;
+    e.bias = x_col_const ? x_col_const : bias0; e.len = len; e.t = t;
+    e.c_state = c_state0; e.h_state = h_state0; e.ld_state = ld_state;
+    e.hout = hb0 + (long)(t + 1) * M * ldh0; e.h_wide = h_lo ? 3 : 2;
+    e.hout_lo = hbuf0_bf16 + (long)(t + 1) * M * H;
+    e.gates = gates0 ? (uint2*)gates0 + (long)t * M * H : nullptr;
+    e.c_hist = c_all0 ? c_all0 + (long)(t + 1) * M * H : nullptr;
+    e.row_map = row_map;
+    e.M = p.M; e.H = H;
+  };
+  auto step1 = [&](int t, GemmOperands& p, LstmFwdParams& e, int& k1, int& k2) {          // layer 1: the plain f16 step on image t; x_t = layer 0's row slab t + 1
+    p = GemmOperands();
+    p.M = rows_per_step ? rows_per_step[t] : M; p.Nu = H; p.group_stride = H; p.ldb = 2L * H; p.nk1 = p.nk2 = 0;
+    p.A1lo = p.A2lo = p.Blo = nullptr;
+    p.A1 = hb0 + (long)(t + 1) * M * ldh0; p.lda1 = ldh0; k1 = H;
+    p.A2 = hb1 + (long)t * M * H; p.lda2 = H; k2 = t == 0 ? 0 : H;
+    p.B = (const bf16_t*)wT16_1 + (long)t * w16_step_stride;
+    e = LstmFwdParams();
+    e.zx = nullptr; e.ldzx = 4L * H;
+    e.bias = bias1; e.len = len; e.t = t;
+    e.c_state = c_state1; e.h_state = h_state1; e.ld_state = ld_state;
+    e.hout = hb1 + (long)(t + 1) * M * H; e.h_wide = 0;
+    e.hout_lo = hbuf1_bf16 + (long)(t + 1) * M * H;
+    e.gates = gates1 ? (uint2*)gates1 + (long)t * M * H : nullptr;
+    e.c_hist = c_all1 ? c_all1 + (long)(t + 1) * M * H : nullptr;
+    e.row_map = row_map;
+    e.M = p.M; e.H = H;
+  };
+  static const bool uneven224 = getenv("EVC_FWD_EVEN_224") == nullptr;
+  for (int s = 0; s <= T; ++s) {
+    GemmOperands pa, pb;
+    LstmFwdParams ea, eb;
+    int k1a = 0, k2a = 0, k1b = 0, k2b = 0;
+    bool has_a = s < T, has_b = s >= 1;
+    if (has_a) { step0(s, pa, ea, k1a, k2a); has_a = ea.M > 0; }
+    if (has_b) { step1(s - 1, pb, eb, k1b, k2b); has_b = eb.M > 0; }
+    if (!has_a && !has_b) continue;
+    const int pick = pick_fwd_tile_v3(has_b ? eb.M : ea.M, H);       // layer 1 runs the earlier step: at least as many rows as layer 0
+    if (pick == 0 || pick == 1 || pick == 4) {
+      if (!has_a) { pa = pb; ea = eb; }                              // (the absent role's arguments are never read: tiles_m = 0)
+      if (!has_b) { pb = pa; eb = ea; }
+#define EVC_WALK2_HIGH(CFG)                                                                                                   \
+      do {                                                                                                                    \
+        if (x_row_scale) launch_lstm_fwd_walk2<CFG, true, true, true, false>(pa, ea, k1a, k2a, has_a, pb, eb, k1b, k2b, has_b, st);   \
+        else launch_lstm_fwd_walk2<CFG, true, true, false, false>(pa, ea, k1a, k2a, has_a, pb, eb, k1b, k2b, has_b, st);              \
+      } while (0)
+      if (pick == 0) EVC_WALK2_HIGH(CfgLstmV3_256);
+      else if (pick == 4) EVC_WALK2_HIGH(CfgLstmV3_240);
+      else if (uneven224) EVC_WALK2_HIGH(CfgLstmV3_224u);
+      else EVC_WALK2_HIGH(CfgLstmV3_224);
+#undef EVC_WALK2_HIGH
+      continue;
+    }
+    if (has_a) {
+      if (x_row_scale) {
+        if (pick == 2) launch_lstm_fwd<CfgLstmV3_192, false, true, true, true>(pa, ea, k1a, k2a, st);
+        else launch_lstm_fwd<CfgLstmV3_160, false, true, true, true>(pa, ea, k1a, k2a, st);
+      } else {
+        if (pick == 2) launch_lstm_fwd<CfgLstmV3_192, false, true, true>(pa, ea, k1a, k2a, st);
+        else launch_lstm_fwd<CfgLstmV3_160, false, true, true>(pa, ea, k1a, k2a, st);
+      }
+    }
+    if (has_b) {
+      if (pick == 2) launch_lstm_fwd<CfgLstmV3_192, false, true>(pb, eb, k1b, k2b, st);
+      else launch_lstm_fwd<CfgLstmV3_160, false, true>(pb, eb, k1b, k2b, st);
     }
   }
   EVC_LAUNCH_CHECK();

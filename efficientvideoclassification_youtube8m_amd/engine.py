@@ -122,6 +122,9 @@ class LstmStack:
     HOIST_BELOW = int(os.environ.get("EVC_HOIST_BELOW", "1025"))
     wavefront = os.environ.get("EVC_NO_WAVEFRONT") != "1"   # two-layer M ~ batch stacks: see forward()
     fwd_walk2 = os.environ.get("EVC_FWD_WALK2", "1") != "0"   # two-layer many-row stacks (bf16): two tiles per workgroup, T + 1 launches (A/B: 0)
+    # ... and the "high" mode's L1 level (round 6, ops.lstm_level2_fwd_high: bit-identical, NOT faster - alone 2.41 against 2.37 ms per teacher level, the training
+    # step 11.67 against 11.56 ms, profiles/r06_walk2_high_ab.txt: a 96 us tile on 59 ring stages does not notice a 10 us tail; off unless EVC_FWD_WALK2_HIGH=1)
+    fwd_walk2_high = os.environ.get("EVC_FWD_WALK2_HIGH", "0") == "1"
     # two-layer stacks with many rows (the L1 levels), the gradient arriving at layer 0 from layer 1:
     #   "off"   (default) one hoisted dX = dz1 . Wx1^T product over all T (bf16 result, re-read by layer 0's steps);
     #   "fused" contracted inside layer 0's BPTT steps (two-matrix K walk, K = 8H, f32 accumulator);
@@ -232,6 +235,26 @@ class LstmStack:
                     "the fp8 L1 level takes ops.l2norm_chunk(..., f16_segments=1, fp8_tail=True) rows (or ops.l2norm_chunk_int's)"
                 assert x_rs is None or tw.x_int(), "integer-frame rows need layer 0 on the f16 + e4m3 form (HLstmTower.x_int)"
                 inp, ldx, kx16 = x16, x16.shape[-1], self.Kin
+                if L == 2 and tuple(dl) == (1,) and not wh0 and self.fwd_walk2_high:
+                    # the shipped layout as T + 1 two-tile launches (round 6; ops.lstm_level2_fwd_high): layer 0 on its f16 + e4m3 stages and the dithered upper
+                    # layer, step s and step s-1 of one launch - the same bits as the two layer calls below
+                    (k0, b0), (k1, b1) = self.names(0), self.names(1)
+                    assert tw.shadow16d[k1].shape[0] >= T
+                    x8_off, kx8, xi, gap = 2 * self.Kin, 2 * self.Kin, None, 0
+                    if x_rs is not None:
+                        kx8, gap, xi = self.Kin, self.Kin, (x_rs, tw.x_col_const[k0])
+                    if self.timing is not None:
+                        e0 = torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                    ops.lstm_level2_fwd_high(inp, ldx, kx16, x8_off, kx8, tw.shadow16[k0], tw.shadow8[k0], tw.store.p(b0), tw.shadow16d[k1], tw.store.p(b1),
+                                             lens, T, M, H, h16[0], hb[0], h16[1], hb[1], self.S, gates, c_all, plan=plan, h_lo=al, x_int=xi, b8_gap=gap)
+                    if self.timing is not None:
+                        e1 = torch.cuda.Event(enable_timing=True)
+                        e1.record()
+                        flops = sum(2.0 * r * 4 * H * (self.kin[l] + (H if t > 0 else 0)) for l in range(2) for t, r in enumerate(rows))
+                        live = sum(1 for r in rows if r > 0)
+                        self.timing.append((e0, e1, live + 1 if live else 0, flops))
+                    return self.S
                 for l in range(L):
                     kn, bn = self.names(l)
                     if self.timing is not None:

@@ -484,6 +484,25 @@ def lstm_layer_fwd_f16_dith(x16, ldx, kx16, x8_off, kx8, wT16_steps, wT8, ldb8, 
               _p(hbuf16), _p(hbuf_bf), _p(c_state), _p(h_state), ld_state, _p(gates), _p(c_all), *_plan_args(plan), _stream())
 
 
+def lstm_level2_fwd_high(x16, ldx, kx16, x8_off, kx8, wT16_0, wT8_0, bias0, wT16_1_steps, bias1, lens, T, M, H, h0_rows, hbuf0, h1_rows, hbuf1, S,
+                         gates=(None, None), c_all=(None, None), plan=None, w8_scale_exp=FP8_W_SCALE_EXP, h_lo=False, x_int=None, b8_gap=0):
+    """The two-layer L1 level of the "high" mode as T + 1 two-tile launches (evc_lstm_level2_fwd_high): lstm_layer_fwd_f16_fp8lo for layer 0 (same
+    arguments) + lstm_layer_fwd_f16_dith(kx8 = 0) for layer 1 on wT16_1_steps [T'][4H][2H], bit for bit.  h0_rows [(T+1)][M][2H or 3H/2] f16 containers,
+    h1_rows [(T+1)][M][H] f16, hbuf0 / hbuf1 the bf16 copies; S [rows][4H] f32 = [c0 | h0 | c1 | h1]."""
+    assert x16.dtype == F16 and wT16_0.dtype == F16 and wT8_0.dtype == torch.uint8 and wT16_1_steps.dtype == F16
+    assert h0_rows.dtype == F16 and h1_rows.dtype == F16 and hbuf0.dtype == BF16 and hbuf1.dtype == BF16
+    assert wT16_0.shape == (4 * H, kx16 + H) and wT8_0.shape == (4 * H, kx8 + b8_gap + (2 if h_lo else 1) * H) and wT16_0.is_contiguous() and wT8_0.is_contiguous()
+    assert wT16_1_steps.dim() == 3 and wT16_1_steps.shape[1:] == (4 * H, 2 * H) and wT16_1_steps.is_contiguous() and (wT16_1_steps.shape[0] == 1 or wT16_1_steps.shape[0] >= T)
+    assert h0_rows.shape[-1] == (2 * H if h_lo else 3 * H // 2) and h1_rows.shape[-1] == H
+    rs, cc = x_int if x_int is not None else (None, None)
+    assert x_int is None or (rs.dtype == F32 and cc.dtype == F32 and rs.numel() >= T * M and cc.numel() == 4 * H and rs.is_contiguous() and cc.is_contiguous())
+    stride = 0 if wT16_1_steps.shape[0] == 1 else wT16_1_steps.stride(0)
+    _lib.call("evc_lstm_level2_fwd_high", _p(x16), ldx, kx16, x8_off, kx8, _p(wT16_0), _p(wT8_0), w8_scale_exp, 1 if h_lo else 0, _p(bias0), _p(rs), _p(cc), b8_gap,
+              _p(wT16_1_steps), stride, _p(bias1), _p(lens), T, M, H, _p(h0_rows), _p(hbuf0), _p(h1_rows), _p(hbuf1),
+              _p(S[:, 0:]), _p(S[:, H:]), _p(S[:, 2 * H:]), _p(S[:, 3 * H:]), S.stride(0),
+              _p(gates[0]), _p(c_all[0]), _p(gates[1]), _p(c_all[1]), *_plan_args(plan), _stream())
+
+
 def cast_f16_dither(p, out, seed, col0=0):
     """out [T][...p.shape] f16: the T time-dithered f16 images of the f32 tensor p (evc_cast_f32_to_f16_dither; oracle/lowprec.py::f16_dither_images).
     col0 > 0 (p 2-D): only the columns from col0 on are dithered, the others hold their round-to-nearest value in every image."""

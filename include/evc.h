@@ -36,7 +36,7 @@ extern "C" {
 #define EVC_ERR_HIP (-4)
 #define EVC_ERR_BAD_ARG (-5)
 
-#define EVC_VERSION 106   /* 106 (round 6): evc_gemm_nt_sqnorm, evc_l2norm_chunk_int + the x_row_scale / x_col_const / b8_gap arguments of evc_lstm_layer_fwd_f16_fp8lo (integer-frame layer 0: the uint8 input exact), evc_lstm_layer_fwd_f16_fp8lo / evc_lstm_stack2_fwd_f16_fp8lo gained h_lo (low-order half of h corrected: 4H-byte h rows), evc_cast_f32_to_fp8_lohi, evc_lstm_adam_fused gained fp8_hi_tail; evc_absmax_partials, evc_cast_f32_to_f16_fp8x_dyn, evc_gemm_nt_f16_fp8_dyn (dynamic e4m3 range of the MoE head's input state); evc_l2norm_chunk_fwd accepts out1 == NULL (student-only graphs read the sub-sampled frames only), evc_clip_adam_small limited to 2^15 elements per tensor; 105 (round 5, second session): evc_cast_f32_to_f16_dither, evc_lstm_layer_fwd_f16_dith (time-dithered f16 weight images: an L1 layer of the "high" mode without stages for its weights' low-order halves), evc_gemm_tn2_rows (weight-gradient products that skip the dead rows of a row-planned level's time slabs); 104 (round 5): evc_lstm_level2_fwd, evc_ce_loss_ordered, evc_rep_loss_ordered, evc_gemm_tn2_slabs, evc_sum_slabs, evc_clip_adam_small; evc_moe_grad_update* accept p_bf16 == NULL (forward shadow not written), evc_lstm_stack2_bwd runs M <= 512 stacks on the skinny pair launches, evc_dbof_cluster_pool_fwd walks tiles (EVC_DBOF_WALK), EVC_DETERMINISTIC parsed as "set, not empty, not 0"; 103 (round 4): evc_sqnorm2_partials, evc_lstm_adam_fused, evc_gram_slabs, evc_moe_grad_norms, evc_moe_grad_update_apply, evc_adam2d_fused, evc_colsum_bf16_det, evc_sample_sequence_gather, evc_relu6_fwd/bwd, evc_framepool_mean_fwd/bwd, evc_stream_create_cu_mask / evc_stream_destroy; EVC_DETERMINISTIC=1 read by the library; 102: evc_lstm_layer_fwd_f16_fp8lo, evc_lstm_stack2_fwd_f16_fp8lo, evc_gemm_nt_f16_fp8, evc_cast_f32_to_fp8_lo, evc_cast_f32_to_f16_fp8x, aux_mode 5, evc_moe_grad_update_wide; 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
+#define EVC_VERSION 107   /* 107 (round 6, late): evc_lstm_level2_fwd_high (the two-layer L1 level of the "high" mode in T + 1 two-tile launches); 106 (round 6): evc_gemm_nt_sqnorm, evc_l2norm_chunk_int + the x_row_scale / x_col_const / b8_gap arguments of evc_lstm_layer_fwd_f16_fp8lo (integer-frame layer 0: the uint8 input exact), evc_lstm_layer_fwd_f16_fp8lo / evc_lstm_stack2_fwd_f16_fp8lo gained h_lo (low-order half of h corrected: 4H-byte h rows), evc_cast_f32_to_fp8_lohi, evc_lstm_adam_fused gained fp8_hi_tail; evc_absmax_partials, evc_cast_f32_to_f16_fp8x_dyn, evc_gemm_nt_f16_fp8_dyn (dynamic e4m3 range of the MoE head's input state); evc_l2norm_chunk_fwd accepts out1 == NULL (student-only graphs read the sub-sampled frames only), evc_clip_adam_small limited to 2^15 elements per tensor; 105 (round 5, second session): evc_cast_f32_to_f16_dither, evc_lstm_layer_fwd_f16_dith (time-dithered f16 weight images: an L1 layer of the "high" mode without stages for its weights' low-order halves), evc_gemm_tn2_rows (weight-gradient products that skip the dead rows of a row-planned level's time slabs); 104 (round 5): evc_lstm_level2_fwd, evc_ce_loss_ordered, evc_rep_loss_ordered, evc_gemm_tn2_slabs, evc_sum_slabs, evc_clip_adam_small; evc_moe_grad_update* accept p_bf16 == NULL (forward shadow not written), evc_lstm_stack2_bwd runs M <= 512 stacks on the skinny pair launches, evc_dbof_cluster_pool_fwd walks tiles (EVC_DBOF_WALK), EVC_DETERMINISTIC parsed as "set, not empty, not 0"; 103 (round 4): evc_sqnorm2_partials, evc_lstm_adam_fused, evc_gram_slabs, evc_moe_grad_norms, evc_moe_grad_update_apply, evc_adam2d_fused, evc_colsum_bf16_det, evc_sample_sequence_gather, evc_relu6_fwd/bwd, evc_framepool_mean_fwd/bwd, evc_stream_create_cu_mask / evc_stream_destroy; EVC_DETERMINISTIC=1 read by the library; 102: evc_lstm_layer_fwd_f16_fp8lo, evc_lstm_stack2_fwd_f16_fp8lo, evc_gemm_nt_f16_fp8, evc_cast_f32_to_fp8_lo, evc_cast_f32_to_f16_fp8x, aux_mode 5, evc_moe_grad_update_wide; 101 (round 3): evc_l2norm_chunk_fwd gained aux_mode; evc_lstm_layer_fwd_hp takes wide split operands; f16 / wide-split entries added */
 
 typedef uint16_t evc_bf16;
 typedef uint16_t evc_f16;   /* raw IEEE binary16 bits (the "high" precision forward operands of the L1 levels) */
@@ -231,6 +231,18 @@ int evc_lstm_layer_fwd_f16_dith(const evc_f16* x, int64_t ldx, int kx16, int64_t
                                 const int32_t* len, int T, int M, int H, evc_f16* hbuf, evc_bf16* hbuf_bf16, float* c_state,
                                 float* h_state, int64_t ld_state, void* gates, evc_bf16* c_all, const int32_t* row_map,
                                 const int32_t* rows_per_step, void* stream);
+/* The two-layer L1 level of the "high" mode in T + 1 launches (round 6; the reference's two stacked BasicLSTMCells under dynamic_rnn,
+ * cs/frame_level_models.py:221-250): layer 0 as evc_lstm_layer_fwd_f16_fp8lo (x / wT16_0 / wT8_0 / w8_scale_exp / h_lo / bias0 / x_row_scale / x_col_const /
+ * b8_gap: that entry's arguments), layer 1 as evc_lstm_layer_fwd_f16_dith with kx8 = 0 (wT16_1 = [4H][2H] f16 images, image t at + t * w16_step_stride
+ * halfwords, contracting layer 0's rows [f16(h) | ...] and its own plain f16 rows).  One launch = layer 0's step s + layer 1's step s-1, every workgroup
+ * walking both tiles (the bf16 form: evc_lstm_level2_fwd).  hbuf0 [(T+1)][M] rows of 4H bytes (h_lo) or 3H bytes, hbuf1 [(T+1)][M][H] plain f16,
+ * hbuf*_bf16 [(T+1)][M][H] the bf16 copies of the backward pass.  Results: those of the two layer entries, bit for bit. */
+int evc_lstm_level2_fwd_high(const evc_f16* x, int64_t ldx, int kx16, int64_t x8_off, int kx8, const evc_f16* wT16_0, const uint8_t* wT8_0,
+                             int w8_scale_exp, int h_lo, const float* bias0, const float* x_row_scale, const float* x_col_const, int b8_gap,
+                             const evc_f16* wT16_1, int64_t w16_step_stride, const float* bias1, const int32_t* len, int T, int M, int H,
+                             evc_f16* hbuf0, evc_bf16* hbuf0_bf16, evc_f16* hbuf1, evc_bf16* hbuf1_bf16, float* c_state0, float* h_state0,
+                             float* c_state1, float* h_state1, int64_t ld_state, void* gates0, evc_bf16* c_all0, void* gates1, evc_bf16* c_all1,
+                             const int32_t* row_map, const int32_t* rows_per_step, void* stream);
 /* evc_lstm_stack2_fwd (below) on IEEE f16 operands, the "high" precision form of the L2 level: layer 0 plain f16 (x-projection
  * hoisted into one f16 product), layer 1 with its kernel K-extended by the weights' low-order halves - wT1_wlo [4H] rows
  * [f16(Wx) | (Wx - f16(Wx))*64 | f16(Wh) | (Wh - f16(Wh))*64] (evc_cast_f32_to_f16_wlo) against activation rows [h | h/64] - because

@@ -88,7 +88,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "declared in evc.h but not exported: " + name
     assert sorted(_lib.EXPORTS) == declared, (set(_lib.EXPORTS) ^ set(declared))
     l = _lib.load()
-    assert l.evc_version() == 106
+    assert l.evc_version() == 107
     assert l.evc_last_error() is not None
 
 

@@ -1559,6 +1559,100 @@ def test_lstm_level2_fwd_two_tiles_per_workgroup_equals_two_layer_calls(ops, M, 
                     assert torch.equal(ga[l][t, :rt], gw[l][t, :rt]) and torch.equal(ca[l][t + 1, :rt].view(torch.int16), cw[l][t + 1, :rt].view(torch.int16)), (l, t)
 
 
+@pytest.mark.parametrize("M,T,F,H,planned,int_form,h_lo", [(4096, 4, 384, 256, True, True, True), (5120, 5, 384, 128, True, False, True), (3840, 3, 384, 256, False, True, True),
+                                                            (3840, 3, 512, 128, False, False, False), (600, 4, 384, 128, True, True, True)])
+def test_lstm_level2_fwd_high_equals_the_two_layer_calls(ops, M, T, F, H, planned, int_form, h_lo):
+    """Round 6: the "high" mode's two-layer L1 level as T + 1 two-tile launches (evc_lstm_level2_fwd_high) - tile a = layer 0's step s on f16 + e4m3 stages
+    (integer frames with the accumulator rescale, or f32-input rows; h rows with or without the low-order image), tile b = the dithered upper layer's step
+    s-1 on plain f16 stages, each in its own loop mode - against evc_lstm_layer_fwd_f16_fp8lo + evc_lstm_layer_fwd_f16_dith: the same arithmetic in the
+    same order, so every h row image, the bf16 copies, the states, the gate records and the cell history must be IDENTICAL - on row plans, with launches
+    that fall back to separate ones (600 rows), and in the evaluation form (no tape)."""
+    rng = np.random.default_rng(M + T + H)
+    lens = rng.integers(1, T + 1, size=M).astype(np.int32)
+    lens[rng.random(M) < (0.25 if planned else 0.0)] = 0
+    lens[:2] = [T, T if not planned else 0]
+    q = rng.integers(0, 256, size=(T, M, F), dtype=np.uint8)
+    xr = mm.dequantize(q.astype(np.float64))
+    nrm = np.sqrt((xr ** 2).sum(-1))
+    xt = torch.from_numpy((xr / nrm[..., None]).astype(np.float32)).to(DEV)
+    qt = torch.from_numpy(q).to(DEV)
+    k0 = torch.from_numpy(np.ascontiguousarray((mm.glorot_uniform(rng, (F + H, 4 * H)) * 2.0).astype(np.float32).T)).to(DEV)
+    k1 = torch.from_numpy(np.ascontiguousarray((mm.glorot_uniform(rng, (2 * H, 4 * H)) * 2.0).astype(np.float32).T)).to(DEV)
+    b0 = torch.from_numpy((rng.standard_normal(4 * H) * 0.1).astype(np.float32)).to(DEV)
+    b1 = torch.from_numpy((rng.standard_normal(4 * H) * 0.1).astype(np.float32)).to(DEV)
+    w16 = torch.empty((4 * H, F + H), dtype=torch.float16, device=DEV)
+    ops.cast_f16(k0, w16)
+    w8 = torch.empty((4 * H, (2 * F + 2 * H) if h_lo else (2 * F + H)), dtype=torch.uint8, device=DEV)
+    ops.cast_fp8_lo(k0, w8, hi_cols=F, hi_tail=h_lo)
+    w16d = torch.empty((T, 4 * H, 2 * H), dtype=torch.float16, device=DEV)
+    ops.cast_f16_dither(k1, w16d, 1234)
+    x8 = (xt * 128.0).clamp(-448, 448).to(torch.float8_e4m3fn)
+    if int_form:
+        src = torch.zeros((T, M, 3 * F // 2), dtype=torch.float16, device=DEV)
+        src[:, :, :F] = (2.0 * qt.float() - 255.0).half()
+        src[:, :, F:] = x8.view(torch.float16)
+        rs = torch.from_numpy(((2.0 / 255.0) / nrm).astype(np.float32)).to(DEV).contiguous()
+        cc = w16[:, :F].sum(dim=1, dtype=torch.float32) * (255.0 / 256.0)
+        cc[2 * H:3 * H] -= 1.0
+        cc = cc.contiguous()
+        x8_off, kx8, gap = 2 * F, F, F
+    else:
+        src = torch.zeros((T, M, 2 * F), dtype=torch.float16, device=DEV)
+        hi = xt.half()
+        src[:, :, :F] = hi
+        src[:, :, F:3 * F // 2] = x8.view(torch.float16)
+        src[:, :, 3 * F // 2:] = ((xt - hi.float()) * 2.0 ** 18).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.float16)
+        rs = cc = None
+        x8_off, kx8, gap = 2 * F, 2 * F, 0
+    ln = torch.from_numpy(lens).to(DEV)
+    plan = ops.RowPlan(ln, lens, T) if planned else None
+    P = plan.P if plan is not None else M
+    inp, lens_d, rs_run = src, ln, rs
+    if plan is not None:
+        live_rows = plan.rows[0]
+        inp = torch.zeros((T, P, src.shape[-1]), dtype=torch.float16, device=DEV)
+        inp[:, :live_rows] = src[:, plan.inv[:live_rows].long()]
+        if rs is not None:
+            rs_run = torch.zeros((T, P), dtype=torch.float32, device=DEV)
+            rs_run[:, :live_rows] = rs[:, plan.inv[:live_rows].long()]
+        lens_d = plan.lens
+    xi = (rs_run, cc) if int_form else None
+    wrow = 2 * H if h_lo else 3 * H // 2
+    for tape in (True, False):
+        outs = []
+        for walk in (False, True):
+            h0 = torch.full((T + 1, P, wrow), float("nan"), dtype=torch.float16, device=DEV)
+            h1 = torch.full((T + 1, P, H), float("nan"), dtype=torch.float16, device=DEV)
+            hb = [torch.full((T + 1, P, H), float("nan"), dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+            S = torch.full((M, 4 * H), float("nan"), dtype=torch.float32, device=DEV)
+            gates = [torch.full((T, P, H, 2), -1, dtype=torch.int32, device=DEV) if tape else None for _ in range(2)]
+            c_all = [torch.full((T + 1, P, H), float("nan"), dtype=torch.bfloat16, device=DEV) if tape else None for _ in range(2)]
+            if walk:
+                ops.lstm_level2_fwd_high(inp, inp.shape[-1], F, x8_off, kx8, w16, w8, b0, w16d, b1, lens_d, T, P, H, h0, hb[0], h1, hb[1], S, gates, c_all, plan=plan,
+                                         h_lo=h_lo, x_int=xi, b8_gap=gap)
+            else:
+                ops.lstm_layer_fwd_f16_fp8lo(inp, inp.shape[-1], F, x8_off, kx8, w16, w8, b0, lens_d, T, P, H, h0, hb[0], S[:, 0:], S[:, H:], 4 * H, gates[0], c_all[0],
+                                             plan=plan, h_lo=h_lo, x_int=xi, b8_gap=gap)
+                ops.lstm_layer_fwd_f16_dith(h0[1:], wrow, H, 0, 0, w16d, None, 0, 7 + ops.FP8_W_SCALE_EXP, b1, lens_d, T, P, H, h1, hb[1], S[:, 2 * H:], S[:, 3 * H:], 4 * H,
+                                            gates[1], c_all[1], plan=plan)
+            torch.cuda.synchronize()
+            outs.append((h0, h1, hb, S, gates, c_all))
+        (h0a, h1a, ha, Sa, ga, ca), (h0w, h1w, hw, Sw, gw, cw) = outs
+        rows = plan.rows if plan is not None else [M] * T
+        live = torch.from_numpy(np.nonzero(lens > 0)[0]).to(DEV)
+        assert torch.equal(Sa[live].view(torch.int32), Sw[live].view(torch.int32)) and bool(torch.isfinite(Sw[live]).all())
+        assert bool((h0w[0] == 0).all()) and bool((h1w[0] == 0).all()) and bool((hw[0][0] == 0).all()) and bool((hw[1][0] == 0).all())
+        for t in range(T):
+            rt = rows[t]
+            assert torch.equal(h0a[t + 1, :rt].view(torch.int16), h0w[t + 1, :rt].view(torch.int16)), ("h0 rows", t)
+            assert torch.equal(h1a[t + 1, :rt].view(torch.int16), h1w[t + 1, :rt].view(torch.int16)), ("h1 rows", t)
+            for l in range(2):
+                assert torch.equal(ha[l][t + 1, :rt].view(torch.int16), hw[l][t + 1, :rt].view(torch.int16)), (l, t)
+                if tape:
+                    assert torch.equal(ga[l][t, :rt], gw[l][t, :rt]) and torch.equal(ca[l][t + 1, :rt].view(torch.int16), cw[l][t + 1, :rt].view(torch.int16)), (l, t)
+    assert float(Sw[live].abs().max()) > 0.05
+
+
 @pytest.mark.parametrize("M,N1,N2,K,il", [(512, 256, 128, 4096, 128), (256, 192, 0, 2048, 0), (1024, 512, 256, 8192, 256)])
 def test_gemm_tn_det_slabs_equal_the_product_and_repeat_bit_for_bit(ops, M, N1, N2, K, il):
     """EVC_DETERMINISTIC=1 weight gradients (round 5): the TN product with its K split kept, the partial products stored as slabs

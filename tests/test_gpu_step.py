@@ -327,6 +327,17 @@ def test_headline_batch_256_high_mode_on_trained_magnitude_weights(frames):
     for k, v in keep.items():
         d = (out4[k] - v).abs().max().item()
         assert d < 2e-4, (k, d)                          # (tile heights, split-K joins and accumulation order differ with the batch)
+    # the teacher's L1 level as two-tile launches (evc_lstm_level2_fwd_high; measured not faster, off by default): the same bits through the engine
+    from efficientvideoclassification_youtube8m_amd.engine import LstmStack
+    full = {k: out[k].clone() for k in ("predictions", "student_predictions", "teacher_state", "student_state")}
+    saved = LstmStack.fwd_walk2_high
+    LstmStack.fwd_walk2_high = True
+    try:
+        out_w = g.step(xd, yd, nd, apply=False, num_frames_host=nb)
+    finally:
+        LstmStack.fwd_walk2_high = saved
+    for k, v in full.items():
+        assert torch.equal(out_w[k], v) if k.endswith("state") else float((out_w[k] - v).abs().max()) < 1e-6, k
 
 
 LONG_STEPS = (16, 128, 512)
