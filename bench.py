@@ -602,6 +602,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="hlstm", choices=["hlstm", "dbof"], help="hlstm: BASELINE cfg 3 (the metric); dbof: cfg 4")
     ap.add_argument("--batch", type=int, default=None, help="videos per GPU (default 256; 512 for --config dbof)")
+    ap.add_argument("--global_batch", type=int, default=None, help="STRONG scaling (SURVEY.md 8(d): 'also report global-256'): this many videos per step over all "
+                    "GPUs, global_batch / gpus each (must divide); the line says \"scaling\": \"strong\".  Default: --batch per GPU, weak")
     ap.add_argument("--every_n", type=int, default=10)
     ap.add_argument("--mode", default="teacher_student", choices=["teacher_student", "teacher", "student"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "high", "split"])
@@ -682,6 +684,10 @@ def main():
         return
 
     B = args.batch or 256
+    if args.global_batch:
+        if args.global_batch % n_gpus or args.batch:
+            raise SystemExit("--global_batch %d must be a multiple of --gpus %d (and excludes --batch)" % (args.global_batch, n_gpus))
+        B = args.global_batch // n_gpus
     head = run_hlstm(device, rank, world, B, args.mode, args.every_n, args.steps, args.warmup, args.all_full, args.precision,
                      args.pool, not args.no_overlap, not args.no_fused_moe, args.student_forward_early, roofline=True, input_u8=args.input == "uint8")
     _log("headline done: %.2f ms/step" % head["ms_per_step"])
@@ -755,7 +761,8 @@ def main():
         res = {
             "metric": "frames/sec (whole node) H-LSTM teacher+student B=256x300x1152; GAP@20",
             "value": head["frames_per_sec"], "unit": "frames/sec", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": head["ms_per_step"], **{k: head[k] for k in STAT_KEYS}, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": head["ms_per_step"], **{k: head[k] for k in STAT_KEYS}, "higher_is_better": True,
+            "scaling": "strong" if args.global_batch else "weak",
             "vs_baseline": None, "dtype": DTYPE_OF[args.precision], "data": "synthetic", "precision_mode": args.precision,
             "config": {"workload": "HierarchicalLstmModel %s every_n=%d, lstm_cells=1024x2, MoE(2), batch %d x 300 x 1152 per GPU"
                                    % (args.mode, args.every_n, B),

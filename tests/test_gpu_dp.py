@@ -248,14 +248,15 @@ def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks():
     env = dict(os.environ, EVC_BENCH_SHARED_GPU="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16", "--pool", "2",
-           "--no_cpu_baseline"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--global_batch", "32", "--pool", "2",
+           "--no_cpu_baseline"]                                              # (strong-scaling form: 32 videos per step over the two ranks)
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout.decode()[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 32 and d["config"]["parallelism"] == "dp2" and d["value"] > 0
+    assert d["scaling"] == "strong" and "batch 16 x 300" in d["config"]["workload"]
     assert d["dp"]["world"] == 2 and d["dp"]["process_group"] == dict(d["dp"]["process_group"], backend="gloo", ranks=2, launched_by="bench.py --gpus N itself")
     assert d["ms_per_step_median"] > 0 and d["ms_per_step_max"] >= d["ms_per_step_median"] and isinstance(d["stall_suspected"], bool)
 
