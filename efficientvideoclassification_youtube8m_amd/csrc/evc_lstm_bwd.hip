@@ -138,8 +138,126 @@ __device__ __forceinline__ void lstm_bwd_zero_tile(const LstmBwdParams& e, int m
 #ifndef EVC_BWD_TAPE_NT
 #define EVC_BWD_TAPE_NT 0
 #endif
-template <class Cfg>
-__device__ __forceinline__ void lstm_bwd_tail_rowmajor(f32x4 (&acc)[Cfg::MI][1][Cfg::NI], const LstmBwdParams& e, int m0, int u0, char* lds) {
+#ifndef EVC_BWD_TAIL_PRE
+#define EVC_BWD_TAIL_PRE 8          // row slots (of BM / 8 per thread) whose tape / state loads are issued BEFORE the main loop (round 6); 0 = every load in the tail (rounds 3-5)
+#endif
+// What a thread loads for N of its rows: the running dc (or the state gradient dS at a row's last step), the gate records, the cell history before and
+// after the step, the gradient arriving from the layer above.  None of it depends on this launch's product.
+template <int N>
+struct BwdTailRows {
+  unsigned long long dcv[N], dhs[N];      // float2 bits (ONE 64-bit value each: as two floats hipcc assigns the halves to unrelated registers and moves - waits - after the load)
+  uint4 grec[N];
+  uint32_t cn[N], co[N], dha[N];
+};
+// row length of slot p (wave-uniform, a scalar load from the constant address space; -1: row outside the launch or units outside H)
+__device__ __forceinline__ int bwd_tail_len(const LstmBwdParams& e, int m) {
+  return m < e.M ? ((const __attribute__((address_space(4))) int*)e.len)[m] : -1;
+}
+template <int N>
+__device__ __forceinline__ void lstm_bwd_tail_load(const LstmBwdParams& e, int m0, int u, bool u_in, int wave, int p0, BwdTailRows<N>& r) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int m = m0 + (p0 + i) * 8 + wave;                    // wave-uniform
+    const int ln = u_in ? bwd_tail_len(e, m) : -1;
+    r.dcv[i] = r.dhs[i] = 0ull;
+    r.grec[i] = make_uint4(0u, 0u, 0u, 0u);
+    r.cn[i] = r.co[i] = r.dha[i] = 0u;
+    if (e.t < ln) {
+      const long hu = (long)m * e.H + u;
+      // (ONE load instruction for dc whichever buffer it comes from - the state gradient at a row's last step, the running dc otherwise: two loads merged
+      //  behind a branch cost a register move, and with it a wait for the load, right here in front of the main loop)
+      const bool last = e.t == ln - 1;
+      long su = 0;
+      if (last) su = (long)(e.row_map ? ((const __attribute__((address_space(4))) int*)e.row_map)[m] : m) * e.ld_dS + u;
+      if (e.dc_bf16 && !last) {
+        const uint32_t d = *(const uint32_t*)((const bf16_t*)e.dc_ws + hu);
+        r.dcv[i] = (unsigned long long)(d << 16) | ((unsigned long long)(d & 0xffff0000u) << 32);
+      } else {
+        r.dcv[i] = *(const unsigned long long*)(last ? e.dS_c + su : e.dc_ws + hu);
+      }
+      if (last) r.dhs[i] = *(const unsigned long long*)(e.dS_h + su);
+#if EVC_BWD_TAPE_NT      // (A/B: the tape - gate records, cell history, the gradient from the layer above - is read ONCE, milliseconds after it was written: non-temporal loads)
+      if (e.dh_above) r.dha[i] = __builtin_nontemporal_load((const uint32_t*)(e.dh_above + hu));
+      { const u32x4_t gq = __builtin_nontemporal_load((const u32x4_t*)(e.gates + hu)); r.grec[i] = make_uint4(gq[0], gq[1], gq[2], gq[3]); }
+      r.cn[i] = __builtin_nontemporal_load((const uint32_t*)(e.c_new + hu));
+      if (e.c_old) r.co[i] = __builtin_nontemporal_load((const uint32_t*)(e.c_old + hu));
+#else
+      if (e.dh_above) r.dha[i] = *(const uint32_t*)(e.dh_above + hu);
+      r.grec[i] = *(const uint4*)(e.gates + hu);
+      r.cn[i] = *(const uint32_t*)(e.c_new + hu);
+      if (e.c_old) r.co[i] = *(const uint32_t*)(e.c_old + hu);
+#endif
+    }
+  }
+}
+// gate derivatives of N loaded rows against their dh (in LDS), then their stores
+template <int RS, int N>
+__device__ __forceinline__ void lstm_bwd_tail_finish(const LstmBwdParams& e, int m0, int u, bool u_in, int lane, int wave, int p0, const BwdTailRows<N>& r,
+                                                     const char* lds, float (&bs)[2][4]) {
+  // compute phase, then store phase: with the stores of row i between the computations of rows i and i+1 hipcc put
+  // `s_waitcnt vmcnt(0)` in front of every row (it cannot count across the per-row branches), i.e. every row waited for the
+  // store acknowledgements of the row before
+  float2 dcn[N];
+  uint4 dzr[N];
+  int what[N];                                                 // 0: nothing, 1: zero dz (inactive row), 2: dc + dz
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int rl = (p0 + i) * 8 + wave;
+    const int ln = u_in ? bwd_tail_len(e, m0 + rl) : -1;
+    what[i] = ln < 0 ? 0 : (e.t >= ln ? 1 : 2);
+    dcn[i] = make_float2(0.f, 0.f);
+    dzr[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (what[i] != 2) continue;
+    const float2 dhv = *(const float2*)(lds + rl * RS + lane * 8);
+    float dh[2] = {dhv.x, dhv.y};
+    if (e.t == ln - 1) {     // nothing flows back through the recurrent product from the (inactive) later steps
+      const float sx = __uint_as_float((uint32_t)r.dhs[i]), sy = __uint_as_float((uint32_t)(r.dhs[i] >> 32));
+      if (e.fused_above) { dh[0] += sx; dh[1] += sy; }
+      else { dh[0] = sx; dh[1] = sy; }
+    }
+    if (e.dh_above) { dh[0] += __uint_as_float(r.dha[i] << 16); dh[1] += __uint_as_float(r.dha[i] & 0xffff0000u); }
+    const float dci[2] = {__uint_as_float((uint32_t)r.dcv[i]), __uint_as_float((uint32_t)(r.dcv[i] >> 32))};
+    const uint2 recs[2] = {make_uint2(r.grec[i].x, r.grec[i].y), make_uint2(r.grec[i].z, r.grec[i].w)};
+    const float cna[2] = {__uint_as_float(r.cn[i] << 16), __uint_as_float(r.cn[i] & 0xffff0000u)};
+    const float coa[2] = {__uint_as_float(r.co[i] << 16), __uint_as_float(r.co[i] & 0xffff0000u)};
+    float dcv2[2];
+    uint2 dz2[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float gi = __uint_as_float(recs[q].x << 16), gj = __uint_as_float(recs[q].x & 0xffff0000u);
+      const float gf = __uint_as_float(recs[q].y << 16), go = __uint_as_float(recs[q].y & 0xffff0000u);
+      const float tcv = tanhf_(cna[q]);
+      const float dc = dci[q] + dh[q] * go * (1.f - tcv * tcv);
+      dcv2[q] = dc * gf;
+      const float z0 = dc * gj * gi * (1.f - gi), z1 = dc * gi * (1.f - gj * gj);
+      const float z2 = dc * coa[q] * gf * (1.f - gf), z3 = dh[q] * tcv * go * (1.f - go);
+      bs[q][0] += z0; bs[q][1] += z1; bs[q][2] += z2; bs[q][3] += z3;
+      dz2[q] = make_uint2(pack_bf16x2(z0, z1), pack_bf16x2(z2, z3));
+    }
+    dcn[i] = make_float2(dcv2[0], dcv2[1]);
+    dzr[i] = make_uint4(dz2[0].x, dz2[0].y, dz2[1].x, dz2[1].y);
+  }
+  // every load of the group has been consumed above; saying so (vmcnt(0), encoded 0x0F70) lets the stores below issue back
+  // to back - across the per-row branches hipcc otherwise keeps some load destinations "pending" and waits before each row
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if (what[i] == 0) continue;
+    const long hu = (long)(m0 + (p0 + i) * 8 + wave) * e.H + u;
+    if (what[i] == 2) {
+      if (e.dc_bf16) *(uint32_t*)((bf16_t*)e.dc_ws + hu) = pack_bf16x2(dcn[i].x, dcn[i].y);
+      else *(float2*)(e.dc_ws + hu) = dcn[i];
+    }
+    *(uint4*)(e.dz4 + hu) = dzr[i];                            // zeros for an inactive row: state passes through, no gate gradient
+  }
+}
+
+// PRE row slots arrive preloaded (lstm_bwd_step_body issues their loads before the main loop: they land under the product instead of at its end - 4 groups
+// of 4 rows used to pay a memory round trip each, one after the other, with nothing else on the CU); the next group's loads are issued before the preloaded
+// rows are finished.
+template <class Cfg, int PRE>
+__device__ __forceinline__ void lstm_bwd_tail_rowmajor(f32x4 (&acc)[Cfg::MI][1][Cfg::NI], const LstmBwdParams& e, int m0, int u0, char* lds,
+                                                       const BwdTailRows<(PRE > 0 ? PRE : 1)>& pre) {
   static_assert(Cfg::BU == 128 && Cfg::NT == 512, "row-major tail: 128-unit tiles, 8 waves");
   constexpr int RS = Cfg::BU * 4 + 16;                        // dh rows in LDS, padded
   static_assert(Cfg::BM * RS <= Cfg::LDS_BYTES && 8 * 128 * 4 * 4 <= Cfg::LDS_BYTES, "dh tile (then the bias-gradient partials) must fit the ring");
@@ -161,101 +279,28 @@ __device__ __forceinline__ void lstm_bwd_tail_rowmajor(f32x4 (&acc)[Cfg::MI][1][
   const int u = u0 + lane * 2;                                // this lane's two units
   const bool u_in = u < e.H;                                  // H % 2 == 0
   float bs[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  constexpr int GROUP = 4;                                    // rows per thread in flight (2: 67.0 us per step, 4: 65.1)
-  static_assert(Cfg::BM % (8 * GROUP) == 0, "tile rows must divide into 8 waves x GROUP");
-  for (int p0 = 0; p0 < Cfg::BM / 8; p0 += GROUP) {
-    int ln[GROUP];
-    float2 dcv[GROUP], dhs[GROUP], dhv[GROUP];
-    uint4 grec[GROUP];
-    uint32_t cn[GROUP], co[GROUP], dha[GROUP];
+  constexpr int SLOTS = Cfg::BM / 8;
+  constexpr int GROUP = PRE > 0 ? 8 : 4;                      // rows per thread in flight in the tail itself (rounds 3-5: 2: 67.0 us per step, 4: 65.1)
+  static_assert(PRE % 4 == 0 && PRE <= SLOTS && (SLOTS - PRE) % GROUP == 0, "tile rows must divide into 8 waves x (PRE + k GROUP)");
+  if constexpr (PRE > 0) {
+    if constexpr (PRE < SLOTS) {
+      BwdTailRows<GROUP> nb;
+      lstm_bwd_tail_load<GROUP>(e, m0, u, u_in, wave, PRE, nb);
+      lstm_bwd_tail_finish<RS, PRE>(e, m0, u, u_in, lane, wave, 0, pre, lds, bs);
 #pragma unroll
-    for (int i = 0; i < GROUP; ++i) {                          // load phase
-      const int rl = (p0 + i) * 8 + wave;
-      const int m = m0 + rl;                                   // wave-uniform
-      const int lnm = m < e.M ? ((const __attribute__((address_space(4))) int*)e.len)[m] : -1;   // scalar load (constant address space)
-      ln[i] = u_in ? lnm : -1;
-      dcv[i] = dhs[i] = make_float2(0.f, 0.f);
-      grec[i] = make_uint4(0u, 0u, 0u, 0u);
-      cn[i] = co[i] = dha[i] = 0u;
-      dhv[i] = *(const float2*)(lds + rl * RS + lane * 8);
-      if (e.t < ln[i]) {
-        const long hu = (long)m * e.H + u;
-        if (e.t == ln[i] - 1) {
-          const long su = (long)(e.row_map ? ((const __attribute__((address_space(4))) int*)e.row_map)[m] : m) * e.ld_dS + u;
-          dhs[i] = *(const float2*)(e.dS_h + su);
-          dcv[i] = *(const float2*)(e.dS_c + su);
-        } else {
-          if (e.dc_bf16) {
-            const uint32_t d = *(const uint32_t*)((const bf16_t*)e.dc_ws + hu);
-            dcv[i] = make_float2(__uint_as_float(d << 16), __uint_as_float(d & 0xffff0000u));
-          } else {
-            dcv[i] = *(const float2*)(e.dc_ws + hu);
-          }
-        }
-#if EVC_BWD_TAPE_NT      // (A/B: the tape - gate records, cell history, the gradient from the layer above - is read ONCE, milliseconds after it was written: non-temporal loads)
-        if (e.dh_above) dha[i] = __builtin_nontemporal_load((const uint32_t*)(e.dh_above + hu));
-        { const u32x4_t gq = __builtin_nontemporal_load((const u32x4_t*)(e.gates + hu)); grec[i] = make_uint4(gq[0], gq[1], gq[2], gq[3]); }
-        cn[i] = __builtin_nontemporal_load((const uint32_t*)(e.c_new + hu));
-        if (e.c_old) co[i] = __builtin_nontemporal_load((const uint32_t*)(e.c_old + hu));
-#else
-        if (e.dh_above) dha[i] = *(const uint32_t*)(e.dh_above + hu);
-        grec[i] = *(const uint4*)(e.gates + hu);
-        cn[i] = *(const uint32_t*)(e.c_new + hu);
-        if (e.c_old) co[i] = *(const uint32_t*)(e.c_old + hu);
-#endif
+      for (int p0 = PRE; p0 < SLOTS; p0 += GROUP) {
+        lstm_bwd_tail_finish<RS, GROUP>(e, m0, u, u_in, lane, wave, p0, nb, lds, bs);
+        if (p0 + GROUP < SLOTS) lstm_bwd_tail_load<GROUP>(e, m0, u, u_in, wave, p0 + GROUP, nb);
       }
+    } else {
+      lstm_bwd_tail_finish<RS, PRE>(e, m0, u, u_in, lane, wave, 0, pre, lds, bs);
     }
-    // compute phase, then store phase: with the stores of row i between the computations of rows i and i+1 hipcc put
-    // `s_waitcnt vmcnt(0)` in front of every row (it cannot count across the per-row branches), i.e. every row waited for the
-    // store acknowledgements of the row before
-    float2 dcn[GROUP];
-    uint4 dzr[GROUP];
-    int what[GROUP];                                           // 0: nothing, 1: zero dz (inactive row), 2: dc + dz
-#pragma unroll
-    for (int i = 0; i < GROUP; ++i) {
-      what[i] = ln[i] < 0 ? 0 : (e.t >= ln[i] ? 1 : 2);
-      dcn[i] = make_float2(0.f, 0.f);
-      dzr[i] = make_uint4(0u, 0u, 0u, 0u);
-      if (what[i] != 2) continue;
-      float dh[2] = {dhv[i].x, dhv[i].y};
-      if (e.t == ln[i] - 1) {     // nothing flows back through the recurrent product from the (inactive) later steps
-        if (e.fused_above) { dh[0] += dhs[i].x; dh[1] += dhs[i].y; }
-        else { dh[0] = dhs[i].x; dh[1] = dhs[i].y; }
-      }
-      if (e.dh_above) { dh[0] += __uint_as_float(dha[i] << 16); dh[1] += __uint_as_float(dha[i] & 0xffff0000u); }
-      const float dci[2] = {dcv[i].x, dcv[i].y};
-      const uint2 recs[2] = {make_uint2(grec[i].x, grec[i].y), make_uint2(grec[i].z, grec[i].w)};
-      const float cna[2] = {__uint_as_float(cn[i] << 16), __uint_as_float(cn[i] & 0xffff0000u)};
-      const float coa[2] = {__uint_as_float(co[i] << 16), __uint_as_float(co[i] & 0xffff0000u)};
-      float dcv2[2];
-      uint2 dz2[2];
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const float gi = __uint_as_float(recs[r].x << 16), gj = __uint_as_float(recs[r].x & 0xffff0000u);
-        const float gf = __uint_as_float(recs[r].y << 16), go = __uint_as_float(recs[r].y & 0xffff0000u);
-        const float tcv = tanhf_(cna[r]);
-        const float dc = dci[r] + dh[r] * go * (1.f - tcv * tcv);
-        dcv2[r] = dc * gf;
-        const float z0 = dc * gj * gi * (1.f - gi), z1 = dc * gi * (1.f - gj * gj);
-        const float z2 = dc * coa[r] * gf * (1.f - gf), z3 = dh[r] * tcv * go * (1.f - go);
-        bs[r][0] += z0; bs[r][1] += z1; bs[r][2] += z2; bs[r][3] += z3;
-        dz2[r] = make_uint2(pack_bf16x2(z0, z1), pack_bf16x2(z2, z3));
-      }
-      dcn[i] = make_float2(dcv2[0], dcv2[1]);
-      dzr[i] = make_uint4(dz2[0].x, dz2[0].y, dz2[1].x, dz2[1].y);
-    }
-    // every load of the group has been consumed above; saying so (vmcnt(0), encoded 0x0F70) lets the stores below issue back
-    // to back - across the per-row branches hipcc otherwise keeps some load destinations "pending" and waits before each row
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-#pragma unroll
-    for (int i = 0; i < GROUP; ++i) {
-      if (what[i] == 0) continue;
-      const long hu = (long)(m0 + (p0 + i) * 8 + wave) * e.H + u;
-      if (what[i] == 2) {
-        if (e.dc_bf16) *(uint32_t*)((bf16_t*)e.dc_ws + hu) = pack_bf16x2(dcn[i].x, dcn[i].y);
-        else *(float2*)(e.dc_ws + hu) = dcn[i];
-      }
-      *(uint4*)(e.dz4 + hu) = dzr[i];                          // zeros for an inactive row: state passes through, no gate gradient
+  } else {
+#pragma unroll 1
+    for (int p0 = 0; p0 < SLOTS; p0 += GROUP) {
+      BwdTailRows<GROUP> cur;
+      lstm_bwd_tail_load<GROUP>(e, m0, u, u_in, wave, p0, cur);
+      lstm_bwd_tail_finish<RS, GROUP>(e, m0, u, u_in, lane, wave, p0, cur, lds, bs);
     }
   }
   if (e.db) {      // bias gradient: the 8 waves hold partial sums of the same 128 units x 4 gates: through LDS, then one atomic per sum
@@ -288,6 +333,19 @@ __device__ __forceinline__ void lstm_bwd_step_body(const GemmOperands& p, const 
     return;
   }
   f32x4 acc[Cfg::MI][1][Cfg::NI];
+#if !defined(EVC_ABLATE_BWD_EPI) && !defined(EVC_BWD_TAIL_FRAGMENTS)
+  constexpr bool ROWMAJOR = is_v2<Cfg>::value && Cfg::BU == 128 && Cfg::NT == 512 && Cfg::BM % 32 == 0 && BATCH_LOADS;
+#else
+  constexpr bool ROWMAJOR = false;
+#endif
+  // the row-major tail's first PRE row slots: loads issued here, consumed after the product (older than every ring load: the ring's counted waits hold)
+  constexpr int PRE = (ROWMAJOR && (Cfg::BM / 8 - EVC_BWD_TAIL_PRE) % 8 == 0 && EVC_BWD_TAIL_PRE <= Cfg::BM / 8) ? EVC_BWD_TAIL_PRE : 0;
+  BwdTailRows<(PRE > 0 ? PRE : 1)> pre;
+  if constexpr (PRE > 0) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int u = u0 + lane * 2;
+    lstm_bwd_tail_load<PRE>(e, m0, u, u < e.H, wave, 0, pre);
+  }
 #ifdef EVC_ABLATE_BWD_MAIN     // debug build: epilogue only
 #pragma unroll
   for (int mi = 0; mi < Cfg::MI; ++mi)
@@ -296,12 +354,10 @@ __device__ __forceinline__ void lstm_bwd_step_body(const GemmOperands& p, const 
 #else
   run_mainloop<Cfg, 1, true, true, EVC_BWD_LOOP_MODE>(p, m0, u0, acc);     // transposed accumulators: lane = one row, 4 consecutive units
 #endif
-#if !defined(EVC_ABLATE_BWD_EPI) && !defined(EVC_BWD_TAIL_FRAGMENTS)
-  if constexpr (is_v2<Cfg>::value && Cfg::BU == 128 && Cfg::NT == 512 && Cfg::BM % 32 == 0 && BATCH_LOADS) {
-    lstm_bwd_tail_rowmajor<Cfg>(acc, e, m0, u0, lds_dyn);
+  if constexpr (ROWMAJOR) {
+    lstm_bwd_tail_rowmajor<Cfg, PRE>(acc, e, m0, u0, lds_dyn, pre);
     return;
   }
-#endif
   TileCoordsT<Cfg> tc;
 #pragma unroll
   for (int ni = 0; ni < Cfg::NI; ++ni) {
